@@ -1,0 +1,253 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED.
+//
+// oracle_capi.cpp — extern "C" batched entry points over the restated reference math so
+// that tests/ and bench.py's cpu_baseline leg can drive it through ctypes.  `threads`
+// mirrors the reference's Ceres num_threads (src/lvio_fusion/src/estimator.cpp:10):
+// OpenMP over residual blocks / query points.
+#include <omp.h>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "factors.h"
+#include "imu.h"
+#include "knn.h"
+#include "robust.h"
+
+using namespace lvo;
+
+extern "C" {
+
+struct lvo_camera { double fx, fy, cx, cy; double extrinsic[7]; };
+static inline Camera cam_of(const lvo_camera* c) {
+  Camera k; k.fx = c->fx; k.fy = c->fy; k.cx = c->cx; k.cy = c->cy; std::memcpy(k.extrinsic, c->extrinsic, sizeof(k.extrinsic)); return k;
+}
+
+// flattened imu::Preint (same field order as include/lvf.h's lvf_preint)
+struct lvo_preint {
+  double sum_dt; double lin_ba[3]; double lin_bg[3]; double dp[3]; double dq[4]; double dv[3];
+  double jac[225]; double cov[225];
+};
+
+int lvo_max_threads(void) { return omp_get_max_threads(); }
+
+// ---------------- visual ----------------
+// PoseOnly: r[n][2], J[n][2][7] (row-major 2x7), J may be null.
+void lvo_pose_only_eval(int n, const double* ob, const int* kf_idx, const int* pw_idx, const double* pw,
+                        const double* poses, const double* w_kf, const lvo_camera* cam0_, double* r,
+                        double* J, int threads) {
+  const Camera cam0 = cam_of(cam0_);
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int i = 0; i < n; ++i) {
+    const double* pose = poses + 7 * kf_idx[i];
+    const double w = w_kf[kf_idx[i]];
+    if (J) {
+      Jet<7> T[7], rr[2];
+      for (int k = 0; k < 7; ++k) T[k] = Jet<7>(pose[k], k);
+      PoseOnlyResidual(ob + 2 * i, pw + 3 * pw_idx[i], cam0, w, T, rr);
+      for (int a = 0; a < 2; ++a) { r[2 * i + a] = rr[a].a; for (int k = 0; k < 7; ++k) J[14 * i + 7 * a + k] = rr[a].v[k]; }
+    } else {
+      PoseOnlyResidual<double>(ob + 2 * i, pw + 3 * pw_idx[i], cam0, w, pose, r + 2 * i);
+    }
+  }
+}
+
+// TwoFrame: r[n][2], J_d[n][2], J_p1[n][14], J_p2[n][14]; weight = w_kf[kf2]
+void lvo_two_frame_eval(int n, const double* first_ob, const double* ob, const int* lm_idx, const int* kf1_idx,
+                        const int* kf2_idx, const double* inv_depth, const double* poses, const double* w_kf,
+                        const lvo_camera* left_, const lvo_camera* right_, double* r, double* Jd, double* J1,
+                        double* J2, int threads) {
+  const Camera left = cam_of(left_), right = cam_of(right_);
+  const bool want_j = Jd || J1 || J2;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int i = 0; i < n; ++i) {
+    const double* p1 = poses + 7 * kf1_idx[i];
+    const double* p2 = poses + 7 * kf2_idx[i];
+    const double w = w_kf[kf2_idx[i]];
+    const double rho = inv_depth[lm_idx[i]];
+    if (want_j) {
+      Jet<15> d(rho, 0), A[7], B[7], rr[2];
+      for (int k = 0; k < 7; ++k) { A[k] = Jet<15>(p1[k], 1 + k); B[k] = Jet<15>(p2[k], 8 + k); }
+      TwoFrameResidual(first_ob + 2 * i, ob + 2 * i, left, right, w, &d, A, B, rr);
+      for (int a = 0; a < 2; ++a) {
+        r[2 * i + a] = rr[a].a;
+        if (Jd) Jd[2 * i + a] = rr[a].v[0];
+        if (J1) for (int k = 0; k < 7; ++k) J1[14 * i + 7 * a + k] = rr[a].v[1 + k];
+        if (J2) for (int k = 0; k < 7; ++k) J2[14 * i + 7 * a + k] = rr[a].v[8 + k];
+      }
+    } else {
+      TwoFrameResidual<double>(first_ob + 2 * i, ob + 2 * i, left, right, w, &rho, p1, p2, r + 2 * i);
+    }
+  }
+}
+
+// TwoCamera: r[n][2], J[n][2]; weight = 5 * w_kf[kf]  (backend.cpp:123)
+void lvo_two_camera_eval(int n, const double* left_ob, const double* right_ob, const int* lm_idx, const int* kf_idx,
+                         const double* inv_depth, const double* w_kf, const lvo_camera* left_,
+                         const lvo_camera* right_, double* r, double* J, int threads) {
+  const Camera left = cam_of(left_), right = cam_of(right_);
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int i = 0; i < n; ++i) {
+    const double w = 5 * w_kf[kf_idx[i]];
+    const double rho = inv_depth[lm_idx[i]];
+    if (J) {
+      Jet<1> d(rho, 0), rr[2];
+      TwoCameraResidual(left_ob + 2 * i, right_ob + 2 * i, left, right, w, &d, rr);
+      for (int a = 0; a < 2; ++a) { r[2 * i + a] = rr[a].a; J[2 * i + a] = rr[a].v[0]; }
+    } else {
+      TwoCameraResidual<double>(left_ob + 2 * i, right_ob + 2 * i, left, right, w, &rho, r + 2 * i);
+    }
+  }
+}
+
+// ---------------- lidar ----------------
+void lvo_plane_normals(int n, const double* pa, const double* pb, const double* pc, double* nrm) {
+  for (int i = 0; i < n; ++i) PlaneNormal(pa + 3 * i, pb + 3 * i, pc + 3 * i, nrm + 3 * i);
+}
+// mode 0 = RPZ (params pitch=rpyxyz[1], roll=[2], z=[5]); mode 1 = YXY (yaw=[0], x=[3], y=[4]).
+// The three scalar parameter blocks are read from rpyxyz itself (the reference passes
+// para+1, para+2, para+5 / para+0, para+3, para+4 — association.cpp:274-276,332-334).
+// r[n], J[n][3] (d r / d param0..2).
+void lvo_lidar_plane_eval(int mode, int n, const double* p, const double* pa, const double* nrm,
+                          const double* Twc1, const double* rpyxyz, double weight, double* r, double* J,
+                          int threads) {
+  const int i0 = mode == 0 ? 1 : 0, i1 = mode == 0 ? 2 : 3, i2 = mode == 0 ? 5 : 4;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int i = 0; i < n; ++i) {
+    if (J) {
+      Jet<3> a(rpyxyz[i0], 0), b(rpyxyz[i1], 1), c(rpyxyz[i2], 2), rr;
+      if (mode == 0) LidarPlaneRpzResidual(p + 3 * i, pa + 3 * i, nrm + 3 * i, Twc1, rpyxyz, weight, &a, &b, &c, &rr);
+      else LidarPlaneYxyResidual(p + 3 * i, pa + 3 * i, nrm + 3 * i, Twc1, rpyxyz, weight, &a, &b, &c, &rr);
+      r[i] = rr.a; J[3 * i] = rr.v[0]; J[3 * i + 1] = rr.v[1]; J[3 * i + 2] = rr.v[2];
+    } else {
+      const double a = rpyxyz[i0], b = rpyxyz[i1], c = rpyxyz[i2];
+      if (mode == 0) LidarPlaneRpzResidual<double>(p + 3 * i, pa + 3 * i, nrm + 3 * i, Twc1, rpyxyz, weight, &a, &b, &c, r + i);
+      else LidarPlaneYxyResidual<double>(p + 3 * i, pa + 3 * i, nrm + 3 * i, Twc1, rpyxyz, weight, &a, &b, &c, r + i);
+    }
+  }
+}
+// inner factor LidarPlaneError<1,7>: r[n], J[n][7]
+void lvo_lidar_plane_se3_eval(int n, const double* p, const double* pa, const double* nrm, const double* Twc2,
+                              double* r, double* J) {
+  for (int i = 0; i < n; ++i) {
+    Jet<7> T[7], rr;
+    for (int k = 0; k < 7; ++k) T[k] = Jet<7>(Twc2[k], k);
+    LidarPlaneResidual(p + 3 * i, pa + 3 * i, nrm + 3 * i, T, &rr);
+    r[i] = rr.a;
+    if (J) for (int k = 0; k < 7; ++k) J[7 * i + k] = rr.v[k];
+  }
+}
+
+// ---------------- pose priors (a11) ----------------
+void lvo_pose_graph_eval(const double* target_rpyxyz, double weight, double v, const double* Twc1,
+                         const double* Twc2, double* r, double* J1, double* J2) {
+  Jet<14> A[7], B[7], rr[6];
+  for (int k = 0; k < 7; ++k) { A[k] = Jet<14>(Twc1[k], k); B[k] = Jet<14>(Twc2[k], 7 + k); }
+  PoseGraphResidual(target_rpyxyz, weight, v, A, B, rr);
+  for (int a = 0; a < 6; ++a) {
+    r[a] = rr[a].a;
+    for (int k = 0; k < 7; ++k) { if (J1) J1[7 * a + k] = rr[a].v[k]; if (J2) J2[7 * a + k] = rr[a].v[7 + k]; }
+  }
+}
+void lvo_pose_graph_target(const double* last_pose, const double* pose, double* target_rpyxyz) {
+  double inv[7], rel[7];   // pose_error.hpp:13-17  (Sophus inverse*product on unit quaternions)
+  Se3Inv<double>(last_pose, inv); Se3Mul<double>(inv, pose, rel); Se3ToRpyxyz<double>(rel, target_rpyxyz);
+}
+void lvo_pose_prior_eval(const double* origin, double weight, double v, const double* pose, double* r, double* J) {
+  Jet<7> T[7], rr[6];
+  for (int k = 0; k < 7; ++k) T[k] = Jet<7>(pose[k], k);
+  PosePriorResidual(origin, weight, v, T, rr);
+  for (int a = 0; a < 6; ++a) { r[a] = rr[a].a; if (J) for (int k = 0; k < 7; ++k) J[7 * a + k] = rr[a].v[k]; }
+}
+void lvo_prior3_eval(int mode, const double* rpyxyz0, double weight, const double* rpyxyz, double* r, double* J) {
+  if (mode == 0) PriorRpzResidual<double>(rpyxyz0, weight, rpyxyz + 1, rpyxyz + 2, rpyxyz + 5, r);
+  else PriorYxyResidual<double>(rpyxyz0, weight, rpyxyz + 0, rpyxyz + 3, rpyxyz + 4, r);
+  if (J) {  // 3x3, d r / d (param0,param1,param2); RPZ residual order is (roll, pitch, z) vs params (pitch, roll, z)
+    std::memset(J, 0, 9 * sizeof(double));
+    if (mode == 0) { J[0 * 3 + 1] = weight; J[1 * 3 + 0] = weight; J[2 * 3 + 2] = weight; }
+    else { J[0] = weight; J[4] = weight; J[8] = weight; }
+  }
+}
+
+// ---------------- se3 helpers for tests ----------------
+void lvo_se3_to_rpyxyz(const double* se3, double* rpyxyz) { Se3ToRpyxyz<double>(se3, rpyxyz); }
+void lvo_rpyxyz_to_se3(const double* rpyxyz, double* se3) { RpyxyzToSe3<double>(rpyxyz, se3); }
+void lvo_se3_mul(const double* A, const double* B, double* C) { Se3Mul<double>(A, B, C); }
+void lvo_se3_inv(const double* A, double* C) { Se3Inv<double>(A, C); }
+void lvo_se3_apply(const double* A, const double* p, double* o) { Se3Apply<double>(A, p, o); }
+void lvo_se3_apply_f32(const float* A, const float* p, float* o) { Se3Apply<float>(A, p, o); }
+
+// ---------------- robust / parameterisation ----------------
+void lvo_loss(double a, double s, double* rho) { loss_eval(a, s, rho); }
+void lvo_quat_plus(const double* x, const double* d, double* out) { eigen_quat_plus(x, d, out); }
+void lvo_quat_plus_jacobian(const double* x, double* j12) { eigen_quat_plus_jacobian(x, j12); }
+void lvo_pose_jac_to_local(const double* pose, int rows, const double* J7, double* J6) { pose_jac_to_local(pose, rows, J7, J6); }
+
+// ---------------- IMU ----------------
+static void preint_to_flat(const imu::Preint& P, lvo_preint* o) {
+  o->sum_dt = P.sum_dt;
+  for (int i = 0; i < 3; ++i) { o->lin_ba[i] = P.lin_ba[i]; o->lin_bg[i] = P.lin_bg[i]; o->dp[i] = P.dp[i]; o->dv[i] = P.dv[i]; }
+  o->dq[0] = P.dq.x; o->dq[1] = P.dq.y; o->dq[2] = P.dq.z; o->dq[3] = P.dq.w;
+  std::memcpy(o->jac, P.jac, sizeof(o->jac)); std::memcpy(o->cov, P.cov, sizeof(o->cov));
+}
+static void flat_to_preint(const lvo_preint* f, imu::Preint& P) {
+  std::memset(&P, 0, sizeof(P));
+  P.sum_dt = f->sum_dt;
+  for (int i = 0; i < 3; ++i) { P.lin_ba[i] = f->lin_ba[i]; P.lin_bg[i] = f->lin_bg[i]; P.dp[i] = f->dp[i]; P.dv[i] = f->dv[i]; }
+  P.dq = imu::Quat{f->dq[0], f->dq[1], f->dq[2], f->dq[3]};
+  std::memcpy(P.jac, f->jac, sizeof(P.jac)); std::memcpy(P.cov, f->cov, sizeof(P.cov));
+}
+// samples[ns][7] = (dt, acc xyz, gyr xyz); acc0/gyr0 = the measurement latched at the first Append
+void lvo_imu_preintegrate(int ns, const double* samples, const double* acc0, const double* gyr0, const double* ba,
+                          const double* bg, const double* noise4, lvo_preint* out) {
+  imu::Preint P;
+  P.init(ba, bg, acc0, gyr0, imu::Noise{noise4[0], noise4[1], noise4[2], noise4[3]});
+  for (int s = 0; s < ns; ++s) P.propagate(samples[7 * s], samples + 7 * s + 1, samples + 7 * s + 4);
+  preint_to_flat(P, out);
+}
+void lvo_imu_sqrt_info(const lvo_preint* f, double* S225) {
+  imu::Preint P; flat_to_preint(f, P);
+  double S[15][15]; imu::sqrt_info_from_cov(P.cov, S); std::memcpy(S225, S, sizeof(S));
+}
+// n factors; state arrays poses[nkf][7], vel/ba/bg[nkf][3]; r[n][15]; J packed per factor as
+// 15x7,15x3,15x3,15x3,15x7,15x3,15x3,15x3 row-major blocks = 15*32 doubles (J may be null).
+void lvo_imu_eval(int n, const lvo_preint* pre, const int* kf_i, const int* kf_j, const double* poses,
+                  const double* vel, const double* ba, const double* bg, double* r, double* J, int threads) {
+  static const int off[8] = {0, 105, 150, 195, 240, 345, 390, 435};
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int f = 0; f < n; ++f) {
+    imu::Preint P; flat_to_preint(pre + f, P);
+    const int i = kf_i[f], j = kf_j[f];
+    const double* prm[8] = {poses + 7 * i, vel + 3 * i, ba + 3 * i, bg + 3 * i, poses + 7 * j, vel + 3 * j, ba + 3 * j, bg + 3 * j};
+    double* Jp[8];
+    if (J) for (int k = 0; k < 8; ++k) Jp[k] = J + (size_t)480 * f + off[k];
+    imu::imu_error_evaluate(P, prm, r + 15 * f, J ? Jp : nullptr);
+  }
+}
+
+// ---------------- kNN association ----------------
+// query/map clouds: float xyz with `stride` floats per point.  tf_d = frame pose (double, Sophus
+// order), cast to float exactly as association.cpp:287.  Outputs idx[Q][3], d2[Q][3], valid[Q].
+// method 0 = brute force (checker), 1 = leaf-15 kd-tree (timing baseline).
+void lvo_knn3(const float* map, int M, int mstride, const float* query, int Q, int qstride, const double* tf_d,
+              float thr, int* idx, float* d2, uint8_t* valid, int method, int threads) {
+  float tf[7];
+  for (int k = 0; k < 7; ++k) tf[k] = (float)tf_d[k];
+  KdTree tree;
+  if (method == 1) tree.build(map, M, mstride);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 256)
+  for (int i = 0; i < Q; ++i) {
+    float w[3];
+    transform_query_f32(tf, query + (size_t)i * qstride, w);
+    Best3 b;
+    if (method == 1) b = tree.query(w); else knn3_brute(map, M, mstride, w, &b);
+    for (int k = 0; k < 3; ++k) { idx[3 * i + k] = b.i[k]; d2[3 * i + k] = b.d[k]; }
+    valid[i] = (b.i[0] >= 0 && b.d[0] < thr && b.i[1] >= 0 && b.d[1] < thr && b.i[2] >= 0 && b.d[2] < thr) ? 1 : 0;
+  }
+}
+double lvo_kdtree_build_seconds(const float* map, int M, int mstride) {
+  const double t0 = omp_get_wtime();
+  KdTree tree; tree.build(map, M, mstride);
+  return omp_get_wtime() - t0 + (tree.nodes.empty() ? 1e-12 : 0.0);
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes front-end of oracle/liblvf_oracle.so.
+
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import this, and
+only as the checker.  PARITY UNPINNED (see oracle/jet.h): the reference has no tests or
+golden vectors and its third-party numerics are absent from the container.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblvf_oracle.so")
+
+PREINT_DOUBLES = 1 + 3 + 3 + 3 + 4 + 3 + 225 + 225  # 467, layout of lvo_preint / lvf_preint
+IMU_J_OFF = (0, 105, 150, 195, 240, 345, 390, 435, 480)
+IMU_J_COLS = (7, 3, 3, 3, 7, 3, 3, 3)
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("extrinsic", C.c_double * 7)]
+
+    @staticmethod
+    def make(fx, fy, cx, cy, extrinsic):
+        c = Camera()
+        c.fx, c.fy, c.cx, c.cy = fx, fy, cx, cy
+        for i in range(7):
+            c.extrinsic[i] = float(extrinsic[i])
+        return c
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.lvo_kdtree_build_seconds.restype = C.c_double
+        _lib.lvo_max_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a, t=C.c_double):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def max_threads():
+    return lib().lvo_max_threads()
+
+
+def pose_only(ob, kf_idx, pw_idx, pw, poses, w_kf, cam0, jac=True, threads=1):
+    ob, pw, poses, w_kf = _f64(ob), _f64(pw), _f64(poses), _f64(w_kf)
+    kf_idx, pw_idx = _i32(kf_idx), _i32(pw_idx)
+    n = ob.shape[0]
+    r = np.empty((n, 2)); J = np.empty((n, 2, 7)) if jac else None
+    lib().lvo_pose_only_eval(n, _p(ob), _p(kf_idx, C.c_int), _p(pw_idx, C.c_int), _p(pw), _p(poses), _p(w_kf),
+                             C.byref(cam0), _p(r), _p(J), int(threads))
+    return r, J
+
+
+def two_frame(first_ob, ob, lm_idx, kf1, kf2, inv_depth, poses, w_kf, left, right, jac=True, threads=1):
+    first_ob, ob, inv_depth, poses, w_kf = map(_f64, (first_ob, ob, inv_depth, poses, w_kf))
+    lm_idx, kf1, kf2 = map(_i32, (lm_idx, kf1, kf2))
+    n = ob.shape[0]
+    r = np.empty((n, 2))
+    Jd = np.empty((n, 2)) if jac else None
+    J1 = np.empty((n, 2, 7)) if jac else None
+    J2 = np.empty((n, 2, 7)) if jac else None
+    lib().lvo_two_frame_eval(n, _p(first_ob), _p(ob), _p(lm_idx, C.c_int), _p(kf1, C.c_int), _p(kf2, C.c_int),
+                             _p(inv_depth), _p(poses), _p(w_kf), C.byref(left), C.byref(right), _p(r), _p(Jd),
+                             _p(J1), _p(J2), int(threads))
+    return r, Jd, J1, J2
+
+
+def two_camera(left_ob, right_ob, lm_idx, kf_idx, inv_depth, w_kf, left, right, jac=True, threads=1):
+    left_ob, right_ob, inv_depth, w_kf = map(_f64, (left_ob, right_ob, inv_depth, w_kf))
+    lm_idx, kf_idx = _i32(lm_idx), _i32(kf_idx)
+    n = left_ob.shape[0]
+    r = np.empty((n, 2)); J = np.empty((n, 2)) if jac else None
+    lib().lvo_two_camera_eval(n, _p(left_ob), _p(right_ob), _p(lm_idx, C.c_int), _p(kf_idx, C.c_int), _p(inv_depth),
+                              _p(w_kf), C.byref(left), C.byref(right), _p(r), _p(J), int(threads))
+    return r, J
+
+
+def plane_normals(pa, pb, pc):
+    pa, pb, pc = map(_f64, (pa, pb, pc))
+    n = pa.shape[0]
+    out = np.empty((n, 3))
+    lib().lvo_plane_normals(n, _p(pa), _p(pb), _p(pc), _p(out))
+    return out
+
+
+def lidar_plane(mode, p, pa, nrm, Twc1, rpyxyz, weight, jac=True, threads=1):
+    p, pa, nrm, Twc1, rpyxyz = map(_f64, (p, pa, nrm, Twc1, rpyxyz))
+    n = p.shape[0]
+    r = np.empty(n); J = np.empty((n, 3)) if jac else None
+    lib().lvo_lidar_plane_eval(int(mode), n, _p(p), _p(pa), _p(nrm), _p(Twc1), _p(rpyxyz), C.c_double(weight), _p(r),
+                               _p(J), int(threads))
+    return r, J
+
+
+def lidar_plane_se3(p, pa, nrm, Twc2):
+    p, pa, nrm, Twc2 = map(_f64, (p, pa, nrm, Twc2))
+    n = p.shape[0]
+    r = np.empty(n); J = np.empty((n, 7))
+    lib().lvo_lidar_plane_se3_eval(n, _p(p), _p(pa), _p(nrm), _p(Twc2), _p(r), _p(J))
+    return r, J
+
+
+def pose_graph(target_rpyxyz, weight, v, Twc1, Twc2):
+    t, a, b = map(_f64, (target_rpyxyz, Twc1, Twc2))
+    r = np.empty(6); J1 = np.empty((6, 7)); J2 = np.empty((6, 7))
+    lib().lvo_pose_graph_eval(_p(t), C.c_double(weight), C.c_double(v), _p(a), _p(b), _p(r), _p(J1), _p(J2))
+    return r, J1, J2
+
+
+def pose_graph_target(last_pose, pose):
+    a, b = _f64(last_pose), _f64(pose)
+    out = np.empty(6)
+    lib().lvo_pose_graph_target(_p(a), _p(b), _p(out))
+    return out
+
+
+def pose_prior(origin, weight, v, pose):
+    o, p = _f64(origin), _f64(pose)
+    r = np.empty(6); J = np.empty((6, 7))
+    lib().lvo_pose_prior_eval(_p(o), C.c_double(weight), C.c_double(v), _p(p), _p(r), _p(J))
+    return r, J
+
+
+def prior3(mode, rpyxyz0, weight, rpyxyz):
+    a, b = _f64(rpyxyz0), _f64(rpyxyz)
+    r = np.empty(3); J = np.empty((3, 3))
+    lib().lvo_prior3_eval(int(mode), _p(a), C.c_double(weight), _p(b), _p(r), _p(J))
+    return r, J
+
+
+def se3_to_rpyxyz(se3):
+    a = _f64(se3); out = np.empty(6)
+    lib().lvo_se3_to_rpyxyz(_p(a), _p(out)); return out
+
+
+def rpyxyz_to_se3(rpyxyz):
+    a = _f64(rpyxyz); out = np.empty(7)
+    lib().lvo_rpyxyz_to_se3(_p(a), _p(out)); return out
+
+
+def se3_mul(A, B):
+    a, b = _f64(A), _f64(B); out = np.empty(7)
+    lib().lvo_se3_mul(_p(a), _p(b), _p(out)); return out
+
+
+def se3_inv(A):
+    a = _f64(A); out = np.empty(7)
+    lib().lvo_se3_inv(_p(a), _p(out)); return out
+
+
+def se3_apply(A, p):
+    a, b = _f64(A), _f64(p); out = np.empty(3)
+    lib().lvo_se3_apply(_p(a), _p(b), _p(out)); return out
+
+
+def se3_apply_f32(A, p):
+    a, b = _f32(A), _f32(p); out = np.empty(3, dtype=np.float32)
+    lib().lvo_se3_apply_f32(_p(a, C.c_float), _p(b, C.c_float), _p(out, C.c_float)); return out
+
+
+def loss(a, s):
+    rho = np.empty(3)
+    lib().lvo_loss(C.c_double(a), C.c_double(s), _p(rho)); return rho
+
+
+def quat_plus(x, d):
+    a, b = _f64(x), _f64(d); out = np.empty(4)
+    lib().lvo_quat_plus(_p(a), _p(b), _p(out)); return out
+
+
+def quat_plus_jacobian(x):
+    a = _f64(x); out = np.empty((4, 3))
+    lib().lvo_quat_plus_jacobian(_p(a), _p(out)); return out
+
+
+def pose_jac_to_local(pose, J7):
+    p, J7 = _f64(pose), _f64(J7)
+    rows = J7.shape[0]
+    out = np.empty((rows, 6))
+    lib().lvo_pose_jac_to_local(_p(p), rows, _p(J7), _p(out)); return out
+
+
+def imu_preintegrate(samples, acc0, gyr0, ba, bg, noise4):
+    s, a0, g0, ba, bg, nz = map(_f64, (samples, acc0, gyr0, ba, bg, noise4))
+    out = np.zeros(PREINT_DOUBLES)
+    lib().lvo_imu_preintegrate(s.shape[0], _p(s), _p(a0), _p(g0), _p(ba), _p(bg), _p(nz), _p(out))
+    return out
+
+
+def imu_sqrt_info(pre):
+    p = _f64(pre); S = np.empty((15, 15))
+    lib().lvo_imu_sqrt_info(_p(p), _p(S)); return S
+
+
+def imu_eval(pre, kf_i, kf_j, poses, vel, ba, bg, jac=True, threads=1):
+    pre, poses, vel, ba, bg = map(_f64, (pre, poses, vel, ba, bg))
+    kf_i, kf_j = _i32(kf_i), _i32(kf_j)
+    n = pre.shape[0]
+    r = np.empty((n, 15)); J = np.empty((n, 480)) if jac else None
+    lib().lvo_imu_eval(n, _p(pre), _p(kf_i, C.c_int), _p(kf_j, C.c_int), _p(poses), _p(vel), _p(ba), _p(bg), _p(r),
+                       _p(J), int(threads))
+    return r, J
+
+
+def imu_split_jac(J480):
+    """(n,480) -> list of 8 arrays (n,15,cols)"""
+    n = J480.shape[0]
+    return [J480[:, IMU_J_OFF[k]:IMU_J_OFF[k + 1]].reshape(n, 15, IMU_J_COLS[k]) for k in range(8)]
+
+
+def knn3(map_xyz, query_xyz, tf_d, thr, method=0, threads=1):
+    m, q, tf = _f32(map_xyz), _f32(query_xyz), _f64(tf_d)
+    M, Q = m.shape[0], q.shape[0]
+    idx = np.empty((Q, 3), dtype=np.int32); d2 = np.empty((Q, 3), dtype=np.float32); valid = np.empty(Q, dtype=np.uint8)
+    lib().lvo_knn3(_p(m, C.c_float), M, m.shape[1], _p(q, C.c_float), Q, q.shape[1], _p(tf), C.c_float(thr),
+                   _p(idx, C.c_int), _p(d2, C.c_float), _p(valid, C.c_uint8), int(method), int(threads))
+    return idx, d2, valid
+
+
+def kdtree_build_seconds(map_xyz):
+    m = _f32(map_xyz)
+    return lib().lvo_kdtree_build_seconds(_p(m, C.c_float), m.shape[0], m.shape[1])
