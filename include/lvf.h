@@ -1,0 +1,231 @@
+/* lvf.h — C-ABI of the MI355X-native lvio_fusion hot path (local-BA factor evaluation,
+ * normal-equation / Schur reduction, LiDAR scan-to-map 3-NN association + point-to-plane ICP).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each group cites
+ * the reference interface it replaces (paths under src/lvio_fusion/ of jypjypjypjyp/lvio_fusion):
+ *
+ *   lvf_pose_only_*    <- PoseOnlyReprojectionError::Create / AutoDiffCostFunction<..,2,7>::Evaluate
+ *                         include/lvio_fusion/ceres/visual_error.hpp:48-76
+ *   lvf_two_frame_*    <- TwoFrameReprojectionError  <2,1,7,7>   visual_error.hpp:78-107
+ *   lvf_two_camera_*   <- TwoCameraReprojectionError <2,1>       visual_error.hpp:109-137
+ *   lvf_lidar_plane_*  <- LidarPlaneErrorRPZ / LidarPlaneErrorYXY <1,1,1,1>
+ *                         include/lvio_fusion/ceres/lidar_error.hpp:42-110 (+ ctor normal :13-18)
+ *   lvf_imu_*          <- ImuError : SizedCostFunction<15,7,3,3,3,7,3,3,3>
+ *                         include/lvio_fusion/ceres/imu_error.hpp:12-122, src/preintegration.cpp:144-165
+ *   lvf_preintegrate   <- imu::Preintegration::{Append,Propagate,MidPointIntegration}
+ *                         src/preintegration.cpp:30-127, include/lvio_fusion/imu/preintegration.h:29-41
+ *   lvf_map_* / lvf_scan_* / lvf_knn3_*
+ *                      <- pcl::KdTreeFLANN::setInputCloud + nearestKSearch(point,3,..) + the 3x(d2<thr) gate
+ *                         src/association.cpp:278-301 (ground), :336-359 (surf)
+ *   lvf_icp_*          <- FeatureAssociation::ScanToMapWith{Ground,Segmented} + the DENSE_QR solve
+ *                         src/association.cpp:270-384, src/mapping.cpp:154-178
+ *   lvf_problem_*      <- adapt::Problem::{AddParameterBlock,AddResidualBlock,SetParameterBlockConstant}
+ *                         + adapt::Solve (include/lvio_fusion/adapt/problem.h:34-88) as driven by
+ *                         Backend::BuildProblem / Backend::Optimize (src/backend.cpp:96-183, :192-246)
+ *
+ * Conventions
+ *   - pose block = Sophus SE3d::data() = [qx,qy,qz,qw,tx,ty,tz] (7 doubles), Twc maps body->world.
+ *   - Jacobians are row-major num_residuals x block_size, w.r.t. AMBIENT parameters
+ *     (the ceres::CostFunction::Evaluate contract).
+ *   - every function returns 0 (LVF_OK) on success; on failure outputs are untouched and
+ *     lvf_last_error() (thread-local) describes the problem.  No exceptions cross the boundary.
+ *   - "create" calls copy their inputs to HBM; evaluate/solve calls are asynchronous on the
+ *     context's HIP stream and leave their outputs resident in HBM; *_download calls synchronise.
+ *   - a context is bound to one device and one stream; use one context per host thread
+ *     (Backend::Optimize and Relocator can be in flight concurrently: src/relocator.cpp:188).
+ *   - there is NO CPU fallback: without a usable gfx950 device lvf_ctx_create fails.
+ */
+#ifndef LVF_H_
+#define LVF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVF_OK 0
+#define LVF_ERR_INVALID 1   /* bad argument */
+#define LVF_ERR_HIP 2       /* HIP runtime error (see lvf_last_error) */
+#define LVF_ERR_NO_DEVICE 3 /* no usable GPU: the product path refuses to run */
+#define LVF_ERR_STATE 4     /* call sequence error (e.g. download before evaluate) */
+
+typedef struct lvf_ctx lvf_ctx;
+typedef struct lvf_state lvf_state;
+typedef struct lvf_batch lvf_batch;
+typedef struct lvf_map lvf_map;
+typedef struct lvf_scan lvf_scan;
+typedef struct lvf_icp lvf_icp;
+typedef struct lvf_problem lvf_problem;
+
+/* Camera = intrinsics + sensor->robot extrinsic (include/lvio_fusion/sensor.h:41-44, visual/camera.h:74). */
+typedef struct lvf_camera {
+  double fx, fy, cx, cy;
+  double extrinsic[7];
+} lvf_camera;
+
+/* Snapshot of imu::Preintegration after the last Append (include/lvio_fusion/imu/preintegration.h:66-86). */
+typedef struct lvf_preint {
+  double sum_dt;
+  double lin_ba[3];
+  double lin_bg[3];
+  double dp[3];
+  double dq[4]; /* x,y,z,w */
+  double dv[3];
+  double jac[225]; /* 15x15 row-major */
+  double cov[225]; /* 15x15 row-major */
+} lvf_preint;
+
+const char* lvf_last_error(void);
+const char* lvf_version(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* stream: an existing hipStream_t to run on (e.g. the caller's), or NULL to create a private one. */
+int lvf_ctx_create(int device, void* hip_stream, lvf_ctx** out);
+int lvf_ctx_destroy(lvf_ctx* ctx);
+int lvf_ctx_synchronize(lvf_ctx* ctx);
+void* lvf_ctx_stream(lvf_ctx* ctx);
+/* HIP-event timing of the context's stream, for bench.py: begin/end record events, elapsed synchronises. */
+int lvf_timer_begin(lvf_ctx* ctx);
+int lvf_timer_end(lvf_ctx* ctx);
+int lvf_timer_elapsed_ms(lvf_ctx* ctx, float* ms);
+
+/* ---- parameter state (the caller-owned double* blocks of the Ceres problem, mirrored in HBM) - */
+enum lvf_field {
+  LVF_POSES = 0,     /* n_kf x 7   frame->pose.data()                      backend.cpp:110 */
+  LVF_VEL = 1,       /* n_kf x 3   frame->Vw.data()                        backend.cpp:147 */
+  LVF_BA = 2,        /* n_kf x 3   frame->bias.linearized_ba.data()        backend.cpp:149 */
+  LVF_BG = 3,        /* n_kf x 3   frame->bias.linearized_bg.data()        backend.cpp:148 */
+  LVF_INV_DEPTH = 4, /* n_lm       &landmark->inv_depth                    backend.cpp:121 */
+  LVF_W_VISUAL = 5   /* n_kf       frame->weights.visual                   frame.cpp:13    */
+};
+int lvf_state_create(lvf_ctx* ctx, int n_kf, int n_lm, lvf_state** out);
+int lvf_state_destroy(lvf_state* st);
+int lvf_state_set(lvf_state* st, int field, const double* host);
+int lvf_state_get(lvf_state* st, int field, double* host);
+
+/* ---- factor batches (one batch = all residual blocks of one functor type) ------------------ */
+/* n blocks; ob[n][2]; kf_idx[n] selects the pose block and the per-frame weight; pw_idx[n] indexes
+ * pw[n_pw][3] (landmark->ToWorld(), constant during the solve: backend.cpp:129). */
+int lvf_pose_only_create(lvf_ctx* ctx, const lvf_camera* cam0, int n, const double* ob, const int32_t* kf_idx,
+                         const int32_t* pw_idx, int n_pw, const double* pw, lvf_batch** out);
+/* first_ob[n][2] = right-image observation in the birth frame, ob[n][2] = current left observation;
+ * parameter blocks (inv_depth[lm_idx], pose[kf1_idx], pose[kf2_idx]); weight = w_visual[kf2]. backend.cpp:134-139 */
+int lvf_two_frame_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera* right, int n,
+                         const double* first_ob, const double* ob, const int32_t* lm_idx, const int32_t* kf1_idx,
+                         const int32_t* kf2_idx, lvf_batch** out);
+/* parameter block inv_depth[lm_idx]; weight = 5 * w_visual[kf_idx]   backend.cpp:119-124 */
+int lvf_two_camera_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera* right, int n,
+                          const double* left_ob, const double* right_ob, const int32_t* lm_idx,
+                          const int32_t* kf_idx, lvf_batch** out);
+/* parameter blocks (pose,v,ba,bg)[kf_i], (pose,v,ba,bg)[kf_j]; sqrt_info = LLT(cov^-1).L^T is factorised
+ * once here (the reference re-inverts on every Evaluate: imu_error.hpp:32). */
+int lvf_imu_create(lvf_ctx* ctx, int n, const lvf_preint* pre, const int32_t* kf_i, const int32_t* kf_j,
+                   lvf_batch** out);
+/* mode 0 = RPZ (pitch,roll,z), 1 = YXY (yaw,x,y).  p/pa/pb/pc [n][3]: the scan point and its three
+ * map neighbours (association.cpp:303-314); the unit normal (pa-pb)x(pa-pc) is computed on device. */
+int lvf_lidar_plane_create(lvf_ctx* ctx, int mode, int n, const double* p, const double* pa, const double* pb,
+                           const double* pc, const double* Twc1, double weight, lvf_batch** out);
+int lvf_batch_destroy(lvf_batch* b);
+int lvf_batch_size(const lvf_batch* b);
+int lvf_batch_num_param_blocks(const lvf_batch* b);
+
+/* Batched CostFunction::Evaluate: residuals (+ Jacobians if want_jacobians) in Ceres layout, left in HBM.
+ * st supplies the parameter blocks.  For lidar batches st may be NULL and rpyxyz (host, 6 doubles — the
+ * caller's LIVE array, lidar_error.hpp:52,87) is read at call time. */
+int lvf_batch_evaluate(lvf_batch* b, const lvf_state* st, const double* rpyxyz, int want_jacobians);
+/* Copies of the last evaluate's outputs.  block = parameter-block index in the functor's template order.
+ * Sizes: residuals n*R doubles; jacobian(block) n*R*size_block doubles (row-major R x size per block). */
+int lvf_batch_download_residuals(lvf_batch* b, double* host);
+int lvf_batch_download_jacobian(lvf_batch* b, int block, double* host);
+/* lidar batches only: the device-computed unit normals [n][3] */
+int lvf_batch_download_normals(lvf_batch* b, double* host);
+/* device pointers of the same buffers (valid until the batch is destroyed) */
+void* lvf_batch_residuals_dev(lvf_batch* b);
+void* lvf_batch_jacobian_dev(lvf_batch* b, int block);
+
+/* ---- IMU pre-integration on device ---------------------------------------------------------- */
+/* n independent keyframe pairs; pair k owns samples[offset[k] .. offset[k+1]) rows of (dt, acc[3], gyr[3]);
+ * acc0/gyr0 [n][3] are the measurements latched by the first Append; ba/bg [n][3] the linearisation biases;
+ * noise4 = (ACC_N, GYR_N, ACC_W, GYR_W).  out[n] receives the propagated state. */
+int lvf_preintegrate(lvf_ctx* ctx, int n, const int32_t* offset, const double* samples, const double* acc0,
+                     const double* gyr0, const double* ba, const double* bg, const double* noise4, lvf_preint* out);
+
+/* ---- scan-to-map association (float32, bit-exact 3-NN) --------------------------------------- */
+/* map cloud: M points, xyz at the start of each `stride_floats`-float record (pcl::PointXYZI: 8).
+ * Builds a uniform-grid index on device.  max_radius2 = the largest squared gate that will be queried
+ * (e.g. resolution^2*100); it only sizes the cells, any thr may be queried later. */
+int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats, float max_radius2, lvf_map** out);
+int lvf_map_destroy(lvf_map* m);
+int lvf_scan_create(lvf_ctx* ctx, const float* scan_xyz, int Q, int stride_floats, lvf_scan** out);
+int lvf_scan_destroy(lvf_scan* s);
+/* For every scan point: point = SE3TransformPoint<float>(pose.cast<float>(), p); its 3 nearest map points by
+ * squared L2 in float ((dx*dx+dy*dy)+dz*dz, no FMA), ties by ascending map index; valid iff all three
+ * d2 < thr.  Outputs stay in HBM (owned by the scan).  idx/d2 are exact for valid points; for invalid
+ * points they hold the best candidates found inside the gate radius (or -1/inf).  thr = +inf asks for the
+ * exact 3-NN of every point. */
+int lvf_knn3(lvf_map* m, lvf_scan* s, const double* pose, float thr);
+int lvf_scan_download(lvf_scan* s, int32_t* idx3, float* d2_3, uint8_t* valid);
+
+/* ---- one scan-to-map sub-problem (3-DoF LM on device) ---------------------------------------- */
+typedef struct lvf_icp_options {
+  int mode;                /* 0 = ground/RPZ (TrivialLoss), 1 = surf/YXY (HuberLoss(0.1)) */
+  float thr;               /* squared distance gate */
+  double weight;           /* frame->weights.lidar_ground / lidar_surf */
+  double huber_a;          /* <=0: TrivialLoss (association.cpp:272), 0.1 for surf (:330) */
+  double prior_weight;     /* PoseErrorRPZ/YXY weight = |features_left| * weights.visual; 0 = relocate mode */
+  int max_num_iterations;  /* 4 (mapping.cpp:161) */
+} lvf_icp_options;
+typedef struct lvf_icp_summary {
+  double initial_cost, final_cost;
+  int num_residual_blocks; /* valid correspondences (+1 if prior) — Summary::num_residual_blocks_reduced */
+  int num_iterations;
+  int num_successful_steps;
+} lvf_icp_summary;
+/* Runs association (lvf_knn3 with frame_pose = map_pose * rpyxyz2se3(rpyxyz)), builds the point-to-plane
+ * problem and solves it; rpyxyz (host, 6 doubles) is updated IN PLACE like the reference's stack array
+ * (mapping.cpp:153-165). */
+int lvf_icp_solve(lvf_map* m, lvf_scan* s, const double* map_pose, double* rpyxyz, const lvf_icp_options* opt,
+                  lvf_icp_summary* summary);
+
+/* ---- sliding-window BA problem (adapt::Problem + adapt::Solve) --------------------------------- */
+typedef struct lvf_solver_options {
+  int max_num_iterations;          /* Ceres default 50; UpdateFrontend uses 1 (backend.cpp:264) */
+  double max_solver_time_in_seconds; /* backend.cpp:208 ; <=0 = unlimited */
+  double huber_a;                  /* shared HuberLoss(1.0) on visual blocks (backend.cpp:98) */
+  double initial_trust_region_radius; /* 1e4 */
+  double function_tolerance;       /* 1e-6 */
+  double gradient_tolerance;       /* 1e-10 */
+  double parameter_tolerance;      /* 1e-8 */
+  double min_relative_decrease;    /* 1e-3 */
+} lvf_solver_options;
+typedef struct lvf_solver_summary {
+  double initial_cost, final_cost;
+  int num_iterations, num_successful_steps;
+  int num_residual_blocks;
+  int termination; /* 0 convergence, 1 no_convergence (iteration/time cap), 2 failure */
+} lvf_solver_summary;
+void lvf_solver_options_default(lvf_solver_options* o);
+/* The problem borrows the state and the batches (they must outlive it).  Any of the batch pointers may
+ * be NULL.  Pose blocks use ProductParameterization(EigenQuaternion, Identity3) (backend.cpp:99-101). */
+int lvf_problem_create(lvf_ctx* ctx, lvf_state* st, lvf_batch* two_camera, lvf_batch* two_frame,
+                       lvf_batch* pose_only, lvf_batch* imu, lvf_problem** out);
+int lvf_problem_destroy(lvf_problem* p);
+int lvf_problem_set_pose_constant(lvf_problem* p, int kf, int is_constant);
+/* Problem::Evaluate-style cost at the current state: 0.5 * sum rho(|r|^2). */
+int lvf_problem_cost(lvf_problem* p, const lvf_solver_options* o, double* cost);
+/* One Levenberg-Marquardt iteration from the current state with trust-region radius *radius (updated);
+ * accepted != 0 if the step was taken.  Deterministic per-iteration parity point. */
+int lvf_problem_lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* radius, double* decrease_factor,
+                             double* cost_before, double* cost_after, int* accepted);
+int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary);
+/* Debug/parity taps of the last linearisation: reduced (Schur) system S [d x d row-major], rhs [d],
+ * d = 15 * n_kf (pose tangent 6 | v 3 | ba 3 | bg 3 per keyframe). */
+int lvf_problem_reduced_dim(lvf_problem* p);
+int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVF_H_ */

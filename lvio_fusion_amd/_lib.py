@@ -1,0 +1,128 @@
+"""ctypes loader for the C-ABI library (include/lvf.h -> lvio_fusion_amd/liblvf_hip.so).
+
+The library is the product; this module only declares signatures.  It never falls back to a CPU
+implementation: if the .so is missing it raises, and if no gfx950 device is usable lvf_ctx_create
+fails with LVF_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "liblvf_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "lvf.h")
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int32)
+c_u8_p = C.POINTER(C.c_uint8)
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("extrinsic", C.c_double * 7)]
+
+
+class IcpOptions(C.Structure):
+    _fields_ = [("mode", C.c_int), ("thr", C.c_float), ("weight", C.c_double), ("huber_a", C.c_double),
+                ("prior_weight", C.c_double), ("max_num_iterations", C.c_int)]
+
+
+class IcpSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("num_residual_blocks", C.c_int),
+                ("num_iterations", C.c_int), ("num_successful_steps", C.c_int)]
+
+
+class SolverOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("max_solver_time_in_seconds", C.c_double), ("huber_a", C.c_double),
+                ("initial_trust_region_radius", C.c_double), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("min_relative_decrease", C.c_double)]
+
+
+class SolverSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("num_iterations", C.c_int),
+                ("num_successful_steps", C.c_int), ("num_residual_blocks", C.c_int), ("termination", C.c_int)]
+
+
+def build(force=False):
+    """Compile every HIP translation unit for gfx950 into liblvf_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".hip", ".hpp"))]
+    srcs.append(HEADER)
+    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(s) for s in srcs):
+        return SO_PATH
+    subprocess.check_call(["bash", os.path.join(HERE, "csrc", "build.sh")])
+    return SO_PATH
+
+
+_lib = None
+
+_VP = C.c_void_p
+_SIGS = {
+    "lvf_last_error": (C.c_char_p, []),
+    "lvf_version": (C.c_char_p, []),
+    "lvf_ctx_create": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
+    "lvf_ctx_destroy": (C.c_int, [_VP]),
+    "lvf_ctx_synchronize": (C.c_int, [_VP]),
+    "lvf_ctx_stream": (_VP, [_VP]),
+    "lvf_timer_begin": (C.c_int, [_VP]),
+    "lvf_timer_end": (C.c_int, [_VP]),
+    "lvf_timer_elapsed_ms": (C.c_int, [_VP, c_float_p]),
+    "lvf_state_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "lvf_state_destroy": (C.c_int, [_VP]),
+    "lvf_state_set": (C.c_int, [_VP, C.c_int, c_double_p]),
+    "lvf_state_get": (C.c_int, [_VP, C.c_int, c_double_p]),
+    "lvf_pose_only_create": (C.c_int, [_VP, C.POINTER(Camera), C.c_int, c_double_p, c_int_p, c_int_p, C.c_int, c_double_p, C.POINTER(_VP)]),
+    "lvf_two_frame_create": (C.c_int, [_VP, C.POINTER(Camera), C.POINTER(Camera), C.c_int, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, C.POINTER(_VP)]),
+    "lvf_two_camera_create": (C.c_int, [_VP, C.POINTER(Camera), C.POINTER(Camera), C.c_int, c_double_p, c_double_p, c_int_p, c_int_p, C.POINTER(_VP)]),
+    "lvf_imu_create": (C.c_int, [_VP, C.c_int, c_double_p, c_int_p, c_int_p, C.POINTER(_VP)]),
+    "lvf_lidar_plane_create": (C.c_int, [_VP, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, C.POINTER(_VP)]),
+    "lvf_batch_destroy": (C.c_int, [_VP]),
+    "lvf_batch_size": (C.c_int, [_VP]),
+    "lvf_batch_num_param_blocks": (C.c_int, [_VP]),
+    "lvf_batch_evaluate": (C.c_int, [_VP, _VP, c_double_p, C.c_int]),
+    "lvf_batch_download_residuals": (C.c_int, [_VP, c_double_p]),
+    "lvf_batch_download_jacobian": (C.c_int, [_VP, C.c_int, c_double_p]),
+    "lvf_batch_download_normals": (C.c_int, [_VP, c_double_p]),
+    "lvf_batch_residuals_dev": (_VP, [_VP]),
+    "lvf_batch_jacobian_dev": (_VP, [_VP, C.c_int]),
+    "lvf_preintegrate": (C.c_int, [_VP, C.c_int, c_int_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "lvf_map_create": (C.c_int, [_VP, c_float_p, C.c_int, C.c_int, C.c_float, C.POINTER(_VP)]),
+    "lvf_map_destroy": (C.c_int, [_VP]),
+    "lvf_scan_create": (C.c_int, [_VP, c_float_p, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "lvf_scan_destroy": (C.c_int, [_VP]),
+    "lvf_knn3": (C.c_int, [_VP, _VP, c_double_p, C.c_float]),
+    "lvf_scan_download": (C.c_int, [_VP, c_int_p, c_float_p, c_u8_p]),
+    "lvf_icp_solve": (C.c_int, [_VP, _VP, c_double_p, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
+    "lvf_solver_options_default": (None, [C.POINTER(SolverOptions)]),
+    "lvf_problem_create": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
+    "lvf_problem_destroy": (C.c_int, [_VP]),
+    "lvf_problem_set_pose_constant": (C.c_int, [_VP, C.c_int, C.c_int]),
+    "lvf_problem_cost": (C.c_int, [_VP, C.POINTER(SolverOptions), c_double_p]),
+    "lvf_problem_lm_iteration": (C.c_int, [_VP, C.POINTER(SolverOptions), c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
+    "lvf_problem_solve": (C.c_int, [_VP, C.POINTER(SolverOptions), C.POINTER(SolverSummary)]),
+    "lvf_problem_reduced_dim": (C.c_int, [_VP]),
+    "lvf_problem_download_reduced": (C.c_int, [_VP, c_double_p, c_double_p]),
+}
+
+
+def declared_symbols():
+    """Every function name declared in include/lvf.h (used by the CPU export test)."""
+    import re
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lvf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback for the HIP path)")
+        _lib = C.CDLL(SO_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib

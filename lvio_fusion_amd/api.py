@@ -1,0 +1,277 @@
+"""Thin numpy-facing handles over the C-ABI (include/lvf.h).  Used by tests/ and bench.py; the C++ adapter
+(include/lvf_ceres_adapter.hpp) is the reference-shaped host interface.  Everything here runs on the GPU —
+errors from the library are raised, never papered over."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Camera, IcpOptions, IcpSummary, SolverOptions, SolverSummary
+
+POSES, VEL, BA, BG, INV_DEPTH, W_VISUAL = range(6)
+IMU_BLOCK_SIZES = (7, 3, 3, 3, 7, 3, 3, 3)
+
+
+class LvfError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise LvfError(f"lvf error {rc}: {_lib.lib().lvf_last_error().decode()}")
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_lib.c_int_p)
+
+
+def make_camera(c):
+    k = Camera()
+    k.fx, k.fy, k.cx, k.cy = c["fx"], c["fy"], c["cx"], c["cy"]
+    for i in range(7):
+        k.extrinsic[i] = float(c["extrinsic"][i])
+    return k
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        _chk(_lib.lib().lvf_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self.h)))
+        self.L = _lib.lib()
+
+    def synchronize(self):
+        _chk(self.L.lvf_ctx_synchronize(self.h))
+
+    def timer_begin(self):
+        _chk(self.L.lvf_timer_begin(self.h))
+
+    def timer_end(self):
+        _chk(self.L.lvf_timer_end(self.h))
+
+    def timer_ms(self):
+        ms = C.c_float()
+        _chk(self.L.lvf_timer_elapsed_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.L.lvf_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class State:
+    def __init__(self, ctx, n_kf, n_lm):
+        self.ctx, self.n_kf, self.n_lm = ctx, n_kf, n_lm
+        self.h = C.c_void_p()
+        _chk(ctx.L.lvf_state_create(ctx.h, n_kf, n_lm, C.byref(self.h)))
+
+    def _size(self, field):
+        return {POSES: 7 * self.n_kf, VEL: 3 * self.n_kf, BA: 3 * self.n_kf, BG: 3 * self.n_kf, INV_DEPTH: self.n_lm,
+                W_VISUAL: self.n_kf}[field]
+
+    def set(self, field, arr):
+        a = _d(arr)
+        if a.size != self._size(field):
+            raise ValueError(f"state field {field}: expected {self._size(field)} doubles, got {a.size}")
+        _chk(self.ctx.L.lvf_state_set(self.h, field, _dp(a)))
+
+    def get(self, field):
+        out = np.empty(self._size(field))
+        _chk(self.ctx.L.lvf_state_get(self.h, field, _dp(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lvf_state_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Batch:
+    """One functor type's residual blocks.  evaluate() == batched CostFunction::Evaluate."""
+
+    def __init__(self, ctx, h, n, n_res, block_sizes):
+        self.ctx, self.h, self.n, self.n_res, self.block_sizes = ctx, h, n, n_res, tuple(block_sizes)
+
+    def evaluate(self, state=None, rpyxyz=None, jacobians=True):
+        r = _d(rpyxyz) if rpyxyz is not None else None
+        _chk(self.ctx.L.lvf_batch_evaluate(self.h, state.h if state is not None else None, _dp(r) if r is not None else None,
+                                           1 if jacobians else 0))
+
+    def residuals(self):
+        out = np.empty((self.n, self.n_res))
+        _chk(self.ctx.L.lvf_batch_download_residuals(self.h, _dp(out)))
+        return out
+
+    def jacobian(self, block):
+        out = np.empty((self.n, self.n_res, self.block_sizes[block]))
+        _chk(self.ctx.L.lvf_batch_download_jacobian(self.h, block, _dp(out)))
+        return out
+
+    def normals(self):
+        out = np.empty((self.n, 3))
+        _chk(self.ctx.L.lvf_batch_download_normals(self.h, _dp(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lvf_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def pose_only_batch(ctx, cam0, ob, kf_idx, pw_idx, pw):
+    ob, pw, kf_idx, pw_idx = _d(ob), _d(pw), _i(kf_idx), _i(pw_idx)
+    h = C.c_void_p()
+    cam = make_camera(cam0)
+    _chk(ctx.L.lvf_pose_only_create(ctx.h, C.byref(cam), ob.shape[0], _dp(ob), _ip(kf_idx), _ip(pw_idx), pw.shape[0], _dp(pw), C.byref(h)))
+    return Batch(ctx, h, ob.shape[0], 2, (7,))
+
+
+def two_frame_batch(ctx, left, right, first_ob, ob, lm_idx, kf1_idx, kf2_idx):
+    first_ob, ob = _d(first_ob), _d(ob)
+    lm_idx, kf1_idx, kf2_idx = _i(lm_idx), _i(kf1_idx), _i(kf2_idx)
+    h = C.c_void_p()
+    cl, cr = make_camera(left), make_camera(right)
+    _chk(ctx.L.lvf_two_frame_create(ctx.h, C.byref(cl), C.byref(cr), ob.shape[0], _dp(first_ob), _dp(ob), _ip(lm_idx), _ip(kf1_idx),
+                                    _ip(kf2_idx), C.byref(h)))
+    return Batch(ctx, h, ob.shape[0], 2, (1, 7, 7))
+
+
+def two_camera_batch(ctx, left, right, left_ob, right_ob, lm_idx, kf_idx):
+    left_ob, right_ob, lm_idx, kf_idx = _d(left_ob), _d(right_ob), _i(lm_idx), _i(kf_idx)
+    h = C.c_void_p()
+    cl, cr = make_camera(left), make_camera(right)
+    _chk(ctx.L.lvf_two_camera_create(ctx.h, C.byref(cl), C.byref(cr), left_ob.shape[0], _dp(left_ob), _dp(right_ob), _ip(lm_idx),
+                                     _ip(kf_idx), C.byref(h)))
+    return Batch(ctx, h, left_ob.shape[0], 2, (1,))
+
+
+def imu_batch(ctx, pre, kf_i, kf_j):
+    pre, kf_i, kf_j = _d(pre), _i(kf_i), _i(kf_j)
+    assert pre.ndim == 2 and pre.shape[1] == 467
+    h = C.c_void_p()
+    _chk(ctx.L.lvf_imu_create(ctx.h, pre.shape[0], _dp(pre), _ip(kf_i), _ip(kf_j), C.byref(h)))
+    return Batch(ctx, h, pre.shape[0], 15, IMU_BLOCK_SIZES)
+
+
+def lidar_plane_batch(ctx, mode, p, pa, pb, pc, Twc1, weight):
+    p, pa, pb, pc, Twc1 = map(_d, (p, pa, pb, pc, Twc1))
+    h = C.c_void_p()
+    _chk(ctx.L.lvf_lidar_plane_create(ctx.h, int(mode), p.shape[0], _dp(p), _dp(pa), _dp(pb), _dp(pc), _dp(Twc1), float(weight), C.byref(h)))
+    return Batch(ctx, h, p.shape[0], 1, (1, 1, 1))
+
+
+def preintegrate(ctx, samples_list, acc0, gyr0, ba, bg, noise4):
+    n = len(samples_list)
+    offset = np.zeros(n + 1, np.int32)
+    offset[1:] = np.cumsum([s.shape[0] for s in samples_list])
+    samples = _d(np.concatenate(samples_list)) if n else np.zeros((0, 7))
+    acc0, gyr0, ba, bg, noise4 = map(_d, (acc0, gyr0, ba, bg, noise4))
+    out = np.zeros((n, 467))
+    _chk(ctx.L.lvf_preintegrate(ctx.h, n, _ip(offset), _dp(samples), _dp(acc0), _dp(gyr0), _dp(ba), _dp(bg), _dp(noise4), _dp(out)))
+    return out
+
+
+class Map:
+    def __init__(self, ctx, xyz, max_radius2):
+        a = _f(xyz)
+        self.ctx, self.M = ctx, a.shape[0]
+        self.h = C.c_void_p()
+        _chk(ctx.L.lvf_map_create(ctx.h, a.ctypes.data_as(_lib.c_float_p), a.shape[0], a.shape[1] if a.ndim == 2 else 3,
+                                  float(max_radius2), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lvf_map_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Scan:
+    def __init__(self, ctx, xyz):
+        a = _f(xyz)
+        self.ctx, self.Q = ctx, a.shape[0]
+        self.h = C.c_void_p()
+        _chk(ctx.L.lvf_scan_create(ctx.h, a.ctypes.data_as(_lib.c_float_p), a.shape[0], a.shape[1] if a.ndim == 2 else 3, C.byref(self.h)))
+
+    def download(self):
+        idx = np.empty((self.Q, 3), np.int32); d2 = np.empty((self.Q, 3), np.float32); valid = np.empty(self.Q, np.uint8)
+        _chk(self.ctx.L.lvf_scan_download(self.h, _ip(idx), d2.ctypes.data_as(_lib.c_float_p), valid.ctypes.data_as(_lib.c_u8_p)))
+        return idx, d2, valid
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lvf_scan_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def knn3(map_, scan, pose, thr):
+    p = _d(pose)
+    _chk(map_.ctx.L.lvf_knn3(map_.h, scan.h, _dp(p), float(thr)))
+
+
+def icp_solve(map_, scan, map_pose, rpyxyz, mode, thr, weight, huber_a, prior_weight=0.0, max_num_iterations=4):
+    """rpyxyz is updated IN PLACE (numpy float64[6]); returns the summary struct."""
+    assert rpyxyz.dtype == np.float64 and rpyxyz.flags.c_contiguous and rpyxyz.size == 6
+    mp = _d(map_pose)
+    opt = IcpOptions(int(mode), float(thr), float(weight), float(huber_a), float(prior_weight), int(max_num_iterations))
+    summ = IcpSummary()
+    _chk(map_.ctx.L.lvf_icp_solve(map_.h, scan.h, _dp(mp), _dp(rpyxyz), C.byref(opt), C.byref(summ)))
+    return summ
+
+
+def default_solver_options():
+    o = SolverOptions()
+    _lib.lib().lvf_solver_options_default(C.byref(o))
+    return o
+
+
+class Problem:
+    def __init__(self, ctx, state, two_camera=None, two_frame=None, pose_only=None, imu=None):
+        self.ctx, self.state = ctx, state
+        self.h = C.c_void_p()
+        hs = [b.h if b is not None else None for b in (two_camera, two_frame, pose_only, imu)]
+        _chk(ctx.L.lvf_problem_create(ctx.h, state.h, hs[0], hs[1], hs[2], hs[3], C.byref(self.h)))
+
+    def set_pose_constant(self, kf, const=True):
+        _chk(self.ctx.L.lvf_problem_set_pose_constant(self.h, int(kf), 1 if const else 0))
+
+    def cost(self, opt):
+        c = C.c_double()
+        _chk(self.ctx.L.lvf_problem_cost(self.h, C.byref(opt), C.byref(c)))
+        return c.value
+
+    def lm_iteration(self, opt, radius, decrease_factor=2.0):
+        r, d, c0, c1, acc = C.c_double(radius), C.c_double(decrease_factor), C.c_double(), C.c_double(), C.c_int()
+        _chk(self.ctx.L.lvf_problem_lm_iteration(self.h, C.byref(opt), C.byref(r), C.byref(d), C.byref(c0), C.byref(c1), C.byref(acc)))
+        return dict(radius=r.value, decrease_factor=d.value, cost_before=c0.value, cost_after=c1.value, accepted=bool(acc.value))
+
+    def solve(self, opt):
+        s = SolverSummary()
+        _chk(self.ctx.L.lvf_problem_solve(self.h, C.byref(opt), C.byref(s)))
+        return s
+
+    def reduced_system(self):
+        d = self.ctx.L.lvf_problem_reduced_dim(self.h)
+        S = np.empty((d, d)); rhs = np.empty(d)
+        _chk(self.ctx.L.lvf_problem_download_reduced(self.h, _dp(S), _dp(rhs)))
+        return S, rhs
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lvf_problem_destroy(self.h)
+            self.h = C.c_void_p()

@@ -1,0 +1,353 @@
+// capi.hip — the extern "C" surface of include/lvf.h: context, parameter state, factor batches.
+#include "lvf_internal.hpp"
+
+namespace lvf {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
+  return LVF_ERR_HIP;
+}
+
+// host-side rotation of the (constant) camera extrinsic; mirrors derive_pose
+static void host_rot(const double q[4], double R[9]) {
+  const double s = 1.0 / std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double x = s * q[0], y = s * q[1], z = s * q[2], w = s * q[3];
+  R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - w * z);       R[2] = 2.0 * (x * z + w * y);
+  R[3] = 2.0 * (x * y + w * z);       R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - w * x);
+  R[6] = 2.0 * (x * z - w * y);       R[7] = 2.0 * (y * z + w * x);       R[8] = 1.0 - 2.0 * (x * x + y * y);
+}
+void make_camd(const lvf_camera& c, CamD& d) {
+  d.fx = c.fx; d.fy = c.fy; d.cx = c.cx; d.cy = c.cy;
+  host_rot(c.extrinsic, d.Re);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d.E[3 * i + j] = d.Re[3 * j + i];
+  for (int i = 0; i < 3; ++i) {
+    d.te[i] = c.extrinsic[4 + i];
+    d.c0[i] = -(d.E[3 * i] * c.extrinsic[4] + d.E[3 * i + 1] * c.extrinsic[5] + d.E[3 * i + 2] * c.extrinsic[6]);
+  }
+}
+
+static int check_idx(const int32_t* idx, int n, const char* name) {
+  for (int i = 0; i < n; ++i)
+    if (idx[i] < 0) { set_error("%s[%d] = %d is negative", name, i, idx[i]); return LVF_ERR_INVALID; }
+  return LVF_OK;
+}
+static int32_t max_idx(const int32_t* idx, int n) { int32_t m = -1; for (int i = 0; i < n; ++i) if (idx[i] > m) m = idx[i]; return m; }
+static bool is_sorted_i32(const int32_t* idx, int n) { for (int i = 1; i < n; ++i) if (idx[i] < idx[i - 1]) return false; return true; }
+
+static int alloc_outputs(lvf_batch* b) {
+  LVF_TRY(b->res.alloc((size_t)b->n * b->n_res));
+  for (int k = 0; k < b->n_blocks; ++k) LVF_TRY(b->jac[k].alloc((size_t)b->n * b->n_res * b->block_size[k]));
+  return LVF_OK;
+}
+
+// [n][3] AoS -> [3][n] SoA
+static std::vector<double> to_soa3(const double* a, int n) {
+  std::vector<double> o((size_t)3 * n);
+  for (int i = 0; i < n; ++i) { o[i] = a[3 * i]; o[(size_t)n + i] = a[3 * i + 1]; o[(size_t)2 * n + i] = a[3 * i + 2]; }
+  return o;
+}
+
+}  // namespace lvf
+
+using namespace lvf;
+
+extern "C" {
+
+const char* lvf_last_error(void) { return g_err.c_str(); }
+const char* lvf_version(void) { return "lvio_fusion_amd 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------ context
+int lvf_ctx_create(int device, void* hip_stream, lvf_ctx** out) {
+  LVF_REQUIRE(out, "lvf_ctx_create: out is null");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    set_error("lvf_ctx_create: no usable HIP device (hipGetDeviceCount -> %d, count %d); there is no CPU fallback", (int)e, count);
+    (void)hipGetLastError();
+    return LVF_ERR_NO_DEVICE;
+  }
+  LVF_REQUIRE(device >= 0 && device < count, "lvf_ctx_create: device %d out of range [0,%d)", device, count);
+  LVF_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  LVF_HIP(hipGetDeviceProperties(&prop, device));
+  auto* c = new lvf_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount;
+  if (hip_stream) { c->stream = static_cast<hipStream_t>(hip_stream); c->own_stream = false; }
+  else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__); }
+    c->own_stream = true;
+  }
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c; set_error("lvf_ctx_create: hipEventCreate failed"); return LVF_ERR_HIP;
+  }
+  *out = c;
+  return LVF_OK;
+}
+int lvf_ctx_destroy(lvf_ctx* c) {
+  if (!c) return LVF_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return LVF_OK;
+}
+int lvf_ctx_synchronize(lvf_ctx* c) { LVF_REQUIRE(c, "null ctx"); LVF_HIP(hipStreamSynchronize(c->stream)); return LVF_OK; }
+void* lvf_ctx_stream(lvf_ctx* c) { return c ? c->stream : nullptr; }
+int lvf_timer_begin(lvf_ctx* c) { LVF_REQUIRE(c, "null ctx"); LVF_HIP(hipEventRecord(c->ev0, c->stream)); return LVF_OK; }
+int lvf_timer_end(lvf_ctx* c) { LVF_REQUIRE(c, "null ctx"); LVF_HIP(hipEventRecord(c->ev1, c->stream)); return LVF_OK; }
+int lvf_timer_elapsed_ms(lvf_ctx* c, float* ms) {
+  LVF_REQUIRE(c && ms, "null argument");
+  LVF_HIP(hipEventSynchronize(c->ev1));
+  LVF_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return LVF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ state
+int lvf_state_create(lvf_ctx* ctx, int n_kf, int n_lm, lvf_state** out) {
+  LVF_REQUIRE(ctx && out, "lvf_state_create: null ctx/out");
+  LVF_REQUIRE(n_kf >= 0 && n_lm >= 0, "lvf_state_create: negative size");
+  LVF_HIP(hipSetDevice(ctx->device));
+  auto* st = new lvf_state();
+  st->ctx = ctx; st->n_kf = n_kf; st->n_lm = n_lm;
+  int rc;
+  if ((rc = st->poses.alloc((size_t)7 * n_kf)) || (rc = st->vel.alloc((size_t)3 * n_kf)) || (rc = st->ba.alloc((size_t)3 * n_kf)) ||
+      (rc = st->bg.alloc((size_t)3 * n_kf)) || (rc = st->inv_depth.alloc(n_lm)) || (rc = st->w_visual.alloc(n_kf))) {
+    delete st; return rc;
+  }
+  // identity poses, zero elsewhere, unit weights: a defined state even before the caller uploads
+  std::vector<double> id((size_t)7 * n_kf, 0.0), ones(n_kf, 1.0);
+  for (int k = 0; k < n_kf; ++k) id[7 * k + 3] = 1.0;
+  hipStream_t s = ctx->stream;
+  if (n_kf) {
+    LVF_HIP(hipMemcpyAsync(st->poses.p, id.data(), id.size() * 8, hipMemcpyHostToDevice, s));
+    LVF_HIP(hipMemcpyAsync(st->w_visual.p, ones.data(), ones.size() * 8, hipMemcpyHostToDevice, s));
+    LVF_HIP(hipMemsetAsync(st->vel.p, 0, (size_t)24 * n_kf, s));
+    LVF_HIP(hipMemsetAsync(st->ba.p, 0, (size_t)24 * n_kf, s));
+    LVF_HIP(hipMemsetAsync(st->bg.p, 0, (size_t)24 * n_kf, s));
+  }
+  if (n_lm) LVF_HIP(hipMemsetAsync(st->inv_depth.p, 0, (size_t)8 * n_lm, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  *out = st;
+  return LVF_OK;
+}
+int lvf_state_destroy(lvf_state* st) { delete st; return LVF_OK; }
+
+static int state_field(lvf_state* st, int field, double** p, size_t* n) {
+  switch (field) {
+    case LVF_POSES: *p = st->poses.p; *n = (size_t)7 * st->n_kf; return LVF_OK;
+    case LVF_VEL: *p = st->vel.p; *n = (size_t)3 * st->n_kf; return LVF_OK;
+    case LVF_BA: *p = st->ba.p; *n = (size_t)3 * st->n_kf; return LVF_OK;
+    case LVF_BG: *p = st->bg.p; *n = (size_t)3 * st->n_kf; return LVF_OK;
+    case LVF_INV_DEPTH: *p = st->inv_depth.p; *n = (size_t)st->n_lm; return LVF_OK;
+    case LVF_W_VISUAL: *p = st->w_visual.p; *n = (size_t)st->n_kf; return LVF_OK;
+  }
+  set_error("unknown state field %d", field);
+  return LVF_ERR_INVALID;
+}
+int lvf_state_set(lvf_state* st, int field, const double* host) {
+  LVF_REQUIRE(st && host, "lvf_state_set: null argument");
+  double* p; size_t n;
+  LVF_TRY(state_field(st, field, &p, &n));
+  if (n) { LVF_HIP(hipMemcpyAsync(p, host, n * 8, hipMemcpyHostToDevice, st->ctx->stream)); LVF_HIP(hipStreamSynchronize(st->ctx->stream)); }
+  return LVF_OK;
+}
+int lvf_state_get(lvf_state* st, int field, double* host) {
+  LVF_REQUIRE(st && host, "lvf_state_get: null argument");
+  double* p; size_t n;
+  LVF_TRY(state_field(st, field, &p, &n));
+  if (n) LVF_HIP(hipMemcpyAsync(host, p, n * 8, hipMemcpyDeviceToHost, st->ctx->stream));
+  LVF_HIP(hipStreamSynchronize(st->ctx->stream));
+  return LVF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batches
+static lvf_batch* new_batch(lvf_ctx* ctx, int kind, int n, int n_res, std::initializer_list<int> sizes) {
+  auto* b = new lvf_batch();
+  b->ctx = ctx; b->kind = kind; b->n = n; b->n_res = n_res;
+  for (int s : sizes) b->block_size[b->n_blocks++] = s;
+  return b;
+}
+
+int lvf_pose_only_create(lvf_ctx* ctx, const lvf_camera* cam0, int n, const double* ob, const int32_t* kf_idx,
+                         const int32_t* pw_idx, int n_pw, const double* pw, lvf_batch** out) {
+  LVF_REQUIRE(ctx && cam0 && out, "lvf_pose_only_create: null argument");
+  LVF_REQUIRE(n >= 0 && n_pw >= 0, "lvf_pose_only_create: negative size");
+  LVF_REQUIRE(n == 0 || (ob && kf_idx && pw_idx && pw), "lvf_pose_only_create: null input array");
+  LVF_TRY(check_idx(kf_idx, n, "kf_idx")); LVF_TRY(check_idx(pw_idx, n, "pw_idx"));
+  LVF_REQUIRE(max_idx(pw_idx, n) < n_pw, "lvf_pose_only_create: pw_idx out of range (n_pw=%d)", n_pw);
+  LVF_HIP(hipSetDevice(ctx->device));
+  lvf_batch* b = new_batch(ctx, LVF_K_POSE_ONLY, n, 2, {7});
+  make_camd(*cam0, b->cam_a);
+  b->n_table = n_pw;
+  b->sorted_by_kf = is_sorted_i32(kf_idx, n);
+  b->min_n_kf = max_idx(kf_idx, n) + 1;
+  hipStream_t s = ctx->stream;
+  int rc;
+  if ((rc = b->ob_a.upload(ob, (size_t)2 * n, s)) || (rc = b->idx_a.upload(kf_idx, n, s)) || (rc = b->idx_b.upload(pw_idx, n, s)) ||
+      (rc = b->table.upload(pw, (size_t)3 * n_pw, s)) || (rc = alloc_outputs(b))) { delete b; return rc; }
+  LVF_HIP(hipStreamSynchronize(s));
+  *out = b;
+  return LVF_OK;
+}
+
+int lvf_two_frame_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera* right, int n, const double* first_ob,
+                         const double* ob, const int32_t* lm_idx, const int32_t* kf1_idx, const int32_t* kf2_idx,
+                         lvf_batch** out) {
+  LVF_REQUIRE(ctx && left && right && out, "lvf_two_frame_create: null argument");
+  LVF_REQUIRE(n >= 0, "lvf_two_frame_create: negative size");
+  LVF_REQUIRE(n == 0 || (first_ob && ob && lm_idx && kf1_idx && kf2_idx), "lvf_two_frame_create: null input array");
+  LVF_TRY(check_idx(lm_idx, n, "lm_idx")); LVF_TRY(check_idx(kf1_idx, n, "kf1_idx")); LVF_TRY(check_idx(kf2_idx, n, "kf2_idx"));
+  LVF_HIP(hipSetDevice(ctx->device));
+  lvf_batch* b = new_batch(ctx, LVF_K_TWO_FRAME, n, 2, {1, 7, 7});
+  make_camd(*left, b->cam_a); make_camd(*right, b->cam_b);
+  b->sorted_by_kf = is_sorted_i32(kf2_idx, n);
+  hipStream_t s = ctx->stream;
+  int rc;
+  if ((rc = b->ob_a.upload(first_ob, (size_t)2 * n, s)) || (rc = b->ob_b.upload(ob, (size_t)2 * n, s)) ||
+      (rc = b->idx_a.upload(lm_idx, n, s)) || (rc = b->idx_b.upload(kf1_idx, n, s)) || (rc = b->idx_c.upload(kf2_idx, n, s)) ||
+      (rc = alloc_outputs(b))) { delete b; return rc; }
+  b->min_n_kf = std::max(max_idx(kf1_idx, n), max_idx(kf2_idx, n)) + 1;
+  b->min_n_lm = max_idx(lm_idx, n) + 1;
+  LVF_HIP(hipStreamSynchronize(s));
+  *out = b;
+  return LVF_OK;
+}
+
+int lvf_two_camera_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera* right, int n, const double* left_ob,
+                          const double* right_ob, const int32_t* lm_idx, const int32_t* kf_idx, lvf_batch** out) {
+  LVF_REQUIRE(ctx && left && right && out, "lvf_two_camera_create: null argument");
+  LVF_REQUIRE(n >= 0, "lvf_two_camera_create: negative size");
+  LVF_REQUIRE(n == 0 || (left_ob && right_ob && lm_idx && kf_idx), "lvf_two_camera_create: null input array");
+  LVF_TRY(check_idx(lm_idx, n, "lm_idx")); LVF_TRY(check_idx(kf_idx, n, "kf_idx"));
+  LVF_HIP(hipSetDevice(ctx->device));
+  lvf_batch* b = new_batch(ctx, LVF_K_TWO_CAMERA, n, 2, {1});
+  make_camd(*left, b->cam_a); make_camd(*right, b->cam_b);
+  hipStream_t s = ctx->stream;
+  int rc;
+  if ((rc = b->ob_a.upload(left_ob, (size_t)2 * n, s)) || (rc = b->ob_b.upload(right_ob, (size_t)2 * n, s)) ||
+      (rc = b->idx_a.upload(lm_idx, n, s)) || (rc = b->idx_b.upload(kf_idx, n, s)) || (rc = alloc_outputs(b))) { delete b; return rc; }
+  b->min_n_kf = max_idx(kf_idx, n) + 1;
+  b->min_n_lm = max_idx(lm_idx, n) + 1;
+  LVF_HIP(hipStreamSynchronize(s));
+  *out = b;
+  return LVF_OK;
+}
+
+int lvf_imu_create(lvf_ctx* ctx, int n, const lvf_preint* pre, const int32_t* kf_i, const int32_t* kf_j, lvf_batch** out) {
+  LVF_REQUIRE(ctx && out, "lvf_imu_create: null argument");
+  LVF_REQUIRE(n >= 0, "lvf_imu_create: negative size");
+  LVF_REQUIRE(n == 0 || (pre && kf_i && kf_j), "lvf_imu_create: null input array");
+  static_assert(sizeof(lvf_preint) == 467 * sizeof(double), "lvf_preint must be 467 packed doubles");
+  LVF_TRY(check_idx(kf_i, n, "kf_i")); LVF_TRY(check_idx(kf_j, n, "kf_j"));
+  LVF_HIP(hipSetDevice(ctx->device));
+  lvf_batch* b = new_batch(ctx, LVF_K_IMU, n, 15, {7, 3, 3, 3, 7, 3, 3, 3});
+  hipStream_t s = ctx->stream;
+  int rc;
+  if ((rc = b->pre.upload(reinterpret_cast<const double*>(pre), (size_t)467 * n, s)) || (rc = b->idx_a.upload(kf_i, n, s)) ||
+      (rc = b->idx_b.upload(kf_j, n, s)) || (rc = b->sqrt_info.alloc((size_t)225 * n)) || (rc = alloc_outputs(b)) ||
+      (rc = launch_imu_sqrt_info(b))) { delete b; return rc; }
+  b->min_n_kf = std::max(max_idx(kf_i, n), max_idx(kf_j, n)) + 1;
+  LVF_HIP(hipStreamSynchronize(s));
+  *out = b;
+  return LVF_OK;
+}
+
+int lvf_lidar_plane_create(lvf_ctx* ctx, int mode, int n, const double* p, const double* pa, const double* pb,
+                           const double* pc, const double* Twc1, double weight, lvf_batch** out) {
+  LVF_REQUIRE(ctx && out && Twc1, "lvf_lidar_plane_create: null argument");
+  LVF_REQUIRE(mode == 0 || mode == 1, "lvf_lidar_plane_create: mode must be 0 (RPZ) or 1 (YXY)");
+  LVF_REQUIRE(n >= 0, "lvf_lidar_plane_create: negative size");
+  LVF_REQUIRE(n == 0 || (p && pa && pb && pc), "lvf_lidar_plane_create: null input array");
+  LVF_HIP(hipSetDevice(ctx->device));
+  lvf_batch* b = new_batch(ctx, LVF_K_LIDAR, n, 1, {1, 1, 1});
+  b->lidar_mode = mode; b->lidar_weight = weight;
+  std::memcpy(b->Twc1, Twc1, sizeof(b->Twc1));
+  hipStream_t s = ctx->stream;
+  DevBuf<double> dpb, dpc;
+  const auto sp = to_soa3(p, n), spa = to_soa3(pa, n), spb = to_soa3(pb, n), spc = to_soa3(pc, n);
+  int rc;
+  if ((rc = b->lp.upload(sp.data(), sp.size(), s)) || (rc = b->lpa.upload(spa.data(), spa.size(), s)) ||
+      (rc = dpb.upload(spb.data(), spb.size(), s)) || (rc = dpc.upload(spc.data(), spc.size(), s)) ||
+      (rc = b->lnrm.alloc((size_t)3 * n)) || (rc = alloc_outputs(b)) || (rc = launch_lidar_normals(b, dpb.p, dpc.p))) { delete b; return rc; }
+  LVF_HIP(hipStreamSynchronize(s));
+  *out = b;
+  return LVF_OK;
+}
+
+int lvf_batch_destroy(lvf_batch* b) { delete b; return LVF_OK; }
+int lvf_batch_size(const lvf_batch* b) { return b ? b->n : -1; }
+int lvf_batch_num_param_blocks(const lvf_batch* b) { return b ? b->n_blocks : -1; }
+
+int lvf_batch_evaluate(lvf_batch* b, const lvf_state* st, const double* rpyxyz, int want_jacobians) {
+  LVF_REQUIRE(b, "lvf_batch_evaluate: null batch");
+  LVF_HIP(hipSetDevice(b->ctx->device));
+  const bool wj = want_jacobians != 0;
+  int rc = LVF_OK;
+  if (b->kind == LVF_K_LIDAR) {
+    LVF_REQUIRE(rpyxyz, "lvf_batch_evaluate: lidar batches need the live rpyxyz[6]");
+    rc = launch_lidar_plane(b, rpyxyz, wj);
+  } else {
+    LVF_REQUIRE(st, "lvf_batch_evaluate: state is null");
+    LVF_REQUIRE(st->ctx == b->ctx, "lvf_batch_evaluate: state and batch belong to different contexts");
+    switch (b->kind) {
+      case LVF_K_POSE_ONLY:
+        LVF_REQUIRE(st->n_kf >= b->min_n_kf, "pose-only batch references keyframe %d but the state has %d", b->min_n_kf - 1, st->n_kf);
+        rc = launch_pose_only(b, st, wj); break;
+      case LVF_K_TWO_FRAME:
+        LVF_REQUIRE(st->n_kf >= b->min_n_kf && st->n_lm >= b->min_n_lm, "two-frame batch indices exceed the state (n_kf=%d n_lm=%d)", st->n_kf, st->n_lm);
+        rc = launch_two_frame(b, st, wj); break;
+      case LVF_K_TWO_CAMERA:
+        LVF_REQUIRE(st->n_kf >= b->min_n_kf && st->n_lm >= b->min_n_lm, "two-camera batch indices exceed the state (n_kf=%d n_lm=%d)", st->n_kf, st->n_lm);
+        rc = launch_two_camera(b, st, wj); break;
+      case LVF_K_IMU:
+        LVF_REQUIRE(st->n_kf >= b->min_n_kf, "imu batch indices exceed the state (n_kf=%d)", st->n_kf);
+        rc = launch_imu(b, st, wj); break;
+      default: set_error("unknown batch kind %d", b->kind); return LVF_ERR_INVALID;
+    }
+  }
+  if (rc == LVF_OK) { b->evaluated = true; b->have_jac = wj; }
+  return rc;
+}
+
+static int download(lvf_batch* b, const double* dev, double* host, size_t count) {
+  if (count) LVF_HIP(hipMemcpyAsync(host, dev, count * 8, hipMemcpyDeviceToHost, b->ctx->stream));
+  LVF_HIP(hipStreamSynchronize(b->ctx->stream));
+  return LVF_OK;
+}
+int lvf_batch_download_residuals(lvf_batch* b, double* host) {
+  LVF_REQUIRE(b && host, "lvf_batch_download_residuals: null argument");
+  if (!b->evaluated) { set_error("download before evaluate"); return LVF_ERR_STATE; }
+  return download(b, b->res.p, host, (size_t)b->n * b->n_res);
+}
+int lvf_batch_download_jacobian(lvf_batch* b, int block, double* host) {
+  LVF_REQUIRE(b && host, "lvf_batch_download_jacobian: null argument");
+  LVF_REQUIRE(block >= 0 && block < b->n_blocks, "jacobian block %d out of range [0,%d)", block, b->n_blocks);
+  if (!b->evaluated || !b->have_jac) { set_error("jacobians were not evaluated"); return LVF_ERR_STATE; }
+  return download(b, b->jac[block].p, host, (size_t)b->n * b->n_res * b->block_size[block]);
+}
+int lvf_batch_download_normals(lvf_batch* b, double* host) {
+  LVF_REQUIRE(b && host, "lvf_batch_download_normals: null argument");
+  LVF_REQUIRE(b->kind == LVF_K_LIDAR, "normals exist only for lidar batches");
+  std::vector<double> soa((size_t)3 * b->n);
+  LVF_TRY(download(b, b->lnrm.p, soa.data(), soa.size()));
+  for (int i = 0; i < b->n; ++i) { host[3 * i] = soa[i]; host[3 * i + 1] = soa[(size_t)b->n + i]; host[3 * i + 2] = soa[(size_t)2 * b->n + i]; }
+  return LVF_OK;
+}
+void* lvf_batch_residuals_dev(lvf_batch* b) { return b ? b->res.p : nullptr; }
+void* lvf_batch_jacobian_dev(lvf_batch* b, int block) { return (b && block >= 0 && block < b->n_blocks) ? b->jac[block].p : nullptr; }
+
+}  // extern "C"
