@@ -77,6 +77,12 @@ __global__ __launch_bounds__(kB) void k_cell_count(int M, const float4* __restri
   atomicAdd(counts + c, 1);
 }
 
+__global__ __launch_bounds__(kB) void k_count_nonempty(int n, const int* __restrict__ counts, int* __restrict__ total) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  const unsigned long long m = __ballot(i < n && counts[i] > 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(total, __popcll(m));
+}
+
 // 3-phase exclusive scan over `n` ints, 1024 elements per workgroup
 constexpr int kScanT = 256, kScanE = 4, kScanChunk = kScanT * kScanE;
 __device__ __forceinline__ int block_exclusive_scan(int v, int* s_warp, int& total) {
@@ -280,24 +286,44 @@ int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats,
   for (int k = 0; k < 3; ++k) { lo[k] = ord2f(hb[k]); hi[k] = ord2f(hb[3 + k]); }
   for (int k = 0; k < 3; ++k)
     if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) { set_error("lvf_map_create: non-finite map coordinates"); return fail(LVF_ERR_INVALID); }
-  // cell edge = gate radius / 2 (two shells cover the gate); enlarge until the grid fits the cell budget
-  float cell = std::sqrt(max_radius2) * 0.5f;
+  // Cell edge: start at gate radius / 2 and HALVE while the mean occupancy of non-empty cells stays above
+  // kTargetOcc (lidar clouds are surfaces: a coarse cell holds hundreds of points and every query would scan
+  // thousands of candidates; ~4-8 points per occupied cell keeps the first shells at ~100 candidates).
   const double kMaxCells = 4.0 * 1024 * 1024;
-  for (;;) {
-    const double nx = std::floor((hi[0] - lo[0]) / cell) + 1, ny = std::floor((hi[1] - lo[1]) / cell) + 1, nz = std::floor((hi[2] - lo[2]) / cell) + 1;
-    if (nx * ny * nz <= kMaxCells) { m->nx = (int)nx; m->ny = (int)ny; m->nz = (int)nz; break; }
-    cell *= 1.25f;
+  const double kTargetOcc = 6.0;
+  auto dims_for = [&](float c, double& nx, double& ny, double& nz) {
+    nx = std::floor((hi[0] - lo[0]) / c) + 1; ny = std::floor((hi[1] - lo[1]) / c) + 1; nz = std::floor((hi[2] - lo[2]) / c) + 1;
+    return nx * ny * nz;
+  };
+  float cell = std::sqrt(max_radius2) * 0.5f;
+  double dnx, dny, dnz;
+  while (dims_for(cell, dnx, dny, dnz) > kMaxCells) cell *= 1.25f;
+  if ((rc = cell_of.alloc(M)) != LVF_OK || (rc = total.alloc(1)) != LVF_OK) return fail(rc);
+  GridP g{};
+  int ncells = 0;
+  for (int trial = 0; trial < 8; ++trial) {
+    dims_for(cell, dnx, dny, dnz);
+    m->nx = (int)dnx; m->ny = (int)dny; m->nz = (int)dnz;
+    m->cell = cell; m->inv_cell = 1.0f / cell; m->ox = lo[0]; m->oy = lo[1]; m->oz = lo[2];
+    ncells = m->nx * m->ny * m->nz;
+    g = GridP{m->ox, m->oy, m->oz, m->cell, m->inv_cell, m->nx, m->ny, m->nz};
+    if ((rc = counts.alloc(ncells)) != LVF_OK) return fail(rc);
+    LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)ncells * sizeof(int), s));
+    LVF_HIP(hipMemsetAsync(total.p, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_cell_count, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, g, cell_of.p, counts.p);
+    hipLaunchKernelGGL(k_count_nonempty, dim3((ncells + kB - 1) / kB), dim3(kB), 0, s, ncells, counts.p, total.p);
+    int nonempty = 0;
+    LVF_HIP(hipMemcpyAsync(&nonempty, total.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    LVF_HIP(hipStreamSynchronize(s));
+    const double occ = nonempty > 0 ? (double)M / nonempty : 0.0;
+    double tnx, tny, tnz;
+    if (occ <= kTargetOcc || dims_for(cell * 0.5f, tnx, tny, tnz) > kMaxCells) break;
+    cell *= 0.5f;
   }
-  m->cell = cell; m->inv_cell = 1.0f / cell; m->ox = lo[0]; m->oy = lo[1]; m->oz = lo[2];
-  const int ncells = m->nx * m->ny * m->nz;
-  const GridP g{m->ox, m->oy, m->oz, m->cell, m->inv_cell, m->nx, m->ny, m->nz};
   const int nb = (ncells + kScanChunk - 1) / kScanChunk;
-  if ((rc = cell_of.alloc(M)) != LVF_OK || (rc = counts.alloc(ncells)) != LVF_OK || (rc = cursor.alloc(ncells)) != LVF_OK ||
-      (rc = bsums.alloc(nb)) != LVF_OK || (rc = total.alloc(1)) != LVF_OK || (rc = m->cell_start.alloc((size_t)ncells + 1)) != LVF_OK)
+  if ((rc = cursor.alloc(ncells)) != LVF_OK || (rc = bsums.alloc(nb)) != LVF_OK || (rc = m->cell_start.alloc((size_t)ncells + 1)) != LVF_OK)
     return fail(rc);
-  LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)ncells * sizeof(int), s));
   LVF_HIP(hipMemsetAsync(cursor.p, 0, (size_t)ncells * sizeof(int), s));
-  hipLaunchKernelGGL(k_cell_count, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, g, cell_of.p, counts.p);
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, total.p);
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p, m->cell_start.p);

@@ -259,7 +259,7 @@ def config4_window(n_kf=50, n_lm=10000, n_prewindow=2000, seed=SEED_CFG4, imu_sa
 
 
 # ----------------------------------------------------------------------------- config 3 (lidar)
-def _raycast_scene(origin, R_wl, rng, boxes, n_rings=64, n_az=1563, ang_bottom=24.9, ang_res_y=0.427,
+def _raycast_scene(origin, R_wl, rng, boxes, n_rings=64, n_az=2900, ang_bottom=24.9, ang_res_y=0.427,
                    min_range=5.0, max_range=30.0, ground_z=-1.73, wall_y=8.0):
     """64-beam sweep against ground plane + two walls + axis-aligned boxes. Returns points in the
     LIDAR/body frame and a ground flag."""
@@ -285,9 +285,11 @@ def _raycast_scene(origin, R_wl, rng, boxes, n_rings=64, n_az=1563, ang_bottom=2
     return pts_l, is_ground[keep]
 
 
-def config3_icp(seed=SEED_CFG3, n_query=100000, noise=0.02):
+def config3_icp(seed=SEED_CFG3, n_query=100000, noise=0.02, n_az=2900):
     """Scan-to-map association inputs: query scan in the body frame, map = 3 previous scans merged in
-    world frame.  Float32 xyz + pad (16 B/pt)."""
+    world frame.  Float32 xyz + pad (16 B/pt).  The azimuth sampling (2900 steps x 64 rings)
+    is denser than kitti.yaml's horizon_scan so that, after the 5-30 m range gate, the query has the stated
+    100 000 points and the 3-scan map ~300 000."""
     rng = np.random.default_rng(seed)
     boxes = []
     for _ in range(40):
@@ -297,7 +299,7 @@ def config3_icp(seed=SEED_CFG3, n_query=100000, noise=0.02):
     poses = drive_poses(4, rng)
     clouds, grounds = [], []
     for i in range(4):
-        pl, g = _raycast_scene(poses[i, 4:], rotmat(poses[i, :4]), rng, boxes)
+        pl, g = _raycast_scene(poses[i, 4:], rotmat(poses[i, :4]), rng, boxes, n_az=n_az)
         pl = pl + rng.normal(0, noise, pl.shape)
         clouds.append(pl); grounds.append(g)
     map_w = np.concatenate([se3_apply(poses[i], clouds[i]) for i in range(3)])
