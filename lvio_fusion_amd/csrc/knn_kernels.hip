@@ -25,6 +25,7 @@
 namespace lvf {
 
 constexpr int kB = 256;
+constexpr int kMaxLevels = LVF_MAX_GRID_LEVELS;
 
 // round-to-nearest primitives defined UNDER the pragma above (the HIP header versions carry the `contract` flag)
 __device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
@@ -77,10 +78,14 @@ __global__ __launch_bounds__(kB) void k_cell_count(int M, const float4* __restri
   atomicAdd(counts + c, 1);
 }
 
-__global__ __launch_bounds__(kB) void k_count_nonempty(int n, const int* __restrict__ counts, int* __restrict__ total) {
+// sum over cells of count^2: (that sum / M) is the population of the cell a random map point lives in, i.e. the
+// candidates a query in a typical (point-weighted) place has to scan per cell.
+__global__ __launch_bounds__(kB) void k_cell_stats(int n, const int* __restrict__ counts, unsigned long long* __restrict__ sumsq) {
   const int i = blockIdx.x * kB + threadIdx.x;
-  const unsigned long long m = __ballot(i < n && counts[i] > 0);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(total, __popcll(m));
+  unsigned long long v = 0;
+  if (i < n) { const unsigned long long c = (unsigned long long)counts[i]; v = c * c; }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(sumsq, v);
 }
 
 // 3-phase exclusive scan over `n` ints, 1024 elements per workgroup
@@ -177,7 +182,7 @@ __device__ __forceinline__ float tf_row(const float* a, float p0, float p1, floa
 
 __device__ __forceinline__ bool lex_less(float da, int ia, float db, int ib) { return da < db || (da == db && (unsigned)ia < (unsigned)ib); }
 __device__ __forceinline__ void best3_push(float d, int i, float bd[3], int bi[3]) {
-  if (!lex_less(d, i, bd[2], bi[2])) return;
+  if (!lex_less(d, i, bd[2], bi[2]) || i == bi[0] || i == bi[1]) return;   // worse than 3rd, or already held
   if (lex_less(d, i, bd[1], bi[1])) {
     bd[2] = bd[1]; bi[2] = bi[1];
     if (lex_less(d, i, bd[0], bi[0])) { bd[1] = bd[0]; bi[1] = bi[0]; bd[0] = d; bi[0] = i; }
@@ -185,75 +190,222 @@ __device__ __forceinline__ void best3_push(float d, int i, float bd[3], int bi[3
   } else { bd[2] = d; bi[2] = i; }
 }
 
+struct KnnStats { int candidates, lookups, level, shells; };
+
+constexpr int kGroup = 8;   // lanes cooperating on one query (8 queries per wave64)
+
+// Candidates of one contiguous cell range.  Loads are issued four at a time so that four 16-B gathers are in flight
+// per lane (the loop is otherwise a chain of dependent L2/MALL round trips).
 __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, int lo, int hi, float qx, float qy, float qz,
-                                           float bd[3], int bi[3]) {
-  for (int j = lo; j < hi; ++j) {
-    const float4 m = sorted[j];
-    const float dx = sub_rn(qx, m.x), dy = sub_rn(qy, m.y), dz = sub_rn(qz, m.z);
-    const float d = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-    best3_push(d, __float_as_int(m.w), bd, bi);
+                                           float bd[3], int bi[3], KnnStats* st = nullptr) {
+  for (int j = lo; j < hi; j += 4) {
+    const int last = hi - 1;
+    const float4 m0 = sorted[j], m1 = sorted[min(j + 1, last)], m2 = sorted[min(j + 2, last)], m3 = sorted[min(j + 3, last)];
+    const float4 mm[4] = {m0, m1, m2, m3};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // a clamped duplicate of the last point is rejected by best3_push (same index)
+      const float dx = sub_rn(qx, mm[u].x), dy = sub_rn(qy, mm[u].y), dz = sub_rn(qz, mm[u].z);
+      const float d = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+      best3_push(d, __float_as_int(mm[u].w), bd, bi);
+    }
   }
 }
 
+// The whole group scans ONE long range: lane g takes candidates lo+g, lo+g+8, ... (coalesced 128-B rows), four
+// strides in flight per lane.  Used for ranges a single lane would take hundreds of dependent round trips to walk.
+__device__ __forceinline__ void scan_range_group(const float4* __restrict__ sorted, int lo, int hi, int g_lane, float qx,
+                                                 float qy, float qz, float bd[3], int bi[3]) {
+  for (int j = lo + g_lane; j < hi; j += 4 * kGroup) {
+    const int last = hi - 1;
+    const float4 mm[4] = {sorted[j], sorted[min(j + kGroup, last)], sorted[min(j + 2 * kGroup, last)], sorted[min(j + 3 * kGroup, last)]};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float dx = sub_rn(qx, mm[u].x), dy = sub_rn(qy, mm[u].y), dz = sub_rn(qz, mm[u].z);
+      const float d = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+      best3_push(d, __float_as_int(mm[u].w), bd, bi);
+    }
+  }
+}
+
+constexpr int kLongRange = 24;   // candidates; longer ranges are deferred to the cooperative scan
+
 struct TfArg { float v[7]; };
 
-__global__ __launch_bounds__(kB) void k_knn3(int Q, const float4* __restrict__ scan, const TfArg tfa,
-                                             const float4* __restrict__ sorted, const int* __restrict__ cell_start,
-                                             const GridP g, float thr, int* __restrict__ idx, float* __restrict__ d2,
-                                             uint8_t* __restrict__ valid) {
-  const int i = blockIdx.x * kB + threadIdx.x;
-  if (i >= Q) return;
+struct LevelP { const float4* sorted; const int* cell_start; GridP g; };
+struct LevelsP { LevelP l[kMaxLevels]; int n; };   // l[0] = finest ... l[n-1] = coarsest (cell >= gate radius / 2)
+
+// One cubic shell of cells around (cx,cy,cz); the (dz,dy) rows of the shell are dealt round-robin to the kGroup lanes
+// of the query's group (lane `g` takes rows g, g+kGroup, ...).  Returns the lower bound on the distance to any point
+// of THIS level's grid outside shells 0..r (INFINITY when the shells already cover the whole grid).
+__device__ __forceinline__ float scan_shell(const LevelP& L, int cx, int cy, int cz, int r, int g_lane, float qx, float qy,
+                                            float qz, float bd[3], int bi[3], KnnStats* st) {
+  const GridP& g = L.g;
+  const int side = 2 * r + 1;
+  // Pruning radius: the group's 3rd-best d2 as of the previous shell (all lanes hold the merged list).  A cell whose
+  // closest corner is farther than that cannot contribute (ties included: only strictly farther cells are skipped);
+  // gaps are shrunk by 1e-4 relative + 1e-6 cell to stay conservative against float cell-assignment rounding.
+  const float prune2 = bd[2];
+  const float slack = 1e-6f * g.cell;
+  const int lane_in_wave = threadIdx.x & 63;
+  const int group_shift = lane_in_wave & ~(kGroup - 1);
+  for (int it = 0; it * kGroup < side * side; ++it) {       // lock-step over the group: lane g owns row it*kGroup+g
+    const int row_id = it * kGroup + g_lane;
+    int la = 0, ha = 0, lb = 0, hb = 0;                    // up to two candidate ranges for this lane's row
+    if (row_id < side * side) {
+      const int dz = row_id / side - r, dy = row_id % side - r;
+      const int z = cz + dz, y = cy + dy;
+      if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+        float gy = 0.0f, gz = 0.0f;
+        if (y > cy) gy = (g.oy + (float)y * g.cell) - qy; else if (y < cy) gy = qy - (g.oy + (float)(y + 1) * g.cell);
+        if (z > cz) gz = (g.oz + (float)z * g.cell) - qz; else if (z < cz) gz = qz - (g.oz + (float)(z + 1) * g.cell);
+        gy = fmaxf(gy * 0.9999f - slack, 0.0f); gz = fmaxf(gz * 0.9999f - slack, 0.0f);
+        const float base2 = gy * gy + gz * gz;
+        if (!(base2 > prune2)) {
+          int xlo = 0, xhi = g.nx - 1;
+          if (prune2 < INFINITY) {
+            const float dxm = sqrtf(prune2 - base2) * 1.0001f + slack;
+            xlo = max(xlo, (int)floorf((qx - dxm - g.ox) * g.inv_cell - 1e-3f));
+            xhi = min(xhi, (int)floorf((qx + dxm - g.ox) * g.inv_cell + 1e-3f));
+          }
+          const int row = (z * g.ny + y) * g.nx;
+          if (abs(dz) == r || abs(dy) == r) {   // full x-run of the shell: one contiguous range
+            const int x0 = max(cx - r, xlo), x1 = min(cx + r, xhi);
+            if (x0 <= x1) { la = L.cell_start[row + x0]; ha = L.cell_start[row + x1 + 1]; }
+          } else {                              // interior row: only the two end caps
+            const int xa = cx - r, xb = cx + r;
+            if (xa >= xlo && xa <= xhi) { la = L.cell_start[row + xa]; ha = L.cell_start[row + xa + 1]; }
+            if (xb <= xhi && xb >= xlo) { lb = L.cell_start[row + xb]; hb = L.cell_start[row + xb + 1]; }
+          }
+        }
+      }
+    }
+    if (st) { st->lookups += (ha > la) + (hb > lb); st->candidates += (ha - la) + (hb - lb); }
+    const bool long_a = (ha - la) > kLongRange, long_b = (hb - lb) > kLongRange;
+    if (!long_a && ha > la) scan_range(L.sorted, la, ha, qx, qy, qz, bd, bi);
+    if (!long_b && hb > lb) scan_range(L.sorted, lb, hb, qx, qy, qz, bd, bi);
+    // long ranges: every lane of the group helps, one owner at a time
+    unsigned owners = (unsigned)((__ballot(long_a || long_b) >> group_shift) & ((1u << kGroup) - 1u));
+    while (owners) {
+      const int k = __ffs(owners) - 1;
+      owners &= owners - 1;
+      const int src = group_shift + k;
+      const int rla = __shfl(la, src), rha = __shfl(ha, src), rlb = __shfl(lb, src), rhb = __shfl(hb, src);
+      if (rha - rla > kLongRange) scan_range_group(L.sorted, rla, rha, g_lane, qx, qy, qz, bd, bi);
+      if (rhb - rlb > kLongRange) scan_range_group(L.sorted, rlb, rhb, g_lane, qx, qy, qz, bd, bi);
+    }
+  }
+  float m = INFINITY;
+  if (cx + r + 1 <= g.nx - 1) m = fminf(m, (g.ox + (float)(cx + r + 1) * g.cell) - qx);
+  if (cx - r - 1 >= 0) m = fminf(m, qx - (g.ox + (float)(cx - r) * g.cell));
+  if (cy + r + 1 <= g.ny - 1) m = fminf(m, (g.oy + (float)(cy + r + 1) * g.cell) - qy);
+  if (cy - r - 1 >= 0) m = fminf(m, qy - (g.oy + (float)(cy - r) * g.cell));
+  if (cz + r + 1 <= g.nz - 1) m = fminf(m, (g.oz + (float)(cz + r + 1) * g.cell) - qz);
+  if (cz - r - 1 >= 0) m = fminf(m, qz - (g.oz + (float)(cz - r) * g.cell));
+  return m;
+}
+
+// butterfly all-reduce of the per-lane best-3 lists inside each aligned kGroup-lane group; the (d2, index) order with
+// same-index rejection makes the merge commutative/associative, so every lane ends with the identical list.
+__device__ __forceinline__ void group_merge_best3(float bd[3], int bi[3]) {
+#pragma unroll
+  for (int mask = 1; mask < kGroup; mask <<= 1) {
+    float od[3]; int oi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { od[k] = __shfl_xor(bd[k], mask); oi[k] = __shfl_xor(bi[k], mask); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (oi[k] >= 0) best3_push(od[k], oi[k], bd, bi);
+  }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kB) void k_knn3(int Q, const float4* __restrict__ scan, const TfArg tfa, const LevelsP L,
+                                             float thr, int* __restrict__ idx, float* __restrict__ d2,
+                                             uint8_t* __restrict__ valid, KnnStats* __restrict__ stats) {
+  const int t = blockIdx.x * kB + threadIdx.x;
+  const int g_lane = t & (kGroup - 1);
+  const int i = min(t / kGroup, Q - 1);          // surplus groups of the last block shadow the last query (no divergent exit
+  const bool writer = (t / kGroup) < Q && g_lane == 0;   // before the shuffles)
   const Tf32 T = make_tf32(tfa.v);
   const float4 p = scan[i];
   const float qx = tf_row(T.a + 0, p.x, p.y, p.z, p.x, T.t[0]);
   const float qy = tf_row(T.a + 3, p.x, p.y, p.z, p.y, T.t[1]);
   const float qz = tf_row(T.a + 6, p.x, p.y, p.z, p.z, T.t[2]);
-  const int cx = cell_coord(qx, g.ox, g.inv_cell, g.nx), cy = cell_coord(qy, g.oy, g.inv_cell, g.ny), cz = cell_coord(qz, g.oz, g.inv_cell, g.nz);
   float bd[3] = {INFINITY, INFINITY, INFINITY};
   int bi[3] = {-1, -1, -1};
-  const int rmax = max(g.nx, max(g.ny, g.nz));
-  for (int r = 0; r <= rmax; ++r) {
-    for (int dz = -r; dz <= r; ++dz) {
-      const int z = cz + dz;
-      if (z < 0 || z >= g.nz) continue;
-      for (int dy = -r; dy <= r; ++dy) {
-        const int y = cy + dy;
-        if (y < 0 || y >= g.ny) continue;
-        const int row = (z * g.ny + y) * g.nx;
-        if (abs(dz) == r || abs(dy) == r) {   // full x-run of the shell: one contiguous range
-          const int x0 = max(cx - r, 0), x1 = min(cx + r, g.nx - 1);
-          if (x0 <= x1) scan_range(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, bd, bi);
-        } else {                              // interior row: only the two end caps
-          const int xa = cx - r, xb = cx + r;
-          if (xa >= 0) scan_range(sorted, cell_start[row + xa], cell_start[row + xa + 1], qx, qy, qz, bd, bi);
-          if (xb < g.nx) scan_range(sorted, cell_start[row + xb], cell_start[row + xb + 1], qx, qy, qz, bd, bi);
-        }
-      }
+  KnnStats st{0, 0, 0, 0};
+  KnnStats* stp = STATS ? &st : nullptr;
+  // fine -> coarse: two shells per level; dense neighbourhoods finish in the finest grid, sparse ones escalate to a
+  // grid whose cells are 4x larger instead of walking dozens of empty fine shells.  Re-visited points are rejected
+  // by best3_push (same index), so levels can overlap freely.
+  for (int lv = 0; lv < L.n; ++lv) {
+    const LevelP& lev = L.l[lv];
+    const GridP& g = lev.g;
+    const int cx = cell_coord(qx, g.ox, g.inv_cell, g.nx), cy = cell_coord(qy, g.oy, g.inv_cell, g.ny), cz = cell_coord(qz, g.oz, g.inv_cell, g.nz);
+    const int rcap = (lv == L.n - 1) ? max(g.nx, max(g.ny, g.nz)) : 2;
+    bool done = false;
+    for (int r = 0; r <= rcap; ++r) {
+      const float m = scan_shell(lev, cx, cy, cz, r, g_lane, qx, qy, qz, bd, bi, stp);
+      group_merge_best3(bd, bi);
+      if (STATS) { st.level = lv; st.shells += 1; }
+      if (!(m < INFINITY)) { done = true; break; }                   // every point of the map has been seen
+      const float ms = fmaxf(m, 0.0f) * 0.9999f - 1e-6f * g.cell;   // conservative against cell-assignment rounding
+      const float ms2 = ms > 0.0f ? ms * ms : 0.0f;
+      if (bd[2] < ms2 || ms2 >= thr) { done = true; break; }         // 3rd best beats anything unvisited / beyond the gate
     }
-    // lower bound on the distance to anything not yet visited
-    float m = INFINITY;
-    if (cx + r + 1 <= g.nx - 1) m = fminf(m, (g.ox + (float)(cx + r + 1) * g.cell) - qx);
-    if (cx - r - 1 >= 0) m = fminf(m, qx - (g.ox + (float)(cx - r) * g.cell));
-    if (cy + r + 1 <= g.ny - 1) m = fminf(m, (g.oy + (float)(cy + r + 1) * g.cell) - qy);
-    if (cy - r - 1 >= 0) m = fminf(m, qy - (g.oy + (float)(cy - r) * g.cell));
-    if (cz + r + 1 <= g.nz - 1) m = fminf(m, (g.oz + (float)(cz + r + 1) * g.cell) - qz);
-    if (cz - r - 1 >= 0) m = fminf(m, qz - (g.oz + (float)(cz - r) * g.cell));
-    if (!(m < INFINITY)) break;                       // every cell visited
-    const float ms = fmaxf(m, 0.0f) * 0.9999f - 1e-6f * g.cell;  // conservative against cell-assignment rounding
-    const float ms2 = ms > 0.0f ? ms * ms : 0.0f;
-    if (bd[2] < ms2) break;                           // 3rd best is closer than anything unvisited
-    if (ms2 >= thr) break;                            // nothing unvisited can pass the gate
+    if (done) break;
   }
-  idx[3 * i + 0] = bi[0]; idx[3 * i + 1] = bi[1]; idx[3 * i + 2] = bi[2];
-  d2[3 * i + 0] = bd[0]; d2[3 * i + 1] = bd[1]; d2[3 * i + 2] = bd[2];
-  valid[i] = (bi[0] >= 0 && bd[0] < thr && bi[1] >= 0 && bd[1] < thr && bi[2] >= 0 && bd[2] < thr) ? 1 : 0;
+  if (STATS) {
+#pragma unroll
+    for (int mask = 1; mask < kGroup; mask <<= 1) { st.candidates += __shfl_xor(st.candidates, mask); st.lookups += __shfl_xor(st.lookups, mask); }
+    if (writer) stats[i] = st;
+  }
+  if (writer) {
+    idx[3 * i + 0] = bi[0]; idx[3 * i + 1] = bi[1]; idx[3 * i + 2] = bi[2];
+    d2[3 * i + 0] = bd[0]; d2[3 * i + 1] = bd[1]; d2[3 * i + 2] = bd[2];
+    valid[i] = (bi[0] >= 0 && bd[0] < thr && bi[1] >= 0 && bd[1] < thr && bi[2] >= 0 && bd[2] < thr) ? 1 : 0;
+  }
 }
 
 }  // namespace lvf
 
 using namespace lvf;
 
+static inline int knn_grid(int Q) { return (int)(((long long)Q * kGroup + kB - 1) / kB); }
+
 extern "C" {
+
+// Builds one grid level (counting sort of the map by cell) into lv.  *occupancy = point-weighted mean cell population.
+static int build_level(lvf_map* m, lvf_map::Level& lv, float cell, const float lo[3], const float hi[3], double* occupancy) {
+  hipStream_t s = m->ctx->stream;
+  const int M = m->M;
+  lv.nx = (int)(std::floor((hi[0] - lo[0]) / cell) + 1); lv.ny = (int)(std::floor((hi[1] - lo[1]) / cell) + 1);
+  lv.nz = (int)(std::floor((hi[2] - lo[2]) / cell) + 1);
+  lv.cell = cell; lv.inv_cell = 1.0f / cell; lv.ox = lo[0]; lv.oy = lo[1]; lv.oz = lo[2];
+  const int ncells = lv.nx * lv.ny * lv.nz;
+  const GridP g{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz};
+  const int gridM = (M + kB - 1) / kB, nb = (ncells + kScanChunk - 1) / kScanChunk;
+  DevBuf<int> cell_of, counts, cursor, bsums, total;
+  DevBuf<unsigned long long> sumsq;
+  LVF_TRY(cell_of.alloc(M)); LVF_TRY(counts.alloc(ncells)); LVF_TRY(cursor.alloc(ncells)); LVF_TRY(bsums.alloc(nb));
+  LVF_TRY(total.alloc(2)); LVF_TRY(sumsq.alloc(1)); LVF_TRY(lv.cell_start.alloc((size_t)ncells + 1)); LVF_TRY(lv.sorted.alloc(M));
+  LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)ncells * sizeof(int), s));
+  LVF_HIP(hipMemsetAsync(cursor.p, 0, (size_t)ncells * sizeof(int), s));
+  LVF_HIP(hipMemsetAsync(total.p, 0, 2 * sizeof(int), s));
+  LVF_HIP(hipMemsetAsync(sumsq.p, 0, sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(k_cell_count, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, g, cell_of.p, counts.p);
+  hipLaunchKernelGGL(k_cell_stats, dim3((ncells + kB - 1) / kB), dim3(kB), 0, s, ncells, counts.p, sumsq.p);
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, total.p + 1);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p, lv.cell_start.p);
+  LVF_HIP(hipMemcpyAsync(lv.cell_start.p + ncells, total.p + 1, sizeof(int), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_cell_scatter, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, cell_of.p, lv.cell_start.p, cursor.p, lv.sorted.p);
+  LVF_HIP(hipGetLastError());
+  unsigned long long ss = 0;
+  LVF_HIP(hipMemcpyAsync(&ss, sumsq.p, sizeof(ss), hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));   // temporaries are freed on return
+  *occupancy = (double)ss / (double)M;
+  return LVF_OK;
+}
 
 int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats, float max_radius2, lvf_map** out) {
   LVF_REQUIRE(ctx && out, "lvf_map_create: null ctx/out");
@@ -265,20 +417,22 @@ int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats,
   m->ctx = ctx; m->M = M;
   auto fail = [&](int rc) { delete m; return rc; };
   int rc;
-  if (M == 0) {
-    if ((rc = m->cell_start.alloc(2)) != LVF_OK) return fail(rc);
-    LVF_HIP(hipMemsetAsync(m->cell_start.p, 0, 2 * sizeof(int), s));
-    m->cell = std::sqrt(max_radius2); m->inv_cell = 1.0f / m->cell;
+  if (M == 0) {   // an empty map: one 1-cell level with no points
+    auto& lv = m->levels[0];
+    if ((rc = lv.cell_start.alloc(2)) != LVF_OK) return fail(rc);
+    LVF_HIP(hipMemsetAsync(lv.cell_start.p, 0, 2 * sizeof(int), s));
+    LVF_HIP(hipStreamSynchronize(s));
+    lv.cell = std::sqrt(max_radius2); lv.inv_cell = 1.0f / lv.cell;
+    m->n_levels = 1;
     *out = m;
     return LVF_OK;
   }
-  DevBuf<float> src; DevBuf<unsigned> bounds; DevBuf<int> cell_of, counts, cursor, bsums, total;
+  DevBuf<float> src; DevBuf<unsigned> bounds;
   if ((rc = src.upload(map_xyz, (size_t)M * stride_floats, s)) != LVF_OK) return fail(rc);
-  if ((rc = m->raw.alloc(M)) != LVF_OK || (rc = m->sorted.alloc(M)) != LVF_OK || (rc = bounds.alloc(6)) != LVF_OK) return fail(rc);
+  if ((rc = m->raw.alloc(M)) != LVF_OK || (rc = bounds.alloc(6)) != LVF_OK) return fail(rc);
   const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   LVF_HIP(hipMemcpyAsync(bounds.p, init, sizeof(init), hipMemcpyHostToDevice, s));
-  const int gridM = (M + kB - 1) / kB;
-  hipLaunchKernelGGL(k_pack_bounds, dim3(gridM), dim3(kB), 0, s, M, src.p, stride_floats, m->raw.p, bounds.p);
+  hipLaunchKernelGGL(k_pack_bounds, dim3((M + kB - 1) / kB), dim3(kB), 0, s, M, src.p, stride_floats, m->raw.p, bounds.p);
   unsigned hb[6];
   LVF_HIP(hipMemcpyAsync(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost, s));
   LVF_HIP(hipStreamSynchronize(s));
@@ -286,51 +440,27 @@ int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats,
   for (int k = 0; k < 3; ++k) { lo[k] = ord2f(hb[k]); hi[k] = ord2f(hb[3 + k]); }
   for (int k = 0; k < 3; ++k)
     if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) { set_error("lvf_map_create: non-finite map coordinates"); return fail(LVF_ERR_INVALID); }
-  // Cell edge: start at gate radius / 2 and HALVE while the mean occupancy of non-empty cells stays above
-  // kTargetOcc (lidar clouds are surfaces: a coarse cell holds hundreds of points and every query would scan
-  // thousands of candidates; ~4-8 points per occupied cell keeps the first shells at ~100 candidates).
-  const double kMaxCells = 4.0 * 1024 * 1024;
-  const double kTargetOcc = 6.0;
-  auto dims_for = [&](float c, double& nx, double& ny, double& nz) {
-    nx = std::floor((hi[0] - lo[0]) / c) + 1; ny = std::floor((hi[1] - lo[1]) / c) + 1; nz = std::floor((hi[2] - lo[2]) / c) + 1;
-    return nx * ny * nz;
+  // Grid pyramid.  Coarsest level: cell = gate radius / 2, so its first two shells cover the whole gate.  Each finer
+  // level divides the cell by 4 and is added while the POINT-WEIGHTED cell population (sum count^2 / M) is above
+  // kTargetOcc: lidar density varies by 100x between 5 m and 30 m range, so the plain mean over cells is dominated by
+  // the sparse far field while most queries sit in the dense near field.
+  const double kMaxCells = 32.0 * 1024 * 1024, kTargetOcc = 12.0;
+  auto ncells_for = [&](float c) {
+    return (std::floor((hi[0] - lo[0]) / c) + 1) * (std::floor((hi[1] - lo[1]) / c) + 1) * (std::floor((hi[2] - lo[2]) / c) + 1);
   };
   float cell = std::sqrt(max_radius2) * 0.5f;
-  double dnx, dny, dnz;
-  while (dims_for(cell, dnx, dny, dnz) > kMaxCells) cell *= 1.25f;
-  if ((rc = cell_of.alloc(M)) != LVF_OK || (rc = total.alloc(1)) != LVF_OK) return fail(rc);
-  GridP g{};
-  int ncells = 0;
-  for (int trial = 0; trial < 8; ++trial) {
-    dims_for(cell, dnx, dny, dnz);
-    m->nx = (int)dnx; m->ny = (int)dny; m->nz = (int)dnz;
-    m->cell = cell; m->inv_cell = 1.0f / cell; m->ox = lo[0]; m->oy = lo[1]; m->oz = lo[2];
-    ncells = m->nx * m->ny * m->nz;
-    g = GridP{m->ox, m->oy, m->oz, m->cell, m->inv_cell, m->nx, m->ny, m->nz};
-    if ((rc = counts.alloc(ncells)) != LVF_OK) return fail(rc);
-    LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)ncells * sizeof(int), s));
-    LVF_HIP(hipMemsetAsync(total.p, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_cell_count, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, g, cell_of.p, counts.p);
-    hipLaunchKernelGGL(k_count_nonempty, dim3((ncells + kB - 1) / kB), dim3(kB), 0, s, ncells, counts.p, total.p);
-    int nonempty = 0;
-    LVF_HIP(hipMemcpyAsync(&nonempty, total.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    LVF_HIP(hipStreamSynchronize(s));
-    const double occ = nonempty > 0 ? (double)M / nonempty : 0.0;
-    double tnx, tny, tnz;
-    if (occ <= kTargetOcc || dims_for(cell * 0.5f, tnx, tny, tnz) > kMaxCells) break;
-    cell *= 0.5f;
+  while (ncells_for(cell) > kMaxCells) cell *= 1.25f;
+  lvf_map::Level built[LVF_MAX_GRID_LEVELS];
+  int nb = 0;
+  for (;;) {
+    double occ = 0.0;
+    if ((rc = build_level(m, built[nb], cell, lo, hi, &occ)) != LVF_OK) return fail(rc);
+    ++nb;
+    if (occ <= kTargetOcc || nb == LVF_MAX_GRID_LEVELS || ncells_for(cell * 0.25f) > kMaxCells) break;
+    cell *= 0.25f;
   }
-  const int nb = (ncells + kScanChunk - 1) / kScanChunk;
-  if ((rc = cursor.alloc(ncells)) != LVF_OK || (rc = bsums.alloc(nb)) != LVF_OK || (rc = m->cell_start.alloc((size_t)ncells + 1)) != LVF_OK)
-    return fail(rc);
-  LVF_HIP(hipMemsetAsync(cursor.p, 0, (size_t)ncells * sizeof(int), s));
-  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, total.p);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p, m->cell_start.p);
-  LVF_HIP(hipMemcpyAsync(m->cell_start.p + ncells, total.p, sizeof(int), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(k_cell_scatter, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, cell_of.p, m->cell_start.p, cursor.p, m->sorted.p);
-  LVF_HIP(hipGetLastError());
-  LVF_HIP(hipStreamSynchronize(s));   // temporaries are freed on return
+  m->n_levels = nb;
+  for (int k = 0; k < nb; ++k) m->levels[k] = std::move(built[nb - 1 - k]);   // finest first
   *out = m;
   return LVF_OK;
 }
@@ -360,6 +490,33 @@ int lvf_scan_create(lvf_ctx* ctx, const float* scan_xyz, int Q, int stride_float
 
 int lvf_scan_destroy(lvf_scan* s) { delete s; return LVF_OK; }
 
+// diagnostic (not part of the reference surface): per-query search statistics {candidates, range lookups, last level,
+// shells}, and the grid pyramid geometry {cell, nx, ny, nz} per level.
+int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* sc, const double* pose, float thr, int32_t* stats4, float* levels4, int* n_levels) {
+  LVF_REQUIRE(m && sc && pose && stats4, "lvf_knn3_debug_stats: null argument");
+  LVF_HIP(hipSetDevice(m->ctx->device));
+  if (n_levels) *n_levels = m->n_levels;
+  if (levels4) for (int k = 0; k < m->n_levels; ++k) { levels4[4 * k] = m->levels[k].cell; levels4[4 * k + 1] = (float)m->levels[k].nx; levels4[4 * k + 2] = (float)m->levels[k].ny; levels4[4 * k + 3] = (float)m->levels[k].nz; }
+  if (sc->Q == 0) return LVF_OK;
+  DevBuf<KnnStats> st;
+  LVF_TRY(st.alloc(sc->Q));
+  TfArg tf;
+  for (int k = 0; k < 7; ++k) tf.v[k] = (float)pose[k];
+  LevelsP L;
+  L.n = m->n_levels;
+  for (int k = 0; k < m->n_levels; ++k) {
+    const auto& lv = m->levels[k];
+    L.l[k] = LevelP{lv.sorted.p, lv.cell_start.p, GridP{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz}};
+  }
+  hipLaunchKernelGGL(k_knn3<true>, dim3(knn_grid(sc->Q)), dim3(kB), 0, m->ctx->stream, sc->Q, sc->pts.p, tf, L, thr,
+                     sc->idx.p, sc->d2.p, sc->valid.p, st.p);
+  LVF_HIP(hipGetLastError());
+  LVF_HIP(hipMemcpyAsync(stats4, st.p, (size_t)sc->Q * sizeof(KnnStats), hipMemcpyDeviceToHost, m->ctx->stream));
+  LVF_HIP(hipStreamSynchronize(m->ctx->stream));
+  sc->searched = true;
+  return LVF_OK;
+}
+
 int lvf_knn3(lvf_map* m, lvf_scan* sc, const double* pose, float thr) {
   LVF_REQUIRE(m && sc && pose, "lvf_knn3: null argument");
   LVF_REQUIRE(m->ctx == sc->ctx, "lvf_knn3: map and scan belong to different contexts");
@@ -368,9 +525,14 @@ int lvf_knn3(lvf_map* m, lvf_scan* sc, const double* pose, float thr) {
   if (sc->Q > 0) {
     TfArg tf;
     for (int k = 0; k < 7; ++k) tf.v[k] = (float)pose[k];   // Sophus SE3d::cast<float>()  association.cpp:287
-    const GridP g{m->ox, m->oy, m->oz, m->cell, m->inv_cell, m->nx, m->ny, m->nz};
-    hipLaunchKernelGGL(k_knn3, dim3((sc->Q + kB - 1) / kB), dim3(kB), 0, m->ctx->stream, sc->Q, sc->pts.p, tf, m->sorted.p,
-                       m->cell_start.p, g, thr, sc->idx.p, sc->d2.p, sc->valid.p);
+    LevelsP L;
+    L.n = m->n_levels;
+    for (int k = 0; k < m->n_levels; ++k) {
+      const auto& lv = m->levels[k];
+      L.l[k] = LevelP{lv.sorted.p, lv.cell_start.p, GridP{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz}};
+    }
+    hipLaunchKernelGGL(k_knn3<false>, dim3(knn_grid(sc->Q)), dim3(kB), 0, m->ctx->stream, sc->Q, sc->pts.p, tf, L, thr,
+                       sc->idx.p, sc->d2.p, sc->valid.p, (KnnStats*)nullptr);
     LVF_HIP(hipGetLastError());
   }
   sc->searched = true;

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/lvf.h"
@@ -100,14 +101,27 @@ struct lvf_batch {
   lvf::DevBuf<double> jac[8];
 };
 
+#define LVF_MAX_GRID_LEVELS 4
 struct lvf_map {
+  struct Level {
+    lvf::DevBuf<float4> sorted;      // cell-sorted points, .w = bitcast original index
+    lvf::DevBuf<int> cell_start;     // ncells + 1
+    float ox = 0, oy = 0, oz = 0, cell = 1, inv_cell = 1;
+    int nx = 1, ny = 1, nz = 1;
+    Level() = default;
+    Level(Level&& o) noexcept { *this = std::move(o); }
+    Level& operator=(Level&& o) noexcept {
+      std::swap(sorted.p, o.sorted.p); std::swap(sorted.n, o.sorted.n);
+      std::swap(cell_start.p, o.cell_start.p); std::swap(cell_start.n, o.cell_start.n);
+      ox = o.ox; oy = o.oy; oz = o.oz; cell = o.cell; inv_cell = o.inv_cell; nx = o.nx; ny = o.ny; nz = o.nz;
+      return *this;
+    }
+  };
   lvf_ctx* ctx = nullptr;
   int M = 0;
-  lvf::DevBuf<float4> sorted;        // cell-sorted points, .w = bitcast original index
-  lvf::DevBuf<float4> raw;           // original order (x,y,z,·) — gather source for plane fitting
-  lvf::DevBuf<int> cell_start;       // ncells + 1
-  float ox = 0, oy = 0, oz = 0, cell = 1, inv_cell = 1;
-  int nx = 1, ny = 1, nz = 1;
+  lvf::DevBuf<float4> raw;           // original order (x,y,z,.) — gather source for plane fitting
+  int n_levels = 0;
+  Level levels[LVF_MAX_GRID_LEVELS]; // [0] = finest ... [n_levels-1] = coarsest (cell = gate radius / 2)
 };
 
 struct lvf_scan {
