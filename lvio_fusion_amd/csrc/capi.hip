@@ -253,6 +253,7 @@ int lvf_imu_create(lvf_ctx* ctx, int n, const lvf_preint* pre, const int32_t* kf
   LVF_REQUIRE(n == 0 || (pre && kf_i && kf_j), "lvf_imu_create: null input array");
   static_assert(sizeof(lvf_preint) == 467 * sizeof(double), "lvf_preint must be 467 packed doubles");
   LVF_TRY(check_idx(kf_i, n, "kf_i")); LVF_TRY(check_idx(kf_j, n, "kf_j"));
+  for (int f = 0; f < n; ++f) LVF_REQUIRE(kf_i[f] != kf_j[f], "lvf_imu_create: factor %d links keyframe %d to itself", f, kf_i[f]);
   LVF_HIP(hipSetDevice(ctx->device));
   lvf_batch* b = new_batch(ctx, LVF_K_IMU, n, 15, {7, 3, 3, 3, 7, 3, 3, 3});
   hipStream_t s = ctx->stream;

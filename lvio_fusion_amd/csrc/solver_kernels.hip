@@ -1,0 +1,795 @@
+// solver_kernels.hip — the sliding-window BA problem on device: fused robustified linearisation, Schur
+// elimination of the 1x1 inverse-depth blocks (MFMA f64), dense Cholesky of the reduced camera system, step
+// evaluation.  Replaces what ceres::Solve does under adapt::Solve for Backend::Optimize
+// (src/lvio_fusion/include/lvio_fusion/adapt/problem.h:83-88; src/lvio_fusion/src/backend.cpp:96-183, 206-211).
+//
+// Unknown ordering (reduced system, d = 15 n_kf):  [ pose tangent 6 x n_kf | (v, ba, bg) 9 x n_kf ].
+// H = [B E^T; E C], C diagonal (one inverse depth per landmark).  LM step: (H + D^2/radius) dx = -g with
+// D^2 = clamp(diag H, 1e-6, 1e32).  S = B + Dc - E^T diag(1/(C + Dl)) E touches only the pose-pose corner, so E is
+// kept dense [n_lm x ldE] (ldE = 6 n_kf rounded up to 16, +1 column carrying g_rho) and the rank-n_lm update is one
+// v_mfma_f64_16x16x4_f64 SYRK ("MFMA only for the dense Schur reduce").  The right-hand side rides along as an
+// augmented ROW of S (index d), so the forward substitution comes out of the Cholesky for free.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "factor_eval.hpp"
+#include "lvf_internal.hpp"
+
+struct lvf_problem {
+  lvf_ctx* ctx = nullptr;
+  lvf_state* st = nullptr;
+  lvf_batch *tc = nullptr, *tf = nullptr, *po = nullptr, *imu = nullptr;
+  int n_kf = 0, n_lm = 0, d = 0, dp = 0, ldE = 0, dpad = 0, nb = 0;
+  lvf::DevBuf<double> B, gc, C, gr, E, Cd, S, dxc, dxl, scal;
+  lvf::DevBuf<double> poses2, vel2, ba2, bg2, invd2;   // candidate state x + dx
+  lvf::DevBuf<uint8_t> pose_const;
+  lvf::DevBuf<int> fail;
+  std::vector<uint8_t> pose_const_h;
+  bool linearized = false;
+  double last_radius = 0;
+};
+
+namespace lvf {
+
+constexpr int kT = 256;
+// device scalar slots
+enum { SC_COST = 0, SC_COST_NEW = 1, SC_MODEL = 2, SC_DXNORM = 3, SC_XNORM = 4, SC_GMAX = 5, SC_N = 8 };
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+__device__ __forceinline__ void block_add(double v, double* dst) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst, v);
+}
+
+struct StateP { const double *poses, *vel, *ba, *bg, *inv_depth, *w_kf; };
+
+// lower-triangle accumulation of a 6x6 block pair J_a^T J_b into B at (ra, rb) block offsets (ra >= rb required
+// for off-diagonal; for ra == rb only the lower half is written)
+__device__ __forceinline__ void add_block66(double* __restrict__ B, int ld, int ra, int rb, const double Ja[12], const double Jb[12]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (ra == rb && j > i) continue;
+      atomicAdd(&B[(size_t)(ra + i) * ld + rb + j], Ja[i] * Jb[j] + Ja[6 + i] * Jb[6 + j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ TwoCamera
+template <bool COST_ONLY>
+__global__ __launch_bounds__(kT) void k_lin_tc(int n, const double2* __restrict__ lo, const double2* __restrict__ ro,
+                                               const int* __restrict__ lm, const int* __restrict__ kf, StateP s,
+                                               CamD left, CamD right, double huber, double* __restrict__ C,
+                                               double* __restrict__ gr, double* __restrict__ cost) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  double c = 0.0;
+  if (i < n) {
+    const int l = lm[i];
+    const double2 a = lo[i], b = ro[i];
+    double r[2], J[2];
+    eval_two_camera<!COST_ONLY>(left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], 5.0 * s.w_kf[kf[i]], r, J);
+    double rho;
+    const double sc = robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
+    c = 0.5 * rho;
+    if (!COST_ONLY) {
+      const double s2 = sc * sc;
+      atomicAdd(&C[l], s2 * (J[0] * J[0] + J[1] * J[1]));
+      atomicAdd(&gr[l], s2 * (J[0] * r[0] + J[1] * r[1]));
+    }
+  }
+  block_add(c, cost);
+}
+
+// ------------------------------------------------------------------------------------------------ TwoFrame
+template <bool COST_ONLY>
+__global__ __launch_bounds__(kT) void k_lin_tf(int n, int n_kf, const double2* __restrict__ fo, const double2* __restrict__ ob,
+                                               const int* __restrict__ lm, const int* __restrict__ kf1,
+                                               const int* __restrict__ kf2, StateP s, CamD left, CamD right, double huber,
+                                               const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
+                                               double* __restrict__ gc, double* __restrict__ E, int ldE,
+                                               double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost) {
+  __shared__ PoseD s_pose[kMaxStagedKf];
+  stage_poses<kT>(s_pose, s.poses, n_kf);
+  const int i = blockIdx.x * kT + threadIdx.x;
+  double c = 0.0;
+  if (i < n) {
+    const int l = lm[i], k1 = kf1[i], k2 = kf2[i];
+    const double2 a = fo[i], b = ob[i];
+    const PoseD P1 = fetch_pose(s_pose, s.poses, n_kf, k1), P2 = fetch_pose(s_pose, s.poses, n_kf, k2);
+    double r[2], Jd[2], J1[14], J2[14];
+    eval_two_frame<!COST_ONLY>(P1, P2, left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], s.w_kf[k2], r, Jd, J1, J2);
+    double rho;
+    const double sc = robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
+    c = 0.5 * rho;
+    if (!COST_ONLY) {
+      double L1[12], L2[12];
+      pose_rows_to_local(J1, s.poses + 7 * k1, pose_const[k1] ? 0.0 : sc, L1);
+      pose_rows_to_local(J2, s.poses + 7 * k2, pose_const[k2] ? 0.0 : sc, L2);
+      const double r0 = sc * r[0], r1 = sc * r[1], d0 = sc * Jd[0], d1 = sc * Jd[1];
+      atomicAdd(&C[l], d0 * d0 + d1 * d1);
+      atomicAdd(&gr[l], d0 * r0 + d1 * r1);
+      if (k1 == k2) {   // degenerate: both pose blocks are the same parameter
+#pragma unroll
+        for (int q = 0; q < 12; ++q) L1[q] += L2[q];
+        add_block66(B, ld, 6 * k1, 6 * k1, L1, L1);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { atomicAdd(&gc[6 * k1 + q], L1[q] * r0 + L1[6 + q] * r1); atomicAdd(&E[(size_t)l * ldE + 6 * k1 + q], L1[q] * d0 + L1[6 + q] * d1); }
+      } else {
+        add_block66(B, ld, 6 * k1, 6 * k1, L1, L1);
+        add_block66(B, ld, 6 * k2, 6 * k2, L2, L2);
+        if (k2 > k1) add_block66(B, ld, 6 * k2, 6 * k1, L2, L1); else add_block66(B, ld, 6 * k1, 6 * k2, L1, L2);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          atomicAdd(&gc[6 * k1 + q], L1[q] * r0 + L1[6 + q] * r1);
+          atomicAdd(&gc[6 * k2 + q], L2[q] * r0 + L2[6 + q] * r1);
+          atomicAdd(&E[(size_t)l * ldE + 6 * k1 + q], L1[q] * d0 + L1[6 + q] * d1);
+          atomicAdd(&E[(size_t)l * ldE + 6 * k2 + q], L2[q] * d0 + L2[6 + q] * d1);
+        }
+      }
+    }
+  }
+  block_add(c, cost);
+}
+
+// ------------------------------------------------------------------------------------------------ PoseOnly
+template <bool COST_ONLY>
+__global__ __launch_bounds__(kT) void k_lin_po(int n, int n_kf, const double2* __restrict__ ob, const int* __restrict__ kf,
+                                               const int* __restrict__ pwi, const double* __restrict__ pw, StateP s, CamD cam,
+                                               double huber, const uint8_t* __restrict__ pose_const, double* __restrict__ B,
+                                               int ld, double* __restrict__ gc, double* __restrict__ cost) {
+  __shared__ PoseD s_pose[kMaxStagedKf];
+  stage_poses<kT>(s_pose, s.poses, n_kf);
+  const int i = blockIdx.x * kT + threadIdx.x;
+  double c = 0.0;
+  int k = -1;
+  double v[27];
+#pragma unroll
+  for (int q = 0; q < 27; ++q) v[q] = 0.0;
+  if (i < n) {
+    k = kf[i];
+    const int l = pwi[i];
+    const double2 o = ob[i];
+    const PoseD P = fetch_pose(s_pose, s.poses, n_kf, k);
+    const double pwl[3] = {pw[3 * l], pw[3 * l + 1], pw[3 * l + 2]};
+    double r[2], J[14];
+    eval_pose_only<!COST_ONLY>(P, cam, o.x, o.y, pwl, s.w_kf[k], r, J);
+    double rho;
+    const double sc = robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
+    c = 0.5 * rho;
+    if (!COST_ONLY) {
+      double Lc[12];
+      pose_rows_to_local(J, s.poses + 7 * k, pose_const[k] ? 0.0 : sc, Lc);
+      const double r0 = sc * r[0], r1 = sc * r[1];
+      int q = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) v[q++] = Lc[a] * Lc[b] + Lc[6 + a] * Lc[6 + b];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) v[21 + a] = Lc[a] * r0 + Lc[6 + a] * r1;
+    }
+  }
+  if (!COST_ONLY) {
+    // blocks are normally sorted by keyframe: when the whole wave shares one pose block, reduce the 21+6 sums with
+    // wave shuffles and issue ONE set of atomics per wave (the per-pose-block JtJ/Jtr reduction of the north star)
+    const int k0 = __shfl(k, 0);
+    const bool uniform = __all(k == k0) && k0 >= 0;
+    if (uniform) {
+#pragma unroll
+      for (int q = 0; q < 27; ++q) v[q] = wave_sum(v[q]);
+      if ((threadIdx.x & 63) == 0) {
+        int q = 0;
+        for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) atomicAdd(&B[(size_t)(6 * k0 + a) * ld + 6 * k0 + b], v[q++]);
+        for (int a = 0; a < 6; ++a) atomicAdd(&gc[6 * k0 + a], v[21 + a]);
+      }
+    } else if (k >= 0) {
+      int q = 0;
+      for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) atomicAdd(&B[(size_t)(6 * k + a) * ld + 6 * k + b], v[q++]);
+      for (int a = 0; a < 6; ++a) atomicAdd(&gc[6 * k + a], v[21 + a]);
+    }
+  }
+  block_add(c, cost);
+}
+
+// ------------------------------------------------------------------------------------------------ IMU
+// consumes the materialised ImuError outputs (res[n][15], eight Jacobian blocks) of launch_imu; one wave per factor
+struct ImuJ { const double* j[8]; };
+__global__ __launch_bounds__(64) void k_lin_imu(int n, int n_kf, const double* __restrict__ res, ImuJ J, const int* __restrict__ kf_i,
+                                                const int* __restrict__ kf_j, const double* __restrict__ poses,
+                                                const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
+                                                double* __restrict__ gc, double* __restrict__ cost) {
+  __shared__ double sJ[15 * 30];   // local Jacobian: [pose_i 6 | vbb_i 9 | pose_j 6 | vbb_j 9]
+  __shared__ double sr[15];
+  __shared__ int sidx[30];
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const int ki = kf_i[f], kj = kf_j[f];
+  if (lane < 15) sr[lane] = res[(size_t)f * 15 + lane];
+  if (lane < 30) {
+    int g;
+    if (lane < 6) g = 6 * ki + lane; else if (lane < 15) g = 6 * n_kf + 9 * ki + (lane - 6);
+    else if (lane < 21) g = 6 * kj + (lane - 15); else g = 6 * n_kf + 9 * kj + (lane - 21);
+    sidx[lane] = g;
+  }
+  // pose blocks: 15 rows x (7 -> 6)
+  for (int e = lane; e < 30; e += 64) {
+    const int row = e % 15, which = e / 15;            // which: 0 = pose_i, 1 = pose_j
+    const double* Jr = J.j[which ? 4 : 0] + (size_t)f * 105 + 7 * row;
+    const int kk = which ? kj : ki;
+    const double* q = poses + 7 * kk;
+    const double sc = pose_const[kk] ? 0.0 : 1.0;
+    double l3[3];
+    quat_row_to_local(Jr, q, l3);
+    double* o = sJ + row * 30 + (which ? 15 : 0);
+    o[0] = sc * l3[0]; o[1] = sc * l3[1]; o[2] = sc * l3[2]; o[3] = sc * Jr[4]; o[4] = sc * Jr[5]; o[5] = sc * Jr[6];
+  }
+  for (int e = lane; e < 15 * 18; e += 64) {           // six 15x3 blocks
+    const int row = e / 18, c = e % 18, blk = c / 3, cc = c % 3;   // blk 0..2 -> (v,ba,bg)_i ; 3..5 -> _j
+    const int src = blk < 3 ? 1 + blk : 5 + (blk - 3);
+    sJ[row * 30 + (blk < 3 ? 6 + 3 * blk : 21 + 3 * (blk - 3)) + cc] = J.j[src][(size_t)f * 45 + 3 * row + cc];
+  }
+  __syncthreads();
+  double c = 0.0;
+  if (lane < 15) c = 0.5 * sr[lane] * sr[lane];
+  c = wave_sum(c);
+  if (lane == 0) atomicAdd(cost, c);
+  for (int e = lane; e < 30 * 30; e += 64) {
+    const int a = e / 30, b = e % 30;
+    const int ga = sidx[a], gb = sidx[b];
+    if (gb > ga || (ga == gb && a != b)) continue;    // lower triangle in GLOBAL indices (kf_i != kf_j is validated)
+    double h = 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) h += sJ[k * 30 + a] * sJ[k * 30 + b];
+    atomicAdd(&B[(size_t)ga * ld + gb], h);
+  }
+  if (lane < 30) {
+    double g = 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) g += sJ[k * 30 + lane] * sr[k];
+    atomicAdd(&gc[sidx[lane]], g);
+  }
+}
+__global__ __launch_bounds__(kT) void k_cost_imu(int n15, const double* __restrict__ res, double* __restrict__ cost) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  double c = 0.0;
+  if (i < n15) { const double r = res[i]; c = 0.5 * r * r; }
+  block_add(c, cost);
+}
+
+// ------------------------------------------------------------------------------------------------ damping / assembly
+__device__ __forceinline__ double clamp_diag(double v) { return fmin(fmax(v, 1e-6), 1e32); }
+
+// S (lower) = B (lower) + Dc on the diagonal; augmented row d = -gc ; padding rows = identity.
+__global__ __launch_bounds__(kT) void k_prepare_S(int d, int dpad, const double* __restrict__ B, const double* __restrict__ gc,
+                                                  double inv_radius, double* __restrict__ S) {
+  const size_t e = (size_t)blockIdx.x * kT + threadIdx.x;
+  if (e >= (size_t)dpad * dpad) return;
+  const int i = (int)(e / dpad), j = (int)(e % dpad);
+  double v = 0.0;
+  if (i < d && j < d) {
+    if (j <= i) { v = B[e]; if (i == j) v += clamp_diag(v) * inv_radius; }
+  } else if (i == d) {
+    v = (j < d) ? -gc[j] : (j == d ? 1e300 : 0.0);   // huge corner keeps the augmented matrix positive definite
+  } else if (i > d && i == j) {
+    v = 1.0;
+  }
+  S[e] = v;
+}
+// Cd = C + clamp(C)/radius ; E[l][dp] = gr[l] (the extra column that makes the SYRK also produce E^T Cd^-1 g_rho)
+__global__ __launch_bounds__(kT) void k_prepare_lm(int n_lm, int dp, int ldE, const double* __restrict__ C, const double* __restrict__ gr,
+                                                   double inv_radius, double* __restrict__ Cd, double* __restrict__ E) {
+  const int l = blockIdx.x * kT + threadIdx.x;
+  if (l >= n_lm) return;
+  const double c = C[l];
+  Cd[l] = c + clamp_diag(c) * inv_radius;
+  E[(size_t)l * ldE + dp] = gr[l];
+}
+
+// ------------------------------------------------------------------------------------------------ Schur reduce (MFMA f64)
+// T = Ea^T diag(1/Cd) Ea with Ea = [E | g_rho] (n_lm x ldE).  One wave per (16x16 output tile, K-chunk); tiles on or
+// below the diagonal only.  v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// D: col = lane&15, row = (lane>>4) + 4*reg.   S[i][j] -= T[i][j] (i,j < dp);  S[d][i] += T[dp][i].
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int kSchurChunk = 512;
+__global__ __launch_bounds__(64) void k_schur_syrk(int n_lm, int dp, int ldE, int ntile, const double* __restrict__ E,
+                                                   const double* __restrict__ Cd, int d, int ldS, double* __restrict__ S) {
+  // decode lower-triangular tile index
+  int t = blockIdx.x, ti = 0;
+  while (t >= ti + 1) { t -= ti + 1; ++ti; }
+  const int tj = t;
+  const int lane = threadIdx.x, lk = lane >> 4, lc = lane & 15;
+  const int k_begin = blockIdx.y * kSchurChunk, k_end = min(n_lm, k_begin + kSchurChunk);
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = k_begin; k0 < k_end; k0 += 4) {
+    const int l = k0 + lk;
+    double a = 0.0, b = 0.0;
+    if (l < k_end) {
+      const double* row = E + (size_t)l * ldE;
+      a = row[ti * 16 + lc] / Cd[l];
+      b = row[tj * 16 + lc];
+    }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gi = ti * 16 + lk + 4 * r, gj = tj * 16 + lc;
+    const double v = acc[r];
+    if (v == 0.0) continue;
+    if (gi < dp && gj < dp) { if (gj <= gi) atomicAdd(&S[(size_t)gi * ldS + gj], -v); }
+    else if (gi == dp && gj < dp) atomicAdd(&S[(size_t)d * ldS + gj], v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ blocked Cholesky (64)
+constexpr int kNB = 64, kLd = 65;
+// factor the diagonal block kb in place (one wave; right-looking in LDS)
+__global__ __launch_bounds__(64) void k_chol_diag(double* __restrict__ S, int ld, int kb, int* __restrict__ fail) {
+  __shared__ double T[kNB * kLd];
+  const int lane = threadIdx.x;
+  double* blk = S + (size_t)(kb * kNB) * ld + kb * kNB;
+  for (int r = 0; r < kNB; ++r) T[r * kLd + lane] = (lane <= r) ? blk[(size_t)r * ld + lane] : 0.0;
+  __syncthreads();
+  for (int j = 0; j < kNB; ++j) {
+    const double djj = T[j * kLd + j];
+    if (!(djj > 0.0)) { if (lane == 0) atomicExch(fail, 1 + kb * kNB + j); }
+    const double l = sqrt(fmax(djj, 1e-300));
+    double cij = 0.0;
+    if (lane > j) { cij = T[lane * kLd + j] / l; T[lane * kLd + j] = cij; }
+    if (lane == j) T[j * kLd + j] = l;
+    __syncthreads();
+    for (int t = j + 1; t < kNB; ++t) {
+      const double ctj = T[t * kLd + j];            // broadcast
+      if (lane >= t) T[lane * kLd + t] -= cij * ctj;
+    }
+    __syncthreads();
+  }
+  for (int r = 0; r < kNB; ++r) if (lane <= r) blk[(size_t)r * ld + lane] = T[r * kLd + lane];
+}
+// panel: rows below the diagonal block: X = A L_kk^-T, one thread per row (left-looking forward substitution)
+__global__ __launch_bounds__(64) void k_chol_panel(double* __restrict__ S, int ld, int kb) {
+  __shared__ double Lk[kNB * kLd];
+  __shared__ double X[kNB * kLd];
+  const int lane = threadIdx.x;
+  const double* dblk = S + (size_t)(kb * kNB) * ld + kb * kNB;
+  double* ablk = S + (size_t)((kb + 1 + blockIdx.x) * kNB) * ld + kb * kNB;
+  for (int r = 0; r < kNB; ++r) { Lk[r * kLd + lane] = dblk[(size_t)r * ld + lane]; X[r * kLd + lane] = ablk[(size_t)r * ld + lane]; }
+  __syncthreads();
+  for (int j = 0; j < kNB; ++j) {
+    double s = X[lane * kLd + j];
+    for (int t = 0; t < j; ++t) s -= X[lane * kLd + t] * Lk[j * kLd + t];
+    X[lane * kLd + j] = s / Lk[j * kLd + j];
+  }
+  __syncthreads();
+  for (int r = 0; r < kNB; ++r) ablk[(size_t)r * ld + lane] = X[r * kLd + lane];
+}
+// trailing update: A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int ld, int kb) {
+  __shared__ double Pi[kNB * kLd];
+  __shared__ double Pj[kNB * kLd];
+  int t = blockIdx.x, ii = 0;
+  while (t >= ii + 1) { t -= ii + 1; ++ii; }
+  const int bi = kb + 1 + ii, bj = kb + 1 + t;
+  const double* pi = S + (size_t)(bi * kNB) * ld + kb * kNB;
+  const double* pj = S + (size_t)(bj * kNB) * ld + kb * kNB;
+  for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Pi[r * kLd + c] = pi[(size_t)r * ld + c];
+    Pj[r * kLd + c] = pj[(size_t)r * ld + c];
+  }
+  __syncthreads();
+  const int tr = (threadIdx.x >> 4) * 4, tc = (threadIdx.x & 15) * 4;
+  double acc[4][4] = {};
+  for (int k = 0; k < kNB; ++k) {
+    double a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[q] = Pi[(tr + q) * kLd + k]; b[q] = Pj[(tc + q) * kLd + k]; }
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
+  }
+  double* out = S + (size_t)(bi * kNB) * ld + bj * kNB;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) out[(size_t)(tr + x) * ld + tc + y] -= acc[x][y];
+}
+// back substitution x = L^-T y with y = augmented row L[d][0..d); single workgroup
+__global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ S, int ld, int d, double* __restrict__ x) {
+  extern __shared__ double y[];   // d doubles + a 64x65 block
+  double* Lb = y + ((d + 63) / 64) * 64;
+  const int tid = threadIdx.x;
+  const int nblk = (d + kNB - 1) / kNB;
+  for (int i = tid; i < nblk * kNB; i += 256) y[i] = (i < d) ? S[(size_t)d * ld + i] : 0.0;
+  __syncthreads();
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    const int r0 = kb * kNB;
+    for (int e = tid; e < kNB * kNB; e += 256) { const int r = e >> 6, c = e & 63; Lb[r * kLd + c] = S[(size_t)(r0 + r) * ld + r0 + c]; }
+    __syncthreads();
+    if (tid < 64) {   // one wave: L_kk^T x = y_kb, backwards
+      for (int j = kNB - 1; j >= 0; --j) {
+        const bool live = (r0 + j) < d;
+        const double xj = live ? y[r0 + j] / Lb[j * kLd + j] : 0.0;   // broadcast read, same value in every lane
+        if (tid == j) y[r0 + j] = xj;
+        if (tid < j) y[r0 + tid] -= Lb[j * kLd + tid] * xj;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this step visible to the next
+      }
+    }
+    __syncthreads();
+    // y_i -= sum_c L[r0+c][i] x_c for all i < r0 (row r0+c of L, columns i: coalesced over i)
+    for (int i = tid; i < r0; i += 256) {
+      double s = 0.0;
+      const int cmax = min(kNB, d - r0);
+      for (int c = 0; c < cmax; ++c) s += S[(size_t)(r0 + c) * ld + i] * y[r0 + c];
+      y[i] -= s;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < d; i += 256) x[i] = y[i];
+}
+
+// ------------------------------------------------------------------------------------------------ step pieces
+// landmark back-substitution: dl = (-gr - e_l . dx_pose) / Cd ; model terms and norms
+__global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE, const double* __restrict__ E, const double* __restrict__ C,
+                                                      const double* __restrict__ Cd, const double* __restrict__ gr,
+                                                      const double* __restrict__ dxc, const double* __restrict__ inv_depth,
+                                                      double* __restrict__ dxl, double* __restrict__ scal) {
+  extern __shared__ double sdx[];
+  for (int i = threadIdx.x; i < dp; i += kT) sdx[i] = dxc[i];
+  __syncthreads();
+  const int l = blockIdx.x * kT + threadIdx.x;
+  double m = 0.0, n2 = 0.0, x2 = 0.0;
+  if (l < n_lm) {
+    const double* e = E + (size_t)l * ldE;
+    double ed = 0.0;
+    for (int i = 0; i < dp; ++i) ed += e[i] * sdx[i];
+    const double dl = (-gr[l] - ed) / Cd[l];
+    dxl[l] = dl;
+    m = dl * (gr[l] + 0.5 * C[l] * dl) + dl * ed;
+    n2 = dl * dl; x2 = inv_depth[l] * inv_depth[l];
+  }
+  block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM); block_add(x2, scal + SC_XNORM);
+}
+// camera part of the model: sum_i dc_i (gc_i + (B dc)_i / 2), B symmetric stored lower
+__global__ __launch_bounds__(kT) void k_model_cam(int d, int ld, const double* __restrict__ B, const double* __restrict__ gc,
+                                                  const double* __restrict__ dxc, double* __restrict__ scal) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  double m = 0.0, n2 = 0.0, g = 0.0;
+  if (i < d) {
+    double hb = 0.0;
+    for (int j = 0; j <= i; ++j) hb += B[(size_t)i * ld + j] * dxc[j];
+    for (int j = i + 1; j < d; ++j) hb += B[(size_t)j * ld + i] * dxc[j];
+    m = dxc[i] * (gc[i] + 0.5 * hb);
+    n2 = dxc[i] * dxc[i];
+    g = fabs(gc[i]);
+  }
+  block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM);
+  for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_down(g, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX), (unsigned long long)__double_as_longlong(g));
+}
+// x_new = x [+] dx  (EigenQuaternionParameterization::Plus on the quaternion, plain add elsewhere)
+__global__ __launch_bounds__(kT) void k_apply_step(int n_kf, int n_lm, StateP s, const double* __restrict__ dxc, const double* __restrict__ dxl,
+                                                   double* __restrict__ poses2, double* __restrict__ vel2, double* __restrict__ ba2,
+                                                   double* __restrict__ bg2, double* __restrict__ invd2, double* __restrict__ scal) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  double x2 = 0.0;
+  if (i < n_kf) {
+    const double* p = s.poses + 7 * i; const double* dlt = dxc + 6 * i;
+    const double nrm = sqrt(dlt[0] * dlt[0] + dlt[1] * dlt[1] + dlt[2] * dlt[2]);
+    double* o = poses2 + 7 * i;
+    if (nrm > 0.0) {
+      const double sn = sin(nrm) / nrm, cw = cos(nrm);
+      const double dx = sn * dlt[0], dy = sn * dlt[1], dz = sn * dlt[2];
+      const double xw = p[3], xx = p[0], xy = p[1], xz = p[2];   // q_delta (x) x, Hamilton [w,x,y,z]
+      o[3] = cw * xw - dx * xx - dy * xy - dz * xz;
+      o[0] = cw * xx + dx * xw + dy * xz - dz * xy;
+      o[1] = cw * xy - dx * xz + dy * xw + dz * xx;
+      o[2] = cw * xz + dx * xy - dy * xx + dz * xw;
+    } else { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
+    for (int c = 0; c < 3; ++c) o[4 + c] = p[4 + c] + dlt[3 + c];
+    const double* dv = dxc + 6 * n_kf + 9 * i;
+    for (int c = 0; c < 3; ++c) { vel2[3 * i + c] = s.vel[3 * i + c] + dv[c]; ba2[3 * i + c] = s.ba[3 * i + c] + dv[3 + c]; bg2[3 * i + c] = s.bg[3 * i + c] + dv[6 + c]; }
+    for (int c = 0; c < 7; ++c) x2 += p[c] * p[c];
+    for (int c = 0; c < 3; ++c) x2 += s.vel[3 * i + c] * s.vel[3 * i + c] + s.ba[3 * i + c] * s.ba[3 * i + c] + s.bg[3 * i + c] * s.bg[3 * i + c];
+  }
+  if (i < n_lm) invd2[i] = s.inv_depth[i] + dxl[i];
+  block_add(x2, scal + SC_XNORM);
+}
+
+// ================================================================================================ host side
+static StateP state_ptrs(const lvf_state* st) { return StateP{st->poses.p, st->vel.p, st->ba.p, st->bg.p, st->inv_depth.p, st->w_visual.p}; }
+static inline int grid(int n) { return (n + kT - 1) / kT; }
+
+// accumulates 1/2 sum rho into *cost_slot at the given state (residual-only pass)
+static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_state_view, double huber, double* cost_slot) {
+  hipStream_t q = p->ctx->stream;
+  if (p->tc && p->tc->n)
+    hipLaunchKernelGGL(k_lin_tc<true>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
+                       p->tc->idx_a.p, p->tc->idx_b.p, s, p->tc->cam_a, p->tc->cam_b, huber, (double*)nullptr, (double*)nullptr, cost_slot);
+  if (p->tf && p->tf->n)
+    hipLaunchKernelGGL(k_lin_tf<true>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
+                       p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, (double*)nullptr, 0,
+                       (double*)nullptr, (double*)nullptr, 0, (double*)nullptr, (double*)nullptr, cost_slot);
+  if (p->po && p->po->n)
+    hipLaunchKernelGGL(k_lin_po<true>, dim3(grid(p->po->n)), dim3(kT), 0, q, p->po->n, p->n_kf, (const double2*)p->po->ob_a.p, p->po->idx_a.p,
+                       p->po->idx_b.p, p->po->table.p, s, p->po->cam_a, huber, p->pose_const.p, (double*)nullptr, 0, (double*)nullptr, cost_slot);
+  if (p->imu && p->imu->n) {
+    LVF_TRY(launch_imu(p->imu, imu_state_view, false));
+    hipLaunchKernelGGL(k_cost_imu, dim3(grid(15 * p->imu->n)), dim3(kT), 0, q, 15 * p->imu->n, p->imu->res.p, cost_slot);
+  }
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+
+static int enqueue_linearize(lvf_problem* p, double huber) {
+  hipStream_t q = p->ctx->stream;
+  const StateP s = state_ptrs(p->st);
+  LVF_HIP(hipMemsetAsync(p->B.p, 0, p->B.n * 8, q));
+  LVF_HIP(hipMemsetAsync(p->gc.p, 0, p->gc.n * 8, q));
+  if (p->n_lm) {
+    LVF_HIP(hipMemsetAsync(p->E.p, 0, p->E.n * 8, q));
+    LVF_HIP(hipMemsetAsync(p->C.p, 0, p->C.n * 8, q));
+    LVF_HIP(hipMemsetAsync(p->gr.p, 0, p->gr.n * 8, q));
+  }
+  LVF_HIP(hipMemsetAsync(p->scal.p, 0, SC_N * 8, q));
+  double* cost = p->scal.p + SC_COST;
+  if (p->tc && p->tc->n)
+    hipLaunchKernelGGL(k_lin_tc<false>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
+                       p->tc->idx_a.p, p->tc->idx_b.p, s, p->tc->cam_a, p->tc->cam_b, huber, p->C.p, p->gr.p, cost);
+  if (p->tf && p->tf->n)
+    hipLaunchKernelGGL(k_lin_tf<false>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
+                       p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, p->B.p, p->dpad,
+                       p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
+  if (p->po && p->po->n)
+    hipLaunchKernelGGL(k_lin_po<false>, dim3(grid(p->po->n)), dim3(kT), 0, q, p->po->n, p->n_kf, (const double2*)p->po->ob_a.p, p->po->idx_a.p,
+                       p->po->idx_b.p, p->po->table.p, s, p->po->cam_a, huber, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
+  if (p->imu && p->imu->n) {
+    LVF_TRY(launch_imu(p->imu, p->st, true));
+    ImuJ J;
+    for (int k = 0; k < 8; ++k) J.j[k] = p->imu->jac[k].p;
+    hipLaunchKernelGGL(k_lin_imu, dim3(p->imu->n), dim3(64), 0, q, p->imu->n, p->n_kf, p->imu->res.p, J, p->imu->idx_a.p, p->imu->idx_b.p,
+                       p->st->poses.p, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
+  }
+  LVF_HIP(hipGetLastError());
+  p->linearized = true;
+  return LVF_OK;
+}
+
+// builds the damped reduced system, factors it and leaves dx in dxc/dxl, the candidate state in *2 buffers and the
+// scalars (model change, norms, candidate cost) in scal
+static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_flag_dev) {
+  hipStream_t q = p->ctx->stream;
+  const double inv_r = 1.0 / radius;
+  const size_t nS = (size_t)p->dpad * p->dpad;
+  hipLaunchKernelGGL(k_prepare_S, dim3((unsigned)((nS + kT - 1) / kT)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, inv_r, p->S.p);
+  if (p->n_lm) {
+    hipLaunchKernelGGL(k_prepare_lm, dim3(grid(p->n_lm)), dim3(kT), 0, q, p->n_lm, p->dp, p->ldE, p->C.p, p->gr.p, inv_r, p->Cd.p, p->E.p);
+    const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(k_schur_syrk, dim3(ntile, (p->n_lm + kSchurChunk - 1) / kSchurChunk), dim3(64), 0, q, p->n_lm, p->dp, p->ldE, ntile, p->E.p,
+                       p->Cd.p, p->d, p->dpad, p->S.p);
+  }
+  LVF_HIP(hipMemsetAsync(fail_flag_dev, 0, sizeof(int), q));
+  for (int kb = 0; kb < p->nb; ++kb) {
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, q, p->S.p, p->dpad, kb, fail_flag_dev);
+    const int below = p->nb - kb - 1;
+    if (below > 0) {
+      hipLaunchKernelGGL(k_chol_panel, dim3(below), dim3(64), 0, q, p->S.p, p->dpad, kb);
+      hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, q, p->S.p, p->dpad, kb);
+    }
+  }
+  const size_t sh = ((size_t)((p->d + 63) / 64) * 64 + kNB * kLd) * sizeof(double);
+  hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(256), sh, q, p->S.p, p->dpad, p->d, p->dxc.p);
+  // model / norms / candidate state
+  LVF_HIP(hipMemsetAsync(p->scal.p + SC_COST_NEW, 0, (SC_N - SC_COST_NEW) * 8, q));
+  const StateP s = state_ptrs(p->st);
+  if (p->n_lm)
+    hipLaunchKernelGGL(k_landmark_back, dim3(grid(p->n_lm)), dim3(kT), p->dp * sizeof(double), q, p->n_lm, p->dp, p->ldE, p->E.p, p->C.p, p->Cd.p,
+                       p->gr.p, p->dxc.p, p->st->inv_depth.p, p->dxl.p, p->scal.p);
+  hipLaunchKernelGGL(k_model_cam, dim3(grid(p->d)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, p->dxc.p, p->scal.p);
+  hipLaunchKernelGGL(k_apply_step, dim3(grid(std::max(p->n_kf, p->n_lm))), dim3(kT), 0, q, p->n_kf, p->n_lm, s, p->dxc.p, p->dxl.p, p->poses2.p,
+                     p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->scal.p);
+  LVF_HIP(hipGetLastError());
+  // candidate cost
+  lvf_state view;   // borrowed pointers: a state-shaped view of the candidate buffers for launch_imu
+  view.ctx = p->ctx; view.n_kf = p->n_kf; view.n_lm = p->n_lm;
+  view.poses.p = p->poses2.p; view.vel.p = p->vel2.p; view.ba.p = p->ba2.p; view.bg.p = p->bg2.p; view.inv_depth.p = p->invd2.p;
+  view.w_visual.p = p->st->w_visual.p;
+  const StateP s2{p->poses2.p, p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->st->w_visual.p};
+  const int rc = enqueue_cost(p, s2, &view, huber, p->scal.p + SC_COST_NEW);
+  view.poses.p = view.vel.p = view.ba.p = view.bg.p = view.inv_depth.p = view.w_visual.p = nullptr;   // not owned
+  return rc;
+}
+
+static int commit_candidate(lvf_problem* p) {
+  hipStream_t q = p->ctx->stream;
+  lvf_state* st = p->st;
+  if (p->n_kf) {
+    LVF_HIP(hipMemcpyAsync(st->poses.p, p->poses2.p, (size_t)56 * p->n_kf, hipMemcpyDeviceToDevice, q));
+    LVF_HIP(hipMemcpyAsync(st->vel.p, p->vel2.p, (size_t)24 * p->n_kf, hipMemcpyDeviceToDevice, q));
+    LVF_HIP(hipMemcpyAsync(st->ba.p, p->ba2.p, (size_t)24 * p->n_kf, hipMemcpyDeviceToDevice, q));
+    LVF_HIP(hipMemcpyAsync(st->bg.p, p->bg2.p, (size_t)24 * p->n_kf, hipMemcpyDeviceToDevice, q));
+  }
+  if (p->n_lm) LVF_HIP(hipMemcpyAsync(st->inv_depth.p, p->invd2.p, (size_t)8 * p->n_lm, hipMemcpyDeviceToDevice, q));
+  return LVF_OK;
+}
+
+struct IterOut { double cost_before, cost_after, model, dxnorm, xnorm, gmax; bool accepted, solved; };
+
+static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* radius, double* decrease, IterOut* out) {
+  hipStream_t q = p->ctx->stream;
+  LVF_TRY(enqueue_linearize(p, o->huber_a));
+  LVF_TRY(enqueue_step(p, o->huber_a, *radius, p->fail.p));
+  double h[SC_N]; int hfail = 0;
+  LVF_HIP(hipMemcpyAsync(h, p->scal.p, sizeof(h), hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipMemcpyAsync(&hfail, p->fail.p, sizeof(int), hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipStreamSynchronize(q));
+  out->cost_before = h[SC_COST]; out->cost_after = h[SC_COST_NEW]; out->model = -h[SC_MODEL];
+  out->dxnorm = std::sqrt(h[SC_DXNORM]); out->xnorm = std::sqrt(h[SC_XNORM]);
+  long long gbits; std::memcpy(&gbits, &h[SC_GMAX], 8); std::memcpy(&out->gmax, &gbits, 8);
+  out->solved = hfail == 0 && std::isfinite(out->cost_after) && std::isfinite(out->model);
+  out->accepted = false;
+  p->last_radius = *radius;
+  if (out->solved && out->model > 0.0) {
+    const double rho = (out->cost_before - out->cost_after) / out->model;
+    if (rho > o->min_relative_decrease) {
+      out->accepted = true;
+      LVF_TRY(commit_candidate(p));
+      const double t = 2.0 * rho - 1.0;
+      *radius = std::fmin(*radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
+      *decrease = 2.0;
+      return LVF_OK;
+    }
+  }
+  if (!out->accepted) out->cost_after = out->solved ? out->cost_after : out->cost_before;
+  *radius = *radius / *decrease;
+  *decrease *= 2.0;
+  return LVF_OK;
+}
+
+}  // namespace lvf
+
+using namespace lvf;
+
+extern "C" {
+
+void lvf_solver_options_default(lvf_solver_options* o) {
+  if (!o) return;
+  o->max_num_iterations = 50; o->max_solver_time_in_seconds = 0.0; o->huber_a = 1.0;
+  o->initial_trust_region_radius = 1e4; o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8; o->min_relative_decrease = 1e-3;
+}
+
+int lvf_problem_create(lvf_ctx* ctx, lvf_state* st, lvf_batch* two_camera, lvf_batch* two_frame, lvf_batch* pose_only,
+                       lvf_batch* imu, lvf_problem** out) {
+  LVF_REQUIRE(ctx && st && out, "lvf_problem_create: null argument");
+  LVF_REQUIRE(st->ctx == ctx, "lvf_problem_create: state belongs to another context");
+  LVF_REQUIRE(!two_camera || two_camera->kind == LVF_K_TWO_CAMERA, "two_camera batch has the wrong kind");
+  LVF_REQUIRE(!two_frame || two_frame->kind == LVF_K_TWO_FRAME, "two_frame batch has the wrong kind");
+  LVF_REQUIRE(!pose_only || pose_only->kind == LVF_K_POSE_ONLY, "pose_only batch has the wrong kind");
+  LVF_REQUIRE(!imu || imu->kind == LVF_K_IMU, "imu batch has the wrong kind");
+  for (lvf_batch* b : {two_camera, two_frame, pose_only, imu})
+    if (b) {
+      LVF_REQUIRE(b->ctx == ctx, "batch belongs to another context");
+      LVF_REQUIRE(b->min_n_kf <= st->n_kf && b->min_n_lm <= st->n_lm, "batch indices exceed the state (n_kf=%d n_lm=%d)", st->n_kf, st->n_lm);
+    }
+  LVF_REQUIRE(st->n_kf > 0, "lvf_problem_create: empty window");
+  LVF_HIP(hipSetDevice(ctx->device));
+  auto* p = new lvf_problem();
+  p->ctx = ctx; p->st = st; p->tc = two_camera; p->tf = two_frame; p->po = pose_only; p->imu = imu;
+  p->n_kf = st->n_kf; p->n_lm = st->n_lm;
+  p->d = 15 * p->n_kf; p->dp = 6 * p->n_kf;
+  p->ldE = ((p->dp + 1 + 15) / 16) * 16;
+  p->dpad = ((p->d + 1 + 63) / 64) * 64;
+  p->nb = p->dpad / 64;
+  const size_t nS = (size_t)p->dpad * p->dpad;
+  int rc;
+  if ((rc = p->B.alloc(nS)) || (rc = p->S.alloc(nS)) || (rc = p->gc.alloc(p->dpad)) || (rc = p->dxc.alloc(p->dpad)) ||
+      (rc = p->C.alloc(p->n_lm)) || (rc = p->gr.alloc(p->n_lm)) || (rc = p->Cd.alloc(p->n_lm)) || (rc = p->dxl.alloc(p->n_lm)) ||
+      (rc = p->E.alloc((size_t)p->n_lm * p->ldE)) || (rc = p->scal.alloc(SC_N)) || (rc = p->poses2.alloc((size_t)7 * p->n_kf)) ||
+      (rc = p->vel2.alloc((size_t)3 * p->n_kf)) || (rc = p->ba2.alloc((size_t)3 * p->n_kf)) || (rc = p->bg2.alloc((size_t)3 * p->n_kf)) ||
+      (rc = p->invd2.alloc(p->n_lm)) || (rc = p->pose_const.alloc(p->n_kf)) || (rc = p->fail.alloc(1))) { delete p; return rc; }
+  p->pose_const_h.assign(p->n_kf, 0);
+  LVF_HIP(hipMemsetAsync(p->pose_const.p, 0, p->n_kf, ctx->stream));
+  LVF_HIP(hipMemsetAsync(p->dxc.p, 0, p->dpad * 8, ctx->stream));
+  LVF_HIP(hipStreamSynchronize(ctx->stream));
+  *out = p;
+  return LVF_OK;
+}
+int lvf_problem_destroy(lvf_problem* p) { delete p; return LVF_OK; }
+
+int lvf_problem_set_pose_constant(lvf_problem* p, int kf, int is_constant) {
+  LVF_REQUIRE(p, "null problem");
+  LVF_REQUIRE(kf >= 0 && kf < p->n_kf, "keyframe %d out of range", kf);
+  p->pose_const_h[kf] = is_constant ? 1 : 0;
+  LVF_HIP(hipMemcpyAsync(p->pose_const.p, p->pose_const_h.data(), p->n_kf, hipMemcpyHostToDevice, p->ctx->stream));
+  LVF_HIP(hipStreamSynchronize(p->ctx->stream));
+  return LVF_OK;
+}
+
+int lvf_problem_cost(lvf_problem* p, const lvf_solver_options* o, double* cost) {
+  LVF_REQUIRE(p && o && cost, "lvf_problem_cost: null argument");
+  LVF_HIP(hipSetDevice(p->ctx->device));
+  hipStream_t q = p->ctx->stream;
+  LVF_HIP(hipMemsetAsync(p->scal.p, 0, SC_N * 8, q));
+  LVF_TRY(enqueue_cost(p, state_ptrs(p->st), p->st, o->huber_a, p->scal.p + SC_COST));
+  LVF_HIP(hipMemcpyAsync(cost, p->scal.p + SC_COST, 8, hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipStreamSynchronize(q));
+  return LVF_OK;
+}
+
+int lvf_problem_lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* radius, double* decrease_factor,
+                             double* cost_before, double* cost_after, int* accepted) {
+  LVF_REQUIRE(p && o && radius && decrease_factor, "lvf_problem_lm_iteration: null argument");
+  LVF_REQUIRE(*radius > 0.0 && *decrease_factor > 0.0, "radius and decrease_factor must be positive");
+  LVF_HIP(hipSetDevice(p->ctx->device));
+  IterOut it;
+  LVF_TRY(lm_iteration(p, o, radius, decrease_factor, &it));
+  if (cost_before) *cost_before = it.cost_before;
+  if (cost_after) *cost_after = it.cost_after;
+  if (accepted) *accepted = it.accepted ? 1 : 0;
+  return LVF_OK;
+}
+
+int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary) {
+  LVF_REQUIRE(p && o && summary, "lvf_problem_solve: null argument");
+  LVF_HIP(hipSetDevice(p->ctx->device));
+  double radius = o->initial_trust_region_radius, decrease = 2.0;
+  std::memset(summary, 0, sizeof(*summary));
+  summary->num_residual_blocks = (p->tc ? p->tc->n : 0) + (p->tf ? p->tf->n : 0) + (p->po ? p->po->n : 0) + (p->imu ? p->imu->n : 0);
+  summary->termination = 1;
+  const auto wall0 = std::chrono::steady_clock::now();
+  double cost = 0.0;
+  for (int it = 0; it < o->max_num_iterations; ++it) {
+    IterOut r;
+    LVF_TRY(lm_iteration(p, o, &radius, &decrease, &r));
+    if (it == 0) { summary->initial_cost = r.cost_before; cost = r.cost_before; }
+    summary->num_iterations = it + 1;
+    if (!r.solved && radius < 1e-32) { summary->termination = 2; break; }
+    if (r.accepted) {
+      summary->num_successful_steps++;
+      const double change = cost - r.cost_after;
+      cost = r.cost_after;
+      if (std::fabs(change) <= o->function_tolerance * std::fabs(r.cost_before)) { summary->termination = 0; break; }
+    }
+    if (it == 0 && r.gmax <= o->gradient_tolerance) { summary->termination = 0; break; }
+    if (r.solved && r.dxnorm <= o->parameter_tolerance * (r.xnorm + o->parameter_tolerance)) { summary->termination = 0; break; }
+    if (o->max_solver_time_in_seconds > 0.0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) break;
+  }
+  summary->final_cost = cost;
+  return LVF_OK;
+}
+
+int lvf_problem_reduced_dim(lvf_problem* p) { return p ? p->d : -1; }
+
+// the DAMPED reduced system of the last lm_iteration, rebuilt (the factorisation overwrote S): S [d x d] symmetric, rhs [d]
+int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs) {
+  LVF_REQUIRE(p && S && rhs, "lvf_problem_download_reduced: null argument");
+  if (!p->linearized) { set_error("no linearisation yet"); return LVF_ERR_STATE; }
+  LVF_HIP(hipSetDevice(p->ctx->device));
+  hipStream_t q = p->ctx->stream;
+  const double inv_r = 1.0 / p->last_radius;
+  const size_t nS = (size_t)p->dpad * p->dpad;
+  hipLaunchKernelGGL(k_prepare_S, dim3((unsigned)((nS + kT - 1) / kT)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, inv_r, p->S.p);
+  if (p->n_lm) {
+    hipLaunchKernelGGL(k_prepare_lm, dim3(grid(p->n_lm)), dim3(kT), 0, q, p->n_lm, p->dp, p->ldE, p->C.p, p->gr.p, inv_r, p->Cd.p, p->E.p);
+    const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(k_schur_syrk, dim3(ntile, (p->n_lm + kSchurChunk - 1) / kSchurChunk), dim3(64), 0, q, p->n_lm, p->dp, p->ldE, ntile, p->E.p,
+                       p->Cd.p, p->d, p->dpad, p->S.p);
+  }
+  LVF_HIP(hipGetLastError());
+  std::vector<double> h(nS);
+  LVF_HIP(hipMemcpyAsync(h.data(), p->S.p, nS * 8, hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipStreamSynchronize(q));
+  const int d = p->d, ld = p->dpad;
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j <= i; ++j) { S[(size_t)i * d + j] = h[(size_t)i * ld + j]; S[(size_t)j * d + i] = h[(size_t)i * ld + j]; }
+  for (int j = 0; j < d; ++j) rhs[j] = h[(size_t)d * ld + j];
+  return LVF_OK;
+}
+
+}  // extern "C"

@@ -13,26 +13,13 @@
 //   * Jacobian rows are produced in registers, transposed through a padded LDS tile (row stride 15 doubles:
 //     conflict-free ds_write_b64) and written back as fully coalesced 16 B/lane stores in the exact
 //     row-major num_residuals x block_size Ceres layout.
+#include "factor_eval.hpp"
 #include "lvf_internal.hpp"
 
 namespace lvf {
 
 constexpr int kBlock = 256;
-constexpr int kMaxStagedKf = 64;
 constexpr int kTileStride = 15;  // 14 Jacobian doubles + 1 pad
-
-__device__ __forceinline__ void stage_poses(PoseD* s_pose, const double* __restrict__ poses, int n_kf) {
-  if (n_kf <= kMaxStagedKf) {
-    for (int k = threadIdx.x; k < n_kf; k += kBlock) derive_pose(poses + 7 * k, s_pose[k]);
-    __syncthreads();
-  }
-}
-__device__ __forceinline__ PoseD fetch_pose(const PoseD* s_pose, const double* __restrict__ poses, int n_kf, int kf) {
-  if (n_kf <= kMaxStagedKf) return s_pose[kf];
-  PoseD d;
-  derive_pose(poses + 7 * kf, d);
-  return d;
-}
 
 // cooperative, coalesced write-back of a [cnt][14] tile staged in LDS with row stride kTileStride
 __device__ __forceinline__ void flush_tile14(const double* s_tile, double* __restrict__ out, int first, int cnt) {
@@ -54,38 +41,27 @@ __global__ __launch_bounds__(kBlock) void k_pose_only(int n, int n_kf, const dou
                                                       double2* __restrict__ res, double* __restrict__ jac) {
   __shared__ PoseD s_pose[kMaxStagedKf];
   __shared__ double s_tile[WITH_J ? kBlock * kTileStride : 1];
-  stage_poses(s_pose, poses, n_kf);
+  stage_poses<kBlock>(s_pose, poses, n_kf);
   const int first = blockIdx.x * kBlock;
   const int i = first + threadIdx.x;
   if (i < n) {
     const int kf = kf_idx[i];
     const int l = pw_idx[i];
     const double2 o = ob[i];
-    const double w = w_kf[kf];
     const PoseD P = fetch_pose(s_pose, poses, n_kf, kf);
-    const double d[3] = {pw[3 * l] - P.t[0], pw[3 * l + 1] - P.t[1], pw[3 * l + 2] - P.t[2]};
-    double pb[3];
-    mat3t_mul_vec(P.R, d, pb);
-    double px[2], M[6];
-    project_and_chain(cam, pb, w, px, M);
-    res[i] = make_double2(w * (px[0] - o.x), w * (px[1] - o.y));
+    const double pwl[3] = {pw[3 * l], pw[3 * l + 1], pw[3 * l + 2]};
+    double r[2], J[14];
+    eval_pose_only<WITH_J>(P, cam, o.x, o.y, pwl, w_kf[kf], r, J);
+    res[i] = make_double2(r[0], r[1]);
     if (WITH_J) {
-      const double fmp[3] = {pb[0] - d[0], pb[1] - d[1], pb[2] - d[2]};
       double* row = s_tile + threadIdx.x * kTileStride;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        double q4[4], t3[3];
-        row_times_drot_dq<true>(M + 3 * a, P.u, P.inv_n, d, fmp, q4);
-        mat3_mul_vec(P.R, M + 3 * a, t3);  // (M_row R^T)^T = R M_row^T
-        row[7 * a + 0] = q4[0]; row[7 * a + 1] = q4[1]; row[7 * a + 2] = q4[2]; row[7 * a + 3] = q4[3];
-        row[7 * a + 4] = -t3[0]; row[7 * a + 5] = -t3[1]; row[7 * a + 6] = -t3[2];
-      }
+      for (int k = 0; k < 14; ++k) row[k] = J[k];
     }
   }
   if (WITH_J) {
     __syncthreads();
-    const int cnt = min(kBlock, n - first);
-    flush_tile14(s_tile, jac, first, cnt);
+    flush_tile14(s_tile, jac, first, min(kBlock, n - first));
   }
 }
 
@@ -101,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_two_frame(int n, int n_kf, const dou
                                                       double* __restrict__ j2) {
   __shared__ PoseD s_pose[kMaxStagedKf];
   __shared__ double s_tile[WITH_J ? kBlock * kTileStride : 1];
-  stage_poses(s_pose, poses, n_kf);
+  stage_poses<kBlock>(s_pose, poses, n_kf);
   const int first = blockIdx.x * kBlock;
   const int i = first + threadIdx.x;
   const int cnt = min(kBlock, n - first);
@@ -109,47 +85,16 @@ __global__ __launch_bounds__(kBlock) void k_two_frame(int n, int n_kf, const dou
   if (i < n) {
     const int k1 = kf1_idx[i], k2 = kf2_idx[i];
     const double2 fo = first_ob[i], o = ob[i];
-    const double rho = inv_depth[lm_idx[i]];
-    const double w = w_kf[k2];
     const PoseD P1 = fetch_pose(s_pose, poses, n_kf, k1);
     const PoseD P2 = fetch_pose(s_pose, poses, n_kf, k2);
-    // Pixel2Robot through the RIGHT camera (visual_error.hpp:25-33)
-    const double dpt = 1.0 / rho;
-    const double dir[3] = {(fo.x - right.cx) / right.fx, (fo.y - right.cy) / right.fy, 1.0};
-    const double ps[3] = {dir[0] * dpt, dir[1] * dpt, dpt};
-    double pb1[3];
-    mat3_mul_vec(right.Re, ps, pb1);
-    pb1[0] += right.te[0]; pb1[1] += right.te[1]; pb1[2] += right.te[2];
-    double rp[3];
-    mat3_mul_vec(P1.R, pb1, rp);                                   // R1 pb1
-    const double pwd[3] = {rp[0] + P1.t[0], rp[1] + P1.t[1], rp[2] + P1.t[2]};
-    const double dd[3] = {pwd[0] - P2.t[0], pwd[1] - P2.t[1], pwd[2] - P2.t[2]};
-    double pb2[3];
-    mat3t_mul_vec(P2.R, dd, pb2);
-    double px[2], M[6];
-    project_and_chain(left, pb2, w, px, M);
-    res[i] = make_double2(w * (px[0] - o.x), w * (px[1] - o.y));
+    double r[2], Jd[2], J1[14];
+    eval_two_frame<WITH_J>(P1, P2, left, right, fo.x, fo.y, o.x, o.y, inv_depth[lm_idx[i]], w_kf[k2], r, Jd, J1, J2row);
+    res[i] = make_double2(r[0], r[1]);
     if (WITH_J) {
-      const double fmp2[3] = {pb2[0] - dd[0], pb2[1] - dd[1], pb2[2] - dd[2]};
-      const double fmp1[3] = {rp[0] - pb1[0], rp[1] - pb1[1], rp[2] - pb1[2]};
-      double rd[3];                                                  // R1 Re dir
-      { double t[3]; mat3_mul_vec(right.Re, dir, t); mat3_mul_vec(P1.R, t, rd); }
-      const double md2 = -(dpt * dpt);
+      jd[i] = make_double2(Jd[0], Jd[1]);
       double* row = s_tile + threadIdx.x * kTileStride;
-      double jdv[2];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        double A[3], q4[4];
-        mat3_mul_vec(P2.R, M + 3 * a, A);                            // d r_a / d pw
-        row_times_drot_dq<true>(M + 3 * a, P2.u, P2.inv_n, dd, fmp2, q4);
-        J2row[7 * a + 0] = q4[0]; J2row[7 * a + 1] = q4[1]; J2row[7 * a + 2] = q4[2]; J2row[7 * a + 3] = q4[3];
-        J2row[7 * a + 4] = -A[0]; J2row[7 * a + 5] = -A[1]; J2row[7 * a + 6] = -A[2];
-        row_times_drot_dq<false>(A, P1.u, P1.inv_n, pb1, fmp1, q4);
-        row[7 * a + 0] = q4[0]; row[7 * a + 1] = q4[1]; row[7 * a + 2] = q4[2]; row[7 * a + 3] = q4[3];
-        row[7 * a + 4] = A[0]; row[7 * a + 5] = A[1]; row[7 * a + 6] = A[2];
-        jdv[a] = (A[0] * rd[0] + A[1] * rd[1] + A[2] * rd[2]) * md2;
-      }
-      jd[i] = make_double2(jdv[0], jdv[1]);
+      for (int k = 0; k < 14; ++k) row[k] = J1[k];
     }
   }
   if (WITH_J) {
@@ -178,24 +123,10 @@ __global__ __launch_bounds__(kBlock) void k_two_camera(int n, const double2* __r
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const double2 lo = left_ob[i], ro = right_ob[i];
-  const double rho = inv_depth[lm_idx[i]];
-  const double w = 5.0 * w_kf[kf_idx[i]];                            // backend.cpp:123
-  const double dpt = 1.0 / rho;
-  const double dir[3] = {(ro.x - right.cx) / right.fx, (ro.y - right.cy) / right.fy, 1.0};
-  const double ps[3] = {dir[0] * dpt, dir[1] * dpt, dpt};
-  double pb[3];
-  mat3_mul_vec(right.Re, ps, pb);
-  pb[0] += right.te[0]; pb[1] += right.te[1]; pb[2] += right.te[2];
-  double px[2], M[6];
-  project_and_chain(left, pb, w, px, M);
-  res[i] = make_double2(w * (px[0] - lo.x), w * (px[1] - lo.y));
-  if (WITH_J) {
-    double rd[3];
-    mat3_mul_vec(right.Re, dir, rd);
-    const double md2 = -(dpt * dpt);
-    jac[i] = make_double2((M[0] * rd[0] + M[1] * rd[1] + M[2] * rd[2]) * md2,
-                          (M[3] * rd[0] + M[4] * rd[1] + M[5] * rd[2]) * md2);
-  }
+  double r[2], J[2];
+  eval_two_camera<WITH_J>(left, right, lo.x, lo.y, ro.x, ro.y, inv_depth[lm_idx[i]], 5.0 * w_kf[kf_idx[i]], r, J);
+  res[i] = make_double2(r[0], r[1]);
+  if (WITH_J) jac[i] = make_double2(J[0], J[1]);
 }
 
 // ------------------------------------------------------------------------------------------ launchers

@@ -217,8 +217,8 @@ def config4_window(n_kf=50, n_lm=10000, n_prewindow=2000, seed=SEED_CFG4, imu_sa
         ks = np.arange(birth[l] + 1, birth[l] + length[l])
         if ks.size:
             tf_lm.append(np.full(ks.size, l)); tf_k1.append(np.full(ks.size, birth[l])); tf_k2.append(ks)
-    tf_lm = np.concatenate(tf_lm).astype(np.int32); tf_k1 = np.concatenate(tf_k1).astype(np.int32)
-    tf_k2 = np.concatenate(tf_k2).astype(np.int32)
+    cat = lambda xs: np.concatenate(xs).astype(np.int32) if xs else np.zeros(0, np.int32)
+    tf_lm, tf_k1, tf_k2 = cat(tf_lm), cat(tf_k1), cat(tf_k2)
     px, z = project(cam0, poses[tf_k2], pw[tf_lm])
     keep = z > 2.0
     tf_lm, tf_k1, tf_k2, px = tf_lm[keep], tf_k1[keep], tf_k2[keep], px[keep]

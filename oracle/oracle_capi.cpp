@@ -11,6 +11,7 @@
 #include "factors.h"
 #include "imu.h"
 #include "knn.h"
+#include "lm.h"
 #include "robust.h"
 
 using namespace lvo;
@@ -248,6 +249,57 @@ double lvo_kdtree_build_seconds(const float* map, int M, int mstride) {
   const double t0 = omp_get_wtime();
   KdTree tree; tree.build(map, M, mstride);
   return omp_get_wtime() - t0 + (tree.nodes.empty() ? 1e-12 : 0.0);
+}
+
+// ---------------- sliding-window problem / LM iteration ----------------
+struct lvo_window_c {
+  int n_kf, n_lm;
+  double *poses, *vel, *ba, *bg, *inv_depth;
+  const double* w_kf;
+  lvo_camera cam0, cam1;
+  int n_tc; const double *tc_left_ob, *tc_right_ob; const int *tc_lm, *tc_kf;
+  int n_tf; const double *tf_first_ob, *tf_ob; const int *tf_lm, *tf_kf1, *tf_kf2;
+  int n_po; const double* po_ob; const int *po_kf, *po_pw; const double* po_pwtab;
+  int n_imu; const lvo_preint* pre; const int *imu_i, *imu_j;
+  const unsigned char* pose_const;
+};
+static void to_window(const lvo_window_c* c, Window& w, std::vector<imu::Preint>& pre) {
+  w.n_kf = c->n_kf; w.n_lm = c->n_lm; w.poses = c->poses; w.vel = c->vel; w.ba = c->ba; w.bg = c->bg; w.inv_depth = c->inv_depth;
+  w.w_kf = c->w_kf; w.cam0 = cam_of(&c->cam0); w.cam1 = cam_of(&c->cam1);
+  w.n_tc = c->n_tc; w.tc_left_ob = c->tc_left_ob; w.tc_right_ob = c->tc_right_ob; w.tc_lm = c->tc_lm; w.tc_kf = c->tc_kf;
+  w.n_tf = c->n_tf; w.tf_first_ob = c->tf_first_ob; w.tf_ob = c->tf_ob; w.tf_lm = c->tf_lm; w.tf_kf1 = c->tf_kf1; w.tf_kf2 = c->tf_kf2;
+  w.n_po = c->n_po; w.po_ob = c->po_ob; w.po_kf = c->po_kf; w.po_pw = c->po_pw; w.po_pwtab = c->po_pwtab;
+  pre.resize(c->n_imu);
+  for (int f = 0; f < c->n_imu; ++f) flat_to_preint(c->pre + f, pre[f]);
+  w.n_imu = c->n_imu; w.pre = pre.data(); w.imu_i = c->imu_i; w.imu_j = c->imu_j;
+  w.pose_const = c->pose_const;
+}
+double lvo_window_cost(const lvo_window_c* c, double huber_a) {
+  Window w; std::vector<imu::Preint> pre; to_window(c, w, pre);
+  return window_cost(w, huber_a, w.poses, w.vel, w.ba, w.bg, w.inv_depth);
+}
+// B[d*d], gc[d], E[n_lm*6n_kf], C[n_lm], gr[n_lm]; any output may be null
+double lvo_window_linearize(const lvo_window_c* c, double huber_a, double* B, double* gc, double* E, double* C, double* gr) {
+  Window w; std::vector<imu::Preint> pre; to_window(c, w, pre);
+  Linearization L; window_linearize(w, huber_a, L);
+  if (B) std::memcpy(B, L.B.data(), L.B.size() * 8);
+  if (gc) std::memcpy(gc, L.gc.data(), L.gc.size() * 8);
+  if (E) std::memcpy(E, L.E.data(), L.E.size() * 8);
+  if (C) std::memcpy(C, L.C.data(), L.C.size() * 8);
+  if (gr) std::memcpy(gr, L.gr.data(), L.gr.size() * 8);
+  return L.cost;
+}
+// out6 = {cost_before, cost_after, model_cost_change, rho, accepted, solved}; S[d*d], rhs[d] optional taps.
+// The state arrays inside c are updated in place when the step is accepted; radius/decrease_factor are updated.
+void lvo_window_lm_iteration(lvo_window_c* c, double huber_a, double min_relative_decrease, double* radius,
+                             double* decrease_factor, double* out6, double* S, double* rhs) {
+  Window w; std::vector<imu::Preint> pre; to_window(c, w, pre);
+  LmStep st;
+  lm_iteration(w, huber_a, min_relative_decrease, radius, decrease_factor, st);
+  out6[0] = st.cost_before; out6[1] = st.cost_after; out6[2] = st.model_cost_change; out6[3] = st.rho;
+  out6[4] = st.accepted ? 1.0 : 0.0; out6[5] = st.solved ? 1.0 : 0.0;
+  if (S) std::memcpy(S, st.S.data(), st.S.size() * 8);
+  if (rhs) std::memcpy(rhs, st.rhs.data(), st.rhs.size() * 8);
 }
 
 }  // extern "C"

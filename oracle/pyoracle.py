@@ -251,3 +251,80 @@ def knn3(map_xyz, query_xyz, tf_d, thr, method=0, threads=1):
 def kdtree_build_seconds(map_xyz):
     m = _f32(map_xyz)
     return lib().lvo_kdtree_build_seconds(_p(m, C.c_float), m.shape[0], m.shape[1])
+
+
+# ----------------------------------------------------------------------------- sliding-window problem
+class _WindowC(C.Structure):
+    _fields_ = [("n_kf", C.c_int), ("n_lm", C.c_int),
+                ("poses", C.POINTER(C.c_double)), ("vel", C.POINTER(C.c_double)), ("ba", C.POINTER(C.c_double)),
+                ("bg", C.POINTER(C.c_double)), ("inv_depth", C.POINTER(C.c_double)), ("w_kf", C.POINTER(C.c_double)),
+                ("cam0", Camera), ("cam1", Camera),
+                ("n_tc", C.c_int), ("tc_left_ob", C.POINTER(C.c_double)), ("tc_right_ob", C.POINTER(C.c_double)),
+                ("tc_lm", C.POINTER(C.c_int)), ("tc_kf", C.POINTER(C.c_int)),
+                ("n_tf", C.c_int), ("tf_first_ob", C.POINTER(C.c_double)), ("tf_ob", C.POINTER(C.c_double)),
+                ("tf_lm", C.POINTER(C.c_int)), ("tf_kf1", C.POINTER(C.c_int)), ("tf_kf2", C.POINTER(C.c_int)),
+                ("n_po", C.c_int), ("po_ob", C.POINTER(C.c_double)), ("po_kf", C.POINTER(C.c_int)), ("po_pw", C.POINTER(C.c_int)),
+                ("po_pwtab", C.POINTER(C.c_double)),
+                ("n_imu", C.c_int), ("pre", C.POINTER(C.c_double)), ("imu_i", C.POINTER(C.c_int)), ("imu_j", C.POINTER(C.c_int)),
+                ("pose_const", C.POINTER(C.c_uint8))]
+
+
+class Window:
+    """Owns numpy copies of a config-4 style window (lvio_fusion_amd.synthetic.config4_window dict) + preintegrations."""
+
+    def __init__(self, cfg, pre, pose_const=None, use=("tc", "tf", "po", "imu")):
+        self.n_kf, self.n_lm = cfg["n_kf"], cfg["n_lm"]
+        self.poses = _f64(cfg["poses"]).copy(); self.vel = _f64(cfg["vel"]).copy(); self.ba = _f64(cfg["ba"]).copy()
+        self.bg = _f64(cfg["bg"]).copy(); self.inv_depth = _f64(cfg["inv_depth"]).copy(); self.w_kf = _f64(cfg["w_kf"]).copy()
+        c0, c1 = cfg["cam0"], cfg["cam1"]
+        self._keep = []
+        w = _WindowC()
+        w.n_kf, w.n_lm = self.n_kf, self.n_lm
+        w.poses, w.vel, w.ba, w.bg, w.inv_depth, w.w_kf = map(_p, (self.poses, self.vel, self.ba, self.bg, self.inv_depth, self.w_kf))
+        w.cam0 = Camera.make(c0["fx"], c0["fy"], c0["cx"], c0["cy"], c0["extrinsic"])
+        w.cam1 = Camera.make(c1["fx"], c1["fy"], c1["cx"], c1["cy"], c1["extrinsic"])
+
+        def d(a):
+            a = _f64(a); self._keep.append(a); return _p(a)
+
+        def i(a):
+            a = _i32(a); self._keep.append(a); return _p(a, C.c_int)
+        tc, tf, po = cfg["tc"], cfg["tf"], cfg["po"]
+        w.n_tc = len(tc["lm_idx"]) if "tc" in use else 0
+        w.tc_left_ob, w.tc_right_ob, w.tc_lm, w.tc_kf = d(tc["left_ob"]), d(tc["right_ob"]), i(tc["lm_idx"]), i(tc["kf_idx"])
+        w.n_tf = len(tf["lm_idx"]) if "tf" in use else 0
+        w.tf_first_ob, w.tf_ob, w.tf_lm, w.tf_kf1, w.tf_kf2 = d(tf["first_ob"]), d(tf["ob"]), i(tf["lm_idx"]), i(tf["kf1_idx"]), i(tf["kf2_idx"])
+        w.n_po = len(po["kf_idx"]) if "po" in use else 0
+        w.po_ob, w.po_kf, w.po_pw, w.po_pwtab = d(po["ob"]), i(po["kf_idx"]), i(po["pw_idx"]), d(po["pw"])
+        pre = _f64(pre).reshape(-1, PREINT_DOUBLES); self._keep.append(pre)
+        w.n_imu = pre.shape[0] if "imu" in use else 0
+        w.pre = _p(pre)
+        w.imu_i, w.imu_j = i([f["kf_i"] for f in cfg["imu"]]), i([f["kf_j"] for f in cfg["imu"]])
+        if pose_const is not None:
+            pc = np.ascontiguousarray(pose_const, dtype=np.uint8); self._keep.append(pc)
+            w.pose_const = pc.ctypes.data_as(C.POINTER(C.c_uint8))
+        self.c = w
+        L = lib()
+        L.lvo_window_cost.restype = C.c_double
+        L.lvo_window_linearize.restype = C.c_double
+
+    @property
+    def d(self):
+        return 15 * self.n_kf
+
+    def cost(self, huber_a=1.0):
+        return lib().lvo_window_cost(C.byref(self.c), C.c_double(huber_a))
+
+    def linearize(self, huber_a=1.0):
+        d, dp = self.d, 6 * self.n_kf
+        B = np.empty((d, d)); gc = np.empty(d); E = np.empty((self.n_lm, dp)); Cc = np.empty(self.n_lm); gr = np.empty(self.n_lm)
+        cost = lib().lvo_window_linearize(C.byref(self.c), C.c_double(huber_a), _p(B), _p(gc), _p(E), _p(Cc), _p(gr))
+        return dict(cost=cost, B=B, gc=gc, E=E, C=Cc, gr=gr)
+
+    def lm_iteration(self, radius, decrease_factor=2.0, huber_a=1.0, min_relative_decrease=1e-3):
+        r, dfac = C.c_double(radius), C.c_double(decrease_factor)
+        out6 = np.empty(6); S = np.empty((self.d, self.d)); rhs = np.empty(self.d)
+        lib().lvo_window_lm_iteration(C.byref(self.c), C.c_double(huber_a), C.c_double(min_relative_decrease), C.byref(r), C.byref(dfac),
+                                      _p(out6), _p(S), _p(rhs))
+        return dict(cost_before=out6[0], cost_after=out6[1], model_cost_change=out6[2], rho=out6[3], accepted=bool(out6[4]),
+                    solved=bool(out6[5]), radius=r.value, decrease_factor=dfac.value, S=S, rhs=rhs)

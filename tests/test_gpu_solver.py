@@ -1,0 +1,103 @@
+"""GPU parity of the sliding-window BA solver (lvf_problem_*) against the oracle's LM iteration
+(oracle/lm.h: dense normal equations + exact Schur on the inverse-depth blocks) from identical state."""
+import numpy as np
+import pytest
+
+from lvio_fusion_amd import synthetic as syn
+from tests.helpers import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lvio_fusion_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def build(api, ctx, oracle, n_kf, n_lm, seed, n_pre=40, use=("tc", "tf", "po", "imu")):
+    cfg = syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=n_pre, seed=seed, imu_samples=5)
+    pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+    st = api.State(ctx, n_kf, n_lm)
+    for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth"), (api.W_VISUAL, "w_kf")):
+        st.set(field, cfg[key])
+    tc, tf, po = cfg["tc"], cfg["tf"], cfg["po"]
+    b = dict(
+        tc=api.two_camera_batch(ctx, cfg["cam0"], cfg["cam1"], tc["left_ob"], tc["right_ob"], tc["lm_idx"], tc["kf_idx"]) if "tc" in use else None,
+        tf=api.two_frame_batch(ctx, cfg["cam0"], cfg["cam1"], tf["first_ob"], tf["ob"], tf["lm_idx"], tf["kf1_idx"], tf["kf2_idx"]) if "tf" in use else None,
+        po=api.pose_only_batch(ctx, cfg["cam0"], po["ob"], po["kf_idx"], po["pw_idx"], po["pw"]) if "po" in use else None,
+        imu=api.imu_batch(ctx, pre, [f["kf_i"] for f in cfg["imu"]], [f["kf_j"] for f in cfg["imu"]]) if "imu" in use else None)
+    prob = api.Problem(ctx, st, b["tc"], b["tf"], b["po"], b["imu"])
+    win = oracle.Window(cfg, pre, use=use)
+    return cfg, st, b, prob, win
+
+
+def state_of(api, st):
+    return {k: st.get(f) for k, f in (("poses", api.POSES), ("vel", api.VEL), ("ba", api.BA), ("bg", api.BG), ("inv_depth", api.INV_DEPTH))}
+
+
+@pytest.mark.parametrize("n_kf,n_lm,seed,use", [(8, 120, 3, ("tc", "tf", "po", "imu")), (12, 300, 5, ("tc", "tf", "po", "imu")),
+                                                (6, 80, 7, ("tc", "tf", "po")), (5, 0, 9, ("po", "imu"))])
+def test_lm_iteration_parity(ctx, oracle, n_kf, n_lm, seed, use):
+    from lvio_fusion_amd import api
+    if n_lm == 0:
+        use = tuple(u for u in use if u in ("po", "imu"))
+    cfg, st, b, prob, win = build(api, ctx, oracle, n_kf, max(n_lm, 1), seed, use=use)
+    opt = api.default_solver_options()
+    c_gpu = prob.cost(opt)
+    assert abs(c_gpu - win.cost()) <= 1e-9 * abs(c_gpu)
+    radius, dec = 1e4, 2.0
+    for it in range(4):
+        ref = win.lm_iteration(radius, dec)
+        got = prob.lm_iteration(opt, radius, dec)
+        assert abs(got["cost_before"] - ref["cost_before"]) <= 1e-8 * abs(ref["cost_before"])
+        S, rhs = prob.reduced_system()
+        scale = np.abs(ref["S"]).max()
+        assert np.abs(S - ref["S"]).max() <= 1e-7 * scale, f"iteration {it}: reduced system mismatch"
+        assert_parity(rhs, ref["rhs"], f"rhs it{it}")
+        assert got["accepted"] == ref["accepted"]
+        assert abs(got["cost_after"] - ref["cost_after"]) <= 1e-6 * abs(ref["cost_after"])
+        assert abs(got["radius"] - ref["radius"]) <= 1e-5 * ref["radius"]
+        s = state_of(api, st)
+        assert_parity(s["poses"].reshape(-1, 7), win.poses, f"poses it{it}")
+        assert_parity(s["inv_depth"], win.inv_depth, f"inv_depth it{it}")
+        assert_parity(s["vel"].reshape(-1, 3), win.vel, f"vel it{it}")
+        assert_parity(s["ba"].reshape(-1, 3), win.ba, f"ba it{it}")
+        assert_parity(s["bg"].reshape(-1, 3), win.bg, f"bg it{it}")
+        radius, dec = ref["radius"], ref["decrease_factor"]
+    for h in list(b.values()) + [st]:
+        if h is not None:
+            h.close()
+    prob.close()
+
+
+def test_solve_reduces_cost_and_pose_error(ctx, oracle):
+    from lvio_fusion_amd import api
+    cfg, st, b, prob, win = build(api, ctx, oracle, 10, 200, 21)
+    opt = api.default_solver_options()
+    opt.max_num_iterations = 15
+    e0 = np.abs(cfg["poses"] - cfg["poses_true"]).max()
+    summ = prob.solve(opt)
+    assert summ.final_cost < 0.2 * summ.initial_cost
+    assert summ.num_successful_steps >= 3
+    e1 = np.abs(st.get(api.POSES).reshape(-1, 7) - cfg["poses_true"]).max()
+    assert e1 < 0.5 * e0
+    # quaternions stay unit length under the EigenQuaternion plus operation
+    q = st.get(api.POSES).reshape(-1, 7)[:, :4]
+    assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-9)
+    prob.close()
+
+
+def test_constant_pose_is_not_moved(ctx, oracle):
+    from lvio_fusion_amd import api
+    cfg, st, b, prob, win = build(api, ctx, oracle, 6, 60, 33, use=("tc", "tf", "po"))
+    prob.set_pose_constant(0, True)
+    opt = api.default_solver_options()
+    p0 = st.get(api.POSES).reshape(-1, 7).copy()
+    r = prob.lm_iteration(opt, 1e4)
+    assert r["accepted"]
+    p1 = st.get(api.POSES).reshape(-1, 7)
+    assert np.abs(p1[0] - p0[0]).max() < 1e-12 and np.abs(p1[1:] - p0[1:]).max() > 1e-6
+    prob.close()
