@@ -143,7 +143,40 @@ def extras(api, syn, ctx):
                               "valid_frac": float(sc.download()[2].mean())}
     ex["icp_mpairs_per_sec"] = ex["knn3_ground_thr4.0"]["mpairs_per_s"]
     mp.close(); sc.close()
+    ex["full_window_ba"] = full_window(api, syn, ctx)
     return ex
+
+
+def full_window(api, syn, ctx, iters=30):
+    """configs[3]: 50 KF / 10k landmarks full sliding-window problem; one step = one complete LM iteration
+    (linearise all factors, Schur-eliminate inverse depths, Cholesky, back-substitute, evaluate the candidate)."""
+    cfg = syn.config4_window()
+    pre = api.preintegrate_or_none(ctx, cfg)
+    st = api.State(ctx, cfg["n_kf"], cfg["n_lm"])
+    for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth"), (api.W_VISUAL, "w_kf")):
+        st.set(field, cfg[key])
+    tc, tf, po = cfg["tc"], cfg["tf"], cfg["po"]
+    btc = api.two_camera_batch(ctx, cfg["cam0"], cfg["cam1"], tc["left_ob"], tc["right_ob"], tc["lm_idx"], tc["kf_idx"])
+    btf = api.two_frame_batch(ctx, cfg["cam0"], cfg["cam1"], tf["first_ob"], tf["ob"], tf["lm_idx"], tf["kf1_idx"], tf["kf2_idx"])
+    bpo = api.pose_only_batch(ctx, cfg["cam0"], po["ob"], po["kf_idx"], po["pw_idx"], po["pw"])
+    bimu = api.imu_batch(ctx, pre, [f["kf_i"] for f in cfg["imu"]], [f["kf_j"] for f in cfg["imu"]]) if pre is not None else None
+    prob = api.Problem(ctx, st, btc, btf, bpo, bimu)
+    opt = api.default_solver_options()
+    radius, dec, costs = 1e4, 2.0, []
+    for _ in range(3):
+        r = prob.lm_iteration(opt, radius, dec); radius, dec = r["radius"], r["decrease_factor"]; costs.append(r["cost_before"])
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        r = prob.lm_iteration(opt, radius, dec); radius, dec = r["radius"], r["decrease_factor"]
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    out = {"n_kf": cfg["n_kf"], "n_lm": cfg["n_lm"], "blocks": {"two_camera": btc.n, "two_frame": btf.n, "pose_only": bpo.n, "imu": bimu.n if bimu else 0},
+           "ms_per_lm_iteration": 1e3 * dt, "lm_iters_per_sec": 1.0 / dt, "cost_first": costs[0], "cost_last": r["cost_after"]}
+    for h in (prob, btc, btf, bpo, bimu, st):
+        if h is not None:
+            h.close()
+    return out
 
 
 def cpu_baseline(cfg, n_blocks):

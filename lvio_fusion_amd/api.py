@@ -187,6 +187,16 @@ def preintegrate(ctx, samples_list, acc0, gyr0, ba, bg, noise4):
     return out
 
 
+def preintegrate_or_none(ctx, cfg):
+    """Device pre-integration of a synthetic window's IMU samples (None when the window has no IMU factors)."""
+    from . import synthetic as syn
+    imu = cfg["imu"]
+    if not imu:
+        return None
+    return preintegrate(ctx, [f["samples"] for f in imu], np.stack([f["acc0"] for f in imu]), np.stack([f["gyr0"] for f in imu]),
+                        np.stack([f["ba"] for f in imu]), np.stack([f["bg"] for f in imu]), syn.IMU_NOISE)
+
+
 class Map:
     def __init__(self, ctx, xyz, max_radius2):
         a = _f(xyz)

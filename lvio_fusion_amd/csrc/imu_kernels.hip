@@ -241,6 +241,123 @@ __global__ __launch_bounds__(64) void k_imu(int n, const double* __restrict__ pr
   }
 }
 
+// --------------------------------------------------------------------------------- pre-integration (K5)
+// One workgroup per keyframe pair; the chain over IMU samples is sequential (each sample needs the previous delta_q,
+// jacobian and covariance) but the 15x15 products  jac <- F jac,  cov <- F cov F^T + V N V^T  are spread over the
+// 256 threads with F, V, jac, cov resident in LDS.  Mid-point rule and F/V blocks: preintegration.cpp:30-127.
+__device__ __forceinline__ void mm3(const double A[9], const double B[9], double C[9]) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+__device__ __forceinline__ void skew9(const double v[3], double S[9]) {
+  S[0] = 0; S[1] = -v[2]; S[2] = v[1]; S[3] = v[2]; S[4] = 0; S[5] = -v[0]; S[6] = -v[1]; S[7] = v[0]; S[8] = 0;
+}
+__global__ __launch_bounds__(256) void k_preintegrate(const int* __restrict__ offset, const double* __restrict__ samples,
+                                                      const double* __restrict__ acc0_, const double* __restrict__ gyr0_,
+                                                      const double* __restrict__ ba_, const double* __restrict__ bg_,
+                                                      double acc_n, double gyr_n, double acc_w, double gyr_w,
+                                                      double* __restrict__ out) {
+  __shared__ double sJ[225], sC[225], sF[225], sV[270], sT[225], sN[18];
+  __shared__ double sState[24];   // dp 0..2, dq 3..6 (x,y,z,w), dv 7..9, acc0 10..12, gyr0 13..15, sum_dt 16
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const double* lba = ba_ + 3 * f; const double* lbg = bg_ + 3 * f;
+  if (tid < 225) { sJ[tid] = (tid % 16 == 0) ? 1.0 : 0.0; sC[tid] = 0.0; }
+  if (tid < 18) { const int b = tid / 3; sN[tid] = (b == 0 || b == 2) ? acc_n * acc_n : (b == 1 || b == 3) ? gyr_n * gyr_n : (b == 4 ? acc_w * acc_w : gyr_w * gyr_w); }
+  if (tid == 0) {
+    for (int k = 0; k < 3; ++k) { sState[k] = 0.0; sState[7 + k] = 0.0; sState[10 + k] = acc0_[3 * f + k]; sState[13 + k] = gyr0_[3 * f + k]; }
+    sState[3] = sState[4] = sState[5] = 0.0; sState[6] = 1.0; sState[16] = 0.0;
+  }
+  __syncthreads();
+  for (int sidx = offset[f]; sidx < offset[f + 1]; ++sidx) {
+    if (tid == 0) {
+      const double* smp = samples + 7 * sidx;
+      const double dt = smp[0];
+      const double* acc1 = smp + 1; const double* gyr1 = smp + 4;
+      double a0b[3], a1b[3], ug[3];
+      for (int k = 0; k < 3; ++k) { a0b[k] = sState[10 + k] - lba[k]; a1b[k] = acc1[k] - lba[k]; ug[k] = 0.5 * (sState[13 + k] + gyr1[k]) - lbg[k]; }
+      const Qd dq{sState[3], sState[4], sState[5], sState[6]};
+      double ua0[3], ua1[3];
+      qrot(dq, a0b, ua0);
+      const Qd rq = qmul(dq, Qd{ug[0] * dt / 2, ug[1] * dt / 2, ug[2] * dt / 2, 1.0});
+      qrot(rq, a1b, ua1);
+      double R0[9], R1[9], Rw[9], Ra0[9], Ra1[9], ImRw[9], R0a0[9], R1a1[9], R1a1I[9];
+      qmat(dq, R0); qmat(rq, R1); skew9(ug, Rw); skew9(a0b, Ra0); skew9(a1b, Ra1);
+      for (int k = 0; k < 9; ++k) ImRw[k] = ((k % 4 == 0) ? 1.0 : 0.0) - Rw[k] * dt;
+      mm3(R0, Ra0, R0a0); mm3(R1, Ra1, R1a1); mm3(R1a1, ImRw, R1a1I);
+      for (int k = 0; k < 225; ++k) sF[k] = 0.0;
+      for (int k = 0; k < 270; ++k) sV[k] = 0.0;
+#define FF(r, c) sF[(r) * 15 + (c)]
+#define VV(r, c) sV[(r) * 18 + (c)]
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          const double I = (i == j) ? 1.0 : 0.0;
+          const int e = 3 * i + j;
+          FF(i, j) = I;
+          FF(i, 3 + j) = -0.25 * R0a0[e] * dt * dt + -0.25 * R1a1I[e] * dt * dt;
+          FF(i, 6 + j) = I * dt;
+          FF(i, 9 + j) = -0.25 * (R0[e] + R1[e]) * dt * dt;
+          FF(i, 12 + j) = -0.25 * R1a1[e] * dt * dt * -dt;
+          FF(3 + i, 3 + j) = ImRw[e];
+          FF(3 + i, 12 + j) = -1.0 * I * dt;
+          FF(6 + i, 3 + j) = -0.5 * R0a0[e] * dt + -0.5 * R1a1I[e] * dt;
+          FF(6 + i, 6 + j) = I;
+          FF(6 + i, 9 + j) = -0.5 * (R0[e] + R1[e]) * dt;
+          FF(6 + i, 12 + j) = -0.5 * R1a1[e] * dt * -dt;
+          FF(9 + i, 9 + j) = I;
+          FF(12 + i, 12 + j) = I;
+          VV(i, j) = 0.25 * R0[e] * dt * dt;
+          VV(i, 3 + j) = 0.25 * -R1a1[e] * dt * dt * 0.5 * dt;
+          VV(i, 6 + j) = 0.25 * R1[e] * dt * dt;
+          VV(i, 9 + j) = VV(i, 3 + j);
+          VV(3 + i, 3 + j) = 0.5 * I * dt;
+          VV(3 + i, 9 + j) = 0.5 * I * dt;
+          VV(6 + i, j) = 0.5 * R0[e] * dt;
+          VV(6 + i, 3 + j) = 0.5 * -R1a1[e] * dt * 0.5 * dt;
+          VV(6 + i, 6 + j) = 0.5 * R1[e] * dt;
+          VV(6 + i, 9 + j) = VV(6 + i, 3 + j);
+          VV(9 + i, 12 + j) = I * dt;
+          VV(12 + i, 15 + j) = I * dt;
+        }
+#undef FF
+#undef VV
+      // state update (Propagate tail, preintegration.cpp:116-126): delta_q is re-normalised
+      for (int k = 0; k < 3; ++k) {
+        const double ua = 0.5 * (ua0[k] + ua1[k]);
+        const double np = sState[k] + sState[7 + k] * dt + 0.5 * ua * dt * dt;
+        const double nv = sState[7 + k] + ua * dt;
+        sState[k] = np; sState[7 + k] = nv; sState[10 + k] = acc1[k]; sState[13 + k] = gyr1[k];
+      }
+      const double nq = sqrt(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
+      sState[3] = rq.x / nq; sState[4] = rq.y / nq; sState[5] = rq.z / nq; sState[6] = rq.w / nq;
+      sState[16] += dt;
+    }
+    __syncthreads();
+    double nj = 0.0, fc = 0.0;
+    const int r = tid / 15, c = tid % 15;
+    if (tid < 225) {
+      for (int k = 0; k < 15; ++k) { nj += sF[r * 15 + k] * sJ[k * 15 + c]; fc += sF[r * 15 + k] * sC[k * 15 + c]; }
+      sT[tid] = fc;
+    }
+    __syncthreads();
+    double nc = 0.0;
+    if (tid < 225) {
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < 15; ++k) a += sT[r * 15 + k] * sF[c * 15 + k];
+      for (int k = 0; k < 18; ++k) b += sV[r * 18 + k] * sN[k] * sV[c * 18 + k];
+      nc = a + b;
+    }
+    __syncthreads();
+    if (tid < 225) { sJ[tid] = nj; sC[tid] = nc; }
+    __syncthreads();
+  }
+  double* o = out + (size_t)f * kPre;
+  if (tid == 0) {
+    o[OFF_SUMDT] = sState[16];
+    for (int k = 0; k < 3; ++k) { o[OFF_LBA + k] = lba[k]; o[OFF_LBG + k] = lbg[k]; o[OFF_DP + k] = sState[k]; o[OFF_DV + k] = sState[7 + k]; }
+    for (int k = 0; k < 4; ++k) o[OFF_DQ + k] = sState[3 + k];
+  }
+  if (tid < 225) { o[OFF_JAC + tid] = sJ[tid]; o[OFF_COV + tid] = sC[tid]; }
+}
+
 int launch_imu_sqrt_info(lvf_batch* b) {
   if (b->n == 0) return LVF_OK;
   hipLaunchKernelGGL(k_imu_sqrt_info, dim3((b->n + 63) / 64), dim3(64), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p);
@@ -263,3 +380,28 @@ int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j) {
 }
 
 }  // namespace lvf
+
+using namespace lvf;
+extern "C" int lvf_preintegrate(lvf_ctx* ctx, int n, const int32_t* offset, const double* samples, const double* acc0, const double* gyr0,
+                                const double* ba, const double* bg, const double* noise4, lvf_preint* out) {
+  LVF_REQUIRE(ctx && noise4 && (n == 0 || (offset && acc0 && gyr0 && ba && bg && out)), "lvf_preintegrate: null argument");
+  LVF_REQUIRE(n >= 0, "lvf_preintegrate: negative count");
+  if (n == 0) return LVF_OK;
+  LVF_REQUIRE(offset[0] == 0, "lvf_preintegrate: offset[0] must be 0");
+  for (int k = 0; k < n; ++k) LVF_REQUIRE(offset[k + 1] >= offset[k], "lvf_preintegrate: offsets must be non-decreasing");
+  const int ns = offset[n];
+  LVF_REQUIRE(ns == 0 || samples, "lvf_preintegrate: samples is null");
+  LVF_HIP(hipSetDevice(ctx->device));
+  hipStream_t q = ctx->stream;
+  DevBuf<int> d_off; DevBuf<double> d_s, d_a0, d_g0, d_ba, d_bg, d_out;
+  LVF_TRY(d_off.upload(offset, n + 1, q)); LVF_TRY(d_s.upload(samples, (size_t)7 * ns, q));
+  LVF_TRY(d_a0.upload(acc0, (size_t)3 * n, q)); LVF_TRY(d_g0.upload(gyr0, (size_t)3 * n, q));
+  LVF_TRY(d_ba.upload(ba, (size_t)3 * n, q)); LVF_TRY(d_bg.upload(bg, (size_t)3 * n, q));
+  LVF_TRY(d_out.alloc((size_t)kPre * n));
+  hipLaunchKernelGGL(k_preintegrate, dim3(n), dim3(256), 0, q, d_off.p, d_s.p, d_a0.p, d_g0.p, d_ba.p, d_bg.p, noise4[0], noise4[1], noise4[2],
+                     noise4[3], d_out.p);
+  LVF_HIP(hipGetLastError());
+  LVF_HIP(hipMemcpyAsync(out, d_out.p, (size_t)kPre * n * 8, hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipStreamSynchronize(q));
+  return LVF_OK;
+}

@@ -16,6 +16,7 @@
 #include "factor_eval.hpp"
 #include "lvf_internal.hpp"
 
+namespace lvf { struct TfWork; }
 struct lvf_problem {
   lvf_ctx* ctx = nullptr;
   lvf_state* st = nullptr;
@@ -25,6 +26,7 @@ struct lvf_problem {
   lvf::DevBuf<double> poses2, vel2, ba2, bg2, invd2;   // candidate state x + dx
   lvf::DevBuf<uint8_t> pose_const;
   lvf::DevBuf<int> fail;
+  lvf::DevBuf<lvf::TfWork> tf_work;   // per-workgroup runs of same-k2 blocks (empty => generic atomic path)
   std::vector<uint8_t> pose_const_h;
   bool linearized = false;
   double last_radius = 0;
@@ -133,6 +135,102 @@ __global__ __launch_bounds__(kT) void k_lin_tf(int n, int n_kf, const double2* _
     }
   }
   block_add(c, cost);
+}
+
+// TwoFrame linearisation, fast path: blocks sorted by CURRENT keyframe k2 and every workgroup handed a run of blocks that
+// share one k2 (host-built work list).  Then
+//   * B[k2,k2] and g[k2] are wave-shuffle reductions (one LDS add per wave, one global flush per workgroup),
+//   * B[k1,k1], g[k1] and the cross block B[k2,k1] only depend on k1 <= n_kf: accumulated with ds_add_f64 in a
+//     [n_kf][63] LDS table and flushed once per workgroup (non-zero entries only),
+//   * only the landmark-indexed sums (C, g_rho, E rows) remain global atomics: 14 per block instead of 134.
+struct TfWork { int first, count, k2; };
+constexpr int kAccSlots = 63;   // 21 (B[k1,k1] lower) + 6 (g[k1]) + 36 (cross block, rows = k2 tangent, cols = k1 tangent)
+__global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__ work, int n_kf, const double2* __restrict__ fo,
+                                                      const double2* __restrict__ ob, const int* __restrict__ lm,
+                                                      const int* __restrict__ kf1, StateP s, CamD left, CamD right, double huber,
+                                                      const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
+                                                      double* __restrict__ gc, double* __restrict__ E, int ldE,
+                                                      double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost) {
+  __shared__ PoseD s_pose[kMaxStagedKf];
+  __shared__ double s_acc[kMaxStagedKf * kAccSlots];
+  __shared__ double s_k2[27];
+  const TfWork w = work[blockIdx.x];
+  for (int e = threadIdx.x; e < n_kf * kAccSlots; e += kT) s_acc[e] = 0.0;
+  if (threadIdx.x < 27) s_k2[threadIdx.x] = 0.0;
+  stage_poses<kT>(s_pose, s.poses, n_kf);   // ends with __syncthreads()
+  const int k2 = w.k2;
+  double c = 0.0;
+  double v[27];
+#pragma unroll
+  for (int q = 0; q < 27; ++q) v[q] = 0.0;
+  if ((int)threadIdx.x < w.count) {
+    const int i = w.first + threadIdx.x;
+    const int l = lm[i], k1 = kf1[i];
+    const double2 a = fo[i], b = ob[i];
+    double r[2], Jd[2], J1[14], J2[14];
+    eval_two_frame<true>(s_pose[k1], s_pose[k2], left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], s.w_kf[k2], r, Jd, J1, J2);
+    double rho;
+    const double sc = robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
+    c = 0.5 * rho;
+    double L1[12], L2[12];
+    pose_rows_to_local(J1, s.poses + 7 * k1, pose_const[k1] ? 0.0 : sc, L1);
+    pose_rows_to_local(J2, s.poses + 7 * k2, pose_const[k2] ? 0.0 : sc, L2);
+    const double r0 = sc * r[0], r1 = sc * r[1], d0 = sc * Jd[0], d1 = sc * Jd[1];
+    atomicAdd(&C[l], d0 * d0 + d1 * d1);
+    atomicAdd(&gr[l], d0 * r0 + d1 * r1);
+    double* el = E + (size_t)l * ldE;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      atomicAdd(&el[6 * k1 + q], L1[q] * d0 + L1[6 + q] * d1);
+      atomicAdd(&el[6 * k2 + q], L2[q] * d0 + L2[6 + q] * d1);
+    }
+    double* acc = s_acc + k1 * kAccSlots;
+    int q = 0;
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int y = 0; y <= x; ++y) { atomicAdd(&acc[q], L1[x] * L1[y] + L1[6 + x] * L1[6 + y]); v[q] = L2[x] * L2[y] + L2[6 + x] * L2[6 + y]; ++q; }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) { atomicAdd(&acc[21 + x], L1[x] * r0 + L1[6 + x] * r1); v[21 + x] = L2[x] * r0 + L2[6 + x] * r1; }
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int y = 0; y < 6; ++y) atomicAdd(&acc[27 + 6 * x + y], L2[x] * L1[y] + L2[6 + x] * L1[6 + y]);
+  }
+#pragma unroll
+  for (int q = 0; q < 27; ++q) v[q] = wave_sum(v[q]);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < 27; ++q) if (v[q] != 0.0) atomicAdd(&s_k2[q], v[q]);
+  }
+  block_add(c, cost);
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const double val = s_k2[threadIdx.x];
+    if (val != 0.0) {
+      if (threadIdx.x < 21) {
+        int x = 0, rem = threadIdx.x;
+        while (rem > x) { rem -= x + 1; ++x; }
+        atomicAdd(&B[(size_t)(6 * k2 + x) * ld + 6 * k2 + rem], val);
+      } else atomicAdd(&gc[6 * k2 + threadIdx.x - 21], val);
+    }
+  }
+  for (int e = threadIdx.x; e < n_kf * kAccSlots; e += kT) {
+    const double val = s_acc[e];
+    if (val == 0.0) continue;
+    const int k1 = e / kAccSlots, slot = e % kAccSlots;
+    if (slot < 21) {
+      int x = 0, rem = slot;
+      while (rem > x) { rem -= x + 1; ++x; }
+      atomicAdd(&B[(size_t)(6 * k1 + x) * ld + 6 * k1 + rem], val);
+    } else if (slot < 27) {
+      atomicAdd(&gc[6 * k1 + slot - 21], val);
+    } else {
+      const int x = (slot - 27) / 6, y = (slot - 27) % 6;   // x: k2 tangent index, y: k1 tangent index
+      if (k2 > k1) atomicAdd(&B[(size_t)(6 * k2 + x) * ld + 6 * k1 + y], val);
+      else atomicAdd(&B[(size_t)(6 * k1 + y) * ld + 6 * k2 + x], val);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ PoseOnly
@@ -324,48 +422,75 @@ __global__ __launch_bounds__(64) void k_schur_syrk(int n_lm, int dp, int ldE, in
 }
 
 // ------------------------------------------------------------------------------------------------ blocked Cholesky (64)
+// Right-looking, block 64, TWO launches per block step:
+//   k_chol_factor_panel : every workgroup (one wave) re-factors the 64x64 diagonal block in REGISTERS (lane i owns row i,
+//                         loops fully unrolled so the row lives in 128 VGPRs; column entries of other rows arrive as
+//                         v_readlane scalars), then solves its own 64x64 panel block X L^T = A row-per-lane against an
+//                         LDS copy of L (broadcast reads).  Redundant factorisation costs no wall time
+//                         (all waves run it concurrently) and removes a dependent launch.
+//   k_chol_update       : trailing A[bi][bj] -= P_bi P_bj^T.
+// The sequential critical path is ~64 x (sqrt + div + broadcast) per block; everything else is wide.
 constexpr int kNB = 64, kLd = 65;
-// factor the diagonal block kb in place (one wave; right-looking in LDS)
-__global__ __launch_bounds__(64) void k_chol_diag(double* __restrict__ S, int ld, int kb, int* __restrict__ fail) {
-  __shared__ double T[kNB * kLd];
+
+__device__ __forceinline__ void load_row64(const double* __restrict__ g, double a[kNB]) {
+  const double2* g2 = reinterpret_cast<const double2*>(g);
+#pragma unroll
+  for (int c = 0; c < kNB / 2; ++c) { const double2 v = g2[c]; a[2 * c] = v.x; a[2 * c + 1] = v.y; }
+}
+__device__ __forceinline__ void store_row64(double* __restrict__ g, const double a[kNB]) {
+  double2* g2 = reinterpret_cast<double2*>(g);
+#pragma unroll
+  for (int c = 0; c < kNB / 2; ++c) g2[c] = make_double2(a[2 * c], a[2 * c + 1]);
+}
+
+// broadcast of one lane's double through v_readlane (scalar result: no VGPR, no LDS round trip)
+__device__ __forceinline__ double lane_bcast(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void k_chol_factor_panel(double* __restrict__ S, int ld, int kb, int* __restrict__ fail) {
+  __shared__ double Lk[kNB * kLd];   // factored diagonal block, row-major padded
   const int lane = threadIdx.x;
-  double* blk = S + (size_t)(kb * kNB) * ld + kb * kNB;
-  for (int r = 0; r < kNB; ++r) T[r * kLd + lane] = (lane <= r) ? blk[(size_t)r * ld + lane] : 0.0;
-  __syncthreads();
+  double a[kNB];
+  load_row64(S + (size_t)(kb * kNB + lane) * ld + kb * kNB, a);   // lane owns row `lane` of the diagonal block
+  bool bad = false;
+#pragma unroll
   for (int j = 0; j < kNB; ++j) {
-    const double djj = T[j * kLd + j];
-    if (!(djj > 0.0)) { if (lane == 0) atomicExch(fail, 1 + kb * kNB + j); }
+    const double djj = lane_bcast(a[j], j);          // pivot A_jj (already updated) from lane j
+    bad |= !(djj > 0.0);
     const double l = sqrt(fmax(djj, 1e-300));
-    double cij = 0.0;
-    if (lane > j) { cij = T[lane * kLd + j] / l; T[lane * kLd + j] = cij; }
-    if (lane == j) T[j * kLd + j] = l;
-    __syncthreads();
-    for (int t = j + 1; t < kNB; ++t) {
-      const double ctj = T[t * kLd + j];            // broadcast
-      if (lane >= t) T[lane * kLd + t] -= cij * ctj;
-    }
-    __syncthreads();
+    const double inv_l = 1.0 / l;
+    a[j] = (lane == j) ? l : a[j] * inv_l;           // lanes < j hold upper-triangle garbage there; never used
+#pragma unroll
+    for (int t = j + 1; t < kNB; ++t) a[t] -= a[j] * lane_bcast(a[j], t);   // A_it -= L_ij L_tj (meaningful for i >= t)
   }
-  for (int r = 0; r < kNB; ++r) if (lane <= r) blk[(size_t)r * ld + lane] = T[r * kLd + lane];
-}
-// panel: rows below the diagonal block: X = A L_kk^-T, one thread per row (left-looking forward substitution)
-__global__ __launch_bounds__(64) void k_chol_panel(double* __restrict__ S, int ld, int kb) {
-  __shared__ double Lk[kNB * kLd];
-  __shared__ double X[kNB * kLd];
-  const int lane = threadIdx.x;
-  const double* dblk = S + (size_t)(kb * kNB) * ld + kb * kNB;
-  double* ablk = S + (size_t)((kb + 1 + blockIdx.x) * kNB) * ld + kb * kNB;
-  for (int r = 0; r < kNB; ++r) { Lk[r * kLd + lane] = dblk[(size_t)r * ld + lane]; X[r * kLd + lane] = ablk[(size_t)r * ld + lane]; }
+  if (bad && lane == 0) atomicExch(fail, 1 + kb);
+#pragma unroll
+  for (int c = 0; c < kNB; ++c) Lk[lane * kLd + c] = (c <= lane) ? a[c] : 0.0;
   __syncthreads();
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) if (c > lane) a[c] = 0.0;
+    store_row64(S + (size_t)(kb * kNB + lane) * ld + kb * kNB, a);
+    return;
+  }
+  // panel block (kb + blockIdx.x, kb): X L^T = A, lane owns one row of X
+  double* arow = S + (size_t)((kb + blockIdx.x) * kNB + lane) * ld + kb * kNB;
+  double x[kNB];
+  load_row64(arow, x);
+#pragma unroll
   for (int j = 0; j < kNB; ++j) {
-    double s = X[lane * kLd + j];
-    for (int t = 0; t < j; ++t) s -= X[lane * kLd + t] * Lk[j * kLd + t];
-    X[lane * kLd + j] = s / Lk[j * kLd + j];
+    double s = x[j];
+#pragma unroll
+    for (int t = 0; t < j; ++t) s -= x[t] * Lk[j * kLd + t];   // broadcast LDS reads, static addresses
+    x[j] = s / Lk[j * kLd + j];
   }
-  __syncthreads();
-  for (int r = 0; r < kNB; ++r) ablk[(size_t)r * ld + lane] = X[r * kLd + lane];
+  store_row64(arow, x);
 }
-// trailing update: A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi
+
+// trailing update: A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi; 256 threads, 4x4 register tile each
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int ld, int kb) {
   __shared__ double Pi[kNB * kLd];
   __shared__ double Pj[kNB * kLd];
@@ -382,14 +507,15 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
   __syncthreads();
   const int tr = (threadIdx.x >> 4) * 4, tc = (threadIdx.x & 15) * 4;
   double acc[4][4] = {};
+#pragma unroll 8
   for (int k = 0; k < kNB; ++k) {
-    double a[4], b[4];
+    double av[4], bv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { a[q] = Pi[(tr + q) * kLd + k]; b[q] = Pj[(tc + q) * kLd + k]; }
+    for (int q = 0; q < 4; ++q) { av[q] = Pi[(tr + q) * kLd + k]; bv[q] = Pj[(tc + q) * kLd + k]; }
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
+      for (int y = 0; y < 4; ++y) acc[x][y] += av[x] * bv[y];
   }
   double* out = S + (size_t)(bi * kNB) * ld + bj * kNB;
 #pragma unroll
@@ -397,39 +523,43 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
 #pragma unroll
     for (int y = 0; y < 4; ++y) out[(size_t)(tr + x) * ld + tc + y] -= acc[x][y];
 }
-// back substitution x = L^-T y with y = augmented row L[d][0..d); single workgroup
-__global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ S, int ld, int d, double* __restrict__ x) {
-  extern __shared__ double y[];   // d doubles + a 64x65 block
-  double* Lb = y + ((d + 63) / 64) * 64;
-  const int tid = threadIdx.x;
-  const int nblk = (d + kNB - 1) / kNB;
-  for (int i = tid; i < nblk * kNB; i += 256) y[i] = (i < d) ? S[(size_t)d * ld + i] : 0.0;
+
+// back substitution x = L^-T y with y = augmented row L[d][0..d); single workgroup of 256 threads.
+// Per block (bottom-up): (a) 4-way split gather  y_c -= sum_{r > block} L[r][c] x_r  (rows r are contiguous over c:
+// coalesced), (b) one wave solves the 64x64 transposed triangle with the block's COLUMNS in registers.
+__global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ S, int ld, int d, double* __restrict__ xout) {
+  extern __shared__ double sm[];          // x[nblk*64] | part[4][64]
+  const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
+  const int nblk = (d + kNB - 1) / kNB, n = nblk * kNB;
+  double* x = sm;
+  double* partial = sm + n;
+  for (int i = tid; i < n; i += 256) x[i] = 0.0;
   __syncthreads();
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int r0 = kb * kNB;
-    for (int e = tid; e < kNB * kNB; e += 256) { const int r = e >> 6, c = e & 63; Lb[r * kLd + c] = S[(size_t)(r0 + r) * ld + r0 + c]; }
+    double s = 0.0;
+    for (int r = r0 + kNB + part; r < min(n, d); r += 4) s += S[(size_t)r * ld + r0 + c] * x[r];
+    partial[part * kNB + c] = s;
     __syncthreads();
-    if (tid < 64) {   // one wave: L_kk^T x = y_kb, backwards
+    if (tid < 64) {
+      const int lane = tid;
+      double y = (r0 + lane < d) ? S[(size_t)d * ld + r0 + lane] : 0.0;
+      y -= partial[lane] + partial[kNB + lane] + partial[2 * kNB + lane] + partial[3 * kNB + lane];
+      double a[kNB];                      // a[j] = L[r0 + j][r0 + lane]  (column `lane` of the block), j >= lane
+#pragma unroll
+      for (int j = 0; j < kNB; ++j) a[j] = (j >= lane && r0 + j < d) ? S[(size_t)(r0 + j) * ld + r0 + lane] : ((j == lane) ? 1.0 : 0.0);
+#pragma unroll
       for (int j = kNB - 1; j >= 0; --j) {
-        const bool live = (r0 + j) < d;
-        const double xj = live ? y[r0 + j] / Lb[j * kLd + j] : 0.0;   // broadcast read, same value in every lane
-        if (tid == j) y[r0 + j] = xj;
-        if (tid < j) y[r0 + tid] -= Lb[j * kLd + tid] * xj;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this step visible to the next
+        // x_j = y_j / L_jj on lane j, broadcast, then y_t -= L[j][t] x_j on lanes t < j
+        const double xj = __shfl((lane == j) ? y / a[j] : 0.0, j);
+        if (lane == j) y = xj;
+        else if (lane < j) y -= a[j] * xj;
       }
-    }
-    __syncthreads();
-    // y_i -= sum_c L[r0+c][i] x_c for all i < r0 (row r0+c of L, columns i: coalesced over i)
-    for (int i = tid; i < r0; i += 256) {
-      double s = 0.0;
-      const int cmax = min(kNB, d - r0);
-      for (int c = 0; c < cmax; ++c) s += S[(size_t)(r0 + c) * ld + i] * y[r0 + c];
-      y[i] -= s;
+      x[r0 + lane] = (r0 + lane < d) ? y : 0.0;
     }
     __syncthreads();
   }
-  for (int i = tid; i < d; i += 256) x[i] = y[i];
+  for (int i = tid; i < d; i += 256) xout[i] = x[i];
 }
 
 // ------------------------------------------------------------------------------------------------ step pieces
@@ -449,22 +579,22 @@ __global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE,
     for (int i = 0; i < dp; ++i) ed += e[i] * sdx[i];
     const double dl = (-gr[l] - ed) / Cd[l];
     dxl[l] = dl;
-    m = dl * (gr[l] + 0.5 * C[l] * dl) + dl * ed;
+    m = -0.5 * dl * ((Cd[l] - C[l]) * dl - gr[l]);
     n2 = dl * dl; x2 = inv_depth[l] * inv_depth[l];
   }
   block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM); block_add(x2, scal + SC_XNORM);
 }
-// camera part of the model: sum_i dc_i (gc_i + (B dc)_i / 2), B symmetric stored lower
+// Model cost change without a pass over H:  (H + D) dx = -g  =>  -dx^T (g + H dx / 2) = 1/2 sum_i dx_i (D_i dx_i - g_i).
+// Camera part here (D_i = clamp(B_ii)/radius), landmark part in k_landmark_back.  SC_MODEL accumulates the NEGATED value
+// (host flips the sign), keeping the convention model = -SC_MODEL.
 __global__ __launch_bounds__(kT) void k_model_cam(int d, int ld, const double* __restrict__ B, const double* __restrict__ gc,
-                                                  const double* __restrict__ dxc, double* __restrict__ scal) {
+                                                  const double* __restrict__ dxc, double inv_radius, double* __restrict__ scal) {
   const int i = blockIdx.x * kT + threadIdx.x;
   double m = 0.0, n2 = 0.0, g = 0.0;
   if (i < d) {
-    double hb = 0.0;
-    for (int j = 0; j <= i; ++j) hb += B[(size_t)i * ld + j] * dxc[j];
-    for (int j = i + 1; j < d; ++j) hb += B[(size_t)j * ld + i] * dxc[j];
-    m = dxc[i] * (gc[i] + 0.5 * hb);
-    n2 = dxc[i] * dxc[i];
+    const double dx = dxc[i];
+    m = -0.5 * dx * (clamp_diag(B[(size_t)i * ld + i]) * inv_radius * dx - gc[i]);
+    n2 = dx * dx;
     g = fabs(gc[i]);
   }
   block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM);
@@ -540,10 +670,16 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
   if (p->tc && p->tc->n)
     hipLaunchKernelGGL(k_lin_tc<false>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
                        p->tc->idx_a.p, p->tc->idx_b.p, s, p->tc->cam_a, p->tc->cam_b, huber, p->C.p, p->gr.p, cost);
-  if (p->tf && p->tf->n)
-    hipLaunchKernelGGL(k_lin_tf<false>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
-                       p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, p->B.p, p->dpad,
-                       p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
+  if (p->tf && p->tf->n) {
+    if (p->tf_work.n && p->n_kf <= kMaxStagedKf)
+      hipLaunchKernelGGL(k_lin_tf_sorted, dim3((unsigned)p->tf_work.n), dim3(kT), 0, q, p->tf_work.p, p->n_kf, (const double2*)p->tf->ob_a.p,
+                         (const double2*)p->tf->ob_b.p, p->tf->idx_a.p, p->tf->idx_b.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p,
+                         p->B.p, p->dpad, p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
+    else
+      hipLaunchKernelGGL(k_lin_tf<false>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
+                         p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, p->B.p, p->dpad,
+                         p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
+  }
   if (p->po && p->po->n)
     hipLaunchKernelGGL(k_lin_po<false>, dim3(grid(p->po->n)), dim3(kT), 0, q, p->po->n, p->n_kf, (const double2*)p->po->ob_a.p, p->po->idx_a.p,
                        p->po->idx_b.p, p->po->table.p, s, p->po->cam_a, huber, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
@@ -574,14 +710,13 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   }
   LVF_HIP(hipMemsetAsync(fail_flag_dev, 0, sizeof(int), q));
   for (int kb = 0; kb < p->nb; ++kb) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, q, p->S.p, p->dpad, kb, fail_flag_dev);
     const int below = p->nb - kb - 1;
+    hipLaunchKernelGGL(k_chol_factor_panel, dim3(1 + below), dim3(64), 0, q, p->S.p, p->dpad, kb, fail_flag_dev);
     if (below > 0) {
-      hipLaunchKernelGGL(k_chol_panel, dim3(below), dim3(64), 0, q, p->S.p, p->dpad, kb);
       hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, q, p->S.p, p->dpad, kb);
     }
   }
-  const size_t sh = ((size_t)((p->d + 63) / 64) * 64 + kNB * kLd) * sizeof(double);
+  const size_t sh = ((size_t)((p->d + 63) / 64) * 64 + 4 * kNB) * sizeof(double);
   hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(256), sh, q, p->S.p, p->dpad, p->d, p->dxc.p);
   // model / norms / candidate state
   LVF_HIP(hipMemsetAsync(p->scal.p + SC_COST_NEW, 0, (SC_N - SC_COST_NEW) * 8, q));
@@ -589,7 +724,7 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   if (p->n_lm)
     hipLaunchKernelGGL(k_landmark_back, dim3(grid(p->n_lm)), dim3(kT), p->dp * sizeof(double), q, p->n_lm, p->dp, p->ldE, p->E.p, p->C.p, p->Cd.p,
                        p->gr.p, p->dxc.p, p->st->inv_depth.p, p->dxl.p, p->scal.p);
-  hipLaunchKernelGGL(k_model_cam, dim3(grid(p->d)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, p->dxc.p, p->scal.p);
+  hipLaunchKernelGGL(k_model_cam, dim3(grid(p->d)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, p->dxc.p, inv_r, p->scal.p);
   hipLaunchKernelGGL(k_apply_step, dim3(grid(std::max(p->n_kf, p->n_lm))), dim3(kT), 0, q, p->n_kf, p->n_lm, s, p->dxc.p, p->dxl.p, p->poses2.p,
                      p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->scal.p);
   LVF_HIP(hipGetLastError());
@@ -693,6 +828,22 @@ int lvf_problem_create(lvf_ctx* ctx, lvf_state* st, lvf_batch* two_camera, lvf_b
       (rc = p->vel2.alloc((size_t)3 * p->n_kf)) || (rc = p->ba2.alloc((size_t)3 * p->n_kf)) || (rc = p->bg2.alloc((size_t)3 * p->n_kf)) ||
       (rc = p->invd2.alloc(p->n_lm)) || (rc = p->pose_const.alloc(p->n_kf)) || (rc = p->fail.alloc(1))) { delete p; return rc; }
   p->pose_const_h.assign(p->n_kf, 0);
+  if (two_frame && two_frame->n && two_frame->sorted_by_kf && !two_frame->host_kf2.empty()) {
+    // work list for the sorted fast path: runs of <= kT blocks sharing one current keyframe; k1 == k2 disables it
+    const std::vector<int32_t>& k2 = two_frame->host_kf2; const std::vector<int32_t>& k1 = two_frame->host_kf1;
+    bool ok = true;
+    for (int i = 0; i < two_frame->n && ok; ++i) ok = k1[i] != k2[i];
+    if (ok) {
+      std::vector<TfWork> wl;
+      for (int i = 0; i < two_frame->n;) {
+        int j = i;
+        while (j < two_frame->n && k2[j] == k2[i] && j - i < kT) ++j;
+        wl.push_back(TfWork{i, j - i, k2[i]});
+        i = j;
+      }
+      if ((rc = p->tf_work.upload(wl.data(), wl.size(), ctx->stream))) { delete p; return rc; }
+    }
+  }
   LVF_HIP(hipMemsetAsync(p->pose_const.p, 0, p->n_kf, ctx->stream));
   LVF_HIP(hipMemsetAsync(p->dxc.p, 0, p->dpad * 8, ctx->stream));
   LVF_HIP(hipStreamSynchronize(ctx->stream));

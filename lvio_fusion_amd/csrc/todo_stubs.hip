@@ -3,6 +3,5 @@
 using namespace lvf;
 extern "C" {
 #define LVF_TODO(name) do { set_error(name ": not implemented yet"); return LVF_ERR_STATE; } while (0)
-int lvf_preintegrate(lvf_ctx*, int, const int32_t*, const double*, const double*, const double*, const double*, const double*, const double*, lvf_preint*) { LVF_TODO("lvf_preintegrate"); }
 int lvf_icp_solve(lvf_map*, lvf_scan*, const double*, double*, const lvf_icp_options*, lvf_icp_summary*) { LVF_TODO("lvf_icp_solve"); }
 }

@@ -157,3 +157,22 @@ def test_imu_parity(ctx, oracle):
     for k in range(8):
         assert_parity(b.jacobian(k), Jb[k], f"imu J{k}")
     b.close(); st.close()
+
+
+def test_preintegration_parity(ctx, oracle):
+    """lvf_preintegrate (device mid-point integration + F/V covariance propagation) vs the oracle, ragged sample counts."""
+    from lvio_fusion_amd import api
+    cfg = syn.config4_window(n_kf=9, n_lm=10, n_prewindow=2, seed=88, imu_samples=10)
+    rng = np.random.default_rng(0)
+    samples = [f["samples"][: int(rng.integers(1, 11))] for f in cfg["imu"]]
+    samples[2] = np.zeros((0, 7))                     # a pair with no samples: identity jacobian, zero covariance
+    samples[3] = np.concatenate([cfg["imu"][3]["samples"]] * 10)   # 100 samples (100 Hz IMU)
+    a0 = np.stack([f["acc0"] for f in cfg["imu"]]); g0 = np.stack([f["gyr0"] for f in cfg["imu"]])
+    ba = np.stack([f["ba"] for f in cfg["imu"]]); bg = np.stack([f["bg"] for f in cfg["imu"]])
+    got = api.preintegrate(ctx, samples, a0, g0, ba, bg, syn.IMU_NOISE)
+    for k, s in enumerate(samples):
+        ref = oracle.imu_preintegrate(s, a0[k], g0[k], ba[k], bg[k], syn.IMU_NOISE)
+        assert_parity(got[k][:17], ref[:17], f"pair {k} state")
+        assert_parity(got[k][17:242], ref[17:242], f"pair {k} jacobian")
+        assert_parity(got[k][242:], ref[242:], f"pair {k} covariance")
+    assert api.preintegrate(ctx, [], np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), syn.IMU_NOISE).shape == (0, 467)

@@ -101,3 +101,28 @@ def test_constant_pose_is_not_moved(ctx, oracle):
     p1 = st.get(api.POSES).reshape(-1, 7)
     assert np.abs(p1[0] - p0[0]).max() < 1e-12 and np.abs(p1[1:] - p0[1:]).max() > 1e-6
     prob.close()
+
+
+def test_unsorted_two_frame_uses_generic_path(ctx, oracle):
+    """Blocks in arbitrary order (not sorted by current keyframe) go through the generic atomic linearisation and
+    must give the same reduced system as the sorted fast path."""
+    from lvio_fusion_amd import api
+    cfg = syn.config4_window(n_kf=7, n_lm=90, n_prewindow=20, seed=41, imu_samples=4)
+    perm = np.random.default_rng(0).permutation(len(cfg["tf"]["lm_idx"]))
+    cfg2 = dict(cfg); cfg2["tf"] = {k: v[perm] for k, v in cfg["tf"].items()}
+    pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+    out = []
+    for c in (cfg, cfg2):
+        st = api.State(ctx, c["n_kf"], c["n_lm"])
+        for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth"), (api.W_VISUAL, "w_kf")):
+            st.set(field, c[key])
+        tf = c["tf"]
+        btf = api.two_frame_batch(ctx, c["cam0"], c["cam1"], tf["first_ob"], tf["ob"], tf["lm_idx"], tf["kf1_idx"], tf["kf2_idx"])
+        prob = api.Problem(ctx, st, None, btf, None, None)
+        r = prob.lm_iteration(api.default_solver_options(), 1e4)
+        S, rhs = prob.reduced_system()
+        out.append((r, S, rhs, st.get(api.POSES)))
+        prob.close(); btf.close(); st.close()
+    assert abs(out[0][0]["cost_before"] - out[1][0]["cost_before"]) <= 1e-10 * out[0][0]["cost_before"]
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-9 * np.abs(out[0][1]).max()
+    assert_parity(out[1][3], out[0][3], "poses after one iteration")
