@@ -187,11 +187,12 @@ typedef struct lvf_icp_summary {
   int num_iterations;
   int num_successful_steps;
 } lvf_icp_summary;
-/* Runs association (lvf_knn3 with frame_pose = map_pose * rpyxyz2se3(rpyxyz)), builds the point-to-plane
- * problem and solves it; rpyxyz (host, 6 doubles) is updated IN PLACE like the reference's stack array
- * (mapping.cpp:153-165). */
-int lvf_icp_solve(lvf_map* m, lvf_scan* s, const double* map_pose, double* rpyxyz, const lvf_icp_options* opt,
-                  lvf_icp_summary* summary);
+/* Runs association at frame_pose (the frame's current pose, cast to float as association.cpp:287), builds the
+ * point-to-plane problem against map_pose (Twc1) and solves it on device; rpyxyz (host, 6 doubles =
+ * se32rpyxyz(map_pose^-1 * frame_pose), mapping.cpp:154) is updated IN PLACE like the reference's stack array
+ * (mapping.cpp:153-165).  The caller then sets frame->pose = map_pose * rpyxyz2se3(rpyxyz) (mapping.cpp:164). */
+int lvf_icp_solve(lvf_map* m, lvf_scan* s, const double* map_pose, const double* frame_pose, double* rpyxyz,
+                  const lvf_icp_options* opt, lvf_icp_summary* summary);
 
 /* ---- sliding-window BA problem (adapt::Problem + adapt::Solve) --------------------------------- */
 typedef struct lvf_solver_options {

@@ -94,7 +94,7 @@ _SIGS = {
     "lvf_knn3": (C.c_int, [_VP, _VP, c_double_p, C.c_float]),
     "lvf_scan_download": (C.c_int, [_VP, c_int_p, c_float_p, c_u8_p]),
     "lvf_knn3_debug_stats": (C.c_int, [_VP, _VP, c_double_p, C.c_float, c_int_p, c_float_p, C.POINTER(C.c_int)]),
-    "lvf_icp_solve": (C.c_int, [_VP, _VP, c_double_p, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
+    "lvf_icp_solve": (C.c_int, [_VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
     "lvf_solver_options_default": (None, [C.POINTER(SolverOptions)]),
     "lvf_problem_create": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "lvf_problem_destroy": (C.c_int, [_VP]),

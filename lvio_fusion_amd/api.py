@@ -234,13 +234,13 @@ def knn3(map_, scan, pose, thr):
     _chk(map_.ctx.L.lvf_knn3(map_.h, scan.h, _dp(p), float(thr)))
 
 
-def icp_solve(map_, scan, map_pose, rpyxyz, mode, thr, weight, huber_a, prior_weight=0.0, max_num_iterations=4):
+def icp_solve(map_, scan, map_pose, frame_pose, rpyxyz, mode, thr, weight, huber_a, prior_weight=0.0, max_num_iterations=4):
     """rpyxyz is updated IN PLACE (numpy float64[6]); returns the summary struct."""
     assert rpyxyz.dtype == np.float64 and rpyxyz.flags.c_contiguous and rpyxyz.size == 6
-    mp = _d(map_pose)
+    mp, fp = _d(map_pose), _d(frame_pose)
     opt = IcpOptions(int(mode), float(thr), float(weight), float(huber_a), float(prior_weight), int(max_num_iterations))
     summ = IcpSummary()
-    _chk(map_.ctx.L.lvf_icp_solve(map_.h, scan.h, _dp(mp), _dp(rpyxyz), C.byref(opt), C.byref(summ)))
+    _chk(map_.ctx.L.lvf_icp_solve(map_.h, scan.h, _dp(mp), _dp(fp), _dp(rpyxyz), C.byref(opt), C.byref(summ)))
     return summ
 
 

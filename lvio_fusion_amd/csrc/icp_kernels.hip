@@ -1,0 +1,234 @@
+// icp_kernels.hip — one scan-to-map sub-problem solved entirely on device.
+//
+// Replaces FeatureAssociation::ScanToMapWithGround / ScanToMapWithSegmented (src/lvio_fusion/src/association.cpp:270-384)
+// plus the 3-parameter ceres::Solve that follows them (src/lvio_fusion/src/mapping.cpp:154-178, :264-296):
+//   association (k_knn3) -> correspondence build (plane normal from the three map neighbours, float -> double as
+//   association.cpp:303-314) -> up to max_num_iterations Levenberg-Marquardt steps on (pitch,roll,z) or (yaw,x,y).
+// The LM loop never leaves the GPU: parameters, trust-region radius, accept/reject and termination live in a small
+// device struct; every iteration is four dependent launches on the context's stream
+//   eval(x, with J) -> step (1 thread: 3x3 damped normal equations) -> eval(x + dx, cost only) -> decide (1 thread)
+// and the host only reads the result back at the end.  Normal-equation sums are wave-shuffle reduced (10 doubles per
+// wave) before touching memory.  Solver semantics as declared for the BA problem (oracle/lm.h header); DENSE_QR and the
+// damped normal equations solve the same 3x3 least-squares step.
+#include <cmath>
+#include "lidar_eval.hpp"
+#include "lvf_internal.hpp"
+
+namespace lvf {
+
+constexpr int kTI = 256;
+
+struct IcpDev {
+  double x[3], x0[3], xc[3];
+  double radius, decrease;
+  double acc[10];            // H lower (00,10,11,20,21,22), g (3), cost  — at x
+  double cost_cand;          // data cost at xc
+  double cost_cur, initial_cost, model;
+  double rpyxyz[6];
+  int done, iters, successes, nvalid, first;
+};
+
+struct IcpArgs {
+  double Twc1[7];
+  double weight, huber, prior_w;
+  double function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease;
+  int mode, max_iters;
+};
+
+__device__ __forceinline__ void param_slots(int mode, int& i0, int& i1, int& i2) {
+  if (mode == 0) { i0 = 1; i1 = 2; i2 = 5; } else { i0 = 0; i1 = 3; i2 = 4; }
+}
+
+// correspondences: scan point (double), first neighbour pa, unit normal — SoA [3][Q]; invalid points keep valid = 0
+__global__ __launch_bounds__(kTI) void k_icp_build(int Q, const float4* __restrict__ scan, const int* __restrict__ idx,
+                                                   const uint8_t* __restrict__ valid, const float4* __restrict__ map_raw,
+                                                   double* __restrict__ P, double* __restrict__ PA, double* __restrict__ N,
+                                                   IcpDev* __restrict__ dev) {
+  const int i = blockIdx.x * kTI + threadIdx.x;
+  const bool ok = i < Q && valid[i];
+  if (ok) {
+    const float4 p = scan[i];
+    const float4 a = map_raw[idx[3 * i]], b = map_raw[idx[3 * i + 1]], c = map_raw[idx[3 * i + 2]];
+    const double pa[3] = {(double)a.x, (double)a.y, (double)a.z}, pb[3] = {(double)b.x, (double)b.y, (double)b.z}, pc[3] = {(double)c.x, (double)c.y, (double)c.z};
+    double n[3];
+    plane_normal(pa, pb, pc, n);
+    P[i] = (double)p.x; P[Q + i] = (double)p.y; P[2 * Q + i] = (double)p.z;
+    PA[i] = pa[0]; PA[Q + i] = pa[1]; PA[2 * Q + i] = pa[2];
+    N[i] = n[0]; N[Q + i] = n[1]; N[2 * Q + i] = n[2];
+  }
+  const unsigned long long m = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&dev->nvalid, __popcll(m));
+}
+
+template <bool WITH_J>
+__global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restrict__ P, const double* __restrict__ PA,
+                                                  const double* __restrict__ N, const uint8_t* __restrict__ valid,
+                                                  const IcpArgs args, IcpDev* __restrict__ dev) {
+  __shared__ LidarU U;
+  if (dev->done) return;                              // uniform: the flag is only written by single-thread kernels
+  if (threadIdx.x == 0) {
+    LidarArgs a;
+    for (int k = 0; k < 7; ++k) a.Twc1[k] = args.Twc1[k];
+    for (int k = 0; k < 6; ++k) a.rpyxyz[k] = dev->rpyxyz[k];
+    int i0, i1, i2;
+    param_slots(args.mode, i0, i1, i2);
+    const double* x = WITH_J ? dev->x : dev->xc;
+    a.rpyxyz[i0] = x[0]; a.rpyxyz[i1] = x[1]; a.rpyxyz[i2] = x[2];
+    a.weight = args.weight; a.mode = args.mode;
+    derive_lidar(a, U);
+  }
+  __syncthreads();
+  const int i = blockIdx.x * kTI + threadIdx.x;
+  double v[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) v[q] = 0.0;
+  if (i < Q && valid[i]) {
+    const double pp[3] = {P[i], P[Q + i], P[2 * Q + i]}, qa[3] = {PA[i], PA[Q + i], PA[2 * Q + i]}, nn[3] = {N[i], N[Q + i], N[2 * Q + i]};
+    double r, J[3];
+    lidar_point(U, args.mode, pp, qa, nn, r, J);
+    double rho;
+    const double sc = robust_scale(args.huber, r * r, rho);
+    v[9] = 0.5 * rho;
+    if (WITH_J) {
+      const double rs = sc * r, j0 = sc * J[0], j1 = sc * J[1], j2 = sc * J[2];
+      v[0] = j0 * j0; v[1] = j1 * j0; v[2] = j1 * j1; v[3] = j2 * j0; v[4] = j2 * j1; v[5] = j2 * j2;
+      v[6] = j0 * rs; v[7] = j1 * rs; v[8] = j2 * rs;
+    }
+  }
+  if (WITH_J) {
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      double s = v[q];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+      if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(&dev->acc[q], s);
+    }
+  } else {
+    double s = v[9];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(&dev->cost_cand, s);
+  }
+}
+
+__device__ __forceinline__ double clampd(double v) { return fmin(fmax(v, 1e-6), 1e32); }
+
+// 3x3 damped normal equations; PoseErrorRPZ / PoseErrorYXY prior (pose_error.hpp:135-190): residual_k = w (x_k - x0_k)
+__global__ void k_icp_step(const IcpArgs args, IcpDev* __restrict__ dev) {
+  if (dev->done) return;
+  const double w2 = args.prior_w * args.prior_w;
+  double H[6], g[3];
+  for (int q = 0; q < 6; ++q) H[q] = dev->acc[q];
+  for (int q = 0; q < 3; ++q) g[q] = dev->acc[6 + q];
+  double cost = dev->acc[9];
+  if (args.prior_w > 0.0) {
+    H[0] += w2; H[2] += w2; H[5] += w2;
+    for (int q = 0; q < 3; ++q) { const double dxp = dev->x[q] - dev->x0[q]; g[q] += w2 * dxp; cost += 0.5 * w2 * dxp * dxp; }
+  }
+  dev->cost_cur = cost;
+  if (dev->first) { dev->initial_cost = cost; dev->first = 0; }
+  const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+  if (gmax <= args.gradient_tolerance) { dev->done = 1; return; }
+  const double inv_r = 1.0 / dev->radius;
+  const double D0 = clampd(H[0]) * inv_r, D1 = clampd(H[2]) * inv_r, D2 = clampd(H[5]) * inv_r;
+  // Cholesky of [[a00,.,.],[a10,a11,.],[a20,a21,a22]]
+  const double a00 = H[0] + D0, a10 = H[1], a11 = H[2] + D1, a20 = H[3], a21 = H[4], a22 = H[5] + D2;
+  const double l00 = sqrt(a00), l10 = a10 / l00, l20 = a20 / l00;
+  const double t11 = a11 - l10 * l10;
+  const double l11 = sqrt(t11), l21 = (a21 - l20 * l10) / l11;
+  const double t22 = a22 - l20 * l20 - l21 * l21;
+  const double l22 = sqrt(t22);
+  bool ok = a00 > 0.0 && t11 > 0.0 && t22 > 0.0;
+  double dx[3] = {0, 0, 0};
+  if (ok) {
+    const double y0 = -g[0] / l00, y1 = (-g[1] - l10 * y0) / l11, y2 = (-g[2] - l20 * y0 - l21 * y1) / l22;
+    dx[2] = y2 / l22; dx[1] = (y1 - l21 * dx[2]) / l11; dx[0] = (y0 - l10 * dx[1] - l20 * dx[2]) / l00;
+    ok = isfinite(dx[0]) && isfinite(dx[1]) && isfinite(dx[2]);
+  }
+  dev->model = ok ? 0.5 * (dx[0] * (D0 * dx[0] - g[0]) + dx[1] * (D1 * dx[1] - g[1]) + dx[2] * (D2 * dx[2] - g[2])) : -1.0;
+  for (int q = 0; q < 3; ++q) dev->xc[q] = dev->x[q] + dx[q];
+  dev->cost_cand = 0.0;
+  const double dn = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+  const double xn = sqrt(dev->x[0] * dev->x[0] + dev->x[1] * dev->x[1] + dev->x[2] * dev->x[2]);
+  if (ok && dn <= args.parameter_tolerance * (xn + args.parameter_tolerance)) dev->done = 1;
+}
+
+__global__ void k_icp_decide(const IcpArgs args, IcpDev* __restrict__ dev) {
+  if (dev->done) return;
+  double cand = dev->cost_cand;
+  if (args.prior_w > 0.0) {
+    const double w2 = args.prior_w * args.prior_w;
+    for (int q = 0; q < 3; ++q) { const double dxp = dev->xc[q] - dev->x0[q]; cand += 0.5 * w2 * dxp * dxp; }
+  }
+  dev->iters += 1;
+  bool accepted = false;
+  if (dev->model > 0.0 && isfinite(cand)) {
+    const double rho = (dev->cost_cur - cand) / dev->model;
+    if (rho > args.min_relative_decrease) {
+      accepted = true;
+      const double change = dev->cost_cur - cand;
+      const double before = dev->cost_cur;
+      for (int q = 0; q < 3; ++q) dev->x[q] = dev->xc[q];
+      dev->cost_cur = cand;
+      dev->successes += 1;
+      const double t = 2.0 * rho - 1.0;
+      dev->radius = fmin(dev->radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
+      dev->decrease = 2.0;
+      if (fabs(change) <= args.function_tolerance * fabs(before)) dev->done = 1;
+    }
+  }
+  if (!accepted) { dev->radius = dev->radius / dev->decrease; dev->decrease *= 2.0; if (dev->radius < 1e-32) dev->done = 1; }
+  if (dev->iters >= args.max_iters) dev->done = 1;
+  for (int q = 0; q < 10; ++q) dev->acc[q] = 0.0;
+}
+
+}  // namespace lvf
+
+using namespace lvf;
+
+extern "C" int lvf_icp_solve(lvf_map* m, lvf_scan* sc, const double* map_pose, const double* frame_pose, double* rpyxyz,
+                             const lvf_icp_options* opt, lvf_icp_summary* summary) {
+  LVF_REQUIRE(m && sc && map_pose && frame_pose && rpyxyz && opt && summary, "lvf_icp_solve: null argument");
+  LVF_REQUIRE(m->ctx == sc->ctx, "lvf_icp_solve: map and scan belong to different contexts");
+  LVF_REQUIRE(opt->mode == 0 || opt->mode == 1, "lvf_icp_solve: mode must be 0 (ground/RPZ) or 1 (surf/YXY)");
+  LVF_REQUIRE(opt->thr > 0.0f && opt->max_num_iterations >= 0, "lvf_icp_solve: bad options");
+  LVF_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t q = m->ctx->stream;
+  const int Q = sc->Q;
+  std::memset(summary, 0, sizeof(*summary));
+  // 1. association at the frame's current pose (association.cpp:287-301 / :345-359)
+  LVF_TRY(lvf_knn3(m, sc, frame_pose, opt->thr));
+  // 2. correspondences + device solver state
+  if (sc->corr.n < (size_t)9 * std::max(Q, 1)) LVF_TRY(sc->corr.alloc((size_t)9 * std::max(Q, 1)));
+  if (!sc->icp_dev.p) LVF_TRY(sc->icp_dev.alloc(sizeof(IcpDev)));
+  double* P = sc->corr.p; double* PA = P + (size_t)3 * Q; double* N = PA + (size_t)3 * Q;
+  IcpDev h;
+  std::memset(&h, 0, sizeof(h));
+  const int i0 = opt->mode == 0 ? 1 : 0, i1 = opt->mode == 0 ? 2 : 3, i2 = opt->mode == 0 ? 5 : 4;
+  h.x[0] = h.x0[0] = rpyxyz[i0]; h.x[1] = h.x0[1] = rpyxyz[i1]; h.x[2] = h.x0[2] = rpyxyz[i2];
+  for (int k = 0; k < 6; ++k) h.rpyxyz[k] = rpyxyz[k];
+  h.radius = 1e4; h.decrease = 2.0; h.first = 1;
+  IcpDev* dev = reinterpret_cast<IcpDev*>(sc->icp_dev.p);
+  LVF_HIP(hipMemcpyAsync(dev, &h, sizeof(h), hipMemcpyHostToDevice, q));
+  IcpArgs a;
+  std::memcpy(a.Twc1, map_pose, sizeof(a.Twc1));
+  a.weight = opt->weight; a.huber = opt->huber_a; a.prior_w = opt->prior_weight;
+  a.function_tolerance = 1e-6; a.gradient_tolerance = 1e-10; a.parameter_tolerance = 1e-8; a.min_relative_decrease = 1e-3;
+  a.mode = opt->mode; a.max_iters = opt->max_num_iterations;
+  const int grid = (std::max(Q, 1) + kTI - 1) / kTI;
+  if (Q > 0) hipLaunchKernelGGL(k_icp_build, dim3(grid), dim3(kTI), 0, q, Q, sc->pts.p, sc->idx.p, sc->valid.p, m->raw.p, P, PA, N, dev);
+  // 3. LM iterations, all on device
+  for (int it = 0; it < std::max(1, opt->max_num_iterations); ++it) {
+    if (Q > 0) hipLaunchKernelGGL(k_icp_eval<true>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, sc->valid.p, a, dev);
+    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1), 0, q, a, dev);
+    if (opt->max_num_iterations == 0) break;
+    if (Q > 0) hipLaunchKernelGGL(k_icp_eval<false>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, sc->valid.p, a, dev);
+    hipLaunchKernelGGL(k_icp_decide, dim3(1), dim3(1), 0, q, a, dev);
+  }
+  LVF_HIP(hipGetLastError());
+  LVF_HIP(hipMemcpyAsync(&h, dev, sizeof(h), hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipStreamSynchronize(q));
+  rpyxyz[i0] = h.x[0]; rpyxyz[i1] = h.x[1]; rpyxyz[i2] = h.x[2];
+  summary->initial_cost = h.initial_cost; summary->final_cost = h.cost_cur;
+  summary->num_residual_blocks = h.nvalid + (opt->prior_weight > 0.0 ? 1 : 0);
+  summary->num_iterations = h.iters; summary->num_successful_steps = h.successes;
+  return LVF_OK;
+}

@@ -133,6 +133,8 @@ struct lvf_scan {
   lvf::DevBuf<float> d2;             // [Q][3]
   lvf::DevBuf<uint8_t> valid;        // [Q]
   bool searched = false;
+  lvf::DevBuf<double> corr;          // ICP correspondences: p | pa | n, each SoA [3][Q]
+  lvf::DevBuf<char> icp_dev;         // device-resident LM state of lvf_icp_solve
 };
 
 namespace lvf {

@@ -35,6 +35,7 @@ struct lvf_problem {
 namespace lvf {
 
 constexpr int kT = 256;
+typedef double double4_t __attribute__((ext_vector_type(4)));
 // device scalar slots
 enum { SC_COST = 0, SC_COST_NEW = 1, SC_MODEL = 2, SC_DXNORM = 3, SC_XNORM = 4, SC_GMAX = 5, SC_N = 8 };
 
@@ -390,7 +391,6 @@ __global__ __launch_bounds__(kT) void k_prepare_lm(int n_lm, int dp, int ldE, co
 // T = Ea^T diag(1/Cd) Ea with Ea = [E | g_rho] (n_lm x ldE).  One wave per (16x16 output tile, K-chunk); tiles on or
 // below the diagonal only.  v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // D: col = lane&15, row = (lane>>4) + 4*reg.   S[i][j] -= T[i][j] (i,j < dp);  S[d][i] += T[dp][i].
-typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int kSchurChunk = 512;
 __global__ __launch_bounds__(64) void k_schur_syrk(int n_lm, int dp, int ldE, int ntile, const double* __restrict__ E,
                                                    const double* __restrict__ Cd, int d, int ldS, double* __restrict__ S) {
@@ -450,47 +450,95 @@ __device__ __forceinline__ double lane_bcast(double v, int srclane) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(64) void k_chol_factor_panel(double* __restrict__ S, int ld, int kb, int* __restrict__ fail) {
-  __shared__ double Lk[kNB * kLd];   // factored diagonal block, row-major padded
-  const int lane = threadIdx.x;
-  double a[kNB];
-  load_row64(S + (size_t)(kb * kNB + lane) * ld + kb * kNB, a);   // lane owns row `lane` of the diagonal block
+// 256 threads.  Factor: thread (row r = tid & 63, wave q = tid >> 6) owns columns 16q..16q+15 of row r; per column j the
+// owning wave scales it and publishes it through a double-buffered LDS line (ONE barrier per column), then every wave
+// applies the rank-1 update to its own 16 columns (<= 16 FMAs per thread per column instead of up to 63 in one wave).
+// Panel: 4 adjacent lanes share one row of X (lane `part` holds x_t, t = 4 tt + part): the dot product of the forward
+// substitution is split 4 ways and combined with two quad shuffles, so a 64-step solve costs ~64 x (j/4 FMAs + shuffle).
+// the per-wave body of the diagonal-block factorisation; Q (the wave's column group) is a template parameter so that
+// every "is column t right of j" test folds at compile time and each wave only carries its own FMAs
+template <int Q>
+__device__ __forceinline__ bool factor_columns(double a[16], int r, double (*col)[kNB], double* dinv) {
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < kNB; ++j) {
-    const double djj = lane_bcast(a[j], j);          // pivot A_jj (already updated) from lane j
-    bad |= !(djj > 0.0);
-    const double l = sqrt(fmax(djj, 1e-300));
-    const double inv_l = 1.0 / l;
-    a[j] = (lane == j) ? l : a[j] * inv_l;           // lanes < j hold upper-triangle garbage there; never used
+    const int qj = j >> 4, jj = j & 15, buf = j & 1;
+    if (Q == qj) {
+      const double djj = lane_bcast(a[jj], j);       // pivot A_jj sits in lane j (= row j) of this wave
+      bad |= !(djj > 0.0);
+      const double inv_l = rsqrt(fmax(djj, 1e-300));
+      a[jj] = (r == j) ? djj * inv_l : a[jj] * inv_l;
+      col[buf][r] = a[jj];
+      if (r == j) dinv[j] = inv_l;
+    }
+    __syncthreads();
+    if (16 * Q + 15 > j) {
+      const double cr = col[buf][r];
 #pragma unroll
-    for (int t = j + 1; t < kNB; ++t) a[t] -= a[j] * lane_bcast(a[j], t);   // A_it -= L_ij L_tj (meaningful for i >= t)
+      for (int tt = 0; tt < 16; ++tt)
+        if (16 * Q + tt > j) a[tt] -= cr * col[buf][16 * Q + tt];   // A_rt -= L_rj L_tj (meaningful for r >= t)
+    }
   }
-  if (bad && lane == 0) atomicExch(fail, 1 + kb);
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) Lk[lane * kLd + c] = (c <= lane) ? a[c] : 0.0;
-  __syncthreads();
-  if (blockIdx.x == 0) {
-#pragma unroll
-    for (int c = 0; c < kNB; ++c) if (c > lane) a[c] = 0.0;
-    store_row64(S + (size_t)(kb * kNB + lane) * ld + kb * kNB, a);
-    return;
-  }
-  // panel block (kb + blockIdx.x, kb): X L^T = A, lane owns one row of X
-  double* arow = S + (size_t)((kb + blockIdx.x) * kNB + lane) * ld + kb * kNB;
-  double x[kNB];
-  load_row64(arow, x);
-#pragma unroll
-  for (int j = 0; j < kNB; ++j) {
-    double s = x[j];
-#pragma unroll
-    for (int t = 0; t < j; ++t) s -= x[t] * Lk[j * kLd + t];   // broadcast LDS reads, static addresses
-    x[j] = s / Lk[j * kLd + j];
-  }
-  store_row64(arow, x);
+  return bad;
 }
 
-// trailing update: A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi; 256 threads, 4x4 register tile each
+__global__ __launch_bounds__(256) void k_chol_factor_panel(double* __restrict__ S, int ld, int kb, int* __restrict__ fail) {
+  __shared__ double Lk[kNB * kLd];     // factored diagonal block, row-major padded, zero above the diagonal
+  __shared__ double col[2][kNB];
+  __shared__ double dinv[kNB];         // 1 / L_jj
+  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
+  double a[16];
+  {
+    const double2* g2 = reinterpret_cast<const double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; a[2 * c] = v.x; a[2 * c + 1] = v.y; }
+  }
+  bool bad;
+  switch (q) {                                       // wave-uniform dispatch
+    case 0: bad = factor_columns<0>(a, r, col, dinv); break;
+    case 1: bad = factor_columns<1>(a, r, col, dinv); break;
+    case 2: bad = factor_columns<2>(a, r, col, dinv); break;
+    default: bad = factor_columns<3>(a, r, col, dinv); break;
+  }
+  if (bad && r == 0) atomicExch(fail, 1 + kb);
+#pragma unroll
+  for (int tt = 0; tt < 16; ++tt) {
+    const int c = 16 * q + tt;
+    if (c > r) a[tt] = 0.0;
+    Lk[r * kLd + c] = a[tt];
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    double2* g2 = reinterpret_cast<double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) g2[c] = make_double2(a[2 * c], a[2 * c + 1]);
+    return;
+  }
+  // panel block (kb + blockIdx.x, kb): X L^T = A
+  const int row = tid >> 2, part = tid & 3;
+  double* arow = S + (size_t)((kb + blockIdx.x) * kNB + row) * ld + kb * kNB;
+  double x[16];
+#pragma unroll
+  for (int tt = 0; tt < 16; ++tt) x[tt] = arow[4 * tt + part];
+#pragma unroll
+  for (int j = 0; j < kNB; ++j) {
+    const int jt = j >> 2, pj = j & 3;
+    const double* Lj = Lk + j * kLd;
+    double sum = 0.0;
+#pragma unroll
+    for (int tt = 0; tt < jt; ++tt) sum += x[tt] * Lj[4 * tt + part];
+    if (pj > 0) sum += (part < pj) ? x[jt] * Lj[4 * jt + part] : 0.0;
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (part == pj) x[jt] = (x[jt] - sum) * dinv[j];
+  }
+#pragma unroll
+  for (int tt = 0; tt < 16; ++tt) arow[4 * tt + part] = x[tt];
+}
+
+// trailing update: A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi.  One workgroup per 64x64 tile; both 64x64 panels are
+// staged in LDS (row stride 65) and each of the 4 waves produces a 16x64 strip with v_mfma_f64_16x16x4_f64
+// (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D: col = lane&15, row = (lane>>4) + 4 reg).
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int ld, int kb) {
   __shared__ double Pi[kNB * kLd];
   __shared__ double Pj[kNB * kLd];
@@ -500,33 +548,29 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
   const double* pi = S + (size_t)(bi * kNB) * ld + kb * kNB;
   const double* pj = S + (size_t)(bj * kNB) * ld + kb * kNB;
   for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Pi[r * kLd + c] = pi[(size_t)r * ld + c];
-    Pj[r * kLd + c] = pj[(size_t)r * ld + c];
+    const int rr = e >> 6, c = e & 63;
+    Pi[rr * kLd + c] = pi[(size_t)rr * ld + c];
+    Pj[rr * kLd + c] = pj[(size_t)rr * ld + c];
   }
   __syncthreads();
-  const int tr = (threadIdx.x >> 4) * 4, tc = (threadIdx.x & 15) * 4;
-  double acc[4][4] = {};
-#pragma unroll 8
-  for (int k = 0; k < kNB; ++k) {
-    double av[4], bv[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lc = lane & 15;
+  double4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { av[q] = Pi[(tr + q) * kLd + k]; bv[q] = Pj[(tc + q) * kLd + k]; }
+  for (int k0 = 0; k0 < kNB; k0 += 4) {
+    const double av = Pi[(16 * w + lc) * kLd + k0 + lk];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] += av[x] * bv[y];
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pj[(16 * ct + lc) * kLd + k0 + lk], acc[ct], 0, 0, 0);
   }
-  double* out = S + (size_t)(bi * kNB) * ld + bj * kNB;
+  double* out = S + (size_t)(bi * kNB + 16 * w) * ld + bj * kNB;
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) out[(size_t)(tr + x) * ld + tc + y] -= acc[x][y];
+    for (int rg = 0; rg < 4; ++rg) out[(size_t)(lk + 4 * rg) * ld + 16 * ct + lc] -= acc[ct][rg];
 }
 
 // back substitution x = L^-T y with y = augmented row L[d][0..d); single workgroup of 256 threads.
 // Per block (bottom-up): (a) 4-way split gather  y_c -= sum_{r > block} L[r][c] x_r  (rows r are contiguous over c:
-// coalesced), (b) one wave solves the 64x64 transposed triangle with the block's COLUMNS in registers.
+// coalesced, 8 loads in flight), (b) one wave solves the 64x64 transposed triangle with the block's COLUMNS in registers.
 __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ S, int ld, int d, double* __restrict__ xout) {
   extern __shared__ double sm[];          // x[nblk*64] | part[4][64]
   const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
@@ -538,7 +582,16 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int r0 = kb * kNB;
     double s = 0.0;
-    for (int r = r0 + kNB + part; r < min(n, d); r += 4) s += S[(size_t)r * ld + r0 + c] * x[r];
+    const int rend = min(n, d);
+    int r = r0 + kNB + part;
+    for (; r + 28 < rend; r += 32) {
+      double lv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) lv[u] = S[(size_t)(r + 4 * u) * ld + r0 + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += lv[u] * x[r + 4 * u];
+    }
+    for (; r < rend; r += 4) s += S[(size_t)r * ld + r0 + c] * x[r];
     partial[part * kNB + c] = s;
     __syncthreads();
     if (tid < 64) {
@@ -551,7 +604,7 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
 #pragma unroll
       for (int j = kNB - 1; j >= 0; --j) {
         // x_j = y_j / L_jj on lane j, broadcast, then y_t -= L[j][t] x_j on lanes t < j
-        const double xj = __shfl((lane == j) ? y / a[j] : 0.0, j);
+        const double xj = lane_bcast(y / a[j], j);
         if (lane == j) y = xj;
         else if (lane < j) y -= a[j] * xj;
       }
@@ -711,7 +764,7 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   LVF_HIP(hipMemsetAsync(fail_flag_dev, 0, sizeof(int), q));
   for (int kb = 0; kb < p->nb; ++kb) {
     const int below = p->nb - kb - 1;
-    hipLaunchKernelGGL(k_chol_factor_panel, dim3(1 + below), dim3(64), 0, q, p->S.p, p->dpad, kb, fail_flag_dev);
+    hipLaunchKernelGGL(k_chol_factor_panel, dim3(1 + below), dim3(256), 0, q, p->S.p, p->dpad, kb, fail_flag_dev);
     if (below > 0) {
       hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, q, p->S.p, p->dpad, kb);
     }

@@ -10,6 +10,7 @@
 #include <vector>
 #include "factors.h"
 #include "imu.h"
+#include "icp.h"
 #include "knn.h"
 #include "lm.h"
 #include "robust.h"
@@ -300,6 +301,16 @@ void lvo_window_lm_iteration(lvo_window_c* c, double huber_a, double min_relativ
   out6[4] = st.accepted ? 1.0 : 0.0; out6[5] = st.solved ? 1.0 : 0.0;
   if (S) std::memcpy(S, st.S.data(), st.S.size() * 8);
   if (rhs) std::memcpy(rhs, st.rhs.data(), st.rhs.size() * 8);
+}
+
+// ---------------- scan-to-map sub-problem ----------------
+// out5 = {initial_cost, final_cost, num_residual_blocks, iterations, successful steps}; rpyxyz updated in place
+void lvo_icp_solve(const float* map, int M, int mstride, const float* query, int Q, int qstride, const double* map_pose,
+                   const double* frame_pose, double* rpyxyz, int mode, float thr, double weight, double huber_a, double prior_w,
+                   int max_iters, int use_kdtree, double* out5) {
+  IcpOut o;
+  icp_solve(map, M, mstride, query, Q, qstride, map_pose, frame_pose, rpyxyz, mode, thr, weight, huber_a, prior_w, max_iters, use_kdtree != 0, &o);
+  out5[0] = o.initial_cost; out5[1] = o.final_cost; out5[2] = o.nres; out5[3] = o.iters; out5[4] = o.successes;
 }
 
 }  // extern "C"

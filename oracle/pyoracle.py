@@ -248,6 +248,16 @@ def knn3(map_xyz, query_xyz, tf_d, thr, method=0, threads=1):
     return idx, d2, valid
 
 
+def icp_solve(map_xyz, query_xyz, map_pose, frame_pose, rpyxyz, mode, thr, weight, huber_a, prior_w=0.0, max_iters=4, use_kdtree=True):
+    """Returns (rpyxyz_new, dict) — the input rpyxyz is not modified."""
+    m, q = _f32(map_xyz), _f32(query_xyz)
+    mp, fp = _f64(map_pose), _f64(frame_pose)
+    x = _f64(rpyxyz).copy(); out5 = np.empty(5)
+    lib().lvo_icp_solve(_p(m, C.c_float), m.shape[0], m.shape[1], _p(q, C.c_float), q.shape[0], q.shape[1], _p(mp), _p(fp), _p(x), int(mode),
+                        C.c_float(thr), C.c_double(weight), C.c_double(huber_a), C.c_double(prior_w), int(max_iters), int(use_kdtree), _p(out5))
+    return x, dict(initial_cost=out5[0], final_cost=out5[1], num_residual_blocks=int(out5[2]), num_iterations=int(out5[3]), num_successful_steps=int(out5[4]))
+
+
 def kdtree_build_seconds(map_xyz):
     m = _f32(map_xyz)
     return lib().lvo_kdtree_build_seconds(_p(m, C.c_float), m.shape[0], m.shape[1])
