@@ -12,6 +12,7 @@
  *                         include/lvio_fusion/ceres/lidar_error.hpp:42-110 (+ ctor normal :13-18)
  *   lvf_imu_*          <- ImuError : SizedCostFunction<15,7,3,3,3,7,3,3,3>
  *                         include/lvio_fusion/ceres/imu_error.hpp:12-122, src/preintegration.cpp:144-165
+ *   lvf_pose_prior_*   <- PoseGraphError <6,7,7> / PoseError <6,7>   include/lvio_fusion/ceres/pose_error.hpp:10-86
  *   lvf_preintegrate   <- imu::Preintegration::{Append,Propagate,MidPointIntegration}
  *                         src/preintegration.cpp:30-127, include/lvio_fusion/imu/preintegration.h:29-41
  *   lvf_map_* / lvf_scan_* / lvf_knn3_*
@@ -127,6 +128,15 @@ int lvf_imu_create(lvf_ctx* ctx, int n, const lvf_preint* pre, const int32_t* kf
  * map neighbours (association.cpp:303-314); the unit normal (pa-pb)x(pa-pc) is computed on device. */
 int lvf_lidar_plane_create(lvf_ctx* ctx, int mode, int n, const double* p, const double* pa, const double* pb,
                            const double* pc, const double* Twc1, double weight, lvf_batch** out);
+/* Weak-constraint pose priors of a window (backend.cpp:164-178).  Block i with kf_a[i] >= 0 is
+ * PoseGraphError<6,7,7>(Twc1 = pose[kf_a], Twc2 = pose[kf_b]) with target[i][0..6) = rpyxyz_ (pose_error.hpp:13-17,
+ * see lvf_relative_rpyxyz); with kf_a[i] < 0 it is PoseError<6,7>(pose[kf_b]) with target[i][0..7) = the origin pose
+ * (pose_error.hpp:55-76).  target is [n][7]; weight[n], v[n] are the functor's (weight, v) ctor arguments.
+ * Parameter blocks: 0 = pose[kf_a] (all-zero Jacobian for PoseError blocks), 1 = pose[kf_b]; 6 residuals. */
+int lvf_pose_prior_create(lvf_ctx* ctx, int n, const int32_t* kf_a, const int32_t* kf_b, const double* target,
+                          const double* weight, const double* v, lvf_batch** out);
+/* rpyxyz6 = SE3ToRpyxyz(last_pose^-1 * pose): the constant PoseGraphError's constructor stores (host arithmetic). */
+int lvf_relative_rpyxyz(const double* last_pose, const double* pose, double* rpyxyz6);
 int lvf_batch_destroy(lvf_batch* b);
 int lvf_batch_size(const lvf_batch* b);
 int lvf_batch_num_param_blocks(const lvf_batch* b);
@@ -194,6 +204,17 @@ typedef struct lvf_icp_summary {
 int lvf_icp_solve(lvf_map* m, lvf_scan* s, const double* map_pose, const double* frame_pose, double* rpyxyz,
                   const lvf_icp_options* opt, lvf_icp_summary* summary);
 
+/* The same device-resident 3-DoF solve over a caller-built lidar batch (lvf_lidar_plane_create): what adapt::Solve
+ * does for the problem ScanToMapWithGround/Segmented assembled (mapping.cpp:157-163, :270-296).  mode, weight and Twc1
+ * are the batch's; opt supplies huber_a, prior_weight and max_num_iterations (opt->mode/weight/thr are ignored). */
+int lvf_lidar_solve(lvf_batch* lidar_batch, double* rpyxyz, const lvf_icp_options* opt, lvf_icp_summary* summary);
+
+/* PoseErrorRPZ / PoseErrorYXY <3,1,1,1> (pose_error.hpp:135-190) evaluated stand-alone.  target3 and x3 are in PARAMETER
+ * order — (pitch, roll, z) for mode 0, (yaw, x, y) for mode 1; residuals3 in the functor's order — (roll, pitch, z) /
+ * (yaw, x, y); jacobians9 (may be NULL) = three 3x1 blocks, one per parameter block, concatenated. */
+int lvf_prior3_evaluate(lvf_ctx* ctx, int mode, const double* target3, double weight, const double* x3, double* residuals3,
+                        double* jacobians9);
+
 /* ---- sliding-window BA problem (adapt::Problem + adapt::Solve) --------------------------------- */
 typedef struct lvf_solver_options {
   int max_num_iterations;          /* Ceres default 50; UpdateFrontend uses 1 (backend.cpp:264) */
@@ -217,6 +238,8 @@ void lvf_solver_options_default(lvf_solver_options* o);
 int lvf_problem_create(lvf_ctx* ctx, lvf_state* st, lvf_batch* two_camera, lvf_batch* two_frame,
                        lvf_batch* pose_only, lvf_batch* imu, lvf_problem** out);
 int lvf_problem_destroy(lvf_problem* p);
+/* Adds (or with NULL removes) the window's pose-prior batch (ProblemType::Other blocks with no loss function). */
+int lvf_problem_set_pose_priors(lvf_problem* p, lvf_batch* pose_priors);
 int lvf_problem_set_pose_constant(lvf_problem* p, int kf, int is_constant);
 /* Problem::Evaluate-style cost at the current state: 0.5 * sum rho(|r|^2). */
 int lvf_problem_cost(lvf_problem* p, const lvf_solver_options* o, double* cost);

@@ -1,0 +1,796 @@
+// lvf_ceres_adapter.hpp — lvio_fusion's own host interface for the hot path, re-seated on the MI355X library.
+//
+// What the reference calls                                   what this header provides (namespace lvio_fusion::gpu)
+//   XError::Create(...)  -> ceres::CostFunction*               same class names, same factory argument meaning, same
+//     include/lvio_fusion/ceres/visual_error.hpp:66-70,98-102,128-132     template sizes (SizedCostFunction<...>); the object
+//     lidar_error.hpp:65-69,100-104  imu_error.hpp:110-113                carries the functor's constructor constants and a
+//     pose_error.hpp:40-49,78-81,155-158,183-186                          type tag instead of a Jet-differentiated operator()
+//   CostFunction::Evaluate(parameters, residuals, jacobians)   batch-of-one evaluation ON THE GPU through the C-ABI
+//     (Ceres calls it per block, per thread)                     (parity / debugging surface; not the fast path)
+//   adapt::Solve(options, &problem, &summary)                  gpu::Solve — the single choke point (adapt/problem.h:83-88):
+//     src/backend.cpp:211,267  src/mapping.cpp:162,177,276,290   walks the ceres::Problem, recognises the tagged blocks,
+//                                                                uploads them as SoA batches, runs the device LM loop and
+//                                                                writes the result back IN PLACE into the caller's arrays
+//   ceres::Problem::Evaluate(opts, &cost, &residuals, ...)     gpu::Evaluate — batched cost + residual vector
+//
+// Eigen / Sophus / OpenCV types do not appear: factories take plain double arrays (Vector2d::data(), SE3d::data(),
+// lvf_camera); INTEGRATION.md shows the one-line wrappers that restore the reference's exact signatures.
+//
+// Failure is SOFT, as the reference expects (it never reads Summary::termination_type, backend.cpp:210-211): on any
+// error parameters are left untouched, Summary::termination_type = FAILURE and Summary::message says why.  There is no
+// CPU solver behind this header: an unsupported problem is reported, not silently solved elsewhere.
+#ifndef LVF_CERES_ADAPTER_HPP_
+#define LVF_CERES_ADAPTER_HPP_
+
+#if defined(__has_include)
+#if __has_include(<ceres/ceres.h>) && !defined(LVF_FORCE_CERES_COMPAT)
+#include <ceres/ceres.h>
+#define LVF_HAVE_REAL_CERES 1
+#endif
+#endif
+#ifndef LVF_HAVE_REAL_CERES
+#include "lvf_ceres_compat.h"
+#endif
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "lvf.h"
+
+namespace lvio_fusion {
+namespace gpu {
+
+// --------------------------------------------------------------------------------------------- context per host thread
+// Backend::Optimize and Relocator::CorrectLoop -> Mapping::Relocate can be in flight at once (relocator.cpp:188), and
+// Ceres calls Evaluate from its worker threads: every host thread gets its own context (= its own HIP stream).
+// Device: LVF_DEVICE environment variable, default 0.
+struct ThreadContext {
+  lvf_ctx* ctx = nullptr;
+  std::string error;
+  ThreadContext() {
+    const char* d = std::getenv("LVF_DEVICE");
+    if (lvf_ctx_create(d ? std::atoi(d) : 0, nullptr, &ctx) != LVF_OK) { error = lvf_last_error(); ctx = nullptr; }
+  }
+  ~ThreadContext() { if (ctx) lvf_ctx_destroy(ctx); }
+};
+inline ThreadContext& thread_context() {
+  static thread_local ThreadContext tc;
+  return tc;
+}
+
+enum class Kind { PoseOnly, TwoFrame, TwoCamera, Imu, LidarPlaneRPZ, LidarPlaneYXY, PoseErrorRPZ, PoseErrorYXY, PoseGraph, Pose };
+
+// RAII for the C handles used inside one call
+struct Handles {
+  std::vector<lvf_batch*> batches;
+  lvf_state* st = nullptr;
+  lvf_problem* prob = nullptr;
+  ~Handles() {
+    if (prob) lvf_problem_destroy(prob);
+    for (auto* b : batches) if (b) lvf_batch_destroy(b);
+    if (st) lvf_state_destroy(st);
+  }
+  lvf_batch* keep(lvf_batch* b) { batches.push_back(b); return b; }
+};
+
+// --------------------------------------------------------------------------------------------- tagged cost functions
+class GpuCostFunction {
+ public:
+  virtual ~GpuCostFunction() {}
+  virtual Kind kind() const = 0;
+};
+
+namespace detail {
+inline bool fetch(lvf_batch* b, int n_blocks, const int* sizes, int n_res, double* residuals, double** jacobians) {
+  if (lvf_batch_download_residuals(b, residuals) != LVF_OK) return false;
+  if (jacobians)
+    for (int k = 0; k < n_blocks; ++k)
+      if (jacobians[k] && lvf_batch_download_jacobian(b, k, jacobians[k]) != LVF_OK) return false;
+  (void)sizes; (void)n_res;
+  return true;
+}
+inline bool set_state(lvf_state* st, int field, const double* v) { return lvf_state_set(st, field, v) == LVF_OK; }
+}  // namespace detail
+
+// PoseOnlyReprojectionError <2,7>  visual_error.hpp:48-76 ; Create(ob, pw, camera, weight) :66
+class PoseOnlyReprojectionError : public ceres::SizedCostFunction<2, 7>, public GpuCostFunction {
+ public:
+  PoseOnlyReprojectionError(const double ob[2], const double pw[3], const lvf_camera& camera, double weight) : cam(camera), weight(weight) {
+    std::memcpy(this->ob, ob, sizeof(this->ob)); std::memcpy(this->pw, pw, sizeof(this->pw));
+  }
+  static ceres::CostFunction* Create(const double ob[2], const double pw[3], const lvf_camera& camera, double weight) {
+    return new PoseOnlyReprojectionError(ob, pw, camera, weight);
+  }
+  Kind kind() const override { return Kind::PoseOnly; }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    ThreadContext& tc = thread_context();
+    if (!tc.ctx) return false;
+    Handles h;
+    const int32_t zero = 0;
+    if (lvf_state_create(tc.ctx, 1, 0, &h.st) != LVF_OK) return false;
+    if (!detail::set_state(h.st, LVF_POSES, parameters[0]) || !detail::set_state(h.st, LVF_W_VISUAL, &weight)) return false;
+    lvf_batch* b = nullptr;
+    if (lvf_pose_only_create(tc.ctx, &cam, 1, ob, &zero, &zero, 1, pw, &b) != LVF_OK) return false;
+    h.keep(b);
+    if (lvf_batch_evaluate(b, h.st, nullptr, jacobians != nullptr) != LVF_OK) return false;
+    const int sizes[1] = {7};
+    return detail::fetch(b, 1, sizes, 2, residuals, jacobians);
+  }
+  double ob[2], pw[3];
+  lvf_camera cam;
+  double weight;
+};
+
+// TwoFrameReprojectionError <2,1,7,7>  visual_error.hpp:78-107 ; Create(first_ob, ob, left, right, weight) :98
+class TwoFrameReprojectionError : public ceres::SizedCostFunction<2, 1, 7, 7>, public GpuCostFunction {
+ public:
+  TwoFrameReprojectionError(const double first_ob[2], const double ob[2], const lvf_camera& left, const lvf_camera& right, double weight)
+      : left(left), right(right), weight(weight) {
+    std::memcpy(this->first_ob, first_ob, sizeof(this->first_ob)); std::memcpy(this->ob, ob, sizeof(this->ob));
+  }
+  static ceres::CostFunction* Create(const double first_ob[2], const double ob[2], const lvf_camera& left, const lvf_camera& right, double weight) {
+    return new TwoFrameReprojectionError(first_ob, ob, left, right, weight);
+  }
+  Kind kind() const override { return Kind::TwoFrame; }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    ThreadContext& tc = thread_context();
+    if (!tc.ctx) return false;
+    Handles h;
+    const int32_t zero = 0, one = 1;
+    if (lvf_state_create(tc.ctx, 2, 1, &h.st) != LVF_OK) return false;
+    double poses[14], w2[2] = {weight, weight};
+    std::memcpy(poses, parameters[1], 56); std::memcpy(poses + 7, parameters[2], 56);
+    if (!detail::set_state(h.st, LVF_POSES, poses) || !detail::set_state(h.st, LVF_W_VISUAL, w2) ||
+        !detail::set_state(h.st, LVF_INV_DEPTH, parameters[0])) return false;
+    lvf_batch* b = nullptr;
+    if (lvf_two_frame_create(tc.ctx, &left, &right, 1, first_ob, ob, &zero, &zero, &one, &b) != LVF_OK) return false;
+    h.keep(b);
+    if (lvf_batch_evaluate(b, h.st, nullptr, jacobians != nullptr) != LVF_OK) return false;
+    const int sizes[3] = {1, 7, 7};
+    return detail::fetch(b, 3, sizes, 2, residuals, jacobians);
+  }
+  double first_ob[2], ob[2];
+  lvf_camera left, right;
+  double weight;
+};
+
+// TwoCameraReprojectionError <2,1>  visual_error.hpp:109-137 ; Create(left_ob, right_ob, left, right, weight) :128
+// (weight is what the caller passes — backend.cpp:123 passes 5 * frame->weights.visual)
+class TwoCameraReprojectionError : public ceres::SizedCostFunction<2, 1>, public GpuCostFunction {
+ public:
+  TwoCameraReprojectionError(const double left_ob[2], const double right_ob[2], const lvf_camera& left, const lvf_camera& right, double weight)
+      : left(left), right(right), weight(weight) {
+    std::memcpy(this->left_ob, left_ob, sizeof(this->left_ob)); std::memcpy(this->right_ob, right_ob, sizeof(this->right_ob));
+  }
+  static ceres::CostFunction* Create(const double left_ob[2], const double right_ob[2], const lvf_camera& left, const lvf_camera& right, double weight) {
+    return new TwoCameraReprojectionError(left_ob, right_ob, left, right, weight);
+  }
+  Kind kind() const override { return Kind::TwoCamera; }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    ThreadContext& tc = thread_context();
+    if (!tc.ctx) return false;
+    Handles h;
+    const int32_t zero = 0;
+    if (lvf_state_create(tc.ctx, 1, 1, &h.st) != LVF_OK) return false;
+    const double wk = weight / 5.0;   // the library applies the reference's 5x to the per-keyframe visual weight
+    if (!detail::set_state(h.st, LVF_W_VISUAL, &wk) || !detail::set_state(h.st, LVF_INV_DEPTH, parameters[0])) return false;
+    lvf_batch* b = nullptr;
+    if (lvf_two_camera_create(tc.ctx, &left, &right, 1, left_ob, right_ob, &zero, &zero, &b) != LVF_OK) return false;
+    h.keep(b);
+    if (lvf_batch_evaluate(b, h.st, nullptr, jacobians != nullptr) != LVF_OK) return false;
+    const int sizes[1] = {1};
+    return detail::fetch(b, 1, sizes, 2, residuals, jacobians);
+  }
+  double left_ob[2], right_ob[2];
+  lvf_camera left, right;
+  double weight;
+};
+
+// ImuError : SizedCostFunction<15,7,3,3,3,7,3,3,3>  imu_error.hpp:12-122 ; Create(preintegration) :110
+// The reference holds a shared_ptr to the live Preintegration (read-only during a solve); here the snapshot is copied.
+class ImuError : public ceres::SizedCostFunction<15, 7, 3, 3, 3, 7, 3, 3, 3>, public GpuCostFunction {
+ public:
+  explicit ImuError(const lvf_preint& preintegration) : pre(preintegration) {}
+  static ceres::CostFunction* Create(const lvf_preint& preintegration) { return new ImuError(preintegration); }
+  Kind kind() const override { return Kind::Imu; }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    ThreadContext& tc = thread_context();
+    if (!tc.ctx) return false;
+    Handles h;
+    const int32_t zero = 0, one = 1;
+    if (lvf_state_create(tc.ctx, 2, 0, &h.st) != LVF_OK) return false;
+    double poses[14], v[6], ba[6], bg[6];
+    std::memcpy(poses, parameters[0], 56); std::memcpy(poses + 7, parameters[4], 56);
+    std::memcpy(v, parameters[1], 24); std::memcpy(v + 3, parameters[5], 24);
+    std::memcpy(ba, parameters[2], 24); std::memcpy(ba + 3, parameters[6], 24);
+    std::memcpy(bg, parameters[3], 24); std::memcpy(bg + 3, parameters[7], 24);
+    if (!detail::set_state(h.st, LVF_POSES, poses) || !detail::set_state(h.st, LVF_VEL, v) || !detail::set_state(h.st, LVF_BA, ba) ||
+        !detail::set_state(h.st, LVF_BG, bg)) return false;
+    lvf_batch* b = nullptr;
+    if (lvf_imu_create(tc.ctx, 1, &pre, &zero, &one, &b) != LVF_OK) return false;
+    h.keep(b);
+    if (lvf_batch_evaluate(b, h.st, nullptr, jacobians != nullptr) != LVF_OK) return false;
+    const int sizes[8] = {7, 3, 3, 3, 7, 3, 3, 3};
+    return detail::fetch(b, 8, sizes, 15, residuals, jacobians);
+  }
+  lvf_preint pre;
+};
+
+// LidarPlaneErrorRPZ / LidarPlaneErrorYXY <1,1,1,1>  lidar_error.hpp:42-110
+// Create(p, pa, pb, pc, Twc1, rpyxyz, weight) :65,:100 — rpyxyz is the caller's LIVE array (lidar_error.hpp:52,87).
+class LidarPlaneErrorBase : public ceres::SizedCostFunction<1, 1, 1, 1>, public GpuCostFunction {
+ public:
+  LidarPlaneErrorBase(int mode, const double p[3], const double pa[3], const double pb[3], const double pc[3], const double Twc1[7],
+                      double* rpyxyz, double weight) : mode(mode), rpyxyz(rpyxyz), weight(weight) {
+    std::memcpy(this->p, p, 24); std::memcpy(this->pa, pa, 24); std::memcpy(this->pb, pb, 24); std::memcpy(this->pc, pc, 24);
+    std::memcpy(this->Twc1, Twc1, 56);
+  }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    ThreadContext& tc = thread_context();
+    if (!tc.ctx) return false;
+    Handles h;
+    double x[6];
+    std::memcpy(x, rpyxyz, sizeof(x));
+    const int s0 = mode == 0 ? 1 : 0, s1 = mode == 0 ? 2 : 3, s2 = mode == 0 ? 5 : 4;
+    x[s0] = parameters[0][0]; x[s1] = parameters[1][0]; x[s2] = parameters[2][0];
+    lvf_batch* b = nullptr;
+    if (lvf_lidar_plane_create(tc.ctx, mode, 1, p, pa, pb, pc, Twc1, weight, &b) != LVF_OK) return false;
+    h.keep(b);
+    if (lvf_batch_evaluate(b, nullptr, x, jacobians != nullptr) != LVF_OK) return false;
+    const int sizes[3] = {1, 1, 1};
+    return detail::fetch(b, 3, sizes, 1, residuals, jacobians);
+  }
+  int mode;
+  double p[3], pa[3], pb[3], pc[3], Twc1[7];
+  double* rpyxyz;
+  double weight;
+};
+class LidarPlaneErrorRPZ : public LidarPlaneErrorBase {
+ public:
+  using LidarPlaneErrorBase::LidarPlaneErrorBase;
+  static ceres::CostFunction* Create(const double p[3], const double pa[3], const double pb[3], const double pc[3], const double Twc1[7],
+                                     double* rpyxyz, double weight) { return new LidarPlaneErrorRPZ(0, p, pa, pb, pc, Twc1, rpyxyz, weight); }
+  Kind kind() const override { return Kind::LidarPlaneRPZ; }
+};
+class LidarPlaneErrorYXY : public LidarPlaneErrorBase {
+ public:
+  using LidarPlaneErrorBase::LidarPlaneErrorBase;
+  static ceres::CostFunction* Create(const double p[3], const double pa[3], const double pb[3], const double pc[3], const double Twc1[7],
+                                     double* rpyxyz, double weight) { return new LidarPlaneErrorYXY(1, p, pa, pb, pc, Twc1, rpyxyz, weight); }
+  Kind kind() const override { return Kind::LidarPlaneYXY; }
+};
+
+// PoseErrorRPZ / PoseErrorYXY <3,1,1,1>  pose_error.hpp:135-190 ; Create(rpyxyz, weight): the target is COPIED at
+// construction (:139-141, :167-169).  target[] is kept in parameter order (p,r,z) / (Y,x,y).
+class PoseError3Base : public ceres::SizedCostFunction<3, 1, 1, 1>, public GpuCostFunction {
+ public:
+  PoseError3Base(int mode, const double* rpyxyz, double weight) : mode(mode), weight(weight) {
+    if (mode == 0) { target[0] = rpyxyz[1]; target[1] = rpyxyz[2]; target[2] = rpyxyz[5]; }
+    else { target[0] = rpyxyz[0]; target[1] = rpyxyz[3]; target[2] = rpyxyz[4]; }
+  }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    ThreadContext& tc = thread_context();
+    if (!tc.ctx) return false;
+    const double x[3] = {parameters[0][0], parameters[1][0], parameters[2][0]};
+    double J[9];
+    if (lvf_prior3_evaluate(tc.ctx, mode, target, weight, x, residuals, jacobians ? J : nullptr) != LVF_OK) return false;
+    if (jacobians) for (int k = 0; k < 3; ++k) if (jacobians[k]) std::memcpy(jacobians[k], J + 3 * k, 24);
+    return true;
+  }
+  int mode;
+  double target[3];
+  double weight;
+};
+class PoseErrorRPZ : public PoseError3Base {
+ public:
+  using PoseError3Base::PoseError3Base;
+  static ceres::CostFunction* Create(double* rpyxyz, double weight = 1) { return new PoseErrorRPZ(0, rpyxyz, weight); }
+  Kind kind() const override { return Kind::PoseErrorRPZ; }
+};
+class PoseErrorYXY : public PoseError3Base {
+ public:
+  using PoseError3Base::PoseError3Base;
+  static ceres::CostFunction* Create(double* rpyxyz, double weight = 1) { return new PoseErrorYXY(1, rpyxyz, weight); }
+  Kind kind() const override { return Kind::PoseErrorYXY; }
+};
+
+// PoseGraphError <6,7,7>  pose_error.hpp:10-53 ; Create(last_pose, pose, weight, v) :40 / Create(relative_i_j, weight, v) :45
+class PoseGraphError : public ceres::SizedCostFunction<6, 7, 7>, public GpuCostFunction {
+ public:
+  PoseGraphError(const double rpyxyz_target[6], double weight, double v) : weight(weight), v(v) { std::memcpy(target, rpyxyz_target, 48); target[6] = 0.0; }
+  static ceres::CostFunction* Create(const double last_pose[7], const double pose[7], double weight = 1, double v = 1) {
+    double t[6];
+    if (lvf_relative_rpyxyz(last_pose, pose, t) != LVF_OK) return nullptr;
+    return new PoseGraphError(t, weight, v);
+  }
+  static ceres::CostFunction* Create(const double relative_i_j[7], double weight = 1, double v = 1) {
+    const double id[7] = {0, 0, 0, 1, 0, 0, 0};
+    return Create(id, relative_i_j, weight, v);
+  }
+  Kind kind() const override { return Kind::PoseGraph; }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    ThreadContext& tc = thread_context();
+    if (!tc.ctx) return false;
+    Handles h;
+    const int32_t zero = 0, one = 1;
+    if (lvf_state_create(tc.ctx, 2, 0, &h.st) != LVF_OK) return false;
+    double poses[14];
+    std::memcpy(poses, parameters[0], 56); std::memcpy(poses + 7, parameters[1], 56);
+    if (!detail::set_state(h.st, LVF_POSES, poses)) return false;
+    lvf_batch* b = nullptr;
+    if (lvf_pose_prior_create(tc.ctx, 1, &zero, &one, target, &weight, &v, &b) != LVF_OK) return false;
+    h.keep(b);
+    if (lvf_batch_evaluate(b, h.st, nullptr, jacobians != nullptr) != LVF_OK) return false;
+    const int sizes[2] = {7, 7};
+    return detail::fetch(b, 2, sizes, 6, residuals, jacobians);
+  }
+  double target[7];
+  double weight, v;
+};
+
+// PoseError <6,7>  pose_error.hpp:55-86 ; Create(pose, weight, v) :78
+class PoseError : public ceres::SizedCostFunction<6, 7>, public GpuCostFunction {
+ public:
+  PoseError(const double pose[7], double weight, double v) : weight(weight), v(v) { std::memcpy(origin, pose, 56); }
+  static ceres::CostFunction* Create(const double pose[7], double weight = 1, double v = 1) { return new PoseError(pose, weight, v); }
+  Kind kind() const override { return Kind::Pose; }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    ThreadContext& tc = thread_context();
+    if (!tc.ctx) return false;
+    Handles h;
+    const int32_t minus = -1, zero = 0;
+    if (lvf_state_create(tc.ctx, 1, 0, &h.st) != LVF_OK) return false;
+    if (!detail::set_state(h.st, LVF_POSES, parameters[0])) return false;
+    lvf_batch* b = nullptr;
+    if (lvf_pose_prior_create(tc.ctx, 1, &minus, &zero, origin, &weight, &v, &b) != LVF_OK) return false;
+    h.keep(b);
+    if (lvf_batch_evaluate(b, h.st, nullptr, jacobians != nullptr) != LVF_OK) return false;
+    if (lvf_batch_download_residuals(b, residuals) != LVF_OK) return false;
+    if (jacobians && jacobians[0] && lvf_batch_download_jacobian(b, 1, jacobians[0]) != LVF_OK) return false;   // block 1 = the pose
+    return true;
+  }
+  double origin[7];
+  double weight, v;
+};
+
+// --------------------------------------------------------------------------------------------- problem -> device
+namespace detail {
+
+// HuberLoss(a) / TrivialLoss / NULL are told apart through the LossFunction's own public Evaluate: for s > a^2 Huber has
+// rho'(s) = a / sqrt(s) (so rho'(4s) = rho'(s)/2), Trivial has rho' = 1.  Returns a (0 = no robustification), or -1 if
+// the loss is neither.
+inline double probe_huber(const ceres::LossFunction* loss) {
+  if (!loss) return 0.0;
+  double r1[3], r2[3];
+  const double s = 1e12;
+  loss->Evaluate(s, r1); loss->Evaluate(4.0 * s, r2);
+  if (r1[1] == 1.0 && r2[1] == 1.0) return 0.0;
+  const double a = r1[1] * std::sqrt(s);
+  if (a > 0.0 && std::fabs(r2[1] * 2.0 - r1[1]) <= 1e-12 * r1[1]) {
+    double r0[3];
+    loss->Evaluate(0.25 * a * a, r0);   // inside the quadratic zone rho(s) = s
+    if (std::fabs(r0[0] - 0.25 * a * a) <= 1e-12 * a * a && r0[1] == 1.0) return a;
+  }
+  return -1.0;
+}
+
+inline bool same_cam(const lvf_camera& a, const lvf_camera& b) { return std::memcmp(&a, &b, sizeof(lvf_camera)) == 0; }
+
+struct Fail {
+  ceres::Solver::Summary* s;
+  bool operator()(const std::string& why) const {
+    s->termination_type = ceres::FAILURE;
+    s->message = "lvf: " + why;
+    return false;
+  }
+};
+
+struct BlockView {
+  const ceres::CostFunction* cf;
+  const GpuCostFunction* g;
+  const ceres::LossFunction* loss;
+  std::vector<double*> params;
+};
+
+inline bool collect(ceres::Problem* problem, std::vector<BlockView>* out, const Fail& fail) {
+  std::vector<ceres::ResidualBlockId> ids;
+  problem->GetResidualBlocks(&ids);
+  out->reserve(ids.size());
+  for (size_t i = 0; i < ids.size(); ++i) {
+    BlockView v;
+    v.cf = problem->GetCostFunctionForResidualBlock(ids[i]);
+    v.g = dynamic_cast<const GpuCostFunction*>(v.cf);
+    if (!v.g) return fail("residual block " + std::to_string(i) + " is not an lvio_fusion::gpu cost function (no CPU solver is linked)");
+    v.loss = problem->GetLossFunctionForResidualBlock(ids[i]);
+    problem->GetParameterBlocksForResidualBlock(ids[i], &v.params);
+    out->push_back(std::move(v));
+  }
+  return true;
+}
+
+// ---- scan-to-map sub-problem: N x LidarPlaneError{RPZ|YXY} + at most one PoseError{RPZ|YXY}
+inline bool solve_lidar(const ceres::Solver::Options& options, ceres::Problem* problem, const std::vector<BlockView>& blocks,
+                        ceres::Solver::Summary* summary, const Fail& fail) {
+  ThreadContext& tc = thread_context();
+  if (!tc.ctx) return fail("no usable GPU context: " + tc.error);
+  int mode = -1;
+  const LidarPlaneErrorBase* first = nullptr;
+  const PoseError3Base* prior = nullptr;
+  double* prm[3] = {nullptr, nullptr, nullptr};
+  std::vector<double> p, pa, pb, pc;
+  const ceres::LossFunction* loss = nullptr;
+  for (const BlockView& b : blocks) {
+    const Kind k = b.g->kind();
+    const int m = (k == Kind::LidarPlaneRPZ || k == Kind::PoseErrorRPZ) ? 0 : 1;
+    if (mode < 0) mode = m;
+    if (m != mode) return fail("RPZ and YXY blocks mixed in one scan-to-map problem");
+    if (!prm[0]) { prm[0] = b.params[0]; prm[1] = b.params[1]; prm[2] = b.params[2]; }
+    if (b.params[0] != prm[0] || b.params[1] != prm[1] || b.params[2] != prm[2]) return fail("scan-to-map blocks do not share their three parameter blocks");
+    if (k == Kind::LidarPlaneRPZ || k == Kind::LidarPlaneYXY) {
+      const auto* f = static_cast<const LidarPlaneErrorBase*>(b.g);
+      if (!first) { first = f; loss = b.loss; }
+      if (std::memcmp(f->Twc1, first->Twc1, 56) != 0 || f->weight != first->weight || f->rpyxyz != first->rpyxyz)
+        return fail("lidar blocks of one problem must share Twc1, weight and the live rpyxyz array");
+      if (b.loss != loss) return fail("lidar blocks of one problem must share one loss function");
+      p.insert(p.end(), f->p, f->p + 3); pa.insert(pa.end(), f->pa, f->pa + 3);
+      pb.insert(pb.end(), f->pb, f->pb + 3); pc.insert(pc.end(), f->pc, f->pc + 3);
+    } else {
+      if (prior) return fail("more than one PoseErrorRPZ/YXY prior");
+      if (b.loss && probe_huber(b.loss) != 0.0) return fail("a robust loss on the PoseErrorRPZ/YXY prior is not supported");
+      prior = static_cast<const PoseError3Base*>(b.g);
+    }
+  }
+  for (int k = 0; k < 3; ++k)
+    if (problem->IsParameterBlockConstant(prm[k])) return fail("constant parameter blocks are not supported in the scan-to-map problem");
+  const double huber = probe_huber(loss);
+  if (huber < 0.0) return fail("unsupported loss function (only HuberLoss / TrivialLoss / NULL)");
+  const int s0 = mode == 0 ? 1 : 0, s1 = mode == 0 ? 2 : 3, s2 = mode == 0 ? 5 : 4;
+  double x[6] = {0, 0, 0, 0, 0, 0};
+  const double id7[7] = {0, 0, 0, 1, 0, 0, 0};
+  if (first) std::memcpy(x, first->rpyxyz, sizeof(x));
+  x[s0] = *prm[0]; x[s1] = *prm[1]; x[s2] = *prm[2];
+  if (prior && (prior->target[0] != x[s0] || prior->target[1] != x[s1] || prior->target[2] != x[s2]))
+    return fail("the PoseErrorRPZ/YXY target must equal the initial parameter values (as mapping.cpp builds it)");
+  Handles h;
+  lvf_batch* b = nullptr;
+  const int n = (int)(p.size() / 3);
+  if (lvf_lidar_plane_create(tc.ctx, mode, n, p.data(), pa.data(), pb.data(), pc.data(), first ? first->Twc1 : id7, first ? first->weight : 1.0, &b) != LVF_OK)
+    return fail(lvf_last_error());
+  h.keep(b);
+  lvf_icp_options o;
+  std::memset(&o, 0, sizeof(o));
+  o.mode = mode; o.huber_a = huber; o.prior_weight = prior ? prior->weight : 0.0; o.max_num_iterations = options.max_num_iterations;
+  lvf_icp_summary s;
+  if (lvf_lidar_solve(b, x, &o, &s) != LVF_OK) return fail(lvf_last_error());
+  *prm[0] = x[s0]; *prm[1] = x[s1]; *prm[2] = x[s2];          // in place, like ceres::Solve
+  summary->initial_cost = s.initial_cost; summary->final_cost = s.final_cost;
+  summary->num_successful_steps = s.num_successful_steps; summary->num_unsuccessful_steps = s.num_iterations - s.num_successful_steps;
+  summary->num_residual_blocks = summary->num_residual_blocks_reduced = (int)blocks.size();
+  summary->num_parameter_blocks = summary->num_parameter_blocks_reduced = 3;
+  summary->termination_type = s.num_iterations >= options.max_num_iterations ? ceres::NO_CONVERGENCE : ceres::CONVERGENCE;
+  summary->message = "scan-to-map sub-problem solved on device";
+  return true;
+}
+
+// ---- sliding-window BA: the device image of what Backend::BuildProblem registered
+struct Window {
+  std::vector<double*> pose_ptr, lm_ptr;
+  std::unordered_map<double*, int> pose_id, lm_id;
+  std::vector<double*> v_ptr, ba_ptr, bg_ptr;      // per keyframe, null if the frame has no IMU blocks
+  std::vector<double> w_kf;
+  std::vector<char> w_known;
+  // batches (insertion order preserved per type)
+  std::vector<double> tc_l, tc_r; std::vector<int32_t> tc_lm, tc_kf; std::vector<double> tc_w;
+  std::vector<double> tf_f, tf_o; std::vector<int32_t> tf_lm, tf_k1, tf_k2;
+  std::vector<double> po_o, po_pw; std::vector<int32_t> po_kf, po_pi;
+  std::vector<lvf_preint> imu_pre; std::vector<int32_t> imu_i, imu_j;
+  std::vector<int32_t> pr_a, pr_b; std::vector<double> pr_t, pr_w, pr_v;
+  std::vector<int> order_kind, order_idx;          // per residual block: which batch, which row
+  lvf_camera left, right; bool have_left = false, have_right = false;
+  double huber = -2.0;                             // -2 = not seen yet
+};
+
+inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& blocks, Window* w, const Fail& fail) {
+  // keyframes = 7-sized parameter blocks in the order the caller registered them (BuildProblem walks frames in time order)
+  std::vector<double*> all;
+  problem->GetParameterBlocks(&all);
+  for (double* p : all) {
+    const int sz = problem->ParameterBlockSize(p);
+    if (sz == 7) { w->pose_id[p] = (int)w->pose_ptr.size(); w->pose_ptr.push_back(p); }
+  }
+  const int n_kf = (int)w->pose_ptr.size();
+  if (n_kf == 0) return fail("no pose parameter blocks in the problem");
+  w->v_ptr.assign(n_kf, nullptr); w->ba_ptr.assign(n_kf, nullptr); w->bg_ptr.assign(n_kf, nullptr);
+  w->w_kf.assign(n_kf, 1.0); w->w_known.assign(n_kf, 0);
+  auto kf_of = [&](double* p) { auto it = w->pose_id.find(p); return it == w->pose_id.end() ? -1 : it->second; };
+  auto lm_of = [&](double* p) {
+    auto it = w->lm_id.find(p);
+    if (it != w->lm_id.end()) return it->second;
+    const int id = (int)w->lm_ptr.size();
+    w->lm_id[p] = id; w->lm_ptr.push_back(p);
+    return id;
+  };
+  auto set_w = [&](int kf, double wv) {
+    if (w->w_known[kf] && w->w_kf[kf] != wv) return false;
+    w->w_kf[kf] = wv; w->w_known[kf] = 1;
+    return true;
+  };
+  auto use_cam = [&](const lvf_camera& c, lvf_camera* slot, bool* have) {
+    if (!*have) { *slot = c; *have = true; return true; }
+    return same_cam(*slot, c);
+  };
+  auto use_loss = [&](const ceres::LossFunction* loss) {
+    const double a = probe_huber(loss);
+    if (a < 0.0) return false;
+    if (w->huber == -2.0) w->huber = a;
+    return w->huber == a;
+  };
+  auto bind3 = [&](std::vector<double*>& slot, int kf, double* p) {
+    if (slot[kf] && slot[kf] != p) return false;
+    slot[kf] = p;
+    return true;
+  };
+  std::vector<size_t> two_camera_pending;
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    const BlockView& b = blocks[i];
+    const std::string at = "residual block " + std::to_string(i) + ": ";
+    switch (b.g->kind()) {
+      case Kind::PoseOnly: {
+        const auto* f = static_cast<const PoseOnlyReprojectionError*>(b.g);
+        const int kf = kf_of(b.params[0]);
+        if (kf < 0) return fail(at + "pose block not registered");
+        if (!set_w(kf, f->weight)) return fail(at + "visual blocks of one keyframe must share one weight (frame->weights.visual)");
+        if (!use_cam(f->cam, &w->left, &w->have_left)) return fail(at + "all blocks must share the left camera");
+        if (!use_loss(b.loss)) return fail(at + "visual blocks must share one HuberLoss/TrivialLoss");
+        w->order_kind.push_back(2); w->order_idx.push_back((int)w->po_kf.size());
+        w->po_o.insert(w->po_o.end(), f->ob, f->ob + 2); w->po_pw.insert(w->po_pw.end(), f->pw, f->pw + 3);
+        w->po_pi.push_back((int)w->po_kf.size()); w->po_kf.push_back(kf);
+        break;
+      }
+      case Kind::TwoFrame: {
+        const auto* f = static_cast<const TwoFrameReprojectionError*>(b.g);
+        const int k1 = kf_of(b.params[1]), k2 = kf_of(b.params[2]);
+        if (k1 < 0 || k2 < 0) return fail(at + "pose block not registered");
+        if (!set_w(k2, f->weight)) return fail(at + "visual blocks of one keyframe must share one weight (frame->weights.visual)");
+        if (!use_cam(f->left, &w->left, &w->have_left) || !use_cam(f->right, &w->right, &w->have_right)) return fail(at + "all blocks must share the stereo pair");
+        if (!use_loss(b.loss)) return fail(at + "visual blocks must share one HuberLoss/TrivialLoss");
+        w->order_kind.push_back(1); w->order_idx.push_back((int)w->tf_lm.size());
+        w->tf_f.insert(w->tf_f.end(), f->first_ob, f->first_ob + 2); w->tf_o.insert(w->tf_o.end(), f->ob, f->ob + 2);
+        w->tf_lm.push_back(lm_of(b.params[0])); w->tf_k1.push_back(k1); w->tf_k2.push_back(k2);
+        break;
+      }
+      case Kind::TwoCamera: {
+        const auto* f = static_cast<const TwoCameraReprojectionError*>(b.g);
+        if (!use_cam(f->left, &w->left, &w->have_left) || !use_cam(f->right, &w->right, &w->have_right)) return fail(at + "all blocks must share the stereo pair");
+        if (!use_loss(b.loss)) return fail(at + "visual blocks must share one HuberLoss/TrivialLoss");
+        w->order_kind.push_back(0); w->order_idx.push_back((int)w->tc_lm.size());
+        w->tc_l.insert(w->tc_l.end(), f->left_ob, f->left_ob + 2); w->tc_r.insert(w->tc_r.end(), f->right_ob, f->right_ob + 2);
+        w->tc_lm.push_back(lm_of(b.params[0])); w->tc_kf.push_back(-1); w->tc_w.push_back(f->weight / 5.0);
+        two_camera_pending.push_back(w->tc_kf.size() - 1);
+        break;
+      }
+      case Kind::Imu: {
+        const auto* f = static_cast<const ImuError*>(b.g);
+        const int ki = kf_of(b.params[0]), kj = kf_of(b.params[4]);
+        if (ki < 0 || kj < 0) return fail(at + "pose block not registered");
+        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at + "a robust loss on ImuError is not supported (the reference passes NULL)");
+        if (!bind3(w->v_ptr, ki, b.params[1]) || !bind3(w->ba_ptr, ki, b.params[2]) || !bind3(w->bg_ptr, ki, b.params[3]) ||
+            !bind3(w->v_ptr, kj, b.params[5]) || !bind3(w->ba_ptr, kj, b.params[6]) || !bind3(w->bg_ptr, kj, b.params[7]))
+          return fail(at + "a keyframe is linked to two different velocity/bias blocks");
+        w->order_kind.push_back(3); w->order_idx.push_back((int)w->imu_i.size());
+        w->imu_pre.push_back(f->pre); w->imu_i.push_back(ki); w->imu_j.push_back(kj);
+        break;
+      }
+      case Kind::PoseGraph: {
+        const auto* f = static_cast<const PoseGraphError*>(b.g);
+        const int ka = kf_of(b.params[0]), kb = kf_of(b.params[1]);
+        if (ka < 0 || kb < 0) return fail(at + "pose block not registered");
+        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at + "a robust loss on PoseGraphError is not supported (the reference passes NULL)");
+        w->order_kind.push_back(4); w->order_idx.push_back((int)w->pr_a.size());
+        w->pr_a.push_back(ka); w->pr_b.push_back(kb); w->pr_t.insert(w->pr_t.end(), f->target, f->target + 7);
+        w->pr_w.push_back(f->weight); w->pr_v.push_back(f->v);
+        break;
+      }
+      case Kind::Pose: {
+        const auto* f = static_cast<const PoseError*>(b.g);
+        const int kb = kf_of(b.params[0]);
+        if (kb < 0) return fail(at + "pose block not registered");
+        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at + "a robust loss on PoseError is not supported (the reference passes NULL)");
+        w->order_kind.push_back(4); w->order_idx.push_back((int)w->pr_a.size());
+        w->pr_a.push_back(-1); w->pr_b.push_back(kb); w->pr_t.insert(w->pr_t.end(), f->origin, f->origin + 7);
+        w->pr_w.push_back(f->weight); w->pr_v.push_back(f->v);
+        break;
+      }
+      default: return fail(at + "lidar blocks cannot be mixed into a BA window");
+    }
+  }
+  // TwoCamera blocks only carry a weight (5 * frame->weights.visual); the library looks weights up per keyframe, so each
+  // block is pointed at ANY keyframe with that weight, claiming a keyframe of still-unknown weight if none matches.
+  for (size_t idx : two_camera_pending) {
+    const double wv = w->tc_w[idx];
+    int hit = -1;
+    for (int k = 0; k < n_kf && hit < 0; ++k) if (w->w_known[k] && w->w_kf[k] == wv) hit = k;
+    for (int k = 0; k < n_kf && hit < 0; ++k) if (!w->w_known[k]) { w->w_kf[k] = wv; w->w_known[k] = 1; hit = k; }
+    if (hit < 0) return fail("TwoCameraReprojectionError weight " + std::to_string(5.0 * wv) + " matches no keyframe's 5 x visual weight");
+    w->tc_kf[idx] = hit;
+  }
+  if (w->huber == -2.0) w->huber = 0.0;
+  // parameter blocks the device solver cannot hold constant individually
+  for (double* p : w->lm_ptr) if (problem->IsParameterBlockConstant(p)) return fail("constant inverse-depth blocks are not supported");
+  for (int k = 0; k < n_kf; ++k)
+    for (double* p : {w->v_ptr[k], w->ba_ptr[k], w->bg_ptr[k]})
+      if (p && problem->IsParameterBlockConstant(p)) return fail("constant velocity/bias blocks are not supported");
+  return true;
+}
+
+struct DeviceWindow {
+  Handles h;
+  lvf_batch *tc = nullptr, *tf = nullptr, *po = nullptr, *imu = nullptr, *prior = nullptr;
+};
+
+inline bool upload_window(lvf_ctx* ctx, ceres::Problem* problem, const Window& w, DeviceWindow* d, const Fail& fail) {
+  const int n_kf = (int)w.pose_ptr.size(), n_lm = (int)w.lm_ptr.size();
+  if (lvf_state_create(ctx, n_kf, n_lm, &d->h.st) != LVF_OK) return fail(lvf_last_error());
+  std::vector<double> poses(7 * (size_t)n_kf), vel(3 * (size_t)n_kf, 0.0), ba(vel), bg(vel), invd(n_lm);
+  for (int k = 0; k < n_kf; ++k) {
+    std::memcpy(&poses[7 * (size_t)k], w.pose_ptr[k], 56);
+    if (w.v_ptr[k]) std::memcpy(&vel[3 * (size_t)k], w.v_ptr[k], 24);
+    if (w.ba_ptr[k]) std::memcpy(&ba[3 * (size_t)k], w.ba_ptr[k], 24);
+    if (w.bg_ptr[k]) std::memcpy(&bg[3 * (size_t)k], w.bg_ptr[k], 24);
+  }
+  for (int l = 0; l < n_lm; ++l) invd[l] = *w.lm_ptr[l];
+  lvf_state* st = d->h.st;
+  if (lvf_state_set(st, LVF_POSES, poses.data()) || lvf_state_set(st, LVF_VEL, vel.data()) || lvf_state_set(st, LVF_BA, ba.data()) ||
+      lvf_state_set(st, LVF_BG, bg.data()) || lvf_state_set(st, LVF_W_VISUAL, w.w_kf.data()) || (n_lm && lvf_state_set(st, LVF_INV_DEPTH, invd.data())))
+    return fail(lvf_last_error());
+  if (!w.tc_lm.empty()) {
+    if (lvf_two_camera_create(ctx, &w.left, &w.right, (int)w.tc_lm.size(), w.tc_l.data(), w.tc_r.data(), w.tc_lm.data(), w.tc_kf.data(), &d->tc) != LVF_OK)
+      return fail(lvf_last_error());
+    d->h.keep(d->tc);
+  }
+  if (!w.tf_lm.empty()) {
+    if (lvf_two_frame_create(ctx, &w.left, &w.right, (int)w.tf_lm.size(), w.tf_f.data(), w.tf_o.data(), w.tf_lm.data(), w.tf_k1.data(), w.tf_k2.data(), &d->tf) != LVF_OK)
+      return fail(lvf_last_error());
+    d->h.keep(d->tf);
+  }
+  if (!w.po_kf.empty()) {
+    if (lvf_pose_only_create(ctx, &w.left, (int)w.po_kf.size(), w.po_o.data(), w.po_kf.data(), w.po_pi.data(), (int)w.po_kf.size(), w.po_pw.data(), &d->po) != LVF_OK)
+      return fail(lvf_last_error());
+    d->h.keep(d->po);
+  }
+  if (!w.imu_i.empty()) {
+    if (lvf_imu_create(ctx, (int)w.imu_i.size(), w.imu_pre.data(), w.imu_i.data(), w.imu_j.data(), &d->imu) != LVF_OK) return fail(lvf_last_error());
+    d->h.keep(d->imu);
+  }
+  if (!w.pr_b.empty()) {
+    if (lvf_pose_prior_create(ctx, (int)w.pr_b.size(), w.pr_a.data(), w.pr_b.data(), w.pr_t.data(), w.pr_w.data(), w.pr_v.data(), &d->prior) != LVF_OK)
+      return fail(lvf_last_error());
+    d->h.keep(d->prior);
+  }
+  if (lvf_problem_create(ctx, st, d->tc, d->tf, d->po, d->imu, &d->h.prob) != LVF_OK) return fail(lvf_last_error());
+  if (d->prior && lvf_problem_set_pose_priors(d->h.prob, d->prior) != LVF_OK) return fail(lvf_last_error());
+  for (int k = 0; k < n_kf; ++k)
+    if (problem->IsParameterBlockConstant(w.pose_ptr[k]) && lvf_problem_set_pose_constant(d->h.prob, k, 1) != LVF_OK) return fail(lvf_last_error());
+  return true;
+}
+
+inline void to_lvf_options(const ceres::Solver::Options& o, double huber, lvf_solver_options* out) {
+  lvf_solver_options_default(out);
+  out->max_num_iterations = o.max_num_iterations;
+  out->max_solver_time_in_seconds = o.max_solver_time_in_seconds >= 1e8 ? 0.0 : o.max_solver_time_in_seconds;
+  out->huber_a = huber;
+  out->initial_trust_region_radius = o.initial_trust_region_radius;
+  out->function_tolerance = o.function_tolerance;
+  out->gradient_tolerance = o.gradient_tolerance;
+  out->parameter_tolerance = o.parameter_tolerance;
+  out->min_relative_decrease = o.min_relative_decrease;
+}
+
+inline bool solve_window(const ceres::Solver::Options& options, ceres::Problem* problem, const std::vector<BlockView>& blocks,
+                         ceres::Solver::Summary* summary, const Fail& fail) {
+  ThreadContext& tc = thread_context();
+  if (!tc.ctx) return fail("no usable GPU context: " + tc.error);
+  Window w;
+  if (!build_window(problem, blocks, &w, fail)) return false;
+  DeviceWindow d;
+  if (!upload_window(tc.ctx, problem, w, &d, fail)) return false;
+  lvf_solver_options o;
+  to_lvf_options(options, w.huber, &o);
+  lvf_solver_summary s;
+  if (lvf_problem_solve(d.h.prob, &o, &s) != LVF_OK) return fail(lvf_last_error());
+  if (s.termination == 2) return fail("device LM failed (normal equations not positive definite at the smallest trust region)");
+  // read back, then write IN PLACE into the caller's parameter arrays (frame->pose.data(), &landmark->inv_depth, ...)
+  const int n_kf = (int)w.pose_ptr.size(), n_lm = (int)w.lm_ptr.size();
+  std::vector<double> poses(7 * (size_t)n_kf), vel(3 * (size_t)n_kf), ba(vel), bg(vel), invd(n_lm);
+  lvf_state* st = d.h.st;
+  if (lvf_state_get(st, LVF_POSES, poses.data()) || lvf_state_get(st, LVF_VEL, vel.data()) || lvf_state_get(st, LVF_BA, ba.data()) ||
+      lvf_state_get(st, LVF_BG, bg.data()) || (n_lm && lvf_state_get(st, LVF_INV_DEPTH, invd.data()))) return fail(lvf_last_error());
+  for (int k = 0; k < n_kf; ++k) {
+    std::memcpy(w.pose_ptr[k], &poses[7 * (size_t)k], 56);
+    if (w.v_ptr[k]) std::memcpy(w.v_ptr[k], &vel[3 * (size_t)k], 24);
+    if (w.ba_ptr[k]) std::memcpy(w.ba_ptr[k], &ba[3 * (size_t)k], 24);
+    if (w.bg_ptr[k]) std::memcpy(w.bg_ptr[k], &bg[3 * (size_t)k], 24);
+  }
+  for (int l = 0; l < n_lm; ++l) *w.lm_ptr[l] = invd[l];
+  summary->initial_cost = s.initial_cost; summary->final_cost = s.final_cost;
+  summary->num_successful_steps = s.num_successful_steps; summary->num_unsuccessful_steps = s.num_iterations - s.num_successful_steps;
+  summary->num_residual_blocks = summary->num_residual_blocks_reduced = s.num_residual_blocks;
+  summary->num_parameter_blocks = summary->num_parameter_blocks_reduced = problem->NumParameterBlocks();
+  summary->termination_type = s.termination == 0 ? ceres::CONVERGENCE : ceres::NO_CONVERGENCE;
+  summary->message = "sliding-window BA solved on device";
+  return true;
+}
+
+}  // namespace detail
+
+// --------------------------------------------------------------------------------------------- the adapt::Solve body
+inline void Solve(const ceres::Solver::Options& options, ceres::Problem* problem, ceres::Solver::Summary* summary) {
+  const auto t0 = std::chrono::steady_clock::now();
+  *summary = ceres::Solver::Summary();
+  const detail::Fail fail{summary};
+  std::vector<detail::BlockView> blocks;
+  if (!detail::collect(problem, &blocks, fail)) return;
+  if (blocks.empty()) {
+    summary->termination_type = ceres::CONVERGENCE; summary->initial_cost = summary->final_cost = 0.0;
+    summary->num_successful_steps = summary->num_unsuccessful_steps = 0; summary->num_residual_blocks = summary->num_residual_blocks_reduced = 0;
+    summary->message = "empty problem";
+    return;
+  }
+  bool lidar = false;
+  for (const auto& b : blocks) {
+    const Kind k = b.g->kind();
+    if (k == Kind::LidarPlaneRPZ || k == Kind::LidarPlaneYXY || k == Kind::PoseErrorRPZ || k == Kind::PoseErrorYXY) { lidar = true; break; }
+  }
+  if (lidar) detail::solve_lidar(options, problem, blocks, summary, fail);
+  else detail::solve_window(options, problem, blocks, summary, fail);
+  summary->total_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// --------------------------------------------------------------------------------------------- batched Problem::Evaluate
+// cost = 1/2 sum rho(|r_b|^2) at the CURRENT parameter values; residuals (optional) = the raw residual vector in block
+// insertion order (apply_loss_function = false semantics for the vector, loss applied in the cost).  BA windows only.
+inline bool Evaluate(ceres::Problem* problem, double* cost, std::vector<double>* residuals, std::string* error = nullptr) {
+  ceres::Solver::Summary dummy;
+  const detail::Fail fail{&dummy};
+  auto bail = [&]() { if (error) *error = dummy.message; return false; };
+  std::vector<detail::BlockView> blocks;
+  if (!detail::collect(problem, &blocks, fail)) return bail();
+  ThreadContext& tc = thread_context();
+  if (!tc.ctx) { if (error) *error = tc.error; return false; }
+  detail::Window w;
+  if (!detail::build_window(problem, blocks, &w, fail)) return bail();
+  detail::DeviceWindow d;
+  if (!detail::upload_window(tc.ctx, problem, w, &d, fail)) return bail();
+  lvf_solver_options o;
+  detail::to_lvf_options(ceres::Solver::Options(), w.huber, &o);
+  if (cost && lvf_problem_cost(d.h.prob, &o, cost) != LVF_OK) { if (error) *error = lvf_last_error(); return false; }
+  if (residuals) {
+    lvf_batch* bs[5] = {d.tc, d.tf, d.po, d.imu, d.prior};
+    const int nres[5] = {2, 2, 2, 15, 6};
+    std::vector<double> r[5];
+    for (int k = 0; k < 5; ++k) {
+      if (!bs[k]) continue;
+      r[k].resize((size_t)lvf_batch_size(bs[k]) * nres[k]);
+      if (lvf_batch_evaluate(bs[k], d.h.st, nullptr, 0) != LVF_OK || lvf_batch_download_residuals(bs[k], r[k].data()) != LVF_OK) {
+        if (error) *error = lvf_last_error();
+        return false;
+      }
+    }
+    residuals->clear();
+    for (size_t i = 0; i < w.order_kind.size(); ++i) {
+      const int k = w.order_kind[i];
+      const double* src = r[k].data() + (size_t)w.order_idx[i] * nres[k];
+      residuals->insert(residuals->end(), src, src + nres[k]);
+    }
+  }
+  return true;
+}
+
+}  // namespace gpu
+}  // namespace lvio_fusion
+#endif  // LVF_CERES_ADAPTER_HPP_

@@ -77,6 +77,9 @@ _SIGS = {
     "lvf_two_camera_create": (C.c_int, [_VP, C.POINTER(Camera), C.POINTER(Camera), C.c_int, c_double_p, c_double_p, c_int_p, c_int_p, C.POINTER(_VP)]),
     "lvf_imu_create": (C.c_int, [_VP, C.c_int, c_double_p, c_int_p, c_int_p, C.POINTER(_VP)]),
     "lvf_lidar_plane_create": (C.c_int, [_VP, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, C.POINTER(_VP)]),
+    "lvf_pose_prior_create": (C.c_int, [_VP, C.c_int, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p, C.POINTER(_VP)]),
+    "lvf_relative_rpyxyz": (C.c_int, [c_double_p, c_double_p, c_double_p]),
+    "lvf_problem_set_pose_priors": (C.c_int, [_VP, _VP]),
     "lvf_batch_destroy": (C.c_int, [_VP]),
     "lvf_batch_size": (C.c_int, [_VP]),
     "lvf_batch_num_param_blocks": (C.c_int, [_VP]),
@@ -95,6 +98,8 @@ _SIGS = {
     "lvf_scan_download": (C.c_int, [_VP, c_int_p, c_float_p, c_u8_p]),
     "lvf_knn3_debug_stats": (C.c_int, [_VP, _VP, c_double_p, C.c_float, c_int_p, c_float_p, C.POINTER(C.c_int)]),
     "lvf_icp_solve": (C.c_int, [_VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
+    "lvf_lidar_solve": (C.c_int, [_VP, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
+    "lvf_prior3_evaluate": (C.c_int, [_VP, C.c_int, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p]),
     "lvf_solver_options_default": (None, [C.POINTER(SolverOptions)]),
     "lvf_problem_create": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "lvf_problem_destroy": (C.c_int, [_VP]),

@@ -176,6 +176,23 @@ def lidar_plane_batch(ctx, mode, p, pa, pb, pc, Twc1, weight):
     return Batch(ctx, h, p.shape[0], 1, (1, 1, 1))
 
 
+def pose_prior_batch(ctx, kf_a, kf_b, target, weight, v):
+    """kf_a[i] < 0: PoseError on pose kf_b[i] with origin target[i][:7]; else PoseGraphError(kf_a, kf_b) with
+    target[i][:6] = rpyxyz_ (see relative_rpyxyz)."""
+    kf_a, kf_b, target, weight, v = _i(kf_a), _i(kf_b), _d(target), _d(weight), _d(v)
+    n = kf_a.shape[0]
+    assert target.shape == (n, 7)
+    h = C.c_void_p()
+    _chk(ctx.L.lvf_pose_prior_create(ctx.h, n, _ip(kf_a), _ip(kf_b), _dp(target), _dp(weight), _dp(v), C.byref(h)))
+    return Batch(ctx, h, n, 6, (7, 7))
+
+
+def relative_rpyxyz(last_pose, pose):
+    a, b, out = _d(last_pose), _d(pose), np.empty(6)
+    _chk(_lib.lib().lvf_relative_rpyxyz(_dp(a), _dp(b), _dp(out)))
+    return out
+
+
 def preintegrate(ctx, samples_list, acc0, gyr0, ba, bg, noise4):
     n = len(samples_list)
     offset = np.zeros(n + 1, np.int32)
@@ -244,6 +261,15 @@ def icp_solve(map_, scan, map_pose, frame_pose, rpyxyz, mode, thr, weight, huber
     return summ
 
 
+def lidar_solve(batch, rpyxyz, huber_a, prior_weight=0.0, max_num_iterations=4):
+    """3-DoF LM over a caller-built lidar batch; rpyxyz (float64[6]) is updated IN PLACE."""
+    assert rpyxyz.dtype == np.float64 and rpyxyz.flags.c_contiguous and rpyxyz.size == 6
+    opt = IcpOptions(0, 0.0, 0.0, float(huber_a), float(prior_weight), int(max_num_iterations))
+    summ = IcpSummary()
+    _chk(batch.ctx.L.lvf_lidar_solve(batch.h, _dp(rpyxyz), C.byref(opt), C.byref(summ)))
+    return summ
+
+
 def default_solver_options():
     o = SolverOptions()
     _lib.lib().lvf_solver_options_default(C.byref(o))
@@ -256,6 +282,9 @@ class Problem:
         self.h = C.c_void_p()
         hs = [b.h if b is not None else None for b in (two_camera, two_frame, pose_only, imu)]
         _chk(ctx.L.lvf_problem_create(ctx.h, state.h, hs[0], hs[1], hs[2], hs[3], C.byref(self.h)))
+
+    def set_pose_priors(self, batch):
+        _chk(self.ctx.L.lvf_problem_set_pose_priors(self.h, batch.h if batch is not None else None))
 
     def set_pose_constant(self, kf, const=True):
         _chk(self.ctx.L.lvf_problem_set_pose_constant(self.h, int(kf), 1 if const else 0))

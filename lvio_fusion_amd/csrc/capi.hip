@@ -318,6 +318,9 @@ int lvf_batch_evaluate(lvf_batch* b, const lvf_state* st, const double* rpyxyz, 
       case LVF_K_IMU:
         LVF_REQUIRE(st->n_kf >= b->min_n_kf, "imu batch indices exceed the state (n_kf=%d)", st->n_kf);
         rc = launch_imu(b, st, wj); break;
+      case LVF_K_POSE_PRIOR:
+        LVF_REQUIRE(st->n_kf >= b->min_n_kf, "pose-prior batch indices exceed the state (n_kf=%d)", st->n_kf);
+        rc = launch_pose_prior(b, st, wj); break;
       default: set_error("unknown batch kind %d", b->kind); return LVF_ERR_INVALID;
     }
   }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restric
   double v[10];
 #pragma unroll
   for (int q = 0; q < 10; ++q) v[q] = 0.0;
-  if (i < Q && valid[i]) {
+  if (i < Q && (!valid || valid[i])) {
     const double pp[3] = {P[i], P[Q + i], P[2 * Q + i]}, qa[3] = {PA[i], PA[Q + i], PA[2 * Q + i]}, nn[3] = {N[i], N[Q + i], N[2 * Q + i]};
     double r, J[3];
     lidar_point(U, args.mode, pp, qa, nn, r, J);
@@ -182,6 +182,40 @@ __global__ void k_icp_decide(const IcpArgs args, IcpDev* __restrict__ dev) {
 
 }  // namespace lvf
 
+namespace lvf {
+static IcpArgs make_args(const double* Twc1, const lvf_icp_options* opt) {
+  IcpArgs a;
+  std::memcpy(a.Twc1, Twc1, sizeof(a.Twc1));
+  a.weight = opt->weight; a.huber = opt->huber_a; a.prior_w = opt->prior_weight;
+  a.function_tolerance = 1e-6; a.gradient_tolerance = 1e-10; a.parameter_tolerance = 1e-8; a.min_relative_decrease = 1e-3;
+  a.mode = opt->mode; a.max_iters = opt->max_num_iterations;
+  return a;
+}
+static void init_dev(IcpDev& h, int mode, const double* rpyxyz) {
+  std::memset(&h, 0, sizeof(h));
+  const int i0 = mode == 0 ? 1 : 0, i1 = mode == 0 ? 2 : 3, i2 = mode == 0 ? 5 : 4;
+  h.x[0] = h.x0[0] = rpyxyz[i0]; h.x[1] = h.x0[1] = rpyxyz[i1]; h.x[2] = h.x0[2] = rpyxyz[i2];
+  for (int k = 0; k < 6; ++k) h.rpyxyz[k] = rpyxyz[k];
+  h.radius = 1e4; h.decrease = 2.0; h.first = 1;
+}
+// the device-resident LM loop over correspondences P | PA | N (SoA [3][Q]); valid may be null (all rows count)
+static int run_lm(hipStream_t q, int Q, const double* P, const double* PA, const double* N, const uint8_t* valid, const IcpArgs& a,
+                  IcpDev* dev, IcpDev* host_out) {
+  const int grid = (std::max(Q, 1) + kTI - 1) / kTI;
+  for (int it = 0; it < std::max(1, a.max_iters); ++it) {
+    if (Q > 0) hipLaunchKernelGGL(k_icp_eval<true>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, valid, a, dev);
+    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1), 0, q, a, dev);
+    if (a.max_iters == 0) break;
+    if (Q > 0) hipLaunchKernelGGL(k_icp_eval<false>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, valid, a, dev);
+    hipLaunchKernelGGL(k_icp_decide, dim3(1), dim3(1), 0, q, a, dev);
+  }
+  LVF_HIP(hipGetLastError());
+  LVF_HIP(hipMemcpyAsync(host_out, dev, sizeof(IcpDev), hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipStreamSynchronize(q));
+  return LVF_OK;
+}
+}  // namespace lvf
+
 using namespace lvf;
 
 extern "C" int lvf_icp_solve(lvf_map* m, lvf_scan* sc, const double* map_pose, const double* frame_pose, double* rpyxyz,
@@ -201,34 +235,83 @@ extern "C" int lvf_icp_solve(lvf_map* m, lvf_scan* sc, const double* map_pose, c
   if (!sc->icp_dev.p) LVF_TRY(sc->icp_dev.alloc(sizeof(IcpDev)));
   double* P = sc->corr.p; double* PA = P + (size_t)3 * Q; double* N = PA + (size_t)3 * Q;
   IcpDev h;
-  std::memset(&h, 0, sizeof(h));
+  init_dev(h, opt->mode, rpyxyz);
   const int i0 = opt->mode == 0 ? 1 : 0, i1 = opt->mode == 0 ? 2 : 3, i2 = opt->mode == 0 ? 5 : 4;
-  h.x[0] = h.x0[0] = rpyxyz[i0]; h.x[1] = h.x0[1] = rpyxyz[i1]; h.x[2] = h.x0[2] = rpyxyz[i2];
-  for (int k = 0; k < 6; ++k) h.rpyxyz[k] = rpyxyz[k];
-  h.radius = 1e4; h.decrease = 2.0; h.first = 1;
   IcpDev* dev = reinterpret_cast<IcpDev*>(sc->icp_dev.p);
   LVF_HIP(hipMemcpyAsync(dev, &h, sizeof(h), hipMemcpyHostToDevice, q));
-  IcpArgs a;
-  std::memcpy(a.Twc1, map_pose, sizeof(a.Twc1));
-  a.weight = opt->weight; a.huber = opt->huber_a; a.prior_w = opt->prior_weight;
-  a.function_tolerance = 1e-6; a.gradient_tolerance = 1e-10; a.parameter_tolerance = 1e-8; a.min_relative_decrease = 1e-3;
-  a.mode = opt->mode; a.max_iters = opt->max_num_iterations;
+  IcpArgs a = make_args(map_pose, opt);
   const int grid = (std::max(Q, 1) + kTI - 1) / kTI;
   if (Q > 0) hipLaunchKernelGGL(k_icp_build, dim3(grid), dim3(kTI), 0, q, Q, sc->pts.p, sc->idx.p, sc->valid.p, m->raw.p, P, PA, N, dev);
   // 3. LM iterations, all on device
-  for (int it = 0; it < std::max(1, opt->max_num_iterations); ++it) {
-    if (Q > 0) hipLaunchKernelGGL(k_icp_eval<true>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, sc->valid.p, a, dev);
-    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1), 0, q, a, dev);
-    if (opt->max_num_iterations == 0) break;
-    if (Q > 0) hipLaunchKernelGGL(k_icp_eval<false>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, sc->valid.p, a, dev);
-    hipLaunchKernelGGL(k_icp_decide, dim3(1), dim3(1), 0, q, a, dev);
-  }
-  LVF_HIP(hipGetLastError());
-  LVF_HIP(hipMemcpyAsync(&h, dev, sizeof(h), hipMemcpyDeviceToHost, q));
-  LVF_HIP(hipStreamSynchronize(q));
+  LVF_TRY(run_lm(q, Q, P, PA, N, sc->valid.p, a, dev, &h));
   rpyxyz[i0] = h.x[0]; rpyxyz[i1] = h.x[1]; rpyxyz[i2] = h.x[2];
   summary->initial_cost = h.initial_cost; summary->final_cost = h.cost_cur;
   summary->num_residual_blocks = h.nvalid + (opt->prior_weight > 0.0 ? 1 : 0);
   summary->num_iterations = h.iters; summary->num_successful_steps = h.successes;
+  return LVF_OK;
+}
+
+// adapt::Solve for a problem made of LidarPlaneErrorRPZ/YXY blocks (+ optionally one PoseErrorRPZ/YXY prior) that were
+// built by the CALLER (association.cpp:303-333 / :361-384 left on the host): the same device-resident 3-DoF LM as
+// lvf_icp_solve, run over the batch's own correspondences.  mode, weight and Twc1 come from the batch.
+extern "C" int lvf_lidar_solve(lvf_batch* b, double* rpyxyz, const lvf_icp_options* opt, lvf_icp_summary* summary) {
+  LVF_REQUIRE(b && rpyxyz && opt && summary, "lvf_lidar_solve: null argument");
+  LVF_REQUIRE(b->kind == LVF_K_LIDAR, "lvf_lidar_solve: not a lidar-plane batch");
+  LVF_REQUIRE(opt->max_num_iterations >= 0, "lvf_lidar_solve: bad options");
+  LVF_HIP(hipSetDevice(b->ctx->device));
+  hipStream_t q = b->ctx->stream;
+  std::memset(summary, 0, sizeof(*summary));
+  if (!b->icp_dev.p) LVF_TRY(b->icp_dev.alloc(sizeof(IcpDev)));
+  lvf_icp_options o = *opt;
+  o.mode = b->lidar_mode; o.weight = b->lidar_weight;
+  IcpDev h;
+  init_dev(h, o.mode, rpyxyz);
+  h.nvalid = b->n;
+  IcpDev* dev = reinterpret_cast<IcpDev*>(b->icp_dev.p);
+  LVF_HIP(hipMemcpyAsync(dev, &h, sizeof(h), hipMemcpyHostToDevice, q));
+  const IcpArgs a = make_args(b->Twc1, &o);
+  LVF_TRY(run_lm(q, b->n, b->lp.p, b->lpa.p, b->lnrm.p, nullptr, a, dev, &h));
+  const int i0 = o.mode == 0 ? 1 : 0, i1 = o.mode == 0 ? 2 : 3, i2 = o.mode == 0 ? 5 : 4;
+  rpyxyz[i0] = h.x[0]; rpyxyz[i1] = h.x[1]; rpyxyz[i2] = h.x[2];
+  summary->initial_cost = h.initial_cost; summary->final_cost = h.cost_cur;
+  summary->num_residual_blocks = b->n + (o.prior_weight > 0.0 ? 1 : 0);
+  summary->num_iterations = h.iters; summary->num_successful_steps = h.successes;
+  return LVF_OK;
+}
+
+// PoseErrorRPZ / PoseErrorYXY <3,1,1,1> (pose_error.hpp:135-190) as a stand-alone CostFunction::Evaluate: three linear
+// residuals.  Inside lvf_icp_solve / lvf_lidar_solve the prior is folded into k_icp_step; this entry point exists so the
+// per-block ceres::CostFunction surface of the adapter has a device evaluation for every functor on the path.
+namespace lvf {
+__global__ void k_prior3(int mode, const double w, const double t0, const double t1, const double t2, const double x0, const double x1,
+                         const double x2, double* __restrict__ out /* r[3] | J0[3] | J1[3] | J2[3] */) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // parameter order (p, r, z) / (Y, x, y); residual order (r, p, z) / (Y, x, y)
+  for (int k = 0; k < 12; ++k) out[k] = 0.0;
+  if (mode == 0) {
+    out[0] = w * (x1 - t1); out[1] = w * (x0 - t0); out[2] = w * (x2 - t2);
+    out[3 + 1] = w;   // d r1 / d p
+    out[6 + 0] = w;   // d r0 / d r
+    out[9 + 2] = w;   // d r2 / d z
+  } else {
+    out[0] = w * (x0 - t0); out[1] = w * (x1 - t1); out[2] = w * (x2 - t2);
+    out[3 + 0] = w; out[6 + 1] = w; out[9 + 2] = w;
+  }
+}
+}  // namespace lvf
+extern "C" int lvf_prior3_evaluate(lvf_ctx* ctx, int mode, const double* target3, double weight, const double* x3, double* residuals3,
+                                   double* jacobians9) {
+  LVF_REQUIRE(ctx && target3 && x3 && residuals3, "lvf_prior3_evaluate: null argument");
+  LVF_REQUIRE(mode == 0 || mode == 1, "lvf_prior3_evaluate: mode must be 0 (RPZ) or 1 (YXY)");
+  LVF_HIP(hipSetDevice(ctx->device));
+  DevBuf<double> out;
+  LVF_TRY(out.alloc(12));
+  hipLaunchKernelGGL(k_prior3, dim3(1), dim3(1), 0, ctx->stream, mode, weight, target3[0], target3[1], target3[2], x3[0], x3[1], x3[2], out.p);
+  LVF_HIP(hipGetLastError());
+  double h[12];
+  LVF_HIP(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  LVF_HIP(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 3; ++k) residuals3[k] = h[k];
+  if (jacobians9) for (int k = 0; k < 9; ++k) jacobians9[k] = h[3 + k];
   return LVF_OK;
 }

@@ -70,7 +70,7 @@ struct lvf_state {
   lvf::DevBuf<double> poses, vel, ba, bg, inv_depth, w_visual;
 };
 
-enum lvf_batch_kind { LVF_K_POSE_ONLY = 0, LVF_K_TWO_FRAME = 1, LVF_K_TWO_CAMERA = 2, LVF_K_IMU = 3, LVF_K_LIDAR = 4 };
+enum lvf_batch_kind { LVF_K_POSE_ONLY = 0, LVF_K_TWO_FRAME = 1, LVF_K_TWO_CAMERA = 2, LVF_K_IMU = 3, LVF_K_LIDAR = 4, LVF_K_POSE_PRIOR = 5 };
 
 struct lvf_batch {
   lvf_ctx* ctx = nullptr;
@@ -93,7 +93,8 @@ struct lvf_batch {
   int lidar_mode = 0;
   double lidar_weight = 1.0;
   double Twc1[7] = {0, 0, 0, 1, 0, 0, 0};
-  lvf::DevBuf<double> lp, lpa, lnrm;     // [n][3]
+  lvf::DevBuf<double> lp, lpa, lnrm;     // SoA [3][n]
+  lvf::DevBuf<char> icp_dev;             // device LM state of lvf_lidar_solve
   // imu
   lvf::DevBuf<double> pre;               // [n][467] flattened lvf_preint
   lvf::DevBuf<double> sqrt_info;         // [n][225]
@@ -146,5 +147,6 @@ int launch_lidar_normals(lvf_batch* b, const double* d_pb, const double* d_pc);
 int launch_lidar_plane(lvf_batch* b, const double* rpyxyz_host, bool want_j);
 int launch_imu_sqrt_info(lvf_batch* b);
 int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j);
+int launch_pose_prior(lvf_batch* b, const lvf_state* st, bool want_j);
 void make_camd(const lvf_camera& c, CamD& d);
 }  // namespace lvf

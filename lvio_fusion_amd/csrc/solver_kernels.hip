@@ -20,7 +20,7 @@ namespace lvf { struct TfWork; }
 struct lvf_problem {
   lvf_ctx* ctx = nullptr;
   lvf_state* st = nullptr;
-  lvf_batch *tc = nullptr, *tf = nullptr, *po = nullptr, *imu = nullptr;
+  lvf_batch *tc = nullptr, *tf = nullptr, *po = nullptr, *imu = nullptr, *prior = nullptr;
   int n_kf = 0, n_lm = 0, d = 0, dp = 0, ldE = 0, dpad = 0, nb = 0;
   lvf::DevBuf<double> B, gc, C, gr, E, Cd, S, dxc, dxl, scal;
   lvf::DevBuf<double> poses2, vel2, ba2, bg2, invd2;   // candidate state x + dx
@@ -355,6 +355,71 @@ __global__ __launch_bounds__(kT) void k_cost_imu(int n15, const double* __restri
   const int i = blockIdx.x * kT + threadIdx.x;
   double c = 0.0;
   if (i < n15) { const double r = res[i]; c = 0.5 * r * r; }
+  block_add(c, cost);
+}
+
+// ------------------------------------------------------------------------------------------------ pose priors
+// consumes the materialised PoseGraphError / PoseError outputs of launch_pose_prior (res[n][6], ja/jb [n][6][7]); no loss
+// function (backend.cpp:171,176).  <= n_kf blocks: one thread per block, global atomics.
+__global__ __launch_bounds__(64) void k_lin_prior(int n, const double* __restrict__ res, const double* __restrict__ ja,
+                                                  const double* __restrict__ jb, const int* __restrict__ kf_a, const int* __restrict__ kf_b,
+                                                  const double* __restrict__ poses, const uint8_t* __restrict__ pose_const,
+                                                  double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const int a = kf_a[i], b = kf_b[i];
+  double r[6], La[36], Lb[36];   // local Jacobians, row-major 6 x 6
+  double c = 0.0;
+  for (int k = 0; k < 6; ++k) { r[k] = res[6 * i + k]; c += 0.5 * r[k] * r[k]; }
+  for (int k = 0; k < 6; ++k) {
+    const double* row = jb + (size_t)42 * i + 7 * k;
+    const double sc = pose_const[b] ? 0.0 : 1.0;
+    double l3[3];
+    quat_row_to_local(row, poses + 7 * b, l3);
+    Lb[6 * k] = sc * l3[0]; Lb[6 * k + 1] = sc * l3[1]; Lb[6 * k + 2] = sc * l3[2];
+    Lb[6 * k + 3] = sc * row[4]; Lb[6 * k + 4] = sc * row[5]; Lb[6 * k + 5] = sc * row[6];
+    if (a >= 0) {
+      const double* rowa = ja + (size_t)42 * i + 7 * k;
+      const double sa = pose_const[a] ? 0.0 : 1.0;
+      quat_row_to_local(rowa, poses + 7 * a, l3);
+      La[6 * k] = sa * l3[0]; La[6 * k + 1] = sa * l3[1]; La[6 * k + 2] = sa * l3[2];
+      La[6 * k + 3] = sa * rowa[4]; La[6 * k + 4] = sa * rowa[5]; La[6 * k + 5] = sa * rowa[6];
+    }
+  }
+  atomicAdd(cost, c);
+  for (int x = 0; x < 6; ++x) {
+    double g = 0.0;
+    for (int k = 0; k < 6; ++k) g += Lb[6 * k + x] * r[k];
+    atomicAdd(&gc[6 * b + x], g);
+    for (int y = 0; y <= x; ++y) {
+      double h = 0.0;
+      for (int k = 0; k < 6; ++k) h += Lb[6 * k + x] * Lb[6 * k + y];
+      atomicAdd(&B[(size_t)(6 * b + x) * ld + 6 * b + y], h);
+    }
+  }
+  if (a >= 0) {
+    for (int x = 0; x < 6; ++x) {
+      double g = 0.0;
+      for (int k = 0; k < 6; ++k) g += La[6 * k + x] * r[k];
+      atomicAdd(&gc[6 * a + x], g);
+      for (int y = 0; y <= x; ++y) {
+        double h = 0.0;
+        for (int k = 0; k < 6; ++k) h += La[6 * k + x] * La[6 * k + y];
+        atomicAdd(&B[(size_t)(6 * a + x) * ld + 6 * a + y], h);
+      }
+      for (int y = 0; y < 6; ++y) {   // cross block, stored in the lower triangle of B
+        double h = 0.0;
+        for (int k = 0; k < 6; ++k) h += La[6 * k + x] * Lb[6 * k + y];
+        if (a > b) atomicAdd(&B[(size_t)(6 * a + x) * ld + 6 * b + y], h);
+        else atomicAdd(&B[(size_t)(6 * b + y) * ld + 6 * a + x], h);
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(kT) void k_cost_sq(int n, const double* __restrict__ res, double* __restrict__ cost) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  double c = 0.0;
+  if (i < n) { const double r = res[i]; c = 0.5 * r * r; }
   block_add(c, cost);
 }
 
@@ -704,6 +769,10 @@ static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_st
     LVF_TRY(launch_imu(p->imu, imu_state_view, false));
     hipLaunchKernelGGL(k_cost_imu, dim3(grid(15 * p->imu->n)), dim3(kT), 0, q, 15 * p->imu->n, p->imu->res.p, cost_slot);
   }
+  if (p->prior && p->prior->n) {
+    LVF_TRY(launch_pose_prior(p->prior, imu_state_view, false));
+    hipLaunchKernelGGL(k_cost_sq, dim3(grid(6 * p->prior->n)), dim3(kT), 0, q, 6 * p->prior->n, p->prior->res.p, cost_slot);
+  }
   LVF_HIP(hipGetLastError());
   return LVF_OK;
 }
@@ -742,6 +811,11 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
     for (int k = 0; k < 8; ++k) J.j[k] = p->imu->jac[k].p;
     hipLaunchKernelGGL(k_lin_imu, dim3(p->imu->n), dim3(64), 0, q, p->imu->n, p->n_kf, p->imu->res.p, J, p->imu->idx_a.p, p->imu->idx_b.p,
                        p->st->poses.p, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
+  }
+  if (p->prior && p->prior->n) {
+    LVF_TRY(launch_pose_prior(p->prior, p->st, true));
+    hipLaunchKernelGGL(k_lin_prior, dim3((p->prior->n + 63) / 64), dim3(64), 0, q, p->prior->n, p->prior->res.p, p->prior->jac[0].p,
+                       p->prior->jac[1].p, p->prior->idx_a.p, p->prior->idx_b.p, p->st->poses.p, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
   }
   LVF_HIP(hipGetLastError());
   p->linearized = true;
@@ -905,6 +979,18 @@ int lvf_problem_create(lvf_ctx* ctx, lvf_state* st, lvf_batch* two_camera, lvf_b
 }
 int lvf_problem_destroy(lvf_problem* p) { delete p; return LVF_OK; }
 
+int lvf_problem_set_pose_priors(lvf_problem* p, lvf_batch* pose_priors) {
+  LVF_REQUIRE(p, "lvf_problem_set_pose_priors: null problem");
+  if (pose_priors) {
+    LVF_REQUIRE(pose_priors->kind == LVF_K_POSE_PRIOR, "pose_priors batch has the wrong kind");
+    LVF_REQUIRE(pose_priors->ctx == p->ctx, "batch belongs to another context");
+    LVF_REQUIRE(pose_priors->min_n_kf <= p->n_kf, "pose-prior batch references keyframe %d but the window has %d", pose_priors->min_n_kf - 1, p->n_kf);
+  }
+  p->prior = pose_priors;
+  p->linearized = false;
+  return LVF_OK;
+}
+
 int lvf_problem_set_pose_constant(lvf_problem* p, int kf, int is_constant) {
   LVF_REQUIRE(p, "null problem");
   LVF_REQUIRE(kf >= 0 && kf < p->n_kf, "keyframe %d out of range", kf);
@@ -943,7 +1029,7 @@ int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_su
   LVF_HIP(hipSetDevice(p->ctx->device));
   double radius = o->initial_trust_region_radius, decrease = 2.0;
   std::memset(summary, 0, sizeof(*summary));
-  summary->num_residual_blocks = (p->tc ? p->tc->n : 0) + (p->tf ? p->tf->n : 0) + (p->po ? p->po->n : 0) + (p->imu ? p->imu->n : 0);
+  summary->num_residual_blocks = (p->tc ? p->tc->n : 0) + (p->tf ? p->tf->n : 0) + (p->po ? p->po->n : 0) + (p->imu ? p->imu->n : 0) + (p->prior ? p->prior->n : 0);
   summary->termination = 1;
   const auto wall0 = std::chrono::steady_clock::now();
   double cost = 0.0;

@@ -1,0 +1,237 @@
+// adapter_selftest.cpp — drives the C++ host interface (include/lvf_ceres_adapter.hpp + host/adapt_problem.h) exactly the
+// way the reference's callers do, on inputs written by tests/test_gpu_adapter.py, and dumps what came out.
+//
+//   adapter_selftest window <dir>   Backend::BuildProblem's loop shape (src/lvio_fusion/src/backend.cpp:96-183) over a
+//                                   synthetic window, gpu::Evaluate, per-block CostFunction::Evaluate spot checks, then
+//                                   adapt::Solve as Backend::Optimize issues it (:206-211)
+//   adapter_selftest lidar <dir>    ScanToMapWithGround/Segmented's problem (association.cpp:270-384) + Mapping's solve
+//                                   (mapping.cpp:153-163)
+// Raw little-endian arrays: <dir>/<name>.f64 / .i32 in, <dir>/out_<name>.f64 out; a one-line JSON summary on stdout.
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "adapt_problem.h"
+
+using namespace lvio_fusion;
+
+template <typename T>
+static std::vector<T> rd(const std::string& dir, const std::string& name) {
+  std::ifstream f(dir + "/" + name, std::ios::binary | std::ios::ate);
+  if (!f) { std::fprintf(stderr, "missing %s/%s\n", dir.c_str(), name.c_str()); std::exit(2); }
+  const std::streamsize n = f.tellg();
+  f.seekg(0);
+  std::vector<T> v((size_t)n / sizeof(T));
+  f.read(reinterpret_cast<char*>(v.data()), n);
+  return v;
+}
+static void wr(const std::string& dir, const std::string& name, const std::vector<double>& v) {
+  std::ofstream f(dir + "/" + name, std::ios::binary);
+  f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(double)));
+}
+static lvf_camera cam_of(const std::vector<double>& c) {
+  lvf_camera k;
+  k.fx = c[0]; k.fy = c[1]; k.cx = c[2]; k.cy = c[3];
+  for (int i = 0; i < 7; ++i) k.extrinsic[i] = c[4 + i];
+  return k;
+}
+
+static int run_window(const std::string& dir) {
+  auto meta = rd<int32_t>(dir, "meta.i32");   // n_kf, n_lm, max_iterations, weak_threshold, const_kf (-1 none)
+  const int n_kf = meta[0], n_lm = meta[1], max_it = meta[2], weak_thr = meta[3], const_kf = meta[4];
+  auto poses = rd<double>(dir, "poses.f64"), vel = rd<double>(dir, "vel.f64"), ba = rd<double>(dir, "ba.f64"), bg = rd<double>(dir, "bg.f64");
+  auto invd = rd<double>(dir, "inv_depth.f64"), w_kf = rd<double>(dir, "w_kf.f64");
+  const lvf_camera cam0 = cam_of(rd<double>(dir, "cam0.f64")), cam1 = cam_of(rd<double>(dir, "cam1.f64"));
+  auto tc_l = rd<double>(dir, "tc_left_ob.f64"), tc_r = rd<double>(dir, "tc_right_ob.f64"); auto tc_lm = rd<int32_t>(dir, "tc_lm.i32"), tc_kf = rd<int32_t>(dir, "tc_kf.i32");
+  auto tf_f = rd<double>(dir, "tf_first_ob.f64"), tf_o = rd<double>(dir, "tf_ob.f64");
+  auto tf_lm = rd<int32_t>(dir, "tf_lm.i32"), tf_k1 = rd<int32_t>(dir, "tf_kf1.i32"), tf_k2 = rd<int32_t>(dir, "tf_kf2.i32");
+  auto po_o = rd<double>(dir, "po_ob.f64"), po_pw = rd<double>(dir, "po_pw.f64"); auto po_kf = rd<int32_t>(dir, "po_kf.i32"), po_pi = rd<int32_t>(dir, "po_pw_idx.i32");
+  auto pre = rd<double>(dir, "preint.f64"); auto imu_i = rd<int32_t>(dir, "imu_i.i32"), imu_j = rd<int32_t>(dir, "imu_j.i32");
+  (void)n_lm;
+
+  adapt::Problem problem;
+  ceres::LossFunction* loss_function = new ceres::HuberLoss(1.0);
+  ceres::LocalParameterization* local_parameterization =
+      new ceres::ProductParameterization(new ceres::EigenQuaternionParameterization(), new ceres::IdentityParameterization(3));
+  std::vector<ceres::CostFunction*> probe_cf;          // first block of each functor type, for Evaluate() spot checks
+  std::vector<std::vector<double*>> probe_params;
+  auto remember = [&](size_t want, ceres::CostFunction* cf, std::vector<double*> prm) {
+    if (probe_cf.size() == want) { probe_cf.push_back(cf); probe_params.push_back(prm); }
+  };
+  size_t itc = 0, itf = 0, ipo = 0, iimu = 0;
+  int n_prior = 0;
+  double* para_last_kf = nullptr;
+  for (int k = 0; k < n_kf; ++k) {
+    double* para_kf = &poses[7 * k];
+    problem.AddParameterBlock(para_kf, 7, local_parameterization);
+    // the frame's features in the order the python generator batched them (sorted by current keyframe within each type)
+    while (itc < tc_kf.size() && tc_kf[itc] == k) {
+      double* para_inv_depth = &invd[tc_lm[itc]];
+      problem.AddParameterBlock(para_inv_depth, 1);
+      auto* cf = gpu::TwoCameraReprojectionError::Create(&tc_l[2 * itc], &tc_r[2 * itc], cam0, cam1, 5 * w_kf[k]);
+      problem.AddResidualBlock(ProblemType::Other, cf, loss_function, para_inv_depth);
+      remember(0, cf, {para_inv_depth});
+      ++itc;
+    }
+    while (ipo < po_kf.size() && po_kf[ipo] == k) {
+      auto* cf = gpu::PoseOnlyReprojectionError::Create(&po_o[2 * ipo], &po_pw[3 * po_pi[ipo]], cam0, w_kf[k]);
+      problem.AddResidualBlock(ProblemType::VisualError, cf, loss_function, para_kf);
+      if (probe_cf.size() == 1) remember(1, cf, {para_kf});
+      ++ipo;
+    }
+    while (itf < tf_k2.size() && tf_k2[itf] == k) {
+      double* para_first_kf = &poses[7 * tf_k1[itf]];
+      double* para_inv_depth = &invd[tf_lm[itf]];
+      problem.AddParameterBlock(para_inv_depth, 1);
+      auto* cf = gpu::TwoFrameReprojectionError::Create(&tf_f[2 * itf], &tf_o[2 * itf], cam0, cam1, w_kf[k]);
+      problem.AddResidualBlock(ProblemType::VisualError, cf, loss_function, para_inv_depth, para_first_kf, para_kf);
+      if (probe_cf.size() == 2) remember(2, cf, {para_inv_depth, para_first_kf, para_kf});
+      ++itf;
+    }
+    if (!imu_j.empty()) {
+      problem.AddParameterBlock(&vel[3 * k], 3); problem.AddParameterBlock(&ba[3 * k], 3); problem.AddParameterBlock(&bg[3 * k], 3);
+      while (iimu < imu_j.size() && imu_j[iimu] == k) {
+        const int i = imu_i[iimu];
+        lvf_preint P;
+        std::memcpy(&P, &pre[467 * iimu], sizeof(P));
+        auto* cf = gpu::ImuError::Create(P);
+        problem.AddResidualBlock(ProblemType::ImuError, cf, nullptr, &poses[7 * i], &vel[3 * i], &ba[3 * i], &bg[3 * i], para_kf, &vel[3 * k], &ba[3 * k], &bg[3 * k]);
+        if (probe_cf.size() == 3) remember(3, cf, {&poses[7 * i], &vel[3 * i], &ba[3 * i], &bg[3 * i], para_kf, &vel[3 * k], &ba[3 * k], &bg[3 * k]});
+        ++iimu;
+      }
+    }
+    // weak-constraint check, backend.cpp:164-178 (threshold is a test knob; the reference uses 20)
+    auto num_types = problem.GetTypes(para_kf);
+    if (!num_types[ProblemType::ImuError] && num_types[ProblemType::VisualError] < weak_thr) {
+      if (para_last_kf) {
+        auto* cf = gpu::PoseGraphError::Create(para_last_kf, para_kf, 100, 0);
+        problem.AddResidualBlock(ProblemType::Other, cf, nullptr, para_last_kf, para_kf);
+      } else {
+        auto* cf = gpu::PoseError::Create(para_kf, 100, 0);
+        problem.AddResidualBlock(ProblemType::Other, cf, nullptr, para_kf);
+      }
+      ++n_prior;
+    }
+    para_last_kf = para_kf;
+  }
+  if (const_kf >= 0) problem.SetParameterBlockConstant(&poses[7 * const_kf]);
+
+  // batched Problem::Evaluate at the initial point
+  double cost0 = -1.0;
+  std::vector<double> residuals;
+  std::string err;
+  if (!gpu::Evaluate(&problem, &cost0, &residuals, &err)) { std::fprintf(stderr, "Evaluate failed: %s\n", err.c_str()); return 1; }
+  wr(dir, "out_residuals.f64", residuals);
+
+  // per-block CostFunction::Evaluate (Ceres calling convention) on the first block of each type
+  std::vector<double> probe_out;
+  for (size_t b = 0; b < probe_cf.size(); ++b) {
+    const ceres::CostFunction* cf = probe_cf[b];
+    const int R = cf->num_residuals();
+    const auto& sizes = cf->parameter_block_sizes();
+    std::vector<double> r(R);
+    std::vector<std::vector<double>> J(sizes.size());
+    std::vector<double*> Jp(sizes.size());
+    for (size_t k = 0; k < sizes.size(); ++k) { J[k].assign((size_t)R * sizes[k], 0.0); Jp[k] = J[k].data(); }
+    if (sizes.size() > 1) Jp[1] = nullptr;   // a NULL jacobians[i] must be honoured (constant block)
+    if (!cf->Evaluate(probe_params[b].data(), r.data(), Jp.data())) { std::fprintf(stderr, "CostFunction::Evaluate failed on probe %zu: %s\n", b, lvf_last_error()); return 1; }
+    std::vector<double> r2(R);
+    if (!cf->Evaluate(probe_params[b].data(), r2.data(), nullptr) || r2 != r) { std::fprintf(stderr, "residual-only Evaluate differs on probe %zu\n", b); return 1; }
+    probe_out.insert(probe_out.end(), r.begin(), r.end());
+    for (size_t k = 0; k < sizes.size(); ++k) probe_out.insert(probe_out.end(), J[k].begin(), J[k].end());
+  }
+  wr(dir, "out_probe.f64", probe_out);
+
+  ceres::Solver::Options options;
+  options.linear_solver_type = ceres::SPARSE_SCHUR;
+  options.max_num_iterations = max_it;
+  options.num_threads = 4;
+  ceres::Solver::Summary summary;
+  adapt::Solve(options, &problem, &summary);
+  wr(dir, "out_poses.f64", poses); wr(dir, "out_vel.f64", vel); wr(dir, "out_ba.f64", ba); wr(dir, "out_bg.f64", bg); wr(dir, "out_inv_depth.f64", invd);
+  std::printf("{\"ok\": %d, \"message\": \"%s\", \"cost0\": %.17g, \"initial_cost\": %.17g, \"final_cost\": %.17g, \"successful\": %d, \"unsuccessful\": %d, "
+              "\"num_residual_blocks\": %d, \"num_frames\": %d, \"n_prior\": %d, \"n_probe\": %zu, \"termination\": %d}\n",
+              summary.termination_type != ceres::FAILURE, summary.message.c_str(), cost0, summary.initial_cost, summary.final_cost, summary.num_successful_steps,
+              summary.num_unsuccessful_steps, summary.num_residual_blocks_reduced, problem.num_frames, n_prior, probe_cf.size(), (int)summary.termination_type);
+  return summary.termination_type == ceres::FAILURE ? 1 : 0;
+}
+
+static int run_lidar(const std::string& dir) {
+  auto meta = rd<int32_t>(dir, "meta.i32");   // mode, use_prior
+  const int mode = meta[0], use_prior = meta[1];
+  auto sc = rd<double>(dir, "scalars.f64");   // weight, huber_a (<=0: TrivialLoss), prior_weight
+  auto p = rd<double>(dir, "p.f64"), pa = rd<double>(dir, "pa.f64"), pb = rd<double>(dir, "pb.f64"), pc = rd<double>(dir, "pc.f64");
+  auto Twc1 = rd<double>(dir, "map_pose.f64"), rpy = rd<double>(dir, "rpyxyz.f64");
+  const size_t n = p.size() / 3;
+  double* rpyxyz = rpy.data();   // the live array of mapping.cpp:153
+  adapt::Problem problem;
+  ceres::LossFunction* loss = sc[1] > 0.0 ? static_cast<ceres::LossFunction*>(new ceres::HuberLoss(sc[1])) : new ceres::TrivialLoss();
+  // association.cpp:273-275 / :331-333
+  double *q0, *q1, *q2;
+  if (mode == 0) { q0 = rpyxyz + 1; q1 = rpyxyz + 2; q2 = rpyxyz + 5; } else { q0 = rpyxyz + 0; q1 = rpyxyz + 3; q2 = rpyxyz + 4; }
+  problem.AddParameterBlock(q0, 1); problem.AddParameterBlock(q1, 1); problem.AddParameterBlock(q2, 1);
+  ceres::CostFunction* probe = nullptr;
+  for (size_t i = 0; i < n; ++i) {
+    ceres::CostFunction* cf = mode == 0 ? gpu::LidarPlaneErrorRPZ::Create(&p[3 * i], &pa[3 * i], &pb[3 * i], &pc[3 * i], Twc1.data(), rpyxyz, sc[0])
+                                        : gpu::LidarPlaneErrorYXY::Create(&p[3 * i], &pa[3 * i], &pb[3 * i], &pc[3 * i], Twc1.data(), rpyxyz, sc[0]);
+    problem.AddResidualBlock(ProblemType::LidarError, cf, loss, q0, q1, q2);
+    if (!probe) probe = cf;
+  }
+  ceres::CostFunction* prior = nullptr;
+  if (use_prior) {
+    prior = mode == 0 ? gpu::PoseErrorRPZ::Create(rpyxyz, sc[2]) : gpu::PoseErrorYXY::Create(rpyxyz, sc[2]);
+    problem.AddResidualBlock(ProblemType::PoseError, prior, nullptr, q0, q1, q2);
+  }
+  std::vector<double> probe_out;
+  double* prm[3] = {q0, q1, q2};
+  if (probe) {
+    double r, j0, j1, j2; double* J[3] = {&j0, &j1, &j2};
+    if (!probe->Evaluate(prm, &r, J)) { std::fprintf(stderr, "lidar Evaluate failed: %s\n", lvf_last_error()); return 1; }
+    probe_out = {r, j0, j1, j2};
+  }
+  if (prior) {
+    double x[3] = {*q0 + 0.01, *q1 - 0.02, *q2 + 0.03};
+    double* xp[3] = {&x[0], &x[1], &x[2]};
+    double r[3], j0[3], j1[3], j2[3]; double* J[3] = {j0, j1, j2};
+    if (!prior->Evaluate(xp, r, J)) { std::fprintf(stderr, "prior Evaluate failed: %s\n", lvf_last_error()); return 1; }
+    for (double v : r) probe_out.push_back(v);
+    for (double* jj : J) for (int k = 0; k < 3; ++k) probe_out.push_back(jj[k]);
+  }
+  wr(dir, "out_probe.f64", probe_out);
+  ceres::Solver::Options options;       // mapping.cpp:159-161
+  options.linear_solver_type = ceres::DENSE_QR;
+  options.max_num_iterations = 4;
+  options.num_threads = 4;
+  ceres::Solver::Summary summary;
+  adapt::Solve(options, &problem, &summary);
+  wr(dir, "out_rpyxyz.f64", rpy);
+  std::printf("{\"ok\": %d, \"message\": \"%s\", \"initial_cost\": %.17g, \"final_cost\": %.17g, \"successful\": %d, \"unsuccessful\": %d, \"num_residual_blocks\": %d}\n",
+              summary.termination_type != ceres::FAILURE, summary.message.c_str(), summary.initial_cost, summary.final_cost, summary.num_successful_steps,
+              summary.num_unsuccessful_steps, summary.num_residual_blocks_reduced);
+  return summary.termination_type == ceres::FAILURE ? 1 : 0;
+}
+
+// a cost function the adapter does not own must be refused softly (parameters untouched, FAILURE reported)
+struct Foreign : ceres::SizedCostFunction<1, 1> {
+  bool Evaluate(double const* const* p, double* r, double** J) const override { r[0] = p[0][0]; if (J && J[0]) J[0][0] = 1; return true; }
+};
+static int run_foreign() {
+  adapt::Problem problem;
+  double x = 3.0;
+  problem.AddParameterBlock(&x, 1);
+  problem.AddResidualBlock(ProblemType::Other, new Foreign(), nullptr, &x);
+  ceres::Solver::Options options; ceres::Solver::Summary summary;
+  adapt::Solve(options, &problem, &summary);
+  std::printf("{\"ok\": %d, \"x\": %.17g, \"message\": \"%s\"}\n", summary.termination_type != ceres::FAILURE, x, summary.message.c_str());
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && std::string(argv[1]) == "foreign") return run_foreign();
+  if (argc < 3) { std::fprintf(stderr, "usage: %s window|lidar <dir> | foreign\n", argv[0]); return 2; }
+  const std::string mode = argv[1];
+  if (mode == "window") return run_window(argv[2]);
+  if (mode == "lidar") return run_lidar(argv[2]);
+  return 2;
+}

@@ -34,6 +34,9 @@ struct Window {
   int n_po; const double *po_ob; const int *po_kf, *po_pw; const double* po_pwtab;
   int n_imu; const imu::Preint* pre; const int *imu_i, *imu_j;
   const unsigned char* pose_const;  // may be null
+  // weak-constraint priors (backend.cpp:164-178): prior_a[i] < 0 -> PoseError(origin = prior_target[i][0..7)) on pose prior_b[i];
+  // else PoseGraphError(pose prior_a[i], pose prior_b[i]) with rpyxyz_ = prior_target[i][0..6).  No loss function.
+  int n_prior = 0; const int *prior_a = nullptr, *prior_b = nullptr; const double *prior_target = nullptr, *prior_w = nullptr, *prior_v = nullptr;
 };
 
 struct Linearization {
@@ -77,6 +80,12 @@ inline double window_cost(const Window& w, double huber_a, const double* poses, 
     imu::imu_error_evaluate(w.pre[f], prm, r, nullptr);
     double s = 0; for (int k = 0; k < 15; ++k) s += r[k] * r[k];
     cost += 0.5 * s;     // loss NULL
+  }
+  for (int i = 0; i < w.n_prior; ++i) {
+    double r[6];
+    if (w.prior_a[i] >= 0) PoseGraphResidual<double>(w.prior_target + 7 * i, w.prior_w[i], w.prior_v[i], poses + 7 * w.prior_a[i], poses + 7 * w.prior_b[i], r);
+    else PosePriorResidual<double>(w.prior_target + 7 * i, w.prior_w[i], w.prior_v[i], poses + 7 * w.prior_b[i], r);
+    for (int k = 0; k < 6; ++k) cost += 0.5 * r[k] * r[k];
   }
   return cost;
 }
@@ -177,6 +186,33 @@ inline void window_linearize(const Window& w, double huber_a, Linearization& L) 
       }
     Piece pc[4] = {{pose_off(i), 6, Pi}, {vbb_off(w, i), 9, Vi}, {pose_off(j), 6, Pj}, {vbb_off(w, j), 9, Vj}};
     accumulate(L, 15, r, pc, 4, -1, nullptr);
+  }
+  for (int i = 0; i < w.n_prior; ++i) {
+    const int a = w.prior_a[i], b = w.prior_b[i];
+    double r[6], Ja[42], Jb[42], La[36], Lb[36];
+    if (a >= 0) {
+      Jet<14> A[7], Bq[7], rr[6];
+      for (int k = 0; k < 7; ++k) { A[k] = Jet<14>(w.poses[7 * a + k], k); Bq[k] = Jet<14>(w.poses[7 * b + k], 7 + k); }
+      PoseGraphResidual(w.prior_target + 7 * i, w.prior_w[i], w.prior_v[i], A, Bq, rr);
+      for (int k = 0; k < 6; ++k) { r[k] = rr[k].a; for (int c = 0; c < 7; ++c) { Ja[7 * k + c] = rr[k].v[c]; Jb[7 * k + c] = rr[k].v[7 + c]; } }
+    } else {
+      Jet<7> P[7], rr[6];
+      for (int k = 0; k < 7; ++k) P[k] = Jet<7>(w.poses[7 * b + k], k);
+      PosePriorResidual(w.prior_target + 7 * i, w.prior_w[i], w.prior_v[i], P, rr);
+      for (int k = 0; k < 6; ++k) { r[k] = rr[k].a; for (int c = 0; c < 7; ++c) Jb[7 * k + c] = rr[k].v[c]; }
+    }
+    for (int k = 0; k < 6; ++k) cost += 0.5 * r[k] * r[k];
+    pose_jac_to_local(w.poses + 7 * b, 6, Jb, Lb);
+    if (is_const(b)) std::memset(Lb, 0, sizeof(Lb));
+    if (a >= 0) {
+      pose_jac_to_local(w.poses + 7 * a, 6, Ja, La);
+      if (is_const(a)) std::memset(La, 0, sizeof(La));
+      Piece pc[2] = {{pose_off(a), 6, La}, {pose_off(b), 6, Lb}};
+      accumulate(L, 6, r, pc, 2, -1, nullptr);
+    } else {
+      Piece pc[1] = {{pose_off(b), 6, Lb}};
+      accumulate(L, 6, r, pc, 1, -1, nullptr);
+    }
   }
   L.cost = cost;
 }

@@ -276,13 +276,15 @@ class _WindowC(C.Structure):
                 ("n_po", C.c_int), ("po_ob", C.POINTER(C.c_double)), ("po_kf", C.POINTER(C.c_int)), ("po_pw", C.POINTER(C.c_int)),
                 ("po_pwtab", C.POINTER(C.c_double)),
                 ("n_imu", C.c_int), ("pre", C.POINTER(C.c_double)), ("imu_i", C.POINTER(C.c_int)), ("imu_j", C.POINTER(C.c_int)),
-                ("pose_const", C.POINTER(C.c_uint8))]
+                ("pose_const", C.POINTER(C.c_uint8)),
+                ("n_prior", C.c_int), ("prior_a", C.POINTER(C.c_int)), ("prior_b", C.POINTER(C.c_int)),
+                ("prior_target", C.POINTER(C.c_double)), ("prior_w", C.POINTER(C.c_double)), ("prior_v", C.POINTER(C.c_double))]
 
 
 class Window:
     """Owns numpy copies of a config-4 style window (lvio_fusion_amd.synthetic.config4_window dict) + preintegrations."""
 
-    def __init__(self, cfg, pre, pose_const=None, use=("tc", "tf", "po", "imu")):
+    def __init__(self, cfg, pre, pose_const=None, use=("tc", "tf", "po", "imu"), priors=None):
         self.n_kf, self.n_lm = cfg["n_kf"], cfg["n_lm"]
         self.poses = _f64(cfg["poses"]).copy(); self.vel = _f64(cfg["vel"]).copy(); self.ba = _f64(cfg["ba"]).copy()
         self.bg = _f64(cfg["bg"]).copy(); self.inv_depth = _f64(cfg["inv_depth"]).copy(); self.w_kf = _f64(cfg["w_kf"]).copy()
@@ -313,6 +315,10 @@ class Window:
         if pose_const is not None:
             pc = np.ascontiguousarray(pose_const, dtype=np.uint8); self._keep.append(pc)
             w.pose_const = pc.ctypes.data_as(C.POINTER(C.c_uint8))
+        if priors is not None:   # dict(kf_a, kf_b, target[n][7], weight[n], v[n])
+            w.n_prior = len(priors["kf_a"])
+            w.prior_a, w.prior_b = i(priors["kf_a"]), i(priors["kf_b"])
+            w.prior_target, w.prior_w, w.prior_v = d(priors["target"]), d(priors["weight"]), d(priors["v"])
         self.c = w
         L = lib()
         L.lvo_window_cost.restype = C.c_double

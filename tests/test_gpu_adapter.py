@@ -1,0 +1,213 @@
+"""The C++ host interface (include/lvf_ceres_adapter.hpp: reference-shaped CostFunction factories + adapt::Solve routed to
+the GPU) driven by lvio_fusion_amd/host/adapter_selftest in the exact shape of Backend::BuildProblem / ScanToMapWith* —
+checked against the oracle (per-block Evaluate, batched residual vector) and against the same window solved through the
+flat C-ABI from Python."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from lvio_fusion_amd import synthetic as syn
+from tests.helpers import assert_parity, ocam
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "lvio_fusion_amd", "host", "adapter_selftest")
+
+pytestmark = pytest.mark.gpu
+
+
+def _dump(d, name, arr, dtype):
+    np.ascontiguousarray(arr, dtype=dtype).tofile(os.path.join(d, name))
+
+
+def _cam_vec(c):
+    return np.concatenate([[c["fx"], c["fy"], c["cx"], c["cy"]], c["extrinsic"]])
+
+
+def _run(*args):
+    assert os.path.exists(EXE), f"{EXE} is missing: run __graft_entry__.build()"
+    p = subprocess.run([EXE, *args], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, f"adapter_selftest failed: {p.stdout}\n{p.stderr}"
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def _sorted_by_kf(cfg):
+    """TwoCamera blocks in per-frame order (BuildProblem walks frames, then each frame's features)."""
+    tc = cfg["tc"]
+    o = np.argsort(tc["kf_idx"], kind="stable")
+    cfg = dict(cfg)
+    cfg["tc"] = {k: v[o] for k, v in tc.items()}
+    return cfg
+
+
+@pytest.mark.parametrize("with_imu,weak_thr,const_kf", [(True, 0, -1), (False, 10 ** 6, -1), (False, 0, 0)])
+def test_window_through_adapter(tmp_path, oracle, with_imu, weak_thr, const_kf):
+    from lvio_fusion_amd import api
+    n_kf, n_lm, max_it = 7, 90, 6
+    cfg = _sorted_by_kf(syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=30, seed=77, imu_samples=4))
+    pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+    d = str(tmp_path)
+    tc, tf, po = cfg["tc"], cfg["tf"], cfg["po"]
+    _dump(d, "meta.i32", [n_kf, n_lm, max_it, weak_thr, const_kf], np.int32)
+    for name, key in (("poses", "poses"), ("vel", "vel"), ("ba", "ba"), ("bg", "bg"), ("inv_depth", "inv_depth"), ("w_kf", "w_kf")):
+        _dump(d, name + ".f64", cfg[key], np.float64)
+    _dump(d, "cam0.f64", _cam_vec(cfg["cam0"]), np.float64); _dump(d, "cam1.f64", _cam_vec(cfg["cam1"]), np.float64)
+    _dump(d, "tc_left_ob.f64", tc["left_ob"], np.float64); _dump(d, "tc_right_ob.f64", tc["right_ob"], np.float64)
+    _dump(d, "tc_lm.i32", tc["lm_idx"], np.int32); _dump(d, "tc_kf.i32", tc["kf_idx"], np.int32)
+    _dump(d, "tf_first_ob.f64", tf["first_ob"], np.float64); _dump(d, "tf_ob.f64", tf["ob"], np.float64)
+    _dump(d, "tf_lm.i32", tf["lm_idx"], np.int32); _dump(d, "tf_kf1.i32", tf["kf1_idx"], np.int32); _dump(d, "tf_kf2.i32", tf["kf2_idx"], np.int32)
+    _dump(d, "po_ob.f64", po["ob"], np.float64); _dump(d, "po_pw.f64", po["pw"], np.float64)
+    _dump(d, "po_kf.i32", po["kf_idx"], np.int32); _dump(d, "po_pw_idx.i32", po["pw_idx"], np.int32)
+    imu = cfg["imu"] if with_imu else []
+    _dump(d, "preint.f64", pre if with_imu else np.zeros(0), np.float64)
+    _dump(d, "imu_i.i32", [f["kf_i"] for f in imu], np.int32); _dump(d, "imu_j.i32", [f["kf_j"] for f in imu], np.int32)
+    out = _run("window", d)
+    assert out["ok"] == 1 and out["num_frames"] == n_kf
+
+    # ---- expected priors (backend.cpp:164-178 with the test's threshold): frames without IMU and few visual blocks
+    kf_a, kf_b, tgt = [], [], []
+    if not with_imu:
+        for k in range(n_kf):
+            n_vis = int((po["kf_idx"] == k).sum() + (tf["kf2_idx"] == k).sum())
+            if n_vis < weak_thr:
+                if k == 0:
+                    kf_a.append(-1); kf_b.append(0); tgt.append(cfg["poses"][0])
+                else:
+                    kf_a.append(k - 1); kf_b.append(k)
+                    tgt.append(np.concatenate([oracle.pose_graph_target(cfg["poses"][k - 1], cfg["poses"][k]), [0.0]]))
+    assert out["n_prior"] == len(kf_b)
+    n_blocks = len(tc["lm_idx"]) + len(tf["lm_idx"]) + len(po["kf_idx"]) + len(imu) + len(kf_b)
+    assert out["num_residual_blocks"] == n_blocks
+
+    # ---- the same window through the flat C-ABI from python (identical kernels; only block/landmark numbering differs)
+    ctx = api.Context(0)
+    st = api.State(ctx, n_kf, n_lm)
+    for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth"), (api.W_VISUAL, "w_kf")):
+        st.set(field, cfg[key])
+    btc = api.two_camera_batch(ctx, cfg["cam0"], cfg["cam1"], tc["left_ob"], tc["right_ob"], tc["lm_idx"], tc["kf_idx"])
+    btf = api.two_frame_batch(ctx, cfg["cam0"], cfg["cam1"], tf["first_ob"], tf["ob"], tf["lm_idx"], tf["kf1_idx"], tf["kf2_idx"])
+    bpo = api.pose_only_batch(ctx, cfg["cam0"], po["ob"], po["kf_idx"], po["pw_idx"], po["pw"])
+    bimu = api.imu_batch(ctx, pre, [f["kf_i"] for f in imu], [f["kf_j"] for f in imu]) if with_imu else None
+    prob = api.Problem(ctx, st, btc, btf, bpo, bimu)
+    bpr = None
+    if kf_b:
+        bpr = api.pose_prior_batch(ctx, kf_a, kf_b, np.array(tgt), np.full(len(kf_b), 100.0), np.zeros(len(kf_b)))
+        prob.set_pose_priors(bpr)
+    if const_kf >= 0:
+        prob.set_pose_constant(const_kf, True)
+    opt = api.default_solver_options()
+    opt.max_num_iterations = max_it
+    cost0 = prob.cost(opt)
+    assert abs(out["cost0"] - cost0) <= 1e-9 * cost0
+    summ = prob.solve(opt)
+    assert abs(out["initial_cost"] - summ.initial_cost) <= 1e-9 * summ.initial_cost
+    assert abs(out["final_cost"] - summ.final_cost) <= 1e-6 * summ.final_cost
+    assert out["successful"] == summ.num_successful_steps and out["successful"] >= 2
+    assert out["final_cost"] < 0.5 * out["initial_cost"]
+    rd = lambda name: np.fromfile(os.path.join(d, name))
+    assert_parity(rd("out_poses.f64"), st.get(api.POSES), "poses written back in place")
+    assert_parity(rd("out_inv_depth.f64"), st.get(api.INV_DEPTH), "inverse depths written back in place")
+    if with_imu:
+        assert_parity(rd("out_vel.f64"), st.get(api.VEL), "velocities"); assert_parity(rd("out_ba.f64"), st.get(api.BA), "ba")
+        assert_parity(rd("out_bg.f64"), st.get(api.BG), "bg")
+    else:   # blocks that were never registered are never written
+        assert np.array_equal(rd("out_vel.f64"), cfg["vel"].ravel())
+    if const_kf >= 0:
+        assert np.array_equal(rd("out_poses.f64")[7 * const_kf:7 * const_kf + 7], cfg["poses"][const_kf])
+
+    # ---- batched Evaluate: residual vector in block insertion order vs the oracle
+    c0, c1 = ocam(oracle, cfg["cam0"]), ocam(oracle, cfg["cam1"])
+    r_tc, _ = oracle.two_camera(tc["left_ob"], tc["right_ob"], tc["lm_idx"], tc["kf_idx"], cfg["inv_depth"], cfg["w_kf"], c0, c1, jac=False)
+    r_tf = oracle.two_frame(tf["first_ob"], tf["ob"], tf["lm_idx"], tf["kf1_idx"], tf["kf2_idx"], cfg["inv_depth"], cfg["poses"], cfg["w_kf"], c0, c1, jac=False)[0]
+    r_po, _ = oracle.pose_only(po["ob"], po["kf_idx"], po["pw_idx"], po["pw"], cfg["poses"], cfg["w_kf"], c0, jac=False)
+    r_imu = oracle.imu_eval(pre, [f["kf_i"] for f in imu], [f["kf_j"] for f in imu], cfg["poses"], cfg["vel"], cfg["ba"], cfg["bg"], jac=False)[0] if with_imu else None
+    exp = []
+    ip = 0
+    for k in range(n_kf):
+        exp += [r_tc[i] for i in np.nonzero(tc["kf_idx"] == k)[0]]
+        exp += [r_po[i] for i in np.nonzero(po["kf_idx"] == k)[0]]
+        exp += [r_tf[i] for i in np.nonzero(tf["kf2_idx"] == k)[0]]
+        if with_imu and k > 0:
+            exp.append(r_imu[k - 1])
+        if ip < len(kf_b) and kf_b[ip] == k:
+            exp.append(np.zeros(6)); ip += 1      # priors are anchored at the initial poses: zero residual
+    exp = np.concatenate(exp)
+    got = rd("out_residuals.f64")
+    assert got.shape == exp.shape
+    scale = np.abs(exp).max()
+    assert np.abs(got - exp).max() <= 1e-6 * scale
+
+    # ---- per-block CostFunction::Evaluate probes: [TwoCamera | PoseOnly | TwoFrame | ImuError], jacobians[1] = NULL honoured
+    probe = rd("out_probe.f64")
+    assert out["n_probe"] == (4 if with_imu else 3)
+    i_tc = int(np.nonzero(tc["kf_idx"] == 0)[0][0]); i_po = int(np.nonzero(po["kf_idx"] == 0)[0][0]); i_tf = 0
+    r, J = oracle.two_camera(tc["left_ob"][i_tc:i_tc + 1], tc["right_ob"][i_tc:i_tc + 1], tc["lm_idx"][i_tc:i_tc + 1], tc["kf_idx"][i_tc:i_tc + 1], cfg["inv_depth"], cfg["w_kf"], c0, c1)
+    assert_parity(probe[:4], np.concatenate([r[0], J[0]]), "TwoCamera Evaluate"); probe = probe[4:]
+    r, J = oracle.pose_only(po["ob"][i_po:i_po + 1], po["kf_idx"][i_po:i_po + 1], po["pw_idx"][i_po:i_po + 1], po["pw"], cfg["poses"], cfg["w_kf"], c0)
+    assert_parity(probe[:16], np.concatenate([r[0], J[0].ravel()]), "PoseOnly Evaluate"); probe = probe[16:]
+    r, Jd, J1, J2 = oracle.two_frame(tf["first_ob"][:1], tf["ob"][:1], tf["lm_idx"][:1], tf["kf1_idx"][:1], tf["kf2_idx"][:1], cfg["inv_depth"], cfg["poses"], cfg["w_kf"], c0, c1)
+    assert_parity(probe[:32], np.concatenate([r[0], Jd[0], np.zeros(14), J2[0].ravel()]), "TwoFrame Evaluate (jacobians[1] NULL)"); probe = probe[32:]
+    if with_imu:
+        r, J = oracle.imu_eval(pre[:1], [0], [1], cfg["poses"], cfg["vel"], cfg["ba"], cfg["bg"])
+        Js = oracle.imu_split_jac(J)
+        exp_imu = np.concatenate([r[0]] + [Js[k][0].ravel() if k != 1 else np.zeros(45) for k in range(8)])
+        assert_parity(probe, exp_imu, "ImuError Evaluate (jacobians[1] NULL)")
+    for h in (prob, btc, btf, bpo, bimu, bpr, st):
+        if h is not None:
+            h.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode,use_prior", [(0, 1), (1, 0)])
+def test_scan_to_map_through_adapter(tmp_path, oracle, mode, use_prior):
+    from lvio_fusion_amd import api
+    c = syn.config3_icp()
+    sel = np.sort(np.random.default_rng(5).choice(c["query"].shape[0], 4000, replace=False))
+    q, qg = c["query"][sel], c["query_ground"][sel]
+    qq = q[qg] if mode == 0 else q[~qg]
+    mm = c["map"][c["map_ground"]] if mode == 0 else c["map"][~c["map_ground"]]
+    thr = c["thr_ground"] if mode == 0 else c["thr_surf"]
+    w = syn.W_LIDAR_GROUND if mode == 0 else syn.W_LIDAR_SURF
+    huber = 0.0 if mode == 0 else 0.1
+    prior = 300 * syn.W_VISUAL if use_prior else 0.0
+    rpyxyz0 = oracle.se3_to_rpyxyz(oracle.se3_mul(oracle.se3_inv(c["map_pose"]), c["pose0"]))
+    ref_x, ref = oracle.icp_solve(mm, qq, c["map_pose"], c["pose0"], rpyxyz0, mode, thr, w, huber, prior_w=prior)
+    # association stays where the reference has it (host loop over the 3-NN result); here the device 3-NN provides it
+    ctx = api.Context(0)
+    mp, sc = api.Map(ctx, mm, thr), api.Scan(ctx, qq)
+    api.knn3(mp, sc, c["pose0"], thr)
+    idx, d2, valid = sc.download()
+    v = valid > 0
+    p = qq[v, :3].astype(np.float64)
+    pa, pb, pc = (mm[idx[v, k], :3].astype(np.float64) for k in range(3))
+    mp.close(); sc.close(); ctx.close()
+    d = str(tmp_path)
+    _dump(d, "meta.i32", [mode, use_prior], np.int32)
+    _dump(d, "scalars.f64", [w, huber, prior], np.float64)
+    for name, arr in (("p", p), ("pa", pa), ("pb", pb), ("pc", pc), ("map_pose", c["map_pose"]), ("rpyxyz", rpyxyz0)):
+        _dump(d, name + ".f64", arr, np.float64)
+    out = _run("lidar", d)
+    assert out["ok"] == 1
+    assert out["num_residual_blocks"] == ref["num_residual_blocks"]
+    assert out["successful"] == ref["num_successful_steps"]
+    assert abs(out["initial_cost"] - ref["initial_cost"]) <= 1e-9 * abs(ref["initial_cost"])
+    assert abs(out["final_cost"] - ref["final_cost"]) <= 1e-6 * abs(ref["final_cost"])
+    x = np.fromfile(os.path.join(d, "out_rpyxyz.f64"))
+    assert np.allclose(x, ref_x, rtol=1e-6, atol=1e-9)
+    probe = np.fromfile(os.path.join(d, "out_probe.f64"))
+    nrm = oracle.plane_normals(pa[:1], pb[:1], pc[:1])
+    r, J = oracle.lidar_plane(mode, p[:1], pa[:1], nrm, c["map_pose"], rpyxyz0, w)
+    assert_parity(probe[:4], np.concatenate([r.ravel(), J.ravel()]), "LidarPlaneError Evaluate")
+    if use_prior:
+        s = [1, 2, 5] if mode == 0 else [0, 3, 4]
+        xx = rpyxyz0.copy(); xx[s[0]] += 0.01; xx[s[1]] -= 0.02; xx[s[2]] += 0.03
+        r3, J3 = oracle.prior3(mode, rpyxyz0, prior, xx)
+        assert_parity(probe[4:7], r3, "PoseErrorRPZ/YXY residuals")
+        assert_parity(probe[7:16].reshape(3, 3).T, J3, "PoseErrorRPZ/YXY jacobians")
+
+
+def test_foreign_cost_function_fails_soft():
+    out = _run("foreign")
+    assert out["ok"] == 0 and out["x"] == 3.0 and "not an lvio_fusion::gpu cost function" in out["message"]

@@ -80,3 +80,34 @@ def test_icp_no_correspondences(ctx):
     assert s.num_residual_blocks == 0 and s.final_cost == 0.0
     assert np.array_equal(x, [0.1, 0.0, 0.0, 1.0, 2.0, 3.0])
     mp.close(); sc.close()
+
+
+@pytest.mark.parametrize("mode,prior", [(0, 0.0), (1, 500 * syn.W_VISUAL)])
+def test_lidar_solve_on_caller_built_batch(ctx, oracle, scene, mode, prior):
+    """adapt::Solve-level drop-in: the caller keeps association.cpp's host loop (here: the device 3-NN result downloaded
+    and turned into LidarPlaneError constructor arguments), hands the blocks over as one lidar batch, and
+    lvf_lidar_solve must land exactly where the oracle's ScanToMap + solve lands."""
+    from lvio_fusion_amd import api
+    c, q, qg = scene
+    qq = q[qg] if mode == 0 else q[~qg]
+    mm = c["map"][c["map_ground"]] if mode == 0 else c["map"][~c["map_ground"]]
+    thr = c["thr_ground"] if mode == 0 else c["thr_surf"]
+    w = syn.W_LIDAR_GROUND if mode == 0 else syn.W_LIDAR_SURF
+    huber = 0.0 if mode == 0 else 0.1
+    rpyxyz0 = oracle.se3_to_rpyxyz(oracle.se3_mul(oracle.se3_inv(c["map_pose"]), c["pose0"]))
+    ref_x, ref = oracle.icp_solve(mm, qq, c["map_pose"], c["pose0"], rpyxyz0, mode, thr, w, huber, prior_w=prior)
+    mp, sc = api.Map(ctx, mm, thr), api.Scan(ctx, qq)
+    api.knn3(mp, sc, c["pose0"], thr)
+    idx, d2, valid = sc.download()
+    v = valid > 0
+    p = qq[v, :3].astype(np.float64)
+    pa, pb, pc = (mm[idx[v, k], :3].astype(np.float64) for k in range(3))
+    b = api.lidar_plane_batch(ctx, mode, p, pa, pb, pc, c["map_pose"], w)
+    x = rpyxyz0.copy()
+    s = api.lidar_solve(b, x, huber, prior_weight=prior)
+    assert s.num_residual_blocks == ref["num_residual_blocks"]
+    assert s.num_iterations == ref["num_iterations"] and s.num_successful_steps == ref["num_successful_steps"]
+    assert abs(s.initial_cost - ref["initial_cost"]) <= 1e-9 * abs(ref["initial_cost"])
+    assert abs(s.final_cost - ref["final_cost"]) <= 1e-6 * abs(ref["final_cost"])
+    assert np.allclose(x, ref_x, rtol=1e-6, atol=1e-9)
+    b.close(); mp.close(); sc.close()
