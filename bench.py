@@ -29,6 +29,25 @@ POSE_ONLY_BYTES_PER_BLOCK = 152  # ob 16 + 2 idx 8 + r 16 + J 112
 KNN_BYTES = lambda Q, M: 40 * Q + 16 * M   # SURVEY §8d kNN pass
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_latest.json, written by
+    tools/prof_summary.py from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  FETCH_SIZE
+    is doubled for the gfx950 half-count of wide coalesced reads (MI355X_MICROARCH.md §HBM); counters are KiB.  None when no
+    profile has been committed: bench.py itself cannot collect PMC counters."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        for name, c in d["kernels"].items():
+            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return {"bytes": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "fetch_kib_raw": c["FETCH_SIZE"], "write_kib": c["WRITE_SIZE"],
+                        "source": "profiles/pmc_latest.json (" + d.get("tag", "?") + "); FETCH_SIZE x2 per gfx950 correction"}
+    except Exception:
+        return None
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,7 +120,8 @@ def main():
                                    "(500000 blocks, materialised Ceres-layout r+J), one independent window per GPU",
                        "blocks_per_step": n_blocks, "parallelism": f"{world} independent windows"},
             "roofline": {"bound": "hbm", "kernel": "k_pose_only<true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": (pmc_traffic("k_pose_only<true>") or {}).get("bytes"),
+                         "traffic_detail": pmc_traffic("k_pose_only<true>"),
                          "algorithmic_bytes_per_launch": POSE_ONLY_BYTES_PER_BLOCK * n_blocks,
                          "avg_kernel_ms": kernel_ms},
         }
@@ -111,6 +131,20 @@ def main():
         out["extras"] = extras(api, syn, ctx)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, n_blocks)
+    # configs[4] on N GPUs: 8 loop-closure candidates sharded rank-round-robin, one all_gather of the records over RCCL
+    if world > 1 and not args.no_extras:
+        from lvio_fusion_amd import relocalize as rl
+        cands = syn.config5_candidates(8)
+        rl.evaluate_candidate(api, ctx, cands[rank % 8])      # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        best, rec = rl.relocalize(api, ctx, cands, rank=rank, world=world, device=torch.device("cuda", local_rank))
+        barrier()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            out["extras"] = {"relocalize_8_candidates": {"ms_total": 1e3 * dt, "candidates_per_sec": 8 / dt, "ranks": world,
+                                                         "best": None if best is None else {"candidate": best[0], "score": best[1]},
+                                                         "scores": [float(x) for x in rec[rec[:, 8] >= 0][np.argsort(rec[rec[:, 8] >= 0][:, 8]), 0]]}}
     batch.close(); st.close(); ctx.close()
     if world > 1:
         dist.destroy_process_group()
@@ -143,8 +177,51 @@ def extras(api, syn, ctx):
                               "valid_frac": float(sc.download()[2].mean())}
     ex["icp_mpairs_per_sec"] = ex["knn3_ground_thr4.0"]["mpairs_per_s"]
     mp.close(); sc.close()
+    ex["scan_match_frame"] = scan_match_frame(api, syn, ctx, c3)
     ex["full_window_ba"] = full_window(api, syn, ctx)
+    ex["relocalize_8_candidates"] = relocalize_leg(api, syn, ctx)
     return ex
+
+
+def scan_match_frame(api, syn, ctx, c3, reps=10):
+    """Mapping::Optimize's per-frame body on configs[2]: ground (pitch,roll,z) then surf (yaw,x,y) sub-problem, each =
+    association over the whole feature cloud + <= 4 LM iterations on device (lvf_scan_match, maps resident)."""
+    mg, ms = c3["map"][c3["map_ground"]], c3["map"][~c3["map_ground"]]
+    qg, qs = c3["query"][c3["query_ground"]], c3["query"][~c3["query_ground"]]
+    opt = api.scan_match_options(0.2, outer_iterations=1, prior_weight=0.0)   # relocate-mode blocks: no visual prior pinning the step
+    mpg, scg, mps, scs = api.Map(ctx, mg, opt.thr_ground), api.Scan(ctx, qg), api.Map(ctx, ms, opt.thr_surf), api.Scan(ctx, qs)
+    for _ in range(2):
+        res = api.scan_match(mpg, scg, mps, scs, c3["map_pose"], c3["pose0"], opt)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = api.scan_match(mpg, scg, mps, scs, c3["map_pose"], c3["pose0"], opt)
+    dt = (time.perf_counter() - t0) / reps
+    out = {"Q_ground": int(len(qg)), "Q_surf": int(len(qs)), "M_ground": int(len(mg)), "M_surf": int(len(ms)), "ms_per_frame": 1e3 * dt,
+           "frames_per_sec": 1.0 / dt, "mpairs_per_s": (len(qg) + len(qs)) / dt / 1e6,
+           "valid": [res.ground.num_residual_blocks, res.surf.num_residual_blocks],
+           "lm_iterations": [res.ground.num_iterations, res.surf.num_iterations],
+           "pos_err_before_m": float(np.abs(c3["pose0"][4:] - c3["pose_true"][4:]).max()),
+           "pos_err_after_m": float(np.abs(np.array(res.pose[:])[4:] - c3["pose_true"][4:]).max())}
+    for h in (mpg, scg, mps, scs):
+        h.close()
+    return out
+
+
+def relocalize_leg(api, syn, ctx, n=8):
+    """configs[4] unit of work on ONE GPU: n loop-closure candidates (Mapping::Relocate = 4 outer x {ground, surf}) evaluated
+    back to back incl. map-index builds and uploads; on N GPUs each rank takes n/N of them and one 72-B/record all_gather
+    follows (lvio_fusion_amd/relocalize.py)."""
+    from lvio_fusion_amd import relocalize as rl
+    cands = syn.config5_candidates(n)
+    rl.relocalize(api, ctx, cands[:1])
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    best, rec = rl.relocalize(api, ctx, cands)
+    dt = time.perf_counter() - t0
+    return {"candidates": n, "points_per_candidate": int(cands[0]["query"].shape[0]), "map_points": int(cands[0]["map"].shape[0]),
+            "ms_total": 1e3 * dt, "candidates_per_sec": n / dt, "best": None if best is None else {"candidate": best[0], "score": best[1]},
+            "scores": [float(x) for x in rec[np.argsort(rec[:, 8]), 0]]}
 
 
 def full_window(api, syn, ctx, iters=30):
@@ -195,9 +272,33 @@ def cpu_baseline(cfg, n_blocks):
         if time.perf_counter() - t0 > 10.0 or reps >= 50:
             break
     dt = (time.perf_counter() - t0) / reps
-    return {"value": 1.0 / dt, "unit": "iter/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} full passes over the same {n_blocks}-block window (oracle Jet<7> autodiff, OpenMP, "
-                      f"{threads} threads on a {nproc}-core host); restated reference CPU path — Ceres/PCL are not in the image"}
+    out = {"value": 1.0 / dt, "unit": "iter/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} full passes over the same {n_blocks}-block window (oracle Jet<7> autodiff, OpenMP, "
+                     f"{threads} threads on a {nproc}-core host); restated reference CPU path — Ceres/PCL are not in the image"}
+    # the other two legs of the metric, bounded samples (a few seconds each)
+    from lvio_fusion_amd import synthetic as syn
+    try:
+        c4 = syn.config4_window()
+        pre = np.stack([po.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in c4["imu"]])
+        win = po.Window(c4, pre)
+        r = win.lm_iteration(1e4, 2.0)                       # warm (page faults, OpenMP pool)
+        t0 = time.perf_counter(); k = 0
+        while k < 8 and time.perf_counter() - t0 < 6.0:
+            r = win.lm_iteration(r["radius"], r["decrease_factor"]); k += 1
+        out["full_window_lm_iters_per_sec"] = {"value": k / (time.perf_counter() - t0), "cores": po.max_threads(),
+                                               "sample": f"{k} LM iterations of the configs[3] window (oracle: Jet autodiff linearisation + exact Schur + dense Cholesky, OpenMP)"}
+        c3 = syn.config3_icp()
+        nq = 20000
+        build_s = po.kdtree_build_seconds(c3["map"])
+        t0 = time.perf_counter()
+        po.knn3(c3["map"], c3["query"][:nq], c3["pose0"], c3["thr_ground"], method=1, threads=1)
+        q_s = time.perf_counter() - t0 - build_s
+        out["icp_mpairs_per_sec"] = {"value": nq / max(q_s, 1e-9) / 1e6, "incl_tree_build": 100000 / (build_s + 5 * max(q_s, 1e-9)) / 1e6, "cores": 1,
+                                     "sample": f"{nq} of the 100000 configs[2] queries against the 340k-point map, leaf-15 kd-tree (the reference's "
+                                               "PCL/FLANN structure, rebuilt per call there: association.cpp:279), 1 thread like the reference's loop"}
+    except Exception as e:   # a failing baseline must not take the GPU numbers down with it
+        out["extras_error"] = repr(e)
+    return out
 
 
 if __name__ == "__main__":

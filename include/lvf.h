@@ -20,6 +20,7 @@
  *                         src/association.cpp:278-301 (ground), :336-359 (surf)
  *   lvf_icp_*          <- FeatureAssociation::ScanToMapWith{Ground,Segmented} + the DENSE_QR solve
  *                         src/association.cpp:270-384, src/mapping.cpp:154-178
+ *   lvf_scan_match     <- Mapping::Optimize's per-frame body / Mapping::Relocate   src/mapping.cpp:147-178, :251-300
  *   lvf_problem_*      <- adapt::Problem::{AddParameterBlock,AddResidualBlock,SetParameterBlockConstant}
  *                         + adapt::Solve (include/lvio_fusion/adapt/problem.h:34-88) as driven by
  *                         Backend::BuildProblem / Backend::Optimize (src/backend.cpp:96-183, :192-246)
@@ -203,6 +204,29 @@ typedef struct lvf_icp_summary {
  * (mapping.cpp:153-165).  The caller then sets frame->pose = map_pose * rpyxyz2se3(rpyxyz) (mapping.cpp:164). */
 int lvf_icp_solve(lvf_map* m, lvf_scan* s, const double* map_pose, const double* frame_pose, double* rpyxyz,
                   const lvf_icp_options* opt, lvf_icp_summary* summary);
+
+/* ---- one frame's scan-to-map update: Mapping::Optimize's body (mapping.cpp:147-178) / Mapping::Relocate (:251-300) ---- */
+typedef struct lvf_scan_match_options {
+  float thr_ground, thr_surf;      /* resolution^2 * 100 / * 25 (association.cpp:285,343) */
+  double weight_ground, weight_surf; /* frame->weights.lidar_ground / lidar_surf */
+  double huber_surf;               /* 0.1 (association.cpp:330); ground uses TrivialLoss */
+  double prior_weight;             /* |features_left| * weights.visual; 0 = relocate mode (association.cpp:321,379) */
+  int outer_iterations;            /* 1 = Mapping::Optimize, 4 = Mapping::Relocate (mapping.cpp:264) */
+  int max_num_iterations;          /* 4 */
+} lvf_scan_match_options;
+typedef struct lvf_scan_match_result {
+  double pose[7];                  /* the frame's pose after the update */
+  double relative_o_c[7];          /* last_pose^-1 * pose (mapping.cpp:298); = pose when last_pose is NULL */
+  double score_ground, score_surf; /* mapping.cpp:279-280, :293-294 (last outer iteration) */
+  int score;                       /* (int)(score_ground + score_surf): Mapping::Relocate's return value */
+  lvf_icp_summary ground, surf;    /* summaries of the last ground / surf sub-problem */
+} lvf_scan_match_result;
+void lvf_scan_match_options_default(lvf_scan_match_options* o, double lidar_resolution);
+/* Either (map, scan) pair may be NULL (empty cloud: the reference skips that sub-problem).  All four handles must
+ * belong to one context. */
+int lvf_scan_match(lvf_map* map_ground, lvf_scan* scan_ground, lvf_map* map_surf, lvf_scan* scan_surf, const double* map_pose,
+                   const double* frame_pose, const double* last_pose, const lvf_scan_match_options* opt,
+                   lvf_scan_match_result* result);
 
 /* The same device-resident 3-DoF solve over a caller-built lidar batch (lvf_lidar_plane_create): what adapt::Solve
  * does for the problem ScanToMapWithGround/Segmented assembled (mapping.cpp:157-163, :270-296).  mode, weight and Twc1

@@ -33,6 +33,16 @@ class IcpSummary(C.Structure):
                 ("num_iterations", C.c_int), ("num_successful_steps", C.c_int)]
 
 
+class ScanMatchOptions(C.Structure):
+    _fields_ = [("thr_ground", C.c_float), ("thr_surf", C.c_float), ("weight_ground", C.c_double), ("weight_surf", C.c_double),
+                ("huber_surf", C.c_double), ("prior_weight", C.c_double), ("outer_iterations", C.c_int), ("max_num_iterations", C.c_int)]
+
+
+class ScanMatchResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 7), ("relative_o_c", C.c_double * 7), ("score_ground", C.c_double), ("score_surf", C.c_double),
+                ("score", C.c_int), ("ground", IcpSummary), ("surf", IcpSummary)]
+
+
 class SolverOptions(C.Structure):
     _fields_ = [("max_num_iterations", C.c_int), ("max_solver_time_in_seconds", C.c_double), ("huber_a", C.c_double),
                 ("initial_trust_region_radius", C.c_double), ("function_tolerance", C.c_double),
@@ -98,6 +108,8 @@ _SIGS = {
     "lvf_scan_download": (C.c_int, [_VP, c_int_p, c_float_p, c_u8_p]),
     "lvf_knn3_debug_stats": (C.c_int, [_VP, _VP, c_double_p, C.c_float, c_int_p, c_float_p, C.POINTER(C.c_int)]),
     "lvf_icp_solve": (C.c_int, [_VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
+    "lvf_scan_match_options_default": (None, [C.POINTER(ScanMatchOptions), C.c_double]),
+    "lvf_scan_match": (C.c_int, [_VP, _VP, _VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(ScanMatchOptions), C.POINTER(ScanMatchResult)]),
     "lvf_lidar_solve": (C.c_int, [_VP, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
     "lvf_prior3_evaluate": (C.c_int, [_VP, C.c_int, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p]),
     "lvf_solver_options_default": (None, [C.POINTER(SolverOptions)]),

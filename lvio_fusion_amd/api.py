@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Camera, IcpOptions, IcpSummary, SolverOptions, SolverSummary
+from ._lib import Camera, IcpOptions, IcpSummary, ScanMatchOptions, ScanMatchResult, SolverOptions, SolverSummary
 
 POSES, VEL, BA, BG, INV_DEPTH, W_VISUAL = range(6)
 IMU_BLOCK_SIZES = (7, 3, 3, 3, 7, 3, 3, 3)
@@ -259,6 +259,25 @@ def icp_solve(map_, scan, map_pose, frame_pose, rpyxyz, mode, thr, weight, huber
     summ = IcpSummary()
     _chk(map_.ctx.L.lvf_icp_solve(map_.h, scan.h, _dp(mp), _dp(fp), _dp(rpyxyz), C.byref(opt), C.byref(summ)))
     return summ
+
+
+def scan_match_options(resolution=0.2, outer_iterations=1, prior_weight=0.0):
+    o = ScanMatchOptions()
+    _lib.lib().lvf_scan_match_options_default(C.byref(o), float(resolution))
+    o.outer_iterations, o.prior_weight = int(outer_iterations), float(prior_weight)
+    return o
+
+
+def scan_match(map_ground, scan_ground, map_surf, scan_surf, map_pose, frame_pose, opt, last_pose=None):
+    """Mapping::Optimize's per-frame body (outer_iterations=1, prior) / Mapping::Relocate (outer_iterations=4, no prior)."""
+    mp, fp = _d(map_pose), _d(frame_pose)
+    lp = _d(last_pose) if last_pose is not None else None
+    res = ScanMatchResult()
+    anyh = map_ground if map_ground is not None else map_surf
+    h = lambda x: x.h if x is not None else None
+    _chk(anyh.ctx.L.lvf_scan_match(h(map_ground), h(scan_ground), h(map_surf), h(scan_surf), _dp(mp), _dp(fp), _dp(lp) if lp is not None else None,
+                                   C.byref(opt), C.byref(res)))
+    return res
 
 
 def lidar_solve(batch, rpyxyz, huber_a, prior_weight=0.0, max_num_iterations=4):

@@ -1,0 +1,95 @@
+"""Loop-closure candidate evaluation sharded one candidate per GPU (BASELINE configs[4]).
+
+Reference flow (src/lvio_fusion/src/relocator.cpp:188-206): for every keyframe of the new sub-map, Relocator::Relocate ->
+Mapping::Relocate (src/mapping.cpp:251-300: 4 outer iterations x {ground, surf} scan-to-map solves, no shared mutable
+state between candidates) sets loop_closure->score = score - 20 and relative_o_c; the candidate with the largest score
+(`>=`, so the LAST of equal scores; only scores > 0 qualify) becomes best_frame.
+
+Here: rank r evaluates candidates r, r + world, ... on its own GPU (lvf_scan_match, everything device-resident), the ranks
+exchange ONE fixed-size record per candidate slot — (loop score, relative_o_c[7], candidate id) — with a single
+all_gather (RCCL over xGMI on GPUs: pure latency; gloo in the CPU tests), and every rank runs the same arg-max.
+No other collective touches the data path.
+"""
+import numpy as np
+
+RELOCATE_BASE_SCORE = 20          # relocator.cpp:181  loop_closure->score += score - 20
+RECORD = 9                        # score, relative_o_c[7], candidate id
+
+
+def owned(n_candidates, rank, world):
+    return list(range(rank, n_candidates, world))
+
+
+def slots(n_candidates, world):
+    return (n_candidates + world - 1) // world
+
+
+def empty_records(n_slots):
+    r = np.zeros((n_slots, RECORD))
+    r[:, 0] = -np.inf
+    r[:, 4] = 1.0                 # identity quaternion (x,y,z,w)
+    r[:, 8] = -1.0                # unused slot
+    return r
+
+
+def make_record(cand_id, mapping_score, relative_o_c):
+    rec = np.empty(RECORD)
+    rec[0] = float(int(mapping_score) - RELOCATE_BASE_SCORE)
+    rec[1:8] = relative_o_c
+    rec[8] = float(cand_id)
+    return rec
+
+
+def choose_best(records):
+    """records: (n, 9).  Returns (candidate id, score, relative_o_c) or None — relocator.cpp:191-204 in candidate order."""
+    recs = [r for r in np.asarray(records).reshape(-1, RECORD) if r[8] >= 0]
+    recs.sort(key=lambda r: r[8])
+    best, max_score = None, -1.0
+    for r in recs:
+        if r[0] > 0 and r[0] >= max_score:          # Relocate() returned true, and `>=` keeps the later candidate on ties
+            max_score, best = r[0], r
+    if best is None:
+        return None
+    return int(best[8]), float(best[0]), best[1:8].copy()
+
+
+def gather_records(local, world, device=None):
+    """One all_gather of the (slots, 9) float64 table.  world == 1: no communication."""
+    if world == 1:
+        return local.copy()
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(local))
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return np.concatenate([o.cpu().numpy() for o in out])
+
+
+def evaluate_candidate(api, ctx, cand, resolution=0.2):
+    """cand: dict(map, map_ground(mask), query, query_ground(mask), map_pose, last_pose, init_pose).  Mapping::Relocate."""
+    mg, ms = cand["map"][cand["map_ground"]], cand["map"][~cand["map_ground"]]
+    qg, qs = cand["query"][cand["query_ground"]], cand["query"][~cand["query_ground"]]
+    opt = api.scan_match_options(resolution, outer_iterations=4, prior_weight=0.0)
+    h = []
+    try:
+        mpg = api.Map(ctx, mg, opt.thr_ground) if len(mg) else None
+        scg = api.Scan(ctx, qg) if mpg is not None else None
+        mps = api.Map(ctx, ms, opt.thr_surf) if len(ms) else None
+        scs = api.Scan(ctx, qs) if mps is not None else None
+        h = [x for x in (mpg, scg, mps, scs) if x is not None]
+        return api.scan_match(mpg, scg, mps, scs, cand["map_pose"], cand["init_pose"], opt, last_pose=cand["last_pose"])
+    finally:
+        for x in h:
+            x.close()
+
+
+def relocalize(api, ctx, candidates, rank=0, world=1, device=None):
+    """Evaluates this rank's share, exchanges the records, returns (best or None, all records)."""
+    table = empty_records(slots(len(candidates), world))
+    for s, cid in enumerate(owned(len(candidates), rank, world)):
+        res = evaluate_candidate(api, ctx, candidates[cid])
+        table[s] = make_record(cid, res.score, np.array(res.relative_o_c[:]))
+    allrec = gather_records(table, world, device)
+    return choose_best(allrec), allrec

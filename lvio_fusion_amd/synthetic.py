@@ -317,3 +317,15 @@ def config3_icp(seed=SEED_CFG3, n_query=100000, noise=0.02, n_az=2900):
         out = np.zeros((a.shape[0], 4), np.float32); out[:, :3] = a.astype(np.float32); return out
     return dict(query=pad(q), query_ground=qg, map=pad(map_w), map_ground=map_ground, pose_true=poses[3], pose0=pose0,
                 map_pose=poses[2], thr_ground=THR_GROUND, thr_surf=THR_SURF)
+
+
+# ----------------------------------------------------------------------------- config 5 (loop-closure candidates)
+def config5_candidates(n=8, seed=0x5CA7, n_query=20000, n_az=600):
+    """n independent relocalisation candidates (SURVEY §8d config 5): each is a config-3 style scene with its own seed;
+    the 'old' keyframe is the map pose, the candidate's initial pose is the perturbed query pose."""
+    out = []
+    for i in range(n):
+        c = config3_icp(seed=seed + i, n_query=n_query, n_az=n_az)
+        out.append(dict(map=c["map"], map_ground=c["map_ground"], query=c["query"], query_ground=c["query_ground"],
+                        map_pose=c["map_pose"], last_pose=c["map_pose"], init_pose=c["pose0"], pose_true=c["pose_true"]))
+    return out

@@ -1,0 +1,76 @@
+"""The N>1 path on CPU: world_size-2 gloo processes exercise the sharding, the single all_gather and the arg-max of the
+loop-closure candidate evaluation (lvio_fusion_amd/relocalize.py) with scripted per-candidate results — the collective
+logic is device-independent; the per-candidate solve itself is covered on the GPU (tests/test_gpu_relocalize.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from lvio_fusion_amd import relocalize as rl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ownership_covers_every_candidate_once():
+    for n in (1, 5, 8, 13):
+        for world in (1, 2, 4, 8):
+            got = sorted(c for r in range(world) for c in rl.owned(n, r, world))
+            assert got == list(range(n))
+            assert all(len(rl.owned(n, r, world)) <= rl.slots(n, world) for r in range(world))
+
+
+def test_choose_best_follows_relocator_rules():
+    recs = rl.empty_records(5)
+    ident = [0, 0, 0, 1, 0, 0, 0]
+    recs[0] = rl.make_record(0, 25.9, ident)     # int(25.9) - 20 = 5
+    recs[1] = rl.make_record(1, 20.0, ident)     # 0: not > 0 -> Relocate() returned false
+    recs[2] = rl.make_record(2, 31.0, ident)     # 11
+    recs[3] = rl.make_record(3, 31.7, ident)     # 11: ties go to the LATER candidate (>=)
+    best = rl.choose_best(recs)
+    assert best[0] == 3 and best[1] == 11.0
+    assert rl.choose_best(rl.empty_records(3)) is None
+    only_bad = rl.empty_records(2); only_bad[0] = rl.make_record(0, 12.0, ident)
+    assert rl.choose_best(only_bad) is None
+
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from lvio_fusion_amd import relocalize as rl
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = 7
+scores = [22.0, 45.5, 19.0, 45.2, 30.0, 21.0, 44.9]          # scripted Mapping::Relocate results
+table = rl.empty_records(rl.slots(n, world))
+for s, cid in enumerate(rl.owned(n, rank, world)):
+    rel = np.array([0, 0, np.sin(0.01 * cid), np.cos(0.01 * cid), cid, 2.0 * cid, 0.5])
+    table[s] = rl.make_record(cid, scores[cid], rel)
+allrec = rl.gather_records(table, world)
+best = rl.choose_best(allrec)
+print(json.dumps({"rank": rank, "best": [best[0], best[1]] + best[2].tolist(), "n_rec": int((allrec[:, 8] >= 0).sum())}))
+dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_gather_and_argmax(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e
+        outs.append(__import__("json").loads(o.strip().splitlines()[-1]))
+    # both ranks see all 7 records and agree on the winner: candidates 1 and 3 tie at int(45.x) - 20 = 25 -> the later one
+    assert all(o["n_rec"] == 7 for o in outs)
+    assert outs[0]["best"] == outs[1]["best"]
+    assert outs[0]["best"][0] == 3 and outs[0]["best"][1] == 25.0
+    assert np.allclose(outs[0]["best"][2:], [0, 0, np.sin(0.03), np.cos(0.03), 3, 6.0, 0.5])

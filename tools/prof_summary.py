@@ -54,8 +54,29 @@ def pmc(d, label):
         print("  " + "  ".join(f"{c}={v[0] / v[1]:.1f} (n={v[1]})" for c, v in sorted(cs.items())) + "  " + short(k, 90))
 
 
+def pmc_json(root, tag):
+    """per-kernel average counters of all PMC passes -> dict for profiles/pmc_latest.json (read by bench.py's roofline.traffic)"""
+    out = {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_l2"):
+        f = find(os.path.join(root, sub), "counter_collection.csv")
+        if not f:
+            continue
+        acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+        for r in csv.DictReader(open(f)):
+            a = acc[r["Kernel_Name"]][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+        for k, cs in acc.items():
+            for c, v in cs.items():
+                out.setdefault(k, {})[c] = v[0] / v[1]
+    return {"tag": tag, "units": "average per dispatch; FETCH_SIZE/WRITE_SIZE in KiB (FETCH_SIZE under-counts wide reads 2x on gfx950)", "kernels": out}
+
+
 if __name__ == "__main__":
     root = sys.argv[1]
+    if len(sys.argv) > 2 and sys.argv[2] == "--json":
+        import json
+        print(json.dumps(pmc_json(root, os.path.basename(root.rstrip("/"))), indent=1))
+        sys.exit(0)
     kernel_stats(os.path.join(root, "trace"))
     for sub, label in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_l2", "TCC_HIT_sum TCC_MISS_sum")):
         pmc(os.path.join(root, sub), label)

@@ -17,6 +17,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O
 timeout 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -o bench -- $PMCB > "$OUT/pmc_l2.log" 2>&1
 cd "$ROOT"
 python tools/prof_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
+python tools/prof_summary.py "$OUT" --json > "$OUT/pmc.json" 2>/dev/null
 tail -3 "$OUT/trace.log"
 cat "$OUT/summary.txt"
 # keep the merged payload small: the raw per-dispatch CSVs can be large
