@@ -119,9 +119,9 @@ def main():
             "config": {"workload": "configs[1]: batched PoseOnlyReprojection residual+Jacobian, 10k landmarks x 50 KF "
                                    "(500000 blocks, materialised Ceres-layout r+J), one independent window per GPU",
                        "blocks_per_step": n_blocks, "parallelism": f"{world} independent windows"},
-            "roofline": {"bound": "hbm", "kernel": "k_pose_only<true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": (pmc_traffic("k_pose_only<true>") or {}).get("bytes"),
-                         "traffic_detail": pmc_traffic("k_pose_only<true>"),
+            "roofline": {"bound": "hbm", "kernel": "k_pose_only_rj", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": (pmc_traffic("k_pose_only_rj") or {}).get("bytes"),
+                         "traffic_detail": pmc_traffic("k_pose_only_rj"),
                          "algorithmic_bytes_per_launch": POSE_ONLY_BYTES_PER_BLOCK * n_blocks,
                          "avg_kernel_ms": kernel_ms},
         }

@@ -13,6 +13,8 @@
 //   * Jacobian rows are produced in registers, transposed through a padded LDS tile (row stride 15 doubles:
 //     conflict-free ds_write_b64) and written back as fully coalesced 16 B/lane stores in the exact
 //     row-major num_residuals x block_size Ceres layout.
+#include <algorithm>
+#include <cstdlib>
 #include "factor_eval.hpp"
 #include "lvf_internal.hpp"
 
@@ -62,6 +64,57 @@ __global__ __launch_bounds__(kBlock) void k_pose_only(int n, int n_kf, const dou
   if (WITH_J) {
     __syncthreads();
     flush_tile14(s_tile, jac, first, min(kBlock, n - first));
+  }
+}
+
+// Materialised r + J, the bench headline: write-once outputs dominate (128 of 152 B/block), so
+//   * outputs leave with NON-TEMPORAL 16-B stores (measured 15.5 -> 13.1 us at 500 k blocks: the stream no longer
+//     allocates in L2/MALL; nt LOADS of the inputs measured slower and are not used),
+//   * the grid is persistent (<= 4 workgroups per CU, each walking the same number of 256-block tiles round-robin) so the
+//     pose staging is paid once per workgroup; concurrently active workgroups write ADJACENT 128-B aligned tiles (an even
+//     contiguous split per workgroup measured 20 % slower: unaligned range starts turn wave stores into partial lines).
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store2_nt(double2* p, double2 v) {
+  d2v_t t = {v.x, v.y};
+  __builtin_nontemporal_store(t, reinterpret_cast<d2v_t*>(p));
+}
+__global__ __launch_bounds__(kBlock) void k_pose_only_rj(int n, int n_kf, const double2* __restrict__ ob,
+                                                         const int* __restrict__ kf_idx, const int* __restrict__ pw_idx,
+                                                         const double* __restrict__ pw, const double* __restrict__ poses,
+                                                         const double* __restrict__ w_kf, const CamD cam,
+                                                         double2* __restrict__ res, double* __restrict__ jac) {
+  __shared__ PoseD s_pose[kMaxStagedKf];
+  __shared__ double s_tile[kBlock * kTileStride];
+  stage_poses<kBlock>(s_pose, poses, n_kf);
+  const int ntiles = (n + kBlock - 1) / kBlock;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int first = tile * kBlock;
+    const int i = first + threadIdx.x;
+    if (i < n) {
+      const int kf = kf_idx[i];
+      const int l = pw_idx[i];
+      const double2 o = ob[i];
+      const PoseD P = fetch_pose(s_pose, poses, n_kf, kf);
+      const double pwl[3] = {pw[3 * l], pw[3 * l + 1], pw[3 * l + 2]};
+      double r[2], J[14];
+      eval_pose_only<true>(P, cam, o.x, o.y, pwl, w_kf[kf], r, J);
+      store2_nt(res + i, make_double2(r[0], r[1]));
+      double* row = s_tile + threadIdx.x * kTileStride;
+#pragma unroll
+      for (int k = 0; k < 14; ++k) row[k] = J[k];
+    }
+    __syncthreads();
+    {
+      const int cnt = min(kBlock, n - first);
+      double2* dst = reinterpret_cast<double2*>(jac + (size_t)first * 14);
+      const int pairs = cnt * 7;
+      for (int e2 = threadIdx.x; e2 < pairs; e2 += kBlock) {
+        const int th = e2 / 7, k = 2 * (e2 - th * 7);
+        const double* sp = s_tile + th * kTileStride + k;
+        store2_nt(dst + e2, make_double2(sp[0], sp[1]));
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -137,6 +190,16 @@ int launch_pose_only(lvf_batch* b, const lvf_state* st, bool want_j) {
   hipStream_t s = b->ctx->stream;
   auto ob = reinterpret_cast<const double2*>(b->ob_a.p);
   auto res = reinterpret_cast<double2*>(b->res.p);
+  if (want_j && st->n_kf <= kMaxStagedKf) {
+    // balanced persistent grid: every workgroup gets the same number of tiles (the last one possibly fewer)
+    const int ntiles = grid_for(b->n), cap = b->ctx->num_cu * 4;
+    const int per_wg = (ntiles + cap - 1) / cap;
+    const int grid = (ntiles + per_wg - 1) / per_wg;
+    hipLaunchKernelGGL(k_pose_only_rj, dim3(grid), dim3(kBlock), 0, s, b->n, st->n_kf, ob, b->idx_a.p, b->idx_b.p, b->table.p, st->poses.p,
+                       st->w_visual.p, b->cam_a, res, b->jac[0].p);
+    LVF_HIP(hipGetLastError());
+    return LVF_OK;
+  }
   if (want_j)
     hipLaunchKernelGGL(k_pose_only<true>, dim3(grid_for(b->n)), dim3(kBlock), 0, s, b->n, st->n_kf, ob, b->idx_a.p,
                        b->idx_b.p, b->table.p, st->poses.p, st->w_visual.p, b->cam_a, res, b->jac[0].p);
