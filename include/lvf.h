@@ -20,6 +20,8 @@
  *                         src/association.cpp:278-301 (ground), :336-359 (surf)
  *   lvf_icp_*          <- FeatureAssociation::ScanToMapWith{Ground,Segmented} + the DENSE_QR solve
  *                         src/association.cpp:270-384, src/mapping.cpp:154-178
+ *   lvf_cloud_*        <- Mapping::MergeScan/ToWorld/BuildMapFrame, pcl::VoxelGrid / RadiusOutlierRemoval / SACSegmentation
+ *                         src/mapping.cpp:78-137,193-220, src/association.cpp:210-268
  *   lvf_scan_match     <- Mapping::Optimize's per-frame body / Mapping::Relocate   src/mapping.cpp:147-178, :251-300
  *   lvf_problem_*      <- adapt::Problem::{AddParameterBlock,AddResidualBlock,SetParameterBlockConstant}
  *                         + adapt::Solve (include/lvio_fusion/adapt/problem.h:34-88) as driven by
@@ -59,6 +61,7 @@ typedef struct lvf_batch lvf_batch;
 typedef struct lvf_map lvf_map;
 typedef struct lvf_scan lvf_scan;
 typedef struct lvf_icp lvf_icp;
+typedef struct lvf_cloud lvf_cloud;
 typedef struct lvf_problem lvf_problem;
 
 /* Camera = intrinsics + sensor->robot extrinsic (include/lvio_fusion/sensor.h:41-44, visual/camera.h:74). */
@@ -182,6 +185,34 @@ int lvf_scan_download(lvf_scan* s, int32_t* idx3, float* d2_3, uint8_t* valid);
  * and the grid pyramid levels4[L][4] = {cell, nx, ny, nz}. */
 int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* s, const double* pose, float thr, int32_t* stats4, float* levels4,
                          int* n_levels);
+
+/* ---- map-cloud maintenance on device (the steps immediately before the association) ------------- */
+/* A cloud is n x (x, y, z, intensity) float32 in HBM (pcl::PointXYZI payload).  points: strided host records, xyz at the
+ * start, intensity at float offset `intensity_offset` (4 for pcl::PointXYZI; -1 = none -> 0). */
+int lvf_cloud_create(lvf_ctx* ctx, const float* points, int n, int stride_floats, int intensity_offset, lvf_cloud** out);
+int lvf_cloud_destroy(lvf_cloud* c);
+int lvf_cloud_size(const lvf_cloud* c);
+int lvf_cloud_download(const lvf_cloud* c, float* xyzi /* [n][4] */);
+/* Mapping::MergeScan / ToWorld / Sensor2Robot (mapping.cpp:193-220, association.cpp:236-247): out_i = SE3TransformPoint<float>
+ * (pose.cast<float>(), in_i), intensity copied.  Bit-exact float arithmetic (normalise-then-rotate polynomial, no FMA). */
+int lvf_cloud_transform(const lvf_cloud* in, const double* pose, lvf_cloud** out);
+/* `merged += pointclouds[t]` of BuildMapFrame / BuildOldMapFrame (mapping.cpp:78-137): device-side concatenation. */
+int lvf_cloud_concat(lvf_ctx* ctx, const lvf_cloud* const* parts, int n_parts, lvf_cloud** out);
+/* pcl::VoxelGrid<PointXYZI> with a cubic leaf (association.cpp:210-215, 222-224): per-voxel centroid of all four fields,
+ * voxels in ascending (i + j*dx + k*dx*dy) order. */
+int lvf_cloud_voxel_filter(const lvf_cloud* in, float leaf, lvf_cloud** out);
+/* pcl::RadiusOutlierRemoval (association.cpp:217-221): keeps a point iff more than min_neighbors points (itself
+ * included) lie at squared distance < radius^2; input order preserved. */
+int lvf_cloud_radius_outlier_filter(const lvf_cloud* in, float radius, int min_neighbors, lvf_cloud** out);
+/* FeatureAssociation::SegmentGround (association.cpp:249-268): RANSAC plane (all hypotheses scored in one launch, PCL's
+ * adaptive stopping rule applied in hypothesis order), least-squares refit, inliers extracted in input order.
+ * coefficients4 (may be NULL) = (nx, ny, nz, d) with nz >= 0; iterations_used (may be NULL) = hypotheses consumed.
+ * Sampling is splitmix64(seed, hypothesis, draw) — PCL's boost::mt19937 stream is not reproducible without PCL. */
+int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int max_iterations, uint64_t seed, lvf_cloud** out,
+                            double* coefficients4, int* iterations_used);
+/* kNN index / query scan straight from device-resident clouds (no host round trip) */
+int lvf_map_create_from_cloud(const lvf_cloud* c, float max_radius2, lvf_map** out);
+int lvf_scan_create_from_cloud(const lvf_cloud* c, lvf_scan** out);
 
 /* ---- one scan-to-map sub-problem (3-DoF LM on device) ---------------------------------------- */
 typedef struct lvf_icp_options {

@@ -108,6 +108,17 @@ _SIGS = {
     "lvf_scan_download": (C.c_int, [_VP, c_int_p, c_float_p, c_u8_p]),
     "lvf_knn3_debug_stats": (C.c_int, [_VP, _VP, c_double_p, C.c_float, c_int_p, c_float_p, C.POINTER(C.c_int)]),
     "lvf_icp_solve": (C.c_int, [_VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
+    "lvf_cloud_create": (C.c_int, [_VP, c_float_p, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "lvf_cloud_destroy": (C.c_int, [_VP]),
+    "lvf_cloud_size": (C.c_int, [_VP]),
+    "lvf_cloud_download": (C.c_int, [_VP, c_float_p]),
+    "lvf_cloud_transform": (C.c_int, [_VP, c_double_p, C.POINTER(_VP)]),
+    "lvf_cloud_concat": (C.c_int, [_VP, C.POINTER(_VP), C.c_int, C.POINTER(_VP)]),
+    "lvf_cloud_voxel_filter": (C.c_int, [_VP, C.c_float, C.POINTER(_VP)]),
+    "lvf_cloud_radius_outlier_filter": (C.c_int, [_VP, C.c_float, C.c_int, C.POINTER(_VP)]),
+    "lvf_cloud_segment_plane": (C.c_int, [_VP, C.c_float, C.c_int, C.c_uint64, C.POINTER(_VP), c_double_p, C.POINTER(C.c_int)]),
+    "lvf_map_create_from_cloud": (C.c_int, [_VP, C.c_float, C.POINTER(_VP)]),
+    "lvf_scan_create_from_cloud": (C.c_int, [_VP, C.POINTER(_VP)]),
     "lvf_scan_match_options_default": (None, [C.POINTER(ScanMatchOptions), C.c_double]),
     "lvf_scan_match": (C.c_int, [_VP, _VP, _VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(ScanMatchOptions), C.POINTER(ScanMatchResult)]),
     "lvf_lidar_solve": (C.c_int, [_VP, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),

@@ -214,11 +214,70 @@ def preintegrate_or_none(ctx, cfg):
                         np.stack([f["ba"] for f in imu]), np.stack([f["bg"] for f in imu]), syn.IMU_NOISE)
 
 
+class Cloud:
+    """Device-resident (x, y, z, intensity) float32 cloud; every method returns a new device cloud."""
+
+    def __init__(self, ctx, xyzi=None, _h=None):
+        self.ctx = ctx
+        if _h is not None:
+            self.h = _h
+        else:
+            a = _f(xyzi)
+            assert a.ndim == 2 and a.shape[1] >= 3
+            self.h = C.c_void_p()
+            _chk(ctx.L.lvf_cloud_create(ctx.h, a.ctypes.data_as(_lib.c_float_p), a.shape[0], a.shape[1], 3 if a.shape[1] > 3 else -1, C.byref(self.h)))
+
+    def __len__(self):
+        return self.ctx.L.lvf_cloud_size(self.h)
+
+    def download(self):
+        out = np.empty((len(self), 4), np.float32)
+        _chk(self.ctx.L.lvf_cloud_download(self.h, out.ctypes.data_as(_lib.c_float_p)))
+        return out
+
+    def _new(self, fn, *args):
+        h = C.c_void_p()
+        _chk(fn(self.h, *args, C.byref(h)))
+        return Cloud(self.ctx, _h=h)
+
+    def transform(self, pose):
+        p = _d(pose)
+        return self._new(self.ctx.L.lvf_cloud_transform, _dp(p))
+
+    def voxel_filter(self, leaf):
+        return self._new(self.ctx.L.lvf_cloud_voxel_filter, float(leaf))
+
+    def radius_outlier_filter(self, radius, min_neighbors):
+        return self._new(self.ctx.L.lvf_cloud_radius_outlier_filter, float(radius), int(min_neighbors))
+
+    def segment_plane(self, thr, max_iterations=100, seed=12345):
+        h = C.c_void_p(); co = np.empty(4); it = C.c_int()
+        _chk(self.ctx.L.lvf_cloud_segment_plane(self.h, float(thr), int(max_iterations), int(seed), C.byref(h), _dp(co), C.byref(it)))
+        return Cloud(self.ctx, _h=h), co, it.value
+
+    @staticmethod
+    def concat(ctx, parts):
+        arr = (C.c_void_p * len(parts))(*[p.h for p in parts])
+        h = C.c_void_p()
+        _chk(ctx.L.lvf_cloud_concat(ctx.h, arr, len(parts), C.byref(h)))
+        return Cloud(ctx, _h=h)
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lvf_cloud_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class Map:
     def __init__(self, ctx, xyz, max_radius2):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        if isinstance(xyz, Cloud):
+            self.M = len(xyz)
+            _chk(ctx.L.lvf_map_create_from_cloud(xyz.h, float(max_radius2), C.byref(self.h)))
+            return
         a = _f(xyz)
         self.ctx, self.M = ctx, a.shape[0]
-        self.h = C.c_void_p()
         _chk(ctx.L.lvf_map_create(ctx.h, a.ctypes.data_as(_lib.c_float_p), a.shape[0], a.shape[1] if a.ndim == 2 else 3,
                                   float(max_radius2), C.byref(self.h)))
 
@@ -230,9 +289,14 @@ class Map:
 
 class Scan:
     def __init__(self, ctx, xyz):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        if isinstance(xyz, Cloud):
+            self.Q = len(xyz)
+            _chk(ctx.L.lvf_scan_create_from_cloud(xyz.h, C.byref(self.h)))
+            return
         a = _f(xyz)
         self.ctx, self.Q = ctx, a.shape[0]
-        self.h = C.c_void_p()
         _chk(ctx.L.lvf_scan_create(ctx.h, a.ctypes.data_as(_lib.c_float_p), a.shape[0], a.shape[1] if a.ndim == 2 else 3, C.byref(self.h)))
 
     def download(self):

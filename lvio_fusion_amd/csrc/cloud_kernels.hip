@@ -1,0 +1,526 @@
+// cloud_kernels.hip — map-cloud maintenance on device: the steps immediately before the kNN association.
+//
+// Replaces, with the clouds resident in HBM between scan-to-map solves,
+//   Mapping::MergeScan / ToWorld, FeatureAssociation::Sensor2Robot   float SE3 transform of a whole cloud
+//        src/lvio_fusion/src/mapping.cpp:193-220, src/association.cpp:236-247                     -> lvf_cloud_transform
+//   Mapping::BuildMapFrame / BuildOldMapFrame  `points_merged += pointclouds[t]`  mapping.cpp:78-137 -> lvf_cloud_concat
+//   pcl::VoxelGrid<PointI> (leaf 2 x resolution)              association.cpp:210-215,222-224       -> lvf_cloud_voxel_filter
+//   pcl::RadiusOutlierRemoval<PointI> (r = 4 x resolution, min 4)  association.cpp:217-221          -> lvf_cloud_radius_outlier_filter
+//   FeatureAssociation::SegmentGround: pcl::SACSegmentation(SACMODEL_PLANE, SAC_RANSAC, 100 its, thr 0.1 x resolution,
+//        optimize coefficients) + ExtractIndices               association.cpp:249-268               -> lvf_cloud_segment_plane
+// All HBM-streaming or small-grid work: one thread per point, counting sorts, prefix-sum compaction.
+//
+// DECLARED upstream semantics (PCL is un-vendored; restated in oracle/cloud.h):
+//   VoxelGrid: inverse_leaf = 1/leaf (float); min_b = floor(min * inverse_leaf), div_b = max_b - min_b + 1; a point's voxel
+//     is ijk = floor(p * inverse_leaf) - min_b, idx = i + j div_x + k div_x div_y; output = per-voxel centroid of ALL fields
+//     (x, y, z, intensity), voxels in ascending idx.  PCL accumulates the centroid in float in the order its (unstable)
+//     std::sort leaves the points; here sums are double atomics (order-independent to ~1e-16) rounded once to float.
+//   RadiusOutlierRemoval: keep a point iff (number of points with squared distance < r^2, itself included) > min_neighbors;
+//     input order preserved.
+//   SACSegmentation/RANSAC: hypothesis = plane through 3 distinct sampled points; inliers |n.p + d| < thr; best = most
+//     inliers (first wins ties); PCL's adaptive stop k = log(1 - 0.99) / log(1 - w^3) is applied in hypothesis order; then
+//     the plane is re-fitted to the inliers (centroid + smallest eigenvector of the covariance) and the inliers re-selected.
+//     PCL draws samples from boost::mt19937(12345) through its own shuffling; that stream cannot be reproduced without PCL,
+//     so sampling uses a documented counter-based generator (splitmix64 of (seed, hypothesis, draw)).
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+#include "lvf_internal.hpp"
+
+#pragma clang fp contract(off)   // the float SE3 transform must round after every multiply and add (bit-exact with the oracle)
+
+namespace lvf {
+
+constexpr int kC = 256;
+static inline int gridc(int n) { return (std::max(n, 1) + kC - 1) / kC; }
+
+// ---------------------------------------------------------------------------------------------- pack / transform / concat
+__global__ __launch_bounds__(kC) void k_cloud_pack(int n, const float* __restrict__ src, int stride, int ioff, float4* __restrict__ dst) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  if (i >= n) return;
+  const float* s = src + (size_t)i * stride;
+  dst[i] = make_float4(s[0], s[1], s[2], ioff >= 0 ? s[ioff] : 0.0f);
+}
+
+struct Tf32c { float a[9]; float t[3]; };
+// float instantiation of ceres::QuaternionRotatePoint (1.x): normalise, then the expanded polynomial — same sequence of
+// rounded operations as knn_kernels.hip::make_tf32 and oracle/knn.h::transform_query_f32
+__device__ __forceinline__ Tf32c make_tf(const float tf[7]) {
+  const float q0 = tf[3], q1 = tf[0], q2 = tf[1], q3 = tf[2];
+  const float ss = ((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3;
+  const float scale = 1.0f / __builtin_sqrtf(ss);
+  const float u0 = scale * q0, u1 = scale * q1, u2 = scale * q2, u3 = scale * q3;
+  const float t2 = u0 * u1, t3 = u0 * u2, t4 = u0 * u3, t5 = -u1 * u1, t6 = u1 * u2, t7 = u1 * u3, t8 = -u2 * u2, t9 = u2 * u3, t1 = -u3 * u3;
+  Tf32c T;
+  T.a[0] = t8 + t1; T.a[1] = t6 - t4; T.a[2] = t3 + t7;
+  T.a[3] = t4 + t6; T.a[4] = t5 + t1; T.a[5] = t9 - t2;
+  T.a[6] = t7 - t3; T.a[7] = t2 + t9; T.a[8] = t5 + t8;
+  T.t[0] = tf[4]; T.t[1] = tf[5]; T.t[2] = tf[6];
+  return T;
+}
+struct TfArgC { float v[7]; };
+__global__ __launch_bounds__(kC) void k_cloud_transform(int n, const float4* __restrict__ in, TfArgC tfa, float4* __restrict__ out) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  if (i >= n) return;
+  const Tf32c T = make_tf(tfa.v);
+  const float4 p = in[i];
+  float4 o;
+  o.x = (2.0f * ((T.a[0] * p.x + T.a[1] * p.y) + T.a[2] * p.z) + p.x) + T.t[0];
+  o.y = (2.0f * ((T.a[3] * p.x + T.a[4] * p.y) + T.a[5] * p.z) + p.y) + T.t[1];
+  o.z = (2.0f * ((T.a[6] * p.x + T.a[7] * p.y) + T.a[8] * p.z) + p.z) + T.t[2];
+  o.w = p.w;                                   // intensity rides along (mapping.cpp:201)
+  out[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------- bounds
+__device__ __forceinline__ unsigned f2ord_c(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+static inline float ord2f_c(unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &u, 4); return f; }
+__global__ __launch_bounds__(kC) void k_cloud_bounds(int n, const float4* __restrict__ pts, unsigned* __restrict__ bounds) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  float x = INFINITY, y = INFINITY, z = INFINITY, X = -INFINITY, Y = -INFINITY, Z = -INFINITY;
+  if (i < n) { const float4 p = pts[i]; x = X = p.x; y = Y = p.y; z = Z = p.z; }
+  for (int o = 32; o > 0; o >>= 1) {
+    x = fminf(x, __shfl_down(x, o)); y = fminf(y, __shfl_down(y, o)); z = fminf(z, __shfl_down(z, o));
+    X = fmaxf(X, __shfl_down(X, o)); Y = fmaxf(Y, __shfl_down(Y, o)); Z = fmaxf(Z, __shfl_down(Z, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(bounds + 0, f2ord_c(x)); atomicMin(bounds + 1, f2ord_c(y)); atomicMin(bounds + 2, f2ord_c(z));
+    atomicMax(bounds + 3, f2ord_c(X)); atomicMax(bounds + 4, f2ord_c(Y)); atomicMax(bounds + 5, f2ord_c(Z));
+  }
+}
+static int cloud_bounds(const lvf_cloud* c, float lo[3], float hi[3]) {
+  DevBuf<unsigned> b;
+  LVF_TRY(b.alloc(6));
+  const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  hipStream_t s = c->ctx->stream;
+  LVF_HIP(hipMemcpyAsync(b.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_cloud_bounds, dim3(gridc(c->n)), dim3(kC), 0, s, c->n, c->pts.p, b.p);
+  unsigned h[6];
+  LVF_HIP(hipMemcpyAsync(h, b.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  for (int k = 0; k < 3; ++k) { lo[k] = ord2f_c(h[k]); hi[k] = ord2f_c(h[3 + k]); }
+  for (int k = 0; k < 3; ++k)
+    if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) { set_error("cloud has non-finite coordinates"); return LVF_ERR_INVALID; }
+  return LVF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- voxel grid
+struct VoxP { float inv_leaf; int minb[3]; int div[3]; };
+__device__ __forceinline__ int voxel_of(const float4 p, const VoxP v) {
+  const int i = (int)(floorf(p.x * v.inv_leaf) - (float)v.minb[0]);
+  const int j = (int)(floorf(p.y * v.inv_leaf) - (float)v.minb[1]);
+  const int k = (int)(floorf(p.z * v.inv_leaf) - (float)v.minb[2]);
+  return i + j * v.div[0] + k * v.div[0] * v.div[1];
+}
+__global__ __launch_bounds__(kC) void k_voxel_accumulate(int n, const float4* __restrict__ pts, VoxP v, double* __restrict__ sums /* [ncell][4] */,
+                                                         int* __restrict__ counts) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  const int c = voxel_of(p, v);
+  double* s = sums + 4 * (size_t)c;
+  atomicAdd(s + 0, (double)p.x); atomicAdd(s + 1, (double)p.y); atomicAdd(s + 2, (double)p.z); atomicAdd(s + 3, (double)p.w);
+  atomicAdd(counts + c, 1);
+}
+__global__ __launch_bounds__(kC) void k_flag_nonzero(int n, const int* __restrict__ counts, int* __restrict__ flags) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  if (i < n) flags[i] = counts[i] > 0 ? 1 : 0;
+}
+__global__ __launch_bounds__(kC) void k_voxel_emit(int ncell, const double* __restrict__ sums, const int* __restrict__ counts, const int* __restrict__ pos,
+                                                   float4* __restrict__ out) {
+  const int c = blockIdx.x * kC + threadIdx.x;
+  if (c >= ncell) return;
+  const int k = counts[c];
+  if (k == 0) return;
+  const double inv = 1.0 / (double)k;
+  const double* s = sums + 4 * (size_t)c;
+  out[pos[c]] = make_float4((float)(s[0] * inv), (float)(s[1] * inv), (float)(s[2] * inv), (float)(s[3] * inv));
+}
+
+// ---------------------------------------------------------------------------------------------- uniform grid (cell-sorted copy)
+struct GridC { float ox, oy, oz, inv_cell; int nx, ny, nz; };
+__device__ __forceinline__ int gcoord(float v, float o, float inv_cell, int n) {
+  int c = (int)floorf((v - o) * inv_cell);
+  return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+__global__ __launch_bounds__(kC) void k_grid_count(int n, const float4* __restrict__ pts, GridC g, int* __restrict__ cell_of, int* __restrict__ counts) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  const int c = (gcoord(p.z, g.oz, g.inv_cell, g.nz) * g.ny + gcoord(p.y, g.oy, g.inv_cell, g.ny)) * g.nx + gcoord(p.x, g.ox, g.inv_cell, g.nx);
+  cell_of[i] = c;
+  atomicAdd(counts + c, 1);
+}
+__global__ __launch_bounds__(kC) void k_grid_scatter(int n, const float4* __restrict__ pts, const int* __restrict__ cell_of, const int* __restrict__ cell_start,
+                                                     int* __restrict__ cursor, float4* __restrict__ sorted) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  if (i >= n) return;
+  const int c = cell_of[i];
+  sorted[cell_start[c] + atomicAdd(cursor + c, 1)] = pts[i];
+}
+// neighbours within radius (squared distance < r2, the point itself included); cell size >= radius => 27 cells.
+// The count does not depend on the order points sit inside a cell, so the atomic scatter above is harmless.
+__global__ __launch_bounds__(kC) void k_radius_count(int n, const float4* __restrict__ pts, GridC g, const int* __restrict__ cell_start,
+                                                     const float4* __restrict__ sorted, float r2, int min_neighbors, int* __restrict__ flags) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  const int cx = gcoord(p.x, g.ox, g.inv_cell, g.nx), cy = gcoord(p.y, g.oy, g.inv_cell, g.ny), cz = gcoord(p.z, g.oz, g.inv_cell, g.nz);
+  int cnt = 0;
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int z = cz + dz;
+    if (z < 0 || z >= g.nz) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int y = cy + dy;
+      if (y < 0 || y >= g.ny) continue;
+      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+      const int row = (z * g.ny + y) * g.nx;
+      const int lo = cell_start[row + x0], hi = cell_start[row + x1 + 1];   // x-adjacent cells are contiguous
+      for (int j = lo; j < hi; ++j) {
+        const float4 q = sorted[j];
+        const float dx = p.x - q.x, dyy = p.y - q.y, dzz = p.z - q.z;
+        const float d = (dx * dx + dyy * dyy) + dzz * dzz;
+        cnt += d < r2 ? 1 : 0;
+      }
+    }
+  }
+  flags[i] = cnt > min_neighbors ? 1 : 0;
+}
+__global__ __launch_bounds__(kC) void k_compact(int n, const float4* __restrict__ pts, const int* __restrict__ flags, const int* __restrict__ pos,
+                                                float4* __restrict__ out) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  if (i < n && flags[i]) out[pos[i]] = pts[i];
+}
+
+// ---------------------------------------------------------------------------------------------- RANSAC plane
+__host__ __device__ inline unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// three distinct indices for hypothesis h (identical on host, device and in the oracle)
+__host__ __device__ inline void sample3(unsigned long long seed, int h, int n, int idx[3]) {
+  int got = 0;
+  for (unsigned draw = 0; got < 3; ++draw) {
+    const int v = (int)(splitmix64(seed ^ ((unsigned long long)h << 32) ^ draw) % (unsigned long long)n);
+    bool dup = false;
+    for (int k = 0; k < got; ++k) dup |= idx[k] == v;
+    if (!dup) idx[got++] = v;
+  }
+}
+// SampleConsensusModelPlane::computeModelCoefficients: n = (p1 - p0) x (p2 - p0) normalised, d = -n.p0 (float)
+__device__ __forceinline__ bool plane_from3(const float4 a, const float4 b, const float4 c, float co[4]) {
+  const float ux = b.x - a.x, uy = b.y - a.y, uz = b.z - a.z, vx = c.x - a.x, vy = c.y - a.y, vz = c.z - a.z;
+  float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+  const float nn = (nx * nx + ny * ny) + nz * nz;
+  if (!(nn > 0.0f)) return false;              // collinear sample
+  const float s = 1.0f / __builtin_sqrtf(nn);
+  nx *= s; ny *= s; nz *= s;
+  co[0] = nx; co[1] = ny; co[2] = nz; co[3] = -((nx * a.x + ny * a.y) + nz * a.z);
+  return true;
+}
+__global__ __launch_bounds__(kC) void k_ransac_count(int n, const float4* __restrict__ pts, unsigned long long seed, float thr, int* __restrict__ counts) {
+  __shared__ float co[4];
+  __shared__ int ok;
+  const int h = blockIdx.y;
+  if (threadIdx.x == 0) {
+    int id[3];
+    sample3(seed, h, n, id);
+    float c4[4] = {0, 0, 0, 0};
+    ok = plane_from3(pts[id[0]], pts[id[1]], pts[id[2]], c4) ? 1 : 0;
+    co[0] = c4[0]; co[1] = c4[1]; co[2] = c4[2]; co[3] = c4[3];
+  }
+  __syncthreads();
+  if (!ok) return;                              // counts[h] stays 0: a degenerate sample never wins
+  int cnt = 0;
+  for (int i = blockIdx.x * kC + threadIdx.x; i < n; i += gridDim.x * kC) {
+    const float4 p = pts[i];
+    const float d = ((co[0] * p.x + co[1] * p.y) + co[2] * p.z) + co[3];
+    cnt += fabsf(d) < thr ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(counts + h, cnt);
+}
+// inliers of plane `co`: flags, and (optionally) first and second moments in double for the least-squares refit
+__global__ __launch_bounds__(kC) void k_plane_inliers(int n, const float4* __restrict__ pts, float c0, float c1, float c2, float c3, float thr,
+                                                      int* __restrict__ flags, double* __restrict__ mom /* n, sx,sy,sz, xx,xy,xz,yy,yz,zz */) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (i < n) {
+    const float4 p = pts[i];
+    const float d = ((c0 * p.x + c1 * p.y) + c2 * p.z) + c3;
+    const int in = fabsf(d) < thr ? 1 : 0;
+    flags[i] = in;
+    if (in && mom) {
+      const double x = p.x, y = p.y, z = p.z;
+      v[0] = 1; v[1] = x; v[2] = y; v[3] = z; v[4] = x * x; v[5] = x * y; v[6] = x * z; v[7] = y * y; v[8] = y * z; v[9] = z * z;
+    }
+  }
+  if (mom) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      double s = v[k];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+      if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(mom + k, s);
+    }
+  }
+}
+
+// smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi, host; the reference calls pcl::eigen33 here)
+static void smallest_eigvec3(const double A_in[9], double v[3]) {
+  double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int k = 0; k < 9; ++k) A[k] = A_in[k];
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = A[3 * p + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        const double theta = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) { const double akp = A[3 * k + p], akq = A[3 * k + q]; A[3 * k + p] = c * akp - s * akq; A[3 * k + q] = s * akp + c * akq; }
+        for (int k = 0; k < 3; ++k) { const double apk = A[3 * p + k], aqk = A[3 * q + k]; A[3 * p + k] = c * apk - s * aqk; A[3 * q + k] = s * apk + c * aqk; }
+        for (int k = 0; k < 3; ++k) { const double vkp = V[3 * k + p], vkq = V[3 * k + q]; V[3 * k + p] = c * vkp - s * vkq; V[3 * k + q] = s * vkp + c * vkq; }
+      }
+  }
+  int m = 0;
+  for (int k = 1; k < 3; ++k) if (A[4 * k] < A[4 * m]) m = k;
+  for (int k = 0; k < 3; ++k) v[k] = V[3 * k + m];
+}
+
+static int new_cloud(lvf_ctx* ctx, int n, lvf_cloud** out) {
+  auto* c = new lvf_cloud();
+  c->ctx = ctx; c->n = n;
+  const int rc = c->pts.alloc(std::max(n, 0));
+  if (rc != LVF_OK) { delete c; return rc; }
+  *out = c;
+  return LVF_OK;
+}
+// out = the flagged points of `in`, input order preserved
+static int compact_cloud(const lvf_cloud* in, const int* flags_dev, lvf_cloud** out) {
+  lvf_ctx* ctx = in->ctx;
+  hipStream_t s = ctx->stream;
+  DevBuf<int> pos;
+  LVF_TRY(pos.alloc((size_t)in->n + 1));
+  LVF_TRY(device_exclusive_scan_i32(ctx, flags_dev, in->n, pos.p));
+  int total = 0;
+  LVF_HIP(hipMemcpyAsync(&total, pos.p + in->n, sizeof(int), hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  LVF_TRY(new_cloud(ctx, total, out));
+  if (total) hipLaunchKernelGGL(k_compact, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, flags_dev, pos.p, (*out)->pts.p);
+  LVF_HIP(hipGetLastError());
+  LVF_HIP(hipStreamSynchronize(s));
+  return LVF_OK;
+}
+
+}  // namespace lvf
+
+using namespace lvf;
+
+extern "C" {
+
+int lvf_cloud_create(lvf_ctx* ctx, const float* points, int n, int stride_floats, int intensity_offset, lvf_cloud** out) {
+  LVF_REQUIRE(ctx && out, "lvf_cloud_create: null ctx/out");
+  LVF_REQUIRE(n >= 0 && (n == 0 || points) && stride_floats >= 3 && intensity_offset < stride_floats, "lvf_cloud_create: bad cloud (n=%d stride=%d ioff=%d)", n,
+              stride_floats, intensity_offset);
+  LVF_HIP(hipSetDevice(ctx->device));
+  lvf_cloud* c = nullptr;
+  LVF_TRY(new_cloud(ctx, n, &c));
+  if (n) {
+    DevBuf<float> src;
+    int rc = src.upload(points, (size_t)n * stride_floats, ctx->stream);
+    if (rc != LVF_OK) { delete c; return rc; }
+    hipLaunchKernelGGL(k_cloud_pack, dim3(gridc(n)), dim3(kC), 0, ctx->stream, n, src.p, stride_floats, intensity_offset, c->pts.p);
+    LVF_HIP(hipGetLastError());
+    LVF_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  *out = c;
+  return LVF_OK;
+}
+int lvf_cloud_destroy(lvf_cloud* c) { delete c; return LVF_OK; }
+int lvf_cloud_size(const lvf_cloud* c) { return c ? c->n : -1; }
+int lvf_cloud_download(const lvf_cloud* c, float* xyzi) {
+  LVF_REQUIRE(c && (c->n == 0 || xyzi), "lvf_cloud_download: null argument");
+  if (c->n) LVF_HIP(hipMemcpyAsync(xyzi, c->pts.p, (size_t)c->n * sizeof(float4), hipMemcpyDeviceToHost, c->ctx->stream));
+  LVF_HIP(hipStreamSynchronize(c->ctx->stream));
+  return LVF_OK;
+}
+
+int lvf_cloud_transform(const lvf_cloud* in, const double* pose, lvf_cloud** out) {
+  LVF_REQUIRE(in && pose && out, "lvf_cloud_transform: null argument");
+  LVF_HIP(hipSetDevice(in->ctx->device));
+  lvf_cloud* c = nullptr;
+  LVF_TRY(new_cloud(in->ctx, in->n, &c));
+  TfArgC tf;
+  for (int k = 0; k < 7; ++k) tf.v[k] = (float)pose[k];          // Sophus SE3d::cast<float>()  mapping.cpp:195
+  if (in->n) hipLaunchKernelGGL(k_cloud_transform, dim3(gridc(in->n)), dim3(kC), 0, in->ctx->stream, in->n, in->pts.p, tf, c->pts.p);
+  LVF_HIP(hipGetLastError());
+  *out = c;
+  return LVF_OK;
+}
+
+int lvf_cloud_concat(lvf_ctx* ctx, const lvf_cloud* const* parts, int n_parts, lvf_cloud** out) {
+  LVF_REQUIRE(ctx && out && n_parts >= 0 && (n_parts == 0 || parts), "lvf_cloud_concat: bad argument");
+  long long total = 0;
+  for (int k = 0; k < n_parts; ++k) { LVF_REQUIRE(parts[k] && parts[k]->ctx == ctx, "lvf_cloud_concat: part %d is null or of another context", k); total += parts[k]->n; }
+  LVF_REQUIRE(total < (1ll << 31), "lvf_cloud_concat: too many points");
+  LVF_HIP(hipSetDevice(ctx->device));
+  lvf_cloud* c = nullptr;
+  LVF_TRY(new_cloud(ctx, (int)total, &c));
+  size_t off = 0;
+  for (int k = 0; k < n_parts; ++k) {
+    if (parts[k]->n) LVF_HIP(hipMemcpyAsync(c->pts.p + off, parts[k]->pts.p, (size_t)parts[k]->n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    off += parts[k]->n;
+  }
+  *out = c;
+  return LVF_OK;
+}
+
+int lvf_cloud_voxel_filter(const lvf_cloud* in, float leaf, lvf_cloud** out) {
+  LVF_REQUIRE(in && out, "lvf_cloud_voxel_filter: null argument");
+  LVF_REQUIRE(leaf > 0.0f && std::isfinite(leaf), "lvf_cloud_voxel_filter: leaf must be finite > 0");
+  lvf_ctx* ctx = in->ctx;
+  LVF_HIP(hipSetDevice(ctx->device));
+  if (in->n == 0) return new_cloud(ctx, 0, out);
+  hipStream_t s = ctx->stream;
+  float lo[3], hi[3];
+  LVF_TRY(cloud_bounds(in, lo, hi));
+  VoxP v;
+  v.inv_leaf = 1.0f / leaf;
+  long long ncell = 1;
+  for (int k = 0; k < 3; ++k) {
+    v.minb[k] = (int)std::floor(lo[k] * v.inv_leaf);
+    const int maxb = (int)std::floor(hi[k] * v.inv_leaf);
+    v.div[k] = maxb - v.minb[k] + 1;
+    ncell *= v.div[k];
+  }
+  // PCL refuses such grids too ("Leaf size is too small for the input dataset. Integer indices would overflow.")
+  LVF_REQUIRE(ncell > 0 && ncell <= (1ll << 26), "lvf_cloud_voxel_filter: %lld voxels: leaf size too small for the cloud's extent", ncell);
+  DevBuf<double> sums; DevBuf<int> counts, flags, pos;
+  LVF_TRY(sums.alloc((size_t)4 * ncell)); LVF_TRY(counts.alloc(ncell)); LVF_TRY(flags.alloc(ncell)); LVF_TRY(pos.alloc((size_t)ncell + 1));
+  LVF_HIP(hipMemsetAsync(sums.p, 0, (size_t)32 * ncell, s));
+  LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)4 * ncell, s));
+  hipLaunchKernelGGL(k_voxel_accumulate, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, v, sums.p, counts.p);
+  hipLaunchKernelGGL(k_flag_nonzero, dim3(gridc((int)ncell)), dim3(kC), 0, s, (int)ncell, counts.p, flags.p);
+  LVF_HIP(hipGetLastError());
+  LVF_TRY(device_exclusive_scan_i32(ctx, flags.p, (int)ncell, pos.p));
+  int total = 0;
+  LVF_HIP(hipMemcpyAsync(&total, pos.p + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  lvf_cloud* c = nullptr;
+  LVF_TRY(new_cloud(ctx, total, &c));
+  hipLaunchKernelGGL(k_voxel_emit, dim3(gridc((int)ncell)), dim3(kC), 0, s, (int)ncell, sums.p, counts.p, pos.p, c->pts.p);
+  LVF_HIP(hipGetLastError());
+  LVF_HIP(hipStreamSynchronize(s));
+  *out = c;
+  return LVF_OK;
+}
+
+int lvf_cloud_radius_outlier_filter(const lvf_cloud* in, float radius, int min_neighbors, lvf_cloud** out) {
+  LVF_REQUIRE(in && out, "lvf_cloud_radius_outlier_filter: null argument");
+  LVF_REQUIRE(radius > 0.0f && std::isfinite(radius) && min_neighbors >= 0, "lvf_cloud_radius_outlier_filter: bad radius / min_neighbors");
+  lvf_ctx* ctx = in->ctx;
+  LVF_HIP(hipSetDevice(ctx->device));
+  if (in->n == 0) return new_cloud(ctx, 0, out);
+  hipStream_t s = ctx->stream;
+  float lo[3], hi[3];
+  LVF_TRY(cloud_bounds(in, lo, hi));
+  float cell = radius * 1.0001f;               // strictly larger than the radius: the 27-cell stencil is exhaustive
+  auto dims = [&](float c, int d[3]) { long long t = 1; for (int k = 0; k < 3; ++k) { d[k] = (int)std::floor((hi[k] - lo[k]) / c) + 1; t *= d[k]; } return t; };
+  int d[3];
+  while (dims(cell, d) > (1ll << 25)) cell *= 1.5f;   // bigger cells stay correct, only slower
+  const int ncell = d[0] * d[1] * d[2];
+  const GridC g{lo[0], lo[1], lo[2], 1.0f / cell, d[0], d[1], d[2]};
+  DevBuf<int> cell_of, counts, cursor, start, flags;
+  DevBuf<float4> sorted;
+  LVF_TRY(cell_of.alloc(in->n)); LVF_TRY(counts.alloc(ncell)); LVF_TRY(cursor.alloc(ncell)); LVF_TRY(start.alloc((size_t)ncell + 1));
+  LVF_TRY(flags.alloc(in->n)); LVF_TRY(sorted.alloc(in->n));
+  LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)4 * ncell, s));
+  LVF_HIP(hipMemsetAsync(cursor.p, 0, (size_t)4 * ncell, s));
+  hipLaunchKernelGGL(k_grid_count, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, g, cell_of.p, counts.p);
+  LVF_HIP(hipGetLastError());
+  LVF_TRY(device_exclusive_scan_i32(ctx, counts.p, ncell, start.p));
+  hipLaunchKernelGGL(k_grid_scatter, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, cell_of.p, start.p, cursor.p, sorted.p);
+  hipLaunchKernelGGL(k_radius_count, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, g, start.p, sorted.p, radius * radius, min_neighbors, flags.p);
+  LVF_HIP(hipGetLastError());
+  return compact_cloud(in, flags.p, out);
+}
+
+int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int max_iterations, uint64_t seed, lvf_cloud** out, double* coefficients4,
+                            int* iterations_used) {
+  LVF_REQUIRE(in && out, "lvf_cloud_segment_plane: null argument");
+  LVF_REQUIRE(distance_threshold > 0.0f && max_iterations > 0 && max_iterations <= 4096, "lvf_cloud_segment_plane: bad threshold / iteration count");
+  lvf_ctx* ctx = in->ctx;
+  LVF_HIP(hipSetDevice(ctx->device));
+  if (coefficients4) for (int k = 0; k < 4; ++k) coefficients4[k] = 0.0;
+  if (iterations_used) *iterations_used = 0;
+  if (in->n < 3) return new_cloud(ctx, 0, out);          // SACSegmentation cannot fit a model: no inliers
+  hipStream_t s = ctx->stream;
+  const int n = in->n;
+  DevBuf<int> counts, flags; DevBuf<double> mom;
+  LVF_TRY(counts.alloc(max_iterations)); LVF_TRY(flags.alloc(n)); LVF_TRY(mom.alloc(10));
+  LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)4 * max_iterations, s));
+  const int gx = std::min(gridc(n), 64);
+  hipLaunchKernelGGL(k_ransac_count, dim3(gx, max_iterations), dim3(kC), 0, s, n, in->pts.p, (unsigned long long)seed, distance_threshold, counts.p);
+  LVF_HIP(hipGetLastError());
+  std::vector<int> hc(max_iterations);
+  LVF_HIP(hipMemcpyAsync(hc.data(), counts.p, (size_t)4 * max_iterations, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  // pcl::RandomSampleConsensus::computeModel's bookkeeping, applied in hypothesis order
+  int best = -1, best_count = 0, used = 0;
+  double k = 1.0;
+  const double log_probability = std::log(1.0 - 0.99);
+  for (int h = 0; h < max_iterations && (double)h < k; ++h) {
+    used = h + 1;
+    if (hc[h] > best_count) {
+      best_count = hc[h]; best = h;
+      const double w = (double)best_count / (double)n;
+      double p_no_outliers = 1.0 - w * w * w;
+      p_no_outliers = std::max(std::numeric_limits<double>::epsilon(), p_no_outliers);
+      p_no_outliers = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no_outliers);
+      k = log_probability / std::log(p_no_outliers);
+    }
+  }
+  if (iterations_used) *iterations_used = used;
+  if (best < 0) return new_cloud(ctx, 0, out);
+  // recompute the winning plane on the host from its three sample points (same float arithmetic as the device)
+  int id[3];
+  sample3(seed, best, n, id);
+  float4 sp[3];
+  for (int q = 0; q < 3; ++q) LVF_HIP(hipMemcpyAsync(&sp[q], in->pts.p + id[q], sizeof(float4), hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  float co[4];
+  {
+    const float ux = sp[1].x - sp[0].x, uy = sp[1].y - sp[0].y, uz = sp[1].z - sp[0].z, vx = sp[2].x - sp[0].x, vy = sp[2].y - sp[0].y, vz = sp[2].z - sp[0].z;
+    float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+    const float inv = 1.0f / std::sqrt((nx * nx + ny * ny) + nz * nz);
+    nx *= inv; ny *= inv; nz *= inv;
+    co[0] = nx; co[1] = ny; co[2] = nz; co[3] = -((nx * sp[0].x + ny * sp[0].y) + nz * sp[0].z);
+  }
+  // optimizeModelCoefficients: least-squares plane through the inliers, then re-select (SACSegmentation::segment)
+  LVF_HIP(hipMemsetAsync(mom.p, 0, 80, s));
+  hipLaunchKernelGGL(k_plane_inliers, dim3(gridc(n)), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, mom.p);
+  LVF_HIP(hipGetLastError());
+  double m[10];
+  LVF_HIP(hipMemcpyAsync(m, mom.p, sizeof(m), hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  if (m[0] >= 3.0) {
+    const double inv = 1.0 / m[0], cx = m[1] * inv, cy = m[2] * inv, cz = m[3] * inv;
+    const double C[9] = {m[4] * inv - cx * cx, m[5] * inv - cx * cy, m[6] * inv - cx * cz, m[5] * inv - cx * cy, m[7] * inv - cy * cy, m[8] * inv - cy * cz,
+                         m[6] * inv - cx * cz, m[8] * inv - cy * cz, m[9] * inv - cz * cz};
+    double nv[3];
+    smallest_eigvec3(C, nv);
+    if (nv[2] < 0.0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }       // fixed orientation (inlier selection is sign-free)
+    co[0] = (float)nv[0]; co[1] = (float)nv[1]; co[2] = (float)nv[2]; co[3] = (float)(-(nv[0] * cx + nv[1] * cy + nv[2] * cz));
+    hipLaunchKernelGGL(k_plane_inliers, dim3(gridc(n)), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, (double*)nullptr);
+    LVF_HIP(hipGetLastError());
+  }
+  if (coefficients4) for (int q = 0; q < 4; ++q) coefficients4[q] = co[q];
+  return compact_cloud(in, flags.p, out);
+}
+
+}  // extern "C"

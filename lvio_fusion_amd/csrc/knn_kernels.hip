@@ -366,6 +366,21 @@ __global__ __launch_bounds__(kB) void k_knn3(int Q, const float4* __restrict__ s
   }
 }
 
+// exclusive prefix sum of n ints on the context's stream; out has n + 1 entries (out[n] = grand total).  in != out.
+int device_exclusive_scan_i32(lvf_ctx* ctx, const int* in, int n, int* out) {
+  hipStream_t s = ctx->stream;
+  if (n <= 0) { LVF_HIP(hipMemsetAsync(out, 0, sizeof(int), s)); return LVF_OK; }
+  const int nb = (n + kScanChunk - 1) / kScanChunk;
+  DevBuf<int> bsums;
+  LVF_TRY(bsums.alloc(nb));
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanT), 0, s, n, in, bsums.p);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, out + n);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, n, in, bsums.p, out);
+  LVF_HIP(hipGetLastError());
+  LVF_HIP(hipStreamSynchronize(s));   // bsums is freed on return
+  return LVF_OK;
+}
+
 }  // namespace lvf
 
 using namespace lvf;
@@ -407,7 +422,8 @@ static int build_level(lvf_map* m, lvf_map::Level& lv, float cell, const float l
   return LVF_OK;
 }
 
-int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats, float max_radius2, lvf_map** out) {
+// src_is_device: map_xyz already lives in HBM (a lvf_cloud): no upload
+static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_device, int M, int stride_floats, float max_radius2, lvf_map** out) {
   LVF_REQUIRE(ctx && out, "lvf_map_create: null ctx/out");
   LVF_REQUIRE(M >= 0 && (M == 0 || map_xyz) && stride_floats >= 3, "lvf_map_create: bad cloud (M=%d stride=%d)", M, stride_floats);
   LVF_REQUIRE(max_radius2 > 0.0f && std::isfinite(max_radius2), "lvf_map_create: max_radius2 must be finite > 0");
@@ -428,11 +444,11 @@ int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats,
     return LVF_OK;
   }
   DevBuf<float> src; DevBuf<unsigned> bounds;
-  if ((rc = src.upload(map_xyz, (size_t)M * stride_floats, s)) != LVF_OK) return fail(rc);
+  if (!src_is_device && (rc = src.upload(map_xyz, (size_t)M * stride_floats, s)) != LVF_OK) return fail(rc);
   if ((rc = m->raw.alloc(M)) != LVF_OK || (rc = bounds.alloc(6)) != LVF_OK) return fail(rc);
   const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   LVF_HIP(hipMemcpyAsync(bounds.p, init, sizeof(init), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_pack_bounds, dim3((M + kB - 1) / kB), dim3(kB), 0, s, M, src.p, stride_floats, m->raw.p, bounds.p);
+  hipLaunchKernelGGL(k_pack_bounds, dim3((M + kB - 1) / kB), dim3(kB), 0, s, M, src_is_device ? map_xyz : src.p, stride_floats, m->raw.p, bounds.p);
   unsigned hb[6];
   LVF_HIP(hipMemcpyAsync(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost, s));
   LVF_HIP(hipStreamSynchronize(s));
@@ -465,9 +481,17 @@ int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats,
   return LVF_OK;
 }
 
+int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats, float max_radius2, lvf_map** out) {
+  return map_create_impl(ctx, map_xyz, false, M, stride_floats, max_radius2, out);
+}
+int lvf_map_create_from_cloud(const lvf_cloud* c, float max_radius2, lvf_map** out) {
+  LVF_REQUIRE(c, "lvf_map_create_from_cloud: null cloud");
+  return map_create_impl(c->ctx, reinterpret_cast<const float*>(c->pts.p), true, c->n, 4, max_radius2, out);
+}
+
 int lvf_map_destroy(lvf_map* m) { delete m; return LVF_OK; }
 
-int lvf_scan_create(lvf_ctx* ctx, const float* scan_xyz, int Q, int stride_floats, lvf_scan** out) {
+static int scan_create_impl(lvf_ctx* ctx, const float* scan_xyz, bool src_is_device, int Q, int stride_floats, lvf_scan** out) {
   LVF_REQUIRE(ctx && out, "lvf_scan_create: null ctx/out");
   LVF_REQUIRE(Q >= 0 && (Q == 0 || scan_xyz) && stride_floats >= 3, "lvf_scan_create: bad cloud (Q=%d stride=%d)", Q, stride_floats);
   LVF_HIP(hipSetDevice(ctx->device));
@@ -476,16 +500,23 @@ int lvf_scan_create(lvf_ctx* ctx, const float* scan_xyz, int Q, int stride_float
   int rc = LVF_OK;
   DevBuf<float> src;
   if (Q > 0) {
-    if ((rc = src.upload(scan_xyz, (size_t)Q * stride_floats, ctx->stream)) != LVF_OK || (rc = sc->pts.alloc(Q)) != LVF_OK ||
+    if ((!src_is_device && (rc = src.upload(scan_xyz, (size_t)Q * stride_floats, ctx->stream)) != LVF_OK) || (rc = sc->pts.alloc(Q)) != LVF_OK ||
         (rc = sc->idx.alloc((size_t)3 * Q)) != LVF_OK || (rc = sc->d2.alloc((size_t)3 * Q)) != LVF_OK || (rc = sc->valid.alloc(Q)) != LVF_OK) {
       delete sc; return rc;
     }
-    hipLaunchKernelGGL(k_pack, dim3((Q + kB - 1) / kB), dim3(kB), 0, ctx->stream, Q, src.p, stride_floats, sc->pts.p);
+    hipLaunchKernelGGL(k_pack, dim3((Q + kB - 1) / kB), dim3(kB), 0, ctx->stream, Q, src_is_device ? scan_xyz : src.p, stride_floats, sc->pts.p);
     LVF_HIP(hipGetLastError());
     LVF_HIP(hipStreamSynchronize(ctx->stream));
   }
   *out = sc;
   return LVF_OK;
+}
+int lvf_scan_create(lvf_ctx* ctx, const float* scan_xyz, int Q, int stride_floats, lvf_scan** out) {
+  return scan_create_impl(ctx, scan_xyz, false, Q, stride_floats, out);
+}
+int lvf_scan_create_from_cloud(const lvf_cloud* c, lvf_scan** out) {
+  LVF_REQUIRE(c, "lvf_scan_create_from_cloud: null cloud");
+  return scan_create_impl(c->ctx, reinterpret_cast<const float*>(c->pts.p), true, c->n, 4, out);
 }
 
 int lvf_scan_destroy(lvf_scan* s) { delete s; return LVF_OK; }

@@ -138,7 +138,14 @@ struct lvf_scan {
   lvf::DevBuf<char> icp_dev;         // device-resident LM state of lvf_icp_solve
 };
 
+struct lvf_cloud {
+  lvf_ctx* ctx = nullptr;
+  int n = 0;
+  lvf::DevBuf<float4> pts;           // x, y, z, intensity  (pcl::PointXYZI payload, 16 B on device)
+};
+
 namespace lvf {
+int device_exclusive_scan_i32(lvf_ctx* ctx, const int* in, int n, int* out);
 // kernels / launchers implemented in the .hip translation units
 int launch_pose_only(lvf_batch* b, const lvf_state* st, bool want_j);
 int launch_two_frame(lvf_batch* b, const lvf_state* st, bool want_j);

@@ -37,7 +37,7 @@ namespace lvf {
 constexpr int kT = 256;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 // device scalar slots
-enum { SC_COST = 0, SC_COST_NEW = 1, SC_MODEL = 2, SC_DXNORM = 3, SC_XNORM = 4, SC_GMAX = 5, SC_N = 8 };
+enum { SC_COST = 0, SC_COST_NEW = 1, SC_MODEL = 2, SC_DXNORM = 3, SC_XNORM = 4, SC_GMAX = 5, SC_N = 8, SC_FAIL = 8 /* int flag */, SC_ALLOC = 9 };
 
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
@@ -60,6 +60,17 @@ __device__ __forceinline__ void add_block66(double* __restrict__ B, int ld, int 
       if (ra == rb && j > i) continue;
       atomicAdd(&B[(size_t)(ra + i) * ld + rb + j], Ja[i] * Jb[j] + Ja[6 + i] * Jb[6 + j]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ housekeeping
+// one launch zeroes every accumulator of a linearisation (B, gc, E, C, gr, scalars) instead of six fill kernels
+struct ZeroList { double* p[6]; unsigned long long n[6]; };
+__global__ __launch_bounds__(kT) void k_zero_multi(ZeroList z) {
+  double* p = z.p[blockIdx.y];
+  const unsigned long long n = z.n[blockIdx.y], n2 = n / 2;
+  double2* p2 = reinterpret_cast<double2*>(p);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * kT + threadIdx.x; i < n2; i += (unsigned long long)gridDim.x * kT) p2[i] = make_double2(0.0, 0.0);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------ TwoCamera
@@ -426,9 +437,27 @@ __global__ __launch_bounds__(kT) void k_cost_sq(int n, const double* __restrict_
 // ------------------------------------------------------------------------------------------------ damping / assembly
 __device__ __forceinline__ double clamp_diag(double v) { return fmin(fmax(v, 1e-6), 1e32); }
 
-// S (lower) = B (lower) + Dc on the diagonal; augmented row d = -gc ; padding rows = identity.
-__global__ __launch_bounds__(kT) void k_prepare_S(int d, int dpad, const double* __restrict__ B, const double* __restrict__ gc,
-                                                  double inv_radius, double* __restrict__ S) {
+// One launch prepares the damped system of a step:
+//   blocks [0, nS_blocks)      : S (lower) = B (lower) + Dc on the diagonal; augmented row d = -gc ; padding rows = identity
+//   blocks [nS_blocks, ...)    : Cd = C + clamp(C)/radius ; E[l][dp] = gr[l] (the extra column that makes the SYRK also
+//                                produce E^T Cd^-1 g_rho)
+//   block 0 / thread 0         : resets the per-step scalars (candidate cost, model change, norms) and the Cholesky fail flag
+__global__ __launch_bounds__(kT) void k_prepare(int d, int dpad, const double* __restrict__ B, const double* __restrict__ gc, double inv_radius,
+                                                double* __restrict__ S, unsigned nS_blocks, int n_lm, int dp, int ldE, const double* __restrict__ C,
+                                                const double* __restrict__ gr, double* __restrict__ Cd, double* __restrict__ E,
+                                                double* __restrict__ scal) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && scal) {
+    for (int k = SC_COST_NEW; k < SC_N; ++k) scal[k] = 0.0;
+    *reinterpret_cast<int*>(scal + SC_FAIL) = 0;
+  }
+  if (blockIdx.x >= nS_blocks) {
+    const int l = (blockIdx.x - nS_blocks) * kT + threadIdx.x;
+    if (l >= n_lm) return;
+    const double c = C[l];
+    Cd[l] = c + clamp_diag(c) * inv_radius;
+    E[(size_t)l * ldE + dp] = gr[l];
+    return;
+  }
   const size_t e = (size_t)blockIdx.x * kT + threadIdx.x;
   if (e >= (size_t)dpad * dpad) return;
   const int i = (int)(e / dpad), j = (int)(e % dpad);
@@ -441,15 +470,6 @@ __global__ __launch_bounds__(kT) void k_prepare_S(int d, int dpad, const double*
     v = 1.0;
   }
   S[e] = v;
-}
-// Cd = C + clamp(C)/radius ; E[l][dp] = gr[l] (the extra column that makes the SYRK also produce E^T Cd^-1 g_rho)
-__global__ __launch_bounds__(kT) void k_prepare_lm(int n_lm, int dp, int ldE, const double* __restrict__ C, const double* __restrict__ gr,
-                                                   double inv_radius, double* __restrict__ Cd, double* __restrict__ E) {
-  const int l = blockIdx.x * kT + threadIdx.x;
-  if (l >= n_lm) return;
-  const double c = C[l];
-  Cd[l] = c + clamp_diag(c) * inv_radius;
-  E[(size_t)l * ldE + dp] = gr[l];
 }
 
 // ------------------------------------------------------------------------------------------------ Schur reduce (MFMA f64)
@@ -703,27 +723,29 @@ __global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE,
   block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM); block_add(x2, scal + SC_XNORM);
 }
 // Model cost change without a pass over H:  (H + D) dx = -g  =>  -dx^T (g + H dx / 2) = 1/2 sum_i dx_i (D_i dx_i - g_i).
-// Camera part here (D_i = clamp(B_ii)/radius), landmark part in k_landmark_back.  SC_MODEL accumulates the NEGATED value
+// Camera part in k_apply_step (D_i = clamp(B_ii)/radius), landmark part in k_landmark_back.  SC_MODEL accumulates the NEGATED value
 // (host flips the sign), keeping the convention model = -SC_MODEL.
-__global__ __launch_bounds__(kT) void k_model_cam(int d, int ld, const double* __restrict__ B, const double* __restrict__ gc,
-                                                  const double* __restrict__ dxc, double inv_radius, double* __restrict__ scal) {
-  const int i = blockIdx.x * kT + threadIdx.x;
-  double m = 0.0, n2 = 0.0, g = 0.0;
-  if (i < d) {
-    const double dx = dxc[i];
-    m = -0.5 * dx * (clamp_diag(B[(size_t)i * ld + i]) * inv_radius * dx - gc[i]);
-    n2 = dx * dx;
-    g = fabs(gc[i]);
-  }
-  block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM);
-  for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_down(g, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX), (unsigned long long)__double_as_longlong(g));
-}
 // x_new = x [+] dx  (EigenQuaternionParameterization::Plus on the quaternion, plain add elsewhere)
+// ... fused with the camera part of the model cost change (k_model_cam's body; d <= 15 n_kf threads of the same grid)
 __global__ __launch_bounds__(kT) void k_apply_step(int n_kf, int n_lm, StateP s, const double* __restrict__ dxc, const double* __restrict__ dxl,
                                                    double* __restrict__ poses2, double* __restrict__ vel2, double* __restrict__ ba2,
-                                                   double* __restrict__ bg2, double* __restrict__ invd2, double* __restrict__ scal) {
+                                                   double* __restrict__ bg2, double* __restrict__ invd2, double* __restrict__ scal, int d, int ld,
+                                                   const double* __restrict__ B, const double* __restrict__ gc, double inv_radius) {
   const int i = blockIdx.x * kT + threadIdx.x;
+  {
+    double m = 0.0, n2 = 0.0, g = 0.0;
+    if (i < d) {
+      const double dx = dxc[i];
+      m = -0.5 * dx * (clamp_diag(B[(size_t)i * ld + i]) * inv_radius * dx - gc[i]);
+      n2 = dx * dx;
+      g = fabs(gc[i]);
+    }
+    if (blockIdx.x * kT < d) {      // block-uniform
+      block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM);
+      for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_down(g, o));
+      if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX), (unsigned long long)__double_as_longlong(g));
+    }
+  }
   double x2 = 0.0;
   if (i < n_kf) {
     const double* p = s.poses + 7 * i; const double* dlt = dxc + 6 * i;
@@ -780,14 +802,14 @@ static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_st
 static int enqueue_linearize(lvf_problem* p, double huber) {
   hipStream_t q = p->ctx->stream;
   const StateP s = state_ptrs(p->st);
-  LVF_HIP(hipMemsetAsync(p->B.p, 0, p->B.n * 8, q));
-  LVF_HIP(hipMemsetAsync(p->gc.p, 0, p->gc.n * 8, q));
-  if (p->n_lm) {
-    LVF_HIP(hipMemsetAsync(p->E.p, 0, p->E.n * 8, q));
-    LVF_HIP(hipMemsetAsync(p->C.p, 0, p->C.n * 8, q));
-    LVF_HIP(hipMemsetAsync(p->gr.p, 0, p->gr.n * 8, q));
+  {
+    ZeroList z;
+    int k = 0;
+    auto add = [&](double* ptr, size_t n) { if (ptr && n) { z.p[k] = ptr; z.n[k] = n; ++k; } };
+    add(p->B.p, p->B.n); add(p->gc.p, p->gc.n); add(p->scal.p, SC_N);
+    if (p->n_lm) { add(p->E.p, p->E.n); add(p->C.p, p->C.n); add(p->gr.p, p->gr.n); }
+    hipLaunchKernelGGL(k_zero_multi, dim3(512, k), dim3(kT), 0, q, z);
   }
-  LVF_HIP(hipMemsetAsync(p->scal.p, 0, SC_N * 8, q));
   double* cost = p->scal.p + SC_COST;
   if (p->tc && p->tc->n)
     hipLaunchKernelGGL(k_lin_tc<false>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
@@ -828,14 +850,14 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   hipStream_t q = p->ctx->stream;
   const double inv_r = 1.0 / radius;
   const size_t nS = (size_t)p->dpad * p->dpad;
-  hipLaunchKernelGGL(k_prepare_S, dim3((unsigned)((nS + kT - 1) / kT)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, inv_r, p->S.p);
+  const unsigned nSb = (unsigned)((nS + kT - 1) / kT);
+  hipLaunchKernelGGL(k_prepare, dim3(nSb + (p->n_lm ? grid(p->n_lm) : 0)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, inv_r, p->S.p, nSb, p->n_lm,
+                     p->dp, p->ldE, p->C.p, p->gr.p, p->Cd.p, p->E.p, p->scal.p);
   if (p->n_lm) {
-    hipLaunchKernelGGL(k_prepare_lm, dim3(grid(p->n_lm)), dim3(kT), 0, q, p->n_lm, p->dp, p->ldE, p->C.p, p->gr.p, inv_r, p->Cd.p, p->E.p);
     const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
     hipLaunchKernelGGL(k_schur_syrk, dim3(ntile, (p->n_lm + kSchurChunk - 1) / kSchurChunk), dim3(64), 0, q, p->n_lm, p->dp, p->ldE, ntile, p->E.p,
                        p->Cd.p, p->d, p->dpad, p->S.p);
   }
-  LVF_HIP(hipMemsetAsync(fail_flag_dev, 0, sizeof(int), q));
   for (int kb = 0; kb < p->nb; ++kb) {
     const int below = p->nb - kb - 1;
     hipLaunchKernelGGL(k_chol_factor_panel, dim3(1 + below), dim3(256), 0, q, p->S.p, p->dpad, kb, fail_flag_dev);
@@ -846,14 +868,12 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   const size_t sh = ((size_t)((p->d + 63) / 64) * 64 + 4 * kNB) * sizeof(double);
   hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(256), sh, q, p->S.p, p->dpad, p->d, p->dxc.p);
   // model / norms / candidate state
-  LVF_HIP(hipMemsetAsync(p->scal.p + SC_COST_NEW, 0, (SC_N - SC_COST_NEW) * 8, q));
   const StateP s = state_ptrs(p->st);
   if (p->n_lm)
     hipLaunchKernelGGL(k_landmark_back, dim3(grid(p->n_lm)), dim3(kT), p->dp * sizeof(double), q, p->n_lm, p->dp, p->ldE, p->E.p, p->C.p, p->Cd.p,
                        p->gr.p, p->dxc.p, p->st->inv_depth.p, p->dxl.p, p->scal.p);
-  hipLaunchKernelGGL(k_model_cam, dim3(grid(p->d)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, p->dxc.p, inv_r, p->scal.p);
-  hipLaunchKernelGGL(k_apply_step, dim3(grid(std::max(p->n_kf, p->n_lm))), dim3(kT), 0, q, p->n_kf, p->n_lm, s, p->dxc.p, p->dxl.p, p->poses2.p,
-                     p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->scal.p);
+  hipLaunchKernelGGL(k_apply_step, dim3(grid(std::max(p->d, p->n_lm))), dim3(kT), 0, q, p->n_kf, p->n_lm, s, p->dxc.p, p->dxl.p, p->poses2.p,
+                     p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->scal.p, p->d, p->dpad, p->B.p, p->gc.p, inv_r);
   LVF_HIP(hipGetLastError());
   // candidate cost
   lvf_state view;   // borrowed pointers: a state-shaped view of the candidate buffers for launch_imu
@@ -866,16 +886,12 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   return rc;
 }
 
+// an accepted step makes the candidate buffers the state: pointer swap, no copies (the buffers have identical sizes; batches and
+// the C-ABI accessors always go through the lvf_state object, never through cached device pointers)
 static int commit_candidate(lvf_problem* p) {
-  hipStream_t q = p->ctx->stream;
   lvf_state* st = p->st;
-  if (p->n_kf) {
-    LVF_HIP(hipMemcpyAsync(st->poses.p, p->poses2.p, (size_t)56 * p->n_kf, hipMemcpyDeviceToDevice, q));
-    LVF_HIP(hipMemcpyAsync(st->vel.p, p->vel2.p, (size_t)24 * p->n_kf, hipMemcpyDeviceToDevice, q));
-    LVF_HIP(hipMemcpyAsync(st->ba.p, p->ba2.p, (size_t)24 * p->n_kf, hipMemcpyDeviceToDevice, q));
-    LVF_HIP(hipMemcpyAsync(st->bg.p, p->bg2.p, (size_t)24 * p->n_kf, hipMemcpyDeviceToDevice, q));
-  }
-  if (p->n_lm) LVF_HIP(hipMemcpyAsync(st->inv_depth.p, p->invd2.p, (size_t)8 * p->n_lm, hipMemcpyDeviceToDevice, q));
+  std::swap(st->poses.p, p->poses2.p); std::swap(st->vel.p, p->vel2.p); std::swap(st->ba.p, p->ba2.p); std::swap(st->bg.p, p->bg2.p);
+  std::swap(st->inv_depth.p, p->invd2.p);
   return LVF_OK;
 }
 
@@ -884,11 +900,11 @@ struct IterOut { double cost_before, cost_after, model, dxnorm, xnorm, gmax; boo
 static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* radius, double* decrease, IterOut* out) {
   hipStream_t q = p->ctx->stream;
   LVF_TRY(enqueue_linearize(p, o->huber_a));
-  LVF_TRY(enqueue_step(p, o->huber_a, *radius, p->fail.p));
-  double h[SC_N]; int hfail = 0;
+  LVF_TRY(enqueue_step(p, o->huber_a, *radius, reinterpret_cast<int*>(p->scal.p + SC_FAIL)));
+  double h[SC_ALLOC];
   LVF_HIP(hipMemcpyAsync(h, p->scal.p, sizeof(h), hipMemcpyDeviceToHost, q));
-  LVF_HIP(hipMemcpyAsync(&hfail, p->fail.p, sizeof(int), hipMemcpyDeviceToHost, q));
   LVF_HIP(hipStreamSynchronize(q));
+  int hfail; std::memcpy(&hfail, &h[SC_FAIL], sizeof(int));
   out->cost_before = h[SC_COST]; out->cost_after = h[SC_COST_NEW]; out->model = -h[SC_MODEL];
   out->dxnorm = std::sqrt(h[SC_DXNORM]); out->xnorm = std::sqrt(h[SC_XNORM]);
   long long gbits; std::memcpy(&gbits, &h[SC_GMAX], 8); std::memcpy(&out->gmax, &gbits, 8);
@@ -951,7 +967,7 @@ int lvf_problem_create(lvf_ctx* ctx, lvf_state* st, lvf_batch* two_camera, lvf_b
   int rc;
   if ((rc = p->B.alloc(nS)) || (rc = p->S.alloc(nS)) || (rc = p->gc.alloc(p->dpad)) || (rc = p->dxc.alloc(p->dpad)) ||
       (rc = p->C.alloc(p->n_lm)) || (rc = p->gr.alloc(p->n_lm)) || (rc = p->Cd.alloc(p->n_lm)) || (rc = p->dxl.alloc(p->n_lm)) ||
-      (rc = p->E.alloc((size_t)p->n_lm * p->ldE)) || (rc = p->scal.alloc(SC_N)) || (rc = p->poses2.alloc((size_t)7 * p->n_kf)) ||
+      (rc = p->E.alloc((size_t)p->n_lm * p->ldE)) || (rc = p->scal.alloc(SC_ALLOC)) || (rc = p->poses2.alloc((size_t)7 * p->n_kf)) ||
       (rc = p->vel2.alloc((size_t)3 * p->n_kf)) || (rc = p->ba2.alloc((size_t)3 * p->n_kf)) || (rc = p->bg2.alloc((size_t)3 * p->n_kf)) ||
       (rc = p->invd2.alloc(p->n_lm)) || (rc = p->pose_const.alloc(p->n_kf)) || (rc = p->fail.alloc(1))) { delete p; return rc; }
   p->pose_const_h.assign(p->n_kf, 0);
@@ -1064,9 +1080,10 @@ int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs) {
   hipStream_t q = p->ctx->stream;
   const double inv_r = 1.0 / p->last_radius;
   const size_t nS = (size_t)p->dpad * p->dpad;
-  hipLaunchKernelGGL(k_prepare_S, dim3((unsigned)((nS + kT - 1) / kT)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, inv_r, p->S.p);
+  const unsigned nSb = (unsigned)((nS + kT - 1) / kT);
+  hipLaunchKernelGGL(k_prepare, dim3(nSb + (p->n_lm ? grid(p->n_lm) : 0)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, inv_r, p->S.p, nSb, p->n_lm,
+                     p->dp, p->ldE, p->C.p, p->gr.p, p->Cd.p, p->E.p, (double*)nullptr);
   if (p->n_lm) {
-    hipLaunchKernelGGL(k_prepare_lm, dim3(grid(p->n_lm)), dim3(kT), 0, q, p->n_lm, p->dp, p->ldE, p->C.p, p->gr.p, inv_r, p->Cd.p, p->E.p);
     const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
     hipLaunchKernelGGL(k_schur_syrk, dim3(ntile, (p->n_lm + kSchurChunk - 1) / kSchurChunk), dim3(64), 0, q, p->n_lm, p->dp, p->ldE, ntile, p->E.p,
                        p->Cd.p, p->d, p->dpad, p->S.p);

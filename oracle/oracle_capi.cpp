@@ -11,6 +11,7 @@
 #include "factors.h"
 #include "imu.h"
 #include "icp.h"
+#include "cloud.h"
 #include "knn.h"
 #include "lm.h"
 #include "robust.h"
@@ -313,6 +314,26 @@ void lvo_icp_solve(const float* map, int M, int mstride, const float* query, int
   IcpOut o;
   icp_solve(map, M, mstride, query, Q, qstride, map_pose, frame_pose, rpyxyz, mode, thr, weight, huber_a, prior_w, max_iters, use_kdtree != 0, &o);
   out5[0] = o.initial_cost; out5[1] = o.final_cost; out5[2] = o.nres; out5[3] = o.iters; out5[4] = o.successes;
+}
+
+
+// ---------------- map-cloud maintenance (cloud.h) ----------------
+void lvo_cloud_transform(const float* in, int n, const double* pose, float* out) { cloud_transform(in, n, pose, out); }
+// returns the number of output points; out (capacity n*4 floats) receives them
+int lvo_voxel_filter(const float* in, int n, float leaf, float* out) {
+  const std::vector<float> v = voxel_filter(in, n, leaf);
+  std::memcpy(out, v.data(), v.size() * sizeof(float));
+  return (int)(v.size() / 4);
+}
+void lvo_radius_outlier_keep(const float* in, int n, float radius, int min_neighbors, unsigned char* keep) {
+  const auto k = radius_outlier_keep(in, n, radius, min_neighbors);
+  std::memcpy(keep, k.data(), k.size());
+}
+int lvo_segment_plane(const float* in, int n, float thr, int max_iterations, unsigned long long seed, unsigned char* mask, double* coeff4) {
+  int iters = 0;
+  const auto m = segment_plane(in, n, thr, max_iterations, seed, coeff4, &iters);
+  std::memcpy(mask, m.data(), m.size());
+  return iters;
 }
 
 }  // extern "C"

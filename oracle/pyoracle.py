@@ -263,6 +263,36 @@ def kdtree_build_seconds(map_xyz):
     return lib().lvo_kdtree_build_seconds(_p(m, C.c_float), m.shape[0], m.shape[1])
 
 
+# ----------------------------------------------------------------------------- map-cloud maintenance (cloud.h)
+def cloud_transform(xyzi, pose):
+    a, t = _f32(xyzi), _f64(pose)
+    out = np.empty_like(a)
+    lib().lvo_cloud_transform(_p(a, C.c_float), a.shape[0], _p(t), _p(out, C.c_float))
+    return out
+
+
+def voxel_filter(xyzi, leaf):
+    a = _f32(xyzi)
+    out = np.empty_like(a)
+    n = lib().lvo_voxel_filter(_p(a, C.c_float), a.shape[0], C.c_float(leaf), _p(out, C.c_float))
+    return out[:n].copy()
+
+
+def radius_outlier_keep(xyzi, radius, min_neighbors):
+    a = _f32(xyzi)
+    keep = np.empty(a.shape[0], np.uint8)
+    lib().lvo_radius_outlier_keep(_p(a, C.c_float), a.shape[0], C.c_float(radius), int(min_neighbors), keep.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return keep
+
+
+def segment_plane(xyzi, thr, max_iterations=100, seed=12345):
+    a = _f32(xyzi)
+    mask = np.empty(a.shape[0], np.uint8); co = np.empty(4)
+    it = lib().lvo_segment_plane(_p(a, C.c_float), a.shape[0], C.c_float(thr), int(max_iterations), C.c_ulonglong(seed),
+                                 mask.ctypes.data_as(C.POINTER(C.c_uint8)), _p(co))
+    return mask, co, it
+
+
 # ----------------------------------------------------------------------------- sliding-window problem
 class _WindowC(C.Structure):
     _fields_ = [("n_kf", C.c_int), ("n_lm", C.c_int),

@@ -1,0 +1,124 @@
+"""GPU parity of the map-cloud maintenance kernels (lvf_cloud_*: MergeScan/ToWorld, BuildMapFrame's merge, VoxelGrid,
+RadiusOutlierRemoval, SegmentGround) against oracle/cloud.h, and the device-resident chain
+filter -> transform -> merge -> kNN index -> association without host round trips."""
+import numpy as np
+import pytest
+
+from lvio_fusion_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lvio_fusion_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def scene():
+    c = syn.config3_icp(seed=321, n_query=20000, n_az=700)
+    q = c["query"].copy()
+    q[:, 3] = np.random.default_rng(0).uniform(0, 255, len(q)).astype(np.float32)
+    return c, q
+
+
+def test_transform_bit_exact_and_concat(ctx, oracle, scene):
+    from lvio_fusion_amd import api
+    c, q = scene
+    cl = api.Cloud(ctx, q)
+    assert len(cl) == len(q) and np.array_equal(cl.download(), q)
+    tw = cl.transform(c["pose0"])
+    assert np.array_equal(tw.download(), oracle.cloud_transform(q, c["pose0"]))          # bit-exact float arithmetic
+    un = np.array([0.3, -0.2, 0.9, 1.7, 5.0, -3.0, 1.0])                                  # un-normalised quaternion: normalised inside
+    t2 = cl.transform(un)
+    assert np.array_equal(t2.download(), oracle.cloud_transform(q, un))
+    merged = api.Cloud.concat(ctx, [tw, t2, cl])
+    assert np.array_equal(merged.download(), np.concatenate([tw.download(), t2.download(), q]))
+    empty = api.Cloud(ctx, np.zeros((0, 4), np.float32))
+    assert len(empty.transform(c["pose0"])) == 0 and len(api.Cloud.concat(ctx, [empty, empty])) == 0
+    for h in (cl, tw, t2, merged, empty):
+        h.close()
+
+
+@pytest.mark.parametrize("leaf", [0.4, 1.0])
+def test_voxel_filter_parity(ctx, oracle, scene, leaf):
+    from lvio_fusion_amd import api
+    _, q = scene
+    cl = api.Cloud(ctx, q)
+    out = cl.voxel_filter(leaf).download()
+    ref = oracle.voxel_filter(q, leaf)
+    assert out.shape == ref.shape                               # same voxels, same (ascending index) order
+    scale = np.abs(ref).max(0)
+    assert (np.abs(out - ref) <= 2e-6 * np.abs(ref) + 1e-6 * scale).all()   # double-atomic sums vs the oracle's float accumulation
+    assert len(api.Cloud(ctx, np.zeros((0, 4), np.float32)).voxel_filter(leaf)) == 0
+    one = api.Cloud(ctx, q[:1]).voxel_filter(leaf).download()
+    assert np.array_equal(one, q[:1])
+    cl.close()
+
+
+def test_radius_outlier_filter_parity(ctx, oracle, scene):
+    from lvio_fusion_amd import api
+    _, q = scene
+    sub = q[:8000]
+    cl = api.Cloud(ctx, sub)
+    out = cl.radius_outlier_filter(0.8, 4).download()
+    keep = oracle.radius_outlier_keep(sub, 0.8, 4).astype(bool)
+    assert np.array_equal(out, sub[keep])                       # same points, input order preserved (integer decision: exact)
+    assert 0 < keep.sum() < len(keep)
+    cl.close()
+
+
+def test_segment_plane_parity(ctx, oracle, scene):
+    from lvio_fusion_amd import api
+    c, q = scene
+    g = q[c["query_ground"]]
+    rng = np.random.default_rng(3)
+    clutter = g[:500].copy(); clutter[:, 2] += rng.uniform(0.3, 2.0, 500).astype(np.float32)
+    pts = np.concatenate([g, clutter]).astype(np.float32)
+    cl = api.Cloud(ctx, pts)
+    for seed in (12345, 99):
+        inl, co, it = cl.segment_plane(0.05, 100, seed)
+        mask, co_ref, it_ref = oracle.segment_plane(pts, 0.05, 100, seed)
+        assert it == it_ref
+        assert np.allclose(co, co_ref, rtol=1e-6, atol=1e-7)
+        got = inl.download()
+        ref = pts[mask > 0]
+        # the refit goes through double atomics (order-dependent last bits): a point exactly at the threshold may flip
+        assert abs(len(got) - len(ref)) <= 2
+        if len(got) == len(ref):
+            assert np.array_equal(got, ref)
+        inl.close()
+    tiny = api.Cloud(ctx, pts[:2])
+    e, co, it = tiny.segment_plane(0.05)
+    assert len(e) == 0 and it == 0
+    cl.close()
+
+
+def test_device_resident_map_pipeline(ctx, oracle, scene):
+    """Sensor2Robot-style transform -> voxel filter -> ToWorld -> merge of three scans -> kNN index -> association, all
+    from device clouds; must equal the same chain with every cloud taken through the host."""
+    from lvio_fusion_amd import api
+    c, q = scene
+    poses = [c["map_pose"], c["pose0"], c["pose_true"]]
+    parts_dev, parts_host = [], []
+    for k, T in enumerate(poses):
+        sub = q[k::3]
+        cl = api.Cloud(ctx, sub)
+        vf = cl.voxel_filter(0.4)
+        tw = vf.transform(T)
+        parts_dev.append(tw)
+        parts_host.append(tw.download())
+    merged = api.Cloud.concat(ctx, parts_dev)
+    host_map = np.concatenate(parts_host)
+    qs = api.Cloud(ctx, q[:3000])
+    m1, s1 = api.Map(ctx, merged, 4.0), api.Scan(ctx, qs)
+    m2, s2 = api.Map(ctx, host_map, 4.0), api.Scan(ctx, q[:3000])
+    api.knn3(m1, s1, c["pose0"], 4.0); api.knn3(m2, s2, c["pose0"], 4.0)
+    i1, d1, v1 = s1.download(); i2, d2, v2 = s2.download()
+    assert np.array_equal(v1, v2) and np.array_equal(i1[v1 > 0], i2[v2 > 0]) and np.array_equal(d1[v1 > 0], d2[v2 > 0])
+    i0, d0, v0 = oracle.knn3(host_map, q[:3000], c["pose0"], 4.0)
+    assert np.array_equal(v1, v0) and np.array_equal(i1[v0 > 0], i0[v0 > 0])
+    assert v0.sum() > 1000
