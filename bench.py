@@ -178,7 +178,9 @@ def extras(api, syn, ctx):
     ex["icp_mpairs_per_sec"] = ex["knn3_ground_thr4.0"]["mpairs_per_s"]
     mp.close(); sc.close()
     ex["scan_match_frame"] = scan_match_frame(api, syn, ctx, c3)
+    ex["map_maintenance"] = map_maintenance(api, ctx, c3)
     ex["full_window_ba"] = full_window(api, syn, ctx)
+    ex["window_tick"] = window_tick(api, syn, ctx)
     ex["relocalize_8_candidates"] = relocalize_leg(api, syn, ctx)
     return ex
 
@@ -205,6 +207,75 @@ def scan_match_frame(api, syn, ctx, c3, reps=10):
            "pos_err_after_m": float(np.abs(np.array(res.pose[:])[4:] - c3["pose_true"][4:]).max())}
     for h in (mpg, scg, mps, scs):
         h.close()
+    return out
+
+
+def map_maintenance(api, ctx, c3, reps=10):
+    """SURVEY 8f row 2 on configs[2]'s clouds, everything device-resident: ToWorld transform of the 100k-point scan (HBM-bound:
+    32 B/point), VoxelGrid (leaf 0.4), RadiusOutlierRemoval (0.8 m, 4), RANSAC ground plane on the ground points, and the map
+    index build from the merged device cloud."""
+    out = {}
+    q = api.Cloud(ctx, c3["query"]); mp = api.Cloud(ctx, c3["map"]); qg = api.Cloud(ctx, c3["query"][c3["query_ground"]])
+
+    def timed(fn, n=reps):
+        h = fn(); ctx.synchronize()
+        (h[0] if isinstance(h, tuple) else h).close()
+        t0 = time.perf_counter()
+        hs = [fn() for _ in range(n)]
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        size = len(hs[0][0] if isinstance(hs[0], tuple) else hs[0])
+        for h in hs:
+            (h[0] if isinstance(h, tuple) else h).close()
+        return dt, size
+    dt, n = timed(lambda: q.transform(c3["pose0"]))
+    out["transform"] = {"points": n, "us": 1e6 * dt, "gb_per_s_incl_alloc": 32.0 * n / dt / 1e9}
+    dt, n = timed(lambda: q.voxel_filter(0.4))
+    out["voxel_filter_0.4"] = {"points_in": len(q), "points_out": n, "us": 1e6 * dt}
+    dt, n = timed(lambda: q.radius_outlier_filter(0.8, 4))
+    out["radius_outlier_0.8_4"] = {"points_in": len(q), "points_out": n, "us": 1e6 * dt}
+    dt, n = timed(lambda: qg.segment_plane(0.02, 100, 12345))
+    out["segment_plane_100_hyp"] = {"points_in": len(qg), "inliers": n, "us": 1e6 * dt}
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m = api.Map(ctx, mp, 4.0); m.close()
+    ctx.synchronize()
+    out["map_index_from_device_cloud_us"] = 1e6 * (time.perf_counter() - t0) / reps
+    for h in (q, mp, qg):
+        h.close()
+    return out
+
+
+def window_tick(api, syn, ctx, reps=10):
+    """one backend tick through the PERSISTENT window (lvf_window_solve with max_num_iterations = 1 =
+    assemble the block lists from the incremental host mirror + refill the persistent device batches + one LM iteration +
+    read-back) on the configs[3]-sized window; the assembly/upload overhead is what remains after subtracting the LM
+    iteration measured above."""
+    cfg = syn.config4_window(n_prewindow=0)
+    pre = api.preintegrate_or_none(ctx, cfg)
+    win = api.Window(ctx, cfg["cam0"], cfg["cam1"], baseline=syn.baseline())
+    tc, tf = cfg["tc"], cfg["tf"]
+    t0 = time.perf_counter()
+    order_tc = np.argsort(tc["kf_idx"], kind="stable")
+    tf_by_kf = {k: np.nonzero(tf["kf2_idx"] == k)[0] for k in range(cfg["n_kf"])}
+    j = 0
+    for k in range(cfg["n_kf"]):
+        win.add_keyframe(k, cfg["poses"][k], cfg["w_kf"][k])
+        win.set_imu(k, cfg["vel"][k], cfg["ba"][k], cfg["bg"][k], pre[k - 1] if k > 0 else None)
+        while j < len(order_tc) and tc["kf_idx"][order_tc[j]] == k:
+            i = order_tc[j]; j += 1
+            win.add_landmark(int(tc["lm_idx"][i]), k, tc["left_ob"][i], tc["right_ob"][i], cfg["inv_depth"][tc["lm_idx"][i]])
+        for i in tf_by_kf[k]:
+            win.add_observation(int(tf["lm_idx"][i]), k, tf["ob"][i])
+    populate_s = time.perf_counter() - t0
+    opt = api.default_solver_options(); opt.max_num_iterations = 1
+    win.solve(opt); win.solve(opt)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        win.solve(opt)
+    dt = (time.perf_counter() - t0) / reps
+    out = {"counts": win.counts(), "ms_per_tick_1_iteration": 1e3 * dt, "python_populate_s": populate_s}
+    win.close()
     return out
 
 

@@ -23,6 +23,7 @@
  *   lvf_cloud_*        <- Mapping::MergeScan/ToWorld/BuildMapFrame, pcl::VoxelGrid / RadiusOutlierRemoval / SACSegmentation
  *                         src/mapping.cpp:78-137,193-220, src/association.cpp:210-268
  *   lvf_scan_match     <- Mapping::Optimize's per-frame body / Mapping::Relocate   src/mapping.cpp:147-178, :251-300
+ *   lvf_window_*       <- Backend::BuildProblem's assembly kept incrementally          src/backend.cpp:96-183
  *   lvf_problem_*      <- adapt::Problem::{AddParameterBlock,AddResidualBlock,SetParameterBlockConstant}
  *                         + adapt::Solve (include/lvio_fusion/adapt/problem.h:34-88) as driven by
  *                         Backend::BuildProblem / Backend::Optimize (src/backend.cpp:96-183, :192-246)
@@ -62,6 +63,7 @@ typedef struct lvf_map lvf_map;
 typedef struct lvf_scan lvf_scan;
 typedef struct lvf_icp lvf_icp;
 typedef struct lvf_cloud lvf_cloud;
+typedef struct lvf_window lvf_window;
 typedef struct lvf_problem lvf_problem;
 
 /* Camera = intrinsics + sensor->robot extrinsic (include/lvio_fusion/sensor.h:41-44, visual/camera.h:74). */
@@ -307,6 +309,35 @@ int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_su
  * d = 15 * n_kf (pose tangent 6 | v 3 | ba 3 | bg 3 per keyframe). */
 int lvf_problem_reduced_dim(lvf_problem* p);
 int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs);
+
+/* ---- persistent sliding window (Backend::BuildProblem's assembly, kept incrementally) -------------- */
+/* The window mirrors Map's active keyframes, their features_left and the landmarks behind them as flat arrays that the
+ * front-end updates as it goes; lvf_window_solve assembles the block lists with BuildProblem's rules (backend.cpp:96-183) in
+ * frame order / ascending landmark id, re-fills persistent device batches (no per-tick allocation) and runs adapt::Solve's
+ * device loop.  Keyframe and landmark ids are the caller's (frame->id, landmark->id); keyframe ids must increase. */
+typedef struct lvf_window_options {
+  double baseline;              /* Camera::baseline: a landmark deeper than 50 baselines is "Far" (camera.h:38-41) */
+  int weak_visual_threshold;    /* 20 (backend.cpp:166) */
+  double prior_weight, prior_v; /* PoseGraphError / PoseError (.., 100, 0)  (backend.cpp:170,175) */
+} lvf_window_options;
+void lvf_window_options_default(lvf_window_options* o);
+int lvf_window_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera* right, const lvf_window_options* opt, lvf_window** out);
+int lvf_window_destroy(lvf_window* w);
+int lvf_window_add_keyframe(lvf_window* w, int64_t kf_id, const double* pose7, double w_visual);
+/* marks the frame good_imu with its Vw / linearised biases; pre (may be NULL) = frame->preintegration from the previous keyframe */
+int lvf_window_set_imu(lvf_window* w, int64_t kf_id, const double* vel3, const double* ba3, const double* bg3, const lvf_preint* pre);
+/* a landmark triangulated in keyframe birth_kf_id: its left feature there and first_observation (right image) */
+int lvf_window_add_landmark(lvf_window* w, int64_t lm_id, int64_t birth_kf_id, const double* left_ob2, const double* right_ob2, double inv_depth);
+int lvf_window_add_observation(lvf_window* w, int64_t lm_id, int64_t kf_id, const double* ob2);
+int lvf_window_remove_observation(lvf_window* w, int64_t lm_id, int64_t kf_id);   /* outlier rejection, backend.cpp:232-243 */
+int lvf_window_slide(lvf_window* w, int64_t first_active_kf_id);                  /* Map::GetKeyFrames(finished) */
+int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summary* summary);
+int lvf_window_set_pose(lvf_window* w, int64_t kf_id, const double* pose7);       /* front-end / ForwardUpdate writes */
+int lvf_window_get_pose(const lvf_window* w, int64_t kf_id, double* pose7);
+int lvf_window_get_imu(const lvf_window* w, int64_t kf_id, double* vel3, double* ba3, double* bg3);
+int lvf_window_get_inv_depth(const lvf_window* w, int64_t lm_id, double* inv_depth);
+/* counts8 = {keyframes, landmarks in the problem, TwoCamera, TwoFrame, PoseOnly, ImuError, prior blocks, landmarks known} of the last solve */
+int lvf_window_counts(const lvf_window* w, int32_t* counts8);
 
 #ifdef __cplusplus
 }

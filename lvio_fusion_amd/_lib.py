@@ -43,6 +43,10 @@ class ScanMatchResult(C.Structure):
                 ("score", C.c_int), ("ground", IcpSummary), ("surf", IcpSummary)]
 
 
+class WindowOptions(C.Structure):
+    _fields_ = [("baseline", C.c_double), ("weak_visual_threshold", C.c_int), ("prior_weight", C.c_double), ("prior_v", C.c_double)]
+
+
 class SolverOptions(C.Structure):
     _fields_ = [("max_num_iterations", C.c_int), ("max_solver_time_in_seconds", C.c_double), ("huber_a", C.c_double),
                 ("initial_trust_region_radius", C.c_double), ("function_tolerance", C.c_double),
@@ -123,6 +127,21 @@ _SIGS = {
     "lvf_scan_match": (C.c_int, [_VP, _VP, _VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(ScanMatchOptions), C.POINTER(ScanMatchResult)]),
     "lvf_lidar_solve": (C.c_int, [_VP, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
     "lvf_prior3_evaluate": (C.c_int, [_VP, C.c_int, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p]),
+    "lvf_window_options_default": (None, [C.POINTER(WindowOptions)]),
+    "lvf_window_create": (C.c_int, [_VP, C.POINTER(Camera), C.POINTER(Camera), C.POINTER(WindowOptions), C.POINTER(_VP)]),
+    "lvf_window_destroy": (C.c_int, [_VP]),
+    "lvf_window_add_keyframe": (C.c_int, [_VP, C.c_int64, c_double_p, C.c_double]),
+    "lvf_window_set_imu": (C.c_int, [_VP, C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "lvf_window_add_landmark": (C.c_int, [_VP, C.c_int64, C.c_int64, c_double_p, c_double_p, C.c_double]),
+    "lvf_window_add_observation": (C.c_int, [_VP, C.c_int64, C.c_int64, c_double_p]),
+    "lvf_window_remove_observation": (C.c_int, [_VP, C.c_int64, C.c_int64]),
+    "lvf_window_slide": (C.c_int, [_VP, C.c_int64]),
+    "lvf_window_solve": (C.c_int, [_VP, C.POINTER(SolverOptions), C.POINTER(SolverSummary)]),
+    "lvf_window_set_pose": (C.c_int, [_VP, C.c_int64, c_double_p]),
+    "lvf_window_get_pose": (C.c_int, [_VP, C.c_int64, c_double_p]),
+    "lvf_window_get_imu": (C.c_int, [_VP, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    "lvf_window_get_inv_depth": (C.c_int, [_VP, C.c_int64, c_double_p]),
+    "lvf_window_counts": (C.c_int, [_VP, c_int_p]),
     "lvf_solver_options_default": (None, [C.POINTER(SolverOptions)]),
     "lvf_problem_create": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "lvf_problem_destroy": (C.c_int, [_VP]),

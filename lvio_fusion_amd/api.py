@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Camera, IcpOptions, IcpSummary, ScanMatchOptions, ScanMatchResult, SolverOptions, SolverSummary
+from ._lib import WindowOptions, Camera, IcpOptions, IcpSummary, ScanMatchOptions, ScanMatchResult, SolverOptions, SolverSummary
 
 POSES, VEL, BA, BG, INV_DEPTH, W_VISUAL = range(6)
 IMU_BLOCK_SIZES = (7, 3, 3, 3, 7, 3, 3, 3)
@@ -351,6 +351,78 @@ def lidar_solve(batch, rpyxyz, huber_a, prior_weight=0.0, max_num_iterations=4):
     summ = IcpSummary()
     _chk(batch.ctx.L.lvf_lidar_solve(batch.h, _dp(rpyxyz), C.byref(opt), C.byref(summ)))
     return summ
+
+
+class Window:
+    """Persistent sliding window (lvf_window_*): Backend::BuildProblem's assembly kept incrementally across ticks."""
+
+    def __init__(self, ctx, left, right, baseline=None, weak_visual_threshold=20):
+        self.ctx = ctx
+        o = WindowOptions()
+        ctx.L.lvf_window_options_default(C.byref(o))
+        if baseline is not None:
+            o.baseline = float(baseline)
+        o.weak_visual_threshold = int(weak_visual_threshold)
+        self.h = C.c_void_p()
+        cl, cr = make_camera(left), make_camera(right)
+        _chk(ctx.L.lvf_window_create(ctx.h, C.byref(cl), C.byref(cr), C.byref(o), C.byref(self.h)))
+
+    def add_keyframe(self, kf_id, pose, w_visual):
+        p = _d(pose)
+        _chk(self.ctx.L.lvf_window_add_keyframe(self.h, int(kf_id), _dp(p), float(w_visual)))
+
+    def set_imu(self, kf_id, vel, ba, bg, pre=None):
+        v, a, g = _d(vel), _d(ba), _d(bg)
+        pr = _d(pre) if pre is not None else None
+        _chk(self.ctx.L.lvf_window_set_imu(self.h, int(kf_id), _dp(v), _dp(a), _dp(g), _dp(pr) if pr is not None else None))
+
+    def add_landmark(self, lm_id, birth_kf, left_ob, right_ob, inv_depth):
+        l, r = _d(left_ob), _d(right_ob)
+        _chk(self.ctx.L.lvf_window_add_landmark(self.h, int(lm_id), int(birth_kf), _dp(l), _dp(r), float(inv_depth)))
+
+    def add_observation(self, lm_id, kf_id, ob):
+        o = _d(ob)
+        _chk(self.ctx.L.lvf_window_add_observation(self.h, int(lm_id), int(kf_id), _dp(o)))
+
+    def remove_observation(self, lm_id, kf_id):
+        _chk(self.ctx.L.lvf_window_remove_observation(self.h, int(lm_id), int(kf_id)))
+
+    def slide(self, first_active_kf):
+        _chk(self.ctx.L.lvf_window_slide(self.h, int(first_active_kf)))
+
+    def solve(self, opt):
+        s = SolverSummary()
+        _chk(self.ctx.L.lvf_window_solve(self.h, C.byref(opt), C.byref(s)))
+        return s
+
+    def pose(self, kf_id):
+        out = np.empty(7)
+        _chk(self.ctx.L.lvf_window_get_pose(self.h, int(kf_id), _dp(out)))
+        return out
+
+    def set_pose(self, kf_id, pose):
+        p = _d(pose)
+        _chk(self.ctx.L.lvf_window_set_pose(self.h, int(kf_id), _dp(p)))
+
+    def imu(self, kf_id):
+        v, a, g = np.empty(3), np.empty(3), np.empty(3)
+        _chk(self.ctx.L.lvf_window_get_imu(self.h, int(kf_id), _dp(v), _dp(a), _dp(g)))
+        return v, a, g
+
+    def inv_depth(self, lm_id):
+        d = C.c_double()
+        _chk(self.ctx.L.lvf_window_get_inv_depth(self.h, int(lm_id), C.byref(d)))
+        return d.value
+
+    def counts(self):
+        c = np.zeros(8, np.int32)
+        _chk(self.ctx.L.lvf_window_counts(self.h, _ip(c)))
+        return dict(zip(("kf", "lm", "tc", "tf", "po", "imu", "prior", "lm_known"), c.tolist()))
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lvf_window_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 def default_solver_options():

@@ -36,15 +36,30 @@ template <typename T>
 struct DevBuf {  // owning device buffer
   T* p = nullptr;
   size_t n = 0;
+  size_t cap = 0;   // allocated elements (>= n); ensure()/assign() only ever grow it
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { if (p) (void)hipFree(p); }
   int alloc(size_t count) {
     if (p) { (void)hipFree(p); p = nullptr; }
-    n = count;
+    n = count; cap = count;
     if (count == 0) return LVF_OK;
     LVF_HIP(hipMalloc(&p, count * sizeof(T)));
+    return LVF_OK;
+  }
+  // grow-only resize (contents are NOT preserved across a growth): the persistent-window path re-uses buffers across ticks
+  int ensure(size_t count) {
+    if (count <= cap && (p || count == 0)) { n = count; return LVF_OK; }
+    const size_t want = count + count / 4 + 16;
+    if (p) { (void)hipFree(p); p = nullptr; }
+    LVF_HIP(hipMalloc(&p, want * sizeof(T)));
+    cap = want; n = count;
+    return LVF_OK;
+  }
+  int assign(const T* host, size_t count, hipStream_t s) {
+    LVF_TRY(ensure(count));
+    if (count) LVF_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
     return LVF_OK;
   }
   int upload(const T* host, size_t count, hipStream_t s) {
@@ -144,7 +159,11 @@ struct lvf_cloud {
   lvf::DevBuf<float4> pts;           // x, y, z, intensity  (pcl::PointXYZI payload, 16 B on device)
 };
 
+struct lvf_problem;
 namespace lvf {
+// (re)derives a problem's dimensions from its state's CURRENT n_kf / n_lm, grows its work buffers if needed and rebuilds the
+// TwoFrame work list; called by lvf_problem_create and, every tick, by the persistent window (window.hip)
+int problem_configure(lvf_problem* p);
 int device_exclusive_scan_i32(lvf_ctx* ctx, const int* in, int n, int* out);
 // kernels / launchers implemented in the .hip translation units
 int launch_pose_only(lvf_batch* b, const lvf_state* st, bool want_j);

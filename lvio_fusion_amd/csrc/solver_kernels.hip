@@ -806,8 +806,8 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
     ZeroList z;
     int k = 0;
     auto add = [&](double* ptr, size_t n) { if (ptr && n) { z.p[k] = ptr; z.n[k] = n; ++k; } };
-    add(p->B.p, p->B.n); add(p->gc.p, p->gc.n); add(p->scal.p, SC_N);
-    if (p->n_lm) { add(p->E.p, p->E.n); add(p->C.p, p->C.n); add(p->gr.p, p->gr.n); }
+    add(p->B.p, (size_t)p->dpad * p->dpad); add(p->gc.p, p->dpad); add(p->scal.p, SC_N);
+    if (p->n_lm) { add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
     hipLaunchKernelGGL(k_zero_multi, dim3(512, k), dim3(kT), 0, q, z);
   }
   double* cost = p->scal.p + SC_COST;
@@ -890,8 +890,9 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
 // the C-ABI accessors always go through the lvf_state object, never through cached device pointers)
 static int commit_candidate(lvf_problem* p) {
   lvf_state* st = p->st;
-  std::swap(st->poses.p, p->poses2.p); std::swap(st->vel.p, p->vel2.p); std::swap(st->ba.p, p->ba2.p); std::swap(st->bg.p, p->bg2.p);
-  std::swap(st->inv_depth.p, p->invd2.p);
+  auto swap_storage = [](lvf::DevBuf<double>& a, lvf::DevBuf<double>& b) { std::swap(a.p, b.p); std::swap(a.cap, b.cap); };
+  swap_storage(st->poses, p->poses2); swap_storage(st->vel, p->vel2); swap_storage(st->ba, p->ba2); swap_storage(st->bg, p->bg2);
+  swap_storage(st->inv_depth, p->invd2);
   return LVF_OK;
 }
 
@@ -928,6 +929,49 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
   return LVF_OK;
 }
 
+int problem_configure(lvf_problem* p) {
+  lvf_state* st = p->st;
+  lvf_ctx* ctx = p->ctx;
+  p->n_kf = st->n_kf; p->n_lm = st->n_lm;
+  p->d = 15 * p->n_kf; p->dp = 6 * p->n_kf;
+  p->ldE = ((p->dp + 1 + 15) / 16) * 16;
+  p->dpad = ((p->d + 1 + 63) / 64) * 64;
+  p->nb = p->dpad / 64;
+  const size_t nS = (size_t)p->dpad * p->dpad;
+  LVF_TRY(p->B.ensure(nS)); LVF_TRY(p->S.ensure(nS)); LVF_TRY(p->gc.ensure(p->dpad)); LVF_TRY(p->dxc.ensure(p->dpad));
+  LVF_TRY(p->C.ensure(p->n_lm)); LVF_TRY(p->gr.ensure(p->n_lm)); LVF_TRY(p->Cd.ensure(p->n_lm)); LVF_TRY(p->dxl.ensure(p->n_lm));
+  LVF_TRY(p->E.ensure((size_t)p->n_lm * p->ldE)); LVF_TRY(p->scal.ensure(SC_ALLOC));
+  // the candidate buffers are swapped with the state's on an accepted step: they must match the state's CAPACITY
+  LVF_TRY(p->poses2.ensure(std::max(st->poses.cap, (size_t)7 * p->n_kf))); LVF_TRY(p->vel2.ensure(std::max(st->vel.cap, (size_t)3 * p->n_kf)));
+  LVF_TRY(p->ba2.ensure(std::max(st->ba.cap, (size_t)3 * p->n_kf))); LVF_TRY(p->bg2.ensure(std::max(st->bg.cap, (size_t)3 * p->n_kf)));
+  LVF_TRY(p->invd2.ensure(std::max(st->inv_depth.cap, (size_t)p->n_lm)));
+  LVF_TRY(p->pose_const.ensure(p->n_kf)); LVF_TRY(p->fail.ensure(1));
+  p->pose_const_h.assign(p->n_kf, 0);
+  p->tf_work.n = 0;
+  lvf_batch* two_frame = p->tf;
+  if (two_frame && two_frame->n && two_frame->sorted_by_kf && !two_frame->host_kf2.empty()) {
+    // work list for the sorted fast path: runs of <= kT blocks sharing one current keyframe; k1 == k2 disables it
+    const std::vector<int32_t>& k2 = two_frame->host_kf2; const std::vector<int32_t>& k1 = two_frame->host_kf1;
+    bool ok = true;
+    for (int i = 0; i < two_frame->n && ok; ++i) ok = k1[i] != k2[i];
+    if (ok) {
+      std::vector<TfWork> wl;
+      for (int i = 0; i < two_frame->n;) {
+        int j = i;
+        while (j < two_frame->n && k2[j] == k2[i] && j - i < kT) ++j;
+        wl.push_back(TfWork{i, j - i, k2[i]});
+        i = j;
+      }
+      LVF_TRY(p->tf_work.assign(wl.data(), wl.size(), ctx->stream));
+    }
+  }
+  LVF_HIP(hipMemsetAsync(p->pose_const.p, 0, p->n_kf, ctx->stream));
+  LVF_HIP(hipMemsetAsync(p->dxc.p, 0, (size_t)p->dpad * 8, ctx->stream));
+  LVF_HIP(hipStreamSynchronize(ctx->stream));
+  p->linearized = false;
+  return LVF_OK;
+}
+
 }  // namespace lvf
 
 using namespace lvf;
@@ -958,38 +1002,8 @@ int lvf_problem_create(lvf_ctx* ctx, lvf_state* st, lvf_batch* two_camera, lvf_b
   LVF_HIP(hipSetDevice(ctx->device));
   auto* p = new lvf_problem();
   p->ctx = ctx; p->st = st; p->tc = two_camera; p->tf = two_frame; p->po = pose_only; p->imu = imu;
-  p->n_kf = st->n_kf; p->n_lm = st->n_lm;
-  p->d = 15 * p->n_kf; p->dp = 6 * p->n_kf;
-  p->ldE = ((p->dp + 1 + 15) / 16) * 16;
-  p->dpad = ((p->d + 1 + 63) / 64) * 64;
-  p->nb = p->dpad / 64;
-  const size_t nS = (size_t)p->dpad * p->dpad;
-  int rc;
-  if ((rc = p->B.alloc(nS)) || (rc = p->S.alloc(nS)) || (rc = p->gc.alloc(p->dpad)) || (rc = p->dxc.alloc(p->dpad)) ||
-      (rc = p->C.alloc(p->n_lm)) || (rc = p->gr.alloc(p->n_lm)) || (rc = p->Cd.alloc(p->n_lm)) || (rc = p->dxl.alloc(p->n_lm)) ||
-      (rc = p->E.alloc((size_t)p->n_lm * p->ldE)) || (rc = p->scal.alloc(SC_ALLOC)) || (rc = p->poses2.alloc((size_t)7 * p->n_kf)) ||
-      (rc = p->vel2.alloc((size_t)3 * p->n_kf)) || (rc = p->ba2.alloc((size_t)3 * p->n_kf)) || (rc = p->bg2.alloc((size_t)3 * p->n_kf)) ||
-      (rc = p->invd2.alloc(p->n_lm)) || (rc = p->pose_const.alloc(p->n_kf)) || (rc = p->fail.alloc(1))) { delete p; return rc; }
-  p->pose_const_h.assign(p->n_kf, 0);
-  if (two_frame && two_frame->n && two_frame->sorted_by_kf && !two_frame->host_kf2.empty()) {
-    // work list for the sorted fast path: runs of <= kT blocks sharing one current keyframe; k1 == k2 disables it
-    const std::vector<int32_t>& k2 = two_frame->host_kf2; const std::vector<int32_t>& k1 = two_frame->host_kf1;
-    bool ok = true;
-    for (int i = 0; i < two_frame->n && ok; ++i) ok = k1[i] != k2[i];
-    if (ok) {
-      std::vector<TfWork> wl;
-      for (int i = 0; i < two_frame->n;) {
-        int j = i;
-        while (j < two_frame->n && k2[j] == k2[i] && j - i < kT) ++j;
-        wl.push_back(TfWork{i, j - i, k2[i]});
-        i = j;
-      }
-      if ((rc = p->tf_work.upload(wl.data(), wl.size(), ctx->stream))) { delete p; return rc; }
-    }
-  }
-  LVF_HIP(hipMemsetAsync(p->pose_const.p, 0, p->n_kf, ctx->stream));
-  LVF_HIP(hipMemsetAsync(p->dxc.p, 0, p->dpad * 8, ctx->stream));
-  LVF_HIP(hipStreamSynchronize(ctx->stream));
+  const int rc = problem_configure(p);
+  if (rc != LVF_OK) { delete p; return rc; }
   *out = p;
   return LVF_OK;
 }

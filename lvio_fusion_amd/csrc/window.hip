@@ -1,0 +1,386 @@
+// window.hip — a PERSISTENT sliding window (the problem-assembly step immediately before the hot path).
+//
+// The reference rebuilds its whole Ceres problem from the pointer graph twice per backend tick
+// (Backend::BuildProblem, src/lvio_fusion/src/backend.cpp:96-183, called from Optimize :206 and UpdateFrontend :261): one
+// heap-allocated functor per observation, std::map walks over frames -> features -> landmarks.  Here the window is kept as
+// flat host arrays that are updated INCREMENTALLY when the front-end adds a keyframe / landmark / observation or the window
+// slides, and the device SoA batches, parameter state and solver work buffers live across ticks (grow-only buffers, no
+// hipMalloc / hipFree per tick).  lvf_window_solve assembles the block lists with BuildProblem's rules —
+//   feature of frame k, landmark born in k            -> TwoCameraReprojectionError (weight 5 w_k)            :117-125
+//   landmark's birth frame older than the window       -> PoseOnlyReprojectionError on landmark->ToWorld()    :126-131
+//   otherwise                                          -> TwoFrameReprojectionError(inv_depth, birth, k)      :132-140
+//   good_imu frame after a good_imu frame              -> ImuError                                            :143-161
+//   no IMU block and < 20 near visual blocks           -> PoseGraphError(last, k, 100, 0) / PoseError(k, 100, 0)  :163-178
+// ("near" = !Camera::Far: depth in cam0 <= 50 baselines, include/lvio_fusion/visual/camera.h:38-41) — in frame order, features
+// by ascending landmark id (features_left is a std::map keyed by landmark id), uploads them with one copy per array and runs
+// the device LM loop; results are read back into the host mirror.
+#include <algorithm>
+#include <map>
+#include <unordered_map>
+#include "host_se3.hpp"
+#include "lvf_internal.hpp"
+
+struct lvf_window {
+  struct Obs { int64_t lm_id; int lm; double ob[2]; };  // lm = index into lms
+  struct Kf {
+    int64_t id = 0;
+    double pose[7], vel[3] = {0, 0, 0}, ba[3] = {0, 0, 0}, bg[3] = {0, 0, 0};
+    double w_visual = 1.0;
+    bool good_imu = false, has_pre = false;
+    lvf_preint pre;
+    std::vector<Obs> obs;                                // kept sorted by landmark id (BuildProblem's iteration order) lazily
+    bool sorted = true;
+    void put(const Obs& o) { if (!obs.empty() && o.lm_id <= obs.back().lm_id) sorted = false; obs.push_back(o); }
+    void sort_unique() {                                 // std::map semantics: ascending key, a re-inserted key overwrites
+      if (sorted) return;
+      std::stable_sort(obs.begin(), obs.end(), [](const Obs& a, const Obs& b) { return a.lm_id < b.lm_id; });
+      size_t o = 0;
+      for (size_t i = 0; i < obs.size(); ++i) {
+        if (i + 1 < obs.size() && obs[i + 1].lm_id == obs[i].lm_id) continue;   // keep the last of equal keys
+        obs[o++] = obs[i];
+      }
+      obs.resize(o);
+      sorted = true;
+    }
+  };
+  struct Lm {
+    int64_t id = 0, birth_kf = 0;
+    double left_ob[2], right_ob[2], inv_depth = 0.0;
+    bool fixed = false;                                  // birth frame left the window: world point frozen
+    double pw[3] = {0, 0, 0};
+    int slot = -1;                                       // dense index in the current assembly (-1: not in the problem)
+  };
+  lvf_ctx* ctx = nullptr;
+  lvf_camera left, right;
+  lvf_window_options opt;
+  std::vector<Kf> kfs;                                   // active keyframes, oldest first
+  std::unordered_map<int64_t, int> kf_index;             // id -> position in kfs
+  std::unordered_map<int64_t, std::array<double, 7>> departed;   // poses of frames that left the window (for ToWorld)
+  std::vector<Lm> lms;
+  std::unordered_map<int64_t, int> lm_index;
+  // device side, persistent across ticks
+  lvf_state* st = nullptr;
+  lvf_batch *tc = nullptr, *tf = nullptr, *po = nullptr, *imu = nullptr, *prior = nullptr;
+  lvf_problem* prob = nullptr;
+  // assembly of the last solve
+  std::vector<int> slot_lm;                              // dense landmark slot -> index into lms
+  int n_tc = 0, n_tf = 0, n_po = 0, n_imu = 0, n_prior = 0;
+  ~lvf_window() {
+    if (prob) lvf_problem_destroy(prob);
+    for (lvf_batch* b : {tc, tf, po, imu, prior}) if (b) lvf_batch_destroy(b);
+    if (st) lvf_state_destroy(st);
+  }
+};
+
+namespace lvf {
+
+// Landmark::ToWorld (src/lvio_fusion/src/landmark.cpp:15-19): Pixel2Robot through the RIGHT camera, then the birth pose
+static void to_world(const lvf_camera& right, const double rob[2], double inv_depth, const double birth_pose[7], double pw[3]) {
+  const double d = 1.0 / inv_depth;
+  const double ps[3] = {(rob[0] - right.cx) * d / right.fx, (rob[1] - right.cy) * d / right.fy, d};
+  double pb[3], r[3];
+  hse3::rotate(right.extrinsic, ps, pb);
+  for (int k = 0; k < 3; ++k) pb[k] += right.extrinsic[4 + k];
+  hse3::rotate(birth_pose, pb, r);
+  for (int k = 0; k < 3; ++k) pw[k] = r[k] + birth_pose[4 + k];
+}
+template <typename T>
+static int put(DevBuf<T>& buf, const std::vector<T>& v, hipStream_t s) { return buf.assign(v.data(), v.size(), s); }
+
+}  // namespace lvf
+
+using namespace lvf;
+
+extern "C" {
+
+void lvf_window_options_default(lvf_window_options* o) {
+  if (!o) return;
+  o->baseline = 0.537;                 // |t_cam1 - t_cam0| of the KITTI rig (config/kitti.yaml); Camera::baseline
+  o->weak_visual_threshold = 20;       // backend.cpp:166
+  o->prior_weight = 100.0; o->prior_v = 0.0;   // backend.cpp:170,175
+}
+
+int lvf_window_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera* right, const lvf_window_options* opt, lvf_window** out) {
+  LVF_REQUIRE(ctx && left && right && out, "lvf_window_create: null argument");
+  auto* w = new lvf_window();
+  w->ctx = ctx; w->left = *left; w->right = *right;
+  if (opt) w->opt = *opt; else lvf_window_options_default(&w->opt);
+  *out = w;
+  return LVF_OK;
+}
+int lvf_window_destroy(lvf_window* w) { delete w; return LVF_OK; }
+
+int lvf_window_add_keyframe(lvf_window* w, int64_t kf_id, const double* pose7, double w_visual) {
+  LVF_REQUIRE(w && pose7, "lvf_window_add_keyframe: null argument");
+  LVF_REQUIRE(w->kfs.empty() || kf_id > w->kfs.back().id, "lvf_window_add_keyframe: keyframe ids must increase (got %lld after %lld)", (long long)kf_id,
+              (long long)(w->kfs.empty() ? 0 : w->kfs.back().id));
+  lvf_window::Kf k;
+  k.id = kf_id; std::memcpy(k.pose, pose7, 56); k.w_visual = w_visual;
+  w->kf_index[kf_id] = (int)w->kfs.size();
+  w->kfs.push_back(std::move(k));
+  return LVF_OK;
+}
+int lvf_window_set_imu(lvf_window* w, int64_t kf_id, const double* vel3, const double* ba3, const double* bg3, const lvf_preint* pre) {
+  LVF_REQUIRE(w && vel3 && ba3 && bg3, "lvf_window_set_imu: null argument");
+  auto it = w->kf_index.find(kf_id);
+  LVF_REQUIRE(it != w->kf_index.end(), "lvf_window_set_imu: keyframe %lld is not in the window", (long long)kf_id);
+  lvf_window::Kf& k = w->kfs[it->second];
+  std::memcpy(k.vel, vel3, 24); std::memcpy(k.ba, ba3, 24); std::memcpy(k.bg, bg3, 24);
+  k.good_imu = true; k.has_pre = pre != nullptr;
+  if (pre) k.pre = *pre;
+  return LVF_OK;
+}
+int lvf_window_add_landmark(lvf_window* w, int64_t lm_id, int64_t birth_kf_id, const double* left_ob2, const double* right_ob2, double inv_depth) {
+  LVF_REQUIRE(w && left_ob2 && right_ob2, "lvf_window_add_landmark: null argument");
+  LVF_REQUIRE(!w->lm_index.count(lm_id), "lvf_window_add_landmark: landmark %lld exists", (long long)lm_id);
+  auto it = w->kf_index.find(birth_kf_id);
+  LVF_REQUIRE(it != w->kf_index.end(), "lvf_window_add_landmark: birth keyframe %lld is not in the window", (long long)birth_kf_id);
+  LVF_REQUIRE(inv_depth != 0.0, "lvf_window_add_landmark: zero inverse depth");
+  lvf_window::Lm l;
+  l.id = lm_id; l.birth_kf = birth_kf_id; l.inv_depth = inv_depth;
+  std::memcpy(l.left_ob, left_ob2, 16); std::memcpy(l.right_ob, right_ob2, 16);
+  const int idx = (int)w->lms.size();
+  w->lm_index[lm_id] = idx;
+  w->lms.push_back(l);
+  // the landmark's own left feature in its birth frame (features_left[lm] of the first frame -> the TwoCamera block)
+  lvf_window::Obs o; o.lm_id = lm_id; o.lm = idx; o.ob[0] = left_ob2[0]; o.ob[1] = left_ob2[1];
+  w->kfs[it->second].put(o);
+  return LVF_OK;
+}
+int lvf_window_add_observation(lvf_window* w, int64_t lm_id, int64_t kf_id, const double* ob2) {
+  LVF_REQUIRE(w && ob2, "lvf_window_add_observation: null argument");
+  auto il = w->lm_index.find(lm_id);
+  LVF_REQUIRE(il != w->lm_index.end(), "lvf_window_add_observation: unknown landmark %lld", (long long)lm_id);
+  auto ik = w->kf_index.find(kf_id);
+  LVF_REQUIRE(ik != w->kf_index.end(), "lvf_window_add_observation: keyframe %lld is not in the window", (long long)kf_id);
+  LVF_REQUIRE(w->lms[il->second].birth_kf < kf_id, "lvf_window_add_observation: observation in or before the birth frame");
+  lvf_window::Obs o; o.lm_id = lm_id; o.lm = il->second; o.ob[0] = ob2[0]; o.ob[1] = ob2[1];
+  w->kfs[ik->second].put(o);
+  return LVF_OK;
+}
+int lvf_window_remove_observation(lvf_window* w, int64_t lm_id, int64_t kf_id) {
+  LVF_REQUIRE(w, "lvf_window_remove_observation: null window");
+  auto ik = w->kf_index.find(kf_id);
+  LVF_REQUIRE(ik != w->kf_index.end(), "lvf_window_remove_observation: keyframe %lld is not in the window", (long long)kf_id);
+  auto& v = w->kfs[ik->second].obs;
+  v.erase(std::remove_if(v.begin(), v.end(), [&](const lvf_window::Obs& o) { return o.lm_id == lm_id; }), v.end());
+  return LVF_OK;
+}
+
+// Map::GetKeyFrames(finished) (src/map.cpp:49-55): frames older than first_active_kf_id leave the problem.  Landmarks born in a
+// departing frame keep their world point at the departing frame's final pose and their last inverse depth (they become
+// PoseOnly blocks, backend.cpp:126-131).
+int lvf_window_slide(lvf_window* w, int64_t first_active_kf_id) {
+  LVF_REQUIRE(w, "lvf_window_slide: null window");
+  size_t drop = 0;
+  while (drop < w->kfs.size() && w->kfs[drop].id < first_active_kf_id) ++drop;
+  if (drop == 0) return LVF_OK;
+  for (size_t k = 0; k < drop; ++k) {
+    std::array<double, 7> p;
+    std::memcpy(p.data(), w->kfs[k].pose, 56);
+    w->departed[w->kfs[k].id] = p;
+  }
+  for (lvf_window::Lm& l : w->lms)
+    if (!l.fixed && l.birth_kf < first_active_kf_id) {
+      auto it = w->departed.find(l.birth_kf);
+      if (it != w->departed.end()) { to_world(w->right, l.right_ob, l.inv_depth, it->second.data(), l.pw); l.fixed = true; }
+    }
+  w->kfs.erase(w->kfs.begin(), w->kfs.begin() + drop);
+  w->kf_index.clear();
+  for (size_t k = 0; k < w->kfs.size(); ++k) w->kf_index[w->kfs[k].id] = (int)k;
+  return LVF_OK;
+}
+
+int lvf_window_set_pose(lvf_window* w, int64_t kf_id, const double* pose7) {
+  LVF_REQUIRE(w && pose7, "lvf_window_set_pose: null argument");
+  auto ik = w->kf_index.find(kf_id);
+  LVF_REQUIRE(ik != w->kf_index.end(), "lvf_window_set_pose: keyframe %lld is not in the window", (long long)kf_id);
+  std::memcpy(w->kfs[ik->second].pose, pose7, 56);
+  return LVF_OK;
+}
+int lvf_window_get_pose(const lvf_window* w, int64_t kf_id, double* pose7) {
+  LVF_REQUIRE(w && pose7, "lvf_window_get_pose: null argument");
+  auto ik = w->kf_index.find(kf_id);
+  if (ik != w->kf_index.end()) { std::memcpy(pose7, w->kfs[ik->second].pose, 56); return LVF_OK; }
+  auto id = w->departed.find(kf_id);
+  LVF_REQUIRE(id != w->departed.end(), "lvf_window_get_pose: unknown keyframe %lld", (long long)kf_id);
+  std::memcpy(pose7, id->second.data(), 56);
+  return LVF_OK;
+}
+int lvf_window_get_imu(const lvf_window* w, int64_t kf_id, double* vel3, double* ba3, double* bg3) {
+  LVF_REQUIRE(w, "lvf_window_get_imu: null window");
+  auto ik = w->kf_index.find(kf_id);
+  LVF_REQUIRE(ik != w->kf_index.end(), "lvf_window_get_imu: keyframe %lld is not in the window", (long long)kf_id);
+  const lvf_window::Kf& k = w->kfs[ik->second];
+  if (vel3) std::memcpy(vel3, k.vel, 24);
+  if (ba3) std::memcpy(ba3, k.ba, 24);
+  if (bg3) std::memcpy(bg3, k.bg, 24);
+  return LVF_OK;
+}
+int lvf_window_get_inv_depth(const lvf_window* w, int64_t lm_id, double* inv_depth) {
+  LVF_REQUIRE(w && inv_depth, "lvf_window_get_inv_depth: null argument");
+  auto il = w->lm_index.find(lm_id);
+  LVF_REQUIRE(il != w->lm_index.end(), "lvf_window_get_inv_depth: unknown landmark %lld", (long long)lm_id);
+  *inv_depth = w->lms[il->second].inv_depth;
+  return LVF_OK;
+}
+int lvf_window_counts(const lvf_window* w, int32_t* counts8) {
+  LVF_REQUIRE(w && counts8, "lvf_window_counts: null argument");
+  counts8[0] = (int)w->kfs.size(); counts8[1] = (int)w->slot_lm.size(); counts8[2] = w->n_tc; counts8[3] = w->n_tf; counts8[4] = w->n_po;
+  counts8[5] = w->n_imu; counts8[6] = w->n_prior; counts8[7] = (int)w->lms.size();
+  return LVF_OK;
+}
+
+int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summary* summary) {
+  LVF_REQUIRE(w && o && summary, "lvf_window_solve: null argument");
+  LVF_REQUIRE(!w->kfs.empty(), "lvf_window_solve: empty window");
+  lvf_ctx* ctx = w->ctx;
+  LVF_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int n_kf = (int)w->kfs.size();
+  // ---- assemble the block lists in BuildProblem's order
+  std::vector<double> tc_l, tc_r, tf_f, tf_o, po_o, po_pw, pr_t, pr_w, pr_v;
+  std::vector<int32_t> tc_lm, tc_kf, tf_lm, tf_k1, tf_k2, po_kf, po_pi, imu_i, imu_j, pr_a, pr_b;
+  std::vector<lvf_preint> imu_pre;
+  for (lvf_window::Lm& l : w->lms) l.slot = -1;
+  w->slot_lm.clear();
+  auto slot_of = [&](int lm) {
+    lvf_window::Lm& l = w->lms[lm];
+    if (l.slot < 0) { l.slot = (int)w->slot_lm.size(); w->slot_lm.push_back(lm); }
+    return l.slot;
+  };
+  // landmark->ToWorld() once per live landmark per tick (the reference recomputes it per feature), and per frame the one row of
+  // the world->cam0 transform that Camera::Far needs
+  std::vector<double> lm_pw((size_t)3 * w->lms.size());
+  std::vector<int> lm_birth_pos(w->lms.size(), -1);
+  for (size_t i = 0; i < w->lms.size(); ++i) {
+    const lvf_window::Lm& l = w->lms[i];
+    if (l.fixed) { std::memcpy(&lm_pw[3 * i], l.pw, 24); continue; }
+    auto ib = w->kf_index.find(l.birth_kf);
+    if (ib == w->kf_index.end()) continue;
+    lm_birth_pos[i] = ib->second;
+    to_world(w->right, l.right_ob, l.inv_depth, w->kfs[ib->second].pose, &lm_pw[3 * i]);
+  }
+  double inv_e[7];
+  hse3::inv(w->left.extrinsic, inv_e);
+  const double far_z = w->opt.baseline * 50.0;
+  for (int k = 0; k < n_kf; ++k) {
+    lvf_window::Kf& f = w->kfs[k];
+    f.sort_unique();
+    // z_cam(pw) = zrow . pw + zoff  with  pc = R_e^-1 (R_wc^-1 pw + t_inv) + t_e_inv
+    double inv_pose[7], zrow[3], zoff;
+    hse3::inv(f.pose, inv_pose);
+    {
+      double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0}, ez[3] = {0, 0, 1}, c0[3], c1[3], c2[3], t[3], r[3];
+      hse3::rotate(inv_pose, ex, r); hse3::rotate(inv_e, r, c0);
+      hse3::rotate(inv_pose, ey, r); hse3::rotate(inv_e, r, c1);
+      hse3::rotate(inv_pose, ez, r); hse3::rotate(inv_e, r, c2);
+      zrow[0] = c0[2]; zrow[1] = c1[2]; zrow[2] = c2[2];
+      hse3::rotate(inv_e, inv_pose + 4, t);
+      zoff = t[2] + inv_e[6];
+    }
+    int near_visual = 0;
+    for (const lvf_window::Obs& ob : f.obs) {
+      lvf_window::Lm& l = w->lms[ob.lm];
+      if (l.birth_kf == f.id) {
+        tc_l.insert(tc_l.end(), ob.ob, ob.ob + 2); tc_r.insert(tc_r.end(), l.right_ob, l.right_ob + 2);
+        tc_lm.push_back(slot_of(ob.lm)); tc_kf.push_back(k);
+        continue;
+      }
+      const double* pw = &lm_pw[(size_t)3 * ob.lm];
+      const int bpos = lm_birth_pos[ob.lm];
+      if (bpos < 0) {
+        if (!l.fixed) continue;                        // birth frame unknown (never happens through this API)
+        po_o.insert(po_o.end(), ob.ob, ob.ob + 2); po_pw.insert(po_pw.end(), pw, pw + 3);
+        po_pi.push_back((int)po_kf.size()); po_kf.push_back(k);
+      } else {
+        tf_f.insert(tf_f.end(), l.right_ob, l.right_ob + 2); tf_o.insert(tf_o.end(), ob.ob, ob.ob + 2);
+        tf_lm.push_back(slot_of(ob.lm)); tf_k1.push_back(bpos); tf_k2.push_back(k);
+      }
+      if (!(zrow[0] * pw[0] + zrow[1] * pw[1] + zrow[2] * pw[2] + zoff > far_z)) ++near_visual;   // !Camera::Far
+    }
+    bool imu_block = false;
+    if (f.good_imu && k > 0 && w->kfs[k - 1].good_imu && f.has_pre) {
+      imu_pre.push_back(f.pre); imu_i.push_back(k - 1); imu_j.push_back(k);
+      imu_block = true;
+    }
+    if (!imu_block && near_visual < w->opt.weak_visual_threshold) {
+      double t7[7] = {0, 0, 0, 0, 0, 0, 0};
+      if (k > 0) { LVF_TRY(lvf_relative_rpyxyz(w->kfs[k - 1].pose, f.pose, t7)); pr_a.push_back(k - 1); }
+      else { std::memcpy(t7, f.pose, 56); pr_a.push_back(-1); }
+      pr_b.push_back(k); pr_t.insert(pr_t.end(), t7, t7 + 7); pr_w.push_back(w->opt.prior_weight); pr_v.push_back(w->opt.prior_v);
+    }
+  }
+  const int n_lm = (int)w->slot_lm.size();
+  w->n_tc = (int)tc_lm.size(); w->n_tf = (int)tf_lm.size(); w->n_po = (int)po_kf.size(); w->n_imu = (int)imu_i.size(); w->n_prior = (int)pr_b.size();
+
+  // ---- persistent device objects: created once (empty), re-filled every tick through grow-only buffers
+  if (!w->st) {
+    LVF_TRY(lvf_state_create(ctx, 0, 0, &w->st));
+    const double z2[2] = {0, 0}; const int32_t z = 0; const double id7[7] = {0, 0, 0, 1, 0, 0, 0};
+    LVF_TRY(lvf_two_camera_create(ctx, &w->left, &w->right, 0, z2, z2, &z, &z, &w->tc));
+    LVF_TRY(lvf_two_frame_create(ctx, &w->left, &w->right, 0, z2, z2, &z, &z, &z, &w->tf));
+    LVF_TRY(lvf_pose_only_create(ctx, &w->left, 0, z2, &z, &z, 0, id7, &w->po));
+    LVF_TRY(lvf_imu_create(ctx, 0, nullptr, nullptr, nullptr, &w->imu));
+    LVF_TRY(lvf_pose_prior_create(ctx, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &w->prior));
+  }
+  lvf_state* st = w->st;
+  st->n_kf = n_kf; st->n_lm = n_lm;
+  std::vector<double> poses((size_t)7 * n_kf), vel((size_t)3 * n_kf), ba(vel), bg(vel), wv(n_kf), invd(n_lm);
+  for (int k = 0; k < n_kf; ++k) {
+    const lvf_window::Kf& f = w->kfs[k];
+    std::memcpy(&poses[(size_t)7 * k], f.pose, 56); std::memcpy(&vel[(size_t)3 * k], f.vel, 24); std::memcpy(&ba[(size_t)3 * k], f.ba, 24);
+    std::memcpy(&bg[(size_t)3 * k], f.bg, 24); wv[k] = f.w_visual;
+  }
+  for (int l = 0; l < n_lm; ++l) invd[l] = w->lms[w->slot_lm[l]].inv_depth;
+  LVF_TRY(put(st->poses, poses, s)); LVF_TRY(put(st->vel, vel, s)); LVF_TRY(put(st->ba, ba, s)); LVF_TRY(put(st->bg, bg, s));
+  LVF_TRY(put(st->w_visual, wv, s)); LVF_TRY(put(st->inv_depth, invd, s));
+  auto idx_ok = [](lvf_batch* b, int n, int nkf, int nlm) { b->n = n; b->min_n_kf = nkf; b->min_n_lm = nlm; b->evaluated = false; };
+  LVF_TRY(put(w->tc->ob_a, tc_l, s)); LVF_TRY(put(w->tc->ob_b, tc_r, s)); LVF_TRY(put(w->tc->idx_a, tc_lm, s)); LVF_TRY(put(w->tc->idx_b, tc_kf, s));
+  idx_ok(w->tc, w->n_tc, n_kf, n_lm);
+  LVF_TRY(put(w->tf->ob_a, tf_f, s)); LVF_TRY(put(w->tf->ob_b, tf_o, s)); LVF_TRY(put(w->tf->idx_a, tf_lm, s)); LVF_TRY(put(w->tf->idx_b, tf_k1, s));
+  LVF_TRY(put(w->tf->idx_c, tf_k2, s));
+  idx_ok(w->tf, w->n_tf, n_kf, n_lm);
+  w->tf->sorted_by_kf = true; w->tf->host_kf1 = tf_k1; w->tf->host_kf2 = tf_k2;     // assembled frame by frame: sorted by current keyframe
+  LVF_TRY(put(w->po->ob_a, po_o, s)); LVF_TRY(put(w->po->idx_a, po_kf, s)); LVF_TRY(put(w->po->idx_b, po_pi, s)); LVF_TRY(put(w->po->table, po_pw, s));
+  idx_ok(w->po, w->n_po, n_kf, 0); w->po->n_table = w->n_po; w->po->sorted_by_kf = true;
+  {
+    lvf_batch* b = w->imu;
+    LVF_TRY(b->pre.assign(reinterpret_cast<const double*>(imu_pre.data()), (size_t)467 * w->n_imu, s));
+    LVF_TRY(put(b->idx_a, imu_i, s)); LVF_TRY(put(b->idx_b, imu_j, s));
+    LVF_TRY(b->sqrt_info.ensure((size_t)225 * w->n_imu)); LVF_TRY(b->res.ensure((size_t)15 * w->n_imu));
+    for (int q = 0; q < 8; ++q) LVF_TRY(b->jac[q].ensure((size_t)15 * b->block_size[q] * w->n_imu));
+    idx_ok(b, w->n_imu, n_kf, 0);
+    LVF_TRY(launch_imu_sqrt_info(b));
+  }
+  {
+    lvf_batch* b = w->prior;
+    LVF_TRY(put(b->idx_a, pr_a, s)); LVF_TRY(put(b->idx_b, pr_b, s)); LVF_TRY(put(b->table, pr_t, s)); LVF_TRY(put(b->ob_a, pr_w, s)); LVF_TRY(put(b->ob_b, pr_v, s));
+    LVF_TRY(b->res.ensure((size_t)6 * w->n_prior)); LVF_TRY(b->jac[0].ensure((size_t)42 * w->n_prior)); LVF_TRY(b->jac[1].ensure((size_t)42 * w->n_prior));
+    idx_ok(b, w->n_prior, n_kf, 0);
+    b->host_kf1 = pr_a; b->host_kf2 = pr_b;
+  }
+  if (!w->prob) {
+    LVF_TRY(lvf_problem_create(ctx, st, w->tc, w->tf, w->po, w->imu, &w->prob));
+    LVF_TRY(lvf_problem_set_pose_priors(w->prob, w->prior));
+  } else {
+    LVF_TRY(problem_configure(w->prob));
+  }
+  LVF_TRY(lvf_problem_solve(w->prob, o, summary));
+  // ---- read the solution back into the host mirror (frame->pose, Vw, biases, landmark->inv_depth)
+  LVF_HIP(hipMemcpyAsync(poses.data(), st->poses.p, poses.size() * 8, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipMemcpyAsync(vel.data(), st->vel.p, vel.size() * 8, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipMemcpyAsync(ba.data(), st->ba.p, ba.size() * 8, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipMemcpyAsync(bg.data(), st->bg.p, bg.size() * 8, hipMemcpyDeviceToHost, s));
+  if (n_lm) LVF_HIP(hipMemcpyAsync(invd.data(), st->inv_depth.p, invd.size() * 8, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  for (int k = 0; k < n_kf; ++k) {
+    lvf_window::Kf& f = w->kfs[k];
+    std::memcpy(f.pose, &poses[(size_t)7 * k], 56);
+    if (f.good_imu) { std::memcpy(f.vel, &vel[(size_t)3 * k], 24); std::memcpy(f.ba, &ba[(size_t)3 * k], 24); std::memcpy(f.bg, &bg[(size_t)3 * k], 24); }
+  }
+  for (int l = 0; l < n_lm; ++l) w->lms[w->slot_lm[l]].inv_depth = invd[l];
+  return LVF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""The persistent sliding window (lvf_window_*) replayed tick by tick over a synthetic drive, against the
+same ticks assembled FROM SCRATCH each time with Backend::BuildProblem's rules (src/lvio_fusion/src/backend.cpp:96-183) in
+python and solved through the flat batch API.  Both run the same kernels, so the comparison pins the incremental
+bookkeeping: block sets and order, TwoFrame -> PoseOnly conversion when a birth frame leaves, the Far / weak-prior rule."""
+import numpy as np
+import pytest
+
+from lvio_fusion_amd import synthetic as syn
+from tests.helpers import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def to_world(right, rob, inv_depth, pose):
+    d = 1.0 / inv_depth
+    ps = np.array([(rob[0] - right["cx"]) * d / right["fx"], (rob[1] - right["cy"]) * d / right["fy"], d])
+    return syn.se3_apply(pose, syn.se3_apply(right["extrinsic"], ps))
+
+
+def is_far(cam0, baseline, pw, pose):
+    pc = syn.se3_apply(syn.se3_inv(cam0["extrinsic"]), syn.se3_apply(syn.se3_inv(pose), pw))
+    return pc[2] > 50.0 * baseline
+
+
+@pytest.mark.parametrize("with_imu,weak_thr", [(True, 20), (False, 10 ** 6), (False, 8)])
+def test_ticks_match_from_scratch_assembly(oracle, with_imu, weak_thr):
+    from lvio_fusion_amd import api
+    N, W, max_it = 12, 6, 3
+    cfg = syn.config4_window(n_kf=N, n_lm=150, n_prewindow=0, seed=606, imu_samples=4)
+    cam0, cam1 = cfg["cam0"], cfg["cam1"]
+    baseline = syn.baseline()
+    tc, tf = cfg["tc"], cfg["tf"]
+    pre = [oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]]
+    ctx = api.Context(0)
+    win = api.Window(ctx, cam0, cam1, baseline=baseline, weak_visual_threshold=weak_thr)
+    opt = api.default_solver_options(); opt.max_num_iterations = max_it
+    # ---- from-scratch mirror state
+    pose = {}; vel = {}; ba = {}; bg = {}; invd = {}; departed = {}; fixed_pw = {}
+    obs = {k: {} for k in range(N)}          # kf -> {lm: ob}
+    birth = {int(l): int(k) for l, k in zip(tc["lm_idx"], tc["kf_idx"])}
+    right_ob = {int(l): tc["right_ob"][i] for i, l in enumerate(tc["lm_idx"])}
+    left_ob = {int(l): tc["left_ob"][i] for i, l in enumerate(tc["lm_idx"])}
+    seen_po = seen_prior = 0
+    for t in range(N):
+        # front-end adds keyframe t, its IMU state, the landmarks it triangulated and its observations of older landmarks
+        win.add_keyframe(100 + t, cfg["poses"][t], cfg["w_kf"][t]); pose[t] = cfg["poses"][t].copy()
+        if with_imu:
+            win.set_imu(100 + t, cfg["vel"][t], cfg["ba"][t], cfg["bg"][t], pre[t - 1] if t > 0 else None)
+            vel[t], ba[t], bg[t] = cfg["vel"][t].copy(), cfg["ba"][t].copy(), cfg["bg"][t].copy()
+        for l in sorted(l for l, k in birth.items() if k == t):
+            win.add_landmark(5000 + l, 100 + t, left_ob[l], right_ob[l], cfg["inv_depth"][l]); invd[l] = float(cfg["inv_depth"][l])
+            obs[t][l] = left_ob[l]
+        for i in np.nonzero(tf["kf2_idx"] == t)[0]:
+            l = int(tf["lm_idx"][i])
+            win.add_observation(5000 + l, 100 + t, tf["ob"][i]); obs[t][l] = tf["ob"][i]
+        first = max(0, t - W + 1)
+        win.slide(100 + first)
+        for k in [k for k in pose if k < first and k not in departed]:
+            departed[k] = pose[k].copy()
+        for l, b in birth.items():
+            if b < first and l in invd and l not in fixed_pw:
+                fixed_pw[l] = to_world(cam1, right_ob[l], invd[l], departed[b])
+        s_win = win.solve(opt)
+
+        # ---- the same tick assembled from scratch with BuildProblem's rules
+        act = list(range(first, t + 1)); pos = {k: i for i, k in enumerate(act)}
+        slot = {}; b_tc = [[], [], [], []]; b_tf = [[], [], [], [], []]; b_po = [[], [], []]; pw_tab = []
+        pr = dict(kf_a=[], kf_b=[], target=[], weight=[], v=[]); imu_i, imu_j, imu_pre = [], [], []
+        for k in act:
+            near = 0
+            for l in sorted(obs[k]):
+                ob = obs[k][l]
+                if birth[l] == k:
+                    b_tc[0].append(ob); b_tc[1].append(right_ob[l]); b_tc[2].append(slot.setdefault(l, len(slot))); b_tc[3].append(pos[k]); continue
+                if birth[l] < first:
+                    pw = fixed_pw[l]
+                    b_po[0].append(ob); b_po[1].append(pos[k]); b_po[2].append(len(pw_tab)); pw_tab.append(pw)
+                else:
+                    pw = to_world(cam1, right_ob[l], invd[l], pose[birth[l]])
+                    b_tf[0].append(right_ob[l]); b_tf[1].append(ob); b_tf[2].append(slot.setdefault(l, len(slot))); b_tf[3].append(pos[birth[l]]); b_tf[4].append(pos[k])
+                near += 0 if is_far(cam0, baseline, pw, pose[k]) else 1
+            has_imu = with_imu and k > first
+            if has_imu:
+                imu_i.append(pos[k] - 1); imu_j.append(pos[k]); imu_pre.append(pre[k - 1])
+            if not has_imu and near < weak_thr:
+                if k > first:
+                    pr["kf_a"].append(pos[k] - 1); pr["target"].append(np.concatenate([oracle.pose_graph_target(pose[k - 1], pose[k]), [0.0]]))
+                else:
+                    pr["kf_a"].append(-1); pr["target"].append(pose[k])
+                pr["kf_b"].append(pos[k]); pr["weight"].append(100.0); pr["v"].append(0.0)
+        cnt = win.counts()
+        assert (cnt["kf"], cnt["lm"], cnt["tc"], cnt["tf"], cnt["po"], cnt["imu"], cnt["prior"]) == \
+               (len(act), len(slot), len(b_tc[2]), len(b_tf[2]), len(b_po[1]), len(imu_i), len(pr["kf_b"])), f"tick {t}: block census"
+        seen_po += len(b_po[1]); seen_prior += len(pr["kf_b"])
+        st = api.State(ctx, len(act), max(len(slot), 1))
+        st.set(api.POSES, np.array([pose[k] for k in act])); st.set(api.W_VISUAL, np.array([cfg["w_kf"][k] for k in act]))
+        if with_imu:
+            st.set(api.VEL, np.array([vel[k] for k in act])); st.set(api.BA, np.array([ba[k] for k in act])); st.set(api.BG, np.array([bg[k] for k in act]))
+        inv_arr = np.ones(max(len(slot), 1))
+        for l, sidx in slot.items():
+            inv_arr[sidx] = invd[l]
+        st.set(api.INV_DEPTH, inv_arr)
+        z2 = np.zeros((0, 2)); zi = np.zeros(0, np.int32)
+        arr = lambda x, w: np.array(x).reshape(-1, w) if len(x) else np.zeros((0, w))
+        hs = []
+        btc = api.two_camera_batch(ctx, cam0, cam1, arr(b_tc[0], 2), arr(b_tc[1], 2), np.array(b_tc[2], np.int32), np.array(b_tc[3], np.int32)); hs.append(btc)
+        btf = api.two_frame_batch(ctx, cam0, cam1, arr(b_tf[0], 2), arr(b_tf[1], 2), np.array(b_tf[2], np.int32), np.array(b_tf[3], np.int32), np.array(b_tf[4], np.int32)); hs.append(btf)
+        bpo = api.pose_only_batch(ctx, cam0, arr(b_po[0], 2), np.array(b_po[1], np.int32), np.array(b_po[2], np.int32), arr(pw_tab, 3) if pw_tab else np.zeros((1, 3))); hs.append(bpo)
+        bim = api.imu_batch(ctx, np.array(imu_pre), imu_i, imu_j) if imu_i else None
+        prob = api.Problem(ctx, st, btc, btf, bpo, bim)
+        bpr = None
+        if pr["kf_b"]:
+            bpr = api.pose_prior_batch(ctx, pr["kf_a"], pr["kf_b"], np.array(pr["target"]), pr["weight"], pr["v"]); prob.set_pose_priors(bpr)
+        s_ref = prob.solve(opt)
+        assert abs(s_win.initial_cost - s_ref.initial_cost) <= 1e-8 * abs(s_ref.initial_cost) + 1e-12, f"tick {t}: initial cost"
+        assert abs(s_win.final_cost - s_ref.final_cost) <= 1e-6 * abs(s_ref.final_cost) + 1e-12, f"tick {t}: final cost"
+        assert s_win.num_successful_steps == s_ref.num_successful_steps and s_win.num_residual_blocks == s_ref.num_residual_blocks
+        P = st.get(api.POSES).reshape(-1, 7); D = st.get(api.INV_DEPTH)
+        for k in act:
+            pose[k] = P[pos[k]].copy()
+            assert_parity(win.pose(100 + k), pose[k], f"tick {t} pose {k}")
+        for l, sidx in slot.items():
+            invd[l] = float(D[sidx])
+            assert abs(win.inv_depth(5000 + l) - invd[l]) <= 1e-6 * abs(invd[l])
+        if with_imu:
+            V, A, G = st.get(api.VEL).reshape(-1, 3), st.get(api.BA).reshape(-1, 3), st.get(api.BG).reshape(-1, 3)
+            for k in act:
+                vel[k], ba[k], bg[k] = V[pos[k]].copy(), A[pos[k]].copy(), G[pos[k]].copy()
+                wv, wa, wg = win.imu(100 + k)
+                assert_parity(wv, vel[k], f"tick {t} vel {k}")
+        for h in [prob, bim, bpr, st] + hs:
+            if h is not None:
+                h.close()
+    assert seen_po > 0, "the replay never exercised the TwoFrame -> PoseOnly conversion"
+    if not with_imu:
+        assert seen_prior > 0
+    # departed frames stay queryable (their pose anchors the frozen landmarks)
+    assert_parity(win.pose(100), departed[0], "departed pose")
+    win.close(); ctx.close()
