@@ -137,7 +137,9 @@ int lvf_lidar_plane_create(lvf_ctx* ctx, int mode, int n, const double* p, const
 /* Weak-constraint pose priors of a window (backend.cpp:164-178).  Block i with kf_a[i] >= 0 is
  * PoseGraphError<6,7,7>(Twc1 = pose[kf_a], Twc2 = pose[kf_b]) with target[i][0..6) = rpyxyz_ (pose_error.hpp:13-17,
  * see lvf_relative_rpyxyz); with kf_a[i] < 0 it is PoseError<6,7>(pose[kf_b]) with target[i][0..7) = the origin pose
- * (pose_error.hpp:55-76).  target is [n][7]; weight[n], v[n] are the functor's (weight, v) ctor arguments.
+ * (pose_error.hpp:55-76); with kf_a[i] == -2 it is RError<4,7>(pose[kf_b]) with target[i][0..4) = the stored quaternion (x,y,z,w)
+ * (pose_error.hpp:88-110; residual rows 4,5 and their Jacobian rows are zero padding).
+ * target is [n][7]; weight[n], v[n] are the functor's (weight, v) ctor arguments.
  * Parameter blocks: 0 = pose[kf_a] (all-zero Jacobian for PoseError blocks), 1 = pose[kf_b]; 6 residuals. */
 int lvf_pose_prior_create(lvf_ctx* ctx, int n, const int32_t* kf_a, const int32_t* kf_b, const double* target,
                           const double* weight, const double* v, lvf_batch** out);

@@ -63,7 +63,7 @@ inline ThreadContext& thread_context() {
   return tc;
 }
 
-enum class Kind { PoseOnly, TwoFrame, TwoCamera, Imu, LidarPlaneRPZ, LidarPlaneYXY, PoseErrorRPZ, PoseErrorYXY, PoseGraph, Pose };
+enum class Kind { PoseOnly, TwoFrame, TwoCamera, Imu, LidarPlaneRPZ, LidarPlaneYXY, PoseErrorRPZ, PoseErrorYXY, PoseGraph, Pose, R };
 
 // RAII for the C handles used inside one call
 struct Handles {
@@ -358,6 +358,38 @@ class PoseError : public ceres::SizedCostFunction<6, 7>, public GpuCostFunction 
   double weight, v;
 };
 
+// RError <4,7>  pose_error.hpp:88-110 ; Create(pose, weight) :102 — the quaternion prior of PoseGraph::BuildProblem
+// (src/pose_graph.cpp:190-191)
+class RError : public ceres::SizedCostFunction<4, 7>, public GpuCostFunction {
+ public:
+  RError(const double pose[7], double weight) : weight(weight) { std::memcpy(origin, pose, 56); }
+  static ceres::CostFunction* Create(const double pose[7], double weight = 1) { return new RError(pose, weight); }
+  Kind kind() const override { return Kind::R; }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    ThreadContext& tc = thread_context();
+    if (!tc.ctx) return false;
+    Handles h;
+    const int32_t minus2 = -2, zero = 0;
+    const double v = 0.0;
+    if (lvf_state_create(tc.ctx, 1, 0, &h.st) != LVF_OK) return false;
+    if (!detail::set_state(h.st, LVF_POSES, parameters[0])) return false;
+    lvf_batch* b = nullptr;
+    if (lvf_pose_prior_create(tc.ctx, 1, &minus2, &zero, origin, &weight, &v, &b) != LVF_OK) return false;
+    h.keep(b);
+    if (lvf_batch_evaluate(b, h.st, nullptr, jacobians != nullptr) != LVF_OK) return false;
+    double r6[6], J[42];
+    if (lvf_batch_download_residuals(b, r6) != LVF_OK) return false;
+    std::memcpy(residuals, r6, 32);                                   // rows 4,5 of the batch are padding
+    if (jacobians && jacobians[0]) {
+      if (lvf_batch_download_jacobian(b, 1, J) != LVF_OK) return false;
+      std::memcpy(jacobians[0], J, 28 * sizeof(double));
+    }
+    return true;
+  }
+  double origin[7];
+  double weight;
+};
+
 // --------------------------------------------------------------------------------------------- problem -> device
 namespace detail {
 
@@ -604,6 +636,16 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
         w->order_kind.push_back(4); w->order_idx.push_back((int)w->pr_a.size());
         w->pr_a.push_back(-1); w->pr_b.push_back(kb); w->pr_t.insert(w->pr_t.end(), f->origin, f->origin + 7);
         w->pr_w.push_back(f->weight); w->pr_v.push_back(f->v);
+        break;
+      }
+      case Kind::R: {
+        const auto* f = static_cast<const RError*>(b.g);
+        const int kb = kf_of(b.params[0]);
+        if (kb < 0) return fail(at + "pose block not registered");
+        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at + "a robust loss on RError is not supported (the reference passes NULL)");
+        w->order_kind.push_back(4); w->order_idx.push_back((int)w->pr_a.size());
+        w->pr_a.push_back(-2); w->pr_b.push_back(kb); w->pr_t.insert(w->pr_t.end(), f->origin, f->origin + 7);
+        w->pr_w.push_back(f->weight); w->pr_v.push_back(0.0);
         break;
       }
       default: return fail(at + "lidar blocks cannot be mixed into a BA window");

@@ -3,6 +3,7 @@
 // Replaces per-block ceres::AutoDiffCostFunction::Evaluate of
 //   PoseGraphError <6,7,7>   src/lvio_fusion/include/lvio_fusion/ceres/pose_error.hpp:10-53
 //   PoseError      <6,7>     pose_error.hpp:55-86
+//   RError         <4,7>     pose_error.hpp:88-110 (quaternion prior of the pose-graph problem, src/pose_graph.cpp:190-191)
 // as Backend::BuildProblem adds them to frames with no IMU factor and < 20 near visual blocks
 // (src/lvio_fusion/src/backend.cpp:164-178; weight 100, v 0).  Both chain SE3Inverse -> SE3Product -> SE3ToRpyxyz
 // (include/lvio_fusion/ceres/base.hpp:41-55, :71-78, :94-141): atan2/asin of the UN-normalised quaternion product,
@@ -66,7 +67,7 @@ __device__ __forceinline__ void se3_to_rpyxyz(const T rel[7], T out[6]) {
   out[3] = rel[4]; out[4] = rel[5]; out[5] = rel[6];
 }
 
-// One thread per prior block.  kf_a < 0: PoseError on pose kf_b with origin = target[0..7);
+// One thread per prior block.  kf_a == -2: RError on pose kf_b with q0 = target[0..4); kf_a == -1: PoseError on pose kf_b with origin = target[0..7);
 // kf_a >= 0: PoseGraphError between Twc1 = pose kf_a and Twc2 = pose kf_b with rpyxyz_ = target[0..6).
 // Outputs: res [n][6]; ja, jb [n][6][7] row-major (ja is all-zero for PoseError blocks).
 template <bool WITH_J>
@@ -80,6 +81,18 @@ __global__ __launch_bounds__(64) void k_pose_prior(int n, const int* __restrict_
   const int a = kf_a[i], b = kf_b[i];
   const double w = weight[i], v = vv[i];
   const double* tg = target + 7 * i;
+  if (a == -2) {
+    // RError <4,7> (pose_error.hpp:88-110): r_k = w (q_k - q0_k) on the four quaternion components; rows 4,5 are padding
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      res[6 * i + k] = k < 4 ? w * (poses[7 * b + k] - tg[k]) : 0.0;
+      if (WITH_J) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) { ja[(size_t)42 * i + 7 * k + c] = 0.0; jb[(size_t)42 * i + 7 * k + c] = (k < 4 && c == k) ? w : 0.0; }
+      }
+    }
+    return;
+  }
   J rp[6];
   double scale[6], offs[6], sign;
   if (a >= 0) {

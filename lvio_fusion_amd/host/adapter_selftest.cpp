@@ -212,6 +212,50 @@ static int run_lidar(const std::string& dir) {
   return summary.termination_type == ceres::FAILURE ? 1 : 0;
 }
 
+// PoseGraph::BuildProblem + Optimize's solve (src/lvio_fusion/src/pose_graph.cpp:163-208): old and start frames constant, one pose
+// per section start, PoseGraphError between consecutive poses (targets = the CURRENT relative poses, i.e. before the loop
+// correction moved the start frame), RError on every section pose, default solver options.
+static int run_posegraph(const std::string& dir) {
+  auto poses = rd<double>(dir, "poses.f64");          // [n][7]: old frame, section starts ..., start frame (already relocated)
+  auto start_before = rd<double>(dir, "start_before.f64");   // the start frame's pose before relocation (defines the last edge)
+  const int n = (int)(poses.size() / 7);
+  adapt::Problem problem;
+  ceres::LocalParameterization* lp = new ceres::ProductParameterization(new ceres::EigenQuaternionParameterization(), new ceres::IdentityParameterization(3));
+  double* para_old = &poses[0];
+  double* para_start = &poses[7 * (n - 1)];
+  problem.AddParameterBlock(para_old, 7, lp); problem.SetParameterBlockConstant(para_old);
+  problem.AddParameterBlock(para_start, 7, lp); problem.SetParameterBlockConstant(para_start);
+  double* last = para_old;
+  for (int k = 1; k < n - 1; ++k) {
+    double* para = &poses[7 * k];
+    problem.AddParameterBlock(para, 7, lp);
+    problem.AddResidualBlock(ProblemType::Other, gpu::PoseGraphError::Create(last, para), nullptr, last, para);
+    problem.AddResidualBlock(ProblemType::Other, gpu::RError::Create(para), nullptr, para);
+    last = para;
+  }
+  problem.AddResidualBlock(ProblemType::Other, gpu::PoseGraphError::Create(last, start_before.data()), nullptr, last, para_start);
+  // RError::Evaluate spot check on a perturbed pose
+  std::vector<double> probe;
+  {
+    ceres::CostFunction* cf = gpu::RError::Create(&poses[7], 3.0);
+    double x[7]; for (int k = 0; k < 7; ++k) x[k] = poses[7 + k] + 0.01 * (k + 1);
+    double* xp[1] = {x}; double r[4], J[28]; double* Jp[1] = {J};
+    if (!cf->Evaluate(xp, r, Jp)) { std::fprintf(stderr, "RError Evaluate failed: %s\n", lvf_last_error()); return 1; }
+    probe.insert(probe.end(), r, r + 4); probe.insert(probe.end(), J, J + 28);
+    delete cf;
+  }
+  wr(dir, "out_probe.f64", probe);
+  ceres::Solver::Options options;
+  options.linear_solver_type = ceres::SPARSE_NORMAL_CHOLESKY;
+  ceres::Solver::Summary summary;
+  adapt::Solve(options, &problem, &summary);
+  wr(dir, "out_poses.f64", poses);
+  std::printf("{\"ok\": %d, \"message\": \"%s\", \"initial_cost\": %.17g, \"final_cost\": %.17g, \"successful\": %d, \"unsuccessful\": %d, \"num_residual_blocks\": %d}\n",
+              summary.termination_type != ceres::FAILURE, summary.message.c_str(), summary.initial_cost, summary.final_cost, summary.num_successful_steps,
+              summary.num_unsuccessful_steps, summary.num_residual_blocks_reduced);
+  return summary.termination_type == ceres::FAILURE ? 1 : 0;
+}
+
 // a cost function the adapter does not own must be refused softly (parameters untouched, FAILURE reported)
 struct Foreign : ceres::SizedCostFunction<1, 1> {
   bool Evaluate(double const* const* p, double* r, double** J) const override { r[0] = p[0][0]; if (J && J[0]) J[0][0] = 1; return true; }
@@ -229,9 +273,10 @@ static int run_foreign() {
 
 int main(int argc, char** argv) {
   if (argc >= 2 && std::string(argv[1]) == "foreign") return run_foreign();
-  if (argc < 3) { std::fprintf(stderr, "usage: %s window|lidar <dir> | foreign\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s window|lidar|posegraph <dir> | foreign\n", argv[0]); return 2; }
   const std::string mode = argv[1];
   if (mode == "window") return run_window(argv[2]);
   if (mode == "lidar") return run_lidar(argv[2]);
+  if (mode == "posegraph") return run_posegraph(argv[2]);
   return 2;
 }

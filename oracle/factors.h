@@ -186,6 +186,12 @@ inline void PosePriorResidual(const double origin_[7], double weight, double v, 
   r[5] = T(weight) * rpyxyz[5];
 }
 
+// RError::operator()  pose_error.hpp:93-100   <4,7>
+template <typename T>
+inline void RErrorResidual(const double origin_[7], double weight, const T* pose, T* r) {
+  for (int k = 0; k < 4; ++k) r[k] = T(weight) * (pose[k] - T(origin_[k]));
+}
+
 // PoseErrorRPZ::operator() pose_error.hpp:147-153 (params p,r,z; note residual order r,p,z)
 // PoseErrorYXY::operator() pose_error.hpp:175-181
 template <typename T>

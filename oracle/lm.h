@@ -34,7 +34,7 @@ struct Window {
   int n_po; const double *po_ob; const int *po_kf, *po_pw; const double* po_pwtab;
   int n_imu; const imu::Preint* pre; const int *imu_i, *imu_j;
   const unsigned char* pose_const;  // may be null
-  // weak-constraint priors (backend.cpp:164-178): prior_a[i] < 0 -> PoseError(origin = prior_target[i][0..7)) on pose prior_b[i];
+  // weak-constraint priors (backend.cpp:164-178): prior_a[i] == -2 -> RError (pose_graph.cpp:190), prior_a[i] == -1 -> PoseError(origin = prior_target[i][0..7)) on pose prior_b[i];
   // else PoseGraphError(pose prior_a[i], pose prior_b[i]) with rpyxyz_ = prior_target[i][0..6).  No loss function.
   int n_prior = 0; const int *prior_a = nullptr, *prior_b = nullptr; const double *prior_target = nullptr, *prior_w = nullptr, *prior_v = nullptr;
 };
@@ -83,7 +83,9 @@ inline double window_cost(const Window& w, double huber_a, const double* poses, 
   }
   for (int i = 0; i < w.n_prior; ++i) {
     double r[6];
+    for (int k = 0; k < 6; ++k) r[k] = 0.0;
     if (w.prior_a[i] >= 0) PoseGraphResidual<double>(w.prior_target + 7 * i, w.prior_w[i], w.prior_v[i], poses + 7 * w.prior_a[i], poses + 7 * w.prior_b[i], r);
+    else if (w.prior_a[i] == -2) RErrorResidual<double>(w.prior_target + 7 * i, w.prior_w[i], poses + 7 * w.prior_b[i], r);
     else PosePriorResidual<double>(w.prior_target + 7 * i, w.prior_w[i], w.prior_v[i], poses + 7 * w.prior_b[i], r);
     for (int k = 0; k < 6; ++k) cost += 0.5 * r[k] * r[k];
   }
@@ -198,7 +200,8 @@ inline void window_linearize(const Window& w, double huber_a, Linearization& L) 
     } else {
       Jet<7> P[7], rr[6];
       for (int k = 0; k < 7; ++k) P[k] = Jet<7>(w.poses[7 * b + k], k);
-      PosePriorResidual(w.prior_target + 7 * i, w.prior_w[i], w.prior_v[i], P, rr);
+      if (a == -2) RErrorResidual(w.prior_target + 7 * i, w.prior_w[i], P, rr);   // rows 4,5 stay zero
+      else PosePriorResidual(w.prior_target + 7 * i, w.prior_w[i], w.prior_v[i], P, rr);
       for (int k = 0; k < 6; ++k) { r[k] = rr[k].a; for (int c = 0; c < 7; ++c) Jb[7 * k + c] = rr[k].v[c]; }
     }
     for (int k = 0; k < 6; ++k) cost += 0.5 * r[k] * r[k];

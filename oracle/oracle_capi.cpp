@@ -161,6 +161,12 @@ void lvo_pose_prior_eval(const double* origin, double weight, double v, const do
   PosePriorResidual(origin, weight, v, T, rr);
   for (int a = 0; a < 6; ++a) { r[a] = rr[a].a; if (J) for (int k = 0; k < 7; ++k) J[7 * a + k] = rr[a].v[k]; }
 }
+void lvo_r_error_eval(const double* origin, double weight, const double* pose, double* r, double* J) {
+  Jet<7> T[7], rr[4];
+  for (int k = 0; k < 7; ++k) T[k] = Jet<7>(pose[k], k);
+  RErrorResidual(origin, weight, T, rr);
+  for (int a = 0; a < 4; ++a) { r[a] = rr[a].a; if (J) for (int k = 0; k < 7; ++k) J[7 * a + k] = rr[a].v[k]; }
+}
 void lvo_prior3_eval(int mode, const double* rpyxyz0, double weight, const double* rpyxyz, double* r, double* J) {
   if (mode == 0) PriorRpzResidual<double>(rpyxyz0, weight, rpyxyz + 1, rpyxyz + 2, rpyxyz + 5, r);
   else PriorYxyResidual<double>(rpyxyz0, weight, rpyxyz + 0, rpyxyz + 3, rpyxyz + 4, r);

@@ -152,6 +152,13 @@ def pose_prior(origin, weight, v, pose):
     return r, J
 
 
+def r_error(origin, weight, pose):
+    o, p = _f64(origin), _f64(pose)
+    r = np.empty(4); J = np.empty((4, 7))
+    lib().lvo_r_error_eval(_p(o), C.c_double(weight), _p(p), _p(r), _p(J))
+    return r, J
+
+
 def prior3(mode, rpyxyz0, weight, rpyxyz):
     a, b = _f64(rpyxyz0), _f64(rpyxyz)
     r = np.empty(3); J = np.empty((3, 3))
