@@ -127,24 +127,47 @@ def main():
         }
 
     # ---- extra legs + CPU baseline: rank 0, single-GPU runs only (keeps multi-GPU runs short)
+    # (every optional leg is fenced: a failure there must never take the headline line down with it)
     if rank == 0 and world == 1 and not args.no_extras:
-        out["extras"] = extras(api, syn, ctx)
+        try:
+            out["extras"] = extras(api, syn, ctx)
+        except Exception as e:
+            out["extras"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, n_blocks)
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, n_blocks)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
     # configs[4] on N GPUs: 8 loop-closure candidates sharded rank-round-robin, one all_gather of the records over RCCL
     if world > 1 and not args.no_extras:
         from lvio_fusion_amd import relocalize as rl
-        cands = syn.config5_candidates(8)
-        rl.evaluate_candidate(api, ctx, cands[rank % 8])      # warm-up
+        err = None
+        table = rl.empty_records(rl.slots(8, world))
+        dt = 0.0
+        cands = None
+        try:        # the local (per-GPU) parts may fail without desynchronising the ranks: barriers and the collective always run
+            cands = syn.config5_candidates(8)
+            rl.evaluate_candidate(api, ctx, cands[rank % 8])      # warm-up
+        except Exception as e:
+            err = repr(e)
         barrier()
         t0 = time.perf_counter()
-        best, rec = rl.relocalize(api, ctx, cands, rank=rank, world=world, device=torch.device("cuda", local_rank))
+        try:
+            if cands is not None:
+                for s_, cid in enumerate(rl.owned(8, rank, world)):
+                    res = rl.evaluate_candidate(api, ctx, cands[cid])
+                    table[s_] = rl.make_record(cid, res.score, np.array(res.relative_o_c[:]))
+        except Exception as e:
+            err = repr(e)
+        rec = rl.gather_records(table, world, torch.device("cuda", local_rank))
         barrier()
         dt = time.perf_counter() - t0
         if rank == 0:
-            out["extras"] = {"relocalize_8_candidates": {"ms_total": 1e3 * dt, "candidates_per_sec": 8 / dt, "ranks": world,
+            live = rec[rec[:, 8] >= 0]
+            best = rl.choose_best(rec)
+            out["extras"] = {"relocalize_8_candidates": {"ms_total": 1e3 * dt, "candidates_per_sec": 8 / dt if dt > 0 else None, "ranks": world,
                                                          "best": None if best is None else {"candidate": best[0], "score": best[1]},
-                                                         "scores": [float(x) for x in rec[rec[:, 8] >= 0][np.argsort(rec[rec[:, 8] >= 0][:, 8]), 0]]}}
+                                                         "scores": [float(x) for x in live[np.argsort(live[:, 8]), 0]], "error": err}}
     batch.close(); st.close(); ctx.close()
     if world > 1:
         dist.destroy_process_group()
