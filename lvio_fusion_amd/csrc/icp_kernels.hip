@@ -10,6 +10,7 @@
 // and the host only reads the result back at the end.  Normal-equation sums are wave-shuffle reduced (10 doubles per
 // wave) before touching memory.  Solver semantics as declared for the BA problem (oracle/lm.h header); DENSE_QR and the
 // damped normal equations solve the same 3x3 least-squares step.
+#include <algorithm>
 #include <cmath>
 #include "lidar_eval.hpp"
 #include "lvf_internal.hpp"
@@ -17,6 +18,7 @@
 namespace lvf {
 
 constexpr int kTI = 256;
+constexpr int kIcpMaxBlocks = 128;   // k_icp_eval grid cap (grid-stride above it)
 
 struct IcpDev {
   double x[3], x0[3], xc[3];
@@ -78,34 +80,40 @@ __global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restric
     derive_lidar(a, U);
   }
   __syncthreads();
-  const int i = blockIdx.x * kTI + threadIdx.x;
+  // grid-stride over the correspondences (the grid is capped at kIcpMaxBlocks): sums stay in registers, then ONE set of
+  // atomics per workgroup (wave shuffles -> LDS -> wave 0) instead of one per wave — the ten accumulators are single
+  // addresses, and ~900 serialised L2 atomics per address were the kernel's whole run time
   double v[10];
 #pragma unroll
   for (int q = 0; q < 10; ++q) v[q] = 0.0;
-  if (i < Q && (!valid || valid[i])) {
+  for (int i = blockIdx.x * kTI + threadIdx.x; i < Q; i += gridDim.x * kTI) {
+    if (valid && !valid[i]) continue;
     const double pp[3] = {P[i], P[Q + i], P[2 * Q + i]}, qa[3] = {PA[i], PA[Q + i], PA[2 * Q + i]}, nn[3] = {N[i], N[Q + i], N[2 * Q + i]};
     double r, J[3];
     lidar_point(U, args.mode, pp, qa, nn, r, J);
     double rho;
     const double sc = robust_scale(args.huber, r * r, rho);
-    v[9] = 0.5 * rho;
+    v[9] += 0.5 * rho;
     if (WITH_J) {
       const double rs = sc * r, j0 = sc * J[0], j1 = sc * J[1], j2 = sc * J[2];
-      v[0] = j0 * j0; v[1] = j1 * j0; v[2] = j1 * j1; v[3] = j2 * j0; v[4] = j2 * j1; v[5] = j2 * j2;
-      v[6] = j0 * rs; v[7] = j1 * rs; v[8] = j2 * rs;
+      v[0] += j0 * j0; v[1] += j1 * j0; v[2] += j1 * j1; v[3] += j2 * j0; v[4] += j2 * j1; v[5] += j2 * j2;
+      v[6] += j0 * rs; v[7] += j1 * rs; v[8] += j2 * rs;
     }
   }
-  if (WITH_J) {
+  __shared__ double s_part[kTI / 64][10];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-    for (int q = 0; q < 10; ++q) {
-      double s = v[q];
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-      if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(&dev->acc[q], s);
-    }
-  } else {
-    double s = v[9];
+  for (int q = WITH_J ? 0 : 9; q < 10; ++q) {
+    double s = v[q];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(&dev->cost_cand, s);
+    if (lane == 0) s_part[wid][q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 10 && (WITH_J || threadIdx.x == 9)) {
+    double s = 0.0;
+#pragma unroll
+    for (int w2 = 0; w2 < kTI / 64; ++w2) s += s_part[w2][threadIdx.x];
+    if (s != 0.0) atomicAdd(WITH_J ? &dev->acc[threadIdx.x] : &dev->cost_cand, s);
   }
 }
 
@@ -201,7 +209,7 @@ static void init_dev(IcpDev& h, int mode, const double* rpyxyz) {
 // the device-resident LM loop over correspondences P | PA | N (SoA [3][Q]); valid may be null (all rows count)
 static int run_lm(hipStream_t q, int Q, const double* P, const double* PA, const double* N, const uint8_t* valid, const IcpArgs& a,
                   IcpDev* dev, IcpDev* host_out) {
-  const int grid = (std::max(Q, 1) + kTI - 1) / kTI;
+  const int grid = std::min((std::max(Q, 1) + kTI - 1) / kTI, kIcpMaxBlocks);
   for (int it = 0; it < std::max(1, a.max_iters); ++it) {
     if (Q > 0) hipLaunchKernelGGL(k_icp_eval<true>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, valid, a, dev);
     hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1), 0, q, a, dev);
