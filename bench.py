@@ -264,6 +264,16 @@ def map_maintenance(api, ctx, c3, reps=10):
         m = api.Map(ctx, mp, 4.0); m.close()
     ctx.synchronize()
     out["map_index_from_device_cloud_us"] = 1e6 * (time.perf_counter() - t0) / reps
+    # FeatureAssociation::Process on one raw 64 x 1800 revolution (upload + projection + ground + segmentation +
+    # smoothness + picks + voxel / outlier / plane tail + Sensor2Robot)
+    from lvio_fusion_amd import synthetic as syn
+    scan = syn.raw_scan(); ext = syn.lidar_extrinsic()
+    g, s = api.lidar_extract(ctx, scan, ext); ctx.synchronize(); ng, ns = len(g), len(s); g.close(); s.close()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g, s = api.lidar_extract(ctx, scan, ext); g.close(); s.close()
+    ctx.synchronize()
+    out["feature_extraction"] = {"points_in": int(scan.shape[0]), "ground_out": ng, "surf_out": ns, "ms_per_scan": 1e3 * (time.perf_counter() - t0) / reps}
     for h in (q, mp, qg):
         h.close()
     return out

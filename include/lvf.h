@@ -214,6 +214,27 @@ int lvf_cloud_radius_outlier_filter(const lvf_cloud* in, float radius, int min_n
  * Sampling is splitmix64(seed, hypothesis, draw) — PCL's boost::mt19937 stream is not reproducible without PCL. */
 int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int max_iterations, uint64_t seed, lvf_cloud** out,
                             double* coefficients4, int* iterations_used);
+/* ---- LiDAR feature extraction of one keyframe scan: FeatureAssociation::Process, association.cpp:86-235 - */
+typedef struct lvf_lidar_params {
+  int num_scans, horizon_scan;       /* 64, 1800 (config/kitti.yaml:35-36); num_scans <= 64 */
+  float ang_res_y, ang_bottom;       /* 0.427, 24.9 */
+  int ground_rows;                   /* 60 */
+  double cycle_time;                 /* 0.1036 (a double in FeatureAssociation) */
+  float min_range, max_range, resolution;   /* 5, 30, 0.2 */
+  uint64_t ransac_seed;              /* SegmentGround's sampler (see lvf_cloud_segment_plane) */
+} lvf_lidar_params;
+void lvf_lidar_params_default(lvf_lidar_params* p);
+/* optional taps for parity tests: host arrays (may each be NULL) sized num_scans*horizon_scan (label/ground/range) or
+ * num_scans*horizon_scan*4 floats (ground_raw / surf_raw = ExtractFeatures' picks before the PCL filters) */
+typedef struct lvf_lidar_extract_debug {
+  int n_filtered, n_segmented, n_ground_raw, n_surf_raw;
+  int32_t* label_mat; int8_t* ground_mat; float* range_mat; float* ground_raw; float* surf_raw;
+} lvf_lidar_extract_debug;
+/* points: the raw sensor-frame scan (xyz at the start of each stride_floats record, scan order = acquisition order);
+ * extrinsic7 = Lidar::Get()->extrinsic (sensor -> robot).  ground_out / surf_out = frame->feature_lidar->points_ground /
+ * points_surf as NEW device clouds (robot frame; intensity = ring + relative time as the reference writes it). */
+int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_floats, const lvf_lidar_params* prm, const double* extrinsic7,
+                      lvf_cloud** ground_out, lvf_cloud** surf_out, lvf_lidar_extract_debug* dbg);
 /* kNN index / query scan straight from device-resident clouds (no host round trip) */
 int lvf_map_create_from_cloud(const lvf_cloud* c, float max_radius2, lvf_map** out);
 int lvf_scan_create_from_cloud(const lvf_cloud* c, lvf_scan** out);

@@ -47,6 +47,17 @@ class WindowOptions(C.Structure):
     _fields_ = [("baseline", C.c_double), ("weak_visual_threshold", C.c_int), ("prior_weight", C.c_double), ("prior_v", C.c_double)]
 
 
+class LidarParams(C.Structure):
+    _fields_ = [("num_scans", C.c_int), ("horizon_scan", C.c_int), ("ang_res_y", C.c_float), ("ang_bottom", C.c_float), ("ground_rows", C.c_int),
+                ("cycle_time", C.c_double), ("min_range", C.c_float), ("max_range", C.c_float), ("resolution", C.c_float), ("ransac_seed", C.c_uint64)]
+
+
+class LidarExtractDebug(C.Structure):
+    _fields_ = [("n_filtered", C.c_int), ("n_segmented", C.c_int), ("n_ground_raw", C.c_int), ("n_surf_raw", C.c_int),
+                ("label_mat", C.POINTER(C.c_int32)), ("ground_mat", C.POINTER(C.c_int8)), ("range_mat", c_float_p), ("ground_raw", c_float_p),
+                ("surf_raw", c_float_p)]
+
+
 class SolverOptions(C.Structure):
     _fields_ = [("max_num_iterations", C.c_int), ("max_solver_time_in_seconds", C.c_double), ("huber_a", C.c_double),
                 ("initial_trust_region_radius", C.c_double), ("function_tolerance", C.c_double),
@@ -123,6 +134,8 @@ _SIGS = {
     "lvf_cloud_segment_plane": (C.c_int, [_VP, C.c_float, C.c_int, C.c_uint64, C.POINTER(_VP), c_double_p, C.POINTER(C.c_int)]),
     "lvf_map_create_from_cloud": (C.c_int, [_VP, C.c_float, C.POINTER(_VP)]),
     "lvf_scan_create_from_cloud": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "lvf_lidar_params_default": (None, [C.POINTER(LidarParams)]),
+    "lvf_lidar_extract": (C.c_int, [_VP, c_float_p, C.c_int, C.c_int, C.POINTER(LidarParams), c_double_p, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(LidarExtractDebug)]),
     "lvf_scan_match_options_default": (None, [C.POINTER(ScanMatchOptions), C.c_double]),
     "lvf_scan_match": (C.c_int, [_VP, _VP, _VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(ScanMatchOptions), C.POINTER(ScanMatchResult)]),
     "lvf_lidar_solve": (C.c_int, [_VP, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),

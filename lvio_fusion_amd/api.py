@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import WindowOptions, Camera, IcpOptions, IcpSummary, ScanMatchOptions, ScanMatchResult, SolverOptions, SolverSummary
+from ._lib import LidarExtractDebug, LidarParams, WindowOptions, Camera, IcpOptions, IcpSummary, ScanMatchOptions, ScanMatchResult, SolverOptions, SolverSummary
 
 POSES, VEL, BA, BG, INV_DEPTH, W_VISUAL = range(6)
 IMU_BLOCK_SIZES = (7, 3, 3, 3, 7, 3, 3, 3)
@@ -266,6 +266,41 @@ class Cloud:
         if self.h:
             self.ctx.L.lvf_cloud_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def lidar_params(**kw):
+    p = LidarParams()
+    _lib.lib().lvf_lidar_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def lidar_extract(ctx, points, extrinsic, params=None, debug=False):
+    """FeatureAssociation::Process on device: raw sensor-frame scan -> (ground Cloud, surf Cloud[, debug dict])."""
+    a = _f(points); e = _d(extrinsic)
+    prm = params if params is not None else lidar_params()
+    hg, hs = C.c_void_p(), C.c_void_p()
+    dbg = None
+    if debug:
+        npix = prm.num_scans * prm.horizon_scan
+        cap = max(npix, 1)
+        keep = dict(label_mat=np.zeros(npix, np.int32), ground_mat=np.zeros(npix, np.int8), range_mat=np.zeros(npix, np.float32),
+                    ground_raw=np.zeros((cap, 4), np.float32), surf_raw=np.zeros((cap, 4), np.float32))
+        dbg = LidarExtractDebug()
+        dbg.label_mat = keep["label_mat"].ctypes.data_as(C.POINTER(C.c_int32)); dbg.ground_mat = keep["ground_mat"].ctypes.data_as(C.POINTER(C.c_int8))
+        dbg.range_mat = keep["range_mat"].ctypes.data_as(_lib.c_float_p); dbg.ground_raw = keep["ground_raw"].ctypes.data_as(_lib.c_float_p)
+        dbg.surf_raw = keep["surf_raw"].ctypes.data_as(_lib.c_float_p)
+    _chk(ctx.L.lvf_lidar_extract(ctx.h, a.ctypes.data_as(_lib.c_float_p), a.shape[0], a.shape[1], C.byref(prm), _dp(e), C.byref(hg), C.byref(hs),
+                                 C.byref(dbg) if dbg is not None else None))
+    g, s = Cloud(ctx, _h=hg), Cloud(ctx, _h=hs)
+    if not debug:
+        return g, s
+    R, Cn = prm.num_scans, prm.horizon_scan
+    out = dict(label_mat=keep["label_mat"].reshape(R, Cn), ground_mat=keep["ground_mat"].reshape(R, Cn), range_mat=keep["range_mat"].reshape(R, Cn),
+               ground_raw=keep["ground_raw"][:dbg.n_ground_raw].copy(), surf_raw=keep["surf_raw"][:dbg.n_surf_raw].copy(),
+               n_filtered=dbg.n_filtered, n_segmented=dbg.n_segmented)
+    return g, s, out
 
 
 class Map:

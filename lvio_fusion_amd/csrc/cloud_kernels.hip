@@ -300,23 +300,25 @@ static int new_cloud(lvf_ctx* ctx, int n, lvf_cloud** out) {
   *out = c;
   return LVF_OK;
 }
-// out = the flagged points of `in`, input order preserved
-static int compact_cloud(const lvf_cloud* in, const int* flags_dev, lvf_cloud** out) {
-  lvf_ctx* ctx = in->ctx;
+// out (a NEW cloud) = the flagged points of pts[0..n), input order preserved — shared with extract_kernels.hip
+int compact_points(lvf_ctx* ctx, const float4* pts, int n, const int* flags_dev, lvf_cloud** out) {
   hipStream_t s = ctx->stream;
   DevBuf<int> pos;
-  LVF_TRY(pos.alloc((size_t)in->n + 1));
-  LVF_TRY(device_exclusive_scan_i32(ctx, flags_dev, in->n, pos.p));
+  LVF_TRY(pos.alloc((size_t)n + 1));
+  LVF_TRY(device_exclusive_scan_i32(ctx, flags_dev, n, pos.p));
   int total = 0;
-  LVF_HIP(hipMemcpyAsync(&total, pos.p + in->n, sizeof(int), hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipMemcpyAsync(&total, pos.p + n, sizeof(int), hipMemcpyDeviceToHost, s));
   LVF_HIP(hipStreamSynchronize(s));
   LVF_TRY(new_cloud(ctx, total, out));
-  if (total) hipLaunchKernelGGL(k_compact, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, flags_dev, pos.p, (*out)->pts.p);
+  if (total) hipLaunchKernelGGL(k_compact, dim3(gridc(n)), dim3(kC), 0, s, n, pts, flags_dev, pos.p, (*out)->pts.p);
   LVF_HIP(hipGetLastError());
   LVF_HIP(hipStreamSynchronize(s));
   return LVF_OK;
 }
-
+// out = the flagged points of `in`, input order preserved
+static int compact_cloud(const lvf_cloud* in, const int* flags_dev, lvf_cloud** out) {
+  return compact_points(in->ctx, in->pts.p, in->n, flags_dev, out);
+}
 }  // namespace lvf
 
 using namespace lvf;

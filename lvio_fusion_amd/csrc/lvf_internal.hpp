@@ -165,6 +165,7 @@ namespace lvf {
 // TwoFrame work list; called by lvf_problem_create and, every tick, by the persistent window (window.hip)
 int problem_configure(lvf_problem* p);
 int device_exclusive_scan_i32(lvf_ctx* ctx, const int* in, int n, int* out);
+int compact_points(lvf_ctx* ctx, const float4* pts, int n, const int* flags_dev, lvf_cloud** out);
 // kernels / launchers implemented in the .hip translation units
 int launch_pose_only(lvf_batch* b, const lvf_state* st, bool want_j);
 int launch_two_frame(lvf_batch* b, const lvf_state* st, bool want_j);

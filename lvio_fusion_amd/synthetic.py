@@ -329,3 +329,42 @@ def config5_candidates(n=8, seed=0x5CA7, n_query=20000, n_az=600):
         out.append(dict(map=c["map"], map_ground=c["map_ground"], query=c["query"], query_ground=c["query_ground"],
                         map_pose=c["map_pose"], last_pose=c["map_pose"], init_pose=c["pose0"], pose_true=c["pose_true"]))
     return out
+
+
+# ----------------------------------------------------------------------------- raw sensor-frame scan (feature extraction)
+def raw_scan(seed=0x5CA9, n_az=1800, noise=0.01, max_return=120.0):
+    """One 64-beam revolution in the SENSOR frame in acquisition order (azimuth sweeps clockwise like a Velodyne, all rings per
+    firing), against the street scene of config 3; rays with no return within max_return are NaN (pcl::removeNaNFromPointCloud has
+    work to do), nothing is range-gated (Preprocess does that).  float32 [n][4] (x, y, z, 0)."""
+    rng = np.random.default_rng(seed)
+    boxes = []
+    for _ in range(40):
+        c = np.array([rng.uniform(-30, 30), rng.uniform(-7, 7), -1.73])
+        sz = rng.uniform(0.5, 3.0, 3)
+        boxes.append((c - np.array([sz[0] / 2, sz[1] / 2, 0]), c + np.array([sz[0] / 2, sz[1] / 2, sz[2]])))
+    el = np.deg2rad(-24.9 + 0.427 * (np.arange(64) + rng.uniform(0.35, 0.65)))     # rings sit inside their rows, not on the boundaries
+    # clockwise (-atan2(y, x) increases); firings sit near the CENTRES of the range-image columns (column = round(angle / 0.2 deg)),
+    # away from the rounding boundaries where an ulp of atan2f would decide the pixel
+    az = np.pi - 2 * np.pi * (np.arange(n_az) + 1.0 + rng.uniform(-0.25, 0.25)) / n_az
+    A, E = np.meshgrid(az, el, indexing="ij")                                      # azimuth-major
+    d = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
+    best = np.full(d.shape[0], np.inf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = -1.73 / d[:, 2]; ok = (t > 0) & (t < best); best[ok] = t[ok]
+        for s in (+1.0, -1.0):
+            t = (s * 8.0) / d[:, 1]; ok = (t > 0) & (t < best); best[ok] = t[ok]
+        for (lo, hi) in boxes:
+            t1 = lo / d; t2 = hi / d
+            tn = np.nanmax(np.minimum(t1, t2), axis=1); tf_ = np.nanmin(np.maximum(t1, t2), axis=1)
+            ok = (tn > 0) & (tn <= tf_) & (tn < best); best[ok] = tn[ok]
+    best = best * (1 + rng.normal(0, noise / 10, best.shape))
+    pts = d * best[:, None]
+    pts[~(best < max_return)] = np.nan
+    out = np.zeros((pts.shape[0], 4), np.float32)
+    out[:, :3] = pts.astype(np.float32)
+    return out
+
+
+def lidar_extrinsic():
+    """body_to_lidar of config/kitti.yaml:74-80 as an SE3 (sensor -> robot)."""
+    return np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]) if False else np.concatenate([quat_from_ypr(np.deg2rad(0.4), np.deg2rad(-0.3), np.deg2rad(0.2)), [0.27, 0.0, -0.08]])

@@ -12,6 +12,7 @@
 #include "imu.h"
 #include "icp.h"
 #include "cloud.h"
+#include "extract.h"
 #include "knn.h"
 #include "lm.h"
 #include "robust.h"
@@ -340,6 +341,26 @@ int lvo_segment_plane(const float* in, int n, float thr, int max_iterations, uns
   const auto m = segment_plane(in, n, thr, max_iterations, seed, coeff4, &iters);
   std::memcpy(mask, m.data(), m.size());
   return iters;
+}
+
+
+// ---------------- LiDAR feature extraction (extract.h) ----------------
+struct lvo_lidar_params_c { int num_scans, horizon_scan, ground_rows; float ang_res_y, ang_bottom, min_range, max_range, resolution; double cycle_time; };
+// outputs (caller-allocated, capacity n points each): ground / surf final clouds; ground_raw / surf_raw picks; label/ground/range mats
+// counts8 = {n_filtered, n_segmented, n_ground_raw, n_surf_raw, n_ground, n_surf, 0, 0}
+void lvo_lidar_extract(const float* pts, int n, int stride, const lvo_lidar_params_c* p, const double* extrinsic, unsigned long long seed, float* ground,
+                       float* surf, float* ground_raw, float* surf_raw, int* label_mat, signed char* ground_mat, float* range_mat, int* counts8) {
+  LidarParams P{p->num_scans, p->horizon_scan, p->ground_rows, p->ang_res_y, p->ang_bottom, p->min_range, p->max_range, p->resolution, p->cycle_time};
+  ExtractDebug D;
+  lidar_extract(pts, n, stride, P, D);
+  std::vector<float> g, s;
+  lidar_extract_tail(D, P, extrinsic, seed, g, s);
+  std::memcpy(ground, g.data(), g.size() * 4); std::memcpy(surf, s.data(), s.size() * 4);
+  std::memcpy(ground_raw, D.ground_raw.data(), D.ground_raw.size() * 4); std::memcpy(surf_raw, D.surf_raw.data(), D.surf_raw.size() * 4);
+  std::memcpy(label_mat, D.label_mat.data(), D.label_mat.size() * 4); std::memcpy(ground_mat, D.ground_mat.data(), D.ground_mat.size());
+  std::memcpy(range_mat, D.range_mat.data(), D.range_mat.size() * 4);
+  counts8[0] = (int)D.filtered.size() / 4; counts8[1] = (int)D.segmented.size() / 4; counts8[2] = (int)D.ground_raw.size() / 4; counts8[3] = (int)D.surf_raw.size() / 4;
+  counts8[4] = (int)g.size() / 4; counts8[5] = (int)s.size() / 4; counts8[6] = counts8[7] = 0;
 }
 
 }  // extern "C"

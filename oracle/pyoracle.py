@@ -300,6 +300,28 @@ def segment_plane(xyzi, thr, max_iterations=100, seed=12345):
     return mask, co, it
 
 
+# ----------------------------------------------------------------------------- LiDAR feature extraction (extract.h)
+class LidarParams(C.Structure):
+    _fields_ = [("num_scans", C.c_int), ("horizon_scan", C.c_int), ("ground_rows", C.c_int), ("ang_res_y", C.c_float), ("ang_bottom", C.c_float),
+                ("min_range", C.c_float), ("max_range", C.c_float), ("resolution", C.c_float), ("cycle_time", C.c_double)]
+
+
+def lidar_extract(points, extrinsic, seed=12345, num_scans=64, horizon_scan=1800, ground_rows=60, ang_res_y=0.427, ang_bottom=24.9, min_range=5.0,
+                  max_range=30.0, resolution=0.2, cycle_time=0.1036):
+    a = _f32(points); e = _f64(extrinsic)
+    n = a.shape[0]
+    prm = LidarParams(num_scans, horizon_scan, ground_rows, ang_res_y, ang_bottom, min_range, max_range, resolution, cycle_time)
+    npix = num_scans * horizon_scan
+    cap = max(n, 1)
+    g = np.empty((cap, 4), np.float32); s = np.empty((cap, 4), np.float32); gr = np.empty((cap, 4), np.float32); sr = np.empty((cap, 4), np.float32)
+    label = np.empty(npix, np.int32); gm = np.empty(npix, np.int8); rm = np.empty(npix, np.float32); cnt = np.zeros(8, np.int32)
+    lib().lvo_lidar_extract(_p(a, C.c_float), n, a.shape[1], C.byref(prm), _p(e), C.c_ulonglong(seed), _p(g, C.c_float), _p(s, C.c_float), _p(gr, C.c_float),
+                            _p(sr, C.c_float), _p(label, C.c_int), gm.ctypes.data_as(C.POINTER(C.c_int8)), _p(rm, C.c_float), _p(cnt, C.c_int))
+    return dict(ground=g[:cnt[4]].copy(), surf=s[:cnt[5]].copy(), ground_raw=gr[:cnt[2]].copy(), surf_raw=sr[:cnt[3]].copy(),
+                label_mat=label.reshape(num_scans, horizon_scan), ground_mat=gm.reshape(num_scans, horizon_scan),
+                range_mat=rm.reshape(num_scans, horizon_scan), n_filtered=int(cnt[0]), n_segmented=int(cnt[1]))
+
+
 # ----------------------------------------------------------------------------- sliding-window problem
 class _WindowC(C.Structure):
     _fields_ = [("n_kf", C.c_int), ("n_lm", C.c_int),

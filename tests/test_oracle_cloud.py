@@ -72,3 +72,25 @@ def test_segment_plane_recovers_the_ground(oracle, scene):
     assert np.array_equal(mask, m2)
     m3, co3, _ = oracle.segment_plane(pts, 0.05, 100, seed=7)
     assert np.abs(co3 - co).max() < 5e-3
+
+
+def test_lidar_extract_restatement_is_sane(oracle):
+    """oracle/extract.h on a synthetic revolution: the flat ground ends up in the ground cloud, walls/boxes in surf, sparse clutter
+    is rejected as outlier segments, and every stage's bookkeeping is self-consistent."""
+    scan = syn.raw_scan(seed=3)
+    r = oracle.lidar_extract(scan, syn.lidar_extrinsic())
+    assert np.isnan(scan[:, 0]).sum() > 0 and r["n_filtered"] < len(scan)
+    d2 = (scan[:, :3] ** 2).sum(1)
+    assert r["n_filtered"] == int(((d2 > 25) & (d2 < 900)).sum())
+    occ = r["range_mat"] < 1e30
+    assert 0.2 < occ.mean() < 0.9 and (r["label_mat"][~occ] == -1).all()
+    gm = r["ground_mat"] == 1
+    assert gm[11:20].mean() > 0.5 and gm[61:].sum() == 0                    # rings that meet the road inside the 5-30 m gate; rows above ground_rows never do
+    assert (r["label_mat"][gm] == -1).all()
+    raw_g = r["ground_raw"]
+    assert np.median(np.abs(raw_g[:, 2] + 1.73)) < 0.05                     # mostly the road (flat box tops qualify as "ground" too)
+    ring = np.round(raw_g[:, 3])
+    assert ring.min() >= 0 and ring.max() < 64 and np.abs(raw_g[:, 3] - ring).max() < 0.16   # intensity = ring + cycle_time * rel_time, rel_time in about [-0.25, 1.25]
+    assert len(r["surf"]) > 100 and len(r["ground"]) > 100
+    # the voxel / outlier / plane tail only ever removes points
+    assert len(r["surf"]) < len(r["surf_raw"]) and len(r["ground"]) < len(r["ground_raw"])
