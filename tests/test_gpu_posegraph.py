@@ -61,7 +61,8 @@ def test_r_error_and_pose_graph_iterations(oracle):
     const = np.zeros(n, np.uint8); const[0] = const[-1] = 1
     win = oracle.Window(cfg, np.zeros((0, 467)), pose_const=const, use=(), priors=pr)
     opt = api.default_solver_options()
-    assert abs(prob.cost(opt) - win.cost()) <= 1e-9 * win.cost() and win.cost() > 0
+    cost0 = win.cost()
+    assert abs(prob.cost(opt) - cost0) <= 1e-9 * cost0 and cost0 > 0
     radius, dec = 1e4, 2.0
     for it in range(5):
         ref = win.lm_iteration(radius, dec)
@@ -72,7 +73,7 @@ def test_r_error_and_pose_graph_iterations(oracle):
         radius, dec = ref["radius"], ref["decrease_factor"]
     Pn = st.get(api.POSES).reshape(-1, 7)
     assert np.array_equal(Pn[0], P[0]) and np.array_equal(Pn[-1], P[-1])          # constant ends
-    assert got["cost_after"] < win.cost()
+    assert got["cost_after"] < 0.5 * cost0
     # the correction is spread over the chain: interior poses moved, monotonically more toward the relocated end
     moved = np.linalg.norm(Pn[1:-1, 4:] - P[1:-1, 4:], axis=1)
     assert moved[-1] > moved[0] > 0
