@@ -4,6 +4,14 @@
 namespace lvf {
 
 static thread_local std::string g_err;
+thread_local std::shared_ptr<Pool> g_pool;
+
+int enter(lvf_ctx* ctx) {
+  if (!ctx) { set_error("null context"); return LVF_ERR_INVALID; }
+  LVF_HIP(hipSetDevice(ctx->device));
+  g_pool = ctx->pool;
+  return LVF_OK;
+}
 
 void set_error(const char* fmt, ...) {
   char buf[1024];
@@ -82,6 +90,7 @@ int lvf_ctx_create(int device, void* hip_stream, lvf_ctx** out) {
   LVF_HIP(hipGetDeviceProperties(&prop, device));
   auto* c = new lvf_ctx();
   c->device = device;
+  g_pool = c->pool;
   c->num_cu = prop.multiProcessorCount;
   if (hip_stream) { c->stream = static_cast<hipStream_t>(hip_stream); c->own_stream = false; }
   else {
@@ -102,6 +111,8 @@ int lvf_ctx_destroy(lvf_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  c->pool->close();                 // objects that outlive their context free straight to the driver from now on
+  if (g_pool == c->pool) g_pool.reset();
   delete c;
   return LVF_OK;
 }
@@ -120,7 +131,7 @@ int lvf_timer_elapsed_ms(lvf_ctx* c, float* ms) {
 int lvf_state_create(lvf_ctx* ctx, int n_kf, int n_lm, lvf_state** out) {
   LVF_REQUIRE(ctx && out, "lvf_state_create: null ctx/out");
   LVF_REQUIRE(n_kf >= 0 && n_lm >= 0, "lvf_state_create: negative size");
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   auto* st = new lvf_state();
   st->ctx = ctx; st->n_kf = n_kf; st->n_lm = n_lm;
   int rc;
@@ -189,7 +200,7 @@ int lvf_pose_only_create(lvf_ctx* ctx, const lvf_camera* cam0, int n, const doub
   LVF_REQUIRE(n == 0 || (ob && kf_idx && pw_idx && pw), "lvf_pose_only_create: null input array");
   LVF_TRY(check_idx(kf_idx, n, "kf_idx")); LVF_TRY(check_idx(pw_idx, n, "pw_idx"));
   LVF_REQUIRE(max_idx(pw_idx, n) < n_pw, "lvf_pose_only_create: pw_idx out of range (n_pw=%d)", n_pw);
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   lvf_batch* b = new_batch(ctx, LVF_K_POSE_ONLY, n, 2, {7});
   make_camd(*cam0, b->cam_a);
   b->n_table = n_pw;
@@ -211,7 +222,7 @@ int lvf_two_frame_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera*
   LVF_REQUIRE(n >= 0, "lvf_two_frame_create: negative size");
   LVF_REQUIRE(n == 0 || (first_ob && ob && lm_idx && kf1_idx && kf2_idx), "lvf_two_frame_create: null input array");
   LVF_TRY(check_idx(lm_idx, n, "lm_idx")); LVF_TRY(check_idx(kf1_idx, n, "kf1_idx")); LVF_TRY(check_idx(kf2_idx, n, "kf2_idx"));
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   lvf_batch* b = new_batch(ctx, LVF_K_TWO_FRAME, n, 2, {1, 7, 7});
   make_camd(*left, b->cam_a); make_camd(*right, b->cam_b);
   b->sorted_by_kf = is_sorted_i32(kf2_idx, n);
@@ -234,7 +245,7 @@ int lvf_two_camera_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera
   LVF_REQUIRE(n >= 0, "lvf_two_camera_create: negative size");
   LVF_REQUIRE(n == 0 || (left_ob && right_ob && lm_idx && kf_idx), "lvf_two_camera_create: null input array");
   LVF_TRY(check_idx(lm_idx, n, "lm_idx")); LVF_TRY(check_idx(kf_idx, n, "kf_idx"));
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   lvf_batch* b = new_batch(ctx, LVF_K_TWO_CAMERA, n, 2, {1});
   make_camd(*left, b->cam_a); make_camd(*right, b->cam_b);
   hipStream_t s = ctx->stream;
@@ -255,7 +266,7 @@ int lvf_imu_create(lvf_ctx* ctx, int n, const lvf_preint* pre, const int32_t* kf
   static_assert(sizeof(lvf_preint) == 467 * sizeof(double), "lvf_preint must be 467 packed doubles");
   LVF_TRY(check_idx(kf_i, n, "kf_i")); LVF_TRY(check_idx(kf_j, n, "kf_j"));
   for (int f = 0; f < n; ++f) LVF_REQUIRE(kf_i[f] != kf_j[f], "lvf_imu_create: factor %d links keyframe %d to itself", f, kf_i[f]);
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   lvf_batch* b = new_batch(ctx, LVF_K_IMU, n, 15, {7, 3, 3, 3, 7, 3, 3, 3});
   hipStream_t s = ctx->stream;
   int rc;
@@ -274,7 +285,7 @@ int lvf_lidar_plane_create(lvf_ctx* ctx, int mode, int n, const double* p, const
   LVF_REQUIRE(mode == 0 || mode == 1, "lvf_lidar_plane_create: mode must be 0 (RPZ) or 1 (YXY)");
   LVF_REQUIRE(n >= 0, "lvf_lidar_plane_create: negative size");
   LVF_REQUIRE(n == 0 || (p && pa && pb && pc), "lvf_lidar_plane_create: null input array");
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   lvf_batch* b = new_batch(ctx, LVF_K_LIDAR, n, 1, {1, 1, 1});
   b->lidar_mode = mode; b->lidar_weight = weight;
   std::memcpy(b->Twc1, Twc1, sizeof(b->Twc1));
@@ -296,7 +307,7 @@ int lvf_batch_num_param_blocks(const lvf_batch* b) { return b ? b->n_blocks : -1
 
 int lvf_batch_evaluate(lvf_batch* b, const lvf_state* st, const double* rpyxyz, int want_jacobians) {
   LVF_REQUIRE(b, "lvf_batch_evaluate: null batch");
-  LVF_HIP(hipSetDevice(b->ctx->device));
+  LVF_TRY(lvf::enter(b->ctx));
   const bool wj = want_jacobians != 0;
   int rc = LVF_OK;
   if (b->kind == LVF_K_LIDAR) {

@@ -329,7 +329,7 @@ int lvf_cloud_create(lvf_ctx* ctx, const float* points, int n, int stride_floats
   LVF_REQUIRE(ctx && out, "lvf_cloud_create: null ctx/out");
   LVF_REQUIRE(n >= 0 && (n == 0 || points) && stride_floats >= 3 && intensity_offset < stride_floats, "lvf_cloud_create: bad cloud (n=%d stride=%d ioff=%d)", n,
               stride_floats, intensity_offset);
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   lvf_cloud* c = nullptr;
   LVF_TRY(new_cloud(ctx, n, &c));
   if (n) {
@@ -354,7 +354,7 @@ int lvf_cloud_download(const lvf_cloud* c, float* xyzi) {
 
 int lvf_cloud_transform(const lvf_cloud* in, const double* pose, lvf_cloud** out) {
   LVF_REQUIRE(in && pose && out, "lvf_cloud_transform: null argument");
-  LVF_HIP(hipSetDevice(in->ctx->device));
+  LVF_TRY(lvf::enter(in->ctx));
   lvf_cloud* c = nullptr;
   LVF_TRY(new_cloud(in->ctx, in->n, &c));
   TfArgC tf;
@@ -370,7 +370,7 @@ int lvf_cloud_concat(lvf_ctx* ctx, const lvf_cloud* const* parts, int n_parts, l
   long long total = 0;
   for (int k = 0; k < n_parts; ++k) { LVF_REQUIRE(parts[k] && parts[k]->ctx == ctx, "lvf_cloud_concat: part %d is null or of another context", k); total += parts[k]->n; }
   LVF_REQUIRE(total < (1ll << 31), "lvf_cloud_concat: too many points");
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   lvf_cloud* c = nullptr;
   LVF_TRY(new_cloud(ctx, (int)total, &c));
   size_t off = 0;
@@ -386,7 +386,7 @@ int lvf_cloud_voxel_filter(const lvf_cloud* in, float leaf, lvf_cloud** out) {
   LVF_REQUIRE(in && out, "lvf_cloud_voxel_filter: null argument");
   LVF_REQUIRE(leaf > 0.0f && std::isfinite(leaf), "lvf_cloud_voxel_filter: leaf must be finite > 0");
   lvf_ctx* ctx = in->ctx;
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   if (in->n == 0) return new_cloud(ctx, 0, out);
   hipStream_t s = ctx->stream;
   float lo[3], hi[3];
@@ -426,7 +426,7 @@ int lvf_cloud_radius_outlier_filter(const lvf_cloud* in, float radius, int min_n
   LVF_REQUIRE(in && out, "lvf_cloud_radius_outlier_filter: null argument");
   LVF_REQUIRE(radius > 0.0f && std::isfinite(radius) && min_neighbors >= 0, "lvf_cloud_radius_outlier_filter: bad radius / min_neighbors");
   lvf_ctx* ctx = in->ctx;
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   if (in->n == 0) return new_cloud(ctx, 0, out);
   hipStream_t s = ctx->stream;
   float lo[3], hi[3];
@@ -457,7 +457,7 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
   LVF_REQUIRE(in && out, "lvf_cloud_segment_plane: null argument");
   LVF_REQUIRE(distance_threshold > 0.0f && max_iterations > 0 && max_iterations <= 4096, "lvf_cloud_segment_plane: bad threshold / iteration count");
   lvf_ctx* ctx = in->ctx;
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   if (coefficients4) for (int k = 0; k < 4; ++k) coefficients4[k] = 0.0;
   if (iterations_used) *iterations_used = 0;
   if (in->n < 3) return new_cloud(ctx, 0, out);          // SACSegmentation cannot fit a model: no inliers

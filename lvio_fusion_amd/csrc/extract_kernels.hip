@@ -249,7 +249,7 @@ int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_float
   LVF_REQUIRE(n >= 0 && (n == 0 || points) && stride_floats >= 3, "lvf_lidar_extract: bad scan (n=%d stride=%d)", n, stride_floats);
   LVF_REQUIRE(prm->num_scans > 1 && prm->num_scans <= 64 && prm->horizon_scan > 0 && prm->ground_rows >= 0 && prm->ground_rows < prm->num_scans,
               "lvf_lidar_extract: unsupported geometry (num_scans <= 64, 0 <= ground_rows < num_scans)");
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   hipStream_t s = ctx->stream;
   ExP P;
   P.R = prm->num_scans; P.Cn = prm->horizon_scan; P.ground_rows = prm->ground_rows;

@@ -232,7 +232,7 @@ extern "C" int lvf_icp_solve(lvf_map* m, lvf_scan* sc, const double* map_pose, c
   LVF_REQUIRE(m->ctx == sc->ctx, "lvf_icp_solve: map and scan belong to different contexts");
   LVF_REQUIRE(opt->mode == 0 || opt->mode == 1, "lvf_icp_solve: mode must be 0 (ground/RPZ) or 1 (surf/YXY)");
   LVF_REQUIRE(opt->thr > 0.0f && opt->max_num_iterations >= 0, "lvf_icp_solve: bad options");
-  LVF_HIP(hipSetDevice(m->ctx->device));
+  LVF_TRY(lvf::enter(m->ctx));
   hipStream_t q = m->ctx->stream;
   const int Q = sc->Q;
   std::memset(summary, 0, sizeof(*summary));
@@ -266,7 +266,7 @@ extern "C" int lvf_lidar_solve(lvf_batch* b, double* rpyxyz, const lvf_icp_optio
   LVF_REQUIRE(b && rpyxyz && opt && summary, "lvf_lidar_solve: null argument");
   LVF_REQUIRE(b->kind == LVF_K_LIDAR, "lvf_lidar_solve: not a lidar-plane batch");
   LVF_REQUIRE(opt->max_num_iterations >= 0, "lvf_lidar_solve: bad options");
-  LVF_HIP(hipSetDevice(b->ctx->device));
+  LVF_TRY(lvf::enter(b->ctx));
   hipStream_t q = b->ctx->stream;
   std::memset(summary, 0, sizeof(*summary));
   if (!b->icp_dev.p) LVF_TRY(b->icp_dev.alloc(sizeof(IcpDev)));
@@ -311,7 +311,7 @@ extern "C" int lvf_prior3_evaluate(lvf_ctx* ctx, int mode, const double* target3
                                    double* jacobians9) {
   LVF_REQUIRE(ctx && target3 && x3 && residuals3, "lvf_prior3_evaluate: null argument");
   LVF_REQUIRE(mode == 0 || mode == 1, "lvf_prior3_evaluate: mode must be 0 (RPZ) or 1 (YXY)");
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   DevBuf<double> out;
   LVF_TRY(out.alloc(12));
   hipLaunchKernelGGL(k_prior3, dim3(1), dim3(1), 0, ctx->stream, mode, weight, target3[0], target3[1], target3[2], x3[0], x3[1], x3[2], out.p);

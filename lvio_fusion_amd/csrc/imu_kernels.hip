@@ -391,7 +391,7 @@ extern "C" int lvf_preintegrate(lvf_ctx* ctx, int n, const int32_t* offset, cons
   for (int k = 0; k < n; ++k) LVF_REQUIRE(offset[k + 1] >= offset[k], "lvf_preintegrate: offsets must be non-decreasing");
   const int ns = offset[n];
   LVF_REQUIRE(ns == 0 || samples, "lvf_preintegrate: samples is null");
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   hipStream_t q = ctx->stream;
   DevBuf<int> d_off; DevBuf<double> d_s, d_a0, d_g0, d_ba, d_bg, d_out;
   LVF_TRY(d_off.upload(offset, n + 1, q)); LVF_TRY(d_s.upload(samples, (size_t)7 * ns, q));

@@ -427,7 +427,7 @@ static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_devic
   LVF_REQUIRE(ctx && out, "lvf_map_create: null ctx/out");
   LVF_REQUIRE(M >= 0 && (M == 0 || map_xyz) && stride_floats >= 3, "lvf_map_create: bad cloud (M=%d stride=%d)", M, stride_floats);
   LVF_REQUIRE(max_radius2 > 0.0f && std::isfinite(max_radius2), "lvf_map_create: max_radius2 must be finite > 0");
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   hipStream_t s = ctx->stream;
   auto* m = new lvf_map();
   m->ctx = ctx; m->M = M;
@@ -494,7 +494,7 @@ int lvf_map_destroy(lvf_map* m) { delete m; return LVF_OK; }
 static int scan_create_impl(lvf_ctx* ctx, const float* scan_xyz, bool src_is_device, int Q, int stride_floats, lvf_scan** out) {
   LVF_REQUIRE(ctx && out, "lvf_scan_create: null ctx/out");
   LVF_REQUIRE(Q >= 0 && (Q == 0 || scan_xyz) && stride_floats >= 3, "lvf_scan_create: bad cloud (Q=%d stride=%d)", Q, stride_floats);
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   auto* sc = new lvf_scan();
   sc->ctx = ctx; sc->Q = Q;
   int rc = LVF_OK;
@@ -525,7 +525,7 @@ int lvf_scan_destroy(lvf_scan* s) { delete s; return LVF_OK; }
 // shells}, and the grid pyramid geometry {cell, nx, ny, nz} per level.
 int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* sc, const double* pose, float thr, int32_t* stats4, float* levels4, int* n_levels) {
   LVF_REQUIRE(m && sc && pose && stats4, "lvf_knn3_debug_stats: null argument");
-  LVF_HIP(hipSetDevice(m->ctx->device));
+  LVF_TRY(lvf::enter(m->ctx));
   if (n_levels) *n_levels = m->n_levels;
   if (levels4) for (int k = 0; k < m->n_levels; ++k) { levels4[4 * k] = m->levels[k].cell; levels4[4 * k + 1] = (float)m->levels[k].nx; levels4[4 * k + 2] = (float)m->levels[k].ny; levels4[4 * k + 3] = (float)m->levels[k].nz; }
   if (sc->Q == 0) return LVF_OK;
@@ -552,7 +552,7 @@ int lvf_knn3(lvf_map* m, lvf_scan* sc, const double* pose, float thr) {
   LVF_REQUIRE(m && sc && pose, "lvf_knn3: null argument");
   LVF_REQUIRE(m->ctx == sc->ctx, "lvf_knn3: map and scan belong to different contexts");
   LVF_REQUIRE(!(thr != thr) && thr > 0.0f, "lvf_knn3: thr must be > 0");
-  LVF_HIP(hipSetDevice(m->ctx->device));
+  LVF_TRY(lvf::enter(m->ctx));
   if (sc->Q > 0) {
     TfArg tf;
     for (int k = 0; k < 7; ++k) tf.v[k] = (float)pose[k];   // Sophus SE3d::cast<float>()  association.cpp:287

@@ -5,7 +5,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -32,29 +35,86 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     if (rc__ != LVF_OK) return rc__;                                           \
   } while (0)
 
+// Per-context caching device allocator.  hipMalloc / hipFree cost 0.1-0.3 ms each (hipFree synchronises the device) and the
+// create-heavy paths (map index build, cloud filters, feature extraction, per-tick batches) issue dozens of them per call;
+// freed blocks are parked in size buckets and handed back to later requests of the SAME context, i.e. the same HIP stream,
+// so reuse is stream-ordered and needs no extra synchronisation.  A closed pool (context destroyed) frees directly.
+struct Pool {
+  std::mutex mu;
+  std::unordered_multimap<size_t, void*> parked;
+  size_t held = 0;
+  bool closed = false;
+  static constexpr size_t kMaxHeld = (size_t)4 << 30;   // beyond this, blocks go straight back to the driver
+  static size_t bucket(size_t bytes) {
+    if (bytes <= 4096) return (bytes + 255) & ~(size_t)255;
+    size_t b = 4096;
+    while (b < bytes) b <<= 1;                           // next power of two ...
+    const size_t step = b >> 4;                          // ... refined to 1/8-octave steps: <= 12.5 % slack
+    return ((bytes + step - 1) / step) * step;
+  }
+  void* get(size_t bucket_bytes) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = parked.find(bucket_bytes);
+    if (it == parked.end()) return nullptr;
+    void* p = it->second;
+    parked.erase(it);
+    held -= bucket_bytes;
+    return p;
+  }
+  bool put(void* p, size_t bucket_bytes) {               // false: caller must hipFree
+    std::lock_guard<std::mutex> g(mu);
+    if (closed || held + bucket_bytes > kMaxHeld) return false;
+    parked.emplace(bucket_bytes, p);
+    held += bucket_bytes;
+    return true;
+  }
+  void close() {
+    std::unordered_multimap<size_t, void*> all;
+    { std::lock_guard<std::mutex> g(mu); closed = true; all.swap(parked); held = 0; }
+    for (auto& kv : all) (void)hipFree(kv.second);
+  }
+  ~Pool() { close(); }
+};
+extern thread_local std::shared_ptr<Pool> g_pool;         // the calling entry point's context pool (set by lvf::enter)
+
 template <typename T>
 struct DevBuf {  // owning device buffer
   T* p = nullptr;
   size_t n = 0;
-  size_t cap = 0;   // allocated elements (>= n); ensure()/assign() only ever grow it
+  size_t cap = 0;   // usable elements (>= n); ensure()/assign() only ever grow it
+  size_t bytes = 0; // bucketed allocation size
+  std::shared_ptr<Pool> pool;
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t count) {
-    if (p) { (void)hipFree(p); p = nullptr; }
-    n = count; cap = count;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) { if (!(pool && pool->put(p, bytes))) (void)hipFree(p); }
+    p = nullptr; cap = 0; bytes = 0; pool.reset();
+  }
+  int raw_alloc(size_t count) {
+    release();
     if (count == 0) return LVF_OK;
-    LVF_HIP(hipMalloc(&p, count * sizeof(T)));
+    pool = g_pool;
+    bytes = Pool::bucket(count * sizeof(T));
+    void* q = pool ? pool->get(bytes) : nullptr;
+    if (!q) {
+      hipError_t e = hipMalloc(&q, bytes);
+      if (e != hipSuccess) { bytes = 0; pool.reset(); return ::lvf::hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    }
+    p = static_cast<T*>(q);
+    cap = count;
     return LVF_OK;
+  }
+  int alloc(size_t count) {
+    n = count;
+    return raw_alloc(count);
   }
   // grow-only resize (contents are NOT preserved across a growth): the persistent-window path re-uses buffers across ticks
   int ensure(size_t count) {
     if (count <= cap && (p || count == 0)) { n = count; return LVF_OK; }
-    const size_t want = count + count / 4 + 16;
-    if (p) { (void)hipFree(p); p = nullptr; }
-    LVF_HIP(hipMalloc(&p, want * sizeof(T)));
-    cap = want; n = count;
+    LVF_TRY(raw_alloc(count + count / 4 + 16));
+    n = count;
     return LVF_OK;
   }
   int assign(const T* host, size_t count, hipStream_t s) {
@@ -67,11 +127,14 @@ struct DevBuf {  // owning device buffer
     if (count) LVF_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
     return LVF_OK;
   }
+  // exchange the storage (not the logical size) of two buffers: the accepted-step pointer swap of the solver
+  void swap_storage(DevBuf& o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(bytes, o.bytes); std::swap(pool, o.pool); }
 };
 
 }  // namespace lvf
 
 struct lvf_ctx {
+  std::shared_ptr<lvf::Pool> pool = std::make_shared<lvf::Pool>();
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -128,8 +191,8 @@ struct lvf_map {
     Level() = default;
     Level(Level&& o) noexcept { *this = std::move(o); }
     Level& operator=(Level&& o) noexcept {
-      std::swap(sorted.p, o.sorted.p); std::swap(sorted.n, o.sorted.n);
-      std::swap(cell_start.p, o.cell_start.p); std::swap(cell_start.n, o.cell_start.n);
+      sorted.swap_storage(o.sorted); std::swap(sorted.n, o.sorted.n);
+      cell_start.swap_storage(o.cell_start); std::swap(cell_start.n, o.cell_start.n);
       ox = o.ox; oy = o.oy; oz = o.oz; cell = o.cell; inv_cell = o.inv_cell; nx = o.nx; ny = o.ny; nz = o.nz;
       return *this;
     }
@@ -164,6 +227,8 @@ namespace lvf {
 // (re)derives a problem's dimensions from its state's CURRENT n_kf / n_lm, grows its work buffers if needed and rebuilds the
 // TwoFrame work list; called by lvf_problem_create and, every tick, by the persistent window (window.hip)
 int problem_configure(lvf_problem* p);
+// every extern "C" entry point starts here: selects the context's device and allocator for the calling thread
+int enter(lvf_ctx* ctx);
 int device_exclusive_scan_i32(lvf_ctx* ctx, const int* in, int n, int* out);
 int compact_points(lvf_ctx* ctx, const float4* pts, int n, const int* flags_dev, lvf_cloud** out);
 // kernels / launchers implemented in the .hip translation units

@@ -163,7 +163,7 @@ int lvf_pose_prior_create(lvf_ctx* ctx, int n, const int32_t* kf_a, const int32_
     LVF_REQUIRE(kf_a[i] != kf_b[i], "lvf_pose_prior_create: block %d links keyframe %d to itself", i, kf_b[i]);
     mx = std::max(mx, std::max(kf_a[i], kf_b[i]));
   }
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   auto* b = new lvf_batch();
   b->ctx = ctx; b->kind = LVF_K_POSE_PRIOR; b->n = n; b->n_res = 6; b->n_blocks = 2; b->block_size[0] = 7; b->block_size[1] = 7;
   b->min_n_kf = mx + 1;

@@ -890,9 +890,8 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
 // the C-ABI accessors always go through the lvf_state object, never through cached device pointers)
 static int commit_candidate(lvf_problem* p) {
   lvf_state* st = p->st;
-  auto swap_storage = [](lvf::DevBuf<double>& a, lvf::DevBuf<double>& b) { std::swap(a.p, b.p); std::swap(a.cap, b.cap); };
-  swap_storage(st->poses, p->poses2); swap_storage(st->vel, p->vel2); swap_storage(st->ba, p->ba2); swap_storage(st->bg, p->bg2);
-  swap_storage(st->inv_depth, p->invd2);
+  st->poses.swap_storage(p->poses2); st->vel.swap_storage(p->vel2); st->ba.swap_storage(p->ba2); st->bg.swap_storage(p->bg2);
+  st->inv_depth.swap_storage(p->invd2);
   return LVF_OK;
 }
 
@@ -999,7 +998,7 @@ int lvf_problem_create(lvf_ctx* ctx, lvf_state* st, lvf_batch* two_camera, lvf_b
       LVF_REQUIRE(b->min_n_kf <= st->n_kf && b->min_n_lm <= st->n_lm, "batch indices exceed the state (n_kf=%d n_lm=%d)", st->n_kf, st->n_lm);
     }
   LVF_REQUIRE(st->n_kf > 0, "lvf_problem_create: empty window");
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   auto* p = new lvf_problem();
   p->ctx = ctx; p->st = st; p->tc = two_camera; p->tf = two_frame; p->po = pose_only; p->imu = imu;
   const int rc = problem_configure(p);
@@ -1032,7 +1031,7 @@ int lvf_problem_set_pose_constant(lvf_problem* p, int kf, int is_constant) {
 
 int lvf_problem_cost(lvf_problem* p, const lvf_solver_options* o, double* cost) {
   LVF_REQUIRE(p && o && cost, "lvf_problem_cost: null argument");
-  LVF_HIP(hipSetDevice(p->ctx->device));
+  LVF_TRY(lvf::enter(p->ctx));
   hipStream_t q = p->ctx->stream;
   LVF_HIP(hipMemsetAsync(p->scal.p, 0, SC_N * 8, q));
   LVF_TRY(enqueue_cost(p, state_ptrs(p->st), p->st, o->huber_a, p->scal.p + SC_COST));
@@ -1045,7 +1044,7 @@ int lvf_problem_lm_iteration(lvf_problem* p, const lvf_solver_options* o, double
                              double* cost_before, double* cost_after, int* accepted) {
   LVF_REQUIRE(p && o && radius && decrease_factor, "lvf_problem_lm_iteration: null argument");
   LVF_REQUIRE(*radius > 0.0 && *decrease_factor > 0.0, "radius and decrease_factor must be positive");
-  LVF_HIP(hipSetDevice(p->ctx->device));
+  LVF_TRY(lvf::enter(p->ctx));
   IterOut it;
   LVF_TRY(lm_iteration(p, o, radius, decrease_factor, &it));
   if (cost_before) *cost_before = it.cost_before;
@@ -1056,7 +1055,7 @@ int lvf_problem_lm_iteration(lvf_problem* p, const lvf_solver_options* o, double
 
 int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary) {
   LVF_REQUIRE(p && o && summary, "lvf_problem_solve: null argument");
-  LVF_HIP(hipSetDevice(p->ctx->device));
+  LVF_TRY(lvf::enter(p->ctx));
   double radius = o->initial_trust_region_radius, decrease = 2.0;
   std::memset(summary, 0, sizeof(*summary));
   summary->num_residual_blocks = (p->tc ? p->tc->n : 0) + (p->tf ? p->tf->n : 0) + (p->po ? p->po->n : 0) + (p->imu ? p->imu->n : 0) + (p->prior ? p->prior->n : 0);
@@ -1090,7 +1089,7 @@ int lvf_problem_reduced_dim(lvf_problem* p) { return p ? p->d : -1; }
 int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs) {
   LVF_REQUIRE(p && S && rhs, "lvf_problem_download_reduced: null argument");
   if (!p->linearized) { set_error("no linearisation yet"); return LVF_ERR_STATE; }
-  LVF_HIP(hipSetDevice(p->ctx->device));
+  LVF_TRY(lvf::enter(p->ctx));
   hipStream_t q = p->ctx->stream;
   const double inv_r = 1.0 / p->last_radius;
   const size_t nS = (size_t)p->dpad * p->dpad;

@@ -235,7 +235,7 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   LVF_REQUIRE(w && o && summary, "lvf_window_solve: null argument");
   LVF_REQUIRE(!w->kfs.empty(), "lvf_window_solve: empty window");
   lvf_ctx* ctx = w->ctx;
-  LVF_HIP(hipSetDevice(ctx->device));
+  LVF_TRY(lvf::enter(ctx));
   hipStream_t s = ctx->stream;
   const int n_kf = (int)w->kfs.size();
   // ---- assemble the block lists in BuildProblem's order
