@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 #include "factor_eval.hpp"
 #include "lvf_internal.hpp"
@@ -506,6 +507,104 @@ __global__ __launch_bounds__(64) void k_schur_syrk(int n_lm, int dp, int ldE, in
   }
 }
 
+// LDS-staged variant (used whenever ldE <= 320, i.e. up to 53 keyframes; larger windows fall back to k_schur_syrk): workgroup = (tile group g of kSchurGroups, K slice).  The slice's rows
+// of Ea are streamed through LDS in 16-row chunks with fully coalesced loads (the next chunk is prefetched into registers while
+// the current one feeds the matrix cores); every wave keeps up to kSchurTilesPerWave 16x16 accumulators in registers across
+// the whole slice and the workgroup touches S once at the end.  Versus one wave per (tile, 512-row chunk) with strided 8-byte
+// global operand loads: the same MFMA count, 1/8 of the atomics, and E is read once per tile group instead of once per tile.
+constexpr int kSchurGroups = 8, kSchurTilesPerWave = 8, kSchurRows = 16;
+__global__ __launch_bounds__(256) void k_schur_lds(int n_lm, int dp, int ldE, int ntile, int rows_per_slice, const double* __restrict__ E,
+                                                   const double* __restrict__ Cd, int d, int ldS, double* __restrict__ S) {
+  extern __shared__ double sh[];          // Es[kSchurRows][ldE] | icd[kSchurRows]
+  double* Es = sh;
+  double* icd = sh + kSchurRows * ldE;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lk = lane >> 4, lc = lane & 15;
+  const int g = blockIdx.x, slice = blockIdx.y;
+  const int k_begin = slice * rows_per_slice, k_end = min(n_lm, k_begin + rows_per_slice);
+  // this wave's tiles: t = g + kSchurGroups * (w + 4 * s), s = 0..; decode (ti, tj) of the lower-triangular enumeration
+  int ti[kSchurTilesPerWave], tj[kSchurTilesPerWave], nt = 0;
+#pragma unroll
+  for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_) {
+    const int t = g + kSchurGroups * (w + 4 * s_);
+    ti[s_] = 0; tj[s_] = 0;
+    if (t < ntile) {
+      int a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+      while ((a + 1) * (a + 2) / 2 <= t) ++a;
+      while (a * (a + 1) / 2 > t) --a;
+      ti[s_] = a; tj[s_] = t - a * (a + 1) / 2;
+      nt = s_ + 1;
+    }
+  }
+  double4_t acc[kSchurTilesPerWave];
+#pragma unroll
+  for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_) acc[s_] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int per_row = ldE;                 // doubles per staged row
+  const int total = kSchurRows * per_row;  // elements per chunk
+  constexpr int kPf = 20;                  // prefetch registers per thread: 256 * 20 >= 16 * 304 (ldE <= 320 on this path; larger ldE loops)
+  double pf[kPf];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < kPf; ++u) {
+      const int e = tid + 256 * u;
+      double v = 0.0;
+      if (e < total) { const int rr = e / per_row, cc = e - rr * per_row; if (k0 + rr < k_end) v = E[(size_t)(k0 + rr) * ldE + cc]; }
+      pf[u] = v;
+    }
+  };
+  auto fetch_tail = [&](int k0) {         // elements beyond 256 * kPf (only when ldE > 320): straight to LDS
+    for (int e = tid + 256 * kPf; e < total; e += 256) {
+      const int rr = e / per_row, cc = e - rr * per_row;
+      Es[e] = (k0 + rr < k_end) ? E[(size_t)(k0 + rr) * ldE + cc] : 0.0;
+    }
+  };
+  if (k_begin < k_end) fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += kSchurRows) {
+    __syncthreads();                       // the previous chunk has been consumed
+#pragma unroll
+    for (int u = 0; u < kPf; ++u) { const int e = tid + 256 * u; if (e < total) Es[e] = pf[u]; }
+    fetch_tail(k0);
+    if (tid < kSchurRows) icd[tid] = (k0 + tid < k_end) ? 1.0 / Cd[k0 + tid] : 0.0;
+    __syncthreads();
+    if (k0 + kSchurRows < k_end) fetch(k0 + kSchurRows);   // in flight while the matrix cores work
+#pragma unroll
+    for (int kk = 0; kk < kSchurRows; kk += 4) {
+      const double* row = Es + (kk + lk) * per_row;
+      const double wgt = icd[kk + lk];
+#pragma unroll
+      for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_)
+        if (s_ < nt) acc[s_] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[16 * ti[s_] + lc] * wgt, row[16 * tj[s_] + lc], acc[s_], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_) {
+    if (s_ >= nt) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = ti[s_] * 16 + lk + 4 * r, gj = tj[s_] * 16 + lc;
+      const double v = acc[s_][r];
+      if (v == 0.0) continue;
+      if (gi < dp && gj < dp) { if (gj <= gi) atomicAdd(&S[(size_t)gi * ldS + gj], -v); }
+      else if (gi == dp && gj < dp) atomicAdd(&S[(size_t)d * ldS + gj], v);
+    }
+  }
+}
+static int launch_schur(hipStream_t q, int n_lm, int dp, int ldE, const double* E, const double* Cd, int d, int ldS, double* S) {
+  const int nt = ldE / 16, ntile = nt * (nt + 1) / 2;
+  const bool lds_path = ldE <= 320 && ntile <= kSchurGroups * 4 * kSchurTilesPerWave;
+  if (lds_path) {
+    const int slices = std::max(1, std::min(32, (n_lm + 4 * kSchurRows - 1) / (4 * kSchurRows)));   // 16..128 measured: 32 is the optimum at 10 k rows
+    int rows_per_slice = (n_lm + slices - 1) / slices;
+    rows_per_slice = ((rows_per_slice + kSchurRows - 1) / kSchurRows) * kSchurRows;
+    const size_t shb = ((size_t)kSchurRows * ldE + kSchurRows) * sizeof(double);
+    hipLaunchKernelGGL(k_schur_lds, dim3(kSchurGroups, (n_lm + rows_per_slice - 1) / rows_per_slice), dim3(256), shb, q, n_lm, dp, ldE, ntile, rows_per_slice, E,
+                       Cd, d, ldS, S);
+  } else {
+    hipLaunchKernelGGL(k_schur_syrk, dim3(ntile, (n_lm + kSchurChunk - 1) / kSchurChunk), dim3(64), 0, q, n_lm, dp, ldE, ntile, E, Cd, d, ldS, S);
+  }
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ blocked Cholesky (64)
 // Right-looking, block 64, TWO launches per block step:
 //   k_chol_factor_panel : every workgroup (one wave) re-factors the 64x64 diagonal block in REGISTERS (lane i owns row i,
@@ -854,9 +953,7 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   hipLaunchKernelGGL(k_prepare, dim3(nSb + (p->n_lm ? grid(p->n_lm) : 0)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, inv_r, p->S.p, nSb, p->n_lm,
                      p->dp, p->ldE, p->C.p, p->gr.p, p->Cd.p, p->E.p, p->scal.p);
   if (p->n_lm) {
-    const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(k_schur_syrk, dim3(ntile, (p->n_lm + kSchurChunk - 1) / kSchurChunk), dim3(64), 0, q, p->n_lm, p->dp, p->ldE, ntile, p->E.p,
-                       p->Cd.p, p->d, p->dpad, p->S.p);
+    LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->d, p->dpad, p->S.p));
   }
   for (int kb = 0; kb < p->nb; ++kb) {
     const int below = p->nb - kb - 1;
@@ -1097,9 +1194,7 @@ int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs) {
   hipLaunchKernelGGL(k_prepare, dim3(nSb + (p->n_lm ? grid(p->n_lm) : 0)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, inv_r, p->S.p, nSb, p->n_lm,
                      p->dp, p->ldE, p->C.p, p->gr.p, p->Cd.p, p->E.p, (double*)nullptr);
   if (p->n_lm) {
-    const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(k_schur_syrk, dim3(ntile, (p->n_lm + kSchurChunk - 1) / kSchurChunk), dim3(64), 0, q, p->n_lm, p->dp, p->ldE, ntile, p->E.p,
-                       p->Cd.p, p->d, p->dpad, p->S.p);
+    LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->d, p->dpad, p->S.p));
   }
   LVF_HIP(hipGetLastError());
   std::vector<double> h(nS);
