@@ -80,3 +80,7 @@ if __name__ == "__main__":
     kernel_stats(os.path.join(root, "trace"))
     for sub, label in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_l2", "TCC_HIT_sum TCC_MISS_sum")):
         pmc(os.path.join(root, sub), label)
+    if os.path.isdir(os.path.join(root, "win_trace")):
+        print("\n## tools/run_full_window.py 30  (configs[3]: 50 KF / 10 k landmarks, one LM iteration per step)")
+        kernel_stats(os.path.join(root, "win_trace"))
+        pmc(os.path.join(root, "win_pmc_mfma"), "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE (MfmaUtil = MFMA_BUSY / (GUI_ACTIVE * 4 SIMDs * CUs))")
