@@ -226,7 +226,7 @@ int lvf_two_frame_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera*
   lvf_batch* b = new_batch(ctx, LVF_K_TWO_FRAME, n, 2, {1, 7, 7});
   make_camd(*left, b->cam_a); make_camd(*right, b->cam_b);
   b->sorted_by_kf = is_sorted_i32(kf2_idx, n);
-  b->host_kf1.assign(kf1_idx, kf1_idx + n); b->host_kf2.assign(kf2_idx, kf2_idx + n);
+  b->host_kf1.assign(kf1_idx, kf1_idx + n); b->host_kf2.assign(kf2_idx, kf2_idx + n); b->host_lm.assign(lm_idx, lm_idx + n);
   hipStream_t s = ctx->stream;
   int rc;
   if ((rc = b->ob_a.upload(first_ob, (size_t)2 * n, s)) || (rc = b->ob_b.upload(ob, (size_t)2 * n, s)) ||

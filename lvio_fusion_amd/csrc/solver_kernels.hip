@@ -30,6 +30,7 @@ struct lvf_problem {
   lvf::DevBuf<lvf::TfWork> tf_work;   // per-workgroup runs of same-k2 blocks (empty => generic atomic path)
   std::vector<uint8_t> pose_const_h;
   bool linearized = false;
+  bool tf_unique_lk2 = false;   // no (landmark, current keyframe) pair occurs twice in the TwoFrame batch
   double last_radius = 0;
 };
 
@@ -38,7 +39,13 @@ namespace lvf {
 constexpr int kT = 256;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 // device scalar slots
-enum { SC_COST = 0, SC_COST_NEW = 1, SC_MODEL = 2, SC_DXNORM = 3, SC_XNORM = 4, SC_GMAX = 5, SC_N = 8, SC_FAIL = 8 /* int flag */, SC_ALLOC = 9 };
+// Each sum slot is STRIPED over kStripes addresses (workgroup b adds into stripe b % kStripes, the host adds the stripes up): a
+// cost pass issues one atomic per wave, ~1100 of them at configs[3], and on ONE address they serialise in L2 (measured: the
+// residual-only TwoFrame pass spent 2/3 of its 16 us there).  SC_GMAX is a max and uses stripe 0 only.
+constexpr int kStripes = 32;
+enum { SC_COST = 0, SC_COST_NEW = 1 * kStripes, SC_MODEL = 2 * kStripes, SC_DXNORM = 3 * kStripes, SC_XNORM = 4 * kStripes, SC_GMAX = 5 * kStripes,
+       SC_N = 6 * kStripes, SC_FAIL = SC_N /* int flag */, SC_ALLOC = SC_N + 1 };
+static inline double stripe_sum(const double* h, int slot) { double s = 0.0; for (int k = 0; k < kStripes; ++k) s += h[slot + k]; return s; }
 
 __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
@@ -46,7 +53,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 __device__ __forceinline__ void block_add(double v, double* dst) {
   v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst, v);
+  if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst + (blockIdx.x & (kStripes - 1)), v);
 }
 
 struct StateP { const double *poses, *vel, *ba, *bg, *inv_depth, *w_kf; };
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__
                                                       const int* __restrict__ kf1, StateP s, CamD left, CamD right, double huber,
                                                       const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
                                                       double* __restrict__ gc, double* __restrict__ E, int ldE,
-                                                      double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost) {
+                                                      double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost, int unique_lk2) {
   __shared__ PoseD s_pose[kMaxStagedKf];
   __shared__ double s_acc[kMaxStagedKf * kAccSlots];
   __shared__ double s_k2[27];
@@ -192,10 +199,14 @@ __global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__
     atomicAdd(&C[l], d0 * d0 + d1 * d1);
     atomicAdd(&gr[l], d0 * r0 + d1 * r1);
     double* el = E + (size_t)l * ldE;
+    // E[l][k2 columns] has exactly ONE writer when no landmark is observed twice by a keyframe (checked on the host when the batch
+    // is created; always true for what BuildProblem builds): plain stores.  The landmark-indexed global atomics were half of this
+    // kernel's run time (ablation: 75 -> 37 us without them).
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       atomicAdd(&el[6 * k1 + q], L1[q] * d0 + L1[6 + q] * d1);
-      atomicAdd(&el[6 * k2 + q], L2[q] * d0 + L2[6 + q] * d1);
+      const double e2 = L2[q] * d0 + L2[6 + q] * d1;
+      if (unique_lk2) el[6 * k2 + q] = e2; else atomicAdd(&el[6 * k2 + q], e2);
     }
     double* acc = s_acc + k1 * kAccSlots;
     int q = 0;
@@ -285,22 +296,49 @@ __global__ __launch_bounds__(kT) void k_lin_po(int n, int n_kf, const double2* _
     }
   }
   if (!COST_ONLY) {
-    // blocks are normally sorted by keyframe: when the whole wave shares one pose block, reduce the 21+6 sums with
-    // wave shuffles and issue ONE set of atomics per wave (the per-pose-block JtJ/Jtr reduction of the north star)
+    // blocks are normally sorted by keyframe: when the whole wave shares one pose block, reduce the 21+6 sums with wave shuffles
+    // (the per-pose-block JtJ/Jtr reduction of the north star).  The wave sums then meet in a per-workgroup LDS table
+    // [n_kf][27] and only its non-zero entries go to global memory: ~15 waves per keyframe used to hit the SAME 27 addresses of B
+    // with global atomics, which serialise in L2.
+    __shared__ double s_acc[kMaxStagedKf * 27];
+    const bool lds_path = n_kf <= kMaxStagedKf;
+    if (lds_path) {
+      for (int e = threadIdx.x; e < n_kf * 27; e += kT) s_acc[e] = 0.0;
+      __syncthreads();
+    }
     const int k0 = __shfl(k, 0);
     const bool uniform = __all(k == k0) && k0 >= 0;
     if (uniform) {
 #pragma unroll
       for (int q = 0; q < 27; ++q) v[q] = wave_sum(v[q]);
       if ((threadIdx.x & 63) == 0) {
-        int q = 0;
-        for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) atomicAdd(&B[(size_t)(6 * k0 + a) * ld + 6 * k0 + b], v[q++]);
-        for (int a = 0; a < 6; ++a) atomicAdd(&gc[6 * k0 + a], v[21 + a]);
+        if (lds_path) { for (int q = 0; q < 27; ++q) atomicAdd(&s_acc[k0 * 27 + q], v[q]); }
+        else {
+          int q = 0;
+          for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) atomicAdd(&B[(size_t)(6 * k0 + a) * ld + 6 * k0 + b], v[q++]);
+          for (int a = 0; a < 6; ++a) atomicAdd(&gc[6 * k0 + a], v[21 + a]);
+        }
       }
     } else if (k >= 0) {
-      int q = 0;
-      for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) atomicAdd(&B[(size_t)(6 * k + a) * ld + 6 * k + b], v[q++]);
-      for (int a = 0; a < 6; ++a) atomicAdd(&gc[6 * k + a], v[21 + a]);
+      if (lds_path) { for (int q = 0; q < 27; ++q) atomicAdd(&s_acc[k * 27 + q], v[q]); }
+      else {
+        int q = 0;
+        for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) atomicAdd(&B[(size_t)(6 * k + a) * ld + 6 * k + b], v[q++]);
+        for (int a = 0; a < 6; ++a) atomicAdd(&gc[6 * k + a], v[21 + a]);
+      }
+    }
+    if (lds_path) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < n_kf * 27; e += kT) {
+        const double val = s_acc[e];
+        if (val == 0.0) continue;
+        const int kk = e / 27, slot = e - kk * 27;
+        if (slot < 21) {
+          int x = 0, rem = slot;
+          while (rem > x) { rem -= x + 1; ++x; }
+          atomicAdd(&B[(size_t)(6 * kk + x) * ld + 6 * kk + rem], val);
+        } else atomicAdd(&gc[6 * kk + slot - 21], val);
+      }
     }
   }
   block_add(c, cost);
@@ -346,7 +384,7 @@ __global__ __launch_bounds__(64) void k_lin_imu(int n, int n_kf, const double* _
   double c = 0.0;
   if (lane < 15) c = 0.5 * sr[lane] * sr[lane];
   c = wave_sum(c);
-  if (lane == 0) atomicAdd(cost, c);
+  if (lane == 0) atomicAdd(cost + (blockIdx.x & (kStripes - 1)), c);
   for (int e = lane; e < 30 * 30; e += 64) {
     const int a = e / 30, b = e % 30;
     const int ga = sidx[a], gb = sidx[b];
@@ -398,7 +436,7 @@ __global__ __launch_bounds__(64) void k_lin_prior(int n, const double* __restric
       La[6 * k + 3] = sa * rowa[4]; La[6 * k + 4] = sa * rowa[5]; La[6 * k + 5] = sa * rowa[6];
     }
   }
-  atomicAdd(cost, c);
+  atomicAdd(cost + (i & (kStripes - 1)), c);
   for (int x = 0; x < 6; ++x) {
     double g = 0.0;
     for (int k = 0; k < 6; ++k) g += Lb[6 * k + x] * r[k];
@@ -447,9 +485,9 @@ __global__ __launch_bounds__(kT) void k_prepare(int d, int dpad, const double* _
                                                 double* __restrict__ S, unsigned nS_blocks, int n_lm, int dp, int ldE, const double* __restrict__ C,
                                                 const double* __restrict__ gr, double* __restrict__ Cd, double* __restrict__ E,
                                                 double* __restrict__ scal) {
-  if (blockIdx.x == 0 && threadIdx.x == 0 && scal) {
-    for (int k = SC_COST_NEW; k < SC_N; ++k) scal[k] = 0.0;
-    *reinterpret_cast<int*>(scal + SC_FAIL) = 0;
+  if (blockIdx.x == 0 && scal) {
+    for (int k = SC_COST_NEW + threadIdx.x; k < SC_N; k += kT) scal[k] = 0.0;
+    if (threadIdx.x == 0) *reinterpret_cast<int*>(scal + SC_FAIL) = 0;
   }
   if (blockIdx.x >= nS_blocks) {
     const int l = (blockIdx.x - nS_blocks) * kT + threadIdx.x;
@@ -801,6 +839,8 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
 
 // ------------------------------------------------------------------------------------------------ step pieces
 // landmark back-substitution: dl = (-gr - e_l . dx_pose) / Cd ; model terms and norms
+// one thread per landmark walking its E row (a wave-per-landmark sweep with coalesced loads + shuffle reduce measured SLOWER,
+// 29.9 vs 25.6 us: 10 k independent threads hide the strided loads better than 2.5 k waves with a serial tail)
 __global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE, const double* __restrict__ E, const double* __restrict__ C,
                                                       const double* __restrict__ Cd, const double* __restrict__ gr,
                                                       const double* __restrict__ dxc, const double* __restrict__ inv_depth,
@@ -917,7 +957,7 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
     if (p->tf_work.n && p->n_kf <= kMaxStagedKf)
       hipLaunchKernelGGL(k_lin_tf_sorted, dim3((unsigned)p->tf_work.n), dim3(kT), 0, q, p->tf_work.p, p->n_kf, (const double2*)p->tf->ob_a.p,
                          (const double2*)p->tf->ob_b.p, p->tf->idx_a.p, p->tf->idx_b.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p,
-                         p->B.p, p->dpad, p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
+                         p->B.p, p->dpad, p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost, p->tf_unique_lk2 ? 1 : 0);
     else
       hipLaunchKernelGGL(k_lin_tf<false>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
                          p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, p->B.p, p->dpad,
@@ -1002,8 +1042,8 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
   LVF_HIP(hipMemcpyAsync(h, p->scal.p, sizeof(h), hipMemcpyDeviceToHost, q));
   LVF_HIP(hipStreamSynchronize(q));
   int hfail; std::memcpy(&hfail, &h[SC_FAIL], sizeof(int));
-  out->cost_before = h[SC_COST]; out->cost_after = h[SC_COST_NEW]; out->model = -h[SC_MODEL];
-  out->dxnorm = std::sqrt(h[SC_DXNORM]); out->xnorm = std::sqrt(h[SC_XNORM]);
+  out->cost_before = stripe_sum(h, SC_COST); out->cost_after = stripe_sum(h, SC_COST_NEW); out->model = -stripe_sum(h, SC_MODEL);
+  out->dxnorm = std::sqrt(stripe_sum(h, SC_DXNORM)); out->xnorm = std::sqrt(stripe_sum(h, SC_XNORM));
   long long gbits; std::memcpy(&gbits, &h[SC_GMAX], 8); std::memcpy(&out->gmax, &gbits, 8);
   out->solved = hfail == 0 && std::isfinite(out->cost_after) && std::isfinite(out->model);
   out->accepted = false;
@@ -1044,6 +1084,7 @@ int problem_configure(lvf_problem* p) {
   LVF_TRY(p->pose_const.ensure(p->n_kf)); LVF_TRY(p->fail.ensure(1));
   p->pose_const_h.assign(p->n_kf, 0);
   p->tf_work.n = 0;
+  p->tf_unique_lk2 = false;
   lvf_batch* two_frame = p->tf;
   if (two_frame && two_frame->n && two_frame->sorted_by_kf && !two_frame->host_kf2.empty()) {
     // work list for the sorted fast path: runs of <= kT blocks sharing one current keyframe; k1 == k2 disables it
@@ -1059,6 +1100,21 @@ int problem_configure(lvf_problem* p) {
         i = j;
       }
       LVF_TRY(p->tf_work.assign(wl.data(), wl.size(), ctx->stream));
+      // blocks are sorted by k2: a duplicate (landmark, k2) pair shows up as a repeated landmark inside one k2 run
+      const std::vector<int32_t>& lmh = two_frame->host_lm;
+      bool uniq = lmh.size() == (size_t)two_frame->n;
+      if (uniq) {
+        std::vector<int32_t> run;
+        for (int i = 0; i < two_frame->n && uniq;) {
+          int j = i;
+          while (j < two_frame->n && k2[j] == k2[i]) ++j;
+          run.assign(lmh.begin() + i, lmh.begin() + j);
+          std::sort(run.begin(), run.end());
+          uniq = std::adjacent_find(run.begin(), run.end()) == run.end();
+          i = j;
+        }
+      }
+      p->tf_unique_lk2 = uniq;
     }
   }
   LVF_HIP(hipMemsetAsync(p->pose_const.p, 0, p->n_kf, ctx->stream));
@@ -1132,8 +1188,10 @@ int lvf_problem_cost(lvf_problem* p, const lvf_solver_options* o, double* cost) 
   hipStream_t q = p->ctx->stream;
   LVF_HIP(hipMemsetAsync(p->scal.p, 0, SC_N * 8, q));
   LVF_TRY(enqueue_cost(p, state_ptrs(p->st), p->st, o->huber_a, p->scal.p + SC_COST));
-  LVF_HIP(hipMemcpyAsync(cost, p->scal.p + SC_COST, 8, hipMemcpyDeviceToHost, q));
+  double hc[kStripes];
+  LVF_HIP(hipMemcpyAsync(hc, p->scal.p + SC_COST, sizeof(hc), hipMemcpyDeviceToHost, q));
   LVF_HIP(hipStreamSynchronize(q));
+  *cost = stripe_sum(hc, 0);
   return LVF_OK;
 }
 

@@ -341,7 +341,7 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   LVF_TRY(put(w->tf->ob_a, tf_f, s)); LVF_TRY(put(w->tf->ob_b, tf_o, s)); LVF_TRY(put(w->tf->idx_a, tf_lm, s)); LVF_TRY(put(w->tf->idx_b, tf_k1, s));
   LVF_TRY(put(w->tf->idx_c, tf_k2, s));
   idx_ok(w->tf, w->n_tf, n_kf, n_lm);
-  w->tf->sorted_by_kf = true; w->tf->host_kf1 = tf_k1; w->tf->host_kf2 = tf_k2;     // assembled frame by frame: sorted by current keyframe
+  w->tf->sorted_by_kf = true; w->tf->host_kf1 = tf_k1; w->tf->host_kf2 = tf_k2; w->tf->host_lm = tf_lm;     // assembled frame by frame: sorted by current keyframe
   LVF_TRY(put(w->po->ob_a, po_o, s)); LVF_TRY(put(w->po->idx_a, po_kf, s)); LVF_TRY(put(w->po->idx_b, po_pi, s)); LVF_TRY(put(w->po->table, po_pw, s));
   idx_ok(w->po, w->n_po, n_kf, 0); w->po->n_table = w->n_po; w->po->sorted_by_kf = true;
   {
