@@ -64,27 +64,44 @@ __device__ __forceinline__ void blk3(const double* J15, int r, int c, double B[9
 // Declared algorithm (identical to the oracle's, oracle/imu.h): partial-pivot LU inverse of cov, then lower
 // Cholesky of the inverse reading the lower triangle; sqrt_info = L^T.  cov has condition number ~1e8+, so the
 // operation ORDER matters for 1e-6 parity: contraction is disabled here.
-__global__ void k_imu_sqrt_info(int n, const double* __restrict__ pre, double* __restrict__ sqrt_info) {
+// One WORKGROUP per factor (the first version ran one THREAD per factor with the three 15x15 work arrays in scratch: 0.47 ms for
+// the 49 factors of a window, paid at every batch creation and every persistent-window tick).  Every matrix element goes
+// through exactly the same sequence of operations as in the scalar algorithm — the elimination step k updates all (i, j) > k
+// independently, the 15 columns of the inverse are independent, Cholesky column j is independent over rows i — so the result
+// is bit-identical and only the loop nests that were independent run side by side.
+__global__ __launch_bounds__(256) void k_imu_sqrt_info(int n, const double* __restrict__ pre, double* __restrict__ sqrt_info) {
 #pragma clang fp contract(off)
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double LU[225], X[225], L[225];
+  __shared__ int piv[15];
+  const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
   const double* cov = pre + (size_t)f * kPre + OFF_COV;
-  double LU[225], X[225], L[225];
-  int piv[15];
-  for (int i = 0; i < 225; ++i) LU[i] = cov[i];
+  if (tid < 225) { LU[tid] = cov[tid]; L[tid] = 0.0; }
+  __syncthreads();
+  const int ti = tid >> 4, tj = tid & 15;          // element (ti, tj) of a 16 x 16 thread grid
   for (int k = 0; k < 15; ++k) {
-    int p = k;
-    double best = fabs(LU[15 * k + k]);
-    for (int i = k + 1; i < 15; ++i) { const double a = fabs(LU[15 * i + k]); if (a > best) { best = a; p = i; } }
-    piv[k] = p;
-    if (p != k) for (int j = 0; j < 15; ++j) { const double t = LU[15 * k + j]; LU[15 * k + j] = LU[15 * p + j]; LU[15 * p + j] = t; }
-    for (int i = k + 1; i < 15; ++i) {
-      LU[15 * i + k] /= LU[15 * k + k];
-      const double l = LU[15 * i + k];
-      for (int j = k + 1; j < 15; ++j) LU[15 * i + j] -= l * LU[15 * k + j];
+    if (tid == 0) {
+      int p = k;
+      double best = fabs(LU[15 * k + k]);
+      for (int i = k + 1; i < 15; ++i) { const double a = fabs(LU[15 * i + k]); if (a > best) { best = a; p = i; } }
+      piv[k] = p;
     }
+    __syncthreads();
+    const int p = piv[k];
+    if (p != k && tid < 15) { const double t = LU[15 * k + tid]; LU[15 * k + tid] = LU[15 * p + tid]; LU[15 * p + tid] = t; }
+    __syncthreads();
+    double l = 0.0;
+    const bool row = ti > k && ti < 15;
+    if (row) l = LU[15 * ti + k] / LU[15 * k + k];
+    __syncthreads();                               // every thread of a row has read LU[i][k] before tj == k overwrites it
+    if (row) {
+      if (tj == k) LU[15 * ti + k] = l;
+      else if (tj > k && tj < 15) LU[15 * ti + tj] -= l * LU[15 * k + tj];
+    }
+    __syncthreads();
   }
-  for (int c = 0; c < 15; ++c) {
+  if (tid < 15) {
+    const int c = tid;
     double b[15];
     for (int i = 0; i < 15; ++i) b[i] = (i == c) ? 1.0 : 0.0;
     for (int k = 0; k < 15; ++k) { const double t = b[k]; b[k] = b[piv[k]]; b[piv[k]] = t; }
@@ -92,19 +109,24 @@ __global__ void k_imu_sqrt_info(int n, const double* __restrict__ pre, double* _
     for (int i = 14; i >= 0; --i) { double s = b[i]; for (int j = i + 1; j < 15; ++j) s -= LU[15 * i + j] * b[j]; b[i] = s / LU[15 * i + i]; }
     for (int i = 0; i < 15; ++i) X[15 * i + c] = b[i];
   }
-  for (int i = 0; i < 225; ++i) L[i] = 0.0;
+  __syncthreads();
   for (int j = 0; j < 15; ++j) {
-    double d = X[15 * j + j];
-    for (int k = 0; k < j; ++k) d -= L[15 * j + k] * L[15 * j + k];
-    L[15 * j + j] = sqrt(d);
-    for (int i = j + 1; i < 15; ++i) {
-      double s = X[15 * i + j];
-      for (int k = 0; k < j; ++k) s -= L[15 * i + k] * L[15 * j + k];
-      L[15 * i + j] = s / L[15 * j + j];
+    if (tid == 0) {
+      double d = X[15 * j + j];
+      for (int k = 0; k < j; ++k) d -= L[15 * j + k] * L[15 * j + k];
+      L[15 * j + j] = sqrt(d);
     }
+    __syncthreads();
+    if (tid > j && tid < 15) {
+      const int i = tid;
+      double s_ = X[15 * i + j];
+      for (int k = 0; k < j; ++k) s_ -= L[15 * i + k] * L[15 * j + k];
+      L[15 * i + j] = s_ / L[15 * j + j];
+    }
+    __syncthreads();
   }
   double* S = sqrt_info + (size_t)f * 225;
-  for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) S[15 * i + j] = L[15 * j + i];
+  if (tid < 225) { const int i = tid / 15, j = tid - 15 * i; S[15 * i + j] = L[15 * j + i]; }
 }
 
 // --------------------------------------------------------------------------------- ImuError evaluate
@@ -360,7 +382,7 @@ __global__ __launch_bounds__(256) void k_preintegrate(const int* __restrict__ of
 
 int launch_imu_sqrt_info(lvf_batch* b) {
   if (b->n == 0) return LVF_OK;
-  hipLaunchKernelGGL(k_imu_sqrt_info, dim3((b->n + 63) / 64), dim3(64), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p);
+  hipLaunchKernelGGL(k_imu_sqrt_info, dim3(b->n), dim3(256), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p);
   LVF_HIP(hipGetLastError());
   return LVF_OK;
 }

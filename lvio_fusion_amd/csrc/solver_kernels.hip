@@ -1102,8 +1102,8 @@ int problem_configure(lvf_problem* p) {
       LVF_TRY(p->tf_work.assign(wl.data(), wl.size(), ctx->stream));
       // blocks are sorted by k2: a duplicate (landmark, k2) pair shows up as a repeated landmark inside one k2 run
       const std::vector<int32_t>& lmh = two_frame->host_lm;
-      bool uniq = lmh.size() == (size_t)two_frame->n;
-      if (uniq) {
+      bool uniq = two_frame->unique_lk2_known || lmh.size() == (size_t)two_frame->n;
+      if (uniq && !two_frame->unique_lk2_known) {
         std::vector<int32_t> run;
         for (int i = 0; i < two_frame->n && uniq;) {
           int j = i;

@@ -15,6 +15,7 @@
 // by ascending landmark id (features_left is a std::map keyed by landmark id), uploads them with one copy per array and runs
 // the device LM loop; results are read back into the host mirror.
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <unordered_map>
 #include "host_se3.hpp"
@@ -238,32 +239,59 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   LVF_TRY(lvf::enter(ctx));
   hipStream_t s = ctx->stream;
   const int n_kf = (int)w->kfs.size();
+  static const bool timing = getenv("LVF_WINDOW_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t_begin = now();
   // ---- assemble the block lists in BuildProblem's order
   std::vector<double> tc_l, tc_r, tf_f, tf_o, po_o, po_pw, pr_t, pr_w, pr_v;
   std::vector<int32_t> tc_lm, tc_kf, tf_lm, tf_k1, tf_k2, po_kf, po_pi, imu_i, imu_j, pr_a, pr_b;
   std::vector<lvf_preint> imu_pre;
   for (lvf_window::Lm& l : w->lms) l.slot = -1;
   w->slot_lm.clear();
-  auto slot_of = [&](int lm) {
-    lvf_window::Lm& l = w->lms[lm];
-    if (l.slot < 0) { l.slot = (int)w->slot_lm.size(); w->slot_lm.push_back(lm); }
-    return l.slot;
+  // landmark->ToWorld() once per live landmark per tick (the reference recomputes it per feature) with the keyframe rotations
+  // expanded once, and per frame the one row of the world->cam0 transform that Camera::Far needs
+  auto rot_of = [](const double q[4], double R[9]) {
+    double e0[3] = {1, 0, 0}, e1[3] = {0, 1, 0}, e2[3] = {0, 0, 1}, c0[3], c1[3], c2[3];
+    hse3::rotate(q, e0, c0); hse3::rotate(q, e1, c1); hse3::rotate(q, e2, c2);
+    R[0] = c0[0]; R[1] = c1[0]; R[2] = c2[0]; R[3] = c0[1]; R[4] = c1[1]; R[5] = c2[1]; R[6] = c0[2]; R[7] = c1[2]; R[8] = c2[2];
   };
-  // landmark->ToWorld() once per live landmark per tick (the reference recomputes it per feature), and per frame the one row of
-  // the world->cam0 transform that Camera::Far needs
-  std::vector<double> lm_pw((size_t)3 * w->lms.size());
-  std::vector<int> lm_birth_pos(w->lms.size(), -1);
-  for (size_t i = 0; i < w->lms.size(); ++i) {
+  std::vector<double> Rk((size_t)9 * n_kf);
+  for (int k = 0; k < n_kf; ++k) rot_of(w->kfs[k].pose, &Rk[(size_t)9 * k]);
+  double Re[9];
+  rot_of(w->right.extrinsic, Re);
+  const double* te = w->right.extrinsic + 4;
+  const size_t nl = w->lms.size();
+  std::vector<double> lm_pw((size_t)3 * nl);
+  std::vector<int> lm_birth_pos(nl, -1);
+  const int64_t first_id = w->kfs.front().id;
+  for (size_t i = 0; i < nl; ++i) {
     const lvf_window::Lm& l = w->lms[i];
     if (l.fixed) { std::memcpy(&lm_pw[3 * i], l.pw, 24); continue; }
+    if (l.birth_kf < first_id) continue;
     auto ib = w->kf_index.find(l.birth_kf);
     if (ib == w->kf_index.end()) continue;
-    lm_birth_pos[i] = ib->second;
-    to_world(w->right, l.right_ob, l.inv_depth, w->kfs[ib->second].pose, &lm_pw[3 * i]);
+    const int bp = ib->second;
+    lm_birth_pos[i] = bp;
+    const double d = 1.0 / l.inv_depth;
+    const double ps[3] = {(l.right_ob[0] - w->right.cx) * d / w->right.fx, (l.right_ob[1] - w->right.cy) * d / w->right.fy, d};
+    const double pb[3] = {Re[0] * ps[0] + Re[1] * ps[1] + Re[2] * ps[2] + te[0], Re[3] * ps[0] + Re[4] * ps[1] + Re[5] * ps[2] + te[1],
+                          Re[6] * ps[0] + Re[7] * ps[1] + Re[8] * ps[2] + te[2]};
+    const double* R = &Rk[(size_t)9 * bp];
+    const double* t = w->kfs[bp].pose + 4;
+    lm_pw[3 * i] = R[0] * pb[0] + R[1] * pb[1] + R[2] * pb[2] + t[0];
+    lm_pw[3 * i + 1] = R[3] * pb[0] + R[4] * pb[1] + R[5] * pb[2] + t[1];
+    lm_pw[3 * i + 2] = R[6] * pb[0] + R[7] * pb[1] + R[8] * pb[2] + t[2];
   }
   double inv_e[7];
   hse3::inv(w->left.extrinsic, inv_e);
   const double far_z = w->opt.baseline * 50.0;
+  // block arrays are written through raw cursors into buffers sized for the worst case (every feature in every list)
+  size_t n_obs = 0;
+  for (const lvf_window::Kf& f : w->kfs) n_obs += f.obs.size();
+  tc_l.resize(2 * n_obs); tc_r.resize(2 * n_obs); tf_f.resize(2 * n_obs); tf_o.resize(2 * n_obs); po_o.resize(2 * n_obs); po_pw.resize(3 * n_obs);
+  tc_lm.resize(n_obs); tc_kf.resize(n_obs); tf_lm.resize(n_obs); tf_k1.resize(n_obs); tf_k2.resize(n_obs); po_kf.resize(n_obs); po_pi.resize(n_obs);
+  size_t ntc = 0, ntf = 0, npo = 0;
   for (int k = 0; k < n_kf; ++k) {
     lvf_window::Kf& f = w->kfs[k];
     f.sort_unique();
@@ -283,19 +311,21 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
     for (const lvf_window::Obs& ob : f.obs) {
       lvf_window::Lm& l = w->lms[ob.lm];
       if (l.birth_kf == f.id) {
-        tc_l.insert(tc_l.end(), ob.ob, ob.ob + 2); tc_r.insert(tc_r.end(), l.right_ob, l.right_ob + 2);
-        tc_lm.push_back(slot_of(ob.lm)); tc_kf.push_back(k);
+        tc_l[2 * ntc] = ob.ob[0]; tc_l[2 * ntc + 1] = ob.ob[1]; tc_r[2 * ntc] = l.right_ob[0]; tc_r[2 * ntc + 1] = l.right_ob[1];
+        if (l.slot < 0) { l.slot = (int)w->slot_lm.size(); w->slot_lm.push_back(ob.lm); }
+        tc_lm[ntc] = l.slot; tc_kf[ntc] = k; ++ntc;
         continue;
       }
       const double* pw = &lm_pw[(size_t)3 * ob.lm];
       const int bpos = lm_birth_pos[ob.lm];
       if (bpos < 0) {
         if (!l.fixed) continue;                        // birth frame unknown (never happens through this API)
-        po_o.insert(po_o.end(), ob.ob, ob.ob + 2); po_pw.insert(po_pw.end(), pw, pw + 3);
-        po_pi.push_back((int)po_kf.size()); po_kf.push_back(k);
+        po_o[2 * npo] = ob.ob[0]; po_o[2 * npo + 1] = ob.ob[1]; po_pw[3 * npo] = pw[0]; po_pw[3 * npo + 1] = pw[1]; po_pw[3 * npo + 2] = pw[2];
+        po_pi[npo] = (int)npo; po_kf[npo] = k; ++npo;
       } else {
-        tf_f.insert(tf_f.end(), l.right_ob, l.right_ob + 2); tf_o.insert(tf_o.end(), ob.ob, ob.ob + 2);
-        tf_lm.push_back(slot_of(ob.lm)); tf_k1.push_back(bpos); tf_k2.push_back(k);
+        tf_f[2 * ntf] = l.right_ob[0]; tf_f[2 * ntf + 1] = l.right_ob[1]; tf_o[2 * ntf] = ob.ob[0]; tf_o[2 * ntf + 1] = ob.ob[1];
+        if (l.slot < 0) { l.slot = (int)w->slot_lm.size(); w->slot_lm.push_back(ob.lm); }
+        tf_lm[ntf] = l.slot; tf_k1[ntf] = bpos; tf_k2[ntf] = k; ++ntf;
       }
       if (!(zrow[0] * pw[0] + zrow[1] * pw[1] + zrow[2] * pw[2] + zoff > far_z)) ++near_visual;   // !Camera::Far
     }
@@ -311,9 +341,13 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
       pr_b.push_back(k); pr_t.insert(pr_t.end(), t7, t7 + 7); pr_w.push_back(w->opt.prior_weight); pr_v.push_back(w->opt.prior_v);
     }
   }
+  tc_l.resize(2 * ntc); tc_r.resize(2 * ntc); tc_lm.resize(ntc); tc_kf.resize(ntc);
+  tf_f.resize(2 * ntf); tf_o.resize(2 * ntf); tf_lm.resize(ntf); tf_k1.resize(ntf); tf_k2.resize(ntf);
+  po_o.resize(2 * npo); po_pw.resize(3 * npo); po_kf.resize(npo); po_pi.resize(npo);
   const int n_lm = (int)w->slot_lm.size();
   w->n_tc = (int)tc_lm.size(); w->n_tf = (int)tf_lm.size(); w->n_po = (int)po_kf.size(); w->n_imu = (int)imu_i.size(); w->n_prior = (int)pr_b.size();
 
+  const auto t_assembled = now();
   // ---- persistent device objects: created once (empty), re-filled every tick through grow-only buffers
   if (!w->st) {
     LVF_TRY(lvf_state_create(ctx, 0, 0, &w->st));
@@ -341,7 +375,7 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   LVF_TRY(put(w->tf->ob_a, tf_f, s)); LVF_TRY(put(w->tf->ob_b, tf_o, s)); LVF_TRY(put(w->tf->idx_a, tf_lm, s)); LVF_TRY(put(w->tf->idx_b, tf_k1, s));
   LVF_TRY(put(w->tf->idx_c, tf_k2, s));
   idx_ok(w->tf, w->n_tf, n_kf, n_lm);
-  w->tf->sorted_by_kf = true; w->tf->host_kf1 = tf_k1; w->tf->host_kf2 = tf_k2; w->tf->host_lm = tf_lm;     // assembled frame by frame: sorted by current keyframe
+  w->tf->sorted_by_kf = true; w->tf->host_kf1 = tf_k1; w->tf->host_kf2 = tf_k2; w->tf->host_lm.clear(); w->tf->unique_lk2_known = true;   // Kf::sort_unique keeps one observation per (keyframe, landmark)     // assembled frame by frame: sorted by current keyframe
   LVF_TRY(put(w->po->ob_a, po_o, s)); LVF_TRY(put(w->po->idx_a, po_kf, s)); LVF_TRY(put(w->po->idx_b, po_pi, s)); LVF_TRY(put(w->po->table, po_pw, s));
   idx_ok(w->po, w->n_po, n_kf, 0); w->po->n_table = w->n_po; w->po->sorted_by_kf = true;
   {
@@ -360,13 +394,16 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
     idx_ok(b, w->n_prior, n_kf, 0);
     b->host_kf1 = pr_a; b->host_kf2 = pr_b;
   }
+  const auto t_uploaded = now();
   if (!w->prob) {
     LVF_TRY(lvf_problem_create(ctx, st, w->tc, w->tf, w->po, w->imu, &w->prob));
     LVF_TRY(lvf_problem_set_pose_priors(w->prob, w->prior));
   } else {
     LVF_TRY(problem_configure(w->prob));
   }
+  const auto t_configured = now();
   LVF_TRY(lvf_problem_solve(w->prob, o, summary));
+  const auto t_solved = now();
   // ---- read the solution back into the host mirror (frame->pose, Vw, biases, landmark->inv_depth)
   LVF_HIP(hipMemcpyAsync(poses.data(), st->poses.p, poses.size() * 8, hipMemcpyDeviceToHost, s));
   LVF_HIP(hipMemcpyAsync(vel.data(), st->vel.p, vel.size() * 8, hipMemcpyDeviceToHost, s));
@@ -380,6 +417,9 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
     if (f.good_imu) { std::memcpy(f.vel, &vel[(size_t)3 * k], 24); std::memcpy(f.ba, &ba[(size_t)3 * k], 24); std::memcpy(f.bg, &bg[(size_t)3 * k], 24); }
   }
   for (int l = 0; l < n_lm; ++l) w->lms[w->slot_lm[l]].inv_depth = invd[l];
+  if (timing)
+    std::fprintf(stderr, "lvf_window_solve: assemble %.3f ms, upload %.3f ms, configure %.3f ms, solve %.3f ms (%d its), read-back %.3f ms\n", ms(t_begin, t_assembled),
+                 ms(t_assembled, t_uploaded), ms(t_uploaded, t_configured), ms(t_configured, t_solved), summary->num_iterations, ms(t_solved, now()));
   return LVF_OK;
 }
 
