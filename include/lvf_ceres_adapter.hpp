@@ -426,22 +426,30 @@ struct BlockView {
   const ceres::CostFunction* cf;
   const GpuCostFunction* g;
   const ceres::LossFunction* loss;
-  std::vector<double*> params;
+  double* const* params;      // into the caller's flat pointer store (one allocation for the whole problem, not one per block)
 };
 
-inline bool collect(ceres::Problem* problem, std::vector<BlockView>* out, const Fail& fail) {
+inline bool collect(ceres::Problem* problem, std::vector<BlockView>* out, std::vector<double*>* flat, const Fail& fail) {
   std::vector<ceres::ResidualBlockId> ids;
   problem->GetResidualBlocks(&ids);
   out->reserve(ids.size());
+  flat->reserve(ids.size() * 3);
+  std::vector<size_t> off;
+  off.reserve(ids.size());
+  std::vector<double*> scratch;
   for (size_t i = 0; i < ids.size(); ++i) {
     BlockView v;
     v.cf = problem->GetCostFunctionForResidualBlock(ids[i]);
     v.g = dynamic_cast<const GpuCostFunction*>(v.cf);
     if (!v.g) return fail("residual block " + std::to_string(i) + " is not an lvio_fusion::gpu cost function (no CPU solver is linked)");
     v.loss = problem->GetLossFunctionForResidualBlock(ids[i]);
-    problem->GetParameterBlocksForResidualBlock(ids[i], &v.params);
-    out->push_back(std::move(v));
+    v.params = nullptr;
+    problem->GetParameterBlocksForResidualBlock(ids[i], &scratch);
+    off.push_back(flat->size());
+    flat->insert(flat->end(), scratch.begin(), scratch.end());
+    out->push_back(v);
   }
+  for (size_t i = 0; i < ids.size(); ++i) (*out)[i].params = flat->data() + off[i];
   return true;
 }
 
@@ -556,29 +564,38 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
     if (!*have) { *slot = c; *have = true; return true; }
     return same_cam(*slot, c);
   };
+  const ceres::LossFunction* loss_seen = nullptr;   // BuildProblem shares ONE loss object: probe each distinct pointer once
+  bool loss_seen_ok = false, loss_seen_any = false;
   auto use_loss = [&](const ceres::LossFunction* loss) {
+    if (loss_seen_any && loss == loss_seen) return loss_seen_ok;
     const double a = probe_huber(loss);
-    if (a < 0.0) return false;
-    if (w->huber == -2.0) w->huber = a;
-    return w->huber == a;
+    bool ok = a >= 0.0;
+    if (ok) {
+      if (w->huber == -2.0) w->huber = a;
+      ok = w->huber == a;
+    }
+    loss_seen = loss; loss_seen_ok = ok; loss_seen_any = true;
+    return ok;
   };
   auto bind3 = [&](std::vector<double*>& slot, int kf, double* p) {
     if (slot[kf] && slot[kf] != p) return false;
     slot[kf] = p;
     return true;
   };
+  auto at = [](size_t i) { return "residual block " + std::to_string(i) + ": "; };   // only built on the failure path
   std::vector<size_t> two_camera_pending;
+  w->order_kind.reserve(blocks.size()); w->order_idx.reserve(blocks.size());
+  w->lm_id.reserve(blocks.size() / 2);
   for (size_t i = 0; i < blocks.size(); ++i) {
     const BlockView& b = blocks[i];
-    const std::string at = "residual block " + std::to_string(i) + ": ";
     switch (b.g->kind()) {
       case Kind::PoseOnly: {
         const auto* f = static_cast<const PoseOnlyReprojectionError*>(b.g);
         const int kf = kf_of(b.params[0]);
-        if (kf < 0) return fail(at + "pose block not registered");
-        if (!set_w(kf, f->weight)) return fail(at + "visual blocks of one keyframe must share one weight (frame->weights.visual)");
-        if (!use_cam(f->cam, &w->left, &w->have_left)) return fail(at + "all blocks must share the left camera");
-        if (!use_loss(b.loss)) return fail(at + "visual blocks must share one HuberLoss/TrivialLoss");
+        if (kf < 0) return fail(at(i) + "pose block not registered");
+        if (!set_w(kf, f->weight)) return fail(at(i) + "visual blocks of one keyframe must share one weight (frame->weights.visual)");
+        if (!use_cam(f->cam, &w->left, &w->have_left)) return fail(at(i) + "all blocks must share the left camera");
+        if (!use_loss(b.loss)) return fail(at(i) + "visual blocks must share one HuberLoss/TrivialLoss");
         w->order_kind.push_back(2); w->order_idx.push_back((int)w->po_kf.size());
         w->po_o.insert(w->po_o.end(), f->ob, f->ob + 2); w->po_pw.insert(w->po_pw.end(), f->pw, f->pw + 3);
         w->po_pi.push_back((int)w->po_kf.size()); w->po_kf.push_back(kf);
@@ -587,10 +604,10 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
       case Kind::TwoFrame: {
         const auto* f = static_cast<const TwoFrameReprojectionError*>(b.g);
         const int k1 = kf_of(b.params[1]), k2 = kf_of(b.params[2]);
-        if (k1 < 0 || k2 < 0) return fail(at + "pose block not registered");
-        if (!set_w(k2, f->weight)) return fail(at + "visual blocks of one keyframe must share one weight (frame->weights.visual)");
-        if (!use_cam(f->left, &w->left, &w->have_left) || !use_cam(f->right, &w->right, &w->have_right)) return fail(at + "all blocks must share the stereo pair");
-        if (!use_loss(b.loss)) return fail(at + "visual blocks must share one HuberLoss/TrivialLoss");
+        if (k1 < 0 || k2 < 0) return fail(at(i) + "pose block not registered");
+        if (!set_w(k2, f->weight)) return fail(at(i) + "visual blocks of one keyframe must share one weight (frame->weights.visual)");
+        if (!use_cam(f->left, &w->left, &w->have_left) || !use_cam(f->right, &w->right, &w->have_right)) return fail(at(i) + "all blocks must share the stereo pair");
+        if (!use_loss(b.loss)) return fail(at(i) + "visual blocks must share one HuberLoss/TrivialLoss");
         w->order_kind.push_back(1); w->order_idx.push_back((int)w->tf_lm.size());
         w->tf_f.insert(w->tf_f.end(), f->first_ob, f->first_ob + 2); w->tf_o.insert(w->tf_o.end(), f->ob, f->ob + 2);
         w->tf_lm.push_back(lm_of(b.params[0])); w->tf_k1.push_back(k1); w->tf_k2.push_back(k2);
@@ -598,8 +615,8 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
       }
       case Kind::TwoCamera: {
         const auto* f = static_cast<const TwoCameraReprojectionError*>(b.g);
-        if (!use_cam(f->left, &w->left, &w->have_left) || !use_cam(f->right, &w->right, &w->have_right)) return fail(at + "all blocks must share the stereo pair");
-        if (!use_loss(b.loss)) return fail(at + "visual blocks must share one HuberLoss/TrivialLoss");
+        if (!use_cam(f->left, &w->left, &w->have_left) || !use_cam(f->right, &w->right, &w->have_right)) return fail(at(i) + "all blocks must share the stereo pair");
+        if (!use_loss(b.loss)) return fail(at(i) + "visual blocks must share one HuberLoss/TrivialLoss");
         w->order_kind.push_back(0); w->order_idx.push_back((int)w->tc_lm.size());
         w->tc_l.insert(w->tc_l.end(), f->left_ob, f->left_ob + 2); w->tc_r.insert(w->tc_r.end(), f->right_ob, f->right_ob + 2);
         w->tc_lm.push_back(lm_of(b.params[0])); w->tc_kf.push_back(-1); w->tc_w.push_back(f->weight / 5.0);
@@ -609,11 +626,11 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
       case Kind::Imu: {
         const auto* f = static_cast<const ImuError*>(b.g);
         const int ki = kf_of(b.params[0]), kj = kf_of(b.params[4]);
-        if (ki < 0 || kj < 0) return fail(at + "pose block not registered");
-        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at + "a robust loss on ImuError is not supported (the reference passes NULL)");
+        if (ki < 0 || kj < 0) return fail(at(i) + "pose block not registered");
+        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at(i) + "a robust loss on ImuError is not supported (the reference passes NULL)");
         if (!bind3(w->v_ptr, ki, b.params[1]) || !bind3(w->ba_ptr, ki, b.params[2]) || !bind3(w->bg_ptr, ki, b.params[3]) ||
             !bind3(w->v_ptr, kj, b.params[5]) || !bind3(w->ba_ptr, kj, b.params[6]) || !bind3(w->bg_ptr, kj, b.params[7]))
-          return fail(at + "a keyframe is linked to two different velocity/bias blocks");
+          return fail(at(i) + "a keyframe is linked to two different velocity/bias blocks");
         w->order_kind.push_back(3); w->order_idx.push_back((int)w->imu_i.size());
         w->imu_pre.push_back(f->pre); w->imu_i.push_back(ki); w->imu_j.push_back(kj);
         break;
@@ -621,8 +638,8 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
       case Kind::PoseGraph: {
         const auto* f = static_cast<const PoseGraphError*>(b.g);
         const int ka = kf_of(b.params[0]), kb = kf_of(b.params[1]);
-        if (ka < 0 || kb < 0) return fail(at + "pose block not registered");
-        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at + "a robust loss on PoseGraphError is not supported (the reference passes NULL)");
+        if (ka < 0 || kb < 0) return fail(at(i) + "pose block not registered");
+        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at(i) + "a robust loss on PoseGraphError is not supported (the reference passes NULL)");
         w->order_kind.push_back(4); w->order_idx.push_back((int)w->pr_a.size());
         w->pr_a.push_back(ka); w->pr_b.push_back(kb); w->pr_t.insert(w->pr_t.end(), f->target, f->target + 7);
         w->pr_w.push_back(f->weight); w->pr_v.push_back(f->v);
@@ -631,8 +648,8 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
       case Kind::Pose: {
         const auto* f = static_cast<const PoseError*>(b.g);
         const int kb = kf_of(b.params[0]);
-        if (kb < 0) return fail(at + "pose block not registered");
-        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at + "a robust loss on PoseError is not supported (the reference passes NULL)");
+        if (kb < 0) return fail(at(i) + "pose block not registered");
+        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at(i) + "a robust loss on PoseError is not supported (the reference passes NULL)");
         w->order_kind.push_back(4); w->order_idx.push_back((int)w->pr_a.size());
         w->pr_a.push_back(-1); w->pr_b.push_back(kb); w->pr_t.insert(w->pr_t.end(), f->origin, f->origin + 7);
         w->pr_w.push_back(f->weight); w->pr_v.push_back(f->v);
@@ -641,14 +658,14 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
       case Kind::R: {
         const auto* f = static_cast<const RError*>(b.g);
         const int kb = kf_of(b.params[0]);
-        if (kb < 0) return fail(at + "pose block not registered");
-        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at + "a robust loss on RError is not supported (the reference passes NULL)");
+        if (kb < 0) return fail(at(i) + "pose block not registered");
+        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at(i) + "a robust loss on RError is not supported (the reference passes NULL)");
         w->order_kind.push_back(4); w->order_idx.push_back((int)w->pr_a.size());
         w->pr_a.push_back(-2); w->pr_b.push_back(kb); w->pr_t.insert(w->pr_t.end(), f->origin, f->origin + 7);
         w->pr_w.push_back(f->weight); w->pr_v.push_back(0.0);
         break;
       }
-      default: return fail(at + "lidar blocks cannot be mixed into a BA window");
+      default: return fail(at(i) + "lidar blocks cannot be mixed into a BA window");
     }
   }
   // TwoCamera blocks only carry a weight (5 * frame->weights.visual); the library looks weights up per keyframe, so each
@@ -737,6 +754,8 @@ inline bool solve_window(const ceres::Solver::Options& options, ceres::Problem* 
                          ceres::Solver::Summary* summary, const Fail& fail) {
   ThreadContext& tc = thread_context();
   if (!tc.ctx) return fail("no usable GPU context: " + tc.error);
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
   Window w;
   if (!build_window(problem, blocks, &w, fail)) return false;
   DeviceWindow d;
@@ -744,7 +763,9 @@ inline bool solve_window(const ceres::Solver::Options& options, ceres::Problem* 
   lvf_solver_options o;
   to_lvf_options(options, w.huber, &o);
   lvf_solver_summary s;
+  const auto t1 = clk::now();
   if (lvf_problem_solve(d.h.prob, &o, &s) != LVF_OK) return fail(lvf_last_error());
+  const auto t2 = clk::now();
   if (s.termination == 2) return fail("device LM failed (normal equations not positive definite at the smallest trust region)");
   // read back, then write IN PLACE into the caller's parameter arrays (frame->pose.data(), &landmark->inv_depth, ...)
   const int n_kf = (int)w.pose_ptr.size(), n_lm = (int)w.lm_ptr.size();
@@ -765,6 +786,9 @@ inline bool solve_window(const ceres::Solver::Options& options, ceres::Problem* 
   summary->num_parameter_blocks = summary->num_parameter_blocks_reduced = problem->NumParameterBlocks();
   summary->termination_type = s.termination == 0 ? ceres::CONVERGENCE : ceres::NO_CONVERGENCE;
   summary->message = "sliding-window BA solved on device";
+  summary->preprocessor_time_in_seconds += std::chrono::duration<double>(t1 - t0).count();   // classify + upload (collect() is added by Solve)
+  summary->minimizer_time_in_seconds = std::chrono::duration<double>(t2 - t1).count();
+  summary->postprocessor_time_in_seconds = std::chrono::duration<double>(clk::now() - t2).count();
   return true;
 }
 
@@ -776,7 +800,9 @@ inline void Solve(const ceres::Solver::Options& options, ceres::Problem* problem
   *summary = ceres::Solver::Summary();
   const detail::Fail fail{summary};
   std::vector<detail::BlockView> blocks;
-  if (!detail::collect(problem, &blocks, fail)) return;
+  std::vector<double*> block_params;
+  if (!detail::collect(problem, &blocks, &block_params, fail)) return;
+  summary->preprocessor_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (blocks.empty()) {
     summary->termination_type = ceres::CONVERGENCE; summary->initial_cost = summary->final_cost = 0.0;
     summary->num_successful_steps = summary->num_unsuccessful_steps = 0; summary->num_residual_blocks = summary->num_residual_blocks_reduced = 0;
@@ -801,7 +827,8 @@ inline bool Evaluate(ceres::Problem* problem, double* cost, std::vector<double>*
   const detail::Fail fail{&dummy};
   auto bail = [&]() { if (error) *error = dummy.message; return false; };
   std::vector<detail::BlockView> blocks;
-  if (!detail::collect(problem, &blocks, fail)) return bail();
+  std::vector<double*> block_params;
+  if (!detail::collect(problem, &blocks, &block_params, fail)) return bail();
   ThreadContext& tc = thread_context();
   if (!tc.ctx) { if (error) *error = tc.error; return false; }
   detail::Window w;

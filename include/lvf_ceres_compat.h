@@ -254,6 +254,7 @@ struct Solver {
     int num_residual_blocks = -1, num_residual_blocks_reduced = -1;
     int num_parameter_blocks = -1, num_parameter_blocks_reduced = -1;
     double total_time_in_seconds = -1.0;
+    double preprocessor_time_in_seconds = 0.0, minimizer_time_in_seconds = 0.0, postprocessor_time_in_seconds = 0.0;
     std::string BriefReport() const {
       return "lvf(gfx950): cost " + std::to_string(initial_cost) + " -> " + std::to_string(final_cost) + ", " +
              std::to_string(num_successful_steps + num_unsuccessful_steps) + " iterations, " + message;
