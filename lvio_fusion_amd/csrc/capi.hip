@@ -274,6 +274,7 @@ int lvf_imu_create(lvf_ctx* ctx, int n, const lvf_preint* pre, const int32_t* kf
       (rc = b->idx_b.upload(kf_j, n, s)) || (rc = b->sqrt_info.alloc((size_t)225 * n)) || (rc = alloc_outputs(b)) ||
       (rc = launch_imu_sqrt_info(b))) { delete b; return rc; }
   b->min_n_kf = std::max(max_idx(kf_i, n), max_idx(kf_j, n)) + 1;
+  if (n > 0) { b->host_kf1.assign(kf_i, kf_i + n); b->host_kf2.assign(kf_j, kf_j + n); }   // the solver's elimination order follows the IMU chain
   LVF_HIP(hipStreamSynchronize(s));
   *out = b;
   return LVF_OK;

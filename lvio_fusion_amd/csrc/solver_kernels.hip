@@ -17,12 +17,28 @@
 #include "factor_eval.hpp"
 #include "lvf_internal.hpp"
 
-namespace lvf { struct TfWork; }
+namespace lvf {
+struct TfWork;
+// one (v, ba, bg) block eliminated ahead of the dense factorisation: its 9 columns start at `col`, its `m` neighbour rows
+// (later-ordered (v, ba, bg) blocks, poses, the augmented row; ascending) sit at rows[row_off .. row_off + m)
+struct SpNode { int col, row_off, m, id; };
+constexpr int kSpMaxLevels = 12, kSpMaxRows = 768;
+struct SpLevels { int n; int first[kSpMaxLevels]; int count[kSpMaxLevels]; };
+}
 struct lvf_problem {
   lvf_ctx* ctx = nullptr;
   lvf_state* st = nullptr;
   lvf_batch *tc = nullptr, *tf = nullptr, *po = nullptr, *imu = nullptr, *prior = nullptr;
   int n_kf = 0, n_lm = 0, d = 0, dp = 0, ldE = 0, dpad = 0, nb = 0;
+  // layout of the factorised matrix S (see "elimination order" below): [sparse (v,ba,bg) blocks | dense (v,ba,bg) blocks | poses | rhs row | pad]
+  int ld = 0, off = 0, off_pose = 0, ndense = 0, aug = 0;
+  lvf::SpLevels sp_levels{};
+  std::vector<int> sp_tiles, sp_shmem;          // per level: workgroups per node, dynamic LDS bytes
+  std::vector<int32_t> plan_key;                // (n_kf, IMU index pairs) the current plan was built for
+  lvf::DevBuf<lvf::SpNode> sp_nodes;
+  lvf::DevBuf<int> sp_rows, perm, iperm;
+  lvf::DevBuf<double> sp_W, sp_L;
+  std::vector<int> perm_h;
   lvf::DevBuf<double> B, gc, C, gr, E, Cd, S, dxc, dxl, scal;
   lvf::DevBuf<double> poses2, vel2, ba2, bg2, invd2;   // candidate state x + dx
   lvf::DevBuf<uint8_t> pose_const;
@@ -477,14 +493,15 @@ __global__ __launch_bounds__(kT) void k_cost_sq(int n, const double* __restrict_
 __device__ __forceinline__ double clamp_diag(double v) { return fmin(fmax(v, 1e-6), 1e32); }
 
 // One launch prepares the damped system of a step:
-//   blocks [0, nS_blocks)      : S (lower) = B (lower) + Dc on the diagonal; augmented row d = -gc ; padding rows = identity
+//   blocks [0, nS_blocks)      : S (lower, in ELIMINATION order: S row I holds unknown iperm[I]) = B (lower, natural order) + Dc on
+//                                the diagonal; augmented row (iperm = -2) = -gc ; padding rows (iperm = -1) = identity
 //   blocks [nS_blocks, ...)    : Cd = C + clamp(C)/radius ; E[l][dp] = gr[l] (the extra column that makes the SYRK also
 //                                produce E^T Cd^-1 g_rho)
 //   block 0 / thread 0         : resets the per-step scalars (candidate cost, model change, norms) and the Cholesky fail flag
-__global__ __launch_bounds__(kT) void k_prepare(int d, int dpad, const double* __restrict__ B, const double* __restrict__ gc, double inv_radius,
-                                                double* __restrict__ S, unsigned nS_blocks, int n_lm, int dp, int ldE, const double* __restrict__ C,
-                                                const double* __restrict__ gr, double* __restrict__ Cd, double* __restrict__ E,
-                                                double* __restrict__ scal) {
+__global__ __launch_bounds__(kT) void k_prepare(int ld, int dpad, const int* __restrict__ iperm, const double* __restrict__ B, const double* __restrict__ gc,
+                                                double inv_radius, double* __restrict__ S, unsigned nS_blocks, int n_lm, int dp, int ldE,
+                                                const double* __restrict__ C, const double* __restrict__ gr, double* __restrict__ Cd,
+                                                double* __restrict__ E, double* __restrict__ scal) {
   if (blockIdx.x == 0 && scal) {
     for (int k = SC_COST_NEW + threadIdx.x; k < SC_N; k += kT) scal[k] = 0.0;
     if (threadIdx.x == 0) *reinterpret_cast<int*>(scal + SC_FAIL) = 0;
@@ -498,14 +515,18 @@ __global__ __launch_bounds__(kT) void k_prepare(int d, int dpad, const double* _
     return;
   }
   const size_t e = (size_t)blockIdx.x * kT + threadIdx.x;
-  if (e >= (size_t)dpad * dpad) return;
-  const int i = (int)(e / dpad), j = (int)(e % dpad);
+  if (e >= (size_t)ld * ld) return;
+  const int I = (int)(e / ld), J = (int)(e % ld);
+  const int oi = iperm[I], oj = iperm[J];
   double v = 0.0;
-  if (i < d && j < d) {
-    if (j <= i) { v = B[e]; if (i == j) v += clamp_diag(v) * inv_radius; }
-  } else if (i == d) {
-    v = (j < d) ? -gc[j] : (j == d ? 1e300 : 0.0);   // huge corner keeps the augmented matrix positive definite
-  } else if (i > d && i == j) {
+  if (oi >= 0) {
+    if (oj >= 0 && J <= I) {
+      v = B[(size_t)max(oi, oj) * dpad + min(oi, oj)];
+      if (I == J) v += clamp_diag(v) * inv_radius;
+    }
+  } else if (oi == -2) {
+    v = (oj >= 0) ? -gc[oj] : (J == I ? 1e300 : 0.0);   // huge corner keeps the augmented matrix positive definite
+  } else if (I == J) {
     v = 1.0;
   }
   S[e] = v;
@@ -790,16 +811,104 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
     for (int rg = 0; rg < 4; ++rg) out[(size_t)(lk + 4 * rg) * ld + 16 * ct + lc] -= acc[ct][rg];
 }
 
-// back substitution x = L^-T y with y = augmented row L[d][0..d); single workgroup of 256 threads.
+// ------------------------------------------------------------------------------------------------ elimination order
+// The (v, ba, bg) blocks only meet each other and the poses through ImuError factors, i.e. along the IMU chain: block k touches
+// blocks k-1, k+1 and poses k-1, k, k+1.  Factorising them FIRST, in nested-dissection order (level 0 = every other block of the
+// chain, level 1 = every other one of what is left, ...; any coupling graph works, the levels are greedy independent sets with
+// fill-in tracked on the host), costs 9 sequential pivots per LEVEL instead of 9 per block, and leaves only the pose corner
+// (6 n_kf) for the dense blocked factorisation: at 50 keyframes 6 x 9 + 300 sequential pivots instead of 750.
+// k_sp_eliminate, one launch per level, `tiles` workgroups per block b with neighbour rows N (|N| = m):
+//   L_bb = chol(S_bb) (wave 0, lane = row, pivots broadcast by v_readlane);  W = S_Nb L_bb^-T (thread per row);
+//   S_NN -= W W^T (pairs split over the tiles; atomics, because blocks of one level share neighbours).
+// W and L_bb go to side buffers (the eliminated columns of S are never read again), so the tiles of a block never race.
+__global__ __launch_bounds__(256) void k_sp_eliminate(const SpNode* __restrict__ nodes, int first, int tiles, const int* __restrict__ rows,
+                                                      double* __restrict__ S, int ld, double* __restrict__ W, double* __restrict__ Lout,
+                                                      int* __restrict__ fail) {
+  extern __shared__ double sp_sm[];        // Ws[m][9] | L[81] | linv[9] | rws[m] (int)
+  const int ni = first + blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
+  const SpNode nd = nodes[ni];
+  const int m = nd.m, col = nd.col;
+  double* Ws = sp_sm;
+  double* L = sp_sm + 9 * m;
+  double* linv = L + 81;
+  int* rws = reinterpret_cast<int*>(linv + 9);
+  if (tid < 64) {
+    const int lane = tid;
+    double a[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) a[c] = (lane < 9 && c <= lane) ? S[(size_t)(col + lane) * ld + col + c] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const double djj = lane_bcast(a[j], j);
+      bad |= !(djj > 0.0);
+      const double inv_l = rsqrt(fmax(djj, 1e-300));
+      a[j] = (lane == j) ? djj * inv_l : a[j] * inv_l;
+      if (lane == j) linv[j] = inv_l;
+#pragma unroll
+      for (int t = j + 1; t < 9; ++t) a[t] -= a[j] * lane_bcast(a[j], t);   // A_rt -= L_rj L_tj (meaningful for t <= r)
+    }
+    if (lane < 9) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) L[lane * 9 + c] = (c <= lane) ? a[c] : 0.0;
+    }
+    if (bad && lane == 0) atomicExch(fail, 100000 + nd.id);
+  }
+  for (int r = tid; r < m; r += 256) rws[r] = rows[nd.row_off + r];
+  __syncthreads();
+  for (int r = tid; r < m; r += 256) {
+    const double* src = S + (size_t)rws[r] * ld + col;
+    double w[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      double v = src[c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) v -= w[k] * L[c * 9 + k];
+      w[c] = v * linv[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Ws[r * 9 + c] = w[c];
+    if (tile == 0) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) W[(size_t)(nd.row_off + r) * 9 + c] = w[c];
+    }
+  }
+  if (tile == 0 && tid < 81) Lout[(size_t)ni * 81 + tid] = L[tid];
+  __syncthreads();
+  const int P = m * (m + 1) / 2;
+  for (int p = tile * 256 + tid; p < P; p += tiles * 256) {
+    int r = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= p) ++r;
+    while (r * (r + 1) / 2 > p) --r;
+    const int c2 = p - r * (r + 1) / 2;
+    const double* wr = Ws + r * 9;
+    const double* wc = Ws + c2 * 9;
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) v += wr[c] * wc[c];
+    if (v != 0.0) atomicAdd(&S[(size_t)rws[r] * ld + rws[c2]], -v);
+  }
+}
+
+struct SpBack {                    // what the back substitution needs of the plan
+  SpLevels lv;
+  const SpNode* nodes; const int* rows; const double* W; const double* L; const int* perm;
+  int off, aug, d_total;
+};
+
+// back substitution x = L^-T y with y = augmented row L[d][0..d); single workgroup of 256 threads.  S points at the DENSE
+// corner (row/column `off` of the full matrix), d = its unknowns.
 // Per block (bottom-up): (a) 4-way split gather  y_c -= sum_{r > block} L[r][c] x_r  (rows r are contiguous over c:
 // coalesced, 8 loads in flight), (b) one wave solves the 64x64 transposed triangle with the block's COLUMNS in registers.
-__global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ S, int ld, int d, double* __restrict__ xout) {
-  extern __shared__ double sm[];          // x[nblk*64] | part[4][64]
+// Then the sparse levels in reverse: x_b = L_bb^-T (y_b - W_b^T x_N), one wave per eliminated block; the solution leaves in the
+// natural unknown order through `perm`.
+__global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ S, int ld, int d, double* __restrict__ xout, SpBack sp) {
+  extern __shared__ double sm[];          // xs[off] | x[nblk*64] | part[4][64]      (sm[R] = x of S row R)
   const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
   const int nblk = (d + kNB - 1) / kNB, n = nblk * kNB;
-  double* x = sm;
-  double* partial = sm + n;
-  for (int i = tid; i < n; i += 256) x[i] = 0.0;
+  double* x = sm + sp.off;
+  double* partial = x + n;
+  for (int i = tid; i < sp.off + n; i += 256) sm[i] = 0.0;
   __syncthreads();
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int r0 = kb * kNB;
@@ -834,7 +943,40 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
     }
     __syncthreads();
   }
-  for (int i = tid; i < d; i += 256) xout[i] = x[i];
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int lv = sp.lv.n - 1; lv >= 0; --lv) {
+    for (int k = wave; k < sp.lv.count[lv]; k += 4) {
+      const int ni = sp.lv.first[lv] + k;
+      const SpNode nd = sp.nodes[ni];
+      double acc[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+      for (int r = lane; r < nd.m; r += 64) {
+        const int R = sp.rows[nd.row_off + r];
+        const double xr = (R == sp.aug) ? -1.0 : sm[R];          // the rhs row carries y_b itself
+        const double* w = sp.W + (size_t)(nd.row_off + r) * 9;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[q] -= w[q] * xr;
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc[q] = wave_sum(acc[q]);
+      if (lane == 0) {
+        const double* L = sp.L + (size_t)ni * 81;
+        double xb[9];
+#pragma unroll
+        for (int q = 8; q >= 0; --q) {
+          double v = acc[q];
+#pragma unroll
+          for (int t = q + 1; t < 9; ++t) v -= L[t * 9 + q] * xb[t];
+          xb[q] = v / L[q * 9 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) sm[nd.col + q] = xb[q];
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < sp.d_total; i += 256) xout[i] = sm[sp.perm[i]];
 }
 
 // ------------------------------------------------------------------------------------------------ step pieces
@@ -983,27 +1125,43 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
   return LVF_OK;
 }
 
+// S (elimination order) = B + D - E^T Cd^-1 E, rhs row = -(gc - E^T Cd^-1 g_rho)
+static int enqueue_reduced_system(lvf_problem* p, double inv_r, double* scal) {
+  hipStream_t q = p->ctx->stream;
+  const size_t nS = (size_t)p->ld * p->ld;
+  const unsigned nSb = (unsigned)((nS + kT - 1) / kT);
+  hipLaunchKernelGGL(k_prepare, dim3(nSb + (p->n_lm ? grid(p->n_lm) : 0)), dim3(kT), 0, q, p->ld, p->dpad, p->iperm.p, p->B.p, p->gc.p, inv_r, p->S.p, nSb,
+                     p->n_lm, p->dp, p->ldE, p->C.p, p->gr.p, p->Cd.p, p->E.p, scal);
+  if (p->n_lm) {
+    // the Schur complement only touches the pose corner (local rhs row = dp)
+    LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->dp, p->ld, p->S.p + (size_t)p->off_pose * (p->ld + 1)));
+  }
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+
 // builds the damped reduced system, factors it and leaves dx in dxc/dxl, the candidate state in *2 buffers and the
 // scalars (model change, norms, candidate cost) in scal
 static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_flag_dev) {
   hipStream_t q = p->ctx->stream;
   const double inv_r = 1.0 / radius;
-  const size_t nS = (size_t)p->dpad * p->dpad;
-  const unsigned nSb = (unsigned)((nS + kT - 1) / kT);
-  hipLaunchKernelGGL(k_prepare, dim3(nSb + (p->n_lm ? grid(p->n_lm) : 0)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, inv_r, p->S.p, nSb, p->n_lm,
-                     p->dp, p->ldE, p->C.p, p->gr.p, p->Cd.p, p->E.p, p->scal.p);
-  if (p->n_lm) {
-    LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->d, p->dpad, p->S.p));
-  }
+  LVF_TRY(enqueue_reduced_system(p, inv_r, p->scal.p));
+  for (int lv = 0; lv < p->sp_levels.n; ++lv)
+    hipLaunchKernelGGL(k_sp_eliminate, dim3(p->sp_levels.count[lv] * p->sp_tiles[lv]), dim3(256), p->sp_shmem[lv], q, p->sp_nodes.p, p->sp_levels.first[lv],
+                       p->sp_tiles[lv], p->sp_rows.p, p->S.p, p->ld, p->sp_W.p, p->sp_L.p, fail_flag_dev);
+  double* Sd = p->S.p + (size_t)p->off * (p->ld + 1);       // dense corner
   for (int kb = 0; kb < p->nb; ++kb) {
     const int below = p->nb - kb - 1;
-    hipLaunchKernelGGL(k_chol_factor_panel, dim3(1 + below), dim3(256), 0, q, p->S.p, p->dpad, kb, fail_flag_dev);
+    hipLaunchKernelGGL(k_chol_factor_panel, dim3(1 + below), dim3(256), 0, q, Sd, p->ld, kb, fail_flag_dev);
     if (below > 0) {
-      hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, q, p->S.p, p->dpad, kb);
+      hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, q, Sd, p->ld, kb);
     }
   }
-  const size_t sh = ((size_t)((p->d + 63) / 64) * 64 + 4 * kNB) * sizeof(double);
-  hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(256), sh, q, p->S.p, p->dpad, p->d, p->dxc.p);
+  SpBack sb;
+  sb.lv = p->sp_levels; sb.nodes = p->sp_nodes.p; sb.rows = p->sp_rows.p; sb.W = p->sp_W.p; sb.L = p->sp_L.p; sb.perm = p->perm.p;
+  sb.off = p->off; sb.aug = p->aug; sb.d_total = p->d;
+  const size_t sh = ((size_t)p->off + (size_t)((p->ndense + 63) / 64) * 64 + 4 * kNB) * sizeof(double);
+  hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(256), sh, q, Sd, p->ld, p->ndense, p->dxc.p, sb);
   // model / norms / candidate state
   const StateP s = state_ptrs(p->st);
   if (p->n_lm)
@@ -1065,6 +1223,115 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
   return LVF_OK;
 }
 
+// Elimination plan (host, <= a few hundred nodes): which (v, ba, bg) blocks are factorised sparsely, in which level, with which
+// neighbour rows; the S row of every unknown.  Rebuilt only when (n_kf, IMU index pairs) change.  LVF_SPARSE_VB=0 keeps every
+// block in the dense corner (the round-1 layout, poses last) for A/B measurements.
+static int build_elimination_plan(lvf_problem* p) {
+  const int n = p->n_kf;
+  std::vector<int32_t> key;
+  key.push_back(n);
+  const lvf_batch* imu = p->imu;
+  const bool have_idx = imu && imu->n > 0 && (int)imu->host_kf1.size() == imu->n && (int)imu->host_kf2.size() == imu->n;
+  if (imu && imu->n > 0) {
+    key.push_back(have_idx ? 1 : 0);
+    if (have_idx) { key.insert(key.end(), imu->host_kf1.begin(), imu->host_kf1.end()); key.insert(key.end(), imu->host_kf2.begin(), imu->host_kf2.end()); }
+  }
+  if (key == p->plan_key && p->ld > 0) return LVF_OK;
+  static const bool sparse_on = [] { const char* e = std::getenv("LVF_SPARSE_VB"); return !(e && e[0] == '0'); }();
+  std::vector<std::vector<char>> va(n, std::vector<char>(n, 0)), pa(n, std::vector<char>(n, 0));
+  bool sparse = sparse_on && (!imu || imu->n == 0 || have_idx);
+  if (have_idx)
+    for (int f = 0; f < imu->n; ++f) {
+      const int i = imu->host_kf1[f], j = imu->host_kf2[f];
+      if (i < 0 || j < 0 || i >= n || j >= n || i == j) continue;
+      va[i][j] = va[j][i] = 1;
+      pa[i][i] = pa[i][j] = pa[j][i] = pa[j][j] = 1;
+    }
+  struct NodeInfo { int kf; std::vector<int> vb, pose; };
+  std::vector<NodeInfo> nodes;
+  std::vector<char> alive(n, 1);
+  SpLevels lv{};
+  while (sparse && lv.n < kSpMaxLevels) {
+    std::vector<char> blocked(n, 0);
+    std::vector<int> chosen;
+    for (int k = 0; k < n; ++k) {
+      if (!alive[k] || blocked[k]) continue;
+      int m = 1;
+      for (int u = 0; u < n; ++u) m += 9 * (va[k][u] && alive[u]) + 6 * pa[k][u];
+      if (m > kSpMaxRows) continue;
+      chosen.push_back(k);
+      for (int u = 0; u < n; ++u) if (va[k][u]) blocked[u] = 1;
+    }
+    if (chosen.empty()) break;
+    lv.first[lv.n] = (int)nodes.size(); lv.count[lv.n] = (int)chosen.size(); ++lv.n;
+    for (int b : chosen) {
+      NodeInfo ni; ni.kf = b;
+      for (int u = 0; u < n; ++u) { if (va[b][u] && alive[u]) ni.vb.push_back(u); if (pa[b][u]) ni.pose.push_back(u); }
+      nodes.push_back(std::move(ni));
+    }
+    for (size_t ci = 0; ci < chosen.size(); ++ci) {   // fill-in among the neighbours of an eliminated block
+      const int b = chosen[ci];
+      const NodeInfo& ni = nodes[lv.first[lv.n - 1] + (int)ci];
+      for (int u : ni.vb) {
+        for (int w : ni.vb) if (w != u) va[u][w] = 1;
+        for (int k : ni.pose) pa[u][k] = 1;
+        va[u][b] = 0;
+      }
+      alive[b] = 0;
+    }
+  }
+  // S rows
+  const int ns = (int)nodes.size();
+  std::vector<int> vbcol(n, -1);
+  for (int s_ = 0; s_ < ns; ++s_) vbcol[nodes[s_].kf] = 9 * s_;
+  p->off = (9 * ns + 1) & ~1;
+  int ndv = 0;
+  for (int k = 0; k < n; ++k) if (alive[k]) vbcol[k] = p->off + 9 * ndv++;
+  p->off_pose = p->off + 9 * ndv;
+  p->ndense = 9 * ndv + p->dp;
+  p->aug = p->off + p->ndense;
+  p->nb = (p->ndense + 1 + 63) / 64;
+  p->ld = p->off + 64 * p->nb;
+  p->perm_h.assign(p->d, 0);
+  std::vector<int> iperm(p->ld, -1);
+  for (int i = 0; i < p->dp; ++i) p->perm_h[i] = p->off_pose + i;
+  for (int k = 0; k < n; ++k) for (int c = 0; c < 9; ++c) p->perm_h[p->dp + 9 * k + c] = vbcol[k] + c;
+  for (int i = 0; i < p->d; ++i) iperm[p->perm_h[i]] = i;
+  iperm[p->aug] = -2;
+  // device tables
+  std::vector<SpNode> dn(ns);
+  std::vector<int> rows;
+  p->sp_tiles.assign(lv.n, 1); p->sp_shmem.assign(lv.n, 0);
+  for (int l = 0; l < lv.n; ++l) {
+    int mmax = 0;
+    for (int s_ = lv.first[l]; s_ < lv.first[l] + lv.count[l]; ++s_) {
+      const NodeInfo& ni = nodes[s_];
+      dn[s_].col = 9 * s_; dn[s_].row_off = (int)rows.size(); dn[s_].id = ni.kf;
+      std::vector<int> r;
+      for (int u : ni.vb) for (int c = 0; c < 9; ++c) r.push_back(vbcol[u] + c);
+      for (int k : ni.pose) for (int c = 0; c < 6; ++c) r.push_back(p->off_pose + 6 * k + c);
+      r.push_back(p->aug);
+      std::sort(r.begin(), r.end());
+      dn[s_].m = (int)r.size();
+      mmax = std::max(mmax, dn[s_].m);
+      rows.insert(rows.end(), r.begin(), r.end());
+    }
+    const int P = mmax * (mmax + 1) / 2;
+    p->sp_tiles[l] = std::max(1, std::min(32, (P + 2047) / 2048));
+    p->sp_shmem[l] = (9 * mmax + 81 + 9) * 8 + 4 * mmax + 16;
+  }
+  p->sp_levels = lv;
+  hipStream_t q = p->ctx->stream;
+  LVF_TRY(p->perm.assign(p->perm_h.data(), p->perm_h.size(), q)); LVF_TRY(p->iperm.assign(iperm.data(), iperm.size(), q));
+  if (ns) {
+    LVF_TRY(p->sp_nodes.assign(dn.data(), dn.size(), q)); LVF_TRY(p->sp_rows.assign(rows.data(), rows.size(), q));
+    LVF_TRY(p->sp_W.ensure(rows.size() * 9)); LVF_TRY(p->sp_L.ensure((size_t)ns * 81));
+  }
+  LVF_HIP(hipStreamSynchronize(q));      // the host vectors above go out of scope
+  p->plan_key = std::move(key);
+  return LVF_OK;
+}
+
 int problem_configure(lvf_problem* p) {
   lvf_state* st = p->st;
   lvf_ctx* ctx = p->ctx;
@@ -1072,9 +1339,9 @@ int problem_configure(lvf_problem* p) {
   p->d = 15 * p->n_kf; p->dp = 6 * p->n_kf;
   p->ldE = ((p->dp + 1 + 15) / 16) * 16;
   p->dpad = ((p->d + 1 + 63) / 64) * 64;
-  p->nb = p->dpad / 64;
+  LVF_TRY(build_elimination_plan(p));                 // sets ld, off, off_pose, ndense, aug, nb and the sparse levels
   const size_t nS = (size_t)p->dpad * p->dpad;
-  LVF_TRY(p->B.ensure(nS)); LVF_TRY(p->S.ensure(nS)); LVF_TRY(p->gc.ensure(p->dpad)); LVF_TRY(p->dxc.ensure(p->dpad));
+  LVF_TRY(p->B.ensure(nS)); LVF_TRY(p->S.ensure((size_t)p->ld * p->ld)); LVF_TRY(p->gc.ensure(p->dpad)); LVF_TRY(p->dxc.ensure(p->dpad));
   LVF_TRY(p->C.ensure(p->n_lm)); LVF_TRY(p->gr.ensure(p->n_lm)); LVF_TRY(p->Cd.ensure(p->n_lm)); LVF_TRY(p->dxl.ensure(p->n_lm));
   LVF_TRY(p->E.ensure((size_t)p->n_lm * p->ldE)); LVF_TRY(p->scal.ensure(SC_ALLOC));
   // the candidate buffers are swapped with the state's on an accepted step: they must match the state's CAPACITY
@@ -1247,21 +1514,19 @@ int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs) {
   LVF_TRY(lvf::enter(p->ctx));
   hipStream_t q = p->ctx->stream;
   const double inv_r = 1.0 / p->last_radius;
-  const size_t nS = (size_t)p->dpad * p->dpad;
-  const unsigned nSb = (unsigned)((nS + kT - 1) / kT);
-  hipLaunchKernelGGL(k_prepare, dim3(nSb + (p->n_lm ? grid(p->n_lm) : 0)), dim3(kT), 0, q, p->d, p->dpad, p->B.p, p->gc.p, inv_r, p->S.p, nSb, p->n_lm,
-                     p->dp, p->ldE, p->C.p, p->gr.p, p->Cd.p, p->E.p, (double*)nullptr);
-  if (p->n_lm) {
-    LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->d, p->dpad, p->S.p));
-  }
-  LVF_HIP(hipGetLastError());
+  const size_t nS = (size_t)p->ld * p->ld;
+  LVF_TRY(enqueue_reduced_system(p, inv_r, nullptr));
   std::vector<double> h(nS);
   LVF_HIP(hipMemcpyAsync(h.data(), p->S.p, nS * 8, hipMemcpyDeviceToHost, q));
   LVF_HIP(hipStreamSynchronize(q));
-  const int d = p->d, ld = p->dpad;
+  const int d = p->d, ld = p->ld;
+  const std::vector<int>& pm = p->perm_h;          // natural unknown -> S row
   for (int i = 0; i < d; ++i)
-    for (int j = 0; j <= i; ++j) { S[(size_t)i * d + j] = h[(size_t)i * ld + j]; S[(size_t)j * d + i] = h[(size_t)i * ld + j]; }
-  for (int j = 0; j < d; ++j) rhs[j] = h[(size_t)d * ld + j];
+    for (int j = 0; j <= i; ++j) {
+      const double v = h[(size_t)std::max(pm[i], pm[j]) * ld + std::min(pm[i], pm[j])];
+      S[(size_t)i * d + j] = v; S[(size_t)j * d + i] = v;
+    }
+  for (int j = 0; j < d; ++j) rhs[j] = h[(size_t)p->aug * ld + pm[j]];
   return LVF_OK;
 }
 

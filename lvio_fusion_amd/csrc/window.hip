@@ -382,6 +382,7 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
     lvf_batch* b = w->imu;
     LVF_TRY(b->pre.assign(reinterpret_cast<const double*>(imu_pre.data()), (size_t)467 * w->n_imu, s));
     LVF_TRY(put(b->idx_a, imu_i, s)); LVF_TRY(put(b->idx_b, imu_j, s));
+    b->host_kf1 = imu_i; b->host_kf2 = imu_j;
     LVF_TRY(b->sqrt_info.ensure((size_t)225 * w->n_imu)); LVF_TRY(b->res.ensure((size_t)15 * w->n_imu));
     for (int q = 0; q < 8; ++q) LVF_TRY(b->jac[q].ensure((size_t)15 * b->block_size[q] * w->n_imu));
     idx_ok(b, w->n_imu, n_kf, 0);
