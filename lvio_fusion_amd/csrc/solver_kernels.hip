@@ -36,7 +36,7 @@ struct lvf_problem {
   std::vector<int> sp_tiles, sp_shmem;          // per level: workgroups per node, dynamic LDS bytes
   std::vector<int32_t> plan_key;                // (n_kf, IMU index pairs) the current plan was built for
   lvf::DevBuf<lvf::SpNode> sp_nodes;
-  lvf::DevBuf<int> sp_rows, perm, iperm;
+  lvf::DevBuf<int> sp_rows, sp_owner, perm, iperm;
   lvf::DevBuf<double> sp_W, sp_L;
   std::vector<int> perm_h;
   lvf::DevBuf<double> B, gc, C, gr, E, Cd, S, dxc, dxl, scal;
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void k_sp_eliminate(const SpNode* __restrict__
 
 struct SpBack {                    // what the back substitution needs of the plan
   SpLevels lv;
-  const SpNode* nodes; const int* rows; const double* W; const double* L; const int* perm;
+  const SpNode* nodes; const int* rows; const int* owner; const double* W; const double* L; const int* perm;
   int off, aug, d_total;
 };
 
@@ -932,10 +932,12 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
       double a[kNB];                      // a[j] = L[r0 + j][r0 + lane]  (column `lane` of the block), j >= lane
 #pragma unroll
       for (int j = 0; j < kNB; ++j) a[j] = (j >= lane && r0 + j < d) ? S[(size_t)(r0 + j) * ld + r0 + lane] : ((j == lane) ? 1.0 : 0.0);
+      // 1 / L_jj of this lane's own column, off the 64-step chain
+      const double inv_diag = (r0 + lane < d) ? 1.0 / S[(size_t)(r0 + lane) * ld + r0 + lane] : 1.0;
 #pragma unroll
       for (int j = kNB - 1; j >= 0; --j) {
         // x_j = y_j / L_jj on lane j, broadcast, then y_t -= L[j][t] x_j on lanes t < j
-        const double xj = lane_bcast(y / a[j], j);
+        const double xj = lane_bcast(y * inv_diag, j);
         if (lane == j) y = xj;
         else if (lane < j) y -= a[j] * xj;
       }
@@ -943,36 +945,41 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
     }
     __syncthreads();
   }
-  const int wave = tid >> 6, lane = tid & 63;
+  // sparse levels, last eliminated first.  All (block, neighbour row) products of a level are spread over the 256 threads
+  // (independent loads, one global round trip per level) and summed per block with LDS atomics; then one thread per block
+  // runs the 9x9 transposed solve.
+  double* accs = partial;                 // [kSpBackNodes][9] (reuses the gather scratch when it fits, see host-side sizing)
   for (int lv = sp.lv.n - 1; lv >= 0; --lv) {
-    for (int k = wave; k < sp.lv.count[lv]; k += 4) {
-      const int ni = sp.lv.first[lv] + k;
-      const SpNode nd = sp.nodes[ni];
-      double acc[9];
+    const int first = sp.lv.first[lv], count = sp.lv.count[lv];
+    const SpNode n0 = sp.nodes[first];
+    const SpNode n1 = sp.nodes[first + count - 1];
+    const int item0 = n0.row_off, items = n1.row_off + n1.m - n0.row_off;     // the level's rows are contiguous in `rows`
+    for (int i = tid; i < 9 * count; i += 256) accs[i] = 0.0;
+    __syncthreads();
+    for (int it = tid; it < items; it += 256) {
+      const int g = item0 + it;
+      const int k = sp.owner[g] - first;   // owning block
+      const int R = sp.rows[g];
+      const double xr = (R == sp.aug) ? -1.0 : sm[R];            // the rhs row carries y_b itself
+      const double* w = sp.W + (size_t)g * 9;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) acc[q] = 0.0;
-      for (int r = lane; r < nd.m; r += 64) {
-        const int R = sp.rows[nd.row_off + r];
-        const double xr = (R == sp.aug) ? -1.0 : sm[R];          // the rhs row carries y_b itself
-        const double* w = sp.W + (size_t)(nd.row_off + r) * 9;
+      for (int q = 0; q < 9; ++q) atomicAdd(&accs[9 * k + q], -w[q] * xr);
+    }
+    __syncthreads();
+    for (int k = tid; k < count; k += 256) {
+      const int ni = first + k;
+      const double* L = sp.L + (size_t)ni * 81;
+      double xb[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) acc[q] -= w[q] * xr;
+      for (int q = 8; q >= 0; --q) {
+        double v = accs[9 * k + q];
+#pragma unroll
+        for (int t = q + 1; t < 9; ++t) v -= L[t * 9 + q] * xb[t];
+        xb[q] = v / L[q * 9 + q];
       }
+      const int col = sp.nodes[ni].col;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) acc[q] = wave_sum(acc[q]);
-      if (lane == 0) {
-        const double* L = sp.L + (size_t)ni * 81;
-        double xb[9];
-#pragma unroll
-        for (int q = 8; q >= 0; --q) {
-          double v = acc[q];
-#pragma unroll
-          for (int t = q + 1; t < 9; ++t) v -= L[t * 9 + q] * xb[t];
-          xb[q] = v / L[q * 9 + q];
-        }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) sm[nd.col + q] = xb[q];
-      }
+      for (int q = 0; q < 9; ++q) sm[col + q] = xb[q];
     }
     __syncthreads();
   }
@@ -1158,9 +1165,11 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
     }
   }
   SpBack sb;
-  sb.lv = p->sp_levels; sb.nodes = p->sp_nodes.p; sb.rows = p->sp_rows.p; sb.W = p->sp_W.p; sb.L = p->sp_L.p; sb.perm = p->perm.p;
+  sb.lv = p->sp_levels; sb.nodes = p->sp_nodes.p; sb.rows = p->sp_rows.p; sb.owner = p->sp_owner.p; sb.W = p->sp_W.p; sb.L = p->sp_L.p; sb.perm = p->perm.p;
   sb.off = p->off; sb.aug = p->aug; sb.d_total = p->d;
-  const size_t sh = ((size_t)p->off + (size_t)((p->ndense + 63) / 64) * 64 + 4 * kNB) * sizeof(double);
+  int max_count = 0;
+  for (int lv = 0; lv < p->sp_levels.n; ++lv) max_count = std::max(max_count, p->sp_levels.count[lv]);
+  const size_t sh = ((size_t)p->off + (size_t)((p->ndense + 63) / 64) * 64 + std::max(4 * kNB, 9 * max_count)) * sizeof(double);
   hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(256), sh, q, Sd, p->ld, p->ndense, p->dxc.p, sb);
   // model / norms / candidate state
   const StateP s = state_ptrs(p->st);
@@ -1300,7 +1309,7 @@ static int build_elimination_plan(lvf_problem* p) {
   iperm[p->aug] = -2;
   // device tables
   std::vector<SpNode> dn(ns);
-  std::vector<int> rows;
+  std::vector<int> rows, owner;
   p->sp_tiles.assign(lv.n, 1); p->sp_shmem.assign(lv.n, 0);
   for (int l = 0; l < lv.n; ++l) {
     int mmax = 0;
@@ -1315,6 +1324,7 @@ static int build_elimination_plan(lvf_problem* p) {
       dn[s_].m = (int)r.size();
       mmax = std::max(mmax, dn[s_].m);
       rows.insert(rows.end(), r.begin(), r.end());
+      owner.insert(owner.end(), r.size(), s_);
     }
     const int P = mmax * (mmax + 1) / 2;
     p->sp_tiles[l] = std::max(1, std::min(32, (P + 2047) / 2048));
@@ -1324,7 +1334,7 @@ static int build_elimination_plan(lvf_problem* p) {
   hipStream_t q = p->ctx->stream;
   LVF_TRY(p->perm.assign(p->perm_h.data(), p->perm_h.size(), q)); LVF_TRY(p->iperm.assign(iperm.data(), iperm.size(), q));
   if (ns) {
-    LVF_TRY(p->sp_nodes.assign(dn.data(), dn.size(), q)); LVF_TRY(p->sp_rows.assign(rows.data(), rows.size(), q));
+    LVF_TRY(p->sp_nodes.assign(dn.data(), dn.size(), q)); LVF_TRY(p->sp_rows.assign(rows.data(), rows.size(), q)); LVF_TRY(p->sp_owner.assign(owner.data(), owner.size(), q));
     LVF_TRY(p->sp_W.ensure(rows.size() * 9)); LVF_TRY(p->sp_L.ensure((size_t)ns * 81));
   }
   LVF_HIP(hipStreamSynchronize(q));      // the host vectors above go out of scope
