@@ -37,6 +37,8 @@ struct lvf_problem {
   std::vector<int32_t> plan_key;                // (n_kf, IMU index pairs) the current plan was built for
   lvf::DevBuf<lvf::SpNode> sp_nodes;
   lvf::DevBuf<int> sp_rows, sp_owner, perm, iperm;
+  lvf::DevBuf<int> lm_kmin, lm_kmax, lm_order, lm_nactive;   // per-landmark keyframe track [kmin, kmax]; Schur row order; #rows with pose blocks
+  bool band_ready = false;
   lvf::DevBuf<double> sp_W, sp_L;
   std::vector<int> perm_h;
   lvf::DevBuf<double> B, gc, C, gr, E, Cd, S, dxc, dxl, scal;
@@ -647,8 +649,158 @@ __global__ __launch_bounds__(256) void k_schur_lds(int n_lm, int dp, int ldE, in
     }
   }
 }
-static int launch_schur(hipStream_t q, int n_lm, int dp, int ldE, const double* E, const double* Cd, int d, int ldS, double* S) {
+// ---- band-limited variant.  A landmark's row of E is non-zero only at the keyframes that observe it, a contiguous track
+// [kmin_l, kmax_l] of the window.  Landmarks are ordered by (track-length class, kmin) once per problem (k_lm_range + k_lm_sort),
+// so a slice of kBandRows consecutive landmarks touches a narrow BAND of 16-column tiles [t0, t1]: the workgroup stages only
+// those columns (plus the tile holding the g_rho column) and only forms the band's lower-triangular tiles.  At configs[3]
+// that is ~1/5 of the MFMAs and ~1/30 of the E bytes of the dense SYRK.  Correctness never depends on the ordering: the
+// band of each slice is computed from the actual kmin/kmax of its rows.
+constexpr int kBandRows = 64, kBandTilesPerGroup = 32;
+__global__ __launch_bounds__(kT) void k_lm_range(int n, const int* __restrict__ lm, const int* __restrict__ k1, const int* __restrict__ k2,
+                                                 int* __restrict__ kmin, int* __restrict__ kmax) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const int l = lm[i], a = min(k1[i], k2[i]), b = max(k1[i], k2[i]);
+  atomicMin(&kmin[l], a); atomicMax(&kmax[l], b);
+}
+__global__ __launch_bounds__(kT) void k_lm_range_init(int n_lm, int* __restrict__ kmin, int* __restrict__ kmax) {
+  const int l = blockIdx.x * kT + threadIdx.x;
+  if (l < n_lm) { kmin[l] = 0x7fffffff; kmax[l] = -1; }
+}
+__device__ __forceinline__ int lm_sort_key(int kmin, int kmax, int n_kf) {
+  if (kmax < 0) return 4 * n_kf;                       // no pose-dependent block: nothing to eliminate, ordered last
+  const int len = kmax - kmin + 1;
+  const int cls = len <= 8 ? 0 : (len <= 16 ? 1 : (len <= 32 ? 2 : 3));
+  return cls * n_kf + kmin;
+}
+// counting sort by key, one workgroup (n_lm is ~1e4; 4 n_kf + 1 buckets in LDS)
+__global__ __launch_bounds__(1024) void k_lm_sort(int n_lm, int n_kf, const int* __restrict__ kmin, const int* __restrict__ kmax,
+                                                  int* __restrict__ order, int* __restrict__ n_active) {
+  extern __shared__ int bucket[];
+  const int nb = 4 * n_kf + 1;
+  for (int b = threadIdx.x; b < nb; b += 1024) bucket[b] = 0;
+  __syncthreads();
+  for (int l = threadIdx.x; l < n_lm; l += 1024) atomicAdd(&bucket[lm_sort_key(kmin[l], kmax[l], n_kf)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 0; b < nb; ++b) { const int c = bucket[b]; bucket[b] = run; run += c; }
+    *n_active = bucket[nb - 1];
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < n_lm; l += 1024) order[atomicAdd(&bucket[lm_sort_key(kmin[l], kmax[l], n_kf)], 1)] = l;
+}
+
+__global__ __launch_bounds__(256) void k_schur_band(int dp, int ldE, const double* __restrict__ E, const double* __restrict__ Cd,
+                                                    const int* __restrict__ order, const int* __restrict__ n_active_p,
+                                                    const int* __restrict__ kmin, const int* __restrict__ kmax, int d, int ldS,
+                                                    double* __restrict__ S) {
+  extern __shared__ double sh[];          // Es[kSchurRows][ldl] | icd[kSchurRows] | rowid (int)[kBandRows]
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lk = lane >> 4, lc = lane & 15;
+  const int n_active = *n_active_p;
+  const int k_begin = blockIdx.x * kBandRows, k_end = min(n_active, k_begin + kBandRows);
+  if (k_begin >= k_end) return;
+  // the slice's band (every wave reduces it for itself: two rows per lane)
+  int lo = 0x7fffffff, hi = -1;
+  for (int r = k_begin + lane; r < k_end; r += 64) { const int l = order[r]; lo = min(lo, kmin[l]); hi = max(hi, kmax[l]); }
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+  const int t0 = (6 * lo) >> 4, t1 = (6 * hi + 5) >> 4, tl = dp >> 4;
+  const int nbt = t1 - t0 + 1, tri = nbt * (nbt + 1) / 2;
+  const bool extra = tl > t1;                                  // the g_rho column's tile lies outside the band
+  const int ntiles = tri + (extra ? nbt : 0);
+  const int tbase = blockIdx.y * kBandTilesPerGroup;
+  if (tbase >= ntiles) return;
+  const int ldl = 16 * (nbt + (extra ? 1 : 0));                // staged doubles per row
+  double* Es = sh;
+  double* icd = sh + kSchurRows * (ldE + 16);
+  int* rowid = reinterpret_cast<int*>(icd + kSchurRows);
+  for (int r = tid; r < kBandRows; r += 256) rowid[r] = (k_begin + r < k_end) ? order[k_begin + r] : -1;
+  // this wave's tiles: t = tbase + w + 4 s; local tile columns (a = row tile, b = column tile), extra row tile = index nbt
+  int ta[kSchurTilesPerWave], tb[kSchurTilesPerWave], nt = 0;
+#pragma unroll
+  for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_) {
+    const int t = tbase + w + 4 * s_;
+    ta[s_] = 0; tb[s_] = 0;
+    if (t < ntiles) {
+      if (t < tri) {
+        int a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((a + 1) * (a + 2) / 2 <= t) ++a;
+        while (a * (a + 1) / 2 > t) --a;
+        ta[s_] = a; tb[s_] = t - a * (a + 1) / 2;
+      } else { ta[s_] = nbt; tb[s_] = t - tri; }
+      nt = s_ + 1;
+    }
+  }
+  double4_t acc[kSchurTilesPerWave];
+#pragma unroll
+  for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_) acc[s_] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // staging: thread (row fr = tid >> 4, column fc = tid & 15) carries column fc of every staged 16-column tile of its row:
+  // no index arithmetic beyond one add per tile, 128-byte runs per 16 lanes
+  constexpr int kPf = 20;                  // tiles prefetched in registers (ldl <= 320); wider bands finish through fetch_tail
+  double pf[kPf];
+  double pf_cd = 1.0;
+  const int fr = tid >> 4, fc = tid & 15, nst = ldl >> 4;
+  __syncthreads();                         // rowid
+  auto fetch = [&](int k0) {
+    const int l = rowid[k0 - k_begin + fr];
+    const double* src = E + (size_t)max(l, 0) * ldE + fc;
+    if (fc == 0) pf_cd = (l >= 0) ? Cd[l] : 1.0;
+#pragma unroll
+    for (int u = 0; u < kPf; ++u) {
+      double v = 0.0;
+      if (u < nst && l >= 0) v = src[16 * (u < nbt ? t0 + u : tl)];
+      pf[u] = v;
+    }
+  };
+  auto fetch_tail = [&](int k0) {
+    const int l = rowid[k0 - k_begin + fr];
+    for (int u = kPf; u < nst; ++u) Es[fr * ldl + 16 * u + fc] = (l >= 0) ? E[(size_t)l * ldE + 16 * (u < nbt ? t0 + u : tl) + fc] : 0.0;
+  };
+  fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += kSchurRows) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPf; ++u) if (u < nst) Es[fr * ldl + 16 * u + fc] = pf[u];
+    fetch_tail(k0);
+    if (fc == 0) icd[fr] = (rowid[k0 - k_begin + fr] >= 0) ? 1.0 / pf_cd : 0.0;
+    __syncthreads();
+    if (k0 + kSchurRows < k_end) fetch(k0 + kSchurRows);
+#pragma unroll
+    for (int kk = 0; kk < kSchurRows; kk += 4) {
+      const double* row = Es + (kk + lk) * ldl;
+      const double wgt = icd[kk + lk];
+#pragma unroll
+      for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_)
+        if (s_ < nt) acc[s_] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[16 * ta[s_] + lc] * wgt, row[16 * tb[s_] + lc], acc[s_], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_) {
+    if (s_ >= nt) continue;
+    const int gti = ta[s_] < nbt ? t0 + ta[s_] : tl, gtj = t0 + tb[s_];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = gti * 16 + lk + 4 * r, gj = gtj * 16 + lc;
+      const double v = acc[s_][r];
+      if (v == 0.0) continue;
+      if (gi < dp && gj < dp) { if (gj <= gi) atomicAdd(&S[(size_t)gi * ldS + gj], -v); }
+      else if (gi == dp && gj < dp) atomicAdd(&S[(size_t)d * ldS + gj], v);
+    }
+  }
+}
+
+struct LmBand { const int* order; const int* n_active; const int* kmin; const int* kmax; };   // null order => dense SYRK
+static int launch_schur(hipStream_t q, int n_lm, int dp, int ldE, const double* E, const double* Cd, int d, int ldS, double* S, const LmBand& band) {
   const int nt = ldE / 16, ntile = nt * (nt + 1) / 2;
+  if (band.order) {
+    const size_t shb = ((size_t)kSchurRows * (ldE + 16) + kSchurRows) * sizeof(double) + kBandRows * sizeof(int);
+    if (shb <= 64 * 1024) {
+      hipLaunchKernelGGL(k_schur_band, dim3((n_lm + kBandRows - 1) / kBandRows, (ntile + kBandTilesPerGroup - 1) / kBandTilesPerGroup), dim3(256), shb, q,
+                         dp, ldE, E, Cd, band.order, band.n_active, band.kmin, band.kmax, d, ldS, S);
+      LVF_HIP(hipGetLastError());
+      return LVF_OK;
+    }
+  }
   const bool lds_path = ldE <= 320 && ntile <= kSchurGroups * 4 * kSchurTilesPerWave;
   if (lds_path) {
     const int slices = std::max(1, std::min(32, (n_lm + 4 * kSchurRows - 1) / (4 * kSchurRows)));   // 16..128 measured: 32 is the optimum at 10 k rows
@@ -988,27 +1140,44 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
 
 // ------------------------------------------------------------------------------------------------ step pieces
 // landmark back-substitution: dl = (-gr - e_l . dx_pose) / Cd ; model terms and norms
-// one thread per landmark walking its E row (a wave-per-landmark sweep with coalesced loads + shuffle reduce measured SLOWER,
-// 29.9 vs 25.6 us: 10 k independent threads hide the strided loads better than 2.5 k waves with a serial tail)
+// (on DENSE rows one thread per landmark beat a wave per landmark, 25.6 vs 29.9 us; with the row limited to the landmark's track
+// a per-thread walk diverges (41-54 us) and 16 lanes per landmark is the right shape)
 __global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE, const double* __restrict__ E, const double* __restrict__ C,
                                                       const double* __restrict__ Cd, const double* __restrict__ gr,
                                                       const double* __restrict__ dxc, const double* __restrict__ inv_depth,
-                                                      double* __restrict__ dxl, double* __restrict__ scal) {
+                                                      double* __restrict__ dxl, double* __restrict__ scal, const int* __restrict__ kmin,
+                                                      const int* __restrict__ kmax, const int* __restrict__ order) {
   extern __shared__ double sdx[];
   for (int i = threadIdx.x; i < dp; i += kT) sdx[i] = dxc[i];
   __syncthreads();
-  const int l = blockIdx.x * kT + threadIdx.x;
+  // 16 lanes per landmark: the band of a row is a few 128-byte runs, read coalesced and reduced with four shuffles; the grid is
+  // capped and strides over the landmarks so that the three scalar sums cost one atomic per WORKGROUP (thousands of per-wave
+  // atomics on the 32 striped slots were most of this kernel's time)
+  const int q = threadIdx.x & 15;
   double m = 0.0, n2 = 0.0, x2 = 0.0;
-  if (l < n_lm) {
+  for (int l = blockIdx.x * (kT / 16) + (threadIdx.x >> 4); l < n_lm; l += gridDim.x * (kT / 16)) {
     const double* e = E + (size_t)l * ldE;
     double ed = 0.0;
-    for (int i = 0; i < dp; ++i) ed += e[i] * sdx[i];
-    const double dl = (-gr[l] - ed) / Cd[l];
-    dxl[l] = dl;
-    m = -0.5 * dl * ((Cd[l] - C[l]) * dl - gr[l]);
-    n2 = dl * dl; x2 = inv_depth[l] * inv_depth[l];
+    const int i0 = kmin ? 6 * min(kmin[l], dp / 6) : 0, i1 = kmin ? 6 * (kmax[l] + 1) : dp;   // the row is zero outside the landmark's track
+    for (int i = (i0 & ~15) + q; i < i1; i += 16) ed += e[i] * sdx[i];
+    ed += __shfl_xor(ed, 8); ed += __shfl_xor(ed, 4); ed += __shfl_xor(ed, 2); ed += __shfl_xor(ed, 1);
+    if (q == 0) {
+      const double dl = (-gr[l] - ed) / Cd[l];
+      dxl[l] = dl;
+      m += -0.5 * dl * ((Cd[l] - C[l]) * dl - gr[l]);
+      n2 += dl * dl; x2 += inv_depth[l] * inv_depth[l];
+    }
   }
-  block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM); block_add(x2, scal + SC_XNORM);
+  __shared__ double red[3][kT / 64];
+  m = wave_sum(m); n2 = wave_sum(n2); x2 = wave_sum(x2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = n2; red[2][threadIdx.x >> 6] = x2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double v = 0.0;
+    for (int k = 0; k < kT / 64; ++k) v += red[threadIdx.x][k];
+    double* dst = scal + (threadIdx.x == 0 ? SC_MODEL : (threadIdx.x == 1 ? SC_DXNORM : SC_XNORM));
+    if (v != 0.0) atomicAdd(dst + (blockIdx.x & (kStripes - 1)), v);
+  }
 }
 // Model cost change without a pass over H:  (H + D) dx = -g  =>  -dx^T (g + H dx / 2) = 1/2 sum_i dx_i (D_i dx_i - g_i).
 // Camera part in k_apply_step (D_i = clamp(B_ii)/radius), landmark part in k_landmark_back.  SC_MODEL accumulates the NEGATED value
@@ -1141,7 +1310,8 @@ static int enqueue_reduced_system(lvf_problem* p, double inv_r, double* scal) {
                      p->n_lm, p->dp, p->ldE, p->C.p, p->gr.p, p->Cd.p, p->E.p, scal);
   if (p->n_lm) {
     // the Schur complement only touches the pose corner (local rhs row = dp)
-    LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->dp, p->ld, p->S.p + (size_t)p->off_pose * (p->ld + 1)));
+    const LmBand band{p->band_ready ? p->lm_order.p : nullptr, p->lm_nactive.p, p->lm_kmin.p, p->lm_kmax.p};
+    LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->dp, p->ld, p->S.p + (size_t)p->off_pose * (p->ld + 1), band));
   }
   LVF_HIP(hipGetLastError());
   return LVF_OK;
@@ -1174,8 +1344,9 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   // model / norms / candidate state
   const StateP s = state_ptrs(p->st);
   if (p->n_lm)
-    hipLaunchKernelGGL(k_landmark_back, dim3(grid(p->n_lm)), dim3(kT), p->dp * sizeof(double), q, p->n_lm, p->dp, p->ldE, p->E.p, p->C.p, p->Cd.p,
-                       p->gr.p, p->dxc.p, p->st->inv_depth.p, p->dxl.p, p->scal.p);
+    hipLaunchKernelGGL(k_landmark_back, dim3(std::min(256, (p->n_lm + kT / 16 - 1) / (kT / 16))), dim3(kT), (size_t)p->ldE * sizeof(double), q, p->n_lm, p->dp, p->ldE, p->E.p, p->C.p, p->Cd.p,
+                       p->gr.p, p->dxc.p, p->st->inv_depth.p, p->dxl.p, p->scal.p, p->band_ready ? p->lm_kmin.p : nullptr, p->lm_kmax.p,
+                       p->band_ready ? p->lm_order.p : nullptr);
   hipLaunchKernelGGL(k_apply_step, dim3(grid(std::max(p->d, p->n_lm))), dim3(kT), 0, q, p->n_kf, p->n_lm, s, p->dxc.p, p->dxl.p, p->poses2.p,
                      p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->scal.p, p->d, p->dpad, p->B.p, p->gc.p, inv_r);
   LVF_HIP(hipGetLastError());
@@ -1393,6 +1564,21 @@ int problem_configure(lvf_problem* p) {
       }
       p->tf_unique_lk2 = uniq;
     }
+  }
+  // landmark tracks -> band-limited Schur (device side: the TwoFrame indices already live there)
+  p->band_ready = false;
+  static const bool band_on = [] { const char* e = std::getenv("LVF_SCHUR_BAND"); return !(e && e[0] == '0'); }();
+  if (band_on && p->n_lm > 0 && (size_t)(4 * p->n_kf + 1) * sizeof(int) <= 48 * 1024) {
+    LVF_TRY(p->lm_kmin.ensure(p->n_lm)); LVF_TRY(p->lm_kmax.ensure(p->n_lm)); LVF_TRY(p->lm_order.ensure(p->n_lm)); LVF_TRY(p->lm_nactive.ensure(1));
+    hipStream_t q = ctx->stream;
+    hipLaunchKernelGGL(k_lm_range_init, dim3(grid(p->n_lm)), dim3(kT), 0, q, p->n_lm, p->lm_kmin.p, p->lm_kmax.p);
+    if (two_frame && two_frame->n)
+      hipLaunchKernelGGL(k_lm_range, dim3(grid(two_frame->n)), dim3(kT), 0, q, two_frame->n, two_frame->idx_a.p, two_frame->idx_b.p, two_frame->idx_c.p,
+                         p->lm_kmin.p, p->lm_kmax.p);
+    hipLaunchKernelGGL(k_lm_sort, dim3(1), dim3(1024), (size_t)(4 * p->n_kf + 1) * sizeof(int), q, p->n_lm, p->n_kf, p->lm_kmin.p, p->lm_kmax.p, p->lm_order.p,
+                       p->lm_nactive.p);
+    LVF_HIP(hipGetLastError());
+    p->band_ready = true;
   }
   LVF_HIP(hipMemsetAsync(p->pose_const.p, 0, p->n_kf, ctx->stream));
   LVF_HIP(hipMemsetAsync(p->dxc.p, 0, (size_t)p->dpad * 8, ctx->stream));
