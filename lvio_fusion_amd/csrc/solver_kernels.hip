@@ -34,12 +34,14 @@ struct lvf_problem {
   int ld = 0, off = 0, off_pose = 0, ndense = 0, aug = 0;
   lvf::SpLevels sp_levels{};
   std::vector<int> sp_tiles, sp_shmem;          // per level: workgroups per node, dynamic LDS bytes
+  std::vector<int> sp_item0, sp_items;          // per level: its slice of sp_rows
   std::vector<int32_t> plan_key;                // (n_kf, IMU index pairs) the current plan was built for
   lvf::DevBuf<lvf::SpNode> sp_nodes;
   lvf::DevBuf<int> sp_rows, sp_owner, perm, iperm;
   lvf::DevBuf<int> lm_kmin, lm_kmax, lm_order, lm_nactive;   // per-landmark keyframe track [kmin, kmax]; Schur row order; #rows with pose blocks
   bool band_ready = false;
-  lvf::DevBuf<double> sp_W, sp_L;
+  lvf::DevBuf<unsigned long long> dbg;
+  lvf::DevBuf<double> sp_W, sp_L, Dinv;         // Dinv: L_kk^-T of every 64x64 diagonal block of the dense corner
   std::vector<int> perm_h;
   lvf::DevBuf<double> B, gc, C, gr, E, Cd, S, dxc, dxl, scal;
   lvf::DevBuf<double> poses2, vel2, ba2, bg2, invd2;   // candidate state x + dx
@@ -877,7 +879,7 @@ __device__ __forceinline__ bool factor_columns(double a[16], int r, double (*col
   return bad;
 }
 
-__global__ __launch_bounds__(256) void k_chol_factor_panel(double* __restrict__ S, int ld, int kb, int* __restrict__ fail) {
+__global__ __launch_bounds__(256) void k_chol_factor_panel(double* __restrict__ S, int ld, int kb, int* __restrict__ fail, double* __restrict__ Dinv) {
   __shared__ double Lk[kNB * kLd];     // factored diagonal block, row-major padded, zero above the diagonal
   __shared__ double col[2][kNB];
   __shared__ double dinv[kNB];         // 1 / L_jj
@@ -909,12 +911,14 @@ __global__ __launch_bounds__(256) void k_chol_factor_panel(double* __restrict__ 
     for (int c = 0; c < 8; ++c) g2[c] = make_double2(a[2 * c], a[2 * c + 1]);
     return;
   }
-  // panel block (kb + blockIdx.x, kb): X L^T = A
+  // panel block (kb + blockIdx.x, kb): X L^T = A.  The LAST workgroup solves against the identity instead: X = L_kk^-T, the
+  // block's inverse factor for the back substitution (runs beside the panel blocks, costs no wall time).
   const int row = tid >> 2, part = tid & 3;
-  double* arow = S + (size_t)((kb + blockIdx.x) * kNB + row) * ld + kb * kNB;
+  const bool inverse_wg = blockIdx.x == gridDim.x - 1;
+  double* arow = inverse_wg ? Dinv + (size_t)kb * kNB * kNB + (size_t)row * kNB : S + (size_t)((kb + blockIdx.x) * kNB + row) * ld + kb * kNB;
   double x[16];
 #pragma unroll
-  for (int tt = 0; tt < 16; ++tt) x[tt] = arow[4 * tt + part];
+  for (int tt = 0; tt < 16; ++tt) x[tt] = inverse_wg ? ((4 * tt + part == row) ? 1.0 : 0.0) : arow[4 * tt + part];
 #pragma unroll
   for (int j = 0; j < kNB; ++j) {
     const int jt = j >> 2, pj = j & 3;
@@ -1025,7 +1029,18 @@ __global__ __launch_bounds__(256) void k_sp_eliminate(const SpNode* __restrict__
       for (int c = 0; c < 9; ++c) W[(size_t)(nd.row_off + r) * 9 + c] = w[c];
     }
   }
-  if (tile == 0 && tid < 81) Lout[(size_t)ni * 81 + tid] = L[tid];
+  if (tile == 0 && tid < 9) {              // column tid of L_bb^-1 (forward substitution against e_tid), for the back substitution
+    double xcol[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      double v = (r == tid) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) v -= L[r * 9 + k] * xcol[k];
+      xcol[r] = v * linv[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) Lout[(size_t)ni * 81 + r * 9 + tid] = xcol[r];
+  }
   __syncthreads();
   const int P = m * (m + 1) / 2;
   for (int p = tile * 256 + tid; p < P; p += tiles * 256) {
@@ -1044,98 +1059,175 @@ __global__ __launch_bounds__(256) void k_sp_eliminate(const SpNode* __restrict__
 
 struct SpBack {                    // what the back substitution needs of the plan
   SpLevels lv;
-  const SpNode* nodes; const int* rows; const int* owner; const double* W; const double* L; const int* perm;
-  int off, aug, d_total;
+  int item0[kSpMaxLevels], items[kSpMaxLevels];   // the level's slice of rows/owner/W
+  const SpNode* nodes; const int* rows; const int* owner; const double* W; const double* Linv; const int* perm;
+  int off, aug, d_total, total_items, n_nodes, max_count, linv_in_lds;
+  int prod_items;                  // > 0: LDS room for that many (row x 9) products => conflict-free two-stage sums; 0: LDS atomics
+  unsigned long long* dbg;         // LVF_BACK_TIMING=1: wall_clock64() stamps (100 MHz) at the phase boundaries, else null
 };
 
-// back substitution x = L^-T y with y = augmented row L[d][0..d); single workgroup of 256 threads.  S points at the DENSE
-// corner (row/column `off` of the full matrix), d = its unknowns.
-// Per block (bottom-up): (a) 4-way split gather  y_c -= sum_{r > block} L[r][c] x_r  (rows r are contiguous over c:
-// coalesced, 8 loads in flight), (b) one wave solves the 64x64 transposed triangle with the block's COLUMNS in registers.
-// Then the sparse levels in reverse: x_b = L_bb^-T (y_b - W_b^T x_N), one wave per eliminated block; the solution leaves in the
-// natural unknown order through `perm`.
-__global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ S, int ld, int d, double* __restrict__ xout, SpBack sp) {
-  extern __shared__ double sm[];          // xs[off] | x[nblk*64] | part[4][64]      (sm[R] = x of S row R)
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the global prefetches
+// that are meant to stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// back substitution x = L^-T y with y = augmented row L[d][0..d); ONE workgroup of 512 threads.  S points at the DENSE corner
+// (row/column `off` of the full matrix), d = its unknowns, Dinv holds L_kk^-T of its 64x64 diagonal blocks.
+// Nothing this kernel LOADS from global memory depends on x, so the chain is kept free of global latency:
+//   * at entry every thread requests its share of the sparse levels' (row, owner, W[9]) items (registers) and the stored
+//     L_bb^-1 (LDS): they arrive while the dense corner is being solved;
+//   * dense corner, bottom-up:  rhs = y_blk - sum_{rows r below} L[r][blk]^T x_r  (thread (column c, part) takes rows part,
+//     part + 8, ...), x_blk = Dinv_blk rhs (64x64 mat-vec split 8 ways); the gather operands and inverse block of the NEXT block
+//     are prefetched while the current one is reduced;
+//   * sparse levels in reverse, x_b = L_bb^-T (y_b - W_b^T x_N): the pre-loaded items are multiplied with x from LDS, summed per
+//     block (wave-wide when a wave holds one block's rows, LDS atomics otherwise), one thread per (block, component) applies
+//     L_bb^-1.  The solution leaves in the natural unknown order through `perm`.
+// (S and Dinv are deliberately NOT __restrict__/invariant: LLVM would sink the prefetch loads past the barriers to their uses.)
+constexpr int kBT = 512, kBParts = kBT / 64, kBackPre = 256 / kBParts, kBackInv = 64 / kBParts, kTailPre = 6;
+__global__ __launch_bounds__(kBT) void k_chol_backsolve(const double* S, int ld, int d, const double* Dinv, double* xout, SpBack sp) {
+  extern __shared__ double sm[];          // xs[off] | x[nblk*64] | partial[kBParts][64] | rhs[64] | accs[9 max_count] | linv[81 n_nodes]
   const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
   const int nblk = (d + kNB - 1) / kNB, n = nblk * kNB;
   double* x = sm + sp.off;
   double* partial = x + n;
-  for (int i = tid; i < sp.off + n; i += 256) sm[i] = 0.0;
-  __syncthreads();
+  double* rhs = partial + kBParts * kNB;
+  double* accs = rhs + kNB;
+  double* linv = accs + 9 * sp.max_count;
+  double* part1 = linv + (sp.linv_in_lds ? 81 * sp.n_nodes : 0);     // [kBT] stage-1 partial sums
+  double* prod = part1 + kBT;                                        // [prod_items][9]
+  int* snode = reinterpret_cast<int*>(prod + 9 * (size_t)sp.prod_items);   // [n_nodes][2] = (row_off, m)
+  int stamp = 0;
+  auto mark = [&]() { if (sp.dbg && tid == 0) sp.dbg[stamp++] = wall_clock64(); };
+  mark();
+  // ---- dense corner
+  const int rend = min(n, d);
+  double gl[kBackPre], xi[kBackInv], yv;
+  auto prefetch = [&](int kb) {
+    const int r0 = kb * kNB;
+#pragma unroll
+    for (int u = 0; u < kBackPre; ++u) {
+      const int r = r0 + kNB + part + kBParts * u;
+      gl[u] = (r < rend) ? S[(size_t)r * ld + r0 + c] : 0.0;
+    }
+    const double* dv = Dinv + (size_t)kb * kNB * kNB + (size_t)c * kNB + kBackInv * part;
+#pragma unroll
+    for (int t = 0; t < kBackInv; ++t) xi[t] = dv[t];
+    yv = (r0 + c < d) ? S[(size_t)d * ld + r0 + c] : 0.0;
+  };
+  prefetch(nblk - 1);
+  // ---- requests for the sparse tail, AFTER the first dense prefetch: loads return in order, so the dense corner does not wait
+  // for them and they land while it is being solved
+  int tR[kTailPre], tK[kTailPre];
+  double tW[kTailPre][9];
+#pragma unroll
+  for (int u = 0; u < kTailPre; ++u) {
+    const int g = tid + kBT * u;
+    const bool ok = g < sp.total_items;
+    tR[u] = ok ? sp.rows[g] : -1;
+    tK[u] = ok ? sp.owner[g] : 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) tW[u][q] = ok ? sp.W[(size_t)g * 9 + q] : 0.0;
+  }
+  if (sp.linv_in_lds) for (int i = tid; i < 81 * sp.n_nodes; i += kBT) linv[i] = sp.Linv[i];
+  for (int i = tid; i < sp.n_nodes; i += kBT) { const SpNode nd = sp.nodes[i]; snode[2 * i] = nd.row_off; snode[2 * i + 1] = nd.m; }
+  for (int i = tid; i < sp.off + n; i += kBT) sm[i] = 0.0;
+  lds_barrier();
+  mark();
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int r0 = kb * kNB;
     double s = 0.0;
-    const int rend = min(n, d);
-    int r = r0 + kNB + part;
-    for (; r + 28 < rend; r += 32) {
-      double lv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) lv[u] = S[(size_t)(r + 4 * u) * ld + r0 + c];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += lv[u] * x[r + 4 * u];
-    }
-    for (; r < rend; r += 4) s += S[(size_t)r * ld + r0 + c] * x[r];
+    for (int u = 0; u < kBackPre; ++u) s += gl[u] * x[min(r0 + kNB + part + kBParts * u, n - 1)];      // gl is 0 beyond the matrix
+    for (int r = r0 + kNB + part + kBParts * kBackPre; r < rend; r += kBParts) s += S[(size_t)r * ld + r0 + c] * x[r];
     partial[part * kNB + c] = s;
-    __syncthreads();
-    if (tid < 64) {
-      const int lane = tid;
-      double y = (r0 + lane < d) ? S[(size_t)d * ld + r0 + lane] : 0.0;
-      y -= partial[lane] + partial[kNB + lane] + partial[2 * kNB + lane] + partial[3 * kNB + lane];
-      double a[kNB];                      // a[j] = L[r0 + j][r0 + lane]  (column `lane` of the block), j >= lane
+    double xc[kBackInv];
 #pragma unroll
-      for (int j = 0; j < kNB; ++j) a[j] = (j >= lane && r0 + j < d) ? S[(size_t)(r0 + j) * ld + r0 + lane] : ((j == lane) ? 1.0 : 0.0);
-      // 1 / L_jj of this lane's own column, off the 64-step chain
-      const double inv_diag = (r0 + lane < d) ? 1.0 / S[(size_t)(r0 + lane) * ld + r0 + lane] : 1.0;
+    for (int t = 0; t < kBackInv; ++t) xc[t] = xi[t];
+    const double yc = yv;
+    if (kb > 0) prefetch(kb - 1);          // in flight during the reductions below
+    lds_barrier();
+    if (part == 0) {
+      double a = yc;
 #pragma unroll
-      for (int j = kNB - 1; j >= 0; --j) {
-        // x_j = y_j / L_jj on lane j, broadcast, then y_t -= L[j][t] x_j on lanes t < j
-        const double xj = lane_bcast(y * inv_diag, j);
-        if (lane == j) y = xj;
-        else if (lane < j) y -= a[j] * xj;
-      }
-      x[r0 + lane] = (r0 + lane < d) ? y : 0.0;
+      for (int pp = 0; pp < kBParts; ++pp) a -= partial[pp * kNB + c];
+      rhs[c] = a;
     }
-    __syncthreads();
+    lds_barrier();
+    double t2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < kBackInv; ++t) t2 += xc[t] * rhs[kBackInv * part + t];
+    partial[part * kNB + c] = t2;
+    lds_barrier();
+    if (part == 0) {
+      double a = 0.0;
+#pragma unroll
+      for (int pp = 0; pp < kBParts; ++pp) a += partial[pp * kNB + c];
+      x[r0 + c] = (r0 + c < d) ? a : 0.0;
+    }
+    lds_barrier();
+    mark();
   }
-  // sparse levels, last eliminated first.  All (block, neighbour row) products of a level are spread over the 256 threads
-  // (independent loads, one global round trip per level) and summed per block with LDS atomics; then one thread per block
-  // runs the 9x9 transposed solve.
-  double* accs = partial;                 // [kSpBackNodes][9] (reuses the gather scratch when it fits, see host-side sizing)
+  // ---- sparse levels, last eliminated first
   for (int lv = sp.lv.n - 1; lv >= 0; --lv) {
-    const int first = sp.lv.first[lv], count = sp.lv.count[lv];
-    const SpNode n0 = sp.nodes[first];
-    const SpNode n1 = sp.nodes[first + count - 1];
-    const int item0 = n0.row_off, items = n1.row_off + n1.m - n0.row_off;     // the level's rows are contiguous in `rows`
-    for (int i = tid; i < 9 * count; i += 256) accs[i] = 0.0;
-    __syncthreads();
-    for (int it = tid; it < items; it += 256) {
-      const int g = item0 + it;
-      const int k = sp.owner[g] - first;   // owning block
-      const int R = sp.rows[g];
-      const double xr = (R == sp.aug) ? -1.0 : sm[R];            // the rhs row carries y_b itself
-      const double* w = sp.W + (size_t)g * 9;
+    const int first = sp.lv.first[lv], count = sp.lv.count[lv], item0 = sp.item0[lv], item1 = item0 + sp.items[lv];
+    const bool staged = sp.items[lv] <= sp.prod_items;
+    if (staged) {
+      // (1) products -W x_r of every (block, row) item into LDS (stride 9 doubles: conflict-free)
 #pragma unroll
-      for (int q = 0; q < 9; ++q) atomicAdd(&accs[9 * k + q], -w[q] * xr);
-    }
-    __syncthreads();
-    for (int k = tid; k < count; k += 256) {
-      const int ni = first + k;
-      const double* L = sp.L + (size_t)ni * 81;
-      double xb[9];
+      for (int u = 0; u < kTailPre; ++u) {
+        const int g = tid + kBT * u;
+        if (g >= item0 && g < item1) {
+          const double xr = (tR[u] == sp.aug) ? -1.0 : sm[tR[u]];          // the rhs row carries y_b itself
 #pragma unroll
-      for (int q = 8; q >= 0; --q) {
-        double v = accs[9 * k + q];
-#pragma unroll
-        for (int t = q + 1; t < 9; ++t) v -= L[t * 9 + q] * xb[t];
-        xb[q] = v / L[q * 9 + q];
+          for (int q = 0; q < 9; ++q) prod[9 * (g - item0) + q] = -tW[u][q] * xr;
+        }
       }
-      const int col = sp.nodes[ni].col;
+      for (int g = max(item0, kBT * kTailPre) + tid; g < item1; g += kBT) {   // items beyond the register window (large windows only)
+        const int R = sp.rows[g];
+        const double xr = (R == sp.aug) ? -1.0 : sm[R];
 #pragma unroll
-      for (int q = 0; q < 9; ++q) sm[col + q] = xb[q];
+        for (int q = 0; q < 9; ++q) prod[9 * (g - item0) + q] = -sp.W[(size_t)g * 9 + q] * xr;
+      }
+      lds_barrier();
+      // (2) thread (block k, component q, part j of J) sums its share of the block's rows; (3) thread (k, q) adds the J parts
+      int J = 1;
+      while (2 * J * 9 * count <= kBT && J < 32) J *= 2;
+      if (tid < 9 * count * J) {
+        const int j = tid % J, kq = tid / J, q = kq % 9, k = kq / 9;
+        const int base = snode[2 * (first + k)] - item0, m = snode[2 * (first + k) + 1];
+        double a = 0.0;
+        for (int r = j; r < m; r += J) a += prod[9 * (base + r) + q];
+        part1[tid] = a;
+      }
+      lds_barrier();
+      if (tid < 9 * count) {
+        double a = 0.0;
+        for (int j = 0; j < J; ++j) a += part1[tid * J + j];
+        accs[tid] = a;
+      }
+    } else {                                   // no LDS room for the products: LDS atomics (slow under contention, but general)
+      for (int i = tid; i < 9 * count; i += kBT) accs[i] = 0.0;
+      lds_barrier();
+      for (int g = item0 + tid; g < item1; g += kBT) {
+        const int R = sp.rows[g], k = sp.owner[g] - first;
+        const double xr = (R == sp.aug) ? -1.0 : sm[R];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) atomicAdd(&accs[9 * k + q], -sp.W[(size_t)g * 9 + q] * xr);
+      }
     }
-    __syncthreads();
+    lds_barrier();
+    for (int idx = tid; idx < 9 * count; idx += kBT) {
+      const int kk = idx / 9, qq = idx - 9 * kk;
+      double v = 0.0;                                       // x_q = sum_{t >= q} (L^-1)[t][q] acc_t
+      if (sp.linv_in_lds) { const double* Li = linv + (size_t)(first + kk) * 81; for (int t = qq; t < 9; ++t) v += Li[t * 9 + qq] * accs[9 * kk + t]; }
+      else { const double* Li = sp.Linv + (size_t)(first + kk) * 81; for (int t = qq; t < 9; ++t) v += Li[t * 9 + qq] * accs[9 * kk + t]; }
+      sm[9 * (first + kk) + qq] = v;                        // block `first + kk` owns S columns 9 (first + kk) ..
+    }
+    lds_barrier();
+    mark();
   }
-  for (int i = tid; i < sp.d_total; i += 256) xout[i] = sm[sp.perm[i]];
+  for (int i = tid; i < sp.d_total; i += kBT) xout[i] = sm[sp.perm[i]];
+  mark();
+  if (sp.dbg && tid == 0) sp.dbg[63] = (unsigned long long)stamp;
 }
 
 // ------------------------------------------------------------------------------------------------ step pieces
@@ -1329,18 +1421,39 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   double* Sd = p->S.p + (size_t)p->off * (p->ld + 1);       // dense corner
   for (int kb = 0; kb < p->nb; ++kb) {
     const int below = p->nb - kb - 1;
-    hipLaunchKernelGGL(k_chol_factor_panel, dim3(1 + below), dim3(256), 0, q, Sd, p->ld, kb, fail_flag_dev);
+    hipLaunchKernelGGL(k_chol_factor_panel, dim3(2 + below), dim3(256), 0, q, Sd, p->ld, kb, fail_flag_dev, p->Dinv.p);
     if (below > 0) {
       hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, q, Sd, p->ld, kb);
     }
   }
   SpBack sb;
-  sb.lv = p->sp_levels; sb.nodes = p->sp_nodes.p; sb.rows = p->sp_rows.p; sb.owner = p->sp_owner.p; sb.W = p->sp_W.p; sb.L = p->sp_L.p; sb.perm = p->perm.p;
+  sb.lv = p->sp_levels; sb.rows = p->sp_rows.p; sb.owner = p->sp_owner.p; sb.W = p->sp_W.p; sb.Linv = p->sp_L.p; sb.perm = p->perm.p;
   sb.off = p->off; sb.aug = p->aug; sb.d_total = p->d;
+  static const bool back_timing = std::getenv("LVF_BACK_TIMING") != nullptr;
+  sb.dbg = nullptr;
+  if (back_timing) { LVF_TRY(p->dbg.ensure(64)); sb.dbg = p->dbg.p; }
   int max_count = 0;
-  for (int lv = 0; lv < p->sp_levels.n; ++lv) max_count = std::max(max_count, p->sp_levels.count[lv]);
-  const size_t sh = ((size_t)p->off + (size_t)((p->ndense + 63) / 64) * 64 + std::max(4 * kNB, 9 * max_count)) * sizeof(double);
-  hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(256), sh, q, Sd, p->ld, p->ndense, p->dxc.p, sb);
+  for (int lv = 0; lv < p->sp_levels.n; ++lv) {
+    max_count = std::max(max_count, p->sp_levels.count[lv]);
+    sb.item0[lv] = p->sp_item0[lv]; sb.items[lv] = p->sp_items[lv];
+  }
+  const int n_nodes = p->sp_levels.n ? p->sp_levels.first[p->sp_levels.n - 1] + p->sp_levels.count[p->sp_levels.n - 1] : 0;
+  sb.total_items = p->sp_levels.n ? p->sp_item0[p->sp_levels.n - 1] + p->sp_items[p->sp_levels.n - 1] : 0;
+  sb.n_nodes = n_nodes; sb.max_count = max_count;
+  sb.nodes = p->sp_nodes.p;
+  static const bool big_lds = [] {        // up to 160 KB of LDS per workgroup on gfx950; the default cap for dynamic LDS is 64 KB
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_backsolve), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
+  }();
+  const size_t lds_cap = big_lds ? 156 * 1024 : 64 * 1024;
+  size_t doubles = (size_t)p->off + (size_t)((p->ndense + 63) / 64) * 64 + (size_t)(kBParts + 1) * kNB + 9 * (size_t)max_count + kBT + (size_t)n_nodes + 2;
+  sb.linv_in_lds = (doubles + 81 * (size_t)n_nodes) * sizeof(double) <= 48 * 1024 ? 1 : 0;
+  if (sb.linv_in_lds) doubles += 81 * (size_t)n_nodes;
+  int max_items = 0;
+  for (int lv = 0; lv < p->sp_levels.n; ++lv) max_items = std::max(max_items, p->sp_items[lv]);
+  sb.prod_items = ((doubles + 9 * (size_t)max_items) * sizeof(double) <= lds_cap) ? max_items : 0;
+  doubles += 9 * (size_t)sb.prod_items;
+  const size_t sh = doubles * sizeof(double);
+  hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(kBT), sh, q, Sd, p->ld, p->ndense, p->Dinv.p, p->dxc.p, sb);
   // model / norms / candidate state
   const StateP s = state_ptrs(p->st);
   if (p->n_lm)
@@ -1379,6 +1492,13 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
   double h[SC_ALLOC];
   LVF_HIP(hipMemcpyAsync(h, p->scal.p, sizeof(h), hipMemcpyDeviceToHost, q));
   LVF_HIP(hipStreamSynchronize(q));
+  if (p->dbg.p && std::getenv("LVF_BACK_TIMING")) {
+    unsigned long long t[64];
+    LVF_HIP(hipMemcpy(t, p->dbg.p, sizeof(t), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "backsolve phases (us):");
+    for (unsigned long long k = 1; k < t[63] && k < 63; ++k) std::fprintf(stderr, " %.2f", (double)(t[k] - t[k - 1]) * 0.01);
+    std::fprintf(stderr, "\n");
+  }
   int hfail; std::memcpy(&hfail, &h[SC_FAIL], sizeof(int));
   out->cost_before = stripe_sum(h, SC_COST); out->cost_after = stripe_sum(h, SC_COST_NEW); out->model = -stripe_sum(h, SC_MODEL);
   out->dxnorm = std::sqrt(stripe_sum(h, SC_DXNORM)); out->xnorm = std::sqrt(stripe_sum(h, SC_XNORM));
@@ -1481,7 +1601,7 @@ static int build_elimination_plan(lvf_problem* p) {
   // device tables
   std::vector<SpNode> dn(ns);
   std::vector<int> rows, owner;
-  p->sp_tiles.assign(lv.n, 1); p->sp_shmem.assign(lv.n, 0);
+  p->sp_tiles.assign(lv.n, 1); p->sp_shmem.assign(lv.n, 0); p->sp_item0.assign(lv.n, 0); p->sp_items.assign(lv.n, 0);
   for (int l = 0; l < lv.n; ++l) {
     int mmax = 0;
     for (int s_ = lv.first[l]; s_ < lv.first[l] + lv.count[l]; ++s_) {
@@ -1497,6 +1617,7 @@ static int build_elimination_plan(lvf_problem* p) {
       rows.insert(rows.end(), r.begin(), r.end());
       owner.insert(owner.end(), r.size(), s_);
     }
+    p->sp_item0[l] = dn[lv.first[l]].row_off; p->sp_items[l] = (int)rows.size() - p->sp_item0[l];
     const int P = mmax * (mmax + 1) / 2;
     p->sp_tiles[l] = std::max(1, std::min(32, (P + 2047) / 2048));
     p->sp_shmem[l] = (9 * mmax + 81 + 9) * 8 + 4 * mmax + 16;
@@ -1522,6 +1643,7 @@ int problem_configure(lvf_problem* p) {
   p->dpad = ((p->d + 1 + 63) / 64) * 64;
   LVF_TRY(build_elimination_plan(p));                 // sets ld, off, off_pose, ndense, aug, nb and the sparse levels
   const size_t nS = (size_t)p->dpad * p->dpad;
+  LVF_TRY(p->Dinv.ensure((size_t)p->nb * kNB * kNB));
   LVF_TRY(p->B.ensure(nS)); LVF_TRY(p->S.ensure((size_t)p->ld * p->ld)); LVF_TRY(p->gc.ensure(p->dpad)); LVF_TRY(p->dxc.ensure(p->dpad));
   LVF_TRY(p->C.ensure(p->n_lm)); LVF_TRY(p->gr.ensure(p->n_lm)); LVF_TRY(p->Cd.ensure(p->n_lm)); LVF_TRY(p->dxl.ensure(p->n_lm));
   LVF_TRY(p->E.ensure((size_t)p->n_lm * p->ldE)); LVF_TRY(p->scal.ensure(SC_ALLOC));
