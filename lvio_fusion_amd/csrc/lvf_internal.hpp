@@ -77,6 +77,31 @@ struct Pool {
 };
 extern thread_local std::shared_ptr<Pool> g_pool;         // the calling entry point's context pool (set by lvf::enter)
 
+// grow-only PINNED host staging array (hipHostMalloc): what the persistent window assembles its block lists into, so that the
+// per-tick uploads are real asynchronous DMA instead of pageable copies through the runtime's bounce buffer, and nothing is
+// re-allocated or zero-filled per tick.  Contents are not preserved across a growth.
+template <typename T>
+struct HostPin {
+  T* p = nullptr;
+  size_t cap = 0;
+  HostPin() = default;
+  HostPin(const HostPin&) = delete;
+  HostPin& operator=(const HostPin&) = delete;
+  ~HostPin() { if (p) (void)hipHostFree(p); }
+  int reserve(size_t count) {
+    if (count <= cap) return LVF_OK;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = count + count / 4 + 64;
+    void* q = nullptr;
+    hipError_t e = hipHostMalloc(&q, want * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return ::lvf::hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+    p = static_cast<T*>(q); cap = want;
+    return LVF_OK;
+  }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
+
 template <typename T>
 struct DevBuf {  // owning device buffer
   T* p = nullptr;

@@ -684,7 +684,19 @@ __global__ __launch_bounds__(1024) void k_lm_sort(int n_lm, int n_kf, const int*
   __syncthreads();
   for (int l = threadIdx.x; l < n_lm; l += 1024) atomicAdd(&bucket[lm_sort_key(kmin[l], kmax[l], n_kf)], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (nb <= 1024) {                         // exclusive scan of the bucket counts: 16 wave scans + 16 wave totals
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid < nb ? bucket[tid] : 0;
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (tid < nb) bucket[tid] = base + incl - c;
+    if (tid == nb - 1) *n_active = base + incl - c;
+  } else if (threadIdx.x == 0) {
     int run = 0;
     for (int b = 0; b < nb; ++b) { const int c = bucket[b]; bucket[b] = run; run += c; }
     *n_active = bucket[nb - 1];

@@ -62,6 +62,9 @@ struct lvf_window {
   // device side, persistent across ticks
   lvf_state* st = nullptr;
   lvf_batch *tc = nullptr, *tf = nullptr, *po = nullptr, *imu = nullptr, *prior = nullptr;
+  // pinned staging for the per-tick block lists (observations / indices per functor type)
+  lvf::HostPin<double> h_tc_l, h_tc_r, h_tf_f, h_tf_o, h_po_o, h_po_pw;
+  lvf::HostPin<int32_t> h_tc_lm, h_tc_kf, h_tf_lm, h_tf_k1, h_tf_k2, h_po_kf, h_po_pi;
   lvf_problem* prob = nullptr;
   // assembly of the last solve
   std::vector<int> slot_lm;                              // dense landmark slot -> index into lms
@@ -244,8 +247,10 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t_begin = now();
   // ---- assemble the block lists in BuildProblem's order
-  std::vector<double> tc_l, tc_r, tf_f, tf_o, po_o, po_pw, pr_t, pr_w, pr_v;
-  std::vector<int32_t> tc_lm, tc_kf, tf_lm, tf_k1, tf_k2, po_kf, po_pi, imu_i, imu_j, pr_a, pr_b;
+  std::vector<double> pr_t, pr_w, pr_v;
+  std::vector<int32_t> imu_i, imu_j, pr_a, pr_b;
+  HostPin<double>&tc_l = w->h_tc_l, &tc_r = w->h_tc_r, &tf_f = w->h_tf_f, &tf_o = w->h_tf_o, &po_o = w->h_po_o, &po_pw = w->h_po_pw;
+  HostPin<int32_t>&tc_lm = w->h_tc_lm, &tc_kf = w->h_tc_kf, &tf_lm = w->h_tf_lm, &tf_k1 = w->h_tf_k1, &tf_k2 = w->h_tf_k2, &po_kf = w->h_po_kf, &po_pi = w->h_po_pi;
   std::vector<lvf_preint> imu_pre;
   for (lvf_window::Lm& l : w->lms) l.slot = -1;
   w->slot_lm.clear();
@@ -289,8 +294,10 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   // block arrays are written through raw cursors into buffers sized for the worst case (every feature in every list)
   size_t n_obs = 0;
   for (const lvf_window::Kf& f : w->kfs) n_obs += f.obs.size();
-  tc_l.resize(2 * n_obs); tc_r.resize(2 * n_obs); tf_f.resize(2 * n_obs); tf_o.resize(2 * n_obs); po_o.resize(2 * n_obs); po_pw.resize(3 * n_obs);
-  tc_lm.resize(n_obs); tc_kf.resize(n_obs); tf_lm.resize(n_obs); tf_k1.resize(n_obs); tf_k2.resize(n_obs); po_kf.resize(n_obs); po_pi.resize(n_obs);
+  LVF_TRY(tc_l.reserve(2 * n_obs)); LVF_TRY(tc_r.reserve(2 * n_obs)); LVF_TRY(tf_f.reserve(2 * n_obs)); LVF_TRY(tf_o.reserve(2 * n_obs));
+  LVF_TRY(po_o.reserve(2 * n_obs)); LVF_TRY(po_pw.reserve(3 * n_obs));
+  LVF_TRY(tc_lm.reserve(n_obs)); LVF_TRY(tc_kf.reserve(n_obs)); LVF_TRY(tf_lm.reserve(n_obs)); LVF_TRY(tf_k1.reserve(n_obs)); LVF_TRY(tf_k2.reserve(n_obs));
+  LVF_TRY(po_kf.reserve(n_obs)); LVF_TRY(po_pi.reserve(n_obs));
   size_t ntc = 0, ntf = 0, npo = 0;
   for (int k = 0; k < n_kf; ++k) {
     lvf_window::Kf& f = w->kfs[k];
@@ -341,11 +348,8 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
       pr_b.push_back(k); pr_t.insert(pr_t.end(), t7, t7 + 7); pr_w.push_back(w->opt.prior_weight); pr_v.push_back(w->opt.prior_v);
     }
   }
-  tc_l.resize(2 * ntc); tc_r.resize(2 * ntc); tc_lm.resize(ntc); tc_kf.resize(ntc);
-  tf_f.resize(2 * ntf); tf_o.resize(2 * ntf); tf_lm.resize(ntf); tf_k1.resize(ntf); tf_k2.resize(ntf);
-  po_o.resize(2 * npo); po_pw.resize(3 * npo); po_kf.resize(npo); po_pi.resize(npo);
   const int n_lm = (int)w->slot_lm.size();
-  w->n_tc = (int)tc_lm.size(); w->n_tf = (int)tf_lm.size(); w->n_po = (int)po_kf.size(); w->n_imu = (int)imu_i.size(); w->n_prior = (int)pr_b.size();
+  w->n_tc = (int)ntc; w->n_tf = (int)ntf; w->n_po = (int)npo; w->n_imu = (int)imu_i.size(); w->n_prior = (int)pr_b.size();
 
   const auto t_assembled = now();
   // ---- persistent device objects: created once (empty), re-filled every tick through grow-only buffers
@@ -370,13 +374,15 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   LVF_TRY(put(st->poses, poses, s)); LVF_TRY(put(st->vel, vel, s)); LVF_TRY(put(st->ba, ba, s)); LVF_TRY(put(st->bg, bg, s));
   LVF_TRY(put(st->w_visual, wv, s)); LVF_TRY(put(st->inv_depth, invd, s));
   auto idx_ok = [](lvf_batch* b, int n, int nkf, int nlm) { b->n = n; b->min_n_kf = nkf; b->min_n_lm = nlm; b->evaluated = false; };
-  LVF_TRY(put(w->tc->ob_a, tc_l, s)); LVF_TRY(put(w->tc->ob_b, tc_r, s)); LVF_TRY(put(w->tc->idx_a, tc_lm, s)); LVF_TRY(put(w->tc->idx_b, tc_kf, s));
+  LVF_TRY(w->tc->ob_a.assign(tc_l.p, 2 * ntc, s)); LVF_TRY(w->tc->ob_b.assign(tc_r.p, 2 * ntc, s));
+  LVF_TRY(w->tc->idx_a.assign(tc_lm.p, ntc, s)); LVF_TRY(w->tc->idx_b.assign(tc_kf.p, ntc, s));
   idx_ok(w->tc, w->n_tc, n_kf, n_lm);
-  LVF_TRY(put(w->tf->ob_a, tf_f, s)); LVF_TRY(put(w->tf->ob_b, tf_o, s)); LVF_TRY(put(w->tf->idx_a, tf_lm, s)); LVF_TRY(put(w->tf->idx_b, tf_k1, s));
-  LVF_TRY(put(w->tf->idx_c, tf_k2, s));
+  LVF_TRY(w->tf->ob_a.assign(tf_f.p, 2 * ntf, s)); LVF_TRY(w->tf->ob_b.assign(tf_o.p, 2 * ntf, s));
+  LVF_TRY(w->tf->idx_a.assign(tf_lm.p, ntf, s)); LVF_TRY(w->tf->idx_b.assign(tf_k1.p, ntf, s)); LVF_TRY(w->tf->idx_c.assign(tf_k2.p, ntf, s));
   idx_ok(w->tf, w->n_tf, n_kf, n_lm);
-  w->tf->sorted_by_kf = true; w->tf->host_kf1 = tf_k1; w->tf->host_kf2 = tf_k2; w->tf->host_lm.clear(); w->tf->unique_lk2_known = true;   // Kf::sort_unique keeps one observation per (keyframe, landmark)     // assembled frame by frame: sorted by current keyframe
-  LVF_TRY(put(w->po->ob_a, po_o, s)); LVF_TRY(put(w->po->idx_a, po_kf, s)); LVF_TRY(put(w->po->idx_b, po_pi, s)); LVF_TRY(put(w->po->table, po_pw, s));
+  w->tf->sorted_by_kf = true; w->tf->host_kf1.assign(tf_k1.p, tf_k1.p + ntf); w->tf->host_kf2.assign(tf_k2.p, tf_k2.p + ntf); w->tf->host_lm.clear(); w->tf->unique_lk2_known = true;   // Kf::sort_unique keeps one observation per (keyframe, landmark)     // assembled frame by frame: sorted by current keyframe
+  LVF_TRY(w->po->ob_a.assign(po_o.p, 2 * npo, s)); LVF_TRY(w->po->idx_a.assign(po_kf.p, npo, s)); LVF_TRY(w->po->idx_b.assign(po_pi.p, npo, s));
+  LVF_TRY(w->po->table.assign(po_pw.p, 3 * npo, s));
   idx_ok(w->po, w->n_po, n_kf, 0); w->po->n_table = w->n_po; w->po->sorted_by_kf = true;
   {
     lvf_batch* b = w->imu;
