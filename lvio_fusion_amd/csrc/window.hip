@@ -65,6 +65,7 @@ struct lvf_window {
   // pinned staging for the per-tick block lists (observations / indices per functor type)
   lvf::HostPin<double> h_tc_l, h_tc_r, h_tf_f, h_tf_o, h_po_o, h_po_pw;
   lvf::HostPin<int32_t> h_tc_lm, h_tc_kf, h_tf_lm, h_tf_k1, h_tf_k2, h_po_kf, h_po_pi;
+  lvf::HostPin<double> h_state;      // poses | vel | ba | bg | w_visual | inv_depth
   lvf_problem* prob = nullptr;
   // assembly of the last solve
   std::vector<int> slot_lm;                              // dense landmark slot -> index into lms
@@ -364,15 +365,20 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   }
   lvf_state* st = w->st;
   st->n_kf = n_kf; st->n_lm = n_lm;
-  std::vector<double> poses((size_t)7 * n_kf), vel((size_t)3 * n_kf), ba(vel), bg(vel), wv(n_kf), invd(n_lm);
+  // state arrays live in one pinned staging block (upload now, read-back after the solve)
+  const size_t o_pose = 0, o_vel = (size_t)7 * n_kf, o_ba = o_vel + (size_t)3 * n_kf, o_bg = o_ba + (size_t)3 * n_kf, o_wv = o_bg + (size_t)3 * n_kf,
+               o_invd = o_wv + n_kf;
+  LVF_TRY(w->h_state.reserve(o_invd + n_lm));
+  double *poses = w->h_state.p + o_pose, *vel = w->h_state.p + o_vel, *ba = w->h_state.p + o_ba, *bg = w->h_state.p + o_bg, *wv = w->h_state.p + o_wv,
+         *invd = w->h_state.p + o_invd;
   for (int k = 0; k < n_kf; ++k) {
     const lvf_window::Kf& f = w->kfs[k];
     std::memcpy(&poses[(size_t)7 * k], f.pose, 56); std::memcpy(&vel[(size_t)3 * k], f.vel, 24); std::memcpy(&ba[(size_t)3 * k], f.ba, 24);
     std::memcpy(&bg[(size_t)3 * k], f.bg, 24); wv[k] = f.w_visual;
   }
   for (int l = 0; l < n_lm; ++l) invd[l] = w->lms[w->slot_lm[l]].inv_depth;
-  LVF_TRY(put(st->poses, poses, s)); LVF_TRY(put(st->vel, vel, s)); LVF_TRY(put(st->ba, ba, s)); LVF_TRY(put(st->bg, bg, s));
-  LVF_TRY(put(st->w_visual, wv, s)); LVF_TRY(put(st->inv_depth, invd, s));
+  LVF_TRY(st->poses.assign(poses, (size_t)7 * n_kf, s)); LVF_TRY(st->vel.assign(vel, (size_t)3 * n_kf, s)); LVF_TRY(st->ba.assign(ba, (size_t)3 * n_kf, s));
+  LVF_TRY(st->bg.assign(bg, (size_t)3 * n_kf, s)); LVF_TRY(st->w_visual.assign(wv, n_kf, s)); LVF_TRY(st->inv_depth.assign(invd, n_lm, s));
   auto idx_ok = [](lvf_batch* b, int n, int nkf, int nlm) { b->n = n; b->min_n_kf = nkf; b->min_n_lm = nlm; b->evaluated = false; };
   LVF_TRY(w->tc->ob_a.assign(tc_l.p, 2 * ntc, s)); LVF_TRY(w->tc->ob_b.assign(tc_r.p, 2 * ntc, s));
   LVF_TRY(w->tc->idx_a.assign(tc_lm.p, ntc, s)); LVF_TRY(w->tc->idx_b.assign(tc_kf.p, ntc, s));
@@ -412,11 +418,11 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   LVF_TRY(lvf_problem_solve(w->prob, o, summary));
   const auto t_solved = now();
   // ---- read the solution back into the host mirror (frame->pose, Vw, biases, landmark->inv_depth)
-  LVF_HIP(hipMemcpyAsync(poses.data(), st->poses.p, poses.size() * 8, hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipMemcpyAsync(vel.data(), st->vel.p, vel.size() * 8, hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipMemcpyAsync(ba.data(), st->ba.p, ba.size() * 8, hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipMemcpyAsync(bg.data(), st->bg.p, bg.size() * 8, hipMemcpyDeviceToHost, s));
-  if (n_lm) LVF_HIP(hipMemcpyAsync(invd.data(), st->inv_depth.p, invd.size() * 8, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipMemcpyAsync(poses, st->poses.p, (size_t)7 * n_kf * 8, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipMemcpyAsync(vel, st->vel.p, (size_t)3 * n_kf * 8, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipMemcpyAsync(ba, st->ba.p, (size_t)3 * n_kf * 8, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipMemcpyAsync(bg, st->bg.p, (size_t)3 * n_kf * 8, hipMemcpyDeviceToHost, s));
+  if (n_lm) LVF_HIP(hipMemcpyAsync(invd, st->inv_depth.p, (size_t)n_lm * 8, hipMemcpyDeviceToHost, s));
   LVF_HIP(hipStreamSynchronize(s));
   for (int k = 0; k < n_kf; ++k) {
     lvf_window::Kf& f = w->kfs[k];
