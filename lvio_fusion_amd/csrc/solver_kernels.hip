@@ -910,7 +910,7 @@ __device__ __forceinline__ bool factor_columns(double a[16], int r, double (*col
   return bad;
 }
 
-__global__ __launch_bounds__(256) void k_chol_factor_panel(double* __restrict__ S, int ld, int kb, int* __restrict__ fail, double* __restrict__ Dinv) {
+__global__ __launch_bounds__(256) void k_chol_factor_panel(double* S, int ld, int kb, int* __restrict__ fail, double* __restrict__ Dinv) {
   __shared__ double Lk[kNB * kLd];     // factored diagonal block, row-major padded, zero above the diagonal
   __shared__ double col[2][kNB];
   __shared__ double dinv[kNB];         // 1 / L_jj
@@ -920,6 +920,15 @@ __global__ __launch_bounds__(256) void k_chol_factor_panel(double* __restrict__ 
     const double2* g2 = reinterpret_cast<const double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
 #pragma unroll
     for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; a[2 * c] = v.x; a[2 * c + 1] = v.y; }
+  }
+  // this workgroup's panel row (or identity row) is requested now and arrives during the factorisation
+  const int row = tid >> 2, part = tid & 3;
+  const bool inverse_wg = blockIdx.x == gridDim.x - 1;
+  double* arow = inverse_wg ? Dinv + (size_t)kb * kNB * kNB + (size_t)row * kNB : S + (size_t)((kb + blockIdx.x) * kNB + row) * ld + kb * kNB;
+  double x[16];
+  if (blockIdx.x != 0) {
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) x[tt] = inverse_wg ? ((4 * tt + part == row) ? 1.0 : 0.0) : arow[4 * tt + part];
   }
   bool bad;
   switch (q) {                                       // wave-uniform dispatch
@@ -944,12 +953,6 @@ __global__ __launch_bounds__(256) void k_chol_factor_panel(double* __restrict__ 
   }
   // panel block (kb + blockIdx.x, kb): X L^T = A.  The LAST workgroup solves against the identity instead: X = L_kk^-T, the
   // block's inverse factor for the back substitution (runs beside the panel blocks, costs no wall time).
-  const int row = tid >> 2, part = tid & 3;
-  const bool inverse_wg = blockIdx.x == gridDim.x - 1;
-  double* arow = inverse_wg ? Dinv + (size_t)kb * kNB * kNB + (size_t)row * kNB : S + (size_t)((kb + blockIdx.x) * kNB + row) * ld + kb * kNB;
-  double x[16];
-#pragma unroll
-  for (int tt = 0; tt < 16; ++tt) x[tt] = inverse_wg ? ((4 * tt + part == row) ? 1.0 : 0.0) : arow[4 * tt + part];
   // Forward substitution along the row, software-pipelined: D_j = sum_{t<j} x_t L[j][t] is split into P_j (terms t < j-1, which
   // only need x up to j-2 and are accumulated while step j-1 is still resolving) and the single term x_{j-1} L[j][j-1].  The
   // dependent chain per step is then one FMA, the quad reduction and the scale.  In-kernel timers: the 64-step solve went
@@ -982,12 +985,21 @@ __global__ __launch_bounds__(256) void k_chol_factor_panel(double* __restrict__ 
 // trailing update: A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi.  One workgroup per 64x64 tile; both 64x64 panels are
 // staged in LDS (row stride 65) and each of the 4 waves produces a 16x64 strip with v_mfma_f64_16x16x4_f64
 // (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D: col = lane&15, row = (lane>>4) + 4 reg).
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int ld, int kb) {
+__global__ __launch_bounds__(256) void k_chol_update(double* S, int ld, int kb) {
   __shared__ double Pi[kNB * kLd];
   __shared__ double Pj[kNB * kLd];
   int t = blockIdx.x, ii = 0;
   while (t >= ii + 1) { t -= ii + 1; ++ii; }
   const int bi = kb + 1 + ii, bj = kb + 1 + t;
+  // the tile being updated is requested FIRST (it does not depend on the product) so its round trip hides under the panel
+  // staging and the matrix-core work; S is not __restrict__ so the loads stay where they are written
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lc = lane & 15;
+  double* out = S + (size_t)(bi * kNB + 16 * w) * ld + bj * kNB;
+  double o[4][4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) o[ct][rg] = out[(size_t)(lk + 4 * rg) * ld + 16 * ct + lc];
   const double* pi = S + (size_t)(bi * kNB) * ld + kb * kNB;
   const double* pj = S + (size_t)(bj * kNB) * ld + kb * kNB;
   for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
@@ -996,7 +1008,6 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
     Pj[rr * kLd + c] = pj[(size_t)rr * ld + c];
   }
   __syncthreads();
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lc = lane & 15;
   double4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
   for (int k0 = 0; k0 < kNB; k0 += 4) {
@@ -1004,11 +1015,10 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pj[(16 * ct + lc) * kLd + k0 + lk], acc[ct], 0, 0, 0);
   }
-  double* out = S + (size_t)(bi * kNB + 16 * w) * ld + bj * kNB;
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) out[(size_t)(lk + 4 * rg) * ld + 16 * ct + lc] -= acc[ct][rg];
+    for (int rg = 0; rg < 4; ++rg) out[(size_t)(lk + 4 * rg) * ld + 16 * ct + lc] = o[ct][rg] - acc[ct][rg];
 }
 
 // ------------------------------------------------------------------------------------------------ elimination order
