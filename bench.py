@@ -23,6 +23,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# CPU-baseline leg: the reference runs Ceres with num_threads = min(8, 0.75 nproc) (estimator.cpp:10); the oracle's OpenMP team is
+# sized the same way (on a 256-core host the default team makes its small dense loops slower, not faster)
+os.environ.setdefault("OMP_NUM_THREADS", str(min(8, max(1, int(0.75 * (os.cpu_count() or 1))))))
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 POSE_ONLY_BYTES_PER_BLOCK = 152  # ob 16 + 2 idx 8 + r 16 + J 112

@@ -1,4 +1,10 @@
 import os
+
+# the CPU oracle parallelises with OpenMP; on a 256-core GPU host the default team size makes its small dense loops
+# pathologically slow (80 s per LM iteration at 60 keyframes instead of ~1 s) — the reference itself runs Ceres with
+# num_threads = min(8, 0.75 nproc) (estimator.cpp:10)
+os.environ.setdefault("OMP_NUM_THREADS", str(min(8, max(1, int(0.75 * (os.cpu_count() or 1))))))
+
 import sys
 
 import pytest

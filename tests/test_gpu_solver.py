@@ -17,8 +17,10 @@ def ctx():
     c.close()
 
 
-def build(api, ctx, oracle, n_kf, n_lm, seed, n_pre=40, use=("tc", "tf", "po", "imu")):
+def build(api, ctx, oracle, n_kf, n_lm, seed, n_pre=40, use=("tc", "tf", "po", "imu"), imu_drop=()):
     cfg = syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=n_pre, seed=seed, imu_samples=5)
+    if imu_drop:       # IMU drop-outs: the (v, ba, bg) coupling graph falls apart into several chains and isolated blocks
+        cfg["imu"] = [f for k, f in enumerate(cfg["imu"]) if k not in imu_drop]
     pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
     st = api.State(ctx, n_kf, n_lm)
     for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth"), (api.W_VISUAL, "w_kf")):
@@ -60,6 +62,35 @@ def test_lm_iteration_parity(ctx, oracle, n_kf, n_lm, seed, use):
         assert got["accepted"] == ref["accepted"]
         assert abs(got["cost_after"] - ref["cost_after"]) <= 1e-6 * abs(ref["cost_after"])
         assert abs(got["radius"] - ref["radius"]) <= 1e-5 * ref["radius"]
+        s = state_of(api, st)
+        assert_parity(s["poses"].reshape(-1, 7), win.poses, f"poses it{it}")
+        assert_parity(s["inv_depth"], win.inv_depth, f"inv_depth it{it}")
+        assert_parity(s["vel"].reshape(-1, 3), win.vel, f"vel it{it}")
+        assert_parity(s["ba"].reshape(-1, 3), win.ba, f"ba it{it}")
+        assert_parity(s["bg"].reshape(-1, 3), win.bg, f"bg it{it}")
+        radius, dec = ref["radius"], ref["decrease_factor"]
+    for h in list(b.values()) + [st]:
+        if h is not None:
+            h.close()
+    prob.close()
+
+
+@pytest.mark.parametrize("n_kf,n_lm,seed,drop", [(12, 200, 11, (2, 3, 7)), (9, 100, 13, (0, 7)), (60, 300, 17, (10, 11, 30))])
+def test_lm_iteration_parity_with_imu_gaps_and_large_windows(ctx, oracle, n_kf, n_lm, seed, drop):
+    """The elimination plan is built from the actual IMU coupling graph (nested-dissection levels per chain, isolated blocks
+    first); 60 keyframes also takes the Schur complement off the LDS-band path (ldE > 320) and deepens the level tree."""
+    from lvio_fusion_amd import api
+    cfg, st, b, prob, win = build(api, ctx, oracle, n_kf, n_lm, seed, imu_drop=drop)
+    opt = api.default_solver_options()
+    radius, dec = 1e4, 2.0
+    for it in range(3):
+        ref = win.lm_iteration(radius, dec)
+        got = prob.lm_iteration(opt, radius, dec)
+        assert abs(got["cost_before"] - ref["cost_before"]) <= 1e-8 * abs(ref["cost_before"])
+        S, rhs = prob.reduced_system()
+        assert np.abs(S - ref["S"]).max() <= 1e-7 * np.abs(ref["S"]).max(), f"iteration {it}: reduced system mismatch"
+        assert got["accepted"] == ref["accepted"]
+        assert abs(got["cost_after"] - ref["cost_after"]) <= 1e-6 * abs(ref["cost_after"])
         s = state_of(api, st)
         assert_parity(s["poses"].reshape(-1, 7), win.poses, f"poses it{it}")
         assert_parity(s["inv_depth"], win.inv_depth, f"inv_depth it{it}")
