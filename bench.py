@@ -133,7 +133,7 @@ def main():
     # (every optional leg is fenced: a failure there must never take the headline line down with it)
     if rank == 0 and world == 1 and not args.no_extras:
         try:
-            out["extras"] = extras(api, syn, ctx)
+            out["extras"] = extras(api, syn, ctx, local_rank)
         except Exception as e:
             out["extras"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -178,7 +178,7 @@ def main():
         print(json.dumps(out))
 
 
-def extras(api, syn, ctx):
+def extras(api, syn, ctx, device=0):
     """ICP association leg (configs[2]): 100k query points vs ~300k map points, ground gate."""
     ex = {}
     c3 = syn.config3_icp()
@@ -207,6 +207,12 @@ def extras(api, syn, ctx):
     ex["map_maintenance"] = map_maintenance(api, ctx, c3)
     ex["full_window_ba"] = full_window(api, syn, ctx)
     ex["window_tick"] = window_tick(api, syn, ctx)
+    try:
+        # 4 = the number of hardware queues HIP multiplexes streams onto by default (more queues measured slower); 8 = the reference's
+        # number of training environments
+        ex["concurrent_windows"] = {"4": concurrent_windows(api, syn, device, n_windows=4), "8": concurrent_windows(api, syn, device, n_windows=8)}
+    except Exception as e:
+        ex["concurrent_windows"] = {"error": repr(e)}
     ex["relocalize_8_candidates"] = relocalize_leg(api, syn, ctx)
     return ex
 
@@ -331,10 +337,8 @@ def relocalize_leg(api, syn, ctx, n=8):
             "scores": [float(x) for x in rec[np.argsort(rec[:, 8]), 0]]}
 
 
-def full_window(api, syn, ctx, iters=30):
-    """configs[3]: 50 KF / 10k landmarks full sliding-window problem; one step = one complete LM iteration
-    (linearise all factors, Schur-eliminate inverse depths, Cholesky, back-substitute, evaluate the candidate)."""
-    cfg = syn.config4_window()
+def _build_window(api, syn, ctx, seed=None):
+    cfg = syn.config4_window() if seed is None else syn.config4_window(seed=seed)
     pre = api.preintegrate_or_none(ctx, cfg)
     st = api.State(ctx, cfg["n_kf"], cfg["n_lm"])
     for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth"), (api.W_VISUAL, "w_kf")):
@@ -345,6 +349,14 @@ def full_window(api, syn, ctx, iters=30):
     bpo = api.pose_only_batch(ctx, cfg["cam0"], po["ob"], po["kf_idx"], po["pw_idx"], po["pw"])
     bimu = api.imu_batch(ctx, pre, [f["kf_i"] for f in cfg["imu"]], [f["kf_j"] for f in cfg["imu"]]) if pre is not None else None
     prob = api.Problem(ctx, st, btc, btf, bpo, bimu)
+    return cfg, prob, (btc, btf, bpo, bimu, st)
+
+
+def full_window(api, syn, ctx, iters=30):
+    """configs[3]: 50 KF / 10k landmarks full sliding-window problem; one step = one complete LM iteration
+    (linearise all factors, Schur-eliminate inverse depths, Cholesky, back-substitute, evaluate the candidate)."""
+    cfg, prob, handles = _build_window(api, syn, ctx)
+    btc, btf, bpo, bimu, st = handles
     opt = api.default_solver_options()
     radius, dec, costs = 1e4, 2.0, []
     for _ in range(3):
@@ -357,10 +369,56 @@ def full_window(api, syn, ctx, iters=30):
     dt = (time.perf_counter() - t0) / iters
     out = {"n_kf": cfg["n_kf"], "n_lm": cfg["n_lm"], "blocks": {"two_camera": btc.n, "two_frame": btf.n, "pose_only": bpo.n, "imu": bimu.n if bimu else 0},
            "ms_per_lm_iteration": 1e3 * dt, "lm_iters_per_sec": 1.0 / dt, "cost_first": costs[0], "cost_last": r["cost_after"]}
-    for h in (prob, btc, btf, bpo, bimu, st):
+    for h in (prob,) + tuple(handles):
         if h is not None:
             h.close()
     return out
+
+
+def concurrent_windows(api, syn, device, n_windows=8, iters=20):
+    """N independent configs[3] windows on ONE GPU, one host thread + lvf context (own stream, own allocator) each — the shape of
+    the reference's independent-window clients (RL environments: 8 train / 100 test).  A single LM iteration is a
+    chain of small launches that leaves most of the 256 CUs idle, so windows overlap almost freely."""
+    import threading
+    gate = threading.Barrier(n_windows)
+    spans, errors = [None] * n_windows, []
+
+    def work(i):
+        try:
+            ctx = api.Context(device)
+            cfg, prob, handles = _build_window(api, syn, ctx, seed=0xC0FFEE + i)
+            opt = api.default_solver_options()
+            radius, dec = 1e4, 2.0
+            for _ in range(3):
+                r = prob.lm_iteration(opt, radius, dec); radius, dec = r["radius"], r["decrease_factor"]
+            ctx.synchronize()
+            gate.wait()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                r = prob.lm_iteration(opt, radius, dec); radius, dec = r["radius"], r["decrease_factor"]
+            ctx.synchronize()
+            spans[i] = (t0, time.perf_counter())
+            for h in (prob,) + tuple(handles):
+                if h is not None:
+                    h.close()
+            ctx.close()
+        except Exception as e:   # a failing thread must not leave the others at the barrier
+            errors.append(repr(e))
+            try:
+                gate.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(n_windows)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errors or any(s is None for s in spans):
+        return {"error": errors[:2] or "a worker did not finish"}
+    wall = max(s[1] for s in spans) - min(s[0] for s in spans)
+    return {"windows": n_windows, "iterations_each": iters, "ms_wall": 1e3 * wall, "lm_iters_per_sec_aggregate": n_windows * iters / wall,
+            "ms_per_iteration_per_window": 1e3 * wall / iters}
 
 
 def cpu_baseline(cfg, n_blocks):
