@@ -76,17 +76,26 @@ __global__ __launch_bounds__(kC) void k_cloud_transform(int n, const float4* __r
 // ---------------------------------------------------------------------------------------------- bounds
 __device__ __forceinline__ unsigned f2ord_c(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 static inline float ord2f_c(unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &u, 4); return f; }
+// capped grid + workgroup-level reduction: 6 atomics per WORKGROUP (one per wave cost 50-110 us on 100 k points, see cell_runs)
+constexpr int kCapBlocks = 256;
 __global__ __launch_bounds__(kC) void k_cloud_bounds(int n, const float4* __restrict__ pts, unsigned* __restrict__ bounds) {
-  const int i = blockIdx.x * kC + threadIdx.x;
   float x = INFINITY, y = INFINITY, z = INFINITY, X = -INFINITY, Y = -INFINITY, Z = -INFINITY;
-  if (i < n) { const float4 p = pts[i]; x = X = p.x; y = Y = p.y; z = Z = p.z; }
+  for (int i = blockIdx.x * kC + threadIdx.x; i < n; i += gridDim.x * kC) {
+    const float4 p = pts[i];
+    x = fminf(x, p.x); y = fminf(y, p.y); z = fminf(z, p.z); X = fmaxf(X, p.x); Y = fmaxf(Y, p.y); Z = fmaxf(Z, p.z);
+  }
   for (int o = 32; o > 0; o >>= 1) {
     x = fminf(x, __shfl_down(x, o)); y = fminf(y, __shfl_down(y, o)); z = fminf(z, __shfl_down(z, o));
     X = fmaxf(X, __shfl_down(X, o)); Y = fmaxf(Y, __shfl_down(Y, o)); Z = fmaxf(Z, __shfl_down(Z, o));
   }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMin(bounds + 0, f2ord_c(x)); atomicMin(bounds + 1, f2ord_c(y)); atomicMin(bounds + 2, f2ord_c(z));
-    atomicMax(bounds + 3, f2ord_c(X)); atomicMax(bounds + 4, f2ord_c(Y)); atomicMax(bounds + 5, f2ord_c(Z));
+  __shared__ float red[kC / 64][6];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w][0] = x; red[w][1] = y; red[w][2] = z; red[w][3] = X; red[w][4] = Y; red[w][5] = Z; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = red[0][threadIdx.x];
+    for (int k = 1; k < kC / 64; ++k) v = threadIdx.x < 3 ? fminf(v, red[k][threadIdx.x]) : fmaxf(v, red[k][threadIdx.x]);
+    if (threadIdx.x < 3) atomicMin(bounds + threadIdx.x, f2ord_c(v)); else atomicMax(bounds + threadIdx.x, f2ord_c(v));
   }
 }
 static int cloud_bounds(const lvf_cloud* c, float lo[3], float hi[3]) {
@@ -95,7 +104,7 @@ static int cloud_bounds(const lvf_cloud* c, float lo[3], float hi[3]) {
   const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   hipStream_t s = c->ctx->stream;
   LVF_HIP(hipMemcpyAsync(b.p, init, sizeof(init), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_cloud_bounds, dim3(gridc(c->n)), dim3(kC), 0, s, c->n, c->pts.p, b.p);
+  hipLaunchKernelGGL(k_cloud_bounds, dim3(std::min(kCapBlocks, gridc(c->n))), dim3(kC), 0, s, c->n, c->pts.p, b.p);
   unsigned h[6];
   LVF_HIP(hipMemcpyAsync(h, b.p, sizeof(h), hipMemcpyDeviceToHost, s));
   LVF_HIP(hipStreamSynchronize(s));
@@ -146,18 +155,26 @@ __device__ __forceinline__ int gcoord(float v, float o, float inv_cell, int n) {
 }
 __global__ __launch_bounds__(kC) void k_grid_count(int n, const float4* __restrict__ pts, GridC g, int* __restrict__ cell_of, int* __restrict__ counts) {
   const int i = blockIdx.x * kC + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  const int c = (gcoord(p.z, g.oz, g.inv_cell, g.nz) * g.ny + gcoord(p.y, g.oy, g.inv_cell, g.ny)) * g.nx + gcoord(p.x, g.ox, g.inv_cell, g.nx);
-  cell_of[i] = c;
-  atomicAdd(counts + c, 1);
+  int c = -1;
+  if (i < n) {
+    const float4 p = pts[i];
+    c = (gcoord(p.z, g.oz, g.inv_cell, g.nz) * g.ny + gcoord(p.y, g.oy, g.inv_cell, g.ny)) * g.nx + gcoord(p.x, g.ox, g.inv_cell, g.nx);
+    cell_of[i] = c;
+  }
+  int start, len;
+  const bool head = cell_runs(c, start, len);
+  if (head && c >= 0) atomicAdd(counts + c, len);
 }
 __global__ __launch_bounds__(kC) void k_grid_scatter(int n, const float4* __restrict__ pts, const int* __restrict__ cell_of, const int* __restrict__ cell_start,
                                                      int* __restrict__ cursor, float4* __restrict__ sorted) {
   const int i = blockIdx.x * kC + threadIdx.x;
-  if (i >= n) return;
-  const int c = cell_of[i];
-  sorted[cell_start[c] + atomicAdd(cursor + c, 1)] = pts[i];
+  const int c = (i < n) ? cell_of[i] : -1;
+  int start, len;
+  const bool head = cell_runs(c, start, len);
+  int base = 0;
+  if (head && c >= 0) base = atomicAdd(cursor + c, len);
+  base = __shfl(base, start);
+  if (c >= 0) sorted[cell_start[c] + base + ((int)(threadIdx.x & 63) - start)] = pts[i];
 }
 // neighbours within radius (squared distance < r2, the point itself included); cell size >= radius => 27 cells.
 // The count does not depend on the order points sit inside a cell, so the atomic scatter above is harmless.
@@ -167,17 +184,19 @@ __global__ __launch_bounds__(kC) void k_radius_count(int n, const float4* __rest
   if (i >= n) return;
   const float4 p = pts[i];
   const int cx = gcoord(p.x, g.ox, g.inv_cell, g.nx), cy = gcoord(p.y, g.oy, g.inv_cell, g.ny), cz = gcoord(p.z, g.oz, g.inv_cell, g.nz);
+  // only "more than min_neighbors" matters: stop at the first row that settles it (dense ground cells hold thousands of points;
+  // scanning all 27 cells to the end was 0.3-0.6 ms of the 0.95 ms filter)
   int cnt = 0;
-  for (int dz = -1; dz <= 1; ++dz) {
+  for (int dz = -1; dz <= 1 && cnt <= min_neighbors; ++dz) {
     const int z = cz + dz;
     if (z < 0 || z >= g.nz) continue;
-    for (int dy = -1; dy <= 1; ++dy) {
+    for (int dy = -1; dy <= 1 && cnt <= min_neighbors; ++dy) {
       const int y = cy + dy;
       if (y < 0 || y >= g.ny) continue;
       const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
       const int row = (z * g.ny + y) * g.nx;
       const int lo = cell_start[row + x0], hi = cell_start[row + x1 + 1];   // x-adjacent cells are contiguous
-      for (int j = lo; j < hi; ++j) {
+      for (int j = lo; j < hi && cnt <= min_neighbors; ++j) {
         const float4 q = sorted[j];
         const float dx = p.x - q.x, dyy = p.y - q.y, dzz = p.z - q.z;
         const float d = (dx * dx + dyy * dyy) + dzz * dzz;
@@ -241,29 +260,43 @@ __global__ __launch_bounds__(kC) void k_ransac_count(int n, const float4* __rest
     cnt += fabsf(d) < thr ? 1 : 0;
   }
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(counts + h, cnt);
+  __shared__ int red[kC / 64];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int k = 0; k < kC / 64; ++k) t += red[k];
+    if (t) atomicAdd(counts + h, t);          // one atomic per workgroup and hypothesis
+  }
 }
 // inliers of plane `co`: flags, and (optionally) first and second moments in double for the least-squares refit
 __global__ __launch_bounds__(kC) void k_plane_inliers(int n, const float4* __restrict__ pts, float c0, float c1, float c2, float c3, float thr,
                                                       int* __restrict__ flags, double* __restrict__ mom /* n, sx,sy,sz, xx,xy,xz,yy,yz,zz */) {
-  const int i = blockIdx.x * kC + threadIdx.x;
+  // capped grid striding over the points; the ten moments leave with one atomic per WORKGROUP each
   double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (i < n) {
+  for (int i = blockIdx.x * kC + threadIdx.x; i < n; i += gridDim.x * kC) {
     const float4 p = pts[i];
     const float d = ((c0 * p.x + c1 * p.y) + c2 * p.z) + c3;
     const int in = fabsf(d) < thr ? 1 : 0;
     flags[i] = in;
     if (in && mom) {
       const double x = p.x, y = p.y, z = p.z;
-      v[0] = 1; v[1] = x; v[2] = y; v[3] = z; v[4] = x * x; v[5] = x * y; v[6] = x * z; v[7] = y * y; v[8] = y * z; v[9] = z * z;
+      v[0] += 1; v[1] += x; v[2] += y; v[3] += z; v[4] += x * x; v[5] += x * y; v[6] += x * z; v[7] += y * y; v[8] += y * z; v[9] += z * z;
     }
   }
   if (mom) {
+    __shared__ double red[kC / 64][10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       double s = v[k];
       for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-      if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(mom + k, s);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+      double t = 0.0;
+      for (int w = 0; w < kC / 64; ++w) t += red[w][threadIdx.x];
+      if (t != 0.0) atomicAdd(mom + threadIdx.x, t);
     }
   }
 }
@@ -466,7 +499,7 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
   DevBuf<int> counts, flags; DevBuf<double> mom;
   LVF_TRY(counts.alloc(max_iterations)); LVF_TRY(flags.alloc(n)); LVF_TRY(mom.alloc(10));
   LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)4 * max_iterations, s));
-  const int gx = std::min(gridc(n), 64);
+  const int gx = std::min(gridc(n), 8);      // x 100 hypotheses = 800 workgroups, one counter atomic each
   hipLaunchKernelGGL(k_ransac_count, dim3(gx, max_iterations), dim3(kC), 0, s, n, in->pts.p, (unsigned long long)seed, distance_threshold, counts.p);
   LVF_HIP(hipGetLastError());
   std::vector<int> hc(max_iterations);
@@ -505,7 +538,7 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
   }
   // optimizeModelCoefficients: least-squares plane through the inliers, then re-select (SACSegmentation::segment)
   LVF_HIP(hipMemsetAsync(mom.p, 0, 80, s));
-  hipLaunchKernelGGL(k_plane_inliers, dim3(gridc(n)), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, mom.p);
+  hipLaunchKernelGGL(k_plane_inliers, dim3(std::min(kCapBlocks, gridc(n))), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, mom.p);
   LVF_HIP(hipGetLastError());
   double m[10];
   LVF_HIP(hipMemcpyAsync(m, mom.p, sizeof(m), hipMemcpyDeviceToHost, s));
@@ -518,7 +551,7 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
     smallest_eigvec3(C, nv);
     if (nv[2] < 0.0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }       // fixed orientation (inlier selection is sign-free)
     co[0] = (float)nv[0]; co[1] = (float)nv[1]; co[2] = (float)nv[2]; co[3] = (float)(-(nv[0] * cx + nv[1] * cy + nv[2] * cz));
-    hipLaunchKernelGGL(k_plane_inliers, dim3(gridc(n)), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, (double*)nullptr);
+    hipLaunchKernelGGL(k_plane_inliers, dim3(std::min(kCapBlocks, gridc(n))), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, (double*)nullptr);
     LVF_HIP(hipGetLastError());
   }
   if (coefficients4) for (int q = 0; q < 4; ++q) coefficients4[q] = co[q];

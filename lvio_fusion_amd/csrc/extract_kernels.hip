@@ -137,12 +137,35 @@ __global__ __launch_bounds__(kE) void k_ex_union(int npix, const float* __restri
     if (parent[down] >= 0 && linked(ra, range[down], P.sin_ay, P.cos_ay, P.theta)) uf_unite(parent, idx, down);
   }
 }
+// segment size and the 64-bit mask of rows its pixels (other than the seed) lie in.  A wave holds 64 consecutive pixels of one
+// or two image rows and neighbouring pixels mostly share their segment, so the root's counters are touched once per run of
+// same-root lanes (cell_runs): per-pixel atomics on the few large segments' roots cost 138 us per scan.
 __global__ __launch_bounds__(kE) void k_ex_stats(int npix, int Cn, int* __restrict__ parent, int* __restrict__ size, unsigned long long* __restrict__ rows) {
   const int idx = blockIdx.x * kE + threadIdx.x;
-  if (idx >= npix || parent[idx] < 0) return;
-  const int root = uf_find(parent, idx);
-  atomicAdd(size + root, 1);
-  if (idx != root) atomicOr(rows + root, 1ull << (idx / Cn));           // line_count_flag: rows of every pixel but the seed
+  const bool live = idx < npix && parent[idx] >= 0;
+  const int root = live ? uf_find(parent, idx) : -1;
+  if (Cn < 64) {                     // a wave could span more than two rows: plain per-pixel counters
+    if (live) { atomicAdd(size + root, 1); if (idx != root) atomicOr(rows + root, 1ull << (idx / Cn)); }
+    return;
+  }
+  int start, len;
+  const bool head = cell_runs(root, start, len);
+  // row bits of the run: every lane contributes its own row unless it is the seed pixel itself
+  const unsigned long long mine = (live && idx != root) ? (1ull << (idx / Cn)) : 0ull;
+  // a run spans at most two rows: OR of the first and last contributing lanes' bits is not enough when the seed sits at either
+  // end, so take the OR over the whole run with two ballots (one per possible row)
+  const int row0 = (blockIdx.x * kE + (threadIdx.x & ~63)) / Cn;           // row of the wave's first pixel
+  const unsigned long long in_r0 = __ballot(mine != 0ull && idx / Cn == row0);
+  const unsigned long long in_r1 = __ballot(mine != 0ull && idx / Cn == row0 + 1);
+  if (head && root >= 0) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long run = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << lane;
+    atomicAdd(size + root, len);
+    unsigned long long bits = 0ull;
+    if (in_r0 & run) bits |= 1ull << row0;
+    if (in_r1 & run) bits |= 1ull << (row0 + 1);
+    if (bits) atomicOr(rows + root, bits);
+  }
 }
 __global__ __launch_bounds__(kE) void k_ex_segflag(int npix, const int* __restrict__ parent, const int* __restrict__ size, const unsigned long long* __restrict__ rows,
                                                    const signed char* __restrict__ ground, int* __restrict__ flags, int* __restrict__ label) {

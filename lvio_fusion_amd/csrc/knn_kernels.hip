@@ -70,21 +70,6 @@ __global__ __launch_bounds__(kB) void k_pack_bounds(int M, const float* __restri
   }
 }
 
-// runs of consecutive lanes that fall into the same cell (clouds arrive in scan order, so a coarse cell sees long runs): only
-// the head lane of a run touches the cell's counter, with the run length.  `start` = head lane of this lane's run, `len` = run
-// length (meaningful on head lanes).
-__device__ __forceinline__ bool cell_runs(int c, int& start, int& len) {
-  const int lane = threadIdx.x & 63;
-  const int prev = __shfl_up(c, 1);
-  const bool head = lane == 0 || c != prev;
-  const unsigned long long hm = __ballot(head);
-  const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-  start = 63 - __clzll((long long)(hm & upto));
-  const unsigned long long above = hm & ~upto;
-  len = (above ? __ffsll((long long)above) - 1 : 64) - lane;
-  return head;
-}
-
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_cell, int n) {
   int c = (int)floorf((v - o) * inv_cell);
   return c < 0 ? 0 : (c >= n ? n - 1 : c);

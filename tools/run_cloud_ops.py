@@ -1,0 +1,10 @@
+"""Runs the map-maintenance leg of the bench N times (for rocprofv3)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from lvio_fusion_amd import api, synthetic as syn
+ctx = api.Context(0)
+c3 = syn.config3_icp()
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
+    out = bench.map_maintenance(api, ctx, c3)
+print(out)
