@@ -28,6 +28,7 @@ struct IcpDev {
   double cost_cur, initial_cost, model;
   double rpyxyz[6];
   int done, iters, successes, nvalid, first;
+  unsigned ticket;           // workgroups that have finished the running k_icp_eval (the last one does the scalar tail)
 };
 
 struct IcpArgs {
@@ -61,6 +62,83 @@ __global__ __launch_bounds__(kTI) void k_icp_build(int Q, const float4* __restri
   const unsigned long long m = __ballot(ok);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(&dev->nvalid, __popcll(m));
 }
+
+// the sums other workgroups added with L2 atomics, read past this CU's L1
+__device__ __forceinline__ double fresh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double clampd(double v) { return fmin(fmax(v, 1e-6), 1e32); }
+
+// 3x3 damped normal equations; PoseErrorRPZ / PoseErrorYXY prior (pose_error.hpp:135-190): residual_k = w (x_k - x0_k)
+__device__ void icp_step(const IcpArgs& args, IcpDev* dev) {
+  if (dev->done) return;
+  const double w2 = args.prior_w * args.prior_w;
+  double H[6], g[3];
+  for (int q = 0; q < 6; ++q) H[q] = fresh(&dev->acc[q]);
+  for (int q = 0; q < 3; ++q) g[q] = fresh(&dev->acc[6 + q]);
+  double cost = fresh(&dev->acc[9]);
+  if (args.prior_w > 0.0) {
+    H[0] += w2; H[2] += w2; H[5] += w2;
+    for (int q = 0; q < 3; ++q) { const double dxp = dev->x[q] - dev->x0[q]; g[q] += w2 * dxp; cost += 0.5 * w2 * dxp * dxp; }
+  }
+  dev->cost_cur = cost;
+  if (dev->first) { dev->initial_cost = cost; dev->first = 0; }
+  const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+  if (gmax <= args.gradient_tolerance) { dev->done = 1; return; }
+  const double inv_r = 1.0 / dev->radius;
+  const double D0 = clampd(H[0]) * inv_r, D1 = clampd(H[2]) * inv_r, D2 = clampd(H[5]) * inv_r;
+  // Cholesky of [[a00,.,.],[a10,a11,.],[a20,a21,a22]]
+  const double a00 = H[0] + D0, a10 = H[1], a11 = H[2] + D1, a20 = H[3], a21 = H[4], a22 = H[5] + D2;
+  const double l00 = sqrt(a00), l10 = a10 / l00, l20 = a20 / l00;
+  const double t11 = a11 - l10 * l10;
+  const double l11 = sqrt(t11), l21 = (a21 - l20 * l10) / l11;
+  const double t22 = a22 - l20 * l20 - l21 * l21;
+  const double l22 = sqrt(t22);
+  bool ok = a00 > 0.0 && t11 > 0.0 && t22 > 0.0;
+  double dx[3] = {0, 0, 0};
+  if (ok) {
+    const double y0 = -g[0] / l00, y1 = (-g[1] - l10 * y0) / l11, y2 = (-g[2] - l20 * y0 - l21 * y1) / l22;
+    dx[2] = y2 / l22; dx[1] = (y1 - l21 * dx[2]) / l11; dx[0] = (y0 - l10 * dx[1] - l20 * dx[2]) / l00;
+    ok = isfinite(dx[0]) && isfinite(dx[1]) && isfinite(dx[2]);
+  }
+  dev->model = ok ? 0.5 * (dx[0] * (D0 * dx[0] - g[0]) + dx[1] * (D1 * dx[1] - g[1]) + dx[2] * (D2 * dx[2] - g[2])) : -1.0;
+  for (int q = 0; q < 3; ++q) dev->xc[q] = dev->x[q] + dx[q];
+  dev->cost_cand = 0.0;
+  const double dn = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+  const double xn = sqrt(dev->x[0] * dev->x[0] + dev->x[1] * dev->x[1] + dev->x[2] * dev->x[2]);
+  if (ok && dn <= args.parameter_tolerance * (xn + args.parameter_tolerance)) dev->done = 1;
+}
+
+__device__ void icp_decide(const IcpArgs& args, IcpDev* dev) {
+  if (dev->done) return;
+  double cand = fresh(&dev->cost_cand);
+  if (args.prior_w > 0.0) {
+    const double w2 = args.prior_w * args.prior_w;
+    for (int q = 0; q < 3; ++q) { const double dxp = dev->xc[q] - dev->x0[q]; cand += 0.5 * w2 * dxp * dxp; }
+  }
+  dev->iters += 1;
+  bool accepted = false;
+  if (dev->model > 0.0 && isfinite(cand)) {
+    const double rho = (dev->cost_cur - cand) / dev->model;
+    if (rho > args.min_relative_decrease) {
+      accepted = true;
+      const double change = dev->cost_cur - cand;
+      const double before = dev->cost_cur;
+      for (int q = 0; q < 3; ++q) dev->x[q] = dev->xc[q];
+      dev->cost_cur = cand;
+      dev->successes += 1;
+      const double t = 2.0 * rho - 1.0;
+      dev->radius = fmin(dev->radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
+      dev->decrease = 2.0;
+      if (fabs(change) <= args.function_tolerance * fabs(before)) dev->done = 1;
+    }
+  }
+  if (!accepted) { dev->radius = dev->radius / dev->decrease; dev->decrease *= 2.0; if (dev->radius < 1e-32) dev->done = 1; }
+  if (dev->iters >= args.max_iters) dev->done = 1;
+  for (int q = 0; q < 10; ++q) dev->acc[q] = 0.0;
+}
+
+// stand-alone forms (problems with no correspondences never launch k_icp_eval)
+__global__ void k_icp_step(const IcpArgs args, IcpDev* dev) { icp_step(args, dev); }
+__global__ void k_icp_decide(const IcpArgs args, IcpDev* dev) { icp_decide(args, dev); }
 
 template <bool WITH_J>
 __global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restrict__ P, const double* __restrict__ PA,
@@ -115,77 +193,18 @@ __global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restric
     for (int w2 = 0; w2 < kTI / 64; ++w2) s += s_part[w2][threadIdx.x];
     if (s != 0.0) atomicAdd(WITH_J ? &dev->acc[threadIdx.x] : &dev->cost_cand, s);
   }
-}
-
-__device__ __forceinline__ double clampd(double v) { return fmin(fmax(v, 1e-6), 1e32); }
-
-// 3x3 damped normal equations; PoseErrorRPZ / PoseErrorYXY prior (pose_error.hpp:135-190): residual_k = w (x_k - x0_k)
-__global__ void k_icp_step(const IcpArgs args, IcpDev* __restrict__ dev) {
-  if (dev->done) return;
-  const double w2 = args.prior_w * args.prior_w;
-  double H[6], g[3];
-  for (int q = 0; q < 6; ++q) H[q] = dev->acc[q];
-  for (int q = 0; q < 3; ++q) g[q] = dev->acc[6 + q];
-  double cost = dev->acc[9];
-  if (args.prior_w > 0.0) {
-    H[0] += w2; H[2] += w2; H[5] += w2;
-    for (int q = 0; q < 3; ++q) { const double dxp = dev->x[q] - dev->x0[q]; g[q] += w2 * dxp; cost += 0.5 * w2 * dxp * dxp; }
-  }
-  dev->cost_cur = cost;
-  if (dev->first) { dev->initial_cost = cost; dev->first = 0; }
-  const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
-  if (gmax <= args.gradient_tolerance) { dev->done = 1; return; }
-  const double inv_r = 1.0 / dev->radius;
-  const double D0 = clampd(H[0]) * inv_r, D1 = clampd(H[2]) * inv_r, D2 = clampd(H[5]) * inv_r;
-  // Cholesky of [[a00,.,.],[a10,a11,.],[a20,a21,a22]]
-  const double a00 = H[0] + D0, a10 = H[1], a11 = H[2] + D1, a20 = H[3], a21 = H[4], a22 = H[5] + D2;
-  const double l00 = sqrt(a00), l10 = a10 / l00, l20 = a20 / l00;
-  const double t11 = a11 - l10 * l10;
-  const double l11 = sqrt(t11), l21 = (a21 - l20 * l10) / l11;
-  const double t22 = a22 - l20 * l20 - l21 * l21;
-  const double l22 = sqrt(t22);
-  bool ok = a00 > 0.0 && t11 > 0.0 && t22 > 0.0;
-  double dx[3] = {0, 0, 0};
-  if (ok) {
-    const double y0 = -g[0] / l00, y1 = (-g[1] - l10 * y0) / l11, y2 = (-g[2] - l20 * y0 - l21 * y1) / l22;
-    dx[2] = y2 / l22; dx[1] = (y1 - l21 * dx[2]) / l11; dx[0] = (y0 - l10 * dx[1] - l20 * dx[2]) / l00;
-    ok = isfinite(dx[0]) && isfinite(dx[1]) && isfinite(dx[2]);
-  }
-  dev->model = ok ? 0.5 * (dx[0] * (D0 * dx[0] - g[0]) + dx[1] * (D1 * dx[1] - g[1]) + dx[2] * (D2 * dx[2] - g[2])) : -1.0;
-  for (int q = 0; q < 3; ++q) dev->xc[q] = dev->x[q] + dx[q];
-  dev->cost_cand = 0.0;
-  const double dn = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
-  const double xn = sqrt(dev->x[0] * dev->x[0] + dev->x[1] * dev->x[1] + dev->x[2] * dev->x[2]);
-  if (ok && dn <= args.parameter_tolerance * (xn + args.parameter_tolerance)) dev->done = 1;
-}
-
-__global__ void k_icp_decide(const IcpArgs args, IcpDev* __restrict__ dev) {
-  if (dev->done) return;
-  double cand = dev->cost_cand;
-  if (args.prior_w > 0.0) {
-    const double w2 = args.prior_w * args.prior_w;
-    for (int q = 0; q < 3; ++q) { const double dxp = dev->xc[q] - dev->x0[q]; cand += 0.5 * w2 * dxp * dxp; }
-  }
-  dev->iters += 1;
-  bool accepted = false;
-  if (dev->model > 0.0 && isfinite(cand)) {
-    const double rho = (dev->cost_cur - cand) / dev->model;
-    if (rho > args.min_relative_decrease) {
-      accepted = true;
-      const double change = dev->cost_cur - cand;
-      const double before = dev->cost_cur;
-      for (int q = 0; q < 3; ++q) dev->x[q] = dev->xc[q];
-      dev->cost_cur = cand;
-      dev->successes += 1;
-      const double t = 2.0 * rho - 1.0;
-      dev->radius = fmin(dev->radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
-      dev->decrease = 2.0;
-      if (fabs(change) <= args.function_tolerance * fabs(before)) dev->done = 1;
+  // the LAST workgroup to get here runs the scalar tail of the phase (3x3 damped solve after the J pass, accept/reject after the
+  // cost pass): two launches per LM iteration instead of four
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned t = atomicAdd(&dev->ticket, 1u);
+    if (t == gridDim.x - 1) {
+      __threadfence();
+      dev->ticket = 0;
+      if (WITH_J) icp_step(args, dev); else icp_decide(args, dev);
     }
   }
-  if (!accepted) { dev->radius = dev->radius / dev->decrease; dev->decrease *= 2.0; if (dev->radius < 1e-32) dev->done = 1; }
-  if (dev->iters >= args.max_iters) dev->done = 1;
-  for (int q = 0; q < 10; ++q) dev->acc[q] = 0.0;
 }
 
 }  // namespace lvf
@@ -212,10 +231,10 @@ static int run_lm(hipStream_t q, int Q, const double* P, const double* PA, const
   const int grid = std::min((std::max(Q, 1) + kTI - 1) / kTI, kIcpMaxBlocks);
   for (int it = 0; it < std::max(1, a.max_iters); ++it) {
     if (Q > 0) hipLaunchKernelGGL(k_icp_eval<true>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, valid, a, dev);
-    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1), 0, q, a, dev);
+    else hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1), 0, q, a, dev);
     if (a.max_iters == 0) break;
     if (Q > 0) hipLaunchKernelGGL(k_icp_eval<false>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, valid, a, dev);
-    hipLaunchKernelGGL(k_icp_decide, dim3(1), dim3(1), 0, q, a, dev);
+    else hipLaunchKernelGGL(k_icp_decide, dim3(1), dim3(1), 0, q, a, dev);
   }
   LVF_HIP(hipGetLastError());
   LVF_HIP(hipMemcpyAsync(host_out, dev, sizeof(IcpDev), hipMemcpyDeviceToHost, q));
