@@ -884,9 +884,13 @@ __device__ __forceinline__ void store_row64(double* __restrict__ g, const double
 // Panel: 4 adjacent lanes share one row of X (lane `part` holds x_t, t = 4 tt + part): the dot product of the forward
 // substitution is split 4 ways and combined with two quad shuffles, so a 64-step solve costs ~64 x (j/4 FMAs + shuffle).
 // the per-wave body of the diagonal-block factorisation; Q (the wave's column group) is a template parameter so that
-// every "is column t right of j" test folds at compile time and each wave only carries its own FMAs
+// every "is column t right of j" test folds at compile time and each wave only carries its own FMAs.
+// The workgroup's PANEL row rides along in the same sweep (b[16] = row r of the panel block, same column group): once column j of
+// L is published, x_rj = b_rj / L_jj is final and the row's later columns take the same rank-1 update with the same 16 broadcast
+// values the diagonal block reads anyway.  The separate 64-step forward substitution (9.3 us of dependent LDS round trips per
+// block step, after a 12.6 us factorisation) is gone; the sweep pays one more LDS write, one more read and 16 more FMAs per pivot.
 template <int Q>
-__device__ __forceinline__ bool factor_columns(double a[16], int r, double (*col)[kNB], double* dinv) {
+__device__ __forceinline__ bool factor_solve_columns(double a[16], double b[16], int r, double (*col)[kNB], double (*col2)[kNB]) {
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < kNB; ++j) {
@@ -896,90 +900,70 @@ __device__ __forceinline__ bool factor_columns(double a[16], int r, double (*col
       bad |= !(djj > 0.0);
       const double inv_l = rsqrt(fmax(djj, 1e-300));
       a[jj] = (r == j) ? djj * inv_l : a[jj] * inv_l;
+      b[jj] *= inv_l;
       col[buf][r] = a[jj];
-      if (r == j) dinv[j] = inv_l;
+      col2[buf][r] = b[jj];
     }
     __syncthreads();
     if (16 * Q + 15 > j) {
-      const double cr = col[buf][r];
+      const double cr = col[buf][r], cr2 = col2[buf][r];
 #pragma unroll
       for (int tt = 0; tt < 16; ++tt)
-        if (16 * Q + tt > j) a[tt] -= cr * col[buf][16 * Q + tt];   // A_rt -= L_rj L_tj (meaningful for r >= t)
+        if (16 * Q + tt > j) {
+          const double l = col[buf][16 * Q + tt];
+          a[tt] -= cr * l;                            // A_rt -= L_rj L_tj (meaningful for r >= t)
+          b[tt] -= cr2 * l;                           // panel row: X_rt's running right-hand side
+        }
     }
   }
   return bad;
 }
 
+// grid = 2 + (block rows below kb): workgroup 0 stores the factored diagonal block; workgroups 1..below solve their panel block
+// X L^T = A; the last workgroup solves against the identity and leaves L_kk^-T for the back substitution.
 __global__ __launch_bounds__(256) void k_chol_factor_panel(double* S, int ld, int kb, int* __restrict__ fail, double* __restrict__ Dinv) {
-  __shared__ double Lk[kNB * kLd];     // factored diagonal block, row-major padded, zero above the diagonal
   __shared__ double col[2][kNB];
-  __shared__ double dinv[kNB];         // 1 / L_jj
+  __shared__ double col2[2][kNB];
   const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
-  double a[16];
+  double a[16], b[16];
   {
     const double2* g2 = reinterpret_cast<const double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
 #pragma unroll
     for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; a[2 * c] = v.x; a[2 * c + 1] = v.y; }
   }
-  // this workgroup's panel row (or identity row) is requested now and arrives during the factorisation
-  const int row = tid >> 2, part = tid & 3;
   const bool inverse_wg = blockIdx.x == gridDim.x - 1;
-  double* arow = inverse_wg ? Dinv + (size_t)kb * kNB * kNB + (size_t)row * kNB : S + (size_t)((kb + blockIdx.x) * kNB + row) * ld + kb * kNB;
-  double x[16];
-  if (blockIdx.x != 0) {
+  double* brow = inverse_wg ? Dinv + (size_t)kb * kNB * kNB + (size_t)r * kNB + 16 * q
+                            : S + (size_t)((kb + blockIdx.x) * kNB + r) * ld + kb * kNB + 16 * q;
+  if (blockIdx.x == 0) {
 #pragma unroll
-    for (int tt = 0; tt < 16; ++tt) x[tt] = inverse_wg ? ((4 * tt + part == row) ? 1.0 : 0.0) : arow[4 * tt + part];
+    for (int c = 0; c < 16; ++c) b[c] = 0.0;
+  } else if (inverse_wg) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) b[c] = (16 * q + c == r) ? 1.0 : 0.0;
+  } else {
+    const double2* g2 = reinterpret_cast<const double2*>(brow);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; b[2 * c] = v.x; b[2 * c + 1] = v.y; }
   }
   bool bad;
   switch (q) {                                       // wave-uniform dispatch
-    case 0: bad = factor_columns<0>(a, r, col, dinv); break;
-    case 1: bad = factor_columns<1>(a, r, col, dinv); break;
-    case 2: bad = factor_columns<2>(a, r, col, dinv); break;
-    default: bad = factor_columns<3>(a, r, col, dinv); break;
+    case 0: bad = factor_solve_columns<0>(a, b, r, col, col2); break;
+    case 1: bad = factor_solve_columns<1>(a, b, r, col, col2); break;
+    case 2: bad = factor_solve_columns<2>(a, b, r, col, col2); break;
+    default: bad = factor_solve_columns<3>(a, b, r, col, col2); break;
   }
   if (bad && r == 0) atomicExch(fail, 1 + kb);
-#pragma unroll
-  for (int tt = 0; tt < 16; ++tt) {
-    const int c = 16 * q + tt;
-    if (c > r) a[tt] = 0.0;
-    Lk[r * kLd + c] = a[tt];
-  }
-  __syncthreads();
   if (blockIdx.x == 0) {
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) if (16 * q + tt > r) a[tt] = 0.0;
     double2* g2 = reinterpret_cast<double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
 #pragma unroll
     for (int c = 0; c < 8; ++c) g2[c] = make_double2(a[2 * c], a[2 * c + 1]);
     return;
   }
-  // panel block (kb + blockIdx.x, kb): X L^T = A.  The LAST workgroup solves against the identity instead: X = L_kk^-T, the
-  // block's inverse factor for the back substitution (runs beside the panel blocks, costs no wall time).
-  // Forward substitution along the row, software-pipelined: D_j = sum_{t<j} x_t L[j][t] is split into P_j (terms t < j-1, which
-  // only need x up to j-2 and are accumulated while step j-1 is still resolving) and the single term x_{j-1} L[j][j-1].  The
-  // dependent chain per step is then one FMA, the quad reduction and the scale.  In-kernel timers: the 64-step solve went
-  // 11.2 us -> 11.2 us with the pipelining alone and -> 9.3 us once the quad reduction left the ds_bpermute path (quad_sum).
-  double P = 0.0;
+  double2* g2 = reinterpret_cast<double2*>(brow);
 #pragma unroll
-  for (int j = 0; j < kNB; ++j) {
-    const int jt = j >> 2, pj = j & 3;
-    double q = P;
-    if (j > 0) q += (part == ((j - 1) & 3)) ? x[(j - 1) >> 2] * Lk[j * kLd + (j - 1)] : 0.0;
-    q = quad_sum(q);
-    // off the chain: P_{j+1} = sum_{t<j} x_t L[j+1][t]   (t = 4 tt + part; two accumulators keep its own chain short)
-    double p0 = 0.0, p1 = 0.0;
-    if (j + 1 < kNB) {
-      const double* Ln = Lk + (j + 1) * kLd;
-#pragma unroll
-      for (int tt = 0; tt < jt; ++tt) { if (tt & 1) p1 += x[tt] * Ln[4 * tt + part]; else p0 += x[tt] * Ln[4 * tt + part]; }
-      if (pj > 0) p1 += (part < pj) ? x[jt] * Ln[4 * jt + part] : 0.0;
-    }
-    if (part == pj) x[jt] = (x[jt] - q) * dinv[j];
-    P = p0 + p1;
-    // opaque to the optimiser on purpose: with P carried across the 64 unrolled steps every x_j is reachable from every earlier
-    // one along exponentially many paths and an LLVM analysis walks them all (compile time > 25 min instead of 2 s)
-    asm volatile("" : "+v"(P));
-  }
-#pragma unroll
-  for (int tt = 0; tt < 16; ++tt) arow[4 * tt + part] = x[tt];
+  for (int c = 0; c < 8; ++c) g2[c] = make_double2(b[2 * c], b[2 * c + 1]);
 }
 
 // trailing update: A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi.  One workgroup per 64x64 tile; both 64x64 panels are
