@@ -186,7 +186,8 @@ int lvf_scan_destroy(lvf_scan* s);
 int lvf_knn3(lvf_map* m, lvf_scan* s, const double* pose, float thr);
 int lvf_scan_download(lvf_scan* s, int32_t* idx3, float* d2_3, uint8_t* valid);
 /* Diagnostic only: per-point search statistics stats4[Q][4] = {candidates, range lookups, last grid level, shells}
- * and the grid pyramid levels4[L][4] = {cell, nx, ny, nz}. */
+ * and the grid pyramid levels4[L][4] = {cell, nx, ny, nz}; the caller provides room for 8 levels (the pyramid halves the cell
+ * per level, at most 8 levels). */
 int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* s, const double* pose, float thr, int32_t* stats4, float* levels4,
                          int* n_levels);
 

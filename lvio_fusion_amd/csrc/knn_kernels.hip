@@ -355,14 +355,17 @@ __global__ __launch_bounds__(kB) void k_knn3(int Q, const float4* __restrict__ s
   int bi[3] = {-1, -1, -1};
   KnnStats st{0, 0, 0, 0};
   KnnStats* stp = STATS ? &st : nullptr;
-  // fine -> coarse: two shells per level; dense neighbourhoods finish in the finest grid, sparse ones escalate to a
-  // grid whose cells are 4x larger instead of walking dozens of empty fine shells.  Re-visited points are rejected
-  // by best3_push (same index), so levels can overlap freely.
+  // fine -> coarse: shells 0..1 of the finest grid, shells 0..2 of every coarser one; dense neighbourhoods finish in the
+  // finest grid, sparse ones escalate to a grid whose cells are 2x larger instead of walking dozens of empty fine shells.
+  // Re-visited points are rejected by best3_push (same index), so levels can overlap freely.  Measured at configs[2]
+  // (ground / surf gate): pyramid ratio 4 with 2 shells per level 626 / 657 Mpairs/s; ratio 2: 756 / 849; ratio 2 with one shell pair
+  // per level 706 / 999; ratio 2 with this schedule 755 / 952.  (Choosing the starting level from the occupancy of the query's
+  // own cell at every level — one more round trip — was slower: 463 / 748.)
   for (int lv = 0; lv < L.n; ++lv) {
     const LevelP& lev = L.l[lv];
     const GridP& g = lev.g;
     const int cx = cell_coord(qx, g.ox, g.inv_cell, g.nx), cy = cell_coord(qy, g.oy, g.inv_cell, g.ny), cz = cell_coord(qz, g.oz, g.inv_cell, g.nz);
-    const int rcap = (lv == L.n - 1) ? max(g.nx, max(g.ny, g.nz)) : 2;
+    const int rcap = (lv == L.n - 1) ? max(g.nx, max(g.ny, g.nz)) : (lv == 0 ? 1 : 2);
     bool done = false;
     for (int r = 0; r <= rcap; ++r) {
       const float m = scan_shell(lev, cx, cy, cz, r, g_lane, qx, qy, qz, bd, bi, stp);
@@ -493,8 +496,8 @@ static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_devic
     double occ = 0.0;
     if ((rc = build_level(m, built[nb], cell, lo, hi, &occ)) != LVF_OK) return fail(rc);
     ++nb;
-    if (occ <= kTargetOcc || nb == LVF_MAX_GRID_LEVELS || ncells_for(cell * 0.25f) > kMaxCells) break;
-    cell *= 0.25f;
+    if (occ <= kTargetOcc || nb == LVF_MAX_GRID_LEVELS || ncells_for(cell * 0.5f) > kMaxCells) break;
+    cell *= 0.5f;
   }
   m->n_levels = nb;
   for (int k = 0; k < nb; ++k) m->levels[k] = std::move(built[nb - 1 - k]);   // finest first

@@ -207,7 +207,7 @@ struct lvf_batch {
   lvf::DevBuf<double> jac[8];
 };
 
-#define LVF_MAX_GRID_LEVELS 4
+#define LVF_MAX_GRID_LEVELS 8
 struct lvf_map {
   struct Level {
     lvf::DevBuf<float4> sorted;      // cell-sorted points, .w = bitcast original index
