@@ -89,21 +89,8 @@ __global__ __launch_bounds__(kB) void k_cell_count(int M, const float4* __restri
   if (head && c >= 0) atomicAdd(counts + c, len);
 }
 
-// sum over cells of count^2: (that sum / M) is the population of the cell a random map point lives in, i.e. the
-// candidates a query in a typical (point-weighted) place has to scan per cell.
-__global__ __launch_bounds__(kB) void k_cell_stats(int n, const int* __restrict__ counts, unsigned long long* __restrict__ sumsq) {
-  unsigned long long v = 0;
-  for (int i = blockIdx.x * kB + threadIdx.x; i < n; i += gridDim.x * kB) { const unsigned long long c = (unsigned long long)counts[i]; v += c * c; }
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-  __shared__ unsigned long long red[kB / 64];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long t = 0;
-    for (int k = 0; k < kB / 64; ++k) t += red[k];
-    if (t) atomicAdd(sumsq, t);
-  }
-}
+// (sum over cells of count^2) / M is the population of the cell a random map point lives in, i.e. the candidates a query in a
+// typical (point-weighted) place has to scan per cell; it is produced by the scan passes below.
 
 // 3-phase exclusive scan over `n` ints, 1024 elements per workgroup
 constexpr int kScanT = 256, kScanE = 4, kScanChunk = kScanT * kScanE;
@@ -120,17 +107,39 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* s_warp, int& tot
   total = tot;
   return base + x - v;
 }
-__global__ __launch_bounds__(kScanT) void k_scan_reduce(int n, const int* __restrict__ in, int* __restrict__ block_sums) {
+// block_sq (optional): per-workgroup sum of squares of the inputs — the grid build's occupancy statistic rides along the pass
+// that reads every count anyway (it used to be its own kernel with a same-address atomic per workgroup)
+__global__ __launch_bounds__(kScanT) void k_scan_reduce(int n, const int* __restrict__ in, int* __restrict__ block_sums,
+                                                        unsigned long long* __restrict__ block_sq) {
   __shared__ int s_warp[kScanT / 64];
+  __shared__ unsigned long long s_sq[kScanT / 64];
   const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanE;
   int v = 0;
-  for (int e = 0; e < kScanE; ++e) if (base + e < n) v += in[base + e];
+  unsigned long long sq = 0;
+  for (int e = 0; e < kScanE; ++e) if (base + e < n) { const int c = in[base + e]; v += c; sq += (unsigned long long)c * (unsigned long long)c; }
   int total;
   (void)block_exclusive_scan(v, s_warp, total);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+  if (block_sq) {
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o);
+    if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < kScanT / 64; ++k) t += s_sq[k]; block_sq[blockIdx.x] = t; }
+  }
 }
-__global__ __launch_bounds__(kScanT) void k_scan_sums(int nb, int* __restrict__ block_sums, int* __restrict__ grand_total) {
+__global__ __launch_bounds__(kScanT) void k_scan_sums(int nb, int* __restrict__ block_sums, int* __restrict__ grand_total,
+                                                      const unsigned long long* __restrict__ block_sq, unsigned long long* __restrict__ sq_total) {
   __shared__ int s_warp[kScanT / 64];
+  if (block_sq) {                                  // total of the per-workgroup square sums
+    __shared__ unsigned long long s_sq[kScanT / 64];
+    unsigned long long sq = 0;
+    for (int i = threadIdx.x; i < nb; i += kScanT) sq += block_sq[i];
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o);
+    if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < kScanT / 64; ++k) t += s_sq[k]; *sq_total = t; }
+    __syncthreads();
+  }
   int carry = 0;
   for (int start = 0; start < nb; start += kScanT) {
     const int i = start + threadIdx.x;
@@ -142,8 +151,9 @@ __global__ __launch_bounds__(kScanT) void k_scan_sums(int nb, int* __restrict__ 
   }
   if (threadIdx.x == 0) *grand_total = carry;
 }
-__global__ __launch_bounds__(kScanT) void k_scan_apply(int n, const int* __restrict__ in, const int* __restrict__ block_sums,
-                                                       int* __restrict__ out) {
+// clear_in: zero the input after reading it (the grid build re-uses the count array as the scatter cursor)
+__global__ __launch_bounds__(kScanT) void k_scan_apply(int n, int* in, const int* __restrict__ block_sums,
+                                                       int* __restrict__ out, int clear_in) {
   __shared__ int s_warp[kScanT / 64];
   const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanE;
   int e_v[kScanE];
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(kScanT) void k_scan_apply(int n, const int* __restr
   for (int e = 0; e < kScanE; ++e) { e_v[e] = (base + e < n) ? in[base + e] : 0; v += e_v[e]; }
   int total;
   int run = block_sums[blockIdx.x] + block_exclusive_scan(v, s_warp, total);
-  for (int e = 0; e < kScanE; ++e) { if (base + e < n) out[base + e] = run; run += e_v[e]; }
+  for (int e = 0; e < kScanE; ++e) { if (base + e < n) { out[base + e] = run; if (clear_in) in[base + e] = 0; } run += e_v[e]; }
 }
 
 __global__ __launch_bounds__(kB) void k_cell_scatter(int M, const float4* __restrict__ pts, const int* __restrict__ cell_of,
@@ -397,9 +407,9 @@ int device_exclusive_scan_i32(lvf_ctx* ctx, const int* in, int n, int* out) {
   const int nb = (n + kScanChunk - 1) / kScanChunk;
   DevBuf<int> bsums;
   LVF_TRY(bsums.alloc(nb));
-  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanT), 0, s, n, in, bsums.p);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, out + n);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, n, in, bsums.p, out);
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanT), 0, s, n, in, bsums.p, (unsigned long long*)nullptr);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, out + n, (const unsigned long long*)nullptr, (unsigned long long*)nullptr);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, n, const_cast<int*>(in), bsums.p, out, 0);
   LVF_HIP(hipGetLastError());
   LVF_HIP(hipStreamSynchronize(s));   // bsums is freed on return
   return LVF_OK;
@@ -423,21 +433,18 @@ static int build_level(lvf_map* m, lvf_map::Level& lv, float cell, const float l
   const int ncells = lv.nx * lv.ny * lv.nz;
   const GridP g{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz};
   const int gridM = (M + kB - 1) / kB, nb = (ncells + kScanChunk - 1) / kScanChunk;
-  DevBuf<int> cell_of, counts, cursor, bsums, total;
-  DevBuf<unsigned long long> sumsq;
-  LVF_TRY(cell_of.alloc(M)); LVF_TRY(counts.alloc(ncells)); LVF_TRY(cursor.alloc(ncells)); LVF_TRY(bsums.alloc(nb));
-  LVF_TRY(total.alloc(2)); LVF_TRY(sumsq.alloc(1)); LVF_TRY(lv.cell_start.alloc((size_t)ncells + 1)); LVF_TRY(lv.sorted.alloc(M));
+  DevBuf<int> cell_of, counts, bsums;
+  DevBuf<unsigned long long> bsq, sumsq;
+  LVF_TRY(cell_of.alloc(M)); LVF_TRY(counts.alloc(ncells)); LVF_TRY(bsums.alloc(nb)); LVF_TRY(bsq.alloc(nb));
+  LVF_TRY(sumsq.alloc(1)); LVF_TRY(lv.cell_start.alloc((size_t)ncells + 1)); LVF_TRY(lv.sorted.alloc(M));
   LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)ncells * sizeof(int), s));
-  LVF_HIP(hipMemsetAsync(cursor.p, 0, (size_t)ncells * sizeof(int), s));
-  LVF_HIP(hipMemsetAsync(total.p, 0, 2 * sizeof(int), s));
-  LVF_HIP(hipMemsetAsync(sumsq.p, 0, sizeof(unsigned long long), s));
   hipLaunchKernelGGL(k_cell_count, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, g, cell_of.p, counts.p);
-  hipLaunchKernelGGL(k_cell_stats, dim3(std::min(kBoundsMaxBlocks, (ncells + kB - 1) / kB)), dim3(kB), 0, s, ncells, counts.p, sumsq.p);
-  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, total.p + 1);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p, lv.cell_start.p);
-  LVF_HIP(hipMemcpyAsync(lv.cell_start.p + ncells, total.p + 1, sizeof(int), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(k_cell_scatter, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, cell_of.p, lv.cell_start.p, cursor.p, lv.sorted.p);
+  // exclusive scan of the counts -> cell_start[0..ncells]; the pass also yields sum(count^2) and leaves the counts zeroed, so the
+  // same array is the scatter cursor
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p, bsq.p);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, lv.cell_start.p + ncells, bsq.p, sumsq.p);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p, lv.cell_start.p, 1);
+  hipLaunchKernelGGL(k_cell_scatter, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, cell_of.p, lv.cell_start.p, counts.p, lv.sorted.p);
   LVF_HIP(hipGetLastError());
   unsigned long long ss = 0;
   LVF_HIP(hipMemcpyAsync(&ss, sumsq.p, sizeof(ss), hipMemcpyDeviceToHost, s));
