@@ -258,7 +258,7 @@ __device__ __forceinline__ void scan_range_group(const float4* __restrict__ sort
   }
 }
 
-constexpr int kLongRange = 24;   // candidates; longer ranges are deferred to the cooperative scan
+constexpr int kLongRange = 12;   // candidates; longer ranges are deferred to the cooperative scan
 
 struct TfArg { float v[7]; };
 
@@ -370,7 +370,10 @@ __global__ __launch_bounds__(kB) void k_knn3(int Q, const float4* __restrict__ s
   // Re-visited points are rejected by best3_push (same index), so levels can overlap freely.  Measured at configs[2]
   // (ground / surf gate): pyramid ratio 4 with 2 shells per level 626 / 657 Mpairs/s; ratio 2: 756 / 849; ratio 2 with one shell pair
   // per level 706 / 999; ratio 2 with this schedule 755 / 952.  (Choosing the starting level from the occupancy of the query's
-  // own cell at every level — one more round trip — was slower: 463 / 748.)
+  // own cell at every level — one more round trip — was slower: 463 / 748.)  Then the finest level itself: the point-weighted
+  // occupancy target kTargetOcc 12 -> 24 -> 48 -> 96..192 gave 755 -> 913 -> 927 -> 1100 Mpairs/s (384: 515, the grid becomes too
+  // coarse), and handing ranges longer than kLongRange 24 -> 12 candidates to the cooperative scan another 2-5 %: dependent
+  // cell look-ups cost more than streaming a few dozen extra candidates.
   for (int lv = 0; lv < L.n; ++lv) {
     const LevelP& lev = L.l[lv];
     const GridP& g = lev.g;
@@ -491,7 +494,7 @@ static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_devic
   // level divides the cell by 4 and is added while the POINT-WEIGHTED cell population (sum count^2 / M) is above
   // kTargetOcc: lidar density varies by 100x between 5 m and 30 m range, so the plain mean over cells is dominated by
   // the sparse far field while most queries sit in the dense near field.
-  const double kMaxCells = 32.0 * 1024 * 1024, kTargetOcc = 12.0;
+  const double kMaxCells = 32.0 * 1024 * 1024, kTargetOcc = 128.0;
   auto ncells_for = [&](float c) {
     return (std::floor((hi[0] - lo[0]) / c) + 1) * (std::floor((hi[1] - lo[1]) / c) + 1) * (std::floor((hi[2] - lo[2]) / c) + 1);
   };
