@@ -279,8 +279,12 @@ __device__ __forceinline__ float scan_shell(const LevelP& L, int cx, int cy, int
   const float slack = 1e-6f * g.cell;
   const int lane_in_wave = threadIdx.x & 63;
   const int group_shift = lane_in_wave & ~(kGroup - 1);
-  for (int it = 0; it * kGroup < side * side; ++it) {       // lock-step over the group: lane g owns row it*kGroup+g
-    const int row_id = it * kGroup + g_lane;
+  // shell 1 has 8 perimeter rows (one range each) + the centre row (two end caps): packed into ONE lock-step pass — the eight
+  // lanes take the perimeter rows and lanes 0 / 1 carry the centre row's caps in their second range slot — instead of a second
+  // pass in which a single lane works (every pass is a chain of dependent look-ups)
+  const bool packed = (r == 1) && (kGroup == 8);
+  for (int it = 0; it * kGroup < (packed ? kGroup : side * side); ++it) {       // lock-step over the group: lane g owns row it*kGroup+g
+    const int row_id = packed ? (g_lane < 4 ? g_lane : g_lane + 1) : it * kGroup + g_lane;
     int la = 0, ha = 0, lb = 0, hb = 0;                    // up to two candidate ranges for this lane's row
     if (row_id < side * side) {
       const int dz = row_id / side - r, dy = row_id % side - r;
@@ -309,6 +313,16 @@ __device__ __forceinline__ float scan_shell(const LevelP& L, int cx, int cy, int
           }
         }
       }
+    }
+    if (packed && g_lane < 2) {                            // centre row (dy = dz = 0: base2 = 0), cap cx - 1 or cx + 1
+      int xlo = 0, xhi = g.nx - 1;
+      if (prune2 < INFINITY) {
+        const float dxm = sqrtf(prune2) * 1.0001f + slack;
+        xlo = max(xlo, (int)floorf((qx - dxm - g.ox) * g.inv_cell - 1e-3f));
+        xhi = min(xhi, (int)floorf((qx + dxm - g.ox) * g.inv_cell + 1e-3f));
+      }
+      const int xc = g_lane == 0 ? cx - 1 : cx + 1;
+      if (xc >= xlo && xc <= xhi) { const int row = (cz * g.ny + cy) * g.nx; lb = L.cell_start[row + xc]; hb = L.cell_start[row + xc + 1]; }
     }
     if (st) { st->lookups += (ha > la) + (hb > lb); st->candidates += (ha - la) + (hb - lb); }
     const bool long_a = (ha - la) > kLongRange, long_b = (hb - lb) > kLongRange;
