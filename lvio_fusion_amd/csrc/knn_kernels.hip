@@ -505,7 +505,7 @@ static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_devic
   for (int k = 0; k < 3; ++k)
     if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) { set_error("lvf_map_create: non-finite map coordinates"); return fail(LVF_ERR_INVALID); }
   // Grid pyramid.  Coarsest level: cell = gate radius / 2, so its first two shells cover the whole gate.  Each finer
-  // level divides the cell by 4 and is added while the POINT-WEIGHTED cell population (sum count^2 / M) is above
+  // level halves the cell and is added while the POINT-WEIGHTED cell population (sum count^2 / M) is above
   // kTargetOcc: lidar density varies by 100x between 5 m and 30 m range, so the plain mean over cells is dominated by
   // the sparse far field while most queries sit in the dense near field.
   const double kMaxCells = 32.0 * 1024 * 1024, kTargetOcc = 128.0;
