@@ -48,6 +48,7 @@ struct lvf_problem {
   lvf::DevBuf<uint8_t> pose_const;
   lvf::DevBuf<int> fail;
   lvf::DevBuf<lvf::TfWork> tf_work;   // per-workgroup runs of same-k2 blocks (empty => generic atomic path)
+  lvf::HostPin<lvf::TfWork> h_tf_work;
   std::vector<uint8_t> pose_const_h;
   bool linearized = false;
   bool tf_unique_lk2 = false;   // no (landmark, current keyframe) pair occurs twice in the TwoFrame batch
@@ -1702,14 +1703,17 @@ int problem_configure(lvf_problem* p) {
     bool ok = true;
     for (int i = 0; i < two_frame->n && ok; ++i) ok = k1[i] != k2[i];
     if (ok) {
-      std::vector<TfWork> wl;
+      // built straight into pinned staging owned by the problem: the upload is a real asynchronous copy and this function does not
+      // have to wait for the stream before returning
+      LVF_TRY(p->h_tf_work.reserve((size_t)two_frame->n / 1 + 1));     // worst case: every block its own run
+      size_t nw = 0;
       for (int i = 0; i < two_frame->n;) {
         int j = i;
         while (j < two_frame->n && k2[j] == k2[i] && j - i < kT) ++j;
-        wl.push_back(TfWork{i, j - i, k2[i]});
+        p->h_tf_work[nw++] = TfWork{i, j - i, k2[i]};
         i = j;
       }
-      LVF_TRY(p->tf_work.assign(wl.data(), wl.size(), ctx->stream));
+      LVF_TRY(p->tf_work.assign(p->h_tf_work.p, nw, ctx->stream));
       // blocks are sorted by k2: a duplicate (landmark, k2) pair shows up as a repeated landmark inside one k2 run
       const std::vector<int32_t>& lmh = two_frame->host_lm;
       bool uniq = two_frame->unique_lk2_known || lmh.size() == (size_t)two_frame->n;
@@ -1744,7 +1748,7 @@ int problem_configure(lvf_problem* p) {
   }
   LVF_HIP(hipMemsetAsync(p->pose_const.p, 0, p->n_kf, ctx->stream));
   LVF_HIP(hipMemsetAsync(p->dxc.p, 0, (size_t)p->dpad * 8, ctx->stream));
-  LVF_HIP(hipStreamSynchronize(ctx->stream));
+  // no stream wait here: every host source above is pinned and owned by the problem (or was waited for by the plan builder)
   p->linearized = false;
   return LVF_OK;
 }
