@@ -337,8 +337,8 @@ def relocalize_leg(api, syn, ctx, n=8):
             "scores": [float(x) for x in rec[np.argsort(rec[:, 8]), 0]]}
 
 
-def _build_window(api, syn, ctx, seed=None):
-    cfg = syn.config4_window() if seed is None else syn.config4_window(seed=seed)
+def _build_window(api, syn, ctx, seed=None, ids_by_birth=False):
+    cfg = syn.config4_window(ids_by_birth=ids_by_birth) if seed is None else syn.config4_window(seed=seed, ids_by_birth=ids_by_birth)
     pre = api.preintegrate_or_none(ctx, cfg)
     st = api.State(ctx, cfg["n_kf"], cfg["n_lm"])
     for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth"), (api.W_VISUAL, "w_kf")):
@@ -352,10 +352,10 @@ def _build_window(api, syn, ctx, seed=None):
     return cfg, prob, (btc, btf, bpo, bimu, st)
 
 
-def full_window(api, syn, ctx, iters=30):
+def full_window(api, syn, ctx, iters=30, ids_by_birth=False):
     """configs[3]: 50 KF / 10k landmarks full sliding-window problem; one step = one complete LM iteration
     (linearise all factors, Schur-eliminate inverse depths, Cholesky, back-substitute, evaluate the candidate)."""
-    cfg, prob, handles = _build_window(api, syn, ctx)
+    cfg, prob, handles = _build_window(api, syn, ctx, ids_by_birth=ids_by_birth)
     btc, btf, bpo, bimu, st = handles
     opt = api.default_solver_options()
     radius, dec, costs = 1e4, 2.0, []

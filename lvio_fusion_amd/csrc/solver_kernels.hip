@@ -229,19 +229,25 @@ __global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__
   double v[27];
 #pragma unroll
   for (int q = 0; q < 27; ++q) v[q] = 0.0;
-  if ((int)threadIdx.x < w.count) {
+  const bool active = (int)threadIdx.x < w.count;
+  int k1 = 0;
+  double L1[12], L2[12], r0 = 0.0, r1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 12; ++q) { L1[q] = 0.0; L2[q] = 0.0; }
+  if (active) {
     const int i = w.first + threadIdx.x;
-    const int l = lm[i], k1 = kf1[i];
+    const int l = lm[i];
+    k1 = kf1[i];
     const double2 a = fo[i], b = ob[i];
     double r[2], Jd[2], J1[14], J2[14];
     eval_two_frame<true>(s_pose[k1], s_pose[k2], left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], s.w_kf[k2], r, Jd, J1, J2);
     double rho;
     const double sc = robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
     c = 0.5 * rho;
-    double L1[12], L2[12];
     pose_rows_to_local(J1, s.poses + 7 * k1, pose_const[k1] ? 0.0 : sc, L1);
     pose_rows_to_local(J2, s.poses + 7 * k2, pose_const[k2] ? 0.0 : sc, L2);
-    const double r0 = sc * r[0], r1 = sc * r[1], d0 = sc * Jd[0], d1 = sc * Jd[1];
+    r0 = sc * r[0]; r1 = sc * r[1];
+    const double d0 = sc * Jd[0], d1 = sc * Jd[1];
     atomicAdd(&C[l], d0 * d0 + d1 * d1);
     atomicAdd(&gr[l], d0 * r0 + d1 * r1);
     double* el = E + (size_t)l * ldE;
@@ -254,18 +260,39 @@ __global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__
       const double e2 = L2[q] * d0 + L2[6 + q] * d1;
       if (unique_lk2) el[6 * k2 + q] = e2; else atomicAdd(&el[6 * k2 + q], e2);
     }
-    double* acc = s_acc + k1 * kAccSlots;
+  }
+  // k1-indexed sums (B[k1,k1], g[k1], cross block).  A live front-end hands out landmark ids in creation order, so the blocks of a
+  // wave usually share their first keyframe: then the 63 sums are wave reductions and one lane adds them (per-lane ds_add_f64 on ONE
+  // address serialises 64-fold: +10 us on this kernel with ids in birth order); mixed waves keep the per-lane LDS atomics.
+  {
+    const unsigned long long am = __ballot(active);
+    const int k1u = am ? __builtin_amdgcn_readlane(k1, (int)__ffsll((long long)am) - 1) : 0;
+    const bool same_k1 = __all(!active || k1 == k1u);
+    double* acc = s_acc + (same_k1 ? k1u : k1) * kAccSlots;
+    const bool lane0 = (threadIdx.x & 63) == 0;
     int q = 0;
 #pragma unroll
     for (int x = 0; x < 6; ++x)
 #pragma unroll
-      for (int y = 0; y <= x; ++y) { atomicAdd(&acc[q], L1[x] * L1[y] + L1[6 + x] * L1[6 + y]); v[q] = L2[x] * L2[y] + L2[6 + x] * L2[6 + y]; ++q; }
+      for (int y = 0; y <= x; ++y) {
+        double t = L1[x] * L1[y] + L1[6 + x] * L1[6 + y];
+        if (same_k1) { t = wave_sum(t); if (lane0 && t != 0.0) atomicAdd(&acc[q], t); } else if (active) atomicAdd(&acc[q], t);
+        v[q] = L2[x] * L2[y] + L2[6 + x] * L2[6 + y];
+        ++q;
+      }
 #pragma unroll
-    for (int x = 0; x < 6; ++x) { atomicAdd(&acc[21 + x], L1[x] * r0 + L1[6 + x] * r1); v[21 + x] = L2[x] * r0 + L2[6 + x] * r1; }
+    for (int x = 0; x < 6; ++x) {
+      double t = L1[x] * r0 + L1[6 + x] * r1;
+      if (same_k1) { t = wave_sum(t); if (lane0 && t != 0.0) atomicAdd(&acc[21 + x], t); } else if (active) atomicAdd(&acc[21 + x], t);
+      v[21 + x] = L2[x] * r0 + L2[6 + x] * r1;
+    }
 #pragma unroll
     for (int x = 0; x < 6; ++x)
 #pragma unroll
-      for (int y = 0; y < 6; ++y) atomicAdd(&acc[27 + 6 * x + y], L2[x] * L1[y] + L2[6 + x] * L1[6 + y]);
+      for (int y = 0; y < 6; ++y) {
+        double t = L2[x] * L1[y] + L2[6 + x] * L1[6 + y];
+        if (same_k1) { t = wave_sum(t); if (lane0 && t != 0.0) atomicAdd(&acc[27 + 6 * x + y], t); } else if (active) atomicAdd(&acc[27 + 6 * x + y], t);
+      }
   }
 #pragma unroll
   for (int q = 0; q < 27; ++q) v[q] = wave_sum(v[q]);

@@ -193,7 +193,7 @@ def synth_imu_samples(pose_i, pose_j, v_i, v_j, ba, bg, n_samples, dt_total, rng
 
 # ----------------------------------------------------------------------------- config 4
 def config4_window(n_kf=50, n_lm=10000, n_prewindow=2000, seed=SEED_CFG4, imu_samples=10, kf_dt=0.1 * 10,
-                   pix_sigma=0.5, p_geom=0.1):
+                   pix_sigma=0.5, p_geom=0.1, ids_by_birth=False):
     """Full sliding-window problem: TwoCamera + TwoFrame + PoseOnly + ImuError block lists
     (block mix of backend.cpp:96-183)."""
     rng = np.random.default_rng(seed)
@@ -201,6 +201,8 @@ def config4_window(n_kf=50, n_lm=10000, n_prewindow=2000, seed=SEED_CFG4, imu_sa
     poses = drive_poses(n_kf, rng)
     # landmarks: born at KF f, defined by right-image pixel + depth in cam1 (Pixel2Robot, visual_error.hpp:25-33)
     birth = rng.integers(0, n_kf, n_lm).astype(np.int32)
+    if ids_by_birth:       # landmark ids handed out in creation order (what a live front-end does): neighbouring blocks of a
+        birth.sort()       # keyframe's feature list then share their first keyframe
     depth = rng.uniform(4.0, 80.0, n_lm)
     u1 = rng.uniform(0, 1241, n_lm); v1 = rng.uniform(0, 376, n_lm)
     ps = np.stack([(u1 - CX) / FX * depth, (v1 - CY) / FY * depth, depth], -1)

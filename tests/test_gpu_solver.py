@@ -17,8 +17,8 @@ def ctx():
     c.close()
 
 
-def build(api, ctx, oracle, n_kf, n_lm, seed, n_pre=40, use=("tc", "tf", "po", "imu"), imu_drop=()):
-    cfg = syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=n_pre, seed=seed, imu_samples=5)
+def build(api, ctx, oracle, n_kf, n_lm, seed, n_pre=40, use=("tc", "tf", "po", "imu"), imu_drop=(), ids_by_birth=False):
+    cfg = syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=n_pre, seed=seed, imu_samples=5, ids_by_birth=ids_by_birth)
     if imu_drop:       # IMU drop-outs: the (v, ba, bg) coupling graph falls apart into several chains and isolated blocks
         cfg["imu"] = [f for k, f in enumerate(cfg["imu"]) if k not in imu_drop]
     pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
@@ -97,6 +97,31 @@ def test_lm_iteration_parity_with_imu_gaps_and_large_windows(ctx, oracle, n_kf, 
         assert_parity(s["vel"].reshape(-1, 3), win.vel, f"vel it{it}")
         assert_parity(s["ba"].reshape(-1, 3), win.ba, f"ba it{it}")
         assert_parity(s["bg"].reshape(-1, 3), win.bg, f"bg it{it}")
+        radius, dec = ref["radius"], ref["decrease_factor"]
+    for h in list(b.values()) + [st]:
+        if h is not None:
+            h.close()
+    prob.close()
+
+
+def test_lm_iteration_parity_with_landmark_ids_in_creation_order(ctx, oracle):
+    """Ids handed out in birth order make whole waves of TwoFrame blocks share their first keyframe (the wave-reduction path of
+    the linearisation) and give the band-limited Schur complement its natural ordering."""
+    from lvio_fusion_amd import api
+    cfg, st, b, prob, win = build(api, ctx, oracle, 8, 2400, 23, ids_by_birth=True)
+    opt = api.default_solver_options()
+    radius, dec = 1e4, 2.0
+    for it in range(3):
+        ref = win.lm_iteration(radius, dec)
+        got = prob.lm_iteration(opt, radius, dec)
+        assert abs(got["cost_before"] - ref["cost_before"]) <= 1e-8 * abs(ref["cost_before"])
+        S, rhs = prob.reduced_system()
+        assert np.abs(S - ref["S"]).max() <= 1e-7 * np.abs(ref["S"]).max(), f"iteration {it}: reduced system mismatch"
+        assert_parity(rhs, ref["rhs"], f"rhs it{it}")
+        assert got["accepted"] == ref["accepted"]
+        s = state_of(api, st)
+        assert_parity(s["poses"].reshape(-1, 7), win.poses, f"poses it{it}")
+        assert_parity(s["inv_depth"], win.inv_depth, f"inv_depth it{it}")
         radius, dec = ref["radius"], ref["decrease_factor"]
     for h in list(b.values()) + [st]:
         if h is not None:
