@@ -182,8 +182,7 @@ __global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restric
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int q = WITH_J ? 0 : 9; q < 10; ++q) {
-    double s = v[q];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    const double s = wave_sum(v[q]);                     // DPP row butterflies + 4 readlanes (lvf_internal.hpp)
     if (lane == 0) s_part[wid][q] = s;
   }
   __syncthreads();

@@ -250,6 +250,35 @@ struct lvf_cloud {
 
 struct lvf_problem;
 namespace lvf {
+// butterfly inside each group of four lanes on the DPP path (quad_perm, VALU latency): __shfl_xor compiles to ds_bpermute, an LDS
+// round trip of ~120 cycles, and two of them per step WERE the panel solve's dependent chain (11 us per 64 columns)
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v) {     // any DPP control word, not only quad_perm ones
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+  v += quad_perm<0xB1>(v);     // lanes [1,0,3,2]
+  v += quad_perm<0x4E>(v);     // lanes [2,3,0,1]
+  return v;
+}
+
+// broadcast of one lane's double through v_readlane (scalar result: no VGPR, no LDS round trip)
+__device__ __forceinline__ double lane_bcast(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+// wave-wide sum on the DPP path: 4 butterfly steps inside each 16-lane row (quad_perm x2, row_half_mirror, row_mirror), then
+// the four row sums are read as scalars.  Every lane returns the total.  (The ds_bpermute-based __shfl_down ladder is 6 dependent
+// LDS round trips per value, and the linearisation kernels reduce 27 values per wave.)  Call with all 64 lanes active.
+__device__ __forceinline__ double wave_sum(double v) {
+  v = quad_sum(v);
+  v += quad_perm<0x141>(v);    // row_half_mirror
+  v += quad_perm<0x140>(v);    // row_mirror
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
 // Same-address global atomics serialise in L2 at ~65 ns each (measured), so counters are touched once per RUN of consecutive lanes
 // holding the same key (clouds arrive in scan order: a coarse cell, a segment or a voxel sees long runs): only the head lane of a
 // run issues the atomic, with the run length.  `start` = head lane of this lane's run, `len` = run

@@ -68,35 +68,6 @@ enum { SC_COST = 0, SC_COST_NEW = 1 * kStripes, SC_MODEL = 2 * kStripes, SC_DXNO
        SC_N = 6 * kStripes, SC_FAIL = SC_N /* int flag */, SC_ALLOC = SC_N + 1 };
 static inline double stripe_sum(const double* h, int slot) { double s = 0.0; for (int k = 0; k < kStripes; ++k) s += h[slot + k]; return s; }
 
-// butterfly inside each group of four lanes on the DPP path (quad_perm, VALU latency): __shfl_xor compiles to ds_bpermute, an LDS
-// round trip of ~120 cycles, and two of them per step WERE the panel solve's dependent chain (11 us per 64 columns)
-template <int CTRL>
-__device__ __forceinline__ double quad_perm(double v) {     // any DPP control word, not only quad_perm ones
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double quad_sum(double v) {
-  v += quad_perm<0xB1>(v);     // lanes [1,0,3,2]
-  v += quad_perm<0x4E>(v);     // lanes [2,3,0,1]
-  return v;
-}
-
-// broadcast of one lane's double through v_readlane (scalar result: no VGPR, no LDS round trip)
-__device__ __forceinline__ double lane_bcast(double v, int srclane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-  return __hiloint2double(hi, lo);
-}
-// wave-wide sum on the DPP path: 4 butterfly steps inside each 16-lane row (quad_perm x2, row_half_mirror, row_mirror), then
-// the four row sums are read as scalars.  Every lane returns the total.  (The ds_bpermute-based __shfl_down ladder is 6 dependent
-// LDS round trips per value, and the linearisation kernels reduce 27 values per wave.)  Call with all 64 lanes active.
-__device__ __forceinline__ double wave_sum(double v) {
-  v = quad_sum(v);
-  v += quad_perm<0x141>(v);    // row_half_mirror
-  v += quad_perm<0x140>(v);    // row_mirror
-  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
-}
 __device__ __forceinline__ void block_add(double v, double* dst) {
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst + (blockIdx.x & (kStripes - 1)), v);
