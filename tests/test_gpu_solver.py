@@ -41,7 +41,9 @@ def state_of(api, st):
 
 
 @pytest.mark.parametrize("n_kf,n_lm,seed,use", [(8, 120, 3, ("tc", "tf", "po", "imu")), (12, 300, 5, ("tc", "tf", "po", "imu")),
-                                                (6, 80, 7, ("tc", "tf", "po")), (5, 0, 9, ("po", "imu"))])
+                                                (6, 80, 7, ("tc", "tf", "po")), (5, 0, 9, ("po", "imu")),
+                                                (7, 150, 29, ("tc", "po", "imu")),      # landmarks without any pose-dependent block
+                                                (2, 40, 31, ("tc", "tf", "po", "imu"))])   # the smallest window with an IMU factor
 def test_lm_iteration_parity(ctx, oracle, n_kf, n_lm, seed, use):
     from lvio_fusion_amd import api
     if n_lm == 0:
