@@ -139,10 +139,11 @@ __global__ __launch_bounds__(64) void k_imu(int n, const double* __restrict__ pr
                                             const int* __restrict__ kf_i, const int* __restrict__ kf_j,
                                             const double* __restrict__ poses, const double* __restrict__ vel,
                                             const double* __restrict__ ba, const double* __restrict__ bg,
-                                            double* __restrict__ res, ImuOut out) {
+                                            double* __restrict__ res, ImuOut out, double* __restrict__ cost_stripes) {
   __shared__ double sS[225];
   __shared__ double sM[15 * 32];
   __shared__ double sr0[15];
+  __shared__ double scost[15];
   const int f = blockIdx.x;
   const int lane = threadIdx.x;
   const double* P = pre + (size_t)f * kPre;
@@ -247,6 +248,17 @@ __global__ __launch_bounds__(64) void k_imu(int n, const double* __restrict__ pr
     double s = 0.0;
     for (int k = 0; k < 15; ++k) s += sS[15 * lane + k] * sr0[k];
     res[(size_t)f * 15 + lane] = s;
+    scost[lane] = 0.5 * s * s;
+  }
+  // optional: the factor's cost 1/2 |r|^2 straight into the solver's striped accumulator (one atomic per factor) — a separate
+  // reduction kernel over 15 n values is a 6 us launch for no work
+  if (cost_stripes) {
+    __syncthreads();
+    if (lane == 0) {
+      double c = 0.0;
+      for (int k = 0; k < 15; ++k) c += scost[k];
+      atomicAdd(cost_stripes + (f & 31), c);
+    }
   }
   if (WITH_J) {
     for (int e = lane; e < 480; e += 64) {
@@ -387,16 +399,16 @@ int launch_imu_sqrt_info(lvf_batch* b) {
   return LVF_OK;
 }
 
-int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j) {
+int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j, double* cost_stripes) {
   if (b->n == 0) return LVF_OK;
   ImuOut o;
   for (int k = 0; k < 8; ++k) o.j[k] = b->jac[k].p;
   if (want_j)
     hipLaunchKernelGGL(k_imu<true>, dim3(b->n), dim3(64), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p, b->idx_a.p,
-                       b->idx_b.p, st->poses.p, st->vel.p, st->ba.p, st->bg.p, b->res.p, o);
+                       b->idx_b.p, st->poses.p, st->vel.p, st->ba.p, st->bg.p, b->res.p, o, cost_stripes);
   else
     hipLaunchKernelGGL(k_imu<false>, dim3(b->n), dim3(64), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p, b->idx_a.p,
-                       b->idx_b.p, st->poses.p, st->vel.p, st->ba.p, st->bg.p, b->res.p, o);
+                       b->idx_b.p, st->poses.p, st->vel.p, st->ba.p, st->bg.p, b->res.p, o, cost_stripes);
   LVF_HIP(hipGetLastError());
   return LVF_OK;
 }

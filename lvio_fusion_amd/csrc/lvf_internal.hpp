@@ -310,7 +310,8 @@ int launch_two_camera(lvf_batch* b, const lvf_state* st, bool want_j);
 int launch_lidar_normals(lvf_batch* b, const double* d_pb, const double* d_pc);
 int launch_lidar_plane(lvf_batch* b, const double* rpyxyz_host, bool want_j);
 int launch_imu_sqrt_info(lvf_batch* b);
-int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j);
+// cost_stripes (optional): 32 striped accumulators that receive 1/2 |r|^2 of every factor
+int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j, double* cost_stripes = nullptr);
 int launch_pose_prior(lvf_batch* b, const lvf_state* st, bool want_j);
 void make_camd(const lvf_camera& c, CamD& d);
 }  // namespace lvf

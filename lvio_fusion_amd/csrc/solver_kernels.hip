@@ -445,13 +445,6 @@ __global__ __launch_bounds__(64) void k_lin_imu(int n, int n_kf, const double* _
     atomicAdd(&gc[sidx[lane]], g);
   }
 }
-__global__ __launch_bounds__(kT) void k_cost_imu(int n15, const double* __restrict__ res, double* __restrict__ cost) {
-  const int i = blockIdx.x * kT + threadIdx.x;
-  double c = 0.0;
-  if (i < n15) { const double r = res[i]; c = 0.5 * r * r; }
-  block_add(c, cost);
-}
-
 // ------------------------------------------------------------------------------------------------ pose priors
 // consumes the materialised PoseGraphError / PoseError outputs of launch_pose_prior (res[n][6], ja/jb [n][6][7]); no loss
 // function (backend.cpp:171,176).  <= n_kf blocks: one thread per block, global atomics.
@@ -1375,8 +1368,8 @@ static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_st
     hipLaunchKernelGGL(k_lin_po<true>, dim3(grid(p->po->n)), dim3(kT), 0, q, p->po->n, p->n_kf, (const double2*)p->po->ob_a.p, p->po->idx_a.p,
                        p->po->idx_b.p, p->po->table.p, s, p->po->cam_a, huber, p->pose_const.p, (double*)nullptr, 0, (double*)nullptr, cost_slot);
   if (p->imu && p->imu->n) {
-    LVF_TRY(launch_imu(p->imu, imu_state_view, false));
-    hipLaunchKernelGGL(k_cost_imu, dim3(grid(15 * p->imu->n)), dim3(kT), 0, q, 15 * p->imu->n, p->imu->res.p, cost_slot);
+    static_assert(kStripes == 32, "k_imu stripes its cost over 32 slots");
+    LVF_TRY(launch_imu(p->imu, imu_state_view, false, cost_slot));      // residuals and their cost in one launch
   }
   if (p->prior && p->prior->n) {
     LVF_TRY(launch_pose_prior(p->prior, imu_state_view, false));
