@@ -270,6 +270,13 @@ __device__ __forceinline__ double lane_bcast(double v, int srclane) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
   return __hiloint2double(hi, lo);
 }
+// sum over each aligned group of 16 lanes (a DPP "row"), delivered to all 16: the first four steps of wave_sum
+__device__ __forceinline__ double row16_sum(double v) {
+  v = quad_sum(v);
+  v += quad_perm<0x141>(v);    // row_half_mirror
+  v += quad_perm<0x140>(v);    // row_mirror
+  return v;
+}
 // wave-wide sum on the DPP path: 4 butterfly steps inside each 16-lane row (quad_perm x2, row_half_mirror, row_mirror), then
 // the four row sums are read as scalars.  Every lane returns the total.  (The ds_bpermute-based __shfl_down ladder is 6 dependent
 // LDS round trips per value, and the linearisation kernels reduce 27 values per wave.)  Call with all 64 lanes active.

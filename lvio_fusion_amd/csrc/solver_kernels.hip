@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE,
     double ed = 0.0;
     const int i0 = kmin ? 6 * min(kmin[l], dp / 6) : 0, i1 = kmin ? 6 * (kmax[l] + 1) : dp;   // the row is zero outside the landmark's track
     for (int i = (i0 & ~15) + q; i < i1; i += 16) ed += e[i] * sdx[i];
-    ed += __shfl_xor(ed, 8); ed += __shfl_xor(ed, 4); ed += __shfl_xor(ed, 2); ed += __shfl_xor(ed, 1);
+    ed = row16_sum(ed);
     if (q == 0) {
       const double dl = (-gr[l] - ed) / Cd[l];
       dxl[l] = dl;
