@@ -351,7 +351,25 @@ __device__ __forceinline__ float scan_shell(const LevelP& L, int cx, int cy, int
 
 // butterfly all-reduce of the per-lane best-3 lists inside each aligned kGroup-lane group; the (d2, index) order with
 // same-index rejection makes the merge commutative/associative, so every lane ends with the identical list.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ void merge_step(float bd[3], int bi[3]) {
+  float od[3]; int oi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { od[k] = __int_as_float(dpp_i<CTRL>(__float_as_int(bd[k]))); oi[k] = dpp_i<CTRL>(bi[k]); }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) if (oi[k] >= 0) best3_push(od[k], oi[k], bd, bi);
+}
 __device__ __forceinline__ void group_merge_best3(float bd[3], int bi[3]) {
+  if (kGroup == 8) {
+    // partner lanes through DPP (VALU latency) instead of ds_bpermute round trips: lane ^ 1, lane ^ 2 (quad_perm), then the mirror
+    // image inside the 8-lane half row (i <-> 7 - i), which pairs the two quads just as well as lane ^ 4
+    merge_step<0xB1>(bd, bi);
+    merge_step<0x4E>(bd, bi);
+    merge_step<0x141>(bd, bi);
+    return;
+  }
 #pragma unroll
   for (int mask = 1; mask < kGroup; mask <<= 1) {
     float od[3]; int oi[3];
