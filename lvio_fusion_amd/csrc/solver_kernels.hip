@@ -301,6 +301,62 @@ __global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------ candidate cost, visual factors
+// One launch for the residual-only passes of the three reprojection batches (the workgroups of the launch are split into a
+// TwoCamera, a TwoFrame and a PoseOnly segment): as three back-to-back launches of 4-9 us they were mostly launch boundaries.
+struct CostVisual {
+  int n_tc, n_tf, n_po, g_tc, g_tf;
+  const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; CamD tc_left, tc_right;
+  const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1, *tf_k2; CamD tf_left, tf_right;
+  const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
+};
+__global__ __launch_bounds__(kT) void k_cost_visual(CostVisual a, int n_kf, StateP s, double huber, double* __restrict__ cost) {
+  __shared__ PoseD s_pose[kMaxStagedKf];
+  const int b = blockIdx.x;
+  double c = 0.0;
+  if (b < a.g_tc) {
+    const int i = b * kT + threadIdx.x;
+    if (i < a.n_tc) {
+      const int l = a.tc_lm[i];
+      const double2 lo = a.tc_lo[i], ro = a.tc_ro[i];
+      double r[2], J[2];
+      eval_two_camera<false>(a.tc_left, a.tc_right, lo.x, lo.y, ro.x, ro.y, s.inv_depth[l], 5.0 * s.w_kf[a.tc_kf[i]], r, J);
+      double rho;
+      (void)robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
+      c = 0.5 * rho;
+    }
+  } else {
+    stage_poses<kT>(s_pose, s.poses, n_kf);     // ends with __syncthreads(); the branch is workgroup-uniform
+    if (b < a.g_tc + a.g_tf) {
+      const int i = (b - a.g_tc) * kT + threadIdx.x;
+      if (i < a.n_tf) {
+        const int l = a.tf_lm[i], k1 = a.tf_k1[i], k2 = a.tf_k2[i];
+        const double2 fo = a.tf_fo[i], ob = a.tf_ob[i];
+        const PoseD P1 = fetch_pose(s_pose, s.poses, n_kf, k1), P2 = fetch_pose(s_pose, s.poses, n_kf, k2);
+        double r[2], Jd[2], J1[14], J2[14];
+        eval_two_frame<false>(P1, P2, a.tf_left, a.tf_right, fo.x, fo.y, ob.x, ob.y, s.inv_depth[l], s.w_kf[k2], r, Jd, J1, J2);
+        double rho;
+        (void)robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
+        c = 0.5 * rho;
+      }
+    } else {
+      const int i = (b - a.g_tc - a.g_tf) * kT + threadIdx.x;
+      if (i < a.n_po) {
+        const int k = a.po_kf[i], l = a.po_pwi[i];
+        const double2 o = a.po_ob[i];
+        const PoseD P = fetch_pose(s_pose, s.poses, n_kf, k);
+        const double pwl[3] = {a.po_pw[3 * l], a.po_pw[3 * l + 1], a.po_pw[3 * l + 2]};
+        double r[2], J[14];
+        eval_pose_only<false>(P, a.po_cam, o.x, o.y, pwl, s.w_kf[k], r, J);
+        double rho;
+        (void)robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
+        c = 0.5 * rho;
+      }
+    }
+  }
+  block_add(c, cost);
+}
+
 // ------------------------------------------------------------------------------------------------ PoseOnly
 template <bool COST_ONLY>
 __global__ __launch_bounds__(kT) void k_lin_po(int n, int n_kf, const double2* __restrict__ ob, const int* __restrict__ kf,
@@ -1357,16 +1413,21 @@ static inline int grid(int n) { return (n + kT - 1) / kT; }
 // accumulates 1/2 sum rho into *cost_slot at the given state (residual-only pass)
 static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_state_view, double huber, double* cost_slot) {
   hipStream_t q = p->ctx->stream;
-  if (p->tc && p->tc->n)
-    hipLaunchKernelGGL(k_lin_tc<true>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
-                       p->tc->idx_a.p, p->tc->idx_b.p, s, p->tc->cam_a, p->tc->cam_b, huber, (double*)nullptr, (double*)nullptr, cost_slot);
-  if (p->tf && p->tf->n)
-    hipLaunchKernelGGL(k_lin_tf<true>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
-                       p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, (double*)nullptr, 0,
-                       (double*)nullptr, (double*)nullptr, 0, (double*)nullptr, (double*)nullptr, cost_slot);
-  if (p->po && p->po->n)
-    hipLaunchKernelGGL(k_lin_po<true>, dim3(grid(p->po->n)), dim3(kT), 0, q, p->po->n, p->n_kf, (const double2*)p->po->ob_a.p, p->po->idx_a.p,
-                       p->po->idx_b.p, p->po->table.p, s, p->po->cam_a, huber, p->pose_const.p, (double*)nullptr, 0, (double*)nullptr, cost_slot);
+  CostVisual a{};
+  if (p->tc && p->tc->n) {
+    a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p;
+    a.tc_left = p->tc->cam_a; a.tc_right = p->tc->cam_b;
+  }
+  if (p->tf && p->tf->n) {
+    a.n_tf = p->tf->n; a.tf_fo = (const double2*)p->tf->ob_a.p; a.tf_ob = (const double2*)p->tf->ob_b.p; a.tf_lm = p->tf->idx_a.p; a.tf_k1 = p->tf->idx_b.p;
+    a.tf_k2 = p->tf->idx_c.p; a.tf_left = p->tf->cam_a; a.tf_right = p->tf->cam_b;
+  }
+  if (p->po && p->po->n) {
+    a.n_po = p->po->n; a.po_ob = (const double2*)p->po->ob_a.p; a.po_kf = p->po->idx_a.p; a.po_pwi = p->po->idx_b.p; a.po_pw = p->po->table.p; a.po_cam = p->po->cam_a;
+  }
+  a.g_tc = grid(a.n_tc); a.g_tf = grid(a.n_tf);
+  const int g_all = a.g_tc + a.g_tf + grid(a.n_po);
+  if (g_all > 0) hipLaunchKernelGGL(k_cost_visual, dim3(g_all), dim3(kT), 0, q, a, p->n_kf, s, huber, cost_slot);
   if (p->imu && p->imu->n) {
     static_assert(kStripes == 32, "k_imu stripes its cost over 32 slots");
     LVF_TRY(launch_imu(p->imu, imu_state_view, false, cost_slot));      // residuals and their cost in one launch
