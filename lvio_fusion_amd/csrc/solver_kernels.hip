@@ -100,11 +100,11 @@ __global__ __launch_bounds__(kT) void k_zero_multi(ZeroList z) {
 
 // ------------------------------------------------------------------------------------------------ TwoCamera
 template <bool COST_ONLY>
-__global__ __launch_bounds__(kT) void k_lin_tc(int n, const double2* __restrict__ lo, const double2* __restrict__ ro,
+__device__ __forceinline__ void lin_tc_body(const int vb, int n, const double2* __restrict__ lo, const double2* __restrict__ ro,
                                                const int* __restrict__ lm, const int* __restrict__ kf, StateP s,
                                                CamD left, CamD right, double huber, double* __restrict__ C,
                                                double* __restrict__ gr, double* __restrict__ cost) {
-  const int i = blockIdx.x * kT + threadIdx.x;
+  const int i = vb * kT + threadIdx.x;
   double c = 0.0;
   if (i < n) {
     const int l = lm[i];
@@ -122,6 +122,11 @@ __global__ __launch_bounds__(kT) void k_lin_tc(int n, const double2* __restrict_
   }
   block_add(c, cost);
 }
+template <bool COST_ONLY>
+__global__ __launch_bounds__(kT) void k_lin_tc(int n, const double2* __restrict__ lo, const double2* __restrict__ ro,
+                                               const int* __restrict__ lm, const int* __restrict__ kf, StateP s,
+                                               CamD left, CamD right, double huber, double* __restrict__ C,
+                                               double* __restrict__ gr, double* __restrict__ cost) { lin_tc_body<COST_ONLY>(blockIdx.x, n, lo, ro, lm, kf, s, left, right, huber, C, gr, cost); }
 
 // ------------------------------------------------------------------------------------------------ TwoFrame
 template <bool COST_ONLY>
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(kT) void k_lin_tf(int n, int n_kf, const double2* _
 //   * only the landmark-indexed sums (C, g_rho, E rows) remain global atomics: 14 per block instead of 134.
 struct TfWork { int first, count, k2; };
 constexpr int kAccSlots = 63;   // 21 (B[k1,k1] lower) + 6 (g[k1]) + 36 (cross block, rows = k2 tangent, cols = k1 tangent)
-__global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__ work, int n_kf, const double2* __restrict__ fo,
+__device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* __restrict__ work, int n_kf, const double2* __restrict__ fo,
                                                       const double2* __restrict__ ob, const int* __restrict__ lm,
                                                       const int* __restrict__ kf1, StateP s, CamD left, CamD right, double huber,
                                                       const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__
   __shared__ PoseD s_pose[kMaxStagedKf];
   __shared__ double s_acc[kMaxStagedKf * kAccSlots];
   __shared__ double s_k2[27];
-  const TfWork w = work[blockIdx.x];
+  const TfWork w = work[vb];
   for (int e = threadIdx.x; e < n_kf * kAccSlots; e += kT) s_acc[e] = 0.0;
   if (threadIdx.x < 27) s_k2[threadIdx.x] = 0.0;
   stage_poses<kT>(s_pose, s.poses, n_kf);   // ends with __syncthreads()
@@ -300,6 +305,12 @@ __global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__
     }
   }
 }
+__global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__ work, int n_kf, const double2* __restrict__ fo,
+                                                      const double2* __restrict__ ob, const int* __restrict__ lm,
+                                                      const int* __restrict__ kf1, StateP s, CamD left, CamD right, double huber,
+                                                      const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
+                                                      double* __restrict__ gc, double* __restrict__ E, int ldE,
+                                                      double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost, int unique_lk2) { lin_tf_sorted_body(blockIdx.x, work, n_kf, fo, ob, lm, kf1, s, left, right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost, unique_lk2); }
 
 // ------------------------------------------------------------------------------------------------ candidate cost, visual factors
 // One launch for the residual-only passes of the three reprojection batches (the workgroups of the launch are split into a
@@ -359,13 +370,13 @@ __global__ __launch_bounds__(kT) void k_cost_visual(CostVisual a, int n_kf, Stat
 
 // ------------------------------------------------------------------------------------------------ PoseOnly
 template <bool COST_ONLY>
-__global__ __launch_bounds__(kT) void k_lin_po(int n, int n_kf, const double2* __restrict__ ob, const int* __restrict__ kf,
+__device__ __forceinline__ void lin_po_body(const int vb, int n, int n_kf, const double2* __restrict__ ob, const int* __restrict__ kf,
                                                const int* __restrict__ pwi, const double* __restrict__ pw, StateP s, CamD cam,
                                                double huber, const uint8_t* __restrict__ pose_const, double* __restrict__ B,
                                                int ld, double* __restrict__ gc, double* __restrict__ cost) {
   __shared__ PoseD s_pose[kMaxStagedKf];
   stage_poses<kT>(s_pose, s.poses, n_kf);
-  const int i = blockIdx.x * kT + threadIdx.x;
+  const int i = vb * kT + threadIdx.x;
   double c = 0.0;
   int k = -1;
   double v[27];
@@ -443,6 +454,38 @@ __global__ __launch_bounds__(kT) void k_lin_po(int n, int n_kf, const double2* _
   }
   block_add(c, cost);
 }
+template <bool COST_ONLY>
+__global__ __launch_bounds__(kT) void k_lin_po(int n, int n_kf, const double2* __restrict__ ob, const int* __restrict__ kf,
+                                               const int* __restrict__ pwi, const double* __restrict__ pw, StateP s, CamD cam,
+                                               double huber, const uint8_t* __restrict__ pose_const, double* __restrict__ B,
+                                               int ld, double* __restrict__ gc, double* __restrict__ cost) { lin_po_body<COST_ONLY>(blockIdx.x, n, n_kf, ob, kf, pwi, pw, s, cam, huber, pose_const, B, ld, gc, cost); }
+
+// ------------------------------------------------------------------------------------------------ linearisation, visual factors
+// The TwoFrame (sorted fast path), TwoCamera and PoseOnly linearisations as ONE launch: workgroups [0, n_tfw) take the TwoFrame
+// work list, the next g_tc the TwoCamera blocks, the rest the PoseOnly blocks.  The two small passes (4.6 + 8.8 us as launches of
+// their own) disappear under the TwoFrame pass; all three only meet in B, gc, C, g_rho through atomics.
+struct LinVisual {
+  int n_tfw, g_tc;
+  // TwoFrame
+  const TfWork* work; const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1; CamD tf_left, tf_right; int unique_lk2;
+  // TwoCamera
+  int n_tc; const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; CamD tc_left, tc_right;
+  // PoseOnly
+  int n_po; const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
+};
+__global__ __launch_bounds__(kT) void k_lin_visual(LinVisual a, int n_kf, StateP s, double huber, const uint8_t* __restrict__ pose_const,
+                                                   double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ E, int ldE,
+                                                   double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost) {
+  const int b = blockIdx.x;
+  if (b < a.n_tfw)
+    lin_tf_sorted_body(b, a.work, n_kf, a.tf_fo, a.tf_ob, a.tf_lm, a.tf_k1, s, a.tf_left, a.tf_right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost,
+                       a.unique_lk2);
+  else if (b < a.n_tfw + a.g_tc)
+    lin_tc_body<false>(b - a.n_tfw, a.n_tc, a.tc_lo, a.tc_ro, a.tc_lm, a.tc_kf, s, a.tc_left, a.tc_right, huber, C, gr, cost);
+  else
+    lin_po_body<false>(b - a.n_tfw - a.g_tc, a.n_po, n_kf, a.po_ob, a.po_kf, a.po_pwi, a.po_pw, s, a.po_cam, huber, pose_const, B, ld, gc, cost);
+}
+
 
 // ------------------------------------------------------------------------------------------------ IMU
 // consumes the materialised ImuError outputs (res[n][15], eight Jacobian blocks) of launch_imu; one wave per factor
@@ -1452,22 +1495,33 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
     hipLaunchKernelGGL(k_zero_multi, dim3(512, k), dim3(kT), 0, q, z);
   }
   double* cost = p->scal.p + SC_COST;
+  const bool tf_fast = p->tf && p->tf->n && p->tf_work.n && p->n_kf <= kMaxStagedKf;
+  if (tf_fast) {
+    LinVisual a{};
+    a.n_tfw = (int)p->tf_work.n; a.work = p->tf_work.p; a.tf_fo = (const double2*)p->tf->ob_a.p; a.tf_ob = (const double2*)p->tf->ob_b.p;
+    a.tf_lm = p->tf->idx_a.p; a.tf_k1 = p->tf->idx_b.p; a.tf_left = p->tf->cam_a; a.tf_right = p->tf->cam_b; a.unique_lk2 = p->tf_unique_lk2 ? 1 : 0;
+    if (p->tc && p->tc->n) {
+      a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p;
+      a.tc_left = p->tc->cam_a; a.tc_right = p->tc->cam_b;
+    }
+    if (p->po && p->po->n) {
+      a.n_po = p->po->n; a.po_ob = (const double2*)p->po->ob_a.p; a.po_kf = p->po->idx_a.p; a.po_pwi = p->po->idx_b.p; a.po_pw = p->po->table.p; a.po_cam = p->po->cam_a;
+    }
+    a.g_tc = grid(a.n_tc);
+    hipLaunchKernelGGL(k_lin_visual, dim3(a.n_tfw + a.g_tc + grid(a.n_po)), dim3(kT), 0, q, a, p->n_kf, s, huber, p->pose_const.p, p->B.p, p->dpad, p->gc.p,
+                       p->E.p, p->ldE, p->C.p, p->gr.p, cost);
+  } else {
   if (p->tc && p->tc->n)
     hipLaunchKernelGGL(k_lin_tc<false>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
                        p->tc->idx_a.p, p->tc->idx_b.p, s, p->tc->cam_a, p->tc->cam_b, huber, p->C.p, p->gr.p, cost);
-  if (p->tf && p->tf->n) {
-    if (p->tf_work.n && p->n_kf <= kMaxStagedKf)
-      hipLaunchKernelGGL(k_lin_tf_sorted, dim3((unsigned)p->tf_work.n), dim3(kT), 0, q, p->tf_work.p, p->n_kf, (const double2*)p->tf->ob_a.p,
-                         (const double2*)p->tf->ob_b.p, p->tf->idx_a.p, p->tf->idx_b.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p,
-                         p->B.p, p->dpad, p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost, p->tf_unique_lk2 ? 1 : 0);
-    else
-      hipLaunchKernelGGL(k_lin_tf<false>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
-                         p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, p->B.p, p->dpad,
-                         p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
-  }
+  if (p->tf && p->tf->n)
+    hipLaunchKernelGGL(k_lin_tf<false>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
+                       p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, p->B.p, p->dpad,
+                       p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
   if (p->po && p->po->n)
     hipLaunchKernelGGL(k_lin_po<false>, dim3(grid(p->po->n)), dim3(kT), 0, q, p->po->n, p->n_kf, (const double2*)p->po->ob_a.p, p->po->idx_a.p,
                        p->po->idx_b.p, p->po->table.p, s, p->po->cam_a, huber, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
+  }
   if (p->imu && p->imu->n) {
     LVF_TRY(launch_imu(p->imu, p->st, true));
     ImuJ J;
