@@ -460,33 +460,6 @@ __global__ __launch_bounds__(kT) void k_lin_po(int n, int n_kf, const double2* _
                                                double huber, const uint8_t* __restrict__ pose_const, double* __restrict__ B,
                                                int ld, double* __restrict__ gc, double* __restrict__ cost) { lin_po_body<COST_ONLY>(blockIdx.x, n, n_kf, ob, kf, pwi, pw, s, cam, huber, pose_const, B, ld, gc, cost); }
 
-// ------------------------------------------------------------------------------------------------ linearisation, visual factors
-// The TwoFrame (sorted fast path), TwoCamera and PoseOnly linearisations as ONE launch: workgroups [0, n_tfw) take the TwoFrame
-// work list, the next g_tc the TwoCamera blocks, the rest the PoseOnly blocks.  The two small passes (4.6 + 8.8 us as launches of
-// their own) disappear under the TwoFrame pass; all three only meet in B, gc, C, g_rho through atomics.
-struct LinVisual {
-  int n_tfw, g_tc;
-  // TwoFrame
-  const TfWork* work; const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1; CamD tf_left, tf_right; int unique_lk2;
-  // TwoCamera
-  int n_tc; const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; CamD tc_left, tc_right;
-  // PoseOnly
-  int n_po; const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
-};
-__global__ __launch_bounds__(kT) void k_lin_visual(LinVisual a, int n_kf, StateP s, double huber, const uint8_t* __restrict__ pose_const,
-                                                   double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ E, int ldE,
-                                                   double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost) {
-  const int b = blockIdx.x;
-  if (b < a.n_tfw)
-    lin_tf_sorted_body(b, a.work, n_kf, a.tf_fo, a.tf_ob, a.tf_lm, a.tf_k1, s, a.tf_left, a.tf_right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost,
-                       a.unique_lk2);
-  else if (b < a.n_tfw + a.g_tc)
-    lin_tc_body<false>(b - a.n_tfw, a.n_tc, a.tc_lo, a.tc_ro, a.tc_lm, a.tc_kf, s, a.tc_left, a.tc_right, huber, C, gr, cost);
-  else
-    lin_po_body<false>(b - a.n_tfw - a.g_tc, a.n_po, n_kf, a.po_ob, a.po_kf, a.po_pwi, a.po_pw, s, a.po_cam, huber, pose_const, B, ld, gc, cost);
-}
-
-
 // ------------------------------------------------------------------------------------------------ IMU
 // consumes the materialised ImuError outputs (res[n][15], eight Jacobian blocks) of launch_imu; one wave per factor
 struct ImuJ { const double* j[8]; };
@@ -544,6 +517,100 @@ __global__ __launch_bounds__(64) void k_lin_imu(int n, int n_kf, const double* _
     atomicAdd(&gc[sidx[lane]], g);
   }
 }
+
+// the same accumulation for use inside a 256-thread workgroup: wave w of virtual block vb takes factor 4 vb + w
+__device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, const double* __restrict__ res, ImuJ J, const int* __restrict__ kf_i,
+                                              const int* __restrict__ kf_j, const double* __restrict__ poses,
+                                              const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
+                                              double* __restrict__ gc, double* __restrict__ cost) {
+  __shared__ double sJ4[4][15 * 30];
+  __shared__ double sr4[4][15];
+  __shared__ int sidx4[4][30];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int f = 4 * vb + w;
+  const bool active = f < n;
+  double* sJ = sJ4[w]; double* sr = sr4[w]; int* sidx = sidx4[w];
+  if (active) {
+    const int ki = kf_i[f], kj = kf_j[f];
+    if (lane < 15) sr[lane] = res[(size_t)f * 15 + lane];
+    if (lane < 30) {
+      int g;
+      if (lane < 6) g = 6 * ki + lane; else if (lane < 15) g = 6 * n_kf + 9 * ki + (lane - 6);
+      else if (lane < 21) g = 6 * kj + (lane - 15); else g = 6 * n_kf + 9 * kj + (lane - 21);
+      sidx[lane] = g;
+    }
+    for (int e = lane; e < 30; e += 64) {
+      const int row = e % 15, which = e / 15;            // which: 0 = pose_i, 1 = pose_j
+      const double* Jr = J.j[which ? 4 : 0] + (size_t)f * 105 + 7 * row;
+      const int kk = which ? kj : ki;
+      const double* q = poses + 7 * kk;
+      const double sc = pose_const[kk] ? 0.0 : 1.0;
+      double l3[3];
+      quat_row_to_local(Jr, q, l3);
+      double* o = sJ + row * 30 + (which ? 15 : 0);
+      o[0] = sc * l3[0]; o[1] = sc * l3[1]; o[2] = sc * l3[2]; o[3] = sc * Jr[4]; o[4] = sc * Jr[5]; o[5] = sc * Jr[6];
+    }
+    for (int e = lane; e < 15 * 18; e += 64) {           // six 15x3 blocks
+      const int row = e / 18, c = e % 18, blk = c / 3, cc = c % 3;   // blk 0..2 -> (v,ba,bg)_i ; 3..5 -> _j
+      const int src = blk < 3 ? 1 + blk : 5 + (blk - 3);
+      sJ[row * 30 + (blk < 3 ? 6 + 3 * blk : 21 + 3 * (blk - 3)) + cc] = J.j[src][(size_t)f * 45 + 3 * row + cc];
+    }
+  }
+  __syncthreads();
+  double c = 0.0;
+  if (active && lane < 15) c = 0.5 * sr[lane] * sr[lane];
+  c = wave_sum(c);
+  if (!active) return;
+  if (lane == 0) atomicAdd(cost + (f & (kStripes - 1)), c);
+  for (int e = lane; e < 30 * 30; e += 64) {
+    const int a = e / 30, b = e % 30;
+    const int ga = sidx[a], gb = sidx[b];
+    if (gb > ga || (ga == gb && a != b)) continue;    // lower triangle in GLOBAL indices (kf_i != kf_j is validated)
+    double h = 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) h += sJ[k * 30 + a] * sJ[k * 30 + b];
+    atomicAdd(&B[(size_t)ga * ld + gb], h);
+  }
+  if (lane < 30) {
+    double g = 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) g += sJ[k * 30 + lane] * sr[k];
+    atomicAdd(&gc[sidx[lane]], g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ linearisation, visual factors
+// The TwoFrame (sorted fast path), TwoCamera and PoseOnly linearisations as ONE launch: workgroups [0, n_tfw) take the TwoFrame
+// work list, the next g_tc the TwoCamera blocks, the rest the PoseOnly blocks.  The two small passes (4.6 + 8.8 us as launches of
+// their own) disappear under the TwoFrame pass; all three only meet in B, gc, C, g_rho through atomics.  A fourth segment
+// accumulates the ImuError blocks (four factors per workgroup) from the Jacobians k_imu<true> materialised just before.
+struct LinVisual {
+  int n_tfw, g_tc;
+  // TwoFrame
+  const TfWork* work; const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1; CamD tf_left, tf_right; int unique_lk2;
+  // TwoCamera
+  int n_tc; const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; CamD tc_left, tc_right;
+  // PoseOnly
+  int n_po, g_po; const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
+  // ImuError (already evaluated)
+  int n_imu; const double* imu_res; ImuJ imu_J; const int *imu_i, *imu_j;
+};
+__global__ __launch_bounds__(kT) void k_lin_visual(LinVisual a, int n_kf, StateP s, double huber, const uint8_t* __restrict__ pose_const,
+                                                   double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ E, int ldE,
+                                                   double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost) {
+  const int b = blockIdx.x;
+  if (b < a.n_tfw)
+    lin_tf_sorted_body(b, a.work, n_kf, a.tf_fo, a.tf_ob, a.tf_lm, a.tf_k1, s, a.tf_left, a.tf_right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost,
+                       a.unique_lk2);
+  else if (b < a.n_tfw + a.g_tc)
+    lin_tc_body<false>(b - a.n_tfw, a.n_tc, a.tc_lo, a.tc_ro, a.tc_lm, a.tc_kf, s, a.tc_left, a.tc_right, huber, C, gr, cost);
+  else if (b < a.n_tfw + a.g_tc + a.g_po)
+    lin_po_body<false>(b - a.n_tfw - a.g_tc, a.n_po, n_kf, a.po_ob, a.po_kf, a.po_pwi, a.po_pw, s, a.po_cam, huber, pose_const, B, ld, gc, cost);
+  else
+    lin_imu_body4(b - a.n_tfw - a.g_tc - a.g_po, a.n_imu, n_kf, a.imu_res, a.imu_J, a.imu_i, a.imu_j, s.poses, pose_const, B, ld, gc, cost);
+}
+
+
 // ------------------------------------------------------------------------------------------------ pose priors
 // consumes the materialised PoseGraphError / PoseError outputs of launch_pose_prior (res[n][6], ja/jb [n][6][7]); no loss
 // function (backend.cpp:171,176).  <= n_kf blocks: one thread per block, global atomics.
@@ -1496,6 +1563,7 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
   }
   double* cost = p->scal.p + SC_COST;
   const bool tf_fast = p->tf && p->tf->n && p->tf_work.n && p->n_kf <= kMaxStagedKf;
+  bool imu_done = false;
   if (tf_fast) {
     LinVisual a{};
     a.n_tfw = (int)p->tf_work.n; a.work = p->tf_work.p; a.tf_fo = (const double2*)p->tf->ob_a.p; a.tf_ob = (const double2*)p->tf->ob_b.p;
@@ -1507,9 +1575,15 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
     if (p->po && p->po->n) {
       a.n_po = p->po->n; a.po_ob = (const double2*)p->po->ob_a.p; a.po_kf = p->po->idx_a.p; a.po_pwi = p->po->idx_b.p; a.po_pw = p->po->table.p; a.po_cam = p->po->cam_a;
     }
-    a.g_tc = grid(a.n_tc);
-    hipLaunchKernelGGL(k_lin_visual, dim3(a.n_tfw + a.g_tc + grid(a.n_po)), dim3(kT), 0, q, a, p->n_kf, s, huber, p->pose_const.p, p->B.p, p->dpad, p->gc.p,
-                       p->E.p, p->ldE, p->C.p, p->gr.p, cost);
+    a.g_tc = grid(a.n_tc); a.g_po = grid(a.n_po);
+    if (p->imu && p->imu->n) {
+      LVF_TRY(launch_imu(p->imu, p->st, true));           // residuals + Jacobians first; their accumulation rides in the launch below
+      a.n_imu = p->imu->n; a.imu_res = p->imu->res.p; a.imu_i = p->imu->idx_a.p; a.imu_j = p->imu->idx_b.p;
+      for (int k = 0; k < 8; ++k) a.imu_J.j[k] = p->imu->jac[k].p;
+      imu_done = true;
+    }
+    hipLaunchKernelGGL(k_lin_visual, dim3(a.n_tfw + a.g_tc + a.g_po + (a.n_imu + 3) / 4), dim3(kT), 0, q, a, p->n_kf, s, huber, p->pose_const.p, p->B.p,
+                       p->dpad, p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
   } else {
   if (p->tc && p->tc->n)
     hipLaunchKernelGGL(k_lin_tc<false>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
@@ -1522,7 +1596,7 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
     hipLaunchKernelGGL(k_lin_po<false>, dim3(grid(p->po->n)), dim3(kT), 0, q, p->po->n, p->n_kf, (const double2*)p->po->ob_a.p, p->po->idx_a.p,
                        p->po->idx_b.p, p->po->table.p, s, p->po->cam_a, huber, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
   }
-  if (p->imu && p->imu->n) {
+  if (p->imu && p->imu->n && !imu_done) {
     LVF_TRY(launch_imu(p->imu, p->st, true));
     ImuJ J;
     for (int k = 0; k < 8; ++k) J.j[k] = p->imu->jac[k].p;
