@@ -1431,11 +1431,11 @@ __global__ __launch_bounds__(kBT) void k_chol_backsolve(const double* S, int ld,
 // landmark back-substitution: dl = (-gr - e_l . dx_pose) / Cd ; model terms and norms
 // (on DENSE rows one thread per landmark beat a wave per landmark, 25.6 vs 29.9 us; with the row limited to the landmark's track
 // a per-thread walk diverges (41-54 us) and 16 lanes per landmark is the right shape)
-__global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE, const double* __restrict__ E, const double* __restrict__ C,
-                                                      const double* __restrict__ Cd, const double* __restrict__ gr,
-                                                      const double* __restrict__ dxc, const double* __restrict__ inv_depth,
-                                                      double* __restrict__ dxl, double* __restrict__ scal, const int* __restrict__ kmin,
-                                                      const int* __restrict__ kmax, const int* __restrict__ order) {
+__device__ __forceinline__ void landmark_back_body(const int vb, const int nwg, int n_lm, int dp, int ldE, const double* __restrict__ E,
+                                                   const double* __restrict__ C, const double* __restrict__ Cd, const double* __restrict__ gr,
+                                                   const double* __restrict__ dxc, const double* __restrict__ inv_depth,
+                                                   double* __restrict__ dxl, double* __restrict__ invd2, double* __restrict__ scal,
+                                                   const int* __restrict__ kmin, const int* __restrict__ kmax) {
   extern __shared__ double sdx[];
   for (int i = threadIdx.x; i < dp; i += kT) sdx[i] = dxc[i];
   __syncthreads();
@@ -1444,7 +1444,7 @@ __global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE,
   // atomics on the 32 striped slots were most of this kernel's time)
   const int q = threadIdx.x & 15;
   double m = 0.0, n2 = 0.0, x2 = 0.0;
-  for (int l = blockIdx.x * (kT / 16) + (threadIdx.x >> 4); l < n_lm; l += gridDim.x * (kT / 16)) {
+  for (int l = vb * (kT / 16) + (threadIdx.x >> 4); l < n_lm; l += nwg * (kT / 16)) {
     const double* e = E + (size_t)l * ldE;
     double ed = 0.0;
     const int i0 = kmin ? 6 * min(kmin[l], dp / 6) : 0, i1 = kmin ? 6 * (kmax[l] + 1) : dp;   // the row is zero outside the landmark's track
@@ -1453,6 +1453,7 @@ __global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE,
     if (q == 0) {
       const double dl = (-gr[l] - ed) / Cd[l];
       dxl[l] = dl;
+      invd2[l] = inv_depth[l] + dl;                 // the candidate inverse depth (was a second pass in k_apply_step)
       m += -0.5 * dl * ((Cd[l] - C[l]) * dl - gr[l]);
       n2 += dl * dl; x2 += inv_depth[l] * inv_depth[l];
     }
@@ -1465,7 +1466,7 @@ __global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE,
     double v = 0.0;
     for (int k = 0; k < kT / 64; ++k) v += red[threadIdx.x][k];
     double* dst = scal + (threadIdx.x == 0 ? SC_MODEL : (threadIdx.x == 1 ? SC_DXNORM : SC_XNORM));
-    if (v != 0.0) atomicAdd(dst + (blockIdx.x & (kStripes - 1)), v);
+    if (v != 0.0) atomicAdd(dst + (vb & (kStripes - 1)), v);
   }
 }
 // Model cost change without a pass over H:  (H + D) dx = -g  =>  -dx^T (g + H dx / 2) = 1/2 sum_i dx_i (D_i dx_i - g_i).
@@ -1473,11 +1474,11 @@ __global__ __launch_bounds__(kT) void k_landmark_back(int n_lm, int dp, int ldE,
 // (host flips the sign), keeping the convention model = -SC_MODEL.
 // x_new = x [+] dx  (EigenQuaternionParameterization::Plus on the quaternion, plain add elsewhere)
 // ... fused with the camera part of the model cost change (k_model_cam's body; d <= 15 n_kf threads of the same grid)
-__global__ __launch_bounds__(kT) void k_apply_step(int n_kf, int n_lm, StateP s, const double* __restrict__ dxc, const double* __restrict__ dxl,
-                                                   double* __restrict__ poses2, double* __restrict__ vel2, double* __restrict__ ba2,
-                                                   double* __restrict__ bg2, double* __restrict__ invd2, double* __restrict__ scal, int d, int ld,
-                                                   const double* __restrict__ B, const double* __restrict__ gc, double inv_radius) {
-  const int i = blockIdx.x * kT + threadIdx.x;
+__device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm, StateP s, const double* __restrict__ dxc, const double* __restrict__ dxl,
+                                                double* __restrict__ poses2, double* __restrict__ vel2, double* __restrict__ ba2,
+                                                double* __restrict__ bg2, double* __restrict__ invd2, double* __restrict__ scal, int d, int ld,
+                                                const double* __restrict__ B, const double* __restrict__ gc, double inv_radius) {
+  const int i = vb * kT + threadIdx.x;
   {
     double m = 0.0, n2 = 0.0, g = 0.0;
     if (i < d) {
@@ -1486,7 +1487,7 @@ __global__ __launch_bounds__(kT) void k_apply_step(int n_kf, int n_lm, StateP s,
       n2 = dx * dx;
       g = fabs(gc[i]);
     }
-    if (blockIdx.x * kT < d) {      // block-uniform
+    if (vb * kT < d) {      // block-uniform
       block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM);
       for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_down(g, o));
       if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX), (unsigned long long)__double_as_longlong(g));
@@ -1514,6 +1515,19 @@ __global__ __launch_bounds__(kT) void k_apply_step(int n_kf, int n_lm, StateP s,
   }
   if (i < n_lm) invd2[i] = s.inv_depth[i] + dxl[i];
   block_add(x2, scal + SC_XNORM);
+}
+
+// landmark back-substitution and the camera-side step / model terms as ONE launch: workgroups [0, g_lm) walk the landmarks,
+// the rest apply dx to the keyframe states (independent of the landmark results)
+__global__ __launch_bounds__(kT) void k_step_tail(int g_lm, int n_lm, int dp, int ldE, const double* __restrict__ E, const double* __restrict__ C,
+                                                  const double* __restrict__ Cd, const double* __restrict__ gr, const double* __restrict__ dxc,
+                                                  double* __restrict__ dxl, double* __restrict__ scal, const int* __restrict__ kmin,
+                                                  const int* __restrict__ kmax, int n_kf, StateP s, double* __restrict__ poses2,
+                                                  double* __restrict__ vel2, double* __restrict__ ba2, double* __restrict__ bg2,
+                                                  double* __restrict__ invd2, int d, int ld, const double* __restrict__ B,
+                                                  const double* __restrict__ gc, double inv_radius) {
+  if ((int)blockIdx.x < g_lm) landmark_back_body(blockIdx.x, g_lm, n_lm, dp, ldE, E, C, Cd, gr, dxc, s.inv_depth, dxl, invd2, scal, kmin, kmax);
+  else apply_step_body(blockIdx.x - g_lm, n_kf, 0, s, dxc, dxl, poses2, vel2, ba2, bg2, invd2, scal, d, ld, B, gc, inv_radius);
 }
 
 // ================================================================================================ host side
@@ -1676,12 +1690,12 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(kBT), sh, q, Sd, p->ld, p->ndense, p->Dinv.p, p->dxc.p, sb);
   // model / norms / candidate state
   const StateP s = state_ptrs(p->st);
-  if (p->n_lm)
-    hipLaunchKernelGGL(k_landmark_back, dim3(std::min(256, (p->n_lm + kT / 16 - 1) / (kT / 16))), dim3(kT), (size_t)p->ldE * sizeof(double), q, p->n_lm, p->dp, p->ldE, p->E.p, p->C.p, p->Cd.p,
-                       p->gr.p, p->dxc.p, p->st->inv_depth.p, p->dxl.p, p->scal.p, p->band_ready ? p->lm_kmin.p : nullptr, p->lm_kmax.p,
-                       p->band_ready ? p->lm_order.p : nullptr);
-  hipLaunchKernelGGL(k_apply_step, dim3(grid(std::max(p->d, p->n_lm))), dim3(kT), 0, q, p->n_kf, p->n_lm, s, p->dxc.p, p->dxl.p, p->poses2.p,
-                     p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->scal.p, p->d, p->dpad, p->B.p, p->gc.p, inv_r);
+  {
+    const int g_lm = p->n_lm ? std::min(256, (p->n_lm + kT / 16 - 1) / (kT / 16)) : 0;
+    hipLaunchKernelGGL(k_step_tail, dim3(g_lm + grid(p->d)), dim3(kT), (size_t)p->ldE * sizeof(double), q, g_lm, p->n_lm, p->dp, p->ldE, p->E.p, p->C.p,
+                       p->Cd.p, p->gr.p, p->dxc.p, p->dxl.p, p->scal.p, p->band_ready ? p->lm_kmin.p : nullptr, p->lm_kmax.p, p->n_kf, s, p->poses2.p,
+                       p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->d, p->dpad, p->B.p, p->gc.p, inv_r);
+  }
   LVF_HIP(hipGetLastError());
   // candidate cost
   lvf_state view;   // borrowed pointers: a state-shaped view of the candidate buffers for launch_imu
