@@ -888,14 +888,14 @@ __global__ __launch_bounds__(1024) void k_lm_sort(int n_lm, int n_kf, const int*
   for (int l = threadIdx.x; l < n_lm; l += 1024) order[atomicAdd(&bucket[lm_sort_key(kmin[l], kmax[l], n_kf)], 1)] = l;
 }
 
-__global__ __launch_bounds__(256) void k_schur_band(int dp, int ldE, const double* __restrict__ E, const double* __restrict__ Cd,
-                                                    const int* __restrict__ order, const int* __restrict__ n_active_p,
-                                                    const int* __restrict__ kmin, const int* __restrict__ kmax, int d, int ldS,
-                                                    double* __restrict__ S) {
+__device__ __forceinline__ void schur_band_body(const int bx, const int by, int dp, int ldE, const double* __restrict__ E,
+                                                const double* __restrict__ Cd, const int* __restrict__ order, const int* __restrict__ n_active_p,
+                                                const int* __restrict__ kmin, const int* __restrict__ kmax, int d, int ldS,
+                                                double* __restrict__ S) {
   extern __shared__ double sh[];          // Es[kSchurRows][ldl] | icd[kSchurRows] | rowid (int)[kBandRows]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lk = lane >> 4, lc = lane & 15;
   const int n_active = *n_active_p;
-  const int k_begin = blockIdx.x * kBandRows, k_end = min(n_active, k_begin + kBandRows);
+  const int k_begin = bx * kBandRows, k_end = min(n_active, k_begin + kBandRows);
   if (k_begin >= k_end) return;
   // the slice's band (every wave reduces it for itself: two rows per lane)
   int lo = 0x7fffffff, hi = -1;
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256) void k_schur_band(int dp, int ldE, const doubl
   const int nbt = t1 - t0 + 1, tri = nbt * (nbt + 1) / 2;
   const bool extra = tl > t1;                                  // the g_rho column's tile lies outside the band
   const int ntiles = tri + (extra ? nbt : 0);
-  const int tbase = blockIdx.y * kBandTilesPerGroup;
+  const int tbase = by * kBandTilesPerGroup;
   if (tbase >= ntiles) return;
   const int ldl = 16 * (nbt + (extra ? 1 : 0));                // staged doubles per row
   double* Es = sh;
@@ -986,6 +986,12 @@ __global__ __launch_bounds__(256) void k_schur_band(int dp, int ldE, const doubl
   }
 }
 
+__global__ __launch_bounds__(256) void k_schur_band(int dp, int ldE, const double* __restrict__ E, const double* __restrict__ Cd,
+                                                    const int* __restrict__ order, const int* __restrict__ n_active_p,
+                                                    const int* __restrict__ kmin, const int* __restrict__ kmax, int d, int ldS,
+                                                    double* __restrict__ S) {
+  schur_band_body(blockIdx.x, blockIdx.y, dp, ldE, E, Cd, order, n_active_p, kmin, kmax, d, ldS, S);
+}
 struct LmBand { const int* order; const int* n_active; const int* kmin; const int* kmax; };   // null order => dense SYRK
 static int launch_schur(hipStream_t q, int n_lm, int dp, int ldE, const double* E, const double* Cd, int d, int ldS, double* S, const LmBand& band) {
   const int nt = ldE / 16, ntile = nt * (nt + 1) / 2;
@@ -1173,11 +1179,11 @@ __global__ __launch_bounds__(256) void k_chol_update(double* S, int ld, int kb) 
 //   L_bb = chol(S_bb) (wave 0, lane = row, pivots broadcast by v_readlane);  W = S_Nb L_bb^-T (thread per row);
 //   S_NN -= W W^T (pairs split over the tiles; atomics, because blocks of one level share neighbours).
 // W and L_bb go to side buffers (the eliminated columns of S are never read again), so the tiles of a block never race.
-__global__ __launch_bounds__(256) void k_sp_eliminate(const SpNode* __restrict__ nodes, int first, int tiles, const int* __restrict__ rows,
-                                                      double* __restrict__ S, int ld, double* __restrict__ W, int wstride,
-                                                      double* __restrict__ Lout, int* __restrict__ fail) {
+__device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __restrict__ nodes, int first, int tiles, const int* __restrict__ rows,
+                                                  double* __restrict__ S, int ld, double* __restrict__ W, int wstride,
+                                                  double* __restrict__ Lout, int* __restrict__ fail) {
   extern __shared__ double sp_sm[];        // Ws[m][9] | L[81] | linv[9] | rws[m] (int)
-  const int ni = first + blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
+  const int ni = first + vb / tiles, tile = vb % tiles, tid = threadIdx.x;
   const SpNode nd = nodes[ni];
   const int m = nd.m, col = nd.col;
   double* Ws = sp_sm;
@@ -1251,6 +1257,24 @@ __global__ __launch_bounds__(256) void k_sp_eliminate(const SpNode* __restrict__
     for (int c = 0; c < 9; ++c) v += wr[c] * wc[c];
     if (v != 0.0) atomicAdd(&S[(size_t)rws[r] * ld + rws[c2]], -v);
   }
+}
+__global__ __launch_bounds__(256) void k_sp_eliminate(const SpNode* __restrict__ nodes, int first, int tiles, const int* __restrict__ rows,
+                                                      double* __restrict__ S, int ld, double* __restrict__ W, int wstride,
+                                                      double* __restrict__ Lout, int* __restrict__ fail) {
+  sp_eliminate_body(blockIdx.x, nodes, first, tiles, rows, S, ld, W, wstride, Lout, fail);
+}
+// The band-limited Schur complement and the FIRST sparse level in one launch: both only ADD (atomically) into entries of S the other
+// does not read — the Schur complement touches the pose corner and the pose part of the rhs row, level 0 reads its own (v,ba,bg)
+// columns — so they are independent; later levels depend on level 0 and stay launches of their own.
+__global__ __launch_bounds__(256) void k_schur_sp0(int n_slices, int n_groups, int dp, int ldE, const double* __restrict__ E,
+                                                   const double* __restrict__ Cd, const int* __restrict__ order, const int* __restrict__ n_active_p,
+                                                   const int* __restrict__ kmin, const int* __restrict__ kmax, int d_local, int ldS,
+                                                   double* __restrict__ S_pose, const SpNode* __restrict__ nodes, int first, int tiles,
+                                                   const int* __restrict__ rows, double* __restrict__ S, double* __restrict__ W, int wstride,
+                                                   double* __restrict__ Lout, int* __restrict__ fail) {
+  const int b = blockIdx.x, ns = n_slices * n_groups;
+  if (b < ns) schur_band_body(b % n_slices, b / n_slices, dp, ldE, E, Cd, order, n_active_p, kmin, kmax, d_local, ldS, S_pose);
+  else sp_eliminate_body(b - ns, nodes, first, tiles, rows, S, ldS, W, wstride, Lout, fail);
 }
 
 struct SpBack {                    // what the back substitution needs of the plan
@@ -1628,16 +1652,29 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
 }
 
 // S (elimination order) = B + D - E^T Cd^-1 E, rhs row = -(gc - E^T Cd^-1 g_rho)
-static int enqueue_reduced_system(lvf_problem* p, double inv_r, double* scal) {
+static int enqueue_reduced_system(lvf_problem* p, double inv_r, double* scal, int* fail_flag_dev = nullptr, bool* level0_done = nullptr) {
   hipStream_t q = p->ctx->stream;
   const size_t nS = (size_t)p->ld * p->ld;
   const unsigned nSb = (unsigned)((nS + kT - 1) / kT);
   hipLaunchKernelGGL(k_prepare, dim3(nSb + (p->n_lm ? grid(p->n_lm) : 0)), dim3(kT), 0, q, p->ld, p->dpad, p->iperm.p, p->B.p, p->gc.p, inv_r, p->S.p, nSb,
                      p->n_lm, p->dp, p->ldE, p->C.p, p->gr.p, p->Cd.p, p->E.p, scal);
+  if (level0_done) *level0_done = false;
   if (p->n_lm) {
     // the Schur complement only touches the pose corner (local rhs row = dp)
-    const LmBand band{p->band_ready ? p->lm_order.p : nullptr, p->lm_nactive.p, p->lm_kmin.p, p->lm_kmax.p};
-    LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->dp, p->ld, p->S.p + (size_t)p->off_pose * (p->ld + 1), band));
+    double* S_pose = p->S.p + (size_t)p->off_pose * (p->ld + 1);
+    const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
+    const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRows * sizeof(int);
+    if (p->band_ready && shb <= 64 * 1024 && level0_done && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024) {
+      // band-limited Schur complement + first sparse level, one launch
+      const int n_slices = (p->n_lm + kBandRows - 1) / kBandRows, n_groups = (ntile + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
+      hipLaunchKernelGGL(k_schur_sp0, dim3(n_slices * n_groups + p->sp_levels.count[0] * p->sp_tiles[0]), dim3(256), std::max(shb, (size_t)p->sp_shmem[0]), q,
+                         n_slices, n_groups, p->dp, p->ldE, p->E.p, p->Cd.p, p->lm_order.p, p->lm_nactive.p, p->lm_kmin.p, p->lm_kmax.p, p->dp, p->ld, S_pose,
+                         p->sp_nodes.p, p->sp_levels.first[0], p->sp_tiles[0], p->sp_rows.p, p->S.p, p->sp_W.p, p->sp_wstride, p->sp_L.p, fail_flag_dev);
+      *level0_done = true;
+    } else {
+      const LmBand band{p->band_ready ? p->lm_order.p : nullptr, p->lm_nactive.p, p->lm_kmin.p, p->lm_kmax.p};
+      LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->dp, p->ld, S_pose, band));
+    }
   }
   LVF_HIP(hipGetLastError());
   return LVF_OK;
@@ -1648,8 +1685,9 @@ static int enqueue_reduced_system(lvf_problem* p, double inv_r, double* scal) {
 static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_flag_dev) {
   hipStream_t q = p->ctx->stream;
   const double inv_r = 1.0 / radius;
-  LVF_TRY(enqueue_reduced_system(p, inv_r, p->scal.p));
-  for (int lv = 0; lv < p->sp_levels.n; ++lv)
+  bool level0_done = false;
+  LVF_TRY(enqueue_reduced_system(p, inv_r, p->scal.p, fail_flag_dev, &level0_done));
+  for (int lv = level0_done ? 1 : 0; lv < p->sp_levels.n; ++lv)
     hipLaunchKernelGGL(k_sp_eliminate, dim3(p->sp_levels.count[lv] * p->sp_tiles[lv]), dim3(256), p->sp_shmem[lv], q, p->sp_nodes.p, p->sp_levels.first[lv],
                        p->sp_tiles[lv], p->sp_rows.p, p->S.p, p->ld, p->sp_W.p, p->sp_wstride, p->sp_L.p, fail_flag_dev);
   double* Sd = p->S.p + (size_t)p->off * (p->ld + 1);       // dense corner
