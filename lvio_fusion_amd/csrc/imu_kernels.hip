@@ -139,7 +139,19 @@ __global__ __launch_bounds__(64) void k_imu(int n, const double* __restrict__ pr
                                             const int* __restrict__ kf_i, const int* __restrict__ kf_j,
                                             const double* __restrict__ poses, const double* __restrict__ vel,
                                             const double* __restrict__ ba, const double* __restrict__ bg,
-                                            double* __restrict__ res, ImuOut out, double* __restrict__ cost_stripes) {
+                                            double* __restrict__ res, ImuOut out, double* __restrict__ cost_stripes, ZeroList zero,
+                                            int zero_wgs) {
+  if ((int)blockIdx.x >= n) {            // extra workgroups: clear the solver's accumulators (independent of the factors)
+    const unsigned long long t = (unsigned long long)(blockIdx.x - n) * 64 + threadIdx.x, nt = (unsigned long long)zero_wgs * 64;
+    for (int a = 0; a < zero.count; ++a) {
+      double* p = zero.p[a];
+      const unsigned long long cnt = zero.n[a], n2 = cnt / 2;
+      double2* p2 = reinterpret_cast<double2*>(p);
+      for (unsigned long long i = t; i < n2; i += nt) p2[i] = make_double2(0.0, 0.0);
+      if ((cnt & 1) && t == 0) p[cnt - 1] = 0.0;
+    }
+    return;
+  }
   __shared__ double sS[225];
   __shared__ double sM[15 * 32];
   __shared__ double sr0[15];
@@ -399,16 +411,18 @@ int launch_imu_sqrt_info(lvf_batch* b) {
   return LVF_OK;
 }
 
-int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j, double* cost_stripes) {
+int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j, double* cost_stripes, const ZeroList* zero) {
   if (b->n == 0) return LVF_OK;
+  const int zero_wgs = zero ? 4096 : 0;
+  const ZeroList zl = zero ? *zero : ZeroList{};
   ImuOut o;
   for (int k = 0; k < 8; ++k) o.j[k] = b->jac[k].p;
   if (want_j)
-    hipLaunchKernelGGL(k_imu<true>, dim3(b->n), dim3(64), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p, b->idx_a.p,
-                       b->idx_b.p, st->poses.p, st->vel.p, st->ba.p, st->bg.p, b->res.p, o, cost_stripes);
+    hipLaunchKernelGGL(k_imu<true>, dim3(b->n + zero_wgs), dim3(64), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p, b->idx_a.p,
+                       b->idx_b.p, st->poses.p, st->vel.p, st->ba.p, st->bg.p, b->res.p, o, cost_stripes, zl, zero_wgs);
   else
-    hipLaunchKernelGGL(k_imu<false>, dim3(b->n), dim3(64), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p, b->idx_a.p,
-                       b->idx_b.p, st->poses.p, st->vel.p, st->ba.p, st->bg.p, b->res.p, o, cost_stripes);
+    hipLaunchKernelGGL(k_imu<false>, dim3(b->n + zero_wgs), dim3(64), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p, b->idx_a.p,
+                       b->idx_b.p, st->poses.p, st->vel.p, st->ba.p, st->bg.p, b->res.p, o, cost_stripes, zl, zero_wgs);
   LVF_HIP(hipGetLastError());
   return LVF_OK;
 }

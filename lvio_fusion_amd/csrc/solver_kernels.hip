@@ -89,7 +89,7 @@ __device__ __forceinline__ void add_block66(double* __restrict__ B, int ld, int 
 
 // ------------------------------------------------------------------------------------------------ housekeeping
 // one launch zeroes every accumulator of a linearisation (B, gc, E, C, gr, scalars) instead of six fill kernels
-struct ZeroList { double* p[6]; unsigned long long n[6]; };
+// (ZeroList: lvf_internal.hpp)
 __global__ __launch_bounds__(kT) void k_zero_multi(ZeroList z) {
   double* p = z.p[blockIdx.y];
   const unsigned long long n = z.n[blockIdx.y], n2 = n / 2;
@@ -1591,17 +1591,21 @@ static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_st
 static int enqueue_linearize(lvf_problem* p, double huber) {
   hipStream_t q = p->ctx->stream;
   const StateP s = state_ptrs(p->st);
+  ZeroList z{};
   {
-    ZeroList z;
     int k = 0;
     auto add = [&](double* ptr, size_t n) { if (ptr && n) { z.p[k] = ptr; z.n[k] = n; ++k; } };
     add(p->B.p, (size_t)p->dpad * p->dpad); add(p->gc.p, p->dpad); add(p->scal.p, SC_N);
     if (p->n_lm) { add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
-    hipLaunchKernelGGL(k_zero_multi, dim3(512, k), dim3(kT), 0, q, z);
+    z.count = k;
   }
   double* cost = p->scal.p + SC_COST;
   const bool tf_fast = p->tf && p->tf->n && p->tf_work.n && p->n_kf <= kMaxStagedKf;
   bool imu_done = false;
+  // the accumulators are zeroed by extra workgroups of the IMU evaluation launch when there is one ahead of the merged linearisation
+  // (neither depends on the other); otherwise by a launch of their own
+  const bool zero_with_imu = tf_fast && p->imu && p->imu->n;
+  if (!zero_with_imu) hipLaunchKernelGGL(k_zero_multi, dim3(512, z.count), dim3(kT), 0, q, z);
   if (tf_fast) {
     LinVisual a{};
     a.n_tfw = (int)p->tf_work.n; a.work = p->tf_work.p; a.tf_fo = (const double2*)p->tf->ob_a.p; a.tf_ob = (const double2*)p->tf->ob_b.p;
@@ -1615,7 +1619,7 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
     }
     a.g_tc = grid(a.n_tc); a.g_po = grid(a.n_po);
     if (p->imu && p->imu->n) {
-      LVF_TRY(launch_imu(p->imu, p->st, true));           // residuals + Jacobians first; their accumulation rides in the launch below
+      LVF_TRY(launch_imu(p->imu, p->st, true, nullptr, &z));   // residuals + Jacobians (+ the zeroing) first; their accumulation rides in the launch below
       a.n_imu = p->imu->n; a.imu_res = p->imu->res.p; a.imu_i = p->imu->idx_a.p; a.imu_j = p->imu->idx_b.p;
       for (int k = 0; k < 8; ++k) a.imu_J.j[k] = p->imu->jac[k].p;
       imu_done = true;
