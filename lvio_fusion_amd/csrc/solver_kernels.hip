@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64) void k_lin_imu(int n, int n_kf, const double* _
   // pose blocks: 15 rows x (7 -> 6)
   for (int e = lane; e < 30; e += 64) {
     const int row = e % 15, which = e / 15;            // which: 0 = pose_i, 1 = pose_j
-    const double* Jr = J.j[which ? 4 : 0] + (size_t)f * 105 + 7 * row;
+    const double* Jr = (which ? J.j[4] : J.j[0]) + (size_t)f * 105 + 7 * row;
     const int kk = which ? kj : ki;
     const double* q = poses + 7 * kk;
     const double sc = pose_const[kk] ? 0.0 : 1.0;
@@ -494,7 +494,8 @@ __global__ __launch_bounds__(64) void k_lin_imu(int n, int n_kf, const double* _
   for (int e = lane; e < 15 * 18; e += 64) {           // six 15x3 blocks
     const int row = e / 18, c = e % 18, blk = c / 3, cc = c % 3;   // blk 0..2 -> (v,ba,bg)_i ; 3..5 -> _j
     const int src = blk < 3 ? 1 + blk : 5 + (blk - 3);
-    sJ[row * 30 + (blk < 3 ? 6 + 3 * blk : 21 + 3 * (blk - 3)) + cc] = J.j[src][(size_t)f * 45 + 3 * row + cc];
+    const double* jp = src == 1 ? J.j[1] : (src == 2 ? J.j[2] : (src == 3 ? J.j[3] : (src == 5 ? J.j[5] : (src == 6 ? J.j[6] : J.j[7]))));
+    sJ[row * 30 + (blk < 3 ? 6 + 3 * blk : 21 + 3 * (blk - 3)) + cc] = jp[(size_t)f * 45 + 3 * row + cc];
   }
   __syncthreads();
   double c = 0.0;
@@ -541,7 +542,7 @@ __device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, con
     }
     for (int e = lane; e < 30; e += 64) {
       const int row = e % 15, which = e / 15;            // which: 0 = pose_i, 1 = pose_j
-      const double* Jr = J.j[which ? 4 : 0] + (size_t)f * 105 + 7 * row;
+      const double* Jr = (which ? J.j[4] : J.j[0]) + (size_t)f * 105 + 7 * row;
       const int kk = which ? kj : ki;
       const double* q = poses + 7 * kk;
       const double sc = pose_const[kk] ? 0.0 : 1.0;
@@ -553,7 +554,10 @@ __device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, con
     for (int e = lane; e < 15 * 18; e += 64) {           // six 15x3 blocks
       const int row = e / 18, c = e % 18, blk = c / 3, cc = c % 3;   // blk 0..2 -> (v,ba,bg)_i ; 3..5 -> _j
       const int src = blk < 3 ? 1 + blk : 5 + (blk - 3);
-      sJ[row * 30 + (blk < 3 ? 6 + 3 * blk : 21 + 3 * (blk - 3)) + cc] = J.j[src][(size_t)f * 45 + 3 * row + cc];
+      // (static indices only: indexing the by-value pointer table with a run-time value puts it in scratch memory, and a kernel with a
+      // scratch segment pays several microseconds of dispatch set-up)
+      const double* jp = src == 1 ? J.j[1] : (src == 2 ? J.j[2] : (src == 3 ? J.j[3] : (src == 5 ? J.j[5] : (src == 6 ? J.j[6] : J.j[7]))));
+      sJ[row * 30 + (blk < 3 ? 6 + 3 * blk : 21 + 3 * (blk - 3)) + cc] = jp[(size_t)f * 45 + 3 * row + cc];
     }
   }
   __syncthreads();
