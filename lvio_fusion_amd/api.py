@@ -193,6 +193,14 @@ def relative_rpyxyz(last_pose, pose):
     return out
 
 
+def prior3_evaluate(ctx, mode, target3, weight, x3):
+    """PoseErrorRPZ / PoseErrorYXY stand-alone (lvf_prior3_evaluate): returns r[3], J[3 blocks][3 rows]."""
+    t, x = _d(target3), _d(x3)
+    r, J = np.empty(3), np.empty(9)
+    _chk(ctx.L.lvf_prior3_evaluate(ctx.h, int(mode), _dp(t), C.c_double(weight), _dp(x), _dp(r), _dp(J)))
+    return r, J.reshape(3, 3)
+
+
 def preintegrate(ctx, samples_list, acc0, gyr0, ba, bg, noise4):
     n = len(samples_list)
     offset = np.zeros(n + 1, np.int32)

@@ -1,4 +1,7 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).
+// PARITY PINNED to the reference's own text: tests/test_oracle_ref.py compares this restatement BIT-FOR-BIT with oracle/_ref
+// (the reference's ceres/{base,visual_error,lidar_error,pose_error}.hpp compiled unmodified, oracle/ref_driver.cpp) and with the
+// committed reference outputs tests/golden/ref_v1.npz.
 //
 // factors.h — the reference cost functors' templated operator() restated on plain arrays.
 // Instantiated on double (residual only) and on Jet<N> (residual + exact ambient Jacobian,
@@ -190,6 +193,24 @@ inline void PosePriorResidual(const double origin_[7], double weight, double v, 
 template <typename T>
 inline void RErrorResidual(const double origin_[7], double weight, const T* pose, T* r) {
   for (int k = 0; k < 4; ++k) r[k] = T(weight) * (pose[k] - T(origin_[k]));
+}
+
+// TError::operator()  pose_error.hpp:117-122   <3,7>
+template <typename T>
+inline void TErrorResidual(const double p_[3], double weight, const T* pose, T* r) {
+  for (int k = 0; k < 3; ++k) r[k] = T(weight) * (pose[4 + k] - T(p_[k]));
+}
+
+// RelocateRError::operator()  pose_error.hpp:197-214   <7,4>: the single parameter block is a quaternion r = (x,y,z,w);
+// residual = relocated - SE3Product([r, 0], unrelocated), all seven SE3 coefficients (relocator.cpp:261)
+template <typename T>
+inline void RelocateRResidual(const double relocated_[7], const double unrelocated_[7], const T* r4, T* res) {
+  T R[7] = {r4[0], r4[1], r4[2], r4[3], T(0), T(0), T(0)};
+  T unrelocated[7];
+  CastFrom(unrelocated_, 7, unrelocated);
+  T R_unrelocated[7];
+  Se3Mul(R, unrelocated, R_unrelocated);
+  for (int k = 0; k < 7; ++k) res[k] = T(relocated_[k]) - R_unrelocated[k];
 }
 
 // PoseErrorRPZ::operator() pose_error.hpp:147-153 (params p,r,z; note residual order r,p,z)

@@ -1,4 +1,5 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED (Ceres is external: solver semantics are DECLARED);
+// independently checked against a numpy dense normal-equation solve over all unknowns in tests/test_oracle_lm_numpy.py.
 //
 // icp.h — one scan-to-map sub-problem as the reference builds and solves it:
 //   FeatureAssociation::ScanToMapWithGround / ScanToMapWithSegmented   src/lvio_fusion/src/association.cpp:270-384

@@ -1,4 +1,5 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED (Ceres is external: solver semantics are DECLARED);
+// independently checked against a numpy dense normal-equation solve over all unknowns in tests/test_oracle_lm_numpy.py.
 //
 // lm.h — one sliding-window BA problem as Backend::BuildProblem assembles it
 // (src/lvio_fusion/src/backend.cpp:96-183) and one Levenberg-Marquardt iteration as ceres::Solve would

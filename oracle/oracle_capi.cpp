@@ -168,6 +168,19 @@ void lvo_r_error_eval(const double* origin, double weight, const double* pose, d
   RErrorResidual(origin, weight, T, rr);
   for (int a = 0; a < 4; ++a) { r[a] = rr[a].a; if (J) for (int k = 0; k < 7; ++k) J[7 * a + k] = rr[a].v[k]; }
 }
+void lvo_t_error_eval(const double* p3, double weight, const double* pose, double* r, double* J) {
+  Jet<7> T[7], rr[3];
+  for (int k = 0; k < 7; ++k) T[k] = Jet<7>(pose[k], k);
+  TErrorResidual(p3, weight, T, rr);
+  for (int a = 0; a < 3; ++a) { r[a] = rr[a].a; if (J) for (int k = 0; k < 7; ++k) J[7 * a + k] = rr[a].v[k]; }
+}
+// RelocateRError <7,4>: r[7], J[7][4]
+void lvo_relocate_r_eval(const double* relocated, const double* unrelocated, const double* q4, double* r, double* J) {
+  Jet<4> Q[4], rr[7];
+  for (int k = 0; k < 4; ++k) Q[k] = Jet<4>(q4[k], k);
+  RelocateRResidual(relocated, unrelocated, Q, rr);
+  for (int a = 0; a < 7; ++a) { r[a] = rr[a].a; if (J) for (int k = 0; k < 4; ++k) J[4 * a + k] = rr[a].v[k]; }
+}
 void lvo_prior3_eval(int mode, const double* rpyxyz0, double weight, const double* rpyxyz, double* r, double* J) {
   if (mode == 0) PriorRpzResidual<double>(rpyxyz0, weight, rpyxyz + 1, rpyxyz + 2, rpyxyz + 5, r);
   else PriorYxyResidual<double>(rpyxyz0, weight, rpyxyz + 0, rpyxyz + 3, rpyxyz + 4, r);

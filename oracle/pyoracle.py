@@ -19,7 +19,8 @@ IMU_J_COLS = (7, 3, 3, 3, 7, 3, 3, 3)
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".h", ".cpp")) and not f.startswith("ref_")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -156,6 +157,20 @@ def r_error(origin, weight, pose):
     o, p = _f64(origin), _f64(pose)
     r = np.empty(4); J = np.empty((4, 7))
     lib().lvo_r_error_eval(_p(o), C.c_double(weight), _p(p), _p(r), _p(J))
+    return r, J
+
+
+def t_error(p3, weight, pose):
+    t, p = _f64(p3), _f64(pose)
+    r = np.empty(3); J = np.empty((3, 7))
+    lib().lvo_t_error_eval(_p(t), C.c_double(weight), _p(p), _p(r), _p(J))
+    return r, J
+
+
+def relocate_r(relocated, unrelocated, q4):
+    a, b, q = map(_f64, (relocated, unrelocated, q4))
+    r = np.empty(7); J = np.empty((7, 4))
+    lib().lvo_relocate_r_eval(_p(a), _p(b), _p(q), _p(r), _p(J))
     return r, J
 
 

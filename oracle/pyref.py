@@ -1,0 +1,177 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes front-end of oracle/_ref/liblvf_ref.so: the REFERENCE's own cost functors
+(/root/reference/src/lvio_fusion/include/lvio_fusion/ceres/{base,visual_error,lidar_error,pose_error}.hpp compiled unmodified
+against the stand-in third-party headers in oracle/ref_shim/, recipe: oracle/Makefile target `ref`).
+
+/root/reference only exists in the build container, never on the GPU box: available() is False there, and the tests that
+need the library skip; its outputs travel as tests/golden/ref_v1.npz (tests/golden/make_ref_golden.py).  Same call
+signatures as oracle/pyoracle.py so the comparison tests read symmetrically."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .pyoracle import Camera, _f32, _f64, _i32, _p   # same struct layout / helpers
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_ref", "liblvf_ref.so")
+REFERENCE_INCLUDE = "/root/reference/src/lvio_fusion/include"
+
+
+def can_build():
+    return os.path.isdir(os.path.join(REFERENCE_INCLUDE, "lvio_fusion", "ceres"))
+
+
+def build(force=False):
+    """Compiles the reference headers where they lie (never copied).  No-op without /root/reference (the GPU box uses the
+    prebuilt .so that travelled with the snapshot, if any)."""
+    if can_build() and (force or not os.path.exists(_SO)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return _SO if os.path.exists(_SO) else None
+
+
+def available():
+    return os.path.exists(_SO) or can_build()
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if build() is None:
+            raise RuntimeError("oracle/_ref/liblvf_ref.so is not built and /root/reference is absent")
+        _lib = C.CDLL(_SO)
+        _lib.lvr_sources.restype = C.c_char_p
+    return _lib
+
+
+def pose_only(ob, kf_idx, pw_idx, pw, poses, w_kf, cam0, jac=True):
+    ob, pw, poses, w_kf = _f64(ob), _f64(pw), _f64(poses), _f64(w_kf)
+    kf_idx, pw_idx = _i32(kf_idx), _i32(pw_idx)
+    n = ob.shape[0]
+    r = np.empty((n, 2)); J = np.empty((n, 2, 7)) if jac else None
+    lib().lvr_pose_only_eval(n, _p(ob), _p(kf_idx, C.c_int), _p(pw_idx, C.c_int), _p(pw), _p(poses), _p(w_kf), C.byref(cam0), _p(r), _p(J))
+    return r, J
+
+
+def two_frame(first_ob, ob, lm_idx, kf1, kf2, inv_depth, poses, w_kf, left, right, jac=True):
+    first_ob, ob, inv_depth, poses, w_kf = map(_f64, (first_ob, ob, inv_depth, poses, w_kf))
+    lm_idx, kf1, kf2 = map(_i32, (lm_idx, kf1, kf2))
+    n = ob.shape[0]
+    r = np.empty((n, 2))
+    Jd = np.empty((n, 2)) if jac else None
+    J1 = np.empty((n, 2, 7)) if jac else None
+    J2 = np.empty((n, 2, 7)) if jac else None
+    lib().lvr_two_frame_eval(n, _p(first_ob), _p(ob), _p(lm_idx, C.c_int), _p(kf1, C.c_int), _p(kf2, C.c_int), _p(inv_depth), _p(poses), _p(w_kf),
+                             C.byref(left), C.byref(right), _p(r), _p(Jd), _p(J1), _p(J2))
+    return r, Jd, J1, J2
+
+
+def two_camera(left_ob, right_ob, lm_idx, kf_idx, inv_depth, w_kf, left, right, jac=True):
+    left_ob, right_ob, inv_depth, w_kf = map(_f64, (left_ob, right_ob, inv_depth, w_kf))
+    lm_idx, kf_idx = _i32(lm_idx), _i32(kf_idx)
+    n = left_ob.shape[0]
+    r = np.empty((n, 2)); J = np.empty((n, 2)) if jac else None
+    lib().lvr_two_camera_eval(n, _p(left_ob), _p(right_ob), _p(lm_idx, C.c_int), _p(kf_idx, C.c_int), _p(inv_depth), _p(w_kf), C.byref(left),
+                              C.byref(right), _p(r), _p(J))
+    return r, J
+
+
+def lidar_plane(mode, p, pa, pb, pc, Twc1, rpyxyz, weight, jac=True):
+    """NOTE takes the three neighbours (the functor computes its own normal, lidar_error.hpp:16-17), unlike pyoracle.lidar_plane."""
+    p, pa, pb, pc, Twc1 = map(_f64, (p, pa, pb, pc, Twc1))
+    live = _f64(rpyxyz).copy()
+    n = p.shape[0]
+    r = np.empty(n); J = np.empty((n, 3)) if jac else None
+    lib().lvr_lidar_plane_eval(int(mode), n, _p(p), _p(pa), _p(pb), _p(pc), _p(Twc1), _p(live), C.c_double(weight), _p(r), _p(J))
+    return r, J
+
+
+def lidar_plane_se3(p, pa, pb, pc, Twc2):
+    p, pa, pb, pc, Twc2 = map(_f64, (p, pa, pb, pc, Twc2))
+    n = p.shape[0]
+    r = np.empty(n); J = np.empty((n, 7))
+    lib().lvr_lidar_plane_se3_eval(n, _p(p), _p(pa), _p(pb), _p(pc), _p(Twc2), _p(r), _p(J))
+    return r, J
+
+
+def pose_graph(last_pose, pose, weight, v, Twc1, Twc2):
+    lp, ps, a, b = map(_f64, (last_pose, pose, Twc1, Twc2))
+    r = np.empty(6); J1 = np.empty((6, 7)); J2 = np.empty((6, 7))
+    lib().lvr_pose_graph_eval(_p(lp), _p(ps), C.c_double(weight), C.c_double(v), _p(a), _p(b), _p(r), _p(J1), _p(J2))
+    return r, J1, J2
+
+
+def pose_graph_rel(relative_i_j, weight, v, Twc1, Twc2):
+    rel, a, b = map(_f64, (relative_i_j, Twc1, Twc2))
+    r = np.empty(6); J1 = np.empty((6, 7)); J2 = np.empty((6, 7))
+    lib().lvr_pose_graph_rel_eval(_p(rel), C.c_double(weight), C.c_double(v), _p(a), _p(b), _p(r), _p(J1), _p(J2))
+    return r, J1, J2
+
+
+def pose_prior(origin, weight, v, pose):
+    o, p = _f64(origin), _f64(pose)
+    r = np.empty(6); J = np.empty((6, 7))
+    lib().lvr_pose_prior_eval(_p(o), C.c_double(weight), C.c_double(v), _p(p), _p(r), _p(J))
+    return r, J
+
+
+def r_error(origin, weight, pose):
+    o, p = _f64(origin), _f64(pose)
+    r = np.empty(4); J = np.empty((4, 7))
+    lib().lvr_r_error_eval(_p(o), C.c_double(weight), _p(p), _p(r), _p(J))
+    return r, J
+
+
+def t_error(p3, weight, pose):
+    t, p = _f64(p3), _f64(pose)
+    r = np.empty(3); J = np.empty((3, 7))
+    lib().lvr_t_error_eval(_p(t), C.c_double(weight), _p(p), _p(r), _p(J))
+    return r, J
+
+
+def prior3(mode, rpyxyz0, weight, x3):
+    """x3 in parameter order; returns r[3], J[3 blocks][3 rows]."""
+    a, b = _f64(rpyxyz0).copy(), _f64(x3)
+    r = np.empty(3); J = np.empty((3, 3))
+    lib().lvr_prior3_eval(int(mode), _p(a), C.c_double(weight), _p(b), _p(r), _p(J))
+    return r, J
+
+
+def relocate_r(relocated, unrelocated, q4):
+    a, b, q = map(_f64, (relocated, unrelocated, q4))
+    r = np.empty(7); J = np.empty((7, 4))
+    lib().lvr_relocate_r_eval(_p(a), _p(b), _p(q), _p(r), _p(J))
+    return r, J
+
+
+def se3_to_rpyxyz(se3):
+    a = _f64(se3); out = np.empty(6)
+    lib().lvr_se3_to_rpyxyz(_p(a), _p(out)); return out
+
+
+def rpyxyz_to_se3(rpyxyz):
+    a = _f64(rpyxyz); out = np.empty(7)
+    lib().lvr_rpyxyz_to_se3(_p(a), _p(out)); return out
+
+
+def se3_mul(A, B):
+    a, b = _f64(A), _f64(B); out = np.empty(7)
+    lib().lvr_se3_mul(_p(a), _p(b), _p(out)); return out
+
+
+def se3_inv(A):
+    a = _f64(A); out = np.empty(7)
+    lib().lvr_se3_inv(_p(a), _p(out)); return out
+
+
+def se3_apply(A, p):
+    a, b = _f64(A), _f64(p); out = np.empty(3)
+    lib().lvr_se3_apply(_p(a), _p(b), _p(out)); return out
+
+
+def se3_apply_f32(A, p):
+    a, b = _f32(A), _f32(p); out = np.empty(3, dtype=np.float32)
+    lib().lvr_se3_apply_f32(_p(a, C.c_float), _p(b, C.c_float), _p(out, C.c_float)); return out

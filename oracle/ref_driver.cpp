@@ -1,0 +1,171 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  oracle/_ref/liblvf_ref.so: the REFERENCE's own cost functors, compiled unmodified from
+//   /root/reference/src/lvio_fusion/include/lvio_fusion/ceres/{base,visual_error,lidar_error,pose_error}.hpp
+//   (+ visual/camera.h, sensor.h, common.h they include)
+// against the stand-in third-party headers under oracle/ref_shim/ (Ceres Jet/AutoDiffCostFunction/rotation, Eigen vectors, Sophus
+// SE3d, OpenCV Mat, PCL point names).  No reference source is copied into this repository: the headers are included from where
+// they lie (-I/root/reference/src/lvio_fusion/include, oracle/Makefile target `ref`).  Every entry point builds the functor through
+// the reference's own `X::Create(...)` factory and calls ceres::CostFunction::Evaluate — the same surface backend.cpp drives.
+// Used by tests/test_oracle_ref.py to pin oracle/factors.h (the restatement) against the reference's text, and to generate
+// tests/golden/ref_v1.npz (the reference does not exist on the GPU box).  ImuError is NOT covered: imu_error.hpp needs real Eigen
+// (15x15 inverse / LLT, Quaterniond) and preintegration.cpp.
+#include <cstring>
+#include <memory>
+
+#include "lvio_fusion/ceres/lidar_error.hpp"
+#include "lvio_fusion/ceres/pose_error.hpp"
+#include "lvio_fusion/ceres/visual_error.hpp"
+
+// statics the reference defines in its .cpp files (src/visual/camera.cpp, src/estimator.cpp); not on the functor path
+namespace lvio_fusion {
+std::vector<Camera::Ptr> Camera::devices_;
+double Camera::baseline = 1;
+}  // namespace lvio_fusion
+const double epsilon = 1e-3;
+const int num_threads = 1;
+
+using namespace lvio_fusion;
+
+extern "C" {
+
+struct lvr_camera { double fx, fy, cx, cy; double extrinsic[7]; };
+
+// Camera::Create appends to a process-wide registry (camera.h:18-22); the driver resets it per call so ids are 0 / 1
+static Camera::Ptr make_camera(const lvr_camera* c) {
+  const int id = Camera::Create(c->fx, c->fy, c->cx, c->cy, SE3d(c->extrinsic));
+  return Camera::Get(id);
+}
+
+const char* lvr_sources(void) {
+  return "lvio_fusion/ceres/base.hpp visual_error.hpp lidar_error.hpp pose_error.hpp (unmodified, from /root/reference)";
+}
+
+// PoseOnlyReprojectionError::Create(ob, pw, camera, weight)   visual_error.hpp:66-70 ; call site backend.cpp:129-130
+void lvr_pose_only_eval(int n, const double* ob, const int* kf_idx, const int* pw_idx, const double* pw, const double* poses,
+                        const double* w_kf, const lvr_camera* cam0, double* r, double* J) {
+  Camera::Ptr cam = make_camera(cam0);
+  for (int i = 0; i < n; ++i) {
+    const double* p = pw + 3 * pw_idx[i];
+    std::unique_ptr<ceres::CostFunction> f(PoseOnlyReprojectionError::Create(Vector2d(ob[2 * i], ob[2 * i + 1]), Vector3d(p[0], p[1], p[2]), cam, w_kf[kf_idx[i]]));
+    const double* params[1] = {poses + 7 * kf_idx[i]};
+    double* jac[1] = {J ? J + 14 * i : nullptr};
+    f->Evaluate(params, r + 2 * i, J ? jac : nullptr);
+  }
+}
+
+// TwoFrameReprojectionError::Create(first_ob, ob, left, right, weight)   visual_error.hpp:98-102 ; backend.cpp:138
+void lvr_two_frame_eval(int n, const double* first_ob, const double* ob, const int* lm_idx, const int* kf1_idx, const int* kf2_idx,
+                        const double* inv_depth, const double* poses, const double* w_kf, const lvr_camera* left_, const lvr_camera* right_,
+                        double* r, double* Jd, double* J1, double* J2) {
+  Camera::Ptr left = make_camera(left_), right = make_camera(right_);
+  for (int i = 0; i < n; ++i) {
+    std::unique_ptr<ceres::CostFunction> f(TwoFrameReprojectionError::Create(Vector2d(first_ob[2 * i], first_ob[2 * i + 1]), Vector2d(ob[2 * i], ob[2 * i + 1]),
+                                                                             left, right, w_kf[kf2_idx[i]]));
+    const double* params[3] = {inv_depth + lm_idx[i], poses + 7 * kf1_idx[i], poses + 7 * kf2_idx[i]};
+    double* jac[3] = {Jd ? Jd + 2 * i : nullptr, J1 ? J1 + 14 * i : nullptr, J2 ? J2 + 14 * i : nullptr};
+    f->Evaluate(params, r + 2 * i, (Jd || J1 || J2) ? jac : nullptr);
+  }
+}
+
+// TwoCameraReprojectionError::Create(left_ob, right_ob, left, right, 5 * weights.visual)   visual_error.hpp:128-132 ; backend.cpp:123
+void lvr_two_camera_eval(int n, const double* left_ob, const double* right_ob, const int* lm_idx, const int* kf_idx, const double* inv_depth,
+                         const double* w_kf, const lvr_camera* left_, const lvr_camera* right_, double* r, double* J) {
+  Camera::Ptr left = make_camera(left_), right = make_camera(right_);
+  for (int i = 0; i < n; ++i) {
+    std::unique_ptr<ceres::CostFunction> f(TwoCameraReprojectionError::Create(Vector2d(left_ob[2 * i], left_ob[2 * i + 1]), Vector2d(right_ob[2 * i], right_ob[2 * i + 1]),
+                                                                              left, right, 5 * w_kf[kf_idx[i]]));
+    const double* params[1] = {inv_depth + lm_idx[i]};
+    double* jac[1] = {J ? J + 2 * i : nullptr};
+    f->Evaluate(params, r + 2 * i, J ? jac : nullptr);
+  }
+}
+
+// LidarPlaneErrorRPZ / YXY ::Create(p, pa, pb, pc, Twc1, rpyxyz (LIVE pointer), weight)   lidar_error.hpp:65-69, 100-104
+// association.cpp:313-316, :371-374.  r[n], J[n][3]; nrm_out (may be null) is not available from the functor (private) — the
+// normal is checked through the residual.
+void lvr_lidar_plane_eval(int mode, int n, const double* p, const double* pa, const double* pb, const double* pc, const double* Twc1,
+                          double* rpyxyz_live, double weight, double* r, double* J) {
+  const SE3d T1(Twc1);
+  const int i0 = mode == 0 ? 1 : 0, i1 = mode == 0 ? 2 : 3, i2 = mode == 0 ? 5 : 4;
+  for (int i = 0; i < n; ++i) {
+    const Vector3d vp(p[3 * i], p[3 * i + 1], p[3 * i + 2]), va(pa[3 * i], pa[3 * i + 1], pa[3 * i + 2]), vb(pb[3 * i], pb[3 * i + 1], pb[3 * i + 2]),
+        vc(pc[3 * i], pc[3 * i + 1], pc[3 * i + 2]);
+    std::unique_ptr<ceres::CostFunction> f(mode == 0 ? LidarPlaneErrorRPZ::Create(vp, va, vb, vc, T1, rpyxyz_live, weight)
+                                                     : LidarPlaneErrorYXY::Create(vp, va, vb, vc, T1, rpyxyz_live, weight));
+    const double* params[3] = {rpyxyz_live + i0, rpyxyz_live + i1, rpyxyz_live + i2};
+    double* jac[3] = {J ? J + 3 * i : nullptr, J ? J + 3 * i + 1 : nullptr, J ? J + 3 * i + 2 : nullptr};
+    f->Evaluate(params, r + i, J ? jac : nullptr);
+  }
+}
+
+// LidarPlaneError::Create(p, pa, pb, pc) <1,7>   lidar_error.hpp:33-36
+void lvr_lidar_plane_se3_eval(int n, const double* p, const double* pa, const double* pb, const double* pc, const double* Twc2, double* r, double* J) {
+  for (int i = 0; i < n; ++i) {
+    std::unique_ptr<ceres::CostFunction> f(LidarPlaneError::Create(Vector3d(p[3 * i], p[3 * i + 1], p[3 * i + 2]), Vector3d(pa[3 * i], pa[3 * i + 1], pa[3 * i + 2]),
+                                                                   Vector3d(pb[3 * i], pb[3 * i + 1], pb[3 * i + 2]), Vector3d(pc[3 * i], pc[3 * i + 1], pc[3 * i + 2])));
+    const double* params[1] = {Twc2};
+    double* jac[1] = {J ? J + 7 * i : nullptr};
+    f->Evaluate(params, r + i, J ? jac : nullptr);
+  }
+}
+
+// PoseGraphError::Create(last_pose, pose, weight, v) <6,7,7>   pose_error.hpp:40-43 ; backend.cpp:170
+void lvr_pose_graph_eval(const double* last_pose, const double* pose, double weight, double v, const double* Twc1, const double* Twc2, double* r,
+                         double* J1, double* J2) {
+  std::unique_ptr<ceres::CostFunction> f(PoseGraphError::Create(SE3d(last_pose), SE3d(pose), weight, v));
+  const double* params[2] = {Twc1, Twc2};
+  double* jac[2] = {J1, J2};
+  f->Evaluate(params, r, (J1 || J2) ? jac : nullptr);
+}
+// PoseGraphError::Create(relative_i_j, weight, v)   pose_error.hpp:45-48 ; pose_graph.cpp
+void lvr_pose_graph_rel_eval(const double* relative_i_j, double weight, double v, const double* Twc1, const double* Twc2, double* r, double* J1, double* J2) {
+  std::unique_ptr<ceres::CostFunction> f(PoseGraphError::Create(SE3d(relative_i_j), weight, v));
+  const double* params[2] = {Twc1, Twc2};
+  double* jac[2] = {J1, J2};
+  f->Evaluate(params, r, (J1 || J2) ? jac : nullptr);
+}
+// PoseError::Create(pose, weight, v) <6,7>   pose_error.hpp:78-81 ; backend.cpp:175
+void lvr_pose_prior_eval(const double* origin, double weight, double v, const double* pose, double* r, double* J) {
+  std::unique_ptr<ceres::CostFunction> f(PoseError::Create(SE3d(origin), weight, v));
+  const double* params[1] = {pose};
+  double* jac[1] = {J};
+  f->Evaluate(params, r, J ? jac : nullptr);
+}
+// RError::Create(pose, weight) <4,7>   pose_error.hpp:102-105 ; pose_graph.cpp:192
+void lvr_r_error_eval(const double* origin, double weight, const double* pose, double* r, double* J) {
+  std::unique_ptr<ceres::CostFunction> f(RError::Create(SE3d(origin), weight));
+  const double* params[1] = {pose};
+  double* jac[1] = {J};
+  f->Evaluate(params, r, J ? jac : nullptr);
+}
+// TError::Create(p, weight) <3,7>   pose_error.hpp:124-127
+void lvr_t_error_eval(const double* p3, double weight, const double* pose, double* r, double* J) {
+  std::unique_ptr<ceres::CostFunction> f(TError::Create(Vector3d(p3[0], p3[1], p3[2]), weight));
+  const double* params[1] = {pose};
+  double* jac[1] = {J};
+  f->Evaluate(params, r, J ? jac : nullptr);
+}
+// PoseErrorRPZ / PoseErrorYXY ::Create(rpyxyz, weight) <3,1,1,1>   pose_error.hpp:155-158, :183-186 ; association.cpp:323,381
+// x3 in PARAMETER order — (pitch, roll, z) / (yaw, x, y); J = three 3x1 blocks concatenated [block][row]
+void lvr_prior3_eval(int mode, double* rpyxyz0, double weight, const double* x3, double* r, double* J9) {
+  std::unique_ptr<ceres::CostFunction> f(mode == 0 ? PoseErrorRPZ::Create(rpyxyz0, weight) : PoseErrorYXY::Create(rpyxyz0, weight));
+  const double* params[3] = {x3, x3 + 1, x3 + 2};
+  double* jac[3] = {J9, J9 ? J9 + 3 : nullptr, J9 ? J9 + 6 : nullptr};
+  f->Evaluate(params, r, J9 ? jac : nullptr);
+}
+// RelocateRError::Create(relocated, unrelocated) <7,4>   pose_error.hpp:216-219 ; relocator.cpp:261
+void lvr_relocate_r_eval(const double* relocated, const double* unrelocated, const double* q4, double* r, double* J) {
+  std::unique_ptr<ceres::CostFunction> f(RelocateRError::Create(SE3d(relocated), SE3d(unrelocated)));
+  const double* params[1] = {q4};
+  double* jac[1] = {J};
+  f->Evaluate(params, r, J ? jac : nullptr);
+}
+
+// base.hpp helpers instantiated on double / float (the float SE3TransformPoint is the association's transform, association.cpp:289)
+void lvr_se3_to_rpyxyz(const double* se3, double* rpyxyz) { ceres::SE3ToRpyxyz<double>(se3, rpyxyz); }
+void lvr_rpyxyz_to_se3(const double* rpyxyz, double* se3) { ceres::RpyxyzToSE3<double>(rpyxyz, se3); }
+void lvr_se3_mul(const double* A, const double* B, double* C) { ceres::SE3Product<double>(A, B, C); }
+void lvr_se3_inv(const double* A, double* C) { ceres::SE3Inverse<double>(A, C); }
+void lvr_se3_apply(const double* A, const double* p, double* o) { ceres::SE3TransformPoint<double>(A, p, o); }
+void lvr_se3_apply_f32(const float* A, const float* p, float* o) { ceres::SE3TransformPoint<float>(A, p, o); }
+
+}  // extern "C"

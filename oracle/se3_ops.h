@@ -1,4 +1,7 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).
+// PARITY PINNED to the reference's own text: tests/test_oracle_ref.py compares this restatement BIT-FOR-BIT with oracle/_ref
+// (the reference's ceres/{base,visual_error,lidar_error,pose_error}.hpp compiled unmodified, oracle/ref_driver.cpp) and with the
+// committed reference outputs tests/golden/ref_v1.npz.
 //
 // se3_ops.h — array-based quaternion / SE3 algebra, templated on the scalar
 // (double, float, Jet<N>).  Restates

@@ -1,0 +1,193 @@
+"""Independent CPU check of oracle/lm.h and oracle/icp.h (the LM/Schur and 3-DoF reference solvers every GPU solver parity test leans on).
+
+Nothing here goes through lm.h's own linearisation or Schur code: the dense Jacobian is assembled in numpy from the per-factor
+oracle outputs (which tests/test_oracle_ref.py pins to the reference functors), the Huber corrector and the quaternion local
+parameterisation are restated here in numpy from Ceres' published definitions, and the damped normal equations over ALL
+unknowns (poses, velocities, biases, inverse depths — no Schur elimination) are solved with numpy.linalg.solve.  Step, model
+cost change, step quality rho, accept/reject, radius update and the new state must match what lm.h / icp.h produce."""
+import numpy as np
+import pytest
+
+from lvio_fusion_amd import synthetic as syn
+from tests.helpers import ocam
+
+
+def huber_scale(a, s):
+    """Ceres Corrector for rho'' <= 0: residual and Jacobian scale sqrt(rho'); returns (rho, scale)."""
+    if a <= 0 or s <= a * a:
+        return s, 1.0
+    r = np.sqrt(s)
+    return 2 * a * r - a * a, np.sqrt(a / r)
+
+
+def quat_plus_jac(q):      # EigenQuaternionParameterization::ComputeJacobian, x = [x, y, z, w]
+    x, y, z, w = q
+    return np.array([[w, z, -y], [-z, w, x], [y, -x, w], [-x, -y, -z]])
+
+
+def quat_plus(q, d):       # x_plus = q_delta (x) x, Eigen coefficient order
+    n = np.linalg.norm(d)
+    if n == 0:
+        return q.copy()
+    qd = np.concatenate([np.sin(n) / n * d, [np.cos(n)]])
+    return syn.quat_mul(qd, q)
+
+
+def to_local(J7, pose):    # rows x 7 ambient -> rows x 6 tangent
+    return np.concatenate([J7[:, :4] @ quat_plus_jac(pose[:4]), J7[:, 4:]], axis=1)
+
+
+def dense_system(oracle, cfg, pre, state, huber_a=1.0):
+    """Full Jacobian over [pose tangents 6 n_kf | (v, ba, bg) 9 n_kf | inverse depths n_lm] and the robustified residual vector."""
+    n_kf, n_lm = cfg["n_kf"], cfg["n_lm"]
+    poses, vel, ba, bg, rho_l = state
+    c0, c1 = ocam(oracle, cfg["cam0"]), ocam(oracle, cfg["cam1"])
+    ncol = 15 * n_kf + n_lm
+    rows, res, cost = [], [], 0.0
+    lcol = lambda l: 15 * n_kf + l
+    tc, tf, po = cfg["tc"], cfg["tf"], cfg["po"]
+    r, J = oracle.two_camera(tc["left_ob"], tc["right_ob"], tc["lm_idx"], tc["kf_idx"], rho_l, cfg["w_kf"], c0, c1)
+    for i in range(len(r)):
+        c, sc = huber_scale(huber_a, r[i] @ r[i]); cost += 0.5 * c
+        blk = np.zeros((2, ncol)); blk[:, lcol(tc["lm_idx"][i])] = sc * J[i]
+        rows.append(blk); res.append(sc * r[i])
+    r, Jd, J1, J2 = oracle.two_frame(tf["first_ob"], tf["ob"], tf["lm_idx"], tf["kf1_idx"], tf["kf2_idx"], rho_l, poses, cfg["w_kf"], c0, c1)
+    for i in range(len(r)):
+        c, sc = huber_scale(huber_a, r[i] @ r[i]); cost += 0.5 * c
+        k1, k2 = tf["kf1_idx"][i], tf["kf2_idx"][i]
+        blk = np.zeros((2, ncol)); blk[:, lcol(tf["lm_idx"][i])] = sc * Jd[i]
+        blk[:, 6 * k1:6 * k1 + 6] += sc * to_local(J1[i], poses[k1]); blk[:, 6 * k2:6 * k2 + 6] += sc * to_local(J2[i], poses[k2])
+        rows.append(blk); res.append(sc * r[i])
+    r, J = oracle.pose_only(po["ob"], po["kf_idx"], po["pw_idx"], po["pw"], poses, cfg["w_kf"], c0)
+    for i in range(len(r)):
+        c, sc = huber_scale(huber_a, r[i] @ r[i]); cost += 0.5 * c
+        k = po["kf_idx"][i]
+        blk = np.zeros((2, ncol)); blk[:, 6 * k:6 * k + 6] = sc * to_local(J[i], poses[k])
+        rows.append(blk); res.append(sc * r[i])
+    ki = [f["kf_i"] for f in cfg["imu"]]; kj = [f["kf_j"] for f in cfg["imu"]]
+    r, J480 = oracle.imu_eval(pre, ki, kj, poses, vel, ba, bg)
+    Js = oracle.imu_split_jac(J480)
+    for f in range(len(ki)):          # ImuError: no loss function (backend.cpp:159)
+        cost += 0.5 * r[f] @ r[f]
+        blk = np.zeros((15, ncol))
+        for side, k in ((0, ki[f]), (4, kj[f])):
+            blk[:, 6 * k:6 * k + 6] += to_local(Js[side][f], poses[k])
+            o = 6 * n_kf + 9 * k
+            blk[:, o:o + 3] += Js[side + 1][f]; blk[:, o + 3:o + 6] += Js[side + 2][f]; blk[:, o + 6:o + 9] += Js[side + 3][f]
+        rows.append(blk); res.append(r[f])
+    return np.concatenate(rows), np.concatenate(res), cost
+
+
+def cost_only(oracle, cfg, pre, state, huber_a=1.0):
+    return dense_system(oracle, cfg, pre, state, huber_a)[2]
+
+
+@pytest.mark.parametrize("n_kf,n_lm,seed", [(5, 40, 101), (7, 90, 202)])
+def test_lm_iteration_matches_dense_numpy_solve(oracle, n_kf, n_lm, seed):
+    cfg = syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=20, seed=seed, imu_samples=4)
+    pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+    win = oracle.Window(cfg, pre)
+    state = [np.array(cfg[k], dtype=np.float64) for k in ("poses", "vel", "ba", "bg", "inv_depth")]
+    radius, dec = 1e4, 2.0
+    clampd = lambda v: np.minimum(np.maximum(v, 1e-6), 1e32)
+    seen_reject = False
+    for it in range(5):
+        if it == 3:
+            radius = 1e-3 * radius      # a tiny region after a few accepted steps, to visit the damping-dominated regime too
+        J, r, cost = dense_system(oracle, cfg, pre, state)
+        H, g = J.T @ J, J.T @ r
+        D = clampd(np.diag(H)) / radius
+        dx = np.linalg.solve(H + np.diag(D), -g)
+        model = -dx @ (g + 0.5 * H @ dx)
+        new = [s.copy() for s in state]
+        for k in range(n_kf):
+            new[0][k, :4] = quat_plus(state[0][k, :4], dx[6 * k:6 * k + 3]); new[0][k, 4:] += dx[6 * k + 3:6 * k + 6]
+            o = 6 * n_kf + 9 * k
+            new[1][k] += dx[o:o + 3]; new[2][k] += dx[o + 3:o + 6]; new[3][k] += dx[o + 6:o + 9]
+        new[4] = state[4] + dx[15 * n_kf:]
+        cand = cost_only(oracle, cfg, pre, new)
+        rho = (cost - cand) / model
+        ref = win.lm_iteration(radius, dec)
+        assert abs(ref["cost_before"] - cost) <= 1e-10 * cost
+        assert abs(ref["model_cost_change"] - model) <= 1e-7 * abs(model)
+        assert abs(ref["cost_after"] - cand) <= 1e-7 * cand
+        assert abs(ref["rho"] - rho) <= 1e-6 * max(1.0, abs(rho))
+        assert ref["accepted"] == (rho > 1e-3)
+        # the reduced (Schur) system lm.h reports == the Schur complement of the dense damped matrix
+        d = 15 * n_kf
+        A = H + np.diag(D)
+        S = A[:d, :d] - A[:d, d:] @ np.diag(1.0 / np.diag(A[d:, d:])) @ A[d:, :d]
+        assert np.abs(ref["S"] - S).max() <= 1e-9 * np.abs(S).max()
+        rhs = -g[:d] + A[:d, d:] @ (g[d:] / np.diag(A[d:, d:]))
+        assert np.abs(ref["rhs"] - rhs).max() <= 1e-9 * np.abs(rhs).max()
+        if rho > 1e-3:
+            t = 2 * rho - 1
+            radius = min(radius / max(1 / 3, 1 - t ** 3), 1e16); dec = 2.0
+            state = new
+        else:
+            radius /= dec; dec *= 2; seen_reject = True
+        assert abs(ref["radius"] - radius) <= 1e-6 * radius and ref["decrease_factor"] == dec
+        for a, b in zip(state, (win.poses, win.vel, win.ba, win.bg, win.inv_depth)):
+            assert np.abs(a - b).max() <= 1e-8 * max(1.0, np.abs(b).max())
+    assert it == 4
+
+
+@pytest.mark.parametrize("mode,huber_a,prior_w", [(0, 0.0, 0.0), (1, 0.1, 0.0), (0, 0.0, 50.0), (1, 0.1, 30.0)])
+def test_icp_solve_matches_numpy_lm(oracle, mode, huber_a, prior_w):
+    c3 = syn.config3_icp(seed=77, n_query=1200, n_az=140)
+    sel = c3["query_ground"] if mode == 0 else ~c3["query_ground"]
+    msel = c3["map_ground"] if mode == 0 else ~c3["map_ground"]
+    q, m = c3["query"][sel][:500], c3["map"][msel]
+    thr = c3["thr_ground"] if mode == 0 else c3["thr_surf"]
+    weight = syn.W_LIDAR_GROUND if mode == 0 else syn.W_LIDAR_SURF
+    rp0 = oracle.se3_to_rpyxyz(oracle.se3_mul(oracle.se3_inv(c3["map_pose"]), c3["pose0"]))
+    x_ref, summ = oracle.icp_solve(m, q, c3["map_pose"], c3["pose0"], rp0, mode, thr, weight, huber_a, prior_w=prior_w, use_kdtree=False)
+    # numpy restatement of the loop: association once at the frame pose, then <= 4 LM iterations on 3 scalars
+    idx, d2, valid = oracle.knn3(m, q, c3["pose0"], thr)
+    v = valid > 0
+    p = q[v, :3].astype(np.float64); pa, pb, pc = (m[idx[v, k], :3].astype(np.float64) for k in range(3))
+    nrm = oracle.plane_normals(pa, pb, pc)
+    sl = [1, 2, 5] if mode == 0 else [0, 3, 4]
+    x = rp0.copy(); x0 = rp0[sl].copy()
+
+    def lin(xx):
+        r, J = oracle.lidar_plane(mode, p, pa, nrm, c3["map_pose"], xx, weight)
+        c = 0.0; Jr = np.zeros((len(r) + 3, 3)); rr = np.zeros(len(r) + 3)
+        for i in range(len(r)):
+            ci, sc = huber_scale(huber_a, r[i] * r[i]); c += 0.5 * ci
+            Jr[i] = sc * J[i]; rr[i] = sc * r[i]
+        if prior_w > 0:      # PoseErrorRPZ / YXY: weight * (x - x0), identity Jacobian up to the row order (irrelevant for J^T J)
+            Jr[len(r):] = prior_w * np.eye(3); rr[len(r):] = prior_w * (xx[sl] - x0); c += 0.5 * rr[len(r):] @ rr[len(r):]
+        return Jr, rr, c
+    radius, dec, iters, succ = 1e4, 2.0, 0, 0
+    first_cost = None
+    for it in range(4):
+        J, r, cost = lin(x)
+        first_cost = cost if first_cost is None else first_cost
+        H, g = J.T @ J, J.T @ r
+        if np.abs(g).max() <= 1e-10:
+            break
+        D = np.minimum(np.maximum(np.diag(H), 1e-6), 1e32) / radius
+        dx = np.linalg.solve(H + np.diag(D), -g)
+        model = -dx @ (g + 0.5 * H @ dx)
+        if np.linalg.norm(dx) <= 1e-8 * (np.linalg.norm(x[sl]) + 1e-8):
+            break
+        xc = x.copy(); xc[sl] += dx
+        cand = lin(xc)[2]
+        iters += 1
+        rho = (cost - cand) / model if model > 0 else -1
+        if rho > 1e-3:
+            t = 2 * rho - 1
+            radius = min(radius / max(1 / 3, 1 - t ** 3), 1e16); dec = 2.0
+            x = xc; succ += 1
+            if abs(cost - cand) <= 1e-6 * abs(cost):
+                cost = cand
+                break
+            cost = cand
+        else:
+            radius /= dec; dec *= 2
+    assert summ["num_residual_blocks"] == int(v.sum()) + (1 if prior_w > 0 else 0)
+    assert (summ["num_iterations"], summ["num_successful_steps"]) == (iters, succ)
+    assert abs(summ["initial_cost"] - first_cost) <= 1e-9 * first_cost
+    assert np.abs(x_ref - x).max() <= 1e-9
+    assert abs(summ["final_cost"] - lin(x)[2]) <= 1e-8 * max(first_cost, 1e-12)
