@@ -128,6 +128,9 @@ int lvf_two_camera_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera
                           const int32_t* kf_idx, lvf_batch** out);
 /* parameter blocks (pose,v,ba,bg)[kf_i], (pose,v,ba,bg)[kf_j]; sqrt_info = LLT(cov^-1).L^T is factorised
  * once here (the reference re-inverts on every Evaluate: imu_error.hpp:32). */
+/* Optional per-block weights of a TwoCamera batch = each functor's `weight` constructor argument (visual_error.hpp:112; the reference
+ * passes 5 * frame->weights.visual, backend.cpp:123).  weight[n] replaces 5 * w_visual[kf_idx[i]]; NULL restores the per-keyframe rule. */
+int lvf_two_camera_set_block_weights(lvf_batch* b, const double* weight);
 int lvf_imu_create(lvf_ctx* ctx, int n, const lvf_preint* pre, const int32_t* kf_i, const int32_t* kf_j,
                    lvf_batch** out);
 /* mode 0 = RPZ (pitch,roll,z), 1 = YXY (yaw,x,y).  p/pa/pb/pc [n][3]: the scan point and its three
@@ -162,6 +165,14 @@ int lvf_batch_download_normals(lvf_batch* b, double* host);
 /* device pointers of the same buffers (valid until the batch is destroyed) */
 void* lvf_batch_residuals_dev(lvf_batch* b);
 void* lvf_batch_jacobian_dev(lvf_batch* b, int block);
+
+/* Batched Problem::Evaluate surface (upstream ceres::Problem::Evaluate with apply_loss_function = true): residuals [n][R] with the loss
+ * function's Corrector applied (visual batches: rows scaled by sqrt(rho'(|r|^2)) of HuberLoss(huber_a); huber_a <= 0 or non-visual
+ * batches: unchanged) and Jacobians [n][R][L] in LOCAL coordinates, the block's parameter blocks concatenated in functor order with every
+ * 7-sized pose block reduced to its 6 tangent columns (ProductParameterization(EigenQuaternion, Identity3), backend.cpp:99-101); absent
+ * pose blocks (PoseError / RError priors) are zero.  L = lvf_batch_local_columns(b).  jacobians_local may be NULL.  Host outputs. */
+int lvf_batch_local_columns(const lvf_batch* b);
+int lvf_batch_evaluate_local(lvf_batch* b, const lvf_state* st, double huber_a, double* residuals, double* jacobians_local);
 
 /* ---- IMU pre-integration on device ---------------------------------------------------------- */
 /* n independent keyframe pairs; pair k owns samples[offset[k] .. offset[k+1]) rows of (dt, acc[3], gyr[3]);
@@ -334,6 +345,26 @@ int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_su
 int lvf_problem_reduced_dim(lvf_problem* p);
 int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs);
 
+/* Problem::Evaluate's gradient at the current state: J^T r with the Corrector applied and pose blocks in tangent coordinates.
+ * gc[15 n_kf] = (6 x n_kf pose tangents | 9 x n_kf (v, ba, bg)); gl[n_lm] (may be NULL) = the inverse-depth entries.  Constant poses: 0. */
+int lvf_problem_gradient(lvf_problem* p, const lvf_solver_options* o, double* gc, double* gl);
+
+/* ---- loop-correction tail: Relocator::UpdateNewSubmap / PoseGraph::ForwardUpdate ---------------------------------- */
+/* RelocateRError <7,4> (pose_error.hpp:192-222) batched: block i = RelocateRError(relocated[i], unrelocated[i]) evaluated at the shared
+ * quaternion q4 (x,y,z,w, NOT normalised by the functor).  residuals [n][7]; jacobians [n][7][4] row-major ambient, or NULL. */
+int lvf_relocate_r_evaluate(lvf_ctx* ctx, int n, const double* relocated, const double* unrelocated, const double* q4, double* residuals,
+                            double* jacobians);
+/* The rotation solve of Relocator::UpdateNewSubmap (relocator.cpp:251-267): one quaternion parameter under EigenQuaternionParameterization,
+ * n RelocateRError blocks, no loss, LM (the DENSE_QR solve of 3 tangent unknowns) — the whole loop is one device launch.  q4 (x,y,z,w) is
+ * updated IN PLACE like `para` (identity in the reference); on failure (summary->termination == 2) it is left untouched. */
+int lvf_relocate_rotation_solve(lvf_ctx* ctx, int n, const double* relocated, const double* unrelocated, double* q4, const lvf_solver_options* o,
+                                lvf_solver_summary* summary);
+/* PoseGraph::ForwardUpdate (pose_graph.cpp:245-252; also Backend::UpdateFrontend, backend.cpp:256): pose <- transform * pose (Sophus SE3
+ * product: Hamilton product re-normalised, t_T + R(q_T) t) and Vw <- R(q_T) Vw for n keyframes; host arrays updated in place, vw may be NULL. */
+int lvf_forward_update(lvf_ctx* ctx, const double* transform7, int n, double* poses, double* vw);
+/* the same on a device-resident state: keyframes [first_kf, n_kf) of st (poses and velocities), nothing crosses PCIe but the transform */
+int lvf_state_forward_update(lvf_state* st, const double* transform7, int first_kf);
+
 /* ---- persistent sliding window (Backend::BuildProblem's assembly, kept incrementally) -------------- */
 /* The window mirrors Map's active keyframes, their features_left and the landmarks behind them as flat arrays that the
  * front-end updates as it goes; lvf_window_solve assembles the block lists with BuildProblem's rules (backend.cpp:96-183) in
@@ -354,7 +385,11 @@ int lvf_window_set_imu(lvf_window* w, int64_t kf_id, const double* vel3, const d
 int lvf_window_add_landmark(lvf_window* w, int64_t lm_id, int64_t birth_kf_id, const double* left_ob2, const double* right_ob2, double inv_depth);
 int lvf_window_add_observation(lvf_window* w, int64_t lm_id, int64_t kf_id, const double* ob2);
 int lvf_window_remove_observation(lvf_window* w, int64_t lm_id, int64_t kf_id);   /* outlier rejection, backend.cpp:232-243 */
-int lvf_window_slide(lvf_window* w, int64_t first_active_kf_id);                  /* Map::GetKeyFrames(finished) */
+int lvf_window_slide(lvf_window* w, int64_t first_active_kf_id);                  /* Map::GetKeyFrames(finished); also forgets landmarks nobody observes */
+/* Backend::Optimize's outlier gate (backend.cpp:185-190, :229-245): every feature that is not its landmark's first observation is
+ * re-projected on device with weight 1 (PoseOnly residual pass at the window's current poses / inverse depths) and removed from the window
+ * when the pixel error exceeds max_px (10 in the reference).  Up to `capacity` removed (landmark id, keyframe id) pairs are reported. */
+int lvf_window_reject_outliers(lvf_window* w, double max_px, int64_t* removed_lm, int64_t* removed_kf, int capacity, int* n_removed);
 int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summary* summary);
 int lvf_window_set_pose(lvf_window* w, int64_t kf_id, const double* pose7);       /* front-end / ForwardUpdate writes */
 int lvf_window_get_pose(const lvf_window* w, int64_t kf_id, double* pose7);

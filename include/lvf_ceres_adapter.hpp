@@ -671,7 +671,6 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
     return true;
   };
   auto at = [](size_t i) { return "residual block " + std::to_string(i) + ": "; };   // only built on the failure path
-  std::vector<size_t> two_camera_pending;
   w->order_kind.reserve(blocks.size()); w->order_idx.reserve(blocks.size());
   w->lm_id.reserve(blocks.size() / 4);
   for (size_t i = 0; i < blocks.size(); ++i) {
@@ -707,8 +706,8 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
         if (!use_loss(b.loss)) return fail(at(i) + "visual blocks must share one HuberLoss/TrivialLoss");
         w->order_kind.push_back(0); w->order_idx.push_back((int)w->tc_lm.size());
         w->tc_l.insert(w->tc_l.end(), f->left_ob, f->left_ob + 2); w->tc_r.insert(w->tc_r.end(), f->right_ob, f->right_ob + 2);
-        w->tc_lm.push_back(lm_of(b.params[0])); w->tc_kf.push_back(-1); w->tc_w.push_back(f->weight / 5.0);
-        two_camera_pending.push_back(w->tc_kf.size() - 1);
+        // the block carries its own weight (5 * frame->weights.visual at backend.cpp:123): handed to the device per block, no keyframe look-up
+        w->tc_lm.push_back(lm_of(b.params[0])); w->tc_kf.push_back(0); w->tc_w.push_back(f->weight);
         break;
       }
       case Kind::Imu: {
@@ -756,16 +755,6 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
       default: return fail(at(i) + "lidar blocks cannot be mixed into a BA window");
     }
   }
-  // TwoCamera blocks only carry a weight (5 * frame->weights.visual); the library looks weights up per keyframe, so each
-  // block is pointed at ANY keyframe with that weight, claiming a keyframe of still-unknown weight if none matches.
-  for (size_t idx : two_camera_pending) {
-    const double wv = w->tc_w[idx];
-    int hit = -1;
-    for (int k = 0; k < n_kf && hit < 0; ++k) if (w->w_known[k] && w->w_kf[k] == wv) hit = k;
-    for (int k = 0; k < n_kf && hit < 0; ++k) if (!w->w_known[k]) { w->w_kf[k] = wv; w->w_known[k] = 1; hit = k; }
-    if (hit < 0) return fail("TwoCameraReprojectionError weight " + std::to_string(5.0 * wv) + " matches no keyframe's 5 x visual weight");
-    w->tc_kf[idx] = hit;
-  }
   if (w->huber == -2.0) w->huber = 0.0;
   // parameter blocks the device solver cannot hold constant individually
   for (double* p : w->lm_ptr) if (problem->IsParameterBlockConstant(p)) return fail("constant inverse-depth blocks are not supported");
@@ -799,6 +788,7 @@ inline bool upload_window(lvf_ctx* ctx, ceres::Problem* problem, const Window& w
     if (lvf_two_camera_create(ctx, &w.left, &w.right, (int)w.tc_lm.size(), w.tc_l.data(), w.tc_r.data(), w.tc_lm.data(), w.tc_kf.data(), &d->tc) != LVF_OK)
       return fail(lvf_last_error());
     d->h.keep(d->tc);
+    if (lvf_two_camera_set_block_weights(d->tc, w.tc_w.data()) != LVF_OK) return fail(lvf_last_error());
   }
   if (!w.tf_lm.empty()) {
     if (lvf_two_frame_create(ctx, &w.left, &w.right, (int)w.tf_lm.size(), w.tf_f.data(), w.tf_o.data(), w.tf_lm.data(), w.tf_k1.data(), w.tf_k2.data(), &d->tf) != LVF_OK)
@@ -908,44 +898,141 @@ inline void Solve(const ceres::Solver::Options& options, ceres::Problem* problem
 }
 
 // --------------------------------------------------------------------------------------------- batched Problem::Evaluate
-// cost = 1/2 sum rho(|r_b|^2) at the CURRENT parameter values; residuals (optional) = the raw residual vector in block
-// insertion order (apply_loss_function = false semantics for the vector, loss applied in the cost).  BA windows only.
-inline bool Evaluate(ceres::Problem* problem, double* cost, std::vector<double>* residuals, std::string* error = nullptr) {
+// The upstream surface, on the GPU:  ceres::Problem::Evaluate(EvaluateOptions, double* cost, vector<double>* residuals,
+// vector<double>* gradient, CRSMatrix* jacobian) for a sliding-window BA problem built from lvio_fusion::gpu cost functions.
+//   cost      = 1/2 sum rho(|r_b|^2)                      (apply_loss_function = false: 1/2 sum |r_b|^2)
+//   residuals = blocks in insertion order, with the loss function's Corrector applied when apply_loss_function is set
+//   jacobian  = CRS, rows = residuals, columns = the parameter blocks in the order they were added (or options.parameter_blocks) in
+//               LOCAL coordinates (pose blocks: 6 tangent columns of ProductParameterization(EigenQuaternion, Identity3)); blocks that
+//               are constant in the problem keep their (empty) columns, blocks not listed in options.parameter_blocks are held constant
+//               and get no columns — upstream's rules
+//   gradient  = J^T r in the same column order.
+// Any output pointer may be null.  options.residual_blocks must be empty (whole problem).  Values are produced on device
+// (lvf_batch_evaluate_local / lvf_problem_gradient); the host only scatters them into the caller's containers.
+inline bool Evaluate(ceres::Problem* problem, const ceres::Problem::EvaluateOptions& options, double* cost, std::vector<double>* residuals,
+                     std::vector<double>* gradient, ceres::CRSMatrix* jacobian, std::string* error = nullptr) {
   ceres::Solver::Summary dummy;
   const detail::Fail fail{&dummy};
-  auto bail = [&]() { if (error) *error = dummy.message; return false; };
+  auto bail = [&](const std::string& why = std::string()) { if (error) *error = why.empty() ? dummy.message : why; return false; };
+  if (!options.residual_blocks.empty()) return bail("lvf: Evaluate on a subset of residual blocks is not supported");
   std::vector<detail::BlockView> blocks;
   std::vector<double*> block_params;
   if (!detail::collect(problem, &blocks, &block_params, fail)) return bail();
   ThreadContext& tc = thread_context();
-  if (!tc.ctx) { if (error) *error = tc.error; return false; }
+  if (!tc.ctx) return bail(tc.error);
   detail::Window w;
   if (!detail::build_window(problem, blocks, &w, fail)) return bail();
   detail::DeviceWindow d;
   if (!detail::upload_window(tc.ctx, problem, w, &d, fail)) return bail();
   lvf_solver_options o;
-  detail::to_lvf_options(ceres::Solver::Options(), w.huber, &o);
-  if (cost && lvf_problem_cost(d.h.prob, &o, cost) != LVF_OK) { if (error) *error = lvf_last_error(); return false; }
-  if (residuals) {
-    lvf_batch* bs[5] = {d.tc, d.tf, d.po, d.imu, d.prior};
-    const int nres[5] = {2, 2, 2, 15, 6};
-    std::vector<double> r[5];
-    for (int k = 0; k < 5; ++k) {
-      if (!bs[k]) continue;
-      r[k].resize((size_t)lvf_batch_size(bs[k]) * nres[k]);
-      if (lvf_batch_evaluate(bs[k], d.h.st, nullptr, 0) != LVF_OK || lvf_batch_download_residuals(bs[k], r[k].data()) != LVF_OK) {
-        if (error) *error = lvf_last_error();
-        return false;
+  detail::to_lvf_options(ceres::Solver::Options(), options.apply_loss_function ? w.huber : 0.0, &o);
+  if (cost && lvf_problem_cost(d.h.prob, &o, cost) != LVF_OK) return bail(lvf_last_error());
+  if (!residuals && !gradient && !jacobian) return true;
+
+  const int n_kf = (int)w.pose_ptr.size(), n_lm = (int)w.lm_ptr.size();
+  // ---- column layout
+  std::vector<double*> col_blocks = options.parameter_blocks;
+  if (col_blocks.empty()) problem->GetParameterBlocks(&col_blocks);
+  detail::PtrMap col_of;
+  col_of.reserve(col_blocks.size());
+  std::vector<int> col_start(col_blocks.size() + 1, 0);
+  for (size_t i = 0; i < col_blocks.size(); ++i) {
+    double* p = col_blocks[i];
+    if (!problem->HasParameterBlock(p)) return bail("lvf: options.parameter_blocks names a block that is not in the problem");
+    const int size = problem->ParameterBlockSize(p);
+    const ceres::LocalParameterization* lp = problem->GetParameterization(p);
+    const int local = lp ? lp->LocalSize() : size;
+    if (size == 7 && local != 6) return bail("lvf: pose blocks must carry ProductParameterization(EigenQuaternionParameterization, IdentityParameterization(3))");
+    if (size != 7 && local != size) return bail("lvf: only pose blocks may carry a local parameterization");
+    col_of.insert(p, (int)i);
+    col_start[i + 1] = col_start[i] + local;
+  }
+  const int num_cols = col_start.back();
+  auto active_col = [&](double* p) {            // first column of block p, or -1 if it contributes no entries
+    const int i = col_of.find(p);
+    if (i < 0 || problem->IsParameterBlockConstant(p)) return -1;
+    return col_start[i];
+  };
+
+  // ---- device evaluation, one call per functor batch
+  lvf_batch* bs[5] = {d.tc, d.tf, d.po, d.imu, d.prior};
+  const int nres[5] = {2, 2, 2, 15, 6};
+  std::vector<double> r[5], J[5];
+  int L[5] = {0, 0, 0, 0, 0};
+  for (int k = 0; k < 5; ++k) {
+    if (!bs[k]) continue;
+    const size_t n = (size_t)lvf_batch_size(bs[k]);
+    L[k] = lvf_batch_local_columns(bs[k]);
+    r[k].resize(n * nres[k]);
+    if (jacobian) J[k].resize(n * nres[k] * L[k]);
+    if (lvf_batch_evaluate_local(bs[k], d.h.st, o.huber_a, r[k].data(), jacobian ? J[k].data() : nullptr) != LVF_OK) return bail(lvf_last_error());
+  }
+  // slice of each parameter block inside a batch row: TwoCamera [rho]; TwoFrame [rho | pose1 | pose2]; PoseOnly [pose];
+  // ImuError [pose_i v_i ba_i bg_i pose_j v_j ba_j bg_j]; priors [pose_a | pose_b]
+  static const int off_tc[1] = {0}, off_tf[3] = {0, 1, 7}, off_po[1] = {0}, off_imu[8] = {0, 6, 9, 12, 15, 21, 24, 27}, off_pg[2] = {0, 6}, off_p1[1] = {6};
+  static const int wid_tc[1] = {1}, wid_tf[3] = {1, 6, 6}, wid_po[1] = {6}, wid_imu[8] = {6, 3, 3, 3, 6, 3, 3, 3}, wid_pg[2] = {6, 6}, wid_p1[1] = {6};
+  if (residuals) residuals->clear();
+  if (jacobian) { jacobian->rows.assign(1, 0); jacobian->cols.clear(); jacobian->values.clear(); jacobian->num_cols = num_cols; }
+  int num_rows = 0;
+  struct Piece { int col, off, wid; };
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    const int k = w.order_kind[i], idx = w.order_idx[i];
+    const Kind kind = blocks[i].g->kind();
+    const int rows_here = kind == Kind::R ? 4 : nres[k];            // RError<4,7>: the device batch pads it to 6 rows
+    const int* off = nullptr; const int* wid = nullptr; int nb = 0;
+    switch (kind) {
+      case Kind::TwoCamera: off = off_tc; wid = wid_tc; nb = 1; break;
+      case Kind::TwoFrame: off = off_tf; wid = wid_tf; nb = 3; break;
+      case Kind::PoseOnly: off = off_po; wid = wid_po; nb = 1; break;
+      case Kind::Imu: off = off_imu; wid = wid_imu; nb = 8; break;
+      case Kind::PoseGraph: off = off_pg; wid = wid_pg; nb = 2; break;
+      default: off = off_p1; wid = wid_p1; nb = 1; break;          // PoseError / RError: the single pose sits in the batch's second slot
+    }
+    const double* rsrc = r[k].data() + (size_t)idx * nres[k];
+    if (residuals) residuals->insert(residuals->end(), rsrc, rsrc + rows_here);
+    if (jacobian) {
+      Piece pc[8]; int np = 0;
+      for (int b = 0; b < nb; ++b) {
+        const int c = active_col(blocks[i].params[b]);
+        if (c >= 0) pc[np++] = Piece{c, off[b], wid[b]};
+      }
+      std::sort(pc, pc + np, [](const Piece& a, const Piece& b) { return a.col < b.col; });
+      for (int row = 0; row < rows_here; ++row) {
+        const double* jrow = J[k].data() + ((size_t)idx * nres[k] + row) * L[k];
+        for (int q = 0; q < np; ++q)
+          for (int c = 0; c < pc[q].wid; ++c) { jacobian->cols.push_back(pc[q].col + c); jacobian->values.push_back(jrow[pc[q].off + c]); }
+        jacobian->rows.push_back((int)jacobian->cols.size());
       }
     }
-    residuals->clear();
-    for (size_t i = 0; i < w.order_kind.size(); ++i) {
-      const int k = w.order_kind[i];
-      const double* src = r[k].data() + (size_t)w.order_idx[i] * nres[k];
-      residuals->insert(residuals->end(), src, src + nres[k]);
+    num_rows += rows_here;
+  }
+  if (jacobian) jacobian->num_rows = num_rows;
+  if (gradient) {
+    std::vector<double> gc((size_t)15 * n_kf), gl((size_t)std::max(n_lm, 1));
+    if (lvf_problem_gradient(d.h.prob, &o, gc.data(), n_lm ? gl.data() : nullptr) != LVF_OK) return bail(lvf_last_error());
+    gradient->assign(num_cols, 0.0);
+    auto put = [&](double* p, const double* src, int n) {
+      if (!p) return;
+      const int c = active_col(p);
+      if (c >= 0) std::copy(src, src + n, gradient->begin() + c);
+    };
+    for (int kf = 0; kf < n_kf; ++kf) {
+      put(w.pose_ptr[kf], &gc[(size_t)6 * kf], 6);
+      const double* vb = &gc[(size_t)6 * n_kf + (size_t)9 * kf];
+      put(w.v_ptr[kf], vb, 3); put(w.ba_ptr[kf], vb + 3, 3); put(w.bg_ptr[kf], vb + 6, 3);
     }
+    for (int l = 0; l < n_lm; ++l) put(w.lm_ptr[l], &gl[l], 1);
   }
   return true;
+}
+
+// convenience form kept from round 1: cost + the RAW residual vector (loss applied in the cost only)
+inline bool Evaluate(ceres::Problem* problem, double* cost, std::vector<double>* residuals, std::string* error = nullptr) {
+  if (cost && !Evaluate(problem, ceres::Problem::EvaluateOptions(), cost, nullptr, nullptr, nullptr, error)) return false;
+  if (!residuals) return true;
+  ceres::Problem::EvaluateOptions raw;
+  raw.apply_loss_function = false;
+  return Evaluate(problem, raw, nullptr, residuals, nullptr, nullptr, error);
 }
 
 }  // namespace gpu

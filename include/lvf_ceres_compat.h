@@ -161,6 +161,14 @@ struct ResidualBlock {
 }  // namespace internal
 typedef internal::ResidualBlock* ResidualBlockId;
 
+// upstream ceres/crs_matrix.h: compressed-row storage; row i holds values[rows[i] .. rows[i+1]) at columns cols[..]
+struct CRSMatrix {
+  CRSMatrix() : num_rows(0), num_cols(0) {}
+  int num_rows, num_cols;
+  std::vector<int> cols, rows;
+  std::vector<double> values;
+};
+
 enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
 enum TerminationType { CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE };
 
@@ -180,6 +188,15 @@ class Problem {
     for (auto* p : lf) delete p;
     for (auto* p : lp) delete p;
   }
+
+  // upstream Problem::EvaluateOptions (the argument of Problem::Evaluate)
+  struct EvaluateOptions {
+    EvaluateOptions() : apply_loss_function(true), num_threads(1) {}
+    std::vector<double*> parameter_blocks;          // empty = all, in the order they were added; otherwise the column order, others held constant
+    std::vector<ResidualBlockId> residual_blocks;   // empty = all, in the order they were added
+    bool apply_loss_function;
+    int num_threads;
+  };
 
   void AddParameterBlock(double* values, int size) { AddParameterBlock(values, size, nullptr); }
   void AddParameterBlock(double* values, int size, LocalParameterization* local_parameterization) {

@@ -100,6 +100,15 @@ _SIGS = {
     "lvf_pose_only_create": (C.c_int, [_VP, C.POINTER(Camera), C.c_int, c_double_p, c_int_p, c_int_p, C.c_int, c_double_p, C.POINTER(_VP)]),
     "lvf_two_frame_create": (C.c_int, [_VP, C.POINTER(Camera), C.POINTER(Camera), C.c_int, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, C.POINTER(_VP)]),
     "lvf_two_camera_create": (C.c_int, [_VP, C.POINTER(Camera), C.POINTER(Camera), C.c_int, c_double_p, c_double_p, c_int_p, c_int_p, C.POINTER(_VP)]),
+    "lvf_two_camera_set_block_weights": (C.c_int, [_VP, c_double_p]),
+    "lvf_batch_local_columns": (C.c_int, [_VP]),
+    "lvf_batch_evaluate_local": (C.c_int, [_VP, _VP, C.c_double, c_double_p, c_double_p]),
+    "lvf_problem_gradient": (C.c_int, [_VP, C.POINTER(SolverOptions), c_double_p, c_double_p]),
+    "lvf_relocate_r_evaluate": (C.c_int, [_VP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "lvf_relocate_rotation_solve": (C.c_int, [_VP, C.c_int, c_double_p, c_double_p, c_double_p, C.POINTER(SolverOptions), C.POINTER(SolverSummary)]),
+    "lvf_forward_update": (C.c_int, [_VP, c_double_p, C.c_int, c_double_p, c_double_p]),
+    "lvf_state_forward_update": (C.c_int, [_VP, c_double_p, C.c_int]),
+    "lvf_window_reject_outliers": (C.c_int, [_VP, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
     "lvf_imu_create": (C.c_int, [_VP, C.c_int, c_double_p, c_int_p, c_int_p, C.POINTER(_VP)]),
     "lvf_lidar_plane_create": (C.c_int, [_VP, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, C.POINTER(_VP)]),
     "lvf_pose_prior_create": (C.c_int, [_VP, C.c_int, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p, C.POINTER(_VP)]),

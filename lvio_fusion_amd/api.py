@@ -123,6 +123,17 @@ class Batch:
         _chk(self.ctx.L.lvf_batch_download_jacobian(self.h, block, _dp(out)))
         return out
 
+    def evaluate_local(self, state, huber_a=0.0, jacobians=True):
+        """Problem::Evaluate-shaped outputs: robustified residuals [n][R] and LOCAL Jacobians [n][R][L]."""
+        L = self.ctx.L.lvf_batch_local_columns(self.h)
+        r = np.empty((self.n, self.n_res)); J = np.empty((self.n, self.n_res, L)) if jacobians else None
+        _chk(self.ctx.L.lvf_batch_evaluate_local(self.h, state.h, C.c_double(huber_a), _dp(r), _dp(J) if jacobians else None))
+        return r, J
+
+    def set_block_weights(self, weight):
+        w = None if weight is None else _d(weight)
+        _chk(self.ctx.L.lvf_two_camera_set_block_weights(self.h, _dp(w) if w is not None else None))
+
     def normals(self):
         out = np.empty((self.n, 3))
         _chk(self.ctx.L.lvf_batch_download_normals(self.h, _dp(out)))
@@ -191,6 +202,32 @@ def relative_rpyxyz(last_pose, pose):
     a, b, out = _d(last_pose), _d(pose), np.empty(6)
     _chk(_lib.lib().lvf_relative_rpyxyz(_dp(a), _dp(b), _dp(out)))
     return out
+
+
+def relocate_r_evaluate(ctx, relocated, unrelocated, q4, jacobians=True):
+    """RelocateRError <7,4> batched: returns r[n][7], J[n][7][4] (ambient) or None."""
+    a, b, q = _d(relocated), _d(unrelocated), _d(q4)
+    n = a.shape[0]
+    r = np.empty((n, 7)); J = np.empty((n, 7, 4)) if jacobians else None
+    _chk(ctx.L.lvf_relocate_r_evaluate(ctx.h, n, _dp(a), _dp(b), _dp(q), _dp(r), _dp(J) if jacobians else None))
+    return r, J
+
+
+def relocate_rotation_solve(ctx, relocated, unrelocated, q4, opt=None):
+    """Relocator::UpdateNewSubmap's rotation solve; returns (q4_new, SolverSummary)."""
+    a, b = _d(relocated), _d(unrelocated)
+    q = _d(q4).copy()
+    opt = opt or default_solver_options()
+    summ = _lib.SolverSummary()
+    _chk(ctx.L.lvf_relocate_rotation_solve(ctx.h, a.shape[0], _dp(a), _dp(b), _dp(q), C.byref(opt), C.byref(summ)))
+    return q, summ
+
+
+def forward_update(ctx, transform, poses, vw=None):
+    """PoseGraph::ForwardUpdate on host arrays; returns updated copies."""
+    T = _d(transform); P = _d(poses).copy(); V = None if vw is None else _d(vw).copy()
+    _chk(ctx.L.lvf_forward_update(ctx.h, _dp(T), P.shape[0], _dp(P), _dp(V) if V is not None else None))
+    return P, V
 
 
 def prior3_evaluate(ctx, mode, target3, weight, x3):
@@ -430,6 +467,12 @@ class Window:
     def remove_observation(self, lm_id, kf_id):
         _chk(self.ctx.L.lvf_window_remove_observation(self.h, int(lm_id), int(kf_id)))
 
+    def reject_outliers(self, max_px=10.0, capacity=4096):
+        """Backend::Optimize's outlier gate; returns the removed (landmark id, keyframe id) pairs."""
+        lm = (C.c_int64 * capacity)(); kf = (C.c_int64 * capacity)(); n = C.c_int(0)
+        _chk(self.ctx.L.lvf_window_reject_outliers(self.h, C.c_double(max_px), lm, kf, capacity, C.byref(n)))
+        return [(int(lm[i]), int(kf[i])) for i in range(min(n.value, capacity))], n.value
+
     def slide(self, first_active_kf):
         _chk(self.ctx.L.lvf_window_slide(self.h, int(first_active_kf)))
 
@@ -501,6 +544,12 @@ class Problem:
         s = SolverSummary()
         _chk(self.ctx.L.lvf_problem_solve(self.h, C.byref(opt), C.byref(s)))
         return s
+
+    def gradient(self, opt):
+        d = self.ctx.L.lvf_problem_reduced_dim(self.h)
+        gc = np.empty(d); gl = np.empty(max(self.state.n_lm, 1))
+        _chk(self.ctx.L.lvf_problem_gradient(self.h, C.byref(opt), _dp(gc), _dp(gl)))
+        return gc, gl[:self.state.n_lm]
 
     def reduced_system(self):
         d = self.ctx.L.lvf_problem_reduced_dim(self.h)

@@ -1,11 +1,25 @@
 #!/bin/bash
-# Builds lvio_fusion_amd/liblvf_hip.so for gfx950 (cross-compiles without a GPU).
+# Builds lvio_fusion_amd/liblvf_hip.so for gfx950 (cross-compiles without a GPU).  One object per translation unit, compiled in
+# parallel and only when the source or a header is newer than the object; then one link.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../liblvf_hip.so"
+OBJ="$HERE/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=$(ls "$HERE"/*.hip)
-# bounded: an optimiser pathology (see the asm barrier in k_chol_factor_panel) must fail the build, not hang it
-timeout "${LVF_BUILD_TIMEOUT:-1800}" "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-fast-math -Wall -Wno-unused-function \
-  -I"$HERE/../../include" $SRCS -o "$OUT" "$@"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -Wall -Wno-unused-function -I$HERE/../../include"
+mkdir -p "$OBJ"
+NEWEST_HDR=$(ls -t "$HERE"/*.hpp "$HERE"/../../include/lvf.h | head -1)
+todo=()
+for src in "$HERE"/*.hip; do
+  o="$OBJ/$(basename "${src%.hip}").o"
+  if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$NEWEST_HDR" -nt "$o" ]; then todo+=("$src"); fi
+done
+if [ ${#todo[@]} -gt 0 ]; then
+  # bounded: an optimiser pathology (see the asm barrier in k_chol_factor_panel) must fail the build, not hang it
+  printf '%s\n' "${todo[@]}" | xargs -P "${LVF_BUILD_JOBS:-8}" -I{} bash -c \
+    'src="$1"; o="$2/$(basename "${src%.hip}").o"; timeout "$3" "$4" $5 -c "$src" -o "$o.tmp" "${@:6}" && mv "$o.tmp" "$o"' _ {} "$OBJ" "${LVF_BUILD_TIMEOUT:-1800}" "$HIPCC" "$FLAGS" "$@"
+fi
+# objects of sources that no longer exist must not be linked
+for o in "$OBJ"/*.o; do [ -f "$HERE/$(basename "${o%.o}").hip" ] || rm -f "$o"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT"
 echo "built $OUT"

@@ -259,6 +259,18 @@ int lvf_two_camera_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera
   return LVF_OK;
 }
 
+// per-block weights of a TwoCamera batch = the `weight` constructor argument of each TwoCameraReprojectionError (visual_error.hpp:112;
+// backend.cpp:123 passes 5 * frame->weights.visual).  Without this call the kernels use 5 * w_visual[kf_idx[i]].
+int lvf_two_camera_set_block_weights(lvf_batch* b, const double* weight) {
+  LVF_REQUIRE(b && b->kind == LVF_K_TWO_CAMERA, "lvf_two_camera_set_block_weights: not a two-camera batch");
+  LVF_TRY(lvf::enter(b->ctx));
+  if (!weight || b->n == 0) { b->wblk.n = 0; return LVF_OK; }
+  LVF_TRY(b->wblk.assign(weight, (size_t)b->n, b->ctx->stream));
+  LVF_HIP(hipStreamSynchronize(b->ctx->stream));
+  b->evaluated = false;
+  return LVF_OK;
+}
+
 int lvf_imu_create(lvf_ctx* ctx, int n, const lvf_preint* pre, const int32_t* kf_i, const int32_t* kf_j, lvf_batch** out) {
   LVF_REQUIRE(ctx && out, "lvf_imu_create: null argument");
   LVF_REQUIRE(n >= 0, "lvf_imu_create: negative size");

@@ -192,6 +192,7 @@ struct lvf_batch {
   lvf::DevBuf<double> ob_a, ob_b;        // [n][2] each
   lvf::DevBuf<int32_t> idx_a, idx_b, idx_c;
   lvf::DevBuf<double> table;             // pose-only: pw[n_pw][3]
+  lvf::DevBuf<double> wblk;              // two-camera: optional per-block weight (the functor's ctor argument); empty = 5 * w_visual[kf]
   int n_table = 0;
   // lidar
   int lidar_mode = 0;

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <unordered_map>
 
 #include "factor_eval.hpp"
 #include "lvf_internal.hpp"
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kT) void k_zero_multi(ZeroList z) {
 // ------------------------------------------------------------------------------------------------ TwoCamera
 template <bool COST_ONLY>
 __device__ __forceinline__ void lin_tc_body(const int vb, int n, const double2* __restrict__ lo, const double2* __restrict__ ro,
-                                               const int* __restrict__ lm, const int* __restrict__ kf, StateP s,
+                                               const int* __restrict__ lm, const int* __restrict__ kf, const double* __restrict__ wblk, StateP s,
                                                CamD left, CamD right, double huber, double* __restrict__ C,
                                                double* __restrict__ gr, double* __restrict__ cost) {
   const int i = vb * kT + threadIdx.x;
@@ -110,7 +111,7 @@ __device__ __forceinline__ void lin_tc_body(const int vb, int n, const double2* 
     const int l = lm[i];
     const double2 a = lo[i], b = ro[i];
     double r[2], J[2];
-    eval_two_camera<!COST_ONLY>(left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], 5.0 * s.w_kf[kf[i]], r, J);
+    eval_two_camera<!COST_ONLY>(left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], wblk ? wblk[i] : 5.0 * s.w_kf[kf[i]], r, J);
     double rho;
     const double sc = robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
     c = 0.5 * rho;
@@ -124,9 +125,9 @@ __device__ __forceinline__ void lin_tc_body(const int vb, int n, const double2* 
 }
 template <bool COST_ONLY>
 __global__ __launch_bounds__(kT) void k_lin_tc(int n, const double2* __restrict__ lo, const double2* __restrict__ ro,
-                                               const int* __restrict__ lm, const int* __restrict__ kf, StateP s,
+                                               const int* __restrict__ lm, const int* __restrict__ kf, const double* __restrict__ wblk, StateP s,
                                                CamD left, CamD right, double huber, double* __restrict__ C,
-                                               double* __restrict__ gr, double* __restrict__ cost) { lin_tc_body<COST_ONLY>(blockIdx.x, n, lo, ro, lm, kf, s, left, right, huber, C, gr, cost); }
+                                               double* __restrict__ gr, double* __restrict__ cost) { lin_tc_body<COST_ONLY>(blockIdx.x, n, lo, ro, lm, kf, wblk, s, left, right, huber, C, gr, cost); }
 
 // ------------------------------------------------------------------------------------------------ TwoFrame
 template <bool COST_ONLY>
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__
 // TwoCamera, a TwoFrame and a PoseOnly segment): as three back-to-back launches of 4-9 us they were mostly launch boundaries.
 struct CostVisual {
   int n_tc, n_tf, n_po, g_tc, g_tf;
-  const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; CamD tc_left, tc_right;
+  const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; const double* tc_w; CamD tc_left, tc_right;
   const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1, *tf_k2; CamD tf_left, tf_right;
   const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
 };
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(kT) void k_cost_visual(CostVisual a, int n_kf, Stat
       const int l = a.tc_lm[i];
       const double2 lo = a.tc_lo[i], ro = a.tc_ro[i];
       double r[2], J[2];
-      eval_two_camera<false>(a.tc_left, a.tc_right, lo.x, lo.y, ro.x, ro.y, s.inv_depth[l], 5.0 * s.w_kf[a.tc_kf[i]], r, J);
+      eval_two_camera<false>(a.tc_left, a.tc_right, lo.x, lo.y, ro.x, ro.y, s.inv_depth[l], a.tc_w ? a.tc_w[i] : 5.0 * s.w_kf[a.tc_kf[i]], r, J);
       double rho;
       (void)robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
       c = 0.5 * rho;
@@ -593,7 +594,7 @@ struct LinVisual {
   // TwoFrame
   const TfWork* work; const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1; CamD tf_left, tf_right; int unique_lk2;
   // TwoCamera
-  int n_tc; const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; CamD tc_left, tc_right;
+  int n_tc; const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; const double* tc_w; CamD tc_left, tc_right;
   // PoseOnly
   int n_po, g_po; const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
   // ImuError (already evaluated)
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(kT) void k_lin_visual(LinVisual a, int n_kf, StateP
     lin_tf_sorted_body(b, a.work, n_kf, a.tf_fo, a.tf_ob, a.tf_lm, a.tf_k1, s, a.tf_left, a.tf_right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost,
                        a.unique_lk2);
   else if (b < a.n_tfw + a.g_tc)
-    lin_tc_body<false>(b - a.n_tfw, a.n_tc, a.tc_lo, a.tc_ro, a.tc_lm, a.tc_kf, s, a.tc_left, a.tc_right, huber, C, gr, cost);
+    lin_tc_body<false>(b - a.n_tfw, a.n_tc, a.tc_lo, a.tc_ro, a.tc_lm, a.tc_kf, a.tc_w, s, a.tc_left, a.tc_right, huber, C, gr, cost);
   else if (b < a.n_tfw + a.g_tc + a.g_po)
     lin_po_body<false>(b - a.n_tfw - a.g_tc, a.n_po, n_kf, a.po_ob, a.po_kf, a.po_pwi, a.po_pw, s, a.po_cam, huber, pose_const, B, ld, gc, cost);
   else
@@ -1567,7 +1568,7 @@ static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_st
   hipStream_t q = p->ctx->stream;
   CostVisual a{};
   if (p->tc && p->tc->n) {
-    a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p;
+    a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p; a.tc_w = p->tc->wblk.n ? p->tc->wblk.p : nullptr;
     a.tc_left = p->tc->cam_a; a.tc_right = p->tc->cam_b;
   }
   if (p->tf && p->tf->n) {
@@ -1615,7 +1616,7 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
     a.n_tfw = (int)p->tf_work.n; a.work = p->tf_work.p; a.tf_fo = (const double2*)p->tf->ob_a.p; a.tf_ob = (const double2*)p->tf->ob_b.p;
     a.tf_lm = p->tf->idx_a.p; a.tf_k1 = p->tf->idx_b.p; a.tf_left = p->tf->cam_a; a.tf_right = p->tf->cam_b; a.unique_lk2 = p->tf_unique_lk2 ? 1 : 0;
     if (p->tc && p->tc->n) {
-      a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p;
+      a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p; a.tc_w = p->tc->wblk.n ? p->tc->wblk.p : nullptr;
       a.tc_left = p->tc->cam_a; a.tc_right = p->tc->cam_b;
     }
     if (p->po && p->po->n) {
@@ -1633,7 +1634,7 @@ static int enqueue_linearize(lvf_problem* p, double huber) {
   } else {
   if (p->tc && p->tc->n)
     hipLaunchKernelGGL(k_lin_tc<false>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
-                       p->tc->idx_a.p, p->tc->idx_b.p, s, p->tc->cam_a, p->tc->cam_b, huber, p->C.p, p->gr.p, cost);
+                       p->tc->idx_a.p, p->tc->idx_b.p, p->tc->wblk.n ? p->tc->wblk.p : (const double*)nullptr, s, p->tc->cam_a, p->tc->cam_b, huber, p->C.p, p->gr.p, cost);
   if (p->tf && p->tf->n)
     hipLaunchKernelGGL(k_lin_tf<false>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
                        p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, p->B.p, p->dpad,
@@ -1968,6 +1969,16 @@ int problem_configure(lvf_problem* p) {
           i = j;
         }
       }
+      // ... and the plain stores into E[l][k2 columns] must never meet the atomic adds into E[l][k1 columns]: every landmark needs ONE
+      // first keyframe (then k2 == k1(l) is excluded by k1 != k2 above).  BuildProblem's blocks always satisfy this; a hand-made batch may not.
+      if (uniq && !two_frame->unique_lk2_known) {
+        std::unordered_map<int32_t, int32_t> first_kf;
+        first_kf.reserve(lmh.size());
+        for (int i = 0; i < two_frame->n && uniq; ++i) {
+          auto it = first_kf.emplace(lmh[i], k1[i]);
+          if (!it.second && it.first->second != k1[i]) uniq = false;
+        }
+      }
       p->tf_unique_lk2 = uniq;
     }
   }
@@ -2104,6 +2115,20 @@ int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_su
         std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) break;
   }
   summary->final_cost = cost;
+  return LVF_OK;
+}
+
+// Problem::Evaluate's gradient: J^T r with the loss function's Corrector applied and pose blocks in tangent coordinates, at the current
+// state — exactly what the linearisation accumulates.  gc [15 n_kf] in the reduced-system order (6 x n_kf pose tangents | 9 x n_kf (v, ba, bg)),
+// gl [n_lm] (may be NULL) the inverse-depth entries.
+int lvf_problem_gradient(lvf_problem* p, const lvf_solver_options* o, double* gc, double* gl) {
+  LVF_REQUIRE(p && o && gc, "lvf_problem_gradient: null argument");
+  LVF_TRY(lvf::enter(p->ctx));
+  hipStream_t q = p->ctx->stream;
+  LVF_TRY(enqueue_linearize(p, o->huber_a));
+  LVF_HIP(hipMemcpyAsync(gc, p->gc.p, (size_t)p->d * 8, hipMemcpyDeviceToHost, q));
+  if (gl && p->n_lm) LVF_HIP(hipMemcpyAsync(gl, p->gr.p, (size_t)p->n_lm * 8, hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipStreamSynchronize(q));
   return LVF_OK;
 }
 

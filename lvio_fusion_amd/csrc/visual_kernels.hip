@@ -170,14 +170,14 @@ __global__ __launch_bounds__(kBlock) void k_two_camera(int n, const double2* __r
                                                        const double2* __restrict__ right_ob,
                                                        const int* __restrict__ lm_idx, const int* __restrict__ kf_idx,
                                                        const double* __restrict__ inv_depth,
-                                                       const double* __restrict__ w_kf, const CamD left,
+                                                       const double* __restrict__ w_kf, const double* __restrict__ wblk, const CamD left,
                                                        const CamD right, double2* __restrict__ res,
                                                        double2* __restrict__ jac) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const double2 lo = left_ob[i], ro = right_ob[i];
   double r[2], J[2];
-  eval_two_camera<WITH_J>(left, right, lo.x, lo.y, ro.x, ro.y, inv_depth[lm_idx[i]], 5.0 * w_kf[kf_idx[i]], r, J);
+  eval_two_camera<WITH_J>(left, right, lo.x, lo.y, ro.x, ro.y, inv_depth[lm_idx[i]], wblk ? wblk[i] : 5.0 * w_kf[kf_idx[i]], r, J);
   res[i] = make_double2(r[0], r[1]);
   if (WITH_J) jac[i] = make_double2(J[0], J[1]);
 }
@@ -236,11 +236,11 @@ int launch_two_camera(lvf_batch* b, const lvf_state* st, bool want_j) {
   auto res = reinterpret_cast<double2*>(b->res.p);
   if (want_j)
     hipLaunchKernelGGL(k_two_camera<true>, dim3(grid_for(b->n)), dim3(kBlock), 0, s, b->n, lo, ro, b->idx_a.p,
-                       b->idx_b.p, st->inv_depth.p, st->w_visual.p, b->cam_a, b->cam_b, res,
+                       b->idx_b.p, st->inv_depth.p, st->w_visual.p, b->wblk.n ? b->wblk.p : (const double*)nullptr, b->cam_a, b->cam_b, res,
                        reinterpret_cast<double2*>(b->jac[0].p));
   else
     hipLaunchKernelGGL(k_two_camera<false>, dim3(grid_for(b->n)), dim3(kBlock), 0, s, b->n, lo, ro, b->idx_a.p,
-                       b->idx_b.p, st->inv_depth.p, st->w_visual.p, b->cam_a, b->cam_b, res, (double2*)nullptr);
+                       b->idx_b.p, st->inv_depth.p, st->w_visual.p, b->wblk.n ? b->wblk.p : (const double*)nullptr, b->cam_a, b->cam_b, res, (double2*)nullptr);
   LVF_HIP(hipGetLastError());
   return LVF_OK;
 }

@@ -16,6 +16,7 @@
 // the device LM loop; results are read back into the host mirror.
 #include <algorithm>
 #include <chrono>
+#include <iterator>
 #include <map>
 #include <unordered_map>
 #include "host_se3.hpp"
@@ -62,6 +63,9 @@ struct lvf_window {
   // device side, persistent across ticks
   lvf_state* st = nullptr;
   lvf_batch *tc = nullptr, *tf = nullptr, *po = nullptr, *imu = nullptr, *prior = nullptr;
+  lvf_batch* rej = nullptr;            // PoseOnly batch of the outlier gate (lvf_window_reject_outliers), persistent
+  lvf_state* rej_st = nullptr;         // the window's poses with unit visual weights
+  lvf::DevBuf<uint8_t> rej_flags;
   // pinned staging for the per-tick block lists (observations / indices per functor type)
   lvf::HostPin<double> h_tc_l, h_tc_r, h_tf_f, h_tf_o, h_po_o, h_po_pw;
   lvf::HostPin<int32_t> h_tc_lm, h_tc_kf, h_tf_lm, h_tf_k1, h_tf_k2, h_po_kf, h_po_pi;
@@ -69,11 +73,12 @@ struct lvf_window {
   lvf_problem* prob = nullptr;
   // assembly of the last solve
   std::vector<int> slot_lm;                              // dense landmark slot -> index into lms
-  int n_tc = 0, n_tf = 0, n_po = 0, n_imu = 0, n_prior = 0;
+  int n_tc = 0, n_tf = 0, n_po = 0, n_imu = 0, n_prior = 0, n_lm_problem = 0;
   ~lvf_window() {
     if (prob) lvf_problem_destroy(prob);
-    for (lvf_batch* b : {tc, tf, po, imu, prior}) if (b) lvf_batch_destroy(b);
+    for (lvf_batch* b : {tc, tf, po, imu, prior, rej}) if (b) lvf_batch_destroy(b);
     if (st) lvf_state_destroy(st);
+    if (rej_st) lvf_state_destroy(rej_st);
   }
 };
 
@@ -91,6 +96,81 @@ static void to_world(const lvf_camera& right, const double rob[2], double inv_de
 }
 template <typename T>
 static int put(DevBuf<T>& buf, const std::vector<T>& v, hipStream_t s) { return buf.assign(v.data(), v.size(), s); }
+
+// Keeps the host mirror bounded over a long run (the reference removes a landmark once its last observation is gone:
+// Landmark::RemoveObservation / Map::RemoveLandmark): landmarks no active keyframe observes any more are dropped and Obs::lm is
+// re-indexed; poses of departed frames are kept only while a live landmark was born there.
+static void prune(lvf_window* w) {
+  const size_t nl = w->lms.size();
+  std::vector<int> remap(nl, -1);
+  for (const lvf_window::Kf& f : w->kfs)
+    for (const lvf_window::Obs& o : f.obs) remap[o.lm] = 0;
+  size_t live = 0;
+  for (size_t i = 0; i < nl; ++i)
+    if (remap[i] == 0) remap[i] = (int)live++;
+  if (live != nl) {
+    std::vector<lvf_window::Lm> kept;
+    kept.reserve(live);
+    w->lm_index.clear();
+    for (size_t i = 0; i < nl; ++i)
+      if (remap[i] >= 0) { w->lm_index[w->lms[i].id] = remap[i]; kept.push_back(w->lms[i]); }
+    w->lms.swap(kept);
+    for (lvf_window::Kf& f : w->kfs)
+      for (lvf_window::Obs& o : f.obs) o.lm = remap[o.lm];
+    w->slot_lm.clear();          // slots of the last assembly referred to the old indices
+  }
+  if (!w->departed.empty()) {
+    std::unordered_map<int64_t, char> anchor;
+    for (const lvf_window::Lm& l : w->lms) anchor[l.birth_kf] = 1;
+    for (auto it = w->departed.begin(); it != w->departed.end();) it = anchor.count(it->first) ? std::next(it) : w->departed.erase(it);
+  }
+}
+
+// landmark->ToWorld() (src/lvio_fusion/src/landmark.cpp:15-19) for every landmark of the mirror: frozen points as stored, live ones
+// from their birth keyframe's CURRENT pose and inverse depth.  lm_birth_pos[i] = position of the birth keyframe in kfs (-1: not active).
+static void landmarks_to_world(const lvf_window* w, std::vector<double>& lm_pw, std::vector<int>& lm_birth_pos) {
+  const int n_kf = (int)w->kfs.size();
+  auto rot_of = [](const double q[4], double R[9]) {
+    double e0[3] = {1, 0, 0}, e1[3] = {0, 1, 0}, e2[3] = {0, 0, 1}, c0[3], c1[3], c2[3];
+    hse3::rotate(q, e0, c0); hse3::rotate(q, e1, c1); hse3::rotate(q, e2, c2);
+    R[0] = c0[0]; R[1] = c1[0]; R[2] = c2[0]; R[3] = c0[1]; R[4] = c1[1]; R[5] = c2[1]; R[6] = c0[2]; R[7] = c1[2]; R[8] = c2[2];
+  };
+  std::vector<double> Rk((size_t)9 * n_kf);
+  for (int k = 0; k < n_kf; ++k) rot_of(w->kfs[k].pose, &Rk[(size_t)9 * k]);
+  double Re[9];
+  rot_of(w->right.extrinsic, Re);
+  const double* te = w->right.extrinsic + 4;
+  const size_t nl = w->lms.size();
+  lm_pw.assign((size_t)3 * nl, 0.0);
+  lm_birth_pos.assign(nl, -1);
+  const int64_t first_id = w->kfs.front().id;
+  for (size_t i = 0; i < nl; ++i) {
+    const lvf_window::Lm& l = w->lms[i];
+    if (l.fixed) { std::memcpy(&lm_pw[3 * i], l.pw, 24); continue; }
+    if (l.birth_kf < first_id) continue;
+    auto ib = w->kf_index.find(l.birth_kf);
+    if (ib == w->kf_index.end()) continue;
+    const int bp = ib->second;
+    lm_birth_pos[i] = bp;
+    const double d = 1.0 / l.inv_depth;
+    const double ps[3] = {(l.right_ob[0] - w->right.cx) * d / w->right.fx, (l.right_ob[1] - w->right.cy) * d / w->right.fy, d};
+    const double pb[3] = {Re[0] * ps[0] + Re[1] * ps[1] + Re[2] * ps[2] + te[0], Re[3] * ps[0] + Re[4] * ps[1] + Re[5] * ps[2] + te[1],
+                          Re[6] * ps[0] + Re[7] * ps[1] + Re[8] * ps[2] + te[2]};
+    const double* R = &Rk[(size_t)9 * bp];
+    const double* t = w->kfs[bp].pose + 4;
+    lm_pw[3 * i] = R[0] * pb[0] + R[1] * pb[1] + R[2] * pb[2] + t[0];
+    lm_pw[3 * i + 1] = R[3] * pb[0] + R[4] * pb[1] + R[5] * pb[2] + t[1];
+    lm_pw[3 * i + 2] = R[6] * pb[0] + R[7] * pb[1] + R[8] * pb[2] + t[2];
+  }
+}
+
+// flags[i] = 1 iff |residual_i| > max_err  (residual pairs of a PoseOnly pass with unit weights = pixel errors)
+__global__ __launch_bounds__(256) void k_flag_outliers(int n, const double2* __restrict__ res, double max_err, uint8_t* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double2 r = res[i];
+  flags[i] = sqrt(r.x * r.x + r.y * r.y) > max_err ? 1 : 0;      // Vector2d::norm() > 10 (backend.cpp:239)
+}
 
 }  // namespace lvf
 
@@ -193,6 +273,7 @@ int lvf_window_slide(lvf_window* w, int64_t first_active_kf_id) {
   w->kfs.erase(w->kfs.begin(), w->kfs.begin() + drop);
   w->kf_index.clear();
   for (size_t k = 0; k < w->kfs.size(); ++k) w->kf_index[w->kfs[k].id] = (int)k;
+  prune(w);
   return LVF_OK;
 }
 
@@ -231,7 +312,7 @@ int lvf_window_get_inv_depth(const lvf_window* w, int64_t lm_id, double* inv_dep
 }
 int lvf_window_counts(const lvf_window* w, int32_t* counts8) {
   LVF_REQUIRE(w && counts8, "lvf_window_counts: null argument");
-  counts8[0] = (int)w->kfs.size(); counts8[1] = (int)w->slot_lm.size(); counts8[2] = w->n_tc; counts8[3] = w->n_tf; counts8[4] = w->n_po;
+  counts8[0] = (int)w->kfs.size(); counts8[1] = w->n_lm_problem; counts8[2] = w->n_tc; counts8[3] = w->n_tf; counts8[4] = w->n_po;
   counts8[5] = w->n_imu; counts8[6] = w->n_prior; counts8[7] = (int)w->lms.size();
   return LVF_OK;
 }
@@ -257,38 +338,9 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   w->slot_lm.clear();
   // landmark->ToWorld() once per live landmark per tick (the reference recomputes it per feature) with the keyframe rotations
   // expanded once, and per frame the one row of the world->cam0 transform that Camera::Far needs
-  auto rot_of = [](const double q[4], double R[9]) {
-    double e0[3] = {1, 0, 0}, e1[3] = {0, 1, 0}, e2[3] = {0, 0, 1}, c0[3], c1[3], c2[3];
-    hse3::rotate(q, e0, c0); hse3::rotate(q, e1, c1); hse3::rotate(q, e2, c2);
-    R[0] = c0[0]; R[1] = c1[0]; R[2] = c2[0]; R[3] = c0[1]; R[4] = c1[1]; R[5] = c2[1]; R[6] = c0[2]; R[7] = c1[2]; R[8] = c2[2];
-  };
-  std::vector<double> Rk((size_t)9 * n_kf);
-  for (int k = 0; k < n_kf; ++k) rot_of(w->kfs[k].pose, &Rk[(size_t)9 * k]);
-  double Re[9];
-  rot_of(w->right.extrinsic, Re);
-  const double* te = w->right.extrinsic + 4;
-  const size_t nl = w->lms.size();
-  std::vector<double> lm_pw((size_t)3 * nl);
-  std::vector<int> lm_birth_pos(nl, -1);
-  const int64_t first_id = w->kfs.front().id;
-  for (size_t i = 0; i < nl; ++i) {
-    const lvf_window::Lm& l = w->lms[i];
-    if (l.fixed) { std::memcpy(&lm_pw[3 * i], l.pw, 24); continue; }
-    if (l.birth_kf < first_id) continue;
-    auto ib = w->kf_index.find(l.birth_kf);
-    if (ib == w->kf_index.end()) continue;
-    const int bp = ib->second;
-    lm_birth_pos[i] = bp;
-    const double d = 1.0 / l.inv_depth;
-    const double ps[3] = {(l.right_ob[0] - w->right.cx) * d / w->right.fx, (l.right_ob[1] - w->right.cy) * d / w->right.fy, d};
-    const double pb[3] = {Re[0] * ps[0] + Re[1] * ps[1] + Re[2] * ps[2] + te[0], Re[3] * ps[0] + Re[4] * ps[1] + Re[5] * ps[2] + te[1],
-                          Re[6] * ps[0] + Re[7] * ps[1] + Re[8] * ps[2] + te[2]};
-    const double* R = &Rk[(size_t)9 * bp];
-    const double* t = w->kfs[bp].pose + 4;
-    lm_pw[3 * i] = R[0] * pb[0] + R[1] * pb[1] + R[2] * pb[2] + t[0];
-    lm_pw[3 * i + 1] = R[3] * pb[0] + R[4] * pb[1] + R[5] * pb[2] + t[1];
-    lm_pw[3 * i + 2] = R[6] * pb[0] + R[7] * pb[1] + R[8] * pb[2] + t[2];
-  }
+  std::vector<double> lm_pw;
+  std::vector<int> lm_birth_pos;
+  landmarks_to_world(w, lm_pw, lm_birth_pos);
   double inv_e[7];
   hse3::inv(w->left.extrinsic, inv_e);
   const double far_z = w->opt.baseline * 50.0;
@@ -350,6 +402,7 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
     }
   }
   const int n_lm = (int)w->slot_lm.size();
+  w->n_lm_problem = n_lm;
   w->n_tc = (int)ntc; w->n_tf = (int)ntf; w->n_po = (int)npo; w->n_imu = (int)imu_i.size(); w->n_prior = (int)pr_b.size();
 
   const auto t_assembled = now();
@@ -433,6 +486,78 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   if (timing)
     std::fprintf(stderr, "lvf_window_solve: assemble %.3f ms, upload %.3f ms, configure %.3f ms, solve %.3f ms (%d its), read-back %.3f ms\n", ms(t_begin, t_assembled),
                  ms(t_assembled, t_uploaded), ms(t_uploaded, t_configured), ms(t_configured, t_solved), summary->num_iterations, ms(t_solved, now()));
+  return LVF_OK;
+}
+
+// Backend::Optimize's outlier gate (src/lvio_fusion/src/backend.cpp:185-190, :229-245): every feature that is not its landmark's first
+// observation is re-projected with weight 1 — compute_reprojection_error = |PoseOnlyReprojectionError(ob, landmark->ToWorld(), camera, 1)
+// (frame->pose)| — and removed when the error exceeds max_px (10 in the reference).  The residual pass is the PoseOnly hot-path kernel
+// on device (one batch over all such features of the window); the host only applies the removals to its mirror, like
+// landmark->RemoveObservation(feature) + frame->RemoveFeature(feature).  removed_lm / removed_kf (may be NULL) receive up to `capacity`
+// (landmark id, keyframe id) pairs in frame order; *n_removed the total.
+int lvf_window_reject_outliers(lvf_window* w, double max_px, int64_t* removed_lm, int64_t* removed_kf, int capacity, int* n_removed) {
+  LVF_REQUIRE(w && n_removed, "lvf_window_reject_outliers: null argument");
+  LVF_REQUIRE(capacity >= 0 && (capacity == 0 || (removed_lm && removed_kf)), "lvf_window_reject_outliers: bad output arrays");
+  *n_removed = 0;
+  if (w->kfs.empty()) return LVF_OK;
+  lvf_ctx* ctx = w->ctx;
+  LVF_TRY(lvf::enter(ctx));
+  hipStream_t s = ctx->stream;
+  const int n_kf = (int)w->kfs.size();
+  std::vector<double> lm_pw;
+  std::vector<int> lm_birth_pos;
+  landmarks_to_world(w, lm_pw, lm_birth_pos);
+  // features that are not their landmark's first observation, in frame order / ascending landmark id
+  std::vector<double> ob, pw, poses((size_t)7 * n_kf), ones(n_kf, 1.0);
+  std::vector<int32_t> kf, pi;
+  std::vector<std::pair<int, int>> where;          // (keyframe position, index into its obs)
+  for (int k = 0; k < n_kf; ++k) {
+    lvf_window::Kf& f = w->kfs[k];
+    f.sort_unique();
+    std::memcpy(&poses[(size_t)7 * k], f.pose, 56);
+    for (size_t j = 0; j < f.obs.size(); ++j) {
+      const lvf_window::Obs& o = f.obs[j];
+      const lvf_window::Lm& l = w->lms[o.lm];
+      if (l.birth_kf == f.id) continue;
+      if (!l.fixed && lm_birth_pos[o.lm] < 0) continue;   // birth pose unknown (never happens through this API)
+      ob.push_back(o.ob[0]); ob.push_back(o.ob[1]);
+      pw.insert(pw.end(), &lm_pw[(size_t)3 * o.lm], &lm_pw[(size_t)3 * o.lm] + 3);
+      pi.push_back((int32_t)kf.size()); kf.push_back(k);
+      where.emplace_back(k, (int)j);
+    }
+  }
+  const int n = (int)kf.size();
+  if (n == 0) return LVF_OK;
+  if (!w->rej) {
+    const double z2[2] = {0, 0}; const int32_t z = 0; const double id7[7] = {0, 0, 0, 1, 0, 0, 0};
+    LVF_TRY(lvf_pose_only_create(ctx, &w->left, 0, z2, &z, &z, 0, id7, &w->rej));
+    LVF_TRY(lvf_state_create(ctx, 0, 0, &w->rej_st));
+  }
+  lvf_batch* b = w->rej;
+  lvf_state* st = w->rej_st;
+  st->n_kf = n_kf; st->n_lm = 0;
+  LVF_TRY(st->poses.assign(poses.data(), poses.size(), s)); LVF_TRY(st->w_visual.assign(ones.data(), ones.size(), s));
+  LVF_TRY(b->ob_a.assign(ob.data(), ob.size(), s)); LVF_TRY(b->idx_a.assign(kf.data(), kf.size(), s)); LVF_TRY(b->idx_b.assign(pi.data(), pi.size(), s));
+  LVF_TRY(b->table.assign(pw.data(), pw.size(), s)); LVF_TRY(b->res.ensure((size_t)2 * n));
+  b->n = n; b->n_table = n; b->min_n_kf = n_kf; b->min_n_lm = 0; b->sorted_by_kf = true; b->evaluated = false;
+  LVF_TRY(launch_pose_only(b, st, false));
+  LVF_TRY(w->rej_flags.ensure(n));
+  hipLaunchKernelGGL(k_flag_outliers, dim3((n + 255) / 256), dim3(256), 0, s, n, reinterpret_cast<const double2*>(b->res.p), max_px, w->rej_flags.p);
+  LVF_HIP(hipGetLastError());
+  std::vector<uint8_t> flags(n);
+  LVF_HIP(hipMemcpyAsync(flags.data(), w->rej_flags.p, n, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  // apply the removals (back to front inside each keyframe so the stored positions stay valid)
+  int total = 0;
+  for (int i = 0; i < n; ++i)
+    if (flags[i]) {
+      if (total < capacity) { removed_lm[total] = w->kfs[where[i].first].obs[where[i].second].lm_id; removed_kf[total] = w->kfs[where[i].first].id; }
+      ++total;
+    }
+  for (int i = n - 1; i >= 0; --i)
+    if (flags[i]) { auto& v = w->kfs[where[i].first].obs; v.erase(v.begin() + where[i].second); }
+  *n_removed = total;
+  if (total) prune(w);
   return LVF_OK;
 }
 

@@ -31,6 +31,10 @@ static void wr(const std::string& dir, const std::string& name, const std::vecto
   std::ofstream f(dir + "/" + name, std::ios::binary);
   f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(double)));
 }
+static void wri(const std::string& dir, const std::string& name, const std::vector<int>& v) {
+  std::ofstream f(dir + "/" + name, std::ios::binary);
+  f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(int)));
+}
 static lvf_camera cam_of(const std::vector<double>& c) {
   lvf_camera k;
   k.fx = c[0]; k.fy = c[1]; k.cx = c[2]; k.cy = c[3];
@@ -142,6 +146,46 @@ static int run_window(const std::string& dir) {
   std::string err;
   if (!gpu::Evaluate(&problem, &cost0, &residuals, &err)) { std::fprintf(stderr, "Evaluate failed: %s\n", err.c_str()); return 1; }
   wr(dir, "out_residuals.f64", residuals);
+  // the upstream-shaped call: robustified residuals, gradient and the CRS Jacobian in local coordinates
+  int crs_rows = 0, crs_cols = 0;
+  {
+    ceres::Problem::EvaluateOptions eo;
+    double cost1 = -1.0;
+    std::vector<double> res1, grad;
+    ceres::CRSMatrix jac;
+    if (!gpu::Evaluate(&problem, eo, &cost1, &res1, &grad, &jac, &err)) { std::fprintf(stderr, "Evaluate (CRS) failed: %s\n", err.c_str()); return 1; }
+    if (cost1 != cost0) { std::fprintf(stderr, "Evaluate: cost differs between the two forms\n"); return 1; }
+    wr(dir, "out_eval_residuals.f64", res1); wr(dir, "out_eval_gradient.f64", grad); wr(dir, "out_crs_values.f64", jac.values);
+    wri(dir, "out_crs_rows.i32", jac.rows); wri(dir, "out_crs_cols.i32", jac.cols);
+    crs_rows = jac.num_rows; crs_cols = jac.num_cols;
+    // which caller array every column block is: (kind, index, first column) with kind 0 pose, 1 vel, 2 ba, 3 bg, 4 inverse depth
+    std::vector<double*> pbs;
+    problem.GetParameterBlocks(&pbs);
+    std::vector<int> colmap;
+    int col = 0;
+    auto inside = [](const std::vector<double>& a, const double* p) { return !a.empty() && p >= a.data() && p < a.data() + a.size(); };
+    for (double* pb : pbs) {
+      int kind = -1, index = -1, local = 0;
+      if (inside(poses, pb)) { kind = 0; index = (int)(pb - poses.data()) / 7; local = 6; }
+      else if (inside(vel, pb)) { kind = 1; index = (int)(pb - vel.data()) / 3; local = 3; }
+      else if (inside(ba, pb)) { kind = 2; index = (int)(pb - ba.data()) / 3; local = 3; }
+      else if (inside(bg, pb)) { kind = 3; index = (int)(pb - bg.data()) / 3; local = 3; }
+      else if (inside(invd, pb)) { kind = 4; index = (int)(pb - invd.data()); local = 1; }
+      colmap.push_back(kind); colmap.push_back(index); colmap.push_back(col);
+      col += local;
+    }
+    if (col != crs_cols) { std::fprintf(stderr, "Evaluate: %d columns, expected %d\n", crs_cols, col); return 1; }
+    wri(dir, "out_crs_colmap.i32", colmap);
+    // a second call restricted to two parameter blocks, in reverse order: columns follow options.parameter_blocks, the rest is held constant
+    ceres::Problem::EvaluateOptions sub;
+    sub.parameter_blocks = {&poses[7 * (n_kf - 1)], &poses[7 * 1]};
+    sub.apply_loss_function = false;
+    std::vector<double> grad2;
+    ceres::CRSMatrix jac2;
+    if (!gpu::Evaluate(&problem, sub, nullptr, nullptr, &grad2, &jac2, &err)) { std::fprintf(stderr, "Evaluate (subset) failed: %s\n", err.c_str()); return 1; }
+    if (jac2.num_cols != 12 || (int)grad2.size() != 12 || jac2.num_rows != jac.num_rows) { std::fprintf(stderr, "Evaluate (subset): bad shape\n"); return 1; }
+    wr(dir, "out_sub_gradient.f64", grad2); wr(dir, "out_sub_values.f64", jac2.values); wri(dir, "out_sub_rows.i32", jac2.rows); wri(dir, "out_sub_cols.i32", jac2.cols);
+  }
 
   // per-block CostFunction::Evaluate (Ceres calling convention) on the first block of each type
   std::vector<double> probe_out;
@@ -180,9 +224,10 @@ static int run_window(const std::string& dir) {
     poses = p2; vel = v2; ba = a2; bg = g2; invd = d2;
   }
   std::printf("{\"ok\": %d, \"message\": \"%s\", \"cost0\": %.17g, \"initial_cost\": %.17g, \"final_cost\": %.17g, \"successful\": %d, \"unsuccessful\": %d, "
-              "\"num_residual_blocks\": %d, \"num_frames\": %d, \"n_prior\": %d, \"n_probe\": %zu, \"termination\": %d}\n",
+              "\"num_residual_blocks\": %d, \"num_frames\": %d, \"n_prior\": %d, \"n_probe\": %zu, \"termination\": %d, \"crs_rows\": %d, \"crs_cols\": %d}\n",
               summary.termination_type != ceres::FAILURE, summary.message.c_str(), cost0, summary.initial_cost, summary.final_cost, summary.num_successful_steps,
-              summary.num_unsuccessful_steps, summary.num_residual_blocks_reduced, problem.num_frames, n_prior, probe_cf.size(), (int)summary.termination_type);
+              summary.num_unsuccessful_steps, summary.num_residual_blocks_reduced, problem.num_frames, n_prior, probe_cf.size(), (int)summary.termination_type, crs_rows,
+              crs_cols);
   return summary.termination_type == ceres::FAILURE ? 1 : 0;
 }
 

@@ -15,6 +15,7 @@
 #include "extract.h"
 #include "knn.h"
 #include "lm.h"
+#include "loop.h"
 #include "robust.h"
 
 using namespace lvo;
@@ -181,6 +182,14 @@ void lvo_relocate_r_eval(const double* relocated, const double* unrelocated, con
   RelocateRResidual(relocated, unrelocated, Q, rr);
   for (int a = 0; a < 7; ++a) { r[a] = rr[a].a; if (J) for (int k = 0; k < 4; ++k) J[4 * a + k] = rr[a].v[k]; }
 }
+// Relocator::UpdateNewSubmap's rotation solve (relocator.cpp:247-268); opts6 = (max_iters, function_tol, gradient_tol, parameter_tol,
+// min_relative_decrease, initial radius); out5 = (initial_cost, final_cost, iterations, successful steps, termination)
+void lvo_relocate_rotation_solve(int n, const double* relocated, const double* unrelocated, double* q4, const double* opts6, double* out5) {
+  RelocOut o;
+  relocate_rotation_solve(n, relocated, unrelocated, q4, (int)opts6[0], opts6[1], opts6[2], opts6[3], opts6[4], opts6[5], &o);
+  out5[0] = o.initial_cost; out5[1] = o.final_cost; out5[2] = o.iters; out5[3] = o.successes; out5[4] = o.termination;
+}
+void lvo_forward_update(const double* T, int n, double* poses, double* vw) { forward_update(T, n, poses, vw); }
 void lvo_prior3_eval(int mode, const double* rpyxyz0, double weight, const double* rpyxyz, double* r, double* J) {
   if (mode == 0) PriorRpzResidual<double>(rpyxyz0, weight, rpyxyz + 1, rpyxyz + 2, rpyxyz + 5, r);
   else PriorYxyResidual<double>(rpyxyz0, weight, rpyxyz + 0, rpyxyz + 3, rpyxyz + 4, r);

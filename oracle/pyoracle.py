@@ -174,6 +174,22 @@ def relocate_r(relocated, unrelocated, q4):
     return r, J
 
 
+def relocate_rotation_solve(relocated, unrelocated, q4, max_iters=50, function_tol=1e-6, gradient_tol=1e-10, parameter_tol=1e-8, min_relative_decrease=1e-3,
+                            radius=1e4):
+    """Relocator::UpdateNewSubmap's rotation solve; returns (q4_new, summary dict)."""
+    a, b = _f64(relocated), _f64(unrelocated)
+    q = _f64(q4).copy(); opts = _f64([max_iters, function_tol, gradient_tol, parameter_tol, min_relative_decrease, radius]); out5 = np.empty(5)
+    lib().lvo_relocate_rotation_solve(a.shape[0], _p(a), _p(b), _p(q), _p(opts), _p(out5))
+    return q, dict(initial_cost=out5[0], final_cost=out5[1], num_iterations=int(out5[2]), num_successful_steps=int(out5[3]), termination=int(out5[4]))
+
+
+def forward_update(transform, poses, vw=None):
+    """PoseGraph::ForwardUpdate; returns updated copies (poses, vw)."""
+    T = _f64(transform); P = _f64(poses).copy(); V = None if vw is None else _f64(vw).copy()
+    lib().lvo_forward_update(_p(T), P.shape[0], _p(P), _p(V))
+    return P, V
+
+
 def prior3(mode, rpyxyz0, weight, rpyxyz):
     a, b = _f64(rpyxyz0), _f64(rpyxyz)
     r = np.empty(3); J = np.empty((3, 3))

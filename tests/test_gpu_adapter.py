@@ -139,6 +139,79 @@ def test_window_through_adapter(tmp_path, oracle, with_imu, weak_thr, const_kf):
     scale = np.abs(exp).max()
     assert np.abs(got - exp).max() <= 1e-6 * scale
 
+    # ---- upstream-shaped Problem::Evaluate: robustified residuals, gradient, CRS Jacobian in local coordinates vs a numpy assembly
+    from tests.test_oracle_lm_numpy import dense_system, to_local
+    cfg_d = dict(cfg); cfg_d["imu"] = list(imu)
+    state0 = [np.asarray(cfg[k], dtype=np.float64) for k in ("poses", "vel", "ba", "bg", "inv_depth")]
+    Jd, rd_, cost_d = dense_system(oracle, cfg_d, pre if with_imu else np.zeros((0, 467)), state0)
+    n_tc, n_tf, n_po = len(tc["lm_idx"]), len(tf["lm_idx"]), len(po["kf_idx"])
+    ncol_d = 15 * n_kf + n_lm
+    rows_e, res_e = [], []
+    ip = 0
+    for k in range(n_kf):
+        for i in np.nonzero(tc["kf_idx"] == k)[0]:
+            rows_e.append(Jd[2 * i:2 * i + 2]); res_e.append(rd_[2 * i:2 * i + 2])
+        for i in np.nonzero(po["kf_idx"] == k)[0]:
+            o = 2 * (n_tc + n_tf + i); rows_e.append(Jd[o:o + 2]); res_e.append(rd_[o:o + 2])
+        for i in np.nonzero(tf["kf2_idx"] == k)[0]:
+            o = 2 * (n_tc + i); rows_e.append(Jd[o:o + 2]); res_e.append(rd_[o:o + 2])
+        if with_imu and k > 0:
+            o = 2 * (n_tc + n_tf + n_po) + 15 * (k - 1); rows_e.append(Jd[o:o + 15]); res_e.append(rd_[o:o + 15])
+        if ip < len(kf_b) and kf_b[ip] == k:
+            blk = np.zeros((6, ncol_d))
+            if kf_a[ip] < 0:
+                r6, J6 = oracle.pose_prior(tgt[ip], 100.0, 0.0, cfg["poses"][k]); blk[:, 6 * k:6 * k + 6] = to_local(J6, cfg["poses"][k])
+            else:
+                r6, Ja, Jb = oracle.pose_graph(tgt[ip][:6], 100.0, 0.0, cfg["poses"][k - 1], cfg["poses"][k])
+                blk[:, 6 * (k - 1):6 * k] = to_local(Ja, cfg["poses"][k - 1]); blk[:, 6 * k:6 * k + 6] = to_local(Jb, cfg["poses"][k])
+            rows_e.append(blk); res_e.append(r6); ip += 1
+    J_exp, r_exp = np.concatenate(rows_e), np.concatenate(res_e)
+    if const_kf >= 0:
+        J_exp[:, 6 * const_kf:6 * const_kf + 6] = 0.0
+    colmap = np.fromfile(os.path.join(d, "out_crs_colmap.i32"), dtype=np.int32).reshape(-1, 3)
+    crs_rows, crs_cols = np.fromfile(os.path.join(d, "out_crs_rows.i32"), dtype=np.int32), np.fromfile(os.path.join(d, "out_crs_cols.i32"), dtype=np.int32)
+    crs_vals = rd("out_crs_values.f64")
+    assert out["crs_rows"] == J_exp.shape[0] == len(crs_rows) - 1
+    J_got = np.zeros((out["crs_rows"], out["crs_cols"]))
+    for i in range(out["crs_rows"]):
+        cs = crs_cols[crs_rows[i]:crs_rows[i + 1]]
+        assert np.all(np.diff(cs) > 0), "CRS columns of a row must ascend"
+        J_got[i, cs] = crs_vals[crs_rows[i]:crs_rows[i + 1]]
+    local = {0: 6, 1: 3, 2: 3, 3: 3, 4: 1}
+    dense_col = lambda kind, idx: (6 * idx if kind == 0 else (6 * n_kf + 9 * idx + 3 * (kind - 1) if kind < 4 else 15 * n_kf + idx))
+    perm = np.concatenate([np.arange(dense_col(k_, i_), dense_col(k_, i_) + local[k_]) for k_, i_, c_ in colmap])
+    assert [c_ for _, _, c_ in colmap] == list(np.cumsum([0] + [local[k_] for k_, _, _ in colmap])[:-1])
+    assert_parity(rd("out_eval_residuals.f64"), r_exp, "Problem::Evaluate residuals (loss applied)")
+    scale = np.abs(J_exp).max()
+    assert np.abs(J_got - J_exp[:, perm]).max() <= 1e-6 * scale, "Problem::Evaluate CRS Jacobian"
+    g_exp = (J_exp.T @ r_exp)[perm]
+    assert np.abs(rd("out_eval_gradient.f64") - g_exp).max() <= 1e-6 * np.abs(g_exp).max(), "Problem::Evaluate gradient"
+    if const_kf >= 0:       # a constant block keeps its columns, without entries
+        c0_ = int(colmap[(colmap[:, 0] == 0) & (colmap[:, 1] == const_kf)][0, 2])
+        assert not np.isin(crs_cols, np.arange(c0_, c0_ + 6)).any()
+    # subset call: columns = (pose n_kf-1, pose 1), raw residual Jacobian (apply_loss_function = false)
+    Jr, rr_, _ = dense_system(oracle, cfg_d, pre if with_imu else np.zeros((0, 467)), state0, huber_a=0.0)
+    sub_rows, sub_cols, sub_vals = np.fromfile(os.path.join(d, "out_sub_rows.i32"), dtype=np.int32), np.fromfile(os.path.join(d, "out_sub_cols.i32"), dtype=np.int32), rd("out_sub_values.f64")
+    J_sub = np.zeros((len(sub_rows) - 1, 12))
+    for i in range(len(sub_rows) - 1):
+        J_sub[i, sub_cols[sub_rows[i]:sub_rows[i + 1]]] = sub_vals[sub_rows[i]:sub_rows[i + 1]]
+    # rows of the raw system in insertion order (priors carry no loss: same rows as above)
+    rows_r, ip = [], 0
+    pr_rows = [b_ for b_ in rows_e if b_.shape[0] == 6]
+    for k in range(n_kf):
+        rows_r += [Jr[2 * i:2 * i + 2] for i in np.nonzero(tc["kf_idx"] == k)[0]]
+        rows_r += [Jr[2 * (n_tc + n_tf + i):2 * (n_tc + n_tf + i) + 2] for i in np.nonzero(po["kf_idx"] == k)[0]]
+        rows_r += [Jr[2 * (n_tc + i):2 * (n_tc + i) + 2] for i in np.nonzero(tf["kf2_idx"] == k)[0]]
+        if with_imu and k > 0:
+            o = 2 * (n_tc + n_tf + n_po) + 15 * (k - 1); rows_r.append(Jr[o:o + 15])
+        if ip < len(kf_b) and kf_b[ip] == k:
+            rows_r.append(pr_rows[ip]); ip += 1
+    Jr_exp = np.concatenate(rows_r)
+    sel = np.concatenate([np.arange(6 * (n_kf - 1), 6 * n_kf), np.arange(6, 12)])
+    if const_kf == 1 or const_kf == n_kf - 1:
+        Jr_exp[:, 6 * const_kf:6 * const_kf + 6] = 0.0
+    assert np.abs(J_sub - Jr_exp[:, sel]).max() <= 1e-6 * np.abs(Jr_exp).max(), "Problem::Evaluate with options.parameter_blocks"
+
     # ---- per-block CostFunction::Evaluate probes: [TwoCamera | PoseOnly | TwoFrame | ImuError], jacobians[1] = NULL honoured
     probe = rd("out_probe.f64")
     assert out["n_probe"] == (4 if with_imu else 3)

@@ -134,6 +134,66 @@ def test_ticks_match_from_scratch_assembly(oracle, with_imu, weak_thr):
     assert seen_po > 0, "the replay never exercised the TwoFrame -> PoseOnly conversion"
     if not with_imu:
         assert seen_prior > 0
-    # departed frames stay queryable (their pose anchors the frozen landmarks)
-    assert_parity(win.pose(100), departed[0], "departed pose")
+    # a departed frame stays queryable exactly while a live landmark was born there (its pose anchors the frozen world point);
+    # afterwards the window forgets it (bounded host mirror)
+    act_now = list(range(max(0, N - W), N))
+    for k0 in (0, N - W - 1):
+        anchors = any(birth[l] == k0 for k in act_now for l in obs[k])
+        if anchors:
+            assert_parity(win.pose(100 + k0), departed[k0], "departed pose")
+        else:
+            with pytest.raises(api.LvfError):
+                win.pose(100 + k0)
+    live = {l for k in act_now for l in obs[k]}
+    assert win.counts()["lm_known"] == len(live)
+    win.close(); ctx.close()
+
+
+def test_reject_outliers_matches_the_reference_gate(oracle):
+    """Backend::Optimize's outlier rejection (backend.cpp:229-245): features that are not their landmark's first observation and whose
+    unit-weight reprojection error exceeds 10 px are removed; the device gate must pick exactly the set the oracle's PoseOnly residuals
+    pick at the window's solved state, and the next tick must be assembled without them."""
+    from lvio_fusion_amd import api
+    from tests.helpers import ocam
+    N = 7
+    cfg = syn.config4_window(n_kf=N, n_lm=200, n_prewindow=0, seed=4711, imu_samples=4)
+    cam0, cam1 = cfg["cam0"], cfg["cam1"]
+    tc, tf = cfg["tc"], cfg["tf"]
+    rng = np.random.default_rng(3)
+    bad = rng.choice(len(tf["lm_idx"]), 25, replace=False)
+    tf_ob = tf["ob"].copy(); tf_ob[bad] += rng.choice([-1, 1], (25, 2)) * rng.uniform(25, 60, (25, 2))     # gross outliers
+    ctx = api.Context(0)
+    win = api.Window(ctx, cam0, cam1, baseline=syn.baseline())
+    birth = {int(l): int(k) for l, k in zip(tc["lm_idx"], tc["kf_idx"])}
+    right_ob = {int(l): tc["right_ob"][i] for i, l in enumerate(tc["lm_idx"])}
+    for t in range(N):
+        win.add_keyframe(t, cfg["poses"][t], cfg["w_kf"][t])
+        for i in np.nonzero(tc["kf_idx"] == t)[0]:
+            win.add_landmark(int(tc["lm_idx"][i]), t, tc["left_ob"][i], tc["right_ob"][i], cfg["inv_depth"][tc["lm_idx"][i]])
+        for i in np.nonzero(tf["kf2_idx"] == t)[0]:
+            win.add_observation(int(tf["lm_idx"][i]), t, tf_ob[i])
+    opt = api.default_solver_options(); opt.max_num_iterations = 6
+    win.solve(opt)
+    cnt0 = win.counts()
+    # expected set from the oracle at the solved state
+    poses = np.array([win.pose(t) for t in range(N)])
+    pw = np.array([to_world(cam1, right_ob[int(l)], win.inv_depth(int(l)), poses[birth[int(l)]]) for l in tf["lm_idx"]])
+    r, _ = oracle.pose_only(tf_ob, tf["kf2_idx"], np.arange(len(pw), dtype=np.int32), pw, poses, np.ones(N), ocam(oracle, cam0), jac=False)
+    err = np.linalg.norm(r, axis=1)
+    assert np.abs(err - 10.0).min() > 1e-6, "a feature sits on the threshold: pick another seed"
+    expect = sorted((int(tf["lm_idx"][i]), int(tf["kf2_idx"][i])) for i in np.nonzero(err > 10.0)[0])
+    assert len(expect) >= 20
+    removed, n = win.reject_outliers(10.0)
+    assert n == len(expect) and sorted(removed) == expect
+    # idempotent, and the next tick no longer contains them
+    removed2, n2 = win.reject_outliers(10.0)
+    assert n2 == 0 and removed2 == []
+    win.solve(opt)
+    cnt1 = win.counts()
+    assert cnt1["tf"] == cnt0["tf"] - n and cnt1["tc"] == cnt0["tc"]
+    # a tight gate removes every non-birth feature; landmarks keep their birth observation, nothing else
+    removed3, n3 = win.reject_outliers(0.0, capacity=8)
+    assert n3 == cnt1["tf"] and len(removed3) == 8
+    win.solve(opt)
+    assert win.counts()["tf"] == 0
     win.close(); ctx.close()

@@ -65,8 +65,9 @@ def dense_system(oracle, cfg, pre, state, huber_a=1.0):
         blk = np.zeros((2, ncol)); blk[:, 6 * k:6 * k + 6] = sc * to_local(J[i], poses[k])
         rows.append(blk); res.append(sc * r[i])
     ki = [f["kf_i"] for f in cfg["imu"]]; kj = [f["kf_j"] for f in cfg["imu"]]
-    r, J480 = oracle.imu_eval(pre, ki, kj, poses, vel, ba, bg)
-    Js = oracle.imu_split_jac(J480)
+    if ki:
+        r, J480 = oracle.imu_eval(pre, ki, kj, poses, vel, ba, bg)
+        Js = oracle.imu_split_jac(J480)
     for f in range(len(ki)):          # ImuError: no loss function (backend.cpp:159)
         cost += 0.5 * r[f] @ r[f]
         blk = np.zeros((15, ncol))
