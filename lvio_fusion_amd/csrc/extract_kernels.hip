@@ -16,11 +16,13 @@
 //   * running counters of Segment() (:163-197)                              -> exclusive prefix sum in row-major order
 //   * AdjustDistortion's `half_passed` latch (association.cpp:125-131)     -> prefix-OR of the latch condition
 // Float arithmetic follows the reference's float/double promotions; sin/cos of the two constant angles and the start/end
-// orientations are taken on the HOST (glibc, as the reference), per-point atan2f/sqrtf are the device's.
+// orientations are taken on the HOST; every atan2 of floats — host or device — is cr_atan2f (cr_math.hpp: correctly rounded, one
+// operation sequence for both sides), sqrtf is IEEE on both: the per-pixel decisions are reproducible bit for bit.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <vector>
+#include "cr_math.hpp"
 #include "lvf_internal.hpp"
 
 #pragma clang fp contract(off)
@@ -53,10 +55,10 @@ __global__ __launch_bounds__(kE) void k_ex_preflag(int n, const float* __restric
 __device__ __forceinline__ float deg_of(float rad) { return (float)((double)(rad * 180) / kPi); }   // `x * 180 / M_PI` with x float
 
 __device__ __forceinline__ bool pixel_of(const float4 p, const ExP P, int& row, int& col) {
-  const float va = deg_of(atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)));
+  const float va = deg_of(cr_atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)));
   row = (int)((va + P.ang_bottom) / P.ang_res_y);
   if (row < 0 || row >= P.R) return false;
-  const float ha = deg_of(atan2f(p.x, p.y));
+  const float ha = deg_of(cr_atan2f(p.x, p.y));
   col = (int)(-round(((double)ha - 90.0) / (double)P.ang_res_x) + (double)(P.Cn / 2));
   if (col >= P.Cn) col -= P.Cn;
   return !(col < 0 || col >= P.Cn);
@@ -84,7 +86,7 @@ __device__ __forceinline__ int pair_state(const float4* __restrict__ full, int C
   const float4 lo = full[(size_t)i * Cn + j], up = full[(size_t)(i + 1) * Cn + j];
   if (lo.w == -1.0f || up.w == -1.0f) return 0;
   const float dx = up.x - lo.x, dy = up.y - lo.y, dz = up.z - lo.z;
-  const float angle = deg_of(atan2f(dz, sqrtf(dx * dx + dy * dy)));
+  const float angle = deg_of(cr_atan2f(dz, sqrtf(dx * dx + dy * dy)));
   return fabsf(angle) <= 10.0f ? 1 : 2;
 }
 // ground_mat == 1 after the reference's sequential sweep, and the initial label (-1 = ground or empty, 0 = to be segmented)
@@ -122,7 +124,7 @@ __device__ __forceinline__ void uf_unite(int* parent, int a, int b) {
 }
 __device__ __forceinline__ bool linked(float ra, float rb, float s, float c, float theta) {
   const float d1 = fmaxf(ra, rb), d2 = fminf(ra, rb);
-  return atan2f(d2 * s, d1 - d2 * c) > theta;
+  return cr_atan2f(d2 * s, d1 - d2 * c) > theta;
 }
 __global__ __launch_bounds__(kE) void k_ex_union(int npix, const float* __restrict__ range, ExP P, int* __restrict__ parent) {
   const int idx = blockIdx.x * kE + threadIdx.x;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(kE) void k_ex_segemit(int npix, int Cn, const int* 
 // AdjustDistortion: the latch condition evaluated under "!half_passed" (valid up to and including the first true)
 struct OriP { float start, end, diff; double cycle; };
 __device__ __forceinline__ float ori_first_half(float x, float y, OriP o, bool& latch) {
-  float ori = -atan2f(y, x);
+  float ori = -cr_atan2f(y, x);
   if ((double)ori < (double)o.start - kPi / 2) ori = (float)((double)ori + 2 * kPi);
   else if ((double)ori > (double)o.start + kPi * 3 / 2) ori = (float)((double)ori - 2 * kPi);
   latch = (double)(ori - o.start) > kPi;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(kE) void k_ex_reltime(int m, float4* __restrict__ s
   float ori;
   if (latch_before[i] == 0) { bool l; ori = ori_first_half(p.x, p.y, o, l); }
   else {
-    ori = -atan2f(p.y, p.x);
+    ori = -cr_atan2f(p.y, p.x);
     ori = (float)((double)ori + 2 * kPi);
     if ((double)ori < (double)o.end - kPi * 3 / 2) ori = (float)((double)ori + 2 * kPi);
     else if ((double)ori > (double)o.end + kPi / 2) ori = (float)((double)ori - 2 * kPi);
@@ -321,8 +323,8 @@ int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_float
   // FindStartEndAngle (projection.cpp:42-56), host arithmetic like the reference
   OriP o;
   {
-    float start = -std::atan2(ends[0].y, ends[0].x);
-    float end = -std::atan2(ends[1].y, ends[1].x) + 2 * M_PI;
+    float start = -cr_atan2f(ends[0].y, ends[0].x);
+    float end = -cr_atan2f(ends[1].y, ends[1].x) + 2 * M_PI;
     if (end - start > 3 * M_PI) end -= 2 * M_PI;
     else if (end - start < M_PI) end += 2 * M_PI;
     o.start = start; o.end = end; o.diff = end - start; o.cycle = prm->cycle_time;

@@ -11,6 +11,7 @@
 //     k >= size - 5) hold whatever an earlier scan left; the oracle reads them as 0 (fresh allocation);
 //   * pcl::removeNaNFromPointCloud drops points with a non-finite x, y or z.
 #pragma once
+#include "cr_math.h"
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -63,8 +64,8 @@ inline void lidar_extract(const float* pts, int n, int stride, const LidarParams
   for (size_t i = 0; i < (size_t)R * Cn; ++i) full[4 * i + 3] = -1.0f;
   float start_ori = 0, end_ori = 0, ori_diff = 1;
   if (m > 0) {   // FindStartEndAngle, projection.cpp:42-56
-    start_ori = -std::atan2(F[1], F[0]);
-    end_ori = -std::atan2(F[4 * (size_t)(m - 1) + 1], F[4 * (size_t)(m - 1)]) + 2 * M_PI;
+    start_ori = -cr_atan2f(F[1], F[0]);
+    end_ori = -cr_atan2f(F[4 * (size_t)(m - 1) + 1], F[4 * (size_t)(m - 1)]) + 2 * M_PI;
     if (end_ori - start_ori > 3 * M_PI) end_ori -= 2 * M_PI;
     else if (end_ori - start_ori < M_PI) end_ori += 2 * M_PI;
     ori_diff = end_ori - start_ori;
@@ -72,10 +73,10 @@ inline void lidar_extract(const float* pts, int n, int stride, const LidarParams
   // ---- ProjectPointCloud, projection.cpp:58-98
   for (int i = 0; i < m; ++i) {
     const float x = F[4 * (size_t)i], y = F[4 * (size_t)i + 1], z = F[4 * (size_t)i + 2];
-    const float vertical_angle = std::atan2(z, std::sqrt(x * x + y * y)) * 180 / M_PI;
+    const float vertical_angle = cr_atan2f(z, std::sqrt(x * x + y * y)) * 180 / M_PI;
     const int row = (vertical_angle + ang_bottom) / ang_res_y;
     if (row < 0 || row >= R) continue;
-    const float horizon_angle = std::atan2(x, y) * 180 / M_PI;
+    const float horizon_angle = cr_atan2f(x, y) * 180 / M_PI;
     int col = -std::round((horizon_angle - 90.0) / ang_res_x) + Cn / 2;
     if (col >= Cn) col -= Cn;
     if (col < 0 || col >= Cn) continue;
@@ -90,7 +91,7 @@ inline void lidar_extract(const float* pts, int n, int stride, const LidarParams
       const size_t lo = (size_t)j + (size_t)i * Cn, up = (size_t)j + (size_t)(i + 1) * Cn;
       if (full[4 * lo + 3] == -1 || full[4 * up + 3] == -1) { D.ground_mat[lo] = -1; continue; }
       const float dx = full[4 * up] - full[4 * lo], dy = full[4 * up + 1] - full[4 * lo + 1], dz = full[4 * up + 2] - full[4 * lo + 2];
-      const float angle = std::atan2(dz, std::sqrt(dx * dx + dy * dy)) * 180 / M_PI;
+      const float angle = cr_atan2f(dz, std::sqrt(dx * dx + dy * dy)) * 180 / M_PI;
       if (std::abs(angle) <= 10) { D.ground_mat[lo] = 1; D.ground_mat[up] = 1; }
     }
   for (size_t i = 0; i < (size_t)R * Cn; ++i)
@@ -120,7 +121,7 @@ inline void lidar_extract(const float* pts, int n, int stride, const LidarParams
           const float ra = D.range_mat[(size_t)fx * Cn + fy], rb = D.range_mat[(size_t)tx * Cn + ty];
           const float d1 = std::max(ra, rb), d2 = std::min(ra, rb);
           const float alpha = nb[k][0] == 0 ? alpha_x : alpha_y;
-          const float angle = std::atan2(d2 * std::sin(alpha), (d1 - d2 * std::cos(alpha)));
+          const float angle = cr_atan2f(d2 * std::sin(alpha), (d1 - d2 * std::cos(alpha)));
           if (angle > theta) {
             qx[qend] = tx; qy[qend] = ty; ++qsize; ++qend;
             D.label_mat[(size_t)tx * Cn + ty] = label_count;
@@ -155,7 +156,7 @@ inline void lidar_extract(const float* pts, int n, int stride, const LidarParams
   bool half_passed = false;
   for (int i = 0; i < num; ++i) {
     float* p = &D.segmented[4 * (size_t)i];
-    float ori = -std::atan2(p[1], p[0]);
+    float ori = -cr_atan2f(p[1], p[0]);
     if (!half_passed) {
       if (ori < start_ori - M_PI / 2) ori += 2 * M_PI;
       else if (ori > start_ori + M_PI * 3 / 2) ori -= 2 * M_PI;

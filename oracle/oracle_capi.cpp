@@ -189,6 +189,7 @@ void lvo_relocate_rotation_solve(int n, const double* relocated, const double* u
   relocate_rotation_solve(n, relocated, unrelocated, q4, (int)opts6[0], opts6[1], opts6[2], opts6[3], opts6[4], opts6[5], &o);
   out5[0] = o.initial_cost; out5[1] = o.final_cost; out5[2] = o.iters; out5[3] = o.successes; out5[4] = o.termination;
 }
+void lvo_cr_atan2f(int n, const float* y, const float* x, float* out) { for (int i = 0; i < n; ++i) out[i] = cr_atan2f(y[i], x[i]); }
 void lvo_forward_update(const double* T, int n, double* poses, double* vw) { forward_update(T, n, poses, vw); }
 void lvo_prior3_eval(int mode, const double* rpyxyz0, double weight, const double* rpyxyz, double* r, double* J) {
   if (mode == 0) PriorRpzResidual<double>(rpyxyz0, weight, rpyxyz + 1, rpyxyz + 2, rpyxyz + 5, r);

@@ -183,6 +183,14 @@ def relocate_rotation_solve(relocated, unrelocated, q4, max_iters=50, function_t
     return q, dict(initial_cost=out5[0], final_cost=out5[1], num_iterations=int(out5[2]), num_successful_steps=int(out5[3]), termination=int(out5[4]))
 
 
+def cr_atan2f(y, x):
+    """atan2 of float32 arguments correctly rounded to float32 (oracle/cr_math.h)."""
+    y, x = _f32(y), _f32(x)
+    out = np.empty(y.shape, np.float32)
+    lib().lvo_cr_atan2f(int(y.size), _p(y, C.c_float), _p(x, C.c_float), _p(out, C.c_float))
+    return out
+
+
 def forward_update(transform, poses, vw=None):
     """PoseGraph::ForwardUpdate; returns updated copies (poses, vw)."""
     T = _f64(transform); P = _f64(poses).copy(); V = None if vw is None else _f64(vw).copy()

@@ -94,3 +94,24 @@ def test_lidar_extract_restatement_is_sane(oracle):
     assert len(r["surf"]) > 100 and len(r["ground"]) > 100
     # the voxel / outlier / plane tail only ever removes points
     assert len(r["surf"]) < len(r["surf_raw"]) and len(r["ground"]) < len(r["ground_raw"])
+
+
+def test_cr_atan2f_is_the_correctly_rounded_float(oracle):
+    """oracle/cr_math.h (and its device twin csrc/cr_math.hpp): atan2 of float arguments rounded ONCE to float — checked against
+    mpmath at 50 digits, including the rounding decision (nearest of the neighbouring floats)."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    rng = np.random.default_rng(1)
+    n = 4000
+    y = (rng.normal(0, 1, n) * 10.0 ** rng.integers(-4, 4, n)).astype(np.float32)
+    x = (rng.normal(0, 1, n) * 10.0 ** rng.integers(-4, 4, n)).astype(np.float32)
+    y[:10] = [0, 0, 1, -1, 1, -1, 1e-30, 5, -7.5, 3]; x[:10] = [1, -1, 0, 0, 1, -1, 1, -1e-30, -2, 3]
+    got = oracle.cr_atan2f(y, x)
+    for i in range(n):
+        v = mp.atan2(mp.mpf(float(y[i])), mp.mpf(float(x[i])))
+        f = np.float32(float(v))
+        cands = [f, np.nextafter(f, np.float32(np.inf)), np.nextafter(f, np.float32(-np.inf))]
+        best = min(cands, key=lambda c: abs(mp.mpf(float(c)) - v))
+        assert got[i] == best, (y[i], x[i], got[i], best)
+    assert oracle.cr_atan2f(np.float32([-0.0]), np.float32([-2.0]))[0] == np.float32(-np.pi)       # signed zero: the libm convention
+    assert np.isnan(oracle.cr_atan2f(np.float32([np.nan]), np.float32([1.0]))[0])
