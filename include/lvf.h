@@ -65,6 +65,7 @@ typedef struct lvf_icp lvf_icp;
 typedef struct lvf_cloud lvf_cloud;
 typedef struct lvf_window lvf_window;
 typedef struct lvf_problem lvf_problem;
+typedef struct lvf_comm lvf_comm;
 
 /* Camera = intrinsics + sensor->robot extrinsic (include/lvio_fusion/sensor.h:41-44, visual/camera.h:74). */
 typedef struct lvf_camera {
@@ -364,6 +365,20 @@ int lvf_relocate_rotation_solve(lvf_ctx* ctx, int n, const double* relocated, co
 int lvf_forward_update(lvf_ctx* ctx, const double* transform7, int n, double* poses, double* vw);
 /* the same on a device-resident state: keyframes [first_kf, n_kf) of st (poses and velocities), nothing crosses PCIe but the transform */
 int lvf_state_forward_update(lvf_state* st, const double* transform7, int first_kf);
+
+/* ---- multi-GPU: the path's only exchange, for a C / C++ host ----------------------------------------------------------- */
+/* Independent windows / loop-closure candidates shard one per GPU: one process per GPU, one lvf_ctx each, no data-path collective.  The
+ * single exchange is an all-gather of fixed-size records (score, relative_o_c[7], candidate id: relocator.cpp:196-206) over RCCL / xGMI.
+ * Rank 0 calls lvf_comm_get_unique_id and hands the 128 bytes to the other ranks out of band (file, socket, MPI_Bcast); every rank then
+ * calls lvf_comm_create with the same id.  id128 == NULL with world_size == 1 gives a communicator that needs no RCCL.
+ * lvf_comm_allgather: every rank contributes n_doubles (equal on all ranks); recv[world_size][n_doubles] in rank order (host buffers). */
+#define LVF_COMM_ID_BYTES 128
+int lvf_comm_get_unique_id(void* id128);
+int lvf_comm_create(lvf_ctx* ctx, int world_size, int rank, const void* id128, lvf_comm** out);
+int lvf_comm_destroy(lvf_comm* c);
+int lvf_comm_world_size(const lvf_comm* c);
+int lvf_comm_rank(const lvf_comm* c);
+int lvf_comm_allgather(lvf_comm* c, const double* send, int n_doubles, double* recv);
 
 /* ---- persistent sliding window (Backend::BuildProblem's assembly, kept incrementally) -------------- */
 /* The window mirrors Map's active keyframes, their features_left and the landmarks behind them as flat arrays that the

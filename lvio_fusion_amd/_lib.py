@@ -109,6 +109,12 @@ _SIGS = {
     "lvf_forward_update": (C.c_int, [_VP, c_double_p, C.c_int, c_double_p, c_double_p]),
     "lvf_state_forward_update": (C.c_int, [_VP, c_double_p, C.c_int]),
     "lvf_window_reject_outliers": (C.c_int, [_VP, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
+    "lvf_comm_get_unique_id": (C.c_int, [_VP]),
+    "lvf_comm_create": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(_VP)]),
+    "lvf_comm_destroy": (C.c_int, [_VP]),
+    "lvf_comm_world_size": (C.c_int, [_VP]),
+    "lvf_comm_rank": (C.c_int, [_VP]),
+    "lvf_comm_allgather": (C.c_int, [_VP, c_double_p, C.c_int, c_double_p]),
     "lvf_imu_create": (C.c_int, [_VP, C.c_int, c_double_p, c_int_p, c_int_p, C.POINTER(_VP)]),
     "lvf_lidar_plane_create": (C.c_int, [_VP, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, C.POINTER(_VP)]),
     "lvf_pose_prior_create": (C.c_int, [_VP, C.c_int, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p, C.POINTER(_VP)]),

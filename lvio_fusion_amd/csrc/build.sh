@@ -6,7 +6,7 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../liblvf_hip.so"
 OBJ="$HERE/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -Wall -Wno-unused-function -I$HERE/../../include"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -Wall -Wno-unused-function -I$HERE/../../include -I/opt/rocm/include"
 mkdir -p "$OBJ"
 NEWEST_HDR=$(ls -t "$HERE"/*.hpp "$HERE"/../../include/lvf.h | head -1)
 todo=()
@@ -21,5 +21,5 @@ if [ ${#todo[@]} -gt 0 ]; then
 fi
 # objects of sources that no longer exist must not be linked
 for o in "$OBJ"/*.o; do [ -f "$HERE/$(basename "${o%.o}").hip" ] || rm -f "$o"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -ldl -o "$OUT"
 echo "built $OUT"

@@ -81,3 +81,65 @@ def test_relocalize_single_rank(ctx):
     assert rl.choose_best(merged)[0] == cid
     for c in range(3):
         assert np.allclose(merged[merged[:, 8] == c][0], t0[t0[:, 8] == c][0], rtol=1e-9, atol=1e-12)   # atomics reorder the last bits
+
+
+def test_cpp_driver_threads_and_rccl_gather(ctx, oracle, tmp_path):
+    """The C++ host of configs[4] (lvio_fusion_amd/host/relocalize_driver.cpp): candidates sharded over worker threads (one lvf_ctx each),
+    records gathered through lvf_comm_allgather (a real RCCL communicator of one rank on this box), arg-max, then the loop-correction tail
+    (rotation solve + ForwardUpdate) — against the Python path and the oracle."""
+    import json
+    import os
+    import subprocess
+    from lvio_fusion_amd import api
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(ROOT, "lvio_fusion_amd", "host", "relocalize_driver")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    n = 5
+    cands = syn.config5_candidates(n, seed=313, n_query=5000, n_az=300)
+    d = str(tmp_path)
+    for i, c in enumerate(cands):
+        np.ascontiguousarray(c["map"], np.float32).tofile(f"{d}/c{i}_map.f32"); np.ascontiguousarray(c["query"], np.float32).tofile(f"{d}/c{i}_query.f32")
+        c["map_ground"].astype(np.uint8).tofile(f"{d}/c{i}_map_ground.u8"); c["query_ground"].astype(np.uint8).tofile(f"{d}/c{i}_query_ground.u8")
+        np.concatenate([c["map_pose"], c["last_pose"], c["init_pose"]]).tofile(f"{d}/c{i}_poses.f64")
+    # loop-correction tail inputs
+    rng = np.random.default_rng(8)
+    m = 9
+    un = np.zeros((m, 7)); un[:, :4] = syn.quat_from_ypr(*rng.normal(0, 0.3, (3, m))); un[:, 4:] = rng.normal(0, 5, (m, 3))
+    R = np.concatenate([syn.quat_from_ypr(0.04, -0.01, 0.02), [0, 0, 0]])
+    rel = syn.se3_mul(np.tile(R, (m, 1)), un) + rng.normal(0, 1e-3, (m, 7))
+    rel.tofile(f"{d}/tail_relocated.f64"); un.tofile(f"{d}/tail_unrelocated.f64")
+    T = np.concatenate([syn.quat_from_ypr(0.1, 0.02, -0.03), [1.0, -0.5, 0.2]])
+    fp = np.zeros((6, 7)); fp[:, :4] = syn.quat_from_ypr(*rng.normal(0, 0.5, (3, 6))); fp[:, 4:] = rng.normal(0, 10, (6, 3)); fv = rng.normal(0, 2, (6, 3))
+    np.concatenate([T, fp.ravel(), fv.ravel()]).tofile(f"{d}/tail_forward.f64")
+    best_py, rec_py = rl.relocalize(api, ctx, cands)
+    outs = []
+    for args in ([str(n), "1"], [str(n), "3"], [str(n), "2", "--rank", "0", "--world", "1", "--idfile", f"{d}/id.bin"]):
+        p = subprocess.run([exe, d] + args, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        o = json.loads(p.stdout.strip().splitlines()[-1]); outs.append(o)
+        assert o["ok"] == 1
+        rec = np.fromfile(f"{d}/out_records_r0.f64").reshape(-1, 9)
+        assert np.array_equal(np.sort(rec[:, 8]), np.arange(n))
+        order = np.argsort(rec[:, 8]); ref_order = np.argsort(rec_py[:, 8])
+        assert np.array_equal(rec[order, 0], rec_py[ref_order, 0])                     # integer scores
+        assert np.allclose(rec[order, 1:8], rec_py[ref_order, 1:8], rtol=1e-9, atol=1e-12)
+        if best_py is None:
+            assert o["best"] == -1
+        else:
+            assert o["best"] == best_py[0] and o["best_score"] == best_py[1] and np.allclose(o["best_rel"], best_py[2], rtol=1e-9, atol=1e-12)
+        q_ref, s_ref = oracle.relocate_rotation_solve(rel, un, [0, 0, 0, 1.0])
+        assert np.abs(np.array(o["q4"]) - q_ref).max() <= 1e-9 and o["rot_iterations"] == s_ref["num_iterations"]
+        P0, V0 = oracle.forward_update(T, fp, fv)
+        got = np.fromfile(f"{d}/out_forward_r0.f64")
+        assert np.allclose(got[:42].reshape(6, 7), P0, rtol=1e-9, atol=1e-12) and np.allclose(got[42:].reshape(6, 3), V0, rtol=1e-9, atol=1e-12)
+    assert outs[2]["rccl"] == 1 and outs[0]["rccl"] == 0
+    # the python binding of the same exchange, single rank: RCCL communicator of one, and the RCCL-free one
+    idb = (api.C.c_ubyte * 128)()
+    api._chk(ctx.L.lvf_comm_get_unique_id(idb))
+    for use_id in (True, False):
+        h = api.C.c_void_p()
+        api._chk(ctx.L.lvf_comm_create(ctx.h, 1, 0, idb if use_id else None, api.C.byref(h)))
+        send = np.arange(27, dtype=np.float64); recv = np.zeros(27)
+        api._chk(ctx.L.lvf_comm_allgather(h, send.ctypes.data_as(api._lib.c_double_p), 27, recv.ctypes.data_as(api._lib.c_double_p)))
+        assert np.array_equal(send, recv) and ctx.L.lvf_comm_world_size(h) == 1 and ctx.L.lvf_comm_rank(h) == 0
+        ctx.L.lvf_comm_destroy(h)

@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 gloo processes exercise the sharding, the single all_gather and the arg-max of the
+"""The N>1 path on CPU: world_size-2 and world_size-4 gloo processes exercise the sharding, the single all_gather and the arg-max of the
 loop-closure candidate evaluation (lvio_fusion_amd/relocalize.py) with scripted per-candidate results — the collective
 logic is device-independent; the per-candidate solve itself is covered on the GPU (tests/test_gpu_relocalize.py)."""
 import os
@@ -74,3 +74,68 @@ def test_gloo_world2_gather_and_argmax(tmp_path):
     assert outs[0]["best"] == outs[1]["best"]
     assert outs[0]["best"][0] == 3 and outs[0]["best"][1] == 25.0
     assert np.allclose(outs[0]["best"][2:], [0, 0, np.sin(0.03), np.cos(0.03), 3, 6.0, 0.5])
+
+
+WORKER4 = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from lvio_fusion_amd import relocalize as rl
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+fail_rank, n = int(os.environ["FAIL_RANK"]), int(os.environ["N_CAND"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+scores = [22.0 + 3.0 * ((7 * c) % 5) for c in range(n)]
+table = rl.empty_records(rl.slots(n, world))
+err = None
+try:      # the per-GPU part may fail on one rank: the collective below must still be entered by everyone (bench.py's structure)
+    for s, cid in enumerate(rl.owned(n, rank, world)):
+        if rank == fail_rank and s == 1:
+            raise RuntimeError("device lost mid-evaluation")
+        table[s] = rl.make_record(cid, scores[cid], np.array([0, 0, 0, 1.0, cid, 0, 0]))
+except Exception as e:
+    err = repr(e)
+dist.barrier()
+allrec = rl.gather_records(table, world)
+dist.barrier()
+best = rl.choose_best(allrec)
+live = sorted(int(x) for x in allrec[allrec[:, 8] >= 0][:, 8])
+print(json.dumps({"rank": rank, "err": err, "live": live, "best": None if best is None else [best[0], best[1]]}))
+dist.destroy_process_group()
+'''
+
+
+def _run_world(tmp_path, world, n, fail_rank):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker4.py"
+    script.write_text(WORKER4)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FAIL_RANK=str(fail_rank), N_CAND=str(n))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=240)
+        assert p.returncode == 0, e
+        outs.append(__import__("json").loads(o.strip().splitlines()[-1]))
+    return outs
+
+
+def test_gloo_world4_uneven_candidate_counts(tmp_path):
+    """7 candidates over 4 ranks: shares of 2, 2, 2, 1; the short rank's unused slot must not disturb the arg-max."""
+    outs = _run_world(tmp_path, 4, 7, -1)
+    assert all(o["live"] == list(range(7)) and o["err"] is None for o in outs)
+    scores = [int(22.0 + 3.0 * ((7 * c) % 5)) - 20 for c in range(7)]
+    top = max(scores)
+    want = max(c for c in range(7) if scores[c] == top)          # `>=`: the later candidate wins a tie
+    assert all(o["best"] == [want, float(top)] for o in outs)
+
+
+def test_gloo_world4_a_rank_failing_mid_evaluation_does_not_hang(tmp_path):
+    """Rank 2 throws after its first candidate: every rank still reaches the barriers and the all_gather, the failed rank's
+    remaining candidate simply has no record, and all ranks agree on the winner among the rest."""
+    outs = _run_world(tmp_path, 4, 8, 2)
+    assert outs[2]["err"] is not None and all(o["err"] is None for i, o in enumerate(outs) if i != 2)
+    lost = rl.owned(8, 2, 4)[1]
+    assert all(o["live"] == [c for c in range(8) if c != lost] for o in outs)
+    assert len({tuple(o["best"]) for o in outs}) == 1
