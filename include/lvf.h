@@ -66,6 +66,7 @@ typedef struct lvf_cloud lvf_cloud;
 typedef struct lvf_window lvf_window;
 typedef struct lvf_problem lvf_problem;
 typedef struct lvf_comm lvf_comm;
+typedef struct lvf_problem_batch lvf_problem_batch;
 
 /* Camera = intrinsics + sensor->robot extrinsic (include/lvio_fusion/sensor.h:41-44, visual/camera.h:74). */
 typedef struct lvf_camera {
@@ -345,6 +346,25 @@ int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_su
  * d = 15 * n_kf (pose tangent 6 | v 3 | ba 3 | bg 3 per keyframe). */
 int lvf_problem_reduced_dim(lvf_problem* p);
 int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs);
+
+/* ---- a batch of independent windows on ONE GPU -------------------------------------------------------------------------------------
+ * W windows (each its own lvf_state / batches / lvf_problem, all of one context) advanced by ONE chain of launches per LM iteration: every
+ * kernel of the iteration takes the window as blockIdx.y and reads that window's argument block from a device table.  A single window's
+ * iteration is a chain of small launches that leaves most of the 256 CUs idle; a batch fills the same launches W times over — the shape of
+ * the reference's independent-window clients (RL environments: src/environment.cpp:18-115; loop-closure candidates: relocator.cpp:196-206)
+ * and of what one GPU of the 8-GPU sharding works on.  The LM loop of every window runs on device (accept / reject, trust region and
+ * termination per window; a finished window's launches return immediately).  Per-window results are identical to lvf_problem_solve /
+ * lvf_problem_lm_iteration on that window alone.  Windows that cannot use the table launches (no sorted TwoFrame work list, pose priors,
+ * no IMU blocks) make the batch fall back to running the windows' own chains back to back on the context's stream.
+ * All result arrays have one entry per window, in the order of `problems`. */
+int lvf_problem_batch_create(lvf_ctx* ctx, lvf_problem* const* problems, int n, lvf_problem_batch** out);
+int lvf_problem_batch_destroy(lvf_problem_batch* b);
+int lvf_problem_batch_size(const lvf_problem_batch* b);
+/* 1: table launches (one chain for all windows), 0: fallback, -1: error */
+int lvf_problem_batch_uses_tables(lvf_problem_batch* b, const lvf_solver_options* o);
+int lvf_problem_batch_lm_iteration(lvf_problem_batch* b, const lvf_solver_options* o, double* radius, double* decrease_factor, double* cost_before,
+                                   double* cost_after, int* accepted);
+int lvf_problem_batch_solve(lvf_problem_batch* b, const lvf_solver_options* o, lvf_solver_summary* summaries);
 
 /* Problem::Evaluate's gradient at the current state: J^T r with the Corrector applied and pose blocks in tangent coordinates.
  * gc[15 n_kf] = (6 x n_kf pose tangents | 9 x n_kf (v, ba, bg)); gl[n_lm] (may be NULL) = the inverse-depth entries.  Constant poses: 0. */

@@ -115,6 +115,12 @@ _SIGS = {
     "lvf_comm_world_size": (C.c_int, [_VP]),
     "lvf_comm_rank": (C.c_int, [_VP]),
     "lvf_comm_allgather": (C.c_int, [_VP, c_double_p, C.c_int, c_double_p]),
+    "lvf_problem_batch_create": (C.c_int, [_VP, C.POINTER(_VP), C.c_int, C.POINTER(_VP)]),
+    "lvf_problem_batch_destroy": (C.c_int, [_VP]),
+    "lvf_problem_batch_size": (C.c_int, [_VP]),
+    "lvf_problem_batch_uses_tables": (C.c_int, [_VP, C.POINTER(SolverOptions)]),
+    "lvf_problem_batch_lm_iteration": (C.c_int, [_VP, C.POINTER(SolverOptions), c_double_p, c_double_p, c_double_p, c_double_p, c_int_p]),
+    "lvf_problem_batch_solve": (C.c_int, [_VP, C.POINTER(SolverOptions), C.POINTER(SolverSummary)]),
     "lvf_imu_create": (C.c_int, [_VP, C.c_int, c_double_p, c_int_p, c_int_p, C.POINTER(_VP)]),
     "lvf_lidar_plane_create": (C.c_int, [_VP, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double, C.POINTER(_VP)]),
     "lvf_pose_prior_create": (C.c_int, [_VP, C.c_int, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p, C.POINTER(_VP)]),

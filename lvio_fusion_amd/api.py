@@ -561,3 +561,33 @@ class Problem:
         if self.h:
             self.ctx.L.lvf_problem_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class ProblemBatch:
+    """W independent windows advanced by one chain of launches per LM iteration (lvf_problem_batch_*)."""
+
+    def __init__(self, ctx, problems):
+        self.ctx, self.problems = ctx, list(problems)
+        self.h = C.c_void_p()
+        arr = (C.c_void_p * len(self.problems))(*[p.h for p in self.problems])
+        _chk(ctx.L.lvf_problem_batch_create(ctx.h, arr, len(self.problems), C.byref(self.h)))
+
+    def uses_tables(self, opt):
+        return self.ctx.L.lvf_problem_batch_uses_tables(self.h, C.byref(opt))
+
+    def lm_iteration(self, opt, radius, decrease_factor):
+        n = len(self.problems)
+        r, d = _d(radius).copy(), _d(decrease_factor).copy()
+        c0, c1, acc = np.empty(n), np.empty(n), np.zeros(n, np.int32)
+        _chk(self.ctx.L.lvf_problem_batch_lm_iteration(self.h, C.byref(opt), _dp(r), _dp(d), _dp(c0), _dp(c1), _ip(acc)))
+        return [dict(radius=r[i], decrease_factor=d[i], cost_before=c0[i], cost_after=c1[i], accepted=bool(acc[i])) for i in range(n)]
+
+    def solve(self, opt):
+        out = (SolverSummary * len(self.problems))()
+        _chk(self.ctx.L.lvf_problem_batch_solve(self.h, C.byref(opt), out))
+        return list(out)
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lvf_problem_batch_destroy(self.h)
+            self.h = C.c_void_p()

@@ -132,18 +132,23 @@ __global__ __launch_bounds__(256) void k_imu_sqrt_info(int n, const double* __re
 // --------------------------------------------------------------------------------- ImuError evaluate
 // column layout of the concatenated 15x32 Jacobian: [pose_i 0..6 | v_i 7..9 | ba_i 10..12 | bg_i 13..15 |
 //                                                     pose_j 16..22 | v_j 23..25 | ba_j 26..28 | bg_j 29..31]
-struct ImuOut { double* j[8]; };
-
 template <bool WITH_J>
-__global__ __launch_bounds__(64) void k_imu(int n, const double* __restrict__ pre, const double* __restrict__ sqrt_info,
-                                            const int* __restrict__ kf_i, const int* __restrict__ kf_j,
-                                            const double* __restrict__ poses, const double* __restrict__ vel,
-                                            const double* __restrict__ ba, const double* __restrict__ bg,
-                                            double* __restrict__ res, ImuOut out, double* __restrict__ cost_stripes, ZeroList zero,
-                                            int zero_wgs) {
-  if ((int)blockIdx.x >= n) {            // extra workgroups: clear the solver's accumulators (independent of the factors)
-    const unsigned long long t = (unsigned long long)(blockIdx.x - n) * 64 + threadIdx.x, nt = (unsigned long long)zero_wgs * 64;
-    for (int a = 0; a < zero.count; ++a) {
+__device__ __forceinline__ void imu_body(const int bx, const ImuArgs& A) {
+  if (A.done && *A.done) return;
+  const int n = A.n;
+  const double* __restrict__ pre = A.pre; const double* __restrict__ sqrt_info = A.sqrt_info;
+  const int* __restrict__ kf_i = A.kf_i; const int* __restrict__ kf_j = A.kf_j;
+  const double* __restrict__ poses = A.poses; const double* __restrict__ vel = A.vel; const double* __restrict__ ba = A.ba; const double* __restrict__ bg = A.bg;
+  double* __restrict__ res = A.res; double* __restrict__ cost_stripes = A.cost_stripes;
+  const ImuOut& out = A.out;
+  if (bx >= n) {            // extra workgroups: clear the solver's accumulators (independent of the factors)
+    if (bx >= n + A.zero_wgs) return;
+    const ZeroList& zero = A.zero;
+    const unsigned long long t = (unsigned long long)(bx - n) * 64 + threadIdx.x, nt = (unsigned long long)A.zero_wgs * 64;
+    // (static indices only: a run-time index into the by-value pointer table would put it in scratch memory)
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      if (a >= zero.count) break;
       double* p = zero.p[a];
       const unsigned long long cnt = zero.n[a], n2 = cnt / 2;
       double2* p2 = reinterpret_cast<double2*>(p);
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(64) void k_imu(int n, const double* __restrict__ pr
   __shared__ double sM[15 * 32];
   __shared__ double sr0[15];
   __shared__ double scost[15];
-  const int f = blockIdx.x;
+  const int f = bx;
   const int lane = threadIdx.x;
   const double* P = pre + (size_t)f * kPre;
   for (int k = lane; k < 225; k += 64) sS[k] = sqrt_info[(size_t)f * 225 + k];
@@ -287,6 +292,12 @@ __global__ __launch_bounds__(64) void k_imu(int n, const double* __restrict__ pr
   }
 }
 
+template <bool WITH_J>
+__global__ __launch_bounds__(64) void k_imu(ImuArgs a) { imu_body<WITH_J>(blockIdx.x, a); }
+// one launch for a batch of windows: blockIdx.y selects the window's argument block
+template <bool WITH_J>
+__global__ __launch_bounds__(64) void k_imu_b(const ImuArgs* __restrict__ table) { imu_body<WITH_J>(blockIdx.x, table[blockIdx.y]); }
+
 // --------------------------------------------------------------------------------- pre-integration (K5)
 // One workgroup per keyframe pair; the chain over IMU samples is sequential (each sample needs the previous delta_q,
 // jacobian and covariance) but the 15x15 products  jac <- F jac,  cov <- F cov F^T + V N V^T  are spread over the
@@ -411,20 +422,35 @@ int launch_imu_sqrt_info(lvf_batch* b) {
   return LVF_OK;
 }
 
-int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j, double* cost_stripes, const ZeroList* zero) {
-  if (b->n == 0) return LVF_OK;
-  const int zero_wgs = zero ? 4096 : 0;
-  const ZeroList zl = zero ? *zero : ZeroList{};
-  ImuOut o;
-  for (int k = 0; k < 8; ++k) o.j[k] = b->jac[k].p;
-  if (want_j)
-    hipLaunchKernelGGL(k_imu<true>, dim3(b->n + zero_wgs), dim3(64), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p, b->idx_a.p,
-                       b->idx_b.p, st->poses.p, st->vel.p, st->ba.p, st->bg.p, b->res.p, o, cost_stripes, zl, zero_wgs);
-  else
-    hipLaunchKernelGGL(k_imu<false>, dim3(b->n + zero_wgs), dim3(64), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p, b->idx_a.p,
-                       b->idx_b.p, st->poses.p, st->vel.p, st->ba.p, st->bg.p, b->res.p, o, cost_stripes, zl, zero_wgs);
+void fill_imu_args(const lvf_batch* b, const double* poses, const double* vel, const double* ba, const double* bg, double* cost_stripes,
+                   const ZeroList* zero, const int* done, ImuArgs* o) {
+  o->n = b->n; o->pre = b->pre.p; o->sqrt_info = b->sqrt_info.p; o->kf_i = b->idx_a.p; o->kf_j = b->idx_b.p;
+  o->poses = poses; o->vel = vel; o->ba = ba; o->bg = bg; o->res = b->res.p;
+  for (int k = 0; k < 8; ++k) o->out.j[k] = b->jac[k].p;
+  o->cost_stripes = cost_stripes;
+  o->zero = zero ? *zero : ZeroList{};
+  o->zero_wgs = zero ? kImuZeroWgs : 0;
+  o->done = done;
+}
+int launch_imu_args(hipStream_t s, const ImuArgs& a, bool want_j) {
+  if (a.n + a.zero_wgs == 0) return LVF_OK;
+  if (want_j) hipLaunchKernelGGL(k_imu<true>, dim3(a.n + a.zero_wgs), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(k_imu<false>, dim3(a.n + a.zero_wgs), dim3(64), 0, s, a);
   LVF_HIP(hipGetLastError());
   return LVF_OK;
+}
+int launch_imu_table(hipStream_t s, const ImuArgs* table_dev, int n_windows, int max_blocks, bool want_j) {
+  if (max_blocks == 0 || n_windows == 0) return LVF_OK;
+  if (want_j) hipLaunchKernelGGL(k_imu_b<true>, dim3(max_blocks, n_windows), dim3(64), 0, s, table_dev);
+  else hipLaunchKernelGGL(k_imu_b<false>, dim3(max_blocks, n_windows), dim3(64), 0, s, table_dev);
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j, double* cost_stripes, const ZeroList* zero) {
+  if (b->n == 0) return LVF_OK;
+  ImuArgs a;
+  fill_imu_args(b, st->poses.p, st->vel.p, st->ba.p, st->bg.p, cost_stripes, zero, nullptr, &a);
+  return launch_imu_args(b->ctx->stream, a, want_j);
 }
 
 }  // namespace lvf

@@ -323,6 +323,18 @@ struct ZeroList { double* p[6]; unsigned long long n[6]; int count; };
 // cost_stripes (optional): 32 striped accumulators that receive 1/2 |r|^2 of every factor
 // zero (optional): arrays cleared by extra workgroups of the same launch
 int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j, double* cost_stripes = nullptr, const ZeroList* zero = nullptr);
+// the ImuError evaluation as an argument block: by value for one window, as a device table (one entry per window, blockIdx.y) for a
+// batch of windows.  `done` (optional) points at the window's LM control flag: a finished window skips the launch.
+struct ImuOut { double* j[8]; };
+struct ImuArgs {
+  int n; const double *pre, *sqrt_info; const int *kf_i, *kf_j; const double *poses, *vel, *ba, *bg; double* res; ImuOut out;
+  double* cost_stripes; ZeroList zero; int zero_wgs; const int* done;
+};
+void fill_imu_args(const lvf_batch* b, const double* poses, const double* vel, const double* ba, const double* bg, double* cost_stripes,
+                   const ZeroList* zero, const int* done, ImuArgs* out);
+int launch_imu_args(hipStream_t s, const ImuArgs& a, bool want_j);
+int launch_imu_table(hipStream_t s, const ImuArgs* table_dev, int n_windows, int max_blocks, bool want_j);
+constexpr int kImuZeroWgs = 4096;
 int launch_pose_prior(lvf_batch* b, const lvf_state* st, bool want_j);
 void make_camd(const lvf_camera& c, CamD& d);
 }  // namespace lvf

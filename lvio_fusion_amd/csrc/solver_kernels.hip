@@ -20,6 +20,8 @@
 
 namespace lvf {
 struct TfWork;
+struct LmCtl;
+struct Chain;
 // one (v, ba, bg) block eliminated ahead of the dense factorisation: its 9 columns start at `col`, its `m` neighbour rows
 // (later-ordered (v, ba, bg) blocks, poses, the augmented row; ascending) sit at rows[row_off .. row_off + m)
 struct SpNode { int col, row_off, m, id; };
@@ -54,6 +56,16 @@ struct lvf_problem {
   bool linearized = false;
   bool tf_unique_lk2 = false;   // no (landmark, current keyframe) pair occurs twice in the TwoFrame batch
   double last_radius = 0;
+  // the device-resident LM loop
+  lvf::DevBuf<lvf::LmCtl> ctl;        // control block (radius, costs, accept / reject, termination) in HBM
+  lvf::LmCtl* rec = nullptr;          // host-visible mirror written by k_lm_decide (hipHostMalloc)
+  lvf::HostPin<lvf::LmCtl> h_ctl;     // pinned staging for uploads / read-backs of the control block
+  lvf::Chain* chain = nullptr;        // argument blocks of one iteration
+  bool chain_ready = false;
+  const void* chain_state[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // the state pointers the chain was built for
+  double huber = 1.0;
+  hipGraphExec_t graph_exec = nullptr;
+  ~lvf_problem();
 };
 
 namespace lvf {
@@ -75,6 +87,22 @@ __device__ __forceinline__ void block_add(double v, double* dst) {
 }
 
 struct StateP { const double *poses, *vel, *ba, *bg, *inv_depth, *w_kf; };
+
+// Device-resident control block of one window's Levenberg-Marquardt loop.  Everything that changes from one iteration to the next
+// lives here (trust-region radius, costs, accept / reject, termination), so the arguments of every kernel of an iteration are
+// constant across iterations: the host enqueues iteration after iteration without waiting, k_lm_decide closes each one on device
+// (what the reference's ceres::Solve does on the host between evaluations).
+struct LmCtl {
+  double radius, decrease;                         // trust region (in: start values; updated by every iteration)
+  double last_radius;                              // the radius the last iteration's step was computed with
+  double cost, initial_cost;                       // cost at the current state / at the first linearisation
+  double cost_before, cost_after, model, dxnorm, xnorm, gmax;   // scalars of the last iteration
+  double huber, function_tol, gradient_tol, parameter_tol, min_rel_decrease;
+  int max_iters;
+  int iter, successes, invalid_run;                // iterations taken / accepted steps / consecutive unsolvable steps
+  int accepted, solved;                            // of the last iteration
+  int done, termination;                           // done != 0: the remaining launches of this window return immediately
+};
 
 // lower-triangle accumulation of a 6x6 block pair J_a^T J_b into B at (ra, rb) block offsets (ra >= rb required
 // for off-diagonal; for ra == rb only the lower half is written)
@@ -322,9 +350,12 @@ struct CostVisual {
   const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1, *tf_k2; CamD tf_left, tf_right;
   const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
 };
-__global__ __launch_bounds__(kT) void k_cost_visual(CostVisual a, int n_kf, StateP s, double huber, double* __restrict__ cost) {
+struct CostArgs { CostVisual a; int n_kf; StateP s; double huber; double* cost; int nblocks; const int* done; };
+__device__ __forceinline__ void cost_visual_body(const int b, const CostArgs& A) {
+  if (b >= A.nblocks || (A.done && *A.done)) return;
+  const CostVisual& a = A.a;
+  const int n_kf = A.n_kf; const StateP s = A.s; const double huber = A.huber; double* __restrict__ cost = A.cost;
   __shared__ PoseD s_pose[kMaxStagedKf];
-  const int b = blockIdx.x;
   double c = 0.0;
   if (b < a.g_tc) {
     const int i = b * kT + threadIdx.x;
@@ -368,6 +399,8 @@ __global__ __launch_bounds__(kT) void k_cost_visual(CostVisual a, int n_kf, Stat
   }
   block_add(c, cost);
 }
+__global__ __launch_bounds__(kT) void k_cost_visual(CostArgs a) { cost_visual_body(blockIdx.x, a); }
+__global__ __launch_bounds__(kT) void k_cost_visual_b(const CostArgs* __restrict__ t) { cost_visual_body(blockIdx.x, t[blockIdx.y]); }
 
 // ------------------------------------------------------------------------------------------------ PoseOnly
 template <bool COST_ONLY>
@@ -600,10 +633,15 @@ struct LinVisual {
   // ImuError (already evaluated)
   int n_imu; const double* imu_res; ImuJ imu_J; const int *imu_i, *imu_j;
 };
-__global__ __launch_bounds__(kT) void k_lin_visual(LinVisual a, int n_kf, StateP s, double huber, const uint8_t* __restrict__ pose_const,
-                                                   double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ E, int ldE,
-                                                   double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost) {
-  const int b = blockIdx.x;
+struct LinArgs {
+  LinVisual v; int n_kf; StateP s; double huber; const uint8_t* pose_const; double* B; int ld; double* gc; double* E; int ldE; double *C, *gr, *cost;
+  int nblocks; const int* done;
+};
+__device__ __forceinline__ void lin_visual_body(const int b, const LinArgs& A) {
+  if (b >= A.nblocks || (A.done && *A.done)) return;
+  const LinVisual& a = A.v;
+  const int n_kf = A.n_kf; const StateP s = A.s; const double huber = A.huber; const uint8_t* pose_const = A.pose_const;
+  double* B = A.B; const int ld = A.ld; double* gc = A.gc; double* E = A.E; const int ldE = A.ldE; double* C = A.C; double* gr = A.gr; double* cost = A.cost;
   if (b < a.n_tfw)
     lin_tf_sorted_body(b, a.work, n_kf, a.tf_fo, a.tf_ob, a.tf_lm, a.tf_k1, s, a.tf_left, a.tf_right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost,
                        a.unique_lk2);
@@ -614,6 +652,8 @@ __global__ __launch_bounds__(kT) void k_lin_visual(LinVisual a, int n_kf, StateP
   else
     lin_imu_body4(b - a.n_tfw - a.g_tc - a.g_po, a.n_imu, n_kf, a.imu_res, a.imu_J, a.imu_i, a.imu_j, s.poses, pose_const, B, ld, gc, cost);
 }
+__global__ __launch_bounds__(kT) void k_lin_visual(LinArgs a) { lin_visual_body(blockIdx.x, a); }
+__global__ __launch_bounds__(kT) void k_lin_visual_b(const LinArgs* __restrict__ t) { lin_visual_body(blockIdx.x, t[blockIdx.y]); }
 
 
 // ------------------------------------------------------------------------------------------------ pose priors
@@ -690,23 +730,29 @@ __device__ __forceinline__ double clamp_diag(double v) { return fmin(fmax(v, 1e-
 //   blocks [nS_blocks, ...)    : Cd = C + clamp(C)/radius ; E[l][dp] = gr[l] (the extra column that makes the SYRK also
 //                                produce E^T Cd^-1 g_rho)
 //   block 0 / thread 0         : resets the per-step scalars (candidate cost, model change, norms) and the Cholesky fail flag
-__global__ __launch_bounds__(kT) void k_prepare(int ld, int dpad, const int* __restrict__ iperm, const double* __restrict__ B, const double* __restrict__ gc,
-                                                double inv_radius, double* __restrict__ S, unsigned nS_blocks, int n_lm, int dp, int ldE,
-                                                const double* __restrict__ C, const double* __restrict__ gr, double* __restrict__ Cd,
-                                                double* __restrict__ E, double* __restrict__ scal) {
-  if (blockIdx.x == 0 && scal) {
+struct PrepArgs {
+  int ld, dpad; const int* iperm; const double *B, *gc; const double* radius; double* S; unsigned nS_blocks; int n_lm, dp, ldE; const double *C, *gr;
+  double *Cd, *E, *scal; int nblocks; const int* done;
+};
+__device__ __forceinline__ void prepare_body(const unsigned bx, const PrepArgs& A) {
+  if (bx >= (unsigned)A.nblocks || (A.done && *A.done)) return;
+  const int ld = A.ld, dpad = A.dpad; const int* __restrict__ iperm = A.iperm; const double* __restrict__ B = A.B; const double* __restrict__ gc = A.gc;
+  const double inv_radius = 1.0 / *A.radius;
+  double* __restrict__ S = A.S; const unsigned nS_blocks = A.nS_blocks; const int n_lm = A.n_lm, dp = A.dp, ldE = A.ldE;
+  const double* __restrict__ C = A.C; const double* __restrict__ gr = A.gr; double* __restrict__ Cd = A.Cd; double* __restrict__ E = A.E; double* __restrict__ scal = A.scal;
+  if (bx == 0 && scal) {
     for (int k = SC_COST_NEW + threadIdx.x; k < SC_N; k += kT) scal[k] = 0.0;
     if (threadIdx.x == 0) *reinterpret_cast<int*>(scal + SC_FAIL) = 0;
   }
-  if (blockIdx.x >= nS_blocks) {
-    const int l = (blockIdx.x - nS_blocks) * kT + threadIdx.x;
+  if (bx >= nS_blocks) {
+    const int l = (bx - nS_blocks) * kT + threadIdx.x;
     if (l >= n_lm) return;
     const double c = C[l];
     Cd[l] = c + clamp_diag(c) * inv_radius;
     E[(size_t)l * ldE + dp] = gr[l];
     return;
   }
-  const size_t e = (size_t)blockIdx.x * kT + threadIdx.x;
+  const size_t e = (size_t)bx * kT + threadIdx.x;
   if (e >= (size_t)ld * ld) return;
   const int I = (int)(e / ld), J = (int)(e % ld);
   const int oi = iperm[I], oj = iperm[J];
@@ -723,6 +769,8 @@ __global__ __launch_bounds__(kT) void k_prepare(int ld, int dpad, const int* __r
   }
   S[e] = v;
 }
+__global__ __launch_bounds__(kT) void k_prepare(PrepArgs a) { prepare_body(blockIdx.x, a); }
+__global__ __launch_bounds__(kT) void k_prepare_b(const PrepArgs* __restrict__ t) { prepare_body(blockIdx.x, t[blockIdx.y]); }
 
 // ------------------------------------------------------------------------------------------------ Schur reduce (MFMA f64)
 // T = Ea^T diag(1/Cd) Ea with Ea = [E | g_rho] (n_lm x ldE).  One wave per (16x16 output tile, K-chunk); tiles on or
@@ -1090,7 +1138,11 @@ __device__ __forceinline__ bool factor_solve_columns(double a[16], double b[16],
 
 // grid = 2 + (block rows below kb): workgroup 0 stores the factored diagonal block; workgroups 1..below solve their panel block
 // X L^T = A; the last workgroup solves against the identity and leaves L_kk^-T for the back substitution.
-__global__ __launch_bounds__(256) void k_chol_factor_panel(double* S, int ld, int kb, int* __restrict__ fail, double* __restrict__ Dinv) {
+struct CholArgs { double* Sd; int ld, nb; int* fail; double* Dinv; const int* done; };
+__device__ __forceinline__ void chol_factor_panel_body(const int bx, const CholArgs& A, const int kb) {
+  const int below = A.nb - kb - 1;
+  if (kb >= A.nb || bx >= 2 + below || (A.done && *A.done)) return;      // (workgroup-uniform: no barrier is skipped by part of a workgroup)
+  double* S = A.Sd; const int ld = A.ld; int* __restrict__ fail = A.fail; double* __restrict__ Dinv = A.Dinv;
   __shared__ double col[2][kNB];
   __shared__ double col2[2][kNB];
   const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
@@ -1100,10 +1152,10 @@ __global__ __launch_bounds__(256) void k_chol_factor_panel(double* S, int ld, in
 #pragma unroll
     for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; a[2 * c] = v.x; a[2 * c + 1] = v.y; }
   }
-  const bool inverse_wg = blockIdx.x == gridDim.x - 1;
+  const bool inverse_wg = bx == 1 + below;
   double* brow = inverse_wg ? Dinv + (size_t)kb * kNB * kNB + (size_t)r * kNB + 16 * q
-                            : S + (size_t)((kb + blockIdx.x) * kNB + r) * ld + kb * kNB + 16 * q;
-  if (blockIdx.x == 0) {
+                            : S + (size_t)((kb + bx) * kNB + r) * ld + kb * kNB + 16 * q;
+  if (bx == 0) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) b[c] = 0.0;
   } else if (inverse_wg) {
@@ -1122,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_chol_factor_panel(double* S, int ld, in
     default: bad = factor_solve_columns<3>(a, b, r, col, col2); break;
   }
   if (bad && r == 0) atomicExch(fail, 1 + kb);
-  if (blockIdx.x == 0) {
+  if (bx == 0) {
 #pragma unroll
     for (int tt = 0; tt < 16; ++tt) if (16 * q + tt > r) a[tt] = 0.0;
     double2* g2 = reinterpret_cast<double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
@@ -1134,14 +1186,19 @@ __global__ __launch_bounds__(256) void k_chol_factor_panel(double* S, int ld, in
 #pragma unroll
   for (int c = 0; c < 8; ++c) g2[c] = make_double2(b[2 * c], b[2 * c + 1]);
 }
+__global__ __launch_bounds__(256) void k_chol_factor_panel(CholArgs a, int kb) { chol_factor_panel_body(blockIdx.x, a, kb); }
+__global__ __launch_bounds__(256) void k_chol_factor_panel_b(const CholArgs* __restrict__ t, int kb) { chol_factor_panel_body(blockIdx.x, t[blockIdx.y], kb); }
 
 // trailing update: A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi.  One workgroup per 64x64 tile; both 64x64 panels are
 // staged in LDS (row stride 65) and each of the 4 waves produces a 16x64 strip with v_mfma_f64_16x16x4_f64
 // (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D: col = lane&15, row = (lane>>4) + 4 reg).
-__global__ __launch_bounds__(256) void k_chol_update(double* S, int ld, int kb) {
+__device__ __forceinline__ void chol_update_body(const int bx, const CholArgs& A, const int kb) {
+  const int below = A.nb - kb - 1;
+  if (below <= 0 || bx >= below * (below + 1) / 2 || (A.done && *A.done)) return;
+  double* S = A.Sd; const int ld = A.ld;
   __shared__ double Pi[kNB * kLd];
   __shared__ double Pj[kNB * kLd];
-  int t = blockIdx.x, ii = 0;
+  int t = bx, ii = 0;
   while (t >= ii + 1) { t -= ii + 1; ++ii; }
   const int bi = kb + 1 + ii, bj = kb + 1 + t;
   // the tile being updated is requested FIRST (it does not depend on the product) so its round trip hides under the panel
@@ -1173,6 +1230,8 @@ __global__ __launch_bounds__(256) void k_chol_update(double* S, int ld, int kb) 
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) out[(size_t)(lk + 4 * rg) * ld + 16 * ct + lc] = o[ct][rg] - acc[ct][rg];
 }
+__global__ __launch_bounds__(256) void k_chol_update(CholArgs a, int kb) { chol_update_body(blockIdx.x, a, kb); }
+__global__ __launch_bounds__(256) void k_chol_update_b(const CholArgs* __restrict__ t, int kb) { chol_update_body(blockIdx.x, t[blockIdx.y], kb); }
 
 // ------------------------------------------------------------------------------------------------ elimination order
 // The (v, ba, bg) blocks only meet each other and the poses through ImuError factors, i.e. along the IMU chain: block k touches
@@ -1263,24 +1322,34 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     if (v != 0.0) atomicAdd(&S[(size_t)rws[r] * ld + rws[c2]], -v);
   }
 }
-__global__ __launch_bounds__(256) void k_sp_eliminate(const SpNode* __restrict__ nodes, int first, int tiles, const int* __restrict__ rows,
-                                                      double* __restrict__ S, int ld, double* __restrict__ W, int wstride,
-                                                      double* __restrict__ Lout, int* __restrict__ fail) {
-  sp_eliminate_body(blockIdx.x, nodes, first, tiles, rows, S, ld, W, wstride, Lout, fail);
+struct SpArgs {          // one sparse level
+  const SpNode* nodes; int first, tiles; const int* rows; double* S; int ld; double* W; int wstride; double* Lout; int* fail; int nblocks; const int* done;
+};
+__global__ __launch_bounds__(256) void k_sp_eliminate(SpArgs a) {
+  if ((int)blockIdx.x >= a.nblocks || (a.done && *a.done)) return;
+  sp_eliminate_body(blockIdx.x, a.nodes, a.first, a.tiles, a.rows, a.S, a.ld, a.W, a.wstride, a.Lout, a.fail);
+}
+__global__ __launch_bounds__(256) void k_sp_eliminate_b(const SpArgs* __restrict__ t) {
+  const SpArgs a = t[blockIdx.y];
+  if ((int)blockIdx.x >= a.nblocks || (a.done && *a.done)) return;
+  sp_eliminate_body(blockIdx.x, a.nodes, a.first, a.tiles, a.rows, a.S, a.ld, a.W, a.wstride, a.Lout, a.fail);
 }
 // The band-limited Schur complement and the FIRST sparse level in one launch: both only ADD (atomically) into entries of S the other
 // does not read — the Schur complement touches the pose corner and the pose part of the rhs row, level 0 reads its own (v,ba,bg)
 // columns — so they are independent; later levels depend on level 0 and stay launches of their own.
-__global__ __launch_bounds__(256) void k_schur_sp0(int n_slices, int n_groups, int dp, int ldE, const double* __restrict__ E,
-                                                   const double* __restrict__ Cd, const int* __restrict__ order, const int* __restrict__ n_active_p,
-                                                   const int* __restrict__ kmin, const int* __restrict__ kmax, int d_local, int ldS,
-                                                   double* __restrict__ S_pose, const SpNode* __restrict__ nodes, int first, int tiles,
-                                                   const int* __restrict__ rows, double* __restrict__ S, double* __restrict__ W, int wstride,
-                                                   double* __restrict__ Lout, int* __restrict__ fail) {
-  const int b = blockIdx.x, ns = n_slices * n_groups;
-  if (b < ns) schur_band_body(b % n_slices, b / n_slices, dp, ldE, E, Cd, order, n_active_p, kmin, kmax, d_local, ldS, S_pose);
-  else sp_eliminate_body(b - ns, nodes, first, tiles, rows, S, ldS, W, wstride, Lout, fail);
+struct SchurSp0Args {
+  int n_slices, n_groups, dp, ldE; const double *E, *Cd; const int *order, *n_active, *kmin, *kmax; int d_local, ldS; double* S_pose;
+  SpArgs sp;             // level 0 (sp.nblocks == 0: Schur complement only)
+  int nblocks; const int* done;
+};
+__device__ __forceinline__ void schur_sp0_body(const int b, const SchurSp0Args& A) {
+  if (b >= A.nblocks || (A.done && *A.done)) return;
+  const int ns = A.n_slices * A.n_groups;
+  if (b < ns) schur_band_body(b % A.n_slices, b / A.n_slices, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose);
+  else sp_eliminate_body(b - ns, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail);
 }
+__global__ __launch_bounds__(256) void k_schur_sp0(SchurSp0Args a) { schur_sp0_body(blockIdx.x, a); }
+__global__ __launch_bounds__(256) void k_schur_sp0_b(const SchurSp0Args* __restrict__ t) { schur_sp0_body(blockIdx.x, t[blockIdx.y]); }
 
 struct SpBack {                    // what the back substitution needs of the plan
   SpLevels lv;
@@ -1308,7 +1377,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //     L_bb^-1.  The solution leaves in the natural unknown order through `perm`.
 // (S and Dinv are deliberately NOT __restrict__/invariant: LLVM would sink the prefetch loads past the barriers to their uses.)
 constexpr int kBT = 512, kBParts = kBT / 64, kBackPre = 256 / kBParts, kBackInv = 64 / kBParts, kTailPre = 6;
-__global__ __launch_bounds__(kBT) void k_chol_backsolve(const double* S, int ld, int d, const double* Dinv, double* xout, SpBack sp) {
+struct BackArgs { const double* Sd; int ld, d; const double* Dinv; double* xout; SpBack sp; const int* done; };
+__device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
+  if (A.done && *A.done) return;
+  const double* S = A.Sd; const int ld = A.ld, d = A.d; const double* Dinv = A.Dinv; double* xout = A.xout; const SpBack& sp = A.sp;
   extern __shared__ double sm[];          // xs[off] | x[nblk*64] | partial[kBParts][64] | rhs[64] | accs[9 max_count] | linv[81 n_nodes]
   const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
   const int nblk = (d + kNB - 1) / kNB, n = nblk * kNB;
@@ -1455,6 +1527,8 @@ __global__ __launch_bounds__(kBT) void k_chol_backsolve(const double* S, int ld,
   mark();
   if (sp.dbg && tid == 0) sp.dbg[63] = (unsigned long long)stamp;
 }
+__global__ __launch_bounds__(kBT) void k_chol_backsolve(BackArgs a) { chol_backsolve_body(a); }
+__global__ __launch_bounds__(kBT) void k_chol_backsolve_b(const BackArgs* __restrict__ t) { chol_backsolve_body(t[blockIdx.y]); }
 
 // ------------------------------------------------------------------------------------------------ step pieces
 // landmark back-substitution: dl = (-gr - e_l . dx_pose) / Cd ; model terms and norms
@@ -1548,28 +1622,137 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
 
 // landmark back-substitution and the camera-side step / model terms as ONE launch: workgroups [0, g_lm) walk the landmarks,
 // the rest apply dx to the keyframe states (independent of the landmark results)
-__global__ __launch_bounds__(kT) void k_step_tail(int g_lm, int n_lm, int dp, int ldE, const double* __restrict__ E, const double* __restrict__ C,
-                                                  const double* __restrict__ Cd, const double* __restrict__ gr, const double* __restrict__ dxc,
-                                                  double* __restrict__ dxl, double* __restrict__ scal, const int* __restrict__ kmin,
-                                                  const int* __restrict__ kmax, int n_kf, StateP s, double* __restrict__ poses2,
-                                                  double* __restrict__ vel2, double* __restrict__ ba2, double* __restrict__ bg2,
-                                                  double* __restrict__ invd2, int d, int ld, const double* __restrict__ B,
-                                                  const double* __restrict__ gc, double inv_radius) {
-  if ((int)blockIdx.x < g_lm) landmark_back_body(blockIdx.x, g_lm, n_lm, dp, ldE, E, C, Cd, gr, dxc, s.inv_depth, dxl, invd2, scal, kmin, kmax);
-  else apply_step_body(blockIdx.x - g_lm, n_kf, 0, s, dxc, dxl, poses2, vel2, ba2, bg2, invd2, scal, d, ld, B, gc, inv_radius);
+struct TailArgs {
+  int g_lm, n_lm, dp, ldE; const double *E, *C, *Cd, *gr, *dxc; double *dxl, *scal; const int *kmin, *kmax; int n_kf; StateP s;
+  double *poses2, *vel2, *ba2, *bg2, *invd2; int d, ld; const double *B, *gc; const double* radius; int nblocks; const int* done;
+};
+__device__ __forceinline__ void step_tail_body(const int bx, const TailArgs& A) {
+  if (bx >= A.nblocks || (A.done && *A.done)) return;
+  if (bx < A.g_lm) landmark_back_body(bx, A.g_lm, A.n_lm, A.dp, A.ldE, A.E, A.C, A.Cd, A.gr, A.dxc, A.s.inv_depth, A.dxl, A.invd2, A.scal, A.kmin, A.kmax);
+  else apply_step_body(bx - A.g_lm, A.n_kf, 0, A.s, A.dxc, A.dxl, A.poses2, A.vel2, A.ba2, A.bg2, A.invd2, A.scal, A.d, A.ld, A.B, A.gc, 1.0 / *A.radius);
 }
+__global__ __launch_bounds__(kT) void k_step_tail(TailArgs a) { step_tail_body(blockIdx.x, a); }
+__global__ __launch_bounds__(kT) void k_step_tail_b(const TailArgs* __restrict__ t) { step_tail_body(blockIdx.x, t[blockIdx.y]); }
+
+// ------------------------------------------------------------------------------------------------ closing an iteration on device
+// One workgroup per window: the step-quality test, the trust-region update, the commit of an accepted candidate (a copy of a few tens
+// of kilobytes: the window's poses, velocities, biases and inverse depths) and the termination tests — what ceres::Solve's
+// TrustRegionMinimizer does on the host between evaluations (declared semantics: oracle/lm.h).  The scalars arrive as 32-way striped
+// sums (block_add); `rec` (optional, host-mapped) receives a copy of the control block so a waiting host sees progress without a copy.
+struct DecideArgs {
+  const double* scal; LmCtl* ctl; LmCtl* rec;
+  int n_kf, n_lm;
+  double *poses, *vel, *ba, *bg, *invd;                 // the state
+  const double *poses2, *vel2, *ba2, *bg2, *invd2;      // the candidate
+};
+constexpr int kDT = 1024;
+__device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
+  __shared__ int s_commit, s_skip;
+  LmCtl* c = A.ctl;
+  if (threadIdx.x == 0) s_skip = c->done;
+  __syncthreads();
+  if (s_skip) return;
+  if (threadIdx.x == 0) {
+    const double* h = A.scal;
+    auto ssum = [&](int slot) { double v = 0.0; for (int k = 0; k < kStripes; ++k) v += h[slot + k]; return v; };
+    const int hfail = *reinterpret_cast<const int*>(h + SC_FAIL);
+    const double cost_before = ssum(SC_COST), cost_new = ssum(SC_COST_NEW), model = -ssum(SC_MODEL);
+    const double dxnorm = sqrt(ssum(SC_DXNORM)), xnorm = sqrt(ssum(SC_XNORM));
+    const double gmax = __longlong_as_double(*reinterpret_cast<const long long*>(h + SC_GMAX));
+    const bool solved = hfail == 0 && isfinite(cost_new) && isfinite(model);
+    const int it = c->iter;
+    if (it == 0) { c->initial_cost = cost_before; c->cost = cost_before; }
+    c->cost_before = cost_before; c->model = model; c->dxnorm = dxnorm; c->xnorm = xnorm; c->gmax = gmax; c->solved = solved ? 1 : 0;
+    c->last_radius = c->radius;
+    c->iter = it + 1;
+    bool accepted = false, done = false;
+    int termination = 1;
+    // gradient tolerance: tested on the gradient at the point this iteration started from, before its step is taken
+    if (gmax <= c->gradient_tol) { done = true; termination = 0; }
+    // parameter tolerance: a step this small ends the solve without being taken
+    else if (solved && dxnorm <= c->parameter_tol * (xnorm + c->parameter_tol)) { done = true; termination = 0; }
+    else {
+      if (solved && model > 0.0) {
+        const double rho = (cost_before - cost_new) / model;
+        if (rho > c->min_rel_decrease) {
+          accepted = true;
+          const double t = 2.0 * rho - 1.0;
+          c->radius = fmin(c->radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
+          c->decrease = 2.0;
+          c->successes += 1;
+          const double change = c->cost - cost_new;
+          c->cost = cost_new;
+          if (fabs(change) <= c->function_tol * fabs(cost_before)) { done = true; termination = 0; }
+        }
+      }
+      if (!accepted) {
+        c->radius = c->radius / c->decrease;
+        c->decrease *= 2.0;
+        c->invalid_run = solved ? 0 : c->invalid_run + 1;
+        if (!solved && (c->radius < 1e-32 || c->invalid_run >= 5)) { done = true; termination = 2; }      // max_num_consecutive_invalid_steps
+      } else c->invalid_run = 0;
+    }
+    c->cost_after = accepted ? cost_new : (solved ? cost_new : cost_before);
+    c->accepted = accepted ? 1 : 0;
+    if (!done && c->iter >= c->max_iters) done = true;          // termination stays NO_CONVERGENCE
+    if (done) { c->termination = termination; c->done = 1; }
+    s_commit = accepted ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_commit) {
+    for (int i = threadIdx.x; i < 7 * A.n_kf; i += kDT) A.poses[i] = A.poses2[i];
+    for (int i = threadIdx.x; i < 3 * A.n_kf; i += kDT) { A.vel[i] = A.vel2[i]; A.ba[i] = A.ba2[i]; A.bg[i] = A.bg2[i]; }
+    for (int i = threadIdx.x; i < A.n_lm; i += kDT) A.invd[i] = A.invd2[i];
+  }
+  if (A.rec) {
+    __syncthreads();
+    __threadfence_system();
+    if (threadIdx.x < (int)(sizeof(LmCtl) / 8)) reinterpret_cast<volatile unsigned long long*>(A.rec)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(c)[threadIdx.x];
+  }
+}
+__global__ __launch_bounds__(kDT) void k_lm_decide(DecideArgs a) { lm_decide_body(a); }
+__global__ __launch_bounds__(kDT) void k_lm_decide_b(const DecideArgs* __restrict__ t) { lm_decide_body(t[blockIdx.y]); }
 
 // ================================================================================================ host side
 static StateP state_ptrs(const lvf_state* st) { return StateP{st->poses.p, st->vel.p, st->ba.p, st->bg.p, st->inv_depth.p, st->w_visual.p}; }
 static inline int grid(int n) { return (n + kT - 1) / kT; }
 
-// accumulates 1/2 sum rho into *cost_slot at the given state (residual-only pass)
-static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_state_view, double huber, double* cost_slot) {
-  hipStream_t q = p->ctx->stream;
-  CostVisual a{};
+// The argument blocks of ONE LM iteration of a window.  Nothing in them changes from iteration to iteration (the trust-region radius,
+// the accept / reject state and the termination flag live in the device-resident LmCtl; an accepted candidate is COPIED into the state
+// buffers by k_lm_decide), so they are built once per problem_configure and
+//   * passed by value to the single-window launches, or
+//   * stored as one entry per window in device tables, every launch of the chain then covering a whole batch of windows (blockIdx.y).
+struct Chain {
+  bool fast = false;            // merged linearisation (sorted TwoFrame work list) available
+  bool batchable = false;       // every launch of the iteration has a table form (fast + band Schur merged with sparse level 0 + no priors)
+  bool has_imu = false, has_prior = false;
+  ZeroList zero{};
+  ImuArgs imu_lin{}, imu_cost{};
+  LinArgs lin{};
+  PrepArgs prep{};
+  bool merged_level0 = false;
+  SchurSp0Args ssp0{}; size_t ssp0_lds = 0;
+  int n_levels = 0; SpArgs sp[kSpMaxLevels]; int sp_lds[kSpMaxLevels] = {0};
+  CholArgs chol{};
+  BackArgs back{}; size_t back_lds = 0;
+  TailArgs tail{}; size_t tail_lds = 0;
+  CostArgs cost{};
+  DecideArgs dec{};
+};
+
+}  // namespace lvf
+lvf_problem::~lvf_problem() {
+  delete chain;
+  if (rec) (void)hipHostFree(rec);
+  if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+}
+namespace lvf {
+
+static void fill_cost_visual(const lvf_problem* p, CostVisual& a) {
+  a = CostVisual{};
   if (p->tc && p->tc->n) {
-    a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p; a.tc_w = p->tc->wblk.n ? p->tc->wblk.p : nullptr;
-    a.tc_left = p->tc->cam_a; a.tc_right = p->tc->cam_b;
+    a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p;
+    a.tc_w = p->tc->wblk.n ? p->tc->wblk.p : nullptr; a.tc_left = p->tc->cam_a; a.tc_right = p->tc->cam_b;
   }
   if (p->tf && p->tf->n) {
     a.n_tf = p->tf->n; a.tf_fo = (const double2*)p->tf->ob_a.p; a.tf_ob = (const double2*)p->tf->ob_b.p; a.tf_lm = p->tf->idx_a.p; a.tf_k1 = p->tf->idx_b.p;
@@ -1579,8 +1762,26 @@ static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_st
     a.n_po = p->po->n; a.po_ob = (const double2*)p->po->ob_a.p; a.po_kf = p->po->idx_a.p; a.po_pwi = p->po->idx_b.p; a.po_pw = p->po->table.p; a.po_cam = p->po->cam_a;
   }
   a.g_tc = grid(a.n_tc); a.g_tf = grid(a.n_tf);
-  const int g_all = a.g_tc + a.g_tf + grid(a.n_po);
-  if (g_all > 0) hipLaunchKernelGGL(k_cost_visual, dim3(g_all), dim3(kT), 0, q, a, p->n_kf, s, huber, cost_slot);
+}
+
+// a state-shaped VIEW of borrowed device pointers (for the launchers that take an lvf_state); never destroyed with live pointers
+struct StateView {
+  lvf_state v;
+  StateView(lvf_ctx* ctx, int n_kf, int n_lm, double* poses, double* vel, double* ba, double* bg, double* invd, double* wv) {
+    v.ctx = ctx; v.n_kf = n_kf; v.n_lm = n_lm;
+    v.poses.p = poses; v.vel.p = vel; v.ba.p = ba; v.bg.p = bg; v.inv_depth.p = invd; v.w_visual.p = wv;
+  }
+  ~StateView() { v.poses.p = v.vel.p = v.ba.p = v.bg.p = v.inv_depth.p = v.w_visual.p = nullptr; }
+};
+
+// accumulates 1/2 sum rho into *cost_slot at the given state (residual-only pass); not gated by the LM control block
+static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_state_view, double huber, double* cost_slot) {
+  hipStream_t q = p->ctx->stream;
+  CostArgs c{};
+  fill_cost_visual(p, c.a);
+  c.n_kf = p->n_kf; c.s = s; c.huber = huber; c.cost = cost_slot; c.done = nullptr;
+  c.nblocks = c.a.g_tc + c.a.g_tf + grid(c.a.n_po);
+  if (c.nblocks > 0) hipLaunchKernelGGL(k_cost_visual, dim3(c.nblocks), dim3(kT), 0, q, c);
   if (p->imu && p->imu->n) {
     static_assert(kStripes == 32, "k_imu stripes its cost over 32 slots");
     LVF_TRY(launch_imu(p->imu, imu_state_view, false, cost_slot));      // residuals and their cost in one launch
@@ -1593,126 +1794,11 @@ static int enqueue_cost(lvf_problem* p, const StateP& s, const lvf_state* imu_st
   return LVF_OK;
 }
 
-static int enqueue_linearize(lvf_problem* p, double huber) {
-  hipStream_t q = p->ctx->stream;
-  const StateP s = state_ptrs(p->st);
-  ZeroList z{};
-  {
-    int k = 0;
-    auto add = [&](double* ptr, size_t n) { if (ptr && n) { z.p[k] = ptr; z.n[k] = n; ++k; } };
-    add(p->B.p, (size_t)p->dpad * p->dpad); add(p->gc.p, p->dpad); add(p->scal.p, SC_N);
-    if (p->n_lm) { add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
-    z.count = k;
-  }
-  double* cost = p->scal.p + SC_COST;
-  const bool tf_fast = p->tf && p->tf->n && p->tf_work.n && p->n_kf <= kMaxStagedKf;
-  bool imu_done = false;
-  // the accumulators are zeroed by extra workgroups of the IMU evaluation launch when there is one ahead of the merged linearisation
-  // (neither depends on the other); otherwise by a launch of their own
-  const bool zero_with_imu = tf_fast && p->imu && p->imu->n;
-  if (!zero_with_imu) hipLaunchKernelGGL(k_zero_multi, dim3(512, z.count), dim3(kT), 0, q, z);
-  if (tf_fast) {
-    LinVisual a{};
-    a.n_tfw = (int)p->tf_work.n; a.work = p->tf_work.p; a.tf_fo = (const double2*)p->tf->ob_a.p; a.tf_ob = (const double2*)p->tf->ob_b.p;
-    a.tf_lm = p->tf->idx_a.p; a.tf_k1 = p->tf->idx_b.p; a.tf_left = p->tf->cam_a; a.tf_right = p->tf->cam_b; a.unique_lk2 = p->tf_unique_lk2 ? 1 : 0;
-    if (p->tc && p->tc->n) {
-      a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p; a.tc_w = p->tc->wblk.n ? p->tc->wblk.p : nullptr;
-      a.tc_left = p->tc->cam_a; a.tc_right = p->tc->cam_b;
-    }
-    if (p->po && p->po->n) {
-      a.n_po = p->po->n; a.po_ob = (const double2*)p->po->ob_a.p; a.po_kf = p->po->idx_a.p; a.po_pwi = p->po->idx_b.p; a.po_pw = p->po->table.p; a.po_cam = p->po->cam_a;
-    }
-    a.g_tc = grid(a.n_tc); a.g_po = grid(a.n_po);
-    if (p->imu && p->imu->n) {
-      LVF_TRY(launch_imu(p->imu, p->st, true, nullptr, &z));   // residuals + Jacobians (+ the zeroing) first; their accumulation rides in the launch below
-      a.n_imu = p->imu->n; a.imu_res = p->imu->res.p; a.imu_i = p->imu->idx_a.p; a.imu_j = p->imu->idx_b.p;
-      for (int k = 0; k < 8; ++k) a.imu_J.j[k] = p->imu->jac[k].p;
-      imu_done = true;
-    }
-    hipLaunchKernelGGL(k_lin_visual, dim3(a.n_tfw + a.g_tc + a.g_po + (a.n_imu + 3) / 4), dim3(kT), 0, q, a, p->n_kf, s, huber, p->pose_const.p, p->B.p,
-                       p->dpad, p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
-  } else {
-  if (p->tc && p->tc->n)
-    hipLaunchKernelGGL(k_lin_tc<false>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
-                       p->tc->idx_a.p, p->tc->idx_b.p, p->tc->wblk.n ? p->tc->wblk.p : (const double*)nullptr, s, p->tc->cam_a, p->tc->cam_b, huber, p->C.p, p->gr.p, cost);
-  if (p->tf && p->tf->n)
-    hipLaunchKernelGGL(k_lin_tf<false>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
-                       p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, p->B.p, p->dpad,
-                       p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
-  if (p->po && p->po->n)
-    hipLaunchKernelGGL(k_lin_po<false>, dim3(grid(p->po->n)), dim3(kT), 0, q, p->po->n, p->n_kf, (const double2*)p->po->ob_a.p, p->po->idx_a.p,
-                       p->po->idx_b.p, p->po->table.p, s, p->po->cam_a, huber, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
-  }
-  if (p->imu && p->imu->n && !imu_done) {
-    LVF_TRY(launch_imu(p->imu, p->st, true));
-    ImuJ J;
-    for (int k = 0; k < 8; ++k) J.j[k] = p->imu->jac[k].p;
-    hipLaunchKernelGGL(k_lin_imu, dim3(p->imu->n), dim3(64), 0, q, p->imu->n, p->n_kf, p->imu->res.p, J, p->imu->idx_a.p, p->imu->idx_b.p,
-                       p->st->poses.p, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
-  }
-  if (p->prior && p->prior->n) {
-    LVF_TRY(launch_pose_prior(p->prior, p->st, true));
-    hipLaunchKernelGGL(k_lin_prior, dim3((p->prior->n + 63) / 64), dim3(64), 0, q, p->prior->n, p->prior->res.p, p->prior->jac[0].p,
-                       p->prior->jac[1].p, p->prior->idx_a.p, p->prior->idx_b.p, p->st->poses.p, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
-  }
-  LVF_HIP(hipGetLastError());
-  p->linearized = true;
-  return LVF_OK;
-}
-
-// S (elimination order) = B + D - E^T Cd^-1 E, rhs row = -(gc - E^T Cd^-1 g_rho)
-static int enqueue_reduced_system(lvf_problem* p, double inv_r, double* scal, int* fail_flag_dev = nullptr, bool* level0_done = nullptr) {
-  hipStream_t q = p->ctx->stream;
-  const size_t nS = (size_t)p->ld * p->ld;
-  const unsigned nSb = (unsigned)((nS + kT - 1) / kT);
-  hipLaunchKernelGGL(k_prepare, dim3(nSb + (p->n_lm ? grid(p->n_lm) : 0)), dim3(kT), 0, q, p->ld, p->dpad, p->iperm.p, p->B.p, p->gc.p, inv_r, p->S.p, nSb,
-                     p->n_lm, p->dp, p->ldE, p->C.p, p->gr.p, p->Cd.p, p->E.p, scal);
-  if (level0_done) *level0_done = false;
-  if (p->n_lm) {
-    // the Schur complement only touches the pose corner (local rhs row = dp)
-    double* S_pose = p->S.p + (size_t)p->off_pose * (p->ld + 1);
-    const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
-    const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRows * sizeof(int);
-    if (p->band_ready && shb <= 64 * 1024 && level0_done && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024) {
-      // band-limited Schur complement + first sparse level, one launch
-      const int n_slices = (p->n_lm + kBandRows - 1) / kBandRows, n_groups = (ntile + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
-      hipLaunchKernelGGL(k_schur_sp0, dim3(n_slices * n_groups + p->sp_levels.count[0] * p->sp_tiles[0]), dim3(256), std::max(shb, (size_t)p->sp_shmem[0]), q,
-                         n_slices, n_groups, p->dp, p->ldE, p->E.p, p->Cd.p, p->lm_order.p, p->lm_nactive.p, p->lm_kmin.p, p->lm_kmax.p, p->dp, p->ld, S_pose,
-                         p->sp_nodes.p, p->sp_levels.first[0], p->sp_tiles[0], p->sp_rows.p, p->S.p, p->sp_W.p, p->sp_wstride, p->sp_L.p, fail_flag_dev);
-      *level0_done = true;
-    } else {
-      const LmBand band{p->band_ready ? p->lm_order.p : nullptr, p->lm_nactive.p, p->lm_kmin.p, p->lm_kmax.p};
-      LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->dp, p->ld, S_pose, band));
-    }
-  }
-  LVF_HIP(hipGetLastError());
-  return LVF_OK;
-}
-
-// builds the damped reduced system, factors it and leaves dx in dxc/dxl, the candidate state in *2 buffers and the
-// scalars (model change, norms, candidate cost) in scal
-static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_flag_dev) {
-  hipStream_t q = p->ctx->stream;
-  const double inv_r = 1.0 / radius;
-  bool level0_done = false;
-  LVF_TRY(enqueue_reduced_system(p, inv_r, p->scal.p, fail_flag_dev, &level0_done));
-  for (int lv = level0_done ? 1 : 0; lv < p->sp_levels.n; ++lv)
-    hipLaunchKernelGGL(k_sp_eliminate, dim3(p->sp_levels.count[lv] * p->sp_tiles[lv]), dim3(256), p->sp_shmem[lv], q, p->sp_nodes.p, p->sp_levels.first[lv],
-                       p->sp_tiles[lv], p->sp_rows.p, p->S.p, p->ld, p->sp_W.p, p->sp_wstride, p->sp_L.p, fail_flag_dev);
-  double* Sd = p->S.p + (size_t)p->off * (p->ld + 1);       // dense corner
-  for (int kb = 0; kb < p->nb; ++kb) {
-    const int below = p->nb - kb - 1;
-    hipLaunchKernelGGL(k_chol_factor_panel, dim3(2 + below), dim3(256), 0, q, Sd, p->ld, kb, fail_flag_dev, p->Dinv.p);
-    if (below > 0) {
-      hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, q, Sd, p->ld, kb);
-    }
-  }
-  SpBack sb;
+static void fill_back_args(lvf_problem* p, BackArgs& ba, size_t* lds_bytes) {
+  SpBack sb{};
   sb.lv = p->sp_levels; sb.rows = p->sp_rows.p; sb.owner = p->sp_owner.p; sb.W = p->sp_W.p; sb.Linv = p->sp_L.p; sb.perm = p->perm.p;
   sb.off = p->off; sb.aug = p->aug; sb.d_total = p->d;
-  static const bool back_timing = std::getenv("LVF_BACK_TIMING") != nullptr;
   sb.dbg = nullptr;
-  if (back_timing) { LVF_TRY(p->dbg.ensure(64)); sb.dbg = p->dbg.p; }
   int max_count = 0;
   for (int lv = 0; lv < p->sp_levels.n; ++lv) {
     max_count = std::max(max_count, p->sp_levels.count[lv]);
@@ -1723,7 +1809,8 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   sb.n_nodes = n_nodes; sb.max_count = max_count;
   sb.nodes = p->sp_nodes.p;
   static const bool big_lds = [] {        // up to 160 KB of LDS per workgroup on gfx950; the default cap for dynamic LDS is 64 KB
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_backsolve), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_backsolve), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_backsolve_b), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
   }();
   const size_t lds_cap = big_lds ? 156 * 1024 : 64 * 1024;
   size_t doubles = (size_t)p->off + (size_t)((p->ndense + 63) / 64) * 64 + (size_t)(kBParts + 1) * kNB + 9 * (size_t)max_count + kBT + (size_t)n_nodes + 2;
@@ -1733,46 +1820,278 @@ static int enqueue_step(lvf_problem* p, double huber, double radius, int* fail_f
   for (int lv = 0; lv < p->sp_levels.n; ++lv) max_items = std::max(max_items, p->sp_items[lv]);
   sb.prod_items = ((doubles + 9 * (size_t)max_items) * sizeof(double) <= lds_cap) ? max_items : 0;
   doubles += 9 * (size_t)sb.prod_items;
-  const size_t sh = doubles * sizeof(double);
-  hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(kBT), sh, q, Sd, p->ld, p->ndense, p->Dinv.p, p->dxc.p, sb);
-  // model / norms / candidate state
-  const StateP s = state_ptrs(p->st);
-  {
-    const int g_lm = p->n_lm ? std::min(256, (p->n_lm + kT / 16 - 1) / (kT / 16)) : 0;
-    hipLaunchKernelGGL(k_step_tail, dim3(g_lm + grid(p->d)), dim3(kT), (size_t)p->ldE * sizeof(double), q, g_lm, p->n_lm, p->dp, p->ldE, p->E.p, p->C.p,
-                       p->Cd.p, p->gr.p, p->dxc.p, p->dxl.p, p->scal.p, p->band_ready ? p->lm_kmin.p : nullptr, p->lm_kmax.p, p->n_kf, s, p->poses2.p,
-                       p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->d, p->dpad, p->B.p, p->gc.p, inv_r);
-  }
-  LVF_HIP(hipGetLastError());
-  // candidate cost
-  lvf_state view;   // borrowed pointers: a state-shaped view of the candidate buffers for launch_imu
-  view.ctx = p->ctx; view.n_kf = p->n_kf; view.n_lm = p->n_lm;
-  view.poses.p = p->poses2.p; view.vel.p = p->vel2.p; view.ba.p = p->ba2.p; view.bg.p = p->bg2.p; view.inv_depth.p = p->invd2.p;
-  view.w_visual.p = p->st->w_visual.p;
-  const StateP s2{p->poses2.p, p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->st->w_visual.p};
-  const int rc = enqueue_cost(p, s2, &view, huber, p->scal.p + SC_COST_NEW);
-  view.poses.p = view.vel.p = view.ba.p = view.bg.p = view.inv_depth.p = view.w_visual.p = nullptr;   // not owned
-  return rc;
+  *lds_bytes = doubles * sizeof(double);
+  ba.Sd = p->S.p + (size_t)p->off * (p->ld + 1); ba.ld = p->ld; ba.d = p->ndense; ba.Dinv = p->Dinv.p; ba.xout = p->dxc.p; ba.sp = sb;
 }
 
-// an accepted step makes the candidate buffers the state: pointer swap, no copies (the buffers have identical sizes; batches and
-// the C-ABI accessors always go through the lvf_state object, never through cached device pointers)
-static int commit_candidate(lvf_problem* p) {
-  lvf_state* st = p->st;
-  st->poses.swap_storage(p->poses2); st->vel.swap_storage(p->vel2); st->ba.swap_storage(p->ba2); st->bg.swap_storage(p->bg2);
-  st->inv_depth.swap_storage(p->invd2);
+// (re)builds the argument blocks of an iteration from the problem's CURRENT buffers (call after problem_configure / set_pose_priors)
+static int build_chain(lvf_problem* p) {
+  if (!p->chain) p->chain = new Chain();
+  Chain& c = *p->chain;
+  c = Chain();
+  LVF_TRY(p->ctl.ensure(1));
+  if (!p->rec) {
+    void* h = nullptr;
+    LVF_HIP(hipHostMalloc(&h, sizeof(LmCtl), hipHostMallocDefault));
+    p->rec = static_cast<LmCtl*>(h);
+    std::memset(p->rec, 0, sizeof(LmCtl));
+  }
+  LmCtl* ctl = p->ctl.p;
+  const int* done = &ctl->done;
+  const double* radius = &ctl->radius;
+  const StateP s = state_ptrs(p->st);
+  const StateP s2{p->poses2.p, p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->st->w_visual.p};
+  double* cost = p->scal.p + SC_COST;
+  {
+    int k = 0;
+    auto add = [&](double* ptr, size_t n) { if (ptr && n) { c.zero.p[k] = ptr; c.zero.n[k] = n; ++k; } };
+    add(p->B.p, (size_t)p->dpad * p->dpad); add(p->gc.p, p->dpad); add(p->scal.p, SC_N);
+    if (p->n_lm) { add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
+    c.zero.count = k;
+  }
+  c.fast = p->tf && p->tf->n && p->tf_work.n && p->n_kf <= kMaxStagedKf;
+  c.has_imu = p->imu && p->imu->n;
+  c.has_prior = p->prior && p->prior->n;
+  if (c.has_imu) {
+    fill_imu_args(p->imu, s.poses, s.vel, s.ba, s.bg, nullptr, c.fast ? &c.zero : nullptr, done, &c.imu_lin);
+    fill_imu_args(p->imu, s2.poses, s2.vel, s2.ba, s2.bg, p->scal.p + SC_COST_NEW, nullptr, done, &c.imu_cost);
+  }
+  if (c.fast) {
+    LinVisual& a = c.lin.v;
+    a = LinVisual{};
+    a.n_tfw = (int)p->tf_work.n; a.work = p->tf_work.p; a.tf_fo = (const double2*)p->tf->ob_a.p; a.tf_ob = (const double2*)p->tf->ob_b.p;
+    a.tf_lm = p->tf->idx_a.p; a.tf_k1 = p->tf->idx_b.p; a.tf_left = p->tf->cam_a; a.tf_right = p->tf->cam_b; a.unique_lk2 = p->tf_unique_lk2 ? 1 : 0;
+    if (p->tc && p->tc->n) {
+      a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p;
+      a.tc_w = p->tc->wblk.n ? p->tc->wblk.p : nullptr; a.tc_left = p->tc->cam_a; a.tc_right = p->tc->cam_b;
+    }
+    if (p->po && p->po->n) {
+      a.n_po = p->po->n; a.po_ob = (const double2*)p->po->ob_a.p; a.po_kf = p->po->idx_a.p; a.po_pwi = p->po->idx_b.p; a.po_pw = p->po->table.p; a.po_cam = p->po->cam_a;
+    }
+    a.g_tc = grid(a.n_tc); a.g_po = grid(a.n_po);
+    if (c.has_imu) {
+      a.n_imu = p->imu->n; a.imu_res = p->imu->res.p; a.imu_i = p->imu->idx_a.p; a.imu_j = p->imu->idx_b.p;
+      for (int k = 0; k < 8; ++k) a.imu_J.j[k] = p->imu->jac[k].p;
+    }
+    c.lin.n_kf = p->n_kf; c.lin.s = s; c.lin.huber = 0.0; c.lin.pose_const = p->pose_const.p; c.lin.B = p->B.p; c.lin.ld = p->dpad; c.lin.gc = p->gc.p; c.lin.E = p->E.p;
+    c.lin.ldE = p->ldE; c.lin.C = p->C.p; c.lin.gr = p->gr.p; c.lin.cost = cost; c.lin.done = done;
+    c.lin.nblocks = a.n_tfw + a.g_tc + a.g_po + (a.n_imu + 3) / 4;
+  }
+  // damped system
+  {
+    PrepArgs& a = c.prep;
+    const size_t nS = (size_t)p->ld * p->ld;
+    a.ld = p->ld; a.dpad = p->dpad; a.iperm = p->iperm.p; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.S = p->S.p;
+    a.nS_blocks = (unsigned)((nS + kT - 1) / kT); a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.C = p->C.p; a.gr = p->gr.p; a.Cd = p->Cd.p; a.E = p->E.p;
+    a.scal = p->scal.p; a.nblocks = (int)a.nS_blocks + (p->n_lm ? grid(p->n_lm) : 0); a.done = done;
+  }
+  int* fail = reinterpret_cast<int*>(p->scal.p + SC_FAIL);
+  c.n_levels = p->sp_levels.n;
+  for (int lv = 0; lv < p->sp_levels.n; ++lv) {
+    SpArgs& a = c.sp[lv];
+    a.nodes = p->sp_nodes.p; a.first = p->sp_levels.first[lv]; a.tiles = p->sp_tiles[lv]; a.rows = p->sp_rows.p; a.S = p->S.p; a.ld = p->ld; a.W = p->sp_W.p;
+    a.wstride = p->sp_wstride; a.Lout = p->sp_L.p; a.fail = fail; a.nblocks = p->sp_levels.count[lv] * p->sp_tiles[lv]; a.done = done;
+    c.sp_lds[lv] = p->sp_shmem[lv];
+  }
+  c.merged_level0 = false;
+  if (p->n_lm) {
+    const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
+    const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRows * sizeof(int);
+    if (p->band_ready && shb <= 64 * 1024 && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024) {
+      SchurSp0Args& a = c.ssp0;
+      a.n_slices = (p->n_lm + kBandRows - 1) / kBandRows; a.n_groups = (ntile + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
+      a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.Cd = p->Cd.p; a.order = p->lm_order.p; a.n_active = p->lm_nactive.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p;
+      a.d_local = p->dp; a.ldS = p->ld; a.S_pose = p->S.p + (size_t)p->off_pose * (p->ld + 1);
+      a.sp = c.sp[0];
+      a.nblocks = a.n_slices * a.n_groups + c.sp[0].nblocks; a.done = done;
+      c.ssp0_lds = std::max(shb, (size_t)p->sp_shmem[0]);
+      c.merged_level0 = true;
+    }
+  }
+  c.chol.Sd = p->S.p + (size_t)p->off * (p->ld + 1); c.chol.ld = p->ld; c.chol.nb = p->nb; c.chol.fail = fail; c.chol.Dinv = p->Dinv.p; c.chol.done = done;
+  fill_back_args(p, c.back, &c.back_lds);
+  c.back.done = done;
+  {
+    TailArgs& a = c.tail;
+    a.g_lm = p->n_lm ? std::min(256, (p->n_lm + kT / 16 - 1) / (kT / 16)) : 0;
+    a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.C = p->C.p; a.Cd = p->Cd.p; a.gr = p->gr.p; a.dxc = p->dxc.p; a.dxl = p->dxl.p; a.scal = p->scal.p;
+    a.kmin = p->band_ready ? p->lm_kmin.p : nullptr; a.kmax = p->lm_kmax.p; a.n_kf = p->n_kf; a.s = s; a.poses2 = p->poses2.p; a.vel2 = p->vel2.p; a.ba2 = p->ba2.p;
+    a.bg2 = p->bg2.p; a.invd2 = p->invd2.p; a.d = p->d; a.ld = p->dpad; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.nblocks = a.g_lm + grid(p->d); a.done = done;
+    c.tail_lds = (size_t)p->ldE * sizeof(double);
+  }
+  fill_cost_visual(p, c.cost.a);
+  c.cost.n_kf = p->n_kf; c.cost.s = s2; c.cost.huber = 0.0; c.cost.cost = p->scal.p + SC_COST_NEW; c.cost.done = done;
+  c.cost.nblocks = c.cost.a.g_tc + c.cost.a.g_tf + grid(c.cost.a.n_po);
+  {
+    DecideArgs& a = c.dec;
+    a.scal = p->scal.p; a.ctl = ctl; a.rec = p->rec; a.n_kf = p->n_kf; a.n_lm = p->n_lm;
+    a.poses = p->st->poses.p; a.vel = p->st->vel.p; a.ba = p->st->ba.p; a.bg = p->st->bg.p; a.invd = p->st->inv_depth.p;
+    a.poses2 = p->poses2.p; a.vel2 = p->vel2.p; a.ba2 = p->ba2.p; a.bg2 = p->bg2.p; a.invd2 = p->invd2.p;
+  }
+  c.batchable = c.fast && c.has_imu && !c.has_prior && c.merged_level0 && c.lin.nblocks > 0 && c.cost.nblocks > 0;
+  { const StateP sp = state_ptrs(p->st); std::memcpy(p->chain_state, &sp, sizeof(sp)); }
+  p->chain_ready = true;
+  return LVF_OK;
+}
+static bool chain_stale(const lvf_problem* p) {
+  if (!p->chain_ready || !p->chain) return true;
+  const StateP s = state_ptrs(p->st);
+  static_assert(sizeof(StateP) == sizeof(p->chain_state), "StateP is six pointers");
+  return std::memcmp(&s, p->chain_state, sizeof(StateP)) != 0;      // the state's buffers were re-allocated (window grew)
+}
+
+// the linearisation at the current state: cost, B, gc, E, C, gr.  `gated`: skipped on device once the LM loop has finished
+static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
+  hipStream_t q = p->ctx->stream;
+  if (chain_stale(p)) LVF_TRY(build_chain(p));
+  const Chain& c = *p->chain;
+  const StateP s = state_ptrs(p->st);
+  double* cost = p->scal.p + SC_COST;
+  bool imu_done = false;
+  // the accumulators are zeroed by extra workgroups of the IMU evaluation launch when there is one ahead of the merged linearisation
+  // (neither depends on the other); otherwise by a launch of their own
+  const bool zero_with_imu = c.fast && c.has_imu;
+  if (!zero_with_imu) hipLaunchKernelGGL(k_zero_multi, dim3(512, c.zero.count), dim3(kT), 0, q, c.zero);
+  if (c.fast) {
+    if (c.has_imu) {
+      ImuArgs ia = c.imu_lin;
+      if (!gated) ia.done = nullptr;
+      LVF_TRY(launch_imu_args(q, ia, true));   // residuals + Jacobians (+ the zeroing) first; their accumulation rides in the launch below
+      imu_done = true;
+    }
+    LinArgs la = c.lin;
+    la.huber = huber;
+    if (!gated) la.done = nullptr;
+    hipLaunchKernelGGL(k_lin_visual, dim3(la.nblocks), dim3(kT), 0, q, la);
+  } else {
+    if (p->tc && p->tc->n)
+      hipLaunchKernelGGL(k_lin_tc<false>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
+                         p->tc->idx_a.p, p->tc->idx_b.p, p->tc->wblk.n ? p->tc->wblk.p : (const double*)nullptr, s, p->tc->cam_a, p->tc->cam_b, huber, p->C.p, p->gr.p, cost);
+    if (p->tf && p->tf->n)
+      hipLaunchKernelGGL(k_lin_tf<false>, dim3(grid(p->tf->n)), dim3(kT), 0, q, p->tf->n, p->n_kf, (const double2*)p->tf->ob_a.p, (const double2*)p->tf->ob_b.p,
+                         p->tf->idx_a.p, p->tf->idx_b.p, p->tf->idx_c.p, s, p->tf->cam_a, p->tf->cam_b, huber, p->pose_const.p, p->B.p, p->dpad,
+                         p->gc.p, p->E.p, p->ldE, p->C.p, p->gr.p, cost);
+    if (p->po && p->po->n)
+      hipLaunchKernelGGL(k_lin_po<false>, dim3(grid(p->po->n)), dim3(kT), 0, q, p->po->n, p->n_kf, (const double2*)p->po->ob_a.p, p->po->idx_a.p,
+                         p->po->idx_b.p, p->po->table.p, s, p->po->cam_a, huber, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
+  }
+  if (c.has_imu && !imu_done) {
+    LVF_TRY(launch_imu(p->imu, p->st, true));
+    ImuJ J;
+    for (int k = 0; k < 8; ++k) J.j[k] = p->imu->jac[k].p;
+    hipLaunchKernelGGL(k_lin_imu, dim3(p->imu->n), dim3(64), 0, q, p->imu->n, p->n_kf, p->imu->res.p, J, p->imu->idx_a.p, p->imu->idx_b.p,
+                       p->st->poses.p, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
+  }
+  if (c.has_prior) {
+    LVF_TRY(launch_pose_prior(p->prior, p->st, true));
+    hipLaunchKernelGGL(k_lin_prior, dim3((p->prior->n + 63) / 64), dim3(64), 0, q, p->prior->n, p->prior->res.p, p->prior->jac[0].p,
+                       p->prior->jac[1].p, p->prior->idx_a.p, p->prior->idx_b.p, p->st->poses.p, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
+  }
+  LVF_HIP(hipGetLastError());
+  p->linearized = true;
+  return LVF_OK;
+}
+
+// S (elimination order) = B + D - E^T Cd^-1 E, rhs row = -(gc - E^T Cd^-1 g_rho); radius read from `radius_dev`
+static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool reset_scalars, bool gated, bool* level0_done) {
+  hipStream_t q = p->ctx->stream;
+  const Chain& c = *p->chain;
+  PrepArgs pa = c.prep;
+  pa.radius = radius_dev;
+  if (!reset_scalars) pa.scal = nullptr;
+  if (!gated) pa.done = nullptr;
+  hipLaunchKernelGGL(k_prepare, dim3(pa.nblocks), dim3(kT), 0, q, pa);
+  if (level0_done) *level0_done = false;
+  if (p->n_lm) {
+    if (c.merged_level0 && level0_done) {
+      SchurSp0Args sa = c.ssp0;
+      if (!gated) sa.done = nullptr;
+      hipLaunchKernelGGL(k_schur_sp0, dim3(sa.nblocks), dim3(256), c.ssp0_lds, q, sa);
+      *level0_done = true;
+    } else {
+      double* S_pose = p->S.p + (size_t)p->off_pose * (p->ld + 1);
+      const LmBand band{p->band_ready ? p->lm_order.p : nullptr, p->lm_nactive.p, p->lm_kmin.p, p->lm_kmax.p};
+      LVF_TRY(launch_schur(q, p->n_lm, p->dp, p->ldE, p->E.p, p->Cd.p, p->dp, p->ld, S_pose, band));
+    }
+  }
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+
+// one complete LM iteration of one window on its stream, closed on device by k_lm_decide; nothing is waited for
+static int enqueue_iteration(lvf_problem* p) {
+  hipStream_t q = p->ctx->stream;
+  if (chain_stale(p)) LVF_TRY(build_chain(p));
+  const Chain& c = *p->chain;
+  LVF_TRY(enqueue_linearize(p, p->huber, true));
+  bool level0_done = false;
+  LVF_TRY(enqueue_reduced_system(p, &p->ctl.p->radius, true, true, &level0_done));
+  for (int lv = level0_done ? 1 : 0; lv < c.n_levels; ++lv)
+    hipLaunchKernelGGL(k_sp_eliminate, dim3(c.sp[lv].nblocks), dim3(256), c.sp_lds[lv], q, c.sp[lv]);
+  for (int kb = 0; kb < p->nb; ++kb) {
+    const int below = p->nb - kb - 1;
+    hipLaunchKernelGGL(k_chol_factor_panel, dim3(2 + below), dim3(256), 0, q, c.chol, kb);
+    if (below > 0) hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, q, c.chol, kb);
+  }
+  {
+    BackArgs ba = c.back;
+    static const bool back_timing = std::getenv("LVF_BACK_TIMING") != nullptr;
+    if (back_timing) { LVF_TRY(p->dbg.ensure(64)); ba.sp.dbg = p->dbg.p; }
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(kBT), c.back_lds, q, ba);
+  }
+  hipLaunchKernelGGL(k_step_tail, dim3(c.tail.nblocks), dim3(kT), c.tail_lds, q, c.tail);
+  // candidate cost
+  CostArgs ca = c.cost;
+  ca.huber = p->huber;
+  if (ca.nblocks > 0) hipLaunchKernelGGL(k_cost_visual, dim3(ca.nblocks), dim3(kT), 0, q, ca);
+  if (c.has_imu) LVF_TRY(launch_imu_args(q, c.imu_cost, false));
+  if (c.has_prior) {
+    StateView view(p->ctx, p->n_kf, p->n_lm, p->poses2.p, p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->st->w_visual.p);
+    LVF_TRY(launch_pose_prior(p->prior, &view.v, false));
+    hipLaunchKernelGGL(k_cost_sq, dim3(grid(6 * p->prior->n)), dim3(kT), 0, q, 6 * p->prior->n, p->prior->res.p, p->scal.p + SC_COST_NEW);
+  }
+  hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(kDT), 0, q, c.dec);
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+
+static void ctl_from_options(const lvf_solver_options* o, double radius, double decrease, int max_iters, bool with_tolerances, LmCtl* c) {
+  std::memset(c, 0, sizeof(*c));
+  c->radius = radius; c->decrease = decrease; c->last_radius = radius;
+  c->huber = o->huber_a; c->min_rel_decrease = o->min_relative_decrease;
+  c->function_tol = with_tolerances ? o->function_tolerance : -1.0;
+  c->gradient_tol = with_tolerances ? o->gradient_tolerance : -1.0;
+  c->parameter_tol = with_tolerances ? o->parameter_tolerance : -1.0;
+  c->max_iters = max_iters;
+  c->termination = 1;
+}
+static int upload_ctl(lvf_problem* p, const LmCtl& c) {
+  if (chain_stale(p)) LVF_TRY(build_chain(p));
+  *p->rec = c;                               // the host-visible mirror starts from the same values
+  LVF_TRY(p->h_ctl.reserve(1));
+  p->h_ctl[0] = c;
+  LVF_HIP(hipMemcpyAsync(p->ctl.p, p->h_ctl.p, sizeof(LmCtl), hipMemcpyHostToDevice, p->ctx->stream));
+  return LVF_OK;
+}
+static int download_ctl(lvf_problem* p, LmCtl* out) {
+  hipStream_t q = p->ctx->stream;
+  LVF_TRY(p->h_ctl.reserve(2));
+  LVF_HIP(hipMemcpyAsync(&p->h_ctl[1], p->ctl.p, sizeof(LmCtl), hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipStreamSynchronize(q));
+  *out = p->h_ctl[1];
   return LVF_OK;
 }
 
 struct IterOut { double cost_before, cost_after, model, dxnorm, xnorm, gmax; bool accepted, solved; };
 
+// exactly one LM iteration from the current state (no tolerance tests): the per-iteration parity point
 static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* radius, double* decrease, IterOut* out) {
-  hipStream_t q = p->ctx->stream;
-  LVF_TRY(enqueue_linearize(p, o->huber_a));
-  LVF_TRY(enqueue_step(p, o->huber_a, *radius, reinterpret_cast<int*>(p->scal.p + SC_FAIL)));
-  double h[SC_ALLOC];
-  LVF_HIP(hipMemcpyAsync(h, p->scal.p, sizeof(h), hipMemcpyDeviceToHost, q));
-  LVF_HIP(hipStreamSynchronize(q));
+  LmCtl c;
+  ctl_from_options(o, *radius, *decrease, 1, false, &c);
+  p->huber = o->huber_a;
+  LVF_TRY(upload_ctl(p, c));
+  LVF_TRY(enqueue_iteration(p));
+  LVF_TRY(download_ctl(p, &c));
   if (p->dbg.p && std::getenv("LVF_BACK_TIMING")) {
     unsigned long long t[64];
     LVF_HIP(hipMemcpy(t, p->dbg.p, sizeof(t), hipMemcpyDeviceToHost));
@@ -1780,27 +2099,29 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
     for (unsigned long long k = 1; k < t[63] && k < 63; ++k) std::fprintf(stderr, " %.2f", (double)(t[k] - t[k - 1]) * 0.01);
     std::fprintf(stderr, "\n");
   }
-  int hfail; std::memcpy(&hfail, &h[SC_FAIL], sizeof(int));
-  out->cost_before = stripe_sum(h, SC_COST); out->cost_after = stripe_sum(h, SC_COST_NEW); out->model = -stripe_sum(h, SC_MODEL);
-  out->dxnorm = std::sqrt(stripe_sum(h, SC_DXNORM)); out->xnorm = std::sqrt(stripe_sum(h, SC_XNORM));
-  long long gbits; std::memcpy(&gbits, &h[SC_GMAX], 8); std::memcpy(&out->gmax, &gbits, 8);
-  out->solved = hfail == 0 && std::isfinite(out->cost_after) && std::isfinite(out->model);
-  out->accepted = false;
-  p->last_radius = *radius;
-  if (out->solved && out->model > 0.0) {
-    const double rho = (out->cost_before - out->cost_after) / out->model;
-    if (rho > o->min_relative_decrease) {
-      out->accepted = true;
-      LVF_TRY(commit_candidate(p));
-      const double t = 2.0 * rho - 1.0;
-      *radius = std::fmin(*radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
-      *decrease = 2.0;
-      return LVF_OK;
+  out->cost_before = c.cost_before; out->cost_after = c.cost_after; out->model = c.model; out->dxnorm = c.dxnorm; out->xnorm = c.xnorm; out->gmax = c.gmax;
+  out->solved = c.solved != 0; out->accepted = c.accepted != 0;
+  p->last_radius = c.last_radius;
+  *radius = c.radius; *decrease = c.decrease;
+  return LVF_OK;
+}
+
+// waits until the host-visible mirror shows at least `iter` closed iterations (or the loop finished); falls back to a stream
+// synchronisation when the mirror does not move (e.g. device writes to host memory only becoming visible at kernel boundaries)
+static int wait_for_iteration(lvf_problem* p, int iter) {
+  const volatile LmCtl* r = p->rec;
+  const auto t0 = std::chrono::steady_clock::now();
+  while (r->iter < iter && !r->done) {
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) {
+      LmCtl c;
+      LVF_TRY(download_ctl(p, &c));          // synchronises the stream
+      *p->rec = c;
+      break;
     }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
   }
-  if (!out->accepted) out->cost_after = out->solved ? out->cost_after : out->cost_before;
-  *radius = *radius / *decrease;
-  *decrease *= 2.0;
   return LVF_OK;
 }
 
@@ -1929,7 +2250,7 @@ int problem_configure(lvf_problem* p) {
   LVF_TRY(p->B.ensure(nS)); LVF_TRY(p->S.ensure((size_t)p->ld * p->ld)); LVF_TRY(p->gc.ensure(p->dpad)); LVF_TRY(p->dxc.ensure(p->dpad));
   LVF_TRY(p->C.ensure(p->n_lm)); LVF_TRY(p->gr.ensure(p->n_lm)); LVF_TRY(p->Cd.ensure(p->n_lm)); LVF_TRY(p->dxl.ensure(p->n_lm));
   LVF_TRY(p->E.ensure((size_t)p->n_lm * p->ldE)); LVF_TRY(p->scal.ensure(SC_ALLOC));
-  // the candidate buffers are swapped with the state's on an accepted step: they must match the state's CAPACITY
+  // candidate state x + dx (an accepted candidate is copied into the state by k_lm_decide)
   LVF_TRY(p->poses2.ensure(std::max(st->poses.cap, (size_t)7 * p->n_kf))); LVF_TRY(p->vel2.ensure(std::max(st->vel.cap, (size_t)3 * p->n_kf)));
   LVF_TRY(p->ba2.ensure(std::max(st->ba.cap, (size_t)3 * p->n_kf))); LVF_TRY(p->bg2.ensure(std::max(st->bg.cap, (size_t)3 * p->n_kf)));
   LVF_TRY(p->invd2.ensure(std::max(st->inv_depth.cap, (size_t)p->n_lm)));
@@ -2001,12 +2322,121 @@ int problem_configure(lvf_problem* p) {
   LVF_HIP(hipMemsetAsync(p->dxc.p, 0, (size_t)p->dpad * 8, ctx->stream));
   // no stream wait here: every host source above is pinned and owned by the problem (or was waited for by the plan builder)
   p->linearized = false;
+  p->chain_ready = false;
   return LVF_OK;
 }
 
 }  // namespace lvf
 
 using namespace lvf;
+
+// ------------------------------------------------------------------------------------------------ a batch of windows
+// W independent windows advanced by ONE chain of launches per LM iteration: every kernel of the iteration takes blockIdx.y = window and
+// reads that window's argument block from a device table.  A single window's iteration is a chain of ~23 small launches that leaves
+// most of the 256 CUs idle (sequential pivots, 2 + k workgroups per panel step); a batch fills the same launches W times over — the
+// shape of every independent-window client of the reference: RL environments (src/lvio_fusion/src/environment.cpp:18-115), loop-closure
+// candidates (relocator.cpp:196-206), per-submap replays, and what ONE GPU of the 8-GPU sharding works on.
+struct lvf_problem_batch {
+  lvf_ctx* ctx = nullptr;
+  std::vector<lvf_problem*> probs;
+  bool tables = false;               // every member is batchable: table launches; otherwise the windows' own chains run back to back
+  int W = 0, max_levels = 0, max_nb = 0;
+  // per-stage argument tables [W] (device) and the launch shapes (max over the windows)
+  lvf::DevBuf<lvf::ImuArgs> imu_lin, imu_cost; int g_imu_lin = 0, g_imu_cost = 0;
+  lvf::DevBuf<lvf::LinArgs> lin; int g_lin = 0;
+  lvf::DevBuf<lvf::PrepArgs> prep; int g_prep = 0;
+  lvf::DevBuf<lvf::SchurSp0Args> ssp0; int g_ssp0 = 0; size_t lds_ssp0 = 0;
+  lvf::DevBuf<lvf::SpArgs> sp[lvf::kSpMaxLevels]; int g_sp[lvf::kSpMaxLevels] = {0}; int lds_sp[lvf::kSpMaxLevels] = {0};
+  lvf::DevBuf<lvf::CholArgs> chol;
+  lvf::DevBuf<lvf::BackArgs> back; size_t lds_back = 0;
+  lvf::DevBuf<lvf::TailArgs> tail; int g_tail = 0; size_t lds_tail = 0;
+  lvf::DevBuf<lvf::CostArgs> cost; int g_cost = 0;
+  lvf::DevBuf<lvf::DecideArgs> dec;
+  double huber_built = -1.0;
+};
+
+namespace lvf {
+
+template <typename T>
+static int upload_table(DevBuf<T>& dst, const std::vector<T>& src, hipStream_t q) {
+  LVF_TRY(dst.ensure(src.size()));
+  // pageable source: the runtime stages the copy before returning, so `src` may go out of scope
+  if (!src.empty()) LVF_HIP(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, q));
+  return LVF_OK;
+}
+
+static int batch_build_tables(lvf_problem_batch* b, double huber) {
+  hipStream_t q = b->ctx->stream;
+  const int W = b->W;
+  bool all = true;
+  for (lvf_problem* p : b->probs) {
+    if (chain_stale(p)) LVF_TRY(build_chain(p));
+    all = all && p->chain->batchable;
+  }
+  b->tables = all;
+  if (!all) return LVF_OK;
+  std::vector<ImuArgs> il(W), ic(W); std::vector<LinArgs> li(W); std::vector<PrepArgs> pr(W); std::vector<SchurSp0Args> ss(W);
+  std::vector<CholArgs> ch(W); std::vector<BackArgs> bk(W); std::vector<TailArgs> tl(W); std::vector<CostArgs> co(W); std::vector<DecideArgs> de(W);
+  b->max_levels = 0; b->max_nb = 0;
+  b->g_imu_lin = b->g_imu_cost = b->g_lin = b->g_prep = b->g_ssp0 = b->g_tail = b->g_cost = 0; b->lds_ssp0 = b->lds_back = b->lds_tail = 0;
+  for (int w = 0; w < W; ++w) {
+    const lvf_problem* p = b->probs[w];
+    const Chain& c = *p->chain;
+    il[w] = c.imu_lin; ic[w] = c.imu_cost; li[w] = c.lin; li[w].huber = huber; pr[w] = c.prep; ss[w] = c.ssp0; ch[w] = c.chol; bk[w] = c.back; tl[w] = c.tail;
+    co[w] = c.cost; co[w].huber = huber; de[w] = c.dec;
+    b->g_imu_lin = std::max(b->g_imu_lin, c.imu_lin.n + c.imu_lin.zero_wgs); b->g_imu_cost = std::max(b->g_imu_cost, c.imu_cost.n + c.imu_cost.zero_wgs);
+    b->g_lin = std::max(b->g_lin, c.lin.nblocks); b->g_prep = std::max(b->g_prep, c.prep.nblocks); b->g_ssp0 = std::max(b->g_ssp0, c.ssp0.nblocks);
+    b->lds_ssp0 = std::max(b->lds_ssp0, c.ssp0_lds); b->lds_back = std::max(b->lds_back, c.back_lds); b->g_tail = std::max(b->g_tail, c.tail.nblocks);
+    b->lds_tail = std::max(b->lds_tail, c.tail_lds); b->g_cost = std::max(b->g_cost, c.cost.nblocks);
+    b->max_levels = std::max(b->max_levels, c.n_levels); b->max_nb = std::max(b->max_nb, p->nb);
+  }
+  LVF_TRY(upload_table(b->imu_lin, il, q)); LVF_TRY(upload_table(b->imu_cost, ic, q)); LVF_TRY(upload_table(b->lin, li, q)); LVF_TRY(upload_table(b->prep, pr, q));
+  LVF_TRY(upload_table(b->ssp0, ss, q)); LVF_TRY(upload_table(b->chol, ch, q)); LVF_TRY(upload_table(b->back, bk, q)); LVF_TRY(upload_table(b->tail, tl, q));
+  LVF_TRY(upload_table(b->cost, co, q)); LVF_TRY(upload_table(b->dec, de, q));
+  for (int lv = 1; lv < b->max_levels; ++lv) {        // level 0 rides in the Schur launch
+    std::vector<SpArgs> sp(W);
+    b->g_sp[lv] = 0; b->lds_sp[lv] = 0;
+    for (int w = 0; w < W; ++w) {
+      const Chain& c = *b->probs[w]->chain;
+      if (lv < c.n_levels) { sp[w] = c.sp[lv]; b->g_sp[lv] = std::max(b->g_sp[lv], c.sp[lv].nblocks); b->lds_sp[lv] = std::max(b->lds_sp[lv], c.sp_lds[lv]); }
+      else { sp[w] = SpArgs{}; sp[w].nblocks = 0; }
+    }
+    LVF_TRY(upload_table(b->sp[lv], sp, q));
+  }
+  b->huber_built = huber;
+  return LVF_OK;
+}
+
+// one LM iteration of every window of the batch; nothing is waited for
+static int batch_enqueue_iteration(lvf_problem_batch* b) {
+  hipStream_t q = b->ctx->stream;
+  if (!b->tables) {
+    for (lvf_problem* p : b->probs) LVF_TRY(enqueue_iteration(p));
+    return LVF_OK;
+  }
+  const unsigned W = (unsigned)b->W;
+  LVF_TRY(launch_imu_table(q, b->imu_lin.p, b->W, b->g_imu_lin, true));
+  hipLaunchKernelGGL(k_lin_visual_b, dim3(b->g_lin, W), dim3(kT), 0, q, b->lin.p);
+  hipLaunchKernelGGL(k_prepare_b, dim3(b->g_prep, W), dim3(kT), 0, q, b->prep.p);
+  hipLaunchKernelGGL(k_schur_sp0_b, dim3(b->g_ssp0, W), dim3(256), b->lds_ssp0, q, b->ssp0.p);
+  for (int lv = 1; lv < b->max_levels; ++lv)
+    if (b->g_sp[lv] > 0) hipLaunchKernelGGL(k_sp_eliminate_b, dim3(b->g_sp[lv], W), dim3(256), b->lds_sp[lv], q, b->sp[lv].p);
+  for (int kb = 0; kb < b->max_nb; ++kb) {
+    const int below = b->max_nb - kb - 1;
+    hipLaunchKernelGGL(k_chol_factor_panel_b, dim3(2 + below, W), dim3(256), 0, q, b->chol.p, kb);
+    if (below > 0) hipLaunchKernelGGL(k_chol_update_b, dim3(below * (below + 1) / 2, W), dim3(256), 0, q, b->chol.p, kb);
+  }
+  hipLaunchKernelGGL(k_chol_backsolve_b, dim3(1, W), dim3(kBT), b->lds_back, q, b->back.p);
+  hipLaunchKernelGGL(k_step_tail_b, dim3(b->g_tail, W), dim3(kT), b->lds_tail, q, b->tail.p);
+  hipLaunchKernelGGL(k_cost_visual_b, dim3(b->g_cost, W), dim3(kT), 0, q, b->cost.p);
+  LVF_TRY(launch_imu_table(q, b->imu_cost.p, b->W, b->g_imu_cost, false));
+  hipLaunchKernelGGL(k_lm_decide_b, dim3(1, W), dim3(kDT), 0, q, b->dec.p);
+  LVF_HIP(hipGetLastError());
+  for (lvf_problem* p : b->probs) p->linearized = true;
+  return LVF_OK;
+}
+
+}  // namespace lvf
 
 extern "C" {
 
@@ -2050,6 +2480,7 @@ int lvf_problem_set_pose_priors(lvf_problem* p, lvf_batch* pose_priors) {
   }
   p->prior = pose_priors;
   p->linearized = false;
+  p->chain_ready = false;
   return LVF_OK;
 }
 
@@ -2075,6 +2506,20 @@ int lvf_problem_cost(lvf_problem* p, const lvf_solver_options* o, double* cost) 
   return LVF_OK;
 }
 
+// Problem::Evaluate's gradient: J^T r with the loss function's Corrector applied and pose blocks in tangent coordinates, at the current
+// state — exactly what the linearisation accumulates.  gc [15 n_kf] in the reduced-system order (6 x n_kf pose tangents | 9 x n_kf (v, ba, bg)),
+// gl [n_lm] (may be NULL) the inverse-depth entries.
+int lvf_problem_gradient(lvf_problem* p, const lvf_solver_options* o, double* gc, double* gl) {
+  LVF_REQUIRE(p && o && gc, "lvf_problem_gradient: null argument");
+  LVF_TRY(lvf::enter(p->ctx));
+  hipStream_t q = p->ctx->stream;
+  LVF_TRY(enqueue_linearize(p, o->huber_a, false));
+  LVF_HIP(hipMemcpyAsync(gc, p->gc.p, (size_t)p->d * 8, hipMemcpyDeviceToHost, q));
+  if (gl && p->n_lm) LVF_HIP(hipMemcpyAsync(gl, p->gr.p, (size_t)p->n_lm * 8, hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipStreamSynchronize(q));
+  return LVF_OK;
+}
+
 int lvf_problem_lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* radius, double* decrease_factor,
                              double* cost_before, double* cost_after, int* accepted) {
   LVF_REQUIRE(p && o && radius && decrease_factor, "lvf_problem_lm_iteration: null argument");
@@ -2088,47 +2533,39 @@ int lvf_problem_lm_iteration(lvf_problem* p, const lvf_solver_options* o, double
   return LVF_OK;
 }
 
+static void summary_from_ctl(const lvf_problem* p, const LmCtl& c, lvf_solver_summary* s) {
+  std::memset(s, 0, sizeof(*s));
+  s->num_residual_blocks = (p->tc ? p->tc->n : 0) + (p->tf ? p->tf->n : 0) + (p->po ? p->po->n : 0) + (p->imu ? p->imu->n : 0) + (p->prior ? p->prior->n : 0);
+  s->initial_cost = c.initial_cost; s->final_cost = c.cost; s->num_iterations = c.iter; s->num_successful_steps = c.successes; s->termination = c.termination;
+}
+
+// The device LM loop: iterations are enqueued back to back, each closed on device (k_lm_decide); the host only watches a mirror of the
+// control block to stop enqueueing once the loop has finished (an iteration enqueued after the end costs ~20 empty launches).
 int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary) {
   LVF_REQUIRE(p && o && summary, "lvf_problem_solve: null argument");
   LVF_TRY(lvf::enter(p->ctx));
-  double radius = o->initial_trust_region_radius, decrease = 2.0;
-  std::memset(summary, 0, sizeof(*summary));
-  summary->num_residual_blocks = (p->tc ? p->tc->n : 0) + (p->tf ? p->tf->n : 0) + (p->po ? p->po->n : 0) + (p->imu ? p->imu->n : 0) + (p->prior ? p->prior->n : 0);
-  summary->termination = 1;
+  LmCtl c;
+  ctl_from_options(o, o->initial_trust_region_radius, 2.0, o->max_num_iterations, true, &c);
+  p->huber = o->huber_a;
+  if (o->max_num_iterations <= 0) {          // nothing to iterate: report the cost at the start
+    double cost = 0.0;
+    LVF_TRY(lvf_problem_cost(p, o, &cost));
+    c.initial_cost = c.cost = cost;
+    summary_from_ctl(p, c, summary);
+    return LVF_OK;
+  }
+  LVF_TRY(upload_ctl(p, c));
   const auto wall0 = std::chrono::steady_clock::now();
-  double cost = 0.0;
   for (int it = 0; it < o->max_num_iterations; ++it) {
-    IterOut r;
-    LVF_TRY(lm_iteration(p, o, &radius, &decrease, &r));
-    if (it == 0) { summary->initial_cost = r.cost_before; cost = r.cost_before; }
-    summary->num_iterations = it + 1;
-    if (!r.solved && radius < 1e-32) { summary->termination = 2; break; }
-    if (r.accepted) {
-      summary->num_successful_steps++;
-      const double change = cost - r.cost_after;
-      cost = r.cost_after;
-      if (std::fabs(change) <= o->function_tolerance * std::fabs(r.cost_before)) { summary->termination = 0; break; }
-    }
-    if (it == 0 && r.gmax <= o->gradient_tolerance) { summary->termination = 0; break; }
-    if (r.solved && r.dxnorm <= o->parameter_tolerance * (r.xnorm + o->parameter_tolerance)) { summary->termination = 0; break; }
+    LVF_TRY(enqueue_iteration(p));
+    if (it >= 1) LVF_TRY(wait_for_iteration(p, it));          // iteration it-1 is closed; iteration `it` keeps the device busy meanwhile
+    if (p->rec->done) break;
     if (o->max_solver_time_in_seconds > 0.0 &&
         std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) break;
   }
-  summary->final_cost = cost;
-  return LVF_OK;
-}
-
-// Problem::Evaluate's gradient: J^T r with the loss function's Corrector applied and pose blocks in tangent coordinates, at the current
-// state — exactly what the linearisation accumulates.  gc [15 n_kf] in the reduced-system order (6 x n_kf pose tangents | 9 x n_kf (v, ba, bg)),
-// gl [n_lm] (may be NULL) the inverse-depth entries.
-int lvf_problem_gradient(lvf_problem* p, const lvf_solver_options* o, double* gc, double* gl) {
-  LVF_REQUIRE(p && o && gc, "lvf_problem_gradient: null argument");
-  LVF_TRY(lvf::enter(p->ctx));
-  hipStream_t q = p->ctx->stream;
-  LVF_TRY(enqueue_linearize(p, o->huber_a));
-  LVF_HIP(hipMemcpyAsync(gc, p->gc.p, (size_t)p->d * 8, hipMemcpyDeviceToHost, q));
-  if (gl && p->n_lm) LVF_HIP(hipMemcpyAsync(gl, p->gr.p, (size_t)p->n_lm * 8, hipMemcpyDeviceToHost, q));
-  LVF_HIP(hipStreamSynchronize(q));
+  LVF_TRY(download_ctl(p, &c));
+  p->last_radius = c.last_radius;
+  summary_from_ctl(p, c, summary);
   return LVF_OK;
 }
 
@@ -2137,12 +2574,11 @@ int lvf_problem_reduced_dim(lvf_problem* p) { return p ? p->d : -1; }
 // the DAMPED reduced system of the last lm_iteration, rebuilt (the factorisation overwrote S): S [d x d] symmetric, rhs [d]
 int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs) {
   LVF_REQUIRE(p && S && rhs, "lvf_problem_download_reduced: null argument");
-  if (!p->linearized) { set_error("no linearisation yet"); return LVF_ERR_STATE; }
+  if (!p->linearized || !p->chain_ready) { set_error("no linearisation yet"); return LVF_ERR_STATE; }
   LVF_TRY(lvf::enter(p->ctx));
   hipStream_t q = p->ctx->stream;
-  const double inv_r = 1.0 / p->last_radius;
   const size_t nS = (size_t)p->ld * p->ld;
-  LVF_TRY(enqueue_reduced_system(p, inv_r, nullptr));
+  LVF_TRY(enqueue_reduced_system(p, &p->ctl.p->last_radius, false, false, nullptr));
   std::vector<double> h(nS);
   LVF_HIP(hipMemcpyAsync(h.data(), p->S.p, nS * 8, hipMemcpyDeviceToHost, q));
   LVF_HIP(hipStreamSynchronize(q));
@@ -2154,6 +2590,87 @@ int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs) {
       S[(size_t)i * d + j] = v; S[(size_t)j * d + i] = v;
     }
   for (int j = 0; j < d; ++j) rhs[j] = h[(size_t)p->aug * ld + pm[j]];
+  return LVF_OK;
+}
+
+// ---- batch of windows
+int lvf_problem_batch_create(lvf_ctx* ctx, lvf_problem* const* problems, int n, lvf_problem_batch** out) {
+  LVF_REQUIRE(ctx && out && n >= 1 && problems, "lvf_problem_batch_create: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    LVF_REQUIRE(problems[i], "lvf_problem_batch_create: problem %d is null", i);
+    LVF_REQUIRE(problems[i]->ctx == ctx, "lvf_problem_batch_create: problem %d belongs to another context", i);
+    for (int j = 0; j < i; ++j) LVF_REQUIRE(problems[j] != problems[i] && problems[j]->st != problems[i]->st, "lvf_problem_batch_create: windows %d and %d share state", j, i);
+  }
+  auto* b = new lvf_problem_batch();
+  b->ctx = ctx; b->W = n; b->probs.assign(problems, problems + n);
+  *out = b;
+  return LVF_OK;
+}
+int lvf_problem_batch_destroy(lvf_problem_batch* b) { delete b; return LVF_OK; }
+int lvf_problem_batch_size(const lvf_problem_batch* b) { return b ? b->W : -1; }
+int lvf_problem_batch_uses_tables(lvf_problem_batch* b, const lvf_solver_options* o) {
+  if (!b || !o || lvf::enter(b->ctx) != LVF_OK || batch_build_tables(b, o->huber_a) != LVF_OK) return -1;
+  return b->tables ? 1 : 0;
+}
+
+// one LM iteration of every window (no tolerance tests); all arrays have one entry per window
+int lvf_problem_batch_lm_iteration(lvf_problem_batch* b, const lvf_solver_options* o, double* radius, double* decrease_factor, double* cost_before,
+                                   double* cost_after, int* accepted) {
+  LVF_REQUIRE(b && o && radius && decrease_factor, "lvf_problem_batch_lm_iteration: null argument");
+  LVF_TRY(lvf::enter(b->ctx));
+  LVF_TRY(batch_build_tables(b, o->huber_a));
+  for (int w = 0; w < b->W; ++w) {
+    LVF_REQUIRE(radius[w] > 0.0 && decrease_factor[w] > 0.0, "radius and decrease_factor must be positive");
+    LmCtl c;
+    ctl_from_options(o, radius[w], decrease_factor[w], 1, false, &c);
+    b->probs[w]->huber = o->huber_a;
+    LVF_TRY(upload_ctl(b->probs[w], c));
+  }
+  LVF_TRY(batch_enqueue_iteration(b));
+  for (int w = 0; w < b->W; ++w) {
+    LmCtl c;
+    LVF_TRY(download_ctl(b->probs[w], &c));
+    b->probs[w]->last_radius = c.last_radius;
+    radius[w] = c.radius; decrease_factor[w] = c.decrease;
+    if (cost_before) cost_before[w] = c.cost_before;
+    if (cost_after) cost_after[w] = c.cost_after;
+    if (accepted) accepted[w] = c.accepted;
+  }
+  return LVF_OK;
+}
+
+int lvf_problem_batch_solve(lvf_problem_batch* b, const lvf_solver_options* o, lvf_solver_summary* summaries) {
+  LVF_REQUIRE(b && o && summaries, "lvf_problem_batch_solve: null argument");
+  LVF_TRY(lvf::enter(b->ctx));
+  LVF_TRY(batch_build_tables(b, o->huber_a));
+  if (o->max_num_iterations <= 0) {
+    for (int w = 0; w < b->W; ++w) LVF_TRY(lvf_problem_solve(b->probs[w], o, &summaries[w]));
+    return LVF_OK;
+  }
+  for (int w = 0; w < b->W; ++w) {
+    LmCtl c;
+    ctl_from_options(o, o->initial_trust_region_radius, 2.0, o->max_num_iterations, true, &c);
+    b->probs[w]->huber = o->huber_a;
+    LVF_TRY(upload_ctl(b->probs[w], c));
+  }
+  const auto wall0 = std::chrono::steady_clock::now();
+  for (int it = 0; it < o->max_num_iterations; ++it) {
+    LVF_TRY(batch_enqueue_iteration(b));
+    bool all_done = true;
+    for (int w = 0; w < b->W; ++w) {
+      if (it >= 1) LVF_TRY(wait_for_iteration(b->probs[w], it));
+      all_done = all_done && b->probs[w]->rec->done;
+    }
+    if (all_done) break;
+    if (o->max_solver_time_in_seconds > 0.0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) break;
+  }
+  for (int w = 0; w < b->W; ++w) {
+    LmCtl c;
+    LVF_TRY(download_ctl(b->probs[w], &c));
+    b->probs[w]->last_radius = c.last_radius;
+    summary_from_ctl(b->probs[w], c, &summaries[w]);
+  }
   return LVF_OK;
 }
 
