@@ -43,7 +43,12 @@ struct lvf_problem {
   lvf::DevBuf<int> sp_rows, sp_owner, perm, iperm;
   lvf::DevBuf<int> lm_kmin, lm_kmax, lm_order, lm_nactive;   // per-landmark keyframe track [kmin, kmax]; Schur row order; #rows with pose blocks
   bool band_ready = false;
-  lvf::DevBuf<unsigned long long> dbg;
+  // compact landmark layout + slabs of the atomic-free TwoFrame linearisation (see TfCompact)
+  bool compact = false;
+  lvf::DevBuf<int> lm_eoff, n_slots, tf_slot, run_first;
+  lvf::DevBuf<double> slotB, slabP, slabQ, Ct, grt;
+  lvf::HostPin<int> h_run_first;
+  lvf::DevBuf<unsigned long long> dbg, dbg_lin;
   lvf::DevBuf<double> sp_W, sp_L, Dinv;         // Dinv: L_kk^-T of every 64x64 diagonal block of the dense corner
   std::vector<int> perm_h;
   lvf::DevBuf<double> B, gc, C, gr, E, Cd, S, dxc, dxl, scal;
@@ -55,6 +60,7 @@ struct lvf_problem {
   std::vector<uint8_t> pose_const_h;
   bool linearized = false;
   bool tf_unique_lk2 = false;   // no (landmark, current keyframe) pair occurs twice in the TwoFrame batch
+  bool tf_k1_first = false;     // every TwoFrame block's first keyframe precedes its current keyframe
   double last_radius = 0;
   // the device-resident LM loop
   lvf::DevBuf<lvf::LmCtl> ctl;        // control block (radius, costs, accept / reject, termination) in HBM
@@ -215,20 +221,38 @@ __global__ __launch_bounds__(kT) void k_lin_tf(int n, int n_kf, const double2* _
 //     [n_kf][63] LDS table and flushed once per workgroup (non-zero entries only),
 //   * only the landmark-indexed sums (C, g_rho, E rows) remain global atomics: 14 per block instead of 134.
 struct TfWork { int first, count, k2; };
+// Atomic-free outputs of the sorted TwoFrame linearisation ("compact" mode).  Measured on MI355X: the 8 landmark-indexed global f64
+// atomics per block were 18 of the 21 us a workgroup spent between loading its blocks and its reductions, and together with the
+// per-workgroup flush of the keyframe-indexed sums (~1 M atomics per linearisation at configs[3]) they are a chip-wide L2 bottleneck
+// (~30 atomics / ns) that a batch of windows hits W times over.  Instead:
+//   * the k2 columns of a landmark's (dense) E row have exactly one writer: plain stores.  The row is NOT cleared per linearisation: its
+//     non-zero pattern (the landmark's track) is fixed for a problem, so E is zeroed once per problem_configure and every entry inside
+//     the pattern is overwritten by every linearisation;
+//   * every block owns a SLOT s = eoff[l] + (k2 - k1 - 1) of its landmark's track and writes there, with plain 16-byte stores, one
+//     64-byte record: its contributions to the k1 columns of E (6), to C and to g_rho.  k_prepare reads a landmark's slots as one
+//     contiguous range, sums them and completes the row (k1 columns, g_rho column) and Cd;
+//   * every workgroup writes its LDS table of keyframe-indexed sums to its own slab (slabP[wg][k1][64], slabQ[wg][32]); k_tf_reduce adds
+//     the slabs of a run into B / gc, each entry of B having exactly one owner there.
+struct TfCompact { int on; const int* slot; double *slotB, *slabP, *slabQ; };
+constexpr int kSlabRow = 64, kSlabQ = 32;
 constexpr int kAccSlots = 63;   // 21 (B[k1,k1] lower) + 6 (g[k1]) + 36 (cross block, rows = k2 tangent, cols = k1 tangent)
 __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* __restrict__ work, int n_kf, const double2* __restrict__ fo,
                                                       const double2* __restrict__ ob, const int* __restrict__ lm,
                                                       const int* __restrict__ kf1, StateP s, CamD left, CamD right, double huber,
                                                       const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
                                                       double* __restrict__ gc, double* __restrict__ E, int ldE,
-                                                      double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost, int unique_lk2) {
+                                                      double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost, int unique_lk2,
+                                                      unsigned long long* dbg = nullptr, const TfCompact cp = TfCompact{0, nullptr, nullptr, nullptr, nullptr}) {
   __shared__ PoseD s_pose[kMaxStagedKf];
   __shared__ double s_acc[kMaxStagedKf * kAccSlots];
   __shared__ double s_k2[27];
   const TfWork w = work[vb];
+  auto mark = [&](int k) { if (dbg && threadIdx.x == 0) dbg[(size_t)vb * 8 + k] = wall_clock64(); };   // LVF_LIN_TIMING=1: phase stamps (100 MHz)
+  mark(0);
   for (int e = threadIdx.x; e < n_kf * kAccSlots; e += kT) s_acc[e] = 0.0;
   if (threadIdx.x < 27) s_k2[threadIdx.x] = 0.0;
   stage_poses<kT>(s_pose, s.poses, n_kf);   // ends with __syncthreads()
+  mark(1);
   const int k2 = w.k2;
   double c = 0.0;
   double v[27];
@@ -253,19 +277,31 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
     pose_rows_to_local(J2, s.poses + 7 * k2, pose_const[k2] ? 0.0 : sc, L2);
     r0 = sc * r[0]; r1 = sc * r[1];
     const double d0 = sc * Jd[0], d1 = sc * Jd[1];
-    atomicAdd(&C[l], d0 * d0 + d1 * d1);
-    atomicAdd(&gr[l], d0 * r0 + d1 * r1);
-    double* el = E + (size_t)l * ldE;
-    // E[l][k2 columns] has exactly ONE writer when no landmark is observed twice by a keyframe (checked on the host when the batch
-    // is created; always true for what BuildProblem builds): plain stores.  The landmark-indexed global atomics were half of this
-    // kernel's run time (ablation: 75 -> 37 us without them).
+    if (cp.on) {
+      // atomic-free mode: the k2 columns of the landmark's E row have ONE writer (plain stores); the contributions to C, g_rho and to the
+      // k1 columns go to this block's slot of the landmark's track as one 64-byte record (summed per landmark by k_prepare)
+      double* el = E + (size_t)l * ldE + 6 * k2;
+      double2* rec = reinterpret_cast<double2*>(cp.slotB + (size_t)cp.slot[i] * 8);
+      double e1[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      atomicAdd(&el[6 * k1 + q], L1[q] * d0 + L1[6 + q] * d1);
-      const double e2 = L2[q] * d0 + L2[6 + q] * d1;
-      if (unique_lk2) el[6 * k2 + q] = e2; else atomicAdd(&el[6 * k2 + q], e2);
+      for (int q = 0; q < 6; ++q) { e1[q] = L1[q] * d0 + L1[6 + q] * d1; el[q] = L2[q] * d0 + L2[6 + q] * d1; }
+      rec[0] = make_double2(e1[0], e1[1]); rec[1] = make_double2(e1[2], e1[3]); rec[2] = make_double2(e1[4], e1[5]);
+      rec[3] = make_double2(d0 * d0 + d1 * d1, d0 * r0 + d1 * r1);
+    } else {
+      atomicAdd(&C[l], d0 * d0 + d1 * d1);
+      atomicAdd(&gr[l], d0 * r0 + d1 * r1);
+      double* el = E + (size_t)l * ldE;
+      // E[l][k2 columns] has exactly ONE writer when no landmark is observed twice by a keyframe (checked on the host when the batch
+      // is created; always true for what BuildProblem builds): plain stores.
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        atomicAdd(&el[6 * k1 + q], L1[q] * d0 + L1[6 + q] * d1);
+        const double e2 = L2[q] * d0 + L2[6 + q] * d1;
+        if (unique_lk2) el[6 * k2 + q] = e2; else atomicAdd(&el[6 * k2 + q], e2);
+      }
     }
   }
+  mark(2);
   // k1-indexed sums (B[k1,k1], g[k1], cross block).  A live front-end hands out landmark ids in creation order, so the blocks of a
   // wave usually share their first keyframe: then the 63 sums are wave reductions and one lane adds them (per-lane ds_add_f64 on ONE
   // address serialises 64-fold: +10 us on this kernel with ids in birth order); mixed waves keep the per-lane LDS atomics.
@@ -299,6 +335,7 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
         if (same_k1) { t = wave_sum(t); if (lane0 && t != 0.0) atomicAdd(&acc[27 + 6 * x + y], t); } else if (active) atomicAdd(&acc[27 + 6 * x + y], t);
       }
   }
+  mark(3);
 #pragma unroll
   for (int q = 0; q < 27; ++q) v[q] = wave_sum(v[q]);
   if ((threadIdx.x & 63) == 0) {
@@ -307,6 +344,16 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
   }
   block_add(c, cost);
   __syncthreads();
+  mark(4);
+  if (cp.on) {
+    // the workgroup's sums leave as plain, fully coalesced stores into its own slab (rows k1 < k2 only; k_tf_reduce reads exactly those)
+    if (threadIdx.x < kSlabQ) cp.slabQ[(size_t)vb * kSlabQ + threadIdx.x] = threadIdx.x < 27 ? s_k2[threadIdx.x] : 0.0;
+    double* P = cp.slabP + (size_t)vb * n_kf * kSlabRow;
+    for (int e = threadIdx.x; e < k2 * kSlabRow; e += kT) {
+      const int kk = e >> 6, slot = e & 63;
+      P[e] = slot < kAccSlots ? s_acc[kk * kAccSlots + slot] : 0.0;
+    }
+  } else {
   if (threadIdx.x < 27) {
     const double val = s_k2[threadIdx.x];
     if (val != 0.0) {
@@ -333,6 +380,9 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
       else atomicAdd(&B[(size_t)(6 * k1 + y) * ld + 6 * k2 + x], val);
     }
   }
+  }
+  __syncthreads();
+  mark(5);
 }
 __global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__ work, int n_kf, const double2* __restrict__ fo,
                                                       const double2* __restrict__ ob, const int* __restrict__ lm,
@@ -625,7 +675,7 @@ __device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, con
 struct LinVisual {
   int n_tfw, g_tc;
   // TwoFrame
-  const TfWork* work; const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1; CamD tf_left, tf_right; int unique_lk2;
+  const TfWork* work; const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1; CamD tf_left, tf_right; int unique_lk2; TfCompact cp;
   // TwoCamera
   int n_tc; const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; const double* tc_w; CamD tc_left, tc_right;
   // PoseOnly
@@ -635,7 +685,7 @@ struct LinVisual {
 };
 struct LinArgs {
   LinVisual v; int n_kf; StateP s; double huber; const uint8_t* pose_const; double* B; int ld; double* gc; double* E; int ldE; double *C, *gr, *cost;
-  int nblocks; const int* done;
+  int nblocks; const int* done; unsigned long long* dbg;
 };
 __device__ __forceinline__ void lin_visual_body(const int b, const LinArgs& A) {
   if (b >= A.nblocks || (A.done && *A.done)) return;
@@ -644,7 +694,7 @@ __device__ __forceinline__ void lin_visual_body(const int b, const LinArgs& A) {
   double* B = A.B; const int ld = A.ld; double* gc = A.gc; double* E = A.E; const int ldE = A.ldE; double* C = A.C; double* gr = A.gr; double* cost = A.cost;
   if (b < a.n_tfw)
     lin_tf_sorted_body(b, a.work, n_kf, a.tf_fo, a.tf_ob, a.tf_lm, a.tf_k1, s, a.tf_left, a.tf_right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost,
-                       a.unique_lk2);
+                       a.unique_lk2, A.dbg, a.cp);
   else if (b < a.n_tfw + a.g_tc)
     lin_tc_body<false>(b - a.n_tfw, a.n_tc, a.tc_lo, a.tc_ro, a.tc_lm, a.tc_kf, a.tc_w, s, a.tc_left, a.tc_right, huber, C, gr, cost);
   else if (b < a.n_tfw + a.g_tc + a.g_po)
@@ -654,6 +704,67 @@ __device__ __forceinline__ void lin_visual_body(const int b, const LinArgs& A) {
 }
 __global__ __launch_bounds__(kT) void k_lin_visual(LinArgs a) { lin_visual_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_lin_visual_b(const LinArgs* __restrict__ t) { lin_visual_body(blockIdx.x, t[blockIdx.y]); }
+
+// Adds the TwoFrame slabs of a linearisation into B / gc (compact mode).  Workgroups are sorted by current keyframe: run(k) =
+// workgroups [run_first[k], run_first[k+1]).  Every entry of B has ONE owner thread here (plain read-modify-write; the other factor
+// types' atomic contributions were complete when the linearisation launch ended):
+//   workgroups [0, n_kf)         keyframe k: B[k,k] (21) and g[k] (6) = sum of slabQ over run(k) (k as current keyframe)
+//                                                                      + sum of slabP[.][k][0..27) over every later workgroup (k as first keyframe)
+//   the rest                     one thread per (k2, k1 < k2, entry of the 6x6 cross block) = sum of slabP[.][k1][27..63) over run(k2)
+struct TfReduceArgs { int n_kf, n_wg; const int* run_first; const double *slabP, *slabQ; double* B; int ld; double* gc; int nblocks; const int* done; };
+__device__ __forceinline__ void tf_reduce_body(const int bx, const TfReduceArgs& A) {
+  if (bx >= A.nblocks || (A.done && *A.done)) return;
+  const int n_kf = A.n_kf;
+  const int nchunk = (A.n_wg + 63) / 64;
+  if (bx < n_kf * nchunk) {
+    // keyframe k, chunk c of 64 workgroups: 8 groups of 32 lanes (lane v < 27 owns one value), 8 slab rows per thread, all requested at
+    // once; the chunk's 27 sums go to B / gc with one atomic each (n_kf x nchunk x 27 per linearisation)
+    __shared__ double part[8][32];
+    const int k = bx / nchunk, c = bx - k * nchunk, v = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int r0 = A.run_first[k], r1 = A.run_first[k + 1];
+    double acc = 0.0;
+    if (v < 27) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int wg = 64 * c + g + 8 * u;
+        if (wg >= A.n_wg) break;
+        if (wg >= r1) acc += A.slabP[((size_t)wg * n_kf + k) * kSlabRow + v];       // k as the blocks' first keyframe (later workgroups)
+        else if (wg >= r0) acc += A.slabQ[(size_t)wg * kSlabQ + v];                   // k as the blocks' current keyframe
+      }
+    }
+    part[g][v] = acc;
+    __syncthreads();
+    if (threadIdx.x < 27) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += part[q][threadIdx.x];
+      if (t != 0.0) {
+        if (threadIdx.x < 21) {
+          int x = 0, rem = threadIdx.x;
+          while (rem > x) { rem -= x + 1; ++x; }
+          atomicAdd(&A.B[(size_t)(6 * k + x) * A.ld + 6 * k + rem], t);
+        } else atomicAdd(&A.gc[6 * k + threadIdx.x - 21], t);
+      }
+    }
+    return;
+  }
+  const int e = (bx - n_kf * nchunk) * kT + threadIdx.x;
+  const int npair = n_kf * (n_kf - 1) / 2;
+  if (e >= npair * 36) return;
+  const int pr = e / 36, el = e - 36 * pr;
+  int k2 = (int)((1.0 + sqrt(1.0 + 8.0 * pr)) * 0.5);                 // pr = k2 (k2 - 1) / 2 + k1, k1 < k2
+  while (k2 * (k2 - 1) / 2 > pr) --k2;
+  while ((k2 + 1) * k2 / 2 <= pr) ++k2;
+  const int k1 = pr - k2 * (k2 - 1) / 2;
+  double acc = 0.0;
+  for (int wg = A.run_first[k2]; wg < A.run_first[k2 + 1]; ++wg) acc += A.slabP[((size_t)wg * n_kf + k1) * kSlabRow + 27 + el];
+  if (acc != 0.0) {
+    const int x = el / 6, y = el - 6 * x;                              // x: k2 tangent index, y: k1 tangent index
+    A.B[(size_t)(6 * k2 + x) * A.ld + 6 * k1 + y] += acc;
+  }
+}
+__global__ __launch_bounds__(kT) void k_tf_reduce(TfReduceArgs a) { tf_reduce_body(blockIdx.x, a); }
+__global__ __launch_bounds__(kT) void k_tf_reduce_b(const TfReduceArgs* __restrict__ t) { tf_reduce_body(blockIdx.x, t[blockIdx.y]); }
 
 
 // ------------------------------------------------------------------------------------------------ pose priors
@@ -733,6 +844,8 @@ __device__ __forceinline__ double clamp_diag(double v) { return fmin(fmax(v, 1e-
 struct PrepArgs {
   int ld, dpad; const int* iperm; const double *B, *gc; const double* radius; double* S; unsigned nS_blocks; int n_lm, dp, ldE; const double *C, *gr;
   double *Cd, *E, *scal; int nblocks; const int* done;
+  // atomic-free mode (slotB != nullptr): per-landmark totals from the slot records
+  const int *eoff, *kmin, *kmax; const double* slotB; double *Ct, *grt;
 };
 __device__ __forceinline__ void prepare_body(const unsigned bx, const PrepArgs& A) {
   if (bx >= (unsigned)A.nblocks || (A.done && *A.done)) return;
@@ -745,6 +858,36 @@ __device__ __forceinline__ void prepare_body(const unsigned bx, const PrepArgs& 
     if (threadIdx.x == 0) *reinterpret_cast<int*>(scal + SC_FAIL) = 0;
   }
   if (bx >= nS_blocks) {
+    if (A.slotB) {
+      // atomic-free mode: C, g_rho of the landmark = its TwoCamera part (C, gr: atomics of the linearisation) + its slot records; the k1
+      // columns of its E row = the sum of the records' first-keyframe parts.  8 lanes per landmark (lane j takes slots j, j + 8, ...: the
+      // loads of a track are issued together instead of one dependent loop), DPP sum over the 8 lanes.  The totals go to separate arrays
+      // so the pass can be repeated (lvf_problem_download_reduced).
+      const int l = ((bx - nS_blocks) * kT + threadIdx.x) >> 3, j0 = threadIdx.x & 7;
+      const bool live = l < n_lm;
+      const int lc = live ? l : 0;
+      const int k1 = A.kmin[lc], len = live ? max(0, A.kmax[lc] - k1) : 0;
+      const double2* sb = reinterpret_cast<const double2*>(A.slotB + (size_t)A.eoff[lc] * 8);
+      double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int j = j0; j < len; j += 8) {
+        const double2 b0 = sb[4 * j], b1 = sb[4 * j + 1], b2 = sb[4 * j + 2], cg = sb[4 * j + 3];
+        v[0] += cg.x; v[1] += cg.y; v[2] += b0.x; v[3] += b0.y; v[4] += b1.x; v[5] += b1.y; v[6] += b2.x; v[7] += b2.y;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { v[q] = quad_sum(v[q]); v[q] += quad_perm<0x141>(v[q]); }      // sum over the aligned group of 8 lanes
+      if (live && j0 == 0) {
+        const double c = C[l] + v[0], g = gr[l] + v[1];
+        A.Ct[l] = c; A.grt[l] = g;
+        Cd[l] = c + clamp_diag(c) * inv_radius;
+        double* el = E + (size_t)l * ldE;
+        el[dp] = g;
+        if (len > 0) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) el[6 * k1 + q] = v[2 + q];
+        }
+      }
+      return;
+    }
     const int l = (bx - nS_blocks) * kT + threadIdx.x;
     if (l >= n_lm) return;
     const double c = C[l];
@@ -941,11 +1084,52 @@ __global__ __launch_bounds__(1024) void k_lm_sort(int n_lm, int n_kf, const int*
   for (int l = threadIdx.x; l < n_lm; l += 1024) order[atomicAdd(&bucket[lm_sort_key(kmin[l], kmax[l], n_kf)], 1)] = l;
 }
 
+// ---- compact landmark layout, built once per problem_configure
+// eoff[l] = first slot of landmark l, len_l = kmax_l - kmin_l slots (one per keyframe after the first); *n_slots = their total
+__global__ __launch_bounds__(1024) void k_lm_offsets(int n_lm, const int* __restrict__ kmin, const int* __restrict__ kmax, int* __restrict__ eoff,
+                                                     int* __restrict__ n_slots) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_lm; base += 1024) {
+    const int l = base + tid;
+    const int c = (l < n_lm && kmax[l] >= 0) ? max(0, kmax[l] - kmin[l]) : 0;
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (l < n_lm) eoff[l] = off + incl - c;
+    __syncthreads();
+    if (tid == 1023) carry = off + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *n_slots = carry;
+}
+__global__ __launch_bounds__(kT) void k_tf_slots(int n, const int* __restrict__ lm, const int* __restrict__ k2, const int* __restrict__ kmin,
+                                                 const int* __restrict__ eoff, int* __restrict__ slot) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const int l = lm[i];
+  slot[i] = eoff[l] + (k2[i] - kmin[l] - 1);
+}
+// slots of keyframes that do not observe their landmark (gaps in a track) are never written by the linearisation: cleared once here
+__global__ __launch_bounds__(kT) void k_zero_slots(const int* __restrict__ n_slots, double* __restrict__ slotB) {
+  const size_t n = (size_t)*n_slots * 4;     // double2 elements
+  double2* b = reinterpret_cast<double2*>(slotB);
+  for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) b[i] = make_double2(0.0, 0.0);
+}
+
 __device__ __forceinline__ void schur_band_body(const int bx, const int by, int dp, int ldE, const double* __restrict__ E,
                                                 const double* __restrict__ Cd, const int* __restrict__ order, const int* __restrict__ n_active_p,
                                                 const int* __restrict__ kmin, const int* __restrict__ kmax, int d, int ldS,
-                                                double* __restrict__ S) {
+                                                double* __restrict__ S, unsigned long long* dbg = nullptr) {
   extern __shared__ double sh[];          // Es[kSchurRows][ldl] | icd[kSchurRows] | rowid (int)[kBandRows]
+  auto mark = [&](int k) { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); };   // LVF_SCHUR_TIMING=1: phase stamps of this workgroup
+  mark(0);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lk = lane >> 4, lc = lane & 15;
   const int n_active = *n_active_p;
   const int k_begin = bx * kBandRows, k_end = min(n_active, k_begin + kBandRows);
@@ -1007,6 +1191,7 @@ __device__ __forceinline__ void schur_band_body(const int bx, const int by, int 
     for (int u = kPf; u < nst; ++u) Es[fr * ldl + 16 * u + fc] = (l >= 0) ? E[(size_t)l * ldE + 16 * (u < nbt ? t0 + u : tl) + fc] : 0.0;
   };
   fetch(k_begin);
+  mark(1);
   for (int k0 = k_begin; k0 < k_end; k0 += kSchurRows) {
     __syncthreads();
 #pragma unroll
@@ -1024,6 +1209,7 @@ __device__ __forceinline__ void schur_band_body(const int bx, const int by, int 
         if (s_ < nt) acc[s_] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[16 * ta[s_] + lc] * wgt, row[16 * tb[s_] + lc], acc[s_], 0, 0, 0);
     }
   }
+  mark(2);
 #pragma unroll
   for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_) {
     if (s_ >= nt) continue;
@@ -1037,6 +1223,7 @@ __device__ __forceinline__ void schur_band_body(const int bx, const int by, int 
       else if (gi == dp && gj < dp) atomicAdd(&S[(size_t)d * ldS + gj], v);
     }
   }
+  mark(3);
 }
 
 __global__ __launch_bounds__(256) void k_schur_band(int dp, int ldE, const double* __restrict__ E, const double* __restrict__ Cd,
@@ -1340,17 +1527,16 @@ __global__ __launch_bounds__(256) void k_sp_eliminate_b(const SpArgs* __restrict
 struct SchurSp0Args {
   int n_slices, n_groups, dp, ldE; const double *E, *Cd; const int *order, *n_active, *kmin, *kmax; int d_local, ldS; double* S_pose;
   SpArgs sp;             // level 0 (sp.nblocks == 0: Schur complement only)
-  int nblocks; const int* done;
+  int nblocks; const int* done; unsigned long long* dbg;
 };
 __device__ __forceinline__ void schur_sp0_body(const int b, const SchurSp0Args& A) {
   if (b >= A.nblocks || (A.done && *A.done)) return;
   const int ns = A.n_slices * A.n_groups;
-  if (b < ns) schur_band_body(b % A.n_slices, b / A.n_slices, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose);
+  if (b < ns) schur_band_body(b % A.n_slices, b / A.n_slices, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)b * 8 : nullptr);
   else sp_eliminate_body(b - ns, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail);
 }
 __global__ __launch_bounds__(256) void k_schur_sp0(SchurSp0Args a) { schur_sp0_body(blockIdx.x, a); }
 __global__ __launch_bounds__(256) void k_schur_sp0_b(const SchurSp0Args* __restrict__ t) { schur_sp0_body(blockIdx.x, t[blockIdx.y]); }
-
 struct SpBack {                    // what the back substitution needs of the plan
   SpLevels lv;
   int item0[kSpMaxLevels], items[kSpMaxLevels];   // the level's slice of rows/owner/W
@@ -1645,20 +1831,28 @@ struct DecideArgs {
   double *poses, *vel, *ba, *bg, *invd;                 // the state
   const double *poses2, *vel2, *ba2, *bg2, *invd2;      // the candidate
 };
-constexpr int kDT = 1024;
+constexpr int kDT = 256;
 __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
   __shared__ int s_commit, s_skip;
+  __shared__ double s_sum[8];
   LmCtl* c = A.ctl;
   if (threadIdx.x == 0) s_skip = c->done;
+  // the six striped sums: wave w adds the 32 stripes of slots w, w + 4 (lanes 32..63 contribute zero)
+  {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int slot = wv; slot < 6; slot += kDT / 64) {
+      double v = lane < kStripes ? A.scal[slot * kStripes + lane] : 0.0;
+      v = wave_sum(v);
+      if (lane == 0) s_sum[slot] = v;
+    }
+  }
   __syncthreads();
   if (s_skip) return;
   if (threadIdx.x == 0) {
-    const double* h = A.scal;
-    auto ssum = [&](int slot) { double v = 0.0; for (int k = 0; k < kStripes; ++k) v += h[slot + k]; return v; };
-    const int hfail = *reinterpret_cast<const int*>(h + SC_FAIL);
-    const double cost_before = ssum(SC_COST), cost_new = ssum(SC_COST_NEW), model = -ssum(SC_MODEL);
-    const double dxnorm = sqrt(ssum(SC_DXNORM)), xnorm = sqrt(ssum(SC_XNORM));
-    const double gmax = __longlong_as_double(*reinterpret_cast<const long long*>(h + SC_GMAX));
+    const int hfail = *reinterpret_cast<const int*>(A.scal + SC_FAIL);
+    const double cost_before = s_sum[SC_COST / kStripes], cost_new = s_sum[SC_COST_NEW / kStripes], model = -s_sum[SC_MODEL / kStripes];
+    const double dxnorm = sqrt(s_sum[SC_DXNORM / kStripes]), xnorm = sqrt(s_sum[SC_XNORM / kStripes]);
+    const double gmax = A.scal[SC_GMAX];                       // a max, kept in stripe 0 (the stored bit pattern is the double's)
     const bool solved = hfail == 0 && isfinite(cost_new) && isfinite(model);
     const int it = c->iter;
     if (it == 0) { c->initial_cost = cost_before; c->cost = cost_before; }
@@ -1700,9 +1894,12 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
   }
   __syncthreads();
   if (s_commit) {
+    const double2* p2 = reinterpret_cast<const double2*>(A.invd2);
+    double2* q2 = reinterpret_cast<double2*>(A.invd);
+    for (int i = threadIdx.x; i < A.n_lm / 2; i += kDT) q2[i] = p2[i];
+    if ((A.n_lm & 1) && threadIdx.x == 0) A.invd[A.n_lm - 1] = A.invd2[A.n_lm - 1];
     for (int i = threadIdx.x; i < 7 * A.n_kf; i += kDT) A.poses[i] = A.poses2[i];
     for (int i = threadIdx.x; i < 3 * A.n_kf; i += kDT) { A.vel[i] = A.vel2[i]; A.ba[i] = A.ba2[i]; A.bg[i] = A.bg2[i]; }
-    for (int i = threadIdx.x; i < A.n_lm; i += kDT) A.invd[i] = A.invd2[i];
   }
   if (A.rec) {
     __syncthreads();
@@ -1729,6 +1926,7 @@ struct Chain {
   ZeroList zero{};
   ImuArgs imu_lin{}, imu_cost{};
   LinArgs lin{};
+  TfReduceArgs red{};           // compact mode: the slabs of the TwoFrame linearisation -> B, gc
   PrepArgs prep{};
   bool merged_level0 = false;
   SchurSp0Args ssp0{}; size_t ssp0_lds = 0;
@@ -1846,7 +2044,7 @@ static int build_chain(lvf_problem* p) {
     int k = 0;
     auto add = [&](double* ptr, size_t n) { if (ptr && n) { c.zero.p[k] = ptr; c.zero.n[k] = n; ++k; } };
     add(p->B.p, (size_t)p->dpad * p->dpad); add(p->gc.p, p->dpad); add(p->scal.p, SC_N);
-    if (p->n_lm) { add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
+    if (p->n_lm) { if (!p->compact) add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
     c.zero.count = k;
   }
   c.fast = p->tf && p->tf->n && p->tf_work.n && p->n_kf <= kMaxStagedKf;
@@ -1873,8 +2071,15 @@ static int build_chain(lvf_problem* p) {
       a.n_imu = p->imu->n; a.imu_res = p->imu->res.p; a.imu_i = p->imu->idx_a.p; a.imu_j = p->imu->idx_b.p;
       for (int k = 0; k < 8; ++k) a.imu_J.j[k] = p->imu->jac[k].p;
     }
+    a.cp = TfCompact{0, nullptr, nullptr, nullptr, nullptr};
+    if (p->compact) {
+      a.cp = TfCompact{1, p->tf_slot.p, p->slotB.p, p->slabP.p, p->slabQ.p};
+      TfReduceArgs& r = c.red;
+      r.n_kf = p->n_kf; r.n_wg = a.n_tfw; r.run_first = p->run_first.p; r.slabP = p->slabP.p; r.slabQ = p->slabQ.p; r.B = p->B.p; r.ld = p->dpad; r.gc = p->gc.p;
+      r.nblocks = p->n_kf * ((a.n_tfw + 63) / 64) + grid(p->n_kf * (p->n_kf - 1) / 2 * 36); r.done = done;
+    }
     c.lin.n_kf = p->n_kf; c.lin.s = s; c.lin.huber = 0.0; c.lin.pose_const = p->pose_const.p; c.lin.B = p->B.p; c.lin.ld = p->dpad; c.lin.gc = p->gc.p; c.lin.E = p->E.p;
-    c.lin.ldE = p->ldE; c.lin.C = p->C.p; c.lin.gr = p->gr.p; c.lin.cost = cost; c.lin.done = done;
+    c.lin.ldE = p->ldE; c.lin.C = p->C.p; c.lin.gr = p->gr.p; c.lin.cost = cost; c.lin.done = done; c.lin.dbg = nullptr;
     c.lin.nblocks = a.n_tfw + a.g_tc + a.g_po + (a.n_imu + 3) / 4;
   }
   // damped system
@@ -1883,7 +2088,8 @@ static int build_chain(lvf_problem* p) {
     const size_t nS = (size_t)p->ld * p->ld;
     a.ld = p->ld; a.dpad = p->dpad; a.iperm = p->iperm.p; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.S = p->S.p;
     a.nS_blocks = (unsigned)((nS + kT - 1) / kT); a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.C = p->C.p; a.gr = p->gr.p; a.Cd = p->Cd.p; a.E = p->E.p;
-    a.scal = p->scal.p; a.nblocks = (int)a.nS_blocks + (p->n_lm ? grid(p->n_lm) : 0); a.done = done;
+    a.eoff = p->lm_eoff.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p; a.slotB = p->compact ? p->slotB.p : nullptr; a.Ct = p->Ct.p; a.grt = p->grt.p;
+    a.scal = p->scal.p; a.nblocks = (int)a.nS_blocks + (p->n_lm ? grid(p->compact ? 8 * p->n_lm : p->n_lm) : 0); a.done = done;
   }
   int* fail = reinterpret_cast<int*>(p->scal.p + SC_FAIL);
   c.n_levels = p->sp_levels.n;
@@ -1900,7 +2106,8 @@ static int build_chain(lvf_problem* p) {
     if (p->band_ready && shb <= 64 * 1024 && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024) {
       SchurSp0Args& a = c.ssp0;
       a.n_slices = (p->n_lm + kBandRows - 1) / kBandRows; a.n_groups = (ntile + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
-      a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.Cd = p->Cd.p; a.order = p->lm_order.p; a.n_active = p->lm_nactive.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p;
+      a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.Cd = p->Cd.p; a.order = p->lm_order.p;
+      a.dbg = nullptr; a.n_active = p->lm_nactive.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p;
       a.d_local = p->dp; a.ldS = p->ld; a.S_pose = p->S.p + (size_t)p->off_pose * (p->ld + 1);
       a.sp = c.sp[0];
       a.nblocks = a.n_slices * a.n_groups + c.sp[0].nblocks; a.done = done;
@@ -1914,7 +2121,8 @@ static int build_chain(lvf_problem* p) {
   {
     TailArgs& a = c.tail;
     a.g_lm = p->n_lm ? std::min(256, (p->n_lm + kT / 16 - 1) / (kT / 16)) : 0;
-    a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.C = p->C.p; a.Cd = p->Cd.p; a.gr = p->gr.p; a.dxc = p->dxc.p; a.dxl = p->dxl.p; a.scal = p->scal.p;
+    a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.C = p->compact ? p->Ct.p : p->C.p; a.Cd = p->Cd.p;
+    a.gr = p->compact ? p->grt.p : p->gr.p; a.dxc = p->dxc.p; a.dxl = p->dxl.p; a.scal = p->scal.p;
     a.kmin = p->band_ready ? p->lm_kmin.p : nullptr; a.kmax = p->lm_kmax.p; a.n_kf = p->n_kf; a.s = s; a.poses2 = p->poses2.p; a.vel2 = p->vel2.p; a.ba2 = p->ba2.p;
     a.bg2 = p->bg2.p; a.invd2 = p->invd2.p; a.d = p->d; a.ld = p->dpad; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.nblocks = a.g_lm + grid(p->d); a.done = done;
     c.tail_lds = (size_t)p->ldE * sizeof(double);
@@ -1928,7 +2136,7 @@ static int build_chain(lvf_problem* p) {
     a.poses = p->st->poses.p; a.vel = p->st->vel.p; a.ba = p->st->ba.p; a.bg = p->st->bg.p; a.invd = p->st->inv_depth.p;
     a.poses2 = p->poses2.p; a.vel2 = p->vel2.p; a.ba2 = p->ba2.p; a.bg2 = p->bg2.p; a.invd2 = p->invd2.p;
   }
-  c.batchable = c.fast && c.has_imu && !c.has_prior && c.merged_level0 && c.lin.nblocks > 0 && c.cost.nblocks > 0;
+  c.batchable = c.fast && p->compact && c.has_imu && !c.has_prior && c.merged_level0 && c.lin.nblocks > 0 && c.cost.nblocks > 0;
   { const StateP sp = state_ptrs(p->st); std::memcpy(p->chain_state, &sp, sizeof(sp)); }
   p->chain_ready = true;
   return LVF_OK;
@@ -1962,7 +2170,26 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
     LinArgs la = c.lin;
     la.huber = huber;
     if (!gated) la.done = nullptr;
+    static const bool lin_timing = std::getenv("LVF_LIN_TIMING") != nullptr;
+    if (lin_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)la.v.n_tfw * 8 + 8)); la.dbg = p->dbg_lin.p; }
     hipLaunchKernelGGL(k_lin_visual, dim3(la.nblocks), dim3(kT), 0, q, la);
+    if (p->compact) {
+      TfReduceArgs ra = c.red;
+      if (!gated) ra.done = nullptr;
+      hipLaunchKernelGGL(k_tf_reduce, dim3(ra.nblocks), dim3(kT), 0, q, ra);
+    }
+    if (lin_timing) {
+      std::vector<unsigned long long> t((size_t)la.v.n_tfw * 8);
+      LVF_HIP(hipStreamSynchronize(q));
+      LVF_HIP(hipMemcpy(t.data(), p->dbg_lin.p, t.size() * 8, hipMemcpyDeviceToHost));
+      double ph[5] = {0, 0, 0, 0, 0}; unsigned long long first = ~0ull, last = 0;
+      for (int w = 0; w < la.v.n_tfw; ++w) {
+        for (int k = 0; k < 5; ++k) ph[k] += (double)(t[(size_t)w * 8 + k + 1] - t[(size_t)w * 8 + k]) * 0.01;
+        first = std::min(first, t[(size_t)w * 8]); last = std::max(last, t[(size_t)w * 8 + 5]);
+      }
+      std::fprintf(stderr, "lin_tf phases (us, mean over %d workgroups): stage %.2f | eval+landmark atomics %.2f | k1 sums %.2f | k2 sums %.2f | flush %.2f ; first start -> last end %.2f\n",
+                   la.v.n_tfw, ph[0] / la.v.n_tfw, ph[1] / la.v.n_tfw, ph[2] / la.v.n_tfw, ph[3] / la.v.n_tfw, ph[4] / la.v.n_tfw, (double)(last - first) * 0.01);
+    }
   } else {
     if (p->tc && p->tc->n)
       hipLaunchKernelGGL(k_lin_tc<false>, dim3(grid(p->tc->n)), dim3(kT), 0, q, p->tc->n, (const double2*)p->tc->ob_a.p, (const double2*)p->tc->ob_b.p,
@@ -2003,11 +2230,29 @@ static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool
   hipLaunchKernelGGL(k_prepare, dim3(pa.nblocks), dim3(kT), 0, q, pa);
   if (level0_done) *level0_done = false;
   if (p->n_lm) {
-    if (c.merged_level0 && level0_done) {
+    if (c.merged_level0) {
       SchurSp0Args sa = c.ssp0;
       if (!gated) sa.done = nullptr;
+      if (!level0_done) { sa.nblocks = sa.n_slices * sa.n_groups; sa.sp.nblocks = 0; }       // the Schur complement alone (parity tap)
+      static const bool schur_timing = std::getenv("LVF_SCHUR_TIMING") != nullptr;
+      const int ns = sa.n_slices * sa.n_groups;
+      if (schur_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)ns * 8 + 8)); LVF_HIP(hipMemsetAsync(p->dbg_lin.p, 0, (size_t)ns * 64, q)); sa.dbg = p->dbg_lin.p; }
       hipLaunchKernelGGL(k_schur_sp0, dim3(sa.nblocks), dim3(256), c.ssp0_lds, q, sa);
-      *level0_done = true;
+      if (schur_timing) {
+        std::vector<unsigned long long> t((size_t)ns * 8);
+        LVF_HIP(hipStreamSynchronize(q));
+        LVF_HIP(hipMemcpy(t.data(), p->dbg_lin.p, t.size() * 8, hipMemcpyDeviceToHost));
+        double ph[3] = {0, 0, 0}; int cnt = 0; unsigned long long first = ~0ull, last = 0;
+        for (int w = 0; w < ns; ++w) {
+          if (!t[(size_t)w * 8 + 3]) continue;
+          ++cnt;
+          for (int k = 0; k < 3; ++k) ph[k] += (double)(t[(size_t)w * 8 + k + 1] - t[(size_t)w * 8 + k]) * 0.01;
+          first = std::min(first, t[(size_t)w * 8]); last = std::max(last, t[(size_t)w * 8 + 3]);
+        }
+        std::fprintf(stderr, "schur band phases (us, mean over %d of %d workgroups): setup + first fetch issue %.2f | chunks (stage + mfma) %.2f | output atomics %.2f ; first start -> last end %.2f\n",
+                     cnt, ns, ph[0] / std::max(cnt, 1), ph[1] / std::max(cnt, 1), ph[2] / std::max(cnt, 1), (double)(last - first) * 0.01);
+      }
+      if (level0_done) *level0_done = true;
     } else {
       double* S_pose = p->S.p + (size_t)p->off_pose * (p->ld + 1);
       const LmBand band{p->band_ready ? p->lm_order.p : nullptr, p->lm_nactive.p, p->lm_kmin.p, p->lm_kmax.p};
@@ -2249,7 +2494,7 @@ int problem_configure(lvf_problem* p) {
   LVF_TRY(p->Dinv.ensure((size_t)p->nb * kNB * kNB));
   LVF_TRY(p->B.ensure(nS)); LVF_TRY(p->S.ensure((size_t)p->ld * p->ld)); LVF_TRY(p->gc.ensure(p->dpad)); LVF_TRY(p->dxc.ensure(p->dpad));
   LVF_TRY(p->C.ensure(p->n_lm)); LVF_TRY(p->gr.ensure(p->n_lm)); LVF_TRY(p->Cd.ensure(p->n_lm)); LVF_TRY(p->dxl.ensure(p->n_lm));
-  LVF_TRY(p->E.ensure((size_t)p->n_lm * p->ldE)); LVF_TRY(p->scal.ensure(SC_ALLOC));
+  LVF_TRY(p->scal.ensure(SC_ALLOC));
   // candidate state x + dx (an accepted candidate is copied into the state by k_lm_decide)
   LVF_TRY(p->poses2.ensure(std::max(st->poses.cap, (size_t)7 * p->n_kf))); LVF_TRY(p->vel2.ensure(std::max(st->vel.cap, (size_t)3 * p->n_kf)));
   LVF_TRY(p->ba2.ensure(std::max(st->ba.cap, (size_t)3 * p->n_kf))); LVF_TRY(p->bg2.ensure(std::max(st->bg.cap, (size_t)3 * p->n_kf)));
@@ -2257,13 +2502,14 @@ int problem_configure(lvf_problem* p) {
   LVF_TRY(p->pose_const.ensure(p->n_kf)); LVF_TRY(p->fail.ensure(1));
   p->pose_const_h.assign(p->n_kf, 0);
   p->tf_work.n = 0;
-  p->tf_unique_lk2 = false;
+  p->tf_unique_lk2 = false; p->tf_k1_first = false; p->compact = false;
   lvf_batch* two_frame = p->tf;
   if (two_frame && two_frame->n && two_frame->sorted_by_kf && !two_frame->host_kf2.empty()) {
     // work list for the sorted fast path: runs of <= kT blocks sharing one current keyframe; k1 == k2 disables it
     const std::vector<int32_t>& k2 = two_frame->host_kf2; const std::vector<int32_t>& k1 = two_frame->host_kf1;
-    bool ok = true;
-    for (int i = 0; i < two_frame->n && ok; ++i) ok = k1[i] != k2[i];
+    bool ok = true, k1_first = true;
+    for (int i = 0; i < two_frame->n && ok; ++i) { ok = k1[i] != k2[i]; k1_first = k1_first && k1[i] < k2[i]; }
+    p->tf_k1_first = ok && k1_first;
     if (ok) {
       // built straight into pinned staging owned by the problem: the upload is a real asynchronous copy and this function does not
       // have to wait for the stream before returning
@@ -2317,7 +2563,38 @@ int problem_configure(lvf_problem* p) {
                        p->lm_nactive.p);
     LVF_HIP(hipGetLastError());
     p->band_ready = true;
+    // compact landmark layout + slabs (atomic-free TwoFrame linearisation): needs the sorted work list, one block per (landmark,
+    // keyframe), the landmark's first keyframe ahead of its observations, and the merged band-Schur launch
+    static const bool compact_on = [] { const char* e = std::getenv("LVF_COMPACT"); return !(e && e[0] == '0'); }();
+    const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRows * sizeof(int);
+    const bool merged = shb <= 64 * 1024 && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024;
+    if (compact_on && merged && p->dp <= 320 && two_frame && two_frame->n && p->tf_work.n && p->n_kf <= kMaxStagedKf && p->tf_unique_lk2 && p->tf_k1_first) {
+      const size_t cap_slots = (size_t)p->n_lm * (size_t)std::max(p->n_kf - 1, 1);      // worst case: every landmark seen by every later keyframe
+      const int n_wg = (int)p->tf_work.n;
+      LVF_TRY(p->lm_eoff.ensure(p->n_lm)); LVF_TRY(p->n_slots.ensure(1)); LVF_TRY(p->tf_slot.ensure(two_frame->n));
+      LVF_TRY(p->slotB.ensure(cap_slots * 8));
+      LVF_TRY(p->Ct.ensure(p->n_lm)); LVF_TRY(p->grt.ensure(p->n_lm));
+      LVF_TRY(p->slabP.ensure((size_t)n_wg * p->n_kf * kSlabRow)); LVF_TRY(p->slabQ.ensure((size_t)n_wg * kSlabQ));
+      hipLaunchKernelGGL(k_lm_offsets, dim3(1), dim3(1024), 0, q, p->n_lm, p->lm_kmin.p, p->lm_kmax.p, p->lm_eoff.p, p->n_slots.p);
+      hipLaunchKernelGGL(k_tf_slots, dim3(grid(two_frame->n)), dim3(kT), 0, q, two_frame->n, two_frame->idx_a.p, two_frame->idx_c.p, p->lm_kmin.p, p->lm_eoff.p, p->tf_slot.p);
+      hipLaunchKernelGGL(k_zero_slots, dim3(256), dim3(kT), 0, q, p->n_slots.p, p->slotB.p);
+      LVF_HIP(hipGetLastError());
+      // run_first[k] = first workgroup of current keyframe k's run (the work list is sorted by k2); run_first[n_kf] = n_wg
+      LVF_TRY(p->h_run_first.reserve((size_t)p->n_kf + 1));
+      {
+        int w = 0;
+        for (int k = 0; k <= p->n_kf; ++k) {
+          while (w < n_wg && p->h_tf_work[w].k2 < k) ++w;
+          p->h_run_first[k] = w;
+        }
+      }
+      LVF_TRY(p->run_first.assign(p->h_run_first.p, (size_t)p->n_kf + 1, q));
+      p->compact = true;
+    }
   }
+  LVF_TRY(p->E.ensure((size_t)p->n_lm * p->ldE));
+  // atomic-free mode: E's non-zero pattern is fixed for the problem and fully overwritten by every linearisation — cleared once, here
+  if (p->compact && p->n_lm) LVF_HIP(hipMemsetAsync(p->E.p, 0, (size_t)p->n_lm * p->ldE * sizeof(double), ctx->stream));
   LVF_HIP(hipMemsetAsync(p->pose_const.p, 0, p->n_kf, ctx->stream));
   LVF_HIP(hipMemsetAsync(p->dxc.p, 0, (size_t)p->dpad * 8, ctx->stream));
   // no stream wait here: every host source above is pinned and owned by the problem (or was waited for by the plan builder)
@@ -2344,6 +2621,7 @@ struct lvf_problem_batch {
   // per-stage argument tables [W] (device) and the launch shapes (max over the windows)
   lvf::DevBuf<lvf::ImuArgs> imu_lin, imu_cost; int g_imu_lin = 0, g_imu_cost = 0;
   lvf::DevBuf<lvf::LinArgs> lin; int g_lin = 0;
+  lvf::DevBuf<lvf::TfReduceArgs> red; int g_red = 0;
   lvf::DevBuf<lvf::PrepArgs> prep; int g_prep = 0;
   lvf::DevBuf<lvf::SchurSp0Args> ssp0; int g_ssp0 = 0; size_t lds_ssp0 = 0;
   lvf::DevBuf<lvf::SpArgs> sp[lvf::kSpMaxLevels]; int g_sp[lvf::kSpMaxLevels] = {0}; int lds_sp[lvf::kSpMaxLevels] = {0};
@@ -2375,14 +2653,16 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
   }
   b->tables = all;
   if (!all) return LVF_OK;
-  std::vector<ImuArgs> il(W), ic(W); std::vector<LinArgs> li(W); std::vector<PrepArgs> pr(W); std::vector<SchurSp0Args> ss(W);
+  std::vector<ImuArgs> il(W), ic(W); std::vector<LinArgs> li(W); std::vector<TfReduceArgs> rd(W); std::vector<PrepArgs> pr(W); std::vector<SchurSp0Args> ss(W);
   std::vector<CholArgs> ch(W); std::vector<BackArgs> bk(W); std::vector<TailArgs> tl(W); std::vector<CostArgs> co(W); std::vector<DecideArgs> de(W);
   b->max_levels = 0; b->max_nb = 0;
+  b->g_red = 0;
   b->g_imu_lin = b->g_imu_cost = b->g_lin = b->g_prep = b->g_ssp0 = b->g_tail = b->g_cost = 0; b->lds_ssp0 = b->lds_back = b->lds_tail = 0;
   for (int w = 0; w < W; ++w) {
     const lvf_problem* p = b->probs[w];
     const Chain& c = *p->chain;
-    il[w] = c.imu_lin; ic[w] = c.imu_cost; li[w] = c.lin; li[w].huber = huber; pr[w] = c.prep; ss[w] = c.ssp0; ch[w] = c.chol; bk[w] = c.back; tl[w] = c.tail;
+    il[w] = c.imu_lin; ic[w] = c.imu_cost; li[w] = c.lin; li[w].huber = huber; rd[w] = c.red; if (!p->compact) rd[w].nblocks = 0;
+    b->g_red = std::max(b->g_red, rd[w].nblocks); pr[w] = c.prep; ss[w] = c.ssp0; ch[w] = c.chol; bk[w] = c.back; tl[w] = c.tail;
     co[w] = c.cost; co[w].huber = huber; de[w] = c.dec;
     b->g_imu_lin = std::max(b->g_imu_lin, c.imu_lin.n + c.imu_lin.zero_wgs); b->g_imu_cost = std::max(b->g_imu_cost, c.imu_cost.n + c.imu_cost.zero_wgs);
     b->g_lin = std::max(b->g_lin, c.lin.nblocks); b->g_prep = std::max(b->g_prep, c.prep.nblocks); b->g_ssp0 = std::max(b->g_ssp0, c.ssp0.nblocks);
@@ -2390,7 +2670,7 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
     b->lds_tail = std::max(b->lds_tail, c.tail_lds); b->g_cost = std::max(b->g_cost, c.cost.nblocks);
     b->max_levels = std::max(b->max_levels, c.n_levels); b->max_nb = std::max(b->max_nb, p->nb);
   }
-  LVF_TRY(upload_table(b->imu_lin, il, q)); LVF_TRY(upload_table(b->imu_cost, ic, q)); LVF_TRY(upload_table(b->lin, li, q)); LVF_TRY(upload_table(b->prep, pr, q));
+  LVF_TRY(upload_table(b->imu_lin, il, q)); LVF_TRY(upload_table(b->imu_cost, ic, q)); LVF_TRY(upload_table(b->lin, li, q)); LVF_TRY(upload_table(b->red, rd, q)); LVF_TRY(upload_table(b->prep, pr, q));
   LVF_TRY(upload_table(b->ssp0, ss, q)); LVF_TRY(upload_table(b->chol, ch, q)); LVF_TRY(upload_table(b->back, bk, q)); LVF_TRY(upload_table(b->tail, tl, q));
   LVF_TRY(upload_table(b->cost, co, q)); LVF_TRY(upload_table(b->dec, de, q));
   for (int lv = 1; lv < b->max_levels; ++lv) {        // level 0 rides in the Schur launch
@@ -2417,6 +2697,7 @@ static int batch_enqueue_iteration(lvf_problem_batch* b) {
   const unsigned W = (unsigned)b->W;
   LVF_TRY(launch_imu_table(q, b->imu_lin.p, b->W, b->g_imu_lin, true));
   hipLaunchKernelGGL(k_lin_visual_b, dim3(b->g_lin, W), dim3(kT), 0, q, b->lin.p);
+  if (b->g_red > 0) hipLaunchKernelGGL(k_tf_reduce_b, dim3(b->g_red, W), dim3(kT), 0, q, b->red.p);
   hipLaunchKernelGGL(k_prepare_b, dim3(b->g_prep, W), dim3(kT), 0, q, b->prep.p);
   hipLaunchKernelGGL(k_schur_sp0_b, dim3(b->g_ssp0, W), dim3(256), b->lds_ssp0, q, b->ssp0.p);
   for (int lv = 1; lv < b->max_levels; ++lv)
