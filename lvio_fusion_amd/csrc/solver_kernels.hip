@@ -47,6 +47,7 @@ struct lvf_problem {
   bool compact = false;
   lvf::DevBuf<int> lm_eoff, n_slots, tf_slot, run_first;
   lvf::DevBuf<double> slotB, slabP, slabQ, Ct, grt;
+  int band_rows = 64;           // landmark rows per slice of the band Schur complement (a batch uses more: fewer output atomics)
   lvf::HostPin<int> h_run_first;
   lvf::DevBuf<unsigned long long> dbg, dbg_lin;
   lvf::DevBuf<double> sp_W, sp_L, Dinv;         // Dinv: L_kk^-T of every 64x64 diagonal block of the dense corner
@@ -236,6 +237,9 @@ struct TfWork { int first, count, k2; };
 struct TfCompact { int on; const int* slot; double *slotB, *slabP, *slabQ; };
 constexpr int kSlabRow = 64, kSlabQ = 32;
 constexpr int kAccSlots = 63;   // 21 (B[k1,k1] lower) + 6 (g[k1]) + 36 (cross block, rows = k2 tangent, cols = k1 tangent)
+// DYN: the LDS tables are carved from the launch's dynamic LDS, sized by the window's n_kf (k_lin_visual: 32 KB at 50 keyframes instead of
+// 79 KB of static arrays sized for 64 — three workgroups per CU instead of two)
+template <bool DYN = false>
 __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* __restrict__ work, int n_kf, const double2* __restrict__ fo,
                                                       const double2* __restrict__ ob, const int* __restrict__ lm,
                                                       const int* __restrict__ kf1, StateP s, CamD left, CamD right, double huber,
@@ -243,9 +247,13 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
                                                       double* __restrict__ gc, double* __restrict__ E, int ldE,
                                                       double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost, int unique_lk2,
                                                       unsigned long long* dbg = nullptr, const TfCompact cp = TfCompact{0, nullptr, nullptr, nullptr, nullptr}) {
-  __shared__ PoseD s_pose[kMaxStagedKf];
-  __shared__ double s_acc[kMaxStagedKf * kAccSlots];
-  __shared__ double s_k2[27];
+  __shared__ PoseD s_pose_st[DYN ? 1 : kMaxStagedKf];
+  __shared__ double s_acc_st[DYN ? 1 : kMaxStagedKf * kAccSlots];
+  __shared__ double s_k2_st[DYN ? 1 : 27];
+  extern __shared__ double lin_lds[];
+  PoseD* s_pose = DYN ? reinterpret_cast<PoseD*>(lin_lds) : s_pose_st;
+  double* s_acc = DYN ? lin_lds + (sizeof(PoseD) / 8) * n_kf : s_acc_st;
+  double* s_k2 = DYN ? s_acc + kAccSlots * n_kf : s_k2_st;
   const TfWork w = work[vb];
   auto mark = [&](int k) { if (dbg && threadIdx.x == 0) dbg[(size_t)vb * 8 + k] = wall_clock64(); };   // LVF_LIN_TIMING=1: phase stamps (100 MHz)
   mark(0);
@@ -384,13 +392,6 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
   __syncthreads();
   mark(5);
 }
-__global__ __launch_bounds__(kT) void k_lin_tf_sorted(const TfWork* __restrict__ work, int n_kf, const double2* __restrict__ fo,
-                                                      const double2* __restrict__ ob, const int* __restrict__ lm,
-                                                      const int* __restrict__ kf1, StateP s, CamD left, CamD right, double huber,
-                                                      const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
-                                                      double* __restrict__ gc, double* __restrict__ E, int ldE,
-                                                      double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost, int unique_lk2) { lin_tf_sorted_body(blockIdx.x, work, n_kf, fo, ob, lm, kf1, s, left, right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost, unique_lk2); }
-
 // ------------------------------------------------------------------------------------------------ candidate cost, visual factors
 // One launch for the residual-only passes of the three reprojection batches (the workgroups of the launch are split into a
 // TwoCamera, a TwoFrame and a PoseOnly segment): as three back-to-back launches of 4-9 us they were mostly launch boundaries.
@@ -453,12 +454,14 @@ __global__ __launch_bounds__(kT) void k_cost_visual(CostArgs a) { cost_visual_bo
 __global__ __launch_bounds__(kT) void k_cost_visual_b(const CostArgs* __restrict__ t) { cost_visual_body(blockIdx.x, t[blockIdx.y]); }
 
 // ------------------------------------------------------------------------------------------------ PoseOnly
-template <bool COST_ONLY>
+template <bool COST_ONLY, bool DYN = false>
 __device__ __forceinline__ void lin_po_body(const int vb, int n, int n_kf, const double2* __restrict__ ob, const int* __restrict__ kf,
                                                const int* __restrict__ pwi, const double* __restrict__ pw, StateP s, CamD cam,
                                                double huber, const uint8_t* __restrict__ pose_const, double* __restrict__ B,
                                                int ld, double* __restrict__ gc, double* __restrict__ cost) {
-  __shared__ PoseD s_pose[kMaxStagedKf];
+  __shared__ PoseD s_pose_st[DYN ? 1 : kMaxStagedKf];
+  extern __shared__ double lin_lds[];
+  PoseD* s_pose = DYN ? reinterpret_cast<PoseD*>(lin_lds) : s_pose_st;
   stage_poses<kT>(s_pose, s.poses, n_kf);
   const int i = vb * kT + threadIdx.x;
   double c = 0.0;
@@ -495,7 +498,8 @@ __device__ __forceinline__ void lin_po_body(const int vb, int n, int n_kf, const
     // (the per-pose-block JtJ/Jtr reduction of the north star).  The wave sums then meet in a per-workgroup LDS table
     // [n_kf][27] and only its non-zero entries go to global memory: ~15 waves per keyframe used to hit the SAME 27 addresses of B
     // with global atomics, which serialise in L2.
-    __shared__ double s_acc[kMaxStagedKf * 27];
+    __shared__ double s_acc_st[DYN ? 1 : kMaxStagedKf * 27];
+    double* s_acc = DYN ? lin_lds + (sizeof(PoseD) / 8) * n_kf : s_acc_st;
     const bool lds_path = n_kf <= kMaxStagedKf;
     if (lds_path) {
       for (int e = threadIdx.x; e < n_kf * 27; e += kT) s_acc[e] = 0.0;
@@ -604,17 +608,21 @@ __global__ __launch_bounds__(64) void k_lin_imu(int n, int n_kf, const double* _
 }
 
 // the same accumulation for use inside a 256-thread workgroup: wave w of virtual block vb takes factor 4 vb + w
+template <bool DYN = false>
 __device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, const double* __restrict__ res, ImuJ J, const int* __restrict__ kf_i,
                                               const int* __restrict__ kf_j, const double* __restrict__ poses,
                                               const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
                                               double* __restrict__ gc, double* __restrict__ cost) {
-  __shared__ double sJ4[4][15 * 30];
-  __shared__ double sr4[4][15];
-  __shared__ int sidx4[4][30];
+  __shared__ double sJ4[DYN ? 1 : 4 * 15 * 30];
+  __shared__ double sr4[DYN ? 1 : 4 * 16];
+  __shared__ int sidx4[DYN ? 1 : 4 * 32];
+  extern __shared__ double lin_lds[];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int f = 4 * vb + w;
   const bool active = f < n;
-  double* sJ = sJ4[w]; double* sr = sr4[w]; int* sidx = sidx4[w];
+  double* sJ = (DYN ? lin_lds : sJ4) + w * 450;
+  double* sr = (DYN ? lin_lds + 1800 : sr4) + w * 16;
+  int* sidx = (DYN ? reinterpret_cast<int*>(lin_lds + 1864) : sidx4) + w * 32;
   if (active) {
     const int ki = kf_i[f], kj = kf_j[f];
     if (lane < 15) sr[lane] = res[(size_t)f * 15 + lane];
@@ -685,7 +693,7 @@ struct LinVisual {
 };
 struct LinArgs {
   LinVisual v; int n_kf; StateP s; double huber; const uint8_t* pose_const; double* B; int ld; double* gc; double* E; int ldE; double *C, *gr, *cost;
-  int nblocks; const int* done; unsigned long long* dbg;
+  int nblocks; const int* done; unsigned long long* dbg; int rows;
 };
 __device__ __forceinline__ void lin_visual_body(const int b, const LinArgs& A) {
   if (b >= A.nblocks || (A.done && *A.done)) return;
@@ -693,14 +701,14 @@ __device__ __forceinline__ void lin_visual_body(const int b, const LinArgs& A) {
   const int n_kf = A.n_kf; const StateP s = A.s; const double huber = A.huber; const uint8_t* pose_const = A.pose_const;
   double* B = A.B; const int ld = A.ld; double* gc = A.gc; double* E = A.E; const int ldE = A.ldE; double* C = A.C; double* gr = A.gr; double* cost = A.cost;
   if (b < a.n_tfw)
-    lin_tf_sorted_body(b, a.work, n_kf, a.tf_fo, a.tf_ob, a.tf_lm, a.tf_k1, s, a.tf_left, a.tf_right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost,
+    lin_tf_sorted_body<true>(b, a.work, n_kf, a.tf_fo, a.tf_ob, a.tf_lm, a.tf_k1, s, a.tf_left, a.tf_right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost,
                        a.unique_lk2, A.dbg, a.cp);
   else if (b < a.n_tfw + a.g_tc)
     lin_tc_body<false>(b - a.n_tfw, a.n_tc, a.tc_lo, a.tc_ro, a.tc_lm, a.tc_kf, a.tc_w, s, a.tc_left, a.tc_right, huber, C, gr, cost);
   else if (b < a.n_tfw + a.g_tc + a.g_po)
-    lin_po_body<false>(b - a.n_tfw - a.g_tc, a.n_po, n_kf, a.po_ob, a.po_kf, a.po_pwi, a.po_pw, s, a.po_cam, huber, pose_const, B, ld, gc, cost);
+    lin_po_body<false, true>(b - a.n_tfw - a.g_tc, a.n_po, n_kf, a.po_ob, a.po_kf, a.po_pwi, a.po_pw, s, a.po_cam, huber, pose_const, B, ld, gc, cost);
   else
-    lin_imu_body4(b - a.n_tfw - a.g_tc - a.g_po, a.n_imu, n_kf, a.imu_res, a.imu_J, a.imu_i, a.imu_j, s.poses, pose_const, B, ld, gc, cost);
+    lin_imu_body4<true>(b - a.n_tfw - a.g_tc - a.g_po, a.n_imu, n_kf, a.imu_res, a.imu_J, a.imu_i, a.imu_j, s.poses, pose_const, B, ld, gc, cost);
 }
 __global__ __launch_bounds__(kT) void k_lin_visual(LinArgs a) { lin_visual_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_lin_visual_b(const LinArgs* __restrict__ t) { lin_visual_body(blockIdx.x, t[blockIdx.y]); }
@@ -1036,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_schur_lds(int n_lm, int dp, int ldE, in
 // those columns (plus the tile holding the g_rho column) and only forms the band's lower-triangular tiles.  At configs[3]
 // that is ~1/5 of the MFMAs and ~1/30 of the E bytes of the dense SYRK.  Correctness never depends on the ordering: the
 // band of each slice is computed from the actual kmin/kmax of its rows.
-constexpr int kBandRows = 64, kBandTilesPerGroup = 32;
+constexpr int kBandRows = 64, kBandRowsMax = 256, kBandTilesPerGroup = 32;     // rows per slice: 64 for one window, up to 256 in a batch (fewer output atomics)
 __global__ __launch_bounds__(kT) void k_lm_range(int n, const int* __restrict__ lm, const int* __restrict__ k1, const int* __restrict__ k2,
                                                  int* __restrict__ kmin, int* __restrict__ kmax) {
   const int i = blockIdx.x * kT + threadIdx.x;
@@ -1126,13 +1134,13 @@ __global__ __launch_bounds__(kT) void k_zero_slots(const int* __restrict__ n_slo
 __device__ __forceinline__ void schur_band_body(const int bx, const int by, int dp, int ldE, const double* __restrict__ E,
                                                 const double* __restrict__ Cd, const int* __restrict__ order, const int* __restrict__ n_active_p,
                                                 const int* __restrict__ kmin, const int* __restrict__ kmax, int d, int ldS,
-                                                double* __restrict__ S, unsigned long long* dbg = nullptr) {
+                                                double* __restrict__ S, unsigned long long* dbg = nullptr, const int rows = kBandRows) {
   extern __shared__ double sh[];          // Es[kSchurRows][ldl] | icd[kSchurRows] | rowid (int)[kBandRows]
   auto mark = [&](int k) { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); };   // LVF_SCHUR_TIMING=1: phase stamps of this workgroup
   mark(0);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lk = lane >> 4, lc = lane & 15;
   const int n_active = *n_active_p;
-  const int k_begin = bx * kBandRows, k_end = min(n_active, k_begin + kBandRows);
+  const int k_begin = bx * rows, k_end = min(n_active, k_begin + rows);
   if (k_begin >= k_end) return;
   // the slice's band (every wave reduces it for itself: two rows per lane)
   int lo = 0x7fffffff, hi = -1;
@@ -1148,7 +1156,7 @@ __device__ __forceinline__ void schur_band_body(const int bx, const int by, int 
   double* Es = sh;
   double* icd = sh + kSchurRows * (ldE + 16);
   int* rowid = reinterpret_cast<int*>(icd + kSchurRows);
-  for (int r = tid; r < kBandRows; r += 256) rowid[r] = (k_begin + r < k_end) ? order[k_begin + r] : -1;
+  for (int r = tid; r < rows; r += 256) rowid[r] = (k_begin + r < k_end) ? order[k_begin + r] : -1;
   // this wave's tiles: t = tbase + w + 4 s; local tile columns (a = row tile, b = column tile), extra row tile = index nbt
   int ta[kSchurTilesPerWave], tb[kSchurTilesPerWave], nt = 0;
 #pragma unroll
@@ -1236,7 +1244,7 @@ struct LmBand { const int* order; const int* n_active; const int* kmin; const in
 static int launch_schur(hipStream_t q, int n_lm, int dp, int ldE, const double* E, const double* Cd, int d, int ldS, double* S, const LmBand& band) {
   const int nt = ldE / 16, ntile = nt * (nt + 1) / 2;
   if (band.order) {
-    const size_t shb = ((size_t)kSchurRows * (ldE + 16) + kSchurRows) * sizeof(double) + kBandRows * sizeof(int);
+    const size_t shb = ((size_t)kSchurRows * (ldE + 16) + kSchurRows) * sizeof(double) + kBandRowsMax * sizeof(int);
     if (shb <= 64 * 1024) {
       hipLaunchKernelGGL(k_schur_band, dim3((n_lm + kBandRows - 1) / kBandRows, (ntile + kBandTilesPerGroup - 1) / kBandTilesPerGroup), dim3(256), shb, q,
                          dp, ldE, E, Cd, band.order, band.n_active, band.kmin, band.kmax, d, ldS, S);
@@ -1527,12 +1535,12 @@ __global__ __launch_bounds__(256) void k_sp_eliminate_b(const SpArgs* __restrict
 struct SchurSp0Args {
   int n_slices, n_groups, dp, ldE; const double *E, *Cd; const int *order, *n_active, *kmin, *kmax; int d_local, ldS; double* S_pose;
   SpArgs sp;             // level 0 (sp.nblocks == 0: Schur complement only)
-  int nblocks; const int* done; unsigned long long* dbg;
+  int nblocks; const int* done; unsigned long long* dbg; int rows;
 };
 __device__ __forceinline__ void schur_sp0_body(const int b, const SchurSp0Args& A) {
   if (b >= A.nblocks || (A.done && *A.done)) return;
   const int ns = A.n_slices * A.n_groups;
-  if (b < ns) schur_band_body(b % A.n_slices, b / A.n_slices, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)b * 8 : nullptr);
+  if (b < ns) schur_band_body(b % A.n_slices, b / A.n_slices, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)b * 8 : nullptr, A.rows);
   else sp_eliminate_body(b - ns, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail);
 }
 __global__ __launch_bounds__(256) void k_schur_sp0(SchurSp0Args a) { schur_sp0_body(blockIdx.x, a); }
@@ -1925,7 +1933,7 @@ struct Chain {
   bool has_imu = false, has_prior = false;
   ZeroList zero{};
   ImuArgs imu_lin{}, imu_cost{};
-  LinArgs lin{};
+  LinArgs lin{}; size_t lin_lds = 0;
   TfReduceArgs red{};           // compact mode: the slabs of the TwoFrame linearisation -> B, gc
   PrepArgs prep{};
   bool merged_level0 = false;
@@ -2081,6 +2089,7 @@ static int build_chain(lvf_problem* p) {
     c.lin.n_kf = p->n_kf; c.lin.s = s; c.lin.huber = 0.0; c.lin.pose_const = p->pose_const.p; c.lin.B = p->B.p; c.lin.ld = p->dpad; c.lin.gc = p->gc.p; c.lin.E = p->E.p;
     c.lin.ldE = p->ldE; c.lin.C = p->C.p; c.lin.gr = p->gr.p; c.lin.cost = cost; c.lin.done = done; c.lin.dbg = nullptr;
     c.lin.nblocks = a.n_tfw + a.g_tc + a.g_po + (a.n_imu + 3) / 4;
+    c.lin_lds = std::max((size_t)(sizeof(PoseD) / 8 + kAccSlots) * p->n_kf + 32, (size_t)1864 + 64) * sizeof(double);
   }
   // damped system
   {
@@ -2102,10 +2111,11 @@ static int build_chain(lvf_problem* p) {
   c.merged_level0 = false;
   if (p->n_lm) {
     const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
-    const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRows * sizeof(int);
+    const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRowsMax * sizeof(int);
     if (p->band_ready && shb <= 64 * 1024 && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024) {
       SchurSp0Args& a = c.ssp0;
-      a.n_slices = (p->n_lm + kBandRows - 1) / kBandRows; a.n_groups = (ntile + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
+      a.rows = std::min(kBandRowsMax, std::max(16, p->band_rows));
+      a.n_slices = (p->n_lm + a.rows - 1) / a.rows; a.n_groups = (ntile + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
       a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.Cd = p->Cd.p; a.order = p->lm_order.p;
       a.dbg = nullptr; a.n_active = p->lm_nactive.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p;
       a.d_local = p->dp; a.ldS = p->ld; a.S_pose = p->S.p + (size_t)p->off_pose * (p->ld + 1);
@@ -2172,7 +2182,7 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
     if (!gated) la.done = nullptr;
     static const bool lin_timing = std::getenv("LVF_LIN_TIMING") != nullptr;
     if (lin_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)la.v.n_tfw * 8 + 8)); la.dbg = p->dbg_lin.p; }
-    hipLaunchKernelGGL(k_lin_visual, dim3(la.nblocks), dim3(kT), 0, q, la);
+    hipLaunchKernelGGL(k_lin_visual, dim3(la.nblocks), dim3(kT), c.lin_lds, q, la);
     if (p->compact) {
       TfReduceArgs ra = c.red;
       if (!gated) ra.done = nullptr;
@@ -2566,7 +2576,7 @@ int problem_configure(lvf_problem* p) {
     // compact landmark layout + slabs (atomic-free TwoFrame linearisation): needs the sorted work list, one block per (landmark,
     // keyframe), the landmark's first keyframe ahead of its observations, and the merged band-Schur launch
     static const bool compact_on = [] { const char* e = std::getenv("LVF_COMPACT"); return !(e && e[0] == '0'); }();
-    const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRows * sizeof(int);
+    const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRowsMax * sizeof(int);
     const bool merged = shb <= 64 * 1024 && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024;
     if (compact_on && merged && p->dp <= 320 && two_frame && two_frame->n && p->tf_work.n && p->n_kf <= kMaxStagedKf && p->tf_unique_lk2 && p->tf_k1_first) {
       const size_t cap_slots = (size_t)p->n_lm * (size_t)std::max(p->n_kf - 1, 1);      // worst case: every landmark seen by every later keyframe
@@ -2620,7 +2630,7 @@ struct lvf_problem_batch {
   int W = 0, max_levels = 0, max_nb = 0;
   // per-stage argument tables [W] (device) and the launch shapes (max over the windows)
   lvf::DevBuf<lvf::ImuArgs> imu_lin, imu_cost; int g_imu_lin = 0, g_imu_cost = 0;
-  lvf::DevBuf<lvf::LinArgs> lin; int g_lin = 0;
+  lvf::DevBuf<lvf::LinArgs> lin; int g_lin = 0; size_t lds_lin = 0;
   lvf::DevBuf<lvf::TfReduceArgs> red; int g_red = 0;
   lvf::DevBuf<lvf::PrepArgs> prep; int g_prep = 0;
   lvf::DevBuf<lvf::SchurSp0Args> ssp0; int g_ssp0 = 0; size_t lds_ssp0 = 0;
@@ -2647,7 +2657,9 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
   hipStream_t q = b->ctx->stream;
   const int W = b->W;
   bool all = true;
+  static const int batch_rows = [] { const char* e = std::getenv("LVF_BATCH_BAND_ROWS"); return e ? std::atoi(e) : 128; }();
   for (lvf_problem* p : b->probs) {
+    if (b->W > 1 && p->band_rows != batch_rows) { p->band_rows = batch_rows; p->chain_ready = false; }
     if (chain_stale(p)) LVF_TRY(build_chain(p));
     all = all && p->chain->batchable;
   }
@@ -2657,7 +2669,7 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
   std::vector<CholArgs> ch(W); std::vector<BackArgs> bk(W); std::vector<TailArgs> tl(W); std::vector<CostArgs> co(W); std::vector<DecideArgs> de(W);
   b->max_levels = 0; b->max_nb = 0;
   b->g_red = 0;
-  b->g_imu_lin = b->g_imu_cost = b->g_lin = b->g_prep = b->g_ssp0 = b->g_tail = b->g_cost = 0; b->lds_ssp0 = b->lds_back = b->lds_tail = 0;
+  b->g_imu_lin = b->g_imu_cost = b->g_lin = b->g_prep = b->g_ssp0 = b->g_tail = b->g_cost = 0; b->lds_ssp0 = b->lds_back = b->lds_tail = b->lds_lin = 0;
   for (int w = 0; w < W; ++w) {
     const lvf_problem* p = b->probs[w];
     const Chain& c = *p->chain;
@@ -2665,7 +2677,7 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
     b->g_red = std::max(b->g_red, rd[w].nblocks); pr[w] = c.prep; ss[w] = c.ssp0; ch[w] = c.chol; bk[w] = c.back; tl[w] = c.tail;
     co[w] = c.cost; co[w].huber = huber; de[w] = c.dec;
     b->g_imu_lin = std::max(b->g_imu_lin, c.imu_lin.n + c.imu_lin.zero_wgs); b->g_imu_cost = std::max(b->g_imu_cost, c.imu_cost.n + c.imu_cost.zero_wgs);
-    b->g_lin = std::max(b->g_lin, c.lin.nblocks); b->g_prep = std::max(b->g_prep, c.prep.nblocks); b->g_ssp0 = std::max(b->g_ssp0, c.ssp0.nblocks);
+    b->g_lin = std::max(b->g_lin, c.lin.nblocks); b->lds_lin = std::max(b->lds_lin, c.lin_lds); b->g_prep = std::max(b->g_prep, c.prep.nblocks); b->g_ssp0 = std::max(b->g_ssp0, c.ssp0.nblocks);
     b->lds_ssp0 = std::max(b->lds_ssp0, c.ssp0_lds); b->lds_back = std::max(b->lds_back, c.back_lds); b->g_tail = std::max(b->g_tail, c.tail.nblocks);
     b->lds_tail = std::max(b->lds_tail, c.tail_lds); b->g_cost = std::max(b->g_cost, c.cost.nblocks);
     b->max_levels = std::max(b->max_levels, c.n_levels); b->max_nb = std::max(b->max_nb, p->nb);
@@ -2696,7 +2708,7 @@ static int batch_enqueue_iteration(lvf_problem_batch* b) {
   }
   const unsigned W = (unsigned)b->W;
   LVF_TRY(launch_imu_table(q, b->imu_lin.p, b->W, b->g_imu_lin, true));
-  hipLaunchKernelGGL(k_lin_visual_b, dim3(b->g_lin, W), dim3(kT), 0, q, b->lin.p);
+  hipLaunchKernelGGL(k_lin_visual_b, dim3(b->g_lin, W), dim3(kT), b->lds_lin, q, b->lin.p);
   if (b->g_red > 0) hipLaunchKernelGGL(k_tf_reduce_b, dim3(b->g_red, W), dim3(kT), 0, q, b->red.p);
   hipLaunchKernelGGL(k_prepare_b, dim3(b->g_prep, W), dim3(kT), 0, q, b->prep.p);
   hipLaunchKernelGGL(k_schur_sp0_b, dim3(b->g_ssp0, W), dim3(256), b->lds_ssp0, q, b->ssp0.p);
@@ -2887,7 +2899,11 @@ int lvf_problem_batch_create(lvf_ctx* ctx, lvf_problem* const* problems, int n, 
   *out = b;
   return LVF_OK;
 }
-int lvf_problem_batch_destroy(lvf_problem_batch* b) { delete b; return LVF_OK; }
+int lvf_problem_batch_destroy(lvf_problem_batch* b) {
+  if (b) for (lvf_problem* p : b->probs) if (p->band_rows != 64) { p->band_rows = 64; p->chain_ready = false; }
+  delete b;
+  return LVF_OK;
+}
 int lvf_problem_batch_size(const lvf_problem_batch* b) { return b ? b->W : -1; }
 int lvf_problem_batch_uses_tables(lvf_problem_batch* b, const lvf_solver_options* o) {
   if (!b || !o || lvf::enter(b->ctx) != LVF_OK || batch_build_tables(b, o->huber_a) != LVF_OK) return -1;
