@@ -48,6 +48,8 @@ struct lvf_problem {
   lvf::DevBuf<int> lm_eoff, n_slots, tf_slot, run_first;
   lvf::DevBuf<double> slotB, slabP, slabQ, Ct, grt;
   int band_rows = 64;           // landmark rows per slice of the band Schur complement (a batch uses more: fewer output atomics)
+  lvf::DevBuf<int2> band_work; lvf::DevBuf<int> n_band_work_dev; lvf::HostPin<int> h_n_band_work;
+  int n_band_work = 0, band_rows_built = 0;
   lvf::HostPin<int> h_run_first;
   lvf::DevBuf<unsigned long long> dbg, dbg_lin;
   lvf::DevBuf<double> sp_W, sp_L, Dinv;         // Dinv: L_kk^-T of every 64x64 diagonal block of the dense corner
@@ -1517,6 +1519,26 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     if (v != 0.0) atomicAdd(&S[(size_t)rws[r] * ld + rws[c2]], -v);
   }
 }
+// Work list of the band Schur complement: one item per (slice, tile group) that has tiles to form.  The 2-D grid slices x groups is sized
+// for the widest possible band, but most slices (short tracks) need one group: three quarters of its workgroups had nothing to do and
+// their dispatch — each needs its LDS slice — was most of the launch's span.  Built once per problem_configure (the bands are fixed).
+__global__ __launch_bounds__(64) void k_band_work(int rows, int dp, const int* __restrict__ n_active_p, const int* __restrict__ order,
+                                                  const int* __restrict__ kmin, const int* __restrict__ kmax, int2* __restrict__ work, int* __restrict__ n_work) {
+  const int n_active = *n_active_p, lane = threadIdx.x;
+  const int k_begin = blockIdx.x * rows, k_end = min(n_active, k_begin + rows);
+  if (k_begin >= k_end) return;
+  int lo = 0x7fffffff, hi = -1;
+  for (int r = k_begin + lane; r < k_end; r += 64) { const int l = order[r]; lo = min(lo, kmin[l]); hi = max(hi, kmax[l]); }
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+  if (lane == 0) {
+    const int t0 = (6 * lo) >> 4, t1 = (6 * hi + 5) >> 4, tl = dp >> 4, nbt = t1 - t0 + 1;
+    const int ntiles = nbt * (nbt + 1) / 2 + (tl > t1 ? nbt : 0);
+    const int groups = (ntiles + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
+    const int base = atomicAdd(n_work, groups);
+    for (int g = 0; g < groups; ++g) work[base + g] = make_int2((int)blockIdx.x, g);
+  }
+}
+
 struct SpArgs {          // one sparse level
   const SpNode* nodes; int first, tiles; const int* rows; double* S; int ld; double* W; int wstride; double* Lout; int* fail; int nblocks; const int* done;
 };
@@ -1536,9 +1558,18 @@ struct SchurSp0Args {
   int n_slices, n_groups, dp, ldE; const double *E, *Cd; const int *order, *n_active, *kmin, *kmax; int d_local, ldS; double* S_pose;
   SpArgs sp;             // level 0 (sp.nblocks == 0: Schur complement only)
   int nblocks; const int* done; unsigned long long* dbg; int rows;
+  const int2* work; int n_work;      // (slice, group) items; sparse level 0 runs in workgroups [0, sp.nblocks), the items behind
 };
 __device__ __forceinline__ void schur_sp0_body(const int b, const SchurSp0Args& A) {
   if (b >= A.nblocks || (A.done && *A.done)) return;
+  if (A.work) {
+    if (b < A.sp.nblocks) sp_eliminate_body(b, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail);
+    else {
+      const int2 it = A.work[b - A.sp.nblocks];
+      schur_band_body(it.x, it.y, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)(b - A.sp.nblocks) * 8 : nullptr, A.rows);
+    }
+    return;
+  }
   const int ns = A.n_slices * A.n_groups;
   if (b < ns) schur_band_body(b % A.n_slices, b / A.n_slices, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)b * 8 : nullptr, A.rows);
   else sp_eliminate_body(b - ns, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail);
@@ -2030,11 +2061,30 @@ static void fill_back_args(lvf_problem* p, BackArgs& ba, size_t* lds_bytes) {
   ba.Sd = p->S.p + (size_t)p->off * (p->ld + 1); ba.ld = p->ld; ba.d = p->ndense; ba.Dinv = p->Dinv.p; ba.xout = p->dxc.p; ba.sp = sb;
 }
 
+// the work list of the band Schur complement for the current rows-per-slice setting; its length is part of the launch grid
+static int ensure_band_work(lvf_problem* p) {
+  if (!p->band_ready || p->n_lm == 0 || p->band_rows_built == p->band_rows) return LVF_OK;
+  hipStream_t q = p->ctx->stream;
+  const int rows = std::min(kBandRowsMax, std::max(16, p->band_rows));
+  const int n_slices = (p->n_lm + rows - 1) / rows;
+  const int nt = p->ldE / 16, groups_max = (nt * (nt + 1) / 2 + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
+  LVF_TRY(p->band_work.ensure((size_t)n_slices * groups_max)); LVF_TRY(p->n_band_work_dev.ensure(1)); LVF_TRY(p->h_n_band_work.reserve(1));
+  LVF_HIP(hipMemsetAsync(p->n_band_work_dev.p, 0, sizeof(int), q));
+  hipLaunchKernelGGL(k_band_work, dim3(n_slices), dim3(64), 0, q, rows, p->dp, p->lm_nactive.p, p->lm_order.p, p->lm_kmin.p, p->lm_kmax.p, p->band_work.p, p->n_band_work_dev.p);
+  LVF_HIP(hipGetLastError());
+  LVF_HIP(hipMemcpyAsync(p->h_n_band_work.p, p->n_band_work_dev.p, sizeof(int), hipMemcpyDeviceToHost, q));
+  LVF_HIP(hipStreamSynchronize(q));
+  p->n_band_work = p->h_n_band_work[0];
+  p->band_rows_built = p->band_rows;
+  return LVF_OK;
+}
+
 // (re)builds the argument blocks of an iteration from the problem's CURRENT buffers (call after problem_configure / set_pose_priors)
 static int build_chain(lvf_problem* p) {
   if (!p->chain) p->chain = new Chain();
   Chain& c = *p->chain;
   c = Chain();
+  LVF_TRY(ensure_band_work(p));
   LVF_TRY(p->ctl.ensure(1));
   if (!p->rec) {
     void* h = nullptr;
@@ -2120,7 +2170,8 @@ static int build_chain(lvf_problem* p) {
       a.dbg = nullptr; a.n_active = p->lm_nactive.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p;
       a.d_local = p->dp; a.ldS = p->ld; a.S_pose = p->S.p + (size_t)p->off_pose * (p->ld + 1);
       a.sp = c.sp[0];
-      a.nblocks = a.n_slices * a.n_groups + c.sp[0].nblocks; a.done = done;
+      a.work = p->band_work.p; a.n_work = p->n_band_work;
+      a.nblocks = a.n_work + c.sp[0].nblocks; a.done = done;
       c.ssp0_lds = std::max(shb, (size_t)p->sp_shmem[0]);
       c.merged_level0 = true;
     }
@@ -2243,11 +2294,11 @@ static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool
     if (c.merged_level0) {
       SchurSp0Args sa = c.ssp0;
       if (!gated) sa.done = nullptr;
-      if (!level0_done) { sa.nblocks = sa.n_slices * sa.n_groups; sa.sp.nblocks = 0; }       // the Schur complement alone (parity tap)
+      if (!level0_done) { sa.nblocks = sa.n_work; sa.sp.nblocks = 0; }       // the Schur complement alone (parity tap)
       static const bool schur_timing = std::getenv("LVF_SCHUR_TIMING") != nullptr;
-      const int ns = sa.n_slices * sa.n_groups;
+      const int ns = sa.n_work;
       if (schur_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)ns * 8 + 8)); LVF_HIP(hipMemsetAsync(p->dbg_lin.p, 0, (size_t)ns * 64, q)); sa.dbg = p->dbg_lin.p; }
-      hipLaunchKernelGGL(k_schur_sp0, dim3(sa.nblocks), dim3(256), c.ssp0_lds, q, sa);
+      if (sa.nblocks > 0) hipLaunchKernelGGL(k_schur_sp0, dim3(sa.nblocks), dim3(256), c.ssp0_lds, q, sa);
       if (schur_timing) {
         std::vector<unsigned long long> t((size_t)ns * 8);
         LVF_HIP(hipStreamSynchronize(q));
@@ -2573,6 +2624,7 @@ int problem_configure(lvf_problem* p) {
                        p->lm_nactive.p);
     LVF_HIP(hipGetLastError());
     p->band_ready = true;
+    p->band_rows_built = 0;         // the bands changed: the work list is rebuilt with the next chain
     // compact landmark layout + slabs (atomic-free TwoFrame linearisation): needs the sorted work list, one block per (landmark,
     // keyframe), the landmark's first keyframe ahead of its observations, and the merged band-Schur launch
     static const bool compact_on = [] { const char* e = std::getenv("LVF_COMPACT"); return !(e && e[0] == '0'); }();
