@@ -1270,14 +1270,10 @@ static int launch_schur(hipStream_t q, int n_lm, int dp, int ldE, const double* 
 }
 
 // ------------------------------------------------------------------------------------------------ blocked Cholesky (64)
-// Right-looking, block 64, TWO launches per block step:
-//   k_chol_factor_panel : every workgroup (one wave) re-factors the 64x64 diagonal block in REGISTERS (lane i owns row i,
-//                         loops fully unrolled so the row lives in 128 VGPRs; column entries of other rows arrive as
-//                         v_readlane scalars), then solves its own 64x64 panel block X L^T = A row-per-lane against an
-//                         LDS copy of L (broadcast reads).  Redundant factorisation costs no wall time
-//                         (all waves run it concurrently) and removes a dependent launch.
-//   k_chol_update       : trailing A[bi][bj] -= P_bi P_bj^T.
-// The sequential critical path is ~64 x (sqrt + div + broadcast) per block; everything else is wide.
+// Right-looking, block 64, ONE launch per block step (k_chol_step): every workgroup of the step's column re-factors the 64x64 diagonal
+// block (redundantly: all of them run it concurrently, which removes a dependent launch) while its own panel block rides along in the
+// same sweep, and the trailing update of the previous step is folded into the same launch (chol_step_body).
+// The sequential critical path is ~64 x (rsqrt + broadcast) per block; everything else is wide.
 constexpr int kNB = 64, kLd = 65;
 
 __device__ __forceinline__ void load_row64(const double* __restrict__ g, double a[kNB]) {
@@ -1303,101 +1299,117 @@ __device__ __forceinline__ void store_row64(double* __restrict__ g, const double
 // L is published, x_rj = b_rj / L_jj is final and the row's later columns take the same rank-1 update with the same 16 broadcast
 // values the diagonal block reads anyway.  The separate 64-step forward substitution (9.3 us of dependent LDS round trips per
 // block step, after a 12.6 us factorisation) is gone; the sweep pays one more LDS write, one more read and 16 more FMAs per pivot.
-template <int Q>
-__device__ __forceinline__ bool factor_solve_columns(double a[16], double b[16], int r, double (*col)[kNB], double (*col2)[kNB]) {
+// Pivots are taken kPG at a time: the owning wave finishes a group of kPG columns on its own (the later columns of the group take the
+// earlier ones' rank-1 terms from registers and lane broadcasts), publishes them together, and the workgroup meets at ONE barrier per
+// group.  The sweep over the four column groups is a REAL loop (only the 16 pivots of a group are unrolled, which is what keeps a[]/b[]
+// in registers) and all four waves run the same code: fully unrolled per wave it was ~8000 straight-line instructions fetched once each,
+// and the instruction fetch — not the arithmetic — set the pace of the whole factorisation.
+constexpr int kPG = 2;
+__device__ __forceinline__ bool factor_solve_columns(double a[16], double b[16], const int r, const int Q, double (*col)[kPG][kNB], double (*col2)[kPG][kNB]) {
   bool bad = false;
+#pragma unroll 1
+  for (int qj = 0; qj < kNB / 16; ++qj) {
+    if (Q == qj) {                                   // this wave owns the pivots 16 qj .. 16 qj + 15
 #pragma unroll
-  for (int j = 0; j < kNB; ++j) {
-    const int qj = j >> 4, jj = j & 15, buf = j & 1;
-    if (Q == qj) {
-      const double djj = lane_bcast(a[jj], j);       // pivot A_jj sits in lane j (= row j) of this wave
-      bad |= !(djj > 0.0);
-      const double inv_l = rsqrt(fmax(djj, 1e-300));
-      a[jj] = (r == j) ? djj * inv_l : a[jj] * inv_l;
-      b[jj] *= inv_l;
-      col[buf][r] = a[jj];
-      col2[buf][r] = b[jj];
-    }
-    __syncthreads();
-    if (16 * Q + 15 > j) {
-      const double cr = col[buf][r], cr2 = col2[buf][r];
+      for (int jj0 = 0; jj0 < 16; jj0 += kPG) {
+        const int buf = (jj0 / kPG) & 1;
 #pragma unroll
-      for (int tt = 0; tt < 16; ++tt)
-        if (16 * Q + tt > j) {
-          const double l = col[buf][16 * Q + tt];
-          a[tt] -= cr * l;                            // A_rt -= L_rj L_tj (meaningful for r >= t)
-          b[tt] -= cr2 * l;                           // panel row: X_rt's running right-hand side
+        for (int g = 0; g < kPG; ++g) {
+          const int jj = jj0 + g, j = 16 * qj + jj;
+          const double djj = lane_bcast(a[jj], j);   // pivot A_jj sits in lane j (= row j) of this wave
+          bad |= !(djj > 0.0);
+          // 1/sqrt on the critical path of the whole factorisation: the hardware estimate plus one second-order correction (the
+          // library call adds range checks and two more dependent selects per pivot); a non-positive pivot is flagged above and its
+          // NaN/inf only lives until the step is rejected.  Lane j holds A_jj itself: scaling its entry gives L_jj with no select.
+          const double y0 = __builtin_amdgcn_rsq(djj);
+          const double e = fma(-djj * y0, y0, 1.0);
+          const double inv_l = fma(y0 * e, fma(e, 0.375, 0.5), y0);
+          a[jj] *= inv_l;
+          b[jj] *= inv_l;
+#pragma unroll
+          for (int h = g + 1; h < kPG; ++h) {
+            const double l = lane_bcast(a[jj], j + h - g);   // L_tj of row t = j0 + h
+            a[jj0 + h] -= a[jj] * l;
+            b[jj0 + h] -= b[jj] * l;
+          }
+          col[buf][g][r] = a[jj];
+          col2[buf][g][r] = b[jj];
         }
+        __syncthreads();
+        if (jj0 + kPG < 16) {
+          double cr[kPG], cr2[kPG];
+#pragma unroll
+          for (int g = 0; g < kPG; ++g) { cr[g] = col[buf][g][r]; cr2[g] = col2[buf][g][r]; }
+#pragma unroll
+          for (int tt = jj0 + kPG; tt < 16; ++tt)
+#pragma unroll
+            for (int g = 0; g < kPG; ++g) {
+              const double l = col[buf][g][16 * qj + tt];
+              a[tt] -= cr[g] * l;                     // A_rt -= L_rj L_tj (meaningful for r >= t)
+              b[tt] -= cr2[g] * l;                    // panel row: X_rt's running right-hand side
+            }
+        }
+      }
+    } else if (Q > qj) {                             // columns right of the group: every pivot of it updates all 16
+#pragma unroll
+      for (int jj0 = 0; jj0 < 16; jj0 += kPG) {
+        const int buf = (jj0 / kPG) & 1;
+        __syncthreads();
+        double cr[kPG], cr2[kPG];
+#pragma unroll
+        for (int g = 0; g < kPG; ++g) { cr[g] = col[buf][g][r]; cr2[g] = col2[buf][g][r]; }
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt)
+#pragma unroll
+          for (int g = 0; g < kPG; ++g) {
+            const double l = col[buf][g][16 * Q + tt];
+            a[tt] -= cr[g] * l;
+            b[tt] -= cr2[g] * l;
+          }
+      }
+    } else {                                         // columns left of the group are final: keep the barrier count
+#pragma unroll 1
+      for (int jj0 = 0; jj0 < 16; jj0 += kPG) __syncthreads();
     }
   }
   return bad;
 }
 
-// grid = 2 + (block rows below kb): workgroup 0 stores the factored diagonal block; workgroups 1..below solve their panel block
-// X L^T = A; the last workgroup solves against the identity and leaves L_kk^-T for the back substitution.
-struct CholArgs { double* Sd; int ld, nb; int* fail; double* Dinv; const int* done; };
-__device__ __forceinline__ void chol_factor_panel_body(const int bx, const CholArgs& A, const int kb) {
-  const int below = A.nb - kb - 1;
-  if (kb >= A.nb || bx >= 2 + below || (A.done && *A.done)) return;      // (workgroup-uniform: no barrier is skipped by part of a workgroup)
-  double* S = A.Sd; const int ld = A.ld; int* __restrict__ fail = A.fail; double* __restrict__ Dinv = A.Dinv;
-  __shared__ double col[2][kNB];
-  __shared__ double col2[2][kNB];
-  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
-  double a[16], b[16];
-  {
-    const double2* g2 = reinterpret_cast<const double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; a[2 * c] = v.x; a[2 * c + 1] = v.y; }
-  }
-  const bool inverse_wg = bx == 1 + below;
-  double* brow = inverse_wg ? Dinv + (size_t)kb * kNB * kNB + (size_t)r * kNB + 16 * q
-                            : S + (size_t)((kb + bx) * kNB + r) * ld + kb * kNB + 16 * q;
-  if (bx == 0) {
-#pragma unroll
-    for (int c = 0; c < 16; ++c) b[c] = 0.0;
-  } else if (inverse_wg) {
-#pragma unroll
-    for (int c = 0; c < 16; ++c) b[c] = (16 * q + c == r) ? 1.0 : 0.0;
-  } else {
-    const double2* g2 = reinterpret_cast<const double2*>(brow);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; b[2 * c] = v.x; b[2 * c + 1] = v.y; }
-  }
-  bool bad;
-  switch (q) {                                       // wave-uniform dispatch
-    case 0: bad = factor_solve_columns<0>(a, b, r, col, col2); break;
-    case 1: bad = factor_solve_columns<1>(a, b, r, col, col2); break;
-    case 2: bad = factor_solve_columns<2>(a, b, r, col, col2); break;
-    default: bad = factor_solve_columns<3>(a, b, r, col, col2); break;
-  }
-  if (bad && r == 0) atomicExch(fail, 1 + kb);
-  if (bx == 0) {
-#pragma unroll
-    for (int tt = 0; tt < 16; ++tt) if (16 * q + tt > r) a[tt] = 0.0;
-    double2* g2 = reinterpret_cast<double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) g2[c] = make_double2(a[2 * c], a[2 * c + 1]);
-    return;
-  }
-  double2* g2 = reinterpret_cast<double2*>(brow);
-#pragma unroll
-  for (int c = 0; c < 8; ++c) g2[c] = make_double2(b[2 * c], b[2 * c + 1]);
+// ONE launch per block step kb (grid = chol_step_grid):
+//   workgroups [0, 2 + below)  — the column of step kb.  For kb > 0 each first applies step kb-1's trailing update to the two tiles it
+//       reads, A_kk -= P_k P_k^T and A_ik -= P_i P_k^T (P = the panel of column kb-1, staged in LDS; v_mfma_f64_16x16x4_f64), instead of
+//       waiting for a separate update launch: two tile products (~3 us) on the dependent chain instead of a launch (~10 us).  Then as
+//       before: workgroup 0 stores the factored diagonal block; workgroups 1..below solve their panel block X L^T = A in the same sweep;
+//       the last workgroup solves against the identity and leaves L_kk^-T for the back substitution.
+//   workgroups behind them     — the rest of step kb-1's trailing update, A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi, which nothing in
+//       this launch reads (the next step does).
+struct CholArgs { double* Sd; int ld, nb; int* fail; double* Dinv; const int* done; unsigned long long* dbg; };   // dbg: LVF_CHOL_TIMING stamps
+__host__ __device__ inline int chol_step_grid(int nb, int kb) {
+  const int below = nb - kb - 1;
+  return kb >= nb ? 0 : 2 + below + (kb > 0 ? below * (below + 1) / 2 : 0);
 }
-__global__ __launch_bounds__(256) void k_chol_factor_panel(CholArgs a, int kb) { chol_factor_panel_body(blockIdx.x, a, kb); }
-__global__ __launch_bounds__(256) void k_chol_factor_panel_b(const CholArgs* __restrict__ t, int kb) { chol_factor_panel_body(blockIdx.x, t[blockIdx.y], kb); }
 
-// trailing update: A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi.  One workgroup per 64x64 tile; both 64x64 panels are
-// staged in LDS (row stride 65) and each of the 4 waves produces a 16x64 strip with v_mfma_f64_16x16x4_f64
+// stages the 64x64 block at g (leading dimension ld) into LDS with row stride kLd: all eight 16-byte loads of a thread are in flight
+// before the first LDS write (written as a loop the compiler waits for each load in turn: 8 x ~0.6 us of L2 latency)
+struct Stage64 { double2 v[8]; };
+__device__ __forceinline__ void stage_issue(const double* g, int ld, Stage64& t) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = threadIdx.x + 256 * i, rr = e >> 5, c = (e & 31) * 2;
+    t.v[i] = *reinterpret_cast<const double2*>(g + (size_t)rr * ld + c);
+  }
+}
+__device__ __forceinline__ void stage_commit(const Stage64& t, double* __restrict__ L) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = threadIdx.x + 256 * i, rr = e >> 5, c = (e & 31) * 2;
+    L[rr * kLd + c] = t.v[i].x; L[rr * kLd + c + 1] = t.v[i].y;
+  }
+}
+
+// trailing update of one tile: A[bi][bj] -= P_bi P_bj^T with the panels of column kp.  Each of the 4 waves produces a 16x64 strip
 // (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D: col = lane&15, row = (lane>>4) + 4 reg).
-__device__ __forceinline__ void chol_update_body(const int bx, const CholArgs& A, const int kb) {
-  const int below = A.nb - kb - 1;
-  if (below <= 0 || bx >= below * (below + 1) / 2 || (A.done && *A.done)) return;
-  double* S = A.Sd; const int ld = A.ld;
-  __shared__ double Pi[kNB * kLd];
-  __shared__ double Pj[kNB * kLd];
-  int t = bx, ii = 0;
-  while (t >= ii + 1) { t -= ii + 1; ++ii; }
-  const int bi = kb + 1 + ii, bj = kb + 1 + t;
+__device__ __forceinline__ void chol_update_tile(double* S, int ld, int kp, int bi, int bj, double* Pi, double* Pj) {
   // the tile being updated is requested FIRST (it does not depend on the product) so its round trip hides under the panel
   // staging and the matrix-core work; S is not __restrict__ so the loads stay where they are written
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lc = lane & 15;
@@ -1407,12 +1419,11 @@ __device__ __forceinline__ void chol_update_body(const int bx, const CholArgs& A
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) o[ct][rg] = out[(size_t)(lk + 4 * rg) * ld + 16 * ct + lc];
-  const double* pi = S + (size_t)(bi * kNB) * ld + kb * kNB;
-  const double* pj = S + (size_t)(bj * kNB) * ld + kb * kNB;
-  for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
-    const int rr = e >> 6, c = e & 63;
-    Pi[rr * kLd + c] = pi[(size_t)rr * ld + c];
-    Pj[rr * kLd + c] = pj[(size_t)rr * ld + c];
+  {
+    Stage64 si, sj;
+    stage_issue(S + (size_t)(bi * kNB) * ld + kp * kNB, ld, si);
+    stage_issue(S + (size_t)(bj * kNB) * ld + kp * kNB, ld, sj);
+    stage_commit(si, Pi); stage_commit(sj, Pj);
   }
   __syncthreads();
   double4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -1427,8 +1438,104 @@ __device__ __forceinline__ void chol_update_body(const int bx, const CholArgs& A
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) out[(size_t)(lk + 4 * rg) * ld + 16 * ct + lc] = o[ct][rg] - acc[ct][rg];
 }
-__global__ __launch_bounds__(256) void k_chol_update(CholArgs a, int kb) { chol_update_body(blockIdx.x, a, kb); }
-__global__ __launch_bounds__(256) void k_chol_update_b(const CholArgs* __restrict__ t, int kb) { chol_update_body(blockIdx.x, t[blockIdx.y], kb); }
+
+__device__ __forceinline__ void chol_step_body(const int bx, const CholArgs& A, const int kb) {
+  const int below = A.nb - kb - 1;
+  if (bx >= chol_step_grid(A.nb, kb) || (A.done && *A.done)) return;      // (workgroup-uniform: no barrier is skipped by part of a workgroup)
+  double* S = A.Sd; const int ld = A.ld; int* __restrict__ fail = A.fail; double* __restrict__ Dinv = A.Dinv;
+  __shared__ double Pi[kNB * kLd];
+  __shared__ double Pj[kNB * kLd];
+  __shared__ double col[2][kPG][kNB];
+  __shared__ double col2[2][kPG][kNB];
+  if (bx >= 2 + below) {                              // trailing tiles of step kb-1 right of column kb
+    int t = bx - (2 + below), ii = 0;
+    while (t >= ii + 1) { t -= ii + 1; ++ii; }
+    chol_update_tile(S, ld, kb - 1, kb + 1 + ii, kb + 1 + t, Pi, Pj);
+    return;
+  }
+  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
+  unsigned long long* dbg = (A.dbg && bx == 1 && tid == 0) ? A.dbg + 8 * kb : nullptr;
+  if (dbg) dbg[0] = wall_clock64();
+  double a[16], b[16];
+  {
+    const double2* g2 = reinterpret_cast<const double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; a[2 * c] = v.x; a[2 * c + 1] = v.y; }
+  }
+  const bool inverse_wg = bx == 1 + below, panel_wg = bx > 0 && !inverse_wg;
+  double* brow = inverse_wg ? Dinv + (size_t)kb * kNB * kNB + (size_t)r * kNB + 16 * q
+                            : S + (size_t)((kb + bx) * kNB + r) * ld + kb * kNB + 16 * q;
+  if (bx == 0) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) b[c] = 0.0;
+  } else if (inverse_wg) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) b[c] = (16 * q + c == r) ? 1.0 : 0.0;
+  } else {
+    const double2* g2 = reinterpret_cast<const double2*>(brow);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; b[2 * c] = v.x; b[2 * c + 1] = v.y; }
+  }
+  if (kb > 0) {
+    // step kb-1's update of the tiles just requested: wave w forms rows 16w..16w+15 of P_k P_k^T (lower tiles only) and of P_i P_k^T,
+    // the products go through LDS into the row-per-lane layout of the factorisation
+    const int lane = tid & 63, lk = lane >> 4, lc = lane & 15;
+    {
+      Stage64 si, sj;
+      stage_issue(S + (size_t)(kb * kNB) * ld + (kb - 1) * kNB, ld, sj);
+      if (panel_wg) stage_issue(S + (size_t)((kb + bx) * kNB) * ld + (kb - 1) * kNB, ld, si);
+      stage_commit(sj, Pj);
+      if (panel_wg) stage_commit(si, Pi);
+    }
+    __syncthreads();
+    if (dbg) dbg[1] = wall_clock64();
+    double4_t ad[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, ao[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int k0 = 0; k0 < kNB; k0 += 4) {
+      const double dv = Pj[(16 * q + lc) * kLd + k0 + lk];
+      const double ov = panel_wg ? Pi[(16 * q + lc) * kLd + k0 + lk] : 0.0;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const double bv = Pj[(16 * ct + lc) * kLd + k0 + lk];
+        if (ct <= q) ad[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv, bv, ad[ct], 0, 0, 0);
+        if (panel_wg) ao[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ov, bv, ao[ct], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                  // every wave is done reading the panels: the products take their place
+    if (dbg) dbg[2] = wall_clock64();
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        Pj[(16 * q + lk + 4 * rg) * kLd + 16 * ct + lc] = ad[ct][rg];
+        if (panel_wg) Pi[(16 * q + lk + 4 * rg) * kLd + 16 * ct + lc] = ao[ct][rg];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      a[c] -= Pj[r * kLd + 16 * q + c];              // (entries right of the diagonal are never read as values of A)
+      if (panel_wg) b[c] -= Pi[r * kLd + 16 * q + c];
+    }
+  }
+  if (dbg) dbg[3] = wall_clock64();
+  const bool bad = factor_solve_columns(a, b, r, q, col, col2);
+  if (dbg) dbg[4] = wall_clock64();
+  if (bad && r == 0) atomicExch(fail, 1 + kb);
+  if (bx == 0) {
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) if (16 * q + tt > r) a[tt] = 0.0;
+    double2* g2 = reinterpret_cast<double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) g2[c] = make_double2(a[2 * c], a[2 * c + 1]);
+    return;
+  }
+  double2* g2 = reinterpret_cast<double2*>(brow);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) g2[c] = make_double2(b[2 * c], b[2 * c + 1]);
+  if (dbg) dbg[5] = wall_clock64();
+}
+__global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int kb) { chol_step_body(blockIdx.x, a, kb); }
+__global__ __launch_bounds__(256) void k_chol_step_b(const CholArgs* __restrict__ t, int kb) { chol_step_body(blockIdx.x, t[blockIdx.y], kb); }
 
 // ------------------------------------------------------------------------------------------------ elimination order
 // The (v, ba, bg) blocks only meet each other and the poses through ImuError factors, i.e. along the IMU chain: block k touches
@@ -2335,9 +2442,10 @@ static int enqueue_iteration(lvf_problem* p) {
   for (int lv = level0_done ? 1 : 0; lv < c.n_levels; ++lv)
     hipLaunchKernelGGL(k_sp_eliminate, dim3(c.sp[lv].nblocks), dim3(256), c.sp_lds[lv], q, c.sp[lv]);
   for (int kb = 0; kb < p->nb; ++kb) {
-    const int below = p->nb - kb - 1;
-    hipLaunchKernelGGL(k_chol_factor_panel, dim3(2 + below), dim3(256), 0, q, c.chol, kb);
-    if (below > 0) hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, q, c.chol, kb);
+    CholArgs cha = c.chol;
+    static const bool chol_timing = std::getenv("LVF_CHOL_TIMING") != nullptr;
+    if (chol_timing) { LVF_TRY(p->dbg.ensure(64)); cha.dbg = p->dbg.p; }
+    hipLaunchKernelGGL(k_chol_step, dim3(chol_step_grid(p->nb, kb)), dim3(256), 0, q, cha, kb);
   }
   {
     BackArgs ba = c.back;
@@ -2398,6 +2506,16 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
   LVF_TRY(upload_ctl(p, c));
   LVF_TRY(enqueue_iteration(p));
   LVF_TRY(download_ctl(p, &c));
+  if (p->dbg.p && std::getenv("LVF_CHOL_TIMING")) {
+    unsigned long long t[64];
+    LVF_HIP(hipMemcpy(t, p->dbg.p, sizeof(t), hipMemcpyDeviceToHost));
+    for (int kb = 0; kb < p->nb && kb < 8; ++kb) {
+      const unsigned long long* u = t + 8 * kb;
+      if (kb == 0) std::fprintf(stderr, "chol step 0 (us): loads %.2f | factor %.2f | store %.2f\n", (double)(u[3] - u[0]) * 0.01, (double)(u[4] - u[3]) * 0.01, (double)(u[5] - u[4]) * 0.01);
+      else if (kb + 2 < p->nb + 1) std::fprintf(stderr, "chol step %d (us): stage %.2f | mfma %.2f | relayout %.2f | factor %.2f | store %.2f ; since previous step's end %.2f\n", kb, (double)(u[1] - u[0]) * 0.01,
+                        (double)(u[2] - u[1]) * 0.01, (double)(u[3] - u[2]) * 0.01, (double)(u[4] - u[3]) * 0.01, (double)(u[5] - u[4]) * 0.01, (double)(u[0] - u[-3]) * 0.01);
+    }
+  }
   if (p->dbg.p && std::getenv("LVF_BACK_TIMING")) {
     unsigned long long t[64];
     LVF_HIP(hipMemcpy(t, p->dbg.p, sizeof(t), hipMemcpyDeviceToHost));
@@ -2767,9 +2885,7 @@ static int batch_enqueue_iteration(lvf_problem_batch* b) {
   for (int lv = 1; lv < b->max_levels; ++lv)
     if (b->g_sp[lv] > 0) hipLaunchKernelGGL(k_sp_eliminate_b, dim3(b->g_sp[lv], W), dim3(256), b->lds_sp[lv], q, b->sp[lv].p);
   for (int kb = 0; kb < b->max_nb; ++kb) {
-    const int below = b->max_nb - kb - 1;
-    hipLaunchKernelGGL(k_chol_factor_panel_b, dim3(2 + below, W), dim3(256), 0, q, b->chol.p, kb);
-    if (below > 0) hipLaunchKernelGGL(k_chol_update_b, dim3(below * (below + 1) / 2, W), dim3(256), 0, q, b->chol.p, kb);
+    hipLaunchKernelGGL(k_chol_step_b, dim3(chol_step_grid(b->max_nb, kb), W), dim3(256), 0, q, b->chol.p, kb);
   }
   hipLaunchKernelGGL(k_chol_backsolve_b, dim3(1, W), dim3(kBT), b->lds_back, q, b->back.p);
   hipLaunchKernelGGL(k_step_tail_b, dim3(b->g_tail, W), dim3(kT), b->lds_tail, q, b->tail.p);
