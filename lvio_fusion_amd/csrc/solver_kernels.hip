@@ -1288,99 +1288,140 @@ __device__ __forceinline__ void store_row64(double* __restrict__ g, const double
 }
 
 
-// 256 threads.  Factor: thread (row r = tid & 63, wave q = tid >> 6) owns columns 16q..16q+15 of row r; per column j the
-// owning wave scales it and publishes it through a double-buffered LDS line (ONE barrier per column), then every wave
-// applies the rank-1 update to its own 16 columns (<= 16 FMAs per thread per column instead of up to 63 in one wave).
-// Panel: 4 adjacent lanes share one row of X (lane `part` holds x_t, t = 4 tt + part): the dot product of the forward
-// substitution is split 4 ways and combined with two quad shuffles, so a 64-step solve costs ~64 x (j/4 FMAs + shuffle).
-// the per-wave body of the diagonal-block factorisation; Q (the wave's column group) is a template parameter so that
-// every "is column t right of j" test folds at compile time and each wave only carries its own FMAs.
-// The workgroup's PANEL row rides along in the same sweep (b[16] = row r of the panel block, same column group): once column j of
-// L is published, x_rj = b_rj / L_jj is final and the row's later columns take the same rank-1 update with the same 16 broadcast
-// values the diagonal block reads anyway.  The separate 64-step forward substitution (9.3 us of dependent LDS round trips per
-// block step, after a 12.6 us factorisation) is gone; the sweep pays one more LDS write, one more read and 16 more FMAs per pivot.
-// Pivots are taken kPG at a time: the owning wave finishes a group of kPG columns on its own (the later columns of the group take the
-// earlier ones' rank-1 terms from registers and lane broadcasts), publishes them together, and the workgroup meets at ONE barrier per
-// group.  The sweep over the four column groups is a REAL loop (only the 16 pivots of a group are unrolled, which is what keeps a[]/b[]
-// in registers) and all four waves run the same code: fully unrolled per wave it was ~8000 straight-line instructions fetched once each,
-// and the instruction fetch — not the arithmetic — set the pace of the whole factorisation.
-constexpr int kPG = 2;
-__device__ __forceinline__ bool factor_solve_columns(double a[16], double b[16], const int r, const int Q, double (*col)[kPG][kNB], double (*col2)[kPG][kNB]) {
+// Factor + panel solve of one 64-wide block column by ONE workgroup of 512 threads = 8 waves, thread = row r = tid & 63:
+//   waves 0..3 ("diagonal" waves) hold the diagonal block, wave Q the columns 16Q..16Q+15 of every row;
+//   waves 4..7 ("panel" waves) hold the workgroup's panel block the same way; X L^T = A is solved in the same sweep: once column j of L
+//   is known, x_rj = b_rj / L_jj is final and the row's later columns take the rank-1 term x_rj L_tj.
+// One wave issues at most one VALU instruction per ~8 clocks (tools/ubench), so what a wave costs is its instruction count; the 64
+// pivots are a dependent chain through the diagonal waves, and everything that is not the chain is kept out of their instruction stream.
+// The wave-uniform operands L_tj of the rank-1 updates are fetched with ONE 8-byte LDS read per pivot (lane t of each 16-lane row takes
+// L_tj) and handed out by the DPP row_newbcast operand of v_fmac_f64: as 16-byte broadcast reads they occupied the LDS pipe for 8 clocks
+// each, 8 per pivot and wave, and that pipe — shared by all waves — set the pace (measured 375 clocks per pivot with 4 waves, 512 with
+// 8); through v_readlane + SGPR operands it was slower still (900).
+//   * pivots are taken kPG at a time: the owning wave finishes a group of kPG columns on its own (the later columns of the group take
+//     the earlier ones' rank-1 terms from registers and lane broadcasts) and publishes them (Lcol[j][r], 1/L_jj); the other diagonal
+//     waves apply a group ONE STEP after it was published, so the owner never waits for them: one workgroup barrier per step, at which
+//     the consumers — who have less to do per step — are already waiting when the owner arrives;
+//   * the panel arithmetic (three quarters of the flops) lives in its own four waves, which run one more step behind on the published
+//     columns: they share the barriers but never hold the chain up;
+//   * 1/sqrt is the hardware estimate plus one second-order correction (the library call adds range checks and two dependent selects
+//     per pivot); a non-positive pivot is flagged and its NaN/inf only lives until the step is rejected.  Lane j holds A_jj itself, so
+//     scaling its entry gives L_jj with no select.
+// acc += (lane N of each 16-lane row of lv) * m: the DPP row_newbcast operand of v_fmac_f64 hands a row-uniform value to all 16 lanes
+// inside the multiply-add itself (no LDS broadcast read, no v_readlane + SGPR operand)
+template <int N>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double lv, double m) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(lv), "v"(m), "n"(N));
+}
+// (`from` folds to a constant once the caller's loops are unrolled)
+__device__ __forceinline__ void rank1_row_bcast(const int from, double a[16], double lv, double m) {
+  asm volatile("s_nop 4");                           // (an EXEC change needs 5 wait states before a DPP read; inline asm is not hazard-checked)
+  if (from <= 0) fmac_row_bcast<0>(a[0], lv, m);
+  if (from <= 1) fmac_row_bcast<1>(a[1], lv, m);
+  if (from <= 2) fmac_row_bcast<2>(a[2], lv, m);
+  if (from <= 3) fmac_row_bcast<3>(a[3], lv, m);
+  if (from <= 4) fmac_row_bcast<4>(a[4], lv, m);
+  if (from <= 5) fmac_row_bcast<5>(a[5], lv, m);
+  if (from <= 6) fmac_row_bcast<6>(a[6], lv, m);
+  if (from <= 7) fmac_row_bcast<7>(a[7], lv, m);
+  if (from <= 8) fmac_row_bcast<8>(a[8], lv, m);
+  if (from <= 9) fmac_row_bcast<9>(a[9], lv, m);
+  if (from <= 10) fmac_row_bcast<10>(a[10], lv, m);
+  if (from <= 11) fmac_row_bcast<11>(a[11], lv, m);
+  if (from <= 12) fmac_row_bcast<12>(a[12], lv, m);
+  if (from <= 13) fmac_row_bcast<13>(a[13], lv, m);
+  if (from <= 14) fmac_row_bcast<14>(a[14], lv, m);
+  if (from <= 15) fmac_row_bcast<15>(a[15], lv, m);
+}
+constexpr int kPG = 2, kCT = 512, kGW = 16 / kPG;                    // pivots per group, threads, groups per wave
+struct FactorLds { double* Lcol; double* Xcol; double* Linv; };       // Lcol/Xcol: [64 columns][64 rows]
+
+// diagonal wave Q, steps s = kGW qj + i (i unrolled, qj a real loop: the code of one column group is reused four times).  In step s the
+// owner of group s runs its pivots while every other diagonal wave applies group s - 1 (published at the end of step s - 1); the
+// workgroup meets at one barrier per step.
+__device__ __forceinline__ bool factor_diag_wave(double a[16], const int r, const int Q, const FactorLds& F) {
   bool bad = false;
 #pragma unroll 1
-  for (int qj = 0; qj < kNB / 16; ++qj) {
-    if (Q == qj) {                                   // this wave owns the pivots 16 qj .. 16 qj + 15
+  for (int qj = 0; qj <= kNB / 16; ++qj) {
 #pragma unroll
-      for (int jj0 = 0; jj0 < 16; jj0 += kPG) {
-        const int buf = (jj0 / kPG) & 1;
+    for (int i = 0; i < kGW; ++i) {
+      if (qj == kNB / 16 && i > 0) break;
+      const int j0 = 16 * qj + kPG * i;                   // first pivot of group s
+      const int prev_owner = i > 0 ? qj : qj - 1;         // owner of group s - 1
+      if (j0 > 0 && prev_owner < Q) {                     // columns right of group s - 1: all 16
 #pragma unroll
         for (int g = 0; g < kPG; ++g) {
-          const int jj = jj0 + g, j = 16 * qj + jj;
-          const double djj = lane_bcast(a[jj], j);   // pivot A_jj sits in lane j (= row j) of this wave
+          const int j = j0 - kPG + g;
+          const double cr = F.Lcol[j * kNB + r], lv = F.Lcol[j * kNB + 16 * Q + (r & 15)];
+          rank1_row_bcast(0, a, lv, -cr);                 // A_rt -= L_rj L_tj (meaningful for r >= t)
+        }
+      }
+      if (qj == Q) {                                      // own group: pivots j0 .. j0 + kPG - 1
+#pragma unroll
+        for (int g = 0; g < kPG; ++g) {
+          const int jj = kPG * i + g, j = j0 + g;
+          const double djj = lane_bcast(a[jj], j);        // pivot A_jj sits in lane j (= row j) of this wave
           bad |= !(djj > 0.0);
-          // 1/sqrt on the critical path of the whole factorisation: the hardware estimate plus one second-order correction (the
-          // library call adds range checks and two more dependent selects per pivot); a non-positive pivot is flagged above and its
-          // NaN/inf only lives until the step is rejected.  Lane j holds A_jj itself: scaling its entry gives L_jj with no select.
           const double y0 = __builtin_amdgcn_rsq(djj);
           const double e = fma(-djj * y0, y0, 1.0);
           const double inv_l = fma(y0 * e, fma(e, 0.375, 0.5), y0);
           a[jj] *= inv_l;
-          b[jj] *= inv_l;
+          F.Lcol[j * kNB + r] = a[jj];
+          F.Linv[j] = inv_l;                              // (every lane stores the same value: no exec juggling on the chain)
 #pragma unroll
-          for (int h = g + 1; h < kPG; ++h) {
-            const double l = lane_bcast(a[jj], j + h - g);   // L_tj of row t = j0 + h
-            a[jj0 + h] -= a[jj] * l;
-            b[jj0 + h] -= b[jj] * l;
-          }
-          col[buf][g][r] = a[jj];
-          col2[buf][g][r] = b[jj];
+          for (int h = g + 1; h < kPG; ++h) a[kPG * i + h] -= a[jj] * lane_bcast(a[jj], j0 + h);
         }
-        __syncthreads();
-        if (jj0 + kPG < 16) {
-          double cr[kPG], cr2[kPG];
+        // the rest of this wave's own columns: L_tj of its own rows t comes back from the column it has just published
 #pragma unroll
-          for (int g = 0; g < kPG; ++g) { cr[g] = col[buf][g][r]; cr2[g] = col2[buf][g][r]; }
-#pragma unroll
-          for (int tt = jj0 + kPG; tt < 16; ++tt)
-#pragma unroll
-            for (int g = 0; g < kPG; ++g) {
-              const double l = col[buf][g][16 * qj + tt];
-              a[tt] -= cr[g] * l;                     // A_rt -= L_rj L_tj (meaningful for r >= t)
-              b[tt] -= cr2[g] * l;                    // panel row: X_rt's running right-hand side
-            }
-        }
+        for (int g = 0; g < kPG; ++g)
+          if (kPG * (i + 1) < 16) rank1_row_bcast(kPG * (i + 1), a, F.Lcol[(j0 + g) * kNB + 16 * Q + (r & 15)], -a[kPG * i + g]);
       }
-    } else if (Q > qj) {                             // columns right of the group: every pivot of it updates all 16
-#pragma unroll
-      for (int jj0 = 0; jj0 < 16; jj0 += kPG) {
-        const int buf = (jj0 / kPG) & 1;
-        __syncthreads();
-        double cr[kPG], cr2[kPG];
-#pragma unroll
-        for (int g = 0; g < kPG; ++g) { cr[g] = col[buf][g][r]; cr2[g] = col2[buf][g][r]; }
-#pragma unroll
-        for (int tt = 0; tt < 16; ++tt)
-#pragma unroll
-          for (int g = 0; g < kPG; ++g) {
-            const double l = col[buf][g][16 * Q + tt];
-            a[tt] -= cr[g] * l;
-            b[tt] -= cr2[g] * l;
-          }
-      }
-    } else {                                         // columns left of the group are final: keep the barrier count
-#pragma unroll 1
-      for (int jj0 = 0; jj0 < 16; jj0 += kPG) __syncthreads();
+      __syncthreads();
     }
   }
   return bad;
 }
 
-// ONE launch per block step kb (grid = chol_step_grid):
+// panel wave Q: owns the x columns 16Q..16Q+15 of its rows and runs one step behind the diagonal waves: in step s it applies the x
+// group s - 2 its left neighbours published in step s - 1, then — if it owns group s - 1 — finishes those x columns and publishes them.
+__device__ __forceinline__ void factor_panel_wave(double b[16], const int r, const int Q, const FactorLds& F) {
+#pragma unroll 1
+  for (int qj = 0; qj <= kNB / 16; ++qj) {
+#pragma unroll
+    for (int i = 0; i < kGW; ++i) {
+      if (qj == kNB / 16 && i > 0) break;
+      const int j0 = 16 * qj + kPG * i;
+      const int o2 = i > 1 ? qj : qj - 1;                 // owner of group s - 2
+      if (j0 >= 2 * kPG && o2 < Q) {
+#pragma unroll
+        for (int g = 0; g < kPG; ++g) {
+          const int j = j0 - 2 * kPG + g;
+          const double cx = F.Xcol[j * kNB + r], lv = F.Lcol[j * kNB + 16 * Q + (r & 15)];
+          rank1_row_bcast(0, b, lv, -cx);
+        }
+      }
+      const int o1 = i > 0 ? qj : qj - 1, i1 = (i + kGW - 1) % kGW;     // owner of group s - 1 and its index within the wave
+      if (j0 > 0 && o1 == Q) {
+#pragma unroll
+        for (int g = 0; g < kPG; ++g) {
+          const int jj = kPG * i1 + g, j = 16 * o1 + jj;
+          const double lv = F.Lcol[j * kNB + 16 * Q + (r & 15)];
+          b[jj] *= F.Linv[j];
+          F.Xcol[j * kNB + r] = b[jj];
+          if (jj + 1 < 16) rank1_row_bcast(jj + 1, b, lv, -b[jj]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ONE launch per block step kb (grid = chol_step_grid), 512 threads per workgroup:
 //   workgroups [0, 2 + below)  — the column of step kb.  For kb > 0 each first applies step kb-1's trailing update to the two tiles it
-//       reads, A_kk -= P_k P_k^T and A_ik -= P_i P_k^T (P = the panel of column kb-1, staged in LDS; v_mfma_f64_16x16x4_f64), instead of
-//       waiting for a separate update launch: two tile products (~3 us) on the dependent chain instead of a launch (~10 us).  Then as
-//       before: workgroup 0 stores the factored diagonal block; workgroups 1..below solve their panel block X L^T = A in the same sweep;
-//       the last workgroup solves against the identity and leaves L_kk^-T for the back substitution.
+//       reads, A_kk -= P_k P_k^T (diagonal waves) and A_ik -= P_i P_k^T (panel waves) (P = the panel of column kb-1, staged in LDS;
+//       v_mfma_f64_16x16x4_f64), instead of waiting for a separate update launch.  Then: workgroup 0 stores the factored diagonal
+//       block; workgroups 1..below solve their panel block X L^T = A; the last workgroup solves against the identity and leaves
+//       L_kk^-T for the back substitution.
 //   workgroups behind them     — the rest of step kb-1's trailing update, A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi, which nothing in
 //       this launch reads (the next step does).
 struct CholArgs { double* Sd; int ld, nb; int* fail; double* Dinv; const int* done; unsigned long long* dbg; };   // dbg: LVF_CHOL_TIMING stamps
@@ -1389,52 +1430,52 @@ __host__ __device__ inline int chol_step_grid(int nb, int kb) {
   return kb >= nb ? 0 : 2 + below + (kb > 0 ? below * (below + 1) / 2 : 0);
 }
 
-// stages the 64x64 block at g (leading dimension ld) into LDS with row stride kLd: all eight 16-byte loads of a thread are in flight
-// before the first LDS write (written as a loop the compiler waits for each load in turn: 8 x ~0.6 us of L2 latency)
+// staging of a 64x64 block at g (leading dimension ld) into LDS with row stride kLd by 256 threads (t = 0..255): all eight 16-byte
+// loads of a thread are in flight before the first LDS write (written as one loop the compiler waits for each load in turn)
 struct Stage64 { double2 v[8]; };
-__device__ __forceinline__ void stage_issue(const double* g, int ld, Stage64& t) {
+__device__ __forceinline__ void stage_issue(const double* g, int ld, int t, Stage64& st) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int e = threadIdx.x + 256 * i, rr = e >> 5, c = (e & 31) * 2;
-    t.v[i] = *reinterpret_cast<const double2*>(g + (size_t)rr * ld + c);
+    const int e = t + 256 * i, rr = e >> 5, c = (e & 31) * 2;
+    st.v[i] = *reinterpret_cast<const double2*>(g + (size_t)rr * ld + c);
   }
 }
-__device__ __forceinline__ void stage_commit(const Stage64& t, double* __restrict__ L) {
+__device__ __forceinline__ void stage_commit(const Stage64& st, int t, double* __restrict__ L) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int e = threadIdx.x + 256 * i, rr = e >> 5, c = (e & 31) * 2;
-    L[rr * kLd + c] = t.v[i].x; L[rr * kLd + c + 1] = t.v[i].y;
+    const int e = t + 256 * i, rr = e >> 5, c = (e & 31) * 2;
+    L[rr * kLd + c] = st.v[i].x; L[rr * kLd + c + 1] = st.v[i].y;
   }
 }
 
-// trailing update of one tile: A[bi][bj] -= P_bi P_bj^T with the panels of column kp.  Each of the 4 waves produces a 16x64 strip
-// (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D: col = lane&15, row = (lane>>4) + 4 reg).
+// trailing update of one tile: A[bi][bj] -= P_bi P_bj^T with the panels of column kp.  Wave wv produces rows 16 (wv & 3) .. + 15 of the
+// column half wv >> 2 (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D: col = lane&15, row = (lane>>4) + 4 reg).
 __device__ __forceinline__ void chol_update_tile(double* S, int ld, int kp, int bi, int bj, double* Pi, double* Pj) {
   // the tile being updated is requested FIRST (it does not depend on the product) so its round trip hides under the panel
   // staging and the matrix-core work; S is not __restrict__ so the loads stay where they are written
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lc = lane & 15;
-  double* out = S + (size_t)(bi * kNB + 16 * w) * ld + bj * kNB;
-  double o[4][4];
+  const int wv = threadIdx.x >> 6, w = wv & 3, ch = wv >> 2, lane = threadIdx.x & 63, lk = lane >> 4, lc = lane & 15;
+  double* out = S + (size_t)(bi * kNB + 16 * w) * ld + bj * kNB + 32 * ch;
+  double o[2][4];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
+  for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) o[ct][rg] = out[(size_t)(lk + 4 * rg) * ld + 16 * ct + lc];
   {
-    Stage64 si, sj;
-    stage_issue(S + (size_t)(bi * kNB) * ld + kp * kNB, ld, si);
-    stage_issue(S + (size_t)(bj * kNB) * ld + kp * kNB, ld, sj);
-    stage_commit(si, Pi); stage_commit(sj, Pj);
+    Stage64 st;
+    const int t = threadIdx.x & 255;
+    stage_issue(S + (size_t)((ch ? bj : bi) * kNB) * ld + kp * kNB, ld, t, st);
+    stage_commit(st, t, ch ? Pj : Pi);
   }
   __syncthreads();
-  double4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  double4_t acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
   for (int k0 = 0; k0 < kNB; k0 += 4) {
     const double av = Pi[(16 * w + lc) * kLd + k0 + lk];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pj[(16 * ct + lc) * kLd + k0 + lk], acc[ct], 0, 0, 0);
+    for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pj[(32 * ch + 16 * ct + lc) * kLd + k0 + lk], acc[ct], 0, 0, 0);
   }
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
+  for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) out[(size_t)(lk + 4 * rg) * ld + 16 * ct + lc] = o[ct][rg] - acc[ct][rg];
 }
@@ -1445,97 +1486,102 @@ __device__ __forceinline__ void chol_step_body(const int bx, const CholArgs& A, 
   double* S = A.Sd; const int ld = A.ld; int* __restrict__ fail = A.fail; double* __restrict__ Dinv = A.Dinv;
   __shared__ double Pi[kNB * kLd];
   __shared__ double Pj[kNB * kLd];
-  __shared__ double col[2][kPG][kNB];
-  __shared__ double col2[2][kPG][kNB];
+  __shared__ double Linv[kNB];
   if (bx >= 2 + below) {                              // trailing tiles of step kb-1 right of column kb
     int t = bx - (2 + below), ii = 0;
     while (t >= ii + 1) { t -= ii + 1; ++ii; }
     chol_update_tile(S, ld, kb - 1, kb + 1 + ii, kb + 1 + t, Pi, Pj);
     return;
   }
-  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
+  const int tid = threadIdx.x, r = tid & 63, wv = tid >> 6, q = wv & 3;
+  const bool panel_wave = wv >= 4;                    // wave-uniform
   unsigned long long* dbg = (A.dbg && bx == 1 && tid == 0) ? A.dbg + 8 * kb : nullptr;
   if (dbg) dbg[0] = wall_clock64();
-  double a[16], b[16];
-  {
-    const double2* g2 = reinterpret_cast<const double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; a[2 * c] = v.x; a[2 * c + 1] = v.y; }
-  }
   const bool inverse_wg = bx == 1 + below, panel_wg = bx > 0 && !inverse_wg;
   double* brow = inverse_wg ? Dinv + (size_t)kb * kNB * kNB + (size_t)r * kNB + 16 * q
                             : S + (size_t)((kb + bx) * kNB + r) * ld + kb * kNB + 16 * q;
-  if (bx == 0) {
+  double* drow = S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q;
+  double a[16];                                       // diagonal waves: row r of A_kk; panel waves: row r of the panel block / identity
+  if (!panel_wave || panel_wg) {
+    const double2* g2 = reinterpret_cast<const double2*>(panel_wave ? brow : drow);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) b[c] = 0.0;
-  } else if (inverse_wg) {
-#pragma unroll
-    for (int c = 0; c < 16; ++c) b[c] = (16 * q + c == r) ? 1.0 : 0.0;
+    for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; a[2 * c] = v.x; a[2 * c + 1] = v.y; }
   } else {
-    const double2* g2 = reinterpret_cast<const double2*>(brow);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { const double2 v = g2[c]; b[2 * c] = v.x; b[2 * c + 1] = v.y; }
+    for (int c = 0; c < 16; ++c) a[c] = (inverse_wg && 16 * q + c == r) ? 1.0 : 0.0;
   }
   if (kb > 0) {
-    // step kb-1's update of the tiles just requested: wave w forms rows 16w..16w+15 of P_k P_k^T (lower tiles only) and of P_i P_k^T,
-    // the products go through LDS into the row-per-lane layout of the factorisation
+    // step kb-1's update of the tiles just requested: diagonal wave q forms rows 16q..16q+15 of P_k P_k^T (lower tiles only), panel wave q
+    // those of P_i P_k^T; the products go through LDS into the row-per-lane layout of the factorisation
     const int lane = tid & 63, lk = lane >> 4, lc = lane & 15;
     {
-      Stage64 si, sj;
-      stage_issue(S + (size_t)(kb * kNB) * ld + (kb - 1) * kNB, ld, sj);
-      if (panel_wg) stage_issue(S + (size_t)((kb + bx) * kNB) * ld + (kb - 1) * kNB, ld, si);
-      stage_commit(sj, Pj);
-      if (panel_wg) stage_commit(si, Pi);
+      Stage64 st;
+      const int t = tid & 255;
+      const bool mine = !panel_wave || panel_wg;
+      if (mine) stage_issue(S + (size_t)((panel_wave ? kb + bx : kb) * kNB) * ld + (kb - 1) * kNB, ld, t, st);
+      if (mine) stage_commit(st, t, panel_wave ? Pi : Pj);
     }
     __syncthreads();
     if (dbg) dbg[1] = wall_clock64();
-    double4_t ad[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, ao[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    // 10 lower tiles of P_k P_k^T + (panel workgroups) 16 tiles of P_i P_k^T, dealt round-robin to the 8 waves (two waves share a SIMD's
+    // matrix pipe: 6.5 tile products per SIMD instead of up to 8 with one strip per wave)
+    const int n_tiles = panel_wg ? 26 : 10;
+    double4_t ac[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    int t_m[4], t_c[4]; bool t_own[4];
 #pragma unroll
-    for (int k0 = 0; k0 < kNB; k0 += 4) {
-      const double dv = Pj[(16 * q + lc) * kLd + k0 + lk];
-      const double ov = panel_wg ? Pi[(16 * q + lc) * kLd + k0 + lk] : 0.0;
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const double bv = Pj[(16 * ct + lc) * kLd + k0 + lk];
-        if (ct <= q) ad[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv, bv, ad[ct], 0, 0, 0);
-        if (panel_wg) ao[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ov, bv, ao[ct], 0, 0, 0);
-      }
+    for (int n = 0; n < 4; ++n) {
+      const int t = wv + 8 * n;
+      t_own[n] = t >= 10;
+      if (t_own[n]) { t_m[n] = (t - 10) >> 2; t_c[n] = (t - 10) & 3; }
+      else { int m = 0, u = t; while (u > m) { u -= m + 1; ++m; } t_m[n] = m; t_c[n] = u; }
     }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      if (wv + 8 * n < n_tiles) {
+        const double* Pa = (t_own[n] ? Pi : Pj) + (16 * t_m[n] + lc) * kLd + lk;
+        const double* Pb = Pj + (16 * t_c[n] + lc) * kLd + lk;
+#pragma unroll
+        for (int k0 = 0; k0 < kNB; k0 += 4) ac[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[k0], Pb[k0], ac[n], 0, 0, 0);
+      }
     __syncthreads();                                  // every wave is done reading the panels: the products take their place
     if (dbg) dbg[2] = wall_clock64();
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int n = 0; n < 4; ++n)
+      if (wv + 8 * n < n_tiles) {
+        double* Pw = t_own[n] ? Pi : Pj;
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        Pj[(16 * q + lk + 4 * rg) * kLd + 16 * ct + lc] = ad[ct][rg];
-        if (panel_wg) Pi[(16 * q + lk + 4 * rg) * kLd + 16 * ct + lc] = ao[ct][rg];
+        for (int rg = 0; rg < 4; ++rg) Pw[(16 * t_m[n] + lk + 4 * rg) * kLd + 16 * t_c[n] + lc] = ac[n][rg];
       }
     __syncthreads();
+    const double* Pw = panel_wave ? Pi : Pj;
+    if (!panel_wave || panel_wg)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      a[c] -= Pj[r * kLd + 16 * q + c];              // (entries right of the diagonal are never read as values of A)
-      if (panel_wg) b[c] -= Pi[r * kLd + 16 * q + c];
-    }
+      for (int c = 0; c < 16; ++c) a[c] -= Pw[r * kLd + 16 * q + c];     // (entries right of the diagonal are never read as values of A)
+    __syncthreads();                                  // the factorisation reuses both buffers
   }
-  if (dbg) dbg[3] = wall_clock64();
-  const bool bad = factor_solve_columns(a, b, r, q, col, col2);
-  if (dbg) dbg[4] = wall_clock64();
+  if (dbg) { dbg[3] = wall_clock64(); dbg[6] = clock64(); }
+  const FactorLds F{Pi, Pj, Linv};
+  bool bad = false;
+  if (panel_wave) factor_panel_wave(a, r, q, F);
+  else bad = factor_diag_wave(a, r, q, F);
+  if (dbg) { dbg[4] = wall_clock64(); dbg[7] = clock64(); }
   if (bad && r == 0) atomicExch(fail, 1 + kb);
-  if (bx == 0) {
+  if (bx == 0 && !panel_wave) {
 #pragma unroll
     for (int tt = 0; tt < 16; ++tt) if (16 * q + tt > r) a[tt] = 0.0;
-    double2* g2 = reinterpret_cast<double2*>(S + (size_t)(kb * kNB + r) * ld + kb * kNB + 16 * q);
+    double2* g2 = reinterpret_cast<double2*>(drow);
 #pragma unroll
     for (int c = 0; c < 8; ++c) g2[c] = make_double2(a[2 * c], a[2 * c + 1]);
-    return;
   }
-  double2* g2 = reinterpret_cast<double2*>(brow);
+  if (bx > 0 && panel_wave) {
+    double2* g2 = reinterpret_cast<double2*>(brow);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) g2[c] = make_double2(b[2 * c], b[2 * c + 1]);
+    for (int c = 0; c < 8; ++c) g2[c] = make_double2(a[2 * c], a[2 * c + 1]);
+  }
   if (dbg) dbg[5] = wall_clock64();
 }
-__global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int kb) { chol_step_body(blockIdx.x, a, kb); }
-__global__ __launch_bounds__(256) void k_chol_step_b(const CholArgs* __restrict__ t, int kb) { chol_step_body(blockIdx.x, t[blockIdx.y], kb); }
+__global__ __launch_bounds__(kCT) void k_chol_step(CholArgs a, int kb) { chol_step_body(blockIdx.x, a, kb); }
+__global__ __launch_bounds__(kCT) void k_chol_step_b(const CholArgs* __restrict__ t, int kb) { chol_step_body(blockIdx.x, t[blockIdx.y], kb); }
 
 // ------------------------------------------------------------------------------------------------ elimination order
 // The (v, ba, bg) blocks only meet each other and the poses through ImuError factors, i.e. along the IMU chain: block k touches
@@ -2445,7 +2491,7 @@ static int enqueue_iteration(lvf_problem* p) {
     CholArgs cha = c.chol;
     static const bool chol_timing = std::getenv("LVF_CHOL_TIMING") != nullptr;
     if (chol_timing) { LVF_TRY(p->dbg.ensure(64)); cha.dbg = p->dbg.p; }
-    hipLaunchKernelGGL(k_chol_step, dim3(chol_step_grid(p->nb, kb)), dim3(256), 0, q, cha, kb);
+    hipLaunchKernelGGL(k_chol_step, dim3(chol_step_grid(p->nb, kb)), dim3(kCT), 0, q, cha, kb);
   }
   {
     BackArgs ba = c.back;
@@ -2511,7 +2557,7 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
     LVF_HIP(hipMemcpy(t, p->dbg.p, sizeof(t), hipMemcpyDeviceToHost));
     for (int kb = 0; kb < p->nb && kb < 8; ++kb) {
       const unsigned long long* u = t + 8 * kb;
-      if (kb == 0) std::fprintf(stderr, "chol step 0 (us): loads %.2f | factor %.2f | store %.2f\n", (double)(u[3] - u[0]) * 0.01, (double)(u[4] - u[3]) * 0.01, (double)(u[5] - u[4]) * 0.01);
+      if (kb == 0) std::fprintf(stderr, "chol step 0 (us): loads %.2f | factor %.2f (%llu shader clocks) | store %.2f\n", (double)(u[3] - u[0]) * 0.01, (double)(u[4] - u[3]) * 0.01, u[7] - u[6], (double)(u[5] - u[4]) * 0.01);
       else if (kb + 2 < p->nb + 1) std::fprintf(stderr, "chol step %d (us): stage %.2f | mfma %.2f | relayout %.2f | factor %.2f | store %.2f ; since previous step's end %.2f\n", kb, (double)(u[1] - u[0]) * 0.01,
                         (double)(u[2] - u[1]) * 0.01, (double)(u[3] - u[2]) * 0.01, (double)(u[4] - u[3]) * 0.01, (double)(u[5] - u[4]) * 0.01, (double)(u[0] - u[-3]) * 0.01);
     }
@@ -2885,7 +2931,7 @@ static int batch_enqueue_iteration(lvf_problem_batch* b) {
   for (int lv = 1; lv < b->max_levels; ++lv)
     if (b->g_sp[lv] > 0) hipLaunchKernelGGL(k_sp_eliminate_b, dim3(b->g_sp[lv], W), dim3(256), b->lds_sp[lv], q, b->sp[lv].p);
   for (int kb = 0; kb < b->max_nb; ++kb) {
-    hipLaunchKernelGGL(k_chol_step_b, dim3(chol_step_grid(b->max_nb, kb), W), dim3(256), 0, q, b->chol.p, kb);
+    hipLaunchKernelGGL(k_chol_step_b, dim3(chol_step_grid(b->max_nb, kb), W), dim3(kCT), 0, q, b->chol.p, kb);
   }
   hipLaunchKernelGGL(k_chol_backsolve_b, dim3(1, W), dim3(kBT), b->lds_back, q, b->back.p);
   hipLaunchKernelGGL(k_step_tail_b, dim3(b->g_tail, W), dim3(kT), b->lds_tail, q, b->tail.p);
