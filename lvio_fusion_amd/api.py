@@ -545,6 +545,14 @@ class Problem:
         _chk(self.ctx.L.lvf_problem_solve(self.h, C.byref(opt), C.byref(s)))
         return s
 
+    def stage_times(self, opt, radius=1e4, reps=10):
+        """[(stage name, average microseconds, launches)] of `reps` LM iterations from the current state (HIP events between stages)."""
+        L = self.ctx.L
+        n = L.lvf_problem_stage_count()
+        us = np.zeros(n); la = (C.c_int * n)()
+        _chk(L.lvf_problem_stage_times(self.h, C.byref(opt), float(radius), int(reps), _dp(us), la))
+        return [(L.lvf_problem_stage_name(i).decode(), float(us[i]), int(la[i])) for i in range(n)]
+
     def gradient(self, opt):
         d = self.ctx.L.lvf_problem_reduced_dim(self.h)
         gc = np.empty(d); gl = np.empty(max(self.state.n_lm, 1))

@@ -22,6 +22,7 @@ namespace lvf {
 struct TfWork;
 struct LmCtl;
 struct Chain;
+struct StageClock;
 // one (v, ba, bg) block eliminated ahead of the dense factorisation: its 9 columns start at `col`, its `m` neighbour rows
 // (later-ordered (v, ba, bg) blocks, poses, the augmented row; ascending) sit at rows[row_off .. row_off + m)
 struct SpNode { int col, row_off, m, id; };
@@ -47,6 +48,7 @@ struct lvf_problem {
   bool compact = false;
   lvf::DevBuf<int> lm_eoff, n_slots, tf_slot, run_first;
   lvf::DevBuf<double> slotB, slabP, slabQ, Ct, grt;
+  lvf::StageClock* clk = nullptr;     // lvf_problem_stage_times
   int band_rows = 64;           // landmark rows per slice of the band Schur complement (a batch uses more: fewer output atomics)
   lvf::DevBuf<int2> band_work; lvf::DevBuf<int> n_band_work_dev; lvf::HostPin<int> h_n_band_work;
   int n_band_work = 0, band_rows_built = 0;
@@ -2130,9 +2132,11 @@ struct Chain {
   DecideArgs dec{};
 };
 
+void stage_clock_free(StageClock* k);
 }  // namespace lvf
 lvf_problem::~lvf_problem() {
   delete chain;
+  lvf::stage_clock_free(clk);
   if (rec) (void)hipHostFree(rec);
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
 }
@@ -2363,6 +2367,23 @@ static bool chain_stale(const lvf_problem* p) {
 }
 
 // the linearisation at the current state: cost, B, gc, E, C, gr.  `gated`: skipped on device once the LM loop has finished
+// HIP events between the stages of one LM iteration (lvf_problem_stage_times): event 0 before the first launch, event k + 1 after stage k
+enum { ST_IMU_LIN = 0, ST_LIN_VISUAL, ST_TF_REDUCE, ST_PREPARE, ST_SCHUR_SP0, ST_SP_LEVELS, ST_CHOL, ST_BACKSOLVE, ST_STEP_TAIL, ST_COST, ST_DECIDE, ST_N };
+static const char* const kStageNames[ST_N] = {"k_imu<true> (+accumulator zeroing)", "k_lin_visual", "k_tf_reduce", "k_prepare", "k_schur_sp0", "k_sp_eliminate (levels 1..)",
+                                             "k_chol_step (all block steps)", "k_chol_backsolve", "k_step_tail", "k_cost_visual + k_imu<false> (+priors)", "k_lm_decide"};
+struct StageClock { hipEvent_t ev[ST_N + 1]; int launches[ST_N]; bool on = false; };
+void stage_clock_free(StageClock* k) {
+  if (!k) return;
+  for (auto& e : k->ev) (void)hipEventDestroy(e);
+  delete k;
+}
+static inline void stage_mark(lvf_problem* p, int stage_done, int launches) {
+  StageClock* k = p->clk;
+  if (!k || !k->on) return;
+  (void)hipEventRecord(k->ev[stage_done + 1], p->ctx->stream);
+  k->launches[stage_done] = launches;
+}
+
 static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
   hipStream_t q = p->ctx->stream;
   if (chain_stale(p)) LVF_TRY(build_chain(p));
@@ -2373,6 +2394,7 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
   // the accumulators are zeroed by extra workgroups of the IMU evaluation launch when there is one ahead of the merged linearisation
   // (neither depends on the other); otherwise by a launch of their own
   const bool zero_with_imu = c.fast && c.has_imu;
+  if (p->clk && p->clk->on) (void)hipEventRecord(p->clk->ev[0], q);
   if (!zero_with_imu) hipLaunchKernelGGL(k_zero_multi, dim3(512, c.zero.count), dim3(kT), 0, q, c.zero);
   if (c.fast) {
     if (c.has_imu) {
@@ -2381,17 +2403,20 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
       LVF_TRY(launch_imu_args(q, ia, true));   // residuals + Jacobians (+ the zeroing) first; their accumulation rides in the launch below
       imu_done = true;
     }
+    stage_mark(p, ST_IMU_LIN, c.has_imu ? 1 : 0);
     LinArgs la = c.lin;
     la.huber = huber;
     if (!gated) la.done = nullptr;
     static const bool lin_timing = std::getenv("LVF_LIN_TIMING") != nullptr;
     if (lin_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)la.v.n_tfw * 8 + 8)); la.dbg = p->dbg_lin.p; }
     hipLaunchKernelGGL(k_lin_visual, dim3(la.nblocks), dim3(kT), c.lin_lds, q, la);
+    stage_mark(p, ST_LIN_VISUAL, 1);
     if (p->compact) {
       TfReduceArgs ra = c.red;
       if (!gated) ra.done = nullptr;
       hipLaunchKernelGGL(k_tf_reduce, dim3(ra.nblocks), dim3(kT), 0, q, ra);
     }
+    stage_mark(p, ST_TF_REDUCE, p->compact ? 1 : 0);
     if (lin_timing) {
       std::vector<unsigned long long> t((size_t)la.v.n_tfw * 8);
       LVF_HIP(hipStreamSynchronize(q));
@@ -2442,6 +2467,7 @@ static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool
   if (!reset_scalars) pa.scal = nullptr;
   if (!gated) pa.done = nullptr;
   hipLaunchKernelGGL(k_prepare, dim3(pa.nblocks), dim3(kT), 0, q, pa);
+  stage_mark(p, ST_PREPARE, 1);
   if (level0_done) *level0_done = false;
   if (p->n_lm) {
     if (c.merged_level0) {
@@ -2452,6 +2478,7 @@ static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool
       const int ns = sa.n_work;
       if (schur_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)ns * 8 + 8)); LVF_HIP(hipMemsetAsync(p->dbg_lin.p, 0, (size_t)ns * 64, q)); sa.dbg = p->dbg_lin.p; }
       if (sa.nblocks > 0) hipLaunchKernelGGL(k_schur_sp0, dim3(sa.nblocks), dim3(256), c.ssp0_lds, q, sa);
+      stage_mark(p, ST_SCHUR_SP0, 1);
       if (schur_timing) {
         std::vector<unsigned long long> t((size_t)ns * 8);
         LVF_HIP(hipStreamSynchronize(q));
@@ -2487,6 +2514,7 @@ static int enqueue_iteration(lvf_problem* p) {
   LVF_TRY(enqueue_reduced_system(p, &p->ctl.p->radius, true, true, &level0_done));
   for (int lv = level0_done ? 1 : 0; lv < c.n_levels; ++lv)
     hipLaunchKernelGGL(k_sp_eliminate, dim3(c.sp[lv].nblocks), dim3(256), c.sp_lds[lv], q, c.sp[lv]);
+  stage_mark(p, ST_SP_LEVELS, c.n_levels - (level0_done ? 1 : 0));
   for (int kb = 0; kb < p->nb; ++kb) {
     CholArgs cha = c.chol;
     static const bool chol_timing = std::getenv("LVF_CHOL_TIMING") != nullptr;
@@ -2497,9 +2525,12 @@ static int enqueue_iteration(lvf_problem* p) {
     BackArgs ba = c.back;
     static const bool back_timing = std::getenv("LVF_BACK_TIMING") != nullptr;
     if (back_timing) { LVF_TRY(p->dbg.ensure(64)); ba.sp.dbg = p->dbg.p; }
+    stage_mark(p, ST_CHOL, p->nb);
     hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(kBT), c.back_lds, q, ba);
+    stage_mark(p, ST_BACKSOLVE, 1);
   }
   hipLaunchKernelGGL(k_step_tail, dim3(c.tail.nblocks), dim3(kT), c.tail_lds, q, c.tail);
+  stage_mark(p, ST_STEP_TAIL, 1);
   // candidate cost
   CostArgs ca = c.cost;
   ca.huber = p->huber;
@@ -2510,7 +2541,9 @@ static int enqueue_iteration(lvf_problem* p) {
     LVF_TRY(launch_pose_prior(p->prior, &view.v, false));
     hipLaunchKernelGGL(k_cost_sq, dim3(grid(6 * p->prior->n)), dim3(kT), 0, q, 6 * p->prior->n, p->prior->res.p, p->scal.p + SC_COST_NEW);
   }
+  stage_mark(p, ST_COST, (ca.nblocks > 0 ? 1 : 0) + (c.has_imu ? 1 : 0) + (c.has_prior ? 2 : 0));
   hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(kDT), 0, q, c.dec);
+  stage_mark(p, ST_DECIDE, 1);
   LVF_HIP(hipGetLastError());
   return LVF_OK;
 }
@@ -3016,6 +3049,44 @@ int lvf_problem_cost(lvf_problem* p, const lvf_solver_options* o, double* cost) 
 // Problem::Evaluate's gradient: J^T r with the loss function's Corrector applied and pose blocks in tangent coordinates, at the current
 // state — exactly what the linearisation accumulates.  gc [15 n_kf] in the reduced-system order (6 x n_kf pose tangents | 9 x n_kf (v, ba, bg)),
 // gl [n_lm] (may be NULL) the inverse-depth entries.
+int lvf_problem_stage_count(void) { return ST_N; }
+const char* lvf_problem_stage_name(int stage) { return stage >= 0 && stage < ST_N ? kStageNames[stage] : ""; }
+
+// `reps` LM iterations from the problem's current state (they ARE iterations: accepted steps move the state), HIP events on the
+// library's stream between the stages; us[k] = average duration of stage k, launches[k] = kernel launches it consists of.
+int lvf_problem_stage_times(lvf_problem* p, const lvf_solver_options* o, double radius, int reps, double* us, int* launches) {
+  LVF_REQUIRE(p && o && us && reps > 0, "lvf_problem_stage_times: bad argument");
+  LVF_TRY(lvf::enter(p->ctx));
+  hipStream_t q = p->ctx->stream;
+  if (!p->clk) {
+    p->clk = new StageClock();
+    for (auto& e : p->clk->ev) LVF_HIP(hipEventCreate(&e));
+  }
+  StageClock& k = *p->clk;
+  for (int i = 0; i < ST_N; ++i) { us[i] = 0.0; k.launches[i] = 0; }
+  LmCtl c;
+  ctl_from_options(o, radius, 2.0, reps + 1, false, &c);
+  p->huber = o->huber_a;
+  LVF_TRY(upload_ctl(p, c));
+  for (int r = 0; r < reps; ++r) {
+    k.on = true;
+    const int rc = enqueue_iteration(p);
+    k.on = false;
+    LVF_TRY(rc);
+    LVF_HIP(hipStreamSynchronize(q));
+    for (int i = 0; i < ST_N; ++i) {
+      if (k.launches[i] == 0) continue;
+      int prev = i;                                   // the event after the closest earlier stage that launched something (or event 0)
+      while (prev > 0 && k.launches[prev - 1] == 0) --prev;
+      float ms = 0.f;
+      LVF_HIP(hipEventElapsedTime(&ms, k.ev[prev], k.ev[i + 1]));
+      us[i] += 1e3 * (double)ms / reps;
+    }
+  }
+  if (launches) for (int i = 0; i < ST_N; ++i) launches[i] = k.launches[i];
+  return LVF_OK;
+}
+
 int lvf_problem_gradient(lvf_problem* p, const lvf_solver_options* o, double* gc, double* gl) {
   LVF_REQUIRE(p && o && gc, "lvf_problem_gradient: null argument");
   LVF_TRY(lvf::enter(p->ctx));

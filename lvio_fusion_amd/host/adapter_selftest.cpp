@@ -154,7 +154,8 @@ static int run_window(const std::string& dir) {
     std::vector<double> res1, grad;
     ceres::CRSMatrix jac;
     if (!gpu::Evaluate(&problem, eo, &cost1, &res1, &grad, &jac, &err)) { std::fprintf(stderr, "Evaluate (CRS) failed: %s\n", err.c_str()); return 1; }
-    if (cost1 != cost0) { std::fprintf(stderr, "Evaluate: cost differs between the two forms\n"); return 1; }
+    // (sums of ~10^5 blocks through atomics: the order, hence the last bits, differs from launch to launch)
+    if (std::fabs(cost1 - cost0) > 1e-11 * std::fabs(cost0)) { std::fprintf(stderr, "Evaluate: cost differs between the two forms (%.17g vs %.17g)\n", cost0, cost1); return 1; }
     wr(dir, "out_eval_residuals.f64", res1); wr(dir, "out_eval_gradient.f64", grad); wr(dir, "out_crs_values.f64", jac.values);
     wri(dir, "out_crs_rows.i32", jac.rows); wri(dir, "out_crs_cols.i32", jac.cols);
     crs_rows = jac.num_rows; crs_cols = jac.num_cols;

@@ -57,7 +57,7 @@ def pmc(d, label):
 def pmc_json(root, tag):
     """per-kernel average counters of all PMC passes -> dict for profiles/pmc_latest.json (read by bench.py's roofline.traffic)"""
     out = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_l2"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_mfma"):
         f = find(os.path.join(root, sub), "counter_collection.csv")
         if not f:
             continue
@@ -78,8 +78,10 @@ if __name__ == "__main__":
         print(json.dumps(pmc_json(root, os.path.basename(root.rstrip("/"))), indent=1))
         sys.exit(0)
     kernel_stats(os.path.join(root, "trace"))
-    for sub, label in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_l2", "TCC_HIT_sum TCC_MISS_sum")):
-        pmc(os.path.join(root, sub), label)
+    for sub, label in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_l2", "TCC_HIT_sum TCC_MISS_sum"),
+                       ("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE")):
+        if os.path.isdir(os.path.join(root, sub)):
+            pmc(os.path.join(root, sub), label)
     if os.path.isdir(os.path.join(root, "win_trace")):
         print("\n## tools/run_full_window.py 30  (configs[3]: 50 KF / 10 k landmarks, one LM iteration per step)")
         kernel_stats(os.path.join(root, "win_trace"))

@@ -9,16 +9,16 @@ OUT="$ROOT/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
-PMCB="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $PMCB > "$OUT/pmc_fetch.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $PMCB > "$OUT/pmc_write.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -o bench -- $PMCB > "$OUT/pmc_l2.log" 2>&1
-# the sliding-window LM iteration (configs[3]) on its own: per-kernel times and the matrix-core counters of the Schur reduce
-WIN="python $ROOT/tools/run_full_window.py 30"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/win_trace" -o win -- $WIN > "$OUT/win_trace.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/win_pmc_mfma" -o win -- $WIN > "$OUT/win_pmc_mfma.log" 2>&1
+# the headline (configs[3] LM iterations) + the K1 and batched-windows legs under the kernel trace
+BENCH="python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --legs pose_only_K1,batched_windows_8"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
+PMCB="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --legs pose_only_K1"
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $PMCB > "$OUT/pmc_fetch.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $PMCB > "$OUT/pmc_write.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -o bench -- $PMCB > "$OUT/pmc_l2.log" 2>&1
+# the matrix-core counters of the same command (band Schur complement, Cholesky tile products)
+PMCM="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras"
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -o bench -- $PMCM > "$OUT/pmc_mfma.log" 2>&1
 cd "$ROOT"
 python tools/prof_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
 python tools/prof_summary.py "$OUT" --json > "$OUT/pmc.json" 2>/dev/null
