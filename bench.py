@@ -294,7 +294,8 @@ def roofline(api, ctx, prob, st, cfg, handles):
             flops = 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]
             e.update({"achieved": flops / (us_s * 1e-6) / 1e12, "frac": flops / (us_s * 1e-6) / 1e12 / FP64_PEAK_TFLOPS, "mfma_flops_per_launch": flops,
                       "mfma_busy_cycles": c.get("SQ_VALU_MFMA_BUSY_CYCLES"), "sq_busy_cycles": c.get("SQ_BUSY_CYCLES"),
-                      "mfma_utilisation": (c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"]) if c.get("SQ_BUSY_CYCLES") else None, "source": src})
+                      # matrix-pipe busy cycles over (kernel duration x 2.4 GHz x 1024 SIMDs): the share of the chip's matrix pipes in use
+                      "mfma_utilisation": (c["SQ_VALU_MFMA_BUSY_CYCLES"] / (us_s * 2400.0 * 1024.0)) if c.get("SQ_VALU_MFMA_BUSY_CYCLES") else None, "source": src})
         else:
             e.update({"achieved": None, "frac": None, "note": "no SQ_INSTS_VALU_MFMA_MOPS_F64 pass committed under profiles/"})
         out.append(e)
