@@ -3092,8 +3092,20 @@ int lvf_problem_gradient(lvf_problem* p, const lvf_solver_options* o, double* gc
   LVF_TRY(lvf::enter(p->ctx));
   hipStream_t q = p->ctx->stream;
   LVF_TRY(enqueue_linearize(p, o->huber_a, false));
+  const double* gr = p->gr.p;
+  if (gl && p->n_lm && p->compact) {
+    // atomic-free linearisation: a landmark's gradient entry is completed from its slot records by k_prepare (grt = gr + the slots)
+    LmCtl c;
+    ctl_from_options(o, o->initial_trust_region_radius, 2.0, 1, false, &c);
+    LVF_TRY(upload_ctl(p, c));
+    PrepArgs pa = p->chain->prep;
+    pa.radius = &p->ctl.p->radius; pa.scal = nullptr; pa.done = nullptr;
+    hipLaunchKernelGGL(k_prepare, dim3(pa.nblocks), dim3(kT), 0, q, pa);
+    LVF_HIP(hipGetLastError());
+    gr = p->grt.p;
+  }
   LVF_HIP(hipMemcpyAsync(gc, p->gc.p, (size_t)p->d * 8, hipMemcpyDeviceToHost, q));
-  if (gl && p->n_lm) LVF_HIP(hipMemcpyAsync(gl, p->gr.p, (size_t)p->n_lm * 8, hipMemcpyDeviceToHost, q));
+  if (gl && p->n_lm) LVF_HIP(hipMemcpyAsync(gl, gr, (size_t)p->n_lm * 8, hipMemcpyDeviceToHost, q));
   LVF_HIP(hipStreamSynchronize(q));
   return LVF_OK;
 }
