@@ -113,6 +113,9 @@ int lvf_state_create(lvf_ctx* ctx, int n_kf, int n_lm, lvf_state** out);
 int lvf_state_destroy(lvf_state* st);
 int lvf_state_set(lvf_state* st, int field, const double* host);
 int lvf_state_get(lvf_state* st, int field, double* host);
+/* dst <- src (all fields; same n_kf / n_lm), device to device, asynchronous on dst's context: restoring a saved estimate without a host
+ * round trip. */
+int lvf_state_copy(lvf_state* dst, const lvf_state* src);
 
 /* ---- factor batches (one batch = all residual blocks of one functor type) ------------------ */
 /* n blocks; ob[n][2]; kf_idx[n] selects the pose block and the per-frame weight; pw_idx[n] indexes

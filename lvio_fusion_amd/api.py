@@ -96,6 +96,10 @@ class State:
         _chk(self.ctx.L.lvf_state_get(self.h, field, _dp(out)))
         return out
 
+    def copy_from(self, other):
+        """device-to-device copy of every field (asynchronous)"""
+        _chk(self.ctx.L.lvf_state_copy(self.h, other.h))
+
     def close(self):
         if self.h:
             self.ctx.L.lvf_state_destroy(self.h)

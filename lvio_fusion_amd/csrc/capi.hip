@@ -176,6 +176,21 @@ int lvf_state_set(lvf_state* st, int field, const double* host) {
   if (n) { LVF_HIP(hipMemcpyAsync(p, host, n * 8, hipMemcpyHostToDevice, st->ctx->stream)); LVF_HIP(hipStreamSynchronize(st->ctx->stream)); }
   return LVF_OK;
 }
+// dst <- src, every field, device to device on dst's stream; nothing is waited for (a later call on the same context is ordered after it)
+int lvf_state_copy(lvf_state* dst, const lvf_state* src) {
+  LVF_REQUIRE(dst && src, "lvf_state_copy: null argument");
+  LVF_REQUIRE(dst->n_kf == src->n_kf && dst->n_lm == src->n_lm, "lvf_state_copy: shapes differ (%d/%d keyframes, %d/%d landmarks)", dst->n_kf, src->n_kf, dst->n_lm, src->n_lm);
+  LVF_TRY(lvf::enter(dst->ctx));
+  hipStream_t q = dst->ctx->stream;
+  const size_t k = (size_t)src->n_kf, l = (size_t)src->n_lm;
+  if (k) {
+    LVF_HIP(hipMemcpyAsync(dst->poses.p, src->poses.p, 7 * k * 8, hipMemcpyDeviceToDevice, q)); LVF_HIP(hipMemcpyAsync(dst->vel.p, src->vel.p, 3 * k * 8, hipMemcpyDeviceToDevice, q));
+    LVF_HIP(hipMemcpyAsync(dst->ba.p, src->ba.p, 3 * k * 8, hipMemcpyDeviceToDevice, q)); LVF_HIP(hipMemcpyAsync(dst->bg.p, src->bg.p, 3 * k * 8, hipMemcpyDeviceToDevice, q));
+    LVF_HIP(hipMemcpyAsync(dst->w_visual.p, src->w_visual.p, k * 8, hipMemcpyDeviceToDevice, q));
+  }
+  if (l) LVF_HIP(hipMemcpyAsync(dst->inv_depth.p, src->inv_depth.p, l * 8, hipMemcpyDeviceToDevice, q));
+  return LVF_OK;
+}
 int lvf_state_get(lvf_state* st, int field, double* host) {
   LVF_REQUIRE(st && host, "lvf_state_get: null argument");
   double* p; size_t n;
