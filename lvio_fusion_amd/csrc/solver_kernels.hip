@@ -1499,8 +1499,11 @@ __device__ __forceinline__ void chol_step_body(const int bx, const CholArgs& A, 
     chol_update_tile(S, ld, kb - 1, kb + 1 + ii, kb + 1 + t, Pi, Pj);
     return;
   }
-  const int tid = threadIdx.x, r = tid & 63, wv = tid >> 6, q = wv & 3;
+  const int tid = threadIdx.x, r = tid & 63, wv = tid >> 6;
   const bool panel_wave = wv >= 4;                    // wave-uniform
+  // column group of the wave.  Waves land on SIMD wv % 4: the panel wave of group q sits two SIMDs away from the diagonal wave of group q,
+  // so the two waves that are busiest at the same time (the pivot owner and the panel owner one step behind it) do not share an issue port
+  const int q = panel_wave ? ((wv + 2) & 3) : wv;
   unsigned long long* dbg = (A.dbg && bx == 1 && tid == 0) ? A.dbg + 8 * kb : nullptr;
   if (dbg) dbg[0] = wall_clock64();
   const bool inverse_wg = bx == 1 + below, panel_wg = bx > 0 && !inverse_wg;

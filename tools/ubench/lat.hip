@@ -53,6 +53,17 @@ __global__ void k(double* out, long long* t, double x0, int mode) {
   } else if (mode == 11) {    // dependent f64 add chain
 #pragma unroll
     for (int i = 0; i < N; ++i) x = x + y;
+  } else if (mode == 12) {    // 8 independent v_fmac_f64 with a DPP row_newbcast operand
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc[k]) : "v"(x), "v"(y));
+  } else if (mode == 13) {    // ds_read_b128 broadcast (uniform address) + 2 fma per read
+    const double2* sp2 = reinterpret_cast<const double2*>(sh);
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i)
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) { const double2 v = sp2[(i * 4 + k / 2) & 255]; acc[k] = fma(v.x, y, acc[k]); acc[k + 1] = fma(v.y, y, acc[k + 1]); }
   }
   long long c1 = clock64();
   for (int k = 0; k < 8; ++k) x += acc[k];
@@ -62,9 +73,9 @@ __global__ void k(double* out, long long* t, double x0, int mode) {
 int main() {
   double* out; long long* t; hipMalloc(&out, 1 << 20); hipMalloc(&t, 4096);
   const char* names[] = {"dependent f64 fma", "8 independent f64 fma chains", "readlane->fma chain", "v_rsq_f64 + add chain", "LDS write->barrier->read (256 thr)", "LDS write->read same wave",
-                         "dependent f32 fma", "shfl_xor + add chain", "barrier + add (256 thr)", "independent readlane pair + fma", "dependent f64 mul", "dependent f64 add"};
+                         "dependent f32 fma", "shfl_xor + add chain", "barrier + add (256 thr)", "independent readlane pair + fma", "dependent f64 mul", "dependent f64 add", "independent v_fmac_f64_dpp row_newbcast", "uniform ds_read_b128 + 2 fma (per fma)"};
   for (int threads : {64, 256, 512})
-    for (int mode = 0; mode < 12; ++mode) {
+    for (int mode = 0; mode < 14; ++mode) {
       long long h = 0;
       for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL(k, dim3(1), dim3(threads), 0, 0, out, t, 1.0001, mode); hipMemcpy(&h, t, 8, hipMemcpyDeviceToHost); }
       printf("threads %3d  %-38s %7.1f clocks per step\n", threads, names[mode], (double)h / N);
