@@ -11,54 +11,9 @@
 // 15x32 pre-weighting Jacobian M and sqrt_info S live in LDS, all 64 lanes share the 15x15 x 15x32 product.
 // sqrt_info = LLT(cov^-1).L^T depends only on the pre-integration, so it is factorised ONCE at batch creation
 // (k_imu_sqrt_info) instead of on every Evaluate as the reference does (imu_error.hpp:32).
-#include "lvf_internal.hpp"
+#include "imu_eval.hpp"
 
 namespace lvf {
-
-constexpr int kPre = 467;     // doubles per flattened lvf_preint
-constexpr int OFF_SUMDT = 0, OFF_LBA = 1, OFF_LBG = 4, OFF_DP = 7, OFF_DQ = 10, OFF_DV = 14, OFF_JAC = 17, OFF_COV = 242;
-constexpr int O_T = 0, O_R = 3, O_V = 6, O_BA = 9, O_BG = 12, O_PR = 0, O_PT = 4;   // preintegration.cpp:12
-__device__ constexpr double kG[3] = {0.0, 0.0, 9.81007};                            // preintegration.cpp:13
-
-struct Qd { double x, y, z, w; };
-__device__ __forceinline__ Qd qmul(const Qd& a, const Qd& b) {
-  Qd r;
-  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
-  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
-  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
-  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
-  return r;
-}
-__device__ __forceinline__ Qd qinv(const Qd& q) {
-  const double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-  return Qd{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2};
-}
-__device__ __forceinline__ void qrot(const Qd& q, const double v[3], double o[3]) {
-  double uv[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
-  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
-  o[0] = v[0] + q.w * uv[0] + (q.y * uv[2] - q.z * uv[1]);
-  o[1] = v[1] + q.w * uv[1] + (q.z * uv[0] - q.x * uv[2]);
-  o[2] = v[2] + q.w * uv[2] + (q.x * uv[1] - q.y * uv[0]);
-}
-__device__ __forceinline__ void qmat(const Qd& q, double R[9]) {
-  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
-  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
-  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
-  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
-  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
-  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
-}
-__device__ __forceinline__ Qd q_delta(const double th[3]) { return Qd{th[0] / 2.0, th[1] / 2.0, th[2] / 2.0, 1.0}; }
-// bottom-right 3x3 of q_left(q) (sign=+1) / q_right(q) (sign=-1): w I +- skew(vec)   utility.h:124-140
-__device__ __forceinline__ void q_lr_br(const Qd& q, double sign, double B[9]) {
-  B[0] = q.w;           B[1] = -sign * q.z;  B[2] = sign * q.y;
-  B[3] = sign * q.z;    B[4] = q.w;          B[5] = -sign * q.x;
-  B[6] = -sign * q.y;   B[7] = sign * q.x;   B[8] = q.w;
-}
-__device__ __forceinline__ void blk3(const double* J15, int r, int c, double B[9]) {
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[3 * i + j] = J15[15 * (r + i) + c + j];
-}
 
 // --------------------------------------------------------------------------------- sqrt_info (once per batch)
 // Declared algorithm (identical to the oracle's, oracle/imu.h): partial-pivot LU inverse of cov, then lower
@@ -136,9 +91,6 @@ template <bool WITH_J>
 __device__ __forceinline__ void imu_body(const int bx, const ImuArgs& A) {
   if (A.done && *A.done) return;
   const int n = A.n;
-  const double* __restrict__ pre = A.pre; const double* __restrict__ sqrt_info = A.sqrt_info;
-  const int* __restrict__ kf_i = A.kf_i; const int* __restrict__ kf_j = A.kf_j;
-  const double* __restrict__ poses = A.poses; const double* __restrict__ vel = A.vel; const double* __restrict__ ba = A.ba; const double* __restrict__ bg = A.bg;
   double* __restrict__ res = A.res; double* __restrict__ cost_stripes = A.cost_stripes;
   const ImuOut& out = A.out;
   if (bx >= n) {            // extra workgroups: clear the solver's accumulators (independent of the factors)
@@ -163,107 +115,12 @@ __device__ __forceinline__ void imu_body(const int bx, const ImuArgs& A) {
   __shared__ double scost[15];
   const int f = bx;
   const int lane = threadIdx.x;
-  const double* P = pre + (size_t)f * kPre;
-  for (int k = lane; k < 225; k += 64) sS[k] = sqrt_info[(size_t)f * 225 + k];
-  if (WITH_J) for (int k = lane; k < 480; k += 64) sM[k] = 0.0;
+  imu_stage<WITH_J>(f, lane, A.sqrt_info, sS, sM);
   __syncthreads();
-  if (lane == 0) {
-    const int i = kf_i[f], j = kf_j[f];
-    const double* pi = poses + 7 * i; const double* pj = poses + 7 * j;
-    const Qd Qi{pi[0], pi[1], pi[2], pi[3]}, Qj{pj[0], pj[1], pj[2], pj[3]};
-    const double* Pi = pi + 4; const double* Pj = pj + 4;
-    const double* Vi = vel + 3 * i; const double* Vj = vel + 3 * j;
-    const double* Bai = ba + 3 * i; const double* Baj = ba + 3 * j;
-    const double* Bgi = bg + 3 * i; const double* Bgj = bg + 3 * j;
-    const double T = P[OFF_SUMDT];
-    const double* Jp = P + OFF_JAC;
-    double dp_dba[9], dp_dbg[9], dq_dbg[9], dv_dba[9], dv_dbg[9];
-    blk3(Jp, O_T, O_BA, dp_dba); blk3(Jp, O_T, O_BG, dp_dbg); blk3(Jp, O_R, O_BG, dq_dbg);
-    blk3(Jp, O_V, O_BA, dv_dba); blk3(Jp, O_V, O_BG, dv_dbg);
-    double dba[3], dbg[3];
-    for (int k = 0; k < 3; ++k) { dba[k] = Bai[k] - P[OFF_LBA + k]; dbg[k] = Bgi[k] - P[OFF_LBG + k]; }
-    double th[3];
-    mat3_mul_vec(dq_dbg, dbg, th);
-    const Qd dq{P[OFF_DQ], P[OFF_DQ + 1], P[OFF_DQ + 2], P[OFF_DQ + 3]};
-    const Qd cq = qmul(dq, q_delta(th));
-    double a3[3], b3[3], cv[3], cp[3];
-    mat3_mul_vec(dv_dba, dba, a3); mat3_mul_vec(dv_dbg, dbg, b3);
-    for (int k = 0; k < 3; ++k) cv[k] = P[OFF_DV + k] + a3[k] + b3[k];
-    mat3_mul_vec(dp_dba, dba, a3); mat3_mul_vec(dp_dbg, dbg, b3);
-    for (int k = 0; k < 3; ++k) cp[k] = P[OFF_DP + k] + a3[k] + b3[k];
-    const Qd Qi_inv = qinv(Qi);
-    double tp[3], op[3], tv[3], ov[3];
-    for (int k = 0; k < 3; ++k) tp[k] = 0.5 * kG[k] * T * T + Pj[k] - Pi[k] - Vi[k] * T;
-    qrot(Qi_inv, tp, op);
-    for (int k = 0; k < 3; ++k) tv[k] = kG[k] * T + Vj[k] - Vi[k];
-    qrot(Qi_inv, tv, ov);
-    const Qd e = qmul(qinv(cq), qmul(Qi_inv, Qj));
-    for (int k = 0; k < 3; ++k) { sr0[O_T + k] = op[k] - cp[k]; sr0[O_V + k] = ov[k] - cv[k]; sr0[O_BA + k] = Baj[k] - Bai[k]; sr0[O_BG + k] = Bgj[k] - Bgi[k]; }
-    sr0[O_R + 0] = 2 * e.x; sr0[O_R + 1] = 2 * e.y; sr0[O_R + 2] = 2 * e.z;
-    if (WITH_J) {
-      double Ri_inv[9];
-      qmat(Qi_inv, Ri_inv);
-#define MM(r, c) sM[(r) * 32 + (c)]
-      // pose_i  (cols 0..6)
-      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) MM(O_T + a, O_PT + b) = -Ri_inv[3 * a + b];
-      MM(O_T + 0, O_PR + 1) = -op[2]; MM(O_T + 0, O_PR + 2) = op[1];
-      MM(O_T + 1, O_PR + 0) = op[2];  MM(O_T + 1, O_PR + 2) = -op[0];
-      MM(O_T + 2, O_PR + 0) = -op[1]; MM(O_T + 2, O_PR + 1) = op[0];
-      {
-        // -(q_left(Qj^-1 Qi) q_right(cq)).bottomRightCorner<3,3>() of the 4x4 product:
-        // corner = a_v (-b_v)^T + (a_w I + [a_v]x)(b_w I - [b_v]x)
-        const Qd A = qmul(qinv(Qj), Qi);
-        double LA[9], RB[9];
-        q_lr_br(A, +1.0, LA); q_lr_br(cq, -1.0, RB);
-        const double av[3] = {A.x, A.y, A.z}, bv[3] = {cq.x, cq.y, cq.z};
-        for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b) {
-            double s = av[a] * (-bv[b]);
-            for (int k = 0; k < 3; ++k) s += LA[3 * a + k] * RB[3 * k + b];
-            MM(O_R + a, O_PR + b) = -s;
-          }
-      }
-      MM(O_V + 0, O_PR + 1) = -ov[2]; MM(O_V + 0, O_PR + 2) = ov[1];
-      MM(O_V + 1, O_PR + 0) = ov[2];  MM(O_V + 1, O_PR + 2) = -ov[0];
-      MM(O_V + 2, O_PR + 0) = -ov[1]; MM(O_V + 2, O_PR + 1) = ov[0];
-      // v_i (cols 7..9)
-      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { MM(O_T + a, 7 + b) = -Ri_inv[3 * a + b] * T; MM(O_V + a, 7 + b) = -Ri_inv[3 * a + b]; }
-      // ba_i (cols 10..12)
-      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { MM(O_T + a, 10 + b) = -dp_dba[3 * a + b]; MM(O_V + a, 10 + b) = -dv_dba[3 * a + b]; }
-      for (int a = 0; a < 3; ++a) MM(O_BA + a, 10 + a) = -1.0;
-      // bg_i (cols 13..15)
-      {
-        const Qd B = qmul(qmul(qinv(Qj), Qi), dq);
-        double LB[9];
-        q_lr_br(B, +1.0, LB);
-        for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b) {
-            double s = 0.0;
-            for (int k = 0; k < 3; ++k) s += LB[3 * a + k] * dq_dbg[3 * k + b];
-            MM(O_R + a, 13 + b) = -s;
-            MM(O_T + a, 13 + b) = -dp_dbg[3 * a + b];
-            MM(O_V + a, 13 + b) = -dv_dbg[3 * a + b];
-          }
-        for (int a = 0; a < 3; ++a) MM(O_BG + a, 13 + a) = -1.0;
-      }
-      // pose_j (cols 16..22)
-      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) MM(O_T + a, 16 + O_PT + b) = Ri_inv[3 * a + b];
-      {
-        const Qd C = qmul(qmul(qinv(cq), Qi_inv), Qj);
-        double LC[9];
-        q_lr_br(C, +1.0, LC);
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) MM(O_R + a, 16 + O_PR + b) = LC[3 * a + b];
-      }
-      // v_j (23..25), ba_j (26..28), bg_j (29..31)
-      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) MM(O_V + a, 23 + b) = Ri_inv[3 * a + b];
-      for (int a = 0; a < 3; ++a) { MM(O_BA + a, 26 + a) = 1.0; MM(O_BG + a, 29 + a) = 1.0; }
-#undef MM
-    }
-  }
+  if (lane == 0) imu_raw<WITH_J>(f, A.pre, A.kf_i, A.kf_j, A.poses, A.vel, A.ba, A.bg, sr0, sM);
   __syncthreads();
   if (lane < 15) {
-    double s = 0.0;
-    for (int k = 0; k < 15; ++k) s += sS[15 * lane + k] * sr0[k];
+    const double s = imu_weighted_residual(lane, sS, sr0);
     res[(size_t)f * 15 + lane] = s;
     scost[lane] = 0.5 * s * s;
   }
@@ -280,8 +137,7 @@ __device__ __forceinline__ void imu_body(const int bx, const ImuArgs& A) {
   if (WITH_J) {
     for (int e = lane; e < 480; e += 64) {
       const int r = e >> 5, c = e & 31;
-      double s = 0.0;
-      for (int k = 0; k < 15; ++k) s += sS[15 * r + k] * sM[32 * k + c];
+      const double s = imu_weighted_jacobian(e, sS, sM);
       int blk, cc, width;
       if (c < 7) { blk = 0; cc = c; width = 7; }
       else if (c < 16) { blk = 1 + (c - 7) / 3; cc = (c - 7) % 3; width = 3; }
