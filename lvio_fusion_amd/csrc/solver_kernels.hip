@@ -17,6 +17,7 @@
 
 #include "factor_eval.hpp"
 #include "lvf_internal.hpp"
+#include "imu_eval.hpp"
 
 namespace lvf {
 struct TfWork;
@@ -49,6 +50,7 @@ struct lvf_problem {
   lvf::DevBuf<int> lm_eoff, n_slots, tf_slot, run_first;
   lvf::DevBuf<double> slotB, slabP, slabQ, Ct, grt;
   lvf::StageClock* clk = nullptr;     // lvf_problem_stage_times
+  bool accum_clean = false;           // B / gc / C / g_rho / cost stripes are zero (left so by the last iteration's cost + decision launch)
   int band_rows = 64;           // landmark rows per slice of the band Schur complement (a batch uses more: fewer output atomics)
   lvf::DevBuf<int2> band_work; lvf::DevBuf<int> n_band_work_dev; lvf::HostPin<int> h_n_band_work;
   int n_band_work = 0, band_rows_built = 0;
@@ -137,6 +139,22 @@ __global__ __launch_bounds__(kT) void k_zero_multi(ZeroList z) {
   for (unsigned long long i = (unsigned long long)blockIdx.x * kT + threadIdx.x; i < n2; i += (unsigned long long)gridDim.x * kT) p2[i] = make_double2(0.0, 0.0);
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
 }
+// workgroup `wg` of `n_wgs` (kT threads each) clears its share of every array of the list
+// (static indices only: a run-time index into the by-value pointer table would put it in scratch memory)
+__device__ __forceinline__ void zero_list_share(const ZeroList& zero, const int wg, const int n_wgs) {
+  const unsigned long long t = (unsigned long long)wg * kT + threadIdx.x, nt = (unsigned long long)n_wgs * kT;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    if (a >= zero.count) break;
+    double* p = zero.p[a];
+    const unsigned long long cnt = zero.n[a], n2 = cnt / 2;
+    double2* p2 = reinterpret_cast<double2*>(p);
+    for (unsigned long long i = t; i < n2; i += nt) p2[i] = make_double2(0.0, 0.0);
+    if ((cnt & 1) && t == 0) p[cnt - 1] = 0.0;
+  }
+}
+// one launch for a batch of windows: blockIdx.y = window
+__global__ __launch_bounds__(kT) void k_zero_table(const ZeroList* __restrict__ t) { zero_list_share(t[blockIdx.y], blockIdx.x, gridDim.x); }
 
 // ------------------------------------------------------------------------------------------------ TwoCamera
 template <bool COST_ONLY>
@@ -405,7 +423,10 @@ struct CostVisual {
   const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1, *tf_k2; CamD tf_left, tf_right;
   const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
 };
-struct CostArgs { CostVisual a; int n_kf; StateP s; double huber; double* cost; int nblocks; const int* done; };
+struct CostArgs {
+  CostVisual a; int n_kf; StateP s; double huber; double* cost; int nblocks; const int* done;
+  ZeroList zero; int zero_wgs;      // workgroups [nblocks, nblocks + zero_wgs) of the merged cost + decision launch clear the accumulators for the NEXT linearisation
+};
 // the calling thread's share of the candidate cost (workgroup b of the pass)
 __device__ __forceinline__ double cost_visual_value(const int b, const CostArgs& A) {
   const CostVisual& a = A.a;
@@ -688,6 +709,84 @@ __device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, con
 // work list, the next g_tc the TwoCamera blocks, the rest the PoseOnly blocks.  The two small passes (4.6 + 8.8 us as launches of
 // their own) disappear under the TwoFrame pass; all three only meet in B, gc, C, g_rho through atomics.  A fourth segment
 // accumulates the ImuError blocks (four factors per workgroup) from the Jacobians k_imu<true> materialised just before.
+// ImuError factors of the merged linearisation launch: EVALUATED and accumulated by the same workgroup (one wave per factor, four
+// factors per workgroup), so the linearisation needs no IMU launch ahead of it and the weighted Jacobian never leaves LDS:
+//   stage sqrt_info -> one lane forms the raw residual and the 15 x 32 pre-weighting Jacobian -> all lanes weight them ->
+//   pose columns to tangent coordinates -> J^T J / J^T r into B / gc, 1/2 |r|^2 into the cost.
+// LDS per wave (doubles): sS 225 | sM 480 (later the local 15 x 30 Jacobian) | sJw 480 | sr0 16 | sr 16 | sidx 16  = kImuWaveLds.
+constexpr int kEndZeroWgs = 1024;      // workgroups of the cost + decision launch that clear the accumulators
+constexpr int kImuWaveLds = 225 + 480 + 480 + 16 + 16 + 16;
+struct ImuEvalArgs { int n; const double *pre, *sqrt_info; const int *kf_i, *kf_j; };
+__device__ __forceinline__ void lin_imu_eval_body(const int vb, const ImuEvalArgs& I, int n_kf, const StateP& s, const uint8_t* __restrict__ pose_const,
+                                                  double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost) {
+  extern __shared__ double lin_lds[];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int f = 4 * vb + w;
+  const bool active = f < I.n;
+  double* sS = lin_lds + w * kImuWaveLds;
+  double* sM = sS + 225;
+  double* sJw = sM + 480;
+  double* sr0 = sJw + 480;
+  double* sr = sr0 + 16;
+  int* sidx = reinterpret_cast<int*>(sr + 16);
+  if (active) imu_stage<true>(f, lane, I.sqrt_info, sS, sM);
+  __syncthreads();
+  if (active && lane == 0) imu_raw<true>(f, I.pre, I.kf_i, I.kf_j, s.poses, s.vel, s.ba, s.bg, sr0, sM);
+  __syncthreads();
+  int ki = 0, kj = 0;
+  if (active) {
+    ki = I.kf_i[f]; kj = I.kf_j[f];
+    const double r = imu_weighted_residual(lane, sS, sr0);
+    if (lane < 15) sr[lane] = r;
+    for (int e = lane; e < 480; e += 64) sJw[e] = imu_weighted_jacobian(e, sS, sM);
+    if (lane < 30) {
+      int g;
+      if (lane < 6) g = 6 * ki + lane; else if (lane < 15) g = 6 * n_kf + 9 * ki + (lane - 6);
+      else if (lane < 21) g = 6 * kj + (lane - 15); else g = 6 * n_kf + 9 * kj + (lane - 21);
+      sidx[lane] = g;
+    }
+  }
+  __syncthreads();                                   // sM is dead from here: it becomes the local Jacobian sJ[15][30]
+  double* sJ = sM;
+  if (active) {
+    for (int e = lane; e < 30; e += 64) {
+      const int row = e % 15, which = e / 15;            // which: 0 = pose_i, 1 = pose_j
+      const double* Jr = sJw + 32 * row + (which ? 16 : 0);
+      const int kk = which ? kj : ki;
+      const double sc = pose_const[kk] ? 0.0 : 1.0;
+      double l3[3];
+      quat_row_to_local(Jr, s.poses + 7 * kk, l3);
+      double* o = sJ + row * 30 + (which ? 15 : 0);
+      o[0] = sc * l3[0]; o[1] = sc * l3[1]; o[2] = sc * l3[2]; o[3] = sc * Jr[4]; o[4] = sc * Jr[5]; o[5] = sc * Jr[6];
+    }
+    for (int e = lane; e < 15 * 18; e += 64) {           // six 15x3 blocks: (v, ba, bg)_i = columns 7..15, (v, ba, bg)_j = columns 23..31
+      const int row = e / 18, c = e % 18;
+      sJ[row * 30 + (c < 9 ? 6 + c : 21 + (c - 9))] = sJw[32 * row + (c < 9 ? 7 + c : 23 + (c - 9))];
+    }
+  }
+  __syncthreads();
+  double c = 0.0;
+  if (active && lane < 15) c = 0.5 * sr[lane] * sr[lane];
+  c = wave_sum(c);
+  if (!active) return;
+  if (lane == 0) atomicAdd(cost + (f & (kStripes - 1)), c);
+  for (int e = lane; e < 30 * 30; e += 64) {
+    const int a = e / 30, b = e % 30;
+    const int ga = sidx[a], gb = sidx[b];
+    if (gb > ga || (ga == gb && a != b)) continue;    // lower triangle in GLOBAL indices (kf_i != kf_j is validated)
+    double h = 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) h += sJ[k * 30 + a] * sJ[k * 30 + b];
+    atomicAdd(&B[(size_t)ga * ld + gb], h);
+  }
+  if (lane < 30) {
+    double g = 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) g += sJ[k * 30 + lane] * sr[k];
+    atomicAdd(&gc[sidx[lane]], g);
+  }
+}
+
 struct LinVisual {
   int n_tfw, g_tc;
   // TwoFrame
@@ -696,8 +795,8 @@ struct LinVisual {
   int n_tc; const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; const double* tc_w; CamD tc_left, tc_right;
   // PoseOnly
   int n_po, g_po; const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
-  // ImuError (already evaluated)
-  int n_imu; const double* imu_res; ImuJ imu_J; const int *imu_i, *imu_j;
+  // ImuError: evaluated inside the launch (imu.pre != nullptr) or ahead of it by k_imu<true> (imu_res / imu_J)
+  int n_imu; const double* imu_res; ImuJ imu_J; const int *imu_i, *imu_j; ImuEvalArgs imu;
 };
 struct LinArgs {
   LinVisual v; int n_kf; StateP s; double huber; const uint8_t* pose_const; double* B; int ld; double* gc; double* E; int ldE; double *C, *gr, *cost;
@@ -715,6 +814,8 @@ __device__ __forceinline__ void lin_visual_body(const int b, const LinArgs& A) {
     lin_tc_body<false>(b - a.n_tfw, a.n_tc, a.tc_lo, a.tc_ro, a.tc_lm, a.tc_kf, a.tc_w, s, a.tc_left, a.tc_right, huber, C, gr, cost);
   else if (b < a.n_tfw + a.g_tc + a.g_po)
     lin_po_body<false, true>(b - a.n_tfw - a.g_tc, a.n_po, n_kf, a.po_ob, a.po_kf, a.po_pwi, a.po_pw, s, a.po_cam, huber, pose_const, B, ld, gc, cost);
+  else if (a.imu.pre)
+    lin_imu_eval_body(b - a.n_tfw - a.g_tc - a.g_po, a.imu, n_kf, s, pose_const, B, ld, gc, cost);
   else
     lin_imu_body4<true>(b - a.n_tfw - a.g_tc - a.g_po, a.n_imu, n_kf, a.imu_res, a.imu_J, a.imu_i, a.imu_j, s.poses, pose_const, B, ld, gc, cost);
 }
@@ -2051,6 +2152,7 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
   }
   __syncthreads();
   if (s_skip) return;
+  if (threadIdx.x < kStripes) const_cast<double*>(A.scal)[SC_COST + threadIdx.x] = 0.0;      // read above; the next linearisation adds into it
   if (threadIdx.x == 0) {
     const int hfail = *reinterpret_cast<const int*>(A.scal + SC_FAIL);
     const double cost_before = s_sum[SC_COST / kStripes], cost_new = s_sum[SC_COST_NEW / kStripes], model = -s_sum[SC_MODEL / kStripes];
@@ -2117,8 +2219,14 @@ __global__ __launch_bounds__(kDT) void k_lm_decide_b(const DecideArgs* __restric
 // one that draws the last ticket closes the iteration (the sums live in atomics, so a plain completion wait orders them before the
 // ticket; nothing else this launch writes is read by the decision).  Saves the k_lm_decide launch (~8 us of an iteration).
 static_assert(kDT == kT, "the last workgroup of the cost pass runs the decision with its own threads");
-__device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A, const DecideArgs& D) {
-  if (b >= A.nblocks || (A.done && *A.done)) return;
+__device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A, const DecideArgs& D, const int end_zero) {
+  if (b >= A.nblocks) {
+    // the accumulators of the linearisation (B, gc, C, g_rho, ...) were last read by k_step_tail: cleared here, beside the cost pass, for
+    // the next iteration (never gated: a finished solve leaves them clean for the next one)
+    if (end_zero && b - A.nblocks < A.zero_wgs) zero_list_share(A.zero, b - A.nblocks, A.zero_wgs);
+    return;
+  }
+  if (A.done && *A.done) return;
   {
     // each wave's sum goes out as a RETURNING atomic: its result can only come back once the add has been performed, and the barrier
     // below waits for it — so every add of this workgroup is in the sum before its ticket is drawn (a release fence here would write
@@ -2139,8 +2247,9 @@ __device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A,
   __syncthreads();
   if (s_last) lm_decide_body<true>(D);
 }
-__global__ __launch_bounds__(kT) void k_cost_decide(CostArgs a, DecideArgs d) { cost_decide_body(blockIdx.x, a, d); }
-__global__ __launch_bounds__(kT) void k_cost_decide_b(const CostArgs* __restrict__ t, const DecideArgs* __restrict__ d) { cost_decide_body(blockIdx.x, t[blockIdx.y], d[blockIdx.y]); }
+// end_zero = 0 keeps the accumulators of this iteration's linearisation (per-call API: lvf_problem_download_reduced rebuilds the damped system from them)
+__global__ __launch_bounds__(kT) void k_cost_decide(CostArgs a, DecideArgs d, int end_zero) { cost_decide_body(blockIdx.x, a, d, end_zero); }
+__global__ __launch_bounds__(kT) void k_cost_decide_b(const CostArgs* __restrict__ t, const DecideArgs* __restrict__ d, int end_zero) { cost_decide_body(blockIdx.x, t[blockIdx.y], d[blockIdx.y], end_zero); }
 
 // ================================================================================================ host side
 static StateP state_ptrs(const lvf_state* st) { return StateP{st->poses.p, st->vel.p, st->ba.p, st->bg.p, st->inv_depth.p, st->w_visual.p}; }
@@ -2155,7 +2264,8 @@ struct Chain {
   bool fast = false;            // merged linearisation (sorted TwoFrame work list) available
   bool batchable = false;       // every launch of the iteration has a table form (fast + band Schur merged with sparse level 0 + no priors)
   bool has_imu = false, has_prior = false;
-  ZeroList zero{};
+  ZeroList zero_end{};
+  ZeroList zero{};              // everything a linearisation accumulates into (explicit k_zero_multi when the accumulators are not known clean)
   ImuArgs imu_lin{}, imu_cost{};
   LinArgs lin{}; size_t lin_lds = 0;
   TfReduceArgs red{};           // compact mode: the slabs of the TwoFrame linearisation -> B, gc
@@ -2279,6 +2389,7 @@ static int build_chain(lvf_problem* p) {
   if (!p->chain) p->chain = new Chain();
   Chain& c = *p->chain;
   c = Chain();
+  p->accum_clean = false;           // buffers may have been re-allocated
   LVF_TRY(ensure_band_work(p));
   LVF_TRY(p->ctl.ensure(1));
   if (!p->rec) {
@@ -2296,15 +2407,17 @@ static int build_chain(lvf_problem* p) {
   {
     int k = 0;
     auto add = [&](double* ptr, size_t n) { if (ptr && n) { c.zero.p[k] = ptr; c.zero.n[k] = n; ++k; } };
-    add(p->B.p, (size_t)p->dpad * p->dpad); add(p->gc.p, p->dpad); add(p->scal.p, SC_N);
+    add(p->B.p, (size_t)p->dpad * p->dpad); add(p->gc.p, p->dpad);
     if (p->n_lm) { if (!p->compact) add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
+    c.zero_end = c.zero; c.zero_end.count = k;         // cleared at the END of an iteration, beside the cost pass (the scalars: by the decision itself)
+    add(p->scal.p, SC_N);
     c.zero.count = k;
   }
   c.fast = p->tf && p->tf->n && p->tf_work.n && p->n_kf <= kMaxStagedKf;
   c.has_imu = p->imu && p->imu->n;
   c.has_prior = p->prior && p->prior->n;
   if (c.has_imu) {
-    fill_imu_args(p->imu, s.poses, s.vel, s.ba, s.bg, nullptr, c.fast ? &c.zero : nullptr, done, &c.imu_lin);
+    fill_imu_args(p->imu, s.poses, s.vel, s.ba, s.bg, nullptr, nullptr, done, &c.imu_lin);
     fill_imu_args(p->imu, s2.poses, s2.vel, s2.ba, s2.bg, p->scal.p + SC_COST_NEW, nullptr, done, &c.imu_cost);
   }
   if (c.fast) {
@@ -2323,6 +2436,7 @@ static int build_chain(lvf_problem* p) {
     if (c.has_imu) {
       a.n_imu = p->imu->n; a.imu_res = p->imu->res.p; a.imu_i = p->imu->idx_a.p; a.imu_j = p->imu->idx_b.p;
       for (int k = 0; k < 8; ++k) a.imu_J.j[k] = p->imu->jac[k].p;
+      a.imu = ImuEvalArgs{p->imu->n, p->imu->pre.p, p->imu->sqrt_info.p, p->imu->idx_a.p, p->imu->idx_b.p};
     }
     a.cp = TfCompact{0, nullptr, nullptr, nullptr, nullptr};
     if (p->compact) {
@@ -2334,7 +2448,7 @@ static int build_chain(lvf_problem* p) {
     c.lin.n_kf = p->n_kf; c.lin.s = s; c.lin.huber = 0.0; c.lin.pose_const = p->pose_const.p; c.lin.B = p->B.p; c.lin.ld = p->dpad; c.lin.gc = p->gc.p; c.lin.E = p->E.p;
     c.lin.ldE = p->ldE; c.lin.C = p->C.p; c.lin.gr = p->gr.p; c.lin.cost = cost; c.lin.done = done; c.lin.dbg = nullptr;
     c.lin.nblocks = a.n_tfw + a.g_tc + a.g_po + (a.n_imu + 3) / 4;
-    c.lin_lds = std::max((size_t)(sizeof(PoseD) / 8 + kAccSlots) * p->n_kf + 32, (size_t)1864 + 64) * sizeof(double);
+    c.lin_lds = std::max((size_t)(sizeof(PoseD) / 8 + kAccSlots) * p->n_kf + 32, (size_t)4 * kImuWaveLds) * sizeof(double);
   }
   // damped system
   {
@@ -2386,6 +2500,7 @@ static int build_chain(lvf_problem* p) {
   fill_cost_visual(p, c.cost.a);
   c.cost.n_kf = p->n_kf; c.cost.s = s2; c.cost.huber = 0.0; c.cost.cost = p->scal.p + SC_COST_NEW; c.cost.done = done;
   c.cost.nblocks = c.cost.a.g_tc + c.cost.a.g_tf + grid(c.cost.a.n_po);
+  c.cost.zero = c.zero_end; c.cost.zero_wgs = c.fast ? kEndZeroWgs : 0;
   {
     DecideArgs& a = c.dec;
     a.scal = p->scal.p; a.ctl = ctl; a.rec = p->rec; a.ticket = reinterpret_cast<int*>(p->scal.p + SC_TICKET); a.n_kf = p->n_kf; a.n_lm = p->n_lm;
@@ -2407,7 +2522,7 @@ static bool chain_stale(const lvf_problem* p) {
 // the linearisation at the current state: cost, B, gc, E, C, gr.  `gated`: skipped on device once the LM loop has finished
 // HIP events between the stages of one LM iteration (lvf_problem_stage_times): event 0 before the first launch, event k + 1 after stage k
 enum { ST_IMU_LIN = 0, ST_LIN_VISUAL, ST_TF_REDUCE, ST_PREPARE, ST_SCHUR_SP0, ST_SP_LEVELS, ST_CHOL, ST_BACKSOLVE, ST_STEP_TAIL, ST_COST, ST_DECIDE, ST_N };
-static const char* const kStageNames[ST_N] = {"k_imu<true> (+accumulator zeroing)", "k_lin_visual", "k_tf_reduce", "k_prepare", "k_schur_sp0", "k_sp_eliminate (levels 1..)",
+static const char* const kStageNames[ST_N] = {"k_zero_multi (only when the accumulators are not known clean)", "k_lin_visual", "k_tf_reduce", "k_prepare", "k_schur_sp0", "k_sp_eliminate (levels 1..)",
                                              "k_chol_step (all block steps)", "k_chol_backsolve", "k_step_tail", "k_imu<false> (+priors) + k_cost_decide (candidate cost; its last workgroup closes the iteration)", "k_lm_decide (windows without visual blocks)"};
 struct StageClock { hipEvent_t ev[ST_N + 1]; int launches[ST_N]; bool on = false; };
 void stage_clock_free(StageClock* k) {
@@ -2429,19 +2544,15 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
   const StateP s = state_ptrs(p->st);
   double* cost = p->scal.p + SC_COST;
   bool imu_done = false;
-  // the accumulators are zeroed by extra workgroups of the IMU evaluation launch when there is one ahead of the merged linearisation
-  // (neither depends on the other); otherwise by a launch of their own
-  const bool zero_with_imu = c.fast && c.has_imu;
+  // the accumulators are cleared at the END of every iteration (extra workgroups of the cost + decision launch); a launch of its own is
+  // only needed when they are not known to be clean (first linearisation after a configure, stand-alone gradient / reduced-system taps)
+  const bool clean = c.fast && p->accum_clean;
+  p->accum_clean = false;
   if (p->clk && p->clk->on) (void)hipEventRecord(p->clk->ev[0], q);
-  if (!zero_with_imu) hipLaunchKernelGGL(k_zero_multi, dim3(512, c.zero.count), dim3(kT), 0, q, c.zero);
+  if (!clean) hipLaunchKernelGGL(k_zero_multi, dim3(512, c.zero.count), dim3(kT), 0, q, c.zero);
   if (c.fast) {
-    if (c.has_imu) {
-      ImuArgs ia = c.imu_lin;
-      if (!gated) ia.done = nullptr;
-      LVF_TRY(launch_imu_args(q, ia, true));   // residuals + Jacobians (+ the zeroing) first; their accumulation rides in the launch below
-      imu_done = true;
-    }
-    stage_mark(p, ST_IMU_LIN, c.has_imu ? 1 : 0);
+    imu_done = true;                           // the ImuError factors are evaluated inside the merged launch below
+    stage_mark(p, ST_IMU_LIN, clean ? 0 : 1);
     LinArgs la = c.lin;
     la.huber = huber;
     if (!gated) la.done = nullptr;
@@ -2543,7 +2654,7 @@ static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool
 }
 
 // one complete LM iteration of one window on its stream, closed on device by k_lm_decide; nothing is waited for
-static int enqueue_iteration(lvf_problem* p) {
+static int enqueue_iteration(lvf_problem* p, bool end_zero) {
   hipStream_t q = p->ctx->stream;
   if (chain_stale(p)) LVF_TRY(build_chain(p));
   const Chain& c = *p->chain;
@@ -2579,7 +2690,10 @@ static int enqueue_iteration(lvf_problem* p) {
     hipLaunchKernelGGL(k_cost_sq, dim3(grid(6 * p->prior->n)), dim3(kT), 0, q, 6 * p->prior->n, p->prior->res.p, p->scal.p + SC_COST_NEW);
   }
   if (ca.nblocks > 0) {
-    hipLaunchKernelGGL(k_cost_decide, dim3(ca.nblocks), dim3(kT), 0, q, ca, c.dec);
+    if (!end_zero) ca.zero_wgs = 0;
+    hipLaunchKernelGGL(k_cost_decide, dim3(ca.nblocks + ca.zero_wgs), dim3(kT), 0, q, ca, c.dec, end_zero ? 1 : 0);
+    p->accum_clean = ca.zero_wgs > 0;
+    if (p->accum_clean) p->linearized = false;         // the normal equations of this iteration are gone: no reduced-system tap
     stage_mark(p, ST_COST, 1 + (c.has_imu ? 1 : 0) + (c.has_prior ? 2 : 0));
   } else {
     stage_mark(p, ST_COST, (c.has_imu ? 1 : 0) + (c.has_prior ? 2 : 0));
@@ -2625,7 +2739,7 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
   ctl_from_options(o, *radius, *decrease, 1, false, &c);
   p->huber = o->huber_a;
   LVF_TRY(upload_ctl(p, c));
-  LVF_TRY(enqueue_iteration(p));
+  LVF_TRY(enqueue_iteration(p, false));
   LVF_TRY(download_ctl(p, &c));
   if (p->dbg.p && std::getenv("LVF_CHOL_TIMING")) {
     unsigned long long t[64];
@@ -2931,6 +3045,7 @@ struct lvf_problem_batch {
   lvf::DevBuf<lvf::TailArgs> tail; int g_tail = 0; size_t lds_tail = 0;
   lvf::DevBuf<lvf::CostArgs> cost; int g_cost = 0;
   lvf::DevBuf<lvf::DecideArgs> dec;
+  lvf::DevBuf<lvf::ZeroList> zero;   // every window's full accumulator list (cleared in one launch when a window is not known clean)
   double huber_built = -1.0;
 };
 
@@ -2957,7 +3072,7 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
   b->tables = all;
   if (!all) return LVF_OK;
   std::vector<ImuArgs> il(W), ic(W); std::vector<LinArgs> li(W); std::vector<TfReduceArgs> rd(W); std::vector<PrepArgs> pr(W); std::vector<SchurSp0Args> ss(W);
-  std::vector<CholArgs> ch(W); std::vector<BackArgs> bk(W); std::vector<TailArgs> tl(W); std::vector<CostArgs> co(W); std::vector<DecideArgs> de(W);
+  std::vector<CholArgs> ch(W); std::vector<BackArgs> bk(W); std::vector<TailArgs> tl(W); std::vector<CostArgs> co(W); std::vector<DecideArgs> de(W); std::vector<ZeroList> zl(W);
   b->max_levels = 0; b->max_nb = 0;
   b->g_red = 0;
   b->g_imu_lin = b->g_imu_cost = b->g_lin = b->g_prep = b->g_ssp0 = b->g_tail = b->g_cost = 0; b->lds_ssp0 = b->lds_back = b->lds_tail = b->lds_lin = 0;
@@ -2966,16 +3081,16 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
     const Chain& c = *p->chain;
     il[w] = c.imu_lin; ic[w] = c.imu_cost; li[w] = c.lin; li[w].huber = huber; rd[w] = c.red; if (!p->compact) rd[w].nblocks = 0;
     b->g_red = std::max(b->g_red, rd[w].nblocks); pr[w] = c.prep; ss[w] = c.ssp0; ch[w] = c.chol; bk[w] = c.back; tl[w] = c.tail;
-    co[w] = c.cost; co[w].huber = huber; de[w] = c.dec;
+    co[w] = c.cost; co[w].huber = huber; de[w] = c.dec; zl[w] = c.zero;
     b->g_imu_lin = std::max(b->g_imu_lin, c.imu_lin.n + c.imu_lin.zero_wgs); b->g_imu_cost = std::max(b->g_imu_cost, c.imu_cost.n + c.imu_cost.zero_wgs);
     b->g_lin = std::max(b->g_lin, c.lin.nblocks); b->lds_lin = std::max(b->lds_lin, c.lin_lds); b->g_prep = std::max(b->g_prep, c.prep.nblocks); b->g_ssp0 = std::max(b->g_ssp0, c.ssp0.nblocks);
     b->lds_ssp0 = std::max(b->lds_ssp0, c.ssp0_lds); b->lds_back = std::max(b->lds_back, c.back_lds); b->g_tail = std::max(b->g_tail, c.tail.nblocks);
-    b->lds_tail = std::max(b->lds_tail, c.tail_lds); b->g_cost = std::max(b->g_cost, c.cost.nblocks);
+    b->lds_tail = std::max(b->lds_tail, c.tail_lds); b->g_cost = std::max(b->g_cost, c.cost.nblocks + c.cost.zero_wgs);
     b->max_levels = std::max(b->max_levels, c.n_levels); b->max_nb = std::max(b->max_nb, p->nb);
   }
   LVF_TRY(upload_table(b->imu_lin, il, q)); LVF_TRY(upload_table(b->imu_cost, ic, q)); LVF_TRY(upload_table(b->lin, li, q)); LVF_TRY(upload_table(b->red, rd, q)); LVF_TRY(upload_table(b->prep, pr, q));
   LVF_TRY(upload_table(b->ssp0, ss, q)); LVF_TRY(upload_table(b->chol, ch, q)); LVF_TRY(upload_table(b->back, bk, q)); LVF_TRY(upload_table(b->tail, tl, q));
-  LVF_TRY(upload_table(b->cost, co, q)); LVF_TRY(upload_table(b->dec, de, q));
+  LVF_TRY(upload_table(b->cost, co, q)); LVF_TRY(upload_table(b->dec, de, q)); LVF_TRY(upload_table(b->zero, zl, q));
   for (int lv = 1; lv < b->max_levels; ++lv) {        // level 0 rides in the Schur launch
     std::vector<SpArgs> sp(W);
     b->g_sp[lv] = 0; b->lds_sp[lv] = 0;
@@ -2991,14 +3106,16 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
 }
 
 // one LM iteration of every window of the batch; nothing is waited for
-static int batch_enqueue_iteration(lvf_problem_batch* b) {
+static int batch_enqueue_iteration(lvf_problem_batch* b, bool end_zero) {
   hipStream_t q = b->ctx->stream;
   if (!b->tables) {
-    for (lvf_problem* p : b->probs) LVF_TRY(enqueue_iteration(p));
+    for (lvf_problem* p : b->probs) LVF_TRY(enqueue_iteration(p, end_zero));
     return LVF_OK;
   }
   const unsigned W = (unsigned)b->W;
-  LVF_TRY(launch_imu_table(q, b->imu_lin.p, b->W, b->g_imu_lin, true));
+  bool clean = true;
+  for (lvf_problem* p : b->probs) { clean = clean && p->accum_clean; p->accum_clean = false; }
+  if (!clean) hipLaunchKernelGGL(k_zero_table, dim3(512, W), dim3(kT), 0, q, b->zero.p);
   hipLaunchKernelGGL(k_lin_visual_b, dim3(b->g_lin, W), dim3(kT), b->lds_lin, q, b->lin.p);
   if (b->g_red > 0) hipLaunchKernelGGL(k_tf_reduce_b, dim3(b->g_red, W), dim3(kT), 0, q, b->red.p);
   hipLaunchKernelGGL(k_prepare_b, dim3(b->g_prep, W), dim3(kT), 0, q, b->prep.p);
@@ -3011,9 +3128,9 @@ static int batch_enqueue_iteration(lvf_problem_batch* b) {
   hipLaunchKernelGGL(k_chol_backsolve_b, dim3(1, W), dim3(kBT), b->lds_back, q, b->back.p);
   hipLaunchKernelGGL(k_step_tail_b, dim3(b->g_tail, W), dim3(kT), b->lds_tail, q, b->tail.p);
   LVF_TRY(launch_imu_table(q, b->imu_cost.p, b->W, b->g_imu_cost, false));
-  hipLaunchKernelGGL(k_cost_decide_b, dim3(b->g_cost, W), dim3(kT), 0, q, b->cost.p, b->dec.p);      // (batchable windows always have visual blocks)
+  hipLaunchKernelGGL(k_cost_decide_b, dim3(b->g_cost, W), dim3(kT), 0, q, b->cost.p, b->dec.p, end_zero ? 1 : 0);      // (batchable windows always have visual blocks)
   LVF_HIP(hipGetLastError());
-  for (lvf_problem* p : b->probs) p->linearized = true;
+  for (lvf_problem* p : b->probs) { p->linearized = !end_zero; p->accum_clean = end_zero; }     // (batchable windows: the cost + decision launch clears them)
   return LVF_OK;
 }
 
@@ -3111,7 +3228,7 @@ int lvf_problem_stage_times(lvf_problem* p, const lvf_solver_options* o, double 
   LVF_TRY(upload_ctl(p, c));
   for (int r = 0; r < reps; ++r) {
     k.on = true;
-    const int rc = enqueue_iteration(p);
+    const int rc = enqueue_iteration(p, true);
     k.on = false;
     LVF_TRY(rc);
     LVF_HIP(hipStreamSynchronize(q));
@@ -3188,7 +3305,7 @@ int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_su
   LVF_TRY(upload_ctl(p, c));
   const auto wall0 = std::chrono::steady_clock::now();
   for (int it = 0; it < o->max_num_iterations; ++it) {
-    LVF_TRY(enqueue_iteration(p));
+    LVF_TRY(enqueue_iteration(p, true));
     if (it >= 1) LVF_TRY(wait_for_iteration(p, it));          // iteration it-1 is closed; iteration `it` keeps the device busy meanwhile
     if (p->rec->done) break;
     if (o->max_solver_time_in_seconds > 0.0 &&
@@ -3261,7 +3378,7 @@ int lvf_problem_batch_lm_iteration(lvf_problem_batch* b, const lvf_solver_option
     b->probs[w]->huber = o->huber_a;
     LVF_TRY(upload_ctl(b->probs[w], c));
   }
-  LVF_TRY(batch_enqueue_iteration(b));
+  LVF_TRY(batch_enqueue_iteration(b, false));
   for (int w = 0; w < b->W; ++w) {
     LmCtl c;
     LVF_TRY(download_ctl(b->probs[w], &c));
@@ -3290,7 +3407,7 @@ int lvf_problem_batch_solve(lvf_problem_batch* b, const lvf_solver_options* o, l
   }
   const auto wall0 = std::chrono::steady_clock::now();
   for (int it = 0; it < o->max_num_iterations; ++it) {
-    LVF_TRY(batch_enqueue_iteration(b));
+    LVF_TRY(batch_enqueue_iteration(b, true));
     bool all_done = true;
     for (int w = 0; w < b->W; ++w) {
       if (it >= 1) LVF_TRY(wait_for_iteration(b->probs[w], it));
