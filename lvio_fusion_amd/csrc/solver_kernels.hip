@@ -423,8 +423,10 @@ struct CostVisual {
   const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1, *tf_k2; CamD tf_left, tf_right;
   const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
 };
+struct ImuEvalArgs { int n; const double *pre, *sqrt_info; const int *kf_i, *kf_j; };      // ImuError factors evaluated inside a merged launch
 struct CostArgs {
   CostVisual a; int n_kf; StateP s; double huber; double* cost; int nblocks; const int* done;
+  ImuEvalArgs imu; int g_vis;       // workgroups [g_vis, nblocks) evaluate one ImuError factor each (imu.pre != nullptr)
   ZeroList zero; int zero_wgs;      // workgroups [nblocks, nblocks + zero_wgs) of the merged cost + decision launch clear the accumulators for the NEXT linearisation
 };
 // the calling thread's share of the candidate cost (workgroup b of the pass)
@@ -709,68 +711,69 @@ __device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, con
 // work list, the next g_tc the TwoCamera blocks, the rest the PoseOnly blocks.  The two small passes (4.6 + 8.8 us as launches of
 // their own) disappear under the TwoFrame pass; all three only meet in B, gc, C, g_rho through atomics.  A fourth segment
 // accumulates the ImuError blocks (four factors per workgroup) from the Jacobians k_imu<true> materialised just before.
-// ImuError factors of the merged linearisation launch: EVALUATED and accumulated by the same workgroup (one wave per factor, four
-// factors per workgroup), so the linearisation needs no IMU launch ahead of it and the weighted Jacobian never leaves LDS:
+// ImuError factors of the merged linearisation launch: EVALUATED and accumulated by the same workgroup (one factor per workgroup), so the linearisation needs no IMU launch ahead of it and the weighted Jacobian never leaves LDS:
 //   stage sqrt_info -> one lane forms the raw residual and the 15 x 32 pre-weighting Jacobian -> all lanes weight them ->
 //   pose columns to tangent coordinates -> J^T J / J^T r into B / gc, 1/2 |r|^2 into the cost.
-// LDS per wave (doubles): sS 225 | sM 480 (later the local 15 x 30 Jacobian) | sJw 480 | sr0 16 | sr 16 | sidx 16  = kImuWaveLds.
+// LDS (doubles): sS 225 | sM 480 (later the local 15 x 30 Jacobian) | sJw 480 | sr0 16 | sr 16 | sidx 16  = kImuWaveLds.
 constexpr int kEndZeroWgs = 1024;      // workgroups of the cost + decision launch that clear the accumulators
 constexpr int kImuWaveLds = 225 + 480 + 480 + 16 + 16 + 16;
-struct ImuEvalArgs { int n; const double *pre, *sqrt_info; const int *kf_i, *kf_j; };
-__device__ __forceinline__ void lin_imu_eval_body(const int vb, const ImuEvalArgs& I, int n_kf, const StateP& s, const uint8_t* __restrict__ pose_const,
-                                                  double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost) {
+__device__ __forceinline__ void lin_imu_eval_body(const int f, const ImuEvalArgs& I, int n_kf, const StateP& s, const uint8_t* __restrict__ pose_const,
+                                                  double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost, unsigned long long* dbg) {
+  // ONE factor per workgroup: the evaluation's serial part (one lane) is what it is, everything around it is spread over all kT threads
   extern __shared__ double lin_lds[];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int f = 4 * vb + w;
-  const bool active = f < I.n;
-  double* sS = lin_lds + w * kImuWaveLds;
+  const int tid = threadIdx.x;
+  if (f >= I.n) return;
+  if (f != 0 || tid != 0) dbg = nullptr;               // LVF_LIN_TIMING: factor 0 stamps its phases
+  if (dbg) dbg[0] = wall_clock64();
+  double* sS = lin_lds;
   double* sM = sS + 225;
   double* sJw = sM + 480;
   double* sr0 = sJw + 480;
   double* sr = sr0 + 16;
   int* sidx = reinterpret_cast<int*>(sr + 16);
-  if (active) imu_stage<true>(f, lane, I.sqrt_info, sS, sM);
+  for (int k = tid; k < 225; k += kT) sS[k] = I.sqrt_info[(size_t)f * 225 + k];
+  for (int k = tid; k < 480; k += kT) sM[k] = 0.0;
   __syncthreads();
-  if (active && lane == 0) imu_raw<true>(f, I.pre, I.kf_i, I.kf_j, s.poses, s.vel, s.ba, s.bg, sr0, sM);
+  if (dbg) dbg[1] = wall_clock64();
+  if (tid == 0) imu_raw<true>(f, I.pre, I.kf_i, I.kf_j, s.poses, s.vel, s.ba, s.bg, sr0, sM);
   __syncthreads();
-  int ki = 0, kj = 0;
-  if (active) {
-    ki = I.kf_i[f]; kj = I.kf_j[f];
-    const double r = imu_weighted_residual(lane, sS, sr0);
-    if (lane < 15) sr[lane] = r;
-    for (int e = lane; e < 480; e += 64) sJw[e] = imu_weighted_jacobian(e, sS, sM);
-    if (lane < 30) {
+  if (dbg) dbg[2] = wall_clock64();
+  const int ki = I.kf_i[f], kj = I.kf_j[f];
+  {
+    const double r = imu_weighted_residual(tid, sS, sr0);
+    if (tid < 15) sr[tid] = r;
+    for (int e = tid; e < 480; e += kT) sJw[e] = imu_weighted_jacobian(e, sS, sM);
+    if (tid < 30) {
       int g;
-      if (lane < 6) g = 6 * ki + lane; else if (lane < 15) g = 6 * n_kf + 9 * ki + (lane - 6);
-      else if (lane < 21) g = 6 * kj + (lane - 15); else g = 6 * n_kf + 9 * kj + (lane - 21);
-      sidx[lane] = g;
+      if (tid < 6) g = 6 * ki + tid; else if (tid < 15) g = 6 * n_kf + 9 * ki + (tid - 6);
+      else if (tid < 21) g = 6 * kj + (tid - 15); else g = 6 * n_kf + 9 * kj + (tid - 21);
+      sidx[tid] = g;
     }
   }
   __syncthreads();                                   // sM is dead from here: it becomes the local Jacobian sJ[15][30]
   double* sJ = sM;
-  if (active) {
-    for (int e = lane; e < 30; e += 64) {
-      const int row = e % 15, which = e / 15;            // which: 0 = pose_i, 1 = pose_j
-      const double* Jr = sJw + 32 * row + (which ? 16 : 0);
-      const int kk = which ? kj : ki;
-      const double sc = pose_const[kk] ? 0.0 : 1.0;
-      double l3[3];
-      quat_row_to_local(Jr, s.poses + 7 * kk, l3);
-      double* o = sJ + row * 30 + (which ? 15 : 0);
-      o[0] = sc * l3[0]; o[1] = sc * l3[1]; o[2] = sc * l3[2]; o[3] = sc * Jr[4]; o[4] = sc * Jr[5]; o[5] = sc * Jr[6];
-    }
-    for (int e = lane; e < 15 * 18; e += 64) {           // six 15x3 blocks: (v, ba, bg)_i = columns 7..15, (v, ba, bg)_j = columns 23..31
-      const int row = e / 18, c = e % 18;
-      sJ[row * 30 + (c < 9 ? 6 + c : 21 + (c - 9))] = sJw[32 * row + (c < 9 ? 7 + c : 23 + (c - 9))];
-    }
+  if (tid < 30) {
+    const int row = tid % 15, which = tid / 15;          // which: 0 = pose_i, 1 = pose_j
+    const double* Jr = sJw + 32 * row + (which ? 16 : 0);
+    const int kk = which ? kj : ki;
+    const double sc = pose_const[kk] ? 0.0 : 1.0;
+    double l3[3];
+    quat_row_to_local(Jr, s.poses + 7 * kk, l3);
+    double* o = sJ + row * 30 + (which ? 15 : 0);
+    o[0] = sc * l3[0]; o[1] = sc * l3[1]; o[2] = sc * l3[2]; o[3] = sc * Jr[4]; o[4] = sc * Jr[5]; o[5] = sc * Jr[6];
+  }
+  for (int e = tid; e < 15 * 18; e += kT) {              // six 15x3 blocks: (v, ba, bg)_i = columns 7..15, (v, ba, bg)_j = columns 23..31
+    const int row = e / 18, c = e % 18;
+    sJ[row * 30 + (c < 9 ? 6 + c : 21 + (c - 9))] = sJw[32 * row + (c < 9 ? 7 + c : 23 + (c - 9))];
   }
   __syncthreads();
-  double c = 0.0;
-  if (active && lane < 15) c = 0.5 * sr[lane] * sr[lane];
-  c = wave_sum(c);
-  if (!active) return;
-  if (lane == 0) atomicAdd(cost + (f & (kStripes - 1)), c);
-  for (int e = lane; e < 30 * 30; e += 64) {
+  if (dbg) dbg[3] = wall_clock64();
+  if (tid < 64) {
+    double c = tid < 15 ? 0.5 * sr[tid] * sr[tid] : 0.0;
+    c = wave_sum(c);
+    if (tid == 0) atomicAdd(cost + (f & (kStripes - 1)), c);
+  }
+  for (int e = tid; e < 30 * 30; e += kT) {
     const int a = e / 30, b = e % 30;
     const int ga = sidx[a], gb = sidx[b];
     if (gb > ga || (ga == gb && a != b)) continue;    // lower triangle in GLOBAL indices (kf_i != kf_j is validated)
@@ -779,12 +782,13 @@ __device__ __forceinline__ void lin_imu_eval_body(const int vb, const ImuEvalArg
     for (int k = 0; k < 15; ++k) h += sJ[k * 30 + a] * sJ[k * 30 + b];
     atomicAdd(&B[(size_t)ga * ld + gb], h);
   }
-  if (lane < 30) {
+  if (tid < 30) {
     double g = 0.0;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) g += sJ[k * 30 + lane] * sr[k];
-    atomicAdd(&gc[sidx[lane]], g);
+    for (int k = 0; k < 15; ++k) g += sJ[k * 30 + tid] * sr[k];
+    atomicAdd(&gc[sidx[tid]], g);
   }
+  if (dbg) dbg[4] = wall_clock64();
 }
 
 struct LinVisual {
@@ -815,7 +819,7 @@ __device__ __forceinline__ void lin_visual_body(const int b, const LinArgs& A) {
   else if (b < a.n_tfw + a.g_tc + a.g_po)
     lin_po_body<false, true>(b - a.n_tfw - a.g_tc, a.n_po, n_kf, a.po_ob, a.po_kf, a.po_pwi, a.po_pw, s, a.po_cam, huber, pose_const, B, ld, gc, cost);
   else if (a.imu.pre)
-    lin_imu_eval_body(b - a.n_tfw - a.g_tc - a.g_po, a.imu, n_kf, s, pose_const, B, ld, gc, cost);
+    lin_imu_eval_body(b - a.n_tfw - a.g_tc - a.g_po, a.imu, n_kf, s, pose_const, B, ld, gc, cost, A.dbg ? A.dbg + (size_t)a.n_tfw * 8 : nullptr);
   else
     lin_imu_body4<true>(b - a.n_tfw - a.g_tc - a.g_po, a.n_imu, n_kf, a.imu_res, a.imu_J, a.imu_i, a.imu_j, s.poses, pose_const, B, ld, gc, cost);
 }
@@ -2231,7 +2235,19 @@ __device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A,
     // each wave's sum goes out as a RETURNING atomic: its result can only come back once the add has been performed, and the barrier
     // below waits for it — so every add of this workgroup is in the sum before its ticket is drawn (a release fence here would write
     // the L2 back once per workgroup: measured 7 % slower for 8 windows than the separate decision launch)
-    const double v = wave_sum(cost_visual_value(b, A));
+    double c;
+    if (b < A.g_vis) c = cost_visual_value(b, A);
+    else {                                             // one ImuError factor at the candidate: 1/2 |sqrt_info r|^2
+      __shared__ double sS[225];
+      __shared__ double sr0[16];
+      const int f = b - A.g_vis;
+      for (int k = threadIdx.x; k < 225; k += kT) sS[k] = A.imu.sqrt_info[(size_t)f * 225 + k];
+      if (threadIdx.x == 0) imu_raw<false>(f, A.imu.pre, A.imu.kf_i, A.imu.kf_j, A.s.poses, A.s.vel, A.s.ba, A.s.bg, sr0, nullptr);
+      __syncthreads();
+      const double r = imu_weighted_residual(threadIdx.x, sS, sr0);      // rows 0..14 in lanes 0..14 of wave 0
+      c = threadIdx.x < 15 ? 0.5 * r * r : 0.0;
+    }
+    const double v = wave_sum(c);
     if ((threadIdx.x & 63) == 0 && v != 0.0) {
       const double old = atomicAdd(A.cost + (b & (kStripes - 1)), v);
       asm volatile("" ::"v"(old) : "memory");
@@ -2263,7 +2279,7 @@ static inline int grid(int n) { return (n + kT - 1) / kT; }
 struct Chain {
   bool fast = false;            // merged linearisation (sorted TwoFrame work list) available
   bool batchable = false;       // every launch of the iteration has a table form (fast + band Schur merged with sparse level 0 + no priors)
-  bool has_imu = false, has_prior = false;
+  bool has_imu = false, has_prior = false, imu_in_cost = false;
   ZeroList zero_end{};
   ZeroList zero{};              // everything a linearisation accumulates into (explicit k_zero_multi when the accumulators are not known clean)
   ImuArgs imu_lin{}, imu_cost{};
@@ -2447,8 +2463,8 @@ static int build_chain(lvf_problem* p) {
     }
     c.lin.n_kf = p->n_kf; c.lin.s = s; c.lin.huber = 0.0; c.lin.pose_const = p->pose_const.p; c.lin.B = p->B.p; c.lin.ld = p->dpad; c.lin.gc = p->gc.p; c.lin.E = p->E.p;
     c.lin.ldE = p->ldE; c.lin.C = p->C.p; c.lin.gr = p->gr.p; c.lin.cost = cost; c.lin.done = done; c.lin.dbg = nullptr;
-    c.lin.nblocks = a.n_tfw + a.g_tc + a.g_po + (a.n_imu + 3) / 4;
-    c.lin_lds = std::max((size_t)(sizeof(PoseD) / 8 + kAccSlots) * p->n_kf + 32, (size_t)4 * kImuWaveLds) * sizeof(double);
+    c.lin.nblocks = a.n_tfw + a.g_tc + a.g_po + (a.imu.pre ? a.n_imu : (a.n_imu + 3) / 4);
+    c.lin_lds = std::max((size_t)(sizeof(PoseD) / 8 + kAccSlots) * p->n_kf + 32, (size_t)std::max(kImuWaveLds, 1864 + 64)) * sizeof(double);
   }
   // damped system
   {
@@ -2500,6 +2516,9 @@ static int build_chain(lvf_problem* p) {
   fill_cost_visual(p, c.cost.a);
   c.cost.n_kf = p->n_kf; c.cost.s = s2; c.cost.huber = 0.0; c.cost.cost = p->scal.p + SC_COST_NEW; c.cost.done = done;
   c.cost.nblocks = c.cost.a.g_tc + c.cost.a.g_tf + grid(c.cost.a.n_po);
+  c.cost.g_vis = c.cost.nblocks; c.cost.imu = ImuEvalArgs{};
+  c.imu_in_cost = c.fast && c.has_imu && c.cost.nblocks > 0;         // the IMU cost rides in the merged cost + decision launch
+  if (c.imu_in_cost) { c.cost.imu = ImuEvalArgs{p->imu->n, p->imu->pre.p, p->imu->sqrt_info.p, p->imu->idx_a.p, p->imu->idx_b.p}; c.cost.nblocks += p->imu->n; }
   c.cost.zero = c.zero_end; c.cost.zero_wgs = c.fast ? kEndZeroWgs : 0;
   {
     DecideArgs& a = c.dec;
@@ -2523,7 +2542,7 @@ static bool chain_stale(const lvf_problem* p) {
 // HIP events between the stages of one LM iteration (lvf_problem_stage_times): event 0 before the first launch, event k + 1 after stage k
 enum { ST_IMU_LIN = 0, ST_LIN_VISUAL, ST_TF_REDUCE, ST_PREPARE, ST_SCHUR_SP0, ST_SP_LEVELS, ST_CHOL, ST_BACKSOLVE, ST_STEP_TAIL, ST_COST, ST_DECIDE, ST_N };
 static const char* const kStageNames[ST_N] = {"k_zero_multi (only when the accumulators are not known clean)", "k_lin_visual", "k_tf_reduce", "k_prepare", "k_schur_sp0", "k_sp_eliminate (levels 1..)",
-                                             "k_chol_step (all block steps)", "k_chol_backsolve", "k_step_tail", "k_imu<false> (+priors) + k_cost_decide (candidate cost; its last workgroup closes the iteration)", "k_lm_decide (windows without visual blocks)"};
+                                             "k_chol_step (all block steps)", "k_chol_backsolve", "k_step_tail", "k_cost_decide (candidate cost incl. the ImuError factors; its last workgroup closes the iteration; + prior passes)", "k_lm_decide (windows without visual blocks)"};
 struct StageClock { hipEvent_t ev[ST_N + 1]; int launches[ST_N]; bool on = false; };
 void stage_clock_free(StageClock* k) {
   if (!k) return;
@@ -2577,6 +2596,12 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
       }
       std::fprintf(stderr, "lin_tf phases (us, mean over %d workgroups): stage %.2f | eval+landmark atomics %.2f | k1 sums %.2f | k2 sums %.2f | flush %.2f ; first start -> last end %.2f\n",
                    la.v.n_tfw, ph[0] / la.v.n_tfw, ph[1] / la.v.n_tfw, ph[2] / la.v.n_tfw, ph[3] / la.v.n_tfw, ph[4] / la.v.n_tfw, (double)(last - first) * 0.01);
+      if (la.v.imu.pre) {
+        unsigned long long u[5];
+        LVF_HIP(hipMemcpy(u, p->dbg_lin.p + (size_t)la.v.n_tfw * 8, sizeof(u), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "lin_imu phases of factor 0 (us): stage %.2f | raw residual + pre-weighting Jacobian (one lane) %.2f | weight + to tangent %.2f | J^T J, J^T r %.2f ; start %.2f after the first TwoFrame workgroup, end %.2f before the last one's end\n",
+                     (double)(u[1] - u[0]) * 0.01, (double)(u[2] - u[1]) * 0.01, (double)(u[3] - u[2]) * 0.01, (double)(u[4] - u[3]) * 0.01, ((double)u[0] - (double)first) * 0.01, ((double)last - (double)u[4]) * 0.01);
+      }
     }
   } else {
     if (p->tc && p->tc->n)
@@ -2683,7 +2708,7 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
   // candidate cost: the small passes first, then the visual pass whose last workgroup closes the iteration
   CostArgs ca = c.cost;
   ca.huber = p->huber;
-  if (c.has_imu) LVF_TRY(launch_imu_args(q, c.imu_cost, false));
+  if (c.has_imu && !c.imu_in_cost) LVF_TRY(launch_imu_args(q, c.imu_cost, false));
   if (c.has_prior) {
     StateView view(p->ctx, p->n_kf, p->n_lm, p->poses2.p, p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->st->w_visual.p);
     LVF_TRY(launch_pose_prior(p->prior, &view.v, false));
@@ -2694,7 +2719,7 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
     hipLaunchKernelGGL(k_cost_decide, dim3(ca.nblocks + ca.zero_wgs), dim3(kT), 0, q, ca, c.dec, end_zero ? 1 : 0);
     p->accum_clean = ca.zero_wgs > 0;
     if (p->accum_clean) p->linearized = false;         // the normal equations of this iteration are gone: no reduced-system tap
-    stage_mark(p, ST_COST, 1 + (c.has_imu ? 1 : 0) + (c.has_prior ? 2 : 0));
+    stage_mark(p, ST_COST, 1 + (c.has_imu && !c.imu_in_cost ? 1 : 0) + (c.has_prior ? 2 : 0));
   } else {
     stage_mark(p, ST_COST, (c.has_imu ? 1 : 0) + (c.has_prior ? 2 : 0));
     hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(kDT), 0, q, c.dec);
@@ -3127,7 +3152,6 @@ static int batch_enqueue_iteration(lvf_problem_batch* b, bool end_zero) {
   }
   hipLaunchKernelGGL(k_chol_backsolve_b, dim3(1, W), dim3(kBT), b->lds_back, q, b->back.p);
   hipLaunchKernelGGL(k_step_tail_b, dim3(b->g_tail, W), dim3(kT), b->lds_tail, q, b->tail.p);
-  LVF_TRY(launch_imu_table(q, b->imu_cost.p, b->W, b->g_imu_cost, false));
   hipLaunchKernelGGL(k_cost_decide_b, dim3(b->g_cost, W), dim3(kT), 0, q, b->cost.p, b->dec.p, end_zero ? 1 : 0);      // (batchable windows always have visual blocks)
   LVF_HIP(hipGetLastError());
   for (lvf_problem* p : b->probs) { p->linearized = !end_zero; p->accum_clean = end_zero; }     // (batchable windows: the cost + decision launch clears them)
