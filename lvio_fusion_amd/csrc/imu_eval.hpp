@@ -77,20 +77,23 @@ __device__ __forceinline__ void imu_raw(const int f, const double* __restrict__ 
     const double* Bgi = bg + 3 * i; const double* Bgj = bg + 3 * j;
     const double T = P[OFF_SUMDT];
     const double* Jp = P + OFF_JAC;
-    double dp_dba[9], dp_dbg[9], dq_dbg[9], dv_dba[9], dv_dbg[9];
-    blk3(Jp, O_T, O_BA, dp_dba); blk3(Jp, O_T, O_BG, dp_dbg); blk3(Jp, O_R, O_BG, dq_dbg);
-    blk3(Jp, O_V, O_BA, dv_dba); blk3(Jp, O_V, O_BG, dv_dbg);
+    // the five 3x3 blocks of the pre-integration Jacobian are read where they are used (twice: here and in the Jacobian columns below)
+    // instead of being held in 90 registers across the whole function: this code shares its kernel with the visual linearisation, and
+    // the kernel's register allocation — hence its occupancy — is the maximum over everything inlined into it
     double dba[3], dbg[3];
     for (int k = 0; k < 3; ++k) { dba[k] = Bai[k] - P[OFF_LBA + k]; dbg[k] = Bgi[k] - P[OFF_LBG + k]; }
-    double th[3];
-    mat3_mul_vec(dq_dbg, dbg, th);
+    double th[3], cv[3], cp[3];
     const Qd dq{P[OFF_DQ], P[OFF_DQ + 1], P[OFF_DQ + 2], P[OFF_DQ + 3]};
+    {
+      double blk[9], a3[3], b3[3];
+      blk3(Jp, O_R, O_BG, blk); mat3_mul_vec(blk, dbg, th);
+      blk3(Jp, O_V, O_BA, blk); mat3_mul_vec(blk, dba, a3); blk3(Jp, O_V, O_BG, blk); mat3_mul_vec(blk, dbg, b3);
+      for (int k = 0; k < 3; ++k) cv[k] = P[OFF_DV + k] + a3[k] + b3[k];
+      blk3(Jp, O_T, O_BA, blk); mat3_mul_vec(blk, dba, a3); blk3(Jp, O_T, O_BG, blk); mat3_mul_vec(blk, dbg, b3);
+      for (int k = 0; k < 3; ++k) cp[k] = P[OFF_DP + k] + a3[k] + b3[k];
+    }
+    asm volatile("" ::: "memory");                        // (the blocks are loaded again below, not carried)
     const Qd cq = qmul(dq, q_delta(th));
-    double a3[3], b3[3], cv[3], cp[3];
-    mat3_mul_vec(dv_dba, dba, a3); mat3_mul_vec(dv_dbg, dbg, b3);
-    for (int k = 0; k < 3; ++k) cv[k] = P[OFF_DV + k] + a3[k] + b3[k];
-    mat3_mul_vec(dp_dba, dba, a3); mat3_mul_vec(dp_dbg, dbg, b3);
-    for (int k = 0; k < 3; ++k) cp[k] = P[OFF_DP + k] + a3[k] + b3[k];
     const Qd Qi_inv = qinv(Qi);
     double tp[3], op[3], tv[3], ov[3];
     for (int k = 0; k < 3; ++k) tp[k] = 0.5 * kG[k] * T * T + Pj[k] - Pi[k] - Vi[k] * T;
@@ -129,7 +132,7 @@ __device__ __forceinline__ void imu_raw(const int f, const double* __restrict__ 
       // v_i (cols 7..9)
       for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { MM(O_T + a, 7 + b) = -Ri_inv[3 * a + b] * T; MM(O_V + a, 7 + b) = -Ri_inv[3 * a + b]; }
       // ba_i (cols 10..12)
-      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { MM(O_T + a, 10 + b) = -dp_dba[3 * a + b]; MM(O_V + a, 10 + b) = -dv_dba[3 * a + b]; }
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { MM(O_T + a, 10 + b) = -Jp[15 * (O_T + a) + O_BA + b]; MM(O_V + a, 10 + b) = -Jp[15 * (O_V + a) + O_BA + b]; }
       for (int a = 0; a < 3; ++a) MM(O_BA + a, 10 + a) = -1.0;
       // bg_i (cols 13..15)
       {
@@ -139,10 +142,10 @@ __device__ __forceinline__ void imu_raw(const int f, const double* __restrict__ 
         for (int a = 0; a < 3; ++a)
           for (int b = 0; b < 3; ++b) {
             double s = 0.0;
-            for (int k = 0; k < 3; ++k) s += LB[3 * a + k] * dq_dbg[3 * k + b];
+            for (int k = 0; k < 3; ++k) s += LB[3 * a + k] * Jp[15 * (O_R + k) + O_BG + b];
             MM(O_R + a, 13 + b) = -s;
-            MM(O_T + a, 13 + b) = -dp_dbg[3 * a + b];
-            MM(O_V + a, 13 + b) = -dv_dbg[3 * a + b];
+            MM(O_T + a, 13 + b) = -Jp[15 * (O_T + a) + O_BG + b];
+            MM(O_V + a, 13 + b) = -Jp[15 * (O_V + a) + O_BG + b];
           }
         for (int a = 0; a < 3; ++a) MM(O_BG + a, 13 + a) = -1.0;
       }

@@ -426,7 +426,7 @@ struct CostVisual {
 struct ImuEvalArgs { int n; const double *pre, *sqrt_info; const int *kf_i, *kf_j; };      // ImuError factors evaluated inside a merged launch
 struct CostArgs {
   CostVisual a; int n_kf; StateP s; double huber; double* cost; int nblocks; const int* done;
-  ImuEvalArgs imu; int g_vis;       // workgroups [g_vis, nblocks) evaluate one ImuError factor each (imu.pre != nullptr)
+  ImuEvalArgs imu; int g_imu;       // workgroups [0, g_imu) evaluate one ImuError factor each, the visual passes follow
   ZeroList zero; int zero_wgs;      // workgroups [nblocks, nblocks + zero_wgs) of the merged cost + decision launch clear the accumulators for the NEXT linearisation
 };
 // the calling thread's share of the candidate cost (workgroup b of the pass)
@@ -715,7 +715,7 @@ __device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, con
 //   stage sqrt_info -> one lane forms the raw residual and the 15 x 32 pre-weighting Jacobian -> all lanes weight them ->
 //   pose columns to tangent coordinates -> J^T J / J^T r into B / gc, 1/2 |r|^2 into the cost.
 // LDS (doubles): sS 225 | sM 480 (later the local 15 x 30 Jacobian) | sJw 480 | sr0 16 | sr 16 | sidx 16  = kImuWaveLds.
-constexpr int kEndZeroWgs = 1024;      // workgroups of the cost + decision launch that clear the accumulators
+constexpr int kEndZeroWgs = 192;       // workgroups of the cost + decision launch that clear the accumulators
 constexpr int kImuWaveLds = 225 + 480 + 480 + 16 + 16 + 16;
 __device__ __forceinline__ void lin_imu_eval_body(const int f, const ImuEvalArgs& I, int n_kf, const StateP& s, const uint8_t* __restrict__ pose_const,
                                                   double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost, unsigned long long* dbg) {
@@ -806,20 +806,24 @@ struct LinArgs {
   LinVisual v; int n_kf; StateP s; double huber; const uint8_t* pose_const; double* B; int ld; double* gc; double* E; int ldE; double *C, *gr, *cost;
   int nblocks; const int* done; unsigned long long* dbg; int rows;
 };
-__device__ __forceinline__ void lin_visual_body(const int b, const LinArgs& A) {
-  if (b >= A.nblocks || (A.done && *A.done)) return;
+__device__ __forceinline__ void lin_visual_body(const int bx, const LinArgs& A) {
+  if (bx >= A.nblocks || (A.done && *A.done)) return;
   const LinVisual& a = A.v;
+  // the ImuError workgroups come FIRST: each is a ~12 us chain with a one-lane section, and dispatched last (of the last window of a
+  // batch) it would stick out behind everything else
+  const int g_imu_first = a.imu.pre ? a.n_imu : 0;
+  const int b = bx - g_imu_first;
   const int n_kf = A.n_kf; const StateP s = A.s; const double huber = A.huber; const uint8_t* pose_const = A.pose_const;
   double* B = A.B; const int ld = A.ld; double* gc = A.gc; double* E = A.E; const int ldE = A.ldE; double* C = A.C; double* gr = A.gr; double* cost = A.cost;
-  if (b < a.n_tfw)
+  if (bx < g_imu_first)
+    lin_imu_eval_body(bx, a.imu, n_kf, s, pose_const, B, ld, gc, cost, A.dbg ? A.dbg + (size_t)a.n_tfw * 8 : nullptr);
+  else if (b < a.n_tfw)
     lin_tf_sorted_body<true>(b, a.work, n_kf, a.tf_fo, a.tf_ob, a.tf_lm, a.tf_k1, s, a.tf_left, a.tf_right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost,
                        a.unique_lk2, A.dbg, a.cp);
   else if (b < a.n_tfw + a.g_tc)
     lin_tc_body<false>(b - a.n_tfw, a.n_tc, a.tc_lo, a.tc_ro, a.tc_lm, a.tc_kf, a.tc_w, s, a.tc_left, a.tc_right, huber, C, gr, cost);
   else if (b < a.n_tfw + a.g_tc + a.g_po)
     lin_po_body<false, true>(b - a.n_tfw - a.g_tc, a.n_po, n_kf, a.po_ob, a.po_kf, a.po_pwi, a.po_pw, s, a.po_cam, huber, pose_const, B, ld, gc, cost);
-  else if (a.imu.pre)
-    lin_imu_eval_body(b - a.n_tfw - a.g_tc - a.g_po, a.imu, n_kf, s, pose_const, B, ld, gc, cost, A.dbg ? A.dbg + (size_t)a.n_tfw * 8 : nullptr);
   else
     lin_imu_body4<true>(b - a.n_tfw - a.g_tc - a.g_po, a.n_imu, n_kf, a.imu_res, a.imu_J, a.imu_i, a.imu_j, s.poses, pose_const, B, ld, gc, cost);
 }
@@ -2236,11 +2240,11 @@ __device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A,
     // below waits for it — so every add of this workgroup is in the sum before its ticket is drawn (a release fence here would write
     // the L2 back once per workgroup: measured 7 % slower for 8 windows than the separate decision launch)
     double c;
-    if (b < A.g_vis) c = cost_visual_value(b, A);
+    if (b >= A.g_imu) c = cost_visual_value(b - A.g_imu, A);
     else {                                             // one ImuError factor at the candidate: 1/2 |sqrt_info r|^2
       __shared__ double sS[225];
       __shared__ double sr0[16];
-      const int f = b - A.g_vis;
+      const int f = b;
       for (int k = threadIdx.x; k < 225; k += kT) sS[k] = A.imu.sqrt_info[(size_t)f * 225 + k];
       if (threadIdx.x == 0) imu_raw<false>(f, A.imu.pre, A.imu.kf_i, A.imu.kf_j, A.s.poses, A.s.vel, A.s.ba, A.s.bg, sr0, nullptr);
       __syncthreads();
@@ -2516,9 +2520,9 @@ static int build_chain(lvf_problem* p) {
   fill_cost_visual(p, c.cost.a);
   c.cost.n_kf = p->n_kf; c.cost.s = s2; c.cost.huber = 0.0; c.cost.cost = p->scal.p + SC_COST_NEW; c.cost.done = done;
   c.cost.nblocks = c.cost.a.g_tc + c.cost.a.g_tf + grid(c.cost.a.n_po);
-  c.cost.g_vis = c.cost.nblocks; c.cost.imu = ImuEvalArgs{};
+  c.cost.g_imu = 0; c.cost.imu = ImuEvalArgs{};
   c.imu_in_cost = c.fast && c.has_imu && c.cost.nblocks > 0;         // the IMU cost rides in the merged cost + decision launch
-  if (c.imu_in_cost) { c.cost.imu = ImuEvalArgs{p->imu->n, p->imu->pre.p, p->imu->sqrt_info.p, p->imu->idx_a.p, p->imu->idx_b.p}; c.cost.nblocks += p->imu->n; }
+  if (c.imu_in_cost) { c.cost.imu = ImuEvalArgs{p->imu->n, p->imu->pre.p, p->imu->sqrt_info.p, p->imu->idx_a.p, p->imu->idx_b.p}; c.cost.g_imu = p->imu->n; c.cost.nblocks += p->imu->n; }
   c.cost.zero = c.zero_end; c.cost.zero_wgs = c.fast ? kEndZeroWgs : 0;
   {
     DecideArgs& a = c.dec;
