@@ -2841,7 +2841,42 @@ static int build_elimination_plan(lvf_problem* p) {
   std::vector<NodeInfo> nodes;
   std::vector<char> alive(n, 1);
   SpLevels lv{};
-  while (sparse && lv.n < kSpMaxLevels) {
+  // How many levels to eliminate sparsely.  Whatever is left rides in the dense corner, which is factorised in 64-column block steps:
+  // a level beyond the first (level 0 rides in the Schur launch) costs a launch (~8.5 us), a block step ~18 us.  A dry run of the greedy
+  // level construction gives the number of blocks left after each level; the cut-off minimises 8.5 (levels - 1) + 18 block steps (measured launch costs, us).
+  // (At 50 keyframes: 5 levels and one block in the corner's padding instead of 6 levels; at 5: level 0 only.)
+  int max_levels = kSpMaxLevels;
+  if (sparse) {
+    std::vector<std::vector<char>> va2 = va;
+    std::vector<char> alive2(n, 1);
+    std::vector<int> left_after;                      // blocks left after level l
+    for (int l = 0; l < kSpMaxLevels; ++l) {
+      std::vector<char> blocked(n, 0);
+      std::vector<int> chosen;
+      for (int k = 0; k < n; ++k) {
+        if (!alive2[k] || blocked[k]) continue;
+        chosen.push_back(k);
+        for (int u = 0; u < n; ++u) if (va2[k][u]) blocked[u] = 1;
+      }
+      if (chosen.empty()) break;
+      for (int b : chosen) {
+        std::vector<int> nb_;
+        for (int u = 0; u < n; ++u) if (va2[b][u] && alive2[u]) nb_.push_back(u);
+        for (int u : nb_) { for (int w : nb_) if (w != u) va2[u][w] = 1; va2[u][b] = 0; }
+        alive2[b] = 0;
+      }
+      int left = 0;
+      for (int k = 0; k < n; ++k) left += alive2[k] ? 1 : 0;
+      left_after.push_back(left);
+    }
+    double best = 1e300;
+    for (size_t l = 0; l < left_after.size(); ++l) {
+      const int steps = (9 * left_after[l] + p->dp + 1 + 63) / 64;
+      const double cost = 8.5 * (double)l + 18.0 * steps;
+      if (cost < best - 1e-9) { best = cost; max_levels = (int)l + 1; }
+    }
+  }
+  while (sparse && lv.n < std::min(max_levels, kSpMaxLevels)) {
     std::vector<char> blocked(n, 0);
     std::vector<int> chosen;
     for (int k = 0; k < n; ++k) {
