@@ -185,6 +185,8 @@ struct lvf_batch {
   bool evaluated = false, have_jac = false;
   bool sorted_by_kf = false; // blocks ordered by (current) keyframe
   bool unique_lk2_known = false;  // two-frame: the creator guarantees no (landmark, current keyframe) pair repeats (skips the host check)
+  std::vector<int32_t> kf2_counts; // two-frame, set by a creator that ALSO guarantees k1 < k2 for every block: blocks per current keyframe (ascending);
+                                   // the solver then builds its work list from these counts without walking per-block host copies of the indices
   int min_n_kf = 0, min_n_lm = 0;  // smallest state the index arrays are valid for
   std::vector<int32_t> host_kf1, host_kf2, host_lm;  // two-frame batches keep their indices for the solver's work list / uniqueness check
   lvf::CamD cam_a{}, cam_b{};  // visual: cam_a = left / cam0, cam_b = right

@@ -1732,11 +1732,26 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     for (int j = 0; j < 9; ++j) {
       const double djj = lane_bcast(a[j], j);
       bad |= !(djj > 0.0);
-      const double inv_l = rsqrt(fmax(djj, 1e-300));
-      a[j] = (lane == j) ? djj * inv_l : a[j] * inv_l;
+      // hardware estimate + one second-order correction (as in the dense corner); lane j holds A_jj itself, so no select
+      const double y0 = __builtin_amdgcn_rsq(djj);
+      const double e = fma(-djj * y0, y0, 1.0);
+      const double inv_l = fma(y0 * e, fma(e, 0.375, 0.5), y0);
+      a[j] *= inv_l;
       if (lane == j) linv[j] = inv_l;
-#pragma unroll
-      for (int t = j + 1; t < 9; ++t) a[t] -= a[j] * lane_bcast(a[j], t);   // A_rt -= L_rj L_tj (meaningful for t <= r)
+      // A_rt -= L_rj L_tj (meaningful for t <= r): L_tj sits in lane t of the same 16-lane row — the DPP row broadcast hands it to the
+      // multiply-add directly (one instruction per column instead of two v_readlane + one FMA)
+      {
+        const double m = -a[j];
+        asm volatile("s_nop 4");
+        if (j < 1) fmac_row_bcast<1>(a[1], a[j], m);
+        if (j < 2) fmac_row_bcast<2>(a[2], a[j], m);
+        if (j < 3) fmac_row_bcast<3>(a[3], a[j], m);
+        if (j < 4) fmac_row_bcast<4>(a[4], a[j], m);
+        if (j < 5) fmac_row_bcast<5>(a[5], a[j], m);
+        if (j < 6) fmac_row_bcast<6>(a[6], a[j], m);
+        if (j < 7) fmac_row_bcast<7>(a[7], a[j], m);
+        if (j < 8) fmac_row_bcast<8>(a[8], a[j], m);
+      }
     }
     if (lane < 9) {
 #pragma unroll
@@ -2982,7 +2997,19 @@ int problem_configure(lvf_problem* p) {
   p->tf_work.n = 0;
   p->tf_unique_lk2 = false; p->tf_k1_first = false; p->compact = false;
   lvf_batch* two_frame = p->tf;
-  if (two_frame && two_frame->n && two_frame->sorted_by_kf && !two_frame->host_kf2.empty()) {
+  if (two_frame && two_frame->n && two_frame->sorted_by_kf && !two_frame->kf2_counts.empty() && two_frame->unique_lk2_known) {
+    // the creator (the persistent window) vouches for the shape: sorted by current keyframe, k1 < k2, one block per (landmark, keyframe)
+    size_t total = 0, nw = 0;
+    for (int32_t c : two_frame->kf2_counts) { total += (size_t)c; nw += ((size_t)c + kT - 1) / kT; }
+    if (total != (size_t)two_frame->n) { set_error("two-frame batch: per-keyframe counts do not add up to the number of blocks"); return LVF_ERR_INVALID; }
+    LVF_TRY(p->h_tf_work.reserve(nw + 1));
+    nw = 0;
+    int at = 0;
+    for (size_t k = 0; k < two_frame->kf2_counts.size(); ++k)
+      for (int left = two_frame->kf2_counts[k]; left > 0; left -= kT) { const int c = std::min(left, kT); p->h_tf_work[nw++] = TfWork{at, c, (int)k}; at += c; }
+    LVF_TRY(p->tf_work.assign(p->h_tf_work.p, nw, ctx->stream));
+    p->tf_k1_first = true; p->tf_unique_lk2 = true;
+  } else if (two_frame && two_frame->n && two_frame->sorted_by_kf && !two_frame->host_kf2.empty()) {
     // work list for the sorted fast path: runs of <= kT blocks sharing one current keyframe; k1 == k2 disables it
     const std::vector<int32_t>& k2 = two_frame->host_kf2; const std::vector<int32_t>& k1 = two_frame->host_kf1;
     bool ok = true, k1_first = true;

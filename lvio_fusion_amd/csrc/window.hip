@@ -22,6 +22,11 @@
 #include "host_se3.hpp"
 #include "lvf_internal.hpp"
 
+namespace lvf {
+struct alignas(64) LmHot { double right_ob[2]; double pw[3]; int64_t birth_kf; int bpos; int slot; int fixed; int pad; };
+static_assert(sizeof(LmHot) == 64, "one cache line per landmark");
+}  // namespace lvf
+
 struct lvf_window {
   struct Obs { int64_t lm_id; int lm; double ob[2]; };  // lm = index into lms
   struct Kf {
@@ -67,9 +72,10 @@ struct lvf_window {
   lvf_state* rej_st = nullptr;         // the window's poses with unit visual weights
   lvf::DevBuf<uint8_t> rej_flags;
   // pinned staging for the per-tick block lists (observations / indices per functor type)
-  lvf::HostPin<double> h_tc_l, h_tc_r, h_tf_f, h_tf_o, h_po_o, h_po_pw;
-  lvf::HostPin<int32_t> h_tc_lm, h_tc_kf, h_tf_lm, h_tf_k1, h_tf_k2, h_po_kf, h_po_pi;
-  lvf::HostPin<double> h_state;      // poses | vel | ba | bg | w_visual | inv_depth
+  lvf::HostPin<double> h_state;      // poses | vel | ba | bg | w_visual | inv_depth (read-back staging)
+  std::vector<lvf::LmHot> hot;                           // per-tick compact copy of what the feature walk reads of a landmark
+  lvf::HostPin<unsigned char> h_stage;                   // the tick's packed upload (records + plain segments)
+  lvf::DevBuf<unsigned char> d_stage;
   lvf_problem* prob = nullptr;
   // assembly of the last solve
   std::vector<int> slot_lm;                              // dense landmark slot -> index into lms
@@ -144,13 +150,17 @@ static void landmarks_to_world(const lvf_window* w, std::vector<double>& lm_pw, 
   lm_pw.assign((size_t)3 * nl, 0.0);
   lm_birth_pos.assign(nl, -1);
   const int64_t first_id = w->kfs.front().id;
+  std::vector<int64_t> ids(n_kf);                          // ascending: lvf_window_add_keyframe only accepts increasing ids
+  for (int k = 0; k < n_kf; ++k) ids[k] = w->kfs[k].id;
   for (size_t i = 0; i < nl; ++i) {
     const lvf_window::Lm& l = w->lms[i];
     if (l.fixed) { std::memcpy(&lm_pw[3 * i], l.pw, 24); continue; }
     if (l.birth_kf < first_id) continue;
-    auto ib = w->kf_index.find(l.birth_kf);
-    if (ib == w->kf_index.end()) continue;
-    const int bp = ib->second;
+    // position of the birth frame: the window's ids ascend, so a binary search over <= a few dozen ids (a hash lookup per landmark
+    // was most of this function: 10 k lookups per tick)
+    const int64_t* ib = std::lower_bound(ids.data(), ids.data() + n_kf, l.birth_kf);
+    if (ib == ids.data() + n_kf || *ib != l.birth_kf) continue;
+    const int bp = (int)(ib - ids.data());
     lm_birth_pos[i] = bp;
     const double d = 1.0 / l.inv_depth;
     const double ps[3] = {(l.right_ob[0] - w->right.cx) * d / w->right.fx, (l.right_ob[1] - w->right.cy) * d / w->right.fy, d};
@@ -164,12 +174,85 @@ static void landmarks_to_world(const lvf_window* w, std::vector<double>& lm_pw, 
   }
 }
 
+// What the per-feature walk of lvf_window_solve needs of a landmark, in ONE cache line (the walk is bound by its random accesses:
+// through Lm + two side arrays it touched four lines per feature)
+static void landmarks_hot(const lvf_window* w, std::vector<LmHot>& hot) {
+  std::vector<double> lm_pw;
+  std::vector<int> lm_birth_pos;
+  landmarks_to_world(w, lm_pw, lm_birth_pos);
+  const size_t nl = w->lms.size();
+  hot.resize(nl);
+  for (size_t i = 0; i < nl; ++i) {
+    const lvf_window::Lm& l = w->lms[i];
+    LmHot& h = hot[i];
+    h.right_ob[0] = l.right_ob[0]; h.right_ob[1] = l.right_ob[1]; h.pw[0] = lm_pw[3 * i]; h.pw[1] = lm_pw[3 * i + 1]; h.pw[2] = lm_pw[3 * i + 2];
+    h.birth_kf = l.birth_kf; h.bpos = lm_birth_pos[i]; h.slot = -1; h.fixed = l.fixed ? 1 : 0; h.pad = 0;
+  }
+}
+
 // flags[i] = 1 iff |residual_i| > max_err  (residual pairs of a PoseOnly pass with unit weights = pixel errors)
 __global__ __launch_bounds__(256) void k_flag_outliers(int n, const double2* __restrict__ res, double max_err, uint8_t* __restrict__ flags) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const double2 r = res[i];
   flags[i] = sqrt(r.x * r.x + r.y * r.y) > max_err ? 1 : 0;      // Vector2d::norm() > 10 (backend.cpp:239)
+}
+
+// ---- the tick's upload: ONE host-to-device copy of a packed staging buffer, unpacked on the device.
+// The block lists used to go up as ~25 separate copies; each is a blit launch of its own (~5 us) behind ~10 us of submission latency,
+// and together they kept the GPU waiting for 0.33 ms per tick.  The host now writes one 48-byte record per block —
+//   TwoCamera {left ob, right ob, landmark slot, keyframe}   TwoFrame {first ob, ob, landmark slot, k1, k2}   PoseOnly {ob, pw, keyframe, table row}
+// — into one pinned buffer, followed by the small plain arrays (state, IMU pre-integrations and indices, priors); k_window_unpack turns
+// the records into the batches' SoA arrays and copies the plain segments to their buffers.
+struct TcRec { double l[2], r[2]; int32_t lm, kf, pad0, pad1; };
+struct TfRec { double f[2], o[2]; int32_t lm, k1, k2, pad0; };
+struct PoRec { double o[2], pw[3]; int32_t kf, pi; };
+static_assert(sizeof(TcRec) == 48 && sizeof(TfRec) == 48 && sizeof(PoRec) == 48, "staging records are 48 bytes");
+constexpr int kMaxSegs = 20;
+struct UnpackArgs {
+  const unsigned char* stage;
+  int ntc, ntf, npo; size_t off_tc, off_tf, off_po;
+  double2 *tc_l, *tc_r; int32_t *tc_lm, *tc_kf;
+  double2 *tf_f, *tf_o; int32_t *tf_lm, *tf_k1, *tf_k2;
+  double2* po_o; double* po_pw; int32_t *po_kf, *po_pi;
+  int n_segs; unsigned char* seg_dst[kMaxSegs]; size_t seg_off[kMaxSegs]; unsigned seg_words[kMaxSegs];   // 16-byte words (sizes are padded up)
+  int g_tc, g_tf, g_po, g_seg;
+};
+__global__ __launch_bounds__(256) void k_window_unpack(UnpackArgs a) {
+  int b = blockIdx.x;
+  const int t = threadIdx.x;
+  if (b < a.g_tc) {
+    const int i = b * 256 + t;
+    if (i < a.ntc) { const TcRec r = reinterpret_cast<const TcRec*>(a.stage + a.off_tc)[i]; a.tc_l[i] = make_double2(r.l[0], r.l[1]); a.tc_r[i] = make_double2(r.r[0], r.r[1]); a.tc_lm[i] = r.lm; a.tc_kf[i] = r.kf; }
+    return;
+  }
+  b -= a.g_tc;
+  if (b < a.g_tf) {
+    const int i = b * 256 + t;
+    if (i < a.ntf) {
+      const TfRec r = reinterpret_cast<const TfRec*>(a.stage + a.off_tf)[i];
+      a.tf_f[i] = make_double2(r.f[0], r.f[1]); a.tf_o[i] = make_double2(r.o[0], r.o[1]); a.tf_lm[i] = r.lm; a.tf_k1[i] = r.k1; a.tf_k2[i] = r.k2;
+    }
+    return;
+  }
+  b -= a.g_tf;
+  if (b < a.g_po) {
+    const int i = b * 256 + t;
+    if (i < a.npo) {
+      const PoRec r = reinterpret_cast<const PoRec*>(a.stage + a.off_po)[i];
+      a.po_o[i] = make_double2(r.o[0], r.o[1]); a.po_pw[3 * i] = r.pw[0]; a.po_pw[3 * i + 1] = r.pw[1]; a.po_pw[3 * i + 2] = r.pw[2]; a.po_kf[i] = r.kf; a.po_pi[i] = r.pi;
+    }
+    return;
+  }
+  b -= a.g_po;
+  // plain segments: workgroup b strides over every segment (static indices only: no scratch)
+#pragma unroll
+  for (int k = 0; k < kMaxSegs; ++k) {
+    if (k >= a.n_segs) break;
+    const uint4* src = reinterpret_cast<const uint4*>(a.stage + a.seg_off[k]);
+    uint4* dst = reinterpret_cast<uint4*>(a.seg_dst[k]);
+    for (unsigned i = (unsigned)b * 256 + t; i < a.seg_words[k]; i += (unsigned)a.g_seg * 256) dst[i] = src[i];
+  }
 }
 
 }  // namespace lvf
@@ -328,29 +411,32 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t_begin = now();
-  // ---- assemble the block lists in BuildProblem's order
+  // ---- assemble the block lists in BuildProblem's order, as 48-byte records in ONE pinned staging buffer (see k_window_unpack)
   std::vector<double> pr_t, pr_w, pr_v;
   std::vector<int32_t> imu_i, imu_j, pr_a, pr_b;
-  HostPin<double>&tc_l = w->h_tc_l, &tc_r = w->h_tc_r, &tf_f = w->h_tf_f, &tf_o = w->h_tf_o, &po_o = w->h_po_o, &po_pw = w->h_po_pw;
-  HostPin<int32_t>&tc_lm = w->h_tc_lm, &tc_kf = w->h_tc_kf, &tf_lm = w->h_tf_lm, &tf_k1 = w->h_tf_k1, &tf_k2 = w->h_tf_k2, &po_kf = w->h_po_kf, &po_pi = w->h_po_pi;
   std::vector<lvf_preint> imu_pre;
-  for (lvf_window::Lm& l : w->lms) l.slot = -1;
   w->slot_lm.clear();
   // landmark->ToWorld() once per live landmark per tick (the reference recomputes it per feature) with the keyframe rotations
   // expanded once, and per frame the one row of the world->cam0 transform that Camera::Far needs
-  std::vector<double> lm_pw;
-  std::vector<int> lm_birth_pos;
-  landmarks_to_world(w, lm_pw, lm_birth_pos);
+  std::vector<LmHot>& hot = w->hot;
+  landmarks_hot(w, hot);
   double inv_e[7];
   hse3::inv(w->left.extrinsic, inv_e);
   const double far_z = w->opt.baseline * 50.0;
-  // block arrays are written through raw cursors into buffers sized for the worst case (every feature in every list)
   size_t n_obs = 0;
   for (const lvf_window::Kf& f : w->kfs) n_obs += f.obs.size();
-  LVF_TRY(tc_l.reserve(2 * n_obs)); LVF_TRY(tc_r.reserve(2 * n_obs)); LVF_TRY(tf_f.reserve(2 * n_obs)); LVF_TRY(tf_o.reserve(2 * n_obs));
-  LVF_TRY(po_o.reserve(2 * n_obs)); LVF_TRY(po_pw.reserve(3 * n_obs));
-  LVF_TRY(tc_lm.reserve(n_obs)); LVF_TRY(tc_kf.reserve(n_obs)); LVF_TRY(tf_lm.reserve(n_obs)); LVF_TRY(tf_k1.reserve(n_obs)); LVF_TRY(tf_k2.reserve(n_obs));
-  LVF_TRY(po_kf.reserve(n_obs)); LVF_TRY(po_pi.reserve(n_obs));
+  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  // record regions sized by their upper bounds: one TwoCamera block per live landmark at most, every other feature one TwoFrame or
+  // PoseOnly block; the PoseOnly region comes last so that the copy ends where its data ends
+  const size_t cap_tc = std::min(n_obs, w->lms.size());
+  const size_t off_tc = 0, off_tf = off_tc + cap_tc * 48, off_po = off_tf + n_obs * 48;
+  const size_t tail_bound = up16((size_t)(17 * n_kf) * 8) + 8 * up16((size_t)n_kf * 8 + 64) + up16(w->lms.size() * 8 + 16) + up16((size_t)n_kf * 467 * 8) + 4096;
+  LVF_TRY(w->h_stage.reserve(off_po + n_obs * 48 + tail_bound));
+  unsigned char* hs = w->h_stage.p;
+  TcRec* tcr = reinterpret_cast<TcRec*>(hs + off_tc);
+  TfRec* tfr = reinterpret_cast<TfRec*>(hs + off_tf);
+  PoRec* por = reinterpret_cast<PoRec*>(hs + off_po);
+  std::vector<int32_t> kf2_counts(n_kf, 0);
   size_t ntc = 0, ntf = 0, npo = 0;
   for (int k = 0; k < n_kf; ++k) {
     lvf_window::Kf& f = w->kfs[k];
@@ -369,23 +455,26 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
     }
     int near_visual = 0;
     for (const lvf_window::Obs& ob : f.obs) {
-      lvf_window::Lm& l = w->lms[ob.lm];
+      LmHot& l = hot[ob.lm];
       if (l.birth_kf == f.id) {
-        tc_l[2 * ntc] = ob.ob[0]; tc_l[2 * ntc + 1] = ob.ob[1]; tc_r[2 * ntc] = l.right_ob[0]; tc_r[2 * ntc + 1] = l.right_ob[1];
         if (l.slot < 0) { l.slot = (int)w->slot_lm.size(); w->slot_lm.push_back(ob.lm); }
-        tc_lm[ntc] = l.slot; tc_kf[ntc] = k; ++ntc;
+        TcRec& r = tcr[ntc++];
+        r.l[0] = ob.ob[0]; r.l[1] = ob.ob[1]; r.r[0] = l.right_ob[0]; r.r[1] = l.right_ob[1]; r.lm = l.slot; r.kf = k;
         continue;
       }
-      const double* pw = &lm_pw[(size_t)3 * ob.lm];
-      const int bpos = lm_birth_pos[ob.lm];
+      const double* pw = l.pw;
+      const int bpos = l.bpos;
       if (bpos < 0) {
         if (!l.fixed) continue;                        // birth frame unknown (never happens through this API)
-        po_o[2 * npo] = ob.ob[0]; po_o[2 * npo + 1] = ob.ob[1]; po_pw[3 * npo] = pw[0]; po_pw[3 * npo + 1] = pw[1]; po_pw[3 * npo + 2] = pw[2];
-        po_pi[npo] = (int)npo; po_kf[npo] = k; ++npo;
+        PoRec& r = por[npo];
+        r.o[0] = ob.ob[0]; r.o[1] = ob.ob[1]; r.pw[0] = pw[0]; r.pw[1] = pw[1]; r.pw[2] = pw[2]; r.kf = k; r.pi = (int)npo;
+        ++npo;
       } else {
-        tf_f[2 * ntf] = l.right_ob[0]; tf_f[2 * ntf + 1] = l.right_ob[1]; tf_o[2 * ntf] = ob.ob[0]; tf_o[2 * ntf + 1] = ob.ob[1];
         if (l.slot < 0) { l.slot = (int)w->slot_lm.size(); w->slot_lm.push_back(ob.lm); }
-        tf_lm[ntf] = l.slot; tf_k1[ntf] = bpos; tf_k2[ntf] = k; ++ntf;
+        TfRec& r = tfr[ntf];
+        r.f[0] = l.right_ob[0]; r.f[1] = l.right_ob[1]; r.o[0] = ob.ob[0]; r.o[1] = ob.ob[1]; r.lm = l.slot; r.k1 = bpos; r.k2 = k;
+        ++kf2_counts[k];
+        ++ntf;
       }
       if (!(zrow[0] * pw[0] + zrow[1] * pw[1] + zrow[2] * pw[2] + zoff > far_z)) ++near_visual;   // !Camera::Far
     }
@@ -401,6 +490,8 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
       pr_b.push_back(k); pr_t.insert(pr_t.end(), t7, t7 + 7); pr_w.push_back(w->opt.prior_weight); pr_v.push_back(w->opt.prior_v);
     }
   }
+  for (size_t i = 0; i < hot.size(); ++i) w->lms[i].slot = hot[i].slot;
+  LVF_REQUIRE(ntc <= cap_tc, "lvf_window_solve: more TwoCamera blocks than live landmarks (%zu > %zu)", ntc, cap_tc);
   const int n_lm = (int)w->slot_lm.size();
   w->n_lm_problem = n_lm;
   w->n_tc = (int)ntc; w->n_tf = (int)ntf; w->n_po = (int)npo; w->n_imu = (int)imu_i.size(); w->n_prior = (int)pr_b.size();
@@ -418,48 +509,87 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   }
   lvf_state* st = w->st;
   st->n_kf = n_kf; st->n_lm = n_lm;
-  // state arrays live in one pinned staging block (upload now, read-back after the solve)
+  // the read-back staging of the state (filled after the solve)
   const size_t o_pose = 0, o_vel = (size_t)7 * n_kf, o_ba = o_vel + (size_t)3 * n_kf, o_bg = o_ba + (size_t)3 * n_kf, o_wv = o_bg + (size_t)3 * n_kf,
                o_invd = o_wv + n_kf;
   LVF_TRY(w->h_state.reserve(o_invd + n_lm));
-  double *poses = w->h_state.p + o_pose, *vel = w->h_state.p + o_vel, *ba = w->h_state.p + o_ba, *bg = w->h_state.p + o_bg, *wv = w->h_state.p + o_wv,
-         *invd = w->h_state.p + o_invd;
-  for (int k = 0; k < n_kf; ++k) {
-    const lvf_window::Kf& f = w->kfs[k];
-    std::memcpy(&poses[(size_t)7 * k], f.pose, 56); std::memcpy(&vel[(size_t)3 * k], f.vel, 24); std::memcpy(&ba[(size_t)3 * k], f.ba, 24);
-    std::memcpy(&bg[(size_t)3 * k], f.bg, 24); wv[k] = f.w_visual;
-  }
-  for (int l = 0; l < n_lm; ++l) invd[l] = w->lms[w->slot_lm[l]].inv_depth;
-  LVF_TRY(st->poses.assign(poses, (size_t)7 * n_kf, s)); LVF_TRY(st->vel.assign(vel, (size_t)3 * n_kf, s)); LVF_TRY(st->ba.assign(ba, (size_t)3 * n_kf, s));
-  LVF_TRY(st->bg.assign(bg, (size_t)3 * n_kf, s)); LVF_TRY(st->w_visual.assign(wv, n_kf, s)); LVF_TRY(st->inv_depth.assign(invd, n_lm, s));
+  double *poses = w->h_state.p + o_pose, *vel = w->h_state.p + o_vel, *ba = w->h_state.p + o_ba, *bg = w->h_state.p + o_bg, *invd = w->h_state.p + o_invd;
+  // the plain segments behind the PoseOnly records: state, IMU, priors.  Every destination gets two spare elements: segments are
+  // copied in 16-byte words.
+  UnpackArgs ua{};
+  size_t cur = up16(off_po + npo * 48);
+  auto seg = [&](void* dst, size_t bytes) -> unsigned char* {
+    unsigned char* at = hs + cur;
+    if (bytes) { ua.seg_dst[ua.n_segs] = static_cast<unsigned char*>(dst); ua.seg_off[ua.n_segs] = cur; ua.seg_words[ua.n_segs] = (unsigned)((bytes + 15) / 16); ++ua.n_segs; }
+    cur += up16(bytes);
+    return at;
+  };
   auto idx_ok = [](lvf_batch* b, int n, int nkf, int nlm) { b->n = n; b->min_n_kf = nkf; b->min_n_lm = nlm; b->evaluated = false; };
-  LVF_TRY(w->tc->ob_a.assign(tc_l.p, 2 * ntc, s)); LVF_TRY(w->tc->ob_b.assign(tc_r.p, 2 * ntc, s));
-  LVF_TRY(w->tc->idx_a.assign(tc_lm.p, ntc, s)); LVF_TRY(w->tc->idx_b.assign(tc_kf.p, ntc, s));
+  LVF_TRY(st->poses.ensure((size_t)7 * n_kf + 2)); LVF_TRY(st->vel.ensure((size_t)3 * n_kf + 2)); LVF_TRY(st->ba.ensure((size_t)3 * n_kf + 2)); LVF_TRY(st->bg.ensure((size_t)3 * n_kf + 2));
+  LVF_TRY(st->w_visual.ensure((size_t)n_kf + 2)); LVF_TRY(st->inv_depth.ensure((size_t)n_lm + 2));
+  st->poses.n = (size_t)7 * n_kf; st->vel.n = st->ba.n = st->bg.n = (size_t)3 * n_kf; st->w_visual.n = n_kf; st->inv_depth.n = n_lm;
+  {
+    double* sp = reinterpret_cast<double*>(seg(st->poses.p, (size_t)7 * n_kf * 8));
+    double* sv = reinterpret_cast<double*>(seg(st->vel.p, (size_t)3 * n_kf * 8));
+    double* sa = reinterpret_cast<double*>(seg(st->ba.p, (size_t)3 * n_kf * 8));
+    double* sg = reinterpret_cast<double*>(seg(st->bg.p, (size_t)3 * n_kf * 8));
+    double* sw = reinterpret_cast<double*>(seg(st->w_visual.p, (size_t)n_kf * 8));
+    double* si = reinterpret_cast<double*>(seg(st->inv_depth.p, (size_t)n_lm * 8));
+    for (int k = 0; k < n_kf; ++k) {
+      const lvf_window::Kf& f = w->kfs[k];
+      std::memcpy(&sp[(size_t)7 * k], f.pose, 56); std::memcpy(&sv[(size_t)3 * k], f.vel, 24); std::memcpy(&sa[(size_t)3 * k], f.ba, 24);
+      std::memcpy(&sg[(size_t)3 * k], f.bg, 24); sw[k] = f.w_visual;
+    }
+    for (int l = 0; l < n_lm; ++l) si[l] = w->lms[w->slot_lm[l]].inv_depth;
+  }
+  // block arrays (filled by the unpack kernel from the records)
+  LVF_TRY(w->tc->ob_a.ensure(2 * ntc)); LVF_TRY(w->tc->ob_b.ensure(2 * ntc)); LVF_TRY(w->tc->idx_a.ensure(ntc)); LVF_TRY(w->tc->idx_b.ensure(ntc));
   idx_ok(w->tc, w->n_tc, n_kf, n_lm);
-  LVF_TRY(w->tf->ob_a.assign(tf_f.p, 2 * ntf, s)); LVF_TRY(w->tf->ob_b.assign(tf_o.p, 2 * ntf, s));
-  LVF_TRY(w->tf->idx_a.assign(tf_lm.p, ntf, s)); LVF_TRY(w->tf->idx_b.assign(tf_k1.p, ntf, s)); LVF_TRY(w->tf->idx_c.assign(tf_k2.p, ntf, s));
+  LVF_TRY(w->tf->ob_a.ensure(2 * ntf)); LVF_TRY(w->tf->ob_b.ensure(2 * ntf)); LVF_TRY(w->tf->idx_a.ensure(ntf)); LVF_TRY(w->tf->idx_b.ensure(ntf)); LVF_TRY(w->tf->idx_c.ensure(ntf));
   idx_ok(w->tf, w->n_tf, n_kf, n_lm);
-  w->tf->sorted_by_kf = true; w->tf->host_kf1.assign(tf_k1.p, tf_k1.p + ntf); w->tf->host_kf2.assign(tf_k2.p, tf_k2.p + ntf); w->tf->host_lm.clear(); w->tf->unique_lk2_known = true;   // Kf::sort_unique keeps one observation per (keyframe, landmark)     // assembled frame by frame: sorted by current keyframe
-  LVF_TRY(w->po->ob_a.assign(po_o.p, 2 * npo, s)); LVF_TRY(w->po->idx_a.assign(po_kf.p, npo, s)); LVF_TRY(w->po->idx_b.assign(po_pi.p, npo, s));
-  LVF_TRY(w->po->table.assign(po_pw.p, 3 * npo, s));
+  w->tf->sorted_by_kf = true; w->tf->host_kf1.clear(); w->tf->host_kf2.clear(); w->tf->host_lm.clear(); w->tf->unique_lk2_known = true; w->tf->kf2_counts = std::move(kf2_counts);   // Kf::sort_unique keeps one observation per (keyframe, landmark); assembled frame by frame: sorted by current keyframe
+  LVF_TRY(w->po->ob_a.ensure(2 * npo)); LVF_TRY(w->po->idx_a.ensure(npo)); LVF_TRY(w->po->idx_b.ensure(npo)); LVF_TRY(w->po->table.ensure(3 * npo));
   idx_ok(w->po, w->n_po, n_kf, 0); w->po->n_table = w->n_po; w->po->sorted_by_kf = true;
   {
     lvf_batch* b = w->imu;
-    LVF_TRY(b->pre.assign(reinterpret_cast<const double*>(imu_pre.data()), (size_t)467 * w->n_imu, s));
-    LVF_TRY(put(b->idx_a, imu_i, s)); LVF_TRY(put(b->idx_b, imu_j, s));
+    const size_t ni = (size_t)w->n_imu;
+    LVF_TRY(b->pre.ensure(467 * ni + 2)); LVF_TRY(b->idx_a.ensure(ni + 4)); LVF_TRY(b->idx_b.ensure(ni + 4));
+    b->pre.n = 467 * ni; b->idx_a.n = b->idx_b.n = ni;
+    if (ni) {
+      std::memcpy(seg(b->pre.p, 467 * ni * 8), imu_pre.data(), 467 * ni * 8);
+      std::memcpy(seg(b->idx_a.p, ni * 4), imu_i.data(), ni * 4); std::memcpy(seg(b->idx_b.p, ni * 4), imu_j.data(), ni * 4);
+    }
     b->host_kf1 = imu_i; b->host_kf2 = imu_j;
     LVF_TRY(b->sqrt_info.ensure((size_t)225 * w->n_imu)); LVF_TRY(b->res.ensure((size_t)15 * w->n_imu));
     for (int q = 0; q < 8; ++q) LVF_TRY(b->jac[q].ensure((size_t)15 * b->block_size[q] * w->n_imu));
     idx_ok(b, w->n_imu, n_kf, 0);
-    LVF_TRY(launch_imu_sqrt_info(b));
   }
   {
     lvf_batch* b = w->prior;
-    LVF_TRY(put(b->idx_a, pr_a, s)); LVF_TRY(put(b->idx_b, pr_b, s)); LVF_TRY(put(b->table, pr_t, s)); LVF_TRY(put(b->ob_a, pr_w, s)); LVF_TRY(put(b->ob_b, pr_v, s));
+    const size_t np_ = (size_t)w->n_prior;
+    LVF_TRY(b->idx_a.ensure(np_ + 4)); LVF_TRY(b->idx_b.ensure(np_ + 4)); LVF_TRY(b->table.ensure(7 * np_ + 2)); LVF_TRY(b->ob_a.ensure(np_ + 2)); LVF_TRY(b->ob_b.ensure(np_ + 2));
+    b->idx_a.n = b->idx_b.n = np_; b->table.n = 7 * np_; b->ob_a.n = b->ob_b.n = np_;
+    if (np_) {
+      std::memcpy(seg(b->idx_a.p, np_ * 4), pr_a.data(), np_ * 4); std::memcpy(seg(b->idx_b.p, np_ * 4), pr_b.data(), np_ * 4);
+      std::memcpy(seg(b->table.p, 7 * np_ * 8), pr_t.data(), 7 * np_ * 8);
+      std::memcpy(seg(b->ob_a.p, np_ * 8), pr_w.data(), np_ * 8); std::memcpy(seg(b->ob_b.p, np_ * 8), pr_v.data(), np_ * 8);
+    }
     LVF_TRY(b->res.ensure((size_t)6 * w->n_prior)); LVF_TRY(b->jac[0].ensure((size_t)42 * w->n_prior)); LVF_TRY(b->jac[1].ensure((size_t)42 * w->n_prior));
     idx_ok(b, w->n_prior, n_kf, 0);
     b->host_kf1 = pr_a; b->host_kf2 = pr_b;
   }
+  LVF_REQUIRE(cur <= w->h_stage.cap && ua.n_segs <= kMaxSegs, "lvf_window_solve: staging overflow");
+  // one copy, one unpack launch
+  LVF_TRY(w->d_stage.ensure(cur));
+  LVF_HIP(hipMemcpyAsync(w->d_stage.p, hs, cur, hipMemcpyHostToDevice, s));
+  ua.stage = w->d_stage.p; ua.ntc = (int)ntc; ua.ntf = (int)ntf; ua.npo = (int)npo; ua.off_tc = off_tc; ua.off_tf = off_tf; ua.off_po = off_po;
+  ua.tc_l = reinterpret_cast<double2*>(w->tc->ob_a.p); ua.tc_r = reinterpret_cast<double2*>(w->tc->ob_b.p); ua.tc_lm = w->tc->idx_a.p; ua.tc_kf = w->tc->idx_b.p;
+  ua.tf_f = reinterpret_cast<double2*>(w->tf->ob_a.p); ua.tf_o = reinterpret_cast<double2*>(w->tf->ob_b.p); ua.tf_lm = w->tf->idx_a.p; ua.tf_k1 = w->tf->idx_b.p; ua.tf_k2 = w->tf->idx_c.p;
+  ua.po_o = reinterpret_cast<double2*>(w->po->ob_a.p); ua.po_pw = w->po->table.p; ua.po_kf = w->po->idx_a.p; ua.po_pi = w->po->idx_b.p;
+  ua.g_tc = (int)((ntc + 255) / 256); ua.g_tf = (int)((ntf + 255) / 256); ua.g_po = (int)((npo + 255) / 256); ua.g_seg = 64;
+  hipLaunchKernelGGL(k_window_unpack, dim3(ua.g_tc + ua.g_tf + ua.g_po + ua.g_seg), dim3(256), 0, s, ua);
+  LVF_HIP(hipGetLastError());
+  if (w->n_imu) LVF_TRY(launch_imu_sqrt_info(w->imu));
   const auto t_uploaded = now();
   if (!w->prob) {
     LVF_TRY(lvf_problem_create(ctx, st, w->tc, w->tf, w->po, w->imu, &w->prob));
