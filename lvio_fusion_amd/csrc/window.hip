@@ -190,6 +190,19 @@ static void landmarks_hot(const lvf_window* w, std::vector<LmHot>& hot) {
   }
 }
 
+// the read-back mirror of k_window_unpack's plain segments: device arrays -> one contiguous staging block (then ONE device-to-host copy
+// instead of five, each a submission of its own)
+struct PackArgs { unsigned char* stage; int n_segs; const unsigned char* src[8]; size_t off[8]; unsigned words[8]; };
+__global__ __launch_bounds__(256) void k_window_pack(PackArgs a) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k >= a.n_segs) break;
+    const uint4* src = reinterpret_cast<const uint4*>(a.src[k]);
+    uint4* dst = reinterpret_cast<uint4*>(a.stage + a.off[k]);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < a.words[k]; i += gridDim.x * 256) dst[i] = src[i];
+  }
+}
+
 // flags[i] = 1 iff |residual_i| > max_err  (residual pairs of a PoseOnly pass with unit weights = pixel errors)
 __global__ __launch_bounds__(256) void k_flag_outliers(int n, const double2* __restrict__ res, double max_err, uint8_t* __restrict__ flags) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -438,7 +451,19 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   PoRec* por = reinterpret_cast<PoRec*>(hs + off_po);
   std::vector<int32_t> kf2_counts(n_kf, 0);
   size_t ntc = 0, ntf = 0, npo = 0;
+  // large windows: the records written so far go up while the rest is still being assembled (two extra submissions per third of the
+  // frames; the 4 MB copy of a 50-keyframe window otherwise sits, ~0.1 ms, between the assembly and everything on the device)
+  LVF_TRY(w->d_stage.ensure(off_po + n_obs * 48 + tail_bound));
+  const bool chunked = n_obs >= 30000 && n_kf >= 6;
+  size_t tc_sent = 0, tf_sent = 0;
+  auto send_records = [&]() -> int {
+    if (ntc > tc_sent) LVF_HIP(hipMemcpyAsync(w->d_stage.p + off_tc + tc_sent * 48, hs + off_tc + tc_sent * 48, (ntc - tc_sent) * 48, hipMemcpyHostToDevice, s));
+    if (ntf > tf_sent) LVF_HIP(hipMemcpyAsync(w->d_stage.p + off_tf + tf_sent * 48, hs + off_tf + tf_sent * 48, (ntf - tf_sent) * 48, hipMemcpyHostToDevice, s));
+    tc_sent = ntc; tf_sent = ntf;
+    return LVF_OK;
+  };
   for (int k = 0; k < n_kf; ++k) {
+    if (chunked && (k == n_kf / 3 || k == (2 * n_kf) / 3)) LVF_TRY(send_records());
     lvf_window::Kf& f = w->kfs[k];
     f.sort_unique();
     // z_cam(pw) = zrow . pw + zoff  with  pc = R_e^-1 (R_wc^-1 pw + t_inv) + t_e_inv
@@ -579,9 +604,9 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
     b->host_kf1 = pr_a; b->host_kf2 = pr_b;
   }
   LVF_REQUIRE(cur <= w->h_stage.cap && ua.n_segs <= kMaxSegs, "lvf_window_solve: staging overflow");
-  // one copy, one unpack launch
-  LVF_TRY(w->d_stage.ensure(cur));
-  LVF_HIP(hipMemcpyAsync(w->d_stage.p, hs, cur, hipMemcpyHostToDevice, s));
+  // the rest of the records, then the PoseOnly records and the plain segments in one copy; one unpack launch
+  LVF_TRY(send_records());
+  if (cur > off_po) LVF_HIP(hipMemcpyAsync(w->d_stage.p + off_po, hs + off_po, cur - off_po, hipMemcpyHostToDevice, s));
   ua.stage = w->d_stage.p; ua.ntc = (int)ntc; ua.ntf = (int)ntf; ua.npo = (int)npo; ua.off_tc = off_tc; ua.off_tf = off_tf; ua.off_po = off_po;
   ua.tc_l = reinterpret_cast<double2*>(w->tc->ob_a.p); ua.tc_r = reinterpret_cast<double2*>(w->tc->ob_b.p); ua.tc_lm = w->tc->idx_a.p; ua.tc_kf = w->tc->idx_b.p;
   ua.tf_f = reinterpret_cast<double2*>(w->tf->ob_a.p); ua.tf_o = reinterpret_cast<double2*>(w->tf->ob_b.p); ua.tf_lm = w->tf->idx_a.p; ua.tf_k1 = w->tf->idx_b.p; ua.tf_k2 = w->tf->idx_c.p;
@@ -600,13 +625,27 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   const auto t_configured = now();
   LVF_TRY(lvf_problem_solve(w->prob, o, summary));
   const auto t_solved = now();
-  // ---- read the solution back into the host mirror (frame->pose, Vw, biases, landmark->inv_depth)
-  LVF_HIP(hipMemcpyAsync(poses, st->poses.p, (size_t)7 * n_kf * 8, hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipMemcpyAsync(vel, st->vel.p, (size_t)3 * n_kf * 8, hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipMemcpyAsync(ba, st->ba.p, (size_t)3 * n_kf * 8, hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipMemcpyAsync(bg, st->bg.p, (size_t)3 * n_kf * 8, hipMemcpyDeviceToHost, s));
-  if (n_lm) LVF_HIP(hipMemcpyAsync(invd, st->inv_depth.p, (size_t)n_lm * 8, hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipStreamSynchronize(s));
+  // ---- read the solution back into the host mirror (frame->pose, Vw, biases, landmark->inv_depth): gathered on the device, one copy
+  {
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    PackArgs pa{};
+    size_t at = 0;
+    size_t offs[5];
+    auto seg = [&](const void* src, size_t bytes, int slot) {
+      offs[slot] = at;
+      if (bytes) { pa.src[pa.n_segs] = static_cast<const unsigned char*>(src); pa.off[pa.n_segs] = at; pa.words[pa.n_segs] = (unsigned)((bytes + 15) / 16); ++pa.n_segs; }
+      at += up16(bytes);
+    };
+    seg(st->poses.p, (size_t)7 * n_kf * 8, 0); seg(st->vel.p, (size_t)3 * n_kf * 8, 1); seg(st->ba.p, (size_t)3 * n_kf * 8, 2); seg(st->bg.p, (size_t)3 * n_kf * 8, 3);
+    seg(st->inv_depth.p, (size_t)n_lm * 8, 4);
+    LVF_TRY(w->d_stage.ensure(at + 16)); LVF_TRY(w->h_state.reserve(at / 8 + 2));
+    pa.stage = w->d_stage.p;
+    hipLaunchKernelGGL(k_window_pack, dim3(32), dim3(256), 0, s, pa);
+    LVF_HIP(hipGetLastError());
+    LVF_HIP(hipMemcpyAsync(w->h_state.p, w->d_stage.p, at, hipMemcpyDeviceToHost, s));
+    LVF_HIP(hipStreamSynchronize(s));
+    poses = w->h_state.p + offs[0] / 8; vel = w->h_state.p + offs[1] / 8; ba = w->h_state.p + offs[2] / 8; bg = w->h_state.p + offs[3] / 8; invd = w->h_state.p + offs[4] / 8;
+  }
   for (int k = 0; k < n_kf; ++k) {
     lvf_window::Kf& f = w->kfs[k];
     std::memcpy(f.pose, &poses[(size_t)7 * k], 56);
