@@ -289,6 +289,40 @@ __device__ __forceinline__ double wave_sum(double v) {
   v += quad_perm<0x140>(v);    // row_mirror
   return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
+// Sums of up to 32 per-lane values over the wave at once ("transposed" reduction): instead of 32 independent wave_sum()s (23 instructions
+// each), every butterfly stage halves the number of values a lane carries — the lane keeps the half selected by one bit of its lane id and
+// adds the partner's copy of that half — so 16 + 8 + 4 + 2 + 1 pair-combinations plus one final add do all 32 sums (~125 instructions):
+//   lane bits 5 and 4 (across 16-lane rows): v_permlane32_swap / v_permlane16_swap exchange the halves of a register pair in place,
+//       two swaps + one add per pair, no select;
+//   lane bits 3, 2, 1 (inside a row): a select of keep / send followed by a DPP move (row_ror:8, row_half_mirror, quad_perm [2,3,0,1]);
+//   lane bit 0: a plain quad_perm add.
+// On return EVERY lane l holds the wave-wide sum of v[l >> 1].  v is clobbered.
+typedef unsigned lvf_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap_halves32(double& x, double& y) {        // lanes 32-63 of x <-> lanes 0-31 of y
+  const lvf_v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const lvf_v2u hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi.x, (int)lo.x); y = __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ void swap_rows16(double& x, double& y) {          // odd rows of x <-> even rows of y
+  const lvf_v2u lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const lvf_v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi.x, (int)lo.x); y = __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double wave_sum32(double v[32]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { swap_halves32(v[i], v[i + 16]); v[i] += v[i + 16]; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { swap_rows16(v[i], v[i + 8]); v[i] += v[i + 8]; }
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const double keep = b3 ? v[i + 4] : v[i], send = b3 ? v[i] : v[i + 4]; v[i] = keep + quad_perm<0x128>(send); }   // row_ror:8
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const double keep = b2 ? v[i + 2] : v[i], send = b2 ? v[i] : v[i + 2]; v[i] = keep + quad_perm<0x141>(send); }   // row_half_mirror
+  { const double keep = b1 ? v[1] : v[0], send = b1 ? v[0] : v[1]; v[0] = keep + quad_perm<0x4E>(send); }                                         // lanes [2,3,0,1]
+  return v[0] + quad_perm<0xB1>(v[0]);                                                                                                            // lanes [1,0,3,2]
+}
+
 // Same-address global atomics serialise in L2 at ~65 ns each (measured), so counters are touched once per RUN of consecutive lanes
 // holding the same key (clouds arrive in scan order: a coarse cell, a segment or a voxel sees long runs): only the head lane of a
 // run issues the atomic, with the run length.  `start` = head lane of this lane's run, `len` = run

@@ -333,44 +333,88 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
   }
   mark(2);
   // k1-indexed sums (B[k1,k1], g[k1], cross block).  A live front-end hands out landmark ids in creation order, so the blocks of a
-  // wave usually share their first keyframe: then the 63 sums are wave reductions and one lane adds them (per-lane ds_add_f64 on ONE
-  // address serialises 64-fold: +10 us on this kernel with ids in birth order); mixed waves keep the per-lane LDS atomics.
+  // wave usually share their first keyframe (per-lane ds_add_f64 on ONE address serialises 64-fold: +10 us on this kernel with ids in
+  // birth order).
   {
-    const unsigned long long am = __ballot(active);
-    const int k1u = am ? __builtin_amdgcn_readlane(k1, (int)__ffsll((long long)am) - 1) : 0;
-    const bool same_k1 = __all(!active || k1 == k1u);
-    double* acc = s_acc + (same_k1 ? k1u : k1) * kAccSlots;
-    const bool lane0 = (threadIdx.x & 63) == 0;
-    int q = 0;
+    // the k2-indexed products v[27] (reduced below)
+    {
+      int q = 0;
 #pragma unroll
-    for (int x = 0; x < 6; ++x)
+      for (int x = 0; x < 6; ++x)
 #pragma unroll
-      for (int y = 0; y <= x; ++y) {
-        double t = L1[x] * L1[y] + L1[6 + x] * L1[6 + y];
-        if (same_k1) { t = wave_sum(t); if (lane0 && t != 0.0) atomicAdd(&acc[q], t); } else if (active) atomicAdd(&acc[q], t);
-        v[q] = L2[x] * L2[y] + L2[6 + x] * L2[6 + y];
-        ++q;
-      }
+        for (int y = 0; y <= x; ++y) v[q++] = L2[x] * L2[y] + L2[6 + x] * L2[6 + y];
 #pragma unroll
-    for (int x = 0; x < 6; ++x) {
-      double t = L1[x] * r0 + L1[6 + x] * r1;
-      if (same_k1) { t = wave_sum(t); if (lane0 && t != 0.0) atomicAdd(&acc[21 + x], t); } else if (active) atomicAdd(&acc[21 + x], t);
-      v[21 + x] = L2[x] * r0 + L2[6 + x] * r1;
+      for (int x = 0; x < 6; ++x) v[21 + x] = L2[x] * r0 + L2[6 + x] * r1;
     }
+    // The 63 k1-indexed products, slot order = [B(k1,k1) 21 | g(k1) 6 | cross (k2,k1) 36].  Lanes that share their first keyframe
+    // are reduced TOGETHER (two transposed reductions of 32 slots, formed one batch at a time to keep the register count where three
+    // workgroups fit a CU) — up to four groups of >= 16 lanes per wave, which covers whole waves and the waves that straddle a boundary
+    // between two first keyframes; whatever is left (random landmark ids: nearly every lane its own keyframe) goes through per-lane
+    // LDS atomics, which are only slow when many lanes hit one address.
+    const int lane = threadIdx.x & 63;
+    unsigned long long remaining = __ballot(active);
+    bool mine_done = !active;
+#pragma unroll 1
+    for (int round = 0; round < 4 && remaining; ++round) {
+      const int k1u = __builtin_amdgcn_readlane(k1, (int)__ffsll((long long)remaining) - 1);
+      const bool sel = active && !mine_done && k1 == k1u;
+      const unsigned long long m = __ballot(sel);
+      if (__popcll(m) < 16) break;
+      double* accu = s_acc + k1u * kAccSlots;
+      // the group's lanes keep their first-keyframe Jacobian, everyone else contributes zeros; the scale is opaque to the compiler so
+      // that the 63 products are formed inside this loop (hoisted out of it as loop invariants they cost 126 registers)
+      double z = sel ? 1.0 : 0.0;
+      asm volatile("" : "+v"(z));
+      double M[12];
 #pragma unroll
-    for (int x = 0; x < 6; ++x)
+      for (int i = 0; i < 12; ++i) M[i] = L1[i] * z;
 #pragma unroll
-      for (int y = 0; y < 6; ++y) {
-        double t = L2[x] * L1[y] + L2[6 + x] * L1[6 + y];
-        if (same_k1) { t = wave_sum(t); if (lane0 && t != 0.0) atomicAdd(&acc[27 + 6 * x + y], t); } else if (active) atomicAdd(&acc[27 + 6 * x + y], t);
+      for (int bt = 0; bt < 2; ++bt) {
+        double t[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t[i] = 0.0;
+        int q = 0;
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+          for (int y = 0; y <= x; ++y) { if ((q >> 5) == bt) t[q & 31] = M[x] * L1[y] + M[6 + x] * L1[6 + y]; ++q; }
+#pragma unroll
+        for (int x = 0; x < 6; ++x) { if ((q >> 5) == bt) t[q & 31] = M[x] * r0 + M[6 + x] * r1; ++q; }
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+          for (int y = 0; y < 6; ++y) { if ((q >> 5) == bt) t[q & 31] = L2[x] * M[y] + L2[6 + x] * M[6 + y]; ++q; }
+        const double tot = wave_sum32(t);
+        const int slot = 32 * bt + (lane >> 1);
+        if (!(lane & 1) && slot < 63 && tot != 0.0) atomicAdd(&accu[slot], tot);
       }
+      mine_done = mine_done || sel;
+      remaining &= ~m;
+    }
+    if (!mine_done) {
+      double* acc = s_acc + k1 * kAccSlots;
+      int q = 0;
+#pragma unroll
+      for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int y = 0; y <= x; ++y) atomicAdd(&acc[q++], L1[x] * L1[y] + L1[6 + x] * L1[6 + y]);
+#pragma unroll
+      for (int x = 0; x < 6; ++x) atomicAdd(&acc[21 + x], L1[x] * r0 + L1[6 + x] * r1);
+#pragma unroll
+      for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int y = 0; y < 6; ++y) atomicAdd(&acc[27 + 6 * x + y], L2[x] * L1[y] + L2[6 + x] * L1[6 + y]);
+    }
   }
   mark(3);
+  {
+    // the 27 sums of the wave in one transposed reduction: lane l ends up with the total of value l >> 1, the even lanes add them
+    double v32[32];
 #pragma unroll
-  for (int q = 0; q < 27; ++q) v[q] = wave_sum(v[q]);
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int q = 0; q < 27; ++q) if (v[q] != 0.0) atomicAdd(&s_k2[q], v[q]);
+    for (int q = 0; q < 32; ++q) v32[q] = q < 27 ? v[q] : 0.0;
+    const double tot = wave_sum32(v32);
+    const int lane = threadIdx.x & 63;
+    if (!(lane & 1) && (lane >> 1) < 27 && tot != 0.0) atomicAdd(&s_k2[lane >> 1], tot);
   }
   block_add(c, cost);
   __syncthreads();
@@ -827,8 +871,9 @@ __device__ __forceinline__ void lin_visual_body(const int bx, const LinArgs& A) 
   else
     lin_imu_body4<true>(b - a.n_tfw - a.g_tc - a.g_po, a.n_imu, n_kf, a.imu_res, a.imu_J, a.imu_i, a.imu_j, s.poses, pose_const, B, ld, gc, cost);
 }
-__global__ __launch_bounds__(kT) void k_lin_visual(LinArgs a) { lin_visual_body(blockIdx.x, a); }
-__global__ __launch_bounds__(kT) void k_lin_visual_b(const LinArgs* __restrict__ t) { lin_visual_body(blockIdx.x, t[blockIdx.y]); }
+// (three workgroups per CU: the register allocator is told so — left alone it lands one VGPR above the limit)
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void k_lin_visual(LinArgs a) { lin_visual_body(blockIdx.x, a); }
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void k_lin_visual_b(const LinArgs* __restrict__ t) { lin_visual_body(blockIdx.x, t[blockIdx.y]); }
 
 // Adds the TwoFrame slabs of a linearisation into B / gc (compact mode).  Workgroups are sorted by current keyframe: run(k) =
 // workgroups [run_first[k], run_first[k+1]).  Every entry of B has ONE owner thread here (plain read-modify-write; the other factor
