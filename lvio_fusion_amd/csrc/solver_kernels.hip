@@ -52,7 +52,7 @@ struct lvf_problem {
   lvf::StageClock* clk = nullptr;     // lvf_problem_stage_times
   bool accum_clean = false;           // B / gc / C / g_rho / cost stripes are zero (left so by the last iteration's cost + decision launch)
   int band_rows = 64;           // landmark rows per slice of the band Schur complement (a batch uses more: fewer output atomics)
-  lvf::DevBuf<int2> band_work; lvf::DevBuf<int> n_band_work_dev; lvf::HostPin<int> h_n_band_work;
+  lvf::DevBuf<int4> band_work; lvf::DevBuf<int> n_band_work_dev; lvf::HostPin<int> h_n_band_work;
   int n_band_work = 0, band_rows_built = 0;
   lvf::HostPin<int> h_run_first;
   lvf::DevBuf<unsigned long long> dbg, dbg_lin;
@@ -1296,18 +1296,23 @@ __global__ __launch_bounds__(kT) void k_zero_slots(const int* __restrict__ n_slo
 __device__ __forceinline__ void schur_band_body(const int bx, const int by, int dp, int ldE, const double* __restrict__ E,
                                                 const double* __restrict__ Cd, const int* __restrict__ order, const int* __restrict__ n_active_p,
                                                 const int* __restrict__ kmin, const int* __restrict__ kmax, int d, int ldS,
-                                                double* __restrict__ S, unsigned long long* dbg = nullptr, const int rows = kBandRows) {
+                                                double* __restrict__ S, unsigned long long* dbg = nullptr, const int rows = kBandRows,
+                                                const int4* __restrict__ item = nullptr) {
   extern __shared__ double sh[];          // Es[kSchurRows][ldl] | icd[kSchurRows] | rowid (int)[kBandRows]
   auto mark = [&](int k) { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); };   // LVF_SCHUR_TIMING=1: phase stamps of this workgroup
   mark(0);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lk = lane >> 4, lc = lane & 15;
-  const int n_active = *n_active_p;
-  const int k_begin = bx * rows, k_end = min(n_active, k_begin + rows);
-  if (k_begin >= k_end) return;
-  // the slice's band (every wave reduces it for itself: two rows per lane)
-  int lo = 0x7fffffff, hi = -1;
-  for (int r = k_begin + lane; r < k_end; r += 64) { const int l = order[r]; lo = min(lo, kmin[l]); hi = max(hi, kmax[l]); }
-  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+  // the slice's extent and band: from the work item when there is one (k_band_work computed them once per configure: three dependent
+  // global round trips — n_active, order[], kmin/kmax[] — off the front of every workgroup), else every wave reduces them for itself
+  const int k_begin = bx * rows;
+  int k_end, lo = 0x7fffffff, hi = -1;
+  if (item) { const int4 it = *item; k_end = it.w; lo = it.z & 0xffff; hi = it.z >> 16; }
+  else {
+    k_end = min(*n_active_p, k_begin + rows);
+    if (k_begin >= k_end) return;
+    for (int r = k_begin + lane; r < k_end; r += 64) { const int l = order[r]; lo = min(lo, kmin[l]); hi = max(hi, kmax[l]); }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+  }
   const int t0 = (6 * lo) >> 4, t1 = (6 * hi + 5) >> 4, tl = dp >> 4;
   const int nbt = t1 - t0 + 1, tri = nbt * (nbt + 1) / 2;
   const bool extra = tl > t1;                                  // the g_rho column's tile lies outside the band
@@ -1854,7 +1859,7 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
 // for the widest possible band, but most slices (short tracks) need one group: three quarters of its workgroups had nothing to do and
 // their dispatch — each needs its LDS slice — was most of the launch's span.  Built once per problem_configure (the bands are fixed).
 __global__ __launch_bounds__(64) void k_band_work(int rows, int dp, const int* __restrict__ n_active_p, const int* __restrict__ order,
-                                                  const int* __restrict__ kmin, const int* __restrict__ kmax, int2* __restrict__ work, int* __restrict__ n_work) {
+                                                  const int* __restrict__ kmin, const int* __restrict__ kmax, int4* __restrict__ work, int* __restrict__ n_work) {
   const int n_active = *n_active_p, lane = threadIdx.x;
   const int k_begin = blockIdx.x * rows, k_end = min(n_active, k_begin + rows);
   if (k_begin >= k_end) return;
@@ -1866,7 +1871,7 @@ __global__ __launch_bounds__(64) void k_band_work(int rows, int dp, const int* _
     const int ntiles = nbt * (nbt + 1) / 2 + (tl > t1 ? nbt : 0);
     const int groups = (ntiles + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
     const int base = atomicAdd(n_work, groups);
-    for (int g = 0; g < groups; ++g) work[base + g] = make_int2((int)blockIdx.x, g);
+    for (int g = 0; g < groups; ++g) work[base + g] = make_int4((int)blockIdx.x, g, lo | (hi << 16), k_end);
   }
 }
 
@@ -1889,15 +1894,16 @@ struct SchurSp0Args {
   int n_slices, n_groups, dp, ldE; const double *E, *Cd; const int *order, *n_active, *kmin, *kmax; int d_local, ldS; double* S_pose;
   SpArgs sp;             // level 0 (sp.nblocks == 0: Schur complement only)
   int nblocks; const int* done; unsigned long long* dbg; int rows;
-  const int2* work; int n_work;      // (slice, group) items; sparse level 0 runs in workgroups [0, sp.nblocks), the items behind
+  const int4* work; int n_work;      // (slice, group, band lo | hi << 16, slice end) items; sparse level 0 runs in workgroups [0, sp.nblocks), the items behind
 };
 __device__ __forceinline__ void schur_sp0_body(const int b, const SchurSp0Args& A) {
   if (b >= A.nblocks || (A.done && *A.done)) return;
   if (A.work) {
     if (b < A.sp.nblocks) sp_eliminate_body(b, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail);
     else {
-      const int2 it = A.work[b - A.sp.nblocks];
-      schur_band_body(it.x, it.y, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)(b - A.sp.nblocks) * 8 : nullptr, A.rows);
+      const int4* item = A.work + (b - A.sp.nblocks);
+      const int4 it = *item;
+      schur_band_body(it.x, it.y, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)(b - A.sp.nblocks) * 8 : nullptr, A.rows, item);
     }
     return;
   }
@@ -1905,8 +1911,8 @@ __device__ __forceinline__ void schur_sp0_body(const int b, const SchurSp0Args& 
   if (b < ns) schur_band_body(b % A.n_slices, b / A.n_slices, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)b * 8 : nullptr, A.rows);
   else sp_eliminate_body(b - ns, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail);
 }
-__global__ __launch_bounds__(256) void k_schur_sp0(SchurSp0Args a) { schur_sp0_body(blockIdx.x, a); }
-__global__ __launch_bounds__(256) void k_schur_sp0_b(const SchurSp0Args* __restrict__ t) { schur_sp0_body(blockIdx.x, t[blockIdx.y]); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_schur_sp0(SchurSp0Args a) { schur_sp0_body(blockIdx.x, a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_schur_sp0_b(const SchurSp0Args* __restrict__ t) { schur_sp0_body(blockIdx.x, t[blockIdx.y]); }
 struct SpBack {                    // what the back substitution needs of the plan
   SpLevels lv;
   int item0[kSpMaxLevels], items[kSpMaxLevels];   // the level's slice of rows/owner/W
