@@ -94,6 +94,11 @@ enum { SC_COST = 0, SC_COST_NEW = 1 * kStripes, SC_MODEL = 2 * kStripes, SC_DXNO
        SC_N = 6 * kStripes, SC_FAIL = SC_N /* int flag */, SC_TICKET = SC_N + 1 /* int: workgroups of the candidate-cost pass that are done */, SC_ALLOC = SC_N + 2 };
 static inline double stripe_sum(const double* h, int slot) { double s = 0.0; for (int k = 0; k < kStripes; ++k) s += h[slot + k]; return s; }
 
+// The LM loop's `done` flag gates every launch of an iteration.  Tested at the top of a kernel it is a dependent global round trip
+// (~0.5-1 us) in front of everything; issued FIRST and tested after the kernel's own first loads have been issued, its latency hides
+// under theirs (loads return in order: the test waits for the oldest one only).
+__device__ __forceinline__ int done_flag_issue(const int* done) { return done ? *reinterpret_cast<const volatile int*>(done) : 0; }
+
 __device__ __forceinline__ void block_add(double v, double* dst) {
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst + (blockIdx.x & (kStripes - 1)), v);
@@ -1647,7 +1652,8 @@ __device__ __forceinline__ void chol_update_tile(double* S, int ld, int kp, int 
 
 __device__ __forceinline__ void chol_step_body(const int bx, const CholArgs& A, const int kb) {
   const int below = A.nb - kb - 1;
-  if (bx >= chol_step_grid(A.nb, kb) || (A.done && *A.done)) return;      // (workgroup-uniform: no barrier is skipped by part of a workgroup)
+  if (bx >= chol_step_grid(A.nb, kb)) return;                          // (workgroup-uniform: no barrier is skipped by part of a workgroup)
+  const int dv = done_flag_issue(A.done);
   double* S = A.Sd; const int ld = A.ld; int* __restrict__ fail = A.fail; double* __restrict__ Dinv = A.Dinv;
   __shared__ double Pi[kNB * kLd];
   __shared__ double Pj[kNB * kLd];
@@ -1655,6 +1661,7 @@ __device__ __forceinline__ void chol_step_body(const int bx, const CholArgs& A, 
   if (bx >= 2 + below) {                              // trailing tiles of step kb-1 right of column kb
     int t = bx - (2 + below), ii = 0;
     while (t >= ii + 1) { t -= ii + 1; ++ii; }
+    if (dv) return;
     chol_update_tile(S, ld, kb - 1, kb + 1 + ii, kb + 1 + t, Pi, Pj);
     return;
   }
@@ -1678,6 +1685,7 @@ __device__ __forceinline__ void chol_step_body(const int bx, const CholArgs& A, 
 #pragma unroll
     for (int c = 0; c < 16; ++c) a[c] = (inverse_wg && 16 * q + c == r) ? 1.0 : 0.0;
   }
+  if (dv) return;                                     // (the tile loads above are in flight behind the flag's)
   if (kb > 0) {
     // step kb-1's update of the tiles just requested: diagonal wave q forms rows 16q..16q+15 of P_k P_k^T (lower tiles only), panel wave q
     // those of P_i P_k^T; the products go through LDS into the row-per-lane layout of the factorisation
@@ -1763,10 +1771,12 @@ __global__ __launch_bounds__(kCT) void k_chol_step_b(const CholArgs* __restrict_
 // W and L_bb go to side buffers (the eliminated columns of S are never read again), so the tiles of a block never race.
 __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __restrict__ nodes, int first, int tiles, const int* __restrict__ rows,
                                                   double* __restrict__ S, int ld, double* __restrict__ W, int wstride,
-                                                  double* __restrict__ Lout, int* __restrict__ fail) {
+                                                  double* __restrict__ Lout, int* __restrict__ fail, const int* done = nullptr) {
   extern __shared__ double sp_sm[];        // Ws[m][9] | L[81] | linv[9] | rws[m] (int)
+  const int dv = done_flag_issue(done);
   const int ni = first + vb / tiles, tile = vb % tiles, tid = threadIdx.x;
   const SpNode nd = nodes[ni];
+  if (dv) return;
   const int m = nd.m, col = nd.col;
   double* Ws = sp_sm;
   double* L = sp_sm + 9 * m;
@@ -1879,13 +1889,13 @@ struct SpArgs {          // one sparse level
   const SpNode* nodes; int first, tiles; const int* rows; double* S; int ld; double* W; int wstride; double* Lout; int* fail; int nblocks; const int* done;
 };
 __global__ __launch_bounds__(256) void k_sp_eliminate(SpArgs a) {
-  if ((int)blockIdx.x >= a.nblocks || (a.done && *a.done)) return;
-  sp_eliminate_body(blockIdx.x, a.nodes, a.first, a.tiles, a.rows, a.S, a.ld, a.W, a.wstride, a.Lout, a.fail);
+  if ((int)blockIdx.x >= a.nblocks) return;
+  sp_eliminate_body(blockIdx.x, a.nodes, a.first, a.tiles, a.rows, a.S, a.ld, a.W, a.wstride, a.Lout, a.fail, a.done);
 }
 __global__ __launch_bounds__(256) void k_sp_eliminate_b(const SpArgs* __restrict__ t) {
   const SpArgs a = t[blockIdx.y];
-  if ((int)blockIdx.x >= a.nblocks || (a.done && *a.done)) return;
-  sp_eliminate_body(blockIdx.x, a.nodes, a.first, a.tiles, a.rows, a.S, a.ld, a.W, a.wstride, a.Lout, a.fail);
+  if ((int)blockIdx.x >= a.nblocks) return;
+  sp_eliminate_body(blockIdx.x, a.nodes, a.first, a.tiles, a.rows, a.S, a.ld, a.W, a.wstride, a.Lout, a.fail, a.done);
 }
 // The band-limited Schur complement and the FIRST sparse level in one launch: both only ADD (atomically) into entries of S the other
 // does not read — the Schur complement touches the pose corner and the pose part of the rhs row, level 0 reads its own (v,ba,bg)
@@ -1897,16 +1907,19 @@ struct SchurSp0Args {
   const int4* work; int n_work;      // (slice, group, band lo | hi << 16, slice end) items; sparse level 0 runs in workgroups [0, sp.nblocks), the items behind
 };
 __device__ __forceinline__ void schur_sp0_body(const int b, const SchurSp0Args& A) {
-  if (b >= A.nblocks || (A.done && *A.done)) return;
+  if (b >= A.nblocks) return;
   if (A.work) {
-    if (b < A.sp.nblocks) sp_eliminate_body(b, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail);
+    if (b < A.sp.nblocks) sp_eliminate_body(b, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail, A.done);
     else {
+      const int dv = done_flag_issue(A.done);
       const int4* item = A.work + (b - A.sp.nblocks);
       const int4 it = *item;
+      if (dv) return;
       schur_band_body(it.x, it.y, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)(b - A.sp.nblocks) * 8 : nullptr, A.rows, item);
     }
     return;
   }
+  if (A.done && *A.done) return;
   const int ns = A.n_slices * A.n_groups;
   if (b < ns) schur_band_body(b % A.n_slices, b / A.n_slices, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)b * 8 : nullptr, A.rows);
   else sp_eliminate_body(b - ns, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail);
@@ -1941,7 +1954,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 constexpr int kBT = 512, kBParts = kBT / 64, kBackPre = 256 / kBParts, kBackInv = 64 / kBParts, kTailPre = 6;
 struct BackArgs { const double* Sd; int ld, d; const double* Dinv; double* xout; SpBack sp; const int* done; };
 __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
-  if (A.done && *A.done) return;
+  const int dv = done_flag_issue(A.done);
   const double* S = A.Sd; const int ld = A.ld, d = A.d; const double* Dinv = A.Dinv; double* xout = A.xout; const SpBack& sp = A.sp;
   extern __shared__ double sm[];          // xs[off] | x[nblk*64] | partial[kBParts][64] | rhs[64] | accs[9 max_count] | linv[81 n_nodes]
   const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
@@ -1989,6 +2002,7 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) tW[u][q] = ok ? sp.W[(size_t)q * sp.total_items + g] : 0.0;
   }
+  if (dv) return;                          // (every request above is in flight behind the flag's)
   for (int i = tid; i < sp.off + n; i += kBT) sm[i] = 0.0;
   lds_barrier();
   mark();
