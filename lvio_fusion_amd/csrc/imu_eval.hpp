@@ -64,10 +64,10 @@ __device__ __forceinline__ void imu_stage(const int f, const int lane, const dou
 // Phase B (ONE lane): the raw residual sr0[15] and, WITH_J, the 15 x 32 pre-weighting Jacobian sM (columns: pose_i 0..6, v_i 7..9,
 // ba_i 10..12, bg_i 13..15, pose_j 16..22, v_j 23..25, ba_j 26..28, bg_j 29..31).
 template <bool WITH_J>
-__device__ __forceinline__ void imu_raw(const int f, const double* __restrict__ pre, const int* __restrict__ kf_i, const int* __restrict__ kf_j,
+__device__ __forceinline__ void imu_raw(const int f, const double* P /* the factor's flattened pre-integration: global or staged in LDS */,
+                                        const int* __restrict__ kf_i, const int* __restrict__ kf_j,
                                         const double* __restrict__ poses, const double* __restrict__ vel, const double* __restrict__ ba,
                                         const double* __restrict__ bg, double* sr0, double* sM) {
-  const double* P = pre + (size_t)f * kPre;
     const int i = kf_i[f], j = kf_j[f];
     const double* pi = poses + 7 * i; const double* pj = poses + 7 * j;
     const Qd Qi{pi[0], pi[1], pi[2], pi[3]}, Qj{pj[0], pj[1], pj[2], pj[3]};
@@ -89,6 +89,7 @@ __device__ __forceinline__ void imu_raw(const int f, const double* __restrict__ 
       blk3(Jp, O_R, O_BG, blk); mat3_mul_vec(blk, dbg, th);
       blk3(Jp, O_V, O_BA, blk); mat3_mul_vec(blk, dba, a3); blk3(Jp, O_V, O_BG, blk); mat3_mul_vec(blk, dbg, b3);
       for (int k = 0; k < 3; ++k) cv[k] = P[OFF_DV + k] + a3[k] + b3[k];
+      if (!WITH_J) asm volatile("" ::: "memory");           // residual-only callers stage P in LDS: one block at a time keeps the registers low
       blk3(Jp, O_T, O_BA, blk); mat3_mul_vec(blk, dba, a3); blk3(Jp, O_T, O_BG, blk); mat3_mul_vec(blk, dbg, b3);
       for (int k = 0; k < 3; ++k) cp[k] = P[OFF_DP + k] + a3[k] + b3[k];
     }

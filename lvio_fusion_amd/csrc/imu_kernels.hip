@@ -117,7 +117,7 @@ __device__ __forceinline__ void imu_body(const int bx, const ImuArgs& A) {
   const int lane = threadIdx.x;
   imu_stage<WITH_J>(f, lane, A.sqrt_info, sS, sM);
   __syncthreads();
-  if (lane == 0) imu_raw<WITH_J>(f, A.pre, A.kf_i, A.kf_j, A.poses, A.vel, A.ba, A.bg, sr0, sM);
+  if (lane == 0) imu_raw<WITH_J>(f, A.pre + (size_t)f * kPre, A.kf_i, A.kf_j, A.poses, A.vel, A.ba, A.bg, sr0, sM);
   __syncthreads();
   if (lane < 15) {
     const double s = imu_weighted_residual(lane, sS, sr0);

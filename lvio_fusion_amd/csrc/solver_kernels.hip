@@ -476,51 +476,60 @@ struct ImuEvalArgs { int n; const double *pre, *sqrt_info; const int *kf_i, *kf_
 struct CostArgs {
   CostVisual a; int n_kf; StateP s; double huber; double* cost; int nblocks; const int* done;
   ImuEvalArgs imu; int g_imu;       // workgroups [0, g_imu) evaluate one ImuError factor each, the visual passes follow
+  int tiles;                        // tiles of kT blocks per visual workgroup (0 = 1)
   ZeroList zero; int zero_wgs;      // workgroups [nblocks, nblocks + zero_wgs) of the merged cost + decision launch clear the accumulators for the NEXT linearisation
 };
 // the calling thread's share of the candidate cost (workgroup b of the pass)
 __device__ __forceinline__ double cost_visual_value(const int b, const CostArgs& A) {
   const CostVisual& a = A.a;
   const int n_kf = A.n_kf; const StateP s = A.s; const double huber = A.huber;
+  const int tiles = A.tiles > 0 ? A.tiles : 1;          // tiles of kT blocks per workgroup (a batch of windows uses fatter workgroups: with
+                                                        // 8 x 600 thin ones the launch took 52 us, with a quarter of them 31)
   __shared__ PoseD s_pose[kMaxStagedKf];
   double c = 0.0;
   if (b < a.g_tc) {
-    const int i = b * kT + threadIdx.x;
-    if (i < a.n_tc) {
-      const int l = a.tc_lm[i];
-      const double2 lo = a.tc_lo[i], ro = a.tc_ro[i];
-      double r[2], J[2];
-      eval_two_camera<false>(a.tc_left, a.tc_right, lo.x, lo.y, ro.x, ro.y, s.inv_depth[l], a.tc_w ? a.tc_w[i] : 5.0 * s.w_kf[a.tc_kf[i]], r, J);
-      double rho;
-      (void)robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
-      c = 0.5 * rho;
+    for (int rp = 0; rp < tiles; ++rp) {
+      const int i = (b * tiles + rp) * kT + threadIdx.x;
+      if (i < a.n_tc) {
+        const int l = a.tc_lm[i];
+        const double2 lo = a.tc_lo[i], ro = a.tc_ro[i];
+        double r[2], J[2];
+        eval_two_camera<false>(a.tc_left, a.tc_right, lo.x, lo.y, ro.x, ro.y, s.inv_depth[l], a.tc_w ? a.tc_w[i] : 5.0 * s.w_kf[a.tc_kf[i]], r, J);
+        double rho;
+        (void)robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
+        c += 0.5 * rho;
+      }
     }
   } else {
     stage_poses<kT>(s_pose, s.poses, n_kf);     // ends with __syncthreads(); the branch is workgroup-uniform
     if (b < a.g_tc + a.g_tf) {
-      const int i = (b - a.g_tc) * kT + threadIdx.x;
-      if (i < a.n_tf) {
-        const int l = a.tf_lm[i], k1 = a.tf_k1[i], k2 = a.tf_k2[i];
-        const double2 fo = a.tf_fo[i], ob = a.tf_ob[i];
-        const PoseD P1 = fetch_pose(s_pose, s.poses, n_kf, k1), P2 = fetch_pose(s_pose, s.poses, n_kf, k2);
-        double r[2], Jd[2], J1[14], J2[14];
-        eval_two_frame<false>(P1, P2, a.tf_left, a.tf_right, fo.x, fo.y, ob.x, ob.y, s.inv_depth[l], s.w_kf[k2], r, Jd, J1, J2);
-        double rho;
-        (void)robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
-        c = 0.5 * rho;
+      for (int rp = 0; rp < tiles; ++rp) {
+        const int i = ((b - a.g_tc) * tiles + rp) * kT + threadIdx.x;
+        if (i < a.n_tf) {
+          const int l = a.tf_lm[i], k1 = a.tf_k1[i], k2 = a.tf_k2[i];
+          const double2 fo = a.tf_fo[i], ob = a.tf_ob[i];
+          const PoseD P1 = fetch_pose(s_pose, s.poses, n_kf, k1), P2 = fetch_pose(s_pose, s.poses, n_kf, k2);
+          double r[2], Jd[2], J1[14], J2[14];
+          eval_two_frame<false>(P1, P2, a.tf_left, a.tf_right, fo.x, fo.y, ob.x, ob.y, s.inv_depth[l], s.w_kf[k2], r, Jd, J1, J2);
+          double rho;
+          (void)robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
+          c += 0.5 * rho;
+        }
       }
     } else {
-      const int i = (b - a.g_tc - a.g_tf) * kT + threadIdx.x;
-      if (i < a.n_po) {
-        const int k = a.po_kf[i], l = a.po_pwi[i];
-        const double2 o = a.po_ob[i];
-        const PoseD P = fetch_pose(s_pose, s.poses, n_kf, k);
-        const double pwl[3] = {a.po_pw[3 * l], a.po_pw[3 * l + 1], a.po_pw[3 * l + 2]};
-        double r[2], J[14];
-        eval_pose_only<false>(P, a.po_cam, o.x, o.y, pwl, s.w_kf[k], r, J);
-        double rho;
-        (void)robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
-        c = 0.5 * rho;
+      for (int rp = 0; rp < tiles; ++rp) {
+        const int i = ((b - a.g_tc - a.g_tf) * tiles + rp) * kT + threadIdx.x;
+        if (i < a.n_po) {
+          const int k = a.po_kf[i], l = a.po_pwi[i];
+          const double2 o = a.po_ob[i];
+          const PoseD P = fetch_pose(s_pose, s.poses, n_kf, k);
+          const double pwl[3] = {a.po_pw[3 * l], a.po_pw[3 * l + 1], a.po_pw[3 * l + 2]};
+          double r[2], J[14];
+          eval_pose_only<false>(P, a.po_cam, o.x, o.y, pwl, s.w_kf[k], r, J);
+          double rho;
+          (void)robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
+          c += 0.5 * rho;
+        }
       }
     }
   }
@@ -784,7 +793,7 @@ __device__ __forceinline__ void lin_imu_eval_body(const int f, const ImuEvalArgs
   for (int k = tid; k < 480; k += kT) sM[k] = 0.0;
   __syncthreads();
   if (dbg) dbg[1] = wall_clock64();
-  if (tid == 0) imu_raw<true>(f, I.pre, I.kf_i, I.kf_j, s.poses, s.vel, s.ba, s.bg, sr0, sM);
+  if (tid == 0) imu_raw<true>(f, I.pre + (size_t)f * kPre, I.kf_i, I.kf_j, s.poses, s.vel, s.ba, s.bg, sr0, sM);
   __syncthreads();
   if (dbg) dbg[2] = wall_clock64();
   const int ki = I.kf_i[f], kj = I.kf_j[f];
@@ -2323,10 +2332,15 @@ __device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A,
     if (b >= A.g_imu) c = cost_visual_value(b - A.g_imu, A);
     else {                                             // one ImuError factor at the candidate: 1/2 |sqrt_info r|^2
       __shared__ double sS[225];
+      __shared__ double sP[OFF_COV];                     // sum_dt, linearisation biases, deltas and the 15 x 15 Jacobian of the pre-integration
       __shared__ double sr0[16];
       const int f = b;
       for (int k = threadIdx.x; k < 225; k += kT) sS[k] = A.imu.sqrt_info[(size_t)f * 225 + k];
-      if (threadIdx.x == 0) imu_raw<false>(f, A.imu.pre, A.imu.kf_i, A.imu.kf_j, A.s.poses, A.s.vel, A.s.ba, A.s.bg, sr0, nullptr);
+      for (int k = threadIdx.x; k < OFF_COV; k += kT) sP[k] = A.imu.pre[(size_t)f * kPre + k];
+      __syncthreads();
+      // (from LDS the one lane's ~60 operand reads cost nothing to repeat, so the compiler does not hold them all in registers: this
+      // path shares its kernel with the visual cost pass, whose occupancy it would otherwise set)
+      if (threadIdx.x == 0) imu_raw<false>(f, sP, A.imu.kf_i, A.imu.kf_j, A.s.poses, A.s.vel, A.s.ba, A.s.bg, sr0, nullptr);
       __syncthreads();
       const double r = imu_weighted_residual(threadIdx.x, sS, sr0);      // rows 0..14 in lanes 0..14 of wave 0
       c = threadIdx.x < 15 ? 0.5 * r * r : 0.0;
@@ -3238,10 +3252,18 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
     il[w] = c.imu_lin; ic[w] = c.imu_cost; li[w] = c.lin; li[w].huber = huber; rd[w] = c.red; if (!p->compact) rd[w].nblocks = 0;
     b->g_red = std::max(b->g_red, rd[w].nblocks); pr[w] = c.prep; ss[w] = c.ssp0; ch[w] = c.chol; bk[w] = c.back; tl[w] = c.tail;
     co[w] = c.cost; co[w].huber = huber; de[w] = c.dec; zl[w] = c.zero;
+    if (W >= 4) {                                        // fatter cost / zeroing workgroups in a batch (see cost_visual_value)
+      CostArgs& k = co[w];
+      const int t = 4, per = kT * t;
+      k.tiles = t;
+      k.a.g_tc = (k.a.n_tc + per - 1) / per; k.a.g_tf = (k.a.n_tf + per - 1) / per;
+      k.nblocks = k.g_imu + k.a.g_tc + k.a.g_tf + (k.a.n_po + per - 1) / per;
+      k.zero_wgs = std::min(k.zero_wgs, 48);
+    }
     b->g_imu_lin = std::max(b->g_imu_lin, c.imu_lin.n + c.imu_lin.zero_wgs); b->g_imu_cost = std::max(b->g_imu_cost, c.imu_cost.n + c.imu_cost.zero_wgs);
     b->g_lin = std::max(b->g_lin, c.lin.nblocks); b->lds_lin = std::max(b->lds_lin, c.lin_lds); b->g_prep = std::max(b->g_prep, c.prep.nblocks); b->g_ssp0 = std::max(b->g_ssp0, c.ssp0.nblocks);
     b->lds_ssp0 = std::max(b->lds_ssp0, c.ssp0_lds); b->lds_back = std::max(b->lds_back, c.back_lds); b->g_tail = std::max(b->g_tail, c.tail.nblocks);
-    b->lds_tail = std::max(b->lds_tail, c.tail_lds); b->g_cost = std::max(b->g_cost, c.cost.nblocks + c.cost.zero_wgs);
+    b->lds_tail = std::max(b->lds_tail, c.tail_lds); b->g_cost = std::max(b->g_cost, co[w].nblocks + co[w].zero_wgs);
     b->max_levels = std::max(b->max_levels, c.n_levels); b->max_nb = std::max(b->max_nb, p->nb);
   }
   LVF_TRY(upload_table(b->imu_lin, il, q)); LVF_TRY(upload_table(b->imu_cost, ic, q)); LVF_TRY(upload_table(b->lin, li, q)); LVF_TRY(upload_table(b->red, rd, q)); LVF_TRY(upload_table(b->prep, pr, q));
