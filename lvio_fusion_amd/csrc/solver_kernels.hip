@@ -2324,9 +2324,10 @@ __device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A,
     return;
   }
   if (A.done && *A.done) return;
+  __shared__ double s_part[kT / 64];
   {
-    // each wave's sum goes out as a RETURNING atomic: its result can only come back once the add has been performed, and the barrier
-    // below waits for it — so every add of this workgroup is in the sum before its ticket is drawn (a release fence here would write
+    // the workgroup's sum goes out as a RETURNING atomic: its result can only come back once the add has been performed, and the
+    // ticket below is drawn after it — so every add of this workgroup is in the sum before its ticket is drawn (a release fence here would write
     // the L2 back once per workgroup: measured 7 % slower for 8 windows than the separate decision launch)
     double c;
     if (b >= A.g_imu) c = cost_visual_value(b - A.g_imu, A);
@@ -2345,15 +2346,20 @@ __device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A,
       const double r = imu_weighted_residual(threadIdx.x, sS, sr0);      // rows 0..14 in lanes 0..14 of wave 0
       c = threadIdx.x < 15 ? 0.5 * r * r : 0.0;
     }
+    // one add per WORKGROUP (the four wave sums meet in LDS first): the adds of a stripe serialise at their address
     const double v = wave_sum(c);
-    if ((threadIdx.x & 63) == 0 && v != 0.0) {
-      const double old = atomicAdd(A.cost + (b & (kStripes - 1)), v);
-      asm volatile("" ::"v"(old) : "memory");
-    }
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
   }
   __shared__ int s_last;
   __syncthreads();
   if (threadIdx.x == 0) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < kT / 64; ++k) v += s_part[k];
+    if (v != 0.0) {
+      const double old = atomicAdd(A.cost + (b & (kStripes - 1)), v);
+      asm volatile("" ::"v"(old) : "memory");
+    }
     const int t = atomicAdd(D.ticket, 1);
     s_last = t == A.nblocks - 1;
     if (s_last) atomicExch(D.ticket, 0);
