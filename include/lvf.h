@@ -346,7 +346,9 @@ int lvf_problem_lm_iteration(lvf_problem* p, const lvf_solver_options* o, double
                              double* cost_before, double* cost_after, int* accepted);
 int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary);
 /* Debug/parity taps of the last linearisation: reduced (Schur) system S [d x d row-major], rhs [d],
- * d = 15 * n_kf (pose tangent 6 | v 3 | ba 3 | bg 3 per keyframe). */
+ * d = 15 * n_kf (pose tangent 6 | v 3 | ba 3 | bg 3 per keyframe).  Available after lvf_problem_lm_iteration (the per-call API keeps the
+ * normal equations of its iteration); lvf_problem_solve / lvf_problem_batch_solve clear them at the end of every iteration for the
+ * next one, so after those the tap returns LVF_ERR_STATE ("no linearisation yet"). */
 int lvf_problem_reduced_dim(lvf_problem* p);
 int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs);
 

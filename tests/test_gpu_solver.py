@@ -185,3 +185,46 @@ def test_unsorted_two_frame_uses_generic_path(ctx, oracle):
     assert abs(out[0][0]["cost_before"] - out[1][0]["cost_before"]) <= 1e-10 * out[0][0]["cost_before"]
     assert np.abs(out[0][1] - out[1][1]).max() <= 1e-9 * np.abs(out[0][1]).max()
     assert_parity(out[1][3], out[0][3], "poses after one iteration")
+
+
+def test_mixed_call_sequences_leave_no_stale_accumulators(ctx, oracle):
+    """The device loop clears the normal-equation accumulators at the END of an iteration for the next one and remembers that they are
+    clean; the stand-alone taps and the per-call API dirty them again.  Whatever the order of calls, an LM iteration must see exactly
+    the accumulators of its own linearisation: every sequence below is checked against the oracle from the state it starts at."""
+    from lvio_fusion_amd import api
+    cfg, st, b, prob, win = build(api, ctx, oracle, 9, 200, 41)
+    opt = api.default_solver_options()
+
+    def check_iteration(tag):
+        s = state_of(api, st)
+        win.poses[:] = s["poses"].reshape(-1, 7); win.vel[:] = s["vel"].reshape(-1, 3); win.ba[:] = s["ba"].reshape(-1, 3)
+        win.bg[:] = s["bg"].reshape(-1, 3); win.inv_depth[:] = s["inv_depth"]
+        ref = win.lm_iteration(1e4, 2.0)
+        got = prob.lm_iteration(opt, 1e4, 2.0)
+        assert abs(got["cost_before"] - ref["cost_before"]) <= 1e-8 * abs(ref["cost_before"]), tag
+        assert abs(got["cost_after"] - ref["cost_after"]) <= 1e-6 * abs(ref["cost_after"]), tag
+        assert got["accepted"] == ref["accepted"], tag
+        S, rhs = prob.reduced_system()
+        assert np.abs(S - ref["S"]).max() <= 1e-7 * np.abs(ref["S"]).max(), tag
+
+    o2 = api.default_solver_options(); o2.max_num_iterations = 2; o2.function_tolerance = 0.0; o2.parameter_tolerance = 0.0; o2.gradient_tolerance = 0.0
+    check_iteration("fresh problem")
+    prob.solve(o2)                                    # device loop: leaves the accumulators clean
+    with pytest.raises(api.LvfError):
+        prob.reduced_system()                         # ... and no linearisation to tap
+    check_iteration("after a device-loop solve")
+    prob.gradient(opt)                                # a stand-alone tap dirties them
+    prob.solve(o2)
+    check_iteration("after gradient + solve")
+    prob.cost(opt)
+    check_iteration("after cost")
+    batch = api.ProblemBatch(ctx, [prob])
+    batch.solve(o2)
+    check_iteration("after a batch solve")
+    batch.lm_iteration(opt, [1e4], [2.0])
+    S, rhs = prob.reduced_system()                    # the per-call batch API keeps its normal equations too
+    assert np.isfinite(S).all()
+    check_iteration("after a batch iteration")
+    batch.close()
+    for h in [prob, st] + [x for x in b.values() if x is not None]:
+        h.close()
