@@ -56,6 +56,7 @@ struct lvf_window {
     bool fixed = false;                                  // birth frame left the window: world point frozen
     double pw[3] = {0, 0, 0};
     int slot = -1;                                       // dense index in the current assembly (-1: not in the problem)
+    bool alive = true;                                   // false: a free entry of `lms` (indices are STABLE: Obs::lm and the device tables keep them)
   };
   lvf_ctx* ctx = nullptr;
   lvf_camera left, right;
@@ -63,7 +64,9 @@ struct lvf_window {
   std::vector<Kf> kfs;                                   // active keyframes, oldest first
   std::unordered_map<int64_t, int> kf_index;             // id -> position in kfs
   std::unordered_map<int64_t, std::array<double, 7>> departed;   // poses of frames that left the window (for ToWorld)
-  std::vector<Lm> lms;
+  std::vector<Lm> lms;                                   // entries are re-used through lm_free, never moved
+  std::vector<int> lm_free;
+  int n_lm_live = 0;
   std::unordered_map<int64_t, int> lm_index;
   // device side, persistent across ticks
   lvf_state* st = nullptr;
@@ -108,26 +111,21 @@ static int put(DevBuf<T>& buf, const std::vector<T>& v, hipStream_t s) { return 
 // re-indexed; poses of departed frames are kept only while a live landmark was born there.
 static void prune(lvf_window* w) {
   const size_t nl = w->lms.size();
-  std::vector<int> remap(nl, -1);
+  std::vector<char> seen(nl, 0);
   for (const lvf_window::Kf& f : w->kfs)
-    for (const lvf_window::Obs& o : f.obs) remap[o.lm] = 0;
-  size_t live = 0;
-  for (size_t i = 0; i < nl; ++i)
-    if (remap[i] == 0) remap[i] = (int)live++;
-  if (live != nl) {
-    std::vector<lvf_window::Lm> kept;
-    kept.reserve(live);
-    w->lm_index.clear();
-    for (size_t i = 0; i < nl; ++i)
-      if (remap[i] >= 0) { w->lm_index[w->lms[i].id] = remap[i]; kept.push_back(w->lms[i]); }
-    w->lms.swap(kept);
-    for (lvf_window::Kf& f : w->kfs)
-      for (lvf_window::Obs& o : f.obs) o.lm = remap[o.lm];
-    w->slot_lm.clear();          // slots of the last assembly referred to the old indices
+    for (const lvf_window::Obs& o : f.obs) seen[o.lm] = 1;
+  for (size_t i = 0; i < nl; ++i) {
+    lvf_window::Lm& l = w->lms[i];
+    if (l.alive && !seen[i]) {                 // the entry becomes free; nothing is moved, so every index held elsewhere stays valid
+      w->lm_index.erase(l.id);
+      l.alive = false; l.fixed = false; l.slot = -1;
+      w->lm_free.push_back((int)i);
+      --w->n_lm_live;
+    }
   }
   if (!w->departed.empty()) {
     std::unordered_map<int64_t, char> anchor;
-    for (const lvf_window::Lm& l : w->lms) anchor[l.birth_kf] = 1;
+    for (const lvf_window::Lm& l : w->lms) if (l.alive) anchor[l.birth_kf] = 1;
     for (auto it = w->departed.begin(); it != w->departed.end();) it = anchor.count(it->first) ? std::next(it) : w->departed.erase(it);
   }
 }
@@ -154,6 +152,7 @@ static void landmarks_to_world(const lvf_window* w, std::vector<double>& lm_pw, 
   for (int k = 0; k < n_kf; ++k) ids[k] = w->kfs[k].id;
   for (size_t i = 0; i < nl; ++i) {
     const lvf_window::Lm& l = w->lms[i];
+    if (!l.alive) continue;
     if (l.fixed) { std::memcpy(&lm_pw[3 * i], l.pw, 24); continue; }
     if (l.birth_kf < first_id) continue;
     // position of the birth frame: the window's ids ascend, so a binary search over <= a few dozen ids (a hash lookup per landmark
@@ -320,9 +319,11 @@ int lvf_window_add_landmark(lvf_window* w, int64_t lm_id, int64_t birth_kf_id, c
   lvf_window::Lm l;
   l.id = lm_id; l.birth_kf = birth_kf_id; l.inv_depth = inv_depth;
   std::memcpy(l.left_ob, left_ob2, 16); std::memcpy(l.right_ob, right_ob2, 16);
-  const int idx = (int)w->lms.size();
+  int idx;
+  if (!w->lm_free.empty()) { idx = w->lm_free.back(); w->lm_free.pop_back(); w->lms[idx] = l; }
+  else { idx = (int)w->lms.size(); w->lms.push_back(l); }
   w->lm_index[lm_id] = idx;
-  w->lms.push_back(l);
+  ++w->n_lm_live;
   // the landmark's own left feature in its birth frame (features_left[lm] of the first frame -> the TwoCamera block)
   lvf_window::Obs o; o.lm_id = lm_id; o.lm = idx; o.ob[0] = left_ob2[0]; o.ob[1] = left_ob2[1];
   w->kfs[it->second].put(o);
@@ -362,7 +363,7 @@ int lvf_window_slide(lvf_window* w, int64_t first_active_kf_id) {
     w->departed[w->kfs[k].id] = p;
   }
   for (lvf_window::Lm& l : w->lms)
-    if (!l.fixed && l.birth_kf < first_active_kf_id) {
+    if (l.alive && !l.fixed && l.birth_kf < first_active_kf_id) {
       auto it = w->departed.find(l.birth_kf);
       if (it != w->departed.end()) { to_world(w->right, l.right_ob, l.inv_depth, it->second.data(), l.pw); l.fixed = true; }
     }
@@ -409,7 +410,7 @@ int lvf_window_get_inv_depth(const lvf_window* w, int64_t lm_id, double* inv_dep
 int lvf_window_counts(const lvf_window* w, int32_t* counts8) {
   LVF_REQUIRE(w && counts8, "lvf_window_counts: null argument");
   counts8[0] = (int)w->kfs.size(); counts8[1] = w->n_lm_problem; counts8[2] = w->n_tc; counts8[3] = w->n_tf; counts8[4] = w->n_po;
-  counts8[5] = w->n_imu; counts8[6] = w->n_prior; counts8[7] = (int)w->lms.size();
+  counts8[5] = w->n_imu; counts8[6] = w->n_prior; counts8[7] = w->n_lm_live;
   return LVF_OK;
 }
 
