@@ -421,6 +421,8 @@ typedef struct lvf_window_options {
   double baseline;              /* Camera::baseline: a landmark deeper than 50 baselines is "Far" (camera.h:38-41) */
   int weak_visual_threshold;    /* 20 (backend.cpp:166) */
   double prior_weight, prior_v; /* PoseGraphError / PoseError (.., 100, 0)  (backend.cpp:170,175) */
+  int device_assembly;          /* 1 (default): the per-tick block lists are assembled ON THE DEVICE from resident feature / landmark tables (only
+                                 * what changed since the last tick is uploaded); 0: the host walks every feature and uploads the lists */
 } lvf_window_options;
 void lvf_window_options_default(lvf_window_options* o);
 int lvf_window_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera* right, const lvf_window_options* opt, lvf_window** out);

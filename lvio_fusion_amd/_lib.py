@@ -44,7 +44,8 @@ class ScanMatchResult(C.Structure):
 
 
 class WindowOptions(C.Structure):
-    _fields_ = [("baseline", C.c_double), ("weak_visual_threshold", C.c_int), ("prior_weight", C.c_double), ("prior_v", C.c_double)]
+    _fields_ = [("baseline", C.c_double), ("weak_visual_threshold", C.c_int), ("prior_weight", C.c_double), ("prior_v", C.c_double),
+                ("device_assembly", C.c_int)]
 
 
 class LidarParams(C.Structure):

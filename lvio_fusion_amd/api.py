@@ -440,13 +440,15 @@ def lidar_solve(batch, rpyxyz, huber_a, prior_weight=0.0, max_num_iterations=4):
 class Window:
     """Persistent sliding window (lvf_window_*): Backend::BuildProblem's assembly kept incrementally across ticks."""
 
-    def __init__(self, ctx, left, right, baseline=None, weak_visual_threshold=20):
+    def __init__(self, ctx, left, right, baseline=None, weak_visual_threshold=20, device_assembly=None):
         self.ctx = ctx
         o = WindowOptions()
         ctx.L.lvf_window_options_default(C.byref(o))
         if baseline is not None:
             o.baseline = float(baseline)
         o.weak_visual_threshold = int(weak_visual_threshold)
+        if device_assembly is not None:
+            o.device_assembly = 1 if device_assembly else 0
         self.h = C.c_void_p()
         cl, cr = make_camera(left), make_camera(right)
         _chk(ctx.L.lvf_window_create(ctx.h, C.byref(cl), C.byref(cr), C.byref(o), C.byref(self.h)))

@@ -37,7 +37,9 @@ struct lvf_window {
     lvf_preint pre;
     std::vector<Obs> obs;                                // kept sorted by landmark id (BuildProblem's iteration order) lazily
     bool sorted = true;
-    void put(const Obs& o) { if (!obs.empty() && o.lm_id <= obs.back().lm_id) sorted = false; obs.push_back(o); }
+    bool d_dirty = true;                                 // device-side assembly: the frame's segment of the feature arena is stale
+    size_t d_off = 0, d_cap = 0;                         // ... its place there (elements)
+    void put(const Obs& o) { if (!obs.empty() && o.lm_id <= obs.back().lm_id) sorted = false; obs.push_back(o); d_dirty = true; }
     void sort_unique() {                                 // std::map semantics: ascending key, a re-inserted key overwrites
       if (sorted) return;
       std::stable_sort(obs.begin(), obs.end(), [](const Obs& a, const Obs& b) { return a.lm_id < b.lm_id; });
@@ -76,6 +78,12 @@ struct lvf_window {
   lvf::DevBuf<uint8_t> rej_flags;
   // pinned staging for the per-tick block lists (observations / indices per functor type)
   lvf::HostPin<double> h_state;      // poses | vel | ba | bg | w_visual | inv_depth (read-back staging)
+  // device-side assembly (opt.device_assembly): resident feature arena + per-tick tables and scratch
+  lvf::DevBuf<int32_t> d_obs_lm; lvf::DevBuf<double> d_obs_xy; size_t arena_end = 0;
+  lvf::DevBuf<unsigned char> d_lmtab, d_frames, d_cls, d_used;
+  lvf::DevBuf<int> d_wgcnt, d_wgbase, d_slot, d_slot_lm, d_counts;
+  lvf::DevBuf<double> d_lm_invd_out;
+  lvf::HostPin<int> h_counts;
   std::vector<lvf::LmHot> hot;                           // per-tick compact copy of what the feature walk reads of a landmark
   lvf::HostPin<unsigned char> h_stage;                   // the tick's packed upload (records + plain segments)
   lvf::DevBuf<unsigned char> d_stage;
@@ -132,6 +140,18 @@ static void prune(lvf_window* w) {
 
 // landmark->ToWorld() (src/lvio_fusion/src/landmark.cpp:15-19) for every landmark of the mirror: frozen points as stored, live ones
 // from their birth keyframe's CURRENT pose and inverse depth.  lm_birth_pos[i] = position of the birth keyframe in kfs (-1: not active).
+// Rk[9 k] = rotation of keyframe k (row-major), Rk[9 n_kf] = rotation of the right camera's extrinsic (same construction as in
+// landmarks_to_world: the device-side assembly multiplies with exactly these matrices)
+static void landmarks_to_world_prepare(const lvf_window* w, double* Rk) {
+  const int n_kf = (int)w->kfs.size();
+  auto rot_of = [](const double q[4], double R[9]) {
+    double e0[3] = {1, 0, 0}, e1[3] = {0, 1, 0}, e2[3] = {0, 0, 1}, c0[3], c1[3], c2[3];
+    hse3::rotate(q, e0, c0); hse3::rotate(q, e1, c1); hse3::rotate(q, e2, c2);
+    R[0] = c0[0]; R[1] = c1[0]; R[2] = c2[0]; R[3] = c0[1]; R[4] = c1[1]; R[5] = c2[1]; R[6] = c0[2]; R[7] = c1[2]; R[8] = c2[2];
+  };
+  for (int k = 0; k < n_kf; ++k) rot_of(w->kfs[k].pose, Rk + (size_t)9 * k);
+  rot_of(w->right.extrinsic, Rk + (size_t)9 * n_kf);
+}
 static void landmarks_to_world(const lvf_window* w, std::vector<double>& lm_pw, std::vector<int>& lm_birth_pos) {
   const int n_kf = (int)w->kfs.size();
   auto rot_of = [](const double q[4], double R[9]) {
@@ -189,6 +209,173 @@ static void landmarks_hot(const lvf_window* w, std::vector<LmHot>& hot) {
   }
 }
 
+// ================================================================================================ device-side assembly
+// The block lists of a tick assembled ON THE DEVICE from resident tables, so that the host neither walks ~10^5 features nor uploads
+// ~4 MB of lists per tick:
+//   feature arena   obs_lm[i] (landmark INDEX, stable: lvf_window::lms entries never move), obs_xy[i]; one segment per keyframe, in
+//                   BuildProblem's order (ascending landmark id); only new / changed keyframes are uploaded
+//   landmark table  LmDev[nl] (first observation, inverse depth, birth keyframe id, frozen world point) — re-sent every tick (64 B each)
+//   frame table     FrameDev[n_kf] (id, segment, rotation + translation for Landmark::ToWorld, the Camera::Far row) — every tick
+// k_da_classify : one thread per feature -> block type (BuildProblem's rules), per-workgroup and per-keyframe counts, landmarks in use
+// k_da_scan     : one workgroup: output offsets per workgroup and type (features keep their order: keyframe by keyframe, ascending
+//                 landmark id), dense landmark slots (ascending landmark index), inverse depths into the state
+// k_da_emit     : one thread per feature -> its block's SoA entries
+// The host reads back 4 + 2 n_kf counters (block totals, TwoFrame blocks and near visual blocks per keyframe) for the work list, the
+// IMU / prior decisions and the launch shapes.
+struct LmDev { double right_ob[2]; double pw[3]; double inv_depth; long long birth_kf; int fixed; int alive; };
+struct FrameDev { long long id; int start, cnt; long long arena_off; double zrow[3], zoff; double R[9], t[3]; };
+static_assert(sizeof(LmDev) == 64 && sizeof(FrameDev) % 8 == 0, "device table records");
+constexpr int kDaMaxKf = 64;
+struct DaArgs {
+  int n_kf, total, nl, n_wg;
+  const FrameDev* frames; const int32_t* obs_lm; const double2* obs_xy; const LmDev* lm;
+  double Re[9], te[3], fx, fy, cx, cy, far_z;      // right camera (Landmark::ToWorld goes through it), Camera::Far threshold
+  unsigned char* cls; unsigned char* used; int* wgcnt; int* wgbase; int* slot; int* slot_lm; int* counts;   // counts: [0..3] tc, tf, po, n_lm | tf per kf [64] | near per kf [64]
+  double* state_invd; double* lm_invd_out;
+  double2 *tc_l, *tc_r; int32_t *tc_lm, *tc_kf;
+  double2 *tf_f, *tf_o; int32_t *tf_lm, *tf_k1, *tf_k2;
+  double2* po_o; double* po_pw; int32_t *po_kf, *po_pi;
+};
+// frame of global feature index g (frames' segments concatenated); s_start[n_kf] = total
+__device__ __forceinline__ int da_frame_of(const int* s_start, int n_kf, int g) {
+  int lo = 0, hi = n_kf - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_start[mid] <= g) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+__device__ __forceinline__ int da_birth_pos(const long long* s_id, int n_kf, long long id) {
+  int lo = 0, hi = n_kf - 1;
+  while (lo <= hi) { const int mid = (lo + hi) >> 1; if (s_id[mid] == id) return mid; if (s_id[mid] < id) lo = mid + 1; else hi = mid - 1; }
+  return -1;
+}
+// Landmark::ToWorld (landmark.cpp:15-19) with the matrices the host expanded (same operation order as landmarks_to_world)
+__device__ __forceinline__ void da_to_world(const DaArgs& a, const LmDev& L, const FrameDev& B, double pw[3]) {
+  const double d = 1.0 / L.inv_depth;
+  const double ps[3] = {(L.right_ob[0] - a.cx) * d / a.fx, (L.right_ob[1] - a.cy) * d / a.fy, d};
+  const double pb[3] = {a.Re[0] * ps[0] + a.Re[1] * ps[1] + a.Re[2] * ps[2] + a.te[0], a.Re[3] * ps[0] + a.Re[4] * ps[1] + a.Re[5] * ps[2] + a.te[1],
+                        a.Re[6] * ps[0] + a.Re[7] * ps[1] + a.Re[8] * ps[2] + a.te[2]};
+  pw[0] = B.R[0] * pb[0] + B.R[1] * pb[1] + B.R[2] * pb[2] + B.t[0];
+  pw[1] = B.R[3] * pb[0] + B.R[4] * pb[1] + B.R[5] * pb[2] + B.t[1];
+  pw[2] = B.R[6] * pb[0] + B.R[7] * pb[1] + B.R[8] * pb[2] + B.t[2];
+}
+__global__ __launch_bounds__(256) void k_da_classify(DaArgs a) {
+  __shared__ int s_start[kDaMaxKf + 1];
+  __shared__ long long s_id[kDaMaxKf];
+  __shared__ int s_cnt[3], s_tf[kDaMaxKf], s_near[kDaMaxKf];
+  const int tid = threadIdx.x, g = blockIdx.x * 256 + tid;
+  if (tid < a.n_kf) { s_start[tid] = a.frames[tid].start; s_id[tid] = a.frames[tid].id; s_tf[tid] = 0; s_near[tid] = 0; }
+  if (tid == 0) s_start[a.n_kf] = a.total;
+  if (tid < 3) s_cnt[tid] = 0;
+  __syncthreads();
+  if (g < a.total) {
+    const int k = da_frame_of(s_start, a.n_kf, g);
+    const FrameDev F = a.frames[k];
+    const int lm = a.obs_lm[F.arena_off + (g - F.start)];
+    const LmDev L = a.lm[lm];
+    int c = 0;                                       // 0 none / 1 TwoCamera / 2 TwoFrame / 3 PoseOnly
+    if (L.birth_kf == F.id) c = 1;
+    else {
+      const int bpos = da_birth_pos(s_id, a.n_kf, L.birth_kf);
+      double pw[3];
+      if (bpos < 0) { if (L.fixed) { c = 3; pw[0] = L.pw[0]; pw[1] = L.pw[1]; pw[2] = L.pw[2]; } }
+      else { c = 2; da_to_world(a, L, a.frames[bpos], pw); }
+      if (c && !(F.zrow[0] * pw[0] + F.zrow[1] * pw[1] + F.zrow[2] * pw[2] + F.zoff > a.far_z)) atomicAdd(&s_near[k], 1);      // !Camera::Far
+      if (c == 2) atomicAdd(&s_tf[k], 1);
+    }
+    a.cls[g] = (unsigned char)c;
+    if (c) atomicAdd(&s_cnt[c - 1], 1);
+    if (c == 1 || c == 2) a.used[lm] = 1;
+  }
+  __syncthreads();
+  if (tid < 3) a.wgcnt[3 * blockIdx.x + tid] = s_cnt[tid];
+  if (tid < a.n_kf) {
+    if (s_tf[tid]) atomicAdd(&a.counts[4 + tid], s_tf[tid]);
+    if (s_near[tid]) atomicAdd(&a.counts[4 + kDaMaxKf + tid], s_near[tid]);
+  }
+}
+__global__ __launch_bounds__(1024) void k_da_scan(DaArgs a) {
+  __shared__ int s_a[1024], s_b[1024], s_c[1024];
+  const int tid = threadIdx.x;
+  // (1) exclusive scan of the per-workgroup block counts, per type (n_wg <= a few hundred: chunks of 1024 with a running carry)
+  int carry[3] = {0, 0, 0};
+  for (int base = 0; base < a.n_wg; base += 1024) {
+    const int i = base + tid;
+    int v[3] = {0, 0, 0};
+    if (i < a.n_wg) { v[0] = a.wgcnt[3 * i]; v[1] = a.wgcnt[3 * i + 1]; v[2] = a.wgcnt[3 * i + 2]; }
+    s_a[tid] = v[0]; s_b[tid] = v[1]; s_c[tid] = v[2];
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int xa = tid >= o ? s_a[tid - o] : 0, xb = tid >= o ? s_b[tid - o] : 0, xc = tid >= o ? s_c[tid - o] : 0;
+      __syncthreads();
+      s_a[tid] += xa; s_b[tid] += xb; s_c[tid] += xc;
+      __syncthreads();
+    }
+    if (i < a.n_wg) { a.wgbase[3 * i] = carry[0] + s_a[tid] - v[0]; a.wgbase[3 * i + 1] = carry[1] + s_b[tid] - v[1]; a.wgbase[3 * i + 2] = carry[2] + s_c[tid] - v[2]; }
+    carry[0] += s_a[1023]; carry[1] += s_b[1023]; carry[2] += s_c[1023];
+    __syncthreads();
+  }
+  if (tid == 0) { a.counts[0] = carry[0]; a.counts[1] = carry[1]; a.counts[2] = carry[2]; }
+  // (2) dense landmark slots in ascending landmark index: every thread owns a run of consecutive landmarks
+  const int per = (a.nl + 1023) / 1024, l0 = min(a.nl, tid * per), l1 = min(a.nl, l0 + per);
+  int mine = 0;
+  for (int l = l0; l < l1; ++l) mine += a.used[l] ? 1 : 0;
+  s_a[tid] = mine;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int x = tid >= o ? s_a[tid - o] : 0;
+    __syncthreads();
+    s_a[tid] += x;
+    __syncthreads();
+  }
+  int at = s_a[tid] - mine;
+  for (int l = l0; l < l1; ++l) {
+    const double invd = a.lm[l].inv_depth;
+    a.lm_invd_out[l] = invd;
+    if (a.used[l]) { a.slot[l] = at; a.slot_lm[at] = l; a.state_invd[at] = invd; ++at; } else a.slot[l] = -1;
+  }
+  if (tid == 1023) a.counts[3] = s_a[1023];
+}
+__global__ __launch_bounds__(256) void k_da_emit(DaArgs a) {
+  __shared__ int s_start[kDaMaxKf + 1];
+  __shared__ long long s_id[kDaMaxKf];
+  __shared__ int s_wave[4][3];
+  const int tid = threadIdx.x, g = blockIdx.x * 256 + tid, lane = tid & 63, wv = tid >> 6;
+  if (tid < a.n_kf) { s_start[tid] = a.frames[tid].start; s_id[tid] = a.frames[tid].id; }
+  if (tid == 0) s_start[a.n_kf] = a.total;
+  const int c = g < a.total ? a.cls[g] : 0;
+  // rank of this feature among the workgroup's features of the same type, in feature order
+  int rank = 0;
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int t = 1; t <= 3; ++t) {
+    const unsigned long long m = __ballot(c == t);
+    if (c == t) rank = __popcll(m & below);
+    if (lane == 0) s_wave[wv][t - 1] = __popcll(m);
+  }
+  __syncthreads();
+  if (!c) return;
+  int idx = a.wgbase[3 * blockIdx.x + (c - 1)] + rank;
+  for (int w = 0; w < wv; ++w) idx += s_wave[w][c - 1];
+  const int k = da_frame_of(s_start, a.n_kf, g);
+  const FrameDev F = a.frames[k];
+  const long long i = F.arena_off + (g - F.start);
+  const int lm = a.obs_lm[i];
+  const double2 ob = a.obs_xy[i];
+  const LmDev L = a.lm[lm];
+  if (c == 1) {
+    a.tc_l[idx] = ob; a.tc_r[idx] = make_double2(L.right_ob[0], L.right_ob[1]); a.tc_lm[idx] = a.slot[lm]; a.tc_kf[idx] = k;
+  } else if (c == 2) {
+    a.tf_f[idx] = make_double2(L.right_ob[0], L.right_ob[1]); a.tf_o[idx] = ob; a.tf_lm[idx] = a.slot[lm];
+    a.tf_k1[idx] = da_birth_pos(s_id, a.n_kf, L.birth_kf); a.tf_k2[idx] = k;
+  } else {
+    a.po_o[idx] = ob; a.po_pw[3 * idx] = L.pw[0]; a.po_pw[3 * idx + 1] = L.pw[1]; a.po_pw[3 * idx + 2] = L.pw[2]; a.po_kf[idx] = k; a.po_pi[idx] = idx;
+  }
+}
+// after the solve: the landmarks' inverse depths back into landmark-index order (the host mirror is indexed that way)
+__global__ __launch_bounds__(256) void k_da_scatter_invd(int n_lm, const int* __restrict__ slot_lm, const double* __restrict__ state_invd, double* __restrict__ lm_invd_out) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < n_lm) lm_invd_out[slot_lm[s]] = state_invd[s];
+}
+
 // the read-back mirror of k_window_unpack's plain segments: device arrays -> one contiguous staging block (then ONE device-to-host copy
 // instead of five, each a submission of its own)
 struct PackArgs { unsigned char* stage; int n_segs; const unsigned char* src[8]; size_t off[8]; unsigned words[8]; };
@@ -220,7 +407,7 @@ struct TcRec { double l[2], r[2]; int32_t lm, kf, pad0, pad1; };
 struct TfRec { double f[2], o[2]; int32_t lm, k1, k2, pad0; };
 struct PoRec { double o[2], pw[3]; int32_t kf, pi; };
 static_assert(sizeof(TcRec) == 48 && sizeof(TfRec) == 48 && sizeof(PoRec) == 48, "staging records are 48 bytes");
-constexpr int kMaxSegs = 20;
+constexpr int kMaxSegs = 96;            // (the whole UnpackArgs block stays under the 4 KB kernel-argument limit)
 struct UnpackArgs {
   const unsigned char* stage;
   int ntc, ntf, npo; size_t off_tc, off_tf, off_po;
@@ -278,6 +465,7 @@ void lvf_window_options_default(lvf_window_options* o) {
   o->baseline = 0.537;                 // |t_cam1 - t_cam0| of the KITTI rig (config/kitti.yaml); Camera::baseline
   o->weak_visual_threshold = 20;       // backend.cpp:166
   o->prior_weight = 100.0; o->prior_v = 0.0;   // backend.cpp:170,175
+  o->device_assembly = 1;
 }
 
 int lvf_window_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera* right, const lvf_window_options* opt, lvf_window** out) {
@@ -346,6 +534,7 @@ int lvf_window_remove_observation(lvf_window* w, int64_t lm_id, int64_t kf_id) {
   LVF_REQUIRE(ik != w->kf_index.end(), "lvf_window_remove_observation: keyframe %lld is not in the window", (long long)kf_id);
   auto& v = w->kfs[ik->second].obs;
   v.erase(std::remove_if(v.begin(), v.end(), [&](const lvf_window::Obs& o) { return o.lm_id == lm_id; }), v.end());
+  w->kfs[ik->second].d_dirty = true;
   return LVF_OK;
 }
 
@@ -414,11 +603,299 @@ int lvf_window_counts(const lvf_window* w, int32_t* counts8) {
   return LVF_OK;
 }
 
+
+// lvf_window_solve with the block lists assembled on the device (see "device-side assembly" above).
+}  // extern "C"
+static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_solver_summary* summary) {
+  lvf_ctx* ctx = w->ctx;
+  hipStream_t s = ctx->stream;
+  const int n_kf = (int)w->kfs.size();
+  static const bool timing = getenv("LVF_WINDOW_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const auto t_begin = now();
+  const size_t nl = w->lms.size();
+  // ---- persistent device objects
+  if (!w->st) {
+    LVF_TRY(lvf_state_create(ctx, 0, 0, &w->st));
+    const double z2[2] = {0, 0}; const int32_t z = 0; const double id7[7] = {0, 0, 0, 1, 0, 0, 0};
+    LVF_TRY(lvf_two_camera_create(ctx, &w->left, &w->right, 0, z2, z2, &z, &z, &w->tc));
+    LVF_TRY(lvf_two_frame_create(ctx, &w->left, &w->right, 0, z2, z2, &z, &z, &z, &w->tf));
+    LVF_TRY(lvf_pose_only_create(ctx, &w->left, 0, z2, &z, &z, 0, id7, &w->po));
+    LVF_TRY(lvf_imu_create(ctx, 0, nullptr, nullptr, nullptr, &w->imu));
+    LVF_TRY(lvf_pose_prior_create(ctx, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &w->prior));
+  }
+  lvf_state* st = w->st;
+  // ---- feature arena: every frame owns a segment; new / changed frames are (re)sent, a frame that outgrew its segment moves to the
+  // end, and when the end is reached everything is laid out again from the start
+  size_t n_obs = 0, need_new = 0;
+  for (lvf_window::Kf& f : w->kfs) {
+    f.sort_unique();
+    n_obs += f.obs.size();
+    if (f.d_cap < f.obs.size()) { f.d_dirty = true; need_new += f.obs.size() + f.obs.size() / 4 + 64; }
+  }
+  LVF_REQUIRE(n_obs < (size_t)1 << 30, "lvf_window_solve: too many features");
+  if (w->arena_end + need_new > w->d_obs_lm.cap) {       // re-layout (also the first tick): capacity for twice the window
+    size_t total_cap = 0;
+    for (const lvf_window::Kf& f : w->kfs) total_cap += f.obs.size() + f.obs.size() / 4 + 64;
+    const size_t want = std::max<size_t>(2 * total_cap, 4096);
+    if (want > w->d_obs_lm.cap) { LVF_TRY(w->d_obs_lm.ensure(want)); LVF_TRY(w->d_obs_xy.ensure(2 * want)); }
+    w->arena_end = 0;
+    for (lvf_window::Kf& f : w->kfs) { f.d_cap = 0; f.d_dirty = true; }
+  }
+  for (lvf_window::Kf& f : w->kfs)
+    if (f.d_cap < f.obs.size()) { f.d_off = w->arena_end; f.d_cap = f.obs.size() + f.obs.size() / 4 + 64; w->arena_end += f.d_cap; }
+  // ---- staging: frame table | landmark table | state | dirty feature segments (one copy, one unpack launch)
+  size_t dirty_obs = 0; int dirty_frames = 0;
+  for (const lvf_window::Kf& f : w->kfs) if (f.d_dirty) { dirty_obs += f.obs.size(); ++dirty_frames; }
+  const bool direct_segments = 2 * dirty_frames + 12 > kMaxSegs;      // (a full re-layout of a long window: copy those segments one by one)
+  const size_t stage_bound = up16((size_t)n_kf * sizeof(FrameDev)) + up16(nl * sizeof(LmDev)) + up16((size_t)17 * n_kf * 8) + 8 * 64 + dirty_obs * 24 + (size_t)dirty_frames * 64 + 4096;
+  LVF_TRY(w->h_stage.reserve(stage_bound));
+  LVF_TRY(w->d_stage.ensure(stage_bound));
+  unsigned char* hs = w->h_stage.p;
+  UnpackArgs ua{};
+  size_t cur = 0;
+  auto seg = [&](void* dst, size_t bytes) -> unsigned char* {
+    unsigned char* at = hs + cur;
+    if (bytes) { ua.seg_dst[ua.n_segs] = static_cast<unsigned char*>(dst); ua.seg_off[ua.n_segs] = cur; ua.seg_words[ua.n_segs] = (unsigned)((bytes + 15) / 16); ++ua.n_segs; }
+    cur += up16(bytes);
+    return at;
+  };
+  LVF_TRY(w->d_frames.ensure((size_t)n_kf * sizeof(FrameDev) + 16)); LVF_TRY(w->d_lmtab.ensure(nl * sizeof(LmDev) + 16));
+  // frame table (also what the IMU / prior decisions below need of a frame)
+  std::vector<double> Rk((size_t)9 * n_kf + 9);
+  landmarks_to_world_prepare(w, Rk.data());
+  double inv_e[7];
+  hse3::inv(w->left.extrinsic, inv_e);
+  FrameDev* fd = reinterpret_cast<FrameDev*>(seg(w->d_frames.p, (size_t)n_kf * sizeof(FrameDev)));
+  {
+    int start = 0;
+    for (int k = 0; k < n_kf; ++k) {
+      const lvf_window::Kf& f = w->kfs[k];
+      FrameDev& d = fd[k];
+      d.id = f.id; d.start = start; d.cnt = (int)f.obs.size(); d.arena_off = (long long)f.d_off;
+      start += d.cnt;
+      double inv_pose[7];
+      hse3::inv(f.pose, inv_pose);
+      double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0}, ez[3] = {0, 0, 1}, c0[3], c1[3], c2[3], t[3], r[3];
+      hse3::rotate(inv_pose, ex, r); hse3::rotate(inv_e, r, c0);
+      hse3::rotate(inv_pose, ey, r); hse3::rotate(inv_e, r, c1);
+      hse3::rotate(inv_pose, ez, r); hse3::rotate(inv_e, r, c2);
+      d.zrow[0] = c0[2]; d.zrow[1] = c1[2]; d.zrow[2] = c2[2];
+      hse3::rotate(inv_e, inv_pose + 4, t);
+      d.zoff = t[2] + inv_e[6];
+      std::memcpy(d.R, &Rk[(size_t)9 * k], 72); std::memcpy(d.t, f.pose + 4, 24);
+    }
+  }
+  // landmark table
+  {
+    LmDev* ld = reinterpret_cast<LmDev*>(seg(w->d_lmtab.p, nl * sizeof(LmDev)));
+    for (size_t i = 0; i < nl; ++i) {
+      const lvf_window::Lm& l = w->lms[i];
+      LmDev& d = ld[i];
+      d.right_ob[0] = l.right_ob[0]; d.right_ob[1] = l.right_ob[1]; d.pw[0] = l.pw[0]; d.pw[1] = l.pw[1]; d.pw[2] = l.pw[2];
+      d.inv_depth = l.inv_depth; d.birth_kf = l.alive ? (long long)l.birth_kf : -1; d.fixed = (l.alive && l.fixed) ? 1 : 0; d.alive = l.alive ? 1 : 0;
+    }
+  }
+  // state (the inverse depths are filled on the device, by slot)
+  st->n_kf = n_kf;
+  LVF_TRY(st->poses.ensure((size_t)7 * n_kf + 2)); LVF_TRY(st->vel.ensure((size_t)3 * n_kf + 2)); LVF_TRY(st->ba.ensure((size_t)3 * n_kf + 2)); LVF_TRY(st->bg.ensure((size_t)3 * n_kf + 2));
+  LVF_TRY(st->w_visual.ensure((size_t)n_kf + 2)); LVF_TRY(st->inv_depth.ensure(nl + 2));
+  st->poses.n = (size_t)7 * n_kf; st->vel.n = st->ba.n = st->bg.n = (size_t)3 * n_kf; st->w_visual.n = n_kf;
+  {
+    double* sp = reinterpret_cast<double*>(seg(st->poses.p, (size_t)7 * n_kf * 8));
+    double* sv = reinterpret_cast<double*>(seg(st->vel.p, (size_t)3 * n_kf * 8));
+    double* sa = reinterpret_cast<double*>(seg(st->ba.p, (size_t)3 * n_kf * 8));
+    double* sg = reinterpret_cast<double*>(seg(st->bg.p, (size_t)3 * n_kf * 8));
+    double* sw = reinterpret_cast<double*>(seg(st->w_visual.p, (size_t)n_kf * 8));
+    for (int k = 0; k < n_kf; ++k) {
+      const lvf_window::Kf& f = w->kfs[k];
+      std::memcpy(&sp[(size_t)7 * k], f.pose, 56); std::memcpy(&sv[(size_t)3 * k], f.vel, 24); std::memcpy(&sa[(size_t)3 * k], f.ba, 24);
+      std::memcpy(&sg[(size_t)3 * k], f.bg, 24); sw[k] = f.w_visual;
+    }
+  }
+  // dirty feature segments
+  for (lvf_window::Kf& f : w->kfs) {
+    if (!f.d_dirty) continue;
+    const size_t c = f.obs.size();
+    if (c) {
+      int32_t* dl; double* dx;
+      std::vector<int32_t> tl; std::vector<double> tx;
+      if (direct_segments) { tl.resize(c); tx.resize(2 * c); dl = tl.data(); dx = tx.data(); }
+      else { dl = reinterpret_cast<int32_t*>(seg(w->d_obs_lm.p + f.d_off, c * 4)); dx = reinterpret_cast<double*>(seg(w->d_obs_xy.p + 2 * f.d_off, c * 16)); }
+      for (size_t j = 0; j < c; ++j) { dl[j] = f.obs[j].lm; dx[2 * j] = f.obs[j].ob[0]; dx[2 * j + 1] = f.obs[j].ob[1]; }
+      if (direct_segments) {
+        LVF_HIP(hipMemcpyAsync(w->d_obs_lm.p + f.d_off, dl, c * 4, hipMemcpyHostToDevice, s));
+        LVF_HIP(hipMemcpyAsync(w->d_obs_xy.p + 2 * f.d_off, dx, c * 16, hipMemcpyHostToDevice, s));
+        LVF_HIP(hipStreamSynchronize(s));                 // (pageable temporaries)
+      }
+    }
+    f.d_dirty = false;
+  }
+  LVF_REQUIRE(cur <= w->h_stage.cap && ua.n_segs <= kMaxSegs, "lvf_window_solve: staging overflow");
+  LVF_HIP(hipMemcpyAsync(w->d_stage.p, hs, cur, hipMemcpyHostToDevice, s));
+  ua.stage = w->d_stage.p; ua.g_seg = 64;
+  hipLaunchKernelGGL(k_window_unpack, dim3(ua.g_seg), dim3(256), 0, s, ua);
+  // ---- assembly kernels
+  const int n_wg = (int)((n_obs + 255) / 256);
+  LVF_TRY(w->d_cls.ensure(n_obs + 16)); LVF_TRY(w->d_used.ensure(nl + 16)); LVF_TRY(w->d_wgcnt.ensure((size_t)3 * n_wg + 4)); LVF_TRY(w->d_wgbase.ensure((size_t)3 * n_wg + 4));
+  LVF_TRY(w->d_slot.ensure(nl + 4)); LVF_TRY(w->d_slot_lm.ensure(nl + 4)); LVF_TRY(w->d_counts.ensure(4 + 2 * kDaMaxKf)); LVF_TRY(w->d_lm_invd_out.ensure(nl + 4));
+  LVF_TRY(w->h_counts.reserve(4 + 2 * kDaMaxKf));
+  LVF_TRY(w->tc->ob_a.ensure(2 * std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->ob_b.ensure(2 * std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->idx_a.ensure(std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->idx_b.ensure(std::min(n_obs, nl) + 2));
+  LVF_TRY(w->tf->ob_a.ensure(2 * n_obs + 2)); LVF_TRY(w->tf->ob_b.ensure(2 * n_obs + 2)); LVF_TRY(w->tf->idx_a.ensure(n_obs + 2)); LVF_TRY(w->tf->idx_b.ensure(n_obs + 2)); LVF_TRY(w->tf->idx_c.ensure(n_obs + 2));
+  LVF_TRY(w->po->ob_a.ensure(2 * n_obs + 2)); LVF_TRY(w->po->idx_a.ensure(n_obs + 2)); LVF_TRY(w->po->idx_b.ensure(n_obs + 2)); LVF_TRY(w->po->table.ensure(3 * n_obs + 2));
+  DaArgs da{};
+  da.n_kf = n_kf; da.total = (int)n_obs; da.nl = (int)nl; da.n_wg = n_wg;
+  da.frames = reinterpret_cast<const FrameDev*>(w->d_frames.p); da.obs_lm = w->d_obs_lm.p; da.obs_xy = reinterpret_cast<const double2*>(w->d_obs_xy.p);
+  da.lm = reinterpret_cast<const LmDev*>(w->d_lmtab.p);
+  std::memcpy(da.Re, &Rk[(size_t)9 * n_kf], 72); std::memcpy(da.te, w->right.extrinsic + 4, 24);
+  da.fx = w->right.fx; da.fy = w->right.fy; da.cx = w->right.cx; da.cy = w->right.cy; da.far_z = w->opt.baseline * 50.0;
+  da.cls = w->d_cls.p; da.used = w->d_used.p; da.wgcnt = w->d_wgcnt.p; da.wgbase = w->d_wgbase.p; da.slot = w->d_slot.p; da.slot_lm = w->d_slot_lm.p; da.counts = w->d_counts.p;
+  da.state_invd = st->inv_depth.p; da.lm_invd_out = w->d_lm_invd_out.p;
+  da.tc_l = reinterpret_cast<double2*>(w->tc->ob_a.p); da.tc_r = reinterpret_cast<double2*>(w->tc->ob_b.p); da.tc_lm = w->tc->idx_a.p; da.tc_kf = w->tc->idx_b.p;
+  da.tf_f = reinterpret_cast<double2*>(w->tf->ob_a.p); da.tf_o = reinterpret_cast<double2*>(w->tf->ob_b.p); da.tf_lm = w->tf->idx_a.p; da.tf_k1 = w->tf->idx_b.p; da.tf_k2 = w->tf->idx_c.p;
+  da.po_o = reinterpret_cast<double2*>(w->po->ob_a.p); da.po_pw = w->po->table.p; da.po_kf = w->po->idx_a.p; da.po_pi = w->po->idx_b.p;
+  LVF_HIP(hipMemsetAsync(w->d_used.p, 0, nl + 16, s));
+  LVF_HIP(hipMemsetAsync(w->d_counts.p, 0, (4 + 2 * kDaMaxKf) * sizeof(int), s));
+  if (n_wg) hipLaunchKernelGGL(k_da_classify, dim3(n_wg), dim3(256), 0, s, da);
+  hipLaunchKernelGGL(k_da_scan, dim3(1), dim3(1024), 0, s, da);
+  if (n_wg) hipLaunchKernelGGL(k_da_emit, dim3(n_wg), dim3(256), 0, s, da);
+  LVF_HIP(hipGetLastError());
+  LVF_HIP(hipMemcpyAsync(w->h_counts.p, w->d_counts.p, (4 + 2 * kDaMaxKf) * sizeof(int), hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  const int* hc = w->h_counts.p;
+  const size_t ntc = (size_t)hc[0], ntf = (size_t)hc[1], npo = (size_t)hc[2];
+  const int n_lm = hc[3];
+  const auto t_assembled = now();
+  // ---- the per-frame factors: IMU block or weak-constraint prior (at most one each), from the counters
+  std::vector<double> pr_t, pr_w, pr_v;
+  std::vector<int32_t> imu_i, imu_j, pr_a, pr_b, kf2_counts(n_kf, 0);
+  std::vector<lvf_preint> imu_pre;
+  for (int k = 0; k < n_kf; ++k) {
+    lvf_window::Kf& f = w->kfs[k];
+    kf2_counts[k] = hc[4 + k];
+    bool imu_block = false;
+    if (f.good_imu && k > 0 && w->kfs[k - 1].good_imu && f.has_pre) {
+      imu_pre.push_back(f.pre); imu_i.push_back(k - 1); imu_j.push_back(k);
+      imu_block = true;
+    }
+    if (!imu_block && hc[4 + kDaMaxKf + k] < w->opt.weak_visual_threshold) {
+      double t7[7] = {0, 0, 0, 0, 0, 0, 0};
+      if (k > 0) { LVF_TRY(lvf_relative_rpyxyz(w->kfs[k - 1].pose, f.pose, t7)); pr_a.push_back(k - 1); }
+      else { std::memcpy(t7, f.pose, 56); pr_a.push_back(-1); }
+      pr_b.push_back(k); pr_t.insert(pr_t.end(), t7, t7 + 7); pr_w.push_back(w->opt.prior_weight); pr_v.push_back(w->opt.prior_v);
+    }
+  }
+  w->n_lm_problem = n_lm;
+  w->n_tc = (int)ntc; w->n_tf = (int)ntf; w->n_po = (int)npo; w->n_imu = (int)imu_i.size(); w->n_prior = (int)pr_b.size();
+  st->n_lm = n_lm; st->inv_depth.n = n_lm;
+  auto idx_ok = [](lvf_batch* b, int n, int nkf, int nlm) { b->n = n; b->min_n_kf = nkf; b->min_n_lm = nlm; b->evaluated = false; };
+  w->tc->ob_a.n = w->tc->ob_b.n = 2 * ntc; w->tc->idx_a.n = w->tc->idx_b.n = ntc;
+  idx_ok(w->tc, w->n_tc, n_kf, n_lm);
+  w->tf->ob_a.n = w->tf->ob_b.n = 2 * ntf; w->tf->idx_a.n = w->tf->idx_b.n = w->tf->idx_c.n = ntf;
+  idx_ok(w->tf, w->n_tf, n_kf, n_lm);
+  w->tf->sorted_by_kf = true; w->tf->host_kf1.clear(); w->tf->host_kf2.clear(); w->tf->host_lm.clear(); w->tf->unique_lk2_known = true; w->tf->kf2_counts = std::move(kf2_counts);
+  w->po->ob_a.n = 2 * npo; w->po->idx_a.n = w->po->idx_b.n = npo; w->po->table.n = 3 * npo;
+  idx_ok(w->po, w->n_po, n_kf, 0); w->po->n_table = w->n_po; w->po->sorted_by_kf = true;
+  // second (small) staged upload: IMU pre-integrations and indices, priors
+  {
+    UnpackArgs ub{};
+    size_t at = 0;
+    auto seg2 = [&](void* dst, size_t bytes) -> unsigned char* {
+      unsigned char* pp = hs + at;
+      if (bytes) { ub.seg_dst[ub.n_segs] = static_cast<unsigned char*>(dst); ub.seg_off[ub.n_segs] = at; ub.seg_words[ub.n_segs] = (unsigned)((bytes + 15) / 16); ++ub.n_segs; }
+      at += up16(bytes);
+      return pp;
+    };
+    LVF_TRY(w->h_stage.reserve(up16((size_t)n_kf * 467 * 8) + 16 * 64 + (size_t)n_kf * 128 + 4096));      // (grow-only: the first copy above has completed)
+    hs = w->h_stage.p;
+    lvf_batch* b = w->imu;
+    const size_t ni = (size_t)w->n_imu;
+    LVF_TRY(b->pre.ensure(467 * ni + 2)); LVF_TRY(b->idx_a.ensure(ni + 4)); LVF_TRY(b->idx_b.ensure(ni + 4));
+    b->pre.n = 467 * ni; b->idx_a.n = b->idx_b.n = ni;
+    if (ni) {
+      std::memcpy(seg2(b->pre.p, 467 * ni * 8), imu_pre.data(), 467 * ni * 8);
+      std::memcpy(seg2(b->idx_a.p, ni * 4), imu_i.data(), ni * 4); std::memcpy(seg2(b->idx_b.p, ni * 4), imu_j.data(), ni * 4);
+    }
+    b->host_kf1 = imu_i; b->host_kf2 = imu_j;
+    LVF_TRY(b->sqrt_info.ensure((size_t)225 * w->n_imu)); LVF_TRY(b->res.ensure((size_t)15 * w->n_imu));
+    for (int q = 0; q < 8; ++q) LVF_TRY(b->jac[q].ensure((size_t)15 * b->block_size[q] * w->n_imu));
+    idx_ok(b, w->n_imu, n_kf, 0);
+    b = w->prior;
+    const size_t np_ = (size_t)w->n_prior;
+    LVF_TRY(b->idx_a.ensure(np_ + 4)); LVF_TRY(b->idx_b.ensure(np_ + 4)); LVF_TRY(b->table.ensure(7 * np_ + 2)); LVF_TRY(b->ob_a.ensure(np_ + 2)); LVF_TRY(b->ob_b.ensure(np_ + 2));
+    b->idx_a.n = b->idx_b.n = np_; b->table.n = 7 * np_; b->ob_a.n = b->ob_b.n = np_;
+    if (np_) {
+      std::memcpy(seg2(b->idx_a.p, np_ * 4), pr_a.data(), np_ * 4); std::memcpy(seg2(b->idx_b.p, np_ * 4), pr_b.data(), np_ * 4);
+      std::memcpy(seg2(b->table.p, 7 * np_ * 8), pr_t.data(), 7 * np_ * 8);
+      std::memcpy(seg2(b->ob_a.p, np_ * 8), pr_w.data(), np_ * 8); std::memcpy(seg2(b->ob_b.p, np_ * 8), pr_v.data(), np_ * 8);
+    }
+    LVF_TRY(b->res.ensure((size_t)6 * w->n_prior)); LVF_TRY(b->jac[0].ensure((size_t)42 * w->n_prior)); LVF_TRY(b->jac[1].ensure((size_t)42 * w->n_prior));
+    idx_ok(b, w->n_prior, n_kf, 0);
+    b->host_kf1 = pr_a; b->host_kf2 = pr_b;
+    if (ub.n_segs) {
+      LVF_TRY(w->d_stage.ensure(at + 16));
+      LVF_HIP(hipMemcpyAsync(w->d_stage.p, hs, at, hipMemcpyHostToDevice, s));
+      ub.stage = w->d_stage.p; ub.g_seg = 32;
+      hipLaunchKernelGGL(k_window_unpack, dim3(ub.g_seg), dim3(256), 0, s, ub);
+      LVF_HIP(hipGetLastError());
+    }
+  }
+  if (w->n_imu) LVF_TRY(launch_imu_sqrt_info(w->imu));
+  const auto t_uploaded = now();
+  if (!w->prob) {
+    LVF_TRY(lvf_problem_create(ctx, st, w->tc, w->tf, w->po, w->imu, &w->prob));
+    LVF_TRY(lvf_problem_set_pose_priors(w->prob, w->prior));
+  } else {
+    LVF_TRY(problem_configure(w->prob));
+  }
+  const auto t_configured = now();
+  LVF_TRY(lvf_problem_solve(w->prob, o, summary));
+  const auto t_solved = now();
+  // ---- read-back: poses, velocities, biases by keyframe position; inverse depths in landmark-index order
+  {
+    if (n_lm) hipLaunchKernelGGL(k_da_scatter_invd, dim3((n_lm + 255) / 256), dim3(256), 0, s, n_lm, w->d_slot_lm.p, st->inv_depth.p, w->d_lm_invd_out.p);
+    PackArgs pa{};
+    size_t at = 0;
+    size_t offs[5];
+    auto segp = [&](const void* src, size_t bytes, int slot) {
+      offs[slot] = at;
+      if (bytes) { pa.src[pa.n_segs] = static_cast<const unsigned char*>(src); pa.off[pa.n_segs] = at; pa.words[pa.n_segs] = (unsigned)((bytes + 15) / 16); ++pa.n_segs; }
+      at += up16(bytes);
+    };
+    segp(st->poses.p, (size_t)7 * n_kf * 8, 0); segp(st->vel.p, (size_t)3 * n_kf * 8, 1); segp(st->ba.p, (size_t)3 * n_kf * 8, 2); segp(st->bg.p, (size_t)3 * n_kf * 8, 3);
+    segp(w->d_lm_invd_out.p, nl * 8, 4);
+    LVF_TRY(w->d_stage.ensure(at + 16)); LVF_TRY(w->h_state.reserve(at / 8 + 2));
+    pa.stage = w->d_stage.p;
+    hipLaunchKernelGGL(k_window_pack, dim3(32), dim3(256), 0, s, pa);
+    LVF_HIP(hipGetLastError());
+    LVF_HIP(hipMemcpyAsync(w->h_state.p, w->d_stage.p, at, hipMemcpyDeviceToHost, s));
+    LVF_HIP(hipStreamSynchronize(s));
+    const double *poses = w->h_state.p + offs[0] / 8, *vel = w->h_state.p + offs[1] / 8, *ba = w->h_state.p + offs[2] / 8, *bg = w->h_state.p + offs[3] / 8,
+                 *invd = w->h_state.p + offs[4] / 8;
+    for (int k = 0; k < n_kf; ++k) {
+      lvf_window::Kf& f = w->kfs[k];
+      std::memcpy(f.pose, &poses[(size_t)7 * k], 56);
+      if (f.good_imu) { std::memcpy(f.vel, &vel[(size_t)3 * k], 24); std::memcpy(f.ba, &ba[(size_t)3 * k], 24); std::memcpy(f.bg, &bg[(size_t)3 * k], 24); }
+    }
+    for (size_t i = 0; i < nl; ++i) if (w->lms[i].alive) w->lms[i].inv_depth = invd[i];
+  }
+  w->slot_lm.clear();
+  if (timing)
+    std::fprintf(stderr, "lvf_window_solve (device assembly): tables + assembly + counters %.3f ms, small uploads %.3f ms, configure %.3f ms, solve %.3f ms (%d its), read-back %.3f ms\n",
+                 ms(t_begin, t_assembled), ms(t_assembled, t_uploaded), ms(t_uploaded, t_configured), ms(t_configured, t_solved), summary->num_iterations, ms(t_solved, now()));
+  return LVF_OK;
+}
+
+extern "C" {
 int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summary* summary) {
   LVF_REQUIRE(w && o && summary, "lvf_window_solve: null argument");
   LVF_REQUIRE(!w->kfs.empty(), "lvf_window_solve: empty window");
   lvf_ctx* ctx = w->ctx;
   LVF_TRY(lvf::enter(ctx));
+  static const bool host_asm = getenv("LVF_WINDOW_HOST_ASM") != nullptr;
+  if (w->opt.device_assembly && !host_asm && (int)w->kfs.size() <= lvf::kDaMaxKf) return window_solve_device(w, o, summary);
   hipStream_t s = ctx->stream;
   const int n_kf = (int)w->kfs.size();
   static const bool timing = getenv("LVF_WINDOW_TIMING") != nullptr;
@@ -725,7 +1202,7 @@ int lvf_window_reject_outliers(lvf_window* w, double max_px, int64_t* removed_lm
       ++total;
     }
   for (int i = n - 1; i >= 0; --i)
-    if (flags[i]) { auto& v = w->kfs[where[i].first].obs; v.erase(v.begin() + where[i].second); }
+    if (flags[i]) { auto& v = w->kfs[where[i].first].obs; v.erase(v.begin() + where[i].second); w->kfs[where[i].first].d_dirty = true; }
   *n_removed = total;
   if (total) prune(w);
   return LVF_OK;
