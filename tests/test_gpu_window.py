@@ -22,8 +22,9 @@ def is_far(cam0, baseline, pw, pose):
     return pc[2] > 50.0 * baseline
 
 
+@pytest.mark.parametrize("device_assembly", [True, False])     # block lists assembled on the device / by the host walk
 @pytest.mark.parametrize("with_imu,weak_thr", [(True, 20), (False, 10 ** 6), (False, 8)])
-def test_ticks_match_from_scratch_assembly(oracle, with_imu, weak_thr):
+def test_ticks_match_from_scratch_assembly(oracle, with_imu, weak_thr, device_assembly):
     from lvio_fusion_amd import api
     N, W, max_it = 12, 6, 3
     cfg = syn.config4_window(n_kf=N, n_lm=150, n_prewindow=0, seed=606, imu_samples=4)
@@ -32,7 +33,7 @@ def test_ticks_match_from_scratch_assembly(oracle, with_imu, weak_thr):
     tc, tf = cfg["tc"], cfg["tf"]
     pre = [oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]]
     ctx = api.Context(0)
-    win = api.Window(ctx, cam0, cam1, baseline=baseline, weak_visual_threshold=weak_thr)
+    win = api.Window(ctx, cam0, cam1, baseline=baseline, weak_visual_threshold=weak_thr, device_assembly=device_assembly)
     opt = api.default_solver_options(); opt.max_num_iterations = max_it
     # ---- from-scratch mirror state
     pose = {}; vel = {}; ba = {}; bg = {}; invd = {}; departed = {}; fixed_pw = {}
@@ -53,6 +54,11 @@ def test_ticks_match_from_scratch_assembly(oracle, with_imu, weak_thr):
         for i in np.nonzero(tf["kf2_idx"] == t)[0]:
             l = int(tf["lm_idx"][i])
             win.add_observation(5000 + l, 100 + t, tf["ob"][i]); obs[t][l] = tf["ob"][i]
+        if t in (5, 8):      # an older frame loses a tracked feature (what the outlier gate does): its device-side feature segment is re-sent
+            k_old = t - 2
+            cand = [l for l in sorted(obs[k_old]) if birth[l] != k_old]
+            if cand:
+                win.remove_observation(5000 + cand[len(cand) // 2], 100 + k_old); del obs[k_old][cand[len(cand) // 2]]
         first = max(0, t - W + 1)
         win.slide(100 + first)
         for k in [k for k in pose if k < first and k not in departed]:
