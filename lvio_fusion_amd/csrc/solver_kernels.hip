@@ -1960,6 +1960,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //     block (wave-wide when a wave holds one block's rows, LDS atomics otherwise), one thread per (block, component) applies
 //     L_bb^-1.  The solution leaves in the natural unknown order through `perm`.
 // (S and Dinv are deliberately NOT __restrict__/invariant: LLVM would sink the prefetch loads past the barriers to their uses.)
+template <typename T>
+__device__ __forceinline__ T ld_off32(const T* base, unsigned byte_off) {     // wave-uniform base + 32-bit lane offset (saddr + voffset form)
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 constexpr int kBT = 512, kBParts = kBT / 64, kBackPre = 256 / kBParts, kBackInv = 64 / kBParts, kTailPre = 6;
 struct BackArgs { const double* Sd; int ld, d; const double* Dinv; double* xout; SpBack sp; const int* done; };
 __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
@@ -1982,17 +1986,26 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
   // ---- dense corner
   const int rend = min(n, d);
   double gl[kBackPre], xi[kBackInv], yv;
+  // The kernel is ISSUE-bound (one workgroup, two waves per SIMD): every request below is a wave-uniform base (SALU) plus a 32-bit
+  // per-lane byte offset, i.e. one VMEM instruction and no VALU address arithmetic, and the row tests are scalar branches -- with
+  // 64-bit per-lane addresses and per-lane predicates issuing one block's 41 requests took 1.2-1.8 us of its 2.3-3.4.
+  const int part_u = __builtin_amdgcn_readfirstlane(part);
+  const unsigned c_off = 8u * (unsigned)c;
+  // (no row tests either: k_prepare writes every entry of the padded corner, rows d.. meet x = 0, so the 8-row groups of the
+  // 64 (nblk-1-kb) rows below a block are requested and multiplied whole)
   auto prefetch = [&](int kb) {
-    const int r0 = kb * kNB;
+    const int r0 = kb * kNB, below = nblk - 1 - kb;
+    const double* row = S + (size_t)(r0 + kNB + part_u) * ld + r0;
 #pragma unroll
-    for (int u = 0; u < kBackPre; ++u) {
-      const int r = r0 + kNB + part + kBParts * u;
-      gl[u] = (r < rend) ? S[(size_t)r * ld + r0 + c] : 0.0;
-    }
-    const double* dv = Dinv + (size_t)kb * kNB * kNB + (size_t)c * kNB + kBackInv * part;
+    for (int g = 0; g < kBackPre / 8; ++g)
+      if (g < below) {
 #pragma unroll
-    for (int t = 0; t < kBackInv; ++t) xi[t] = dv[t];
-    yv = (r0 + c < d) ? S[(size_t)d * ld + r0 + c] : 0.0;
+        for (int j = 0; j < 8; ++j) gl[8 * g + j] = ld_off32(row + (size_t)(kBParts * (8 * g + j)) * ld, c_off);
+      }
+    const double* dv = Dinv + (size_t)kb * kNB * kNB + kBackInv * part_u;
+#pragma unroll
+    for (int t = 0; t < kBackInv; ++t) xi[t] = ld_off32(dv + t, (unsigned)kNB * c_off);
+    yv = (r0 + c < d) ? ld_off32(S + (size_t)d * ld + r0, c_off) : 0.0;
   };
   prefetch(nblk - 1);
   if (sp.linv_in_lds) for (int i = tid; i < 81 * sp.n_nodes; i += kBT) linv[i] = sp.Linv[i];
@@ -2006,10 +2019,15 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
   for (int u = 0; u < kTailPre; ++u) {
     const int g = tid + kBT * u;
     const bool ok = g < sp.total_items;
-    tR[u] = ok ? sp.rows[g] : -1;
-    tK[u] = ok ? sp.owner[g] : 0;
+    tR[u] = -1; tK[u] = 0;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) tW[u][q] = ok ? sp.W[(size_t)q * sp.total_items + g] : 0.0;
+    for (int q = 0; q < 9; ++q) tW[u][q] = 0.0;
+    if (ok) {
+      tR[u] = ld_off32(sp.rows, 4u * (unsigned)g);
+      tK[u] = ld_off32(sp.owner, 4u * (unsigned)g);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) tW[u][q] = ld_off32(sp.W, 8u * ((unsigned)q * (unsigned)sp.total_items + (unsigned)g));
+    }
   }
   if (dv) return;                          // (every request above is in flight behind the flag's)
   for (int i = tid; i < sp.off + n; i += kBT) sm[i] = 0.0;
@@ -2019,7 +2037,11 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
     const int r0 = kb * kNB;
     double s = 0.0;
 #pragma unroll
-    for (int u = 0; u < kBackPre; ++u) s += gl[u] * x[min(r0 + kNB + part + kBParts * u, n - 1)];      // gl is 0 beyond the matrix
+    for (int g = 0; g < kBackPre / 8; ++g)
+      if (g < nblk - 1 - kb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += gl[8 * g + j] * x[r0 + kNB + part_u + kBParts * (8 * g + j)];
+      }
     for (int r = r0 + kNB + part + kBParts * kBackPre; r < rend; r += kBParts) s += S[(size_t)r * ld + r0 + c] * x[r];
     partial[part * kNB + c] = s;
     double xc[kBackInv];
