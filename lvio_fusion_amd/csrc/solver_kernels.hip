@@ -359,12 +359,18 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
     const int lane = threadIdx.x & 63;
     unsigned long long remaining = __ballot(active);
     bool mine_done = !active;
+    // a wave with at most four first keyframes (creation-order ids: one or two long runs and a short one at a boundary) is reduced
+    // group by group whatever the group sizes: a 10-lane group left to the atomics serialises 10-fold on each of its 63 addresses
+    int n_groups = 0;
+    for (unsigned long long rem = remaining; rem && n_groups < 5; ++n_groups)
+      rem &= ~__ballot(active && k1 == __builtin_amdgcn_readlane(k1, (int)__ffsll((long long)rem) - 1));
+    const int min_group = n_groups <= 4 ? 1 : 16;
 #pragma unroll 1
     for (int round = 0; round < 4 && remaining; ++round) {
       const int k1u = __builtin_amdgcn_readlane(k1, (int)__ffsll((long long)remaining) - 1);
       const bool sel = active && !mine_done && k1 == k1u;
       const unsigned long long m = __ballot(sel);
-      if (__popcll(m) < 16) break;
+      if (__popcll(m) < min_group) break;
       double* accu = s_acc + k1u * kAccSlots;
       // the group's lanes keep their first-keyframe Jacobian, everyone else contributes zeros; the scale is opaque to the compiler so
       // that the 63 products are formed inside this loop (hoisted out of it as loop invariants they cost 126 registers)

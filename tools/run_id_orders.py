@@ -10,3 +10,6 @@ for ids in (False, True):
     for r in range(3):
         bench.reset_state(api, h[4], cfg); ctx.synchronize(); t0 = time.perf_counter(); s = prob.solve(opt); dt = time.perf_counter() - t0
     print("ids_by_birth", ids, "%.4f ms/iteration" % (1e3 * dt / s.num_iterations))
+    if os.environ.get("LVF_STAGES"):
+        bench.reset_state(api, h[4], cfg)
+        print("  stages (us):", " ".join("%s=%.1f" % (n, us) for n, us, _ in prob.stage_times(opt, reps=10)))
