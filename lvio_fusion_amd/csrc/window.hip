@@ -84,6 +84,7 @@ struct lvf_window {
   lvf::DevBuf<int> d_wgcnt, d_wgbase, d_slot, d_slot_lm, d_counts;
   lvf::DevBuf<double> d_lm_invd_out;
   lvf::HostPin<int> h_counts;
+  hipEvent_t ev_counts = nullptr;                        // recorded behind the counters' copy: the host waits for it, not for the work queued after it
   std::vector<lvf::LmHot> hot;                           // per-tick compact copy of what the feature walk reads of a landmark
   lvf::HostPin<unsigned char> h_stage;                   // the tick's packed upload (records + plain segments)
   lvf::DevBuf<unsigned char> d_stage;
@@ -96,6 +97,7 @@ struct lvf_window {
     for (lvf_batch* b : {tc, tf, po, imu, prior, rej}) if (b) lvf_batch_destroy(b);
     if (st) lvf_state_destroy(st);
     if (rej_st) lvf_state_destroy(rej_st);
+    if (ev_counts) (void)hipEventDestroy(ev_counts);
   }
 };
 
@@ -293,46 +295,66 @@ __global__ __launch_bounds__(256) void k_da_classify(DaArgs a) {
   }
 }
 __global__ __launch_bounds__(1024) void k_da_scan(DaArgs a) {
-  __shared__ int s_a[1024], s_b[1024], s_c[1024];
-  const int tid = threadIdx.x;
-  // (1) exclusive scan of the per-workgroup block counts, per type (n_wg <= a few hundred: chunks of 1024 with a running carry)
-  int carry[3] = {0, 0, 0};
-  for (int base = 0; base < a.n_wg; base += 1024) {
-    const int i = base + tid;
-    int v[3] = {0, 0, 0};
-    if (i < a.n_wg) { v[0] = a.wgcnt[3 * i]; v[1] = a.wgcnt[3 * i + 1]; v[2] = a.wgcnt[3 * i + 2]; }
-    s_a[tid] = v[0]; s_b[tid] = v[1]; s_c[tid] = v[2];
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      const int xa = tid >= o ? s_a[tid - o] : 0, xb = tid >= o ? s_b[tid - o] : 0, xc = tid >= o ? s_c[tid - o] : 0;
-      __syncthreads();
-      s_a[tid] += xa; s_b[tid] += xb; s_c[tid] += xc;
-      __syncthreads();
+  // One workgroup, two barriers per 32 k landmarks: the scans run inside waves (shuffles), a Hillis-Steele scan of 1024 LDS entries
+  // (20 workgroup barriers each, 16 waves) and a per-thread walk over runs of 64-byte landmark records made this launch 35 us.
+  constexpr int kChunks = 32;                       // chunks of 1024 landmarks per pass
+  __shared__ int s_cnt[kChunks * 16];               // used landmarks per (chunk, wave), then their exclusive prefix
+  __shared__ int s_total;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // (1) exclusive scan of the per-workgroup block counts: wave t takes type t, 64 workgroups at a time with a running carry
+  if (wv < 3) {
+    int carry = 0;
+    for (int base = 0; base < a.n_wg; base += 64) {
+      const int i = base + lane;
+      const int v = i < a.n_wg ? a.wgcnt[3 * i + wv] : 0;
+      int inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+      if (i < a.n_wg) a.wgbase[3 * i + wv] = carry + inc - v;
+      carry += __shfl(inc, 63);
     }
-    if (i < a.n_wg) { a.wgbase[3 * i] = carry[0] + s_a[tid] - v[0]; a.wgbase[3 * i + 1] = carry[1] + s_b[tid] - v[1]; a.wgbase[3 * i + 2] = carry[2] + s_c[tid] - v[2]; }
-    carry[0] += s_a[1023]; carry[1] += s_b[1023]; carry[2] += s_c[1023];
+    if (lane == 0) a.counts[wv] = carry;
+  }
+  // (2) dense landmark slots in ascending landmark index (thread = landmark: coalesced; rank = ballot prefix + wave prefix + chunk prefix)
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  int total = 0;
+  for (int sb = 0; sb < a.nl; sb += kChunks * 1024) {
+    const int nch = min(kChunks, (a.nl - sb + 1023) / 1024);
+    for (int c = 0; c < nch; ++c) {
+      const int l = sb + c * 1024 + tid;
+      const unsigned long long m = __ballot(l < a.nl && a.used[l]);
+      if (lane == 0) s_cnt[c * 16 + wv] = __popcll(m);
+    }
+    __syncthreads();
+    if (wv == 0) {
+      int carry = 0;
+      for (int base = 0; base < nch * 16; base += 64) {
+        const int i = base + lane;
+        const int v = i < nch * 16 ? s_cnt[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
+        if (i < nch * 16) s_cnt[i] = carry + inc - v;
+        carry += __shfl(inc, 63);
+      }
+      if (lane == 0) s_total = carry;
+    }
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      const int l = sb + c * 1024 + tid;
+      const bool in = l < a.nl, u = in && a.used[l];
+      const unsigned long long m = __ballot(u);
+      if (in) {
+        const double invd = a.lm[l].inv_depth;
+        a.lm_invd_out[l] = invd;
+        if (u) { const int at = total + s_cnt[c * 16 + wv] + __popcll(m & below); a.slot[l] = at; a.slot_lm[at] = l; a.state_invd[at] = invd; }
+        else a.slot[l] = -1;
+      }
+    }
+    total += s_total;
     __syncthreads();
   }
-  if (tid == 0) { a.counts[0] = carry[0]; a.counts[1] = carry[1]; a.counts[2] = carry[2]; }
-  // (2) dense landmark slots in ascending landmark index: every thread owns a run of consecutive landmarks
-  const int per = (a.nl + 1023) / 1024, l0 = min(a.nl, tid * per), l1 = min(a.nl, l0 + per);
-  int mine = 0;
-  for (int l = l0; l < l1; ++l) mine += a.used[l] ? 1 : 0;
-  s_a[tid] = mine;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int x = tid >= o ? s_a[tid - o] : 0;
-    __syncthreads();
-    s_a[tid] += x;
-    __syncthreads();
-  }
-  int at = s_a[tid] - mine;
-  for (int l = l0; l < l1; ++l) {
-    const double invd = a.lm[l].inv_depth;
-    a.lm_invd_out[l] = invd;
-    if (a.used[l]) { a.slot[l] = at; a.slot_lm[at] = l; a.state_invd[at] = invd; ++at; } else a.slot[l] = -1;
-  }
-  if (tid == 1023) a.counts[3] = s_a[1023];
+  if (tid == 0) a.counts[3] = total;
 }
 __global__ __launch_bounds__(256) void k_da_emit(DaArgs a) {
   __shared__ int s_start[kDaMaxKf + 1];
@@ -416,6 +438,7 @@ struct UnpackArgs {
   double2* po_o; double* po_pw; int32_t *po_kf, *po_pi;
   int n_segs; unsigned char* seg_dst[kMaxSegs]; size_t seg_off[kMaxSegs]; unsigned seg_words[kMaxSegs];   // 16-byte words (sizes are padded up)
   int g_tc, g_tf, g_po, g_seg;
+  unsigned char* zero_dst[2]; unsigned zero_words[2];      // buffers cleared by the same launch (16-byte words)
 };
 __global__ __launch_bounds__(256) void k_window_unpack(UnpackArgs a) {
   int b = blockIdx.x;
@@ -451,6 +474,11 @@ __global__ __launch_bounds__(256) void k_window_unpack(UnpackArgs a) {
     const uint4* src = reinterpret_cast<const uint4*>(a.stage + a.seg_off[k]);
     uint4* dst = reinterpret_cast<uint4*>(a.seg_dst[k]);
     for (unsigned i = (unsigned)b * 256 + t; i < a.seg_words[k]; i += (unsigned)a.g_seg * 256) dst[i] = src[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    uint4* dst = reinterpret_cast<uint4*>(a.zero_dst[k]);
+    for (unsigned i = (unsigned)b * 256 + t; i < a.zero_words[k]; i += (unsigned)a.g_seg * 256) dst[i] = make_uint4(0, 0, 0, 0);
   }
 }
 
@@ -649,8 +677,9 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
   // ---- staging: frame table | landmark table | state | dirty feature segments (one copy, one unpack launch)
   size_t dirty_obs = 0; int dirty_frames = 0;
   for (const lvf_window::Kf& f : w->kfs) if (f.d_dirty) { dirty_obs += f.obs.size(); ++dirty_frames; }
-  const bool direct_segments = 2 * dirty_frames + 12 > kMaxSegs;      // (a full re-layout of a long window: copy those segments one by one)
-  const size_t stage_bound = up16((size_t)n_kf * sizeof(FrameDev)) + up16(nl * sizeof(LmDev)) + up16((size_t)17 * n_kf * 8) + 8 * 64 + dirty_obs * 24 + (size_t)dirty_frames * 64 + 4096;
+  const bool direct_segments = 2 * dirty_frames + 16 > kMaxSegs;      // (a full re-layout of a long window: copy those segments one by one)
+  const size_t stage_bound = up16((size_t)n_kf * sizeof(FrameDev)) + up16(nl * sizeof(LmDev)) + up16((size_t)17 * n_kf * 8) + 8 * 64 + dirty_obs * 24 + (size_t)dirty_frames * 64 + 4096 +
+                             up16((size_t)n_kf * 467 * 8) + (size_t)n_kf * 16 + 64;
   LVF_TRY(w->h_stage.reserve(stage_bound));
   LVF_TRY(w->d_stage.ensure(stage_bound));
   unsigned char* hs = w->h_stage.p;
@@ -715,6 +744,28 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
       std::memcpy(&sg[(size_t)3 * k], f.bg, 24); sw[k] = f.w_visual;
     }
   }
+  // ImuError blocks (backend.cpp:141-153: both frames good, a pre-integration on the later one) do not depend on the assembly: their
+  // pre-integrations ride in this upload and their information matrices are factored while the host waits for the assembly's counters
+  std::vector<int32_t> imu_i, imu_j;
+  {
+    for (int k = 1; k < n_kf; ++k)
+      if (w->kfs[k].good_imu && w->kfs[k - 1].good_imu && w->kfs[k].has_pre) { imu_i.push_back(k - 1); imu_j.push_back(k); }
+    lvf_batch* b = w->imu;
+    const size_t ni = imu_i.size();
+    LVF_TRY(b->pre.ensure(467 * ni + 2)); LVF_TRY(b->idx_a.ensure(ni + 4)); LVF_TRY(b->idx_b.ensure(ni + 4));
+    b->pre.n = 467 * ni; b->idx_a.n = b->idx_b.n = ni;
+    if (ni) {
+      static_assert(sizeof(lvf_preint) == 467 * 8, "lvf_preint is 467 doubles");
+      lvf_preint* dst = reinterpret_cast<lvf_preint*>(seg(b->pre.p, 467 * ni * 8));
+      for (size_t f = 0; f < ni; ++f) dst[f] = w->kfs[imu_j[f]].pre;
+      std::memcpy(seg(b->idx_a.p, ni * 4), imu_i.data(), ni * 4); std::memcpy(seg(b->idx_b.p, ni * 4), imu_j.data(), ni * 4);
+    }
+    b->host_kf1 = imu_i; b->host_kf2 = imu_j;
+    LVF_TRY(b->sqrt_info.ensure((size_t)225 * ni)); LVF_TRY(b->res.ensure((size_t)15 * ni));
+    for (int q = 0; q < 8; ++q) LVF_TRY(b->jac[q].ensure((size_t)15 * b->block_size[q] * ni));
+    b->n = (int)ni; b->min_n_kf = n_kf; b->min_n_lm = 0; b->evaluated = false;
+    w->n_imu = (int)ni;
+  }
   // dirty feature segments
   for (lvf_window::Kf& f : w->kfs) {
     if (!f.d_dirty) continue;
@@ -734,13 +785,18 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
     f.d_dirty = false;
   }
   LVF_REQUIRE(cur <= w->h_stage.cap && ua.n_segs <= kMaxSegs, "lvf_window_solve: staging overflow");
+  const auto t_staged = now();
   LVF_HIP(hipMemcpyAsync(w->d_stage.p, hs, cur, hipMemcpyHostToDevice, s));
   ua.stage = w->d_stage.p; ua.g_seg = 64;
+  // (the assembly's `used` flags and counters are cleared by the unpack launch: two fill launches less)
+  LVF_TRY(w->d_used.ensure(nl + 32)); LVF_TRY(w->d_counts.ensure(4 + 2 * kDaMaxKf));
+  ua.zero_dst[0] = w->d_used.p; ua.zero_words[0] = (unsigned)((nl + 16 + 15) / 16);
+  ua.zero_dst[1] = reinterpret_cast<unsigned char*>(w->d_counts.p); ua.zero_words[1] = (unsigned)(((4 + 2 * kDaMaxKf) * sizeof(int) + 15) / 16);
   hipLaunchKernelGGL(k_window_unpack, dim3(ua.g_seg), dim3(256), 0, s, ua);
   // ---- assembly kernels
   const int n_wg = (int)((n_obs + 255) / 256);
-  LVF_TRY(w->d_cls.ensure(n_obs + 16)); LVF_TRY(w->d_used.ensure(nl + 16)); LVF_TRY(w->d_wgcnt.ensure((size_t)3 * n_wg + 4)); LVF_TRY(w->d_wgbase.ensure((size_t)3 * n_wg + 4));
-  LVF_TRY(w->d_slot.ensure(nl + 4)); LVF_TRY(w->d_slot_lm.ensure(nl + 4)); LVF_TRY(w->d_counts.ensure(4 + 2 * kDaMaxKf)); LVF_TRY(w->d_lm_invd_out.ensure(nl + 4));
+  LVF_TRY(w->d_cls.ensure(n_obs + 16)); LVF_TRY(w->d_wgcnt.ensure((size_t)3 * n_wg + 4)); LVF_TRY(w->d_wgbase.ensure((size_t)3 * n_wg + 4));
+  LVF_TRY(w->d_slot.ensure(nl + 4)); LVF_TRY(w->d_slot_lm.ensure(nl + 4)); LVF_TRY(w->d_lm_invd_out.ensure(nl + 4));
   LVF_TRY(w->h_counts.reserve(4 + 2 * kDaMaxKf));
   LVF_TRY(w->tc->ob_a.ensure(2 * std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->ob_b.ensure(2 * std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->idx_a.ensure(std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->idx_b.ensure(std::min(n_obs, nl) + 2));
   LVF_TRY(w->tf->ob_a.ensure(2 * n_obs + 2)); LVF_TRY(w->tf->ob_b.ensure(2 * n_obs + 2)); LVF_TRY(w->tf->idx_a.ensure(n_obs + 2)); LVF_TRY(w->tf->idx_b.ensure(n_obs + 2)); LVF_TRY(w->tf->idx_c.ensure(n_obs + 2));
@@ -756,39 +812,39 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
   da.tc_l = reinterpret_cast<double2*>(w->tc->ob_a.p); da.tc_r = reinterpret_cast<double2*>(w->tc->ob_b.p); da.tc_lm = w->tc->idx_a.p; da.tc_kf = w->tc->idx_b.p;
   da.tf_f = reinterpret_cast<double2*>(w->tf->ob_a.p); da.tf_o = reinterpret_cast<double2*>(w->tf->ob_b.p); da.tf_lm = w->tf->idx_a.p; da.tf_k1 = w->tf->idx_b.p; da.tf_k2 = w->tf->idx_c.p;
   da.po_o = reinterpret_cast<double2*>(w->po->ob_a.p); da.po_pw = w->po->table.p; da.po_kf = w->po->idx_a.p; da.po_pi = w->po->idx_b.p;
-  LVF_HIP(hipMemsetAsync(w->d_used.p, 0, nl + 16, s));
-  LVF_HIP(hipMemsetAsync(w->d_counts.p, 0, (4 + 2 * kDaMaxKf) * sizeof(int), s));
   if (n_wg) hipLaunchKernelGGL(k_da_classify, dim3(n_wg), dim3(256), 0, s, da);
   hipLaunchKernelGGL(k_da_scan, dim3(1), dim3(1024), 0, s, da);
   if (n_wg) hipLaunchKernelGGL(k_da_emit, dim3(n_wg), dim3(256), 0, s, da);
   LVF_HIP(hipGetLastError());
   LVF_HIP(hipMemcpyAsync(w->h_counts.p, w->d_counts.p, (4 + 2 * kDaMaxKf) * sizeof(int), hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipStreamSynchronize(s));
+  if (!w->ev_counts) LVF_HIP(hipEventCreateWithFlags(&w->ev_counts, hipEventDisableTiming));
+  LVF_HIP(hipEventRecord(w->ev_counts, s));
+  if (w->n_imu) LVF_TRY(launch_imu_sqrt_info(w->imu));          // runs while the host reads the counters and configures the problem
+  LVF_HIP(hipEventSynchronize(w->ev_counts));
   const int* hc = w->h_counts.p;
   const size_t ntc = (size_t)hc[0], ntf = (size_t)hc[1], npo = (size_t)hc[2];
   const int n_lm = hc[3];
   const auto t_assembled = now();
-  // ---- the per-frame factors: IMU block or weak-constraint prior (at most one each), from the counters
+  // ---- weak-constraint priors (backend.cpp:164-178): frames without an ImuError block whose near-feature count is below the threshold
   std::vector<double> pr_t, pr_w, pr_v;
-  std::vector<int32_t> imu_i, imu_j, pr_a, pr_b, kf2_counts(n_kf, 0);
-  std::vector<lvf_preint> imu_pre;
-  for (int k = 0; k < n_kf; ++k) {
-    lvf_window::Kf& f = w->kfs[k];
-    kf2_counts[k] = hc[4 + k];
-    bool imu_block = false;
-    if (f.good_imu && k > 0 && w->kfs[k - 1].good_imu && f.has_pre) {
-      imu_pre.push_back(f.pre); imu_i.push_back(k - 1); imu_j.push_back(k);
-      imu_block = true;
-    }
-    if (!imu_block && hc[4 + kDaMaxKf + k] < w->opt.weak_visual_threshold) {
-      double t7[7] = {0, 0, 0, 0, 0, 0, 0};
-      if (k > 0) { LVF_TRY(lvf_relative_rpyxyz(w->kfs[k - 1].pose, f.pose, t7)); pr_a.push_back(k - 1); }
-      else { std::memcpy(t7, f.pose, 56); pr_a.push_back(-1); }
-      pr_b.push_back(k); pr_t.insert(pr_t.end(), t7, t7 + 7); pr_w.push_back(w->opt.prior_weight); pr_v.push_back(w->opt.prior_v);
+  std::vector<int32_t> pr_a, pr_b, kf2_counts(n_kf, 0);
+  {
+    size_t fi = 0;                                   // imu_j is ascending
+    for (int k = 0; k < n_kf; ++k) {
+      lvf_window::Kf& f = w->kfs[k];
+      kf2_counts[k] = hc[4 + k];
+      const bool imu_block = fi < imu_j.size() && imu_j[fi] == k;
+      if (imu_block) ++fi;
+      if (!imu_block && hc[4 + kDaMaxKf + k] < w->opt.weak_visual_threshold) {
+        double t7[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (k > 0) { LVF_TRY(lvf_relative_rpyxyz(w->kfs[k - 1].pose, f.pose, t7)); pr_a.push_back(k - 1); }
+        else { std::memcpy(t7, f.pose, 56); pr_a.push_back(-1); }
+        pr_b.push_back(k); pr_t.insert(pr_t.end(), t7, t7 + 7); pr_w.push_back(w->opt.prior_weight); pr_v.push_back(w->opt.prior_v);
+      }
     }
   }
   w->n_lm_problem = n_lm;
-  w->n_tc = (int)ntc; w->n_tf = (int)ntf; w->n_po = (int)npo; w->n_imu = (int)imu_i.size(); w->n_prior = (int)pr_b.size();
+  w->n_tc = (int)ntc; w->n_tf = (int)ntf; w->n_po = (int)npo; w->n_prior = (int)pr_b.size();
   st->n_lm = n_lm; st->inv_depth.n = n_lm;
   auto idx_ok = [](lvf_batch* b, int n, int nkf, int nlm) { b->n = n; b->min_n_kf = nkf; b->min_n_lm = nlm; b->evaluated = false; };
   w->tc->ob_a.n = w->tc->ob_b.n = 2 * ntc; w->tc->idx_a.n = w->tc->idx_b.n = ntc;
@@ -798,7 +854,7 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
   w->tf->sorted_by_kf = true; w->tf->host_kf1.clear(); w->tf->host_kf2.clear(); w->tf->host_lm.clear(); w->tf->unique_lk2_known = true; w->tf->kf2_counts = std::move(kf2_counts);
   w->po->ob_a.n = 2 * npo; w->po->idx_a.n = w->po->idx_b.n = npo; w->po->table.n = 3 * npo;
   idx_ok(w->po, w->n_po, n_kf, 0); w->po->n_table = w->n_po; w->po->sorted_by_kf = true;
-  // second (small) staged upload: IMU pre-integrations and indices, priors
+  // second (small) staged upload: the priors
   {
     UnpackArgs ub{};
     size_t at = 0;
@@ -808,21 +864,9 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
       at += up16(bytes);
       return pp;
     };
-    LVF_TRY(w->h_stage.reserve(up16((size_t)n_kf * 467 * 8) + 16 * 64 + (size_t)n_kf * 128 + 4096));      // (grow-only: the first copy above has completed)
+    LVF_TRY(w->h_stage.reserve(16 * 64 + (size_t)n_kf * 128 + 4096));      // (grow-only: the first copy above has completed)
     hs = w->h_stage.p;
-    lvf_batch* b = w->imu;
-    const size_t ni = (size_t)w->n_imu;
-    LVF_TRY(b->pre.ensure(467 * ni + 2)); LVF_TRY(b->idx_a.ensure(ni + 4)); LVF_TRY(b->idx_b.ensure(ni + 4));
-    b->pre.n = 467 * ni; b->idx_a.n = b->idx_b.n = ni;
-    if (ni) {
-      std::memcpy(seg2(b->pre.p, 467 * ni * 8), imu_pre.data(), 467 * ni * 8);
-      std::memcpy(seg2(b->idx_a.p, ni * 4), imu_i.data(), ni * 4); std::memcpy(seg2(b->idx_b.p, ni * 4), imu_j.data(), ni * 4);
-    }
-    b->host_kf1 = imu_i; b->host_kf2 = imu_j;
-    LVF_TRY(b->sqrt_info.ensure((size_t)225 * w->n_imu)); LVF_TRY(b->res.ensure((size_t)15 * w->n_imu));
-    for (int q = 0; q < 8; ++q) LVF_TRY(b->jac[q].ensure((size_t)15 * b->block_size[q] * w->n_imu));
-    idx_ok(b, w->n_imu, n_kf, 0);
-    b = w->prior;
+    lvf_batch* b = w->prior;
     const size_t np_ = (size_t)w->n_prior;
     LVF_TRY(b->idx_a.ensure(np_ + 4)); LVF_TRY(b->idx_b.ensure(np_ + 4)); LVF_TRY(b->table.ensure(7 * np_ + 2)); LVF_TRY(b->ob_a.ensure(np_ + 2)); LVF_TRY(b->ob_b.ensure(np_ + 2));
     b->idx_a.n = b->idx_b.n = np_; b->table.n = 7 * np_; b->ob_a.n = b->ob_b.n = np_;
@@ -837,12 +881,11 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
     if (ub.n_segs) {
       LVF_TRY(w->d_stage.ensure(at + 16));
       LVF_HIP(hipMemcpyAsync(w->d_stage.p, hs, at, hipMemcpyHostToDevice, s));
-      ub.stage = w->d_stage.p; ub.g_seg = 32;
+      ub.stage = w->d_stage.p; ub.g_seg = 8;
       hipLaunchKernelGGL(k_window_unpack, dim3(ub.g_seg), dim3(256), 0, s, ub);
       LVF_HIP(hipGetLastError());
     }
   }
-  if (w->n_imu) LVF_TRY(launch_imu_sqrt_info(w->imu));
   const auto t_uploaded = now();
   if (!w->prob) {
     LVF_TRY(lvf_problem_create(ctx, st, w->tc, w->tf, w->po, w->imu, &w->prob));
@@ -883,8 +926,8 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
   }
   w->slot_lm.clear();
   if (timing)
-    std::fprintf(stderr, "lvf_window_solve (device assembly): tables + assembly + counters %.3f ms, small uploads %.3f ms, configure %.3f ms, solve %.3f ms (%d its), read-back %.3f ms\n",
-                 ms(t_begin, t_assembled), ms(t_assembled, t_uploaded), ms(t_uploaded, t_configured), ms(t_configured, t_solved), summary->num_iterations, ms(t_solved, now()));
+    std::fprintf(stderr, "lvf_window_solve (device assembly): host tables %.3f ms (%zu bytes staged), upload + assembly + counters %.3f ms, small uploads %.3f ms, configure %.3f ms, solve %.3f ms (%d its), read-back %.3f ms\n",
+                 ms(t_begin, t_staged), cur, ms(t_staged, t_assembled), ms(t_assembled, t_uploaded), ms(t_uploaded, t_configured), ms(t_configured, t_solved), summary->num_iterations, ms(t_solved, now()));
   return LVF_OK;
 }
 
