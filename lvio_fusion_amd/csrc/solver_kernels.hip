@@ -1278,26 +1278,51 @@ __global__ __launch_bounds__(1024) void k_lm_sort(int n_lm, int n_kf, const int*
 // eoff[l] = first slot of landmark l, len_l = kmax_l - kmin_l slots (one per keyframe after the first); *n_slots = their total
 __global__ __launch_bounds__(1024) void k_lm_offsets(int n_lm, const int* __restrict__ kmin, const int* __restrict__ kmax, int* __restrict__ eoff,
                                                      int* __restrict__ n_slots) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
+  // scans inside waves, two workgroup barriers per 32 k landmarks (three barriers per 1024 made this launch 14 us at 10 k landmarks)
+  constexpr int kChunks = 32;
+  __shared__ int s_cnt[kChunks * 16];
+  __shared__ int s_total;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n_lm; base += 1024) {
-    const int l = base + tid;
-    const int c = (l < n_lm && kmax[l] >= 0) ? max(0, kmax[l] - kmin[l]) : 0;
+  auto scan_chunk = [&](int l, int& c) {              // inclusive prefix of the slot counts within this wave's 64 landmarks
+    c = (l < n_lm && kmax[l] >= 0) ? max(0, kmax[l] - kmin[l]) : 0;
     int incl = c;
+#pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (lane == 63) wsum[wave] = incl;
+    return incl;
+  };
+  int total = 0;
+  for (int sb = 0; sb < n_lm; sb += kChunks * 1024) {
+    const int nch = min(kChunks, (n_lm - sb + 1023) / 1024);
+    for (int ch = 0; ch < nch; ++ch) {
+      int c;
+      const int incl = scan_chunk(sb + ch * 1024 + tid, c);
+      if (lane == 63) s_cnt[ch * 16 + wave] = incl;
+    }
     __syncthreads();
-    int off = carry;
-    for (int w = 0; w < wave; ++w) off += wsum[w];
-    if (l < n_lm) eoff[l] = off + incl - c;
+    if (wave == 0) {
+      int carry = 0;
+      for (int base = 0; base < nch * 16; base += 64) {
+        const int i = base + lane;
+        const int v = i < nch * 16 ? s_cnt[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (i < nch * 16) s_cnt[i] = carry + inc - v;
+        carry += __shfl(inc, 63);
+      }
+      if (lane == 0) s_total = carry;
+    }
     __syncthreads();
-    if (tid == 1023) carry = off + incl;
+    for (int ch = 0; ch < nch; ++ch) {
+      const int l = sb + ch * 1024 + tid;
+      int c;
+      const int incl = scan_chunk(l, c);
+      if (l < n_lm) eoff[l] = total + s_cnt[ch * 16 + wave] + incl - c;
+    }
+    total += s_total;
     __syncthreads();
   }
-  if (tid == 0) *n_slots = carry;
+  if (tid == 0) *n_slots = total;
 }
 __global__ __launch_bounds__(kT) void k_tf_slots(int n, const int* __restrict__ lm, const int* __restrict__ k2, const int* __restrict__ kmin,
                                                  const int* __restrict__ eoff, int* __restrict__ slot) {
@@ -3105,7 +3130,7 @@ int problem_configure(lvf_problem* p) {
   LVF_TRY(p->poses2.ensure(std::max(st->poses.cap, (size_t)7 * p->n_kf))); LVF_TRY(p->vel2.ensure(std::max(st->vel.cap, (size_t)3 * p->n_kf)));
   LVF_TRY(p->ba2.ensure(std::max(st->ba.cap, (size_t)3 * p->n_kf))); LVF_TRY(p->bg2.ensure(std::max(st->bg.cap, (size_t)3 * p->n_kf)));
   LVF_TRY(p->invd2.ensure(std::max(st->inv_depth.cap, (size_t)p->n_lm)));
-  LVF_TRY(p->pose_const.ensure(p->n_kf)); LVF_TRY(p->fail.ensure(1));
+  LVF_TRY(p->pose_const.ensure((size_t)p->n_kf + 8)); LVF_TRY(p->fail.ensure(1));      // (+8: cleared in 8-byte words)
   p->pose_const_h.assign(p->n_kf, 0);
   p->tf_work.n = 0;
   p->tf_unique_lk2 = false; p->tf_k1_first = false; p->compact = false;
@@ -3213,9 +3238,14 @@ int problem_configure(lvf_problem* p) {
   }
   LVF_TRY(p->E.ensure((size_t)p->n_lm * p->ldE));
   // atomic-free mode: E's non-zero pattern is fixed for the problem and fully overwritten by every linearisation — cleared once, here
-  if (p->compact && p->n_lm) LVF_HIP(hipMemsetAsync(p->E.p, 0, (size_t)p->n_lm * p->ldE * sizeof(double), ctx->stream));
-  LVF_HIP(hipMemsetAsync(p->pose_const.p, 0, p->n_kf, ctx->stream));
-  LVF_HIP(hipMemsetAsync(p->dxc.p, 0, (size_t)p->dpad * 8, ctx->stream));
+  {
+    ZeroList z{};                    // one launch for the three clears (a persistent window reconfigures every tick)
+    if (p->compact && p->n_lm) { z.p[z.count] = p->E.p; z.n[z.count] = (unsigned long long)p->n_lm * p->ldE; ++z.count; }
+    z.p[z.count] = reinterpret_cast<double*>(p->pose_const.p); z.n[z.count] = (unsigned long long)(p->n_kf + 7) / 8; ++z.count;      // (the buffer's capacity is padded)
+    z.p[z.count] = p->dxc.p; z.n[z.count] = (unsigned long long)p->dpad; ++z.count;
+    hipLaunchKernelGGL(k_zero_multi, dim3(512, z.count), dim3(kT), 0, ctx->stream, z);
+    LVF_HIP(hipGetLastError());
+  }
   // no stream wait here: every host source above is pinned and owned by the problem (or was waited for by the plan builder)
   p->linearized = false;
   p->chain_ready = false;
