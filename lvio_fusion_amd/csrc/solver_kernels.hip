@@ -2663,7 +2663,9 @@ static int build_chain(lvf_problem* p) {
   c.back.done = done;
   {
     TailArgs& a = c.tail;
-    a.g_lm = p->n_lm ? std::min(256, (p->n_lm + kT / 16 - 1) / (kT / 16)) : 0;
+    // (640 workgroups take the 10 000 landmarks of the BASELINE window in one pass of 16 per workgroup; measured 1-2 % of an iteration over a cap of 256)
+    static const int tail_cap = [] { const char* e = std::getenv("LVF_TAIL_WGS"); return e ? std::atoi(e) : 640; }();
+    a.g_lm = p->n_lm ? std::min(tail_cap, (p->n_lm + kT / 16 - 1) / (kT / 16)) : 0;
     a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.C = p->compact ? p->Ct.p : p->C.p; a.Cd = p->Cd.p;
     a.gr = p->compact ? p->grt.p : p->gr.p; a.dxc = p->dxc.p; a.dxl = p->dxl.p; a.scal = p->scal.p;
     a.kmin = p->band_ready ? p->lm_kmin.p : nullptr; a.kmax = p->lm_kmax.p; a.n_kf = p->n_kf; a.s = s; a.poses2 = p->poses2.p; a.vel2 = p->vel2.p; a.ba2 = p->ba2.p;
