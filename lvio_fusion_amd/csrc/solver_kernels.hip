@@ -2282,14 +2282,16 @@ struct DecideArgs {
   int n_kf, n_lm;
   double *poses, *vel, *ba, *bg, *invd;                 // the state
   const double *poses2, *vel2, *ba2, *bg2, *invd2;      // the candidate
+  unsigned long long* dbg;                              // LVF_COST_TIMING=1: wall_clock64() stamps (100 MHz), else null
 };
 constexpr int kDT = 256;
 // COHERENT: the sums are read past the caches (the caller is the last workgroup of the launch that produced part of them)
 template <bool COHERENT = false>
 __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
-  __shared__ int s_commit, s_skip;
+  __shared__ int s_commit, s_skip, s_iter, s_done;
   __shared__ double s_sum[8];
   LmCtl* c = A.ctl;
+  if (A.dbg && threadIdx.x == 0) A.dbg[1] = wall_clock64();
   if (threadIdx.x == 0) s_skip = c->done;
   // the six striped sums: wave w adds the 32 stripes of slots w, w + 4 (lanes 32..63 contribute zero)
   {
@@ -2302,64 +2304,88 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
   }
   __syncthreads();
   if (s_skip) return;
+  if (A.dbg && threadIdx.x == 0) A.dbg[2] = wall_clock64();
   if (threadIdx.x < kStripes) const_cast<double*>(A.scal)[SC_COST + threadIdx.x] = 0.0;      // read above; the next linearisation adds into it
   if (threadIdx.x == 0) {
+    // the fields of the control block are read up front (independent requests, one wait) and written back once at the end: read and
+    // written where the logic uses them they were 1.2 us of dependent traffic.  (A whole-struct copy goes through a scratch segment.)
+    struct { double radius, decrease, last_radius, cost, initial_cost, cost_before, cost_after, model, dxnorm, xnorm, gmax;
+             double function_tol, gradient_tol, parameter_tol, min_rel_decrease; int max_iters, iter, successes, invalid_run, accepted, solved, done, termination; } lc;
+    lc.radius = c->radius; lc.decrease = c->decrease; lc.cost = c->cost; lc.initial_cost = c->initial_cost;
+    lc.function_tol = c->function_tol; lc.gradient_tol = c->gradient_tol; lc.parameter_tol = c->parameter_tol; lc.min_rel_decrease = c->min_rel_decrease;
+    lc.max_iters = c->max_iters; lc.iter = c->iter; lc.successes = c->successes; lc.invalid_run = c->invalid_run; lc.done = c->done; lc.termination = c->termination;
     const int hfail = *reinterpret_cast<const int*>(A.scal + SC_FAIL);
     const double cost_before = s_sum[SC_COST / kStripes], cost_new = s_sum[SC_COST_NEW / kStripes], model = -s_sum[SC_MODEL / kStripes];
     const double dxnorm = sqrt(s_sum[SC_DXNORM / kStripes]), xnorm = sqrt(s_sum[SC_XNORM / kStripes]);
     const double gmax = A.scal[SC_GMAX];                       // a max, kept in stripe 0 (the stored bit pattern is the double's)
     const bool solved = hfail == 0 && isfinite(cost_new) && isfinite(model);
-    const int it = c->iter;
-    if (it == 0) { c->initial_cost = cost_before; c->cost = cost_before; }
-    c->cost_before = cost_before; c->model = model; c->dxnorm = dxnorm; c->xnorm = xnorm; c->gmax = gmax; c->solved = solved ? 1 : 0;
-    c->last_radius = c->radius;
-    c->iter = it + 1;
+    const int it = lc.iter;
+    if (it == 0) { lc.initial_cost = cost_before; lc.cost = cost_before; }
+    lc.cost_before = cost_before; lc.model = model; lc.dxnorm = dxnorm; lc.xnorm = xnorm; lc.gmax = gmax; lc.solved = solved ? 1 : 0;
+    lc.last_radius = lc.radius;
+    lc.iter = it + 1;
     bool accepted = false, done = false;
     int termination = 1;
     // gradient tolerance: tested on the gradient at the point this iteration started from, before its step is taken
-    if (gmax <= c->gradient_tol) { done = true; termination = 0; }
+    if (gmax <= lc.gradient_tol) { done = true; termination = 0; }
     // parameter tolerance: a step this small ends the solve without being taken
-    else if (solved && dxnorm <= c->parameter_tol * (xnorm + c->parameter_tol)) { done = true; termination = 0; }
+    else if (solved && dxnorm <= lc.parameter_tol * (xnorm + lc.parameter_tol)) { done = true; termination = 0; }
     else {
       if (solved && model > 0.0) {
         const double rho = (cost_before - cost_new) / model;
-        if (rho > c->min_rel_decrease) {
+        if (rho > lc.min_rel_decrease) {
           accepted = true;
           const double t = 2.0 * rho - 1.0;
-          c->radius = fmin(c->radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
-          c->decrease = 2.0;
-          c->successes += 1;
-          const double change = c->cost - cost_new;
-          c->cost = cost_new;
-          if (fabs(change) <= c->function_tol * fabs(cost_before)) { done = true; termination = 0; }
+          lc.radius = fmin(lc.radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
+          lc.decrease = 2.0;
+          lc.successes += 1;
+          const double change = lc.cost - cost_new;
+          lc.cost = cost_new;
+          if (fabs(change) <= lc.function_tol * fabs(cost_before)) { done = true; termination = 0; }
         }
       }
       if (!accepted) {
-        c->radius = c->radius / c->decrease;
-        c->decrease *= 2.0;
-        c->invalid_run = solved ? 0 : c->invalid_run + 1;
-        if (!solved && (c->radius < 1e-32 || c->invalid_run >= 5)) { done = true; termination = 2; }      // max_num_consecutive_invalid_steps
-      } else c->invalid_run = 0;
+        lc.radius = lc.radius / lc.decrease;
+        lc.decrease *= 2.0;
+        lc.invalid_run = solved ? 0 : lc.invalid_run + 1;
+        if (!solved && (lc.radius < 1e-32 || lc.invalid_run >= 5)) { done = true; termination = 2; }      // max_num_consecutive_invalid_steps
+      } else lc.invalid_run = 0;
     }
-    c->cost_after = accepted ? cost_new : (solved ? cost_new : cost_before);
-    c->accepted = accepted ? 1 : 0;
-    if (!done && c->iter >= c->max_iters) done = true;          // termination stays NO_CONVERGENCE
-    if (done) { c->termination = termination; c->done = 1; }
+    lc.cost_after = accepted ? cost_new : (solved ? cost_new : cost_before);
+    lc.accepted = accepted ? 1 : 0;
+    if (!done && lc.iter >= lc.max_iters) done = true;          // termination stays NO_CONVERGENCE
+    if (done) { lc.termination = termination; lc.done = 1; }
     s_commit = accepted ? 1 : 0;
+    c->radius = lc.radius; c->decrease = lc.decrease; c->last_radius = lc.last_radius; c->cost = lc.cost; c->initial_cost = lc.initial_cost;
+    c->cost_before = lc.cost_before; c->cost_after = lc.cost_after; c->model = lc.model; c->dxnorm = lc.dxnorm; c->xnorm = lc.xnorm; c->gmax = lc.gmax;
+    c->iter = lc.iter; c->successes = lc.successes; c->invalid_run = lc.invalid_run; c->accepted = lc.accepted; c->solved = lc.solved;
+    c->done = lc.done; c->termination = lc.termination;
+    s_iter = lc.iter; s_done = lc.done;
+    if (A.dbg) A.dbg[3] = wall_clock64();
   }
   __syncthreads();
   if (s_commit) {
-    const double2* p2 = reinterpret_cast<const double2*>(A.invd2);
-    double2* q2 = reinterpret_cast<double2*>(A.invd);
-    for (int i = threadIdx.x; i < A.n_lm / 2; i += kDT) q2[i] = p2[i];
+    // (eight 16-byte requests per thread in flight: as a load-store loop the 80 KB of inverse depths took 3.9 us of this one workgroup)
+    const double2* __restrict__ p2 = reinterpret_cast<const double2*>(A.invd2);
+    double2* __restrict__ q2 = reinterpret_cast<double2*>(A.invd);
+    const int n2 = A.n_lm / 2;
+    for (int i0 = 0; i0 < n2; i0 += 8 * kDT) {      // (n2 > 0 inside)
+      double vx[8], vy[8];             // (scalars: an array of double2 is not split into registers and lands in scratch)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const double2 t = p2[min(i0 + u * kDT + (int)threadIdx.x, n2 - 1)]; vx[u] = t.x; vy[u] = t.y; }      // (unconditional, clamped)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q2[min(i0 + u * kDT + (int)threadIdx.x, n2 - 1)] = make_double2(vx[u], vy[u]);      // (past the end: the last element again, same value)
+    }
     if ((A.n_lm & 1) && threadIdx.x == 0) A.invd[A.n_lm - 1] = A.invd2[A.n_lm - 1];
     for (int i = threadIdx.x; i < 7 * A.n_kf; i += kDT) A.poses[i] = A.poses2[i];
     for (int i = threadIdx.x; i < 3 * A.n_kf; i += kDT) { A.vel[i] = A.vel2[i]; A.ba[i] = A.ba2[i]; A.bg[i] = A.bg2[i]; }
   }
-  if (A.rec) {
-    __syncthreads();
-    __threadfence_system();
-    if (threadIdx.x < (int)(sizeof(LmCtl) / 8)) reinterpret_cast<volatile unsigned long long*>(A.rec)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(c)[threadIdx.x];
+  if (A.dbg && threadIdx.x == 0) A.dbg[4] = wall_clock64();
+  // the host only polls `iter` and `done` of its mirror (wait_for_iteration): two uncached stores to the pinned record instead of a
+  // system-scope fence and a copy of the whole block; LAST, so that no load of this workgroup queues behind a write that crosses PCIe
+  if (A.rec && threadIdx.x == 0) {
+    __hip_atomic_store(&A.rec->done, s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&A.rec->iter, s_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 __global__ __launch_bounds__(kDT) void k_lm_decide(DecideArgs a) { lm_decide_body(a); }
@@ -2378,6 +2404,7 @@ __device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A,
   }
   if (A.done && *A.done) return;
   __shared__ double s_part[kT / 64];
+  if (D.dbg && threadIdx.x == 0 && (b == 0 || b == A.g_imu)) D.dbg[b == 0 ? 8 : 12] = wall_clock64();
   {
     // the workgroup's sum goes out as a RETURNING atomic: its result can only come back once the add has been performed, and the
     // ticket below is drawn after it — so every add of this workgroup is in the sum before its ticket is drawn (a release fence here would write
@@ -2394,8 +2421,10 @@ __device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A,
       __syncthreads();
       // (from LDS the one lane's ~60 operand reads cost nothing to repeat, so the compiler does not hold them all in registers: this
       // path shares its kernel with the visual cost pass, whose occupancy it would otherwise set)
+      if (D.dbg && threadIdx.x == 0 && b == 0) D.dbg[9] = wall_clock64();
       if (threadIdx.x == 0) imu_raw<false>(f, sP, A.imu.kf_i, A.imu.kf_j, A.s.poses, A.s.vel, A.s.ba, A.s.bg, sr0, nullptr);
       __syncthreads();
+      if (D.dbg && threadIdx.x == 0 && b == 0) D.dbg[10] = wall_clock64();
       const double r = imu_weighted_residual(threadIdx.x, sS, sr0);      // rows 0..14 in lanes 0..14 of wave 0
       c = threadIdx.x < 15 ? 0.5 * r * r : 0.0;
     }
@@ -2413,12 +2442,14 @@ __device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A,
       const double old = atomicAdd(A.cost + (b & (kStripes - 1)), v);
       asm volatile("" ::"v"(old) : "memory");
     }
+    if (D.dbg && (b == 0 || b == A.g_imu)) D.dbg[b == 0 ? 11 : 13] = wall_clock64();
     const int t = atomicAdd(D.ticket, 1);
     s_last = t == A.nblocks - 1;
     if (s_last) atomicExch(D.ticket, 0);
   }
   __syncthreads();
   if (s_last) lm_decide_body<true>(D);
+  if (s_last && D.dbg && threadIdx.x == 0) D.dbg[5] = wall_clock64();
 }
 // end_zero = 0 keeps the accumulators of this iteration's linearisation (per-call API: lvf_problem_download_reduced rebuilds the damped system from them)
 __global__ __launch_bounds__(kT) void k_cost_decide(CostArgs a, DecideArgs d, int end_zero) { cost_decide_body(blockIdx.x, a, d, end_zero); }
@@ -2875,7 +2906,10 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
   }
   if (ca.nblocks > 0) {
     if (!end_zero) ca.zero_wgs = 0;
-    hipLaunchKernelGGL(k_cost_decide, dim3(ca.nblocks + ca.zero_wgs), dim3(kT), 0, q, ca, c.dec, end_zero ? 1 : 0);
+    DecideArgs da = c.dec;
+    static const bool cost_timing = std::getenv("LVF_COST_TIMING") != nullptr;
+    if (cost_timing) { LVF_TRY(p->dbg.ensure(64)); da.dbg = p->dbg.p; }
+    hipLaunchKernelGGL(k_cost_decide, dim3(ca.nblocks + ca.zero_wgs), dim3(kT), 0, q, ca, da, end_zero ? 1 : 0);
     p->accum_clean = ca.zero_wgs > 0;
     if (p->accum_clean) p->linearized = false;         // the normal equations of this iteration are gone: no reduced-system tap
     stage_mark(p, ST_COST, 1 + (c.has_imu && !c.imu_in_cost ? 1 : 0) + (c.has_prior ? 2 : 0));
@@ -2934,6 +2968,13 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
       else if (kb + 2 < p->nb + 1) std::fprintf(stderr, "chol step %d (us): stage %.2f | mfma %.2f | relayout %.2f | factor %.2f | store %.2f ; since previous step's end %.2f\n", kb, (double)(u[1] - u[0]) * 0.01,
                         (double)(u[2] - u[1]) * 0.01, (double)(u[3] - u[2]) * 0.01, (double)(u[4] - u[3]) * 0.01, (double)(u[5] - u[4]) * 0.01, (double)(u[0] - u[-3]) * 0.01);
     }
+  }
+  if (p->dbg.p && std::getenv("LVF_COST_TIMING")) {
+    unsigned long long t[64];
+    LVF_HIP(hipMemcpy(t, p->dbg.p, sizeof(t), hipMemcpyDeviceToHost));
+    auto us = [&](int a, int b) { return ((double)t[b] - (double)t[a]) * 0.01; };
+    std::fprintf(stderr, "cost+decide (us): imu wg0 stage %.2f | raw (one lane) %.2f | weight+sum %.2f ; first visual wg %.2f (starts %.2f after imu wg0) ; decision starts %.2f after imu wg0's start: sums %.2f | logic %.2f | commit %.2f | record %.2f\n",
+                 us(8, 9), us(9, 10), us(10, 11), us(12, 13), us(8, 12), us(8, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5));
   }
   if (p->dbg.p && std::getenv("LVF_BACK_TIMING")) {
     unsigned long long t[64];
