@@ -2706,6 +2706,17 @@ static int build_chain(lvf_problem* p) {
   fill_cost_visual(p, c.cost.a);
   c.cost.n_kf = p->n_kf; c.cost.s = s2; c.cost.huber = 0.0; c.cost.cost = p->scal.p + SC_COST_NEW; c.cost.done = done;
   c.cost.nblocks = c.cost.a.g_tc + c.cost.a.g_tf + grid(c.cost.a.n_po);
+  {
+    // two tiles of kT blocks per workgroup: half as many workgroups to dispatch ahead of the decision (measured -1 % of an iteration; three: same)
+    static const int cost_tiles = [] { const char* e = std::getenv("LVF_COST_TILES"); return e ? std::atoi(e) : 2; }();
+    if (cost_tiles > 1) {
+      CostArgs& k = c.cost;
+      const int per = kT * cost_tiles;
+      k.tiles = cost_tiles;
+      k.a.g_tc = (k.a.n_tc + per - 1) / per; k.a.g_tf = (k.a.n_tf + per - 1) / per;
+      k.nblocks = k.a.g_tc + k.a.g_tf + (k.a.n_po + per - 1) / per;
+    }
+  }
   c.cost.g_imu = 0; c.cost.imu = ImuEvalArgs{};
   c.imu_in_cost = c.fast && c.has_imu && c.cost.nblocks > 0;         // the IMU cost rides in the merged cost + decision launch
   if (c.imu_in_cost) { c.cost.imu = ImuEvalArgs{p->imu->n, p->imu->pre.p, p->imu->sqrt_info.p, p->imu->idx_a.p, p->imu->idx_b.p}; c.cost.g_imu = p->imu->n; c.cost.nblocks += p->imu->n; }
