@@ -273,6 +273,18 @@ __device__ __forceinline__ double lane_bcast(double v, int srclane) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
   return __hiloint2double(hi, lo);
 }
+// inclusive prefix sum over the 64 lanes on the DPP path: Hillis-Steele inside each 16-lane row (row_shr 1, 2, 4, 8; out-of-row sources
+// read zero), then lane 15 of a row into the next row (row_bcast:15, rows 1 and 3) and lane 31 into rows 2 and 3 (row_bcast:31).  Six
+// VALU instructions; through __shfl_up it is six dependent ds_bpermute round trips (~100 clocks each).
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+  return v;
+}
 // sum over each aligned group of 16 lanes (a DPP "row"), delivered to all 16: the first four steps of wave_sum
 __device__ __forceinline__ double row16_sum(double v) {
   v = quad_sum(v);

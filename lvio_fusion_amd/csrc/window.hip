@@ -295,59 +295,69 @@ __global__ __launch_bounds__(256) void k_da_classify(DaArgs a) {
   }
 }
 __global__ __launch_bounds__(1024) void k_da_scan(DaArgs a) {
-  // One workgroup, two barriers per 32 k landmarks: the scans run inside waves (shuffles), a Hillis-Steele scan of 1024 LDS entries
+  // One workgroup, two barriers per 16 k landmarks: the scans run inside waves (shuffles), a Hillis-Steele scan of 1024 LDS entries
   // (20 workgroup barriers each, 16 waves) and a per-thread walk over runs of 64-byte landmark records made this launch 35 us.
-  constexpr int kChunks = 32;                       // chunks of 1024 landmarks per pass
-  __shared__ int s_cnt[kChunks * 16];               // used landmarks per (chunk, wave), then their exclusive prefix
+  __shared__ int s_cnt[16 * 16];                    // used landmarks per (chunk, wave) of a pass, then their exclusive prefix
   __shared__ int s_total;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // (1) exclusive scan of the per-workgroup block counts: wave t takes type t, 64 workgroups at a time with a running carry
   if (wv < 3) {
     int carry = 0;
-    for (int base = 0; base < a.n_wg; base += 64) {
-      const int i = base + lane;
-      const int v = i < a.n_wg ? a.wgcnt[3 * i + wv] : 0;
-      int inc = v;
+    for (int sb = 0; sb < a.n_wg; sb += 8 * 64) {      // 512 workgroups per pass, their counts requested up front
+      int v[8];
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
-      if (i < a.n_wg) a.wgbase[3 * i + wv] = carry + inc - v;
-      carry += __shfl(inc, 63);
+      for (int g = 0; g < 8; ++g) { const int i = sb + 64 * g + lane; const int t = a.wgcnt[3 * min(i, a.n_wg - 1) + wv]; v[g] = i < a.n_wg ? t : 0; }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int i = sb + 64 * g + lane;
+        const int inc = wave_incl_scan(v[g]);
+        if (i < a.n_wg) a.wgbase[3 * i + wv] = carry + inc - v[g];
+        carry += __shfl(inc, 63);
+      }
     }
     if (lane == 0) a.counts[wv] = carry;
   }
-  // (2) dense landmark slots in ascending landmark index (thread = landmark: coalesced; rank = ballot prefix + wave prefix + chunk prefix)
+  // (2) dense landmark slots in ascending landmark index (thread = landmark: coalesced; rank = ballot prefix + wave prefix + chunk prefix).
+  // 16 k landmarks per pass, the `used` flags and inverse depths of a pass requested up front (a load inside the per-1024 loop is waited
+  // for before the next one is issued)
+  constexpr int kG = 16;
   const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
   int total = 0;
-  for (int sb = 0; sb < a.nl; sb += kChunks * 1024) {
-    const int nch = min(kChunks, (a.nl - sb + 1023) / 1024);
-    for (int c = 0; c < nch; ++c) {
-      const int l = sb + c * 1024 + tid;
-      const unsigned long long m = __ballot(l < a.nl && a.used[l]);
-      if (lane == 0) s_cnt[c * 16 + wv] = __popcll(m);
+  for (int sb = 0; sb < a.nl; sb += kG * 1024) {
+    unsigned ubits = 0;
+    double invd[kG];
+#pragma unroll
+    for (int g = 0; g < kG; ++g) {
+      const int l = sb + g * 1024 + tid, lc = min(l, a.nl - 1);
+      ubits |= (l < a.nl && a.used[lc]) ? (1u << g) : 0u;
+      invd[g] = a.lm[lc].inv_depth;
+    }
+    int rank[kG];
+#pragma unroll
+    for (int g = 0; g < kG; ++g) {
+      const unsigned long long m = __ballot((ubits >> g) & 1u);
+      rank[g] = __popcll(m & below);
+      if (lane == 0) s_cnt[g * 16 + wv] = __popcll(m);
     }
     __syncthreads();
     if (wv == 0) {
       int carry = 0;
-      for (int base = 0; base < nch * 16; base += 64) {
-        const int i = base + lane;
-        const int v = i < nch * 16 ? s_cnt[i] : 0;
-        int inc = v;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o); if (lane >= o) inc += x; }
-        if (i < nch * 16) s_cnt[i] = carry + inc - v;
+      for (int base = 0; base < kG * 16; base += 64) {
+        const int v = s_cnt[base + lane];
+        const int inc = wave_incl_scan(v);
+        s_cnt[base + lane] = carry + inc - v;
         carry += __shfl(inc, 63);
       }
       if (lane == 0) s_total = carry;
     }
     __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-      const int l = sb + c * 1024 + tid;
-      const bool in = l < a.nl, u = in && a.used[l];
-      const unsigned long long m = __ballot(u);
-      if (in) {
-        const double invd = a.lm[l].inv_depth;
-        a.lm_invd_out[l] = invd;
-        if (u) { const int at = total + s_cnt[c * 16 + wv] + __popcll(m & below); a.slot[l] = at; a.slot_lm[at] = l; a.state_invd[at] = invd; }
+#pragma unroll
+    for (int g = 0; g < kG; ++g) {
+      const int l = sb + g * 1024 + tid;
+      if (l < a.nl) {
+        a.lm_invd_out[l] = invd[g];
+        if ((ubits >> g) & 1u) { const int at = total + s_cnt[g * 16 + wv] + rank[g]; a.slot[l] = at; a.slot_lm[at] = l; a.state_invd[at] = invd[g]; }
         else a.slot[l] = -1;
       }
     }
