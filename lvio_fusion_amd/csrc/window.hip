@@ -68,6 +68,13 @@ struct lvf_window {
   std::unordered_map<int64_t, std::array<double, 7>> departed;   // poses of frames that left the window (for ToWorld)
   std::vector<Lm> lms;                                   // entries are re-used through lm_free, never moved
   std::vector<int> lm_free;
+  // device-side assembly keeps the landmark table RESIDENT: only entries the host changed since the last tick are sent (the solved
+  // inverse depths are written into the table by the device itself)
+  std::vector<int> lm_dirty; std::vector<uint8_t> lm_dirty_flag; bool lmtab_valid = false;
+  void mark_lm(int i) {
+    if (lm_dirty_flag.size() <= (size_t)i) lm_dirty_flag.resize((size_t)i + 1 + lm_dirty_flag.size() / 2, 0);
+    if (!lm_dirty_flag[i]) { lm_dirty_flag[i] = 1; lm_dirty.push_back(i); }
+  }
   int n_lm_live = 0;
   std::unordered_map<int64_t, int> lm_index;
   // device side, persistent across ticks
@@ -129,6 +136,7 @@ static void prune(lvf_window* w) {
     if (l.alive && !seen[i]) {                 // the entry becomes free; nothing is moved, so every index held elsewhere stays valid
       w->lm_index.erase(l.id);
       l.alive = false; l.fixed = false; l.slot = -1;
+      w->mark_lm((int)i);
       w->lm_free.push_back((int)i);
       --w->n_lm_live;
     }
@@ -403,9 +411,11 @@ __global__ __launch_bounds__(256) void k_da_emit(DaArgs a) {
   }
 }
 // after the solve: the landmarks' inverse depths back into landmark-index order (the host mirror is indexed that way)
-__global__ __launch_bounds__(256) void k_da_scatter_invd(int n_lm, const int* __restrict__ slot_lm, const double* __restrict__ state_invd, double* __restrict__ lm_invd_out) {
+// ... and into the resident landmark table, which the next tick's assembly reads
+__global__ __launch_bounds__(256) void k_da_scatter_invd(int n_lm, const int* __restrict__ slot_lm, const double* __restrict__ state_invd, double* __restrict__ lm_invd_out,
+                                                         LmDev* __restrict__ lmtab) {
   const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s < n_lm) lm_invd_out[slot_lm[s]] = state_invd[s];
+  if (s < n_lm) { const int l = slot_lm[s]; const double v = state_invd[s]; lm_invd_out[l] = v; lmtab[l].inv_depth = v; }
 }
 
 // the read-back mirror of k_window_unpack's plain segments: device arrays -> one contiguous staging block (then ONE device-to-host copy
@@ -449,6 +459,8 @@ struct UnpackArgs {
   int n_segs; unsigned char* seg_dst[kMaxSegs]; size_t seg_off[kMaxSegs]; unsigned seg_words[kMaxSegs];   // 16-byte words (sizes are padded up)
   int g_tc, g_tf, g_po, g_seg;
   unsigned char* zero_dst[2]; unsigned zero_words[2];      // buffers cleared by the same launch (16-byte words)
+  // changed entries of the resident landmark table: record j (64 bytes at rec_off + 64 j) goes to entry idx[j] (int32 at idx_off + 4 j)
+  int n_lm_dirty; size_t lm_idx_off, lm_rec_off; unsigned char* lmtab;
 };
 __global__ __launch_bounds__(256) void k_window_unpack(UnpackArgs a) {
   int b = blockIdx.x;
@@ -484,6 +496,12 @@ __global__ __launch_bounds__(256) void k_window_unpack(UnpackArgs a) {
     const uint4* src = reinterpret_cast<const uint4*>(a.stage + a.seg_off[k]);
     uint4* dst = reinterpret_cast<uint4*>(a.seg_dst[k]);
     for (unsigned i = (unsigned)b * 256 + t; i < a.seg_words[k]; i += (unsigned)a.g_seg * 256) dst[i] = src[i];
+  }
+  {
+    const int32_t* idx = reinterpret_cast<const int32_t*>(a.stage + a.lm_idx_off);
+    const uint4* rec = reinterpret_cast<const uint4*>(a.stage + a.lm_rec_off);
+    for (unsigned i = (unsigned)b * 256 + t; i < 4u * (unsigned)a.n_lm_dirty; i += (unsigned)a.g_seg * 256)
+      reinterpret_cast<uint4*>(a.lmtab)[4 * (size_t)idx[i >> 2] + (i & 3)] = rec[i];
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -548,6 +566,7 @@ int lvf_window_add_landmark(lvf_window* w, int64_t lm_id, int64_t birth_kf_id, c
   int idx;
   if (!w->lm_free.empty()) { idx = w->lm_free.back(); w->lm_free.pop_back(); w->lms[idx] = l; }
   else { idx = (int)w->lms.size(); w->lms.push_back(l); }
+  w->mark_lm(idx);
   w->lm_index[lm_id] = idx;
   ++w->n_lm_live;
   // the landmark's own left feature in its birth frame (features_left[lm] of the first frame -> the TwoCamera block)
@@ -589,11 +608,13 @@ int lvf_window_slide(lvf_window* w, int64_t first_active_kf_id) {
     std::memcpy(p.data(), w->kfs[k].pose, 56);
     w->departed[w->kfs[k].id] = p;
   }
-  for (lvf_window::Lm& l : w->lms)
+  for (size_t i = 0; i < w->lms.size(); ++i) {
+    lvf_window::Lm& l = w->lms[i];
     if (l.alive && !l.fixed && l.birth_kf < first_active_kf_id) {
       auto it = w->departed.find(l.birth_kf);
-      if (it != w->departed.end()) { to_world(w->right, l.right_ob, l.inv_depth, it->second.data(), l.pw); l.fixed = true; }
+      if (it != w->departed.end()) { to_world(w->right, l.right_ob, l.inv_depth, it->second.data(), l.pw); l.fixed = true; w->mark_lm((int)i); }
     }
+  }
   w->kfs.erase(w->kfs.begin(), w->kfs.begin() + drop);
   w->kf_index.clear();
   for (size_t k = 0; k < w->kfs.size(); ++k) w->kf_index[w->kfs[k].id] = (int)k;
@@ -688,7 +709,7 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
   size_t dirty_obs = 0; int dirty_frames = 0;
   for (const lvf_window::Kf& f : w->kfs) if (f.d_dirty) { dirty_obs += f.obs.size(); ++dirty_frames; }
   const bool direct_segments = 2 * dirty_frames + 16 > kMaxSegs;      // (a full re-layout of a long window: copy those segments one by one)
-  const size_t stage_bound = up16((size_t)n_kf * sizeof(FrameDev)) + up16(nl * sizeof(LmDev)) + up16((size_t)17 * n_kf * 8) + 8 * 64 + dirty_obs * 24 + (size_t)dirty_frames * 64 + 4096 +
+  const size_t stage_bound = up16((size_t)n_kf * sizeof(FrameDev)) + up16(nl * sizeof(LmDev)) + up16(nl * 4) + 64 + up16((size_t)17 * n_kf * 8) + 8 * 64 + dirty_obs * 24 + (size_t)dirty_frames * 64 + 4096 +
                              up16((size_t)n_kf * 467 * 8) + (size_t)n_kf * 16 + 64;
   LVF_TRY(w->h_stage.reserve(stage_bound));
   LVF_TRY(w->d_stage.ensure(stage_bound));
@@ -701,7 +722,9 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
     cur += up16(bytes);
     return at;
   };
+  const unsigned char* lmtab_before = w->d_lmtab.p;
   LVF_TRY(w->d_frames.ensure((size_t)n_kf * sizeof(FrameDev) + 16)); LVF_TRY(w->d_lmtab.ensure(nl * sizeof(LmDev) + 16));
+  if (w->d_lmtab.p != lmtab_before) w->lmtab_valid = false;          // re-allocated: the resident table is gone
   // frame table (also what the IMU / prior decisions below need of a frame)
   std::vector<double> Rk((size_t)9 * n_kf + 9);
   landmarks_to_world_prepare(w, Rk.data());
@@ -727,15 +750,28 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
       std::memcpy(d.R, &Rk[(size_t)9 * k], 72); std::memcpy(d.t, f.pose + 4, 24);
     }
   }
-  // landmark table
+  // landmark table: all of it after a (re)allocation or a tick on the host path, otherwise only what add_landmark / slide / prune touched
   {
-    LmDev* ld = reinterpret_cast<LmDev*>(seg(w->d_lmtab.p, nl * sizeof(LmDev)));
-    for (size_t i = 0; i < nl; ++i) {
-      const lvf_window::Lm& l = w->lms[i];
-      LmDev& d = ld[i];
+    auto fill = [&](LmDev& d, const lvf_window::Lm& l) {
       d.right_ob[0] = l.right_ob[0]; d.right_ob[1] = l.right_ob[1]; d.pw[0] = l.pw[0]; d.pw[1] = l.pw[1]; d.pw[2] = l.pw[2];
       d.inv_depth = l.inv_depth; d.birth_kf = l.alive ? (long long)l.birth_kf : -1; d.fixed = (l.alive && l.fixed) ? 1 : 0; d.alive = l.alive ? 1 : 0;
+    };
+    const bool resident = w->lmtab_valid;
+    w->lmtab_valid = false;                    // (set again once this tick has gone through: an error below leaves the table to be re-sent)
+    if (!resident) {
+      LmDev* ld = reinterpret_cast<LmDev*>(seg(w->d_lmtab.p, nl * sizeof(LmDev)));
+      for (size_t i = 0; i < nl; ++i) fill(ld[i], w->lms[i]);
+    } else if (!w->lm_dirty.empty()) {
+      const size_t nd = w->lm_dirty.size();
+      ua.n_lm_dirty = (int)nd; ua.lmtab = w->d_lmtab.p;
+      ua.lm_idx_off = cur;
+      int32_t* di = reinterpret_cast<int32_t*>(hs + cur); cur += up16(nd * 4);
+      ua.lm_rec_off = cur;
+      LmDev* dr = reinterpret_cast<LmDev*>(hs + cur); cur += nd * sizeof(LmDev);
+      for (size_t j = 0; j < nd; ++j) { di[j] = w->lm_dirty[j]; fill(dr[j], w->lms[w->lm_dirty[j]]); }
     }
+    for (int i : w->lm_dirty) w->lm_dirty_flag[i] = 0;
+    w->lm_dirty.clear();
   }
   // state (the inverse depths are filled on the device, by slot)
   st->n_kf = n_kf;
@@ -908,7 +944,7 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
   const auto t_solved = now();
   // ---- read-back: poses, velocities, biases by keyframe position; inverse depths in landmark-index order
   {
-    if (n_lm) hipLaunchKernelGGL(k_da_scatter_invd, dim3((n_lm + 255) / 256), dim3(256), 0, s, n_lm, w->d_slot_lm.p, st->inv_depth.p, w->d_lm_invd_out.p);
+    if (n_lm) hipLaunchKernelGGL(k_da_scatter_invd, dim3((n_lm + 255) / 256), dim3(256), 0, s, n_lm, w->d_slot_lm.p, st->inv_depth.p, w->d_lm_invd_out.p, reinterpret_cast<LmDev*>(w->d_lmtab.p));
     PackArgs pa{};
     size_t at = 0;
     size_t offs[5];
@@ -935,6 +971,7 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
     for (size_t i = 0; i < nl; ++i) if (w->lms[i].alive) w->lms[i].inv_depth = invd[i];
   }
   w->slot_lm.clear();
+  w->lmtab_valid = true;
   if (timing)
     std::fprintf(stderr, "lvf_window_solve (device assembly): host tables %.3f ms (%zu bytes staged), upload + assembly + counters %.3f ms, small uploads %.3f ms, configure %.3f ms, solve %.3f ms (%d its), read-back %.3f ms\n",
                  ms(t_begin, t_staged), cur, ms(t_staged, t_assembled), ms(t_assembled, t_uploaded), ms(t_uploaded, t_configured), ms(t_configured, t_solved), summary->num_iterations, ms(t_solved, now()));
@@ -951,6 +988,7 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   if (w->opt.device_assembly && !host_asm && (int)w->kfs.size() <= lvf::kDaMaxKf) return window_solve_device(w, o, summary);
   hipStream_t s = ctx->stream;
   const int n_kf = (int)w->kfs.size();
+  w->lmtab_valid = false;                     // (host-side assembly: the device-resident landmark table, if any, goes stale)
   static const bool timing = getenv("LVF_WINDOW_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
