@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_preintegrate(const int* __restrict__ of
                                                       const double* __restrict__ ba_, const double* __restrict__ bg_,
                                                       double acc_n, double gyr_n, double acc_w, double gyr_w,
                                                       double* __restrict__ out) {
-  __shared__ double sJ[225], sC[225], sF[225], sV[270], sT[225], sN[18];
+  __shared__ double sJ[225], sC[225], sF[225], sV[270], sT[225], sN[18], sM[56];
   __shared__ double sState[24];   // dp 0..2, dq 3..6 (x,y,z,w), dv 7..9, acc0 10..12, gyr0 13..15, sum_dt 16
   const int f = blockIdx.x, tid = threadIdx.x;
   const double* lba = ba_ + 3 * f; const double* lbg = bg_ + 3 * f;
@@ -179,6 +179,8 @@ __global__ __launch_bounds__(256) void k_preintegrate(const int* __restrict__ of
     for (int k = 0; k < 3; ++k) { sState[k] = 0.0; sState[7 + k] = 0.0; sState[10 + k] = acc0_[3 * f + k]; sState[13 + k] = gyr0_[3 * f + k]; }
     sState[3] = sState[4] = sState[5] = 0.0; sState[6] = 1.0; sState[16] = 0.0;
   }
+  for (int k = tid; k < 225; k += 256) sF[k] = 0.0;      // the structural zeros of F (15 x 15) and V (15 x 18): one lane clearing 495 LDS words per
+  for (int k = tid; k < 270; k += 256) sV[k] = 0.0;      // sample was a third of the serial part of a step
   __syncthreads();
   for (int sidx = offset[f]; sidx < offset[f + 1]; ++sidx) {
     if (tid == 0) {
@@ -196,42 +198,10 @@ __global__ __launch_bounds__(256) void k_preintegrate(const int* __restrict__ of
       qmat(dq, R0); qmat(rq, R1); skew9(ug, Rw); skew9(a0b, Ra0); skew9(a1b, Ra1);
       for (int k = 0; k < 9; ++k) ImRw[k] = ((k % 4 == 0) ? 1.0 : 0.0) - Rw[k] * dt;
       mm3(R0, Ra0, R0a0); mm3(R1, Ra1, R1a1); mm3(R1a1, ImRw, R1a1I);
-      for (int k = 0; k < 225; ++k) sF[k] = 0.0;
-      for (int k = 0; k < 270; ++k) sV[k] = 0.0;
-#define FF(r, c) sF[(r) * 15 + (c)]
-#define VV(r, c) sV[(r) * 18 + (c)]
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-          const double I = (i == j) ? 1.0 : 0.0;
-          const int e = 3 * i + j;
-          FF(i, j) = I;
-          FF(i, 3 + j) = -0.25 * R0a0[e] * dt * dt + -0.25 * R1a1I[e] * dt * dt;
-          FF(i, 6 + j) = I * dt;
-          FF(i, 9 + j) = -0.25 * (R0[e] + R1[e]) * dt * dt;
-          FF(i, 12 + j) = -0.25 * R1a1[e] * dt * dt * -dt;
-          FF(3 + i, 3 + j) = ImRw[e];
-          FF(3 + i, 12 + j) = -1.0 * I * dt;
-          FF(6 + i, 3 + j) = -0.5 * R0a0[e] * dt + -0.5 * R1a1I[e] * dt;
-          FF(6 + i, 6 + j) = I;
-          FF(6 + i, 9 + j) = -0.5 * (R0[e] + R1[e]) * dt;
-          FF(6 + i, 12 + j) = -0.5 * R1a1[e] * dt * -dt;
-          FF(9 + i, 9 + j) = I;
-          FF(12 + i, 12 + j) = I;
-          VV(i, j) = 0.25 * R0[e] * dt * dt;
-          VV(i, 3 + j) = 0.25 * -R1a1[e] * dt * dt * 0.5 * dt;
-          VV(i, 6 + j) = 0.25 * R1[e] * dt * dt;
-          VV(i, 9 + j) = VV(i, 3 + j);
-          VV(3 + i, 3 + j) = 0.5 * I * dt;
-          VV(3 + i, 9 + j) = 0.5 * I * dt;
-          VV(6 + i, j) = 0.5 * R0[e] * dt;
-          VV(6 + i, 3 + j) = 0.5 * -R1a1[e] * dt * 0.5 * dt;
-          VV(6 + i, 6 + j) = 0.5 * R1[e] * dt;
-          VV(6 + i, 9 + j) = VV(6 + i, 3 + j);
-          VV(9 + i, 12 + j) = I * dt;
-          VV(12 + i, 15 + j) = I * dt;
-        }
-#undef FF
-#undef VV
+      // the 3 x 3 pieces of F and V go to LDS; nine lanes place them below (one lane writing all ~220 entries was most of what was
+      // left of the serial part of a step)
+      for (int k = 0; k < 9; ++k) { sM[k] = R0[k]; sM[9 + k] = R1[k]; sM[18 + k] = R0a0[k]; sM[27 + k] = R1a1[k]; sM[36 + k] = R1a1I[k]; sM[45 + k] = ImRw[k]; }
+      sM[54] = dt;
       // state update (Propagate tail, preintegration.cpp:116-126): delta_q is re-normalised
       for (int k = 0; k < 3; ++k) {
         const double ua = 0.5 * (ua0[k] + ua1[k]);
@@ -242,6 +212,42 @@ __global__ __launch_bounds__(256) void k_preintegrate(const int* __restrict__ of
       const double nq = sqrt(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
       sState[3] = rq.x / nq; sState[4] = rq.y / nq; sState[5] = rq.z / nq; sState[6] = rq.w / nq;
       sState[16] += dt;
+    }
+    __syncthreads();
+    if (tid < 9) {      // (sF / sV were cleared once before the loop: the entries assigned here are the same set for every sample)
+      const int e = tid, i = e / 3, j = e % 3;
+      const double I = (i == j) ? 1.0 : 0.0;
+      const double dt = sM[54];
+      const double R0e = sM[e], R1e = sM[9 + e], R0a0e = sM[18 + e], R1a1e = sM[27 + e], R1a1Ie = sM[36 + e], ImRwe = sM[45 + e];
+#define FF(r, c) sF[(r) * 15 + (c)]
+#define VV(r, c) sV[(r) * 18 + (c)]
+      FF(i, j) = I;
+      FF(i, 3 + j) = -0.25 * R0a0e * dt * dt + -0.25 * R1a1Ie * dt * dt;
+      FF(i, 6 + j) = I * dt;
+      FF(i, 9 + j) = -0.25 * (R0e + R1e) * dt * dt;
+      FF(i, 12 + j) = -0.25 * R1a1e * dt * dt * -dt;
+      FF(3 + i, 3 + j) = ImRwe;
+      FF(3 + i, 12 + j) = -1.0 * I * dt;
+      FF(6 + i, 3 + j) = -0.5 * R0a0e * dt + -0.5 * R1a1Ie * dt;
+      FF(6 + i, 6 + j) = I;
+      FF(6 + i, 9 + j) = -0.5 * (R0e + R1e) * dt;
+      FF(6 + i, 12 + j) = -0.5 * R1a1e * dt * -dt;
+      FF(9 + i, 9 + j) = I;
+      FF(12 + i, 12 + j) = I;
+      VV(i, j) = 0.25 * R0e * dt * dt;
+      VV(i, 3 + j) = 0.25 * -R1a1e * dt * dt * 0.5 * dt;
+      VV(i, 6 + j) = 0.25 * R1e * dt * dt;
+      VV(i, 9 + j) = VV(i, 3 + j);
+      VV(3 + i, 3 + j) = 0.5 * I * dt;
+      VV(3 + i, 9 + j) = 0.5 * I * dt;
+      VV(6 + i, j) = 0.5 * R0e * dt;
+      VV(6 + i, 3 + j) = 0.5 * -R1a1e * dt * 0.5 * dt;
+      VV(6 + i, 6 + j) = 0.5 * R1e * dt;
+      VV(6 + i, 9 + j) = VV(6 + i, 3 + j);
+      VV(9 + i, 12 + j) = I * dt;
+      VV(12 + i, 15 + j) = I * dt;
+#undef FF
+#undef VV
     }
     __syncthreads();
     double nj = 0.0, fc = 0.0;
