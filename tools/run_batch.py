@@ -6,7 +6,7 @@ from lvio_fusion_amd import api, synthetic as syn
 
 
 def build(ctx, seed):
-    cfg = syn.config4_window(seed=seed)
+    cfg = syn.config4_window(seed=seed, ids_by_birth="birth" in sys.argv[3:])
     pre = api.preintegrate_or_none(ctx, cfg)
     st = api.State(ctx, cfg["n_kf"], cfg["n_lm"])
     for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth"), (api.W_VISUAL, "w_kf")):
