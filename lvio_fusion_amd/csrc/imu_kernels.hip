@@ -35,11 +35,15 @@ __global__ __launch_bounds__(256) void k_imu_sqrt_info(int n, const double* __re
   __syncthreads();
   const int ti = tid >> 4, tj = tid & 15;          // element (ti, tj) of a 16 x 16 thread grid
   for (int k = 0; k < 15; ++k) {
-    if (tid == 0) {
-      int p = k;
-      double best = fabs(LU[15 * k + k]);
-      for (int i = k + 1; i < 15; ++i) { const double a = fabs(LU[15 * i + k]); if (a > best) { best = a; p = i; } }
-      piv[k] = p;
+    if (tid < 64) {
+      // partial pivot across the lanes of wave 0: the FIRST row i >= k with the largest |LU[i][k]| — what the scalar loop (keep the
+      // earlier row unless strictly larger) finds; as that loop on one lane it was 15 dependent LDS reads per step
+      const bool in = tid >= k && tid < 15;
+      const double a = in ? fabs(LU[15 * tid + k]) : -1.0;
+      double m = a;
+      for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+      const unsigned long long hit = __ballot(in && a == m);
+      if (tid == 0) piv[k] = hit ? (int)__ffsll((long long)hit) - 1 : k;
     }
     __syncthreads();
     const int p = piv[k];
@@ -58,10 +62,26 @@ __global__ __launch_bounds__(256) void k_imu_sqrt_info(int n, const double* __re
   if (tid < 15) {
     const int c = tid;
     double b[15];
-    for (int i = 0; i < 15; ++i) b[i] = (i == c) ? 1.0 : 0.0;
-    for (int k = 0; k < 15; ++k) { const double t = b[k]; b[k] = b[piv[k]]; b[piv[k]] = t; }
-    for (int i = 0; i < 15; ++i) { double s = b[i]; for (int j = 0; j < i; ++j) s -= LU[15 * i + j] * b[j]; b[i] = s; }
-    for (int i = 14; i >= 0; --i) { double s = b[i]; for (int j = i + 1; j < 15; ++j) s -= LU[15 * i + j] * b[j]; b[i] = s / LU[15 * i + i]; }
+    // the row swaps applied to e_c only move its single 1: track where it ends up (indexing b[] with piv[k] put the array in scratch)
+    int pos = c;
+    for (int k = 0; k < 15; ++k) { const int pk = piv[k]; pos = (pos == k) ? pk : (pos == pk ? k : pos); }
+#pragma unroll
+    for (int i = 0; i < 15; ++i) b[i] = (i == pos) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+      double s = b[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) s -= LU[15 * i + j] * b[j];
+      b[i] = s;
+    }
+#pragma unroll
+    for (int i = 14; i >= 0; --i) {
+      double s = b[i];
+#pragma unroll
+      for (int j = i + 1; j < 15; ++j) s -= LU[15 * i + j] * b[j];
+      b[i] = s / LU[15 * i + i];
+    }
+#pragma unroll
     for (int i = 0; i < 15; ++i) X[15 * i + c] = b[i];
   }
   __syncthreads();
