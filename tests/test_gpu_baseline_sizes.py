@@ -96,3 +96,54 @@ def test_config4_full_window_lm_iterations(ctx, oracle, ids_by_birth):
         radius, dec = ref["radius"], ref["decrease_factor"]
     for h in (prob, btc, btf, bpo, bimu, st):
         h.close()
+
+
+def test_more_than_16k_landmarks(ctx, oracle):
+    """20 000 landmarks in a short window: the one-workgroup scans of problem_configure (k_lm_offsets) and of the device-side window
+    assembly (k_da_scan) work in passes of 16 k landmarks — both are taken through their second pass here.  The flat problem is
+    compared with the oracle; the persistent window must then reproduce the flat problem's iteration."""
+    from lvio_fusion_amd import api
+    cfg = syn.config4_window(n_kf=8, n_lm=20000, n_prewindow=0, imu_samples=4, seed=2020)
+    pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+    st = api.State(ctx, cfg["n_kf"], cfg["n_lm"])
+    for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth"), (api.W_VISUAL, "w_kf")):
+        st.set(field, cfg[key])
+    tc, tf, po = cfg["tc"], cfg["tf"], cfg["po"]
+    assert len(po["kf_idx"]) == 0
+    btc = api.two_camera_batch(ctx, cfg["cam0"], cfg["cam1"], tc["left_ob"], tc["right_ob"], tc["lm_idx"], tc["kf_idx"])
+    btf = api.two_frame_batch(ctx, cfg["cam0"], cfg["cam1"], tf["first_ob"], tf["ob"], tf["lm_idx"], tf["kf1_idx"], tf["kf2_idx"])
+    bimu = api.imu_batch(ctx, pre, [f["kf_i"] for f in cfg["imu"]], [f["kf_j"] for f in cfg["imu"]])
+    prob = api.Problem(ctx, st, btc, btf, None, bimu)
+    ref_win = oracle.Window(cfg, pre)
+    opt = api.default_solver_options()
+    ref = ref_win.lm_iteration(1e4, 2.0)
+    got = prob.lm_iteration(opt, 1e4, 2.0)
+    assert abs(got["cost_before"] - ref["cost_before"]) <= 1e-8 * abs(ref["cost_before"])
+    assert got["accepted"] == ref["accepted"]
+    assert abs(got["cost_after"] - ref["cost_after"]) <= 1e-6 * abs(ref["cost_after"])
+    s = state_of(api, st)
+    assert_parity(s["poses"].reshape(-1, 7), ref_win.poses, "poses")
+    assert_parity(s["inv_depth"], ref_win.inv_depth, "inv_depth")
+    # ---- the same window through lvf_window_* (device-side assembly), one iteration from the same start
+    win = api.Window(ctx, cfg["cam0"], cfg["cam1"], baseline=syn.baseline(), weak_visual_threshold=0)
+    order_tc = np.argsort(tc["kf_idx"], kind="stable")
+    j = 0
+    for k in range(cfg["n_kf"]):
+        win.add_keyframe(k, cfg["poses"][k], cfg["w_kf"][k])
+        win.set_imu(k, cfg["vel"][k], cfg["ba"][k], cfg["bg"][k], pre[k - 1] if k > 0 else None)
+        while j < len(order_tc) and tc["kf_idx"][order_tc[j]] == k:
+            i = order_tc[j]; j += 1
+            win.add_landmark(int(tc["lm_idx"][i]), k, tc["left_ob"][i], tc["right_ob"][i], cfg["inv_depth"][tc["lm_idx"][i]])
+        for i in np.nonzero(tf["kf2_idx"] == k)[0]:
+            win.add_observation(int(tf["lm_idx"][i]), k, tf["ob"][i])
+    opt1 = api.default_solver_options(); opt1.max_num_iterations = 1
+    sw = win.solve(opt1)
+    assert abs(sw.initial_cost - ref["cost_before"]) <= 1e-8 * abs(ref["cost_before"])
+    for k in range(cfg["n_kf"]):
+        assert_parity(win.pose(k), ref_win.poses[k], f"window pose {k}")
+    for l in (0, 1, 9999, 16383, 16384, 19999):
+        assert abs(win.inv_depth(l) - ref_win.inv_depth[l]) <= 1e-6 * abs(ref_win.inv_depth[l])
+    win.solve(opt1)          # a second tick runs on the resident landmark table
+    assert win.counts()["lm"] == 20000
+    for h in (win, prob, btc, btf, bimu, st):
+        h.close()
