@@ -1,11 +1,14 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY PINNED (round 3): tests/test_oracle_ref.py compares this
+// file BIT FOR BIT with the reference's own imu_error.hpp / preintegration.{h,cpp} / utility.h compiled unmodified into oracle/_ref
+// (live where /root/reference exists, and everywhere against tests/golden/ref_v2.npz generated from it).
 //
 // imu.h — IMU pre-integration (mid-point) and the ImuError factor with its analytic
 // Jacobians, restating
 //   src/lvio_fusion/src/preintegration.cpp:12-165          (Preintegration)
 //   src/lvio_fusion/include/lvio_fusion/ceres/imu_error.hpp:12-122   (ImuError::Evaluate)
 //   src/lvio_fusion/include/lvio_fusion/utility.h:99-140   (q_delta, skew_symmetric, q_left, q_right)
-// Eigen (un-vendored) semantics DECLARED here: Quaternion*Vector = v + w*uv + vec x uv with
+// Eigen (un-vendored) semantics DECLARED here and, identically, in oracle/ref_shim/Eigen/Core (real Eigen's last-ulp rounding
+// depends on its version / vector ISA; the shim fixes k-ascending products without FMA): Quaternion*Vector = v + w*uv + vec x uv with
 // uv = 2 vec x v; Quaternion::inverse = conjugate / squaredNorm; toRotationMatrix as in
 // Eigen/Geometry; 15x15 inverse() = partial-pivot LU solve against the identity;
 // LLT = lower Cholesky reading the lower triangle.

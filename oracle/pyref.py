@@ -1,5 +1,5 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes front-end of oracle/_ref/liblvf_ref.so: the REFERENCE's own cost functors
-(/root/reference/src/lvio_fusion/include/lvio_fusion/ceres/{base,visual_error,lidar_error,pose_error}.hpp compiled unmodified
+(/root/reference/src/lvio_fusion/include/lvio_fusion/ceres/{base,visual_error,lidar_error,pose_error,imu_error}.hpp, imu/preintegration.h, utility.h and src/preintegration.cpp compiled unmodified
 against the stand-in third-party headers in oracle/ref_shim/, recipe: oracle/Makefile target `ref`).
 
 /root/reference only exists in the build container, never on the GPU box: available() is False there, and the tests that
@@ -175,3 +175,45 @@ def se3_apply(A, p):
 def se3_apply_f32(A, p):
     a, b = _f32(A), _f32(p); out = np.empty(3, dtype=np.float32)
     lib().lvr_se3_apply_f32(_p(a, C.c_float), _p(b, C.c_float), _p(out, C.c_float)); return out
+
+
+# ---- IMU (round 3): imu::Preintegration + ImuError from the reference's own text ----
+PREINT_DOUBLES = 467          # sum_dt, lin_ba[3], lin_bg[3], dp[3], dq[4], dv[3], jac[225], cov[225]  (lvo_preint / lvf_preint)
+
+
+def imu_preintegrate(samples, acc0, gyr0, ba, bg, noise4):
+    """Preintegration::Create(bias) + Append per sample (preintegration.h:22-41, preintegration.cpp:30-127)."""
+    s, a0, g0, ba, bg, nz = map(_f64, (samples, acc0, gyr0, ba, bg, noise4))
+    s = s.reshape(-1, 7)
+    out = np.zeros(PREINT_DOUBLES)
+    lib().lvr_imu_preintegrate(s.shape[0], _p(s), _p(a0), _p(g0), _p(ba), _p(bg), _p(nz), _p(out))
+    return out
+
+
+def imu_repropagate(samples, acc0, gyr0, ba, bg, new_ba, new_bg, noise4):
+    """Append per sample, then Repropagate(new_ba, new_bg) (preintegration.cpp:128-142)."""
+    s, a0, g0, ba, bg, nba, nbg, nz = map(_f64, (samples, acc0, gyr0, ba, bg, new_ba, new_bg, noise4))
+    s = s.reshape(-1, 7)
+    out = np.zeros(PREINT_DOUBLES)
+    lib().lvr_imu_repropagate(s.shape[0], _p(s), _p(a0), _p(g0), _p(ba), _p(bg), _p(nba), _p(nbg), _p(nz), _p(out))
+    return out
+
+
+def imu_raw_residual(pre, kf_i, kf_j, poses, vel, ba, bg, noise4):
+    """Preintegration::Evaluate — the unweighted residual (preintegration.cpp:144-165)."""
+    pre, poses, vel, ba, bg, nz = map(_f64, (pre, poses, vel, ba, bg, noise4))
+    kf_i, kf_j = _i32(kf_i), _i32(kf_j)
+    n = pre.shape[0]
+    r = np.empty((n, 15))
+    lib().lvr_imu_raw_residual(n, _p(pre), _p(kf_i, C.c_int), _p(kf_j, C.c_int), _p(poses), _p(vel), _p(ba), _p(bg), _p(nz), _p(r))
+    return r
+
+
+def imu_eval(pre, kf_i, kf_j, poses, vel, ba, bg, noise4, jac=True):
+    """ImuError::Create(preintegration)->Evaluate (imu_error.hpp:17-118); same packing as pyoracle.imu_eval."""
+    pre, poses, vel, ba, bg, nz = map(_f64, (pre, poses, vel, ba, bg, noise4))
+    kf_i, kf_j = _i32(kf_i), _i32(kf_j)
+    n = pre.shape[0]
+    r = np.empty((n, 15)); J = np.empty((n, 480)) if jac else None
+    lib().lvr_imu_eval(n, _p(pre), _p(kf_i, C.c_int), _p(kf_j, C.c_int), _p(poses), _p(vel), _p(ba), _p(bg), _p(nz), _p(r), _p(J))
+    return r, J

@@ -6,11 +6,15 @@
 // they lie (-I/root/reference/src/lvio_fusion/include, oracle/Makefile target `ref`).  Every entry point builds the functor through
 // the reference's own `X::Create(...)` factory and calls ceres::CostFunction::Evaluate — the same surface backend.cpp drives.
 // Used by tests/test_oracle_ref.py to pin oracle/factors.h (the restatement) against the reference's text, and to generate
-// tests/golden/ref_v1.npz (the reference does not exist on the GPU box).  ImuError is NOT covered: imu_error.hpp needs real Eigen
-// (15x15 inverse / LLT, Quaterniond) and preintegration.cpp.
+// tests/golden/ref_v1.npz (the reference does not exist on the GPU box).
+// Round 3: ImuError / Preintegration are covered too — ceres/imu_error.hpp, imu/preintegration.h, imu/imu.h, utility.h and frame.h
+// are included, and src/preintegration.cpp is compiled as a second translation unit (oracle/Makefile), all UNMODIFIED, against the
+// fixed-size Matrix / Quaternion / LLT / inverse stand-in in ref_shim/Eigen/Core (whose header declares the evaluation order it
+// fixes: real Eigen's rounding depends on its version and vector ISA).
 #include <cstring>
 #include <memory>
 
+#include "lvio_fusion/ceres/imu_error.hpp"
 #include "lvio_fusion/ceres/lidar_error.hpp"
 #include "lvio_fusion/ceres/pose_error.hpp"
 #include "lvio_fusion/ceres/visual_error.hpp"
@@ -19,6 +23,7 @@
 namespace lvio_fusion {
 std::vector<Camera::Ptr> Camera::devices_;
 double Camera::baseline = 1;
+std::vector<Imu::Ptr> Imu::devices_;      // src/imu/imu.cpp
 }  // namespace lvio_fusion
 const double epsilon = 1e-3;
 const int num_threads = 1;
@@ -36,7 +41,7 @@ static Camera::Ptr make_camera(const lvr_camera* c) {
 }
 
 const char* lvr_sources(void) {
-  return "lvio_fusion/ceres/base.hpp visual_error.hpp lidar_error.hpp pose_error.hpp (unmodified, from /root/reference)";
+  return "lvio_fusion/ceres/base.hpp visual_error.hpp lidar_error.hpp pose_error.hpp imu_error.hpp imu/preintegration.h utility.h + src/preintegration.cpp (unmodified, from /root/reference)";
 }
 
 // PoseOnlyReprojectionError::Create(ob, pw, camera, weight)   visual_error.hpp:66-70 ; call site backend.cpp:129-130
@@ -158,6 +163,94 @@ void lvr_relocate_r_eval(const double* relocated, const double* unrelocated, con
   const double* params[1] = {q4};
   double* jac[1] = {J};
   f->Evaluate(params, r, J ? jac : nullptr);
+}
+
+// ---------------- IMU: imu::Preintegration (preintegration.h:16-91, preintegration.cpp:15-165) and ImuError (imu_error.hpp:12-122) ----------------
+// flattened pre-integration, same field order as oracle_capi.cpp's lvo_preint / include/lvf.h's lvf_preint
+struct lvr_preint {
+  double sum_dt; double lin_ba[3]; double lin_bg[3]; double dp[3]; double dq[4]; double dv[3];
+  double jac[225]; double cov[225];
+};
+
+// the noise densities live in the process-wide Imu device (preintegration.cpp:21-27 reads Imu::Get()); device 0 is created once
+static void set_imu_noise(const double* noise4) {
+  if (Imu::Num() == 0) Imu::Create(SE3d(), 0, 0, 0, 0, 9.81007);
+  Imu::Ptr d = Imu::Get();
+  d->ACC_N = noise4[0]; d->GYR_N = noise4[1]; d->ACC_W = noise4[2]; d->GYR_W = noise4[3];
+}
+static void preint_to_flat(const imu::Preintegration& P, lvr_preint* o) {
+  o->sum_dt = P.sum_dt;
+  for (int i = 0; i < 3; ++i) { o->lin_ba[i] = P.linearized_ba(i); o->lin_bg[i] = P.linearized_bg(i); o->dp[i] = P.delta_p(i); o->dv[i] = P.delta_v(i); }
+  o->dq[0] = P.delta_q.x(); o->dq[1] = P.delta_q.y(); o->dq[2] = P.delta_q.z(); o->dq[3] = P.delta_q.w();
+  for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { o->jac[15 * i + j] = P.jacobian(i, j); o->cov[15 * i + j] = P.covariance(i, j); }
+}
+// the public fields ImuError / Preintegration::Evaluate read, set from a flattened record
+static imu::Preintegration::Ptr flat_to_preint(const lvr_preint* f) {
+  imu::Preintegration::Ptr P = imu::Preintegration::Create(Bias(Vector3d(f->lin_ba[0], f->lin_ba[1], f->lin_ba[2]), Vector3d(f->lin_bg[0], f->lin_bg[1], f->lin_bg[2])));
+  P->sum_dt = f->sum_dt;
+  P->delta_p = Vector3d(f->dp[0], f->dp[1], f->dp[2]);
+  P->delta_q = Quaterniond(f->dq[3], f->dq[0], f->dq[1], f->dq[2]);
+  P->delta_v = Vector3d(f->dv[0], f->dv[1], f->dv[2]);
+  for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { P->jacobian(i, j) = f->jac[15 * i + j]; P->covariance(i, j) = f->cov[15 * i + j]; }
+  return P;
+}
+// samples[ns][7] = (dt, acc xyz, gyr xyz); acc0 / gyr0 = the measurement latched by the first Append (preintegration.h:29-36).
+// Preintegration::Create(bias) then Append per sample — the sequence frontend / initializer code drives.
+void lvr_imu_preintegrate(int ns, const double* samples, const double* acc0, const double* gyr0, const double* ba, const double* bg,
+                          const double* noise4, lvr_preint* out) {
+  set_imu_noise(noise4);
+  imu::Preintegration::Ptr P = imu::Preintegration::Create(Bias(Vector3d(ba[0], ba[1], ba[2]), Vector3d(bg[0], bg[1], bg[2])));
+  const Vector3d a0(acc0[0], acc0[1], acc0[2]), g0(gyr0[0], gyr0[1], gyr0[2]);
+  for (int s = 0; s < ns; ++s) {
+    const double* q = samples + 7 * s;
+    P->Append(q[0], Vector3d(q[1], q[2], q[3]), Vector3d(q[4], q[5], q[6]), a0, g0);
+  }
+  if (ns == 0) { P->acc0 = a0; P->gyr0 = g0; }
+  preint_to_flat(*P, out);
+}
+// Repropagate(ba, bg) over the buffered samples (preintegration.cpp:128-142) — same inputs as above plus the new biases
+void lvr_imu_repropagate(int ns, const double* samples, const double* acc0, const double* gyr0, const double* ba, const double* bg,
+                         const double* new_ba, const double* new_bg, const double* noise4, lvr_preint* out) {
+  set_imu_noise(noise4);
+  imu::Preintegration::Ptr P = imu::Preintegration::Create(Bias(Vector3d(ba[0], ba[1], ba[2]), Vector3d(bg[0], bg[1], bg[2])));
+  const Vector3d a0(acc0[0], acc0[1], acc0[2]), g0(gyr0[0], gyr0[1], gyr0[2]);
+  for (int s = 0; s < ns; ++s) {
+    const double* q = samples + 7 * s;
+    P->Append(q[0], Vector3d(q[1], q[2], q[3]), Vector3d(q[4], q[5], q[6]), a0, g0);
+  }
+  P->Repropagate(Vector3d(new_ba[0], new_ba[1], new_ba[2]), Vector3d(new_bg[0], new_bg[1], new_bg[2]));
+  preint_to_flat(*P, out);
+}
+// Preintegration::Evaluate (the UNWEIGHTED 15-residual, preintegration.cpp:144-165)
+void lvr_imu_raw_residual(int n, const lvr_preint* pre, const int* kf_i, const int* kf_j, const double* poses, const double* vel,
+                          const double* ba, const double* bg, const double* noise4, double* r) {
+  set_imu_noise(noise4);
+  for (int f = 0; f < n; ++f) {
+    imu::Preintegration::Ptr P = flat_to_preint(pre + f);
+    const double *pi = poses + 7 * kf_i[f], *pj = poses + 7 * kf_j[f];
+    const int i = kf_i[f], j = kf_j[f];
+    Matrix<double, 15, 1> e = P->Evaluate(Vector3d(pi[4], pi[5], pi[6]), Quaterniond(pi[3], pi[0], pi[1], pi[2]), Vector3d(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2]),
+                                          Vector3d(ba[3 * i], ba[3 * i + 1], ba[3 * i + 2]), Vector3d(bg[3 * i], bg[3 * i + 1], bg[3 * i + 2]),
+                                          Vector3d(pj[4], pj[5], pj[6]), Quaterniond(pj[3], pj[0], pj[1], pj[2]), Vector3d(vel[3 * j], vel[3 * j + 1], vel[3 * j + 2]),
+                                          Vector3d(ba[3 * j], ba[3 * j + 1], ba[3 * j + 2]), Vector3d(bg[3 * j], bg[3 * j + 1], bg[3 * j + 2]));
+    for (int k = 0; k < 15; ++k) r[15 * f + k] = e(k);
+  }
+}
+// ImuError::Create(preintegration)->Evaluate   imu_error.hpp:17-118 ; call site backend.cpp:150-152.
+// n factors over state arrays poses[nkf][7], vel/ba/bg[nkf][3]; r[n][15]; J packed per factor as the eight row-major blocks
+// 15x7,15x3,15x3,15x3,15x7,15x3,15x3,15x3 = 480 doubles (J may be null) — oracle_capi.cpp's lvo_imu_eval layout.
+void lvr_imu_eval(int n, const lvr_preint* pre, const int* kf_i, const int* kf_j, const double* poses, const double* vel, const double* ba,
+                  const double* bg, const double* noise4, double* r, double* J) {
+  static const int off[8] = {0, 105, 150, 195, 240, 345, 390, 435};
+  set_imu_noise(noise4);
+  for (int f = 0; f < n; ++f) {
+    std::unique_ptr<ceres::CostFunction> fn(ImuError::Create(flat_to_preint(pre + f)));
+    const int i = kf_i[f], j = kf_j[f];
+    const double* prm[8] = {poses + 7 * i, vel + 3 * i, ba + 3 * i, bg + 3 * i, poses + 7 * j, vel + 3 * j, ba + 3 * j, bg + 3 * j};
+    double* Jp[8];
+    if (J) for (int k = 0; k < 8; ++k) Jp[k] = J + (size_t)480 * f + off[k];
+    fn->Evaluate(prm, r + 15 * f, J ? Jp : nullptr);
+  }
 }
 
 // base.hpp helpers instantiated on double / float (the float SE3TransformPoint is the association's transform, association.cpp:289)

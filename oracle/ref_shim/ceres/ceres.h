@@ -89,4 +89,15 @@ class AutoDiffCostFunction : public SizedCostFunction<kNumResiduals, Ns...> {
   std::unique_ptr<CostFunctor> functor_;
 };
 
+// declared so that imu_error.hpp:231-274 (ImuInitGError::Create, initialisation only — not on the hot path) compiles; never evaluated
+enum NumericDiffMethodType { CENTRAL, FORWARD, RIDDERS };
+template <typename CostFunctor, NumericDiffMethodType kMethod, int kNumResiduals, int... Ns>
+class NumericDiffCostFunction : public SizedCostFunction<kNumResiduals, Ns...> {
+ public:
+  explicit NumericDiffCostFunction(CostFunctor* functor) : functor_(functor) {}
+  bool Evaluate(double const* const*, double*, double**) const override { return false; }
+ private:
+  std::unique_ptr<CostFunctor> functor_;
+};
+
 }  // namespace ceres

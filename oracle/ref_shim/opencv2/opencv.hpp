@@ -1,8 +1,14 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Stand-in for <opencv2/opencv.hpp>: cv::Mat / cv::Mat_<T> with the comma initialiser
-// Camera's constructor uses for K and D (visual/camera.h:84-85).  Values are stored, never read by the functor path.
+// Camera's constructor uses for K and D (visual/camera.h:84-85), and the point / key-point value types utility.h, frame.h and
+// visual/feature.h name.  Values are stored, never read by the factor path.
 #pragma once
+#include <bitset>
 #include <vector>
+typedef unsigned char uchar;
 namespace cv {
+struct Point2f { float x, y; Point2f() : x(0), y(0) {} Point2f(float x_, float y_) : x(x_), y(y_) {} };
+struct Point3f { float x, y, z; Point3f() : x(0), y(0), z(0) {} Point3f(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {} };
+struct KeyPoint { Point2f pt; float size; KeyPoint() : size(0) {} KeyPoint(Point2f p, float s) : pt(p), size(s) {} };
 class Mat {
  public:
   Mat() : rows(0), cols(0) {}

@@ -15,6 +15,8 @@ class SE3d {
   double* data() { return d_; }
   const double* data() const { return d_; }
   Eigen::Vector3d translation() const { return Eigen::Vector3d(d_[4], d_[5], d_[6]); }
+  Eigen::Quaterniond unit_quaternion() const { return Eigen::Quaterniond(d_[3], d_[0], d_[1], d_[2]); }
+  Eigen::Matrix3d rotationMatrix() const { return unit_quaternion().toRotationMatrix(); }
   SE3d inverse() const {
     SE3d r;
     r.d_[0] = -d_[0]; r.d_[1] = -d_[1]; r.d_[2] = -d_[2]; r.d_[3] = d_[3];
