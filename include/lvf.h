@@ -328,7 +328,16 @@ typedef struct lvf_solver_summary {
   int num_iterations, num_successful_steps;
   int num_residual_blocks;
   int termination; /* 0 convergence, 1 no_convergence (iteration/time cap), 2 failure */
+  int num_unsuccessful_steps; /* rejected + invalid steps (Summary::num_unsuccessful_steps) */
+  int termination_reason;     /* LVF_WHY_*: which test of ceres::Solve's TrustRegionMinimizer ended the loop */
 } lvf_solver_summary;
+/* ceres::Solve's termination tests in the order the loop applies them (upstream trust_region_minimizer.cc; the test oracle restates the same loop):
+ * before a step — gradient_max_norm <= gradient_tolerance, radius < 1e-32 (both CONVERGENCE, the pass does not count as an iteration);
+ * after the linear solve — 5 consecutive invalid steps (solver failure or model_cost_change <= 0; FAILURE, else radius *= 0.5);
+ * with the candidate — step_norm <= parameter_tolerance (x_norm + parameter_tolerance), then |cost - candidate_cost| <= function_tolerance cost
+ * (both CONVERGENCE, the candidate is NOT taken); after the step — num_iterations >= max_num_iterations (NO_CONVERGENCE), radius < 1e-32. */
+enum { LVF_WHY_NONE = 0, LVF_WHY_GRADIENT = 1, LVF_WHY_PARAMETER = 2, LVF_WHY_FUNCTION = 3, LVF_WHY_MIN_RADIUS = 4, LVF_WHY_MAX_ITERATIONS = 5,
+       LVF_WHY_INVALID_STEPS = 6, LVF_WHY_TIME = 7 };
 void lvf_solver_options_default(lvf_solver_options* o);
 /* The problem borrows the state and the batches (they must outlive it).  Any of the batch pointers may
  * be NULL.  Pose blocks use ProductParameterization(EigenQuaternion, Identity3) (backend.cpp:99-101). */

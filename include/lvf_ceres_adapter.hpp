@@ -859,11 +859,15 @@ inline bool solve_window(const ceres::Solver::Options& options, ceres::Problem* 
   }
   for (int l = 0; l < n_lm; ++l) *w.lm_ptr[l] = invd[l];
   summary->initial_cost = s.initial_cost; summary->final_cost = s.final_cost;
-  summary->num_successful_steps = s.num_successful_steps; summary->num_unsuccessful_steps = s.num_iterations - s.num_successful_steps;
+  summary->num_successful_steps = s.num_successful_steps; summary->num_unsuccessful_steps = s.num_unsuccessful_steps;
   summary->num_residual_blocks = summary->num_residual_blocks_reduced = s.num_residual_blocks;
   summary->num_parameter_blocks = summary->num_parameter_blocks_reduced = problem->NumParameterBlocks();
   summary->termination_type = s.termination == 0 ? ceres::CONVERGENCE : ceres::NO_CONVERGENCE;
-  summary->message = "sliding-window BA solved on device";
+  static const char* const kWhy[] = {"", "Gradient tolerance reached.", "Parameter tolerance reached.", "Function tolerance reached.",
+                                    "Minimum trust region radius reached.", "Maximum number of iterations reached.",
+                                    "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps.",
+                                    "Maximum solver time reached."};
+  summary->message = std::string("sliding-window BA solved on device. ") + kWhy[s.termination_reason >= 0 && s.termination_reason <= 7 ? s.termination_reason : 0];
   summary->preprocessor_time_in_seconds += std::chrono::duration<double>(t1 - t0).count();   // classify + upload (collect() is added by Solve)
   summary->minimizer_time_in_seconds = std::chrono::duration<double>(t2 - t1).count();
   summary->postprocessor_time_in_seconds = std::chrono::duration<double>(clk::now() - t2).count();

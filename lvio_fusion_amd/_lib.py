@@ -68,7 +68,15 @@ class SolverOptions(C.Structure):
 
 class SolverSummary(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("num_iterations", C.c_int),
-                ("num_successful_steps", C.c_int), ("num_residual_blocks", C.c_int), ("termination", C.c_int)]
+                ("num_successful_steps", C.c_int), ("num_residual_blocks", C.c_int), ("termination", C.c_int),
+                ("num_unsuccessful_steps", C.c_int), ("termination_reason", C.c_int)]
+
+    WHY = ("none", "gradient_tolerance", "parameter_tolerance", "function_tolerance", "min_trust_region_radius", "max_num_iterations",
+           "consecutive_invalid_steps", "max_solver_time")          # LVF_WHY_* (include/lvf.h)
+
+    @property
+    def why(self):
+        return self.WHY[self.termination_reason]
 
 
 def build(force=False):

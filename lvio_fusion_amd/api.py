@@ -517,6 +517,17 @@ class Window:
             self.h = C.c_void_p()
 
 
+def event_pair_us(ctx, reps=25):
+    """Microseconds a HIP event pair measures with NOTHING enqueued between its two records (median of `reps`): the marker's own cost,
+    which every event-bracketed stage time carries once (bench.py subtracts it so stage times agree with rocprofv3's kernel durations)."""
+    ctx.synchronize()
+    v = []
+    for _ in range(reps):
+        ctx.timer_begin(); ctx.timer_end()
+        v.append(1e3 * ctx.timer_ms())
+    return float(np.median(v))
+
+
 def default_solver_options():
     o = SolverOptions()
     _lib.lib().lvf_solver_options_default(C.byref(o))

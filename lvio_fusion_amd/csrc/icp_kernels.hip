@@ -28,6 +28,7 @@ struct IcpDev {
   double cost_cur, initial_cost, model;
   double rpyxyz[6];
   int done, iters, successes, nvalid, first;
+  int invalid_run;           // consecutive invalid steps (solver failure or model_cost_change <= 0): 5 end the solve
   unsigned ticket;           // workgroups that have finished the running k_icp_eval (the last one does the scalar tail)
 };
 
@@ -82,7 +83,7 @@ __device__ void icp_step(const IcpArgs& args, IcpDev* dev) {
   dev->cost_cur = cost;
   if (dev->first) { dev->initial_cost = cost; dev->first = 0; }
   const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
-  if (gmax <= args.gradient_tolerance) { dev->done = 1; return; }
+  if (gmax <= args.gradient_tolerance || dev->radius < 1e-32) { dev->done = 1; return; }      // top of ceres::Solve's loop: gradient tolerance, smallest trust region
   const double inv_r = 1.0 / dev->radius;
   const double D0 = clampd(H[0]) * inv_r, D1 = clampd(H[2]) * inv_r, D2 = clampd(H[5]) * inv_r;
   // Cholesky of [[a00,.,.],[a10,a11,.],[a20,a21,a22]]
@@ -104,7 +105,7 @@ __device__ void icp_step(const IcpArgs& args, IcpDev* dev) {
   dev->cost_cand = 0.0;
   const double dn = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
   const double xn = sqrt(dev->x[0] * dev->x[0] + dev->x[1] * dev->x[1] + dev->x[2] * dev->x[2]);
-  if (ok && dn <= args.parameter_tolerance * (xn + args.parameter_tolerance)) dev->done = 1;
+  if (ok && dev->model > 0.0 && dn <= args.parameter_tolerance * (xn + args.parameter_tolerance)) dev->done = 1;      // (a VALID step this small: the candidate is not taken)
 }
 
 __device__ void icp_decide(const IcpArgs& args, IcpDev* dev) {
@@ -114,25 +115,29 @@ __device__ void icp_decide(const IcpArgs& args, IcpDev* dev) {
     const double w2 = args.prior_w * args.prior_w;
     for (int q = 0; q < 3; ++q) { const double dxp = dev->xc[q] - dev->x0[q]; cand += 0.5 * w2 * dxp * dxp; }
   }
-  dev->iters += 1;
-  bool accepted = false;
-  if (dev->model > 0.0 && isfinite(cand)) {
-    const double rho = (dev->cost_cur - cand) / dev->model;
-    if (rho > args.min_relative_decrease) {
-      accepted = true;
-      const double change = dev->cost_cur - cand;
-      const double before = dev->cost_cur;
-      for (int q = 0; q < 3; ++q) dev->x[q] = dev->xc[q];
-      dev->cost_cur = cand;
-      dev->successes += 1;
-      const double t = 2.0 * rho - 1.0;
-      dev->radius = fmin(dev->radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
-      dev->decrease = 2.0;
-      if (fabs(change) <= args.function_tolerance * fabs(before)) dev->done = 1;
+  // ceres::Solve's TrustRegionMinimizer order (declared in oracle/lm.h lm_solve, restated for this 3-unknown problem in oracle/icp.h)
+  const bool valid = dev->model > 0.0 && isfinite(cand);
+  if (!valid) {
+    dev->iters += 1;
+    if (++dev->invalid_run >= 5) dev->done = 1;
+    else dev->radius *= 0.5;
+  } else {
+    dev->invalid_run = 0;
+    if (fabs(dev->cost_cur - cand) <= args.function_tolerance * dev->cost_cur) dev->done = 1;      // BEFORE the step-quality test; the candidate is not taken
+    else {
+      dev->iters += 1;
+      const double rho = (dev->cost_cur - cand) / dev->model;
+      if (rho > args.min_relative_decrease) {
+        for (int q = 0; q < 3; ++q) dev->x[q] = dev->xc[q];
+        dev->cost_cur = cand;
+        dev->successes += 1;
+        const double t = 2.0 * rho - 1.0;
+        dev->radius = fmin(dev->radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
+        dev->decrease = 2.0;
+      } else { dev->radius = dev->radius / dev->decrease; dev->decrease *= 2.0; }
     }
   }
-  if (!accepted) { dev->radius = dev->radius / dev->decrease; dev->decrease *= 2.0; if (dev->radius < 1e-32) dev->done = 1; }
-  if (dev->iters >= args.max_iters) dev->done = 1;
+  if (dev->iters >= args.max_iters || dev->radius < 1e-32) dev->done = 1;
   for (int q = 0; q < 10; ++q) dev->acc[q] = 0.0;
 }
 

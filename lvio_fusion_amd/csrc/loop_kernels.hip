@@ -78,9 +78,10 @@ __global__ __launch_bounds__(kLT) void k_relocate_solve(int n, const double* __r
   double q[4] = {q_in[0], q_in[1], q_in[2], q_in[3]};
   double radius = o.radius0, decrease = 2.0, cost = 0.0, initial_cost = 0.0;
   int iters = 0, successes = 0, termination = 1;
-  bool first = true, done = false;
-  const int max_it = o.max_iters > 1 ? o.max_iters : 1;
-  for (int it = 0; it < max_it && !done; ++it) {
+  // ceres::Solve's TrustRegionMinimizer order (declared semantics: oracle/lm.h lm_solve; this problem's restatement: oracle/loop.h)
+  bool first = true;
+  int invalid_run = 0;
+  for (;;) {
     // EigenQuaternionParameterization::ComputeJacobian at q
     const double P[12] = {q[3], q[2], -q[1], -q[2], q[3], q[0], q[1], -q[0], q[3], -q[0], -q[1], -q[2]};
     double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, c = 0.0;
@@ -104,8 +105,9 @@ __global__ __launch_bounds__(kLT) void k_relocate_solve(int n, const double* __r
     for (int k = 0; k < 6; ++k) h[k] = wg_sum(h[k], red);
     // every thread holds the same sums and takes the same decisions (no divergence across the barriers below)
     if (first) { initial_cost = cost; first = false; }
+    if (iters >= o.max_iters) break;
     if (fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))) <= o.gradient_tol) { termination = 0; break; }
-    if (o.max_iters == 0) break;
+    if (radius < 1e-32) { termination = 0; break; }
     const double H[3][3] = {{h[0], h[1], h[3]}, {h[1], h[2], h[4]}, {h[3], h[4], h[5]}};
     double A[3][3];
 #pragma unroll
@@ -137,8 +139,16 @@ __global__ __launch_bounds__(kLT) void k_relocate_solve(int n, const double* __r
       qc[1] = cw * q[1] - ax * q[2] + ay * q[3] + az * q[0];
       qc[2] = cw * q[2] + ax * q[1] - ay * q[0] + az * q[3];
     }
+    if (!(ok && model > 0.0)) {                      // invalid step (uniform across the workgroup)
+      ++iters;
+      if (++invalid_run >= 5) { termination = 2; break; }
+      radius *= 0.5;
+      continue;
+    }
+    invalid_run = 0;
     const double xn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    if (ok && dn <= o.parameter_tol * (xn + o.parameter_tol)) { termination = 0; break; }
+    const double sn2 = (qc[0] - q[0]) * (qc[0] - q[0]) + (qc[1] - q[1]) * (qc[1] - q[1]) + (qc[2] - q[2]) * (qc[2] - q[2]) + (qc[3] - q[3]) * (qc[3] - q[3]);
+    if (sqrt(sn2) <= o.parameter_tol * (xn + o.parameter_tol)) { termination = 0; break; }
     double cc = 0.0;
     for (int i = tid; i < n; i += kLT) {
       double r[7], J[28];
@@ -147,21 +157,15 @@ __global__ __launch_bounds__(kLT) void k_relocate_solve(int n, const double* __r
       for (int k = 0; k < 7; ++k) cc += 0.5 * r[k] * r[k];
     }
     const double cand = wg_sum(cc, red);
+    if (fabs(cost - cand) <= o.function_tol * cost) { termination = 0; break; }
     ++iters;
-    bool accepted = false;
-    if (ok && model > 0.0) {
-      const double rho = (cost - cand) / model;
-      if (rho > o.min_rel_decrease) {
-        accepted = true;
-        const double change = cost - cand, before = cost;
-        q[0] = qc[0]; q[1] = qc[1]; q[2] = qc[2]; q[3] = qc[3];
-        cost = cand; ++successes;
-        const double t = 2.0 * rho - 1.0;
-        radius = fmin(radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16); decrease = 2.0;
-        if (fabs(change) <= o.function_tol * fabs(before)) { done = true; termination = 0; }
-      }
-    }
-    if (!accepted) { radius /= decrease; decrease *= 2.0; if (radius < 1e-32) { done = true; termination = 2; } }
+    const double rho = (cost - cand) / model;
+    if (rho > o.min_rel_decrease) {
+      q[0] = qc[0]; q[1] = qc[1]; q[2] = qc[2]; q[3] = qc[3];
+      cost = cand; ++successes;
+      const double t = 2.0 * rho - 1.0;
+      radius = fmin(radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16); decrease = 2.0;
+    } else { radius /= decrease; decrease *= 2.0; }
   }
   if (tid == 0) {
     out->q[0] = q[0]; out->q[1] = q[1]; out->q[2] = q[2]; out->q[3] = q[3];
@@ -245,7 +249,7 @@ int lvf_relocate_rotation_solve(lvf_ctx* ctx, int n, const double* relocated, co
   if (h.termination == 2 || !std::isfinite(h.final_cost)) { summary->termination = 2; summary->initial_cost = h.initial_cost; summary->final_cost = h.initial_cost; return LVF_OK; }   // fail soft: q4 untouched
   std::memcpy(q4, h.q, 32);
   summary->initial_cost = h.initial_cost; summary->final_cost = h.final_cost; summary->num_iterations = h.iters; summary->num_successful_steps = h.successes;
-  summary->termination = h.termination;
+  summary->termination = h.termination; summary->num_unsuccessful_steps = h.iters - h.successes;
   return LVF_OK;
 }
 

@@ -120,6 +120,7 @@ struct LmCtl {
   int iter, successes, invalid_run;                // iterations taken / accepted steps / consecutive unsolvable steps
   int accepted, solved;                            // of the last iteration
   int done, termination;                           // done != 0: the remaining launches of this window return immediately
+  int why, rejected;                               // LVF_WHY_* reason of the termination ; rejected / invalid steps so far
 };
 
 // lower-triangle accumulation of a 6x6 block pair J_a^T J_b into B at (ra, rb) block offsets (ra >= rb required
@@ -2183,7 +2184,7 @@ __device__ __forceinline__ void landmark_back_body(const int vb, const int nwg, 
   // capped and strides over the landmarks so that the three scalar sums cost one atomic per WORKGROUP (thousands of per-wave
   // atomics on the 32 striped slots were most of this kernel's time)
   const int q = threadIdx.x & 15;
-  double m = 0.0, n2 = 0.0, x2 = 0.0;
+  double m = 0.0, n2 = 0.0, x2 = 0.0, gmx = 0.0;
   for (int l = vb * (kT / 16) + (threadIdx.x >> 4); l < n_lm; l += nwg * (kT / 16)) {
     const double* e = E + (size_t)l * ldE;
     double ed = 0.0;
@@ -2191,22 +2192,29 @@ __device__ __forceinline__ void landmark_back_body(const int vb, const int nwg, 
     for (int i = (i0 & ~15) + q; i < i1; i += 16) ed += e[i] * sdx[i];
     ed = row16_sum(ed);
     if (q == 0) {
-      const double dl = (-gr[l] - ed) / Cd[l];
+      const double g_l = gr[l];
+      const double dl = (-g_l - ed) / Cd[l];
+      gmx = fmax(gmx, fabs(g_l));                   // Ceres' gradient_max_norm runs over every unknown, the inverse depths included
       dxl[l] = dl;
       invd2[l] = inv_depth[l] + dl;                 // the candidate inverse depth (was a second pass in k_apply_step)
-      m += -0.5 * dl * ((Cd[l] - C[l]) * dl - gr[l]);
+      m += -0.5 * dl * ((Cd[l] - C[l]) * dl - g_l);
       n2 += dl * dl; x2 += inv_depth[l] * inv_depth[l];
     }
   }
-  __shared__ double red[3][kT / 64];
+  __shared__ double red[4][kT / 64];
   m = wave_sum(m); n2 = wave_sum(n2); x2 = wave_sum(x2);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = n2; red[2][threadIdx.x >> 6] = x2; }
+  for (int o = 32; o > 0; o >>= 1) gmx = fmax(gmx, __shfl_down(gmx, o));
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = n2; red[2][threadIdx.x >> 6] = x2; red[3][threadIdx.x >> 6] = gmx; }
   __syncthreads();
   if (threadIdx.x < 3) {
     double v = 0.0;
     for (int k = 0; k < kT / 64; ++k) v += red[threadIdx.x][k];
     double* dst = scal + (threadIdx.x == 0 ? SC_MODEL : (threadIdx.x == 1 ? SC_DXNORM : SC_XNORM));
     if (v != 0.0) atomicAdd(dst + (vb & (kStripes - 1)), v);
+  } else if (threadIdx.x == 3) {
+    double v = 0.0;
+    for (int k = 0; k < kT / 64; ++k) v = fmax(v, red[3][k]);
+    if (v != 0.0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX), (unsigned long long)__double_as_longlong(v));      // (non-negative doubles order like their bit patterns)
   }
 }
 // Model cost change without a pass over H:  (H + D) dx = -g  =>  -dx^T (g + H dx / 2) = 1/2 sum_i dx_i (D_i dx_i - g_i).
@@ -2217,23 +2225,19 @@ __device__ __forceinline__ void landmark_back_body(const int vb, const int nwg, 
 __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm, StateP s, const double* __restrict__ dxc, const double* __restrict__ dxl,
                                                 double* __restrict__ poses2, double* __restrict__ vel2, double* __restrict__ ba2,
                                                 double* __restrict__ bg2, double* __restrict__ invd2, double* __restrict__ scal, int d, int ld,
-                                                const double* __restrict__ B, const double* __restrict__ gc, double inv_radius) {
+                                                const double* __restrict__ B, const double* __restrict__ gc, double inv_radius,
+                                                const unsigned char* __restrict__ pose_const) {
   const int i = vb * kT + threadIdx.x;
-  {
-    double m = 0.0, n2 = 0.0, g = 0.0;
-    if (i < d) {
-      const double dx = dxc[i];
-      m = -0.5 * dx * (clamp_diag(B[(size_t)i * ld + i]) * inv_radius * dx - gc[i]);
-      n2 = dx * dx;
-      g = fabs(gc[i]);
-    }
-    if (vb * kT < d) {      // block-uniform
-      block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM);
-      for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_down(g, o));
-      if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX), (unsigned long long)__double_as_longlong(g));
-    }
+  // step_norm / x_norm as Ceres takes them (trust_region_minimizer.cc): |x - x_plus_delta| and |x| over the AMBIENT parameter vector of the
+  // reduced program — the quaternion's four coefficients, not its three tangent increments; constant pose blocks are not part of it
+  double m = 0.0, n2 = 0.0, g = 0.0, x2 = 0.0;
+  if (i < d) {
+    const double dx = dxc[i];
+    m = -0.5 * dx * (clamp_diag(B[(size_t)i * ld + i]) * inv_radius * dx - gc[i]);
+    const bool rot = i < 6 * n_kf && (i % 6) < 3;           // rotation increments enter through the quaternion difference below
+    n2 = rot ? 0.0 : dx * dx;
+    g = fabs(gc[i]);
   }
-  double x2 = 0.0;
   if (i < n_kf) {
     const double* p = s.poses + 7 * i; const double* dlt = dxc + 6 * i;
     const double nrm = sqrt(dlt[0] * dlt[0] + dlt[1] * dlt[1] + dlt[2] * dlt[2]);
@@ -2250,10 +2254,16 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
     for (int c = 0; c < 3; ++c) o[4 + c] = p[4 + c] + dlt[3 + c];
     const double* dv = dxc + 6 * n_kf + 9 * i;
     for (int c = 0; c < 3; ++c) { vel2[3 * i + c] = s.vel[3 * i + c] + dv[c]; ba2[3 * i + c] = s.ba[3 * i + c] + dv[3 + c]; bg2[3 * i + c] = s.bg[3 * i + c] + dv[6 + c]; }
-    for (int c = 0; c < 7; ++c) x2 += p[c] * p[c];
+    for (int c = 0; c < 4; ++c) n2 += (o[c] - p[c]) * (o[c] - p[c]);
+    if (!(pose_const && pose_const[i])) for (int c = 0; c < 7; ++c) x2 += p[c] * p[c];
     for (int c = 0; c < 3; ++c) x2 += s.vel[3 * i + c] * s.vel[3 * i + c] + s.ba[3 * i + c] * s.ba[3 * i + c] + s.bg[3 * i + c] * s.bg[3 * i + c];
   }
   if (i < n_lm) invd2[i] = s.inv_depth[i] + dxl[i];
+  if (vb * kT < d) {      // block-uniform
+    block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM);
+    for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_down(g, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX), (unsigned long long)__double_as_longlong(g));
+  }
   block_add(x2, scal + SC_XNORM);
 }
 
@@ -2262,11 +2272,12 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
 struct TailArgs {
   int g_lm, n_lm, dp, ldE; const double *E, *C, *Cd, *gr, *dxc; double *dxl, *scal; const int *kmin, *kmax; int n_kf; StateP s;
   double *poses2, *vel2, *ba2, *bg2, *invd2; int d, ld; const double *B, *gc; const double* radius; int nblocks; const int* done;
+  const unsigned char* pose_const;
 };
 __device__ __forceinline__ void step_tail_body(const int bx, const TailArgs& A) {
   if (bx >= A.nblocks || (A.done && *A.done)) return;
   if (bx < A.g_lm) landmark_back_body(bx, A.g_lm, A.n_lm, A.dp, A.ldE, A.E, A.C, A.Cd, A.gr, A.dxc, A.s.inv_depth, A.dxl, A.invd2, A.scal, A.kmin, A.kmax);
-  else apply_step_body(bx - A.g_lm, A.n_kf, 0, A.s, A.dxc, A.dxl, A.poses2, A.vel2, A.ba2, A.bg2, A.invd2, A.scal, A.d, A.ld, A.B, A.gc, 1.0 / *A.radius);
+  else apply_step_body(bx - A.g_lm, A.n_kf, 0, A.s, A.dxc, A.dxl, A.poses2, A.vel2, A.ba2, A.bg2, A.invd2, A.scal, A.d, A.ld, A.B, A.gc, 1.0 / *A.radius, A.pose_const);
 }
 __global__ __launch_bounds__(kT) void k_step_tail(TailArgs a) { step_tail_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_step_tail_b(const TailArgs* __restrict__ t) { step_tail_body(blockIdx.x, t[blockIdx.y]); }
@@ -2309,10 +2320,10 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
     // the fields of the control block are read up front (independent requests, one wait) and written back once at the end: read and
     // written where the logic uses them they were 1.2 us of dependent traffic.  (A whole-struct copy goes through a scratch segment.)
     struct { double radius, decrease, last_radius, cost, initial_cost, cost_before, cost_after, model, dxnorm, xnorm, gmax;
-             double function_tol, gradient_tol, parameter_tol, min_rel_decrease; int max_iters, iter, successes, invalid_run, accepted, solved, done, termination; } lc;
+             double function_tol, gradient_tol, parameter_tol, min_rel_decrease; int max_iters, iter, successes, invalid_run, accepted, solved, done, termination, why, rejected; } lc;
     lc.radius = c->radius; lc.decrease = c->decrease; lc.cost = c->cost; lc.initial_cost = c->initial_cost;
     lc.function_tol = c->function_tol; lc.gradient_tol = c->gradient_tol; lc.parameter_tol = c->parameter_tol; lc.min_rel_decrease = c->min_rel_decrease;
-    lc.max_iters = c->max_iters; lc.iter = c->iter; lc.successes = c->successes; lc.invalid_run = c->invalid_run; lc.done = c->done; lc.termination = c->termination;
+    lc.max_iters = c->max_iters; lc.iter = c->iter; lc.successes = c->successes; lc.invalid_run = c->invalid_run; lc.done = c->done; lc.termination = c->termination; lc.why = c->why; lc.rejected = c->rejected;
     const int hfail = *reinterpret_cast<const int*>(A.scal + SC_FAIL);
     const double cost_before = s_sum[SC_COST / kStripes], cost_new = s_sum[SC_COST_NEW / kStripes], model = -s_sum[SC_MODEL / kStripes];
     const double dxnorm = sqrt(s_sum[SC_DXNORM / kStripes]), xnorm = sqrt(s_sum[SC_XNORM / kStripes]);
@@ -2322,43 +2333,58 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
     if (it == 0) { lc.initial_cost = cost_before; lc.cost = cost_before; }
     lc.cost_before = cost_before; lc.model = model; lc.dxnorm = dxnorm; lc.xnorm = xnorm; lc.gmax = gmax; lc.solved = solved ? 1 : 0;
     lc.last_radius = lc.radius;
-    lc.iter = it + 1;
     bool accepted = false, done = false;
-    int termination = 1;
-    // gradient tolerance: tested on the gradient at the point this iteration started from, before its step is taken
-    if (gmax <= lc.gradient_tol) { done = true; termination = 0; }
-    // parameter tolerance: a step this small ends the solve without being taken
-    else if (solved && dxnorm <= lc.parameter_tol * (xnorm + lc.parameter_tol)) { done = true; termination = 0; }
+    int termination = 1, why = LVF_WHY_MAX_ITERATIONS;
+    // ceres::Solve's TrustRegionMinimizer, in its order (declared semantics + citations: oracle/lm.h lm_solve).
+    // Top of the loop (FinalizeIterationAndCheckIfMinimizerCanContinue): the gradient at the point this pass linearised — it ends the
+    // solve before a step is taken, so the pass is NOT an iteration; the smallest trust region likewise.
+    if (gmax <= lc.gradient_tol) { done = true; termination = 0; why = LVF_WHY_GRADIENT; }
+    else if (lc.radius < 1e-32) { done = true; termination = 0; why = LVF_WHY_MIN_RADIUS; }
     else {
-      if (solved && model > 0.0) {
-        const double rho = (cost_before - cost_new) / model;
-        if (rho > lc.min_rel_decrease) {
-          accepted = true;
-          const double t = 2.0 * rho - 1.0;
-          lc.radius = fmin(lc.radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
-          lc.decrease = 2.0;
-          lc.successes += 1;
-          const double change = lc.cost - cost_new;
-          lc.cost = cost_new;
-          if (fabs(change) <= lc.function_tol * fabs(cost_before)) { done = true; termination = 0; }
+      // (num_iterations = what Ceres records in Summary::iterations: accepted, rejected and invalid steps; a trial step that ends the solve
+      // through the parameter / function tolerance returns before it is recorded)
+      const bool valid = solved && model > 0.0;      // ComputeTrustRegionStep: solver failure or model_cost_change <= 0 = INVALID step
+      if (!valid) {
+        lc.iter = it + 1;
+        lc.rejected += 1;
+        lc.invalid_run += 1;
+        if (lc.invalid_run >= 5) { done = true; termination = 2; why = LVF_WHY_INVALID_STEPS; }      // max_num_consecutive_invalid_steps
+        else lc.radius *= 0.5;                       // LevenbergMarquardtStrategy::StepIsInvalid (decrease factor untouched)
+      } else {
+        lc.invalid_run = 0;
+        // parameter tolerance, then function tolerance: both BEFORE the step-quality test, and neither takes the candidate
+        if (dxnorm <= lc.parameter_tol * (xnorm + lc.parameter_tol)) { done = true; termination = 0; why = LVF_WHY_PARAMETER; }
+        else if (fabs(cost_before - cost_new) <= lc.function_tol * cost_before) { done = true; termination = 0; why = LVF_WHY_FUNCTION; }
+        else {
+          lc.iter = it + 1;
+          const double rho = (cost_before - cost_new) / model;
+          if (rho > lc.min_rel_decrease) {
+            accepted = true;
+            const double t = 2.0 * rho - 1.0;
+            lc.radius = fmin(lc.radius / fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
+            lc.decrease = 2.0;
+            lc.successes += 1;
+            lc.cost = cost_new;
+          } else {
+            lc.radius = lc.radius / lc.decrease;
+            lc.decrease *= 2.0;
+            lc.rejected += 1;
+          }
         }
       }
-      if (!accepted) {
-        lc.radius = lc.radius / lc.decrease;
-        lc.decrease *= 2.0;
-        lc.invalid_run = solved ? 0 : lc.invalid_run + 1;
-        if (!solved && (lc.radius < 1e-32 || lc.invalid_run >= 5)) { done = true; termination = 2; }      // max_num_consecutive_invalid_steps
-      } else lc.invalid_run = 0;
+      // after the step, Finalize's order again: the iteration cap first, then the smallest trust region (the gradient at an accepted point is
+      // only known to the next pass)
+      if (!done && lc.iter >= lc.max_iters) { done = true; termination = 1; why = LVF_WHY_MAX_ITERATIONS; }
+      else if (!done && lc.radius < 1e-32) { done = true; termination = 0; why = LVF_WHY_MIN_RADIUS; }
     }
     lc.cost_after = accepted ? cost_new : (solved ? cost_new : cost_before);
     lc.accepted = accepted ? 1 : 0;
-    if (!done && lc.iter >= lc.max_iters) done = true;          // termination stays NO_CONVERGENCE
-    if (done) { lc.termination = termination; lc.done = 1; }
+    if (done) { lc.termination = termination; lc.why = why; lc.done = 1; }
     s_commit = accepted ? 1 : 0;
     c->radius = lc.radius; c->decrease = lc.decrease; c->last_radius = lc.last_radius; c->cost = lc.cost; c->initial_cost = lc.initial_cost;
     c->cost_before = lc.cost_before; c->cost_after = lc.cost_after; c->model = lc.model; c->dxnorm = lc.dxnorm; c->xnorm = lc.xnorm; c->gmax = lc.gmax;
     c->iter = lc.iter; c->successes = lc.successes; c->invalid_run = lc.invalid_run; c->accepted = lc.accepted; c->solved = lc.solved;
-    c->done = lc.done; c->termination = lc.termination;
+    c->done = lc.done; c->termination = lc.termination; c->why = lc.why; c->rejected = lc.rejected;
     s_iter = lc.iter; s_done = lc.done;
     if (A.dbg) A.dbg[3] = wall_clock64();
   }
@@ -2699,7 +2725,7 @@ static int build_chain(lvf_problem* p) {
     a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.C = p->compact ? p->Ct.p : p->C.p; a.Cd = p->Cd.p;
     a.gr = p->compact ? p->grt.p : p->gr.p; a.dxc = p->dxc.p; a.dxl = p->dxl.p; a.scal = p->scal.p;
     a.kmin = p->band_ready ? p->lm_kmin.p : nullptr; a.kmax = p->lm_kmax.p; a.n_kf = p->n_kf; a.s = s; a.poses2 = p->poses2.p; a.vel2 = p->vel2.p; a.ba2 = p->ba2.p;
-    a.bg2 = p->bg2.p; a.invd2 = p->invd2.p; a.d = p->d; a.ld = p->dpad; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.nblocks = a.g_lm + grid(p->d); a.done = done;
+    a.bg2 = p->bg2.p; a.invd2 = p->invd2.p; a.d = p->d; a.ld = p->dpad; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.nblocks = a.g_lm + grid(p->d); a.done = done; a.pose_const = p->pose_const.p;
     c.tail_lds = (size_t)p->ldE * sizeof(double);
   }
   fill_cost_visual(p, c.cost.a);
@@ -2940,7 +2966,7 @@ static void ctl_from_options(const lvf_solver_options* o, double radius, double 
   c->gradient_tol = with_tolerances ? o->gradient_tolerance : -1.0;
   c->parameter_tol = with_tolerances ? o->parameter_tolerance : -1.0;
   c->max_iters = max_iters;
-  c->termination = 1;
+  c->termination = 1; c->why = LVF_WHY_MAX_ITERATIONS;
 }
 static int upload_ctl(lvf_problem* p, const LmCtl& c) {
   if (chain_stale(p)) LVF_TRY(build_chain(p));
@@ -3496,6 +3522,9 @@ int lvf_problem_cost(lvf_problem* p, const lvf_solver_options* o, double* cost) 
   LVF_TRY(enqueue_cost(p, state_ptrs(p->st), p->st, o->huber_a, p->scal.p + SC_COST));
   double hc[kStripes];
   LVF_HIP(hipMemcpyAsync(hc, p->scal.p + SC_COST, sizeof(hc), hipMemcpyDeviceToHost, q));
+  // the stripes go back to zero: a following linearisation that trusts `accum_clean` (after a device-loop solve nothing else clears
+  // SC_COST) adds its cost into them — solve -> cost -> solve would otherwise start from a doubled cost_before
+  LVF_HIP(hipMemsetAsync(p->scal.p + SC_COST, 0, kStripes * 8, q));
   LVF_HIP(hipStreamSynchronize(q));
   *cost = stripe_sum(hc, 0);
   return LVF_OK;
@@ -3582,6 +3611,7 @@ static void summary_from_ctl(const lvf_problem* p, const LmCtl& c, lvf_solver_su
   std::memset(s, 0, sizeof(*s));
   s->num_residual_blocks = (p->tc ? p->tc->n : 0) + (p->tf ? p->tf->n : 0) + (p->po ? p->po->n : 0) + (p->imu ? p->imu->n : 0) + (p->prior ? p->prior->n : 0);
   s->initial_cost = c.initial_cost; s->final_cost = c.cost; s->num_iterations = c.iter; s->num_successful_steps = c.successes; s->termination = c.termination;
+  s->num_unsuccessful_steps = c.rejected; s->termination_reason = c.why;
 }
 
 // The device LM loop: iterations are enqueued back to back, each closed on device (k_lm_decide); the host only watches a mirror of the
@@ -3601,16 +3631,18 @@ int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_su
   }
   LVF_TRY(upload_ctl(p, c));
   const auto wall0 = std::chrono::steady_clock::now();
+  bool timed_out = false;
   for (int it = 0; it < o->max_num_iterations; ++it) {
     LVF_TRY(enqueue_iteration(p, true));
     if (it >= 1) LVF_TRY(wait_for_iteration(p, it));          // iteration it-1 is closed; iteration `it` keeps the device busy meanwhile
     if (p->rec->done) break;
     if (o->max_solver_time_in_seconds > 0.0 &&
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) break;
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) { timed_out = true; break; }
   }
   LVF_TRY(download_ctl(p, &c));
   p->last_radius = c.last_radius;
   summary_from_ctl(p, c, summary);
+  if (timed_out && !c.done) summary->termination_reason = LVF_WHY_TIME;
   return LVF_OK;
 }
 

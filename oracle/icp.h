@@ -55,8 +55,10 @@ inline void icp_solve(const float* map, int M, int mstride, const float* query, 
   auto clampd = [](double v) { return std::fmin(std::fmax(v, 1e-6), 1e32); };
   double radius = 1e4, decrease = 2.0, cost = 0.0;
   out->iters = 0; out->successes = 0; out->nres = nv + (prior_w > 0.0 ? 1 : 0);
-  bool first = true, done = false;
-  for (int it = 0; it < std::max(1, max_iters) && !done; ++it) {
+  // the loop of ceres::Solve (DENSE_QR, mapping.cpp:159-163), in TrustRegionMinimizer's order — see lm.h lm_solve for the declared semantics
+  bool first = true;
+  int invalid_run = 0;
+  for (;;) {
     double H[3][3] = {}, g[3] = {};
     cost = 0.0;
     for (int i = 0; i < nv; ++i) {
@@ -70,8 +72,9 @@ inline void icp_solve(const float* map, int M, int mstride, const float* query, 
     }
     if (prior_w > 0.0) for (int k = 0; k < 3; ++k) { H[k][k] += w2; g[k] += w2 * (x[k] - x0[k]); cost += 0.5 * w2 * (x[k] - x0[k]) * (x[k] - x0[k]); }
     if (first) { out->initial_cost = cost; first = false; }
+    if (out->iters >= max_iters) break;
     if (std::fmax(std::fabs(g[0]), std::fmax(std::fabs(g[1]), std::fabs(g[2]))) <= 1e-10) break;
-    if (max_iters == 0) break;
+    if (radius < 1e-32) break;
     double A[3][3], D[3];
     for (int u = 0; u < 3; ++u) { D[u] = clampd(H[u][u]) / radius; for (int v = 0; v < 3; ++v) A[u][v] = H[u][v]; A[u][u] += D[u]; }
     // 3x3 Cholesky solve A dx = -g
@@ -83,27 +86,29 @@ inline void icp_solve(const float* map, int M, int mstride, const float* query, 
     if (ok) {
       const double y0 = -g[0] / l00, y1 = (-g[1] - l10 * y0) / l11, y2 = (-g[2] - l20 * y0 - l21 * y1) / l22;
       dx[2] = y2 / l22; dx[1] = (y1 - l21 * dx[2]) / l11; dx[0] = (y0 - l10 * dx[1] - l20 * dx[2]) / l00;
+      ok = std::isfinite(dx[0]) && std::isfinite(dx[1]) && std::isfinite(dx[2]);
     }
     double model = 0.0;
     for (int u = 0; u < 3; ++u) { double hd = 0; for (int v = 0; v < 3; ++v) hd += H[u][v] * dx[v]; model -= dx[u] * (g[u] + 0.5 * hd); }
     const double xc[3] = {x[0] + dx[0], x[1] + dx[1], x[2] + dx[2]};
-    const double dn = std::sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]), xn = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    if (ok && dn <= 1e-8 * (xn + 1e-8)) break;
-    const double cand = cost_at(xc);
-    out->iters += 1;
-    bool accepted = false;
-    if (ok && model > 0.0) {
-      const double rho = (cost - cand) / model;
-      if (rho > 1e-3) {
-        accepted = true;
-        const double change = cost - cand, before = cost;
-        x[0] = xc[0]; x[1] = xc[1]; x[2] = xc[2]; cost = cand; out->successes += 1;
-        const double t = 2.0 * rho - 1.0;
-        radius = std::fmin(radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16); decrease = 2.0;
-        if (std::fabs(change) <= 1e-6 * std::fabs(before)) done = true;
-      }
+    const double cand = (ok && model > 0.0) ? cost_at(xc) : cost;
+    if (!(ok && model > 0.0 && std::isfinite(cand))) {          // invalid step
+      out->iters += 1;
+      if (++invalid_run >= 5) break;
+      radius *= 0.5;
+      continue;
     }
-    if (!accepted) { radius /= decrease; decrease *= 2.0; if (radius < 1e-32) done = true; }
+    invalid_run = 0;
+    const double dn = std::sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]), xn = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    if (dn <= 1e-8 * (xn + 1e-8)) break;                            // parameter tolerance: the candidate is not taken
+    if (std::fabs(cost - cand) <= 1e-6 * cost) break;              // function tolerance, BEFORE the step-quality test: not taken either
+    out->iters += 1;
+    const double rho = (cost - cand) / model;
+    if (rho > 1e-3) {
+      x[0] = xc[0]; x[1] = xc[1]; x[2] = xc[2]; cost = cand; out->successes += 1;
+      const double t = 2.0 * rho - 1.0;
+      radius = std::fmin(radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16); decrease = 2.0;
+    } else { radius /= decrease; decrease *= 2.0; }
   }
   out->final_cost = cost;
   rpyxyz[i0] = x[0]; rpyxyz[i1] = x[1]; rpyxyz[i2] = x[2];

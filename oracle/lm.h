@@ -12,7 +12,8 @@
 //     step solves (H + D^2 / radius) dx = -g exactly, eliminating the 1x1 inverse-depth blocks first (Schur);
 //   * model_cost_change = -dx^T (g + H dx / 2); rho = (cost - cost_new) / model_cost_change;
 //     accept iff rho > min_relative_decrease (1e-3): radius /= max(1/3, 1 - (2 rho - 1)^3), decrease_factor = 2;
-//     else radius /= decrease_factor, decrease_factor *= 2.   (Jacobi column scaling is algebraically a no-op here.)
+//     else radius /= decrease_factor, decrease_factor *= 2; an INVALID step (solver failure or model_cost_change <= 0): radius *= 0.5.
+//     (Jacobi column scaling is algebraically a no-op here.)  The whole loop with Ceres' termination order: lm_solve below.
 // Unknown ordering of the reduced (camera) system, d = 15 n_kf:
 //   [ pose tangent 6 x n_kf (keyframe-major) | (v 3, ba 3, bg 3) x n_kf ].
 #pragma once
@@ -243,6 +244,7 @@ inline bool chol_solve(std::vector<double>& S, std::vector<double>& b, int d) {
 
 struct LmStep {
   double cost_before, cost_after, model_cost_change, rho;
+  double gradient_max_norm, step_norm, x_norm;
   bool accepted, solved;
   std::vector<double> S, rhs;   // reduced system actually solved (damped), for parity taps
   std::vector<double> dx_c, dx_l;
@@ -260,11 +262,14 @@ inline void apply_step(const Window& w, const std::vector<double>& dc, const std
   for (int l = 0; l < w.n_lm; ++l) inv_depth[l] = w.inv_depth[l] + dl[l];
 }
 
-inline void lm_iteration(Window& w, double huber_a, double min_relative_decrease, double* radius, double* decrease_factor, LmStep& out) {
+// The trial step of one LM iteration at trust-region radius `radius`: linearise, damp, Schur-eliminate, solve, back-substitute, model
+// cost change, candidate state and its cost.  Nothing is committed.  cand_* receive the candidate (sizes 7/3/3/3 n_kf, n_lm).
+inline void lm_trial_step(const Window& w, double huber_a, double radius, LmStep& out, std::vector<double>& np, std::vector<double>& nv,
+                          std::vector<double>& nba, std::vector<double>& nbg, std::vector<double>& nd) {
   Linearization L;
   window_linearize(w, huber_a, L);
   const int d = L.d, dp = L.dp, nl = w.n_lm;
-  const double mu = *radius;
+  const double mu = radius;
   auto clampd = [](double v) { return std::fmin(std::fmax(v, 1e-6), 1e32); };
   std::vector<double> Dc(d), Dl(nl), Cd(nl);
   for (int i = 0; i < d; ++i) Dc[i] = clampd(L.B[(size_t)i * d + i]) / mu;
@@ -286,46 +291,151 @@ inline void lm_iteration(Window& w, double huber_a, double min_relative_decrease
   }
   std::vector<double> Sf = out.S, dc = out.rhs;
   out.cost_before = L.cost;
+  // gradient max norm at the linearisation point: max |J^T r| over every unknown (tangent coordinates; constant poses contribute 0)
+  out.gradient_max_norm = 0.0;
+  for (int i = 0; i < d; ++i) out.gradient_max_norm = std::fmax(out.gradient_max_norm, std::fabs(L.gc[i]));
+  for (int l = 0; l < nl; ++l) out.gradient_max_norm = std::fmax(out.gradient_max_norm, std::fabs(L.gr[l]));
   out.solved = chol_solve(Sf, dc, d);
-  out.accepted = false; out.cost_after = L.cost; out.model_cost_change = 0; out.rho = 0;
-  if (out.solved) {
-    std::vector<double> dl(nl);
-    for (int l = 0; l < nl; ++l) {
-      const double* e = &L.E[(size_t)l * dp];
-      double s = -L.gr[l];
-      for (int i = 0; i < dp; ++i) if (e[i] != 0.0) s -= e[i] * dc[i];
-      dl[l] = s / Cd[l];
-    }
-    // model cost change = -dx^T (g + H dx / 2), H undamped
-    double m = 0.0;
-    for (int i = 0; i < d; ++i) {
-      double hb = 0; for (int j = 0; j < d; ++j) hb += L.B[(size_t)i * d + j] * dc[j];
-      m += dc[i] * (L.gc[i] + 0.5 * hb);
-    }
-    for (int l = 0; l < nl; ++l) {
-      const double* e = &L.E[(size_t)l * dp];
-      double ed = 0; for (int i = 0; i < dp; ++i) if (e[i] != 0.0) ed += e[i] * dc[i];
-      m += dl[l] * (L.gr[l] + 0.5 * L.C[l] * dl[l]) + dl[l] * ed;   // cross term counted once (E dc . dl), twice halves
-    }
-    out.model_cost_change = -m;
-    std::vector<double> np(7 * w.n_kf), nv(3 * w.n_kf), nba(3 * w.n_kf), nbg(3 * w.n_kf), nd(nl);
-    apply_step(w, dc, dl, np.data(), nv.data(), nba.data(), nbg.data(), nd.data());
-    out.cost_after = window_cost(w, huber_a, np.data(), nv.data(), nba.data(), nbg.data(), nd.data());
-    out.rho = out.model_cost_change > 0 ? (out.cost_before - out.cost_after) / out.model_cost_change : -1.0;
-    out.dx_c = dc; out.dx_l = dl;
-    if (out.rho > min_relative_decrease) {
-      out.accepted = true;
-      std::memcpy(w.poses, np.data(), np.size() * 8); std::memcpy(w.vel, nv.data(), nv.size() * 8);
-      std::memcpy(w.ba, nba.data(), nba.size() * 8); std::memcpy(w.bg, nbg.data(), nbg.size() * 8);
-      std::memcpy(w.inv_depth, nd.data(), nd.size() * 8);
-      const double t = 2.0 * out.rho - 1.0;
-      *radius = std::fmin(*radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
-      *decrease_factor = 2.0;
-      return;
+  out.accepted = false; out.cost_after = L.cost; out.model_cost_change = 0; out.rho = 0; out.step_norm = 0; out.x_norm = 0;
+  if (!out.solved) return;
+  std::vector<double> dl(nl);
+  for (int l = 0; l < nl; ++l) {
+    const double* e = &L.E[(size_t)l * dp];
+    double s = -L.gr[l];
+    for (int i = 0; i < dp; ++i) if (e[i] != 0.0) s -= e[i] * dc[i];
+    dl[l] = s / Cd[l];
+  }
+  // model cost change = -dx^T (g + H dx / 2), H undamped
+  double m = 0.0;
+  for (int i = 0; i < d; ++i) {
+    double hb = 0; for (int j = 0; j < d; ++j) hb += L.B[(size_t)i * d + j] * dc[j];
+    m += dc[i] * (L.gc[i] + 0.5 * hb);
+  }
+  for (int l = 0; l < nl; ++l) {
+    const double* e = &L.E[(size_t)l * dp];
+    double ed = 0; for (int i = 0; i < dp; ++i) if (e[i] != 0.0) ed += e[i] * dc[i];
+    m += dl[l] * (L.gr[l] + 0.5 * L.C[l] * dl[l]) + dl[l] * ed;   // cross term counted once (E dc . dl), twice halves
+  }
+  out.model_cost_change = -m;
+  np.assign(7 * w.n_kf, 0.0); nv.assign(3 * w.n_kf, 0.0); nba.assign(3 * w.n_kf, 0.0); nbg.assign(3 * w.n_kf, 0.0); nd.assign(nl, 0.0);
+  apply_step(w, dc, dl, np.data(), nv.data(), nba.data(), nbg.data(), nd.data());
+  out.cost_after = window_cost(w, huber_a, np.data(), nv.data(), nba.data(), nbg.data(), nd.data());
+  out.rho = out.model_cost_change > 0 ? (out.cost_before - out.cost_after) / out.model_cost_change : -1.0;
+  out.dx_c = dc; out.dx_l = dl;
+  // Ceres: step_norm = |x - x_plus_delta| and x_norm = |x| over the AMBIENT parameter vector of the reduced program (constant blocks
+  // are not in it).  Window state: poses of the non-constant keyframes, v / ba / bg of every keyframe, every inverse depth.
+  double sn = 0.0, xn = 0.0;
+  for (int k = 0; k < w.n_kf; ++k) {
+    if (!(w.pose_const && w.pose_const[k]))
+      for (int c = 0; c < 7; ++c) { const double a = w.poses[7 * k + c], b = np[7 * k + c]; sn += (a - b) * (a - b); xn += a * a; }
+    for (int c = 0; c < 3; ++c) {
+      sn += (w.vel[3 * k + c] - nv[3 * k + c]) * (w.vel[3 * k + c] - nv[3 * k + c]) + (w.ba[3 * k + c] - nba[3 * k + c]) * (w.ba[3 * k + c] - nba[3 * k + c]) +
+            (w.bg[3 * k + c] - nbg[3 * k + c]) * (w.bg[3 * k + c] - nbg[3 * k + c]);
+      xn += w.vel[3 * k + c] * w.vel[3 * k + c] + w.ba[3 * k + c] * w.ba[3 * k + c] + w.bg[3 * k + c] * w.bg[3 * k + c];
     }
   }
-  *radius = *radius / *decrease_factor;
-  *decrease_factor *= 2.0;
+  for (int l = 0; l < nl; ++l) { sn += (w.inv_depth[l] - nd[l]) * (w.inv_depth[l] - nd[l]); xn += w.inv_depth[l] * w.inv_depth[l]; }
+  out.step_norm = std::sqrt(sn); out.x_norm = std::sqrt(xn);
+}
+
+inline void commit(Window& w, const std::vector<double>& np, const std::vector<double>& nv, const std::vector<double>& nba,
+                   const std::vector<double>& nbg, const std::vector<double>& nd) {
+  std::memcpy(w.poses, np.data(), np.size() * 8); std::memcpy(w.vel, nv.data(), nv.size() * 8);
+  std::memcpy(w.ba, nba.data(), nba.size() * 8); std::memcpy(w.bg, nbg.data(), nbg.size() * 8);
+  std::memcpy(w.inv_depth, nd.data(), nd.size() * 8);
+}
+
+// LevenbergMarquardtStrategy's three radius updates (upstream levenberg_marquardt_strategy.cc, restated)
+inline void radius_step_accepted(double rho, double* radius, double* decrease_factor) {
+  const double t = 2.0 * rho - 1.0;
+  *radius = std::fmin(*radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);      // max_trust_region_radius 1e16
+  *decrease_factor = 2.0;
+}
+inline void radius_step_rejected(double* radius, double* decrease_factor) { *radius = *radius / *decrease_factor; *decrease_factor *= 2.0; }
+inline void radius_step_invalid(double* radius) { *radius *= 0.5; }      // StepIsInvalid: decrease_factor untouched
+
+// One iteration with the radius handed in (no termination tests): the per-iteration parity point of lvf_problem_lm_iteration.
+inline void lm_iteration(Window& w, double huber_a, double min_relative_decrease, double* radius, double* decrease_factor, LmStep& out) {
+  std::vector<double> np, nv, nba, nbg, nd;
+  lm_trial_step(w, huber_a, *radius, out, np, nv, nba, nbg, nd);
+  const bool valid = out.solved && out.model_cost_change > 0.0;
+  if (!valid) { radius_step_invalid(radius); return; }
+  if (out.rho > min_relative_decrease) {
+    out.accepted = true;
+    commit(w, np, nv, nba, nbg, nd);
+    radius_step_accepted(out.rho, radius, decrease_factor);
+    return;
+  }
+  radius_step_rejected(radius, decrease_factor);
+}
+
+// ---- the whole solve: ceres::Solve's TrustRegionMinimizer loop, restated ------------------------------------------------------------
+// (what adapt::Solve runs: backend.cpp:206-211, mapping.cpp:159-163.  Ceres is un-vendored; DECLARED from upstream
+// trust_region_minimizer.cc, in its order:)
+//   IterationZero: evaluate; gradient_max_norm <= gradient_tolerance -> CONVERGENCE.
+//   loop, at the top (FinalizeIterationAndCheckIfMinimizerCanContinue): iterations >= max_num_iterations -> NO_CONVERGENCE;
+//     gradient_max_norm <= gradient_tolerance -> CONVERGENCE; radius < min_trust_region_radius (1e-32) -> CONVERGENCE;
+//   ComputeTrustRegionStep: linear solver failure or model_cost_change <= 0 -> INVALID step: max_num_consecutive_invalid_steps (5) in a
+//     row -> FAILURE, else radius *= 0.5 and the iteration counts as unsuccessful;
+//   candidate = x [+] delta; step_norm <= parameter_tolerance (x_norm + parameter_tolerance) -> CONVERGENCE (candidate NOT taken);
+//   candidate cost; |cost - candidate_cost| <= function_tolerance * cost -> CONVERGENCE (candidate NOT taken; tested BEFORE acceptance);
+//   relative_decrease > min_relative_decrease -> accept (x = candidate, re-linearise, StepAccepted) else StepRejected.
+struct SolveOptions {
+  int max_num_iterations; double huber_a, initial_trust_region_radius, function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease;
+};
+enum { LVO_CONVERGENCE = 0, LVO_NO_CONVERGENCE = 1, LVO_FAILURE = 2 };
+enum { LVO_WHY_NONE = 0, LVO_WHY_GRADIENT = 1, LVO_WHY_PARAMETER = 2, LVO_WHY_FUNCTION = 3, LVO_WHY_MIN_RADIUS = 4, LVO_WHY_MAX_ITERATIONS = 5, LVO_WHY_INVALID_STEPS = 6 };
+struct SolveSummary {
+  double initial_cost, final_cost, final_radius, final_decrease_factor;
+  int num_iterations, num_successful_steps, num_unsuccessful_steps, termination, why, num_trials;
+};
+// trace (optional): per TRIAL step [cost_before, cost_after, radius used, accepted, valid, rho] (6 doubles), at most max_num_iterations + 1 rows
+inline void lm_solve(Window& w, const SolveOptions& o, SolveSummary& s, double* trace = nullptr) {
+  double radius = o.initial_trust_region_radius, decrease = 2.0;
+  std::memset(&s, 0, sizeof(s));
+  s.termination = LVO_NO_CONVERGENCE; s.why = LVO_WHY_MAX_ITERATIONS;
+  int invalid_run = 0, n_trials = 0;
+  bool have_cost = false;
+  double cost = 0.0;
+  LmStep st;
+  std::vector<double> np, nv, nba, nbg, nd;
+  for (;;) {
+    // (the trial step re-linearises at x: after a rejected step that reproduces the previous linearisation — Ceres keeps it)
+    lm_trial_step(w, o.huber_a, radius, st, np, nv, nba, nbg, nd);
+    if (!have_cost) { s.initial_cost = st.cost_before; have_cost = true; }
+    cost = st.cost_before;
+    if (s.num_iterations >= o.max_num_iterations) { s.termination = LVO_NO_CONVERGENCE; s.why = LVO_WHY_MAX_ITERATIONS; break; }   // (<= 0: only the initial cost)
+    if (st.gradient_max_norm <= o.gradient_tolerance) { s.termination = LVO_CONVERGENCE; s.why = LVO_WHY_GRADIENT; break; }
+    if (radius < 1e-32) { s.termination = LVO_CONVERGENCE; s.why = LVO_WHY_MIN_RADIUS; break; }
+    // num_iterations counts what Ceres pushes to Summary::iterations beyond iteration 0: accepted, rejected and invalid steps.  A trial
+    // step that ends the solve through the parameter / function tolerance returns before it is recorded.
+    double* tr = trace ? trace + 6 * n_trials : nullptr;
+    n_trials += 1;
+    const bool valid = st.solved && st.model_cost_change > 0.0;
+    if (tr) { tr[0] = st.cost_before; tr[1] = st.cost_after; tr[2] = radius; tr[3] = 0; tr[4] = valid ? 1 : 0; tr[5] = st.rho; }
+    if (!valid) {
+      s.num_iterations += 1; s.num_unsuccessful_steps += 1;
+      if (++invalid_run >= 5) { s.termination = LVO_FAILURE; s.why = LVO_WHY_INVALID_STEPS; break; }
+      radius_step_invalid(&radius);
+      continue;
+    }
+    invalid_run = 0;
+    if (st.step_norm <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) { s.termination = LVO_CONVERGENCE; s.why = LVO_WHY_PARAMETER; break; }
+    if (std::fabs(st.cost_before - st.cost_after) <= o.function_tolerance * st.cost_before) { s.termination = LVO_CONVERGENCE; s.why = LVO_WHY_FUNCTION; break; }
+    s.num_iterations += 1;
+    if (st.rho > o.min_relative_decrease) {
+      commit(w, np, nv, nba, nbg, nd);
+      cost = st.cost_after;
+      radius_step_accepted(st.rho, &radius, &decrease);
+      s.num_successful_steps += 1;
+      if (tr) tr[3] = 1;
+    } else {
+      radius_step_rejected(&radius, &decrease);
+      s.num_unsuccessful_steps += 1;
+    }
+  }
+  s.num_trials = n_trials;
+  s.final_cost = cost; s.final_radius = radius; s.final_decrease_factor = decrease;
 }
 
 }  // namespace lvo

@@ -33,8 +33,10 @@ inline void relocate_rotation_solve(int n, const double* relocated, const double
   double q[4] = {q4[0], q4[1], q4[2], q4[3]};
   double radius = radius0, decrease = 2.0, cost = 0.0;
   out->iters = 0; out->successes = 0; out->termination = 1;
-  bool first = true, done = false;
-  for (int it = 0; it < std::max(1, max_iters) && !done; ++it) {
+  // ceres::Solve's TrustRegionMinimizer order (declared in lm.h lm_solve)
+  bool first = true;
+  int invalid_run = 0;
+  for (;;) {
     double H[3][3] = {}, g[3] = {};
     cost = 0.0;
     double P[12];
@@ -51,8 +53,9 @@ inline void relocate_rotation_solve(int n, const double* relocated, const double
       }
     }
     if (first) { out->initial_cost = cost; first = false; }
+    if (out->iters >= max_iters) break;                               // NO_CONVERGENCE (termination stays 1)
     if (std::fmax(std::fabs(g[0]), std::fmax(std::fabs(g[1]), std::fabs(g[2]))) <= gradient_tol) { out->termination = 0; break; }
-    if (max_iters == 0) break;
+    if (radius < 1e-32) { out->termination = 0; break; }              // "minimum trust region radius reached" is a CONVERGENCE in Ceres
     double A[3][3], D[3];
     for (int u = 0; u < 3; ++u) { D[u] = clampd(H[u][u]) / radius; for (int v = 0; v < 3; ++v) A[u][v] = H[u][v]; A[u][u] += D[u]; }
     const double l00 = std::sqrt(A[0][0]), l10 = A[1][0] / l00, l20 = A[2][0] / l00;
@@ -68,24 +71,26 @@ inline void relocate_rotation_solve(int n, const double* relocated, const double
     for (int u = 0; u < 3; ++u) { double hd = 0; for (int v = 0; v < 3; ++v) hd += H[u][v] * dx[v]; model -= dx[u] * (g[u] + 0.5 * hd); }
     double qc[4];
     eigen_quat_plus(q, dx, qc);
-    const double dn = std::sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]), xn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    if (ok && dn <= parameter_tol * (xn + parameter_tol)) { out->termination = 0; break; }
-    const double cand = cost_at(qc);
-    out->iters += 1;
-    bool accepted = false;
-    if (ok && model > 0.0) {
-      const double rho = (cost - cand) / model;
-      if (rho > min_rel_decrease) {
-        accepted = true;
-        const double change = cost - cand, before = cost;
-        for (int k = 0; k < 4; ++k) q[k] = qc[k];
-        cost = cand; out->successes += 1;
-        const double t = 2.0 * rho - 1.0;
-        radius = std::fmin(radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16); decrease = 2.0;
-        if (std::fabs(change) <= function_tol * std::fabs(before)) { done = true; out->termination = 0; }
-      }
+    if (!(ok && model > 0.0)) {                                        // invalid step
+      out->iters += 1;
+      if (++invalid_run >= 5) { out->termination = 2; break; }
+      radius *= 0.5;
+      continue;
     }
-    if (!accepted) { radius /= decrease; decrease *= 2.0; if (radius < 1e-32) { done = true; out->termination = 2; } }
+    invalid_run = 0;
+    double d2 = 0.0; for (int k = 0; k < 4; ++k) d2 += (qc[k] - q[k]) * (qc[k] - q[k]);          // |x - x_plus_delta|, ambient
+    const double dn = std::sqrt(d2), xn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (dn <= parameter_tol * (xn + parameter_tol)) { out->termination = 0; break; }
+    const double cand = cost_at(qc);
+    if (std::fabs(cost - cand) <= function_tol * cost) { out->termination = 0; break; }           // before the step-quality test; candidate not taken
+    out->iters += 1;
+    const double rho = (cost - cand) / model;
+    if (rho > min_rel_decrease) {
+      for (int k = 0; k < 4; ++k) q[k] = qc[k];
+      cost = cand; out->successes += 1;
+      const double t = 2.0 * rho - 1.0;
+      radius = std::fmin(radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16); decrease = 2.0;
+    } else { radius /= decrease; decrease *= 2.0; }
   }
   out->final_cost = cost;
   for (int k = 0; k < 4; ++k) q4[k] = q[k];

@@ -336,6 +336,19 @@ void lvo_window_lm_iteration(lvo_window_c* c, double huber_a, double min_relativ
   if (rhs) std::memcpy(rhs, st.rhs.data(), st.rhs.size() * 8);
 }
 
+// The whole solve (lm.h lm_solve: Ceres' TrustRegionMinimizer loop restated).  opts7 = {max_num_iterations, huber_a, initial radius,
+// function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease}; out9 = {initial_cost, final_cost, num_iterations,
+// num_successful_steps, num_unsuccessful_steps, termination, why, final_radius, final_decrease_factor, num_trials}; trace (may be null): 6 doubles
+// per trial step, max_num_iterations + 1 rows.  The state arrays inside c are updated in place.
+void lvo_window_solve(lvo_window_c* c, const double* opts7, double* out9 /* 10 values */, double* trace) {
+  Window w; std::vector<imu::Preint> pre; to_window(c, w, pre);
+  SolveOptions o{(int)opts7[0], opts7[1], opts7[2], opts7[3], opts7[4], opts7[5], opts7[6]};
+  SolveSummary s;
+  lm_solve(w, o, s, trace);
+  out9[0] = s.initial_cost; out9[1] = s.final_cost; out9[2] = s.num_iterations; out9[3] = s.num_successful_steps; out9[4] = s.num_unsuccessful_steps;
+  out9[5] = s.termination; out9[6] = s.why; out9[7] = s.final_radius; out9[8] = s.final_decrease_factor; out9[9] = s.num_trials;
+}
+
 // ---------------- scan-to-map sub-problem ----------------
 // out5 = {initial_cost, final_cost, num_residual_blocks, iterations, successful steps}; rpyxyz updated in place
 void lvo_icp_solve(const float* map, int M, int mstride, const float* query, int Q, int qstride, const double* map_pose,

@@ -442,3 +442,17 @@ class Window:
                                       _p(out6), _p(S), _p(rhs))
         return dict(cost_before=out6[0], cost_after=out6[1], model_cost_change=out6[2], rho=out6[3], accepted=bool(out6[4]),
                     solved=bool(out6[5]), radius=r.value, decrease_factor=dfac.value, S=S, rhs=rhs)
+
+    WHY = ("none", "gradient_tolerance", "parameter_tolerance", "function_tolerance", "min_trust_region_radius", "max_num_iterations", "consecutive_invalid_steps")
+
+    def solve(self, max_num_iterations=50, huber_a=1.0, initial_trust_region_radius=1e4, function_tolerance=1e-6, gradient_tolerance=1e-10,
+              parameter_tolerance=1e-8, min_relative_decrease=1e-3):
+        """ceres::Solve's TrustRegionMinimizer loop restated (oracle/lm.h lm_solve): chained trial steps with ITS radius / decrease factor
+        and Ceres' termination order.  The state arrays of this Window are updated in place.  trace rows: (cost_before, cost_after,
+        radius used, accepted, valid, rho)."""
+        opts = _f64([max_num_iterations, huber_a, initial_trust_region_radius, function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease])
+        out = np.zeros(10); trace = np.zeros((max(0, int(max_num_iterations)) + 1, 6))
+        lib().lvo_window_solve(C.byref(self.c), _p(opts), _p(out), _p(trace))
+        n = int(out[9])
+        return dict(initial_cost=out[0], final_cost=out[1], num_iterations=int(out[2]), num_successful_steps=int(out[3]), num_unsuccessful_steps=int(out[4]),
+                    termination=int(out[5]), why=self.WHY[int(out[6])], final_radius=out[7], final_decrease_factor=out[8], trace=trace[:n])

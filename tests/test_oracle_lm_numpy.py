@@ -160,31 +160,38 @@ def test_icp_solve_matches_numpy_lm(oracle, mode, huber_a, prior_w):
         if prior_w > 0:      # PoseErrorRPZ / YXY: weight * (x - x0), identity Jacobian up to the row order (irrelevant for J^T J)
             Jr[len(r):] = prior_w * np.eye(3); rr[len(r):] = prior_w * (xx[sl] - x0); c += 0.5 * rr[len(r):] @ rr[len(r):]
         return Jr, rr, c
-    radius, dec, iters, succ = 1e4, 2.0, 0, 0
+    # ceres::Solve's TrustRegionMinimizer order (declared in oracle/lm.h lm_solve): the iteration cap, the gradient and the smallest radius
+    # at the top; invalid step -> radius / 2; parameter then function tolerance BEFORE the step-quality test (the candidate is not taken)
+    radius, dec, iters, succ, invalid = 1e4, 2.0, 0, 0, 0
     first_cost = None
-    for it in range(4):
+    while True:
         J, r, cost = lin(x)
         first_cost = cost if first_cost is None else first_cost
         H, g = J.T @ J, J.T @ r
-        if np.abs(g).max() <= 1e-10:
+        if iters >= 4 or np.abs(g).max() <= 1e-10 or radius < 1e-32:
             break
         D = np.minimum(np.maximum(np.diag(H), 1e-6), 1e32) / radius
         dx = np.linalg.solve(H + np.diag(D), -g)
         model = -dx @ (g + 0.5 * H @ dx)
+        if not model > 0:
+            iters += 1; invalid += 1
+            if invalid >= 5:
+                break
+            radius *= 0.5
+            continue
+        invalid = 0
         if np.linalg.norm(dx) <= 1e-8 * (np.linalg.norm(x[sl]) + 1e-8):
             break
         xc = x.copy(); xc[sl] += dx
         cand = lin(xc)[2]
+        if abs(cost - cand) <= 1e-6 * cost:
+            break
         iters += 1
-        rho = (cost - cand) / model if model > 0 else -1
+        rho = (cost - cand) / model
         if rho > 1e-3:
             t = 2 * rho - 1
             radius = min(radius / max(1 / 3, 1 - t ** 3), 1e16); dec = 2.0
             x = xc; succ += 1
-            if abs(cost - cand) <= 1e-6 * abs(cost):
-                cost = cand
-                break
-            cost = cand
         else:
             radius /= dec; dec *= 2
     assert summ["num_residual_blocks"] == int(v.sum()) + (1 if prior_w > 0 else 0)
@@ -192,3 +199,67 @@ def test_icp_solve_matches_numpy_lm(oracle, mode, huber_a, prior_w):
     assert abs(summ["initial_cost"] - first_cost) <= 1e-9 * first_cost
     assert np.abs(x_ref - x).max() <= 1e-9
     assert abs(summ["final_cost"] - lin(x)[2]) <= 1e-8 * max(first_cost, 1e-12)
+
+
+def _window(oracle, n_kf=8, n_lm=300, seed=5, perturb=1.0):
+    cfg = syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=60, seed=seed, imu_samples=5)
+    if perturb != 1.0:
+        rng = np.random.default_rng(seed + 1000)
+        cfg = dict(cfg)
+        cfg["poses"] = syn.perturb_poses(cfg["poses"], rng, 0.5 * perturb, 0.05 * perturb)
+        cfg["inv_depth"] = cfg["inv_depth"] * (1 + rng.normal(0, 0.05 * min(perturb, 8.0), cfg["inv_depth"].shape))
+    pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+    return cfg, pre
+
+
+@pytest.mark.parametrize("perturb,radius", [(1.0, 1e4), (20.0, 1e16)])
+def test_solve_loop_is_the_chain_of_iterations(oracle, perturb, radius):
+    """oracle.Window.solve (ceres::Solve's loop restated, the reference of the device-resident LM loop) == lm_iteration chained with the
+    radius / decrease factor each iteration hands on — including runs of rejected steps (radius / decrease_factor, factor doubling)."""
+    cfg, pre = _window(oracle, perturb=perturb)
+    a, b = oracle.Window(cfg, pre), oracle.Window(cfg, pre)
+    K = 25
+    s = a.solve(max_num_iterations=K, initial_trust_region_radius=radius, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    assert s["num_iterations"] == K and s["why"] == "max_num_iterations" and s["termination"] == 1
+    r, d, acc = radius, 2.0, []
+    for k in range(K):
+        o = b.lm_iteration(r, d)
+        close = lambda x, y: abs(x - y) <= 1e-11 * abs(y)           # (OpenMP reductions: the cost sums are not bit-reproducible run to run)
+        assert close(o["cost_before"], s["trace"][k, 0]) and close(o["cost_after"], s["trace"][k, 1]) and close(r, s["trace"][k, 2]) and o["accepted"] == bool(s["trace"][k, 3])
+        acc.append(o["accepted"]); r, d = o["radius"], o["decrease_factor"]
+    assert s["num_successful_steps"] == sum(acc) and s["num_unsuccessful_steps"] == K - sum(acc)
+    assert abs(r - s["final_radius"]) <= 1e-9 * r and d == s["final_decrease_factor"]
+    for k in ("poses", "vel", "ba", "bg", "inv_depth"):
+        assert np.allclose(getattr(a, k), getattr(b, k), rtol=1e-9, atol=1e-12)
+    if perturb > 1.0:
+        assert K - sum(acc) >= 2, "the far start is there to exercise rejected steps"
+        # decrease_factor doubles through a run of rejections and resets to 2 on acceptance
+        rej = [i for i, x in enumerate(acc) if not x]
+        i0 = rej[0]
+        assert i0 + 1 >= K or s["trace"][i0 + 1, 2] == s["trace"][i0, 2] / 2.0
+        if i0 + 2 < K and not acc[i0 + 1]:
+            assert s["trace"][i0 + 2, 2] == s["trace"][i0 + 1, 2] / 4.0
+
+
+def test_solve_termination_order(oracle):
+    cfg, pre = _window(oracle, n_lm=200, seed=77)
+    W = lambda: oracle.Window(cfg, pre)
+    c0 = W().cost()
+    s = W().solve(max_num_iterations=0)
+    assert (s["num_iterations"], s["why"], s["termination"]) == (0, "max_num_iterations", 1) and s["initial_cost"] == s["final_cost"] and abs(s["initial_cost"] - c0) <= 1e-12 * c0
+    s = W().solve(max_num_iterations=50, gradient_tolerance=1e30)
+    assert (s["num_iterations"], s["why"], s["termination"]) == (0, "gradient_tolerance", 0)
+    s = W().solve(max_num_iterations=50, initial_trust_region_radius=1e-33)
+    assert (s["num_iterations"], s["why"]) == (0, "min_trust_region_radius")
+    w = W(); p0 = w.poses.copy()
+    s = w.solve(max_num_iterations=50, parameter_tolerance=1e3)
+    assert (s["num_iterations"], s["why"]) == (0, "parameter_tolerance") and np.array_equal(w.poses, p0) and len(s["trace"]) == 1
+    # function tolerance is tested BEFORE the acceptance test and the candidate is not taken: the final cost is the cost BEFORE the last trial
+    w = W()
+    s = w.solve(max_num_iterations=50, function_tolerance=1e-3)
+    assert s["why"] == "function_tolerance" and s["termination"] == 0 and len(s["trace"]) == s["num_iterations"] + 1
+    last = s["trace"][-1]
+    assert abs(last[0] - last[1]) <= 1e-3 * last[0] and s["final_cost"] == last[0] and abs(w.cost() - last[0]) <= 1e-11 * last[0]
+    # the iteration cap comes first: exactly max_num_iterations steps
+    s = W().solve(max_num_iterations=2)
+    assert (s["num_iterations"], s["why"]) == (2, "max_num_iterations")
