@@ -367,11 +367,13 @@ int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs);
  * iteration is a chain of small launches that leaves most of the 256 CUs idle; a batch fills the same launches W times over — the shape of
  * the reference's independent-window clients (RL environments: src/environment.cpp:18-115; loop-closure candidates: relocator.cpp:196-206)
  * and of what one GPU of the 8-GPU sharding works on.  The LM loop of every window runs on device (accept / reject, trust region and
- * termination per window; a finished window's launches return immediately).  Per-window results are identical to lvf_problem_solve /
- * lvf_problem_lm_iteration on that window alone.  Windows that cannot use the table launches (no sorted TwoFrame work list, pose priors,
+ * termination per window; a finished window's launches return immediately).  Per-window results equal lvf_problem_solve /
+ * lvf_problem_lm_iteration on that window alone up to summation order (a batch of more than one window sums its Schur complement over
+ * wider landmark slices: same accept / reject decisions and iteration counts, states within ~1e-12 relative).  Windows that cannot use the table launches (no sorted TwoFrame work list, pose priors,
  * no IMU blocks) make the batch fall back to running the windows' own chains back to back on the context's stream.
  * All result arrays have one entry per window, in the order of `problems`. */
 int lvf_problem_batch_create(lvf_ctx* ctx, lvf_problem* const* problems, int n, lvf_problem_batch** out);
+/* The batch BORROWS its problems and resets their slice width on destruction: destroy the batch BEFORE any of its problems. */
 int lvf_problem_batch_destroy(lvf_problem_batch* b);
 int lvf_problem_batch_size(const lvf_problem_batch* b);
 /* 1: table launches (one chain for all windows), 0: fallback, -1: error */

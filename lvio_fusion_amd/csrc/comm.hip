@@ -34,7 +34,7 @@ static Rccl& rccl() {
       x.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (x.h) break;
     }
-    if (!x.h) { x.error = std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "?"); return x; }
+    if (!x.h) { const char* e = dlerror(); x.error = std::string("librccl could not be opened: ") + (e ? e : "?"); return x; }      // (dlerror() clears its state: one call)
     x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.h, "ncclGetUniqueId"));
     x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.h, "ncclCommInitRank"));
     x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.h, "ncclAllGather"));

@@ -51,6 +51,7 @@ struct lvf_problem {
   lvf::DevBuf<double> slotB, slabP, slabQ, Ct, grt;
   lvf::StageClock* clk = nullptr;     // lvf_problem_stage_times
   bool accum_clean = false;           // B / gc / C / g_rho / cost stripes are zero (left so by the last iteration's cost + decision launch)
+  const double* chain_tcw = nullptr;      // the TwoCamera per-block weight array the current chain was built with
   int band_rows = 64;           // landmark rows per slice of the band Schur complement (a batch uses more: fewer output atomics)
   lvf::DevBuf<int4> band_work; lvf::DevBuf<int> n_band_work_dev; lvf::HostPin<int> h_n_band_work;
   int n_band_work = 0, band_rows_built = 0;
@@ -2754,6 +2755,7 @@ static int build_chain(lvf_problem* p) {
   }
   c.batchable = c.fast && p->compact && c.has_imu && !c.has_prior && c.merged_level0 && c.lin.nblocks > 0 && c.cost.nblocks > 0;
   { const StateP sp = state_ptrs(p->st); std::memcpy(p->chain_state, &sp, sizeof(sp)); }
+  p->chain_tcw = p->tc && p->tc->wblk.n ? p->tc->wblk.p : nullptr;
   p->chain_ready = true;
   return LVF_OK;
 }
@@ -2761,7 +2763,10 @@ static bool chain_stale(const lvf_problem* p) {
   if (!p->chain_ready || !p->chain) return true;
   const StateP s = state_ptrs(p->st);
   static_assert(sizeof(StateP) == sizeof(p->chain_state), "StateP is six pointers");
-  return std::memcmp(&s, p->chain_state, sizeof(StateP)) != 0;      // the state's buffers were re-allocated (window grew)
+  if (std::memcmp(&s, p->chain_state, sizeof(StateP)) != 0) return true;      // the state's buffers were re-allocated (window grew)
+  // lvf_two_camera_set_block_weights after the problem was created: the argument blocks hold the old weight pointer (or none)
+  const double* w = p->tc && p->tc->wblk.n ? p->tc->wblk.p : nullptr;
+  return w != p->chain_tcw;
 }
 
 // the linearisation at the current state: cost, B, gc, E, C, gr.  `gated`: skipped on device once the LM loop has finished
