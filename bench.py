@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--legs", default="all", help="comma list of legs to run (default all): batched_windows_8,batched_windows_16,pose_only_K1,icp,scan_match_frame,map_maintenance,window_tick,ceres_surface_solve,relocalize_8_candidates")
+    ap.add_argument("--legs", default="all", help="comma list of legs to run (default all): batched_windows_8,batched_windows_16,small_windows_100,pose_only_K1,icp,scan_match_frame,map_maintenance,window_tick,ceres_surface_solve,relocalize_8_candidates")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,7 +215,7 @@ def main():
             out["legs"] = legs(api, syn, ctx, local_rank, verified, args.legs)
         except Exception as e:
             out["legs"] = {"error": repr(e)}
-        for key in ("batched_windows_8", "window_tick", "ceres_surface_solve", "icp"):     # the drop-in costs and the metric's second half, top level
+        for key in ("batched_windows_8", "small_windows_100", "window_tick", "ceres_surface_solve", "icp"):     # the drop-in costs and the metric's second half, top level
             if isinstance(out.get("legs"), dict) and key in out["legs"]:
                 out[key] = out["legs"][key]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -334,6 +334,7 @@ def legs(api, syn, ctx, device, verified, which="all"):
         return c3[0]
     table = [("batched_windows_8", lambda: batched_windows(api, syn, ctx, 8, verified)),
              ("batched_windows_16", lambda: batched_windows(api, syn, ctx, 16, None)),
+             ("small_windows_100", lambda: small_windows(api, syn, ctx, verified)),
              ("pose_only_K1", lambda: pose_only_leg(api, syn, ctx, verified)),
              ("icp", lambda: icp_leg(api, syn, ctx, verified)),
              ("scan_match_frame", lambda: scan_match_frame(api, syn, ctx, cfg3())),
@@ -383,6 +384,64 @@ def batched_windows(api, syn, ctx, W, verified, iters=20, reps=5):
         for x in (prob,) + tuple(h):
             if x is not None:
                 x.close()
+    return out
+
+
+def small_windows(api, syn, ctx, verified, W=100, n_kf=10, n_lm=1500, iters=20, reps=4):
+    """The reference's independent SMALL windows: RL environments are 10-keyframe windows, 8 while training / 100 while testing
+    (src/environment.cpp:18-115, rl_fusion/td3.py:44-45); the live window is 3 s of keyframes (kitti.yaml:92).  W windows of n_kf keyframes
+    advanced by ONE launch chain per LM iteration (blockIdx.y = window); also one such window alone (latency).  Three of the windows are
+    checked against the oracle's chained loop (final cost + step counts)."""
+    wins = []
+    for i in range(W):
+        cfg = syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=max(100, n_lm // 5), seed=0x5A11 + i)
+        pre = api.preintegrate_or_none(ctx, cfg)
+        st = api.State(ctx, cfg["n_kf"], cfg["n_lm"])
+        for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth"), (api.W_VISUAL, "w_kf")):
+            st.set(field, cfg[key])
+        tc, tf, po = cfg["tc"], cfg["tf"], cfg["po"]
+        hs = [api.two_camera_batch(ctx, cfg["cam0"], cfg["cam1"], tc["left_ob"], tc["right_ob"], tc["lm_idx"], tc["kf_idx"]),
+              api.two_frame_batch(ctx, cfg["cam0"], cfg["cam1"], tf["first_ob"], tf["ob"], tf["lm_idx"], tf["kf1_idx"], tf["kf2_idx"]),
+              api.pose_only_batch(ctx, cfg["cam0"], po["ob"], po["kf_idx"], po["pw_idx"], po["pw"]),
+              api.imu_batch(ctx, pre, [f["kf_i"] for f in cfg["imu"]], [f["kf_j"] for f in cfg["imu"]])]
+        wins.append((cfg, st, hs, api.Problem(ctx, st, *hs)))
+    opt = fixed_iterations(api, iters)
+    b = api.ProblemBatch(ctx, [w[3] for w in wins])
+    rates, ss = [], None
+    for r in range(reps + 1):
+        for cfg, st, _, _ in wins:
+            reset_state(api, st, cfg)
+        ctx.synchronize(); t0 = time.perf_counter(); ss = b.solve(opt); dt = time.perf_counter() - t0
+        if r:
+            rates.append(sum(s.num_iterations for s in ss) / dt)
+    rate = float(np.median(rates))
+    # one window alone: the device loop's latency at this size
+    cfg, st, _, prob = wins[0]
+    lat = []
+    for r in range(4):
+        reset_state(api, st, cfg)
+        ctx.synchronize(); t0 = time.perf_counter(); s1 = prob.solve(opt); lat.append((time.perf_counter() - t0) / max(s1.num_iterations, 1))
+    out = {"windows": W, "n_kf": n_kf, "n_lm": n_lm, "blocks_per_window": {"two_frame": int(len(cfg["tf"]["lm_idx"])), "two_camera": int(len(cfg["tc"]["lm_idx"])), "pose_only": int(len(cfg["po"]["kf_idx"])), "imu": len(cfg["imu"])},
+           "iterations_each": iters, "table_launches": bool(b.uses_tables(opt)), "lm_iters_per_sec_aggregate": rate, "ms_per_batched_iteration": 1e3 * W / rate,
+           "single_window_ms_per_iteration": 1e3 * float(np.median(lat[1:]))}
+    if verified is not None:
+        try:
+            from oracle import pyoracle as po
+            ok = True
+            for i in (0, W // 2, W - 1):
+                cfg = wins[i][0]
+                pre = np.stack([po.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+                ref = po.Window(cfg, pre).solve(max_num_iterations=iters, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+                s = ss[i]
+                ok = ok and abs(s.final_cost - ref["final_cost"]) <= 1e-6 * ref["final_cost"] and (s.num_iterations, s.num_successful_steps) == (ref["num_iterations"], ref["num_successful_steps"])
+            verified["small_windows_100_vs_oracle_3_windows"] = bool(ok)
+        except Exception as e:
+            verified["small_windows_100_vs_oracle_3_windows"] = repr(e)
+    b.close()
+    for _, st, hs, prob in wins:
+        prob.close()
+        for h in hs + [st]:
+            h.close()
     return out
 
 

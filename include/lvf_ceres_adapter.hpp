@@ -34,6 +34,7 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
@@ -612,6 +613,7 @@ struct Window {
   std::vector<double*> v_ptr, ba_ptr, bg_ptr;      // per keyframe, null if the frame has no IMU blocks
   std::vector<double> w_kf;
   std::vector<char> w_known;
+  std::vector<char> pose_const;                    // per keyframe: SetParameterBlockConstant was called on its pose block
   // batches (insertion order preserved per type)
   std::vector<double> tc_l, tc_r; std::vector<int32_t> tc_lm, tc_kf; std::vector<double> tc_w;
   std::vector<double> tf_f, tf_o; std::vector<int32_t> tf_lm, tf_k1, tf_k2;
@@ -623,38 +625,58 @@ struct Window {
   double huber = -2.0;                             // -2 = not seen yet
 };
 
-inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& blocks, Window* w, const Fail& fail) {
-  // keyframes = 7-sized parameter blocks in the order the caller registered them (BuildProblem walks frames in time order)
-  std::vector<double*> all;
-  problem->GetParameterBlocks(&all);
-  for (double* p : all) {
-    const int sz = problem->ParameterBlockSize(p);
-    if (sz == 7) { w->pose_id.insert(p, (int)w->pose_ptr.size()); w->pose_ptr.push_back(p); }
-  }
+// what can only be checked once every block is in: parameter blocks the device solver cannot hold constant individually.
+// `constant` (recorder path) lists the blocks SetParameterBlockConstant was called on; NULL = ask the problem (walk path).
+inline bool finish_window(ceres::Problem* problem, Window* w, const PtrMap* constant, const Fail& fail) {
+  if (w->huber == -2.0) w->huber = 0.0;
   const int n_kf = (int)w->pose_ptr.size();
-  if (n_kf == 0) return fail("no pose parameter blocks in the problem");
-  w->v_ptr.assign(n_kf, nullptr); w->ba_ptr.assign(n_kf, nullptr); w->bg_ptr.assign(n_kf, nullptr);
-  w->w_kf.assign(n_kf, 1.0); w->w_known.assign(n_kf, 0);
-  auto kf_of = [&](double* p) { return w->pose_id.find(p); };
-  auto lm_of = [&](double* p) {
+  auto is_const = [&](double* p) { return constant ? constant->find(p) >= 0 : problem->IsParameterBlockConstant(p); };
+  if (!constant || constant->used) {
+    for (double* p : w->lm_ptr) if (is_const(p)) return fail("constant inverse-depth blocks are not supported");
+    for (int k = 0; k < n_kf; ++k)
+      for (double* p : {w->v_ptr[k], w->ba_ptr[k], w->bg_ptr[k]})
+        if (p && is_const(p)) return fail("constant velocity/bias blocks are not supported");
+  }
+  w->pose_const.assign(n_kf, 0);
+  if (!constant || constant->used)
+    for (int k = 0; k < n_kf; ++k) w->pose_const[k] = is_const(w->pose_ptr[k]) ? 1 : 0;
+  return true;
+}
+
+// One residual block at a time into the device image of the window.  Used by BOTH paths: the walk over a finished ceres::Problem
+// (build_window below) and the recorder that adapt::Problem feeds while Backend::BuildProblem is still adding blocks (Recorder), so that
+// gpu::Solve finds the SoA payload ready instead of chasing 91 k heap objects through the Ceres accessors.
+struct WindowBuilder {
+  Window* w;
+  std::string error;                              // first failure (the block's index and the rule it broke)
+  const ceres::LossFunction* loss_seen = nullptr;  // BuildProblem shares ONE loss object: probe each distinct pointer once
+  bool loss_seen_ok = false, loss_seen_any = false;
+  explicit WindowBuilder(Window* w_) : w(w_) {}
+
+  void add_pose_block(double* p) {
+    if (w->pose_id.find(p) >= 0) return;
+    w->pose_id.insert(p, (int)w->pose_ptr.size()); w->pose_ptr.push_back(p);
+    w->v_ptr.push_back(nullptr); w->ba_ptr.push_back(nullptr); w->bg_ptr.push_back(nullptr);
+    w->w_kf.push_back(1.0); w->w_known.push_back(0);
+  }
+  int kf_of(double* p) const { return w->pose_id.find(p); }
+  int lm_of(double* p) {
     const int hit = w->lm_id.find(p);
     if (hit >= 0) return hit;
     const int id = (int)w->lm_ptr.size();
     w->lm_id.insert(p, id); w->lm_ptr.push_back(p);
     return id;
-  };
-  auto set_w = [&](int kf, double wv) {
+  }
+  bool set_w(int kf, double wv) {
     if (w->w_known[kf] && w->w_kf[kf] != wv) return false;
     w->w_kf[kf] = wv; w->w_known[kf] = 1;
     return true;
-  };
-  auto use_cam = [&](const lvf_camera& c, lvf_camera* slot, bool* have) {
+  }
+  static bool use_cam(const lvf_camera& c, lvf_camera* slot, bool* have) {
     if (!*have) { *slot = c; *have = true; return true; }
     return same_cam(*slot, c);
-  };
-  const ceres::LossFunction* loss_seen = nullptr;   // BuildProblem shares ONE loss object: probe each distinct pointer once
-  bool loss_seen_ok = false, loss_seen_any = false;
-  auto use_loss = [&](const ceres::LossFunction* loss) {
+  }
+  bool use_loss(const ceres::LossFunction* loss) {
     if (loss_seen_any && loss == loss_seen) return loss_seen_ok;
     const double a = probe_huber(loss);
     bool ok = a >= 0.0;
@@ -664,104 +686,114 @@ inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& 
     }
     loss_seen = loss; loss_seen_ok = ok; loss_seen_any = true;
     return ok;
-  };
-  auto bind3 = [&](std::vector<double*>& slot, int kf, double* p) {
+  }
+  static bool bind3(std::vector<double*>& slot, int kf, double* p) {
     if (slot[kf] && slot[kf] != p) return false;
     slot[kf] = p;
     return true;
-  };
-  auto at = [](size_t i) { return "residual block " + std::to_string(i) + ": "; };   // only built on the failure path
-  w->order_kind.reserve(blocks.size()); w->order_idx.reserve(blocks.size());
-  w->lm_id.reserve(blocks.size() / 4);
-  for (size_t i = 0; i < blocks.size(); ++i) {
-    const BlockView& b = blocks[i];
-    switch (b.g->kind()) {
+  }
+  bool err(size_t i, const char* why) {
+    if (error.empty()) error = "residual block " + std::to_string(i) + ": " + why;      // only built on the failure path
+    return false;
+  }
+  // block i of the problem (insertion order): cost function g, its loss and its parameter pointers
+  bool add(size_t i, const GpuCostFunction* g, const ceres::LossFunction* loss, double* const* params) {
+    switch (g->kind()) {
       case Kind::PoseOnly: {
-        const auto* f = static_cast<const PoseOnlyReprojectionError*>(b.g);
-        const int kf = kf_of(b.params[0]);
-        if (kf < 0) return fail(at(i) + "pose block not registered");
-        if (!set_w(kf, f->weight)) return fail(at(i) + "visual blocks of one keyframe must share one weight (frame->weights.visual)");
-        if (!use_cam(f->cam, &w->left, &w->have_left)) return fail(at(i) + "all blocks must share the left camera");
-        if (!use_loss(b.loss)) return fail(at(i) + "visual blocks must share one HuberLoss/TrivialLoss");
+        const auto* f = static_cast<const PoseOnlyReprojectionError*>(g);
+        const int kf = kf_of(params[0]);
+        if (kf < 0) return err(i, "pose block not registered");
+        if (!set_w(kf, f->weight)) return err(i, "visual blocks of one keyframe must share one weight (frame->weights.visual)");
+        if (!use_cam(f->cam, &w->left, &w->have_left)) return err(i, "all blocks must share the left camera");
+        if (!use_loss(loss)) return err(i, "visual blocks must share one HuberLoss/TrivialLoss");
         w->order_kind.push_back(2); w->order_idx.push_back((int)w->po_kf.size());
         w->po_o.insert(w->po_o.end(), f->ob, f->ob + 2); w->po_pw.insert(w->po_pw.end(), f->pw, f->pw + 3);
         w->po_pi.push_back((int)w->po_kf.size()); w->po_kf.push_back(kf);
         break;
       }
       case Kind::TwoFrame: {
-        const auto* f = static_cast<const TwoFrameReprojectionError*>(b.g);
-        const int k1 = kf_of(b.params[1]), k2 = kf_of(b.params[2]);
-        if (k1 < 0 || k2 < 0) return fail(at(i) + "pose block not registered");
-        if (!set_w(k2, f->weight)) return fail(at(i) + "visual blocks of one keyframe must share one weight (frame->weights.visual)");
-        if (!use_cam(f->left, &w->left, &w->have_left) || !use_cam(f->right, &w->right, &w->have_right)) return fail(at(i) + "all blocks must share the stereo pair");
-        if (!use_loss(b.loss)) return fail(at(i) + "visual blocks must share one HuberLoss/TrivialLoss");
+        const auto* f = static_cast<const TwoFrameReprojectionError*>(g);
+        const int k1 = kf_of(params[1]), k2 = kf_of(params[2]);
+        if (k1 < 0 || k2 < 0) return err(i, "pose block not registered");
+        if (!set_w(k2, f->weight)) return err(i, "visual blocks of one keyframe must share one weight (frame->weights.visual)");
+        if (!use_cam(f->left, &w->left, &w->have_left) || !use_cam(f->right, &w->right, &w->have_right)) return err(i, "all blocks must share the stereo pair");
+        if (!use_loss(loss)) return err(i, "visual blocks must share one HuberLoss/TrivialLoss");
         w->order_kind.push_back(1); w->order_idx.push_back((int)w->tf_lm.size());
         w->tf_f.insert(w->tf_f.end(), f->first_ob, f->first_ob + 2); w->tf_o.insert(w->tf_o.end(), f->ob, f->ob + 2);
-        w->tf_lm.push_back(lm_of(b.params[0])); w->tf_k1.push_back(k1); w->tf_k2.push_back(k2);
+        w->tf_lm.push_back(lm_of(params[0])); w->tf_k1.push_back(k1); w->tf_k2.push_back(k2);
         break;
       }
       case Kind::TwoCamera: {
-        const auto* f = static_cast<const TwoCameraReprojectionError*>(b.g);
-        if (!use_cam(f->left, &w->left, &w->have_left) || !use_cam(f->right, &w->right, &w->have_right)) return fail(at(i) + "all blocks must share the stereo pair");
-        if (!use_loss(b.loss)) return fail(at(i) + "visual blocks must share one HuberLoss/TrivialLoss");
+        const auto* f = static_cast<const TwoCameraReprojectionError*>(g);
+        if (!use_cam(f->left, &w->left, &w->have_left) || !use_cam(f->right, &w->right, &w->have_right)) return err(i, "all blocks must share the stereo pair");
+        if (!use_loss(loss)) return err(i, "visual blocks must share one HuberLoss/TrivialLoss");
         w->order_kind.push_back(0); w->order_idx.push_back((int)w->tc_lm.size());
         w->tc_l.insert(w->tc_l.end(), f->left_ob, f->left_ob + 2); w->tc_r.insert(w->tc_r.end(), f->right_ob, f->right_ob + 2);
         // the block carries its own weight (5 * frame->weights.visual at backend.cpp:123): handed to the device per block, no keyframe look-up
-        w->tc_lm.push_back(lm_of(b.params[0])); w->tc_kf.push_back(0); w->tc_w.push_back(f->weight);
+        w->tc_lm.push_back(lm_of(params[0])); w->tc_kf.push_back(0); w->tc_w.push_back(f->weight);
         break;
       }
       case Kind::Imu: {
-        const auto* f = static_cast<const ImuError*>(b.g);
-        const int ki = kf_of(b.params[0]), kj = kf_of(b.params[4]);
-        if (ki < 0 || kj < 0) return fail(at(i) + "pose block not registered");
-        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at(i) + "a robust loss on ImuError is not supported (the reference passes NULL)");
-        if (!bind3(w->v_ptr, ki, b.params[1]) || !bind3(w->ba_ptr, ki, b.params[2]) || !bind3(w->bg_ptr, ki, b.params[3]) ||
-            !bind3(w->v_ptr, kj, b.params[5]) || !bind3(w->ba_ptr, kj, b.params[6]) || !bind3(w->bg_ptr, kj, b.params[7]))
-          return fail(at(i) + "a keyframe is linked to two different velocity/bias blocks");
+        const auto* f = static_cast<const ImuError*>(g);
+        const int ki = kf_of(params[0]), kj = kf_of(params[4]);
+        if (ki < 0 || kj < 0) return err(i, "pose block not registered");
+        if (loss && probe_huber(loss) != 0.0) return err(i, "a robust loss on ImuError is not supported (the reference passes NULL)");
+        if (!bind3(w->v_ptr, ki, params[1]) || !bind3(w->ba_ptr, ki, params[2]) || !bind3(w->bg_ptr, ki, params[3]) ||
+            !bind3(w->v_ptr, kj, params[5]) || !bind3(w->ba_ptr, kj, params[6]) || !bind3(w->bg_ptr, kj, params[7]))
+          return err(i, "a keyframe is linked to two different velocity/bias blocks");
         w->order_kind.push_back(3); w->order_idx.push_back((int)w->imu_i.size());
         w->imu_pre.push_back(f->pre); w->imu_i.push_back(ki); w->imu_j.push_back(kj);
         break;
       }
       case Kind::PoseGraph: {
-        const auto* f = static_cast<const PoseGraphError*>(b.g);
-        const int ka = kf_of(b.params[0]), kb = kf_of(b.params[1]);
-        if (ka < 0 || kb < 0) return fail(at(i) + "pose block not registered");
-        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at(i) + "a robust loss on PoseGraphError is not supported (the reference passes NULL)");
+        const auto* f = static_cast<const PoseGraphError*>(g);
+        const int ka = kf_of(params[0]), kb = kf_of(params[1]);
+        if (ka < 0 || kb < 0) return err(i, "pose block not registered");
+        if (loss && probe_huber(loss) != 0.0) return err(i, "a robust loss on PoseGraphError is not supported (the reference passes NULL)");
         w->order_kind.push_back(4); w->order_idx.push_back((int)w->pr_a.size());
         w->pr_a.push_back(ka); w->pr_b.push_back(kb); w->pr_t.insert(w->pr_t.end(), f->target, f->target + 7);
         w->pr_w.push_back(f->weight); w->pr_v.push_back(f->v);
         break;
       }
       case Kind::Pose: {
-        const auto* f = static_cast<const PoseError*>(b.g);
-        const int kb = kf_of(b.params[0]);
-        if (kb < 0) return fail(at(i) + "pose block not registered");
-        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at(i) + "a robust loss on PoseError is not supported (the reference passes NULL)");
+        const auto* f = static_cast<const PoseError*>(g);
+        const int kb = kf_of(params[0]);
+        if (kb < 0) return err(i, "pose block not registered");
+        if (loss && probe_huber(loss) != 0.0) return err(i, "a robust loss on PoseError is not supported (the reference passes NULL)");
         w->order_kind.push_back(4); w->order_idx.push_back((int)w->pr_a.size());
         w->pr_a.push_back(-1); w->pr_b.push_back(kb); w->pr_t.insert(w->pr_t.end(), f->origin, f->origin + 7);
         w->pr_w.push_back(f->weight); w->pr_v.push_back(f->v);
         break;
       }
       case Kind::R: {
-        const auto* f = static_cast<const RError*>(b.g);
-        const int kb = kf_of(b.params[0]);
-        if (kb < 0) return fail(at(i) + "pose block not registered");
-        if (b.loss && probe_huber(b.loss) != 0.0) return fail(at(i) + "a robust loss on RError is not supported (the reference passes NULL)");
+        const auto* f = static_cast<const RError*>(g);
+        const int kb = kf_of(params[0]);
+        if (kb < 0) return err(i, "pose block not registered");
+        if (loss && probe_huber(loss) != 0.0) return err(i, "a robust loss on RError is not supported (the reference passes NULL)");
         w->order_kind.push_back(4); w->order_idx.push_back((int)w->pr_a.size());
         w->pr_a.push_back(-2); w->pr_b.push_back(kb); w->pr_t.insert(w->pr_t.end(), f->origin, f->origin + 7);
         w->pr_w.push_back(f->weight); w->pr_v.push_back(0.0);
         break;
       }
-      default: return fail(at(i) + "lidar blocks cannot be mixed into a BA window");
+      default: return err(i, "lidar blocks cannot be mixed into a BA window");
     }
+    return true;
   }
-  if (w->huber == -2.0) w->huber = 0.0;
-  // parameter blocks the device solver cannot hold constant individually
-  for (double* p : w->lm_ptr) if (problem->IsParameterBlockConstant(p)) return fail("constant inverse-depth blocks are not supported");
-  for (int k = 0; k < n_kf; ++k)
-    for (double* p : {w->v_ptr[k], w->ba_ptr[k], w->bg_ptr[k]})
-      if (p && problem->IsParameterBlockConstant(p)) return fail("constant velocity/bias blocks are not supported");
-  return true;
+};
+
+inline bool build_window(ceres::Problem* problem, const std::vector<BlockView>& blocks, Window* w, const Fail& fail) {
+  // keyframes = 7-sized parameter blocks in the order the caller registered them (BuildProblem walks frames in time order)
+  WindowBuilder wb(w);
+  std::vector<double*> all;
+  problem->GetParameterBlocks(&all);
+  for (double* p : all)
+    if (problem->ParameterBlockSize(p) == 7) wb.add_pose_block(p);
+  if (w->pose_ptr.empty()) return fail("no pose parameter blocks in the problem");
+  w->order_kind.reserve(blocks.size()); w->order_idx.reserve(blocks.size());
+  w->lm_id.reserve(blocks.size() / 4);
+  for (size_t i = 0; i < blocks.size(); ++i)
+    if (!wb.add(i, blocks[i].g, blocks[i].loss, blocks[i].params)) return fail(wb.error);
+  return finish_window(problem, w, nullptr, fail);
 }
 
 struct DeviceWindow {
@@ -771,6 +803,9 @@ struct DeviceWindow {
 
 inline bool upload_window(lvf_ctx* ctx, ceres::Problem* problem, const Window& w, DeviceWindow* d, const Fail& fail) {
   const int n_kf = (int)w.pose_ptr.size(), n_lm = (int)w.lm_ptr.size();
+  using clk = std::chrono::steady_clock;
+  const bool timing = std::getenv("LVF_ADAPTER_TIMING") != nullptr;
+  const auto u0 = clk::now();
   if (lvf_state_create(ctx, n_kf, n_lm, &d->h.st) != LVF_OK) return fail(lvf_last_error());
   std::vector<double> poses(7 * (size_t)n_kf), vel(3 * (size_t)n_kf, 0.0), ba(vel), bg(vel), invd(n_lm);
   for (int k = 0; k < n_kf; ++k) {
@@ -784,6 +819,7 @@ inline bool upload_window(lvf_ctx* ctx, ceres::Problem* problem, const Window& w
   if (lvf_state_set(st, LVF_POSES, poses.data()) || lvf_state_set(st, LVF_VEL, vel.data()) || lvf_state_set(st, LVF_BA, ba.data()) ||
       lvf_state_set(st, LVF_BG, bg.data()) || lvf_state_set(st, LVF_W_VISUAL, w.w_kf.data()) || (n_lm && lvf_state_set(st, LVF_INV_DEPTH, invd.data())))
     return fail(lvf_last_error());
+  const auto u1 = clk::now();
   if (!w.tc_lm.empty()) {
     if (lvf_two_camera_create(ctx, &w.left, &w.right, (int)w.tc_lm.size(), w.tc_l.data(), w.tc_r.data(), w.tc_lm.data(), w.tc_kf.data(), &d->tc) != LVF_OK)
       return fail(lvf_last_error());
@@ -809,10 +845,13 @@ inline bool upload_window(lvf_ctx* ctx, ceres::Problem* problem, const Window& w
       return fail(lvf_last_error());
     d->h.keep(d->prior);
   }
+  const auto u2 = clk::now();
   if (lvf_problem_create(ctx, st, d->tc, d->tf, d->po, d->imu, &d->h.prob) != LVF_OK) return fail(lvf_last_error());
+  if (timing) std::fprintf(stderr, "  upload ms: state %.3f | batches %.3f | problem_create %.3f\n", 1e3 * std::chrono::duration<double>(u1 - u0).count(),
+                           1e3 * std::chrono::duration<double>(u2 - u1).count(), 1e3 * std::chrono::duration<double>(clk::now() - u2).count());
   if (d->prior && lvf_problem_set_pose_priors(d->h.prob, d->prior) != LVF_OK) return fail(lvf_last_error());
   for (int k = 0; k < n_kf; ++k)
-    if (problem->IsParameterBlockConstant(w.pose_ptr[k]) && lvf_problem_set_pose_constant(d->h.prob, k, 1) != LVF_OK) return fail(lvf_last_error());
+    if (w.pose_const[k] && lvf_problem_set_pose_constant(d->h.prob, k, 1) != LVF_OK) return fail(lvf_last_error());
   return true;
 }
 
@@ -828,14 +867,13 @@ inline void to_lvf_options(const ceres::Solver::Options& o, double huber, lvf_so
   out->min_relative_decrease = o.min_relative_decrease;
 }
 
-inline bool solve_window(const ceres::Solver::Options& options, ceres::Problem* problem, const std::vector<BlockView>& blocks,
-                         ceres::Solver::Summary* summary, const Fail& fail) {
+inline bool solve_window(const ceres::Solver::Options& options, ceres::Problem* problem, const Window& w,
+                         ceres::Solver::Summary* summary, const Fail& fail, double classify_seconds) {
   ThreadContext& tc = thread_context();
   if (!tc.ctx) return fail("no usable GPU context: " + tc.error);
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
-  Window w;
-  if (!build_window(problem, blocks, &w, fail)) return false;
+  const auto t0b = t0;
   DeviceWindow d;
   if (!upload_window(tc.ctx, problem, w, &d, fail)) return false;
   lvf_solver_options o;
@@ -868,23 +906,79 @@ inline bool solve_window(const ceres::Solver::Options& options, ceres::Problem* 
                                     "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps.",
                                     "Maximum solver time reached."};
   summary->message = std::string("sliding-window BA solved on device. ") + kWhy[s.termination_reason >= 0 && s.termination_reason <= 7 ? s.termination_reason : 0];
-  summary->preprocessor_time_in_seconds += std::chrono::duration<double>(t1 - t0).count();   // classify + upload (collect() is added by Solve)
+  summary->preprocessor_time_in_seconds += classify_seconds + std::chrono::duration<double>(t1 - t0).count();   // classify + upload (collect() is added by Solve)
   summary->minimizer_time_in_seconds = std::chrono::duration<double>(t2 - t1).count();
   summary->postprocessor_time_in_seconds = std::chrono::duration<double>(clk::now() - t2).count();
+  if (std::getenv("LVF_ADAPTER_TIMING"))
+    std::fprintf(stderr, "gpu::Solve (window) ms: classify %.3f | upload + configure %.3f | device loop %.3f | read back + write in place %.3f\n",
+                 1e3 * classify_seconds, 1e3 * std::chrono::duration<double>(t1 - t0b).count(),
+                 1e3 * std::chrono::duration<double>(t2 - t1).count(), 1e3 * summary->postprocessor_time_in_seconds);
   return true;
 }
 
 }  // namespace detail
 
+// --------------------------------------------------------------------------------------------- recorder (fed while the problem is built)
+// adapt::Problem (the reference-owned wrapper, adapt/problem.h:34-81) forwards every AddParameterBlock / AddResidualBlock /
+// SetParameterBlockConstant to one of these before handing the call to ceres::Problem (INTEGRATION.md shows the three one-line hooks).
+// Each lvio_fusion::gpu cost function's payload is appended to the window's SoA arrays right there — the object is hot in cache, it
+// was created a few instructions earlier — so gpu::Solve uploads arrays it already has instead of walking 91 k heap cost functions
+// through the Ceres accessors afterwards (6.4 of the 12.7 ms of an adapt::Solve call on the 50-keyframe window).  Anything the recorder
+// cannot follow (a foreign cost function, a pose block used before it was registered, lidar blocks, a block removed again) only marks
+// it unusable: gpu::Solve then falls back to the walk, which also produces the diagnostics.
+class Recorder {
+ public:
+  Recorder() : builder_(&w_) {}
+  Recorder(const Recorder&) = delete;
+  Recorder& operator=(const Recorder&) = delete;
+  void AddParameterBlock(double* values, int size) { if (size == 7) builder_.add_pose_block(values); }
+  void AddResidualBlock(const ceres::CostFunction* cost_function, const ceres::LossFunction* loss_function, double* const* parameter_blocks, int /*num_parameter_blocks*/) {
+    const size_t i = n_blocks_++;
+    if (!usable_) return;
+    const GpuCostFunction* g = detail::as_gpu(cost_function, cache_);
+    if (!g) { usable_ = false; return; }
+    const Kind k = g->kind();
+    if (k == Kind::LidarPlaneRPZ || k == Kind::LidarPlaneYXY || k == Kind::PoseErrorRPZ || k == Kind::PoseErrorYXY) { usable_ = false; return; }   // scan-to-map problems: a few thousand blocks, walked
+    if (!builder_.add(i, g, loss_function, parameter_blocks)) usable_ = false;
+  }
+  void SetParameterBlockConstant(double* values) { constant_.insert(values, 1); }
+  void Invalidate() { usable_ = false; }            // SetParameterBlockVariable, RemoveResidualBlock, RemoveParameterBlock ...
+  bool usable(ceres::Problem* problem) const { return usable_ && n_blocks_ > 0 && n_blocks_ == (size_t)problem->NumResidualBlocks(); }
+  detail::Window& window() { return w_; }
+  const detail::PtrMap& constant_blocks() const { return constant_; }
+  size_t num_residual_blocks() const { return n_blocks_; }
+
+ private:
+  detail::Window w_;
+  detail::WindowBuilder builder_;
+  detail::CastCache cache_;
+  detail::PtrMap constant_;
+  size_t n_blocks_ = 0;
+  bool usable_ = true;
+};
+
 // --------------------------------------------------------------------------------------------- the adapt::Solve body
-inline void Solve(const ceres::Solver::Options& options, ceres::Problem* problem, ceres::Solver::Summary* summary) {
+inline void Solve(const ceres::Solver::Options& options, ceres::Problem* problem, ceres::Solver::Summary* summary, Recorder* recorder = nullptr) {
   const auto t0 = std::chrono::steady_clock::now();
   *summary = ceres::Solver::Summary();
   const detail::Fail fail{summary};
+  const bool timing = std::getenv("LVF_ADAPTER_TIMING") != nullptr;
+  if (recorder && recorder->usable(problem) && !std::getenv("LVF_ADAPTER_WALK")) {      // (LVF_ADAPTER_WALK=1: force the accessor walk, for A/B tests)
+    // the window was assembled while the blocks were added: only the end-of-build checks remain
+    detail::Window& w = recorder->window();
+    if (w.pose_ptr.empty()) { fail("no pose parameter blocks in the problem"); return; }
+    if (!detail::finish_window(problem, &w, &recorder->constant_blocks(), fail)) return;
+    const double pre = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (timing) std::fprintf(stderr, "gpu::Solve ms: recorded window (%zu residual blocks captured while the problem was built) %.3f\n", recorder->num_residual_blocks(), 1e3 * pre);
+    detail::solve_window(options, problem, w, summary, fail, pre);
+    summary->total_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return;
+  }
   std::vector<detail::BlockView> blocks;
   std::vector<double*> block_params;
   if (!detail::collect(problem, &blocks, &block_params, fail)) return;
   summary->preprocessor_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (timing) std::fprintf(stderr, "gpu::Solve ms: collect (walk over %zu residual blocks) %.3f\n", blocks.size(), 1e3 * summary->preprocessor_time_in_seconds);
   if (blocks.empty()) {
     summary->termination_type = ceres::CONVERGENCE; summary->initial_cost = summary->final_cost = 0.0;
     summary->num_successful_steps = summary->num_unsuccessful_steps = 0; summary->num_residual_blocks = summary->num_residual_blocks_reduced = 0;
@@ -897,7 +991,12 @@ inline void Solve(const ceres::Solver::Options& options, ceres::Problem* problem
     if (k == Kind::LidarPlaneRPZ || k == Kind::LidarPlaneYXY || k == Kind::PoseErrorRPZ || k == Kind::PoseErrorYXY) { lidar = true; break; }
   }
   if (lidar) detail::solve_lidar(options, problem, blocks, summary, fail);
-  else detail::solve_window(options, problem, blocks, summary, fail);
+  else {
+    const auto c0 = std::chrono::steady_clock::now();
+    detail::Window w;
+    if (detail::build_window(problem, blocks, &w, fail))
+      detail::solve_window(options, problem, w, summary, fail, std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count());
+  }
   summary->total_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -80,22 +80,52 @@ extern thread_local std::shared_ptr<Pool> g_pool;         // the calling entry p
 // grow-only PINNED host staging array (hipHostMalloc): what the persistent window assembles its block lists into, so that the
 // per-tick uploads are real asynchronous DMA instead of pageable copies through the runtime's bounce buffer, and nothing is
 // re-allocated or zero-filled per tick.  Contents are not preserved across a growth.
+// Pinned blocks are recycled process-wide in size buckets: hipHostMalloc / hipHostFree page-lock and unlock memory (hundreds of
+// microseconds per megabyte), and a problem built per ceres::Solve call (the adapter's path) owns half a dozen of them.
+struct HostPinPool {
+  std::mutex mu;
+  std::unordered_multimap<size_t, void*> parked;
+  size_t held = 0;
+  static constexpr size_t kMaxHeld = (size_t)256 << 20;
+  static HostPinPool& get() { static HostPinPool* g = new HostPinPool(); return *g; }      // (never destroyed: the runtime may be gone at exit)
+  void* take(size_t bytes) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = parked.find(bytes);
+    if (it == parked.end()) return nullptr;
+    void* p = it->second;
+    parked.erase(it); held -= bytes;
+    return p;
+  }
+  bool give(void* p, size_t bytes) {
+    std::lock_guard<std::mutex> g(mu);
+    if (held + bytes > kMaxHeld) return false;
+    parked.emplace(bytes, p); held += bytes;
+    return true;
+  }
+};
 template <typename T>
 struct HostPin {
   T* p = nullptr;
   size_t cap = 0;
+  size_t bytes = 0;
   HostPin() = default;
   HostPin(const HostPin&) = delete;
   HostPin& operator=(const HostPin&) = delete;
-  ~HostPin() { if (p) (void)hipHostFree(p); }
+  ~HostPin() { drop(); }
+  void drop() {
+    if (p && !HostPinPool::get().give(p, bytes)) (void)hipHostFree(p);
+    p = nullptr; cap = 0; bytes = 0;
+  }
   int reserve(size_t count) {
     if (count <= cap) return LVF_OK;
-    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-    const size_t want = count + count / 4 + 64;
-    void* q = nullptr;
-    hipError_t e = hipHostMalloc(&q, want * sizeof(T), hipHostMallocDefault);
-    if (e != hipSuccess) return ::lvf::hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
-    p = static_cast<T*>(q); cap = want;
+    drop();
+    const size_t want = Pool::bucket((count + count / 4 + 64) * sizeof(T));
+    void* q = HostPinPool::get().take(want);
+    if (!q) {
+      hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
+      if (e != hipSuccess) return ::lvf::hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+    }
+    p = static_cast<T*>(q); cap = want / sizeof(T); bytes = want;
     return LVF_OK;
   }
   T& operator[](size_t i) { return p[i]; }

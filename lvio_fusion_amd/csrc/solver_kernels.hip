@@ -2515,7 +2515,7 @@ void stage_clock_free(StageClock* k);
 lvf_problem::~lvf_problem() {
   delete chain;
   lvf::stage_clock_free(clk);
-  if (rec) (void)hipHostFree(rec);
+  if (rec && !lvf::HostPinPool::get().give(rec, lvf::Pool::bucket(sizeof(lvf::LmCtl)))) (void)hipHostFree(rec);
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
 }
 namespace lvf {
@@ -2623,8 +2623,8 @@ static int build_chain(lvf_problem* p) {
   LVF_TRY(ensure_band_work(p));
   LVF_TRY(p->ctl.ensure(1));
   if (!p->rec) {
-    void* h = nullptr;
-    LVF_HIP(hipHostMalloc(&h, sizeof(LmCtl), hipHostMallocDefault));
+    void* h = HostPinPool::get().take(Pool::bucket(sizeof(LmCtl)));       // (pinned blocks are recycled: lvf_internal.hpp)
+    if (!h) LVF_HIP(hipHostMalloc(&h, Pool::bucket(sizeof(LmCtl)), hipHostMallocDefault));
     p->rec = static_cast<LmCtl*>(h);
     std::memset(p->rec, 0, sizeof(LmCtl));
   }
@@ -3198,6 +3198,11 @@ static int build_elimination_plan(lvf_problem* p) {
 }
 
 int problem_configure(lvf_problem* p) {
+  static const bool cfg_timing = std::getenv("LVF_CONFIGURE_TIMING") != nullptr;
+  const auto cfg_t0 = std::chrono::steady_clock::now();
+  auto cfg_mark = [&](const char* what) {
+    if (cfg_timing) std::fprintf(stderr, "  problem_configure: %s at %.3f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - cfg_t0).count());
+  };
   lvf_state* st = p->st;
   lvf_ctx* ctx = p->ctx;
   p->n_kf = st->n_kf; p->n_lm = st->n_lm;
@@ -3205,6 +3210,7 @@ int problem_configure(lvf_problem* p) {
   p->ldE = ((p->dp + 1 + 15) / 16) * 16;
   p->dpad = ((p->d + 1 + 63) / 64) * 64;
   LVF_TRY(build_elimination_plan(p));                 // sets ld, off, off_pose, ndense, aug, nb and the sparse levels
+  cfg_mark("elimination plan");
   const size_t nS = (size_t)p->dpad * p->dpad;
   LVF_TRY(p->Dinv.ensure((size_t)p->nb * kNB * kNB));
   LVF_TRY(p->B.ensure(nS)); LVF_TRY(p->S.ensure((size_t)p->ld * p->ld)); LVF_TRY(p->gc.ensure(p->dpad)); LVF_TRY(p->dxc.ensure(p->dpad));
@@ -3216,6 +3222,7 @@ int problem_configure(lvf_problem* p) {
   LVF_TRY(p->invd2.ensure(std::max(st->inv_depth.cap, (size_t)p->n_lm)));
   LVF_TRY(p->pose_const.ensure((size_t)p->n_kf + 8)); LVF_TRY(p->fail.ensure(1));      // (+8: cleared in 8-byte words)
   p->pose_const_h.assign(p->n_kf, 0);
+  cfg_mark("buffers");
   p->tf_work.n = 0;
   p->tf_unique_lk2 = false; p->tf_k1_first = false; p->compact = false;
   lvf_batch* two_frame = p->tf;
@@ -3240,8 +3247,10 @@ int problem_configure(lvf_problem* p) {
     if (ok) {
       // built straight into pinned staging owned by the problem: the upload is a real asynchronous copy and this function does not
       // have to wait for the stream before returning
-      LVF_TRY(p->h_tf_work.reserve((size_t)two_frame->n / 1 + 1));     // worst case: every block its own run
       size_t nw = 0;
+      for (int i = 0; i < two_frame->n;) { int j = i; while (j < two_frame->n && k2[j] == k2[i] && j - i < kT) ++j; ++nw; i = j; }
+      LVF_TRY(p->h_tf_work.reserve(nw + 1));
+      nw = 0;
       for (int i = 0; i < two_frame->n;) {
         int j = i;
         while (j < two_frame->n && k2[j] == k2[i] && j - i < kT) ++j;
@@ -3252,30 +3261,29 @@ int problem_configure(lvf_problem* p) {
       // blocks are sorted by k2: a duplicate (landmark, k2) pair shows up as a repeated landmark inside one k2 run
       const std::vector<int32_t>& lmh = two_frame->host_lm;
       bool uniq = two_frame->unique_lk2_known || lmh.size() == (size_t)two_frame->n;
-      if (uniq && !two_frame->unique_lk2_known) {
-        std::vector<int32_t> run;
-        for (int i = 0; i < two_frame->n && uniq;) {
-          int j = i;
-          while (j < two_frame->n && k2[j] == k2[i]) ++j;
-          run.assign(lmh.begin() + i, lmh.begin() + j);
-          std::sort(run.begin(), run.end());
-          uniq = std::adjacent_find(run.begin(), run.end()) == run.end();
-          i = j;
-        }
-      }
-      // ... and the plain stores into E[l][k2 columns] must never meet the atomic adds into E[l][k1 columns]: every landmark needs ONE
+      // Both checks in ONE pass over the blocks with two per-landmark tables (a sort per run + a hash map of first keyframes were 3 ms
+      // of a 91 k-block lvf_problem_create): `seen_run[l]` = the last current-keyframe run landmark l appeared in (a repeat inside one
+      // run is a duplicate (landmark, k2) pair), `first_kf[l]` = its first keyframe.
+      // ... the plain stores into E[l][k2 columns] must never meet the atomic adds into E[l][k1 columns]: every landmark needs ONE
       // first keyframe (then k2 == k1(l) is excluded by k1 != k2 above).  BuildProblem's blocks always satisfy this; a hand-made batch may not.
       if (uniq && !two_frame->unique_lk2_known) {
-        std::unordered_map<int32_t, int32_t> first_kf;
-        first_kf.reserve(lmh.size());
+        const int32_t nl = (int32_t)p->n_lm;
+        std::vector<int32_t> seen_run((size_t)nl, -1), first_kf((size_t)nl, -1);
+        int32_t run = -1, cur = -1;
         for (int i = 0; i < two_frame->n && uniq; ++i) {
-          auto it = first_kf.emplace(lmh[i], k1[i]);
-          if (!it.second && it.first->second != k1[i]) uniq = false;
+          if (k2[i] != cur) { cur = k2[i]; ++run; }
+          const int32_t l = lmh[i];
+          if (l < 0 || l >= nl) { uniq = false; break; }
+          if (seen_run[l] == run) uniq = false;
+          seen_run[l] = run;
+          if (first_kf[l] < 0) first_kf[l] = k1[i];
+          else if (first_kf[l] != k1[i]) uniq = false;
         }
       }
       p->tf_unique_lk2 = uniq;
     }
   }
+  cfg_mark("TwoFrame work list + shape checks");
   // landmark tracks -> band-limited Schur (device side: the TwoFrame indices already live there)
   p->band_ready = false;
   static const bool band_on = [] { const char* e = std::getenv("LVF_SCHUR_BAND"); return !(e && e[0] == '0'); }();
@@ -3330,6 +3338,7 @@ int problem_configure(lvf_problem* p) {
     hipLaunchKernelGGL(k_zero_multi, dim3(512, z.count), dim3(kT), 0, ctx->stream, z);
     LVF_HIP(hipGetLastError());
   }
+  cfg_mark("device-side layout launches + E");
   // no stream wait here: every host source above is pinned and owned by the problem (or was waited for by the plan builder)
   p->linearized = false;
   p->chain_ready = false;

@@ -29,12 +29,19 @@ class Problem : public ceres::Problem {
     const ceres::ResidualBlockId id = ceres::Problem::AddResidualBlock(cost_function, loss_function, x0, xs...);
     types[id] = type;
     ++num_types[type];
+    double* const params[] = {x0, xs...};                                                       // [integration hook 1 of 3]
+    recorder.AddResidualBlock(cost_function, loss_function, params, 1 + (int)sizeof...(xs));
   }
-  void AddParameterBlock(double* values, int size) { ceres::Problem::AddParameterBlock(values, size); }
+  void AddParameterBlock(double* values, int size) { ceres::Problem::AddParameterBlock(values, size); recorder.AddParameterBlock(values, size); }
   void AddParameterBlock(double* values, int size, ceres::LocalParameterization* local_parameterization) {
     if (size == 7) ++num_frames;   // SE3d::num_parameters
     ceres::Problem::AddParameterBlock(values, size, local_parameterization);
+    recorder.AddParameterBlock(values, size);                                                   // [integration hook 2 of 3]
   }
+  // (shadows ceres::Problem's: backend.cpp / pose_graph.cpp call it on an adapt::Problem object)
+  void SetParameterBlockConstant(double* values) { ceres::Problem::SetParameterBlockConstant(values); recorder.SetParameterBlockConstant(values); }   // [hook 3 of 3]
+  void SetParameterBlockVariable(double* values) { ceres::Problem::SetParameterBlockVariable(values); recorder.Invalidate(); }
+  gpu::Recorder recorder;      // the window's SoA payload, captured while the blocks are added
   std::map<ProblemType, int> GetTypes(double* para) {
     std::vector<ceres::ResidualBlockId> ids;
     GetResidualBlocksForParameterBlock(para, &ids);
@@ -49,7 +56,7 @@ class Problem : public ceres::Problem {
 
 // the one-line change of the integration: ceres::Solve -> lvio_fusion::gpu::Solve
 inline void Solve(const ceres::Solver::Options& options, adapt::Problem* problem, ceres::Solver::Summary* summary) {
-  gpu::Solve(options, problem, summary);
+  gpu::Solve(options, problem, summary, &problem->recorder);
 }
 
 }  // namespace adapt

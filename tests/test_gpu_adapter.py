@@ -284,3 +284,43 @@ def test_scan_to_map_through_adapter(tmp_path, oracle, mode, use_prior):
 def test_foreign_cost_function_fails_soft():
     out = _run("foreign")
     assert out["ok"] == 0 and out["x"] == 3.0 and "not an lvio_fusion::gpu cost function" in out["message"]
+
+
+def test_recorded_window_equals_the_accessor_walk(tmp_path, oracle):
+    """adapt::Problem records the SoA payload while blocks are added (gpu::Recorder); gpu::Solve then skips the walk through the Ceres
+    accessors.  Both paths must hand the device the same window: identical summaries and written-back parameters, with IMU blocks, weak
+    priors and a constant pose in play (LVF_ADAPTER_WALK=1 forces the walk)."""
+    n_kf, n_lm, max_it = 9, 200, 5
+    for with_imu, weak_thr, const_kf in ((True, 0, 0), (False, 10 ** 6, -1)):
+        cfg = _sorted_by_kf(syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=40, seed=123, imu_samples=4))
+        pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+        outs = []
+        for sub, env in (("rec", {}), ("walk", {"LVF_ADAPTER_WALK": "1"})):
+            d = str(tmp_path / f"{sub}{int(with_imu)}"); os.makedirs(d)
+            tc, tf, po = cfg["tc"], cfg["tf"], cfg["po"]
+            _dump(d, "meta.i32", [n_kf, n_lm, max_it, weak_thr, const_kf], np.int32)
+            for name, key in (("poses", "poses"), ("vel", "vel"), ("ba", "ba"), ("bg", "bg"), ("inv_depth", "inv_depth"), ("w_kf", "w_kf")):
+                _dump(d, name + ".f64", cfg[key], np.float64)
+            _dump(d, "cam0.f64", _cam_vec(cfg["cam0"]), np.float64); _dump(d, "cam1.f64", _cam_vec(cfg["cam1"]), np.float64)
+            _dump(d, "tc_left_ob.f64", tc["left_ob"], np.float64); _dump(d, "tc_right_ob.f64", tc["right_ob"], np.float64)
+            _dump(d, "tc_lm.i32", tc["lm_idx"], np.int32); _dump(d, "tc_kf.i32", tc["kf_idx"], np.int32)
+            _dump(d, "tf_first_ob.f64", tf["first_ob"], np.float64); _dump(d, "tf_ob.f64", tf["ob"], np.float64)
+            _dump(d, "tf_lm.i32", tf["lm_idx"], np.int32); _dump(d, "tf_kf1.i32", tf["kf1_idx"], np.int32); _dump(d, "tf_kf2.i32", tf["kf2_idx"], np.int32)
+            _dump(d, "po_ob.f64", po["ob"], np.float64); _dump(d, "po_pw.f64", po["pw"], np.float64)
+            _dump(d, "po_kf.i32", po["kf_idx"], np.int32); _dump(d, "po_pw_idx.i32", po["pw_idx"], np.int32)
+            imu = cfg["imu"] if with_imu else []
+            _dump(d, "preint.f64", pre if with_imu else np.zeros(0), np.float64)
+            _dump(d, "imu_i.i32", [f["kf_i"] for f in imu], np.int32); _dump(d, "imu_j.i32", [f["kf_j"] for f in imu], np.int32)
+            e = dict(os.environ); e.update(env); e["LVF_ADAPTER_TIMING"] = "1"
+            p = subprocess.run([EXE, "window", d], capture_output=True, text=True, timeout=300, env=e)
+            assert p.returncode == 0, p.stdout + p.stderr
+            assert ("recorded window" in p.stderr) == (sub == "rec"), p.stderr            # the path under test really ran
+            o = json.loads(p.stdout.strip().splitlines()[-1])
+            outs.append((o, {f: np.fromfile(os.path.join(d, f)) for f in ("out_poses.f64", "out_inv_depth.f64", "out_vel.f64", "out_ba.f64", "out_bg.f64")}))
+        (a, fa), (b, fb) = outs
+        for k in ("ok", "successful", "num_residual_blocks", "n_prior", "num_frames"):
+            assert a[k] == b[k], (k, a[k], b[k])
+        for k in ("initial_cost", "final_cost", "cost0"):       # (device sums through atomics: equal up to summation order)
+            assert abs(a[k] - b[k]) <= 1e-12 * abs(b[k]), (k, a[k], b[k])
+        for f in fa:
+            assert np.allclose(fa[f], fb[f], rtol=1e-10, atol=1e-13), f

@@ -185,3 +185,18 @@ def test_config3_k20_the_call_bench_times(ctx, oracle):
     check(api, w, s, ref, "configs[3], K = 20")
     assert s.num_iterations == 20 or s.termination == 0
     close(w)
+
+
+def test_many_small_windows_in_one_batch(ctx, oracle):
+    """The reference's RL-environment shape (10-keyframe windows, up to 100 at once: environment.cpp:18-115, td3.py:44-45): 40 small windows
+    with different seeds / starts in one lvf_problem_batch_solve, every window against its own oracle chain."""
+    from lvio_fusion_amd import api
+    ws = [make(api, ctx, oracle, 10, 300, 900 + i, n_pre=60, perturb=(1.0 if i % 4 else 12.0)) for i in range(40)]
+    o = options(api, max_num_iterations=10)
+    refs = [w["win"].solve(**okw(o)) for w in ws]
+    batch = api.ProblemBatch(ctx, [w["prob"] for w in ws])
+    assert batch.uses_tables(o) == 1
+    out = batch.solve(o)
+    for i, (w, s, ref) in enumerate(zip(ws, out, refs)):
+        check(api, w, s, ref, f"small window {i} of 40")
+    batch.close(); close(*ws)
