@@ -322,14 +322,30 @@ def config3_icp(seed=SEED_CFG3, n_query=100000, noise=0.02, n_az=2900):
 
 
 # ----------------------------------------------------------------------------- config 5 (loop-closure candidates)
-def config5_candidates(n=8, seed=0x5CA7, n_query=20000, n_az=600):
+def config5_candidates(n=8, seed=0x5CA7, n_query=20000, n_az=600, overlap="varied"):
     """n independent relocalisation candidates (SURVEY §8d config 5): each is a config-3 style scene with its own seed;
-    the 'old' keyframe is the map pose, the candidate's initial pose is the perturbed query pose."""
+    the 'old' keyframe is the map pose, the candidate's initial pose is the perturbed query pose.
+
+    Mapping::Relocate's score (mapping.cpp:279-294) is min(N_ground / 10, 20) + min(N_surf / 10, 30) - 2 cost / N per sub-problem,
+    truncated to int: with thousands of accepted correspondences every candidate saturates at 49.  overlap = "varied" (default) gives the
+    candidates DIFFERENT overlap with their old sub-map — candidate i keeps only KEEP[i % 8] ground / surf query points (a loop closure
+    seen from further away, or a mostly occluded one) — so the scores spread from "rejected" (score - 20 <= 0) to saturated and the
+    arg-max has something to decide.  Three slots saturate on purpose: the reference's `>=` keeps the LATER of equal scores
+    (relocator.cpp:200).  overlap = "full": every candidate keeps its whole scan (round 1-2 behaviour)."""
+    KEEP = [(60, 110), (400, 900), (140, 260), (90, 200), (30, 45), (180, 150), (100000, 100000), (100000, 100000)]
     out = []
     for i in range(n):
         c = config3_icp(seed=seed + i, n_query=n_query, n_az=n_az)
-        out.append(dict(map=c["map"], map_ground=c["map_ground"], query=c["query"], query_ground=c["query_ground"],
-                        map_pose=c["map_pose"], last_pose=c["map_pose"], init_pose=c["pose0"], pose_true=c["pose_true"]))
+        q, qg, init = c["query"], c["query_ground"], c["pose0"]
+        if overlap == "varied":
+            rng = np.random.default_rng(seed + 7919 * (i + 1))
+            keep = KEEP[i % len(KEEP)]
+            gi, si = np.flatnonzero(qg), np.flatnonzero(~qg)
+            gi = np.sort(rng.choice(gi, min(keep[0], gi.size), replace=False)); si = np.sort(rng.choice(si, min(keep[1], si.size), replace=False))
+            sel = np.sort(np.concatenate([gi, si]))
+            q, qg = q[sel], qg[sel]
+        out.append(dict(map=c["map"], map_ground=c["map_ground"], query=q, query_ground=qg,
+                        map_pose=c["map_pose"], last_pose=c["map_pose"], init_pose=init, pose_true=c["pose_true"]))
     return out
 
 

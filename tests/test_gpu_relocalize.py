@@ -37,7 +37,7 @@ def oracle_scan_match(oracle, cand, outer, prior_w, res=0.2):
 @pytest.mark.parametrize("outer,prior", [(1, 300 * syn.W_VISUAL), (4, 0.0)])
 def test_scan_match_parity(ctx, oracle, outer, prior):
     from lvio_fusion_amd import api
-    cand = syn.config5_candidates(1, seed=91, n_query=6000, n_az=300)[0]
+    cand = syn.config5_candidates(1, seed=91, n_query=6000, n_az=300, overlap="full")[0]
     ref_pose, sg, ss, g, s = oracle_scan_match(oracle, cand, outer, prior)
     mg, ms = cand["map"][cand["map_ground"]], cand["map"][~cand["map_ground"]]
     qg, qs = cand["query"][cand["query_ground"]], cand["query"][~cand["query_ground"]]
@@ -83,6 +83,32 @@ def test_relocalize_single_rank(ctx):
         assert np.allclose(merged[merged[:, 8] == c][0], t0[t0[:, 8] == c][0], rtol=1e-9, atol=1e-12)   # atomics reorder the last bits
 
 
+def test_argmax_over_candidates_with_different_overlap(ctx, oracle):
+    """configs[4] with candidates whose overlap differs (synthetic.config5_candidates, overlap="varied"): the device's per-candidate
+    Mapping::Relocate (score, relative pose) against the oracle restatement of mapping.cpp:251-300, and the arg-max of
+    relocator.cpp:191-204 — scores spread from rejected (<= 0) to saturated, with ties that `>=` resolves to the LATER candidate."""
+    from lvio_fusion_amd import api
+    cands = syn.config5_candidates(8, seed=313, n_query=5000, n_az=300)
+    ref_scores, ref_rel = [], []
+    for c in cands:
+        pose, sg, ss, _, _ = oracle_scan_match(oracle, c, 4, 0.0)
+        ref_scores.append(int(sg + ss) - rl.RELOCATE_BASE_SCORE); ref_rel.append(oracle.se3_mul(oracle.se3_inv(c["last_pose"]), pose))
+    assert len(set(ref_scores)) >= 5 and min(ref_scores) <= 0 and sorted(ref_scores)[-1] == sorted(ref_scores)[-2], ref_scores   # spread, a rejected one, a tie at the top
+    for order in (list(range(8)), list(range(7, -1, -1)), [6, 2, 7, 0, 5, 1, 3, 4]):
+        best, rec = rl.relocalize(api, ctx, [cands[i] for i in order])
+        scores = [ref_scores[i] for i in order]
+        assert [int(x) for x in rec[np.argsort(rec[:, 8]), 0]] == scores, (order, scores)
+        top = max(s for s in scores if s > 0)
+        want = max(k for k, s in enumerate(scores) if s == top)                 # `>=`: the last candidate with the best score
+        assert best is not None and best[0] == want and best[1] == top, (order, best, scores)
+        assert np.allclose(best[2], ref_rel[order[want]], rtol=1e-6, atol=1e-9)
+    # nobody relocates: every score <= 0 -> no best frame
+    losers = [c for c, s in zip(cands, ref_scores) if s <= 0]
+    assert len(losers) >= 2
+    best, rec = rl.relocalize(api, ctx, losers)
+    assert best is None and np.all(rec[:, 0] <= 0)
+
+
 def test_cpp_driver_threads_and_rccl_gather(ctx, oracle, tmp_path):
     """The C++ host of configs[4] (lvio_fusion_amd/host/relocalize_driver.cpp): candidates sharded over worker threads (one lvf_ctx each),
     records gathered through lvf_comm_allgather (a real RCCL communicator of one rank on this box), arg-max, then the loop-correction tail
@@ -94,8 +120,8 @@ def test_cpp_driver_threads_and_rccl_gather(ctx, oracle, tmp_path):
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(ROOT, "lvio_fusion_amd", "host", "relocalize_driver")
     assert os.path.exists(exe), "run __graft_entry__.build()"
-    n = 5
-    cands = syn.config5_candidates(n, seed=313, n_query=5000, n_az=300)
+    n = 8
+    cands = syn.config5_candidates(n, seed=313, n_query=5000, n_az=300)          # different overlap per candidate: the arg-max discriminates
     d = str(tmp_path)
     for i, c in enumerate(cands):
         np.ascontiguousarray(c["map"], np.float32).tofile(f"{d}/c{i}_map.f32"); np.ascontiguousarray(c["query"], np.float32).tofile(f"{d}/c{i}_query.f32")
@@ -117,7 +143,7 @@ def test_cpp_driver_threads_and_rccl_gather(ctx, oracle, tmp_path):
         p = subprocess.run([exe, d] + args, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stdout + p.stderr
         o = json.loads(p.stdout.strip().splitlines()[-1]); outs.append(o)
-        assert o["ok"] == 1
+        assert o["ok"] == 1 and o["threads"] == int(args[1])          # (three host threads, each with its own context / stream on the device, fill one table)
         rec = np.fromfile(f"{d}/out_records_r0.f64").reshape(-1, 9)
         assert np.array_equal(np.sort(rec[:, 8]), np.arange(n))
         order = np.argsort(rec[:, 8]); ref_order = np.argsort(rec_py[:, 8])

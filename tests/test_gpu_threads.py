@@ -54,7 +54,7 @@ def test_concurrent_contexts_match_serial(oracle):
     from lvio_fusion_amd import api
     cfg = syn.config4_window(n_kf=10, n_lm=300, n_prewindow=40, seed=3, imu_samples=4)
     pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
-    cand = syn.config5_candidates(1, seed=8, n_query=6000, n_az=300)[0]
+    cand = syn.config5_candidates(1, seed=8, n_query=6000, n_az=300, overlap="full")[0]
     serial = {}
     ba_job(api, pre, cfg, serial, "ba", 1); icp_job(api, cand, serial, "icp", 1)
     assert not isinstance(serial["ba"], Exception) and not isinstance(serial["icp"], Exception), serial
