@@ -219,8 +219,13 @@ int lvf_cloud_download(const lvf_cloud* c, float* xyzi /* [n][4] */);
 int lvf_cloud_transform(const lvf_cloud* in, const double* pose, lvf_cloud** out);
 /* `merged += pointclouds[t]` of BuildMapFrame / BuildOldMapFrame (mapping.cpp:78-137): device-side concatenation. */
 int lvf_cloud_concat(lvf_ctx* ctx, const lvf_cloud* const* parts, int n_parts, lvf_cloud** out);
-/* pcl::VoxelGrid<PointXYZI> with a cubic leaf (association.cpp:210-215, 222-224): per-voxel centroid of all four fields,
- * voxels in ascending (i + j*dx + k*dx*dy) order. */
+/* FeatureAssociation::AlignScan (association.cpp:39-64): the keyframe's sweep [time - cycle/2, time + cycle/2] cut out of two consecutive raw
+ * revolutions pc1 (stamped stamp1) + pc2 (stamp2 > stamp1) with the reference's index arithmetic (double, truncated); output points carry
+ * intensity 0 (copyPointCloud from PointXYZ).  *aligned = 0 and an empty cloud where the reference returns false (sweep not covered). */
+int lvf_cloud_align_scan(const lvf_cloud* pc1, double stamp1, const lvf_cloud* pc2, double stamp2, double cycle_time, double time, lvf_cloud** out,
+                         int* aligned);
+/* pcl::VoxelGrid<PointXYZI> with a cubic leaf (association.cpp:210-215, 222-224): per-voxel centroid of all four fields (float accumulation
+ * over the voxel's points in ascending input index — reproducible bit for bit), voxels in ascending (i + j*dx + k*dx*dy) order. */
 int lvf_cloud_voxel_filter(const lvf_cloud* in, float leaf, lvf_cloud** out);
 /* pcl::RadiusOutlierRemoval (association.cpp:217-221): keeps a point iff more than min_neighbors points (itself
  * included) lie at squared distance < radius^2; input order preserved. */

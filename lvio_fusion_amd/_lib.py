@@ -163,6 +163,7 @@ _SIGS = {
     "lvf_cloud_download": (C.c_int, [_VP, c_float_p]),
     "lvf_cloud_transform": (C.c_int, [_VP, c_double_p, C.POINTER(_VP)]),
     "lvf_cloud_concat": (C.c_int, [_VP, C.POINTER(_VP), C.c_int, C.POINTER(_VP)]),
+    "lvf_cloud_align_scan": (C.c_int, [_VP, C.c_double, _VP, C.c_double, C.c_double, C.c_double, C.POINTER(_VP), C.POINTER(C.c_int)]),
     "lvf_cloud_voxel_filter": (C.c_int, [_VP, C.c_float, C.POINTER(_VP)]),
     "lvf_cloud_radius_outlier_filter": (C.c_int, [_VP, C.c_float, C.c_int, C.POINTER(_VP)]),
     "lvf_cloud_segment_plane": (C.c_int, [_VP, C.c_float, C.c_int, C.c_uint64, C.POINTER(_VP), c_double_p, C.POINTER(C.c_int)]),

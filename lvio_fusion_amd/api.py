@@ -311,6 +311,13 @@ class Cloud:
         _chk(ctx.L.lvf_cloud_concat(ctx.h, arr, len(parts), C.byref(h)))
         return Cloud(ctx, _h=h)
 
+    @staticmethod
+    def align_scan(pc1, stamp1, pc2, stamp2, cycle_time, time):
+        """FeatureAssociation::AlignScan on device: (Cloud, True) or (empty Cloud, False) where the reference returns false."""
+        h = C.c_void_p(); ok = C.c_int()
+        _chk(pc1.ctx.L.lvf_cloud_align_scan(pc1.h, float(stamp1), pc2.h, float(stamp2), float(cycle_time), float(time), C.byref(h), C.byref(ok)))
+        return Cloud(pc1.ctx, _h=h), bool(ok.value)
+
     def close(self):
         if self.h:
             self.ctx.L.lvf_cloud_destroy(self.h)

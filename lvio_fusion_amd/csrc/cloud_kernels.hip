@@ -13,8 +13,11 @@
 // DECLARED upstream semantics (PCL is un-vendored; restated in oracle/cloud.h):
 //   VoxelGrid: inverse_leaf = 1/leaf (float); min_b = floor(min * inverse_leaf), div_b = max_b - min_b + 1; a point's voxel
 //     is ijk = floor(p * inverse_leaf) - min_b, idx = i + j div_x + k div_x div_y; output = per-voxel centroid of ALL fields
-//     (x, y, z, intensity), voxels in ascending idx.  PCL accumulates the centroid in float in the order its (unstable)
-//     std::sort leaves the points; here sums are double atomics (order-independent to ~1e-16) rounded once to float.
+//     (x, y, z, intensity), voxels in ascending idx.  PCL accumulates the centroid in FLOAT over the voxel's points in the order its
+//     (unstable) std::sort leaves them; the declared order is ascending input index.  The device does exactly that: a stable sort of
+//     (voxel, point index) pairs, then one thread per voxel adds its points in that order in float and divides by the count — the
+//     result does not depend on scheduling and equals the sequential restatement bit for bit (round 2 used double atomics: 2e-6 off,
+//     enough to flip later radius-outlier / plane decisions).
 //   RadiusOutlierRemoval: keep a point iff (number of points with squared distance < r^2, itself included) > min_neighbors;
 //     input order preserved.
 //   SACSegmentation/RANSAC: hypothesis = plane through 3 distinct sampled points; inliers |n.p + d| < thr; best = most
@@ -41,6 +44,16 @@ __global__ __launch_bounds__(kC) void k_cloud_pack(int n, const float* __restric
   if (i >= n) return;
   const float* s = src + (size_t)i * stride;
   dst[i] = make_float4(s[0], s[1], s[2], ioff >= 0 ? s[ioff] : 0.0f);
+}
+
+// FeatureAssociation::AlignScan's slice: elements [first, first + count) of the virtual concatenation pc1 + pc2, copied as PointXYZI with
+// intensity 0 (pcl::copyPointCloud from PointXYZ leaves the extra field at its default)
+__global__ __launch_bounds__(kC) void k_align_slice(int first, int count, const float4* __restrict__ a, int na, const float4* __restrict__ b, float4* __restrict__ out) {
+  const int i = blockIdx.x * kC + threadIdx.x;
+  if (i >= count) return;
+  const int j = first + i;
+  const float4 p = j < na ? a[j] : b[j - na];
+  out[i] = make_float4(p.x, p.y, p.z, 0.0f);
 }
 
 struct Tf32c { float a[9]; float t[3]; };
@@ -122,29 +135,30 @@ __device__ __forceinline__ int voxel_of(const float4 p, const VoxP v) {
   const int k = (int)(floorf(p.z * v.inv_leaf) - (float)v.minb[2]);
   return i + j * v.div[0] + k * v.div[0] * v.div[1];
 }
-__global__ __launch_bounds__(kC) void k_voxel_accumulate(int n, const float4* __restrict__ pts, VoxP v, double* __restrict__ sums /* [ncell][4] */,
-                                                         int* __restrict__ counts) {
+__global__ __launch_bounds__(kC) void k_voxel_key(int n, const float4* __restrict__ pts, VoxP v, unsigned* __restrict__ key, int* __restrict__ val,
+                                                  int* __restrict__ counts) {
   const int i = blockIdx.x * kC + threadIdx.x;
   if (i >= n) return;
-  const float4 p = pts[i];
-  const int c = voxel_of(p, v);
-  double* s = sums + 4 * (size_t)c;
-  atomicAdd(s + 0, (double)p.x); atomicAdd(s + 1, (double)p.y); atomicAdd(s + 2, (double)p.z); atomicAdd(s + 3, (double)p.w);
+  const int c = voxel_of(pts[i], v);
+  key[i] = (unsigned)c; val[i] = i;
   atomicAdd(counts + c, 1);
 }
 __global__ __launch_bounds__(kC) void k_flag_nonzero(int n, const int* __restrict__ counts, int* __restrict__ flags) {
   const int i = blockIdx.x * kC + threadIdx.x;
   if (i < n) flags[i] = counts[i] > 0 ? 1 : 0;
 }
-__global__ __launch_bounds__(kC) void k_voxel_emit(int ncell, const double* __restrict__ sums, const int* __restrict__ counts, const int* __restrict__ pos,
-                                                   float4* __restrict__ out) {
+// one thread per voxel: the centroid of ALL four fields, accumulated in float over the voxel's points in ascending input index
+// (`order` = point indices sorted stably by voxel; `start` = exclusive scan of the per-voxel counts), then divided by the count
+__global__ __launch_bounds__(kC) void k_voxel_emit(int ncell, const float4* __restrict__ pts, const int* __restrict__ order, const int* __restrict__ start,
+                                                   const int* __restrict__ pos, float4* __restrict__ out) {
   const int c = blockIdx.x * kC + threadIdx.x;
   if (c >= ncell) return;
-  const int k = counts[c];
-  if (k == 0) return;
-  const double inv = 1.0 / (double)k;
-  const double* s = sums + 4 * (size_t)c;
-  out[pos[c]] = make_float4((float)(s[0] * inv), (float)(s[1] * inv), (float)(s[2] * inv), (float)(s[3] * inv));
+  const int j0 = start[c], j1 = start[c + 1];
+  if (j1 == j0) return;
+  float4 s = pts[order[j0]];
+  for (int j = j0 + 1; j < j1; ++j) { const float4 p = pts[order[j]]; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+  const float k = (float)(j1 - j0);
+  out[pos[c]] = make_float4(s.x / k, s.y / k, s.z / k, s.w / k);
 }
 
 // ---------------------------------------------------------------------------------------------- uniform grid (cell-sorted copy)
@@ -267,11 +281,22 @@ __global__ __launch_bounds__(kC) void k_ransac_count(int n, const float4* __rest
     if (t) atomicAdd(counts + h, t);          // one atomic per workgroup and hypothesis
   }
 }
-// inliers of plane `co`: flags, and (optionally) first and second moments in double for the least-squares refit
+// inliers of plane `co`: flags, and (optionally) the count and the first / second moments of the inliers for the least-squares refit.
+// The moments are accumulated EXACTLY: a coordinate is a float, so x and x y are exact doubles; each term is scaled by 2^shift
+// (shift chosen from the cloud's bounds so that |term| < 2^60), rounded ONCE to an integer and added as two integer parts
+// (q >> 24 and q & 0xffffff: neither sum can overflow 64 bits below 2^27 points).  Integer sums do not depend on the order of the
+// additions, so the refitted plane — and every inlier decision that follows — is reproducible and equals the sequential restatement
+// bit for bit (double atomics left the last bits to scheduling: one flipped inlier per ~10 scans).
+struct MomI { unsigned long long v[19]; };      // [0] count, then (hi, lo) of sx sy sz xx xy xz yy yz zz
+__device__ __forceinline__ void mom_add(long long& hi, unsigned long long& lo, double t, double scale) {
+  const long long q = __double2ll_rn(t * scale);          // (t * 2^shift is exact; one rounding to the integer grid)
+  hi += q >> 24; lo += (unsigned long long)(q & 0xffffff);
+}
 __global__ __launch_bounds__(kC) void k_plane_inliers(int n, const float4* __restrict__ pts, float c0, float c1, float c2, float c3, float thr,
-                                                      int* __restrict__ flags, double* __restrict__ mom /* n, sx,sy,sz, xx,xy,xz,yy,yz,zz */) {
-  // capped grid striding over the points; the ten moments leave with one atomic per WORKGROUP each
-  double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                                                      int* __restrict__ flags, MomI* __restrict__ mom, double scale) {
+  long long hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long cnt = 0;
   for (int i = blockIdx.x * kC + threadIdx.x; i < n; i += gridDim.x * kC) {
     const float4 p = pts[i];
     const float d = ((c0 * p.x + c1 * p.y) + c2 * p.z) + c3;
@@ -279,22 +304,29 @@ __global__ __launch_bounds__(kC) void k_plane_inliers(int n, const float4* __res
     flags[i] = in;
     if (in && mom) {
       const double x = p.x, y = p.y, z = p.z;
-      v[0] += 1; v[1] += x; v[2] += y; v[3] += z; v[4] += x * x; v[5] += x * y; v[6] += x * z; v[7] += y * y; v[8] += y * z; v[9] += z * z;
+      ++cnt;
+      mom_add(hi[0], lo[0], x, scale); mom_add(hi[1], lo[1], y, scale); mom_add(hi[2], lo[2], z, scale);
+      mom_add(hi[3], lo[3], x * x, scale); mom_add(hi[4], lo[4], x * y, scale); mom_add(hi[5], lo[5], x * z, scale);
+      mom_add(hi[6], lo[6], y * y, scale); mom_add(hi[7], lo[7], y * z, scale); mom_add(hi[8], lo[8], z * z, scale);
     }
   }
   if (mom) {
-    __shared__ double red[kC / 64][10];
+    __shared__ unsigned long long red[kC / 64][19];
+    unsigned long long v[19];
+    v[0] = cnt;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      double s = v[k];
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+    for (int k = 0; k < 9; ++k) { v[1 + 2 * k] = (unsigned long long)hi[k]; v[2 + 2 * k] = lo[k]; }      // (two's complement: the signed parts add modulo 2^64)
+#pragma unroll
+    for (int k = 0; k < 19; ++k) {
+      unsigned long long t = v[k];
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = t;
     }
     __syncthreads();
-    if (threadIdx.x < 10) {
-      double t = 0.0;
+    if (threadIdx.x < 19) {
+      unsigned long long t = 0;
       for (int w = 0; w < kC / 64; ++w) t += red[w][threadIdx.x];
-      if (t != 0.0) atomicAdd(mom + threadIdx.x, t);
+      if (t) atomicAdd(&mom->v[threadIdx.x], t);
     }
   }
 }
@@ -413,6 +445,36 @@ int lvf_cloud_concat(lvf_ctx* ctx, const lvf_cloud* const* parts, int n_parts, l
   return LVF_OK;
 }
 
+// FeatureAssociation::AlignScan (association.cpp:39-64): the keyframe's sweep cut out of two consecutive raw revolutions.
+// pc1 / pc2 = the revolutions stamped stamp1 < stamp2 (the map entries either side of raw_point_clouds_.upper_bound(time)); a revolution
+// stamped t covers [t - cycle/2, t + cycle/2].  The slice bounds are the reference's own index arithmetic, evaluated in double and
+// truncated toward zero like its iterator offsets:  size * (time - start - cycle/2) / (end - start)  and  size * (time - start + cycle/2) / (end - start)
+// with start = stamp1 - cycle/2, end = stamp2 + cycle/2, size = |pc1| + |pc2|.  *aligned = 0 (and an empty cloud) where the reference
+// returns false: the keyframe's sweep is not covered by the two revolutions.
+int lvf_cloud_align_scan(const lvf_cloud* pc1, double stamp1, const lvf_cloud* pc2, double stamp2, double cycle_time, double time, lvf_cloud** out, int* aligned) {
+  LVF_REQUIRE(pc1 && pc2 && out && aligned, "lvf_cloud_align_scan: null argument");
+  LVF_REQUIRE(pc1->ctx == pc2->ctx, "lvf_cloud_align_scan: clouds of two contexts");
+  LVF_REQUIRE(cycle_time > 0.0 && stamp2 > stamp1, "lvf_cloud_align_scan: stamps must increase and the cycle time be positive");
+  lvf_ctx* ctx = pc1->ctx;
+  LVF_TRY(lvf::enter(ctx));
+  *aligned = 0;
+  const double end_time = stamp2 + cycle_time / 2, start_time = stamp1 - cycle_time / 2;
+  const int size = pc1->n + pc2->n;
+  if (time - cycle_time / 2 < start_time || time + cycle_time / 2 > end_time) return new_cloud(ctx, 0, out);
+  const long long first = (long long)(size * (time - start_time - cycle_time / 2) / (end_time - start_time));
+  const long long last = (long long)(size * (time - start_time + cycle_time / 2) / (end_time - start_time));
+  LVF_REQUIRE(first >= 0 && last >= first && last <= size, "lvf_cloud_align_scan: slice [%lld, %lld) outside the %d points", first, last, size);
+  lvf_cloud* c = nullptr;
+  LVF_TRY(new_cloud(ctx, (int)(last - first), &c));
+  if (last > first) {
+    hipLaunchKernelGGL(k_align_slice, dim3(gridc((int)(last - first))), dim3(kC), 0, ctx->stream, (int)first, (int)(last - first), pc1->pts.p, pc1->n, pc2->pts.p, c->pts.p);
+    LVF_HIP(hipGetLastError());
+  }
+  *aligned = 1;
+  *out = c;
+  return LVF_OK;
+}
+
 int lvf_cloud_voxel_filter(const lvf_cloud* in, float leaf, lvf_cloud** out) {
   LVF_REQUIRE(in && out, "lvf_cloud_voxel_filter: null argument");
   LVF_REQUIRE(leaf > 0.0f && std::isfinite(leaf), "lvf_cloud_voxel_filter: leaf must be finite > 0");
@@ -433,20 +495,24 @@ int lvf_cloud_voxel_filter(const lvf_cloud* in, float leaf, lvf_cloud** out) {
   }
   // PCL refuses such grids too ("Leaf size is too small for the input dataset. Integer indices would overflow.")
   LVF_REQUIRE(ncell > 0 && ncell <= (1ll << 26), "lvf_cloud_voxel_filter: %lld voxels: leaf size too small for the cloud's extent", ncell);
-  DevBuf<double> sums; DevBuf<int> counts, flags, pos;
-  LVF_TRY(sums.alloc((size_t)4 * ncell)); LVF_TRY(counts.alloc(ncell)); LVF_TRY(flags.alloc(ncell)); LVF_TRY(pos.alloc((size_t)ncell + 1));
-  LVF_HIP(hipMemsetAsync(sums.p, 0, (size_t)32 * ncell, s));
+  DevBuf<int> counts, flags, pos, start, val, order; DevBuf<unsigned> key, key_sorted;
+  LVF_TRY(counts.alloc(ncell)); LVF_TRY(flags.alloc(ncell)); LVF_TRY(pos.alloc((size_t)ncell + 1)); LVF_TRY(start.alloc((size_t)ncell + 1));
+  LVF_TRY(key.alloc(in->n)); LVF_TRY(key_sorted.alloc(in->n)); LVF_TRY(val.alloc(in->n)); LVF_TRY(order.alloc(in->n));
   LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)4 * ncell, s));
-  hipLaunchKernelGGL(k_voxel_accumulate, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, v, sums.p, counts.p);
+  hipLaunchKernelGGL(k_voxel_key, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, v, key.p, val.p, counts.p);
   hipLaunchKernelGGL(k_flag_nonzero, dim3(gridc((int)ncell)), dim3(kC), 0, s, (int)ncell, counts.p, flags.p);
   LVF_HIP(hipGetLastError());
+  int bits = 1;
+  while ((1ll << bits) < ncell) ++bits;
+  LVF_TRY(device_sort_pairs_u32(ctx, key.p, key_sorted.p, val.p, order.p, in->n, bits));      // stable: ascending input index inside a voxel
+  LVF_TRY(device_exclusive_scan_i32(ctx, counts.p, (int)ncell, start.p));
   LVF_TRY(device_exclusive_scan_i32(ctx, flags.p, (int)ncell, pos.p));
   int total = 0;
   LVF_HIP(hipMemcpyAsync(&total, pos.p + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
   LVF_HIP(hipStreamSynchronize(s));
   lvf_cloud* c = nullptr;
   LVF_TRY(new_cloud(ctx, total, &c));
-  hipLaunchKernelGGL(k_voxel_emit, dim3(gridc((int)ncell)), dim3(kC), 0, s, (int)ncell, sums.p, counts.p, pos.p, c->pts.p);
+  hipLaunchKernelGGL(k_voxel_emit, dim3(gridc((int)ncell)), dim3(kC), 0, s, (int)ncell, in->pts.p, order.p, start.p, pos.p, c->pts.p);
   LVF_HIP(hipGetLastError());
   LVF_HIP(hipStreamSynchronize(s));
   *out = c;
@@ -494,8 +560,17 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
   if (in->n < 3) return new_cloud(ctx, 0, out);          // SACSegmentation cannot fit a model: no inliers
   hipStream_t s = ctx->stream;
   const int n = in->n;
-  DevBuf<int> counts, flags; DevBuf<double> mom;
-  LVF_TRY(counts.alloc(max_iterations)); LVF_TRY(flags.alloc(n)); LVF_TRY(mom.alloc(10));
+  DevBuf<int> counts, flags; DevBuf<MomI> mom;
+  LVF_TRY(counts.alloc(max_iterations)); LVF_TRY(flags.alloc(n)); LVF_TRY(mom.alloc(1));
+  // scale of the exact moment sums: |coordinate| < 2^e  =>  |x y| 2^shift < 2^60
+  float blo[3], bhi[3];
+  LVF_TRY(cloud_bounds(in, blo, bhi));
+  float maxabs = 0.0f;
+  for (int k = 0; k < 3; ++k) maxabs = std::max(maxabs, std::max(std::fabs(blo[k]), std::fabs(bhi[k])));
+  int e2 = 0;
+  (void)std::frexp(maxabs, &e2);
+  const int shift = 60 - 2 * std::max(e2, 0);
+  const double mom_scale = std::ldexp(1.0, shift);
   LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)4 * max_iterations, s));
   const int gx = std::min(gridc(n), 8);      // x 100 hypotheses = 800 workgroups, one counter atomic each
   hipLaunchKernelGGL(k_ransac_count, dim3(gx, max_iterations), dim3(kC), 0, s, n, in->pts.p, (unsigned long long)seed, distance_threshold, counts.p);
@@ -535,12 +610,15 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
     co[0] = nx; co[1] = ny; co[2] = nz; co[3] = -((nx * sp[0].x + ny * sp[0].y) + nz * sp[0].z);
   }
   // optimizeModelCoefficients: least-squares plane through the inliers, then re-select (SACSegmentation::segment)
-  LVF_HIP(hipMemsetAsync(mom.p, 0, 80, s));
-  hipLaunchKernelGGL(k_plane_inliers, dim3(std::min(kCapBlocks, gridc(n))), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, mom.p);
+  LVF_HIP(hipMemsetAsync(mom.p, 0, sizeof(MomI), s));
+  hipLaunchKernelGGL(k_plane_inliers, dim3(std::min(kCapBlocks, gridc(n))), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, mom.p, mom_scale);
   LVF_HIP(hipGetLastError());
-  double m[10];
-  LVF_HIP(hipMemcpyAsync(m, mom.p, sizeof(m), hipMemcpyDeviceToHost, s));
+  MomI hm;
+  LVF_HIP(hipMemcpyAsync(&hm, mom.p, sizeof(hm), hipMemcpyDeviceToHost, s));
   LVF_HIP(hipStreamSynchronize(s));
+  double m[10];
+  m[0] = (double)hm.v[0];
+  for (int k = 0; k < 9; ++k) m[1 + k] = std::ldexp((double)(long long)hm.v[1 + 2 * k] * 16777216.0 + (double)hm.v[2 + 2 * k], -shift);
   if (m[0] >= 3.0) {
     const double inv = 1.0 / m[0], cx = m[1] * inv, cy = m[2] * inv, cz = m[3] * inv;
     const double C[9] = {m[4] * inv - cx * cx, m[5] * inv - cx * cy, m[6] * inv - cx * cz, m[5] * inv - cx * cy, m[7] * inv - cy * cy, m[8] * inv - cy * cz,
@@ -549,7 +627,7 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
     smallest_eigvec3(C, nv);
     if (nv[2] < 0.0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }       // fixed orientation (inlier selection is sign-free)
     co[0] = (float)nv[0]; co[1] = (float)nv[1]; co[2] = (float)nv[2]; co[3] = (float)(-(nv[0] * cx + nv[1] * cy + nv[2] * cz));
-    hipLaunchKernelGGL(k_plane_inliers, dim3(std::min(kCapBlocks, gridc(n))), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, (double*)nullptr);
+    hipLaunchKernelGGL(k_plane_inliers, dim3(std::min(kCapBlocks, gridc(n))), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, (MomI*)nullptr, 0.0);
     LVF_HIP(hipGetLastError());
   }
   if (coefficients4) for (int q = 0; q < 4; ++q) coefficients4[q] = co[q];

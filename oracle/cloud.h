@@ -7,7 +7,8 @@
 //   pcl::RadiusOutlierRemoval<PointXYZI>        association.cpp:217-221   (radius 4 x resolution, min 4 neighbours)
 //   pcl::SACSegmentation (plane, RANSAC, 100, optimise) + ExtractIndices   association.cpp:249-268
 // Declared: VoxelGrid accumulates each voxel's centroid in FLOAT over the points of the voxel (PCL's order is whatever its
-// unstable std::sort leaves; the oracle fixes ascending input index) and emits voxels by ascending index; RadiusOutlierRemoval
+// unstable std::sort leaves; the oracle fixes ascending input index) and emits voxels by ascending index; the plane refit's moments
+// are summed exactly in scaled integers (order-independent, see segment_plane); RadiusOutlierRemoval
 // keeps a point iff more than min_neighbors points (itself included) lie at squared distance < r^2; RANSAC bookkeeping as
 // in pcl::RandomSampleConsensus::computeModel (probability 0.99), sampling by splitmix64(seed, hypothesis, draw) because
 // PCL's boost::mt19937 stream cannot be reproduced without PCL.
@@ -30,6 +31,18 @@ inline void cloud_transform(const float* in, int n, const double* pose, float* o
     transform_query_f32(tf, in + 4 * (size_t)i, out + 4 * (size_t)i);
     out[4 * (size_t)i + 3] = in[4 * (size_t)i + 3];
   }
+}
+
+// FeatureAssociation::AlignScan  src/lvio_fusion/src/association.cpp:39-64: the slice [first, last) of pc1 + pc2 a keyframe at `time`
+// gets (iterator offsets computed in double and truncated, as `pc.begin() + size * (...) / (...)` does).  Returns false where the
+// reference does.
+inline bool align_scan_range(int n1, double stamp1, int n2, double stamp2, double cycle_time, double time, long long* first, long long* last) {
+  const double end_time = stamp2 + cycle_time / 2, start_time = stamp1 - cycle_time / 2;
+  const int size = n1 + n2;
+  if (time - cycle_time / 2 < start_time || time + cycle_time / 2 > end_time) return false;
+  *first = (long long)(size * (time - start_time - cycle_time / 2) / (end_time - start_time));
+  *last = (long long)(size * (time - start_time + cycle_time / 2) / (end_time - start_time));
+  return true;
 }
 
 inline std::vector<float> voxel_filter(const float* in, int n, float leaf) {
@@ -160,11 +173,25 @@ inline std::vector<unsigned char> segment_plane(const float* in, int n, float th
   }
   if (best < 0) return mask;
   count_inliers(in, n, best_co, thr, &mask);
-  double m[10] = {0};
+  // count and first / second moments of the inliers, accumulated EXACTLY (declared; PCL's own summation order is unpinned): the
+  // coordinates are floats, so x and x y are exact doubles; every term is scaled by 2^shift (|coordinate| < 2^e over the WHOLE cloud,
+  // shift = 60 - 2 max(e, 0)), rounded once to an integer and summed in integers — the sum does not depend on the order of the
+  // additions, which is what lets a parallel implementation reproduce it bit for bit.
+  float maxabs = 0.0f;
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) maxabs = std::fmax(maxabs, std::fabs(in[4 * (size_t)i + k]));
+  int e2 = 0;
+  (void)std::frexp(maxabs, &e2);
+  const int shift = 60 - 2 * std::max(e2, 0);
+  long long hi[9] = {0}; unsigned long long lo[9] = {0}; long long cnt = 0;
+  auto add = [&](int k, double t) { const long long q = std::llrint(std::ldexp(t, shift)); hi[k] += q >> 24; lo[k] += (unsigned long long)(q & 0xffffff); };
   for (int i = 0; i < n; ++i) if (mask[i]) {
     const double x = in[4 * (size_t)i], y = in[4 * (size_t)i + 1], z = in[4 * (size_t)i + 2];
-    m[0] += 1; m[1] += x; m[2] += y; m[3] += z; m[4] += x * x; m[5] += x * y; m[6] += x * z; m[7] += y * y; m[8] += y * z; m[9] += z * z;
+    ++cnt;
+    add(0, x); add(1, y); add(2, z); add(3, x * x); add(4, x * y); add(5, x * z); add(6, y * y); add(7, y * z); add(8, z * z);
   }
+  double m[10];
+  m[0] = (double)cnt;
+  for (int k = 0; k < 9; ++k) m[1 + k] = std::ldexp((double)hi[k] * 16777216.0 + (double)lo[k], -shift);
   float co[4] = {best_co[0], best_co[1], best_co[2], best_co[3]};
   if (m[0] >= 3.0) {
     const double inv = 1.0 / m[0], cx = m[1] * inv, cy = m[2] * inv, cz = m[3] * inv;

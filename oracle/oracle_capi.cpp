@@ -361,6 +361,9 @@ void lvo_icp_solve(const float* map, int M, int mstride, const float* query, int
 
 
 // ---------------- map-cloud maintenance (cloud.h) ----------------
+int lvo_align_scan_range(int n1, double stamp1, int n2, double stamp2, double cycle_time, double time, long long* first_last2) {
+  return align_scan_range(n1, stamp1, n2, stamp2, cycle_time, time, first_last2, first_last2 + 1) ? 1 : 0;
+}
 void lvo_cloud_transform(const float* in, int n, const double* pose, float* out) { cloud_transform(in, n, pose, out); }
 // returns the number of output points; out (capacity n*4 floats) receives them
 int lvo_voxel_filter(const float* in, int n, float leaf, float* out) {

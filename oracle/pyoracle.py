@@ -317,6 +317,21 @@ def cloud_transform(xyzi, pose):
     return out
 
 
+def align_scan(pc1, stamp1, pc2, stamp2, cycle_time, time):
+    """FeatureAssociation::AlignScan (association.cpp:39-64): the keyframe's sweep cut out of two raw revolutions ([n][>=3] float arrays);
+    returns the [m][4] PointXYZI cloud (intensity 0) or None where the reference returns false."""
+    a, b = _f32(pc1), _f32(pc2)
+    fl = np.zeros(2, np.int64)
+    lib().lvo_align_scan_range.restype = C.c_int
+    ok = lib().lvo_align_scan_range(int(a.shape[0]), C.c_double(stamp1), int(b.shape[0]), C.c_double(stamp2), C.c_double(cycle_time), C.c_double(time),
+                                    fl.ctypes.data_as(C.POINTER(C.c_longlong)))
+    if not ok:
+        return None
+    pc = np.concatenate([a[:, :3], b[:, :3]])[fl[0]:fl[1]]
+    out = np.zeros((pc.shape[0], 4), np.float32); out[:, :3] = pc
+    return out
+
+
 def voxel_filter(xyzi, leaf):
     a = _f32(xyzi)
     out = np.empty_like(a)

@@ -51,8 +51,10 @@ def test_voxel_filter_parity(ctx, oracle, scene, leaf):
     out = cl.voxel_filter(leaf).download()
     ref = oracle.voxel_filter(q, leaf)
     assert out.shape == ref.shape                               # same voxels, same (ascending index) order
-    scale = np.abs(ref).max(0)
-    assert (np.abs(out - ref) <= 2e-6 * np.abs(ref) + 1e-6 * scale).all()   # double-atomic sums vs the oracle's float accumulation
+    # float accumulation over each voxel's points in ascending input index, on both sides: equal bit for bit
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    # ... and independent of scheduling: a second run gives the same bits
+    assert np.array_equal(cl.voxel_filter(leaf).download().view(np.uint32), out.view(np.uint32))
     assert len(api.Cloud(ctx, np.zeros((0, 4), np.float32)).voxel_filter(leaf)) == 0
     one = api.Cloud(ctx, q[:1]).voxel_filter(leaf).download()
     assert np.array_equal(one, q[:1])
@@ -83,13 +85,10 @@ def test_segment_plane_parity(ctx, oracle, scene):
         inl, co, it = cl.segment_plane(0.05, 100, seed)
         mask, co_ref, it_ref = oracle.segment_plane(pts, 0.05, 100, seed)
         assert it == it_ref
-        assert np.allclose(co, co_ref, rtol=1e-6, atol=1e-7)
+        # the refit's moments are exact integer sums on both sides: the plane and every inlier decision are EQUAL
+        assert np.array_equal(np.asarray(co, np.float64), np.asarray(co_ref, np.float64))
         got = inl.download()
-        ref = pts[mask > 0]
-        # the refit goes through double atomics (order-dependent last bits): a point exactly at the threshold may flip
-        assert abs(len(got) - len(ref)) <= 2
-        if len(got) == len(ref):
-            assert np.array_equal(got, ref)
+        assert np.array_equal(got, pts[mask > 0])
         inl.close()
     tiny = api.Cloud(ctx, pts[:2])
     e, co, it = tiny.segment_plane(0.05)
@@ -122,3 +121,29 @@ def test_device_resident_map_pipeline(ctx, oracle, scene):
     i0, d0, v0 = oracle.knn3(host_map, q[:3000], c["pose0"], 4.0)
     assert np.array_equal(v1, v0) and np.array_equal(i1[v0 > 0], i0[v0 > 0])
     assert v0.sum() > 1000
+
+
+def test_align_scan_parity(ctx, oracle, scene):
+    """FeatureAssociation::AlignScan (association.cpp:39-64) on device: the slice of two consecutive raw revolutions a keyframe gets — the
+    reference's double index arithmetic, truncated; False where the sweep is not covered."""
+    from lvio_fusion_amd import api
+    _, q = scene
+    pc1, pc2 = q[:4321], q[5000:12345]
+    c1, c2 = api.Cloud(ctx, pc1), api.Cloud(ctx, pc2)
+    cyc = 0.1
+    for t1, t2, t in ((10.0, 10.1, 10.05), (10.0, 10.1, 10.0), (10.0, 10.1, 10.1), (10.0, 10.1, 10.0333333), (3.0, 3.0999, 3.07), (10.0, 10.1, 9.99), (10.0, 10.1, 10.11),
+                      (1e9, 1e9 + 0.1, 1e9 + 0.0421)):
+        ref = oracle.align_scan(pc1, t1, pc2, t2, cyc, t)
+        got, ok = api.Cloud.align_scan(c1, t1, c2, t2, cyc, t)
+        assert ok == (ref is not None), (t1, t2, t)
+        if ref is None:
+            assert len(got) == 0
+        else:
+            assert np.array_equal(got.download(), ref), (t1, t2, t)
+        got.close()
+    assert oracle.align_scan(pc1, 10.0, pc2, 10.1, cyc, 10.05).shape[0] > 1000
+    # the aligned sweep feeds the extraction unchanged
+    g, ok = api.Cloud.align_scan(c1, 10.0, c2, 10.1, cyc, 10.02)
+    assert ok and np.all(g.download()[:, 3] == 0)
+    for h in (g, c1, c2):
+        h.close()
