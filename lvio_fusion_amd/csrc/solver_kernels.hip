@@ -89,7 +89,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // device scalar slots
 // Each sum slot is STRIPED over kStripes addresses (workgroup b adds into stripe b % kStripes, the host adds the stripes up): a
 // cost pass issues one atomic per wave, ~1100 of them at configs[3], and on ONE address they serialise in L2 (measured: the
-// residual-only TwoFrame pass spent 2/3 of its 16 us there).  SC_GMAX is a max and uses stripe 0 only.
+// residual-only TwoFrame pass spent 2/3 of its 16 us there).  SC_GMAX is a max (striped too; the decision takes the max over the stripes).
 constexpr int kStripes = 32;
 enum { SC_COST = 0, SC_COST_NEW = 1 * kStripes, SC_MODEL = 2 * kStripes, SC_DXNORM = 3 * kStripes, SC_XNORM = 4 * kStripes, SC_GMAX = 5 * kStripes,
        SC_N = 6 * kStripes, SC_FAIL = SC_N /* int flag */, SC_TICKET = SC_N + 1 /* int: workgroups of the candidate-cost pass that are done */, SC_ALLOC = SC_N + 2 };
@@ -2215,7 +2215,9 @@ __device__ __forceinline__ void landmark_back_body(const int vb, const int nwg, 
   } else if (threadIdx.x == 3) {
     double v = 0.0;
     for (int k = 0; k < kT / 64; ++k) v = fmax(v, red[3][k]);
-    if (v != 0.0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX), (unsigned long long)__double_as_longlong(v));      // (non-negative doubles order like their bit patterns)
+    // (non-negative doubles order like their bit patterns; striped like the sums: hundreds of workgroups hitting ONE address serialise,
+    // measured +4 us on this launch)
+    if (v != 0.0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX + (vb & (kStripes - 1))), (unsigned long long)__double_as_longlong(v));
   }
 }
 // Model cost change without a pass over H:  (H + D) dx = -g  =>  -dx^T (g + H dx / 2) = 1/2 sum_i dx_i (D_i dx_i - g_i).
@@ -2263,7 +2265,7 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
   if (vb * kT < d) {      // block-uniform
     block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM);
     for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_down(g, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX), (unsigned long long)__double_as_longlong(g));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX + (vb & (kStripes - 1))), (unsigned long long)__double_as_longlong(g));
   }
   block_add(x2, scal + SC_XNORM);
 }
@@ -2309,7 +2311,8 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int slot = wv; slot < 6; slot += kDT / 64) {
       double v = lane < kStripes ? (COHERENT ? __hip_atomic_load(A.scal + slot * kStripes + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A.scal[slot * kStripes + lane]) : 0.0;
-      v = wave_sum(v);
+      if (slot == SC_GMAX / kStripes) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o)); }      // the gradient's max norm: a max over its stripes
+      else v = wave_sum(v);
       if (lane == 0) s_sum[slot] = v;
     }
   }
@@ -2328,7 +2331,7 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
     const int hfail = *reinterpret_cast<const int*>(A.scal + SC_FAIL);
     const double cost_before = s_sum[SC_COST / kStripes], cost_new = s_sum[SC_COST_NEW / kStripes], model = -s_sum[SC_MODEL / kStripes];
     const double dxnorm = sqrt(s_sum[SC_DXNORM / kStripes]), xnorm = sqrt(s_sum[SC_XNORM / kStripes]);
-    const double gmax = A.scal[SC_GMAX];                       // a max, kept in stripe 0 (the stored bit pattern is the double's)
+    const double gmax = s_sum[SC_GMAX / kStripes];             // a max over the stripes (the stored bit patterns are the doubles')
     const bool solved = hfail == 0 && isfinite(cost_new) && isfinite(model);
     const int it = lc.iter;
     if (it == 0) { lc.initial_cost = cost_before; lc.cost = cost_before; }
