@@ -265,3 +265,22 @@ def test_hip_imu_reproduces_reference_fixtures(ctx):
                 assert_parity(b.jacobian(k), G[Jk][:, off[k]:off[k + 1]].reshape(len(ok), 15, cols[k]), f"ImuError {Jk} block {k}")
             b.close()
         st.close()
+
+
+def test_eigen_stand_in_selftest(tmp_path):
+    """oracle/ref_shim/Eigen/Core is what lets the reference's IMU text compile: its operations are checked on their own (plain-loop
+    references and identities inside the C++ self-test) and its 15 x 15 inverse / LLT against numpy, so the IMU pin does not rest on a
+    stand-in that could be wrong the same way on both sides."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "shim_selftest")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "oracle", "ref_shim"),
+                           os.path.join(root, "oracle", "ref_shim_test", "shim_selftest.cpp"), "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    o = json.loads(p.stdout)
+    assert o["fails"] == 0
+    S, Si, L = (np.array(o[k]).reshape(15, 15) for k in ("S", "Sinv", "L"))
+    assert np.allclose(Si, np.linalg.inv(S), rtol=1e-11, atol=1e-13)
+    assert np.allclose(L, np.linalg.cholesky(S), rtol=1e-12, atol=1e-14)
