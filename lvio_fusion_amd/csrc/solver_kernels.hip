@@ -1087,9 +1087,17 @@ __device__ __forceinline__ void prepare_body(const unsigned bx, const PrepArgs& 
     E[(size_t)l * ldE + dp] = gr[l];
     return;
   }
+  // Only the LOWER triangle is assembled (nothing downstream reads an entry right of the diagonal as a value: the factorisations work
+  // on lower tiles, and what they carry in the upper halves of diagonal tiles only ever feeds those same entries).  The triangle is
+  // folded into a rectangle so that consecutive threads still write consecutive entries of a row: rectangle row q holds matrix row q
+  // (columns 0..q) followed by matrix row ld-1-q (columns 0..ld-1-q), ld + 1 entries in all.
   const size_t e = (size_t)bx * kT + threadIdx.x;
-  if (e >= (size_t)ld * ld) return;
-  const int I = (int)(e / ld), J = (int)(e % ld);
+  const int half = (ld + 1) / 2;
+  if (e >= (size_t)half * (ld + 1)) return;
+  const int q = (int)(e / (ld + 1)), cc = (int)(e % (ld + 1));
+  int I, J;
+  if (cc <= q) { I = q; J = cc; }
+  else { I = ld - 1 - q; J = cc - q - 1; if (I == q) return; }      // (odd ld: the middle row is its own partner)
   const int oi = iperm[I], oj = iperm[J];
   double v = 0.0;
   if (oi >= 0) {
@@ -1102,7 +1110,7 @@ __device__ __forceinline__ void prepare_body(const unsigned bx, const PrepArgs& 
   } else if (I == J) {
     v = 1.0;
   }
-  S[e] = v;
+  S[(size_t)I * ld + J] = v;
 }
 __global__ __launch_bounds__(kT) void k_prepare(PrepArgs a) { prepare_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_prepare_b(const PrepArgs* __restrict__ t) { prepare_body(blockIdx.x, t[blockIdx.y]); }
@@ -2686,9 +2694,9 @@ static int build_chain(lvf_problem* p) {
   // damped system
   {
     PrepArgs& a = c.prep;
-    const size_t nS = (size_t)p->ld * p->ld;
     a.ld = p->ld; a.dpad = p->dpad; a.iperm = p->iperm.p; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.S = p->S.p;
-    a.nS_blocks = (unsigned)((nS + kT - 1) / kT); a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.C = p->C.p; a.gr = p->gr.p; a.Cd = p->Cd.p; a.E = p->E.p;
+    // (the lower triangle, folded: prepare_body)
+    a.nS_blocks = (unsigned)(((size_t)((p->ld + 1) / 2) * (p->ld + 1) + kT - 1) / kT); a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.C = p->C.p; a.gr = p->gr.p; a.Cd = p->Cd.p; a.E = p->E.p;
     a.eoff = p->lm_eoff.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p; a.slotB = p->compact ? p->slotB.p : nullptr; a.Ct = p->Ct.p; a.grt = p->grt.p;
     a.scal = p->scal.p; a.nblocks = (int)a.nS_blocks + (p->n_lm ? grid(p->compact ? 8 * p->n_lm : p->n_lm) : 0); a.done = done;
   }
@@ -2874,6 +2882,10 @@ static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool
   pa.radius = radius_dev;
   if (!reset_scalars) pa.scal = nullptr;
   if (!gated) pa.done = nullptr;
+  // LVF_POISON_S=1 (diagnostic): every byte of S is 0xff (NaN) before the assembly, so whatever the assembly does not write — the upper
+  // triangle — stays NaN; results must not change (tests/test_gpu_solver.py runs the parity cases this way too)
+  static const bool poison = std::getenv("LVF_POISON_S") != nullptr;
+  if (poison) LVF_HIP(hipMemsetAsync(p->S.p, 0xff, (size_t)p->ld * p->ld * 8, q));
   hipLaunchKernelGGL(k_prepare, dim3(pa.nblocks), dim3(kT), 0, q, pa);
   stage_mark(p, ST_PREPARE, 1);
   if (level0_done) *level0_done = false;

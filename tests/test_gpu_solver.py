@@ -228,3 +228,18 @@ def test_mixed_call_sequences_leave_no_stale_accumulators(ctx, oracle):
     batch.close()
     for h in [prob, st] + [x for x in b.values() if x is not None]:
         h.close()
+
+
+def test_upper_triangle_of_the_reduced_system_is_never_read():
+    """k_prepare assembles only the lower triangle of S.  With LVF_POISON_S=1 every byte of S is 0xff (NaN) before each assembly, so the
+    upper triangle stays NaN through the Schur complement, the sparse levels, the dense factorisation and the back substitution: the
+    per-iteration and trajectory parity cases must still pass (the switch is read once per process, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["LVF_POISON_S"] = "1"
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_solver.py"),
+                        "-k", "lm_iteration_parity or imu_gaps", os.path.join(root, "tests", "test_gpu_solve_trajectory.py")], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
