@@ -1558,13 +1558,16 @@ struct FactorLds { double* Lcol; double* Xcol; double* Linv; };       // Lcol/Xc
 // diagonal wave Q, steps s = kGW qj + i (i unrolled, qj a real loop: the code of one column group is reused four times).  In step s the
 // owner of group s runs its pivots while every other diagonal wave applies group s - 1 (published at the end of step s - 1); the
 // workgroup meets at one barrier per step.
-__device__ __forceinline__ bool factor_diag_wave(double a[16], const int r, const int Q, const FactorLds& F) {
+// `nsteps` (<= kNB / kPG + 1): the last block of the corner is padded with identity rows / columns — their pivots are 1 and nothing
+// real depends on them — so the sweep stops one step after the last real pivot group (every wave of the workgroup gets the same count:
+// the barriers stay matched)
+__device__ __forceinline__ bool factor_diag_wave(double a[16], const int r, const int Q, const FactorLds& F, const int nsteps = kNB / kPG + 1) {
   bool bad = false;
 #pragma unroll 1
   for (int qj = 0; qj <= kNB / 16; ++qj) {
 #pragma unroll
     for (int i = 0; i < kGW; ++i) {
-      if (qj == kNB / 16 && i > 0) break;
+      if ((qj == kNB / 16 && i > 0) || kGW * qj + i >= nsteps) break;
       const int j0 = 16 * qj + kPG * i;                   // first pivot of group s
       const int prev_owner = i > 0 ? qj : qj - 1;         // owner of group s - 1
       if (j0 > 0 && prev_owner < Q) {                     // columns right of group s - 1: all 16
@@ -1603,12 +1606,12 @@ __device__ __forceinline__ bool factor_diag_wave(double a[16], const int r, cons
 
 // panel wave Q: owns the x columns 16Q..16Q+15 of its rows and runs one step behind the diagonal waves: in step s it applies the x
 // group s - 2 its left neighbours published in step s - 1, then — if it owns group s - 1 — finishes those x columns and publishes them.
-__device__ __forceinline__ void factor_panel_wave(double b[16], const int r, const int Q, const FactorLds& F) {
+__device__ __forceinline__ void factor_panel_wave(double b[16], const int r, const int Q, const FactorLds& F, const int nsteps = kNB / kPG + 1) {
 #pragma unroll 1
   for (int qj = 0; qj <= kNB / 16; ++qj) {
 #pragma unroll
     for (int i = 0; i < kGW; ++i) {
-      if (qj == kNB / 16 && i > 0) break;
+      if ((qj == kNB / 16 && i > 0) || kGW * qj + i >= nsteps) break;
       const int j0 = 16 * qj + kPG * i;
       const int o2 = i > 1 ? qj : qj - 1;                 // owner of group s - 2
       if (j0 >= 2 * kPG && o2 < Q) {
@@ -1643,7 +1646,7 @@ __device__ __forceinline__ void factor_panel_wave(double b[16], const int r, con
 //       L_kk^-T for the back substitution.
 //   workgroups behind them     — the rest of step kb-1's trailing update, A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi, which nothing in
 //       this launch reads (the next step does).
-struct CholArgs { double* Sd; int ld, nb; int* fail; double* Dinv; const int* done; unsigned long long* dbg; };   // dbg: LVF_CHOL_TIMING stamps
+struct CholArgs { double* Sd; int ld, nb; int* fail; double* Dinv; const int* done; unsigned long long* dbg; int last_cols; };   // dbg: LVF_CHOL_TIMING stamps; last_cols: real (un-padded) columns of the last block
 __host__ __device__ inline int chol_step_grid(int nb, int kb) {
   const int below = nb - kb - 1;
   return kb >= nb ? 0 : 2 + below + (kb > 0 ? below * (below + 1) / 2 : 0);
@@ -1787,8 +1790,11 @@ __device__ __forceinline__ void chol_step_body(const int bx, const CholArgs& A, 
   if (dbg) { dbg[3] = wall_clock64(); dbg[6] = clock64(); }
   const FactorLds F{Pi, Pj, Linv};
   bool bad = false;
-  if (panel_wave) factor_panel_wave(a, r, q, F);
-  else bad = factor_diag_wave(a, r, q, F);
+  // pivot groups to run: all of them, except in the last block where only the real columns (the rest is identity padding) need any
+  const int ncols = (kb == A.nb - 1 && A.last_cols > 0) ? min(A.last_cols, kNB) : kNB;
+  const int nsteps = (ncols + kPG - 1) / kPG + 1;
+  if (panel_wave) factor_panel_wave(a, r, q, F, nsteps);
+  else bad = factor_diag_wave(a, r, q, F, nsteps);
   if (dbg) { dbg[4] = wall_clock64(); dbg[7] = clock64(); }
   if (bad && r == 0) atomicExch(fail, 1 + kb);
   if (bx == 0 && !panel_wave) {
@@ -2727,6 +2733,7 @@ static int build_chain(lvf_problem* p) {
     }
   }
   c.chol.Sd = p->S.p + (size_t)p->off * (p->ld + 1); c.chol.ld = p->ld; c.chol.nb = p->nb; c.chol.fail = fail; c.chol.Dinv = p->Dinv.p; c.chol.done = done;
+  c.chol.last_cols = p->ndense + 1 - kNB * (p->nb - 1);       // (the right-hand-side row is the last real one)
   fill_back_args(p, c.back, &c.back_lds);
   c.back.done = done;
   {
