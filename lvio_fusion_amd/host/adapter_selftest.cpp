@@ -9,6 +9,7 @@
 // Raw little-endian arrays: <dir>/<name>.f64 / .i32 in, <dir>/out_<name>.f64 out; a one-line JSON summary on stdout.
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -136,6 +137,24 @@ static int run_window(const std::string& dir) {
       const auto t2 = std::chrono::steady_clock::now();
       std::fprintf(stderr, "host only: collect %.3f ms, build_window %.3f ms (%zu blocks, ok %d)\n", 1e3 * std::chrono::duration<double>(t1 - t0).count(),
                    1e3 * std::chrono::duration<double>(t2 - t1).count(), blocks.size(), (int)ok2);
+      if (rep == 2) {
+        // the window the recorder assembled while the blocks were being added must be the window the walk over the finished problem builds
+        ceres::Solver::Summary sm2;
+        const gpu::detail::Fail fail2{&sm2};
+        gpu::detail::Window& r = problem.recorder.window();
+        const bool usable = problem.recorder.usable(&problem);
+        const bool ok3 = usable && gpu::detail::finish_window(&problem, &r, &problem.recorder.constant_blocks(), fail2);
+        auto eqv = [](const auto& a, const auto& b) { return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0); };
+        const bool same = ok2 && ok3 && eqv(r.pose_ptr, w.pose_ptr) && eqv(r.lm_ptr, w.lm_ptr) && eqv(r.v_ptr, w.v_ptr) && eqv(r.ba_ptr, w.ba_ptr) && eqv(r.bg_ptr, w.bg_ptr) &&
+                          eqv(r.w_kf, w.w_kf) && eqv(r.pose_const, w.pose_const) && eqv(r.tc_l, w.tc_l) && eqv(r.tc_r, w.tc_r) && eqv(r.tc_lm, w.tc_lm) && eqv(r.tc_w, w.tc_w) &&
+                          eqv(r.tf_f, w.tf_f) && eqv(r.tf_o, w.tf_o) && eqv(r.tf_lm, w.tf_lm) && eqv(r.tf_k1, w.tf_k1) && eqv(r.tf_k2, w.tf_k2) && eqv(r.po_o, w.po_o) &&
+                          eqv(r.po_pw, w.po_pw) && eqv(r.po_kf, w.po_kf) && eqv(r.po_pi, w.po_pi) && eqv(r.imu_pre, w.imu_pre) && eqv(r.imu_i, w.imu_i) && eqv(r.imu_j, w.imu_j) &&
+                          eqv(r.pr_a, w.pr_a) && eqv(r.pr_b, w.pr_b) && eqv(r.pr_t, w.pr_t) && eqv(r.pr_w, w.pr_w) && eqv(r.pr_v, w.pr_v) && eqv(r.order_kind, w.order_kind) &&
+                          eqv(r.order_idx, w.order_idx) && r.huber == w.huber && r.have_left == w.have_left && r.have_right == w.have_right &&
+                          (!w.have_left || gpu::detail::same_cam(r.left, w.left)) && (!w.have_right || gpu::detail::same_cam(r.right, w.right));
+        std::printf("{\"host_only\": 1, \"blocks\": %zu, \"walk_ok\": %d, \"recorder_usable\": %d, \"recorded_equals_walk\": %d, \"n_kf\": %zu, \"n_lm\": %zu, \"n_prior\": %zu}\n",
+                    blocks.size(), (int)ok2, (int)usable, (int)same, w.pose_ptr.size(), w.lm_ptr.size(), w.pr_b.size());
+      }
     }
     return 0;
   }

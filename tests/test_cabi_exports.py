@@ -52,3 +52,44 @@ def test_product_path_does_not_touch_oracle():
                         # comments may cite the oracle; code may not use it
                         code_hits = [ln for ln in hits if "oracle/se3_ops.h" not in ln and "oracle/imu.h" not in ln and "oracle's" not in ln]
                         assert not code_hits, f"{sub}/{f} references the oracle: {code_hits[:2]}"
+
+
+def test_recorded_window_equals_walk_host_only(tmp_path):
+    """The host half of the Ceres surface, no GPU involved: adapt::Problem's recorder (payload captured while BuildProblem adds blocks,
+    lvf_ceres_adapter.hpp gpu::Recorder) must assemble exactly the window the walk over the finished ceres::Problem builds — every SoA
+    array, the keyframe / landmark numbering, weights, cameras, the Huber width, pose priors and the constant-pose mask."""
+    import json
+    import subprocess
+    import numpy as np
+    from lvio_fusion_amd import synthetic as syn
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "lvio_fusion_amd", "host", "adapter_selftest")
+    if not os.path.exists(exe):
+        pytest.skip("adapter_selftest not built (run __graft_entry__.build())")
+    dump = lambda d, name, a, dt: np.ascontiguousarray(a, dtype=dt).tofile(os.path.join(d, name))
+    camv = lambda c: np.concatenate([[c["fx"], c["fy"], c["cx"], c["cy"]], c["extrinsic"]])
+    for case, (with_imu, weak_thr, const_kf) in enumerate(((True, 0, 0), (False, 10 ** 6, -1))):
+        cfg = syn.config4_window(n_kf=9, n_lm=250, n_prewindow=50, seed=31 + case, imu_samples=3)
+        tc = cfg["tc"]; o = np.argsort(tc["kf_idx"], kind="stable"); tc = {k: v[o] for k, v in tc.items()}
+        tf, po = cfg["tf"], cfg["po"]
+        d = str(tmp_path / f"c{case}"); os.makedirs(d)
+        dump(d, "meta.i32", [cfg["n_kf"], cfg["n_lm"], 1, weak_thr, const_kf], np.int32)
+        for name in ("poses", "vel", "ba", "bg", "inv_depth", "w_kf"):
+            dump(d, name + ".f64", cfg[name], np.float64)
+        dump(d, "cam0.f64", camv(cfg["cam0"]), np.float64); dump(d, "cam1.f64", camv(cfg["cam1"]), np.float64)
+        dump(d, "tc_left_ob.f64", tc["left_ob"], np.float64); dump(d, "tc_right_ob.f64", tc["right_ob"], np.float64)
+        dump(d, "tc_lm.i32", tc["lm_idx"], np.int32); dump(d, "tc_kf.i32", tc["kf_idx"], np.int32)
+        dump(d, "tf_first_ob.f64", tf["first_ob"], np.float64); dump(d, "tf_ob.f64", tf["ob"], np.float64)
+        dump(d, "tf_lm.i32", tf["lm_idx"], np.int32); dump(d, "tf_kf1.i32", tf["kf1_idx"], np.int32); dump(d, "tf_kf2.i32", tf["kf2_idx"], np.int32)
+        dump(d, "po_ob.f64", po["ob"], np.float64); dump(d, "po_pw.f64", po["pw"], np.float64)
+        dump(d, "po_kf.i32", po["kf_idx"], np.int32); dump(d, "po_pw_idx.i32", po["pw_idx"], np.int32)
+        imu = cfg["imu"] if with_imu else []
+        dump(d, "preint.f64", np.random.default_rng(case).normal(0, 1, (len(imu), 467)), np.float64)      # (content is payload only: copied, never evaluated here)
+        dump(d, "imu_i.i32", [f["kf_i"] for f in imu], np.int32); dump(d, "imu_j.i32", [f["kf_j"] for f in imu], np.int32)
+        env = dict(os.environ); env["LVF_SELFTEST_HOSTONLY"] = "1"
+        p = subprocess.run([exe, "window", d], capture_output=True, text=True, timeout=120, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        out = json.loads(p.stdout.strip().splitlines()[-1])
+        assert out["walk_ok"] == 1 and out["recorder_usable"] == 1 and out["recorded_equals_walk"] == 1, out
+        assert out["n_kf"] == cfg["n_kf"] and out["blocks"] >= len(tf["lm_idx"]) + len(tc["lm_idx"])
+        assert (out["n_prior"] > 0) == (not with_imu)
