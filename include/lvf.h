@@ -352,6 +352,10 @@ int lvf_problem_destroy(lvf_problem* p);
 /* Adds (or with NULL removes) the window's pose-prior batch (ProblemType::Other blocks with no loss function). */
 int lvf_problem_set_pose_priors(lvf_problem* p, lvf_batch* pose_priors);
 int lvf_problem_set_pose_constant(lvf_problem* p, int kf, int is_constant);
+/* SetParameterBlockConstant on keyframe kf's velocity / accelerometer-bias / gyroscope-bias blocks (Environment::Optimize holds all of
+ * them, and the previous frame's, constant: environment.cpp:62-68): the ImuError factors keep their residuals, the blocks get no
+ * Jacobian columns and are left out of the step norm's x_norm like Ceres' reduced program does. */
+int lvf_problem_set_vbb_constant(lvf_problem* p, int kf, int v_constant, int ba_constant, int bg_constant);
 /* Problem::Evaluate-style cost at the current state: 0.5 * sum rho(|r|^2). */
 int lvf_problem_cost(lvf_problem* p, const lvf_solver_options* o, double* cost);
 /* One Levenberg-Marquardt iteration from the current state with trust-region radius *radius (updated);

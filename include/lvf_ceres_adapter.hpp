@@ -614,6 +614,7 @@ struct Window {
   std::vector<double> w_kf;
   std::vector<char> w_known;
   std::vector<char> pose_const;                    // per keyframe: SetParameterBlockConstant was called on its pose block
+  std::vector<char> vbb_const;                     // per keyframe, bit 0 / 1 / 2: ... on its velocity / accelerometer-bias / gyroscope-bias block
   // batches (insertion order preserved per type)
   std::vector<double> tc_l, tc_r; std::vector<int32_t> tc_lm, tc_kf; std::vector<double> tc_w;
   std::vector<double> tf_f, tf_o; std::vector<int32_t> tf_lm, tf_k1, tf_k2;
@@ -631,15 +632,16 @@ inline bool finish_window(ceres::Problem* problem, Window* w, const PtrMap* cons
   if (w->huber == -2.0) w->huber = 0.0;
   const int n_kf = (int)w->pose_ptr.size();
   auto is_const = [&](double* p) { return constant ? constant->find(p) >= 0 : problem->IsParameterBlockConstant(p); };
+  w->pose_const.assign(n_kf, 0);
+  w->vbb_const.assign(n_kf, 0);
   if (!constant || constant->used) {
     for (double* p : w->lm_ptr) if (is_const(p)) return fail("constant inverse-depth blocks are not supported");
-    for (int k = 0; k < n_kf; ++k)
-      for (double* p : {w->v_ptr[k], w->ba_ptr[k], w->bg_ptr[k]})
-        if (p && is_const(p)) return fail("constant velocity/bias blocks are not supported");
+    for (int k = 0; k < n_kf; ++k) {
+      w->pose_const[k] = is_const(w->pose_ptr[k]) ? 1 : 0;
+      // constant velocity / bias blocks (Environment::Optimize holds the frame's and the previous frame's, environment.cpp:62-68)
+      w->vbb_const[k] = (char)((w->v_ptr[k] && is_const(w->v_ptr[k]) ? 1 : 0) | (w->ba_ptr[k] && is_const(w->ba_ptr[k]) ? 2 : 0) | (w->bg_ptr[k] && is_const(w->bg_ptr[k]) ? 4 : 0));
+    }
   }
-  w->pose_const.assign(n_kf, 0);
-  if (!constant || constant->used)
-    for (int k = 0; k < n_kf; ++k) w->pose_const[k] = is_const(w->pose_ptr[k]) ? 1 : 0;
   return true;
 }
 
@@ -850,8 +852,10 @@ inline bool upload_window(lvf_ctx* ctx, ceres::Problem* problem, const Window& w
   if (timing) std::fprintf(stderr, "  upload ms: state %.3f | batches %.3f | problem_create %.3f\n", 1e3 * std::chrono::duration<double>(u1 - u0).count(),
                            1e3 * std::chrono::duration<double>(u2 - u1).count(), 1e3 * std::chrono::duration<double>(clk::now() - u2).count());
   if (d->prior && lvf_problem_set_pose_priors(d->h.prob, d->prior) != LVF_OK) return fail(lvf_last_error());
-  for (int k = 0; k < n_kf; ++k)
+  for (int k = 0; k < n_kf; ++k) {
     if (w.pose_const[k] && lvf_problem_set_pose_constant(d->h.prob, k, 1) != LVF_OK) return fail(lvf_last_error());
+    if (w.vbb_const[k] && lvf_problem_set_vbb_constant(d->h.prob, k, w.vbb_const[k] & 1, (w.vbb_const[k] >> 1) & 1, (w.vbb_const[k] >> 2) & 1) != LVF_OK) return fail(lvf_last_error());
+  }
   return true;
 }
 

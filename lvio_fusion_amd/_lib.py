@@ -194,6 +194,7 @@ _SIGS = {
     "lvf_problem_create": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "lvf_problem_destroy": (C.c_int, [_VP]),
     "lvf_problem_set_pose_constant": (C.c_int, [_VP, C.c_int, C.c_int]),
+    "lvf_problem_set_vbb_constant": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lvf_problem_cost": (C.c_int, [_VP, C.POINTER(SolverOptions), c_double_p]),
     "lvf_problem_lm_iteration": (C.c_int, [_VP, C.POINTER(SolverOptions), c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
     "lvf_problem_solve": (C.c_int, [_VP, C.POINTER(SolverOptions), C.POINTER(SolverSummary)]),

@@ -554,6 +554,9 @@ class Problem:
     def set_pose_constant(self, kf, const=True):
         _chk(self.ctx.L.lvf_problem_set_pose_constant(self.h, int(kf), 1 if const else 0))
 
+    def set_vbb_constant(self, kf, v=True, ba=True, bg=True):
+        _chk(self.ctx.L.lvf_problem_set_vbb_constant(self.h, int(kf), int(bool(v)), int(bool(ba)), int(bool(bg))))
+
     def cost(self, opt):
         c = C.c_double()
         _chk(self.ctx.L.lvf_problem_cost(self.h, C.byref(opt), C.byref(c)))

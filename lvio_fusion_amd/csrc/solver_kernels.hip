@@ -216,8 +216,8 @@ __global__ __launch_bounds__(kT) void k_lin_tf(int n, int n_kf, const double2* _
     c = 0.5 * rho;
     if (!COST_ONLY) {
       double L1[12], L2[12];
-      pose_rows_to_local(J1, s.poses + 7 * k1, pose_const[k1] ? 0.0 : sc, L1);
-      pose_rows_to_local(J2, s.poses + 7 * k2, pose_const[k2] ? 0.0 : sc, L2);
+      pose_rows_to_local(J1, s.poses + 7 * k1, (pose_const[k1] & 1) ? 0.0 : sc, L1);
+      pose_rows_to_local(J2, s.poses + 7 * k2, (pose_const[k2] & 1) ? 0.0 : sc, L2);
       const double r0 = sc * r[0], r1 = sc * r[1], d0 = sc * Jd[0], d1 = sc * Jd[1];
       atomicAdd(&C[l], d0 * d0 + d1 * d1);
       atomicAdd(&gr[l], d0 * r0 + d1 * r1);
@@ -310,8 +310,8 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
     double rho;
     const double sc = robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
     c = 0.5 * rho;
-    pose_rows_to_local(J1, s.poses + 7 * k1, pose_const[k1] ? 0.0 : sc, L1);
-    pose_rows_to_local(J2, s.poses + 7 * k2, pose_const[k2] ? 0.0 : sc, L2);
+    pose_rows_to_local(J1, s.poses + 7 * k1, (pose_const[k1] & 1) ? 0.0 : sc, L1);
+    pose_rows_to_local(J2, s.poses + 7 * k2, (pose_const[k2] & 1) ? 0.0 : sc, L2);
     r0 = sc * r[0]; r1 = sc * r[1];
     const double d0 = sc * Jd[0], d1 = sc * Jd[1];
     if (cp.on) {
@@ -579,7 +579,7 @@ __device__ __forceinline__ void lin_po_body(const int vb, int n, int n_kf, const
     c = 0.5 * rho;
     if (!COST_ONLY) {
       double Lc[12];
-      pose_rows_to_local(J, s.poses + 7 * k, pose_const[k] ? 0.0 : sc, Lc);
+      pose_rows_to_local(J, s.poses + 7 * k, (pose_const[k] & 1) ? 0.0 : sc, Lc);
       const double r0 = sc * r[0], r1 = sc * r[1];
       int q = 0;
 #pragma unroll
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64) void k_lin_imu(int n, int n_kf, const double* _
     const double* Jr = (which ? J.j[4] : J.j[0]) + (size_t)f * 105 + 7 * row;
     const int kk = which ? kj : ki;
     const double* q = poses + 7 * kk;
-    const double sc = pose_const[kk] ? 0.0 : 1.0;
+    const double sc = (pose_const[kk] & 1) ? 0.0 : 1.0;
     double l3[3];
     quat_row_to_local(Jr, q, l3);
     double* o = sJ + row * 30 + (which ? 15 : 0);
@@ -680,7 +680,8 @@ __global__ __launch_bounds__(64) void k_lin_imu(int n, int n_kf, const double* _
     const int row = e / 18, c = e % 18, blk = c / 3, cc = c % 3;   // blk 0..2 -> (v,ba,bg)_i ; 3..5 -> _j
     const int src = blk < 3 ? 1 + blk : 5 + (blk - 3);
     const double* jp = src == 1 ? J.j[1] : (src == 2 ? J.j[2] : (src == 3 ? J.j[3] : (src == 5 ? J.j[5] : (src == 6 ? J.j[6] : J.j[7]))));
-    sJ[row * 30 + (blk < 3 ? 6 + 3 * blk : 21 + 3 * (blk - 3)) + cc] = jp[(size_t)f * 45 + 3 * row + cc];
+    const double scv = ((pose_const[blk < 3 ? ki : kj] >> (1 + blk % 3)) & 1) ? 0.0 : 1.0;      // constant (v | ba | bg) block: bits 1..3 of the mask
+    sJ[row * 30 + (blk < 3 ? 6 + 3 * blk : 21 + 3 * (blk - 3)) + cc] = scv * jp[(size_t)f * 45 + 3 * row + cc];
   }
   __syncthreads();
   double c = 0.0;
@@ -734,7 +735,7 @@ __device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, con
       const double* Jr = (which ? J.j[4] : J.j[0]) + (size_t)f * 105 + 7 * row;
       const int kk = which ? kj : ki;
       const double* q = poses + 7 * kk;
-      const double sc = pose_const[kk] ? 0.0 : 1.0;
+      const double sc = (pose_const[kk] & 1) ? 0.0 : 1.0;
       double l3[3];
       quat_row_to_local(Jr, q, l3);
       double* o = sJ + row * 30 + (which ? 15 : 0);
@@ -746,7 +747,10 @@ __device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, con
       // (static indices only: indexing the by-value pointer table with a run-time value puts it in scratch memory, and a kernel with a
       // scratch segment pays several microseconds of dispatch set-up)
       const double* jp = src == 1 ? J.j[1] : (src == 2 ? J.j[2] : (src == 3 ? J.j[3] : (src == 5 ? J.j[5] : (src == 6 ? J.j[6] : J.j[7]))));
-      sJ[row * 30 + (blk < 3 ? 6 + 3 * blk : 21 + 3 * (blk - 3)) + cc] = jp[(size_t)f * 45 + 3 * row + cc];
+      // a constant velocity / bias block (bits 1..3 of the keyframe's mask; Environment::Optimize holds all of them, environment.cpp:62-68) keeps
+      // its residual but gets no Jacobian columns
+      const double scv = ((pose_const[blk < 3 ? ki : kj] >> (1 + blk % 3)) & 1) ? 0.0 : 1.0;
+      sJ[row * 30 + (blk < 3 ? 6 + 3 * blk : 21 + 3 * (blk - 3)) + cc] = scv * jp[(size_t)f * 45 + 3 * row + cc];
     }
   }
   __syncthreads();
@@ -822,7 +826,7 @@ __device__ __forceinline__ void lin_imu_eval_body(const int f, const ImuEvalArgs
     const int row = tid % 15, which = tid / 15;          // which: 0 = pose_i, 1 = pose_j
     const double* Jr = sJw + 32 * row + (which ? 16 : 0);
     const int kk = which ? kj : ki;
-    const double sc = pose_const[kk] ? 0.0 : 1.0;
+    const double sc = (pose_const[kk] & 1) ? 0.0 : 1.0;
     double l3[3];
     quat_row_to_local(Jr, s.poses + 7 * kk, l3);
     double* o = sJ + row * 30 + (which ? 15 : 0);
@@ -830,7 +834,9 @@ __device__ __forceinline__ void lin_imu_eval_body(const int f, const ImuEvalArgs
   }
   for (int e = tid; e < 15 * 18; e += kT) {              // six 15x3 blocks: (v, ba, bg)_i = columns 7..15, (v, ba, bg)_j = columns 23..31
     const int row = e / 18, c = e % 18;
-    sJ[row * 30 + (c < 9 ? 6 + c : 21 + (c - 9))] = sJw[32 * row + (c < 9 ? 7 + c : 23 + (c - 9))];
+    const int cg = c < 9 ? c / 3 : (c - 9) / 3;          // 0 = v, 1 = ba, 2 = bg
+    const double scv = ((pose_const[c < 9 ? ki : kj] >> (1 + cg)) & 1) ? 0.0 : 1.0;      // constant (v | ba | bg) block: bits 1..3 of the mask
+    sJ[row * 30 + (c < 9 ? 6 + c : 21 + (c - 9))] = scv * sJw[32 * row + (c < 9 ? 7 + c : 23 + (c - 9))];
   }
   __syncthreads();
   if (dbg) dbg[3] = wall_clock64();
@@ -974,14 +980,14 @@ __global__ __launch_bounds__(64) void k_lin_prior(int n, const double* __restric
   for (int k = 0; k < 6; ++k) { r[k] = res[6 * i + k]; c += 0.5 * r[k] * r[k]; }
   for (int k = 0; k < 6; ++k) {
     const double* row = jb + (size_t)42 * i + 7 * k;
-    const double sc = pose_const[b] ? 0.0 : 1.0;
+    const double sc = (pose_const[b] & 1) ? 0.0 : 1.0;
     double l3[3];
     quat_row_to_local(row, poses + 7 * b, l3);
     Lb[6 * k] = sc * l3[0]; Lb[6 * k + 1] = sc * l3[1]; Lb[6 * k + 2] = sc * l3[2];
     Lb[6 * k + 3] = sc * row[4]; Lb[6 * k + 4] = sc * row[5]; Lb[6 * k + 5] = sc * row[6];
     if (a >= 0) {
       const double* rowa = ja + (size_t)42 * i + 7 * k;
-      const double sa = pose_const[a] ? 0.0 : 1.0;
+      const double sa = (pose_const[a] & 1) ? 0.0 : 1.0;
       quat_row_to_local(rowa, poses + 7 * a, l3);
       La[6 * k] = sa * l3[0]; La[6 * k + 1] = sa * l3[1]; La[6 * k + 2] = sa * l3[2];
       La[6 * k + 3] = sa * rowa[4]; La[6 * k + 4] = sa * rowa[5]; La[6 * k + 5] = sa * rowa[6];
@@ -2272,8 +2278,10 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
     const double* dv = dxc + 6 * n_kf + 9 * i;
     for (int c = 0; c < 3; ++c) { vel2[3 * i + c] = s.vel[3 * i + c] + dv[c]; ba2[3 * i + c] = s.ba[3 * i + c] + dv[3 + c]; bg2[3 * i + c] = s.bg[3 * i + c] + dv[6 + c]; }
     for (int c = 0; c < 4; ++c) n2 += (o[c] - p[c]) * (o[c] - p[c]);
-    if (!(pose_const && pose_const[i])) for (int c = 0; c < 7; ++c) x2 += p[c] * p[c];
-    for (int c = 0; c < 3; ++c) x2 += s.vel[3 * i + c] * s.vel[3 * i + c] + s.ba[3 * i + c] * s.ba[3 * i + c] + s.bg[3 * i + c] * s.bg[3 * i + c];
+    const int cm = pose_const ? pose_const[i] : 0;      // bit 0: pose, bits 1..3: v, ba, bg held constant
+    if (!(cm & 1)) for (int c = 0; c < 7; ++c) x2 += p[c] * p[c];
+    for (int c = 0; c < 3; ++c)
+      x2 += ((cm & 2) ? 0.0 : s.vel[3 * i + c] * s.vel[3 * i + c]) + ((cm & 4) ? 0.0 : s.ba[3 * i + c] * s.ba[3 * i + c]) + ((cm & 8) ? 0.0 : s.bg[3 * i + c] * s.bg[3 * i + c]);
   }
   if (i < n_lm) invd2[i] = s.inv_depth[i] + dxl[i];
   if (vb * kT < d) {      // block-uniform
@@ -3541,10 +3549,19 @@ int lvf_problem_set_pose_priors(lvf_problem* p, lvf_batch* pose_priors) {
   return LVF_OK;
 }
 
+int lvf_problem_set_vbb_constant(lvf_problem* p, int kf, int v_constant, int ba_constant, int bg_constant) {
+  LVF_REQUIRE(p, "null problem");
+  LVF_REQUIRE(kf >= 0 && kf < p->n_kf, "keyframe %d out of range", kf);
+  p->pose_const_h[kf] = (uint8_t)((p->pose_const_h[kf] & 1) | (v_constant ? 2 : 0) | (ba_constant ? 4 : 0) | (bg_constant ? 8 : 0));
+  LVF_HIP(hipMemcpyAsync(p->pose_const.p, p->pose_const_h.data(), p->n_kf, hipMemcpyHostToDevice, p->ctx->stream));
+  LVF_HIP(hipStreamSynchronize(p->ctx->stream));
+  return LVF_OK;
+}
+
 int lvf_problem_set_pose_constant(lvf_problem* p, int kf, int is_constant) {
   LVF_REQUIRE(p, "null problem");
   LVF_REQUIRE(kf >= 0 && kf < p->n_kf, "keyframe %d out of range", kf);
-  p->pose_const_h[kf] = is_constant ? 1 : 0;
+  p->pose_const_h[kf] = (uint8_t)((p->pose_const_h[kf] & ~1) | (is_constant ? 1 : 0));
   LVF_HIP(hipMemcpyAsync(p->pose_const.p, p->pose_const_h.data(), p->n_kf, hipMemcpyHostToDevice, p->ctx->stream));
   LVF_HIP(hipStreamSynchronize(p->ctx->stream));
   return LVF_OK;

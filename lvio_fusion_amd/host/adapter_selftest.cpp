@@ -146,7 +146,7 @@ static int run_window(const std::string& dir) {
         const bool ok3 = usable && gpu::detail::finish_window(&problem, &r, &problem.recorder.constant_blocks(), fail2);
         auto eqv = [](const auto& a, const auto& b) { return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0); };
         const bool same = ok2 && ok3 && eqv(r.pose_ptr, w.pose_ptr) && eqv(r.lm_ptr, w.lm_ptr) && eqv(r.v_ptr, w.v_ptr) && eqv(r.ba_ptr, w.ba_ptr) && eqv(r.bg_ptr, w.bg_ptr) &&
-                          eqv(r.w_kf, w.w_kf) && eqv(r.pose_const, w.pose_const) && eqv(r.tc_l, w.tc_l) && eqv(r.tc_r, w.tc_r) && eqv(r.tc_lm, w.tc_lm) && eqv(r.tc_w, w.tc_w) &&
+                          eqv(r.w_kf, w.w_kf) && eqv(r.pose_const, w.pose_const) && eqv(r.vbb_const, w.vbb_const) && eqv(r.tc_l, w.tc_l) && eqv(r.tc_r, w.tc_r) && eqv(r.tc_lm, w.tc_lm) && eqv(r.tc_w, w.tc_w) &&
                           eqv(r.tf_f, w.tf_f) && eqv(r.tf_o, w.tf_o) && eqv(r.tf_lm, w.tf_lm) && eqv(r.tf_k1, w.tf_k1) && eqv(r.tf_k2, w.tf_k2) && eqv(r.po_o, w.po_o) &&
                           eqv(r.po_pw, w.po_pw) && eqv(r.po_kf, w.po_kf) && eqv(r.po_pi, w.po_pi) && eqv(r.imu_pre, w.imu_pre) && eqv(r.imu_i, w.imu_i) && eqv(r.imu_j, w.imu_j) &&
                           eqv(r.pr_a, w.pr_a) && eqv(r.pr_b, w.pr_b) && eqv(r.pr_t, w.pr_t) && eqv(r.pr_w, w.pr_w) && eqv(r.pr_v, w.pr_v) && eqv(r.order_kind, w.order_kind) &&
@@ -365,12 +365,62 @@ static int run_foreign() {
   return 0;
 }
 
+// Environment::Optimize's visual + IMU problem (src/environment.cpp:18-75), block for block: ONE free pose (the environment's frame),
+// PoseOnlyReprojectionError blocks on it under HuberLoss(1.0), and one ImuError to the previous keyframe whose pose, velocity and biases —
+// like the frame's own velocity and biases — are registered and then held constant (:54-68).  The RL weight tuner calls this once per
+// environment step (8 environments while training, 100 while testing: rl_fusion/td3.py:44-45).
+static int run_environment(const std::string& dir) {
+  auto meta = rd<int32_t>(dir, "meta.i32");   // n_blocks, max_iterations, with_imu
+  const int n = meta[0], max_it = meta[1], with_imu = meta[2];
+  auto pose = rd<double>(dir, "pose.f64"), last_pose = rd<double>(dir, "last_pose.f64");        // [7] each
+  auto vbb = rd<double>(dir, "vbb.f64");                                                          // v, ba, bg of the frame, then of the last frame: [18]
+  auto ob = rd<double>(dir, "ob.f64"), pw = rd<double>(dir, "pw.f64");
+  const double weight = rd<double>(dir, "weight.f64")[0];
+  const lvf_camera cam0 = cam_of(rd<double>(dir, "cam0.f64"));
+  auto pre = rd<double>(dir, "preint.f64");
+  adapt::Problem problem;
+  ceres::LocalParameterization* local_parameterization =
+      new ceres::ProductParameterization(new ceres::EigenQuaternionParameterization(), new ceres::IdentityParameterization(3));
+  double* para = pose.data();
+  problem.AddParameterBlock(para, 7, local_parameterization);
+  ceres::LossFunction* loss_function = new ceres::HuberLoss(1.0);
+  for (int i = 0; i < n; ++i)
+    problem.AddResidualBlock(ProblemType::VisualError, gpu::PoseOnlyReprojectionError::Create(&ob[2 * i], &pw[3 * i], cam0, weight), loss_function, para);
+  if (with_imu) {
+    double *para_v = &vbb[0], *para_ba = &vbb[3], *para_bg = &vbb[6], *para_last_kf = last_pose.data(), *para_v_last = &vbb[9], *para_ba_last = &vbb[12], *para_bg_last = &vbb[15];
+    problem.AddParameterBlock(para_v, 3); problem.AddParameterBlock(para_ba, 3); problem.AddParameterBlock(para_bg, 3);
+    problem.AddParameterBlock(para_last_kf, 7);
+    problem.AddParameterBlock(para_v_last, 3); problem.AddParameterBlock(para_ba_last, 3); problem.AddParameterBlock(para_bg_last, 3);
+    problem.SetParameterBlockConstant(para_v); problem.SetParameterBlockConstant(para_ba); problem.SetParameterBlockConstant(para_bg);
+    problem.SetParameterBlockConstant(para_last_kf);
+    problem.SetParameterBlockConstant(para_v_last); problem.SetParameterBlockConstant(para_ba_last); problem.SetParameterBlockConstant(para_bg_last);
+    lvf_preint P;
+    std::memcpy(&P, pre.data(), sizeof(P));
+    problem.AddResidualBlock(ProblemType::ImuError, gpu::ImuError::Create(P), nullptr, para_last_kf, para_v_last, para_ba_last, para_bg_last, para, para_v, para_ba, para_bg);
+  }
+  const std::vector<double> vbb0 = vbb, last0 = last_pose;
+  ceres::Solver::Options options;
+  options.linear_solver_type = ceres::DENSE_QR;
+  options.num_threads = 1;
+  options.max_num_iterations = max_it;
+  ceres::Solver::Summary summary;
+  adapt::Solve(options, &problem, &summary);
+  wr(dir, "out_pose.f64", pose);
+  const bool untouched = vbb == vbb0 && last_pose == last0;       // constant blocks are never written
+  std::printf("{\"ok\": %d, \"message\": \"%s\", \"initial_cost\": %.17g, \"final_cost\": %.17g, \"successful\": %d, \"unsuccessful\": %d, \"num_residual_blocks\": %d, "
+              "\"termination\": %d, \"constant_blocks_untouched\": %d, \"recorder_used\": %d}\n",
+              summary.termination_type != ceres::FAILURE, summary.message.c_str(), summary.initial_cost, summary.final_cost, summary.num_successful_steps,
+              summary.num_unsuccessful_steps, summary.num_residual_blocks_reduced, (int)summary.termination_type, (int)untouched, (int)problem.recorder.usable(&problem));
+  return summary.termination_type == ceres::FAILURE ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 2 && std::string(argv[1]) == "foreign") return run_foreign();
-  if (argc < 3) { std::fprintf(stderr, "usage: %s window|lidar|posegraph <dir> | foreign\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s window|lidar|posegraph|environment <dir> | foreign\n", argv[0]); return 2; }
   const std::string mode = argv[1];
   if (mode == "window") return run_window(argv[2]);
   if (mode == "lidar") return run_lidar(argv[2]);
   if (mode == "posegraph") return run_posegraph(argv[2]);
+  if (mode == "environment") return run_environment(argv[2]);
   return 2;
 }

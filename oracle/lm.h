@@ -36,6 +36,8 @@ struct Window {
   int n_po; const double *po_ob; const int *po_kf, *po_pw; const double* po_pwtab;
   int n_imu; const imu::Preint* pre; const int *imu_i, *imu_j;
   const unsigned char* pose_const;  // may be null
+  const unsigned char* vbb_const = nullptr;  // may be null; per keyframe bit 0 / 1 / 2: its velocity / accelerometer-bias / gyroscope-bias block is held constant
+                                             // (Environment::Optimize, environment.cpp:62-68: SetParameterBlockConstant on all of them)
   // weak-constraint priors (backend.cpp:164-178): prior_a[i] == -2 -> RError (pose_graph.cpp:190), prior_a[i] == -1 -> PoseError(origin = prior_target[i][0..7)) on pose prior_b[i];
   // else PoseGraphError(pose prior_a[i], pose prior_b[i]) with rpyxyz_ = prior_target[i][0..6).  No loss function.
   int n_prior = 0; const int *prior_a = nullptr, *prior_b = nullptr; const double *prior_target = nullptr, *prior_w = nullptr, *prior_v = nullptr;
@@ -188,6 +190,12 @@ inline void window_linearize(const Window& w, double huber_a, Linearization& L) 
         Vi[row * 9 + c] = Jb[1][row * 3 + c]; Vi[row * 9 + 3 + c] = Jb[2][row * 3 + c]; Vi[row * 9 + 6 + c] = Jb[3][row * 3 + c];
         Vj[row * 9 + c] = Jb[5][row * 3 + c]; Vj[row * 9 + 3 + c] = Jb[6][row * 3 + c]; Vj[row * 9 + 6 + c] = Jb[7][row * 3 + c];
       }
+    if (w.vbb_const)      // a constant block keeps its residual but gets no Jacobian columns (Ceres drops it from the reduced program)
+      for (int row = 0; row < 15; ++row)
+        for (int c = 0; c < 9; ++c) {
+          if ((w.vbb_const[i] >> (c / 3)) & 1) Vi[row * 9 + c] = 0.0;
+          if ((w.vbb_const[j] >> (c / 3)) & 1) Vj[row * 9 + c] = 0.0;
+        }
     Piece pc[4] = {{pose_off(i), 6, Pi}, {vbb_off(w, i), 9, Vi}, {pose_off(j), 6, Pj}, {vbb_off(w, j), 9, Vj}};
     accumulate(L, 15, r, pc, 4, -1, nullptr);
   }
@@ -328,10 +336,11 @@ inline void lm_trial_step(const Window& w, double huber_a, double radius, LmStep
   for (int k = 0; k < w.n_kf; ++k) {
     if (!(w.pose_const && w.pose_const[k]))
       for (int c = 0; c < 7; ++c) { const double a = w.poses[7 * k + c], b = np[7 * k + c]; sn += (a - b) * (a - b); xn += a * a; }
+    const int cm = w.vbb_const ? w.vbb_const[k] : 0;
     for (int c = 0; c < 3; ++c) {
       sn += (w.vel[3 * k + c] - nv[3 * k + c]) * (w.vel[3 * k + c] - nv[3 * k + c]) + (w.ba[3 * k + c] - nba[3 * k + c]) * (w.ba[3 * k + c] - nba[3 * k + c]) +
             (w.bg[3 * k + c] - nbg[3 * k + c]) * (w.bg[3 * k + c] - nbg[3 * k + c]);
-      xn += w.vel[3 * k + c] * w.vel[3 * k + c] + w.ba[3 * k + c] * w.ba[3 * k + c] + w.bg[3 * k + c] * w.bg[3 * k + c];
+      xn += ((cm & 1) ? 0.0 : w.vel[3 * k + c] * w.vel[3 * k + c]) + ((cm & 2) ? 0.0 : w.ba[3 * k + c] * w.ba[3 * k + c]) + ((cm & 4) ? 0.0 : w.bg[3 * k + c] * w.bg[3 * k + c]);
     }
   }
   for (int l = 0; l < nl; ++l) { sn += (w.inv_depth[l] - nd[l]) * (w.inv_depth[l] - nd[l]); xn += w.inv_depth[l] * w.inv_depth[l]; }

@@ -295,6 +295,7 @@ struct lvo_window_c {
   int n_imu; const lvo_preint* pre; const int *imu_i, *imu_j;
   const unsigned char* pose_const;
   int n_prior; const int *prior_a, *prior_b; const double *prior_target, *prior_w, *prior_v;
+  const unsigned char* vbb_const;      // may be null: per keyframe bit 0 / 1 / 2 = constant velocity / ba / bg block
 };
 static void to_window(const lvo_window_c* c, Window& w, std::vector<imu::Preint>& pre) {
   w.n_kf = c->n_kf; w.n_lm = c->n_lm; w.poses = c->poses; w.vel = c->vel; w.ba = c->ba; w.bg = c->bg; w.inv_depth = c->inv_depth;
@@ -307,6 +308,7 @@ static void to_window(const lvo_window_c* c, Window& w, std::vector<imu::Preint>
   w.n_imu = c->n_imu; w.pre = pre.data(); w.imu_i = c->imu_i; w.imu_j = c->imu_j;
   w.pose_const = c->pose_const;
   w.n_prior = c->n_prior; w.prior_a = c->prior_a; w.prior_b = c->prior_b; w.prior_target = c->prior_target; w.prior_w = c->prior_w; w.prior_v = c->prior_v;
+  w.vbb_const = c->vbb_const;
 }
 double lvo_window_cost(const lvo_window_c* c, double huber_a) {
   Window w; std::vector<imu::Preint> pre; to_window(c, w, pre);

@@ -391,13 +391,14 @@ class _WindowC(C.Structure):
                 ("n_imu", C.c_int), ("pre", C.POINTER(C.c_double)), ("imu_i", C.POINTER(C.c_int)), ("imu_j", C.POINTER(C.c_int)),
                 ("pose_const", C.POINTER(C.c_uint8)),
                 ("n_prior", C.c_int), ("prior_a", C.POINTER(C.c_int)), ("prior_b", C.POINTER(C.c_int)),
-                ("prior_target", C.POINTER(C.c_double)), ("prior_w", C.POINTER(C.c_double)), ("prior_v", C.POINTER(C.c_double))]
+                ("prior_target", C.POINTER(C.c_double)), ("prior_w", C.POINTER(C.c_double)), ("prior_v", C.POINTER(C.c_double)),
+                ("vbb_const", C.POINTER(C.c_uint8))]
 
 
 class Window:
     """Owns numpy copies of a config-4 style window (lvio_fusion_amd.synthetic.config4_window dict) + preintegrations."""
 
-    def __init__(self, cfg, pre, pose_const=None, use=("tc", "tf", "po", "imu"), priors=None):
+    def __init__(self, cfg, pre, pose_const=None, use=("tc", "tf", "po", "imu"), priors=None, vbb_const=None):
         self.n_kf, self.n_lm = cfg["n_kf"], cfg["n_lm"]
         self.poses = _f64(cfg["poses"]).copy(); self.vel = _f64(cfg["vel"]).copy(); self.ba = _f64(cfg["ba"]).copy()
         self.bg = _f64(cfg["bg"]).copy(); self.inv_depth = _f64(cfg["inv_depth"]).copy(); self.w_kf = _f64(cfg["w_kf"]).copy()
@@ -428,6 +429,9 @@ class Window:
         if pose_const is not None:
             pc = np.ascontiguousarray(pose_const, dtype=np.uint8); self._keep.append(pc)
             w.pose_const = pc.ctypes.data_as(C.POINTER(C.c_uint8))
+        if vbb_const is not None:   # per keyframe bit 0 / 1 / 2: constant velocity / ba / bg block (environment.cpp:62-68)
+            vc = np.ascontiguousarray(vbb_const, dtype=np.uint8); self._keep.append(vc)
+            w.vbb_const = vc.ctypes.data_as(C.POINTER(C.c_uint8))
         if priors is not None:   # dict(kf_a, kf_b, target[n][7], weight[n], v[n])
             w.n_prior = len(priors["kf_a"])
             w.prior_a, w.prior_b = i(priors["kf_a"]), i(priors["kf_b"])

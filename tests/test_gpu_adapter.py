@@ -324,3 +324,46 @@ def test_recorded_window_equals_the_accessor_walk(tmp_path, oracle):
             assert abs(a[k] - b[k]) <= 1e-12 * abs(b[k]), (k, a[k], b[k])
         for f in fa:
             assert np.allclose(fa[f], fb[f], rtol=1e-10, atol=1e-13), f
+
+
+@pytest.mark.parametrize("with_imu", [True, False])
+def test_environment_optimize_through_adapter(tmp_path, oracle, with_imu):
+    """Environment::Optimize's visual + IMU solve (src/environment.cpp:18-75) through adapt::Solve: one free pose, PoseOnly blocks under
+    HuberLoss(1.0), one ImuError whose other seven parameter blocks (the previous keyframe's pose / v / ba / bg and the frame's own
+    v / ba / bg) are held constant.  Against the oracle's ceres::Solve restatement with the same constant masks; the constant blocks must
+    come back untouched."""
+    from lvio_fusion_amd import api
+    cfg = syn.config4_window(n_kf=6, n_lm=40, n_prewindow=300, seed=90, imu_samples=6)
+    po = cfg["po"]
+    kf = 4                                                # the environment's frame; its previous keyframe is kf - 1
+    sel = np.flatnonzero(po["kf_idx"] == kf)
+    assert len(sel) >= 20, "generator changed: no PoseOnly blocks on the chosen keyframe"
+    ob, pw = po["ob"][sel], po["pw"][po["pw_idx"][sel]]
+    f = [x for x in cfg["imu"] if x["kf_j"] == kf][0]
+    pre = oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE)
+    d = str(tmp_path)
+    _dump(d, "meta.i32", [len(sel), 50, int(with_imu)], np.int32)
+    _dump(d, "pose.f64", cfg["poses"][kf], np.float64); _dump(d, "last_pose.f64", cfg["poses"][kf - 1], np.float64)
+    vbb = np.concatenate([cfg["vel"][kf], cfg["ba"][kf], cfg["bg"][kf], cfg["vel"][kf - 1], cfg["ba"][kf - 1], cfg["bg"][kf - 1]])
+    _dump(d, "vbb.f64", vbb, np.float64)
+    _dump(d, "ob.f64", ob, np.float64); _dump(d, "pw.f64", pw, np.float64); _dump(d, "weight.f64", [cfg["w_kf"][kf]], np.float64)
+    _dump(d, "cam0.f64", _cam_vec(cfg["cam0"]), np.float64); _dump(d, "preint.f64", pre, np.float64)
+    out = _run("environment", d)
+    assert out["ok"] == 1 and out["constant_blocks_untouched"] == 1 and out["recorder_used"] == 1
+    assert out["num_residual_blocks"] == len(sel) + int(with_imu)
+    # the oracle: a two-keyframe window (0 = the frame, 1 = the previous keyframe: registration order), everything but pose 0 constant
+    w2 = dict(n_kf=2, n_lm=1, poses=np.stack([cfg["poses"][kf], cfg["poses"][kf - 1]]), vel=np.stack([cfg["vel"][kf], cfg["vel"][kf - 1]]),
+              ba=np.stack([cfg["ba"][kf], cfg["ba"][kf - 1]]), bg=np.stack([cfg["bg"][kf], cfg["bg"][kf - 1]]), inv_depth=np.ones(1), w_kf=np.full(2, cfg["w_kf"][kf]),
+              cam0=cfg["cam0"], cam1=cfg["cam1"],
+              tc=dict(left_ob=np.zeros((0, 2)), right_ob=np.zeros((0, 2)), lm_idx=np.zeros(0, np.int32), kf_idx=np.zeros(0, np.int32)),
+              tf=dict(first_ob=np.zeros((0, 2)), ob=np.zeros((0, 2)), lm_idx=np.zeros(0, np.int32), kf1_idx=np.zeros(0, np.int32), kf2_idx=np.zeros(0, np.int32)),
+              po=dict(ob=ob, kf_idx=np.zeros(len(sel), np.int32), pw_idx=np.arange(len(sel), dtype=np.int32), pw=pw),
+              imu=[dict(kf_i=1, kf_j=0)] if with_imu else [])
+    win = oracle.Window(w2, pre.reshape(1, -1) if with_imu else np.zeros((0, 467)), pose_const=np.array([0, 1], np.uint8), vbb_const=np.array([7, 7], np.uint8),
+                        use=("po", "imu") if with_imu else ("po",))
+    ref = win.solve(max_num_iterations=50)
+    assert abs(out["initial_cost"] - ref["initial_cost"]) <= 1e-9 * ref["initial_cost"]
+    assert abs(out["final_cost"] - ref["final_cost"]) <= 1e-6 * ref["final_cost"]
+    assert (out["successful"], out["unsuccessful"], out["termination"] == 0) == (ref["num_successful_steps"], ref["num_unsuccessful_steps"], ref["termination"] == 0), (out, ref["why"])
+    assert_parity(np.fromfile(os.path.join(d, "out_pose.f64")), win.poses[0], "the environment frame's pose")
+    assert ref["final_cost"] < ref["initial_cost"] and ref["num_successful_steps"] >= 2

@@ -244,3 +244,46 @@ def test_upper_triangle_of_the_reduced_system_is_never_read():
         p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"] + args, cwd=root, env=env,
                            capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+def test_constant_velocity_and_bias_blocks(ctx, oracle):
+    """SetParameterBlockConstant on (v, ba, bg) blocks (Environment::Optimize, environment.cpp:62-68): per keyframe any subset of the three
+    can be held; the ImuError factors keep their residuals, the blocks get no Jacobian columns, never move, and stay out of x_norm.
+    Per-iteration parity and a device-loop trajectory against the oracle with the same masks."""
+    from lvio_fusion_amd import api
+    n_kf = 9
+    cfg, st, b, prob, _ = build(api, ctx, oracle, n_kf, 200, 57)
+    pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+    masks = np.array([7, 0, 1, 2, 4, 3, 0, 6, 5], np.uint8)        # bit 0 v, bit 1 ba, bit 2 bg
+    pc = np.zeros(n_kf, np.uint8); pc[0] = 1
+    win = oracle.Window(cfg, pre, pose_const=pc, vbb_const=masks)
+    prob.set_pose_constant(0, True)
+    for k, m in enumerate(masks):
+        prob.set_vbb_constant(k, v=bool(m & 1), ba=bool(m & 2), bg=bool(m & 4))
+    opt = api.default_solver_options()
+    radius, dec = 1e4, 2.0
+    for it in range(3):
+        ref = win.lm_iteration(radius, dec)
+        got = prob.lm_iteration(opt, radius, dec)
+        S, rhs = prob.reduced_system()
+        assert np.abs(S - ref["S"]).max() <= 1e-7 * np.abs(ref["S"]).max() and got["accepted"] == ref["accepted"]
+        assert abs(got["cost_after"] - ref["cost_after"]) <= 1e-6 * abs(ref["cost_after"])
+        s = state_of(api, st)
+        for name in ("poses", "vel", "ba", "bg", "inv_depth"):
+            assert_parity(np.asarray(s[name]).reshape(np.asarray(getattr(win, name)).shape), getattr(win, name), f"{name} it{it}")
+        radius, dec = ref["radius"], ref["decrease_factor"]
+    s = state_of(api, st)
+    for k, m in enumerate(masks):          # held blocks are bit-for-bit where they started
+        for bit, name in ((1, "vel"), (2, "ba"), (4, "bg")):
+            if m & bit:
+                assert np.array_equal(np.asarray(s[name]).reshape(-1, 3)[k], cfg[name][k]), (k, name)
+    assert np.array_equal(np.asarray(s["poses"]).reshape(-1, 7)[0], cfg["poses"][0])
+    o = api.default_solver_options(); o.max_num_iterations = 8
+    ref = win.solve(max_num_iterations=8)
+    summ = prob.solve(o)
+    assert (summ.num_iterations, summ.num_successful_steps, summ.why) == (ref["num_iterations"], ref["num_successful_steps"], ref["why"])
+    assert abs(summ.final_cost - ref["final_cost"]) <= 1e-6 * ref["final_cost"]
+    prob.close()
+    for h in list(b.values()) + [st]:
+        if h is not None:
+            h.close()
