@@ -300,7 +300,7 @@ def roofline(api, ctx, prob, st, cfg, handles):
         elif "k_schur" in name:
             c, src = pmc_counters("k_schur_sp0")
             e.update({"bound": "mfma", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": (pmc_traffic("k_schur_sp0") or {}).get("bytes"),
-                      "note": "band Schur complement of the inverse depths (v_mfma_f64_16x16x4_f64) + sparse level 0"})
+                      "note": "band Schur complement of the inverse depths (v_mfma_f64_16x16x4_f64) + one sparse level riding in the launch"})
             if c and "SQ_INSTS_VALU_MFMA_MOPS_F64" in c:
                 flops = 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]
                 e.update({"achieved": flops / (us * 1e-6) / 1e12, "frac": flops / (us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS, "mfma_flops_per_launch": flops,

@@ -631,16 +631,19 @@ struct Window {
 inline bool finish_window(ceres::Problem* problem, Window* w, const PtrMap* constant, const Fail& fail) {
   if (w->huber == -2.0) w->huber = 0.0;
   const int n_kf = (int)w->pose_ptr.size();
-  auto is_const = [&](double* p) { return constant ? constant->find(p) >= 0 : problem->IsParameterBlockConstant(p); };
+  // Poses and velocity/bias blocks (<= 4 per keyframe) always ask the problem itself: it stays right even when a caller reaches
+  // SetParameterBlockConstant through a ceres::Problem& and the recorder's shadow never sees the call.  Only the ~10 k inverse-depth
+  // blocks take the recorder's list, to keep 10 k Ceres map lookups off the solve.
+  auto is_const = [&](double* p) { return problem->IsParameterBlockConstant(p); };
+  auto lm_const = [&](double* p) { return constant ? constant->find(p) >= 0 : problem->IsParameterBlockConstant(p); };
   w->pose_const.assign(n_kf, 0);
   w->vbb_const.assign(n_kf, 0);
-  if (!constant || constant->used) {
-    for (double* p : w->lm_ptr) if (is_const(p)) return fail("constant inverse-depth blocks are not supported");
-    for (int k = 0; k < n_kf; ++k) {
-      w->pose_const[k] = is_const(w->pose_ptr[k]) ? 1 : 0;
-      // constant velocity / bias blocks (Environment::Optimize holds the frame's and the previous frame's, environment.cpp:62-68)
-      w->vbb_const[k] = (char)((w->v_ptr[k] && is_const(w->v_ptr[k]) ? 1 : 0) | (w->ba_ptr[k] && is_const(w->ba_ptr[k]) ? 2 : 0) | (w->bg_ptr[k] && is_const(w->bg_ptr[k]) ? 4 : 0));
-    }
+  if (!constant || constant->used)
+    for (double* p : w->lm_ptr) if (lm_const(p)) return fail("constant inverse-depth blocks are not supported");
+  for (int k = 0; k < n_kf; ++k) {
+    w->pose_const[k] = is_const(w->pose_ptr[k]) ? 1 : 0;
+    // constant velocity / bias blocks (Environment::Optimize holds the frame's and the previous frame's, environment.cpp:62-68)
+    w->vbb_const[k] = (char)((w->v_ptr[k] && is_const(w->v_ptr[k]) ? 1 : 0) | (w->ba_ptr[k] && is_const(w->ba_ptr[k]) ? 2 : 0) | (w->bg_ptr[k] && is_const(w->bg_ptr[k]) ? 4 : 0));
   }
   return true;
 }

@@ -119,7 +119,7 @@ __device__ __forceinline__ void imu_body(const int bx, const ImuArgs& A) {
     const unsigned long long t = (unsigned long long)(bx - n) * 64 + threadIdx.x, nt = (unsigned long long)A.zero_wgs * 64;
     // (static indices only: a run-time index into the by-value pointer table would put it in scratch memory)
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+    for (int a = 0; a < kZeroListMax; ++a) {
       if (a >= zero.count) break;
       double* p = zero.p[a];
       const unsigned long long cnt = zero.n[a], n2 = cnt / 2;

@@ -399,7 +399,8 @@ int launch_lidar_normals(lvf_batch* b, const double* d_pb, const double* d_pc);
 int launch_lidar_plane(lvf_batch* b, const double* rpyxyz_host, bool want_j);
 int launch_imu_sqrt_info(lvf_batch* b);
 // arrays to clear before a linearisation (one launch, or extra workgroups of another launch)
-struct ZeroList { double* p[6]; unsigned long long n[6]; int count; };
+constexpr int kZeroListMax = 8;
+struct ZeroList { double* p[kZeroListMax]; unsigned long long n[kZeroListMax]; int count; };
 // cost_stripes (optional): 32 striped accumulators that receive 1/2 |r|^2 of every factor
 // zero (optional): arrays cleared by extra workgroups of the same launch
 int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j, double* cost_stripes = nullptr, const ZeroList* zero = nullptr);

@@ -29,6 +29,22 @@ struct StageClock;
 struct SpNode { int col, row_off, m, id; };
 constexpr int kSpMaxLevels = 12, kSpMaxRows = 768;
 struct SpLevels { int n; int first[kSpMaxLevels]; int count[kSpMaxLevels]; };
+// "Early" sparse levels (see Chain::early): the level reads its columns as  B (natural order, what the ImuError factors accumulated) +
+// LM damping + the updates of the levels below (all S holds there), instead of entries k_prepare assembled — so it does not have to wait
+// for k_prepare and can ride in an earlier launch.  B == nullptr: the classic form (S holds the assembled entries).
+struct SpSrc {
+  const double* B; int ldB, dp; const double* gc; const double* radius; const int* rows_nat;
+  // levels CHAINED inside one launch (the Schur complement's: it lasts long enough for three of them): the level waits until `wait_target`
+  // workgroups of the level below have arrived at *wait_counter, and arrives at *done_counter itself.  What it reads of the level
+  // below are atomic adds into S (agent scope), read back with agent-scope atomic loads — no fences (MI355X_MICROARCH.md, "8-byte agent
+  // atomics both sides").  Producers carry lower workgroup numbers than their consumers, so they are dispatched first.
+  int* wait_counter; int wait_target; int* done_counter;
+};
+struct SpArgs {          // one sparse level
+  const SpNode* nodes; int first, tiles; const int* rows; double* S; int ld; double* W; int wstride; double* Lout; int* fail; int nblocks; const int* done;
+  SpSrc src;
+};
+__device__ __forceinline__ void sp_ride(const int vb, const SpArgs& a);     // workgroup vb of the level (defined with k_sp_eliminate)
 }
 struct lvf_problem {
   lvf_ctx* ctx = nullptr;
@@ -42,7 +58,7 @@ struct lvf_problem {
   std::vector<int> sp_item0, sp_items;          // per level: its slice of sp_rows
   std::vector<int32_t> plan_key;                // (n_kf, IMU index pairs) the current plan was built for
   lvf::DevBuf<lvf::SpNode> sp_nodes;
-  lvf::DevBuf<int> sp_rows, sp_owner, perm, iperm;
+  lvf::DevBuf<int> sp_rows, sp_rows_nat, sp_owner, perm, iperm;      // sp_rows_nat: the natural-order unknown of every entry of sp_rows (-2 = the right-hand-side row)
   lvf::DevBuf<int> lm_kmin, lm_kmax, lm_order, lm_nactive;   // per-landmark keyframe track [kmin, kmax]; Schur row order; #rows with pose blocks
   bool band_ready = false;
   // compact landmark layout + slabs of the atomic-free TwoFrame linearisation (see TfCompact)
@@ -57,6 +73,7 @@ struct lvf_problem {
   int n_band_work = 0, band_rows_built = 0;
   lvf::HostPin<int> h_run_first;
   lvf::DevBuf<unsigned long long> dbg, dbg_lin;
+  lvf::DevBuf<double> sp_sync;                  // arrival counters of sparse levels chained inside one launch (one 8-byte slot per level, an int in each; cleared with the accumulators)
   lvf::DevBuf<double> sp_W, sp_L, Dinv;         // Dinv: L_kk^-T of every 64x64 diagonal block of the dense corner
   std::vector<int> perm_h;
   lvf::DevBuf<double> B, gc, C, gr, E, Cd, S, dxc, dxl, scal;
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(kT) void k_zero_multi(ZeroList z) {
 __device__ __forceinline__ void zero_list_share(const ZeroList& zero, const int wg, const int n_wgs) {
   const unsigned long long t = (unsigned long long)wg * kT + threadIdx.x, nt = (unsigned long long)n_wgs * kT;
 #pragma unroll
-  for (int a = 0; a < 6; ++a) {
+  for (int a = 0; a < kZeroListMax; ++a) {
     if (a >= zero.count) break;
     double* p = zero.p[a];
     const unsigned long long cnt = zero.n[a], n2 = cnt / 2;
@@ -877,9 +894,15 @@ struct LinVisual {
 struct LinArgs {
   LinVisual v; int n_kf; StateP s; double huber; const uint8_t* pose_const; double* B; int ld; double* gc; double* E; int ldE; double *C, *gr, *cost;
   int nblocks; const int* done; unsigned long long* dbg; int rows;
+  double* scal_reset;      // early sparse levels: the per-step scalars and the fail flag are reset HERE (the levels start before k_prepare, which resets them otherwise)
 };
+__device__ __forceinline__ void reset_step_scalars(double* scal) {
+  for (int k = SC_COST_NEW + threadIdx.x; k < SC_N; k += kT) scal[k] = 0.0;
+  if (threadIdx.x == 0) { *reinterpret_cast<int*>(scal + SC_FAIL) = 0; *reinterpret_cast<int*>(scal + SC_TICKET) = 0; }
+}
 __device__ __forceinline__ void lin_visual_body(const int bx, const LinArgs& A) {
   if (bx >= A.nblocks || (A.done && *A.done)) return;
+  if (bx == 0 && A.scal_reset) reset_step_scalars(A.scal_reset);
   const LinVisual& a = A.v;
   // the ImuError workgroups come FIRST: each is a ~12 us chain with a one-lane section, and dispatched last (of the last window of a
   // batch) it would stick out behind everything else
@@ -909,9 +932,13 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void k_
 //   workgroups [0, n_kf)         keyframe k: B[k,k] (21) and g[k] (6) = sum of slabQ over run(k) (k as current keyframe)
 //                                                                      + sum of slabP[.][k][0..27) over every later workgroup (k as first keyframe)
 //   the rest                     one thread per (k2, k1 < k2, entry of the 6x6 cross block) = sum of slabP[.][k1][27..63) over run(k2)
-struct TfReduceArgs { int n_kf, n_wg; const int* run_first; const double *slabP, *slabQ; double* B; int ld; double* gc; int nblocks; const int* done; };
+struct TfReduceArgs {
+  int n_kf, n_wg; const int* run_first; const double *slabP, *slabQ; double* B; int ld; double* gc; int nblocks; const int* done;
+  int own_blocks; SpArgs ride;       // workgroups [own_blocks, nblocks): a sparse level riding in this launch (early form)
+};
 __device__ __forceinline__ void tf_reduce_body(const int bx, const TfReduceArgs& A) {
   if (bx >= A.nblocks || (A.done && *A.done)) return;
+  if (bx >= A.own_blocks) { sp_ride(bx - A.own_blocks, A.ride); return; }
   const int n_kf = A.n_kf;
   const int nchunk = (A.n_wg + 63) / 64;
   if (bx < n_kf * nchunk) {
@@ -1044,17 +1071,19 @@ struct PrepArgs {
   double *Cd, *E, *scal; int nblocks; const int* done;
   // atomic-free mode (slotB != nullptr): per-landmark totals from the slot records
   const int *eoff, *kmin, *kmax; const double* slotB; double *Ct, *grt;
+  // early form (early != 0): S was cleared with the accumulators and sparse levels may already have added into the dense corner, so the
+  // corner's entries (rows / columns >= off) are ADDED, and the columns of the sparse blocks are left alone (the levels form them themselves)
+  int early, off;
+  int own_blocks; SpArgs ride;       // workgroups [own_blocks, nblocks): a sparse level riding in this launch
 };
 __device__ __forceinline__ void prepare_body(const unsigned bx, const PrepArgs& A) {
   if (bx >= (unsigned)A.nblocks || (A.done && *A.done)) return;
+  if (bx >= (unsigned)A.own_blocks) { sp_ride((int)bx - A.own_blocks, A.ride); return; }
   const int ld = A.ld, dpad = A.dpad; const int* __restrict__ iperm = A.iperm; const double* __restrict__ B = A.B; const double* __restrict__ gc = A.gc;
   const double inv_radius = 1.0 / *A.radius;
   double* __restrict__ S = A.S; const unsigned nS_blocks = A.nS_blocks; const int n_lm = A.n_lm, dp = A.dp, ldE = A.ldE;
   const double* __restrict__ C = A.C; const double* __restrict__ gr = A.gr; double* __restrict__ Cd = A.Cd; double* __restrict__ E = A.E; double* __restrict__ scal = A.scal;
-  if (bx == 0 && scal) {
-    for (int k = SC_COST_NEW + threadIdx.x; k < SC_N; k += kT) scal[k] = 0.0;
-    if (threadIdx.x == 0) { *reinterpret_cast<int*>(scal + SC_FAIL) = 0; *reinterpret_cast<int*>(scal + SC_TICKET) = 0; }
-  }
+  if (bx == 0 && scal) reset_step_scalars(scal);
   if (bx >= nS_blocks) {
     if (A.slotB) {
       // atomic-free mode: C, g_rho of the landmark = its TwoCamera part (C, gr: atomics of the linearisation) + its slot records; the k1
@@ -1098,12 +1127,14 @@ __device__ __forceinline__ void prepare_body(const unsigned bx, const PrepArgs& 
   // folded into a rectangle so that consecutive threads still write consecutive entries of a row: rectangle row q holds matrix row q
   // (columns 0..q) followed by matrix row ld-1-q (columns 0..ld-1-q), ld + 1 entries in all.
   const size_t e = (size_t)bx * kT + threadIdx.x;
-  const int half = (ld + 1) / 2;
-  if (e >= (size_t)half * (ld + 1)) return;
-  const int q = (int)(e / (ld + 1)), cc = (int)(e % (ld + 1));
+  const int n0 = A.early ? A.off : 0, nn = ld - n0;                   // early form: the dense corner only
+  const int half = (nn + 1) / 2;
+  if (e >= (size_t)half * (nn + 1)) return;
+  const int q = (int)(e / (nn + 1)), cc = (int)(e % (nn + 1));
   int I, J;
   if (cc <= q) { I = q; J = cc; }
-  else { I = ld - 1 - q; J = cc - q - 1; if (I == q) return; }      // (odd ld: the middle row is its own partner)
+  else { I = nn - 1 - q; J = cc - q - 1; if (I == q) return; }      // (odd size: the middle row is its own partner)
+  I += n0; J += n0;
   const int oi = iperm[I], oj = iperm[J];
   double v = 0.0;
   if (oi >= 0) {
@@ -1116,7 +1147,8 @@ __device__ __forceinline__ void prepare_body(const unsigned bx, const PrepArgs& 
   } else if (I == J) {
     v = 1.0;
   }
-  S[(size_t)I * ld + J] = v;
+  if (!A.early) S[(size_t)I * ld + J] = v;
+  else if (v != 0.0) atomicAdd(&S[(size_t)I * ld + J], v);
 }
 __global__ __launch_bounds__(kT) void k_prepare(PrepArgs a) { prepare_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_prepare_b(const PrepArgs* __restrict__ t) { prepare_body(blockIdx.x, t[blockIdx.y]); }
@@ -1832,22 +1864,84 @@ __global__ __launch_bounds__(kCT) void k_chol_step_b(const CholArgs* __restrict_
 // W and L_bb go to side buffers (the eliminated columns of S are never read again), so the tiles of a block never race.
 __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __restrict__ nodes, int first, int tiles, const int* __restrict__ rows,
                                                   double* __restrict__ S, int ld, double* __restrict__ W, int wstride,
-                                                  double* __restrict__ Lout, int* __restrict__ fail, const int* done = nullptr) {
-  extern __shared__ double sp_sm[];        // Ws[m][9] | L[81] | linv[9] | rws[m] (int)
+                                                  double* __restrict__ Lout, int* __restrict__ fail, const int* done = nullptr,
+                                                  const SpSrc src = SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr}) {
+  extern __shared__ double sp_sm[];        // Ws[m][9] | L[81] | linv[9] | rws[m] (int) | rnat[m] (int, early form)
   const int dv = done_flag_issue(done);
   const int ni = first + vb / tiles, tile = vb % tiles, tid = threadIdx.x;
   const SpNode nd = nodes[ni];
+  const double radius = src.B ? *src.radius : 1.0;
   if (dv) return;
+  const bool chained = src.wait_counter != nullptr;
+  auto ld_s = [&](const double* ptr) -> double {      // an entry of S the level below may have added into during THIS launch
+    return chained ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
+  };
   const int m = nd.m, col = nd.col;
   double* Ws = sp_sm;
   double* L = sp_sm + 9 * m;
   double* linv = L + 81;
   int* rws = reinterpret_cast<int*>(linv + 9);
+  int* rnat = rws + m;
+  const int nb0 = src.dp + 9 * nd.id;      // early form: the block's first unknown in the natural order (poses | 9 per keyframe)
+  // The level is a chain of dependent round trips (node -> row list -> rows -> factor -> W -> updates), so everything is requested as early
+  // as its address is known, and the rows are dealt to waves 1..3 first: their requests are in flight while wave 0 factors the block
+  // (wave 0 only takes rows when there are more than 192).  Each thread keeps its FIRST row in registers; further rows (m > 256) follow
+  // the classic loop behind the barrier.
+  const int r0 = (tid + 192) & 255;
+  const bool has0 = r0 < m;
+  // ---- phase A: what does not depend on the level below
+  for (int r = tid; r < m; r += 256) { rws[r] = rows[nd.row_off + r]; if (src.B) rnat[r] = src.rows_nat[nd.row_off + r]; }
+  int rw0 = 0, rn0 = -1;
+  if (has0) { rw0 = rows[nd.row_off + r0]; if (src.B) rn0 = src.rows_nat[nd.row_off + r0]; }
+  double bd[9], sv0[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) { bd[c] = 0.0; sv0[c] = 0.0; }
+  if (src.B) {
+    if (tid < 9) {                         // what k_prepare would have stored in the diagonal block: B + clamp(diag B) / radius
+      const double inv_radius = 1.0 / radius;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        double b = c <= tid ? src.B[(size_t)(nb0 + tid) * src.ldB + nb0 + c] : 0.0;
+        if (c == tid) b += clamp_diag(b) * inv_radius;
+        bd[c] = b;
+      }
+    }
+    if (has0) {                            // the row's entries of B (lower triangle, natural order) / of -gc (the right-hand-side row)
+      if (rn0 == -2) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) sv0[c] = -src.gc[nb0 + c];
+      } else if (rn0 >= 0) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { const int oj = nb0 + c; sv0[c] = src.B[(size_t)max(rn0, oj) * src.ldB + min(rn0, oj)]; }
+      }
+    }
+  }
+  if (chained) {
+    // bounded: if the level below never arrives (a dispatch order this code does not expect) the step is flagged as failed instead of hanging
+    if (tid == 0) {
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(src.wait_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < src.wait_target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > 200000ull) { atomicExch(fail, 300000 + nd.id); break; }      // 2 ms at 100 MHz
+      }
+    }
+    asm volatile("s_barrier" ::: "memory");           // (not __syncthreads(): the requests above stay in flight across it)
+  }
+  // ---- phase B: what the level below added into S
+  double a[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) a[c] = 0.0;
+  if (tid < 9) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) a[c] = (c <= tid ? ld_s(&S[(size_t)(col + tid) * ld + col + c]) : 0.0) + bd[c];
+  }
+  if (has0) {
+    const double* srow = S + (size_t)rw0 * ld + col;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) sv0[c] += ld_s(srow + c);
+  }
   if (tid < 64) {
     const int lane = tid;
-    double a[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) a[c] = (lane < 9 && c <= lane) ? S[(size_t)(col + lane) * ld + col + c] : 0.0;
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
@@ -1880,14 +1974,12 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     }
     if (bad && lane == 0) atomicExch(fail, 100000 + nd.id);
   }
-  for (int r = tid; r < m; r += 256) rws[r] = rows[nd.row_off + r];
   __syncthreads();
-  for (int r = tid; r < m; r += 256) {     // (requesting these rows before the factorisation measured slower: 8.3 vs 7.5 us per level)
-    const double* src = S + (size_t)rws[r] * ld + col;
+  auto finish_row = [&](const int r, const double sv[9]) {     // W_r = S_rb L_bb^-T
     double w[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      double v = src[c];
+      double v = sv[c];
 #pragma unroll
       for (int k = 0; k < c; ++k) v -= w[k] * L[c * 9 + k];
       w[c] = v * linv[c];
@@ -1898,6 +1990,24 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
 #pragma unroll
       for (int c = 0; c < 9; ++c) W[(size_t)c * wstride + nd.row_off + r] = w[c];     // component-major: coalesced here and in the back substitution
     }
+  };
+  if (has0) finish_row(r0, sv0);
+  for (int r = r0 + 256; r < m; r += 256) {
+    const double* srow = S + (size_t)rws[r] * ld + col;
+    double sv[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) sv[c] = ld_s(srow + c);
+    if (src.B) {
+      const int oi = rnat[r];
+      if (oi == -2) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) sv[c] -= src.gc[nb0 + c];
+      } else if (oi >= 0) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { const int oj = nb0 + c; sv[c] += src.B[(size_t)max(oi, oj) * src.ldB + min(oi, oj)]; }
+      }
+    }
+    finish_row(r, sv);
   }
   if (tile == 0 && tid < 9) {              // column tid of L_bb^-1 (forward substitution against e_tid), for the back substitution
     double xcol[9];
@@ -1925,6 +2035,10 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     for (int c = 0; c < 9; ++c) v += wr[c] * wc[c];
     if (v != 0.0) atomicAdd(&S[(size_t)rws[r] * ld + rws[c2]], -v);
   }
+  if (src.done_counter) {
+    __syncthreads();                       // every wave's atomics have been acknowledged (the barrier drains vmcnt)
+    if (tid == 0) __hip_atomic_fetch_add(src.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 // Work list of the band Schur complement: one item per (slice, tile group) that has tiles to form.  The 2-D grid slices x groups is sized
 // for the widest possible band, but most slices (short tracks) need one group: three quarters of its workgroups had nothing to do and
@@ -1946,44 +2060,42 @@ __global__ __launch_bounds__(64) void k_band_work(int rows, int dp, const int* _
   }
 }
 
-struct SpArgs {          // one sparse level
-  const SpNode* nodes; int first, tiles; const int* rows; double* S; int ld; double* W; int wstride; double* Lout; int* fail; int nblocks; const int* done;
-};
-__global__ __launch_bounds__(256) void k_sp_eliminate(SpArgs a) {
-  if ((int)blockIdx.x >= a.nblocks) return;
-  sp_eliminate_body(blockIdx.x, a.nodes, a.first, a.tiles, a.rows, a.S, a.ld, a.W, a.wstride, a.Lout, a.fail, a.done);
+__device__ __forceinline__ void sp_ride(const int vb, const SpArgs& a) {
+  if (vb >= a.nblocks) return;
+  sp_eliminate_body(vb, a.nodes, a.first, a.tiles, a.rows, a.S, a.ld, a.W, a.wstride, a.Lout, a.fail, a.done, a.src);
 }
-__global__ __launch_bounds__(256) void k_sp_eliminate_b(const SpArgs* __restrict__ t) {
-  const SpArgs a = t[blockIdx.y];
-  if ((int)blockIdx.x >= a.nblocks) return;
-  sp_eliminate_body(blockIdx.x, a.nodes, a.first, a.tiles, a.rows, a.S, a.ld, a.W, a.wstride, a.Lout, a.fail, a.done);
-}
+__global__ __launch_bounds__(256) void k_sp_eliminate(SpArgs a) { sp_ride(blockIdx.x, a); }
+__global__ __launch_bounds__(256) void k_sp_eliminate_b(const SpArgs* __restrict__ t) { sp_ride(blockIdx.x, t[blockIdx.y]); }
 // The band-limited Schur complement and the FIRST sparse level in one launch: both only ADD (atomically) into entries of S the other
 // does not read — the Schur complement touches the pose corner and the pose part of the rhs row, level 0 reads its own (v,ba,bg)
 // columns — so they are independent; later levels depend on level 0 and stay launches of their own.
 struct SchurSp0Args {
   int n_slices, n_groups, dp, ldE; const double *E, *Cd; const int *order, *n_active, *kmin, *kmax; int d_local, ldS; double* S_pose;
-  SpArgs sp;             // level 0 (sp.nblocks == 0: Schur complement only)
+  SpArgs sp;             // the sparse level riding in the launch (sp.nblocks == 0: Schur complement only): level 0, or — early form — the first one left
+  SpArgs sp_b, sp_c;     // early form: the next two levels, chained behind it inside the launch (SpSrc::wait_counter)
   int nblocks; const int* done; unsigned long long* dbg; int rows;
-  const int4* work; int n_work;      // (slice, group, band lo | hi << 16, slice end) items; sparse level 0 runs in workgroups [0, sp.nblocks), the items behind
+  const int4* work; int n_work;      // (slice, group, band lo | hi << 16, slice end) items; the sparse levels run in the first workgroups, the items behind
 };
 __device__ __forceinline__ void schur_sp0_body(const int b, const SchurSp0Args& A) {
   if (b >= A.nblocks) return;
   if (A.work) {
-    if (b < A.sp.nblocks) sp_eliminate_body(b, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail, A.done);
+    const int n_a = A.sp.nblocks, n_b = A.sp_b.nblocks, n_c = A.sp_c.nblocks, n_sp = n_a + n_b + n_c;
+    if (b < n_a) sp_ride(b, A.sp);
+    else if (b < n_a + n_b) sp_ride(b - n_a, A.sp_b);
+    else if (b < n_sp) sp_ride(b - n_a - n_b, A.sp_c);
     else {
       const int dv = done_flag_issue(A.done);
-      const int4* item = A.work + (b - A.sp.nblocks);
+      const int4* item = A.work + (b - n_sp);
       const int4 it = *item;
       if (dv) return;
-      schur_band_body(it.x, it.y, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)(b - A.sp.nblocks) * 8 : nullptr, A.rows, item);
+      schur_band_body(it.x, it.y, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)(b - n_sp) * 8 : nullptr, A.rows, item);
     }
     return;
   }
   if (A.done && *A.done) return;
   const int ns = A.n_slices * A.n_groups;
   if (b < ns) schur_band_body(b % A.n_slices, b / A.n_slices, A.dp, A.ldE, A.E, A.Cd, A.order, A.n_active, A.kmin, A.kmax, A.d_local, A.ldS, A.S_pose, A.dbg ? A.dbg + (size_t)b * 8 : nullptr, A.rows);
-  else sp_eliminate_body(b - ns, A.sp.nodes, A.sp.first, A.sp.tiles, A.sp.rows, A.sp.S, A.ldS, A.sp.W, A.sp.wstride, A.sp.Lout, A.sp.fail);
+  else sp_ride(b - ns, A.sp);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_schur_sp0(SchurSp0Args a) { schur_sp0_body(blockIdx.x, a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_schur_sp0_b(const SchurSp0Args* __restrict__ t) { schur_sp0_body(blockIdx.x, t[blockIdx.y]); }
@@ -2523,8 +2635,15 @@ struct Chain {
   ZeroList zero{};              // everything a linearisation accumulates into (explicit k_zero_multi when the accumulators are not known clean)
   ImuArgs imu_lin{}, imu_cost{};
   LinArgs lin{}; size_t lin_lds = 0;
-  TfReduceArgs red{};           // compact mode: the slabs of the TwoFrame linearisation -> B, gc
-  PrepArgs prep{};
+  TfReduceArgs red{}; size_t red_lds = 0;     // compact mode: the slabs of the TwoFrame linearisation -> B, gc
+  PrepArgs prep{};              // classic form (stores the whole lower triangle); also what the parity taps use
+  // Early sparse levels.  The (v, ba, bg) columns only ever receive ImuError terms, the LM damping and the updates of lower levels, so a
+  // level can form its columns from B itself (SpSrc) as soon as the linearisation launch is over: level 0 rides in the k_tf_reduce
+  // launch, level 1 in k_prepare's, level 2 in the Schur complement's, and only what is left takes launches of its own (at 50 keyframes
+  // two instead of four).  For that S is cleared with the accumulators and k_prepare ADDS the dense corner (prep_early).
+  bool early = false;
+  PrepArgs prep_early{}; size_t prep_lds = 0;
+  int first_own_level = 0;      // sparse levels [first_own_level, n_levels) are launches of their own
   bool merged_level0 = false;
   SchurSp0Args ssp0{}; size_t ssp0_lds = 0;
   int n_levels = 0; SpArgs sp[kSpMaxLevels]; int sp_lds[kSpMaxLevels] = {0};
@@ -2659,18 +2778,28 @@ static int build_chain(lvf_problem* p) {
   const StateP s = state_ptrs(p->st);
   const StateP s2{p->poses2.p, p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->st->w_visual.p};
   double* cost = p->scal.p + SC_COST;
+  c.fast = p->tf && p->tf->n && p->tf_work.n && p->n_kf <= kMaxStagedKf;
+  c.has_imu = p->imu && p->imu->n;
+  c.has_prior = p->prior && p->prior->n;
+  const size_t schur_lds = p->n_lm ? ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRowsMax * sizeof(int) : 0;
+  const bool schur_merged = p->n_lm && p->band_ready && schur_lds <= 64 * 1024 && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024;
+  {
+    // LVF_EARLY_LEVELS=0: the classic order (A/B measurements); LVF_POISON_S fills S with NaN before the assembly, which only the classic form survives
+    static const bool early_on = [] { const char* e = std::getenv("LVF_EARLY_LEVELS"); return !(e && e[0] == '0') && std::getenv("LVF_POISON_S") == nullptr; }();
+    bool fits = true;
+    for (int lv = 0; lv < std::min(3, p->sp_levels.n); ++lv) fits = fits && (size_t)p->sp_shmem[lv] <= 64 * 1024;
+    c.early = early_on && c.fast && c.has_imu && schur_merged && fits && p->sp_levels.n >= 2;      // (one level: it already hides in the Schur launch)
+  }
   {
     int k = 0;
     auto add = [&](double* ptr, size_t n) { if (ptr && n) { c.zero.p[k] = ptr; c.zero.n[k] = n; ++k; } };
     add(p->B.p, (size_t)p->dpad * p->dpad); add(p->gc.p, p->dpad);
     if (p->n_lm) { if (!p->compact) add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
+    if (c.early) { add(p->S.p, (size_t)p->ld * p->ld); add(p->sp_sync.p, kSpMaxLevels); }     // early sparse levels add into S before k_prepare does; their arrival counters
     c.zero_end = c.zero; c.zero_end.count = k;         // cleared at the END of an iteration, beside the cost pass (the scalars: by the decision itself)
     add(p->scal.p, SC_N);
     c.zero.count = k;
   }
-  c.fast = p->tf && p->tf->n && p->tf_work.n && p->n_kf <= kMaxStagedKf;
-  c.has_imu = p->imu && p->imu->n;
-  c.has_prior = p->prior && p->prior->n;
   if (c.has_imu) {
     fill_imu_args(p->imu, s.poses, s.vel, s.ba, s.bg, nullptr, nullptr, done, &c.imu_lin);
     fill_imu_args(p->imu, s2.poses, s2.vel, s2.ba, s2.bg, p->scal.p + SC_COST_NEW, nullptr, done, &c.imu_cost);
@@ -2699,9 +2828,11 @@ static int build_chain(lvf_problem* p) {
       TfReduceArgs& r = c.red;
       r.n_kf = p->n_kf; r.n_wg = a.n_tfw; r.run_first = p->run_first.p; r.slabP = p->slabP.p; r.slabQ = p->slabQ.p; r.B = p->B.p; r.ld = p->dpad; r.gc = p->gc.p;
       r.nblocks = p->n_kf * ((a.n_tfw + 63) / 64) + grid(p->n_kf * (p->n_kf - 1) / 2 * 36); r.done = done;
+      r.own_blocks = r.nblocks; r.ride = SpArgs{}; r.ride.nblocks = 0;
     }
     c.lin.n_kf = p->n_kf; c.lin.s = s; c.lin.huber = 0.0; c.lin.pose_const = p->pose_const.p; c.lin.B = p->B.p; c.lin.ld = p->dpad; c.lin.gc = p->gc.p; c.lin.E = p->E.p;
     c.lin.ldE = p->ldE; c.lin.C = p->C.p; c.lin.gr = p->gr.p; c.lin.cost = cost; c.lin.done = done; c.lin.dbg = nullptr;
+    c.lin.scal_reset = c.early ? p->scal.p : nullptr;
     c.lin.nblocks = a.n_tfw + a.g_tc + a.g_po + (a.imu.pre ? a.n_imu : (a.n_imu + 3) / 4);
     c.lin_lds = std::max((size_t)(sizeof(PoseD) / 8 + kAccSlots) * p->n_kf + 32, (size_t)std::max(kImuWaveLds, 1864 + 64)) * sizeof(double);
   }
@@ -2713,6 +2844,13 @@ static int build_chain(lvf_problem* p) {
     a.nS_blocks = (unsigned)(((size_t)((p->ld + 1) / 2) * (p->ld + 1) + kT - 1) / kT); a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.C = p->C.p; a.gr = p->gr.p; a.Cd = p->Cd.p; a.E = p->E.p;
     a.eoff = p->lm_eoff.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p; a.slotB = p->compact ? p->slotB.p : nullptr; a.Ct = p->Ct.p; a.grt = p->grt.p;
     a.scal = p->scal.p; a.nblocks = (int)a.nS_blocks + (p->n_lm ? grid(p->compact ? 8 * p->n_lm : p->n_lm) : 0); a.done = done;
+    a.early = 0; a.off = p->off; a.own_blocks = a.nblocks; a.ride = SpArgs{}; a.ride.nblocks = 0;
+    PrepArgs& e = c.prep_early;
+    e = a;
+    const int nn = p->ld - p->off;
+    e.early = 1; e.scal = nullptr;                      // (the scalars are reset by the linearisation launch: LinArgs::scal_reset)
+    e.nS_blocks = (unsigned)(((size_t)((nn + 1) / 2) * (nn + 1) + kT - 1) / kT);
+    e.nblocks = e.own_blocks = (int)e.nS_blocks + (p->n_lm ? grid(p->compact ? 8 * p->n_lm : p->n_lm) : 0);
   }
   int* fail = reinterpret_cast<int*>(p->scal.p + SC_FAIL);
   c.n_levels = p->sp_levels.n;
@@ -2720,24 +2858,60 @@ static int build_chain(lvf_problem* p) {
     SpArgs& a = c.sp[lv];
     a.nodes = p->sp_nodes.p; a.first = p->sp_levels.first[lv]; a.tiles = p->sp_tiles[lv]; a.rows = p->sp_rows.p; a.S = p->S.p; a.ld = p->ld; a.W = p->sp_W.p;
     a.wstride = p->sp_wstride; a.Lout = p->sp_L.p; a.fail = fail; a.nblocks = p->sp_levels.count[lv] * p->sp_tiles[lv]; a.done = done;
+    a.src = c.early ? SpSrc{p->B.p, p->dpad, p->dp, p->gc.p, radius, p->sp_rows_nat.p, nullptr, 0, nullptr} : SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     c.sp_lds[lv] = p->sp_shmem[lv];
   }
   c.merged_level0 = false;
   if (p->n_lm) {
     const int nt = p->ldE / 16, ntile = nt * (nt + 1) / 2;
-    const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRowsMax * sizeof(int);
-    if (p->band_ready && shb <= 64 * 1024 && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024) {
+    const size_t shb = schur_lds;
+    // early form: the levels are dealt to the launches that exist anyway, in order
+    int next_level = 0;
+    // Where the levels go (measured, MI355X): the Schur launch hides three (one riding, two chained behind it); a level riding in
+    // k_tf_reduce's launch costs ~0 us, in k_prepare's ~2 us, a launch of its own 7.6 us.  So the LAST three levels go to the Schur launch
+    // and only what is left over rides in the two launches ahead (16 / 20 keyframes, three levels: 0.111 / 0.125 -> 0.098 / 0.118 ms
+    // with the chain alone, 0.103 / 0.123 with riders in front of it).  LVF_RIDE_TF / LVF_RIDE_PREP = 0 | 1 override, LVF_CHAIN_LEVELS = 0..2.
+    static const int ride_tf_env = [] { const char* e = std::getenv("LVF_RIDE_TF"); return e ? std::atoi(e) : -1; }();
+    static const int ride_prep_env = [] { const char* e = std::getenv("LVF_RIDE_PREP"); return e ? std::atoi(e) : -1; }();
+    static const int chain_n = [] { const char* e = std::getenv("LVF_CHAIN_LEVELS"); return e ? std::max(0, std::min(2, std::atoi(e))) : 2; }();
+    const int excess = std::max(0, c.n_levels - (1 + chain_n));
+    const bool ride_tf = ride_tf_env >= 0 ? ride_tf_env != 0 : (p->compact && excess >= 1);
+    const bool ride_prep = ride_prep_env >= 0 ? ride_prep_env != 0 : (excess >= 2 || (excess >= 1 && !(ride_tf && p->compact)));
+    if (c.early) {
+      if (!ride_tf) {}
+      else if (p->compact && next_level < c.n_levels) { c.red.ride = c.sp[next_level]; c.red.nblocks = c.red.own_blocks + c.red.ride.nblocks; c.red_lds = (size_t)c.sp_lds[next_level]; ++next_level; }
+      if (ride_prep && next_level < c.n_levels) { PrepArgs& e = c.prep_early; e.ride = c.sp[next_level]; e.nblocks = e.own_blocks + e.ride.nblocks; c.prep_lds = (size_t)c.sp_lds[next_level]; ++next_level; }
+    }
+    if (schur_merged) {
       SchurSp0Args& a = c.ssp0;
       a.rows = std::min(kBandRowsMax, std::max(16, p->band_rows));
       a.n_slices = (p->n_lm + a.rows - 1) / a.rows; a.n_groups = (ntile + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
       a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.Cd = p->Cd.p; a.order = p->lm_order.p;
       a.dbg = nullptr; a.n_active = p->lm_nactive.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p;
       a.d_local = p->dp; a.ldS = p->ld; a.S_pose = p->S.p + (size_t)p->off_pose * (p->ld + 1);
-      a.sp = c.sp[0];
+      const int ride = c.early ? next_level : 0;       // classic: level 0 rides here
+      a.sp = SpArgs{}; a.sp.nblocks = 0; a.sp_b = a.sp; a.sp_c = a.sp;
+      c.ssp0_lds = shb;
+      next_level = ride;
+      if (ride < c.n_levels) { a.sp = c.sp[ride]; c.ssp0_lds = std::max(c.ssp0_lds, (size_t)p->sp_shmem[ride]); next_level = ride + 1; }
+      // the Schur complement lasts ~20 us at this size, a level ~5: the next two levels wait for their predecessor INSIDE the launch
+      if (c.early && chain_n > 0) {
+        int* cnt = reinterpret_cast<int*>(p->sp_sync.p);
+        SpArgs* slot[2] = {&a.sp_b, &a.sp_c};
+        SpArgs* prev = &a.sp;
+        for (int k = 0; k < std::min(2, chain_n) && next_level < c.n_levels && (size_t)p->sp_shmem[next_level] <= 64 * 1024; ++k) {
+          *slot[k] = c.sp[next_level];
+          prev->src.done_counter = cnt + 2 * (next_level - 1);
+          slot[k]->src.wait_counter = cnt + 2 * (next_level - 1); slot[k]->src.wait_target = prev->nblocks;
+          c.ssp0_lds = std::max(c.ssp0_lds, (size_t)p->sp_shmem[next_level]);
+          prev = slot[k];
+          ++next_level;
+        }
+      }
       a.work = p->band_work.p; a.n_work = p->n_band_work;
-      a.nblocks = a.n_work + c.sp[0].nblocks; a.done = done;
-      c.ssp0_lds = std::max(shb, (size_t)p->sp_shmem[0]);
+      a.nblocks = a.n_work + a.sp.nblocks + a.sp_b.nblocks + a.sp_c.nblocks; a.done = done;
       c.merged_level0 = true;
+      c.first_own_level = next_level;
     }
   }
   c.chol.Sd = p->S.p + (size_t)p->off * (p->ld + 1); c.chol.ld = p->ld; c.chol.nb = p->nb; c.chol.fail = fail; c.chol.Dinv = p->Dinv.p; c.chol.done = done;
@@ -2798,7 +2972,7 @@ static bool chain_stale(const lvf_problem* p) {
 // the linearisation at the current state: cost, B, gc, E, C, gr.  `gated`: skipped on device once the LM loop has finished
 // HIP events between the stages of one LM iteration (lvf_problem_stage_times): event 0 before the first launch, event k + 1 after stage k
 enum { ST_IMU_LIN = 0, ST_LIN_VISUAL, ST_TF_REDUCE, ST_PREPARE, ST_SCHUR_SP0, ST_SP_LEVELS, ST_CHOL, ST_BACKSOLVE, ST_STEP_TAIL, ST_COST, ST_DECIDE, ST_N };
-static const char* const kStageNames[ST_N] = {"k_zero_multi (only when the accumulators are not known clean)", "k_lin_visual", "k_tf_reduce", "k_prepare", "k_schur_sp0", "k_sp_eliminate (levels 1..)",
+static const char* const kStageNames[ST_N] = {"k_zero_multi (only when the accumulators are not known clean)", "k_lin_visual", "k_tf_reduce (+ sparse level 0)", "k_prepare (+ sparse level 1)", "k_schur_sp0 (+ a sparse level)", "k_sp_eliminate (the levels left)",
                                              "k_chol_step (all block steps)", "k_chol_backsolve", "k_step_tail", "k_cost_decide (candidate cost incl. the ImuError factors; its last workgroup closes the iteration; + prior passes)", "k_lm_decide (windows without visual blocks)"};
 struct StageClock { hipEvent_t ev[ST_N + 1]; int launches[ST_N]; bool on = false; };
 void stage_clock_free(StageClock* k) {
@@ -2813,7 +2987,9 @@ static inline void stage_mark(lvf_problem* p, int stage_done, int launches) {
   k->launches[stage_done] = launches;
 }
 
-static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
+// `iteration`: the launches belong to a full LM iteration (enqueue_iteration) — only then do the early sparse levels ride along and are the
+// per-step scalars reset here; a stand-alone linearisation (gradient / cost taps) leaves S and the control block alone
+static int enqueue_linearize(lvf_problem* p, double huber, bool gated, bool iteration = false) {
   hipStream_t q = p->ctx->stream;
   if (chain_stale(p)) LVF_TRY(build_chain(p));
   const Chain& c = *p->chain;
@@ -2832,6 +3008,7 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
     LinArgs la = c.lin;
     la.huber = huber;
     if (!gated) la.done = nullptr;
+    if (!iteration) la.scal_reset = nullptr;
     static const bool lin_timing = std::getenv("LVF_LIN_TIMING") != nullptr;
     if (lin_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)la.v.n_tfw * 8 + 8)); la.dbg = p->dbg_lin.p; }
     hipLaunchKernelGGL(k_lin_visual, dim3(la.nblocks), dim3(kT), c.lin_lds, q, la);
@@ -2839,7 +3016,8 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
     if (p->compact) {
       TfReduceArgs ra = c.red;
       if (!gated) ra.done = nullptr;
-      hipLaunchKernelGGL(k_tf_reduce, dim3(ra.nblocks), dim3(kT), 0, q, ra);
+      if (!iteration) { ra.nblocks = ra.own_blocks; ra.ride.nblocks = 0; }
+      hipLaunchKernelGGL(k_tf_reduce, dim3(ra.nblocks), dim3(kT), ra.ride.nblocks > 0 ? c.red_lds : 0, q, ra);
     }
     stage_mark(p, ST_TF_REDUCE, p->compact ? 1 : 0);
     if (lin_timing) {
@@ -2893,7 +3071,9 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated) {
 static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool reset_scalars, bool gated, bool* level0_done) {
   hipStream_t q = p->ctx->stream;
   const Chain& c = *p->chain;
-  PrepArgs pa = c.prep;
+  // the parity tap (level0_done == nullptr: the damped system alone, nothing eliminated) always takes the classic assembly
+  const bool early = c.early && level0_done != nullptr;
+  PrepArgs pa = early ? c.prep_early : c.prep;
   pa.radius = radius_dev;
   if (!reset_scalars) pa.scal = nullptr;
   if (!gated) pa.done = nullptr;
@@ -2901,14 +3081,15 @@ static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool
   // triangle — stays NaN; results must not change (tests/test_gpu_solver.py runs the parity cases this way too)
   static const bool poison = std::getenv("LVF_POISON_S") != nullptr;
   if (poison) LVF_HIP(hipMemsetAsync(p->S.p, 0xff, (size_t)p->ld * p->ld * 8, q));
-  hipLaunchKernelGGL(k_prepare, dim3(pa.nblocks), dim3(kT), 0, q, pa);
+  hipLaunchKernelGGL(k_prepare, dim3(pa.nblocks), dim3(kT), pa.ride.nblocks > 0 ? c.prep_lds : 0, q, pa);
   stage_mark(p, ST_PREPARE, 1);
+  if (!early && c.early) p->accum_clean = false;       // the tap wrote S: the next iteration must clear it
   if (level0_done) *level0_done = false;
   if (p->n_lm) {
     if (c.merged_level0) {
       SchurSp0Args sa = c.ssp0;
       if (!gated) sa.done = nullptr;
-      if (!level0_done) { sa.nblocks = sa.n_work; sa.sp.nblocks = 0; }       // the Schur complement alone (parity tap)
+      if (!level0_done) { sa.nblocks = sa.n_work; sa.sp.nblocks = 0; sa.sp_b.nblocks = 0; sa.sp_c.nblocks = 0; }       // the Schur complement alone (parity tap)
       static const bool schur_timing = std::getenv("LVF_SCHUR_TIMING") != nullptr;
       const int ns = sa.n_work;
       if (schur_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)ns * 8 + 8)); LVF_HIP(hipMemsetAsync(p->dbg_lin.p, 0, (size_t)ns * 64, q)); sa.dbg = p->dbg_lin.p; }
@@ -2944,12 +3125,13 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
   hipStream_t q = p->ctx->stream;
   if (chain_stale(p)) LVF_TRY(build_chain(p));
   const Chain& c = *p->chain;
-  LVF_TRY(enqueue_linearize(p, p->huber, true));
+  LVF_TRY(enqueue_linearize(p, p->huber, true, true));
   bool level0_done = false;
   LVF_TRY(enqueue_reduced_system(p, &p->ctl.p->radius, true, true, &level0_done));
-  for (int lv = level0_done ? 1 : 0; lv < c.n_levels; ++lv)
+  const int own0 = level0_done ? c.first_own_level : 0;      // (levels below rode in the launches above)
+  for (int lv = own0; lv < c.n_levels; ++lv)
     hipLaunchKernelGGL(k_sp_eliminate, dim3(c.sp[lv].nblocks), dim3(256), c.sp_lds[lv], q, c.sp[lv]);
-  stage_mark(p, ST_SP_LEVELS, c.n_levels - (level0_done ? 1 : 0));
+  stage_mark(p, ST_SP_LEVELS, std::max(0, c.n_levels - own0));
   for (int kb = 0; kb < p->nb; ++kb) {
     CholArgs cha = c.chol;
     static const bool chol_timing = std::getenv("LVF_CHOL_TIMING") != nullptr;
@@ -3192,7 +3374,7 @@ static int build_elimination_plan(lvf_problem* p) {
   iperm[p->aug] = -2;
   // device tables
   std::vector<SpNode> dn(ns);
-  std::vector<int> rows, owner;
+  std::vector<int> rows, owner, rows_nat;
   p->sp_tiles.assign(lv.n, 1); p->sp_shmem.assign(lv.n, 0); p->sp_item0.assign(lv.n, 0); p->sp_items.assign(lv.n, 0);
   for (int l = 0; l < lv.n; ++l) {
     int mmax = 0;
@@ -3212,12 +3394,15 @@ static int build_elimination_plan(lvf_problem* p) {
     p->sp_item0[l] = dn[lv.first[l]].row_off; p->sp_items[l] = (int)rows.size() - p->sp_item0[l];
     const int P = mmax * (mmax + 1) / 2;
     p->sp_tiles[l] = std::max(1, std::min(32, (P + 2047) / 2048));
-    p->sp_shmem[l] = (9 * mmax + 81 + 9) * 8 + 4 * mmax + 16;
+    p->sp_shmem[l] = (9 * mmax + 81 + 9) * 8 + 2 * 4 * mmax + 16;
   }
   p->sp_levels = lv;
   hipStream_t q = p->ctx->stream;
   LVF_TRY(p->perm.assign(p->perm_h.data(), p->perm_h.size(), q)); LVF_TRY(p->iperm.assign(iperm.data(), iperm.size(), q));
   if (ns) {
+    rows_nat.resize(rows.size());
+    for (size_t i = 0; i < rows.size(); ++i) rows_nat[i] = iperm[rows[i]];
+    LVF_TRY(p->sp_rows_nat.assign(rows_nat.data(), rows_nat.size(), q));
     LVF_TRY(p->sp_nodes.assign(dn.data(), dn.size(), q)); LVF_TRY(p->sp_rows.assign(rows.data(), rows.size(), q)); LVF_TRY(p->sp_owner.assign(owner.data(), owner.size(), q));
     LVF_TRY(p->sp_W.ensure(rows.size() * 9)); LVF_TRY(p->sp_L.ensure((size_t)ns * 81));
     p->sp_wstride = (int)rows.size();
@@ -3245,7 +3430,7 @@ int problem_configure(lvf_problem* p) {
   LVF_TRY(p->Dinv.ensure((size_t)p->nb * kNB * kNB));
   LVF_TRY(p->B.ensure(nS)); LVF_TRY(p->S.ensure((size_t)p->ld * p->ld)); LVF_TRY(p->gc.ensure(p->dpad)); LVF_TRY(p->dxc.ensure(p->dpad));
   LVF_TRY(p->C.ensure(p->n_lm)); LVF_TRY(p->gr.ensure(p->n_lm)); LVF_TRY(p->Cd.ensure(p->n_lm)); LVF_TRY(p->dxl.ensure(p->n_lm));
-  LVF_TRY(p->scal.ensure(SC_ALLOC));
+  LVF_TRY(p->scal.ensure(SC_ALLOC)); LVF_TRY(p->sp_sync.ensure(kSpMaxLevels));
   // candidate state x + dx (an accepted candidate is copied into the state by k_lm_decide)
   LVF_TRY(p->poses2.ensure(std::max(st->poses.cap, (size_t)7 * p->n_kf))); LVF_TRY(p->vel2.ensure(std::max(st->vel.cap, (size_t)3 * p->n_kf)));
   LVF_TRY(p->ba2.ensure(std::max(st->ba.cap, (size_t)3 * p->n_kf))); LVF_TRY(p->bg2.ensure(std::max(st->bg.cap, (size_t)3 * p->n_kf)));
@@ -3393,8 +3578,9 @@ struct lvf_problem_batch {
   // per-stage argument tables [W] (device) and the launch shapes (max over the windows)
   lvf::DevBuf<lvf::ImuArgs> imu_lin, imu_cost; int g_imu_lin = 0, g_imu_cost = 0;
   lvf::DevBuf<lvf::LinArgs> lin; int g_lin = 0; size_t lds_lin = 0;
-  lvf::DevBuf<lvf::TfReduceArgs> red; int g_red = 0;
-  lvf::DevBuf<lvf::PrepArgs> prep; int g_prep = 0;
+  lvf::DevBuf<lvf::TfReduceArgs> red; int g_red = 0; size_t lds_red = 0;
+  lvf::DevBuf<lvf::PrepArgs> prep; int g_prep = 0; size_t lds_prep = 0;
+  int first_own_level = 0;           // min over the windows: the first sparse level that is a launch of its own
   lvf::DevBuf<lvf::SchurSp0Args> ssp0; int g_ssp0 = 0; size_t lds_ssp0 = 0;
   lvf::DevBuf<lvf::SpArgs> sp[lvf::kSpMaxLevels]; int g_sp[lvf::kSpMaxLevels] = {0}; int lds_sp[lvf::kSpMaxLevels] = {0};
   lvf::DevBuf<lvf::CholArgs> chol;
@@ -3431,13 +3617,16 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
   std::vector<ImuArgs> il(W), ic(W); std::vector<LinArgs> li(W); std::vector<TfReduceArgs> rd(W); std::vector<PrepArgs> pr(W); std::vector<SchurSp0Args> ss(W);
   std::vector<CholArgs> ch(W); std::vector<BackArgs> bk(W); std::vector<TailArgs> tl(W); std::vector<CostArgs> co(W); std::vector<DecideArgs> de(W); std::vector<ZeroList> zl(W);
   b->max_levels = 0; b->max_nb = 0;
-  b->g_red = 0;
+  b->g_red = 0; b->lds_red = 0; b->lds_prep = 0; b->first_own_level = kSpMaxLevels;
   b->g_imu_lin = b->g_imu_cost = b->g_lin = b->g_prep = b->g_ssp0 = b->g_tail = b->g_cost = 0; b->lds_ssp0 = b->lds_back = b->lds_tail = b->lds_lin = 0;
   for (int w = 0; w < W; ++w) {
     const lvf_problem* p = b->probs[w];
     const Chain& c = *p->chain;
     il[w] = c.imu_lin; ic[w] = c.imu_cost; li[w] = c.lin; li[w].huber = huber; rd[w] = c.red; if (!p->compact) rd[w].nblocks = 0;
-    b->g_red = std::max(b->g_red, rd[w].nblocks); pr[w] = c.prep; ss[w] = c.ssp0; ch[w] = c.chol; bk[w] = c.back; tl[w] = c.tail;
+    b->g_red = std::max(b->g_red, rd[w].nblocks); pr[w] = c.early ? c.prep_early : c.prep; ss[w] = c.ssp0; ch[w] = c.chol; bk[w] = c.back; tl[w] = c.tail;
+    if (rd[w].nblocks > rd[w].own_blocks) b->lds_red = std::max(b->lds_red, c.red_lds);
+    if (pr[w].nblocks > pr[w].own_blocks) b->lds_prep = std::max(b->lds_prep, c.prep_lds);
+    b->first_own_level = std::min(b->first_own_level, c.first_own_level);
     co[w] = c.cost; co[w].huber = huber; de[w] = c.dec; zl[w] = c.zero;
     if (W >= 4) {                                        // fatter cost / zeroing workgroups in a batch (see cost_visual_value)
       CostArgs& k = co[w];
@@ -3451,7 +3640,7 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
       ta.nblocks -= ta.g_lm - g2; ta.g_lm = g2;
     }
     b->g_imu_lin = std::max(b->g_imu_lin, c.imu_lin.n + c.imu_lin.zero_wgs); b->g_imu_cost = std::max(b->g_imu_cost, c.imu_cost.n + c.imu_cost.zero_wgs);
-    b->g_lin = std::max(b->g_lin, c.lin.nblocks); b->lds_lin = std::max(b->lds_lin, c.lin_lds); b->g_prep = std::max(b->g_prep, c.prep.nblocks); b->g_ssp0 = std::max(b->g_ssp0, c.ssp0.nblocks);
+    b->g_lin = std::max(b->g_lin, c.lin.nblocks); b->lds_lin = std::max(b->lds_lin, c.lin_lds); b->g_prep = std::max(b->g_prep, pr[w].nblocks); b->g_ssp0 = std::max(b->g_ssp0, c.ssp0.nblocks);
     b->lds_ssp0 = std::max(b->lds_ssp0, c.ssp0_lds); b->lds_back = std::max(b->lds_back, c.back_lds); b->g_tail = std::max(b->g_tail, tl[w].nblocks);
     b->lds_tail = std::max(b->lds_tail, c.tail_lds); b->g_cost = std::max(b->g_cost, co[w].nblocks + co[w].zero_wgs);
     b->max_levels = std::max(b->max_levels, c.n_levels); b->max_nb = std::max(b->max_nb, p->nb);
@@ -3459,12 +3648,12 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
   LVF_TRY(upload_table(b->imu_lin, il, q)); LVF_TRY(upload_table(b->imu_cost, ic, q)); LVF_TRY(upload_table(b->lin, li, q)); LVF_TRY(upload_table(b->red, rd, q)); LVF_TRY(upload_table(b->prep, pr, q));
   LVF_TRY(upload_table(b->ssp0, ss, q)); LVF_TRY(upload_table(b->chol, ch, q)); LVF_TRY(upload_table(b->back, bk, q)); LVF_TRY(upload_table(b->tail, tl, q));
   LVF_TRY(upload_table(b->cost, co, q)); LVF_TRY(upload_table(b->dec, de, q)); LVF_TRY(upload_table(b->zero, zl, q));
-  for (int lv = 1; lv < b->max_levels; ++lv) {        // level 0 rides in the Schur launch
+  for (int lv = b->first_own_level; lv < b->max_levels; ++lv) {        // (the levels below ride in the launches ahead: Chain::first_own_level)
     std::vector<SpArgs> sp(W);
     b->g_sp[lv] = 0; b->lds_sp[lv] = 0;
     for (int w = 0; w < W; ++w) {
       const Chain& c = *b->probs[w]->chain;
-      if (lv < c.n_levels) { sp[w] = c.sp[lv]; b->g_sp[lv] = std::max(b->g_sp[lv], c.sp[lv].nblocks); b->lds_sp[lv] = std::max(b->lds_sp[lv], c.sp_lds[lv]); }
+      if (lv >= c.first_own_level && lv < c.n_levels) { sp[w] = c.sp[lv]; b->g_sp[lv] = std::max(b->g_sp[lv], c.sp[lv].nblocks); b->lds_sp[lv] = std::max(b->lds_sp[lv], c.sp_lds[lv]); }
       else { sp[w] = SpArgs{}; sp[w].nblocks = 0; }
     }
     LVF_TRY(upload_table(b->sp[lv], sp, q));
@@ -3485,10 +3674,10 @@ static int batch_enqueue_iteration(lvf_problem_batch* b, bool end_zero) {
   for (lvf_problem* p : b->probs) { clean = clean && p->accum_clean; p->accum_clean = false; }
   if (!clean) hipLaunchKernelGGL(k_zero_table, dim3(512, W), dim3(kT), 0, q, b->zero.p);
   hipLaunchKernelGGL(k_lin_visual_b, dim3(b->g_lin, W), dim3(kT), b->lds_lin, q, b->lin.p);
-  if (b->g_red > 0) hipLaunchKernelGGL(k_tf_reduce_b, dim3(b->g_red, W), dim3(kT), 0, q, b->red.p);
-  hipLaunchKernelGGL(k_prepare_b, dim3(b->g_prep, W), dim3(kT), 0, q, b->prep.p);
+  if (b->g_red > 0) hipLaunchKernelGGL(k_tf_reduce_b, dim3(b->g_red, W), dim3(kT), b->lds_red, q, b->red.p);
+  hipLaunchKernelGGL(k_prepare_b, dim3(b->g_prep, W), dim3(kT), b->lds_prep, q, b->prep.p);
   hipLaunchKernelGGL(k_schur_sp0_b, dim3(b->g_ssp0, W), dim3(256), b->lds_ssp0, q, b->ssp0.p);
-  for (int lv = 1; lv < b->max_levels; ++lv)
+  for (int lv = b->first_own_level; lv < b->max_levels; ++lv)
     if (b->g_sp[lv] > 0) hipLaunchKernelGGL(k_sp_eliminate_b, dim3(b->g_sp[lv], W), dim3(256), b->lds_sp[lv], q, b->sp[lv].p);
   for (int kb = 0; kb < b->max_nb; ++kb) {
     hipLaunchKernelGGL(k_chol_step_b, dim3(chol_step_grid(b->max_nb, kb), W), dim3(kCT), 0, q, b->chol.p, kb);
