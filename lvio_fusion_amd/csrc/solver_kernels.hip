@@ -39,6 +39,8 @@ struct SpSrc {
   // below are atomic adds into S (agent scope), read back with agent-scope atomic loads — no fences (MI355X_MICROARCH.md, "8-byte agent
   // atomics both sides").  Producers carry lower workgroup numbers than their consumers, so they are dispatched first.
   int* wait_counter; int wait_target; int* done_counter;
+  int strip_end;           // S rows / columns below it belong to sparse blocks (lvf_problem::off)
+  int rmw_read;            // diagnostic: chained reads by returning atomics instead of agent-scope loads
 };
 struct SpArgs {          // one sparse level
   const SpNode* nodes; int first, tiles; const int* rows; double* S; int ld; double* W; int wstride; double* Lout; int* fail; int nblocks; const int* done;
@@ -84,6 +86,19 @@ struct lvf_problem {
   lvf::HostPin<lvf::TfWork> h_tf_work;
   std::vector<uint8_t> pose_const_h;
   bool linearized = false;
+  // TwoFrame blocks as the solver reads them: the batch's own arrays, or — when the blocks of a current-keyframe run come with their first
+  // keyframes in no order (landmark ids not in creation order) — copies sorted by (current, first) keyframe made at problem_configure, so
+  // that a wave's 64 blocks share a few first keyframes and their sums go through the group-wise reductions instead of 63 LDS atomics per
+  // block (the slowest workgroup of k_lin_visual: 18 -> 12 us).  The batch itself is never reordered (lvf_batch_evaluate keeps its order).
+  lvf::DevBuf<double2> tfs_fo, tfs_ob;
+  lvf::DevBuf<int> tfs_lm, tfs_k1, tfs_k2, tfs_perm;
+  lvf::HostPin<int> h_tfs_perm;     // pinned staging of the permutation (the upload is asynchronous)
+  bool tf_sorted_copy = false;
+  const double2* tf_fo() const { return tf_sorted_copy ? tfs_fo.p : (const double2*)tf->ob_a.p; }
+  const double2* tf_ob() const { return tf_sorted_copy ? tfs_ob.p : (const double2*)tf->ob_b.p; }
+  const int* tf_lm() const { return tf_sorted_copy ? tfs_lm.p : tf->idx_a.p; }
+  const int* tf_k1() const { return tf_sorted_copy ? tfs_k1.p : tf->idx_b.p; }
+  const int* tf_k2() const { return tf_sorted_copy ? tfs_k2.p : tf->idx_c.p; }
   bool tf_unique_lk2 = false;   // no (landmark, current keyframe) pair occurs twice in the TwoFrame batch
   bool tf_k1_first = false;     // every TwoFrame block's first keyframe precedes its current keyframe
   double last_radius = 0;
@@ -280,9 +295,10 @@ struct TfWork { int first, count, k2; };
 //     contiguous range, sums them and completes the row (k1 columns, g_rho column) and Cd;
 //   * every workgroup writes its LDS table of keyframe-indexed sums to its own slab (slabP[wg][k1][64], slabQ[wg][32]); k_tf_reduce adds
 //     the slabs of a run into B / gc, each entry of B having exactly one owner there.
-struct TfCompact { int on; const int* slot; double *slotB, *slabP, *slabQ; };
+struct TfCompact { int on; const int* slot; double *slotB, *slabP, *slabQ; int staged; };
 constexpr int kSlabRow = 64, kSlabQ = 32;
-constexpr int kAccSlots = 63;   // 21 (B[k1,k1] lower) + 6 (g[k1]) + 36 (cross block, rows = k2 tangent, cols = k1 tangent)
+constexpr int kAccSlots = 63;
+constexpr int kStageWave = 64 * 9 + 32;   // doubles of LDS staging per wave (segmented first-keyframe sums): 64 x (8 + 1 pad) values + 64 ints   // 21 (B[k1,k1] lower) + 6 (g[k1]) + 36 (cross block, rows = k2 tangent, cols = k1 tangent)
 // DYN: the LDS tables are carved from the launch's dynamic LDS, sized by the window's n_kf (k_lin_visual: 32 KB at 50 keyframes instead of
 // 79 KB of static arrays sized for 64 — three workgroups per CU instead of two)
 template <bool DYN = false>
@@ -292,7 +308,7 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
                                                       const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
                                                       double* __restrict__ gc, double* __restrict__ E, int ldE,
                                                       double* __restrict__ C, double* __restrict__ gr, double* __restrict__ cost, int unique_lk2,
-                                                      unsigned long long* dbg = nullptr, const TfCompact cp = TfCompact{0, nullptr, nullptr, nullptr, nullptr}) {
+                                                      unsigned long long* dbg = nullptr, const TfCompact cp = TfCompact{0, nullptr, nullptr, nullptr, nullptr, 1}, const int dbg_nw = 0) {
   __shared__ PoseD s_pose_st[DYN ? 1 : kMaxStagedKf];
   __shared__ double s_acc_st[DYN ? 1 : kMaxStagedKf * kAccSlots];
   __shared__ double s_k2_st[DYN ? 1 : 27];
@@ -300,8 +316,14 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
   PoseD* s_pose = DYN ? reinterpret_cast<PoseD*>(lin_lds) : s_pose_st;
   double* s_acc = DYN ? lin_lds + (sizeof(PoseD) / 8) * n_kf : s_acc_st;
   double* s_k2 = DYN ? s_acc + kAccSlots * n_kf : s_k2_st;
+  // per-wave staging of the segmented first-keyframe sums (DYN only): [64 lanes][8 slots + 1 pad] doubles + the lanes' first keyframes
+  double* s_stage = DYN ? s_k2 + 32 + (threadIdx.x >> 6) * kStageWave : nullptr;
+  int* s_stage_k1 = reinterpret_cast<int*>(s_stage + 64 * 9);
   const TfWork w = work[vb];
   auto mark = [&](int k) { if (dbg && threadIdx.x == 0) dbg[(size_t)vb * 8 + k] = wall_clock64(); };   // LVF_LIN_TIMING=1: phase stamps (100 MHz)
+  // ... and per wave (lane 0 of each): [0] before the evaluation, [1] after it, [2] after the first-keyframe sums, [3] = number of first-keyframe groups
+  unsigned long long* dbgw = dbg ? dbg + (size_t)dbg_nw * 8 + 8 + (size_t)vb * 16 + (threadIdx.x >> 6) * 4 : nullptr;
+  auto markw = [&](int k) { if (dbgw && (threadIdx.x & 63) == 0) dbgw[k] = wall_clock64(); };
   mark(0);
   for (int e = threadIdx.x; e < n_kf * kAccSlots; e += kT) s_acc[e] = 0.0;
   if (threadIdx.x < 27) s_k2[threadIdx.x] = 0.0;
@@ -313,6 +335,7 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
 #pragma unroll
   for (int q = 0; q < 27; ++q) v[q] = 0.0;
   const bool active = (int)threadIdx.x < w.count;
+  markw(0);
   int k1 = 0;
   double L1[12], L2[12], r0 = 0.0, r1 = 0.0;
 #pragma unroll
@@ -355,7 +378,7 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
       }
     }
   }
-  mark(2);
+  mark(2); markw(1);
   // k1-indexed sums (B[k1,k1], g[k1], cross block).  A live front-end hands out landmark ids in creation order, so the blocks of a
   // wave usually share their first keyframe (per-lane ds_add_f64 on ONE address serialises 64-fold: +10 us on this kernel with ids in
   // birth order).
@@ -384,6 +407,7 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
     for (unsigned long long rem = remaining; rem && n_groups < 5; ++n_groups)
       rem &= ~__ballot(active && k1 == __builtin_amdgcn_readlane(k1, (int)__ffsll((long long)rem) - 1));
     const int min_group = n_groups <= 4 ? 1 : 16;
+    if (dbgw && lane == 0) dbgw[3] = (unsigned long long)n_groups;
 #pragma unroll 1
     for (int round = 0; round < 4 && remaining; ++round) {
       const int k1u = __builtin_amdgcn_readlane(k1, (int)__ffsll((long long)remaining) - 1);
@@ -421,7 +445,65 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
       mine_done = mine_done || sel;
       remaining &= ~m;
     }
-    if (!mine_done) {
+    if (DYN && n_groups > 4 && cp.staged) {
+      // Many first keyframes in one wave (the old tail of a late keyframe's run: dozens of groups of one to three blocks; or landmark ids
+      // in no order).  LDS f64 atomics retire at ~2 lane-operations per clock per CU (measured: 63 per lane cost a wave 8-10 us with
+      // three workgroups on the CU), so their NUMBER is what counts: the 63 products go through a wave-private LDS tile eight slots
+      // at a time, lane (slot s, part) walks 8 consecutive lanes' values and adds one partial sum per run of equal first keyframes —
+      // 63 x (segments + 7) atomics per wave instead of 63 x 64 (blocks sorted by first keyframe: a few hundred instead of 4 032).
+      if (mine_done && active) {}                        // (lanes the group rounds above have served contribute zeros below)
+      double z = (active && !mine_done) ? 1.0 : 0.0;
+      asm volatile("" : "+v"(z));
+      double M[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) M[i] = L1[i] * z;
+      s_stage_k1[lane] = (active && !mine_done) ? k1 : -1;
+      const int ss = lane & 7, part = lane >> 3;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // the first keyframes of this lane's 8 rows (and of the row behind them), once: everything the segment logic needs sits in registers
+      // before the first atomic (the compiler orders LDS reads behind LDS atomics it cannot tell apart from them)
+      int kk[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) kk[j] = (8 * part + j < 64) ? s_stage_k1[8 * part + j] : -2;
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        double t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = 0.0;
+        int q = 0;
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+          for (int y = 0; y <= x; ++y) { if ((q >> 3) == ch) t[q & 7] = M[x] * L1[y] + M[6 + x] * L1[6 + y]; ++q; }
+#pragma unroll
+        for (int x = 0; x < 6; ++x) { if ((q >> 3) == ch) t[q & 7] = M[x] * r0 + M[6 + x] * r1; ++q; }
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+          for (int y = 0; y < 6; ++y) { if ((q >> 3) == ch) t[q & 7] = L2[x] * M[y] + L2[6 + x] * M[6 + y]; ++q; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_stage[lane * 9 + i] = t[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int slot = 8 * ch + ss;
+        double val[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) val[j] = s_stage[(8 * part + j) * 9 + ss];
+        double run = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          run += val[j];
+          if (j == 7 || kk[j + 1] != kk[j]) {
+            if (kk[j] >= 0 && slot < kAccSlots && run != 0.0) atomicAdd(&s_acc[kk[j] * kAccSlots + slot], run);
+            run = 0.0;
+          }
+        }
+      }
+    } else if (!mine_done) {
       double* acc = s_acc + k1 * kAccSlots;
       int q = 0;
 #pragma unroll
@@ -436,7 +518,7 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
         for (int y = 0; y < 6; ++y) atomicAdd(&acc[27 + 6 * x + y], L2[x] * L1[y] + L2[6 + x] * L1[6 + y]);
     }
   }
-  mark(3);
+  mark(3); markw(2);
   {
     // the 27 sums of the wave in one transposed reduction: lane l ends up with the total of value l >> 1, the even lanes add them
     double v32[32];
@@ -914,7 +996,7 @@ __device__ __forceinline__ void lin_visual_body(const int bx, const LinArgs& A) 
     lin_imu_eval_body(bx, a.imu, n_kf, s, pose_const, B, ld, gc, cost, A.dbg ? A.dbg + (size_t)a.n_tfw * 8 : nullptr);
   else if (b < a.n_tfw)
     lin_tf_sorted_body<true>(b, a.work, n_kf, a.tf_fo, a.tf_ob, a.tf_lm, a.tf_k1, s, a.tf_left, a.tf_right, huber, pose_const, B, ld, gc, E, ldE, C, gr, cost,
-                       a.unique_lk2, A.dbg, a.cp);
+                       a.unique_lk2, A.dbg, a.cp, a.n_tfw);
   else if (b < a.n_tfw + a.g_tc)
     lin_tc_body<false>(b - a.n_tfw, a.n_tc, a.tc_lo, a.tc_ro, a.tc_lm, a.tc_kf, a.tc_w, s, a.tc_left, a.tc_right, huber, C, gr, cost);
   else if (b < a.n_tfw + a.g_tc + a.g_po)
@@ -1379,6 +1461,15 @@ __global__ __launch_bounds__(kT) void k_tf_slots(int n, const int* __restrict__ 
   slot[i] = eoff[l] + (k2[i] - kmin[l] - 1);
 }
 // slots of keyframes that do not observe their landmark (gaps in a track) are never written by the linearisation: cleared once here
+// sorted copies of the TwoFrame block arrays: block i of the copy = block perm[i] of the batch
+__global__ __launch_bounds__(kT) void k_tf_gather(int n, const int* __restrict__ perm, const double2* __restrict__ fo, const double2* __restrict__ ob,
+                                                   const int* __restrict__ lm, const int* __restrict__ k1, const int* __restrict__ k2,
+                                                   double2* __restrict__ fo_s, double2* __restrict__ ob_s, int* __restrict__ lm_s, int* __restrict__ k1_s, int* __restrict__ k2_s) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const int j = perm[i];
+  fo_s[i] = fo[j]; ob_s[i] = ob[j]; lm_s[i] = lm[j]; k1_s[i] = k1[j]; k2_s[i] = k2[j];
+}
 __global__ __launch_bounds__(kT) void k_zero_slots(const int* __restrict__ n_slots, double* __restrict__ slotB) {
   const size_t n = (size_t)*n_slots * 4;     // double2 elements
   double2* b = reinterpret_cast<double2*>(slotB);
@@ -1865,7 +1956,7 @@ __global__ __launch_bounds__(kCT) void k_chol_step_b(const CholArgs* __restrict_
 __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __restrict__ nodes, int first, int tiles, const int* __restrict__ rows,
                                                   double* __restrict__ S, int ld, double* __restrict__ W, int wstride,
                                                   double* __restrict__ Lout, int* __restrict__ fail, const int* done = nullptr,
-                                                  const SpSrc src = SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr}) {
+                                                  const SpSrc src = SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0}) {
   extern __shared__ double sp_sm[];        // Ws[m][9] | L[81] | linv[9] | rws[m] (int) | rnat[m] (int, early form)
   const int dv = done_flag_issue(done);
   const int ni = first + vb / tiles, tile = vb % tiles, tid = threadIdx.x;
@@ -1873,8 +1964,12 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
   const double radius = src.B ? *src.radius : 1.0;
   if (dv) return;
   const bool chained = src.wait_counter != nullptr;
-  auto ld_s = [&](const double* ptr) -> double {      // an entry of S the level below may have added into during THIS launch
-    return chained ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
+  // an entry of S the level below may have added into during THIS launch: read where the adds were performed, by a returning atomic
+  // (adding zero).  An agent-scope atomic LOAD is served by this XCD's L2, which may still hold the line as an earlier level's plain loads
+  // brought it in (a line spans two blocks' columns) — measured: 5 of 12 runs of the 8-keyframe / 20 000-landmark case came out wrong.
+  auto ld_s = [&](double* ptr) -> double {
+    if (!chained) return *ptr;
+    return src.rmw_read ? __hip_atomic_fetch_add(ptr, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   const int m = nd.m, col = nd.col;
   double* Ws = sp_sm;
@@ -1920,8 +2015,8 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     // bounded: if the level below never arrives (a dispatch order this code does not expect) the step is flagged as failed instead of hanging
     if (tid == 0) {
       const unsigned long long t0 = wall_clock64();
-      while (__hip_atomic_load(src.wait_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < src.wait_target) {
-        __builtin_amdgcn_s_sleep(2);
+      while (__hip_atomic_fetch_add(src.wait_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < src.wait_target) {
+        __builtin_amdgcn_s_sleep(4);
         if (wall_clock64() - t0 > 200000ull) { atomicExch(fail, 300000 + nd.id); break; }      // 2 ms at 100 MHz
       }
     }
@@ -1936,7 +2031,7 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     for (int c = 0; c < 9; ++c) a[c] = (c <= tid ? ld_s(&S[(size_t)(col + tid) * ld + col + c]) : 0.0) + bd[c];
   }
   if (has0) {
-    const double* srow = S + (size_t)rw0 * ld + col;
+    double* srow = S + (size_t)rw0 * ld + col;
 #pragma unroll
     for (int c = 0; c < 9; ++c) sv0[c] += ld_s(srow + c);
   }
@@ -1993,7 +2088,7 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
   };
   if (has0) finish_row(r0, sv0);
   for (int r = r0 + 256; r < m; r += 256) {
-    const double* srow = S + (size_t)rws[r] * ld + col;
+    double* srow = S + (size_t)rws[r] * ld + col;
     double sv[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) sv[c] = ld_s(srow + c);
@@ -2022,22 +2117,52 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     for (int r = 0; r < 9; ++r) Lout[(size_t)ni * 81 + r * 9 + tid] = xcol[r];
   }
   __syncthreads();
-  const int P = m * (m + 1) / 2;
-  for (int p = tile * 256 + tid; p < P; p += tiles * 256) {
-    int r = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
-    while ((r + 1) * (r + 2) / 2 <= p) ++r;
-    while (r * (r + 1) / 2 > p) --r;
-    const int c2 = p - r * (r + 1) / 2;
+  // S_NN -= W W^T.  The pairs whose COLUMN belongs to a sparse block (rows [0, ns): later (v, ba, bg) blocks come first in the ascending
+  // row list) are what the next level reads; they go first, and a chained level signals its successor as soon as THEY are acknowledged —
+  // the bulk (the dense corner's entries, four fifths at the top level) and its acknowledgement stay off the chain.
+  int ns = 0;
+  if (src.done_counter && src.strip_end > 0) {                  // (binary search: rws is ascending)
+    int lo = 0, hi = m;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rws[mid] < src.strip_end) lo = mid + 1; else hi = mid; }
+    ns = lo;
+  }
+  auto pair_value = [&](const int r, const int c2) {
     const double* wr = Ws + r * 9;
     const double* wc = Ws + c2 * 9;
     double v = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) v += wr[c] * wc[c];
+    return v;
+  };
+  auto pair_update = [&](const int r, const int c2) {
+    const double v = pair_value(r, c2);
     if (v != 0.0) atomicAdd(&S[(size_t)rws[r] * ld + rws[c2]], -v);
+  };
+  if (ns > 0) {
+    // RETURNING atomics: the value only comes back once the add has been performed where the next level will read it, so the barrier
+    // below (which waits for the returns) really orders them ahead of the arrival.  With returnless adds the acknowledgement that
+    // releases vmcnt came first often enough: 5 of 12 runs of the 8-keyframe / 20 000-landmark case had the next level read entries short of an update.
+    double sink = 0.0;
+    for (int q = tile * 256 + tid; q < ns * m; q += tiles * 256) {      // the m x ns rectangle, its r < c2 corner skipped
+      const int r = q / ns, c2 = q - r * ns;
+      if (r >= c2) {
+        const double v = pair_value(r, c2);
+        if (v != 0.0) sink += __hip_atomic_fetch_add(&S[(size_t)rws[r] * ld + rws[c2]], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (sink == -1.2345678901234567e301) atomicExch(fail, 400000);     // (never: keeps the returns alive)
   }
   if (src.done_counter) {
-    __syncthreads();                       // every wave's atomics have been acknowledged (the barrier drains vmcnt)
+    __syncthreads();                       // every wave has its returns (the barrier drains vmcnt)
     if (tid == 0) __hip_atomic_fetch_add(src.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int m2 = m - ns, P = m2 * (m2 + 1) / 2;                          // the triangle over rows / columns [ns, m)
+  for (int p = tile * 256 + tid; p < P; p += tiles * 256) {
+    int r = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= p) ++r;
+    while (r * (r + 1) / 2 > p) --r;
+    const int c2 = p - r * (r + 1) / 2;
+    pair_update(r + ns, c2 + ns);
   }
 }
 // Work list of the band Schur complement: one item per (slice, tile group) that has tiles to form.  The 2-D grid slices x groups is sized
@@ -2671,8 +2796,8 @@ static void fill_cost_visual(const lvf_problem* p, CostVisual& a) {
     a.tc_w = p->tc->wblk.n ? p->tc->wblk.p : nullptr; a.tc_left = p->tc->cam_a; a.tc_right = p->tc->cam_b;
   }
   if (p->tf && p->tf->n) {
-    a.n_tf = p->tf->n; a.tf_fo = (const double2*)p->tf->ob_a.p; a.tf_ob = (const double2*)p->tf->ob_b.p; a.tf_lm = p->tf->idx_a.p; a.tf_k1 = p->tf->idx_b.p;
-    a.tf_k2 = p->tf->idx_c.p; a.tf_left = p->tf->cam_a; a.tf_right = p->tf->cam_b;
+    a.n_tf = p->tf->n; a.tf_fo = p->tf_fo(); a.tf_ob = p->tf_ob(); a.tf_lm = p->tf_lm(); a.tf_k1 = p->tf_k1();
+    a.tf_k2 = p->tf_k2(); a.tf_left = p->tf->cam_a; a.tf_right = p->tf->cam_b;
   }
   if (p->po && p->po->n) {
     a.n_po = p->po->n; a.po_ob = (const double2*)p->po->ob_a.p; a.po_kf = p->po->idx_a.p; a.po_pwi = p->po->idx_b.p; a.po_pw = p->po->table.p; a.po_cam = p->po->cam_a;
@@ -2807,8 +2932,8 @@ static int build_chain(lvf_problem* p) {
   if (c.fast) {
     LinVisual& a = c.lin.v;
     a = LinVisual{};
-    a.n_tfw = (int)p->tf_work.n; a.work = p->tf_work.p; a.tf_fo = (const double2*)p->tf->ob_a.p; a.tf_ob = (const double2*)p->tf->ob_b.p;
-    a.tf_lm = p->tf->idx_a.p; a.tf_k1 = p->tf->idx_b.p; a.tf_left = p->tf->cam_a; a.tf_right = p->tf->cam_b; a.unique_lk2 = p->tf_unique_lk2 ? 1 : 0;
+    a.n_tfw = (int)p->tf_work.n; a.work = p->tf_work.p; a.tf_fo = p->tf_fo(); a.tf_ob = p->tf_ob();
+    a.tf_lm = p->tf_lm(); a.tf_k1 = p->tf_k1(); a.tf_left = p->tf->cam_a; a.tf_right = p->tf->cam_b; a.unique_lk2 = p->tf_unique_lk2 ? 1 : 0;
     if (p->tc && p->tc->n) {
       a.n_tc = p->tc->n; a.tc_lo = (const double2*)p->tc->ob_a.p; a.tc_ro = (const double2*)p->tc->ob_b.p; a.tc_lm = p->tc->idx_a.p; a.tc_kf = p->tc->idx_b.p;
       a.tc_w = p->tc->wblk.n ? p->tc->wblk.p : nullptr; a.tc_left = p->tc->cam_a; a.tc_right = p->tc->cam_b;
@@ -2822,9 +2947,10 @@ static int build_chain(lvf_problem* p) {
       for (int k = 0; k < 8; ++k) a.imu_J.j[k] = p->imu->jac[k].p;
       a.imu = ImuEvalArgs{p->imu->n, p->imu->pre.p, p->imu->sqrt_info.p, p->imu->idx_a.p, p->imu->idx_b.p};
     }
-    a.cp = TfCompact{0, nullptr, nullptr, nullptr, nullptr};
+    static const int staged_on = [] { const char* e = std::getenv("LVF_STAGED"); return (e && e[0] == '0') ? 0 : 1; }();
+    a.cp = TfCompact{0, nullptr, nullptr, nullptr, nullptr, staged_on};
     if (p->compact) {
-      a.cp = TfCompact{1, p->tf_slot.p, p->slotB.p, p->slabP.p, p->slabQ.p};
+      a.cp = TfCompact{1, p->tf_slot.p, p->slotB.p, p->slabP.p, p->slabQ.p, staged_on};
       TfReduceArgs& r = c.red;
       r.n_kf = p->n_kf; r.n_wg = a.n_tfw; r.run_first = p->run_first.p; r.slabP = p->slabP.p; r.slabQ = p->slabQ.p; r.B = p->B.p; r.ld = p->dpad; r.gc = p->gc.p;
       r.nblocks = p->n_kf * ((a.n_tfw + 63) / 64) + grid(p->n_kf * (p->n_kf - 1) / 2 * 36); r.done = done;
@@ -2834,7 +2960,7 @@ static int build_chain(lvf_problem* p) {
     c.lin.ldE = p->ldE; c.lin.C = p->C.p; c.lin.gr = p->gr.p; c.lin.cost = cost; c.lin.done = done; c.lin.dbg = nullptr;
     c.lin.scal_reset = c.early ? p->scal.p : nullptr;
     c.lin.nblocks = a.n_tfw + a.g_tc + a.g_po + (a.imu.pre ? a.n_imu : (a.n_imu + 3) / 4);
-    c.lin_lds = std::max((size_t)(sizeof(PoseD) / 8 + kAccSlots) * p->n_kf + 32, (size_t)std::max(kImuWaveLds, 1864 + 64)) * sizeof(double);
+    c.lin_lds = std::max((size_t)(sizeof(PoseD) / 8 + kAccSlots) * p->n_kf + 32 + 4 * (size_t)kStageWave, (size_t)std::max(kImuWaveLds, 1864 + 64)) * sizeof(double);
   }
   // damped system
   {
@@ -2858,7 +2984,7 @@ static int build_chain(lvf_problem* p) {
     SpArgs& a = c.sp[lv];
     a.nodes = p->sp_nodes.p; a.first = p->sp_levels.first[lv]; a.tiles = p->sp_tiles[lv]; a.rows = p->sp_rows.p; a.S = p->S.p; a.ld = p->ld; a.W = p->sp_W.p;
     a.wstride = p->sp_wstride; a.Lout = p->sp_L.p; a.fail = fail; a.nblocks = p->sp_levels.count[lv] * p->sp_tiles[lv]; a.done = done;
-    a.src = c.early ? SpSrc{p->B.p, p->dpad, p->dp, p->gc.p, radius, p->sp_rows_nat.p, nullptr, 0, nullptr} : SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    a.src = c.early ? SpSrc{p->B.p, p->dpad, p->dp, p->gc.p, radius, p->sp_rows_nat.p, nullptr, 0, nullptr, p->off, std::getenv("LVF_CHAIN_RMW_READ") ? 1 : 0} : SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, p->off, 0};
     c.sp_lds[lv] = p->sp_shmem[lv];
   }
   c.merged_level0 = false;
@@ -3010,8 +3136,9 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated, bool iter
     if (!gated) la.done = nullptr;
     if (!iteration) la.scal_reset = nullptr;
     static const bool lin_timing = std::getenv("LVF_LIN_TIMING") != nullptr;
-    if (lin_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)la.v.n_tfw * 8 + 8)); la.dbg = p->dbg_lin.p; }
-    hipLaunchKernelGGL(k_lin_visual, dim3(la.nblocks), dim3(kT), c.lin_lds, q, la);
+    if (lin_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)la.v.n_tfw * 24 + 8)); la.dbg = p->dbg_lin.p; }
+    static const size_t lds_pad = [] { const char* e = std::getenv("LVF_LIN_LDS_PAD"); return e ? (size_t)std::atoi(e) : (size_t)0; }();      // experiment: fewer workgroups per CU
+    hipLaunchKernelGGL(k_lin_visual, dim3(la.nblocks), dim3(kT), c.lin_lds + lds_pad, q, la);
     stage_mark(p, ST_LIN_VISUAL, 1);
     if (p->compact) {
       TfReduceArgs ra = c.red;
@@ -3024,11 +3151,41 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated, bool iter
       std::vector<unsigned long long> t((size_t)la.v.n_tfw * 8);
       LVF_HIP(hipStreamSynchronize(q));
       LVF_HIP(hipMemcpy(t.data(), p->dbg_lin.p, t.size() * 8, hipMemcpyDeviceToHost));
-      double ph[5] = {0, 0, 0, 0, 0}; unsigned long long first = ~0ull, last = 0;
+      double ph[5] = {0, 0, 0, 0, 0}; unsigned long long first = ~0ull, last = 0, last_start = 0;
       for (int w = 0; w < la.v.n_tfw; ++w) {
         for (int k = 0; k < 5; ++k) ph[k] += (double)(t[(size_t)w * 8 + k + 1] - t[(size_t)w * 8 + k]) * 0.01;
-        first = std::min(first, t[(size_t)w * 8]); last = std::max(last, t[(size_t)w * 8 + 5]);
+        first = std::min(first, t[(size_t)w * 8]); last = std::max(last, t[(size_t)w * 8 + 5]); last_start = std::max(last_start, t[(size_t)w * 8]);
       }
+      {
+        double mx[5] = {0, 0, 0, 0, 0}; int slow = 0; double slow_t = 0;
+        for (int w = 0; w < la.v.n_tfw; ++w) {
+          for (int k = 0; k < 5; ++k) mx[k] = std::max(mx[k], (double)(t[(size_t)w * 8 + k + 1] - t[(size_t)w * 8 + k]) * 0.01);
+          const double tot = (double)(t[(size_t)w * 8 + 5] - t[(size_t)w * 8]) * 0.01;
+          if (tot > slow_t) { slow_t = tot; slow = w; }
+        }
+        std::vector<TfWork> hw((size_t)la.v.n_tfw);
+        LVF_HIP(hipMemcpy(hw.data(), la.v.work, hw.size() * sizeof(TfWork), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "lin_tf: per-phase MAX over the workgroups (us): %.2f | %.2f | %.2f | %.2f | %.2f ; slowest workgroup %d (k2 = %d, %d blocks): %.2f us =", mx[0], mx[1], mx[2], mx[3], mx[4], slow, hw[slow].k2, hw[slow].count, slow_t);
+        for (int k = 0; k < 5; ++k) std::fprintf(stderr, " %.2f", (double)(t[(size_t)slow * 8 + k + 1] - t[(size_t)slow * 8 + k]) * 0.01);
+        // histogram of workgroup durations by current keyframe decile
+        {
+          unsigned long long u[16];
+          LVF_HIP(hipMemcpy(u, p->dbg_lin.p + (size_t)la.v.n_tfw * 8 + 8 + (size_t)slow * 16, sizeof(u), hipMemcpyDeviceToHost));
+          std::fprintf(stderr, " ; its waves (eval us, k1-sum us, groups):");
+          for (int wv = 0; wv < 4; ++wv) std::fprintf(stderr, " [%.2f %.2f %llu]", (double)(u[4 * wv + 1] - u[4 * wv]) * 0.01, (double)(u[4 * wv + 2] - u[4 * wv + 1]) * 0.01, u[4 * wv + 3]);
+        }
+        std::fprintf(stderr, " ; mean duration by k2 decile:");
+        const int nk = la.n_kf;
+        for (int dcl = 0; dcl < 5; ++dcl) {
+          double sum = 0; int cnt = 0;
+          for (int w = 0; w < la.v.n_tfw; ++w) if (hw[w].k2 * 5 / std::max(nk, 1) == dcl) { sum += (double)(t[(size_t)w * 8 + 5] - t[(size_t)w * 8]) * 0.01; ++cnt; }
+          std::fprintf(stderr, " %.1f(%d)", cnt ? sum / cnt : 0.0, cnt);
+        }
+        std::fprintf(stderr, "\n");
+      }
+      std::fprintf(stderr, "lin_tf: the TwoFrame workgroups START within %.2f us of each other; starts of workgroups 0, 1/4, 1/2, 3/4, last (us after the first): %.2f %.2f %.2f %.2f %.2f\n", (double)(last_start - first) * 0.01,
+                   (double)(t[0] - first) * 0.01, (double)(t[(size_t)(la.v.n_tfw / 4) * 8] - first) * 0.01, (double)(t[(size_t)(la.v.n_tfw / 2) * 8] - first) * 0.01,
+                   (double)(t[(size_t)(3 * la.v.n_tfw / 4) * 8] - first) * 0.01, (double)(t[(size_t)(la.v.n_tfw - 1) * 8] - first) * 0.01);
       std::fprintf(stderr, "lin_tf phases (us, mean over %d workgroups): stage %.2f | eval+landmark atomics %.2f | k1 sums %.2f | k2 sums %.2f | flush %.2f ; first start -> last end %.2f\n",
                    la.v.n_tfw, ph[0] / la.v.n_tfw, ph[1] / la.v.n_tfw, ph[2] / la.v.n_tfw, ph[3] / la.v.n_tfw, ph[4] / la.v.n_tfw, (double)(last - first) * 0.01);
       if (la.v.imu.pre) {
@@ -3439,7 +3596,7 @@ int problem_configure(lvf_problem* p) {
   p->pose_const_h.assign(p->n_kf, 0);
   cfg_mark("buffers");
   p->tf_work.n = 0;
-  p->tf_unique_lk2 = false; p->tf_k1_first = false; p->compact = false;
+  p->tf_unique_lk2 = false; p->tf_k1_first = false; p->compact = false; p->tf_sorted_copy = false;
   lvf_batch* two_frame = p->tf;
   if (two_frame && two_frame->n && two_frame->sorted_by_kf && !two_frame->kf2_counts.empty() && two_frame->unique_lk2_known) {
     // the creator (the persistent window) vouches for the shape: sorted by current keyframe, k1 < k2, one block per (landmark, keyframe)
@@ -3473,6 +3630,34 @@ int problem_configure(lvf_problem* p) {
         i = j;
       }
       LVF_TRY(p->tf_work.assign(p->h_tf_work.p, nw, ctx->stream));
+      // first keyframes out of order inside the runs (more than one block in eight steps DOWN): sorted copies for the linearisation.
+      // BuildProblem's own order (landmark ids in creation order) passes untouched.
+      static const bool k1sort_on = [] { const char* e = std::getenv("LVF_TF_K1SORT"); return !(e && e[0] == '0'); }();
+      if (k1sort_on && p->n_kf <= 256) {
+        int descents = 0;
+        for (int i = 1; i < two_frame->n; ++i) descents += (k2[i] == k2[i - 1] && k1[i] < k1[i - 1]) ? 1 : 0;
+        if ((size_t)descents * 8 > (size_t)two_frame->n) {
+          const int n = two_frame->n;
+          LVF_TRY(p->h_tfs_perm.reserve((size_t)n));
+          int* perm = p->h_tfs_perm.p;
+          std::vector<int32_t> cnt((size_t)p->n_kf + 1);
+          for (int i = 0; i < n;) {                      // counting sort of each current-keyframe run by first keyframe (stable)
+            int j = i;
+            while (j < n && k2[j] == k2[i]) ++j;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int t = i; t < j; ++t) ++cnt[(size_t)std::min(std::max(k1[t], 0), p->n_kf - 1) + 1];
+            for (int k = 0; k < p->n_kf; ++k) cnt[k + 1] += cnt[k];
+            for (int t = i; t < j; ++t) perm[(size_t)i + cnt[(size_t)std::min(std::max(k1[t], 0), p->n_kf - 1)]++] = t;
+            i = j;
+          }
+          LVF_TRY(p->tfs_perm.assign(perm, (size_t)n, ctx->stream));
+          LVF_TRY(p->tfs_fo.ensure(n)); LVF_TRY(p->tfs_ob.ensure(n)); LVF_TRY(p->tfs_lm.ensure(n)); LVF_TRY(p->tfs_k1.ensure(n)); LVF_TRY(p->tfs_k2.ensure(n));
+          hipLaunchKernelGGL(k_tf_gather, dim3(grid(n)), dim3(kT), 0, ctx->stream, n, p->tfs_perm.p, (const double2*)two_frame->ob_a.p, (const double2*)two_frame->ob_b.p,
+                             two_frame->idx_a.p, two_frame->idx_b.p, two_frame->idx_c.p, p->tfs_fo.p, p->tfs_ob.p, p->tfs_lm.p, p->tfs_k1.p, p->tfs_k2.p);
+          LVF_HIP(hipGetLastError());
+          p->tf_sorted_copy = true;
+        }
+      }
       // blocks are sorted by k2: a duplicate (landmark, k2) pair shows up as a repeated landmark inside one k2 run
       const std::vector<int32_t>& lmh = two_frame->host_lm;
       bool uniq = two_frame->unique_lk2_known || lmh.size() == (size_t)two_frame->n;
@@ -3527,7 +3712,7 @@ int problem_configure(lvf_problem* p) {
       LVF_TRY(p->Ct.ensure(p->n_lm)); LVF_TRY(p->grt.ensure(p->n_lm));
       LVF_TRY(p->slabP.ensure((size_t)n_wg * p->n_kf * kSlabRow)); LVF_TRY(p->slabQ.ensure((size_t)n_wg * kSlabQ));
       hipLaunchKernelGGL(k_lm_offsets, dim3(1), dim3(1024), 0, q, p->n_lm, p->lm_kmin.p, p->lm_kmax.p, p->lm_eoff.p, p->n_slots.p);
-      hipLaunchKernelGGL(k_tf_slots, dim3(grid(two_frame->n)), dim3(kT), 0, q, two_frame->n, two_frame->idx_a.p, two_frame->idx_c.p, p->lm_kmin.p, p->lm_eoff.p, p->tf_slot.p);
+      hipLaunchKernelGGL(k_tf_slots, dim3(grid(two_frame->n)), dim3(kT), 0, q, two_frame->n, p->tf_lm(), p->tf_k2(), p->lm_kmin.p, p->lm_eoff.p, p->tf_slot.p);
       hipLaunchKernelGGL(k_zero_slots, dim3(256), dim3(kT), 0, q, p->n_slots.p, p->slotB.p);
       LVF_HIP(hipGetLastError());
       // run_first[k] = first workgroup of current keyframe k's run (the work list is sorted by k2); run_first[n_kf] = n_wg
