@@ -41,6 +41,8 @@ struct SpSrc {
   int* wait_counter; int wait_target; int* done_counter;
   int strip_end;           // S rows / columns below it belong to sparse blocks (lvf_problem::off)
   int rmw_read;            // diagnostic: chained reads by returning atomics instead of agent-scope loads
+  unsigned long long* dbg; // LVF_SP_TIMING=1: eight wall_clock64() stamps per workgroup (tile 0 of every node), else null
+  int s_zero;              // the level has nothing below it (level 0, early form): its part of S is still all zeros, not read
 };
 struct SpArgs {          // one sparse level
   const SpNode* nodes; int first, tiles; const int* rows; double* S; int ld; double* W; int wstride; double* Lout; int* fail; int nblocks; const int* done;
@@ -74,7 +76,7 @@ struct lvf_problem {
   lvf::DevBuf<int4> band_work; lvf::DevBuf<int> n_band_work_dev; lvf::HostPin<int> h_n_band_work;
   int n_band_work = 0, band_rows_built = 0;
   lvf::HostPin<int> h_run_first;
-  lvf::DevBuf<unsigned long long> dbg, dbg_lin;
+  lvf::DevBuf<unsigned long long> dbg, dbg_lin, dbg_sp;
   lvf::DevBuf<double> sp_sync;                  // arrival counters of sparse levels chained inside one launch (one 8-byte slot per level, an int in each; cleared with the accumulators)
   lvf::DevBuf<double> sp_W, sp_L, Dinv;         // Dinv: L_kk^-T of every 64x64 diagonal block of the dense corner
   std::vector<int> perm_h;
@@ -297,8 +299,8 @@ struct TfWork { int first, count, k2; };
 //     the slabs of a run into B / gc, each entry of B having exactly one owner there.
 struct TfCompact { int on; const int* slot; double *slotB, *slabP, *slabQ; int staged; };
 constexpr int kSlabRow = 64, kSlabQ = 32;
-constexpr int kAccSlots = 63;
-constexpr int kStageWave = 64 * 9 + 32;   // doubles of LDS staging per wave (segmented first-keyframe sums): 64 x (8 + 1 pad) values + 64 ints   // 21 (B[k1,k1] lower) + 6 (g[k1]) + 36 (cross block, rows = k2 tangent, cols = k1 tangent)
+constexpr int kAccSlots = 63;   // 21 (B[k1,k1] lower) + 6 (g[k1]) + 36 (cross block, rows = k2 tangent, cols = k1 tangent)
+constexpr int kStageWave = 64 * 9 + 32;   // doubles of LDS staging per wave (segmented first-keyframe sums): 64 x (8 + 1 pad) values + 64 ints
 // DYN: the LDS tables are carved from the launch's dynamic LDS, sized by the window's n_kf (k_lin_visual: 32 KB at 50 keyframes instead of
 // 79 KB of static arrays sized for 64 — three workgroups per CU instead of two)
 template <bool DYN = false>
@@ -1956,10 +1958,12 @@ __global__ __launch_bounds__(kCT) void k_chol_step_b(const CholArgs* __restrict_
 __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __restrict__ nodes, int first, int tiles, const int* __restrict__ rows,
                                                   double* __restrict__ S, int ld, double* __restrict__ W, int wstride,
                                                   double* __restrict__ Lout, int* __restrict__ fail, const int* done = nullptr,
-                                                  const SpSrc src = SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0}) {
+                                                  const SpSrc src = SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0}) {
   extern __shared__ double sp_sm[];        // Ws[m][9] | L[81] | linv[9] | rws[m] (int) | rnat[m] (int, early form)
   const int dv = done_flag_issue(done);
   const int ni = first + vb / tiles, tile = vb % tiles, tid = threadIdx.x;
+  unsigned long long* stamp = (src.dbg && tile == 0 && tid == 0) ? src.dbg + (size_t)ni * 8 : nullptr;
+  if (stamp) stamp[0] = wall_clock64();
   const SpNode nd = nodes[ni];
   const double radius = src.B ? *src.radius : 1.0;
   if (dv) return;
@@ -1983,11 +1987,11 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
   // (wave 0 only takes rows when there are more than 192).  Each thread keeps its FIRST row in registers; further rows (m > 256) follow
   // the classic loop behind the barrier.
   const int r0 = (tid + 192) & 255;
-  const bool has0 = r0 < m;
   // ---- phase A: what does not depend on the level below
-  for (int r = tid; r < m; r += 256) { rws[r] = rows[nd.row_off + r]; if (src.B) rnat[r] = src.rows_nat[nd.row_off + r]; }
+  const bool has0 = r0 < m;
   int rw0 = 0, rn0 = -1;
   if (has0) { rw0 = rows[nd.row_off + r0]; if (src.B) rn0 = src.rows_nat[nd.row_off + r0]; }
+  for (int r = tid; r < m; r += 256) { rws[r] = rows[nd.row_off + r]; if (src.B) rnat[r] = src.rows_nat[nd.row_off + r]; }
   double bd[9], sv0[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) { bd[c] = 0.0; sv0[c] = 0.0; }
@@ -2011,6 +2015,7 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
       }
     }
   }
+  if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[1] = wall_clock64(); }      // (timing only: phase A's requests have landed)
   if (chained) {
     // bounded: if the level below never arrives (a dispatch order this code does not expect) the step is flagged as failed instead of hanging
     if (tid == 0) {
@@ -2022,19 +2027,21 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     }
     asm volatile("s_barrier" ::: "memory");           // (not __syncthreads(): the requests above stay in flight across it)
   }
+  if (stamp) stamp[2] = wall_clock64();
   // ---- phase B: what the level below added into S
   double a[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) a[c] = 0.0;
   if (tid < 9) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) a[c] = (c <= tid ? ld_s(&S[(size_t)(col + tid) * ld + col + c]) : 0.0) + bd[c];
+    for (int c = 0; c < 9; ++c) a[c] = ((c <= tid && !src.s_zero) ? ld_s(&S[(size_t)(col + tid) * ld + col + c]) : 0.0) + bd[c];
   }
-  if (has0) {
+  if (has0 && !src.s_zero) {
     double* srow = S + (size_t)rw0 * ld + col;
 #pragma unroll
     for (int c = 0; c < 9; ++c) sv0[c] += ld_s(srow + c);
   }
+  if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[3] = wall_clock64(); }      // (timing only: the S entries are here)
   if (tid < 64) {
     const int lane = tid;
     bool bad = false;
@@ -2069,6 +2076,7 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     }
     if (bad && lane == 0) atomicExch(fail, 100000 + nd.id);
   }
+  if (stamp) stamp[4] = wall_clock64();
   __syncthreads();
   auto finish_row = [&](const int r, const double sv[9]) {     // W_r = S_rb L_bb^-T
     double w[9];
@@ -2091,7 +2099,7 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     double* srow = S + (size_t)rws[r] * ld + col;
     double sv[9];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) sv[c] = ld_s(srow + c);
+    for (int c = 0; c < 9; ++c) sv[c] = src.s_zero ? 0.0 : ld_s(srow + c);
     if (src.B) {
       const int oi = rnat[r];
       if (oi == -2) {
@@ -2152,10 +2160,12 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     }
     if (sink == -1.2345678901234567e301) atomicExch(fail, 400000);     // (never: keeps the returns alive)
   }
+  if (stamp) stamp[5] = wall_clock64();
   if (src.done_counter) {
     __syncthreads();                       // every wave has its returns (the barrier drains vmcnt)
     if (tid == 0) __hip_atomic_fetch_add(src.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (stamp) stamp[6] = wall_clock64();
   const int m2 = m - ns, P = m2 * (m2 + 1) / 2;                          // the triangle over rows / columns [ns, m)
   for (int p = tile * 256 + tid; p < P; p += tiles * 256) {
     int r = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
@@ -2164,6 +2174,7 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     const int c2 = p - r * (r + 1) / 2;
     pair_update(r + ns, c2 + ns);
   }
+  if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[7] = wall_clock64(); }
 }
 // Work list of the band Schur complement: one item per (slice, tile group) that has tiles to form.  The 2-D grid slices x groups is sized
 // for the widest possible band, but most slices (short tracks) need one group: three quarters of its workgroups had nothing to do and
@@ -2297,9 +2308,21 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
     yv = (r0 + c < d) ? ld_off32(S + (size_t)d * ld + r0, c_off) : 0.0;
   };
   prefetch(nblk - 1);
-  if (sp.linv_in_lds) for (int i = tid; i < 81 * sp.n_nodes; i += kBT) linv[i] = sp.Linv[i];
-  for (int i = tid; i < sp.n_nodes; i += kBT) { const SpNode nd = sp.nodes[i]; snode[2 * i] = nd.row_off; snode[2 * i + 1] = nd.m; }
-  asm volatile("" ::: "memory");          // keep the long register requests below behind the short LDS copies above
+  // the stored L_bb^-1 and the node table go to LDS: ALL of a thread's requests are issued before the first LDS write (written as a
+  // copy loop the compiler waits for every load in turn — eight dependent round trips at 50 keyframes, 4 of this kernel's 30 us)
+  constexpr int kLinvPre = 8;
+  double lpre[kLinvPre];
+  const int n_linv = sp.linv_in_lds ? 81 * sp.n_nodes : 0;
+#pragma unroll
+  for (int u = 0; u < kLinvPre; ++u) { const int i = tid + kBT * u; lpre[u] = i < n_linv ? ld_off32(sp.Linv, 8u * (unsigned)i) : 0.0; }
+  SpNode ndpre = SpNode{0, 0, 0, 0};
+  if (tid < sp.n_nodes) ndpre = sp.nodes[tid];
+#pragma unroll
+  for (int u = 0; u < kLinvPre; ++u) { const int i = tid + kBT * u; if (i < n_linv) linv[i] = lpre[u]; }
+  for (int i = tid + kBT * kLinvPre; i < n_linv; i += kBT) linv[i] = sp.Linv[i];
+  if (tid < sp.n_nodes) { snode[2 * tid] = ndpre.row_off; snode[2 * tid + 1] = ndpre.m; }
+  for (int i = tid + kBT; i < sp.n_nodes; i += kBT) { const SpNode nd = sp.nodes[i]; snode[2 * i] = nd.row_off; snode[2 * i + 1] = nd.m; }
+  asm volatile("" ::: "memory");
   // ---- requests for the sparse tail, AFTER the first dense prefetch: loads return in order, so the dense corner does not wait
   // for them and they land while it is being solved
   int tR[kTailPre], tK[kTailPre];
@@ -2984,7 +3007,7 @@ static int build_chain(lvf_problem* p) {
     SpArgs& a = c.sp[lv];
     a.nodes = p->sp_nodes.p; a.first = p->sp_levels.first[lv]; a.tiles = p->sp_tiles[lv]; a.rows = p->sp_rows.p; a.S = p->S.p; a.ld = p->ld; a.W = p->sp_W.p;
     a.wstride = p->sp_wstride; a.Lout = p->sp_L.p; a.fail = fail; a.nblocks = p->sp_levels.count[lv] * p->sp_tiles[lv]; a.done = done;
-    a.src = c.early ? SpSrc{p->B.p, p->dpad, p->dp, p->gc.p, radius, p->sp_rows_nat.p, nullptr, 0, nullptr, p->off, std::getenv("LVF_CHAIN_RMW_READ") ? 1 : 0} : SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, p->off, 0};
+    a.src = c.early ? SpSrc{p->B.p, p->dpad, p->dp, p->gc.p, radius, p->sp_rows_nat.p, nullptr, 0, nullptr, p->off, std::getenv("LVF_CHAIN_RMW_READ") ? 1 : 0, nullptr, lv == 0 ? 1 : 0} : SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, p->off, 0, nullptr, 0};
     c.sp_lds[lv] = p->sp_shmem[lv];
   }
   c.merged_level0 = false;
@@ -3282,6 +3305,32 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
   hipStream_t q = p->ctx->stream;
   if (chain_stale(p)) LVF_TRY(build_chain(p));
   const Chain& c = *p->chain;
+  static const bool sp_timing = std::getenv("LVF_SP_TIMING") != nullptr;
+  if (sp_timing && c.early) {
+    // diagnostic: the levels' stamps (the chain is rebuilt with the debug pointer in every level's arguments; printed by the next call)
+    const int n_nodes = p->sp_levels.n ? p->sp_levels.first[p->sp_levels.n - 1] + p->sp_levels.count[p->sp_levels.n - 1] : 0;
+    if (p->dbg_sp.n == 0) {
+      LVF_TRY(p->dbg_sp.ensure((size_t)n_nodes * 8 + 8)); p->dbg_sp.n = (size_t)n_nodes * 8;
+      LVF_HIP(hipMemsetAsync(p->dbg_sp.p, 0, (size_t)n_nodes * 64, q));
+      Chain& cw = *p->chain;
+      for (int lv = 0; lv < cw.n_levels; ++lv) cw.sp[lv].src.dbg = p->dbg_sp.p;
+      cw.red.ride.src.dbg = p->dbg_sp.p; cw.prep_early.ride.src.dbg = p->dbg_sp.p; cw.ssp0.sp.src.dbg = p->dbg_sp.p; cw.ssp0.sp_b.src.dbg = p->dbg_sp.p; cw.ssp0.sp_c.src.dbg = p->dbg_sp.p;
+    } else {
+      std::vector<unsigned long long> t((size_t)n_nodes * 8);
+      LVF_HIP(hipStreamSynchronize(q));
+      LVF_HIP(hipMemcpy(t.data(), p->dbg_sp.p, t.size() * 8, hipMemcpyDeviceToHost));
+      for (int lv = 0; lv < p->sp_levels.n; ++lv) {
+        const int f0 = p->sp_levels.first[lv], cnt = p->sp_levels.count[lv];
+        double ph[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long first = ~0ull, last = 0;
+        for (int k = f0; k < f0 + cnt; ++k) {
+          for (int j = 0; j < 7; ++j) ph[j] += (double)(t[(size_t)k * 8 + j + 1] - t[(size_t)k * 8 + j]) * 0.01 / cnt;
+          first = std::min(first, t[(size_t)k * 8]); last = std::max(last, t[(size_t)k * 8 + 7]);
+        }
+        std::fprintf(stderr, "sparse level %d (%d blocks, us): requests by address %.2f | wait for the level below %.2f | S entries %.2f | factor %.2f | W + first adds (returning) %.2f | arrive %.2f | rest of the adds %.2f ; start %.2f after level 0's first start, span %.2f\n",
+                     lv, cnt, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], (double)(first - t[0]) * 0.01, (double)(last - first) * 0.01);
+      }
+    }
+  }
   LVF_TRY(enqueue_linearize(p, p->huber, true, true));
   bool level0_done = false;
   LVF_TRY(enqueue_reduced_system(p, &p->ctl.p->radius, true, true, &level0_done));
