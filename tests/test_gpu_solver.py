@@ -287,3 +287,55 @@ def test_constant_velocity_and_bias_blocks(ctx, oracle):
     for h in list(b.values()) + [st]:
         if h is not None:
             h.close()
+
+
+@pytest.mark.parametrize("n_kf,n_lm,seed,drop", [(16, 400, 51, ()), (24, 500, 53, ()), (24, 500, 55, (5, 6, 17)), (33, 600, 57, ()), (48, 800, 59, ())])
+def test_sparse_level_placements(ctx, oracle, n_kf, n_lm, seed, drop):
+    """The (v, ba, bg) levels ride in different launches depending on how many there are (three: all chained inside the Schur launch;
+    four / five: the first one / two ride in the k_tf_reduce / k_prepare launches): three LM iterations at window sizes on either side
+    of every switch, with the damped-system tap (classic assembly) between them."""
+    from lvio_fusion_amd import api
+    cfg, st, b, prob, win = build(api, ctx, oracle, n_kf, n_lm, seed, imu_drop=drop)
+    opt = api.default_solver_options()
+    radius, dec = 1e4, 2.0
+    for it in range(3):
+        ref = win.lm_iteration(radius, dec)
+        got = prob.lm_iteration(opt, radius, dec)
+        assert abs(got["cost_before"] - ref["cost_before"]) <= 1e-8 * abs(ref["cost_before"])
+        if it == 1:
+            S, rhs = prob.reduced_system()
+            assert np.abs(S - ref["S"]).max() <= 1e-7 * np.abs(ref["S"]).max()
+        assert got["accepted"] == ref["accepted"]
+        assert abs(got["cost_after"] - ref["cost_after"]) <= 1e-6 * abs(ref["cost_after"])
+        s = state_of(api, st)
+        assert_parity(s["poses"].reshape(-1, 7), win.poses, f"poses it{it}")
+        assert_parity(s["vel"].reshape(-1, 3), win.vel, f"vel it{it}")
+        assert_parity(s["bg"].reshape(-1, 3), win.bg, f"bg it{it}")
+        radius, dec = ref["radius"], ref["decrease_factor"]
+    for h in list(b.values()) + [st]:
+        if h is not None:
+            h.close()
+    prob.close()
+
+
+def test_chained_levels_give_the_same_answer_every_time(ctx, oracle):
+    """Levels chained inside one launch hand their updates over through memory while the launch runs.  The case that exposed a hand-over
+    race (8 keyframes, 20 000 landmarks: a long Schur launch around a three-level chain; 5 of 12 runs were wrong before the updates
+    the next level reads became returning atomics) is solved 25 times from the same start: every run must land on the same cost."""
+    from lvio_fusion_amd import api
+    cfg, st, b, prob, win = build(api, ctx, oracle, 8, 20000, 2020, n_pre=0)
+    opt = api.default_solver_options()
+    opt.max_num_iterations = 2
+    opt.function_tolerance = 0.0; opt.parameter_tolerance = 0.0; opt.gradient_tolerance = 0.0
+    finals = []
+    for run in range(25):
+        for field, key in ((api.POSES, "poses"), (api.VEL, "vel"), (api.BA, "ba"), (api.BG, "bg"), (api.INV_DEPTH, "inv_depth")):
+            st.set(field, cfg[key])
+        finals.append(prob.solve(opt).final_cost)
+    finals = np.array(finals)
+    assert np.all(np.isfinite(finals))
+    assert np.ptp(finals) <= 1e-9 * abs(finals[0]), f"runs disagree: spread {np.ptp(finals):.3e} on {finals[0]:.6e}"
+    for h in list(b.values()) + [st]:
+        if h is not None:
+            h.close()
+    prob.close()
