@@ -400,7 +400,9 @@ int launch_lidar_plane(lvf_batch* b, const double* rpyxyz_host, bool want_j);
 int launch_imu_sqrt_info(lvf_batch* b);
 // arrays to clear before a linearisation (one launch, or extra workgroups of another launch)
 constexpr int kZeroListMax = 8;
-struct ZeroList { double* p[kZeroListMax]; unsigned long long n[kZeroListMax]; int count; };
+// tri[k] > 0: entry k is a square matrix of that leading dimension of which only the LOWER triangle (widened to the 64-column block of
+// the diagonal) is ever written, so only that is cleared (B and S: half of the 9.4 MB per window and iteration)
+struct ZeroList { double* p[kZeroListMax]; unsigned long long n[kZeroListMax]; int tri[kZeroListMax]; int count; };
 // cost_stripes (optional): 32 striped accumulators that receive 1/2 |r|^2 of every factor
 // zero (optional): arrays cleared by extra workgroups of the same launch
 int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j, double* cost_stripes = nullptr, const ZeroList* zero = nullptr);

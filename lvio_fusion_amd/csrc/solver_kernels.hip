@@ -173,8 +173,18 @@ __device__ __forceinline__ void add_block66(double* __restrict__ B, int ld, int 
 // ------------------------------------------------------------------------------------------------ housekeeping
 // one launch zeroes every accumulator of a linearisation (B, gc, E, C, gr, scalars) instead of six fill kernels
 // (ZeroList: lvf_internal.hpp)
+// rows of a lower-triangular matrix (leading dimension ld, even): one wave per row, columns [0, end of the row's 64-column block)
+__device__ __forceinline__ void zero_lower(double* __restrict__ p, const int ld, const unsigned long long wave, const unsigned long long n_waves) {
+  const int lane = threadIdx.x & 63;
+  for (unsigned long long r = wave; r < (unsigned long long)ld; r += n_waves) {
+    double2* row = reinterpret_cast<double2*>(p + r * (unsigned long long)ld);
+    const int end2 = min(ld, (((int)r | 63) + 1)) / 2;
+    for (int c = lane; c < end2; c += 64) row[c] = make_double2(0.0, 0.0);
+  }
+}
 __global__ __launch_bounds__(kT) void k_zero_multi(ZeroList z) {
   double* p = z.p[blockIdx.y];
+  if (z.tri[blockIdx.y] > 0) { zero_lower(p, z.tri[blockIdx.y], (unsigned long long)blockIdx.x * (kT / 64) + (threadIdx.x >> 6), (unsigned long long)gridDim.x * (kT / 64)); return; }
   const unsigned long long n = z.n[blockIdx.y], n2 = n / 2;
   double2* p2 = reinterpret_cast<double2*>(p);
   for (unsigned long long i = (unsigned long long)blockIdx.x * kT + threadIdx.x; i < n2; i += (unsigned long long)gridDim.x * kT) p2[i] = make_double2(0.0, 0.0);
@@ -188,6 +198,7 @@ __device__ __forceinline__ void zero_list_share(const ZeroList& zero, const int 
   for (int a = 0; a < kZeroListMax; ++a) {
     if (a >= zero.count) break;
     double* p = zero.p[a];
+    if (zero.tri[a] > 0) { zero_lower(p, zero.tri[a], (unsigned long long)wg * (kT / 64) + (threadIdx.x >> 6), (unsigned long long)n_wgs * (kT / 64)); continue; }
     const unsigned long long cnt = zero.n[a], n2 = cnt / 2;
     double2* p2 = reinterpret_cast<double2*>(p);
     for (unsigned long long i = t; i < n2; i += nt) p2[i] = make_double2(0.0, 0.0);
@@ -2940,10 +2951,11 @@ static int build_chain(lvf_problem* p) {
   }
   {
     int k = 0;
-    auto add = [&](double* ptr, size_t n) { if (ptr && n) { c.zero.p[k] = ptr; c.zero.n[k] = n; ++k; } };
-    add(p->B.p, (size_t)p->dpad * p->dpad); add(p->gc.p, p->dpad);
+    static const bool tri_on = [] { const char* e = std::getenv("LVF_ZERO_TRI"); return !(e && e[0] == '0'); }();
+    auto add = [&](double* ptr, size_t n, int tri = 0) { if (ptr && n) { c.zero.p[k] = ptr; c.zero.n[k] = n; c.zero.tri[k] = (tri_on && tri % 2 == 0) ? tri : 0; ++k; } };
+    add(p->B.p, (size_t)p->dpad * p->dpad, p->dpad); add(p->gc.p, p->dpad);
     if (p->n_lm) { if (!p->compact) add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
-    if (c.early) { add(p->S.p, (size_t)p->ld * p->ld); add(p->sp_sync.p, kSpMaxLevels); }     // early sparse levels add into S before k_prepare does; their arrival counters
+    if (c.early) { add(p->S.p, (size_t)p->ld * p->ld, p->ld); add(p->sp_sync.p, kSpMaxLevels); }     // early sparse levels add into S before k_prepare does; their arrival counters
     c.zero_end = c.zero; c.zero_end.count = k;         // cleared at the END of an iteration, beside the cost pass (the scalars: by the decision itself)
     add(p->scal.p, SC_N);
     c.zero.count = k;
