@@ -464,7 +464,7 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
       // three workgroups on the CU), so their NUMBER is what counts: the 63 products go through a wave-private LDS tile eight slots
       // at a time, lane (slot s, part) walks 8 consecutive lanes' values and adds one partial sum per run of equal first keyframes —
       // 63 x (segments + 7) atomics per wave instead of 63 x 64 (blocks sorted by first keyframe: a few hundred instead of 4 032).
-      if (mine_done && active) {}                        // (lanes the group rounds above have served contribute zeros below)
+      // (lanes the group rounds above have served contribute zeros below)
       double z = (active && !mine_done) ? 1.0 : 0.0;
       asm volatile("" : "+v"(z));
       double M[12];
