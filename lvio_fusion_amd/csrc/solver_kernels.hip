@@ -136,7 +136,8 @@ __device__ __forceinline__ int done_flag_issue(const int* done) { return done ? 
 
 __device__ __forceinline__ void block_add(double v, double* dst) {
   v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst + (blockIdx.x & (kStripes - 1)), v);
+  // (x + y: a table launch may carry the window in either grid dimension — the stripes must be spread by the workgroup's number inside the window)
+  if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst + ((blockIdx.x + blockIdx.y) & (kStripes - 1)), v);
 }
 
 struct StateP { const double *poses, *vel, *ba, *bg, *inv_depth, *w_kf; };
@@ -1020,6 +1021,7 @@ __device__ __forceinline__ void lin_visual_body(const int bx, const LinArgs& A) 
 // (three workgroups per CU: the register allocator is told so — left alone it lands one VGPR above the limit)
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void k_lin_visual(LinArgs a) { lin_visual_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void k_lin_visual_b(const LinArgs* __restrict__ t) { lin_visual_body(blockIdx.x, t[blockIdx.y]); }
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void k_lin_visual_bt(const LinArgs* __restrict__ t) { lin_visual_body(blockIdx.y, t[blockIdx.x]); }
 
 // Adds the TwoFrame slabs of a linearisation into B / gc (compact mode).  Workgroups are sorted by current keyframe: run(k) =
 // workgroups [run_first[k], run_first[k+1]).  Every entry of B has ONE owner thread here (plain read-modify-write; the other factor
@@ -1031,9 +1033,12 @@ struct TfReduceArgs {
   int n_kf, n_wg; const int* run_first; const double *slabP, *slabQ; double* B; int ld; double* gc; int nblocks; const int* done;
   int own_blocks; SpArgs ride;       // workgroups [own_blocks, nblocks): a sparse level riding in this launch (early form)
 };
-__device__ __forceinline__ void tf_reduce_body(const int bx, const TfReduceArgs& A) {
-  if (bx >= A.nblocks || (A.done && *A.done)) return;
-  if (bx >= A.own_blocks) { sp_ride(bx - A.own_blocks, A.ride); return; }
+__device__ __forceinline__ void tf_reduce_body(const int bx0, const TfReduceArgs& A) {
+  if (bx0 >= A.nblocks || (A.done && *A.done)) return;
+  // (the riding level takes the FIRST workgroups: it is the longest piece of the launch, and in a batch the first workgroups of every
+  // window are dispatched first — see the transposed table launches)
+  if (bx0 < A.ride.nblocks) { sp_ride(bx0, A.ride); return; }
+  const int bx = bx0 - A.ride.nblocks;
   const int n_kf = A.n_kf;
   const int nchunk = (A.n_wg + 63) / 64;
   if (bx < n_kf * nchunk) {
@@ -1085,6 +1090,9 @@ __device__ __forceinline__ void tf_reduce_body(const int bx, const TfReduceArgs&
 }
 __global__ __launch_bounds__(kT) void k_tf_reduce(TfReduceArgs a) { tf_reduce_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_tf_reduce_b(const TfReduceArgs* __restrict__ t) { tf_reduce_body(blockIdx.x, t[blockIdx.y]); }
+// (transposed: blockIdx.x = window.  Workgroups are dispatched x-fastest, so the first workgroups of EVERY window — the riding / chained
+// sparse levels, the ImuError factors — start together at the head of the launch instead of each window's behind the previous window's bulk)
+__global__ __launch_bounds__(kT) void k_tf_reduce_bt(const TfReduceArgs* __restrict__ t) { tf_reduce_body(blockIdx.y, t[blockIdx.x]); }
 
 
 // ------------------------------------------------------------------------------------------------ pose priors
@@ -1171,9 +1179,10 @@ struct PrepArgs {
   int early, off;
   int own_blocks; SpArgs ride;       // workgroups [own_blocks, nblocks): a sparse level riding in this launch
 };
-__device__ __forceinline__ void prepare_body(const unsigned bx, const PrepArgs& A) {
-  if (bx >= (unsigned)A.nblocks || (A.done && *A.done)) return;
-  if (bx >= (unsigned)A.own_blocks) { sp_ride((int)bx - A.own_blocks, A.ride); return; }
+__device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs& A) {
+  if (bx0 >= (unsigned)A.nblocks || (A.done && *A.done)) return;
+  if (bx0 < (unsigned)A.ride.nblocks) { sp_ride((int)bx0, A.ride); return; }      // (riders first: tf_reduce_body)
+  const unsigned bx = bx0 - (unsigned)A.ride.nblocks;
   const int ld = A.ld, dpad = A.dpad; const int* __restrict__ iperm = A.iperm; const double* __restrict__ B = A.B; const double* __restrict__ gc = A.gc;
   const double inv_radius = 1.0 / *A.radius;
   double* __restrict__ S = A.S; const unsigned nS_blocks = A.nS_blocks; const int n_lm = A.n_lm, dp = A.dp, ldE = A.ldE;
@@ -1247,6 +1256,7 @@ __device__ __forceinline__ void prepare_body(const unsigned bx, const PrepArgs& 
 }
 __global__ __launch_bounds__(kT) void k_prepare(PrepArgs a) { prepare_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_prepare_b(const PrepArgs* __restrict__ t) { prepare_body(blockIdx.x, t[blockIdx.y]); }
+__global__ __launch_bounds__(kT) void k_prepare_bt(const PrepArgs* __restrict__ t) { prepare_body(blockIdx.y, t[blockIdx.x]); }
 
 // ------------------------------------------------------------------------------------------------ Schur reduce (MFMA f64)
 // T = Ea^T diag(1/Cd) Ea with Ea = [E | g_rho] (n_lm x ldE).  One wave per (16x16 output tile, K-chunk); tiles on or
@@ -1955,6 +1965,7 @@ __device__ __forceinline__ void chol_step_body(const int bx, const CholArgs& A, 
 }
 __global__ __launch_bounds__(kCT) void k_chol_step(CholArgs a, int kb) { chol_step_body(blockIdx.x, a, kb); }
 __global__ __launch_bounds__(kCT) void k_chol_step_b(const CholArgs* __restrict__ t, int kb) { chol_step_body(blockIdx.x, t[blockIdx.y], kb); }
+__global__ __launch_bounds__(kCT) void k_chol_step_bt(const CholArgs* __restrict__ t, int kb) { chol_step_body(blockIdx.y, t[blockIdx.x], kb); }
 
 // ------------------------------------------------------------------------------------------------ elimination order
 // The (v, ba, bg) blocks only meet each other and the poses through ImuError factors, i.e. along the IMU chain: block k touches
@@ -2246,6 +2257,7 @@ __device__ __forceinline__ void schur_sp0_body(const int b, const SchurSp0Args& 
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_schur_sp0(SchurSp0Args a) { schur_sp0_body(blockIdx.x, a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_schur_sp0_b(const SchurSp0Args* __restrict__ t) { schur_sp0_body(blockIdx.x, t[blockIdx.y]); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_schur_sp0_bt(const SchurSp0Args* __restrict__ t) { schur_sp0_body(blockIdx.y, t[blockIdx.x]); }
 struct SpBack {                    // what the back substitution needs of the plan
   SpLevels lv;
   int item0[kSpMaxLevels], items[kSpMaxLevels];   // the level's slice of rows/owner/W
@@ -2577,6 +2589,7 @@ __device__ __forceinline__ void step_tail_body(const int bx, const TailArgs& A) 
 }
 __global__ __launch_bounds__(kT) void k_step_tail(TailArgs a) { step_tail_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_step_tail_b(const TailArgs* __restrict__ t) { step_tail_body(blockIdx.x, t[blockIdx.y]); }
+__global__ __launch_bounds__(kT) void k_step_tail_bt(const TailArgs* __restrict__ t) { step_tail_body(blockIdx.y, t[blockIdx.x]); }
 
 // ------------------------------------------------------------------------------------------------ closing an iteration on device
 // One workgroup per window: the step-quality test, the trust-region update, the commit of an accepted candidate (a copy of a few tens
@@ -2776,6 +2789,7 @@ __device__ __forceinline__ void cost_decide_body(const int b, const CostArgs& A,
 // end_zero = 0 keeps the accumulators of this iteration's linearisation (per-call API: lvf_problem_download_reduced rebuilds the damped system from them)
 __global__ __launch_bounds__(kT) void k_cost_decide(CostArgs a, DecideArgs d, int end_zero) { cost_decide_body(blockIdx.x, a, d, end_zero); }
 __global__ __launch_bounds__(kT) void k_cost_decide_b(const CostArgs* __restrict__ t, const DecideArgs* __restrict__ d, int end_zero) { cost_decide_body(blockIdx.x, t[blockIdx.y], d[blockIdx.y], end_zero); }
+__global__ __launch_bounds__(kT) void k_cost_decide_bt(const CostArgs* __restrict__ t, const DecideArgs* __restrict__ d, int end_zero) { cost_decide_body(blockIdx.y, t[blockIdx.x], d[blockIdx.x], end_zero); }
 
 // ================================================================================================ host side
 static StateP state_ptrs(const lvf_state* st) { return StateP{st->poses.p, st->vel.p, st->ba.p, st->bg.p, st->inv_depth.p, st->w_visual.p}; }
@@ -3919,18 +3933,31 @@ static int batch_enqueue_iteration(lvf_problem_batch* b, bool end_zero) {
   bool clean = true;
   for (lvf_problem* p : b->probs) { clean = clean && p->accum_clean; p->accum_clean = false; }
   if (!clean) hipLaunchKernelGGL(k_zero_table, dim3(512, W), dim3(kT), 0, q, b->zero.p);
-  hipLaunchKernelGGL(k_lin_visual_b, dim3(b->g_lin, W), dim3(kT), b->lds_lin, q, b->lin.p);
-  if (b->g_red > 0) hipLaunchKernelGGL(k_tf_reduce_b, dim3(b->g_red, W), dim3(kT), b->lds_red, q, b->red.p);
-  hipLaunchKernelGGL(k_prepare_b, dim3(b->g_prep, W), dim3(kT), b->lds_prep, q, b->prep.p);
-  hipLaunchKernelGGL(k_schur_sp0_b, dim3(b->g_ssp0, W), dim3(256), b->lds_ssp0, q, b->ssp0.p);
+  // LVF_BATCH_TRANSPOSE (bit mask, default 127: all; measured 8 windows 20.7k -> 22.1k it/s, 32 windows 28.9k -> 29.9k): which of lin (1), tf_reduce (2), prepare (4), Schur (8), block steps (16), tail (32), cost (64) are launched with blockIdx.x = window
+  static const int tr = [] { const char* e = std::getenv("LVF_BATCH_TRANSPOSE"); return e ? std::atoi(e) : 127; }();
+  const bool fits_y = std::max(std::max(b->g_lin, b->g_red), std::max(b->g_prep, b->g_ssp0)) <= 65535;
+  if ((tr & 1) && fits_y) hipLaunchKernelGGL(k_lin_visual_bt, dim3(W, b->g_lin), dim3(kT), b->lds_lin, q, b->lin.p);
+  else hipLaunchKernelGGL(k_lin_visual_b, dim3(b->g_lin, W), dim3(kT), b->lds_lin, q, b->lin.p);
+  if (b->g_red > 0) {
+    if ((tr & 2) && fits_y) hipLaunchKernelGGL(k_tf_reduce_bt, dim3(W, b->g_red), dim3(kT), b->lds_red, q, b->red.p);
+    else hipLaunchKernelGGL(k_tf_reduce_b, dim3(b->g_red, W), dim3(kT), b->lds_red, q, b->red.p);
+  }
+  if ((tr & 4) && fits_y) hipLaunchKernelGGL(k_prepare_bt, dim3(W, b->g_prep), dim3(kT), b->lds_prep, q, b->prep.p);
+  else hipLaunchKernelGGL(k_prepare_b, dim3(b->g_prep, W), dim3(kT), b->lds_prep, q, b->prep.p);
+  if ((tr & 8) && fits_y) hipLaunchKernelGGL(k_schur_sp0_bt, dim3(W, b->g_ssp0), dim3(256), b->lds_ssp0, q, b->ssp0.p);
+  else hipLaunchKernelGGL(k_schur_sp0_b, dim3(b->g_ssp0, W), dim3(256), b->lds_ssp0, q, b->ssp0.p);
   for (int lv = b->first_own_level; lv < b->max_levels; ++lv)
     if (b->g_sp[lv] > 0) hipLaunchKernelGGL(k_sp_eliminate_b, dim3(b->g_sp[lv], W), dim3(256), b->lds_sp[lv], q, b->sp[lv].p);
   for (int kb = 0; kb < b->max_nb; ++kb) {
-    hipLaunchKernelGGL(k_chol_step_b, dim3(chol_step_grid(b->max_nb, kb), W), dim3(kCT), 0, q, b->chol.p, kb);
+    if (tr & 16) hipLaunchKernelGGL(k_chol_step_bt, dim3(W, chol_step_grid(b->max_nb, kb)), dim3(kCT), 0, q, b->chol.p, kb);
+    else hipLaunchKernelGGL(k_chol_step_b, dim3(chol_step_grid(b->max_nb, kb), W), dim3(kCT), 0, q, b->chol.p, kb);
   }
   hipLaunchKernelGGL(k_chol_backsolve_b, dim3(1, W), dim3(kBT), b->lds_back, q, b->back.p);
-  hipLaunchKernelGGL(k_step_tail_b, dim3(b->g_tail, W), dim3(kT), b->lds_tail, q, b->tail.p);
-  hipLaunchKernelGGL(k_cost_decide_b, dim3(b->g_cost, W), dim3(kT), 0, q, b->cost.p, b->dec.p, end_zero ? 1 : 0);      // (batchable windows always have visual blocks)
+  if ((tr & 32) && b->g_tail <= 65535) hipLaunchKernelGGL(k_step_tail_bt, dim3(W, b->g_tail), dim3(kT), b->lds_tail, q, b->tail.p);
+  else hipLaunchKernelGGL(k_step_tail_b, dim3(b->g_tail, W), dim3(kT), b->lds_tail, q, b->tail.p);
+  // (batchable windows always have visual blocks)
+  if ((tr & 64) && b->g_cost <= 65535) hipLaunchKernelGGL(k_cost_decide_bt, dim3(W, b->g_cost), dim3(kT), 0, q, b->cost.p, b->dec.p, end_zero ? 1 : 0);
+  else hipLaunchKernelGGL(k_cost_decide_b, dim3(b->g_cost, W), dim3(kT), 0, q, b->cost.p, b->dec.p, end_zero ? 1 : 0);
   LVF_HIP(hipGetLastError());
   for (lvf_problem* p : b->probs) { p->linearized = !end_zero; p->accum_clean = end_zero; }     // (batchable windows: the cost + decision launch clears them)
   return LVF_OK;
