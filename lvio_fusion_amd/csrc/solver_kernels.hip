@@ -3686,74 +3686,80 @@ int problem_configure(lvf_problem* p) {
     LVF_TRY(p->tf_work.assign(p->h_tf_work.p, nw, ctx->stream));
     p->tf_k1_first = true; p->tf_unique_lk2 = true;
   } else if (two_frame && two_frame->n && two_frame->sorted_by_kf && !two_frame->host_kf2.empty()) {
-    // work list for the sorted fast path: runs of <= kT blocks sharing one current keyframe; k1 == k2 disables it
+    // work list for the sorted fast path: runs of <= kT blocks sharing one current keyframe; k1 == k2 disables it.
+    // ONE pass over the blocks gathers everything the host has to know about them (the list is 72 k entries at configs[3] and this
+    // function is on adapt::Solve's path: seven separate passes were 0.45 ms of it):
+    //   * k1 != k2 everywhere, k1 < k2 everywhere;
+    //   * the current-keyframe runs (their starts) and, per run, how many blocks have which first keyframe (for the counting sort below);
+    //   * how often the first keyframe steps DOWN inside a run (ids in creation order: almost never);
+    //   * one block per (landmark, current keyframe) and ONE first keyframe per landmark, with two per-landmark tables: `seen_run[l]` =
+    //     the last run landmark l appeared in (a repeat inside one run is a duplicate pair), `first_kf[l]` = its first keyframe.  The plain
+    //     stores into E[l][k2 columns] must never meet the adds into E[l][k1 columns]; BuildProblem's blocks always satisfy this, a
+    //     hand-made batch may not.
     const std::vector<int32_t>& k2 = two_frame->host_kf2; const std::vector<int32_t>& k1 = two_frame->host_kf1;
+    const std::vector<int32_t>& lmh = two_frame->host_lm;
+    const int n = two_frame->n, nkf = p->n_kf;
+    static const bool k1sort_on = [] { const char* e = std::getenv("LVF_TF_K1SORT"); return !(e && e[0] == '0'); }();
+    const bool want_hist = k1sort_on && nkf <= 256;
     bool ok = true, k1_first = true;
-    for (int i = 0; i < two_frame->n && ok; ++i) { ok = k1[i] != k2[i]; k1_first = k1_first && k1[i] < k2[i]; }
+    bool uniq = two_frame->unique_lk2_known || lmh.size() == (size_t)n;
+    const bool check_uniq = uniq && !two_frame->unique_lk2_known;
+    const int32_t nl = (int32_t)p->n_lm;
+    std::vector<int32_t> seen_run, first_kf;
+    if (check_uniq) { seen_run.assign((size_t)nl, -1); first_kf.assign((size_t)nl, -1); }
+    std::vector<int32_t> run_start;                 // first block of every current-keyframe run (+ n at the end)
+    std::vector<int32_t> hist;                      // [run][first keyframe] block counts
+    run_start.reserve((size_t)nkf + 2);
+    if (want_hist) hist.reserve((size_t)(nkf + 1) * nkf);
+    int descents = 0, cur = INT32_MIN, run = -1;
+    int32_t* hrow = nullptr;
+    for (int i = 0; i < n; ++i) {
+      const int a = k1[i], c2 = k2[i];
+      ok = ok && a != c2; k1_first = k1_first && a < c2;
+      if (c2 != cur) {
+        cur = c2; ++run; run_start.push_back(i);
+        if (want_hist) { hist.resize(hist.size() + (size_t)nkf, 0); hrow = hist.data() + (size_t)run * nkf; }
+      } else descents += a < k1[i - 1] ? 1 : 0;
+      if (want_hist) ++hrow[std::min(std::max(a, 0), nkf - 1)];
+      if (check_uniq && uniq) {
+        const int32_t l = lmh[i];
+        if (l < 0 || l >= nl) uniq = false;
+        else {
+          if (seen_run[l] == run) uniq = false;
+          seen_run[l] = run;
+          if (first_kf[l] < 0) first_kf[l] = a; else if (first_kf[l] != a) uniq = false;
+        }
+      }
+    }
+    run_start.push_back(n);
     p->tf_k1_first = ok && k1_first;
     if (ok) {
       // built straight into pinned staging owned by the problem: the upload is a real asynchronous copy and this function does not
       // have to wait for the stream before returning
       size_t nw = 0;
-      for (int i = 0; i < two_frame->n;) { int j = i; while (j < two_frame->n && k2[j] == k2[i] && j - i < kT) ++j; ++nw; i = j; }
+      for (size_t r = 0; r + 1 < run_start.size(); ++r) nw += (size_t)(run_start[r + 1] - run_start[r] + kT - 1) / kT;
       LVF_TRY(p->h_tf_work.reserve(nw + 1));
       nw = 0;
-      for (int i = 0; i < two_frame->n;) {
-        int j = i;
-        while (j < two_frame->n && k2[j] == k2[i] && j - i < kT) ++j;
-        p->h_tf_work[nw++] = TfWork{i, j - i, k2[i]};
-        i = j;
-      }
+      for (size_t r = 0; r + 1 < run_start.size(); ++r)
+        for (int i = run_start[r]; i < run_start[r + 1]; i += kT) p->h_tf_work[nw++] = TfWork{i, std::min(kT, run_start[r + 1] - i), k2[run_start[r]]};
       LVF_TRY(p->tf_work.assign(p->h_tf_work.p, nw, ctx->stream));
       // first keyframes out of order inside the runs (more than one block in eight steps DOWN): sorted copies for the linearisation.
       // BuildProblem's own order (landmark ids in creation order) passes untouched.
-      static const bool k1sort_on = [] { const char* e = std::getenv("LVF_TF_K1SORT"); return !(e && e[0] == '0'); }();
-      if (k1sort_on && p->n_kf <= 256) {
-        int descents = 0;
-        for (int i = 1; i < two_frame->n; ++i) descents += (k2[i] == k2[i - 1] && k1[i] < k1[i - 1]) ? 1 : 0;
-        if ((size_t)descents * 8 > (size_t)two_frame->n) {
-          const int n = two_frame->n;
-          LVF_TRY(p->h_tfs_perm.reserve((size_t)n));
-          int* perm = p->h_tfs_perm.p;
-          std::vector<int32_t> cnt((size_t)p->n_kf + 1);
-          for (int i = 0; i < n;) {                      // counting sort of each current-keyframe run by first keyframe (stable)
-            int j = i;
-            while (j < n && k2[j] == k2[i]) ++j;
-            std::fill(cnt.begin(), cnt.end(), 0);
-            for (int t = i; t < j; ++t) ++cnt[(size_t)std::min(std::max(k1[t], 0), p->n_kf - 1) + 1];
-            for (int k = 0; k < p->n_kf; ++k) cnt[k + 1] += cnt[k];
-            for (int t = i; t < j; ++t) perm[(size_t)i + cnt[(size_t)std::min(std::max(k1[t], 0), p->n_kf - 1)]++] = t;
-            i = j;
-          }
-          LVF_TRY(p->tfs_perm.assign(perm, (size_t)n, ctx->stream));
-          LVF_TRY(p->tfs_fo.ensure(n)); LVF_TRY(p->tfs_ob.ensure(n)); LVF_TRY(p->tfs_lm.ensure(n)); LVF_TRY(p->tfs_k1.ensure(n)); LVF_TRY(p->tfs_k2.ensure(n));
-          hipLaunchKernelGGL(k_tf_gather, dim3(grid(n)), dim3(kT), 0, ctx->stream, n, p->tfs_perm.p, (const double2*)two_frame->ob_a.p, (const double2*)two_frame->ob_b.p,
-                             two_frame->idx_a.p, two_frame->idx_b.p, two_frame->idx_c.p, p->tfs_fo.p, p->tfs_ob.p, p->tfs_lm.p, p->tfs_k1.p, p->tfs_k2.p);
-          LVF_HIP(hipGetLastError());
-          p->tf_sorted_copy = true;
+      if (want_hist && (size_t)descents * 8 > (size_t)n) {
+        LVF_TRY(p->h_tfs_perm.reserve((size_t)n));
+        int* perm = p->h_tfs_perm.p;
+        for (size_t r = 0; r + 1 < run_start.size(); ++r) {     // counting sort of each run by first keyframe (stable): the histogram is there
+          int32_t* cnt = hist.data() + r * (size_t)nkf;
+          int32_t at = run_start[r];
+          for (int k = 0; k < nkf; ++k) { const int32_t c = cnt[k]; cnt[k] = at; at += c; }
+          for (int t = run_start[r]; t < run_start[r + 1]; ++t) perm[cnt[std::min(std::max(k1[t], 0), nkf - 1)]++] = t;
         }
-      }
-      // blocks are sorted by k2: a duplicate (landmark, k2) pair shows up as a repeated landmark inside one k2 run
-      const std::vector<int32_t>& lmh = two_frame->host_lm;
-      bool uniq = two_frame->unique_lk2_known || lmh.size() == (size_t)two_frame->n;
-      // Both checks in ONE pass over the blocks with two per-landmark tables (a sort per run + a hash map of first keyframes were 3 ms
-      // of a 91 k-block lvf_problem_create): `seen_run[l]` = the last current-keyframe run landmark l appeared in (a repeat inside one
-      // run is a duplicate (landmark, k2) pair), `first_kf[l]` = its first keyframe.
-      // ... the plain stores into E[l][k2 columns] must never meet the atomic adds into E[l][k1 columns]: every landmark needs ONE
-      // first keyframe (then k2 == k1(l) is excluded by k1 != k2 above).  BuildProblem's blocks always satisfy this; a hand-made batch may not.
-      if (uniq && !two_frame->unique_lk2_known) {
-        const int32_t nl = (int32_t)p->n_lm;
-        std::vector<int32_t> seen_run((size_t)nl, -1), first_kf((size_t)nl, -1);
-        int32_t run = -1, cur = -1;
-        for (int i = 0; i < two_frame->n && uniq; ++i) {
-          if (k2[i] != cur) { cur = k2[i]; ++run; }
-          const int32_t l = lmh[i];
-          if (l < 0 || l >= nl) { uniq = false; break; }
-          if (seen_run[l] == run) uniq = false;
-          seen_run[l] = run;
-          if (first_kf[l] < 0) first_kf[l] = k1[i];
-          else if (first_kf[l] != k1[i]) uniq = false;
-        }
+        LVF_TRY(p->tfs_perm.assign(perm, (size_t)n, ctx->stream));
+        LVF_TRY(p->tfs_fo.ensure(n)); LVF_TRY(p->tfs_ob.ensure(n)); LVF_TRY(p->tfs_lm.ensure(n)); LVF_TRY(p->tfs_k1.ensure(n)); LVF_TRY(p->tfs_k2.ensure(n));
+        hipLaunchKernelGGL(k_tf_gather, dim3(grid(n)), dim3(kT), 0, ctx->stream, n, p->tfs_perm.p, (const double2*)two_frame->ob_a.p, (const double2*)two_frame->ob_b.p,
+                           two_frame->idx_a.p, two_frame->idx_b.p, two_frame->idx_c.p, p->tfs_fo.p, p->tfs_ob.p, p->tfs_lm.p, p->tfs_k1.p, p->tfs_k2.p);
+        LVF_HIP(hipGetLastError());
+        p->tf_sorted_copy = true;
       }
       p->tf_unique_lk2 = uniq;
     }

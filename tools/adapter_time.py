@@ -27,6 +27,6 @@ for max_it in (1, 5):
     _dump(d, "preint.f64", pre, np.float64)
     _dump(d, "imu_i.i32", [f["kf_i"] for f in cfg["imu"]], np.int32); _dump(d, "imu_j.i32", [f["kf_j"] for f in cfg["imu"]], np.int32)
     p = subprocess.run([EXE, "window", d], capture_output=True, text=True)
-    print("max_it", max_it, "\n".join(p.stderr.strip().splitlines()[-3:]) if p.stderr.strip() else p.stdout[-300:])
+    print("max_it", max_it, "\n".join(p.stderr.strip().splitlines()[-14:]) if p.stderr.strip() else p.stdout[-300:])
     if HOST_ONLY:
         break
