@@ -63,18 +63,13 @@ __device__ __forceinline__ void imu_stage(const int f, const int lane, const dou
 
 // Phase B (ONE lane): the raw residual sr0[15] and, WITH_J, the 15 x 32 pre-weighting Jacobian sM (columns: pose_i 0..6, v_i 7..9,
 // ba_i 10..12, bg_i 13..15, pose_j 16..22, v_j 23..25, ba_j 26..28, bg_j 29..31).
+// (imu_raw_at: the two keyframes' blocks by pointer — pose [7], v [3], ba [3], bg [3] each — wherever they live)
 template <bool WITH_J>
-__device__ __forceinline__ void imu_raw(const int f, const double* P /* the factor's flattened pre-integration: global or staged in LDS */,
-                                        const int* __restrict__ kf_i, const int* __restrict__ kf_j,
-                                        const double* __restrict__ poses, const double* __restrict__ vel, const double* __restrict__ ba,
-                                        const double* __restrict__ bg, double* sr0, double* sM) {
-    const int i = kf_i[f], j = kf_j[f];
-    const double* pi = poses + 7 * i; const double* pj = poses + 7 * j;
+__device__ __forceinline__ void imu_raw_at(const double* P /* the factor's flattened pre-integration: global or staged in LDS */,
+                                           const double* pi, const double* pj, const double* Vi, const double* Vj,
+                                           const double* Bai, const double* Baj, const double* Bgi, const double* Bgj, double* sr0, double* sM) {
     const Qd Qi{pi[0], pi[1], pi[2], pi[3]}, Qj{pj[0], pj[1], pj[2], pj[3]};
     const double* Pi = pi + 4; const double* Pj = pj + 4;
-    const double* Vi = vel + 3 * i; const double* Vj = vel + 3 * j;
-    const double* Bai = ba + 3 * i; const double* Baj = ba + 3 * j;
-    const double* Bgi = bg + 3 * i; const double* Bgj = bg + 3 * j;
     const double T = P[OFF_SUMDT];
     const double* Jp = P + OFF_JAC;
     // the five 3x3 blocks of the pre-integration Jacobian are read where they are used (twice: here and in the Jacobian columns below)
@@ -163,6 +158,20 @@ __device__ __forceinline__ void imu_raw(const int f, const double* P /* the fact
       for (int a = 0; a < 3; ++a) { MM(O_BA + a, 26 + a) = 1.0; MM(O_BG + a, 29 + a) = 1.0; }
 #undef MM
     }
+}
+
+
+template <bool WITH_J>
+__device__ __forceinline__ void imu_raw(const int f, const double* P, const int* __restrict__ kf_i, const int* __restrict__ kf_j,
+                                        const double* __restrict__ poses, const double* __restrict__ vel, const double* __restrict__ ba,
+                                        const double* __restrict__ bg, double* sr0, double* sM) {
+  const int i = kf_i[f], j = kf_j[f];
+  imu_raw_at<WITH_J>(P, poses + 7 * i, poses + 7 * j, vel + 3 * i, vel + 3 * j, ba + 3 * i, ba + 3 * j, bg + 3 * i, bg + 3 * j, sr0, sM);
+}
+// the two keyframes' states staged as rows of 16 doubles: [pose 7 | v 3 | ba 3 | bg 3], keyframe i then keyframe j
+template <bool WITH_J>
+__device__ __forceinline__ void imu_raw16(const double* P, const double* X, double* sr0, double* sM) {
+  imu_raw_at<WITH_J>(P, X, X + 16, X + 7, X + 23, X + 10, X + 26, X + 13, X + 29, sr0, sM);
 }
 
 // Phase C: lane r < 15 returns row r of the weighted residual sqrt_info . r0 (other lanes 0)

@@ -899,7 +899,7 @@ __device__ __forceinline__ void lin_imu_body4(const int vb, int n, int n_kf, con
 //   pose columns to tangent coordinates -> J^T J / J^T r into B / gc, 1/2 |r|^2 into the cost.
 // LDS (doubles): sS 225 | sM 480 (later the local 15 x 30 Jacobian) | sJw 480 | sr0 16 | sr 16 | sidx 16  = kImuWaveLds.
 constexpr int kEndZeroWgs = 192;       // workgroups of the cost + decision launch that clear the accumulators
-constexpr int kImuWaveLds = 225 + 480 + 480 + 16 + 16 + 16;
+constexpr int kImuWaveLds = 225 + 480 + 480 + 16 + 16 + 16 + 248 + 32 + 2;      // + the pre-integration's head (OFF_COV doubles) + the two keyframes' states
 __device__ __forceinline__ void lin_imu_eval_body(const int f, const ImuEvalArgs& I, int n_kf, const StateP& s, const uint8_t* __restrict__ pose_const,
                                                   double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost, unsigned long long* dbg) {
   // ONE factor per workgroup: the evaluation's serial part (one lane) is what it is, everything around it is spread over all kT threads
@@ -914,14 +914,24 @@ __device__ __forceinline__ void lin_imu_eval_body(const int f, const ImuEvalArgs
   double* sr0 = sJw + 480;
   double* sr = sr0 + 16;
   int* sidx = reinterpret_cast<int*>(sr + 16);
+  double* sP = reinterpret_cast<double*>(sidx + 32);      // [248] what the one-lane section reads of the pre-integration
+  double* sX = sP + 248;                                  // [32] pose, v, ba, bg of keyframe i (0..15) and j (16..31)
+  // everything the one-lane section reads is staged by the whole workgroup first (as single-lane global reads they were two cold round trips of its 3.6 us)
+  const int ki = I.kf_i[f], kj = I.kf_j[f];
   for (int k = tid; k < 225; k += kT) sS[k] = I.sqrt_info[(size_t)f * 225 + k];
+  for (int k = tid; k < OFF_COV; k += kT) sP[k] = I.pre[(size_t)f * kPre + k];
+  if (tid < 32) {
+    const int kk = tid < 16 ? ki : kj, c = tid & 15;
+    sX[tid] = c < 7 ? s.poses[7 * kk + c] : (c < 10 ? s.vel[3 * kk + c - 7] : (c < 13 ? s.ba[3 * kk + c - 10] : s.bg[3 * kk + c - 13]));
+  }
+  int* smask = reinterpret_cast<int*>(sX + 32);           // the two keyframes' constant-block masks
+  if (tid >= 32 && tid < 34) smask[tid - 32] = pose_const[tid == 32 ? ki : kj];
   for (int k = tid; k < 480; k += kT) sM[k] = 0.0;
   __syncthreads();
   if (dbg) dbg[1] = wall_clock64();
-  if (tid == 0) imu_raw<true>(f, I.pre + (size_t)f * kPre, I.kf_i, I.kf_j, s.poses, s.vel, s.ba, s.bg, sr0, sM);
+  if (tid == 0) imu_raw16<true>(sP, sX, sr0, sM);
   __syncthreads();
   if (dbg) dbg[2] = wall_clock64();
-  const int ki = I.kf_i[f], kj = I.kf_j[f];
   {
     const double r = imu_weighted_residual(tid, sS, sr0);
     if (tid < 15) sr[tid] = r;
@@ -938,17 +948,16 @@ __device__ __forceinline__ void lin_imu_eval_body(const int f, const ImuEvalArgs
   if (tid < 30) {
     const int row = tid % 15, which = tid / 15;          // which: 0 = pose_i, 1 = pose_j
     const double* Jr = sJw + 32 * row + (which ? 16 : 0);
-    const int kk = which ? kj : ki;
-    const double sc = (pose_const[kk] & 1) ? 0.0 : 1.0;
+    const double sc = (smask[which] & 1) ? 0.0 : 1.0;
     double l3[3];
-    quat_row_to_local(Jr, s.poses + 7 * kk, l3);
+    quat_row_to_local(Jr, sX + 16 * which, l3);
     double* o = sJ + row * 30 + (which ? 15 : 0);
     o[0] = sc * l3[0]; o[1] = sc * l3[1]; o[2] = sc * l3[2]; o[3] = sc * Jr[4]; o[4] = sc * Jr[5]; o[5] = sc * Jr[6];
   }
   for (int e = tid; e < 15 * 18; e += kT) {              // six 15x3 blocks: (v, ba, bg)_i = columns 7..15, (v, ba, bg)_j = columns 23..31
     const int row = e / 18, c = e % 18;
     const int cg = c < 9 ? c / 3 : (c - 9) / 3;          // 0 = v, 1 = ba, 2 = bg
-    const double scv = ((pose_const[c < 9 ? ki : kj] >> (1 + cg)) & 1) ? 0.0 : 1.0;      // constant (v | ba | bg) block: bits 1..3 of the mask
+    const double scv = ((smask[c < 9 ? 0 : 1] >> (1 + cg)) & 1) ? 0.0 : 1.0;      // constant (v | ba | bg) block: bits 1..3 of the mask
     sJ[row * 30 + (c < 9 ? 6 + c : 21 + (c - 9))] = scv * sJw[32 * row + (c < 9 ? 7 + c : 23 + (c - 9))];
   }
   __syncthreads();
@@ -3556,6 +3565,8 @@ static int build_elimination_plan(lvf_problem* p) {
       const double cost = 8.5 * (double)l + 18.0 * steps;
       if (cost < best - 1e-9) { best = cost; max_levels = (int)l + 1; }
     }
+    static const int force_levels = [] { const char* e = std::getenv("LVF_FORCE_LEVELS"); return e ? std::atoi(e) : 0; }();      // experiment
+    if (force_levels > 0) max_levels = std::min((int)left_after.size(), force_levels);
   }
   while (sparse && lv.n < std::min(max_levels, kSpMaxLevels)) {
     std::vector<char> blocked(n, 0);
