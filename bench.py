@@ -341,7 +341,7 @@ def legs(api, syn, ctx, device, verified, which="all"):
              ("map_maintenance", lambda: map_maintenance(api, ctx, cfg3())),
              ("window_tick", lambda: window_tick(api, syn, ctx)),
              ("ceres_surface_solve", lambda: ceres_surface(api, syn, ctx)),
-             ("relocalize_8_candidates", lambda: relocalize_leg(api, syn, ctx))]
+             ("relocalize_8_candidates", lambda: relocalize_leg(api, syn, ctx, device=device))]
     ex = {}
     for name, fn in table:
         if want is not None and name not in want:
@@ -680,7 +680,7 @@ def window_tick(api, syn, ctx, reps=10):
     return out
 
 
-def relocalize_leg(api, syn, ctx, n=8):
+def relocalize_leg(api, syn, ctx, n=8, device=0):
     """configs[4] unit of work on ONE GPU: n loop-closure candidates (Mapping::Relocate = 4 outer x {ground, surf}) evaluated
     back to back incl. map-index builds and uploads; on N GPUs each rank takes n/N of them and one 72-B/record all_gather
     follows (lvio_fusion_amd/relocalize.py)."""
@@ -691,9 +691,21 @@ def relocalize_leg(api, syn, ctx, n=8):
     t0 = time.perf_counter()
     best, rec = rl.relocalize(api, ctx, cands)
     dt = time.perf_counter() - t0
+    # the same candidates with three more contexts (streams + host threads) on the same GPU: a candidate is a latency chain
+    workers = [api.Context(int(device) if isinstance(device, int) else 0) for _ in range(3)]
+    rl.relocalize(api, ctx, cands[:4], workers=workers)
+    for c in [ctx] + workers:
+        c.synchronize()
+    t0 = time.perf_counter()
+    best4, rec4 = rl.relocalize(api, ctx, cands, workers=workers)
+    dt4 = time.perf_counter() - t0
+    for c in workers:
+        c.close()
+    same = bool(np.array_equal(rec[:, [0, 8]], rec4[:, [0, 8]]) and np.allclose(rec[:, 1:8], rec4[:, 1:8], rtol=0, atol=1e-12))
     return {"candidates": n, "points_per_candidate": int(cands[0]["query"].shape[0]), "map_points": int(cands[0]["map"].shape[0]),
             "ms_total": 1e3 * dt, "candidates_per_sec": n / dt, "best": None if best is None else {"candidate": best[0], "score": best[1]},
-            "scores": [float(x) for x in rec[np.argsort(rec[:, 8]), 0]]}
+            "scores": [float(x) for x in rec[np.argsort(rec[:, 8]), 0]],
+            "four_streams": {"ms_total": 1e3 * dt4, "candidates_per_sec": n / dt4, "same_records_as_one_stream": same}}
 
 
 def cpu_baseline(api, cfg, prob, st, verified):

@@ -85,11 +85,32 @@ def evaluate_candidate(api, ctx, cand, resolution=0.2):
             x.close()
 
 
-def relocalize(api, ctx, candidates, rank=0, world=1, device=None):
-    """Evaluates this rank's share, exchanges the records, returns (best or None, all records)."""
+def relocalize(api, ctx, candidates, rank=0, world=1, device=None, workers=None):
+    """Evaluates this rank's share, exchanges the records, returns (best or None, all records).
+
+    `workers`: extra api.Context objects on the SAME device.  A candidate is a chain of ~100 small launches and a dozen read-backs
+    (two map indices, 4 x {ground, surf} solves on a few hundred points): latency, not throughput — with more than one candidate per
+    GPU the chains of different candidates overlap on separate streams, one host thread per context (the C-ABI calls release the GIL);
+    what the reference's Relocator thread does one after the other (relocator.cpp:196-206), and what host/relocalize_driver.cpp does in C++."""
     table = empty_records(slots(len(candidates), world))
-    for s, cid in enumerate(owned(len(candidates), rank, world)):
-        res = evaluate_candidate(api, ctx, candidates[cid])
-        table[s] = make_record(cid, res.score, np.array(res.relative_o_c[:]))
+    mine = list(enumerate(owned(len(candidates), rank, world)))
+    ctxs = [ctx] + list(workers or [])
+    if len(ctxs) == 1 or len(mine) <= 1:
+        for s, cid in mine:
+            res = evaluate_candidate(api, ctx, candidates[cid])
+            table[s] = make_record(cid, res.score, np.array(res.relative_o_c[:]))
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(w):
+            out = []
+            for s, cid in mine[w::len(ctxs)]:
+                res = evaluate_candidate(api, ctxs[w], candidates[cid])
+                out.append((s, make_record(cid, res.score, np.array(res.relative_o_c[:]))))
+            return out
+        with ThreadPoolExecutor(max_workers=len(ctxs)) as pool:
+            for part in pool.map(run, range(len(ctxs))):
+                for s, rec in part:
+                    table[s] = rec
     allrec = gather_records(table, world, device)
     return choose_best(allrec), allrec

@@ -83,6 +83,23 @@ def test_relocalize_single_rank(ctx):
         assert np.allclose(merged[merged[:, 8] == c][0], t0[t0[:, 8] == c][0], rtol=1e-9, atol=1e-12)   # atomics reorder the last bits
 
 
+def test_relocalize_on_several_streams_of_one_gpu(ctx):
+    """Candidates evaluated by three host threads on three contexts (streams) of the same device give the records of the one-stream run."""
+    from lvio_fusion_amd import api
+    cands = syn.config5_candidates(7, seed=23, n_query=4000, n_az=300, overlap="varied")
+    one = rl.relocalize(api, ctx, cands)
+    workers = [api.Context(0), api.Context(0)]
+    try:
+        for _ in range(3):
+            best, many = rl.relocalize(api, ctx, cands, workers=workers)
+            assert np.array_equal(many[:, 8], one[1][:, 8]) and np.array_equal(many[:, 0], one[1][:, 0])      # ids and integer scores
+            assert np.allclose(many[:, 1:8], one[1][:, 1:8], rtol=1e-9, atol=1e-12)                          # atomics reorder the last bits
+            assert (best is None) == (one[0] is None) and (best is None or best[0] == one[0][0])
+    finally:
+        for w in workers:
+            w.close()
+
+
 def test_argmax_over_candidates_with_different_overlap(ctx, oracle):
     """configs[4] with candidates whose overlap differs (synthetic.config5_candidates, overlap="varied"): the device's per-candidate
     Mapping::Relocate (score, relative pose) against the oracle restatement of mapping.cpp:251-300, and the arg-max of
