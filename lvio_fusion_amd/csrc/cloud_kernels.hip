@@ -397,7 +397,8 @@ int lvf_cloud_create(lvf_ctx* ctx, const float* points, int n, int stride_floats
   LVF_TRY(new_cloud(ctx, n, &c));
   if (n) {
     DevBuf<float> src;
-    int rc = src.upload(points, (size_t)n * stride_floats, ctx->stream);
+    HostPin<float> stage;                // (pooled pinned staging, released after the stream wait below: DevBuf::upload_staged)
+    int rc = src.upload_staged(points, (size_t)n * stride_floats, ctx->stream, stage);
     if (rc != LVF_OK) { delete c; return rc; }
     hipLaunchKernelGGL(k_cloud_pack, dim3(gridc(n)), dim3(kC), 0, ctx->stream, n, src.p, stride_floats, intensity_offset, c->pts.p);
     LVF_HIP(hipGetLastError());

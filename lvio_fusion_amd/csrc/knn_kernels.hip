@@ -510,7 +510,8 @@ static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_devic
     return LVF_OK;
   }
   DevBuf<float> src; DevBuf<unsigned> bounds;
-  if (!src_is_device && (rc = src.upload(map_xyz, (size_t)M * stride_floats, s)) != LVF_OK) return fail(rc);
+  HostPin<float> stage;                  // (released after the stream wait below)
+  if (!src_is_device && (rc = src.upload_staged(map_xyz, (size_t)M * stride_floats, s, stage)) != LVF_OK) return fail(rc);
   if ((rc = m->raw.alloc(M)) != LVF_OK || (rc = bounds.alloc(6)) != LVF_OK) return fail(rc);
   const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   LVF_HIP(hipMemcpyAsync(bounds.p, init, sizeof(init), hipMemcpyHostToDevice, s));
@@ -565,8 +566,9 @@ static int scan_create_impl(lvf_ctx* ctx, const float* scan_xyz, bool src_is_dev
   sc->ctx = ctx; sc->Q = Q;
   int rc = LVF_OK;
   DevBuf<float> src;
+  HostPin<float> stage;                  // (released after the stream wait below)
   if (Q > 0) {
-    if ((!src_is_device && (rc = src.upload(scan_xyz, (size_t)Q * stride_floats, ctx->stream)) != LVF_OK) || (rc = sc->pts.alloc(Q)) != LVF_OK ||
+    if ((!src_is_device && (rc = src.upload_staged(scan_xyz, (size_t)Q * stride_floats, ctx->stream, stage)) != LVF_OK) || (rc = sc->pts.alloc(Q)) != LVF_OK ||
         (rc = sc->idx.alloc((size_t)3 * Q)) != LVF_OK || (rc = sc->d2.alloc((size_t)3 * Q)) != LVF_OK || (rc = sc->valid.alloc(Q)) != LVF_OK) {
       delete sc; return rc;
     }
