@@ -3158,16 +3158,20 @@ static bool chain_stale(const lvf_problem* p) {
 enum { ST_IMU_LIN = 0, ST_LIN_VISUAL, ST_TF_REDUCE, ST_PREPARE, ST_SCHUR_SP0, ST_SP_LEVELS, ST_CHOL, ST_BACKSOLVE, ST_STEP_TAIL, ST_COST, ST_DECIDE, ST_N };
 static const char* const kStageNames[ST_N] = {"k_zero_multi (only when the accumulators are not known clean)", "k_lin_visual", "k_tf_reduce (+ sparse level 0)", "k_prepare (+ sparse level 1)", "k_schur_sp0 (+ a sparse level)", "k_sp_eliminate (the levels left)",
                                              "k_chol_step (all block steps)", "k_chol_backsolve", "k_step_tail", "k_cost_decide (candidate cost incl. the ImuError factors; its last workgroup closes the iteration; + prior passes)", "k_lm_decide (windows without visual blocks)"};
-struct StageClock { hipEvent_t ev[ST_N + 1]; int launches[ST_N]; bool on = false; };
+// (one event set per timed iteration: the iterations are enqueued back to back and waited for ONCE, so every stage — the first one of an
+// iteration included — starts behind a busy queue like in the device loop; with a wait per iteration the first stage absorbed the idle
+// queue's start-up, ~6 us of k_lin_visual's figure)
+constexpr int kClockReps = 16;
+struct StageClock { hipEvent_t ev[kClockReps][ST_N + 1]; int launches[ST_N]; bool on = false; int rep = 0; };
 void stage_clock_free(StageClock* k) {
   if (!k) return;
-  for (auto& e : k->ev) (void)hipEventDestroy(e);
+  for (auto& r : k->ev) for (auto& e : r) (void)hipEventDestroy(e);
   delete k;
 }
 static inline void stage_mark(lvf_problem* p, int stage_done, int launches) {
   StageClock* k = p->clk;
   if (!k || !k->on) return;
-  (void)hipEventRecord(k->ev[stage_done + 1], p->ctx->stream);
+  (void)hipEventRecord(k->ev[k->rep][stage_done + 1], p->ctx->stream);
   k->launches[stage_done] = launches;
 }
 
@@ -3184,7 +3188,7 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated, bool iter
   // only needed when they are not known to be clean (first linearisation after a configure, stand-alone gradient / reduced-system taps)
   const bool clean = c.fast && p->accum_clean;
   p->accum_clean = false;
-  if (p->clk && p->clk->on) (void)hipEventRecord(p->clk->ev[0], q);
+  if (p->clk && p->clk->on) (void)hipEventRecord(p->clk->ev[p->clk->rep][0], q);
   if (!clean) hipLaunchKernelGGL(k_zero_multi, dim3(512, c.zero.count), dim3(kT), 0, q, c.zero);
   if (c.fast) {
     imu_done = true;                           // the ImuError factors are evaluated inside the merged launch below
@@ -4076,29 +4080,32 @@ int lvf_problem_stage_times(lvf_problem* p, const lvf_solver_options* o, double 
   hipStream_t q = p->ctx->stream;
   if (!p->clk) {
     p->clk = new StageClock();
-    for (auto& e : p->clk->ev) LVF_HIP(hipEventCreate(&e));
+    for (auto& r : p->clk->ev) for (auto& e : r) LVF_HIP(hipEventCreate(&e));
   }
   StageClock& k = *p->clk;
   for (int i = 0; i < ST_N; ++i) { us[i] = 0.0; k.launches[i] = 0; }
+  reps = std::min(reps, kClockReps);
   LmCtl c;
-  ctl_from_options(o, radius, 2.0, reps + 1, false, &c);
+  ctl_from_options(o, radius, 2.0, reps + 2, false, &c);
   p->huber = o->huber_a;
   LVF_TRY(upload_ctl(p, c));
+  LVF_TRY(enqueue_iteration(p, true));             // (un-timed: the timed iterations queue up behind it)
   for (int r = 0; r < reps; ++r) {
-    k.on = true;
+    k.on = true; k.rep = r;
     const int rc = enqueue_iteration(p, true);
     k.on = false;
     LVF_TRY(rc);
-    LVF_HIP(hipStreamSynchronize(q));
+  }
+  LVF_HIP(hipStreamSynchronize(q));
+  for (int r = 0; r < reps; ++r)
     for (int i = 0; i < ST_N; ++i) {
       if (k.launches[i] == 0) continue;
       int prev = i;                                   // the event after the closest earlier stage that launched something (or event 0)
       while (prev > 0 && k.launches[prev - 1] == 0) --prev;
       float ms = 0.f;
-      LVF_HIP(hipEventElapsedTime(&ms, k.ev[prev], k.ev[i + 1]));
+      LVF_HIP(hipEventElapsedTime(&ms, k.ev[r][prev], k.ev[r][i + 1]));
       us[i] += 1e3 * (double)ms / reps;
     }
-  }
   if (launches) for (int i = 0; i < ST_N; ++i) launches[i] = k.launches[i];
   return LVF_OK;
 }
