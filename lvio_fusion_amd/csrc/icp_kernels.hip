@@ -265,7 +265,10 @@ extern "C" int lvf_icp_solve(lvf_map* m, lvf_scan* sc, const double* map_pose, c
   if (sc->corr.n < (size_t)9 * std::max(Q, 1)) LVF_TRY(sc->corr.alloc((size_t)9 * std::max(Q, 1)));
   if (!sc->icp_dev.p) LVF_TRY(sc->icp_dev.alloc(sizeof(IcpDev)));
   double* P = sc->corr.p; double* PA = P + (size_t)3 * Q; double* N = PA + (size_t)3 * Q;
-  IcpDev h;
+  // (the solver state travels through a pinned mirror owned by the scan: from a stack variable both copies went through the runtime's
+  // pageable path, a pin / unpin of the page per solve)
+  LVF_TRY(sc->icp_host.reserve(sizeof(IcpDev)));
+  IcpDev& h = *reinterpret_cast<IcpDev*>(sc->icp_host.p);
   init_dev(h, opt->mode, rpyxyz);
   const int i0 = opt->mode == 0 ? 1 : 0, i1 = opt->mode == 0 ? 2 : 3, i2 = opt->mode == 0 ? 5 : 4;
   IcpDev* dev = reinterpret_cast<IcpDev*>(sc->icp_dev.p);
@@ -295,7 +298,8 @@ extern "C" int lvf_lidar_solve(lvf_batch* b, double* rpyxyz, const lvf_icp_optio
   if (!b->icp_dev.p) LVF_TRY(b->icp_dev.alloc(sizeof(IcpDev)));
   lvf_icp_options o = *opt;
   o.mode = b->lidar_mode; o.weight = b->lidar_weight;
-  IcpDev h;
+  LVF_TRY(b->icp_host.reserve(sizeof(IcpDev)));
+  IcpDev& h = *reinterpret_cast<IcpDev*>(b->icp_host.p);
   init_dev(h, o.mode, rpyxyz);
   h.nvalid = b->n;
   IcpDev* dev = reinterpret_cast<IcpDev*>(b->icp_dev.p);

@@ -248,6 +248,7 @@ struct lvf_batch {
   double Twc1[7] = {0, 0, 0, 1, 0, 0, 0};
   lvf::DevBuf<double> lp, lpa, lnrm;     // SoA [3][n]
   lvf::DevBuf<char> icp_dev;             // device LM state of lvf_lidar_solve
+  lvf::HostPin<char> icp_host;           // its pinned host mirror (initial state up, result down: real asynchronous copies)
   // imu
   lvf::DevBuf<double> pre;               // [n][467] flattened lvf_preint
   lvf::DevBuf<double> sqrt_info;         // [n][225]
@@ -289,6 +290,7 @@ struct lvf_scan {
   bool searched = false;
   lvf::DevBuf<double> corr;          // ICP correspondences: p | pa | n, each SoA [3][Q]
   lvf::DevBuf<char> icp_dev;         // device-resident LM state of lvf_icp_solve
+  lvf::HostPin<char> icp_host;       // its pinned host mirror (initial state up, result down: real asynchronous copies)
 };
 
 struct lvf_cloud {
