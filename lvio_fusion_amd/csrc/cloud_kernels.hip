@@ -114,13 +114,13 @@ __global__ __launch_bounds__(kC) void k_cloud_bounds(int n, const float4* __rest
 static int cloud_bounds(const lvf_cloud* c, float lo[3], float hi[3]) {
   DevBuf<unsigned> b;
   LVF_TRY(b.alloc(6));
-  const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   hipStream_t s = c->ctx->stream;
-  LVF_HIP(hipMemcpyAsync(b.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+  // {+max, +max, +max, 0, 0, 0} as ordered-uint bounds: two memsets instead of a copy from a stack array (a pageable copy)
+  LVF_HIP(hipMemsetAsync(b.p, 0xff, 3 * sizeof(unsigned), s));
+  LVF_HIP(hipMemsetAsync(b.p + 3, 0, 3 * sizeof(unsigned), s));
   hipLaunchKernelGGL(k_cloud_bounds, dim3(std::min(kCapBlocks, gridc(c->n))), dim3(kC), 0, s, c->n, c->pts.p, b.p);
   unsigned h[6];
-  LVF_HIP(hipMemcpyAsync(h, b.p, sizeof(h), hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipStreamSynchronize(s));
+  LVF_TRY(read_back(c->ctx, h, b.p, sizeof(h)));
   for (int k = 0; k < 3; ++k) { lo[k] = ord2f_c(h[k]); hi[k] = ord2f_c(h[3 + k]); }
   for (int k = 0; k < 3; ++k)
     if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) { set_error("cloud has non-finite coordinates"); return LVF_ERR_INVALID; }
@@ -370,8 +370,7 @@ int compact_points(lvf_ctx* ctx, const float4* pts, int n, const int* flags_dev,
   LVF_TRY(pos.alloc((size_t)n + 1));
   LVF_TRY(device_exclusive_scan_i32(ctx, flags_dev, n, pos.p));
   int total = 0;
-  LVF_HIP(hipMemcpyAsync(&total, pos.p + n, sizeof(int), hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipStreamSynchronize(s));
+  LVF_TRY(read_back(ctx, &total, pos.p + n, sizeof(int)));
   LVF_TRY(new_cloud(ctx, total, out));
   if (total) hipLaunchKernelGGL(k_compact, dim3(gridc(n)), dim3(kC), 0, s, n, pts, flags_dev, pos.p, (*out)->pts.p);
   LVF_HIP(hipGetLastError());
@@ -509,8 +508,7 @@ int lvf_cloud_voxel_filter(const lvf_cloud* in, float leaf, lvf_cloud** out) {
   LVF_TRY(device_exclusive_scan_i32(ctx, counts.p, (int)ncell, start.p));
   LVF_TRY(device_exclusive_scan_i32(ctx, flags.p, (int)ncell, pos.p));
   int total = 0;
-  LVF_HIP(hipMemcpyAsync(&total, pos.p + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipStreamSynchronize(s));
+  LVF_TRY(read_back(ctx, &total, pos.p + ncell, sizeof(int)));
   lvf_cloud* c = nullptr;
   LVF_TRY(new_cloud(ctx, total, &c));
   hipLaunchKernelGGL(k_voxel_emit, dim3(gridc((int)ncell)), dim3(kC), 0, s, (int)ncell, in->pts.p, order.p, start.p, pos.p, c->pts.p);
@@ -577,8 +575,7 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
   hipLaunchKernelGGL(k_ransac_count, dim3(gx, max_iterations), dim3(kC), 0, s, n, in->pts.p, (unsigned long long)seed, distance_threshold, counts.p);
   LVF_HIP(hipGetLastError());
   std::vector<int> hc(max_iterations);
-  LVF_HIP(hipMemcpyAsync(hc.data(), counts.p, (size_t)4 * max_iterations, hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipStreamSynchronize(s));
+  LVF_TRY(read_back(ctx, hc.data(), counts.p, (size_t)4 * max_iterations));
   // pcl::RandomSampleConsensus::computeModel's bookkeeping, applied in hypothesis order
   int best = -1, best_count = 0, used = 0;
   double k = 1.0;
@@ -600,8 +597,12 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
   int id[3];
   sample3(seed, best, n, id);
   float4 sp[3];
-  for (int q = 0; q < 3; ++q) LVF_HIP(hipMemcpyAsync(&sp[q], in->pts.p + id[q], sizeof(float4), hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipStreamSynchronize(s));
+  {
+    LVF_TRY(ctx->mailbox.reserve(4096));
+    for (int q = 0; q < 3; ++q) LVF_HIP(hipMemcpyAsync(ctx->mailbox.p + 16 * q, in->pts.p + id[q], sizeof(float4), hipMemcpyDeviceToHost, s));
+    LVF_HIP(hipStreamSynchronize(s));
+    std::memcpy(sp, ctx->mailbox.p, sizeof(sp));
+  }
   float co[4];
   {
     const float ux = sp[1].x - sp[0].x, uy = sp[1].y - sp[0].y, uz = sp[1].z - sp[0].z, vx = sp[2].x - sp[0].x, vy = sp[2].y - sp[0].y, vz = sp[2].z - sp[0].z;
@@ -615,8 +616,7 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
   hipLaunchKernelGGL(k_plane_inliers, dim3(std::min(kCapBlocks, gridc(n))), dim3(kC), 0, s, n, in->pts.p, co[0], co[1], co[2], co[3], distance_threshold, flags.p, mom.p, mom_scale);
   LVF_HIP(hipGetLastError());
   MomI hm;
-  LVF_HIP(hipMemcpyAsync(&hm, mom.p, sizeof(hm), hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipStreamSynchronize(s));
+  LVF_TRY(read_back(ctx, &hm, mom.p, sizeof(hm)));
   double m[10];
   m[0] = (double)hm.v[0];
   for (int k = 0; k < 9; ++k) m[1 + k] = std::ldexp((double)(long long)hm.v[1 + 2 * k] * 16777216.0 + (double)hm.v[2 + 2 * k], -shift);

@@ -314,13 +314,20 @@ int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_float
   LVF_HIP(hipGetLastError());
   LVF_TRY(device_exclusive_scan_i32(ctx, flags.p, npix, pos.p));
   int num = 0;
-  LVF_HIP(hipMemcpyAsync(&num, pos.p + npix, sizeof(int), hipMemcpyDeviceToHost, s));
   float4 ends[2] = {make_float4(1, 0, 0, 0), make_float4(1, 0, 0, 0)};
-  if (m) {
-    LVF_HIP(hipMemcpyAsync(&ends[0], filtered->pts.p, sizeof(float4), hipMemcpyDeviceToHost, s));
-    LVF_HIP(hipMemcpyAsync(&ends[1], filtered->pts.p + (m - 1), sizeof(float4), hipMemcpyDeviceToHost, s));
+  {
+    // three small read-backs, one wait, through the context's pinned mailbox (lvf::read_back's reason)
+    LVF_TRY(ctx->mailbox.reserve(4096));
+    char* mb = ctx->mailbox.p;
+    LVF_HIP(hipMemcpyAsync(mb, pos.p + npix, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (m) {
+      LVF_HIP(hipMemcpyAsync(mb + 16, filtered->pts.p, sizeof(float4), hipMemcpyDeviceToHost, s));
+      LVF_HIP(hipMemcpyAsync(mb + 32, filtered->pts.p + (m - 1), sizeof(float4), hipMemcpyDeviceToHost, s));
+    }
+    LVF_HIP(hipStreamSynchronize(s));
+    std::memcpy(&num, mb, sizeof(int));
+    if (m) { std::memcpy(&ends[0], mb + 16, sizeof(float4)); std::memcpy(&ends[1], mb + 32, sizeof(float4)); }
   }
-  LVF_HIP(hipStreamSynchronize(s));
   // FindStartEndAngle (projection.cpp:42-56), host arithmetic like the reference
   OriP o;
   {

@@ -482,8 +482,7 @@ static int build_level(lvf_map* m, lvf_map::Level& lv, float cell, const float l
   hipLaunchKernelGGL(k_cell_scatter, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, cell_of.p, lv.cell_start.p, counts.p, lv.sorted.p);
   LVF_HIP(hipGetLastError());
   unsigned long long ss = 0;
-  LVF_HIP(hipMemcpyAsync(&ss, sumsq.p, sizeof(ss), hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipStreamSynchronize(s));   // temporaries are freed on return
+  LVF_TRY(read_back(m->ctx, &ss, sumsq.p, sizeof(ss)));   // (waits for the stream: temporaries are freed on return)
   *occupancy = (double)ss / (double)M;
   return LVF_OK;
 }
@@ -513,12 +512,12 @@ static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_devic
   HostPin<float> stage;                  // (released after the stream wait below)
   if (!src_is_device && (rc = src.upload_staged(map_xyz, (size_t)M * stride_floats, s, stage)) != LVF_OK) return fail(rc);
   if ((rc = m->raw.alloc(M)) != LVF_OK || (rc = bounds.alloc(6)) != LVF_OK) return fail(rc);
-  const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-  LVF_HIP(hipMemcpyAsync(bounds.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+  // {+max, +max, +max, 0, 0, 0} as ordered-uint bounds: two memsets instead of a copy from a stack array (a pageable copy)
+  LVF_HIP(hipMemsetAsync(bounds.p, 0xff, 3 * sizeof(unsigned), s));
+  LVF_HIP(hipMemsetAsync(bounds.p + 3, 0, 3 * sizeof(unsigned), s));
   hipLaunchKernelGGL(k_pack_bounds, dim3(std::min(kBoundsMaxBlocks, (M + kB - 1) / kB)), dim3(kB), 0, s, M, src_is_device ? map_xyz : src.p, stride_floats, m->raw.p, bounds.p);
   unsigned hb[6];
-  LVF_HIP(hipMemcpyAsync(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost, s));
-  LVF_HIP(hipStreamSynchronize(s));
+  if ((rc = read_back(ctx, hb, bounds.p, sizeof(hb))) != LVF_OK) return fail(rc);
   float lo[3], hi[3];
   for (int k = 0; k < 3; ++k) { lo[k] = ord2f(hb[k]); hi[k] = ord2f(hb[3 + k]); }
   for (int k = 0; k < 3; ++k)

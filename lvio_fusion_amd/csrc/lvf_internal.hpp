@@ -211,7 +211,31 @@ struct lvf_ctx {
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
+  lvf::HostPin<char> mailbox;       // pinned landing zone of the small read-backs (counters, bounds, moments): see lvf::read_back
 };
+
+namespace lvf {
+// Small device -> host read-back + wait, through the context's pinned mailbox: a copy into a stack variable takes the runtime's pageable
+// path (the page is pinned and unpinned around the copy, ~10-15 us each time; the map index alone reads back once per grid level).
+// One use at a time per context — every caller waits for the stream before it returns, and a context belongs to one host thread.
+inline int read_back(lvf_ctx* ctx, void* host_out, const void* dev, size_t bytes) {
+  if (bytes == 0) return LVF_OK;
+  if (bytes > 4096) {          // (not a scalar read-back: the plain path)
+    hipError_t e = hipMemcpyAsync(host_out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) return ::lvf::hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return ::lvf::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    return LVF_OK;
+  }
+  LVF_TRY(ctx->mailbox.reserve(4096));
+  hipError_t e = hipMemcpyAsync(ctx->mailbox.p, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e != hipSuccess) return ::lvf::hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+  e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ::lvf::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+  std::memcpy(host_out, ctx->mailbox.p, bytes);
+  return LVF_OK;
+}
+}  // namespace lvf
 
 struct lvf_state {
   lvf_ctx* ctx = nullptr;
