@@ -173,7 +173,7 @@ int lvf_state_set(lvf_state* st, int field, const double* host) {
   LVF_REQUIRE(st && host, "lvf_state_set: null argument");
   double* p; size_t n;
   LVF_TRY(state_field(st, field, &p, &n));
-  if (n) { LVF_HIP(hipMemcpyAsync(p, host, n * 8, hipMemcpyHostToDevice, st->ctx->stream)); LVF_HIP(hipStreamSynchronize(st->ctx->stream)); }
+  if (n) LVF_TRY(lvf::copy_up_wait(st->ctx, p, host, n * 8));
   return LVF_OK;
 }
 // dst <- src, every field, device to device on dst's stream; nothing is waited for (a later call on the same context is ordered after it)
@@ -195,8 +195,7 @@ int lvf_state_get(lvf_state* st, int field, double* host) {
   LVF_REQUIRE(st && host, "lvf_state_get: null argument");
   double* p; size_t n;
   LVF_TRY(state_field(st, field, &p, &n));
-  if (n) LVF_HIP(hipMemcpyAsync(host, p, n * 8, hipMemcpyDeviceToHost, st->ctx->stream));
-  LVF_HIP(hipStreamSynchronize(st->ctx->stream));
+  LVF_TRY(lvf::copy_down_wait(st->ctx, host, p, n * 8));
   return LVF_OK;
 }
 

@@ -212,6 +212,7 @@ struct lvf_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
   lvf::HostPin<char> mailbox;       // pinned landing zone of the small read-backs (counters, bounds, moments): see lvf::read_back
+  lvf::HostPin<char> stage;         // pinned staging of host arrays up to 1 MB that are copied and waited for in one call (lvf_state_set / _get)
 };
 
 namespace lvf {
@@ -233,6 +234,28 @@ inline int read_back(lvf_ctx* ctx, void* host_out, const void* dev, size_t bytes
   e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) return ::lvf::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
   std::memcpy(host_out, ctx->mailbox.p, bytes);
+  return LVF_OK;
+}
+// host array -> device / device -> host array, waited for, through the context's pinned staging when it is at most 1 MB (the same
+// reason: a pageable source / destination is pinned and unpinned around every copy)
+inline int copy_up_wait(lvf_ctx* ctx, void* dev, const void* host, size_t bytes) {
+  if (bytes == 0) return LVF_OK;
+  const void* src = host;
+  if (bytes <= ((size_t)1 << 20)) { LVF_TRY(ctx->stage.reserve(bytes)); std::memcpy(ctx->stage.p, host, bytes); src = ctx->stage.p; }
+  hipError_t e = hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) return ::lvf::hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+  e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ::lvf::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+  return LVF_OK;
+}
+inline int copy_down_wait(lvf_ctx* ctx, void* host, const void* dev, size_t bytes) {
+  const bool staged = bytes > 0 && bytes <= ((size_t)1 << 20);
+  if (staged) LVF_TRY(ctx->stage.reserve(bytes));
+  hipError_t e = bytes ? hipMemcpyAsync(staged ? (void*)ctx->stage.p : host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+  if (e != hipSuccess) return ::lvf::hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+  e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ::lvf::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+  if (staged) std::memcpy(host, ctx->stage.p, bytes);
   return LVF_OK;
 }
 }  // namespace lvf
