@@ -89,6 +89,14 @@ typedef struct lvf_preint {
 const char* lvf_last_error(void);
 const char* lvf_version(void);
 
+/* Host memory the device can copy from without the runtime pinning and unpinning the pages around every copy (page-locked, recycled
+ * process-wide in size buckets).  For arrays that are filled on the host and then handed to lvf_*_create / lvf_state_set: the adapter
+ * (include/lvf_ceres_adapter.hpp) records the window's block lists straight into it while Backend::BuildProblem adds blocks
+ * (src/lvio_fusion/src/backend.cpp:96-183), so gpu::Solve's uploads are plain DMA.  Falls back to ordinary memory when no device is
+ * usable (host-only tools).  lvf_host_free takes the SAME byte count the block was allocated with.  Thread-safe. */
+void* lvf_host_alloc(size_t bytes);
+void lvf_host_free(void* p, size_t bytes);
+
 /* ---- context ------------------------------------------------------------------------------ */
 /* stream: an existing hipStream_t to run on (e.g. the caller's), or NULL to create a private one. */
 int lvf_ctx_create(int device, void* hip_stream, lvf_ctx** out);

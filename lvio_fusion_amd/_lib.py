@@ -95,6 +95,8 @@ _VP = C.c_void_p
 _SIGS = {
     "lvf_last_error": (C.c_char_p, []),
     "lvf_version": (C.c_char_p, []),
+    "lvf_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "lvf_host_free": (None, [C.c_void_p, C.c_size_t]),
     "lvf_ctx_create": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     "lvf_ctx_destroy": (C.c_int, [_VP]),
     "lvf_ctx_synchronize": (C.c_int, [_VP]),

@@ -1,4 +1,5 @@
 // capi.hip — the extern "C" surface of include/lvf.h: context, parameter state, factor batches.
+#include <cstdlib>
 #include "lvf_internal.hpp"
 
 namespace lvf {
@@ -75,6 +76,38 @@ const char* lvf_last_error(void) { return g_err.c_str(); }
 const char* lvf_version(void) { return "lvio_fusion_amd 0.1 (gfx950)"; }
 
 // ------------------------------------------------------------------------------------------------ context
+// Pinned host blocks for callers (lvf.h): a 64-byte header in front of the user pointer says whether the block is page-locked (then it
+// is parked in the process-wide HostPinPool by bucket size) or ordinary memory (no usable device: host-only tools).
+namespace {
+struct HostHdr { unsigned long long magic; unsigned long long bucket; int pinned; int pad[11]; };
+static_assert(sizeof(HostHdr) == 64, "the user pointer keeps 64-byte alignment");
+constexpr unsigned long long kHostMagic = 0x4c56465f484f5354ull;     // "LVF_HOST"
+}
+void* lvf_host_alloc(size_t bytes) {
+  const size_t bucket = lvf::Pool::bucket(bytes + sizeof(HostHdr));
+  void* base = lvf::HostPinPool::get().take(bucket);
+  int pinned = 1;
+  if (!base) {
+    if (hipHostMalloc(&base, bucket, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      base = std::malloc(bucket);
+      pinned = 0;
+      if (!base) return nullptr;
+    }
+  }
+  HostHdr* h = static_cast<HostHdr*>(base);
+  h->magic = kHostMagic; h->bucket = bucket; h->pinned = pinned;
+  return static_cast<char*>(base) + sizeof(HostHdr);
+}
+void lvf_host_free(void* p, size_t /*bytes*/) {
+  if (!p) return;
+  HostHdr* h = reinterpret_cast<HostHdr*>(static_cast<char*>(p) - sizeof(HostHdr));
+  if (h->magic != kHostMagic) return;                   // not ours: leave it alone rather than corrupt a heap
+  h->magic = 0;
+  if (!h->pinned) { std::free(h); return; }
+  if (!lvf::HostPinPool::get().give(h, (size_t)h->bucket)) (void)hipHostFree(h);
+}
+
 int lvf_ctx_create(int device, void* hip_stream, lvf_ctx** out) {
   LVF_REQUIRE(out, "lvf_ctx_create: out is null");
   int count = 0;
