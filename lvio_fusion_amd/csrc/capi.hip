@@ -90,7 +90,7 @@ void* lvf_host_alloc(size_t bytes) {
   if (!base) {
     if (hipHostMalloc(&base, bucket, hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
-      base = std::malloc(bucket);
+      base = std::aligned_alloc(64, (bucket + 63) & ~(size_t)63);      // (the user pointer keeps the 64-byte alignment of a page-locked block)
       pinned = 0;
       if (!base) return nullptr;
     }

@@ -93,3 +93,21 @@ def test_recorded_window_equals_walk_host_only(tmp_path):
         assert out["walk_ok"] == 1 and out["recorder_usable"] == 1 and out["recorded_equals_walk"] == 1, out
         assert out["n_kf"] == cfg["n_kf"] and out["blocks"] >= len(tf["lm_idx"]) + len(tc["lm_idx"])
         assert (out["n_prior"] > 0) == (not with_imu)
+
+
+def test_host_alloc_works_without_a_device():
+    """lvf_host_alloc hands out page-locked memory on a GPU box and ordinary memory elsewhere (host-only tools): usable, 64-byte aligned,
+    and lvf_host_free takes it back either way; a pointer that is not ours is left alone."""
+    import ctypes as C
+    from lvio_fusion_amd import _lib
+    L = _lib.lib()
+    blocks = []
+    for n in (1, 4096, 300000):
+        p = L.lvf_host_alloc(n)
+        assert p and p % 64 == 0
+        C.memset(p, 0xAB, n)
+        assert (C.c_ubyte * n).from_address(p)[n - 1] == 0xAB
+        blocks.append((p, n))
+    for p, n in blocks:
+        L.lvf_host_free(p, n)
+    L.lvf_host_free(None, 0)
