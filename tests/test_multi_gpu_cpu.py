@@ -139,3 +139,35 @@ def test_gloo_world4_a_rank_failing_mid_evaluation_does_not_hang(tmp_path):
     lost = rl.owned(8, 2, 4)[1]
     assert all(o["live"] == [c for c in range(8) if c != lost] for o in outs)
     assert len({tuple(o["best"]) for o in outs}) == 1
+
+
+def test_worker_contexts_fill_the_same_slots_as_one_stream(monkeypatch):
+    """relocalize(..., workers=): a rank's candidates are dealt round-robin to its contexts and evaluated by one host thread each; the
+    records must land in the slots the one-stream loop fills (host logic only: the evaluation is scripted)."""
+    import threading
+    from lvio_fusion_amd import relocalize as rl
+
+    class Res:
+        def __init__(self, cid):
+            self.score = 20 + (cid * 7) % 13
+            self.relative_o_c = [0.0, 0.0, 0.0, 1.0, float(cid), 0.5 * cid, -1.0]
+
+    seen = {}
+
+    def fake_eval(api, ctx, cand, resolution=0.2):
+        seen.setdefault(ctx, []).append((cand["id"], threading.get_ident()))
+        return Res(cand["id"])
+    monkeypatch.setattr(rl, "evaluate_candidate", fake_eval)
+    cands = [{"id": i} for i in range(11)]
+    for world in (1, 2):
+        for rank in range(world):
+            one = rl.empty_records(rl.slots(len(cands), world))
+            for s, cid in enumerate(rl.owned(len(cands), rank, world)):
+                one[s] = rl.make_record(cid, Res(cid).score, np.array(Res(cid).relative_o_c))
+            seen.clear()
+            monkeypatch.setattr(rl, "gather_records", lambda local, w, device=None: local.copy())
+            best, many = rl.relocalize(None, "ctx0", cands, rank=rank, world=world, workers=["ctx1", "ctx2"])
+            assert np.array_equal(many, one)
+            assert set(seen) == {"ctx0", "ctx1", "ctx2"}                                   # every context got work ...
+            assert all(len({t for _, t in v}) == 1 for v in seen.values())                # ... from one thread each
+            assert sorted(c for v in seen.values() for c, _ in v) == rl.owned(len(cands), rank, world)
