@@ -1,0 +1,32 @@
+"""configs[4] timing by part: where one loop-closure candidate's time goes on one stream (host masking, map indices, scan uploads,
+the 4 x {ground, surf} solves).  Mapping::Relocate = src/lvio_fusion/src/mapping.cpp:251-300."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from lvio_fusion_amd import api, synthetic as syn
+ctx = api.Context(0)
+cands = syn.config5_candidates(8)
+opt = api.scan_match_options(0.2, outer_iterations=4, prior_weight=0.0)
+T = {k: 0.0 for k in ("mask", "map_ground", "map_surf", "scans", "scan_match", "close")}
+for rep in range(3):
+    for k in T:
+        T[k] = 0.0
+    for c in cands:
+        t = time.perf_counter()
+        mg, ms = c["map"][c["map_ground"]], c["map"][~c["map_ground"]]
+        qg, qs = c["query"][c["query_ground"]], c["query"][~c["query_ground"]]
+        T["mask"] += time.perf_counter() - t; t = time.perf_counter()
+        mpg = api.Map(ctx, mg, opt.thr_ground); ctx.synchronize()
+        T["map_ground"] += time.perf_counter() - t; t = time.perf_counter()
+        mps = api.Map(ctx, ms, opt.thr_surf); ctx.synchronize()
+        T["map_surf"] += time.perf_counter() - t; t = time.perf_counter()
+        scg, scs = api.Scan(ctx, qg), api.Scan(ctx, qs); ctx.synchronize()
+        T["scans"] += time.perf_counter() - t; t = time.perf_counter()
+        res = api.scan_match(mpg, scg, mps, scs, c["map_pose"], c["init_pose"], opt, last_pose=c["last_pose"])
+        T["scan_match"] += time.perf_counter() - t; t = time.perf_counter()
+        for h in (mpg, scg, mps, scs):
+            h.close()
+        T["close"] += time.perf_counter() - t
+    print("8 candidates by part (ms): " + "  ".join("%s %.2f" % (k, 1e3 * v) for k, v in T.items()) + "  total %.2f" % (1e3 * sum(T.values())))
+print("sizes of candidate 0: map ground / surf %d / %d, query ground / surf %d / %d" % (
+    int(cands[0]["map_ground"].sum()), int((~cands[0]["map_ground"]).sum()), int(cands[0]["query_ground"].sum()), int((~cands[0]["query_ground"]).sum())))
