@@ -343,6 +343,8 @@ typedef struct lvf_solver_summary {
   int termination; /* 0 convergence, 1 no_convergence (iteration/time cap), 2 failure */
   int num_unsuccessful_steps; /* rejected + invalid steps (Summary::num_unsuccessful_steps) */
   int termination_reason;     /* LVF_WHY_*: which test of ceres::Solve's TrustRegionMinimizer ended the loop */
+  int hand_over_retries;      /* iterations this problem has re-run (over its lifetime) because an in-launch hand-over between chained sparse levels
+                               * timed out on a busy GPU; each was repeated with un-chained launches — results are unaffected, only slower */
 } lvf_solver_summary;
 /* ceres::Solve's termination tests in the order the loop applies them (upstream trust_region_minimizer.cc; the test oracle restates the same loop):
  * before a step — gradient_max_norm <= gradient_tolerance, radius < 1e-32 (both CONVERGENCE, the pass does not count as an iteration);
@@ -350,7 +352,8 @@ typedef struct lvf_solver_summary {
  * with the candidate — step_norm <= parameter_tolerance (x_norm + parameter_tolerance), then |cost - candidate_cost| <= function_tolerance cost
  * (both CONVERGENCE, the candidate is NOT taken); after the step — num_iterations >= max_num_iterations (NO_CONVERGENCE), radius < 1e-32. */
 enum { LVF_WHY_NONE = 0, LVF_WHY_GRADIENT = 1, LVF_WHY_PARAMETER = 2, LVF_WHY_FUNCTION = 3, LVF_WHY_MIN_RADIUS = 4, LVF_WHY_MAX_ITERATIONS = 5,
-       LVF_WHY_INVALID_STEPS = 6, LVF_WHY_TIME = 7 };
+       LVF_WHY_INVALID_STEPS = 6, LVF_WHY_TIME = 7,
+       LVF_WHY_HANDOVER = 8 /* internal: the device loop stopped for a hand-over retry; only reported if the retry could not run either */ };
 void lvf_solver_options_default(lvf_solver_options* o);
 /* The problem borrows the state and the batches (they must outlive it).  Any of the batch pointers may
  * be NULL.  Pose blocks use ProductParameterization(EigenQuaternion, Identity3) (backend.cpp:99-101). */
@@ -390,7 +393,9 @@ int lvf_problem_download_reduced(lvf_problem* p, double* S, double* rhs);
  * no IMU blocks) make the batch fall back to running the windows' own chains back to back on the context's stream.
  * All result arrays have one entry per window, in the order of `problems`. */
 int lvf_problem_batch_create(lvf_ctx* ctx, lvf_problem* const* problems, int n, lvf_problem_batch** out);
-/* The batch BORROWS its problems and resets their slice width on destruction: destroy the batch BEFORE any of its problems. */
+/* The batch BORROWS its problems and changes nothing of theirs (its wider Schur slices and their work lists are the batch's own): a window
+ * solved alone, in a batch, and alone again runs the same arithmetic the first and the third time.  Destroy order is free: a batch whose
+ * member was destroyed first is marked orphaned (later calls on it return LVF_ERR_STATE) and may still be destroyed. */
 int lvf_problem_batch_destroy(lvf_problem_batch* b);
 int lvf_problem_batch_size(const lvf_problem_batch* b);
 /* 1: table launches (one chain for all windows), 0: fallback, -1: error */
@@ -409,6 +414,10 @@ int lvf_problem_stage_times(lvf_problem* p, const lvf_solver_options* o, double 
 /* Problem::Evaluate's gradient at the current state: J^T r with the Corrector applied and pose blocks in tangent coordinates.
  * gc[15 n_kf] = (6 x n_kf pose tangents | 9 x n_kf (v, ba, bg)); gl[n_lm] (may be NULL) = the inverse-depth entries.  Constant poses: 0. */
 int lvf_problem_gradient(lvf_problem* p, const lvf_solver_options* o, double* gc, double* gl);
+/* Test hook (tests/test_gpu_solver.py): the next n chained hand-overs of this problem wait for a producer that never arrives and time out
+ * after 20 us, so the retry path (LVF_WHY_HANDOVER -> un-chained re-run, lvf_solver_summary::hand_over_retries) can be exercised on an
+ * idle GPU.  Also re-enables chaining for the problem.  Not part of the reference surface. */
+int lvf_problem_debug_force_handover_timeout(lvf_problem* p, int n);
 
 /* ---- loop-correction tail: Relocator::UpdateNewSubmap / PoseGraph::ForwardUpdate ---------------------------------- */
 /* RelocateRError <7,4> (pose_error.hpp:192-222) batched: block i = RelocateRError(relocated[i], unrelocated[i]) evaluated at the shared

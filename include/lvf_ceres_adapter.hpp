@@ -927,8 +927,8 @@ inline bool solve_window(const ceres::Solver::Options& options, ceres::Problem* 
   static const char* const kWhy[] = {"", "Gradient tolerance reached.", "Parameter tolerance reached.", "Function tolerance reached.",
                                     "Minimum trust region radius reached.", "Maximum number of iterations reached.",
                                     "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps.",
-                                    "Maximum solver time reached."};
-  summary->message = std::string("sliding-window BA solved on device. ") + kWhy[s.termination_reason >= 0 && s.termination_reason <= 7 ? s.termination_reason : 0];
+                                    "Maximum solver time reached.", "In-launch hand-over timed out and the un-chained retry could not run."};
+  summary->message = std::string("sliding-window BA solved on device. ") + kWhy[s.termination_reason >= 0 && s.termination_reason <= 8 ? s.termination_reason : 0];
   summary->preprocessor_time_in_seconds += classify_seconds + std::chrono::duration<double>(t1 - t0).count();   // classify + upload (collect() is added by Solve)
   summary->minimizer_time_in_seconds = std::chrono::duration<double>(t2 - t1).count();
   summary->postprocessor_time_in_seconds = std::chrono::duration<double>(clk::now() - t2).count();

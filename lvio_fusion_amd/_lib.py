@@ -69,10 +69,10 @@ class SolverOptions(C.Structure):
 class SolverSummary(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("num_iterations", C.c_int),
                 ("num_successful_steps", C.c_int), ("num_residual_blocks", C.c_int), ("termination", C.c_int),
-                ("num_unsuccessful_steps", C.c_int), ("termination_reason", C.c_int)]
+                ("num_unsuccessful_steps", C.c_int), ("termination_reason", C.c_int), ("hand_over_retries", C.c_int)]
 
     WHY = ("none", "gradient_tolerance", "parameter_tolerance", "function_tolerance", "min_trust_region_radius", "max_num_iterations",
-           "consecutive_invalid_steps", "max_solver_time")          # LVF_WHY_* (include/lvf.h)
+           "consecutive_invalid_steps", "max_solver_time", "hand_over_retry_failed")          # LVF_WHY_* (include/lvf.h)
 
     @property
     def why(self):
@@ -133,6 +133,7 @@ _SIGS = {
     "lvf_problem_batch_create": (C.c_int, [_VP, C.POINTER(_VP), C.c_int, C.POINTER(_VP)]),
     "lvf_problem_batch_destroy": (C.c_int, [_VP]),
     "lvf_problem_batch_size": (C.c_int, [_VP]),
+    "lvf_problem_debug_force_handover_timeout": (C.c_int, [_VP, C.c_int]),
     "lvf_problem_batch_uses_tables": (C.c_int, [_VP, C.POINTER(SolverOptions)]),
     "lvf_problem_batch_lm_iteration": (C.c_int, [_VP, C.POINTER(SolverOptions), c_double_p, c_double_p, c_double_p, c_double_p, c_int_p]),
     "lvf_problem_batch_solve": (C.c_int, [_VP, C.POINTER(SolverOptions), C.POINTER(SolverSummary)]),

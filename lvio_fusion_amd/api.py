@@ -572,6 +572,10 @@ class Problem:
         _chk(self.ctx.L.lvf_problem_solve(self.h, C.byref(opt), C.byref(s)))
         return s
 
+    def debug_force_handover_timeout(self, n=1):
+        """test hook: the next n chained hand-overs of this problem time out (lvf_problem_debug_force_handover_timeout)"""
+        _chk(self.ctx.L.lvf_problem_debug_force_handover_timeout(self.h, int(n)))
+
     def stage_times(self, opt, radius=1e4, reps=10):
         """[(stage name, average microseconds, launches)] of `reps` LM iterations from the current state (HIP events between stages)."""
         L = self.ctx.L

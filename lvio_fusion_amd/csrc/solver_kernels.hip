@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 #include <unordered_map>
 
 #include "factor_eval.hpp"
@@ -36,9 +37,14 @@ struct SpSrc {
   const double* B; int ldB, dp; const double* gc; const double* radius; const int* rows_nat;
   // levels CHAINED inside one launch (the Schur complement's: it lasts long enough for three of them): the level waits until `wait_target`
   // workgroups of the level below have arrived at *wait_counter, and arrives at *done_counter itself.  What it reads of the level
-  // below are atomic adds into S (agent scope), read back with agent-scope atomic loads — no fences (MI355X_MICROARCH.md, "8-byte agent
-  // atomics both sides").  Producers carry lower workgroup numbers than their consumers, so they are dispatched first.
+  // below are RETURNING atomic adds into S (agent scope), read back with agent-scope atomic loads; the arrival is a RELEASE add, the
+  // waiting side follows its spin with an agent-scope ACQUIRE fence in every wave (`fenced`, default; LVF_CHAIN_FENCE=0: the relaxed
+  // round-3 form for A/B timing).  Producers carry lower workgroup numbers than their consumers, so they are normally dispatched
+  // first — nothing DEPENDS on that: a consumer that does not see its producers within `timeout_ticks` raises the hand-over flag
+  // (SC_FAIL >= kFailHandover), the decision ends the loop WITHOUT taking or counting the step (LVF_WHY_HANDOVER) and the host re-runs
+  // the iteration with every level in a launch of its own (lvf_problem::no_chain) — a scheduling delay never becomes a numerical outcome.
   int* wait_counter; int wait_target; int* done_counter;
+  int fenced; unsigned timeout_ticks;      // wall_clock64() ticks (100 MHz) before the hand-over is given up
   int strip_end;           // S rows / columns below it belong to sparse blocks (lvf_problem::off)
   int rmw_read;            // diagnostic: chained reads by returning atomics instead of agent-scope loads
   unsigned long long* dbg; // LVF_SP_TIMING=1: eight wall_clock64() stamps per workgroup (tile 0 of every node), else null
@@ -49,6 +55,9 @@ struct SpArgs {          // one sparse level
   SpSrc src;
 };
 __device__ __forceinline__ void sp_ride(const int vb, const SpArgs& a);     // workgroup vb of the level (defined with k_sp_eliminate)
+// SC_FAIL codes (raised with atomicMax: the largest wins): 1 + kb = dense block step kb met a non-positive pivot, kFailSparse + id = sparse
+// block id did, kFailHandover + id = a chained level gave up waiting for the level below (NOT a property of the problem: see SpSrc)
+constexpr int kFailSparse = 100000, kFailHandover = 300000;
 }
 struct lvf_problem {
   lvf_ctx* ctx = nullptr;
@@ -75,6 +84,8 @@ struct lvf_problem {
   int band_rows = 64;           // landmark rows per slice of the band Schur complement (a batch uses more: fewer output atomics)
   lvf::DevBuf<int4> band_work; lvf::DevBuf<int> n_band_work_dev; lvf::HostPin<int> h_n_band_work;
   int n_band_work = 0, band_rows_built = 0;
+  int band_epoch = 0;                 // bumped whenever the landmark bands change (a batch keeps its own, wider-slice work lists: lvf_problem_batch)
+  std::vector<lvf_problem_batch*> batches;      // the batches that borrow this problem (they are told when it is destroyed)
   lvf::HostPin<int> h_run_first;
   lvf::DevBuf<unsigned long long> dbg, dbg_lin, dbg_sp;
   lvf::DevBuf<double> sp_sync;                  // arrival counters of sparse levels chained inside one launch (one 8-byte slot per level, an int in each; cleared with the accumulators)
@@ -110,6 +121,9 @@ struct lvf_problem {
   lvf::HostPin<lvf::LmCtl> h_ctl;     // pinned staging for uploads / read-backs of the control block
   lvf::Chain* chain = nullptr;        // argument blocks of one iteration
   bool chain_ready = false;
+  bool no_chain = false;              // a chained hand-over timed out once: this problem's levels stay launches of their own from then on
+  int handover_retries = 0;           // iterations re-run because of that (reported in lvf_solver_summary::hand_over_retries)
+  int force_handover_timeouts = 0;    // test hook (lvf_problem_debug_force_handover_timeout): the next chain is built with an unreachable wait target
   const void* chain_state[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // the state pointers the chain was built for
   double huber = 1.0;
   hipGraphExec_t graph_exec = nullptr;
@@ -1957,7 +1971,7 @@ __device__ __forceinline__ void chol_step_body(const int bx, const CholArgs& A, 
   if (panel_wave) factor_panel_wave(a, r, q, F, nsteps);
   else bad = factor_diag_wave(a, r, q, F, nsteps);
   if (dbg) { dbg[4] = wall_clock64(); dbg[7] = clock64(); }
-  if (bad && r == 0) atomicExch(fail, 1 + kb);
+  if (bad && r == 0) atomicMax(fail, 1 + kb);
   if (bx == 0 && !panel_wave) {
 #pragma unroll
     for (int tt = 0; tt < 16; ++tt) if (16 * q + tt > r) a[tt] = 0.0;
@@ -1989,7 +2003,7 @@ __global__ __launch_bounds__(kCT) void k_chol_step_bt(const CholArgs* __restrict
 __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __restrict__ nodes, int first, int tiles, const int* __restrict__ rows,
                                                   double* __restrict__ S, int ld, double* __restrict__ W, int wstride,
                                                   double* __restrict__ Lout, int* __restrict__ fail, const int* done = nullptr,
-                                                  const SpSrc src = SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0}) {
+                                                  const SpSrc src = SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 1, 200000u, 0, 0, nullptr, 0}) {
   extern __shared__ double sp_sm[];        // Ws[m][9] | L[81] | linv[9] | rws[m] (int) | rnat[m] (int, early form)
   const int dv = done_flag_issue(done);
   const int ni = first + vb / tiles, tile = vb % tiles, tid = threadIdx.x;
@@ -1999,9 +2013,10 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
   const double radius = src.B ? *src.radius : 1.0;
   if (dv) return;
   const bool chained = src.wait_counter != nullptr;
-  // an entry of S the level below may have added into during THIS launch: read where the adds were performed, by a returning atomic
-  // (adding zero).  An agent-scope atomic LOAD is served by this XCD's L2, which may still hold the line as an earlier level's plain loads
-  // brought it in (a line spans two blocks' columns) — measured: 5 of 12 runs of the 8-keyframe / 20 000-landmark case came out wrong.
+  // an entry of S the level below may have added into during THIS launch: an agent-scope atomic load behind the acquire fence that
+  // follows the wait (the adds it must see were RETURNING atomics performed before the producer's release arrival; the wrong results
+  // round 3 chased — 5 of 12 runs of the 8-keyframe / 20 000-landmark case — came from RETURNLESS adds on the producer side, not from
+  // this load).  rmw_read (LVF_CHAIN_RMW_READ=1, diagnostic): a returning atomic adding zero instead — same results, 7 us slower.
   auto ld_s = [&](double* ptr) -> double {
     if (!chained) return *ptr;
     return src.rmw_read ? __hip_atomic_fetch_add(ptr, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2048,15 +2063,19 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
   }
   if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[1] = wall_clock64(); }      // (timing only: phase A's requests have landed)
   if (chained) {
-    // bounded: if the level below never arrives (a dispatch order this code does not expect) the step is flagged as failed instead of hanging
+    // bounded: if the level below does not arrive in time (workgroups of another stream or process took the CUs its producers needed, or
+    // a dispatch order this code does not expect) the hand-over flag is raised instead of hanging; the step is then NOT judged: see SpSrc
     if (tid == 0) {
       const unsigned long long t0 = wall_clock64();
       while (__hip_atomic_fetch_add(src.wait_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < src.wait_target) {
         __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > 200000ull) { atomicExch(fail, 300000 + nd.id); break; }      // 2 ms at 100 MHz
+        if (wall_clock64() - t0 > (unsigned long long)src.timeout_ticks) { atomicMax(fail, kFailHandover + nd.id); break; }
       }
     }
     asm volatile("s_barrier" ::: "memory");           // (not __syncthreads(): the requests above stay in flight across it)
+    // every wave orders its reads of S behind the producers' release arrivals (agent scope: the L1 copy of a line an earlier level's
+    // plain loads brought in is dropped; phase A's requests have long landed while the wave sat at the barrier)
+    if (src.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   if (stamp) stamp[2] = wall_clock64();
   // ---- phase B: what the level below added into S
@@ -2105,7 +2124,7 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
 #pragma unroll
       for (int c = 0; c < 9; ++c) L[lane * 9 + c] = (c <= lane) ? a[c] : 0.0;
     }
-    if (bad && lane == 0) atomicExch(fail, 100000 + nd.id);
+    if (bad && lane == 0) atomicMax(fail, kFailSparse + nd.id);
   }
   if (stamp) stamp[4] = wall_clock64();
   __syncthreads();
@@ -2189,12 +2208,15 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
         if (v != 0.0) sink += __hip_atomic_fetch_add(&S[(size_t)rws[r] * ld + rws[c2]], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (sink == -1.2345678901234567e301) atomicExch(fail, 400000);     // (never: keeps the returns alive)
+    if (sink == -1.2345678901234567e301) atomicMax(fail, 50000);     // (never: keeps the returns alive)
   }
   if (stamp) stamp[5] = wall_clock64();
   if (src.done_counter) {
     __syncthreads();                       // every wave has its returns (the barrier drains vmcnt)
-    if (tid == 0) __hip_atomic_fetch_add(src.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      if (src.fenced) __hip_atomic_fetch_add(src.done_counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_fetch_add(src.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (stamp) stamp[6] = wall_clock64();
   const int m2 = m - ns, P = m2 * (m2 + 1) / 2;                          // the triangle over rows / columns [ns, m)
@@ -2657,7 +2679,10 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
     // ceres::Solve's TrustRegionMinimizer, in its order (declared semantics + citations: oracle/lm.h lm_solve).
     // Top of the loop (FinalizeIterationAndCheckIfMinimizerCanContinue): the gradient at the point this pass linearised — it ends the
     // solve before a step is taken, so the pass is NOT an iteration; the smallest trust region likewise.
-    if (gmax <= lc.gradient_tol) { done = true; termination = 0; why = LVF_WHY_GRADIENT; }
+    // a chained sparse level gave up waiting for the level below (SpSrc): nothing about this step is judged — the loop stops where it is
+    // (state, radius and counters untouched) and the host re-runs the iteration with un-chained launches
+    if (hfail >= kFailHandover) { done = true; termination = 2; why = LVF_WHY_HANDOVER; }
+    else if (gmax <= lc.gradient_tol) { done = true; termination = 0; why = LVF_WHY_GRADIENT; }
     else if (lc.radius < 1e-32) { done = true; termination = 0; why = LVF_WHY_MIN_RADIUS; }
     else {
       // (num_iterations = what Ceres records in Summary::iterations: accepted, rejected and invalid steps; a trial step that ends the solve
@@ -2837,8 +2862,12 @@ struct Chain {
 };
 
 void stage_clock_free(StageClock* k);
+void batch_orphan(lvf_problem_batch* b, lvf_problem* dying);
 }  // namespace lvf
 lvf_problem::~lvf_problem() {
+  // a batch that still borrows this problem must never dereference it again: it is marked orphaned (its calls fail with LVF_ERR_STATE)
+  // and forgets every member, so destroying it later touches nothing
+  for (lvf_problem_batch* b : batches) lvf::batch_orphan(b, this);
   delete chain;
   lvf::stage_clock_free(clk);
   if (rec && !lvf::HostPinPool::get().give(rec, lvf::Pool::bucket(sizeof(lvf::LmCtl)))) (void)hipHostFree(rec);
@@ -2923,19 +2952,26 @@ static void fill_back_args(lvf_problem* p, BackArgs& ba, size_t* lds_bytes) {
 }
 
 // the work list of the band Schur complement for the current rows-per-slice setting; its length is part of the launch grid
-static int ensure_band_work(lvf_problem* p) {
-  if (!p->band_ready || p->n_lm == 0 || p->band_rows_built == p->band_rows) return LVF_OK;
+static inline int band_rows_clamped(int rows) { return std::min(kBandRowsMax, std::max(16, rows)); }
+// work list of p's band Schur complement for `rows` landmark rows per slice, into buffers of the caller's (the problem's own list, or a
+// batch's: a batch sums over wider slices and must not touch its members)
+static int build_band_work(lvf_problem* p, int rows_in, DevBuf<int4>& work, int* n_work) {
   hipStream_t q = p->ctx->stream;
-  const int rows = std::min(kBandRowsMax, std::max(16, p->band_rows));
+  const int rows = band_rows_clamped(rows_in);
   const int n_slices = (p->n_lm + rows - 1) / rows;
   const int nt = p->ldE / 16, groups_max = (nt * (nt + 1) / 2 + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
-  LVF_TRY(p->band_work.ensure((size_t)n_slices * groups_max)); LVF_TRY(p->n_band_work_dev.ensure(1)); LVF_TRY(p->h_n_band_work.reserve(1));
+  LVF_TRY(work.ensure((size_t)n_slices * groups_max)); LVF_TRY(p->n_band_work_dev.ensure(1)); LVF_TRY(p->h_n_band_work.reserve(1));
   LVF_HIP(hipMemsetAsync(p->n_band_work_dev.p, 0, sizeof(int), q));
-  hipLaunchKernelGGL(k_band_work, dim3(n_slices), dim3(64), 0, q, rows, p->dp, p->lm_nactive.p, p->lm_order.p, p->lm_kmin.p, p->lm_kmax.p, p->band_work.p, p->n_band_work_dev.p);
+  hipLaunchKernelGGL(k_band_work, dim3(n_slices), dim3(64), 0, q, rows, p->dp, p->lm_nactive.p, p->lm_order.p, p->lm_kmin.p, p->lm_kmax.p, work.p, p->n_band_work_dev.p);
   LVF_HIP(hipGetLastError());
   LVF_HIP(hipMemcpyAsync(p->h_n_band_work.p, p->n_band_work_dev.p, sizeof(int), hipMemcpyDeviceToHost, q));
   LVF_HIP(hipStreamSynchronize(q));
-  p->n_band_work = p->h_n_band_work[0];
+  *n_work = p->h_n_band_work[0];
+  return LVF_OK;
+}
+static int ensure_band_work(lvf_problem* p) {
+  if (!p->band_ready || p->n_lm == 0 || p->band_rows_built == p->band_rows) return LVF_OK;
+  LVF_TRY(build_band_work(p, p->band_rows, p->band_work, &p->n_band_work));
   p->band_rows_built = p->band_rows;
   return LVF_OK;
 }
@@ -2975,13 +3011,19 @@ static int build_chain(lvf_problem* p) {
   {
     int k = 0;
     static const bool tri_on = [] { const char* e = std::getenv("LVF_ZERO_TRI"); return !(e && e[0] == '0'); }();
-    auto add = [&](double* ptr, size_t n, int tri = 0) { if (ptr && n) { c.zero.p[k] = ptr; c.zero.n[k] = n; c.zero.tri[k] = (tri_on && tri % 2 == 0) ? tri : 0; ++k; } };
+    bool overflow = false;
+    auto add = [&](double* ptr, size_t n, int tri = 0) {
+      if (!(ptr && n)) return;
+      if (k >= kZeroListMax) { overflow = true; return; }      // (the struct travels by value: never write past its arrays)
+      c.zero.p[k] = ptr; c.zero.n[k] = n; c.zero.tri[k] = (tri_on && tri % 2 == 0) ? tri : 0; ++k;
+    };
     add(p->B.p, (size_t)p->dpad * p->dpad, p->dpad); add(p->gc.p, p->dpad);
     if (p->n_lm) { if (!p->compact) add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
     if (c.early) { add(p->S.p, (size_t)p->ld * p->ld, p->ld); add(p->sp_sync.p, kSpMaxLevels); }     // early sparse levels add into S before k_prepare does; their arrival counters
     c.zero_end = c.zero; c.zero_end.count = k;         // cleared at the END of an iteration, beside the cost pass (the scalars: by the decision itself)
     add(p->scal.p, SC_N);
     c.zero.count = k;
+    LVF_REQUIRE(!overflow, "build_chain: more than %d accumulator arrays (raise kZeroListMax)", kZeroListMax);
   }
   if (c.has_imu) {
     fill_imu_args(p->imu, s.poses, s.vel, s.ba, s.bg, nullptr, nullptr, done, &c.imu_lin);
@@ -3042,7 +3084,11 @@ static int build_chain(lvf_problem* p) {
     SpArgs& a = c.sp[lv];
     a.nodes = p->sp_nodes.p; a.first = p->sp_levels.first[lv]; a.tiles = p->sp_tiles[lv]; a.rows = p->sp_rows.p; a.S = p->S.p; a.ld = p->ld; a.W = p->sp_W.p;
     a.wstride = p->sp_wstride; a.Lout = p->sp_L.p; a.fail = fail; a.nblocks = p->sp_levels.count[lv] * p->sp_tiles[lv]; a.done = done;
-    a.src = c.early ? SpSrc{p->B.p, p->dpad, p->dp, p->gc.p, radius, p->sp_rows_nat.p, nullptr, 0, nullptr, p->off, std::getenv("LVF_CHAIN_RMW_READ") ? 1 : 0, nullptr, lv == 0 ? 1 : 0} : SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, p->off, 0, nullptr, 0};
+    // (2 ms at 100 MHz before a chained level gives up on the level below; LVF_CHAIN_TIMEOUT_US overrides; LVF_CHAIN_FENCE=0: relaxed hand-over, A/B only)
+    static const unsigned chain_timeout = [] { const char* e = std::getenv("LVF_CHAIN_TIMEOUT_US"); return e ? (unsigned)std::max(1, std::atoi(e)) * 100u : 200000u; }();
+    static const int chain_fenced = [] { const char* e = std::getenv("LVF_CHAIN_FENCE"); return (e && e[0] == '0') ? 0 : 1; }();
+    a.src = c.early ? SpSrc{p->B.p, p->dpad, p->dp, p->gc.p, radius, p->sp_rows_nat.p, nullptr, 0, nullptr, chain_fenced, chain_timeout, p->off, std::getenv("LVF_CHAIN_RMW_READ") ? 1 : 0, nullptr, lv == 0 ? 1 : 0}
+                    : SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, chain_fenced, chain_timeout, p->off, 0, nullptr, 0};
     c.sp_lds[lv] = p->sp_shmem[lv];
   }
   c.merged_level0 = false;
@@ -3057,7 +3103,8 @@ static int build_chain(lvf_problem* p) {
     // with the chain alone, 0.103 / 0.123 with riders in front of it).  LVF_RIDE_TF / LVF_RIDE_PREP = 0 | 1 override, LVF_CHAIN_LEVELS = 0..2.
     static const int ride_tf_env = [] { const char* e = std::getenv("LVF_RIDE_TF"); return e ? std::atoi(e) : -1; }();
     static const int ride_prep_env = [] { const char* e = std::getenv("LVF_RIDE_PREP"); return e ? std::atoi(e) : -1; }();
-    static const int chain_n = [] { const char* e = std::getenv("LVF_CHAIN_LEVELS"); return e ? std::max(0, std::min(2, std::atoi(e))) : 2; }();
+    static const int chain_n_env = [] { const char* e = std::getenv("LVF_CHAIN_LEVELS"); return e ? std::max(0, std::min(2, std::atoi(e))) : 2; }();
+    const int chain_n = p->no_chain ? 0 : chain_n_env;      // (a hand-over that timed out once: every level in a launch of its own from then on)
     const int excess = std::max(0, c.n_levels - (1 + chain_n));
     const bool ride_tf = ride_tf_env >= 0 ? ride_tf_env != 0 : (p->compact && excess >= 1);
     const bool ride_prep = ride_prep_env >= 0 ? ride_prep_env != 0 : (excess >= 2 || (excess >= 1 && !(ride_tf && p->compact)));
@@ -3068,7 +3115,7 @@ static int build_chain(lvf_problem* p) {
     }
     if (schur_merged) {
       SchurSp0Args& a = c.ssp0;
-      a.rows = std::min(kBandRowsMax, std::max(16, p->band_rows));
+      a.rows = band_rows_clamped(p->band_rows);
       a.n_slices = (p->n_lm + a.rows - 1) / a.rows; a.n_groups = (ntile + kBandTilesPerGroup - 1) / kBandTilesPerGroup;
       a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.Cd = p->Cd.p; a.order = p->lm_order.p;
       a.dbg = nullptr; a.n_active = p->lm_nactive.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p;
@@ -3087,6 +3134,7 @@ static int build_chain(lvf_problem* p) {
           *slot[k] = c.sp[next_level];
           prev->src.done_counter = cnt + 2 * (next_level - 1);
           slot[k]->src.wait_counter = cnt + 2 * (next_level - 1); slot[k]->src.wait_target = prev->nblocks;
+          if (p->force_handover_timeouts > 0 && k == 0) { slot[k]->src.wait_target = prev->nblocks + 1; slot[k]->src.timeout_ticks = 2000u; }      // test hook: a producer that never arrives (20 us)
           c.ssp0_lds = std::max(c.ssp0_lds, (size_t)p->sp_shmem[next_level]);
           prev = slot[k];
           ++next_level;
@@ -3447,6 +3495,18 @@ static int download_ctl(lvf_problem* p, LmCtl* out) {
   return LVF_OK;
 }
 
+// The loop ended because a chained sparse level timed out waiting for the level below (LVF_WHY_HANDOVER; the step was neither taken nor
+// counted).  The problem gives up chaining for good (its levels become launches of their own: the LVF_CHAIN_LEVELS=0 form), the control
+// block is re-armed as the aborted iteration found it and the caller enqueues again.  Returns false when there is nothing to retry.
+static bool handover_pending(const lvf_problem* p, const LmCtl& c) { return c.done && c.why == LVF_WHY_HANDOVER && !p->no_chain; }
+static int rearm_after_handover(lvf_problem* p, LmCtl* c) {
+  p->no_chain = true; p->chain_ready = false; p->handover_retries += 1;
+  if (p->force_handover_timeouts > 0) p->force_handover_timeouts -= 1;
+  c->done = 0; c->termination = 1; c->why = LVF_WHY_MAX_ITERATIONS;
+  p->accum_clean = false;                    // (the aborted iteration's partial sums: cleared by an explicit launch before the re-run)
+  return upload_ctl(p, *c);                  // rebuilds the chain
+}
+
 struct IterOut { double cost_before, cost_after, model, dxnorm, xnorm, gmax; bool accepted, solved; };
 
 // exactly one LM iteration from the current state (no tolerance tests): the per-iteration parity point
@@ -3457,6 +3517,11 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
   LVF_TRY(upload_ctl(p, c));
   LVF_TRY(enqueue_iteration(p, false));
   LVF_TRY(download_ctl(p, &c));
+  if (handover_pending(p, c)) {              // a chained hand-over timed out: the same iteration again, un-chained
+    LVF_TRY(rearm_after_handover(p, &c));
+    LVF_TRY(enqueue_iteration(p, false));
+    LVF_TRY(download_ctl(p, &c));
+  }
   if (p->dbg.p && std::getenv("LVF_CHOL_TIMING")) {
     unsigned long long t[64];
     LVF_HIP(hipMemcpy(t, p->dbg.p, sizeof(t), hipMemcpyDeviceToHost));
@@ -3795,6 +3860,7 @@ int problem_configure(lvf_problem* p) {
     LVF_HIP(hipGetLastError());
     p->band_ready = true;
     p->band_rows_built = 0;         // the bands changed: the work list is rebuilt with the next chain
+    p->band_epoch += 1;
     // compact landmark layout + slabs (atomic-free TwoFrame linearisation): needs the sorted work list, one block per (landmark,
     // keyframe), the landmark's first keyframe ahead of its observations, and the merged band-Schur launch
     static const bool compact_on = [] { const char* e = std::getenv("LVF_COMPACT"); return !(e && e[0] == '0'); }();
@@ -3871,9 +3937,21 @@ struct lvf_problem_batch {
   lvf::DevBuf<lvf::DecideArgs> dec;
   lvf::DevBuf<lvf::ZeroList> zero;   // every window's full accumulator list (cleared in one launch when a window is not known clean)
   double huber_built = -1.0;
+  // A batch of more than one window sums its Schur complements over wider landmark slices (fewer output atomics: LVF_BATCH_BAND_ROWS,
+  // default 128).  The work lists for that width belong to the BATCH — a member's own list, slice width and chain are never touched, so a
+  // window solved alone, then in a batch, then alone again runs the same arithmetic the first and the third time.
+  std::vector<std::unique_ptr<lvf::DevBuf<int4>>> band_work; std::vector<int> n_band_work, band_epoch;
+  bool orphaned = false;             // a member was destroyed before the batch: every later call fails with LVF_ERR_STATE
 };
 
 namespace lvf {
+
+void batch_orphan(lvf_problem_batch* b, lvf_problem* dying) {
+  b->orphaned = true;
+  for (lvf_problem* p : b->probs)
+    if (p != dying) p->batches.erase(std::remove(p->batches.begin(), p->batches.end(), b), p->batches.end());
+  b->probs.clear();
+}
 
 template <typename T>
 static int upload_table(DevBuf<T>& dst, const std::vector<T>& src, hipStream_t q) {
@@ -3888,13 +3966,24 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
   const int W = b->W;
   bool all = true;
   static const int batch_rows = [] { const char* e = std::getenv("LVF_BATCH_BAND_ROWS"); return e ? std::atoi(e) : 128; }();
+  if (b->orphaned) { set_error("lvf_problem_batch: a member problem was destroyed before the batch"); return LVF_ERR_STATE; }
   for (lvf_problem* p : b->probs) {
-    if (b->W > 1 && p->band_rows != batch_rows) { p->band_rows = batch_rows; p->chain_ready = false; }
     if (chain_stale(p)) LVF_TRY(build_chain(p));
     all = all && p->chain->batchable;
   }
   b->tables = all;
   if (!all) return LVF_OK;
+  const bool wide = W > 1 && batch_rows != 64;
+  if (wide) {
+    b->band_work.resize(W); b->n_band_work.resize(W, 0); b->band_epoch.resize(W, -1);
+    for (int w = 0; w < W; ++w) {
+      lvf_problem* p = b->probs[w];
+      if (!b->band_work[w]) b->band_work[w].reset(new DevBuf<int4>());
+      if (b->band_epoch[w] == p->band_epoch) continue;
+      LVF_TRY(build_band_work(p, batch_rows, *b->band_work[w], &b->n_band_work[w]));
+      b->band_epoch[w] = p->band_epoch;
+    }
+  }
   std::vector<ImuArgs> il(W), ic(W); std::vector<LinArgs> li(W); std::vector<TfReduceArgs> rd(W); std::vector<PrepArgs> pr(W); std::vector<SchurSp0Args> ss(W);
   std::vector<CholArgs> ch(W); std::vector<BackArgs> bk(W); std::vector<TailArgs> tl(W); std::vector<CostArgs> co(W); std::vector<DecideArgs> de(W); std::vector<ZeroList> zl(W);
   b->max_levels = 0; b->max_nb = 0;
@@ -3905,6 +3994,12 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
     const Chain& c = *p->chain;
     il[w] = c.imu_lin; ic[w] = c.imu_cost; li[w] = c.lin; li[w].huber = huber; rd[w] = c.red; if (!p->compact) rd[w].nblocks = 0;
     b->g_red = std::max(b->g_red, rd[w].nblocks); pr[w] = c.early ? c.prep_early : c.prep; ss[w] = c.ssp0; ch[w] = c.chol; bk[w] = c.back; tl[w] = c.tail;
+    if (wide) {                                          // the batch's own slice width and work list (the member's chain keeps its own)
+      SchurSp0Args& a = ss[w];
+      a.rows = band_rows_clamped(batch_rows); a.n_slices = (p->n_lm + a.rows - 1) / a.rows;
+      a.work = b->band_work[w]->p; a.n_work = b->n_band_work[w];
+      a.nblocks = a.n_work + a.sp.nblocks + a.sp_b.nblocks + a.sp_c.nblocks;
+    }
     if (rd[w].nblocks > rd[w].own_blocks) b->lds_red = std::max(b->lds_red, c.red_lds);
     if (pr[w].nblocks > pr[w].own_blocks) b->lds_prep = std::max(b->lds_prep, c.prep_lds);
     b->first_own_level = std::min(b->first_own_level, c.first_own_level);
@@ -3921,7 +4016,7 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
       ta.nblocks -= ta.g_lm - g2; ta.g_lm = g2;
     }
     b->g_imu_lin = std::max(b->g_imu_lin, c.imu_lin.n + c.imu_lin.zero_wgs); b->g_imu_cost = std::max(b->g_imu_cost, c.imu_cost.n + c.imu_cost.zero_wgs);
-    b->g_lin = std::max(b->g_lin, c.lin.nblocks); b->lds_lin = std::max(b->lds_lin, c.lin_lds); b->g_prep = std::max(b->g_prep, pr[w].nblocks); b->g_ssp0 = std::max(b->g_ssp0, c.ssp0.nblocks);
+    b->g_lin = std::max(b->g_lin, c.lin.nblocks); b->lds_lin = std::max(b->lds_lin, c.lin_lds); b->g_prep = std::max(b->g_prep, pr[w].nblocks); b->g_ssp0 = std::max(b->g_ssp0, ss[w].nblocks);
     b->lds_ssp0 = std::max(b->lds_ssp0, c.ssp0_lds); b->lds_back = std::max(b->lds_back, c.back_lds); b->g_tail = std::max(b->g_tail, tl[w].nblocks);
     b->lds_tail = std::max(b->lds_tail, c.tail_lds); b->g_cost = std::max(b->g_cost, co[w].nblocks + co[w].zero_wgs);
     b->max_levels = std::max(b->max_levels, c.n_levels); b->max_nb = std::max(b->max_nb, p->nb);
@@ -4150,8 +4245,9 @@ static void summary_from_ctl(const lvf_problem* p, const LmCtl& c, lvf_solver_su
   std::memset(s, 0, sizeof(*s));
   s->num_residual_blocks = (p->tc ? p->tc->n : 0) + (p->tf ? p->tf->n : 0) + (p->po ? p->po->n : 0) + (p->imu ? p->imu->n : 0) + (p->prior ? p->prior->n : 0);
   s->initial_cost = c.initial_cost; s->final_cost = c.cost; s->num_iterations = c.iter; s->num_successful_steps = c.successes; s->termination = c.termination;
-  s->num_unsuccessful_steps = c.rejected; s->termination_reason = c.why;
+  s->num_unsuccessful_steps = c.rejected; s->termination_reason = c.why; s->hand_over_retries = p->handover_retries;
 }
+
 
 // The device LM loop: iterations are enqueued back to back, each closed on device (k_lm_decide); the host only watches a mirror of the
 // control block to stop enqueueing once the loop has finished (an iteration enqueued after the end costs ~20 empty launches).
@@ -4171,14 +4267,19 @@ int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_su
   LVF_TRY(upload_ctl(p, c));
   const auto wall0 = std::chrono::steady_clock::now();
   bool timed_out = false;
-  for (int it = 0; it < o->max_num_iterations; ++it) {
-    LVF_TRY(enqueue_iteration(p, true));
-    if (it >= 1) LVF_TRY(wait_for_iteration(p, it));          // iteration it-1 is closed; iteration `it` keeps the device busy meanwhile
-    if (p->rec->done) break;
-    if (o->max_solver_time_in_seconds > 0.0 &&
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) { timed_out = true; break; }
+  for (int first = 0;;) {
+    for (int it = first; it < o->max_num_iterations; ++it) {
+      LVF_TRY(enqueue_iteration(p, true));
+      if (it >= first + 1) LVF_TRY(wait_for_iteration(p, it));          // iteration it-1 is closed; iteration `it` keeps the device busy meanwhile
+      if (p->rec->done) break;
+      if (o->max_solver_time_in_seconds > 0.0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) { timed_out = true; break; }
+    }
+    LVF_TRY(download_ctl(p, &c));
+    if (!handover_pending(p, c)) break;
+    LVF_TRY(rearm_after_handover(p, &c));     // a chained hand-over timed out: the loop goes on from the same point, un-chained
+    first = c.iter;
   }
-  LVF_TRY(download_ctl(p, &c));
   p->last_radius = c.last_radius;
   summary_from_ctl(p, c, summary);
   if (timed_out && !c.done) summary->termination_reason = LVF_WHY_TIME;
@@ -4219,15 +4320,24 @@ int lvf_problem_batch_create(lvf_ctx* ctx, lvf_problem* const* problems, int n, 
   }
   auto* b = new lvf_problem_batch();
   b->ctx = ctx; b->W = n; b->probs.assign(problems, problems + n);
+  for (lvf_problem* p : b->probs) p->batches.push_back(b);
   *out = b;
   return LVF_OK;
 }
+// (members are only told that the batch is gone: nothing of theirs was changed by it)
 int lvf_problem_batch_destroy(lvf_problem_batch* b) {
-  if (b) for (lvf_problem* p : b->probs) if (p->band_rows != 64) { p->band_rows = 64; p->chain_ready = false; }
+  if (b && !b->orphaned)
+    for (lvf_problem* p : b->probs) p->batches.erase(std::remove(p->batches.begin(), p->batches.end(), b), p->batches.end());
   delete b;
   return LVF_OK;
 }
 int lvf_problem_batch_size(const lvf_problem_batch* b) { return b ? b->W : -1; }
+// test hook (see lvf.h)
+int lvf_problem_debug_force_handover_timeout(lvf_problem* p, int n) {
+  LVF_REQUIRE(p && n >= 0, "lvf_problem_debug_force_handover_timeout: bad argument");
+  p->force_handover_timeouts = n; p->no_chain = false; p->chain_ready = false;
+  return LVF_OK;
+}
 int lvf_problem_batch_uses_tables(lvf_problem_batch* b, const lvf_solver_options* o) {
   if (!b || !o || lvf::enter(b->ctx) != LVF_OK || batch_build_tables(b, o->huber_a) != LVF_OK) return -1;
   return b->tables ? 1 : 0;
@@ -4247,6 +4357,16 @@ int lvf_problem_batch_lm_iteration(lvf_problem_batch* b, const lvf_solver_option
     LVF_TRY(upload_ctl(b->probs[w], c));
   }
   LVF_TRY(batch_enqueue_iteration(b, false));
+  {
+    // windows whose chained hand-over timed out repeat the iteration un-chained (the others are done: their launches return at once)
+    bool again = false;
+    for (int w = 0; w < b->W; ++w) {
+      LmCtl c;
+      LVF_TRY(download_ctl(b->probs[w], &c));
+      if (handover_pending(b->probs[w], c)) { LVF_TRY(rearm_after_handover(b->probs[w], &c)); again = true; }
+    }
+    if (again) { LVF_TRY(batch_build_tables(b, o->huber_a)); LVF_TRY(batch_enqueue_iteration(b, false)); }
+  }
   for (int w = 0; w < b->W; ++w) {
     LmCtl c;
     LVF_TRY(download_ctl(b->probs[w], &c));
@@ -4274,22 +4394,33 @@ int lvf_problem_batch_solve(lvf_problem_batch* b, const lvf_solver_options* o, l
     LVF_TRY(upload_ctl(b->probs[w], c));
   }
   const auto wall0 = std::chrono::steady_clock::now();
-  for (int it = 0; it < o->max_num_iterations; ++it) {
-    LVF_TRY(batch_enqueue_iteration(b, true));
-    bool all_done = true;
-    for (int w = 0; w < b->W; ++w) {
-      if (it >= 1) LVF_TRY(wait_for_iteration(b->probs[w], it));
-      all_done = all_done && b->probs[w]->rec->done;
+  std::vector<LmCtl> cs((size_t)b->W);
+  for (int round = 0;; ++round) {
+    // (after a hand-over retry the windows stand at different iteration counts: the wait is for "one more than when this pass started")
+    int base = o->max_num_iterations;
+    for (int w = 0; w < b->W; ++w) if (!b->probs[w]->rec->done) base = std::min(base, (int)b->probs[w]->rec->iter);
+    for (int it = base; it < o->max_num_iterations; ++it) {
+      LVF_TRY(batch_enqueue_iteration(b, true));
+      bool all_done = true;
+      for (int w = 0; w < b->W; ++w) {
+        if (it >= base + 1) LVF_TRY(wait_for_iteration(b->probs[w], it));
+        all_done = all_done && b->probs[w]->rec->done;
+      }
+      if (all_done) break;
+      if (o->max_solver_time_in_seconds > 0.0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) break;
     }
-    if (all_done) break;
-    if (o->max_solver_time_in_seconds > 0.0 &&
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) break;
+    bool again = false;
+    for (int w = 0; w < b->W; ++w) {
+      LVF_TRY(download_ctl(b->probs[w], &cs[w]));
+      if (handover_pending(b->probs[w], cs[w])) { LVF_TRY(rearm_after_handover(b->probs[w], &cs[w])); again = true; }
+    }
+    if (!again) break;
+    LVF_TRY(batch_build_tables(b, o->huber_a));        // the re-armed windows' chains changed shape
   }
   for (int w = 0; w < b->W; ++w) {
-    LmCtl c;
-    LVF_TRY(download_ctl(b->probs[w], &c));
-    b->probs[w]->last_radius = c.last_radius;
-    summary_from_ctl(b->probs[w], c, &summaries[w]);
+    b->probs[w]->last_radius = cs[w].last_radius;
+    summary_from_ctl(b->probs[w], cs[w], &summaries[w]);
   }
   return LVF_OK;
 }
