@@ -314,6 +314,21 @@ int lvf_scan_match(lvf_map* map_ground, lvf_scan* scan_ground, lvf_map* map_surf
                    const double* frame_pose, const double* last_pose, const lvf_scan_match_options* opt,
                    lvf_scan_match_result* result);
 
+/* Many scan-to-map updates of ONE context advanced side by side: the loop-closure candidates Relocator::Relocate evaluates one after the
+ * other (relocator.cpp:196-206 -> Mapping::Relocate, mapping.cpp:251-300: no shared mutable state between candidates).  Every launch of
+ * the chain covers all candidates (the candidate is a grid dimension), each candidate's pose / rpyxyz / scores live in a device record
+ * between its sub-problems, and the n results are read back once.  results[i] equals lvf_scan_match on candidate i (which IS this call
+ * with n = 1).  A candidate's pairs may be NULL like lvf_scan_match's; scan handles must not repeat across candidates (a scan owns its
+ * association outputs).  best (may be NULL) = the reference's choice: the LAST candidate whose score - relocate_base_score is > 0 and
+ * >= every earlier one (relocator.cpp:181,198-204; 20 in the reference), or -1. */
+typedef struct lvf_scan_match_job {
+  lvf_map* map_ground; lvf_scan* scan_ground; lvf_map* map_surf; lvf_scan* scan_surf;
+  double map_pose[7], frame_pose[7], last_pose[7];
+  int has_last_pose;               /* 0: relative_o_c = pose (lvf_scan_match's last_pose == NULL) */
+} lvf_scan_match_job;
+int lvf_scan_match_batch(lvf_ctx* ctx, const lvf_scan_match_job* jobs, int n, const lvf_scan_match_options* opt, int relocate_base_score,
+                         lvf_scan_match_result* results, int* best);
+
 /* The same device-resident 3-DoF solve over a caller-built lidar batch (lvf_lidar_plane_create): what adapt::Solve
  * does for the problem ScanToMapWithGround/Segmented assembled (mapping.cpp:157-163, :270-296).  mode, weight and Twc1
  * are the batch's; opt supplies huber_a, prior_weight and max_num_iterations (opt->mode/weight/thr are ignored). */

@@ -43,6 +43,11 @@ class ScanMatchResult(C.Structure):
                 ("score", C.c_int), ("ground", IcpSummary), ("surf", IcpSummary)]
 
 
+class ScanMatchJob(C.Structure):
+    _fields_ = [("map_ground", C.c_void_p), ("scan_ground", C.c_void_p), ("map_surf", C.c_void_p), ("scan_surf", C.c_void_p),
+                ("map_pose", C.c_double * 7), ("frame_pose", C.c_double * 7), ("last_pose", C.c_double * 7), ("has_last_pose", C.c_int)]
+
+
 class WindowOptions(C.Structure):
     _fields_ = [("baseline", C.c_double), ("weak_visual_threshold", C.c_int), ("prior_weight", C.c_double), ("prior_v", C.c_double),
                 ("device_assembly", C.c_int)]
@@ -176,6 +181,7 @@ _SIGS = {
     "lvf_lidar_extract": (C.c_int, [_VP, c_float_p, C.c_int, C.c_int, C.POINTER(LidarParams), c_double_p, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(LidarExtractDebug)]),
     "lvf_scan_match_options_default": (None, [C.POINTER(ScanMatchOptions), C.c_double]),
     "lvf_scan_match": (C.c_int, [_VP, _VP, _VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(ScanMatchOptions), C.POINTER(ScanMatchResult)]),
+    "lvf_scan_match_batch": (C.c_int, [_VP, C.POINTER(ScanMatchJob), C.c_int, C.POINTER(ScanMatchOptions), C.c_int, C.POINTER(ScanMatchResult), c_int_p]),
     "lvf_lidar_solve": (C.c_int, [_VP, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
     "lvf_prior3_evaluate": (C.c_int, [_VP, C.c_int, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p]),
     "lvf_window_options_default": (None, [C.POINTER(WindowOptions)]),

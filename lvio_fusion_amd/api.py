@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import LidarExtractDebug, LidarParams, WindowOptions, Camera, IcpOptions, IcpSummary, ScanMatchOptions, ScanMatchResult, SolverOptions, SolverSummary
+from ._lib import LidarExtractDebug, LidarParams, WindowOptions, Camera, IcpOptions, IcpSummary, ScanMatchJob, ScanMatchOptions, ScanMatchResult, SolverOptions, SolverSummary
 
 POSES, VEL, BA, BG, INV_DEPTH, W_VISUAL = range(6)
 IMU_BLOCK_SIZES = (7, 3, 3, 3, 7, 3, 3, 3)
@@ -433,6 +433,25 @@ def scan_match(map_ground, scan_ground, map_surf, scan_surf, map_pose, frame_pos
     _chk(anyh.ctx.L.lvf_scan_match(h(map_ground), h(scan_ground), h(map_surf), h(scan_surf), _dp(mp), _dp(fp), _dp(lp) if lp is not None else None,
                                    C.byref(opt), C.byref(res)))
     return res
+
+
+def scan_match_batch(ctx, jobs, opt, relocate_base_score=20):
+    """Many scan-to-map updates side by side (lvf_scan_match_batch).  jobs: list of dicts with map_ground / scan_ground / map_surf /
+    scan_surf (handles or None), map_pose, frame_pose, last_pose (or None).  Returns (results list, best index or -1)."""
+    n = len(jobs)
+    arr = (ScanMatchJob * max(n, 1))()
+    h = lambda x: x.h if x is not None else None
+    for j, a in zip(jobs, arr):
+        a.map_ground, a.scan_ground, a.map_surf, a.scan_surf = h(j.get("map_ground")), h(j.get("scan_ground")), h(j.get("map_surf")), h(j.get("scan_surf"))
+        a.map_pose[:] = list(_d(j["map_pose"])); a.frame_pose[:] = list(_d(j["frame_pose"]))
+        lp = j.get("last_pose")
+        a.has_last_pose = 0 if lp is None else 1
+        if lp is not None:
+            a.last_pose[:] = list(_d(lp))
+    res = (ScanMatchResult * max(n, 1))()
+    best = C.c_int32(-1)
+    _chk(ctx.L.lvf_scan_match_batch(ctx.h, arr, n, C.byref(opt), int(relocate_base_score), res, C.byref(best)))
+    return list(res)[:n], int(best.value)
 
 
 def lidar_solve(batch, rpyxyz, huber_a, prior_weight=0.0, max_num_iterations=4):

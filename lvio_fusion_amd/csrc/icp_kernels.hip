@@ -14,41 +14,23 @@
 #include <cmath>
 #include "lidar_eval.hpp"
 #include "lvf_internal.hpp"
+#include "scan_match_dev.hpp"
 
 namespace lvf {
 
 constexpr int kTI = 256;
-constexpr int kIcpMaxBlocks = 128;   // k_icp_eval grid cap (grid-stride above it)
-
-struct IcpDev {
-  double x[3], x0[3], xc[3];
-  double radius, decrease;
-  double acc[10];            // H lower (00,10,11,20,21,22), g (3), cost  — at x
-  double cost_cand;          // data cost at xc
-  double cost_cur, initial_cost, model;
-  double rpyxyz[6];
-  int done, iters, successes, nvalid, first;
-  int invalid_run;           // consecutive invalid steps (solver failure or model_cost_change <= 0): 5 end the solve
-  unsigned ticket;           // workgroups that have finished the running k_icp_eval (the last one does the scalar tail)
-};
-
-struct IcpArgs {
-  double Twc1[7];
-  double weight, huber, prior_w;
-  double function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease;
-  int mode, max_iters;
-};
+// (IcpDev, IcpArgs, kIcpMaxBlocks: scan_match_dev.hpp)
 
 __device__ __forceinline__ void param_slots(int mode, int& i0, int& i1, int& i2) {
   if (mode == 0) { i0 = 1; i1 = 2; i2 = 5; } else { i0 = 0; i1 = 3; i2 = 4; }
 }
 
 // correspondences: scan point (double), first neighbour pa, unit normal — SoA [3][Q]; invalid points keep valid = 0
-__global__ __launch_bounds__(kTI) void k_icp_build(int Q, const float4* __restrict__ scan, const int* __restrict__ idx,
-                                                   const uint8_t* __restrict__ valid, const float4* __restrict__ map_raw,
-                                                   double* __restrict__ P, double* __restrict__ PA, double* __restrict__ N,
-                                                   IcpDev* __restrict__ dev) {
-  const int i = blockIdx.x * kTI + threadIdx.x;
+__device__ __forceinline__ void icp_build_body(const int bx, int Q, const float4* __restrict__ scan, const int* __restrict__ idx,
+                                               const uint8_t* __restrict__ valid, const float4* __restrict__ map_raw,
+                                               double* __restrict__ P, double* __restrict__ PA, double* __restrict__ N,
+                                               IcpDev* __restrict__ dev) {
+  const int i = bx * kTI + threadIdx.x;
   const bool ok = i < Q && valid[i];
   if (ok) {
     const float4 p = scan[i];
@@ -61,7 +43,19 @@ __global__ __launch_bounds__(kTI) void k_icp_build(int Q, const float4* __restri
     N[i] = n[0]; N[Q + i] = n[1]; N[2 * Q + i] = n[2];
   }
   const unsigned long long m = __ballot(ok);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&dev->nvalid, __popcll(m));
+  if (dev && (threadIdx.x & 63) == 0 && m) atomicAdd(&dev->nvalid, __popcll(m));
+}
+__global__ __launch_bounds__(kTI) void k_icp_build(int Q, const float4* __restrict__ scan, const int* __restrict__ idx,
+                                                   const uint8_t* __restrict__ valid, const float4* __restrict__ map_raw,
+                                                   double* __restrict__ P, double* __restrict__ PA, double* __restrict__ N,
+                                                   IcpDev* __restrict__ dev) {
+  icp_build_body(blockIdx.x, Q, scan, idx, valid, map_raw, P, PA, N, dev);
+}
+// table form (blockIdx.y = candidate); the valid correspondences are counted by the first linearisation pass (IcpDev::count_valid)
+__global__ __launch_bounds__(kTI) void k_icp_build_b(const KnnJob* __restrict__ jobs, int sub) {
+  const KnnJob& J = jobs[2 * blockIdx.y + sub];
+  if ((long long)blockIdx.x * kTI >= (long long)J.Q) return;
+  icp_build_body(blockIdx.x, J.Q, J.scan, J.idx, J.valid, J.map_raw, J.corr, J.corr + (size_t)3 * J.Q, J.corr + (size_t)6 * J.Q, nullptr);
 }
 
 // the sums other workgroups added with L2 atomics, read past this CU's L1
@@ -81,7 +75,7 @@ __device__ void icp_step(const IcpArgs& args, IcpDev* dev) {
     for (int q = 0; q < 3; ++q) { const double dxp = dev->x[q] - dev->x0[q]; g[q] += w2 * dxp; cost += 0.5 * w2 * dxp * dxp; }
   }
   dev->cost_cur = cost;
-  if (dev->first) { dev->initial_cost = cost; dev->first = 0; }
+  if (dev->first) { dev->initial_cost = cost; dev->first = 0; if (dev->count_valid) dev->nvalid = (int)fresh(&dev->acc[10]); }
   const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
   if (gmax <= args.gradient_tolerance || dev->radius < 1e-32) { dev->done = 1; return; }      // top of ceres::Solve's loop: gradient tolerance, smallest trust region
   const double inv_r = 1.0 / dev->radius;
@@ -138,7 +132,7 @@ __device__ void icp_decide(const IcpArgs& args, IcpDev* dev) {
     }
   }
   if (dev->iters >= args.max_iters || dev->radius < 1e-32) dev->done = 1;
-  for (int q = 0; q < 10; ++q) dev->acc[q] = 0.0;
+  for (int q = 0; q < 11; ++q) dev->acc[q] = 0.0;
 }
 
 // stand-alone forms (problems with no correspondences never launch k_icp_eval)
@@ -146,9 +140,9 @@ __global__ void k_icp_step(const IcpArgs args, IcpDev* dev) { icp_step(args, dev
 __global__ void k_icp_decide(const IcpArgs args, IcpDev* dev) { icp_decide(args, dev); }
 
 template <bool WITH_J>
-__global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restrict__ P, const double* __restrict__ PA,
-                                                  const double* __restrict__ N, const uint8_t* __restrict__ valid,
-                                                  const IcpArgs args, IcpDev* __restrict__ dev) {
+__device__ __forceinline__ void icp_eval_body(const int bx, const int nbx, int Q, const double* __restrict__ P, const double* __restrict__ PA,
+                                              const double* __restrict__ N, const uint8_t* __restrict__ valid,
+                                              const IcpArgs& args, IcpDev* __restrict__ dev) {
   __shared__ LidarU U;
   if (dev->done) return;                              // uniform: the flag is only written by single-thread kernels
   if (threadIdx.x == 0) {
@@ -166,11 +160,12 @@ __global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restric
   // grid-stride over the correspondences (the grid is capped at kIcpMaxBlocks): sums stay in registers, then ONE set of
   // atomics per workgroup (wave shuffles -> LDS -> wave 0) instead of one per wave — the ten accumulators are single
   // addresses, and ~900 serialised L2 atomics per address were the kernel's whole run time
-  double v[10];
+  double v[11];
 #pragma unroll
-  for (int q = 0; q < 10; ++q) v[q] = 0.0;
-  for (int i = blockIdx.x * kTI + threadIdx.x; i < Q; i += gridDim.x * kTI) {
+  for (int q = 0; q < 11; ++q) v[q] = 0.0;
+  for (int i = bx * kTI + threadIdx.x; i < Q; i += nbx * kTI) {
     if (valid && !valid[i]) continue;
+    if (WITH_J) v[10] += 1.0;
     const double pp[3] = {P[i], P[Q + i], P[2 * Q + i]}, qa[3] = {PA[i], PA[Q + i], PA[2 * Q + i]}, nn[3] = {N[i], N[Q + i], N[2 * Q + i]};
     double r, J[3];
     lidar_point(U, args.mode, pp, qa, nn, r, J);
@@ -183,15 +178,15 @@ __global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restric
       v[6] += j0 * rs; v[7] += j1 * rs; v[8] += j2 * rs;
     }
   }
-  __shared__ double s_part[kTI / 64][10];
+  __shared__ double s_part[kTI / 64][11];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-  for (int q = WITH_J ? 0 : 9; q < 10; ++q) {
+  for (int q = WITH_J ? 0 : 9; q < (WITH_J ? 11 : 10); ++q) {
     const double s = wave_sum(v[q]);                     // DPP row butterflies + 4 readlanes (lvf_internal.hpp)
     if (lane == 0) s_part[wid][q] = s;
   }
   __syncthreads();
-  if (threadIdx.x < 10 && (WITH_J || threadIdx.x == 9)) {
+  if (threadIdx.x < 11 && (WITH_J || threadIdx.x == 9)) {
     double s = 0.0;
 #pragma unroll
     for (int w2 = 0; w2 < kTI / 64; ++w2) s += s_part[w2][threadIdx.x];
@@ -203,12 +198,30 @@ __global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restric
   if (threadIdx.x == 0) {
     __threadfence();
     const unsigned t = atomicAdd(&dev->ticket, 1u);
-    if (t == gridDim.x - 1) {
+    if (t == (unsigned)nbx - 1u) {
       __threadfence();
       dev->ticket = 0;
       if (WITH_J) icp_step(args, dev); else icp_decide(args, dev);
     }
   }
+}
+template <bool WITH_J>
+__global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restrict__ P, const double* __restrict__ PA,
+                                                  const double* __restrict__ N, const uint8_t* __restrict__ valid,
+                                                  const IcpArgs args, IcpDev* __restrict__ dev) {
+  icp_eval_body<WITH_J>(blockIdx.x, gridDim.x, Q, P, PA, N, valid, args, dev);
+}
+static __host__ __device__ inline int icp_blocks(int Q) { const int b = ((Q > 1 ? Q : 1) + kTI - 1) / kTI; return b < kIcpMaxBlocks ? b : kIcpMaxBlocks; }
+// table form: blockIdx.y = candidate; a candidate's own workgroup count is what its ticket counts (one workgroup even for Q = 0: the
+// scalar tail — the damped 3 x 3 solve / the decision — must run for problems with no correspondences too)
+template <bool WITH_J>
+__global__ __launch_bounds__(kTI) void k_icp_eval_b(const IcpJob* __restrict__ jobs, SmDev* __restrict__ devs, int sub) {
+  SmDev& D = devs[blockIdx.y];
+  if (!D.has[sub]) return;
+  const IcpJob& J = jobs[2 * blockIdx.y + sub];
+  const int nbx = icp_blocks(J.Q);
+  if ((int)blockIdx.x >= nbx) return;
+  icp_eval_body<WITH_J>(blockIdx.x, nbx, J.Q, J.P, J.PA, J.N, J.valid, J.args, &D.icp);
 }
 
 }  // namespace lvf
@@ -221,6 +234,20 @@ static IcpArgs make_args(const double* Twc1, const lvf_icp_options* opt) {
   a.function_tolerance = 1e-6; a.gradient_tolerance = 1e-10; a.parameter_tolerance = 1e-8; a.min_relative_decrease = 1e-3;
   a.mode = opt->mode; a.max_iters = opt->max_num_iterations;
   return a;
+}
+int launch_icp_build_batch(hipStream_t q, const KnnJob* jobs, int n, int sub, int max_Q) {
+  if (n <= 0 || max_Q <= 0) return LVF_OK;
+  hipLaunchKernelGGL(k_icp_build_b, dim3((max_Q + kTI - 1) / kTI, n), dim3(kTI), 0, q, jobs, sub);
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+int launch_icp_eval_batch(hipStream_t q, const IcpJob* jobs, SmDev* devs, int n, int sub, int max_Q, bool with_j) {
+  if (n <= 0) return LVF_OK;
+  const dim3 g(icp_blocks(max_Q), n);
+  if (with_j) hipLaunchKernelGGL(k_icp_eval_b<true>, g, dim3(kTI), 0, q, jobs, devs, sub);
+  else hipLaunchKernelGGL(k_icp_eval_b<false>, g, dim3(kTI), 0, q, jobs, devs, sub);
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
 }
 static void init_dev(IcpDev& h, int mode, const double* rpyxyz) {
   std::memset(&h, 0, sizeof(h));

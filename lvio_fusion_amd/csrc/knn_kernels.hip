@@ -15,6 +15,7 @@
 // ascending (d2, map index), which makes the result independent of traversal order.
 #include <cmath>
 #include "lvf_internal.hpp"
+#include "scan_match_dev.hpp"
 
 // The float32 arithmetic below must round after every multiply and add (bit-exact d2 / transform): the default
 // -ffp-contract=fast would fuse them (HIP's own __fmul_rn/__fadd_rn are plain operators compiled with the
@@ -34,7 +35,7 @@ __device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
 __device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
 __device__ __forceinline__ float sqrt_rn(float a) { return __builtin_sqrtf(a); }
 
-struct GridP { float ox, oy, oz, cell, inv_cell; int nx, ny, nz; };
+// (GridP / LevelP / LevelsP: scan_match_dev.hpp)
 
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __host__ __device__ inline float ord2f(unsigned u) {
@@ -262,8 +263,6 @@ constexpr int kLongRange = 12;   // candidates; longer ranges are deferred to th
 
 struct TfArg { float v[7]; };
 
-struct LevelP { const float4* sorted; const int* cell_start; GridP g; };
-struct LevelsP { LevelP l[kMaxLevels]; int n; };   // l[0] = finest ... l[n-1] = coarsest (cell >= gate radius / 2)
 
 // One cubic shell of cells around (cx,cy,cz); the (dz,dy) rows of the shell are dealt round-robin to the kGroup lanes
 // of the query's group (lane `g` takes rows g, g+kGroup, ...).  Returns the lower bound on the distance to any point
@@ -381,14 +380,14 @@ __device__ __forceinline__ void group_merge_best3(float bd[3], int bi[3]) {
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(kB) void k_knn3(int Q, const float4* __restrict__ scan, const TfArg tfa, const LevelsP L,
-                                             float thr, int* __restrict__ idx, float* __restrict__ d2,
-                                             uint8_t* __restrict__ valid, KnnStats* __restrict__ stats) {
-  const int t = blockIdx.x * kB + threadIdx.x;
+__device__ __forceinline__ void knn3_body(const int bx, int Q, const float4* __restrict__ scan, const float* tfv, const LevelsP& L,
+                                          float thr, int* __restrict__ idx, float* __restrict__ d2,
+                                          uint8_t* __restrict__ valid, KnnStats* __restrict__ stats) {
+  const int t = bx * kB + threadIdx.x;
   const int g_lane = t & (kGroup - 1);
   const int i = min(t / kGroup, Q - 1);          // surplus groups of the last block shadow the last query (no divergent exit
   const bool writer = (t / kGroup) < Q && g_lane == 0;   // before the shuffles)
-  const Tf32 T = make_tf32(tfa.v);
+  const Tf32 T = make_tf32(tfv);
   const float4 p = scan[i];
   const float qx = tf_row(T.a + 0, p.x, p.y, p.z, p.x, T.t[0]);
   const float qy = tf_row(T.a + 3, p.x, p.y, p.z, p.y, T.t[1]);
@@ -434,6 +433,21 @@ __global__ __launch_bounds__(kB) void k_knn3(int Q, const float4* __restrict__ s
     valid[i] = (bi[0] >= 0 && bd[0] < thr && bi[1] >= 0 && bd[1] < thr && bi[2] >= 0 && bd[2] < thr) ? 1 : 0;
   }
 }
+template <bool STATS>
+__global__ __launch_bounds__(kB) void k_knn3(int Q, const float4* __restrict__ scan, const TfArg tfa, const LevelsP L,
+                                             float thr, int* __restrict__ idx, float* __restrict__ d2,
+                                             uint8_t* __restrict__ valid, KnnStats* __restrict__ stats) {
+  knn3_body<STATS>(blockIdx.x, Q, scan, tfa.v, L, thr, idx, d2, valid, stats);
+}
+// Many associations in one launch: blockIdx.y = candidate, the job (scan, map pyramid, gate, outputs) comes from a device table and the
+// float transform from the candidate's device record — the pose the previous sub-problem left there never visits the host.
+__global__ __launch_bounds__(kB) void k_knn3_b(const KnnJob* __restrict__ jobs, const SmDev* __restrict__ devs, int sub) {
+  const KnnJob& J = jobs[2 * blockIdx.y + sub];
+  if ((long long)blockIdx.x * (kB / kGroup) >= (long long)J.Q) return;      // (uniform per workgroup; also Q == 0: nothing to associate)
+  const SmDev& D = devs[blockIdx.y];
+  if (!D.has[sub]) return;
+  knn3_body<false>(blockIdx.x, J.Q, J.scan, D.tf, J.L, J.thr, J.idx, J.d2, J.valid, nullptr);
+}
 
 // exclusive prefix sum of n ints on the context's stream; out has n + 1 entries (out[n] = grand total).  in != out.
 int device_exclusive_scan_i32(lvf_ctx* ctx, const int* in, int n, int* out) {
@@ -455,6 +469,25 @@ int device_exclusive_scan_i32(lvf_ctx* ctx, const int* in, int n, int* out) {
 using namespace lvf;
 
 static inline int knn_grid(int Q) { return (int)(((long long)Q * kGroup + kB - 1) / kB); }
+
+namespace lvf {
+LevelsP levels_of(const lvf_map* m) {
+  LevelsP L;
+  std::memset(&L, 0, sizeof(L));
+  L.n = m->n_levels;
+  for (int k = 0; k < m->n_levels; ++k) {
+    const auto& lv = m->levels[k];
+    L.l[k] = LevelP{lv.sorted.p, lv.cell_start.p, GridP{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz}};
+  }
+  return L;
+}
+int launch_knn3_batch(hipStream_t q, const KnnJob* jobs, const SmDev* devs, int n, int sub, int max_Q) {
+  if (n <= 0 || max_Q <= 0) return LVF_OK;
+  hipLaunchKernelGGL(k_knn3_b, dim3(knn_grid(max_Q), n), dim3(kB), 0, q, jobs, devs, sub);
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+}  // namespace lvf
 
 extern "C" {
 
@@ -600,12 +633,7 @@ int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* sc, const double* pose, float thr
   LVF_TRY(st.alloc(sc->Q));
   TfArg tf;
   for (int k = 0; k < 7; ++k) tf.v[k] = (float)pose[k];
-  LevelsP L;
-  L.n = m->n_levels;
-  for (int k = 0; k < m->n_levels; ++k) {
-    const auto& lv = m->levels[k];
-    L.l[k] = LevelP{lv.sorted.p, lv.cell_start.p, GridP{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz}};
-  }
+  const LevelsP L = levels_of(m);
   hipLaunchKernelGGL(k_knn3<true>, dim3(knn_grid(sc->Q)), dim3(kB), 0, m->ctx->stream, sc->Q, sc->pts.p, tf, L, thr,
                      sc->idx.p, sc->d2.p, sc->valid.p, st.p);
   LVF_HIP(hipGetLastError());
@@ -623,12 +651,7 @@ int lvf_knn3(lvf_map* m, lvf_scan* sc, const double* pose, float thr) {
   if (sc->Q > 0) {
     TfArg tf;
     for (int k = 0; k < 7; ++k) tf.v[k] = (float)pose[k];   // Sophus SE3d::cast<float>()  association.cpp:287
-    LevelsP L;
-    L.n = m->n_levels;
-    for (int k = 0; k < m->n_levels; ++k) {
-      const auto& lv = m->levels[k];
-      L.l[k] = LevelP{lv.sorted.p, lv.cell_start.p, GridP{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz}};
-    }
+    const LevelsP L = levels_of(m);
     hipLaunchKernelGGL(k_knn3<false>, dim3(knn_grid(sc->Q)), dim3(kB), 0, m->ctx->stream, sc->Q, sc->pts.p, tf, L, thr,
                        sc->idx.p, sc->d2.p, sc->valid.p, (KnnStats*)nullptr);
     LVF_HIP(hipGetLastError());

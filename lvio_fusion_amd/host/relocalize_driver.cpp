@@ -10,7 +10,8 @@
 //     loop-correction tail on device: UpdateNewSubmap's rotation solve (lvf_relocate_rotation_solve, :251-267) and ForwardUpdate
 //     (lvf_forward_update, pose_graph.cpp:245-252) over the keyframes that follow.
 //
-//   relocalize_driver <dir> <n_candidates> <threads> [--devices a,b,..] [--rank r --world w --idfile path]
+//   relocalize_driver <dir> <n_candidates> <threads> [--devices a,b,..] [--rank r --world w --idfile path] [--batched 0|1]
+// (a worker's candidates go through ONE launch chain — lvf_scan_match_batch — unless --batched 0)
 // Inputs (raw little-endian, written by tests/test_gpu_relocalize.py): <dir>/c<i>_{map,query}.f32 [n][4], c<i>_{map,query}_ground.u8,
 // c<i>_poses.f64 = map_pose | last_pose | init_pose; optional <dir>/tail_{relocated,unrelocated,forward}.f64.  One JSON line on stdout.
 #include <chrono>
@@ -88,12 +89,52 @@ static bool evaluate(lvf_ctx* ctx, const Candidate& c, double* record, int cand_
   return ok;
 }
 
+// The same for a worker's whole share in ONE launch chain (lvf_scan_match_batch): maps and scans are created per candidate, the solves of
+// all candidates run side by side, the records come back with one read
+static bool evaluate_batch(lvf_ctx* ctx, const std::vector<Candidate>& cands, const std::vector<int>& ids, const std::vector<size_t>& slots, double* table, std::string* err) {
+  lvf_scan_match_options o;
+  lvf_scan_match_options_default(&o, 0.2);
+  o.outer_iterations = 4; o.prior_weight = 0.0;
+  std::vector<lvf_scan_match_job> jobs(ids.size());
+  bool ok = true;
+  auto chk = [&](int rc) { if (rc != LVF_OK && ok) { ok = false; *err = lvf_last_error(); } return rc == LVF_OK; };
+  for (size_t k = 0; k < ids.size() && ok; ++k) {
+    const Candidate& c = cands[ids[k]];
+    lvf_scan_match_job& j = jobs[k];
+    std::memset(&j, 0, sizeof(j));
+    if (!c.map_ground.empty())
+      chk(lvf_map_create(ctx, c.map_ground.data(), (int)c.map_ground.size() / 4, 4, o.thr_ground, &j.map_ground)) &&
+          chk(lvf_scan_create(ctx, c.query_ground.data(), (int)c.query_ground.size() / 4, 4, &j.scan_ground));
+    if (ok && !c.map_surf.empty())
+      chk(lvf_map_create(ctx, c.map_surf.data(), (int)c.map_surf.size() / 4, 4, o.thr_surf, &j.map_surf)) &&
+          chk(lvf_scan_create(ctx, c.query_surf.data(), (int)c.query_surf.size() / 4, 4, &j.scan_surf));
+    std::memcpy(j.map_pose, c.map_pose, 56); std::memcpy(j.frame_pose, c.init_pose, 56); std::memcpy(j.last_pose, c.last_pose, 56);
+    j.has_last_pose = 1;
+  }
+  std::vector<lvf_scan_match_result> res(ids.size());
+  if (ok && chk(lvf_scan_match_batch(ctx, jobs.data(), (int)jobs.size(), &o, kRelocateBaseScore, res.data(), nullptr)))
+    for (size_t k = 0; k < ids.size(); ++k) {
+      double* record = table + slots[k] * kRecord;
+      record[0] = (double)(res[k].score - kRelocateBaseScore);
+      std::memcpy(record + 1, res[k].relative_o_c, 56);
+      record[8] = (double)ids[k];
+    }
+  for (auto& j : jobs) {
+    if (j.scan_ground) lvf_scan_destroy(j.scan_ground);
+    if (j.scan_surf) lvf_scan_destroy(j.scan_surf);
+    if (j.map_ground) lvf_map_destroy(j.map_ground);
+    if (j.map_surf) lvf_map_destroy(j.map_surf);
+  }
+  return ok;
+}
+
 int main(int argc, char** argv) {
   if (argc < 4) { std::fprintf(stderr, "usage: relocalize_driver <dir> <n_candidates> <threads> [--devices a,b] [--rank r --world w --idfile f]\n"); return 2; }
   const std::string dir = argv[1];
   const int n = std::atoi(argv[2]), T = std::max(1, std::atoi(argv[3]));
   std::vector<int> devices{0};
   int rank = 0, world = 1;
+  bool batched = true;                 // a worker's candidates in one launch chain (lvf_scan_match_batch); --batched 0: one lvf_scan_match each
   std::string idfile;
   for (int a = 4; a + 1 < argc; a += 2) {
     const std::string k = argv[a], v = argv[a + 1];
@@ -101,6 +142,7 @@ int main(int argc, char** argv) {
     else if (k == "--rank") rank = std::atoi(v.c_str());
     else if (k == "--world") world = std::atoi(v.c_str());
     else if (k == "--idfile") idfile = v;
+    else if (k == "--batched") batched = std::atoi(v.c_str()) != 0;
   }
   std::vector<Candidate> cands(n);
   for (int i = 0; i < n; ++i) cands[i] = load_candidate(dir, i);
@@ -118,6 +160,11 @@ int main(int argc, char** argv) {
     th.emplace_back([&, t] {
       lvf_ctx* ctx = nullptr;
       if (lvf_ctx_create(devices[t % devices.size()], nullptr, &ctx) != LVF_OK) { errors[t] = lvf_last_error(); return; }
+      if (batched) {
+        std::vector<int> ids; std::vector<size_t> sl;
+        for (size_t s = t; s < mine.size(); s += T) { ids.push_back(mine[s]); sl.push_back(s); }
+        if (!ids.empty()) evaluate_batch(ctx, cands, ids, sl, table.data(), &errors[t]);
+      } else
       for (size_t s = t; s < mine.size(); s += T)
         if (!evaluate(ctx, cands[mine[s]], &table[s * kRecord], mine[s], &errors[t])) break;     // a failed candidate keeps its "unused" slot
       lvf_ctx_destroy(ctx);
@@ -181,9 +228,9 @@ int main(int argc, char** argv) {
   }
   lvf_comm_destroy(comm);
   lvf_ctx_destroy(ctx);
-  std::printf("{\"ok\": %d, \"error\": \"%s\", \"rank\": %d, \"world\": %d, \"threads\": %d, \"rccl\": %d, \"eval_ms\": %.3f, \"best\": %d, \"best_score\": %.1f, "
+  std::printf("{\"ok\": %d, \"error\": \"%s\", \"rank\": %d, \"world\": %d, \"threads\": %d, \"batched\": %d, \"rccl\": %d, \"eval_ms\": %.3f, \"best\": %d, \"best_score\": %.1f, "
               "\"best_rel\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g], \"q4\": [%.17g, %.17g, %.17g, %.17g], \"rot_iterations\": %d, \"rot_final_cost\": %.17g}\n",
-              err.empty() ? 1 : 0, err.c_str(), rank, world, T, use_rccl ? 1 : 0, eval_ms, best, best_score, best_rel[0], best_rel[1], best_rel[2], best_rel[3], best_rel[4],
+              err.empty() ? 1 : 0, err.c_str(), rank, world, T, batched ? 1 : 0, use_rccl ? 1 : 0, eval_ms, best, best_score, best_rel[0], best_rel[1], best_rel[2], best_rel[3], best_rel[4],
               best_rel[5], best_rel[6], q4[0], q4[1], q4[2], q4[3], rs.num_iterations, rs.final_cost);
   return err.empty() ? 0 : 1;
 }

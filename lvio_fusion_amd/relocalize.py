@@ -69,8 +69,7 @@ def gather_records(local, world, device=None):
 
 def evaluate_candidate(api, ctx, cand, resolution=0.2):
     """cand: dict(map, map_ground(mask), query, query_ground(mask), map_pose, last_pose, init_pose).  Mapping::Relocate."""
-    mg, ms = cand["map"][cand["map_ground"]], cand["map"][~cand["map_ground"]]
-    qg, qs = cand["query"][cand["query_ground"]], cand["query"][~cand["query_ground"]]
+    mg, ms, qg, qs = split_candidate(cand)
     opt = api.scan_match_options(resolution, outer_iterations=4, prior_weight=0.0)
     h = []
     try:
@@ -85,17 +84,53 @@ def evaluate_candidate(api, ctx, cand, resolution=0.2):
             x.close()
 
 
-def relocalize(api, ctx, candidates, rank=0, world=1, device=None, workers=None):
+def split_candidate(cand):
+    """(map ground, map surf, query ground, query surf) point arrays of a candidate — the reference holds them as separate clouds
+    (frame->feature_lidar->points_ground / points_surf); the synthetic candidates carry masks."""
+    if "split" not in cand:
+        cand["split"] = (np.ascontiguousarray(cand["map"][cand["map_ground"]]), np.ascontiguousarray(cand["map"][~cand["map_ground"]]),
+                         np.ascontiguousarray(cand["query"][cand["query_ground"]]), np.ascontiguousarray(cand["query"][~cand["query_ground"]]))
+    return cand["split"]
+
+
+def evaluate_candidates_batched(api, ctx, cands, resolution=0.2):
+    """All of this rank's candidates in ONE launch chain (lvf_scan_match_batch): map indices and scans are created per candidate, the 4 x
+    {ground, surf} solves of every candidate run side by side and the records come back with one read.  Returns the result list."""
+    opt = api.scan_match_options(resolution, outer_iterations=4, prior_weight=0.0)
+    handles, jobs = [], []
+    try:
+        for cand in cands:
+            mg, ms, qg, qs = split_candidate(cand)
+            mpg = api.Map(ctx, mg, opt.thr_ground) if len(mg) else None
+            scg = api.Scan(ctx, qg) if mpg is not None else None
+            mps = api.Map(ctx, ms, opt.thr_surf) if len(ms) else None
+            scs = api.Scan(ctx, qs) if mps is not None else None
+            handles += [x for x in (mpg, scg, mps, scs) if x is not None]
+            jobs.append(dict(map_ground=mpg, scan_ground=scg, map_surf=mps, scan_surf=scs, map_pose=cand["map_pose"], frame_pose=cand["init_pose"],
+                             last_pose=cand["last_pose"]))
+        res, _ = api.scan_match_batch(ctx, jobs, opt, RELOCATE_BASE_SCORE)
+        return res
+    finally:
+        for x in handles:
+            x.close()
+
+
+def relocalize(api, ctx, candidates, rank=0, world=1, device=None, workers=None, batched=False):
     """Evaluates this rank's share, exchanges the records, returns (best or None, all records).
 
     `workers`: extra api.Context objects on the SAME device.  A candidate is a chain of ~100 small launches and a dozen read-backs
     (two map indices, 4 x {ground, surf} solves on a few hundred points): latency, not throughput — with more than one candidate per
     GPU the chains of different candidates overlap on separate streams, one host thread per context (the C-ABI calls release the GIL);
-    what the reference's Relocator thread does one after the other (relocator.cpp:196-206), and what host/relocalize_driver.cpp does in C++."""
+    what the reference's Relocator thread does one after the other (relocator.cpp:196-206), and what host/relocalize_driver.cpp does in C++.
+    `batched`: this rank's candidates go through ONE launch chain instead (lvf_scan_match_batch)."""
     table = empty_records(slots(len(candidates), world))
     mine = list(enumerate(owned(len(candidates), rank, world)))
     ctxs = [ctx] + list(workers or [])
-    if len(ctxs) == 1 or len(mine) <= 1:
+    if batched:
+        res = evaluate_candidates_batched(api, ctx, [candidates[cid] for _, cid in mine])
+        for (s, cid), r in zip(mine, res):
+            table[s] = make_record(cid, r.score, np.array(r.relative_o_c[:]))
+    elif len(ctxs) == 1 or len(mine) <= 1:
         for s, cid in mine:
             res = evaluate_candidate(api, ctx, candidates[cid])
             table[s] = make_record(cid, res.score, np.array(res.relative_o_c[:]))

@@ -156,11 +156,11 @@ def test_cpp_driver_threads_and_rccl_gather(ctx, oracle, tmp_path):
     np.concatenate([T, fp.ravel(), fv.ravel()]).tofile(f"{d}/tail_forward.f64")
     best_py, rec_py = rl.relocalize(api, ctx, cands)
     outs = []
-    for args in ([str(n), "1"], [str(n), "3"], [str(n), "2", "--rank", "0", "--world", "1", "--idfile", f"{d}/id.bin"]):
+    for args in ([str(n), "1"], [str(n), "3"], [str(n), "2", "--rank", "0", "--world", "1", "--idfile", f"{d}/id.bin"], [str(n), "2", "--batched", "0"]):
         p = subprocess.run([exe, d] + args, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stdout + p.stderr
         o = json.loads(p.stdout.strip().splitlines()[-1]); outs.append(o)
-        assert o["ok"] == 1 and o["threads"] == int(args[1])          # (three host threads, each with its own context / stream on the device, fill one table)
+        assert o["ok"] == 1 and o["threads"] == int(args[1]) and o["batched"] == (0 if "--batched" in args else 1)   # (host threads with their own contexts fill one table; a thread's share is one launch chain unless --batched 0)
         rec = np.fromfile(f"{d}/out_records_r0.f64").reshape(-1, 9)
         assert np.array_equal(np.sort(rec[:, 8]), np.arange(n))
         order = np.argsort(rec[:, 8]); ref_order = np.argsort(rec_py[:, 8])
@@ -186,3 +186,79 @@ def test_cpp_driver_threads_and_rccl_gather(ctx, oracle, tmp_path):
         api._chk(ctx.L.lvf_comm_allgather(h, send.ctypes.data_as(api._lib.c_double_p), 27, recv.ctypes.data_as(api._lib.c_double_p)))
         assert np.array_equal(send, recv) and ctx.L.lvf_comm_world_size(h) == 1 and ctx.L.lvf_comm_rank(h) == 0
         ctx.L.lvf_comm_destroy(h)
+
+
+def test_batched_candidates_equal_one_at_a_time(ctx, oracle):
+    """lvf_scan_match_batch: the eight candidates in ONE launch chain give the records of the one-at-a-time path and of the oracle's
+    Mapping::Relocate restatement, in three candidate orders; `best` follows relocator.cpp:198-204 (`>=`: the later of equal scores)."""
+    from lvio_fusion_amd import api
+    cands = syn.config5_candidates(8, seed=313, n_query=5000, n_az=300)
+    ref_scores, ref_rel = [], []
+    for c in cands:
+        pose, sg, ss, _, _ = oracle_scan_match(oracle, c, 4, 0.0)
+        ref_scores.append(int(sg + ss) - rl.RELOCATE_BASE_SCORE); ref_rel.append(oracle.se3_mul(oracle.se3_inv(c["last_pose"]), pose))
+    for order in (list(range(8)), list(range(7, -1, -1)), [6, 2, 7, 0, 5, 1, 3, 4]):
+        sel = [cands[i] for i in order]
+        best1, rec1 = rl.relocalize(api, ctx, sel)
+        bestb, recb = rl.relocalize(api, ctx, sel, batched=True)
+        assert np.array_equal(recb[:, [0, 8]], rec1[:, [0, 8]]), (order, recb[:, 0], rec1[:, 0])
+        assert np.allclose(recb[:, 1:8], rec1[:, 1:8], rtol=1e-9, atol=1e-12)                  # atomics reorder the last bits
+        assert [int(x) for x in recb[np.argsort(recb[:, 8]), 0]] == [ref_scores[i] for i in order]
+        assert (bestb is None) == (best1 is None) and bestb[0] == best1[0] and bestb[1] == best1[1]
+        assert np.allclose(bestb[2], ref_rel[order[bestb[0]]], rtol=1e-6, atol=1e-9)
+    # the C entry point's own arg-max
+    opt = api.scan_match_options(0.2, outer_iterations=4, prior_weight=0.0)
+    hs, jobs = [], []
+    for c in cands:
+        mg, ms, qg, qs = rl.split_candidate(c)
+        h = [api.Map(ctx, mg, opt.thr_ground), api.Scan(ctx, qg), api.Map(ctx, ms, opt.thr_surf), api.Scan(ctx, qs)]
+        hs += h
+        jobs.append(dict(map_ground=h[0], scan_ground=h[1], map_surf=h[2], scan_surf=h[3], map_pose=c["map_pose"], frame_pose=c["init_pose"], last_pose=c["last_pose"]))
+    res, best = api.scan_match_batch(ctx, jobs, opt, rl.RELOCATE_BASE_SCORE)
+    top = max(s for s in ref_scores if s > 0)
+    assert best == max(k for k, s in enumerate(ref_scores) if s == top)
+    assert [r.score - rl.RELOCATE_BASE_SCORE for r in res] == ref_scores
+    # per-candidate summaries equal lvf_scan_match's on the same handles
+    one = api.scan_match(jobs[3]["map_ground"], jobs[3]["scan_ground"], jobs[3]["map_surf"], jobs[3]["scan_surf"], cands[3]["map_pose"], cands[3]["init_pose"], opt, last_pose=cands[3]["last_pose"])
+    for a, b in ((one.ground, res[3].ground), (one.surf, res[3].surf)):
+        assert (a.num_residual_blocks, a.num_iterations, a.num_successful_steps) == (b.num_residual_blocks, b.num_iterations, b.num_successful_steps)
+        assert abs(a.final_cost - b.final_cost) <= 1e-9 * abs(a.final_cost) + 1e-300
+    # nobody qualifies -> best = -1 ; an empty batch is fine
+    _, nobody = api.scan_match_batch(ctx, [j for j, s in zip(jobs, ref_scores) if s <= 0], opt, rl.RELOCATE_BASE_SCORE)
+    assert nobody == -1
+    assert api.scan_match_batch(ctx, [], opt) == ([], -1)
+    for h in hs:
+        h.close()
+
+
+def test_batched_candidates_with_missing_clouds(ctx, oracle):
+    """Ragged batch: a candidate without a surf cloud, one without a ground cloud, one whose scan is EMPTY (zero query points against a
+    real map: the reference's problem then holds no residual block) and a full one — each equals lvf_scan_match on it alone; scan handles
+    must not repeat across candidates."""
+    from lvio_fusion_amd import api
+    cands = syn.config5_candidates(4, seed=77, n_query=4000, n_az=300, overlap="full")
+    opt = api.scan_match_options(0.2, outer_iterations=2, prior_weight=0.0)
+    hs, jobs = [], []
+    for i, c in enumerate(cands):
+        mg, ms, qg, qs = rl.split_candidate(c)
+        if i == 2:
+            qs = qs[:0]
+        h = [api.Map(ctx, mg, opt.thr_ground), api.Scan(ctx, qg), api.Map(ctx, ms, opt.thr_surf), api.Scan(ctx, qs)]
+        hs += h
+        j = dict(map_ground=h[0], scan_ground=h[1], map_surf=h[2], scan_surf=h[3], map_pose=c["map_pose"], frame_pose=c["init_pose"], last_pose=None if i == 3 else c["last_pose"])
+        if i == 0:
+            j["map_surf"] = j["scan_surf"] = None
+        if i == 1:
+            j["map_ground"] = j["scan_ground"] = None
+        jobs.append(j)
+    res, _ = api.scan_match_batch(ctx, jobs, opt)
+    for j, r in zip(jobs, res):
+        one = api.scan_match(j["map_ground"], j["scan_ground"], j["map_surf"], j["scan_surf"], j["map_pose"], j["frame_pose"], opt, last_pose=j["last_pose"])
+        assert one.score == r.score and one.ground.num_residual_blocks == r.ground.num_residual_blocks and one.surf.num_residual_blocks == r.surf.num_residual_blocks
+        assert np.allclose(one.pose[:], r.pose[:], rtol=1e-9, atol=1e-12) and np.allclose(one.relative_o_c[:], r.relative_o_c[:], rtol=1e-9, atol=1e-12)
+    assert res[0].surf.num_residual_blocks == 0 and res[1].ground.num_residual_blocks == 0 and res[2].surf.num_residual_blocks == 0 and res[2].score_surf == 0.0
+    assert np.allclose(res[3].relative_o_c[:], res[3].pose[:])
+    with pytest.raises(api.LvfError):
+        api.scan_match_batch(ctx, [jobs[3], dict(jobs[3])], opt)
+    for h in hs:
+        h.close()

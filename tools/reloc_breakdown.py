@@ -30,3 +30,25 @@ for rep in range(3):
     print("8 candidates by part (ms): " + "  ".join("%s %.2f" % (k, 1e3 * v) for k, v in T.items()) + "  total %.2f" % (1e3 * sum(T.values())))
 print("sizes of candidate 0: map ground / surf %d / %d, query ground / surf %d / %d" % (
     int(cands[0]["map_ground"].sum()), int((~cands[0]["map_ground"]).sum()), int(cands[0]["query_ground"].sum()), int((~cands[0]["query_ground"]).sum())))
+# ---- the same eight candidates through ONE launch chain (lvf_scan_match_batch); clouds split beforehand (the reference holds them as separate clouds)
+from lvio_fusion_amd import relocalize as rl
+for c in cands:
+    rl.split_candidate(c)
+for rep in range(4):
+    t0 = time.perf_counter()
+    hs, jobs = [], []
+    for c in cands:
+        mg, ms, qg, qs = rl.split_candidate(c)
+        h = [api.Map(ctx, mg, opt.thr_ground), api.Scan(ctx, qg), api.Map(ctx, ms, opt.thr_surf), api.Scan(ctx, qs)]
+        hs += h
+        jobs.append(dict(map_ground=h[0], scan_ground=h[1], map_surf=h[2], scan_surf=h[3], map_pose=c["map_pose"], frame_pose=c["init_pose"], last_pose=c["last_pose"]))
+    ctx.synchronize(); t1 = time.perf_counter()
+    res, best = api.scan_match_batch(ctx, jobs, opt)
+    t2 = time.perf_counter()
+    for h in hs:
+        h.close()
+    t3 = time.perf_counter()
+    print("batched: maps + scans %.2f ms, lvf_scan_match_batch %.2f ms, close %.2f ms, total %.2f ms; best %d, scores %s" % (
+        1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t3 - t0), best, [r.score - 20 for r in res]))
+t0 = time.perf_counter(); b, rec = rl.relocalize(api, ctx, cands, batched=True); print("relocalize(batched=True): %.2f ms" % (1e3 * (time.perf_counter() - t0)))
+t0 = time.perf_counter(); b, rec = rl.relocalize(api, ctx, cands); print("relocalize(one at a time, clouds split beforehand): %.2f ms" % (1e3 * (time.perf_counter() - t0)))
