@@ -269,15 +269,18 @@ __global__ __launch_bounds__(kT) void k_lin_tf(int n, int n_kf, const double2* _
     const int l = lm[i], k1 = kf1[i], k2 = kf2[i];
     const double2 a = fo[i], b = ob[i];
     const PoseD P1 = fetch_pose(s_pose, s.poses, n_kf, k1), P2 = fetch_pose(s_pose, s.poses, n_kf, k2);
-    double r[2], Jd[2], J1[14], J2[14];
-    eval_two_frame<!COST_ONLY>(P1, P2, left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], s.w_kf[k2], r, Jd, J1, J2);
+    double r[2], Jd[2], L1[12], L2[12];
+    if (COST_ONLY) { double J1[14], J2[14]; eval_two_frame<false>(P1, P2, left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], s.w_kf[k2], r, Jd, J1, J2); }
+    else eval_two_frame_local(P1, P2, left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], s.w_kf[k2], r, Jd, L1, L2);
     double rho;
     const double sc = robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
     c = 0.5 * rho;
     if (!COST_ONLY) {
-      double L1[12], L2[12];
-      pose_rows_to_local(J1, s.poses + 7 * k1, (pose_const[k1] & 1) ? 0.0 : sc, L1);
-      pose_rows_to_local(J2, s.poses + 7 * k2, (pose_const[k2] & 1) ? 0.0 : sc, L2);
+      {
+        const double s1 = (pose_const[k1] & 1) ? 0.0 : sc, s2 = (pose_const[k2] & 1) ? 0.0 : sc;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) { L1[q] *= s1; L2[q] *= s2; }
+      }
       const double r0 = sc * r[0], r1 = sc * r[1], d0 = sc * Jd[0], d1 = sc * Jd[1];
       atomicAdd(&C[l], d0 * d0 + d1 * d1);
       atomicAdd(&gr[l], d0 * r0 + d1 * r1);
@@ -373,13 +376,16 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
     const int l = lm[i];
     k1 = kf1[i];
     const double2 a = fo[i], b = ob[i];
-    double r[2], Jd[2], J1[14], J2[14];
-    eval_two_frame<true>(s_pose[k1], s_pose[k2], left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], s.w_kf[k2], r, Jd, J1, J2);
+    double r[2], Jd[2];
+    eval_two_frame_local(s_pose[k1], s_pose[k2], left, right, a.x, a.y, b.x, b.y, s.inv_depth[l], s.w_kf[k2], r, Jd, L1, L2);      // pose rows in tangent coordinates, closed form
     double rho;
     const double sc = robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
     c = 0.5 * rho;
-    pose_rows_to_local(J1, s.poses + 7 * k1, (pose_const[k1] & 1) ? 0.0 : sc, L1);
-    pose_rows_to_local(J2, s.poses + 7 * k2, (pose_const[k2] & 1) ? 0.0 : sc, L2);
+    {
+      const double s1 = (pose_const[k1] & 1) ? 0.0 : sc, s2 = (pose_const[k2] & 1) ? 0.0 : sc;
+#pragma unroll
+      for (int q = 0; q < 12; ++q) { L1[q] *= s1; L2[q] *= s2; }
+    }
     r0 = sc * r[0]; r1 = sc * r[1];
     const double d0 = sc * Jd[0], d1 = sc * Jd[1];
     if (cp.on) {
@@ -699,14 +705,18 @@ __device__ __forceinline__ void lin_po_body(const int vb, int n, int n_kf, const
     const double2 o = ob[i];
     const PoseD P = fetch_pose(s_pose, s.poses, n_kf, k);
     const double pwl[3] = {pw[3 * l], pw[3 * l + 1], pw[3 * l + 2]};
-    double r[2], J[14];
-    eval_pose_only<!COST_ONLY>(P, cam, o.x, o.y, pwl, s.w_kf[k], r, J);
+    double r[2], Lc[12];
+    if (COST_ONLY) { double J[14]; eval_pose_only<false>(P, cam, o.x, o.y, pwl, s.w_kf[k], r, J); }
+    else eval_pose_only_local(P, cam, o.x, o.y, pwl, s.w_kf[k], r, Lc);
     double rho;
     const double sc = robust_scale(huber, r[0] * r[0] + r[1] * r[1], rho);
     c = 0.5 * rho;
     if (!COST_ONLY) {
-      double Lc[12];
-      pose_rows_to_local(J, s.poses + 7 * k, (pose_const[k] & 1) ? 0.0 : sc, Lc);
+      {
+        const double sl = (pose_const[k] & 1) ? 0.0 : sc;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) Lc[q] *= sl;
+      }
       const double r0 = sc * r[0], r1 = sc * r[1];
       int q = 0;
 #pragma unroll
