@@ -13,9 +13,10 @@ every batch does the same work and the problem never converges into a run of rej
 repeat bracketed by barrier + synchronize with the maximum over ranks taken per repeat: `value` = K / the MEDIAN repeat, so a short
 `--steps 20` run reports the same rate as a long one; the slowest and fastest repeats ride along.
 `roofline` is ONE object: the dominant kernel of the iteration by time (kernel, bound, achieved, peak, unit, frac, traffic);
-`roofline_all` lists it together with the merged linearisation (HBM) and the band Schur complement (MFMA).  All are timed live with
-HIP events on the library's stream (lvf_problem_stage_times) minus the measured cost of an empty event pair (`event_pair_us`), which
-makes the stage times agree with rocprofv3's kernel durations under profiles/.  `legs` holds the other parts of the metric: the
+`roofline_all` lists it together with the merged linearisation (fp64 VALU issue) and the band Schur complement (MFMA).  All are timed
+live inside this run: every kernel of the chain is launched with its own start / stop HIP events (hipExtLaunchKernelGGL: the dispatch
+packet's timestamps, the source rocprofv3's kernel trace reads), a stage's time is the sum over its launches (lvf_problem_stage_times2).
+`roofline_icp` is the same kind of object for the association kernel (k_knn3) of the metric's second half.  `legs` holds the other parts of the metric: the
 batched-windows solver (8/16 windows per launch chain), the configs[1] PoseOnly pass (K1) with its HBM roofline, the ICP association
 as 8d defines a pair, the window tick and the Ceres-surface solve.  `verified` says which legs were checked against the oracle in this
 run.  `cpu_baseline` is the restated reference CPU path (oracle) on a bounded sample — a reported baseline, not the target.
@@ -38,6 +39,8 @@ os.environ.setdefault("OMP_NUM_THREADS", str(min(8, max(1, int(0.75 * (os.cpu_co
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 vector = matrix peak (dense)
+N_SIMD, CLOCK_GHZ = 1024, 2.4    # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 clocks
+VALU_PEAK_GCYC = N_SIMD * CLOCK_GHZ   # SIMD-cycles per nanosecond the chip can spend issuing VALU work
 POSE_ONLY_BYTES_PER_BLOCK = 152  # ob 16 + 2 idx 8 + r 16 + J 112
 KNN_BYTES = lambda Q, M: 40 * Q + 16 * M   # SURVEY 8d kNN pass
 N_REPEATS = 10                   # timed batches of K steps each; the line reports their median
@@ -45,19 +48,23 @@ CHUNK = 20                       # LM iterations per device-loop solve inside a 
 
 
 def pmc_counters(kernel_substr):
-    """Average per-dispatch PMC counters of a kernel from the committed passes (profiles/pmc_latest.json, written by
-    tools/prof_summary.py from separate rocprofv3 --pmc runs of this same command): bench.py itself cannot collect PMC counters."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if not os.path.exists(path):
-        return None, None
-    try:
-        d = json.load(open(path))
-        for name, c in d["kernels"].items():
-            if kernel_substr in name:
-                return c, "profiles/pmc_latest.json (" + d.get("tag", "?") + ")"
-    except Exception:
-        pass
-    return None, None
+    """Average per-dispatch PMC counters of a kernel from the committed passes (profiles/pmc_latest.json and profiles/pmc_icp_latest.json,
+    written by tools/prof_summary.py / tools/prof_icp_summary.py from separate rocprofv3 --pmc runs of these same commands): bench.py
+    itself cannot collect PMC counters.  Counters of the same kernel found in both files are merged (the later file wins)."""
+    out, src = {}, []
+    for fn in ("pmc_latest.json", "pmc_icp_latest.json"):
+        path = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))
+            for name, c in d["kernels"].items():
+                if kernel_substr in name:
+                    out.update(c); src.append("profiles/" + fn + " (" + d.get("tag", "?") + ")")
+                    break
+        except Exception:
+            pass
+    return (out, "; ".join(src)) if out else (None, None)
 
 
 def pmc_traffic(kernel_substr):
@@ -215,6 +222,8 @@ def main():
             out["legs"] = legs(api, syn, ctx, local_rank, verified, args.legs)
         except Exception as e:
             out["legs"] = {"error": repr(e)}
+        if isinstance(out.get("legs"), dict) and isinstance(out["legs"].get("icp"), dict) and "roofline_icp" in out["legs"]["icp"]:
+            out["roofline_icp"] = out["legs"]["icp"]["roofline_icp"]
         for key in ("batched_windows_8", "small_windows_100", "window_tick", "ceres_surface_solve", "icp"):     # the drop-in costs and the metric's second half, top level
             if isinstance(out.get("legs"), dict) and key in out["legs"]:
                 out[key] = out["legs"][key]
@@ -268,17 +277,17 @@ def main():
 
 
 def roofline(api, ctx, prob, st, cfg, handles):
-    """The iteration's launch chain timed stage by stage with HIP events on the library's stream (10 iterations from the perturbed
-    start).  An event pair with nothing between its two records still measures a few microseconds (the marker's own processing): that
-    cost is measured (lvf_event_pair_us) and subtracted once per stage, so a stage's time is its kernels' durations + the gaps between
-    them — what rocprofv3 --kernel-trace reports (profiles/).  Returns (roofline entries, dominant first; stage table; event-pair cost)."""
+    """The iteration's launch chain timed stage by stage (10 iterations from the perturbed start): every kernel is launched with its own
+    start / stop events, a stage's time is the sum of its kernels' durations — what rocprofv3 --kernel-trace reports (profiles/).  The
+    span between the stream events that bracket a stage (kernels + gaps + marker cost) rides along in the table, with the cost of an empty
+    event pair.  Returns (roofline entries, dominant first; stage table; event-pair cost)."""
     btc, btf, bpo, bimu, _ = handles
     reset_state(api, st, cfg)
     ev_us = api.event_pair_us(ctx)
-    raw = prob.stage_times(api.default_solver_options(), radius=1e4, reps=10)
-    stages = [(n, max(us - ev_us, 0.0) if la else 0.0, la) for n, us, la in raw]
+    raw = prob.stage_times(api.default_solver_options(), radius=1e4, reps=10, spans=True)
+    stages = [(n, us if la else 0.0, la) for n, us, la, _ in raw]
     total = sum(us for _, us, _ in stages)
-    table = [{"stage": n, "us": us, "us_with_event_pair": ru, "launches": la, "share": us / total if total else None} for (n, us, la), (_, ru, _) in zip(stages, raw)]
+    table = [{"stage": n, "us": us, "us_span_between_stream_events": sp, "launches": la, "share": us / total if total else None} for (n, us, la), (_, _, _, sp) in zip(stages, raw)]
     by = {n: (us, la) for n, us, la in stages}
     out = []
     d_dense = 64 * ((6 * cfg["n_kf"] + 63) // 64)
@@ -294,11 +303,23 @@ def roofline(api, ctx, prob, st, cfg, handles):
                       "traffic": (pmc_traffic(e["kernel"]) or {}).get("bytes"), "algorithmic_flops_per_iteration": flops,
                       "note": "dense Cholesky of the reduced system's pose corner: a dependent pivot chain (latency-bound); priced against the fp64 matrix peak"})
         elif "k_lin_visual" in name:
+            # Bound by the ISSUE of fp64 vector instructions inside its waves, not by memory: 1.6 waves per SIMD, each a dependent chain of
+            # ~1 400-2 800 VALU instructions.  The roofline is therefore VALU issue: SIMD-cycles the kernel's VALU
+            # instructions occupy (SQ_INSTS_VALU x 4 clocks, from the committed PMC pass) per second of kernel time, against
+            # 1 024 SIMDs x 2.4 GHz.  The HBM view rides along (algorithmic bytes and counter traffic).
             tr = pmc_traffic("k_lin_visual")
-            ach = lin_bytes / (us * 1e-6) / 1e9
-            e.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": (tr or {}).get("bytes"),
-                      "traffic_over_algorithmic": (tr["bytes"] / lin_bytes) if tr else None, "traffic_detail": tr, "algorithmic_bytes_per_launch": lin_bytes,
-                      "note": "merged visual + IMU linearisation; algorithmic bytes = PoseOnly 24 B + TwoFrame 44 B in + 48 B of E out + TwoCamera 36 B per block, IMU 6256 B per factor (DESIGN.md section 4)"})
+            c, src = pmc_counters("k_lin_visual(")
+            hbm = lin_bytes / (us * 1e-6) / 1e9
+            e.update({"bound": "valu", "peak": VALU_PEAK_GCYC, "unit": "G SIMD-cycles/s", "traffic": (tr or {}).get("bytes"),
+                      "hbm_view": {"achieved_GBs": hbm, "frac_of_8TBs": hbm / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": lin_bytes,
+                                   "traffic_over_algorithmic": (tr["bytes"] / lin_bytes) if tr else None, "traffic_detail": tr},
+                      "note": "merged visual + IMU linearisation: fp64 VALU issue-bound (SQ_INSTS_VALU x 4 clk / (1024 SIMDs x kernel time x 2.4 GHz)); algorithmic bytes = PoseOnly 24 B + "
+                              "TwoFrame 44 B in + 48 B of E out + TwoCamera 36 B per block, IMU 6256 B per factor (DESIGN.md section 4)"})
+            if c and "SQ_INSTS_VALU" in c:
+                ach = 4.0 * c["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9
+                e.update({"achieved": ach, "frac": ach / VALU_PEAK_GCYC, "valu_instructions_per_launch": c["SQ_INSTS_VALU"], "waves_per_launch": c.get("SQ_WAVES"), "source": src})
+            else:
+                e.update({"achieved": None, "frac": None})
         elif "k_schur" in name:
             c, src = pmc_counters("k_schur_sp0")
             e.update({"bound": "mfma", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": (pmc_traffic("k_schur_sp0") or {}).get("bytes"),
@@ -531,6 +552,29 @@ def icp_leg(api, syn, ctx, verified):
     ex["pair_association_plus_linearisation"] = {"Q": Q, "ms": 1e3 * dt, "mpairs_per_s": Q / dt / 1e6, "valid_blocks": int(summ.num_residual_blocks),
                                                  "note": "wall time of lvf_icp_solve(max 1 iteration) incl. its 200-byte read-back"}
     ex["icp_mpairs_per_sec"] = ex["pair_association_plus_linearisation"]["mpairs_per_s"]
+    # roofline of the association kernel (the metric's second half): algorithmic pass bytes 40 Q + 16 M against HBM (it is cache / latency
+    # bound: the honest companions are the counter traffic, the candidates a query evaluates and the VALU issue share)
+    try:
+        g = ex["knn3_ground_thr4.0"]
+        c, src = pmc_counters("k_knn3<false>")
+        us = g["ms"] * 1e3
+        ach = KNN_BYTES(Q, M) / (us * 1e-6) / 1e9
+        r = {"kernel": "k_knn3", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_us": us,
+             "algorithmic_bytes_per_launch": KNN_BYTES(Q, M), "traffic": None, "candidates_per_query_mean": g["candidates_per_query_mean"],
+             "candidate_evaluations_per_sec": g["candidate_evaluations_per_sec"],
+             "note": "3-NN association, ground gate, Q = 100 k / M = 340 k: 20 back-to-back launches between two events on the library's stream; cache / latency bound "
+                     "(a query walks ~10 dependent cell look-ups); traffic and VALU share from the committed PMC passes of this leg (average over the ground and surf launches)"}
+        if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            r["traffic_over_algorithmic"] = r["traffic"] / KNN_BYTES(Q, M)
+            r["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c else None
+            r["source"] = src + "; FETCH_SIZE x2 per gfx950 correction"
+        if c and "SQ_INSTS_VALU" in c:
+            r["valu_issue_frac"] = 4.0 * c["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9 / VALU_PEAK_GCYC
+            r["valu_instructions_per_query"] = c["SQ_INSTS_VALU"] * 64.0 / 8.0 / Q      # 8 lanes cooperate on a query
+        ex["roofline_icp"] = r
+    except Exception as e:
+        ex["roofline_icp"] = {"error": repr(e)}
     try:
         from oracle import pyoracle as po
         nq = 4000

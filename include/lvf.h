@@ -419,12 +419,16 @@ int lvf_problem_batch_lm_iteration(lvf_problem_batch* b, const lvf_solver_option
                                    double* cost_after, int* accepted);
 int lvf_problem_batch_solve(lvf_problem_batch* b, const lvf_solver_options* o, lvf_solver_summary* summaries);
 
-/* Measurement tap (bench.py's roofline lines): `reps` LM iterations from the current state with HIP events between the stages of the
- * launch chain, on the library's stream.  us[k] = average duration of stage k in microseconds, launches[k] (may be NULL) = kernel
- * launches it consists of; k < lvf_problem_stage_count(), names from lvf_problem_stage_name. */
+/* Measurement tap (bench.py's roofline lines): `reps` LM iterations from the current state, timed on the library's stream.  us[k] = average
+ * duration of stage k in microseconds (the sum of its kernels' own durations: see lvf_problem_stage_times2), launches[k] (may be NULL) =
+ * kernel launches it consists of; k < lvf_problem_stage_count(), names from lvf_problem_stage_name. */
 int lvf_problem_stage_count(void);
 const char* lvf_problem_stage_name(int stage);
 int lvf_problem_stage_times(lvf_problem* p, const lvf_solver_options* o, double radius, int reps, double* us, int* launches);
+/* The same with both clocks: us[k] = the sum of the stage's KERNEL durations (a start / stop event pair recorded with every launch — the
+ * dispatch's own timestamps, what rocprofv3 --kernel-trace reports); spans_us[k] (may be NULL) = the time between the events that bracket
+ * the stage on the stream (kernels + gaps + the markers' own cost). */
+int lvf_problem_stage_times2(lvf_problem* p, const lvf_solver_options* o, double radius, int reps, double* us, double* spans_us, int* launches);
 
 /* Problem::Evaluate's gradient at the current state: J^T r with the Corrector applied and pose blocks in tangent coordinates.
  * gc[15 n_kf] = (6 x n_kf pose tangents | 9 x n_kf (v, ba, bg)); gl[n_lm] (may be NULL) = the inverse-depth entries.  Constant poses: 0. */

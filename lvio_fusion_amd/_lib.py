@@ -124,6 +124,7 @@ _SIGS = {
     "lvf_problem_stage_count": (C.c_int, []),
     "lvf_problem_stage_name": (C.c_char_p, [C.c_int]),
     "lvf_problem_stage_times": (C.c_int, [_VP, C.POINTER(SolverOptions), C.c_double, C.c_int, c_double_p, C.POINTER(C.c_int)]),
+    "lvf_problem_stage_times2": (C.c_int, [_VP, C.POINTER(SolverOptions), C.c_double, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int)]),
     "lvf_relocate_r_evaluate": (C.c_int, [_VP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "lvf_relocate_rotation_solve": (C.c_int, [_VP, C.c_int, c_double_p, c_double_p, c_double_p, C.POINTER(SolverOptions), C.POINTER(SolverSummary)]),
     "lvf_forward_update": (C.c_int, [_VP, c_double_p, C.c_int, c_double_p, c_double_p]),

@@ -595,12 +595,16 @@ class Problem:
         """test hook: the next n chained hand-overs of this problem time out (lvf_problem_debug_force_handover_timeout)"""
         _chk(self.ctx.L.lvf_problem_debug_force_handover_timeout(self.h, int(n)))
 
-    def stage_times(self, opt, radius=1e4, reps=10):
-        """[(stage name, average microseconds, launches)] of `reps` LM iterations from the current state (HIP events between stages)."""
+    def stage_times(self, opt, radius=1e4, reps=10, spans=False):
+        """[(stage name, average microseconds, launches)] of `reps` LM iterations from the current state: the sum of the stage's KERNEL
+        durations (start / stop events recorded with every launch — the dispatch timestamps rocprofv3's kernel trace reports).
+        spans=True appends the between-stage event span (kernels + gaps + marker cost) as a fourth entry."""
         L = self.ctx.L
         n = L.lvf_problem_stage_count()
-        us = np.zeros(n); la = (C.c_int * n)()
-        _chk(L.lvf_problem_stage_times(self.h, C.byref(opt), float(radius), int(reps), _dp(us), la))
+        us = np.zeros(n); sp = np.zeros(n); la = (C.c_int * n)()
+        _chk(L.lvf_problem_stage_times2(self.h, C.byref(opt), float(radius), int(reps), _dp(us), _dp(sp), la))
+        if spans:
+            return [(L.lvf_problem_stage_name(i).decode(), float(us[i]), int(la[i]), float(sp[i])) for i in range(n)]
         return [(L.lvf_problem_stage_name(i).decode(), float(us[i]), int(la[i])) for i in range(n)]
 
     def gradient(self, opt):

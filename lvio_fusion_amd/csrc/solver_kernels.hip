@@ -9,6 +9,7 @@
 // kept dense [n_lm x ldE] (ldE = 6 n_kf rounded up to 16, +1 column carrying g_rho) and the rank-n_lm update is one
 // v_mfma_f64_16x16x4_f64 SYRK ("MFMA only for the dense Schur reduce").  The right-hand side rides along as an
 // augmented ROW of S (index d), so the forward substitution comes out of the Cholesky for free.
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -3219,13 +3220,31 @@ static const char* const kStageNames[ST_N] = {"k_zero_multi (only when the accum
 // (one event set per timed iteration: the iterations are enqueued back to back and waited for ONCE, so every stage — the first one of an
 // iteration included — starts behind a busy queue like in the device loop; with a wait per iteration the first stage absorbed the idle
 // queue's start-up, ~6 us of k_lin_visual's figure)
-constexpr int kClockReps = 16;
-struct StageClock { hipEvent_t ev[kClockReps][ST_N + 1]; int launches[ST_N]; bool on = false; int rep = 0; };
+constexpr int kClockReps = 16, kClockLaunches = 48;
+// Two sources per timed iteration: ev[] — events between the STAGES on the stream (a span: kernels + the gaps between them + the marker's own
+// cost) — and kstart[] / kstop[] — a start / stop event pair recorded WITH every kernel launch of the fast chain (hipExtLaunchKernelGGL: the
+// dispatch packet's own timestamps, i.e. what rocprofv3 --kernel-trace reports as the kernel's duration).  Stage times are the sums of the
+// second kind, so bench.py's roofline entries follow profiles/ for short stages too (the event-pair subtraction left k_lin_visual 18 % high).
+struct StageClock {
+  hipEvent_t ev[kClockReps][ST_N + 1]; int launches[ST_N]; bool on = false; int rep = 0;
+  hipEvent_t kstart[kClockReps][kClockLaunches], kstop[kClockReps][kClockLaunches]; int kstage[kClockLaunches]; int nk = 0; bool kernel_events = false;
+};
 void stage_clock_free(StageClock* k) {
   if (!k) return;
   for (auto& r : k->ev) for (auto& e : r) (void)hipEventDestroy(e);
+  if (k->kernel_events) { for (auto& r : k->kstart) for (auto& e : r) (void)hipEventDestroy(e); for (auto& r : k->kstop) for (auto& e : r) (void)hipEventDestroy(e); }
   delete k;
 }
+// a launch of the iteration's fast chain: plain, or — while lvf_problem_stage_times is recording — with its own start / stop events
+#define LVF_CHAIN_LAUNCH(p_, stage_, kernel_, grid_, block_, lds_, q_, ...)                                                          \
+  do {                                                                                                                              \
+    StageClock* k__ = (p_)->clk;                                                                                                    \
+    if (k__ && k__->on && k__->kernel_events && k__->nk < kClockLaunches) {                                                         \
+      const int i__ = k__->nk++;                                                                                                    \
+      k__->kstage[i__] = (stage_);                                                                                                  \
+      hipExtLaunchKernelGGL(kernel_, grid_, block_, lds_, q_, k__->kstart[k__->rep][i__], k__->kstop[k__->rep][i__], 0, __VA_ARGS__); \
+    } else hipLaunchKernelGGL(kernel_, grid_, block_, lds_, q_, __VA_ARGS__);                                                       \
+  } while (0)
 static inline void stage_mark(lvf_problem* p, int stage_done, int launches) {
   StageClock* k = p->clk;
   if (!k || !k->on) return;
@@ -3247,7 +3266,7 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated, bool iter
   const bool clean = c.fast && p->accum_clean;
   p->accum_clean = false;
   if (p->clk && p->clk->on) (void)hipEventRecord(p->clk->ev[p->clk->rep][0], q);
-  if (!clean) hipLaunchKernelGGL(k_zero_multi, dim3(512, c.zero.count), dim3(kT), 0, q, c.zero);
+  if (!clean) LVF_CHAIN_LAUNCH(p, ST_IMU_LIN, k_zero_multi, dim3(512, c.zero.count), dim3(kT), 0, q, c.zero);
   if (c.fast) {
     imu_done = true;                           // the ImuError factors are evaluated inside the merged launch below
     stage_mark(p, ST_IMU_LIN, clean ? 0 : 1);
@@ -3258,13 +3277,13 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated, bool iter
     static const bool lin_timing = std::getenv("LVF_LIN_TIMING") != nullptr;
     if (lin_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)la.v.n_tfw * 24 + 8)); la.dbg = p->dbg_lin.p; }
     static const size_t lds_pad = [] { const char* e = std::getenv("LVF_LIN_LDS_PAD"); return e ? (size_t)std::atoi(e) : (size_t)0; }();      // experiment: fewer workgroups per CU
-    hipLaunchKernelGGL(k_lin_visual, dim3(la.nblocks), dim3(kT), c.lin_lds + lds_pad, q, la);
+    LVF_CHAIN_LAUNCH(p, ST_LIN_VISUAL, k_lin_visual, dim3(la.nblocks), dim3(kT), c.lin_lds + lds_pad, q, la);
     stage_mark(p, ST_LIN_VISUAL, 1);
     if (p->compact) {
       TfReduceArgs ra = c.red;
       if (!gated) ra.done = nullptr;
       if (!iteration) { ra.nblocks = ra.own_blocks; ra.ride.nblocks = 0; }
-      hipLaunchKernelGGL(k_tf_reduce, dim3(ra.nblocks), dim3(kT), ra.ride.nblocks > 0 ? c.red_lds : 0, q, ra);
+      LVF_CHAIN_LAUNCH(p, ST_TF_REDUCE, k_tf_reduce, dim3(ra.nblocks), dim3(kT), ra.ride.nblocks > 0 ? c.red_lds : 0, q, ra);
     }
     stage_mark(p, ST_TF_REDUCE, p->compact ? 1 : 0);
     if (lin_timing) {
@@ -3358,7 +3377,7 @@ static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool
   // triangle — stays NaN; results must not change (tests/test_gpu_solver.py runs the parity cases this way too)
   static const bool poison = std::getenv("LVF_POISON_S") != nullptr;
   if (poison) LVF_HIP(hipMemsetAsync(p->S.p, 0xff, (size_t)p->ld * p->ld * 8, q));
-  hipLaunchKernelGGL(k_prepare, dim3(pa.nblocks), dim3(kT), pa.ride.nblocks > 0 ? c.prep_lds : 0, q, pa);
+  LVF_CHAIN_LAUNCH(p, ST_PREPARE, k_prepare, dim3(pa.nblocks), dim3(kT), pa.ride.nblocks > 0 ? c.prep_lds : 0, q, pa);
   stage_mark(p, ST_PREPARE, 1);
   if (!early && c.early) p->accum_clean = false;       // the tap wrote S: the next iteration must clear it
   if (level0_done) *level0_done = false;
@@ -3370,7 +3389,7 @@ static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool
       static const bool schur_timing = std::getenv("LVF_SCHUR_TIMING") != nullptr;
       const int ns = sa.n_work;
       if (schur_timing) { LVF_TRY(p->dbg_lin.ensure((size_t)ns * 8 + 8)); LVF_HIP(hipMemsetAsync(p->dbg_lin.p, 0, (size_t)ns * 64, q)); sa.dbg = p->dbg_lin.p; }
-      if (sa.nblocks > 0) hipLaunchKernelGGL(k_schur_sp0, dim3(sa.nblocks), dim3(256), c.ssp0_lds, q, sa);
+      if (sa.nblocks > 0) LVF_CHAIN_LAUNCH(p, ST_SCHUR_SP0, k_schur_sp0, dim3(sa.nblocks), dim3(256), c.ssp0_lds, q, sa);
       stage_mark(p, ST_SCHUR_SP0, 1);
       if (schur_timing) {
         std::vector<unsigned long long> t((size_t)ns * 8);
@@ -3433,23 +3452,23 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
   LVF_TRY(enqueue_reduced_system(p, &p->ctl.p->radius, true, true, &level0_done));
   const int own0 = level0_done ? c.first_own_level : 0;      // (levels below rode in the launches above)
   for (int lv = own0; lv < c.n_levels; ++lv)
-    hipLaunchKernelGGL(k_sp_eliminate, dim3(c.sp[lv].nblocks), dim3(256), c.sp_lds[lv], q, c.sp[lv]);
+    LVF_CHAIN_LAUNCH(p, ST_SP_LEVELS, k_sp_eliminate, dim3(c.sp[lv].nblocks), dim3(256), c.sp_lds[lv], q, c.sp[lv]);
   stage_mark(p, ST_SP_LEVELS, std::max(0, c.n_levels - own0));
   for (int kb = 0; kb < p->nb; ++kb) {
     CholArgs cha = c.chol;
     static const bool chol_timing = std::getenv("LVF_CHOL_TIMING") != nullptr;
     if (chol_timing) { LVF_TRY(p->dbg.ensure(64)); cha.dbg = p->dbg.p; }
-    hipLaunchKernelGGL(k_chol_step, dim3(chol_step_grid(p->nb, kb)), dim3(kCT), 0, q, cha, kb);
+    LVF_CHAIN_LAUNCH(p, ST_CHOL, k_chol_step, dim3(chol_step_grid(p->nb, kb)), dim3(kCT), 0, q, cha, kb);
   }
   {
     BackArgs ba = c.back;
     static const bool back_timing = std::getenv("LVF_BACK_TIMING") != nullptr;
     if (back_timing) { LVF_TRY(p->dbg.ensure(64)); ba.sp.dbg = p->dbg.p; }
     stage_mark(p, ST_CHOL, p->nb);
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(kBT), c.back_lds, q, ba);
+    LVF_CHAIN_LAUNCH(p, ST_BACKSOLVE, k_chol_backsolve, dim3(1), dim3(kBT), c.back_lds, q, ba);
     stage_mark(p, ST_BACKSOLVE, 1);
   }
-  hipLaunchKernelGGL(k_step_tail, dim3(c.tail.nblocks), dim3(kT), c.tail_lds, q, c.tail);
+  LVF_CHAIN_LAUNCH(p, ST_STEP_TAIL, k_step_tail, dim3(c.tail.nblocks), dim3(kT), c.tail_lds, q, c.tail);
   stage_mark(p, ST_STEP_TAIL, 1);
   // candidate cost: the small passes first, then the visual pass whose last workgroup closes the iteration
   CostArgs ca = c.cost;
@@ -3465,13 +3484,13 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
     DecideArgs da = c.dec;
     static const bool cost_timing = std::getenv("LVF_COST_TIMING") != nullptr;
     if (cost_timing) { LVF_TRY(p->dbg.ensure(64)); da.dbg = p->dbg.p; }
-    hipLaunchKernelGGL(k_cost_decide, dim3(ca.nblocks + ca.zero_wgs), dim3(kT), 0, q, ca, da, end_zero ? 1 : 0);
+    LVF_CHAIN_LAUNCH(p, ST_COST, k_cost_decide, dim3(ca.nblocks + ca.zero_wgs), dim3(kT), 0, q, ca, da, end_zero ? 1 : 0);
     p->accum_clean = ca.zero_wgs > 0;
     if (p->accum_clean) p->linearized = false;         // the normal equations of this iteration are gone: no reduced-system tap
     stage_mark(p, ST_COST, 1 + (c.has_imu && !c.imu_in_cost ? 1 : 0) + (c.has_prior ? 2 : 0));
   } else {
     stage_mark(p, ST_COST, (c.has_imu ? 1 : 0) + (c.has_prior ? 2 : 0));
-    hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(kDT), 0, q, c.dec);
+    LVF_CHAIN_LAUNCH(p, ST_DECIDE, k_lm_decide, dim3(1), dim3(kDT), 0, q, c.dec);
     stage_mark(p, ST_DECIDE, 1);
   }
   LVF_HIP(hipGetLastError());
@@ -4179,40 +4198,61 @@ const char* lvf_problem_stage_name(int stage) { return stage >= 0 && stage < ST_
 
 // `reps` LM iterations from the problem's current state (they ARE iterations: accepted steps move the state), HIP events on the
 // library's stream between the stages; us[k] = average duration of stage k, launches[k] = kernel launches it consists of.
-int lvf_problem_stage_times(lvf_problem* p, const lvf_solver_options* o, double radius, int reps, double* us, int* launches) {
+int lvf_problem_stage_times2(lvf_problem* p, const lvf_solver_options* o, double radius, int reps, double* us, double* spans_us, int* launches) {
   LVF_REQUIRE(p && o && us && reps > 0, "lvf_problem_stage_times: bad argument");
   LVF_TRY(lvf::enter(p->ctx));
   hipStream_t q = p->ctx->stream;
   if (!p->clk) {
     p->clk = new StageClock();
     for (auto& r : p->clk->ev) for (auto& e : r) LVF_HIP(hipEventCreate(&e));
+    for (auto& r : p->clk->kstart) for (auto& e : r) LVF_HIP(hipEventCreate(&e));
+    for (auto& r : p->clk->kstop) for (auto& e : r) LVF_HIP(hipEventCreate(&e));
+    p->clk->kernel_events = true;
   }
   StageClock& k = *p->clk;
   for (int i = 0; i < ST_N; ++i) { us[i] = 0.0; k.launches[i] = 0; }
+  std::vector<double> span(ST_N, 0.0), kern(ST_N, 0.0);
+  std::vector<int> kcount(ST_N, 0);
   reps = std::min(reps, kClockReps);
   LmCtl c;
   ctl_from_options(o, radius, 2.0, reps + 2, false, &c);
   p->huber = o->huber_a;
   LVF_TRY(upload_ctl(p, c));
   LVF_TRY(enqueue_iteration(p, true));             // (un-timed: the timed iterations queue up behind it)
+  int nk = 0;
   for (int r = 0; r < reps; ++r) {
-    k.on = true; k.rep = r;
+    k.on = true; k.rep = r; k.nk = 0;
     const int rc = enqueue_iteration(p, true);
     k.on = false;
+    nk = k.nk;
     LVF_TRY(rc);
   }
   LVF_HIP(hipStreamSynchronize(q));
-  for (int r = 0; r < reps; ++r)
+  for (int r = 0; r < reps; ++r) {
     for (int i = 0; i < ST_N; ++i) {
       if (k.launches[i] == 0) continue;
       int prev = i;                                   // the event after the closest earlier stage that launched something (or event 0)
       while (prev > 0 && k.launches[prev - 1] == 0) --prev;
       float ms = 0.f;
       LVF_HIP(hipEventElapsedTime(&ms, k.ev[r][prev], k.ev[r][i + 1]));
-      us[i] += 1e3 * (double)ms / reps;
+      span[i] += 1e3 * (double)ms / reps;
     }
+    for (int j = 0; j < nk; ++j) {                    // the kernels' own durations (dispatch timestamps)
+      float ms = 0.f;
+      LVF_HIP(hipEventElapsedTime(&ms, k.kstart[r][j], k.kstop[r][j]));
+      kern[k.kstage[j]] += 1e3 * (double)ms / reps;
+      if (r == 0) kcount[k.kstage[j]] += 1;
+    }
+  }
+  // a stage whose launches all carried their own events reports the sum of the kernel durations; others (generic paths: stand-alone IMU /
+  // prior passes) keep the between-stage span
+  for (int i = 0; i < ST_N; ++i) us[i] = (k.launches[i] > 0 && kcount[i] == k.launches[i]) ? kern[i] : span[i];
+  if (spans_us) for (int i = 0; i < ST_N; ++i) spans_us[i] = span[i];
   if (launches) for (int i = 0; i < ST_N; ++i) launches[i] = k.launches[i];
   return LVF_OK;
+}
+int lvf_problem_stage_times(lvf_problem* p, const lvf_solver_options* o, double radius, int reps, double* us, int* launches) {
+  return lvf_problem_stage_times2(p, o, radius, reps, us, nullptr, launches);
 }
 
 int lvf_problem_gradient(lvf_problem* p, const lvf_solver_options* o, double* gc, double* gl) {
