@@ -294,7 +294,8 @@ int lvf_icp_solve(lvf_map* m, lvf_scan* s, const double* map_pose, const double*
 /* ---- one frame's scan-to-map update: Mapping::Optimize's body (mapping.cpp:147-178) / Mapping::Relocate (:251-300) ---- */
 typedef struct lvf_scan_match_options {
   float thr_ground, thr_surf;      /* resolution^2 * 100 / * 25 (association.cpp:285,343) */
-  double weight_ground, weight_surf; /* frame->weights.lidar_ground / lidar_surf */
+  double weight_ground, weight_surf; /* frame->weights.lidar_ground / lidar_surf — FLOAT fields in the reference (adapt/weights.h:10-12): pass the
+                                      * float's value, e.g. (double)0.01f, which is what lvf_scan_match_options_default sets */
   double huber_surf;               /* 0.1 (association.cpp:330); ground uses TrivialLoss */
   double prior_weight;             /* |features_left| * weights.visual; 0 = relocate mode (association.cpp:321,379) */
   int outer_iterations;            /* 1 = Mapping::Optimize, 4 = Mapping::Relocate (mapping.cpp:264) */

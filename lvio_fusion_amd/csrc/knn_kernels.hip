@@ -14,6 +14,7 @@
 // (dx*dx + dy*dy) + dz*dz with explicit round-to-nearest mul/add (no FMA contraction); ties resolve by
 // ascending (d2, map index), which makes the result independent of traversal order.
 #include <cmath>
+#include <cstdlib>
 #include "lvf_internal.hpp"
 #include "scan_match_dev.hpp"
 
@@ -559,7 +560,8 @@ static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_devic
   // level halves the cell and is added while the POINT-WEIGHTED cell population (sum count^2 / M) is above
   // kTargetOcc: lidar density varies by 100x between 5 m and 30 m range, so the plain mean over cells is dominated by
   // the sparse far field while most queries sit in the dense near field.
-  const double kMaxCells = 32.0 * 1024 * 1024, kTargetOcc = 128.0;
+  static const double occ_env = [] { const char* e = std::getenv("LVF_KNN_OCC"); return e ? std::atof(e) : 0.0; }();      // experiment knob
+  const double kMaxCells = 32.0 * 1024 * 1024, kTargetOcc = occ_env > 0.0 ? occ_env : 128.0;
   auto ncells_for = [&](float c) {
     return (std::floor((hi[0] - lo[0]) / c) + 1) * (std::floor((hi[1] - lo[1]) / c) + 1) * (std::floor((hi[2] - lo[2]) / c) + 1);
   };

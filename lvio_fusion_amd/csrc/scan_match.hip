@@ -230,7 +230,7 @@ void lvf_scan_match_options_default(lvf_scan_match_options* o, double resolution
   std::memset(o, 0, sizeof(*o));
   o->thr_ground = (float)(resolution * resolution * 100.0);   // association.cpp:285
   o->thr_surf = (float)(resolution * resolution * 25.0);      // association.cpp:343
-  o->weight_ground = 1.0; o->weight_surf = 0.01;              // frame.cpp:14-15
+  o->weight_ground = 1.0; o->weight_surf = (double)0.01f;     // frame.cpp:14-15 — Weights' fields are floats (adapt/weights.h:10-12): the functors receive float(0.01)
   o->huber_surf = 0.1;                                        // association.cpp:330
   o->prior_weight = 0.0;                                      // relocate mode
   o->outer_iterations = 1;                                    // Mapping::Optimize; Mapping::Relocate uses 4

@@ -1,4 +1,6 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED for the PCL algorithms (third-party semantics, declared below);
+// the reference-authored pieces — Sensor2Robot (association.cpp:236-247) and AlignScan (:39-64) — are pinned to the reference's own text
+// through tests/golden/ref_v3.npz (tests/test_oracle_ref.py).
 //
 // cloud.h — map-cloud maintenance as the reference performs it with PCL (un-vendored; semantics DECLARED here from the
 // upstream implementation, PCL 1.8-1.10):

@@ -1,5 +1,9 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED (Ceres is external: solver semantics are DECLARED);
-// independently checked against a numpy dense normal-equation solve over all unknowns in tests/test_oracle_lm_numpy.py.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  The PROBLEM this file builds — float transform, gate, which points become
+// LidarPlaneErrorRPZ / YXY blocks in which order, the loss function, the PoseErrorRPZ / YXY block — is PINNED to the reference's own text
+// (round 4): association.cpp:270-384 runs unmodified in oracle/_ref (ceres::Problem as a recorder, KdTreeFLANN as the declared exact
+// search) and the recorded blocks, evaluated through CostFunction::Evaluate, equal this restatement (tests/test_oracle_ref.py, ref_v3.npz).
+// The SOLVE stays PARITY UNPINNED (Ceres is external: solver semantics are DECLARED); independently checked against a numpy dense
+// normal-equation solve over all unknowns in tests/test_oracle_lm_numpy.py.
 //
 // icp.h — one scan-to-map sub-problem as the reference builds and solves it:
 //   FeatureAssociation::ScanToMapWithGround / ScanToMapWithSegmented   src/lvio_fusion/src/association.cpp:270-384

@@ -1,4 +1,5 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.h header).  The reference-authored loops around the search (transform, gate, block order) are
+// pinned through oracle/icp.h's fixture (ref_v3.npz); the SEARCH itself is PCL / FLANN — third-party semantics, PARITY UNPINNED, declared below.
 //
 // knn.h — scan-to-map association, restating the loops at
 //   src/lvio_fusion/src/association.cpp:278-301 (ground) and :336-359 (surf):

@@ -393,7 +393,7 @@ void lvo_lidar_extract(const float* pts, int n, int stride, const lvo_lidar_para
                        float* surf, float* ground_raw, float* surf_raw, int* label_mat, signed char* ground_mat, float* range_mat, int* counts8) {
   LidarParams P{p->num_scans, p->horizon_scan, p->ground_rows, p->ang_res_y, p->ang_bottom, p->min_range, p->max_range, p->resolution, p->cycle_time};
   ExtractDebug D;
-  lidar_extract(pts, n, stride, P, D);
+  lidar_extract<false>(pts, n, stride, P, D);
   std::vector<float> g, s;
   lidar_extract_tail(D, P, extrinsic, seed, g, s);
   std::memcpy(ground, g.data(), g.size() * 4); std::memcpy(surf, s.data(), s.size() * 4);
@@ -402,6 +402,24 @@ void lvo_lidar_extract(const float* pts, int n, int stride, const lvo_lidar_para
   std::memcpy(range_mat, D.range_mat.data(), D.range_mat.size() * 4);
   counts8[0] = (int)D.filtered.size() / 4; counts8[1] = (int)D.segmented.size() / 4; counts8[2] = (int)D.ground_raw.size() / 4; counts8[3] = (int)D.surf_raw.size() / 4;
   counts8[4] = (int)g.size() / 4; counts8[5] = (int)s.size() / 4; counts8[6] = counts8[7] = 0;
+}
+
+// the restatement's taps, with libm's atan2f (libm != 0: the form that is pinned bit for bit to the reference's text) or cr_atan2f (what the GPU is
+// compared with).  Arrays sized like oracle/_ref's lvr_lidar_extract: clouds [cap][4], mats [rows * cols].  counts6 = {filtered, segmented, ground picks, surf picks, 0, 0}
+void lvo_lidar_extract_taps(const float* pts, int n, int stride, const lvo_lidar_params_c* p, int libm, float* filtered, float* range_mat, signed char* ground_mat,
+                            int* label_mat, float* segmented, unsigned char* seg_ground, int* seg_col, float* seg_range, int* start_ring, int* end_ring, float* curvature,
+                            float* ground_raw, float* surf_raw, int* counts6) {
+  LidarParams P{p->num_scans, p->horizon_scan, p->ground_rows, p->ang_res_y, p->ang_bottom, p->min_range, p->max_range, p->resolution, p->cycle_time};
+  ExtractDebug D;
+  if (libm) lidar_extract<true>(pts, n, stride, P, D); else lidar_extract<false>(pts, n, stride, P, D);
+  std::memcpy(filtered, D.filtered.data(), D.filtered.size() * 4);
+  std::memcpy(range_mat, D.range_mat.data(), D.range_mat.size() * 4); std::memcpy(ground_mat, D.ground_mat.data(), D.ground_mat.size()); std::memcpy(label_mat, D.label_mat.data(), D.label_mat.size() * 4);
+  std::memcpy(segmented, D.segmented.data(), D.segmented.size() * 4);
+  const size_t m = D.segmented.size() / 4;
+  for (size_t k = 0; k < m; ++k) { seg_ground[k] = D.seg_ground[k]; seg_col[k] = D.seg_col[k]; seg_range[k] = D.seg_range[k]; curvature[k] = D.curvature[k]; }
+  for (int i = 0; i < p->num_scans; ++i) { start_ring[i] = D.start_ring[i]; end_ring[i] = D.end_ring[i]; }
+  std::memcpy(ground_raw, D.ground_raw.data(), D.ground_raw.size() * 4); std::memcpy(surf_raw, D.surf_raw.data(), D.surf_raw.size() * 4);
+  counts6[0] = (int)D.filtered.size() / 4; counts6[1] = (int)m; counts6[2] = (int)D.ground_raw.size() / 4; counts6[3] = (int)D.surf_raw.size() / 4; counts6[4] = counts6[5] = 0;
 }
 
 }  // extern "C"

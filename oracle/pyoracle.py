@@ -376,6 +376,28 @@ def lidar_extract(points, extrinsic, seed=12345, num_scans=64, horizon_scan=1800
                 range_mat=rm.reshape(num_scans, horizon_scan), n_filtered=int(cnt[0]), n_segmented=int(cnt[1]))
 
 
+def lidar_extract_taps(points, libm=False, num_scans=64, horizon_scan=1800, ground_rows=60, ang_res_y=0.427, ang_bottom=24.9, min_range=5.0, max_range=30.0,
+                       resolution=0.2, cycle_time=0.1036):
+    """Every intermediate of extract.h's restatement (same keys as oracle.pyref.lidar_extract).  libm=True: libm's atan2f — the form pinned bit
+    for bit to the reference's text; libm=False: cr_atan2f — what the GPU is compared with."""
+    a = _f32(points)
+    n = a.shape[0]
+    prm = LidarParams(num_scans, horizon_scan, ground_rows, ang_res_y, ang_bottom, min_range, max_range, resolution, cycle_time)
+    npix = num_scans * horizon_scan
+    cap = max(n, npix, 1)
+    filt = np.empty((cap, 4), np.float32); seg = np.empty((cap, 4), np.float32); gp = np.empty((cap, 4), np.float32); sp = np.empty((cap, 4), np.float32)
+    rm = np.empty(npix, np.float32); gm = np.empty(npix, np.int8); lm = np.empty(npix, np.int32)
+    sg = np.empty(cap, np.uint8); sc = np.empty(cap, np.int32); sr = np.empty(cap, np.float32); cur = np.empty(cap, np.float32)
+    r0 = np.empty(num_scans, np.int32); r1 = np.empty(num_scans, np.int32); cnt = np.zeros(6, np.int32)
+    lib().lvo_lidar_extract_taps(_p(a, C.c_float), n, a.shape[1], C.byref(prm), 1 if libm else 0, _p(filt, C.c_float), _p(rm, C.c_float), gm.ctypes.data_as(C.POINTER(C.c_int8)),
+                                 _p(lm, C.c_int), _p(seg, C.c_float), sg.ctypes.data_as(C.POINTER(C.c_uint8)), _p(sc, C.c_int), _p(sr, C.c_float), _p(r0, C.c_int), _p(r1, C.c_int),
+                                 _p(cur, C.c_float), _p(gp, C.c_float), _p(sp, C.c_float), _p(cnt, C.c_int))
+    m = int(cnt[1])
+    return dict(filtered=filt[:cnt[0]].copy(), range_mat=rm.reshape(num_scans, horizon_scan), ground_mat=gm.reshape(num_scans, horizon_scan),
+                label_mat=lm.reshape(num_scans, horizon_scan), segmented=seg[:m].copy(), seg_ground=sg[:m].copy(), seg_col=sc[:m].copy(), seg_range=sr[:m].copy(),
+                start_ring=r0, end_ring=r1, curvature=cur[:m].copy(), ground_raw=gp[:cnt[2]].copy(), surf_raw=sp[:cnt[3]].copy(), n_filtered=int(cnt[0]), n_segmented=m)
+
+
 # ----------------------------------------------------------------------------- sliding-window problem
 class _WindowC(C.Structure):
     _fields_ = [("n_kf", C.c_int), ("n_lm", C.c_int),

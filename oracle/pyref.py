@@ -217,3 +217,56 @@ def imu_eval(pre, kf_i, kf_j, poses, vel, ba, bg, noise4, jac=True):
     r = np.empty((n, 15)); J = np.empty((n, 480)) if jac else None
     lib().lvr_imu_eval(n, _p(pre), _p(kf_i, C.c_int), _p(kf_j, C.c_int), _p(poses), _p(vel), _p(ba), _p(bg), _p(nz), _p(r), _p(J))
     return r, J
+
+
+# ----------------------------------------------------------------------------- LiDAR front half (ref_driver_lidar.cpp: src/projection.cpp + src/association.cpp)
+class LidarParams(C.Structure):
+    _fields_ = [("num_scans", C.c_int), ("horizon_scan", C.c_int), ("ground_rows", C.c_int), ("ang_res_y", C.c_float), ("ang_bottom", C.c_float),
+                ("min_range", C.c_float), ("max_range", C.c_float), ("resolution", C.c_float), ("cycle_time", C.c_double)]
+
+
+def lidar_extract(points, extrinsic=None, num_scans=64, horizon_scan=1800, ground_rows=60, ang_res_y=0.427, ang_bottom=24.9, min_range=5.0,
+                  max_range=30.0, resolution=0.2, cycle_time=0.1036):
+    """FeatureAssociation::Process step by step through the reference's own member functions (association.cpp:86-235, projection.cpp:26-320),
+    PCL filters as pass-throughs: ground_picks / surf_picks are ExtractFeatures' picks (taken through Sensor2Robot when an extrinsic is given)."""
+    a = _f32(points)
+    n = a.shape[0]
+    prm = LidarParams(num_scans, horizon_scan, ground_rows, ang_res_y, ang_bottom, min_range, max_range, resolution, cycle_time)
+    npix = num_scans * horizon_scan
+    cap = max(n, npix, 1)
+    filt = np.empty((cap, 4), np.float32); seg = np.empty((cap, 4), np.float32); gp = np.empty((cap, 4), np.float32); sp = np.empty((cap, 4), np.float32)
+    rm = np.empty(npix, np.float32); gm = np.empty(npix, np.int8); lm = np.empty(npix, np.int32)
+    sg = np.empty(cap, np.uint8); sc = np.empty(cap, np.int32); sr = np.empty(cap, np.float32); cur = np.empty(cap, np.float32)
+    r0 = np.empty(num_scans, np.int32); r1 = np.empty(num_scans, np.int32); cnt = np.zeros(6, np.int32); ori = np.zeros(3, np.float32)
+    e = _f64(extrinsic) if extrinsic is not None else None
+    lib().lvr_lidar_extract(_p(a, C.c_float), n, a.shape[1], C.byref(prm), _p(filt, C.c_float), _p(rm, C.c_float), gm.ctypes.data_as(C.POINTER(C.c_int8)),
+                            _p(lm, C.c_int), _p(seg, C.c_float), sg.ctypes.data_as(C.POINTER(C.c_uint8)), _p(sc, C.c_int), _p(sr, C.c_float), _p(r0, C.c_int),
+                            _p(r1, C.c_int), _p(cur, C.c_float), _p(gp, C.c_float), _p(sp, C.c_float), _p(cnt, C.c_int), _p(ori, C.c_float), _p(e) if e is not None else None)
+    m = int(cnt[1])
+    return dict(filtered=filt[:cnt[0]].copy(), range_mat=rm.reshape(num_scans, horizon_scan), ground_mat=gm.reshape(num_scans, horizon_scan),
+                label_mat=lm.reshape(num_scans, horizon_scan), segmented=seg[:m].copy(), seg_ground=sg[:m].copy(), seg_col=sc[:m].copy(), seg_range=sr[:m].copy(),
+                start_ring=r0, end_ring=r1, curvature=cur[:m].copy(), ground_raw=gp[:cnt[2]].copy(), surf_raw=sp[:cnt[3]].copy(), label_count=int(cnt[4]),
+                orientation=ori, n_filtered=int(cnt[0]), n_segmented=m)
+
+
+def align_scan(pc1, stamp1, pc2, stamp2, cycle_time, time):
+    """FeatureAssociation::AlignScan (association.cpp:39-64): (aligned, [m][4] cloud)."""
+    a, b = _f32(pc1), _f32(pc2)
+    out = np.empty((max(a.shape[0] + b.shape[0], 1), 4), np.float32); n = C.c_int(0)
+    ok = lib().lvr_align_scan(_p(a, C.c_float), a.shape[0], C.c_double(stamp1), _p(b, C.c_float), b.shape[0], C.c_double(stamp2), C.c_double(cycle_time), C.c_double(time),
+                              _p(out, C.c_float), C.byref(n))
+    return bool(ok), out[:n.value].copy()
+
+
+def scan_to_map(mode, scan, map_, frame_pose, map_pose, para6, w_ground=1.0, w_surf=0.01, w_visual=71.8856, n_features_left=0, relocate=True, resolution=0.2):
+    """FeatureAssociation::ScanToMapWithGround (mode 0) / ScanToMapWithSegmented (mode 1), association.cpp:270-384, run as written (brute-force
+    KdTreeFLANN stand-in): the recorded LidarError blocks evaluated at para6 — residuals [k], jacobians [k][3] in insertion order — the loss
+    function's Huber parameter (0 = TrivialLoss), the block counts and the prior block's residuals."""
+    s, m = _f32(scan), _f32(map_)
+    fp, mp, pa = _f64(frame_pose), _f64(map_pose), _f64(para6).copy()
+    k = max(s.shape[0], 1)
+    r = np.empty(k); J = np.empty((k, 3)); ha = C.c_double(0.0); cnt = np.zeros(4, np.int32); pr = np.zeros(4)
+    lib().lvr_scan_to_map(int(mode), _p(s, C.c_float), s.shape[0], _p(m, C.c_float), m.shape[0], _p(fp), _p(mp), _p(pa), C.c_double(w_ground), C.c_double(w_surf),
+                          C.c_double(w_visual), int(n_features_left), 1 if relocate else 0, C.c_double(resolution), _p(r), _p(J), C.byref(ha), _p(cnt, C.c_int), _p(pr))
+    return dict(residuals=r[:cnt[0]].copy(), jacobians=J[:cnt[0]].copy(), huber_a=ha.value, n_lidar=int(cnt[0]), n_other=int(cnt[1]), n_param_blocks=int(cnt[2]),
+                n_lidar_type=int(cnt[3]), prior=pr[:3].copy())

@@ -3,7 +3,11 @@
 // AMBIENT parameters, jacobians / jacobians[i] may be null).  AutoDiffCostFunction evaluates the functor's templated
 // operator() on Jet<double, sum(Ns)> seeded with the identity — the published forward-mode algorithm.  No solver inside.
 #pragma once
+#include <algorithm>
+#include <cmath>
+#include <limits>
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include "jet.h"
@@ -88,6 +92,49 @@ class AutoDiffCostFunction : public SizedCostFunction<kNumResiduals, Ns...> {
  private:
   std::unique_ptr<CostFunctor> functor_;
 };
+
+// ---- the problem-building surface adapt/problem.h:34-88 and association.cpp:270-384 name: loss functions, local parameterisations (type
+// names only), and a ceres::Problem that RECORDS what is added (no solver): the driver reads the blocks back and evaluates them.
+class LossFunction { public: virtual ~LossFunction() {} virtual void Evaluate(double s, double out[3]) const = 0; };
+class TrivialLoss : public LossFunction { public: void Evaluate(double s, double out[3]) const override { out[0] = s; out[1] = 1.0; out[2] = 0.0; } };
+class HuberLoss : public LossFunction {
+ public:
+  explicit HuberLoss(double a) : a_(a), b_(a * a) {}
+  void Evaluate(double s, double rho[3]) const override {      // upstream loss_function.cc
+    if (s > b_) { const double r = std::sqrt(s); rho[0] = 2.0 * a_ * r - b_; rho[1] = std::max(std::numeric_limits<double>::min(), a_ / r); rho[2] = -rho[1] / (2.0 * s); }
+    else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+  }
+  double a() const { return a_; }
+ private:
+  double a_, b_;
+};
+class LocalParameterization { public: virtual ~LocalParameterization() {} };
+namespace internal { struct ResidualBlock { CostFunction* cost; LossFunction* loss; std::vector<double*> params; }; }
+typedef internal::ResidualBlock* ResidualBlockId;
+class Problem {
+ public:
+  virtual ~Problem() { for (auto* b : blocks_) delete b; }       // (cost / loss objects are leaked on purpose: shared between blocks)
+  template <typename... Ts>
+  ResidualBlockId AddResidualBlock(CostFunction* cost, LossFunction* loss, double* x0, Ts*... xs) {
+    auto* b = new internal::ResidualBlock{cost, loss, {x0, xs...}};
+    blocks_.push_back(b);
+    return b;
+  }
+  void AddParameterBlock(double* values, int size) { params_.emplace_back(values, size); }
+  void AddParameterBlock(double* values, int size, LocalParameterization*) { params_.emplace_back(values, size); }
+  void GetResidualBlocksForParameterBlock(const double* values, std::vector<ResidualBlockId>* out) const {
+    out->clear();
+    for (auto* b : blocks_) for (double* p : b->params) if (p == values) { out->push_back(b); break; }
+  }
+  int NumResidualBlocks() const { return (int)blocks_.size(); }
+  const std::vector<ResidualBlockId>& recorded_blocks() const { return blocks_; }                    // shim-only
+  const std::vector<std::pair<double*, int>>& recorded_parameter_blocks() const { return params_; }   // shim-only
+ private:
+  std::vector<ResidualBlockId> blocks_;
+  std::vector<std::pair<double*, int>> params_;
+};
+struct Solver { struct Options {}; struct Summary { double final_cost = 0; int num_residual_blocks_reduced = 0; }; };
+inline void Solve(const Solver::Options&, Problem*, Solver::Summary*) {}      // no solver in the shim (declared semantics: oracle/lm.h, oracle/icp.h)
 
 // declared so that imu_error.hpp:231-274 (ImuInitGError::Create, initialisation only — not on the hot path) compiles; never evaluated
 enum NumericDiffMethodType { CENTRAL, FORWARD, RIDDERS };

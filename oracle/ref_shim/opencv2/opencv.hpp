@@ -2,18 +2,43 @@
 // Camera's constructor uses for K and D (visual/camera.h:84-85), and the point / key-point value types utility.h, frame.h and
 // visual/feature.h name.  Values are stored, never read by the factor path.
 #pragma once
+// the C-compatibility headers the real OpenCV / PCL / Sophus headers pull in: with them libstdc++ puts the float overloads of atan2 /
+// sqrt / abs / round into the GLOBAL namespace, which is what the reference's unqualified calls on float arguments resolve to
+// (projection.cpp:44,73,79,127,130,275; association.cpp:122) — declared, like the Ceres version, because the reference pins nothing
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
 #include <bitset>
+#include <cstring>
 #include <vector>
 typedef unsigned char uchar;
+#define CV_8S 1
+#define CV_32S 4
+#define CV_32F 5
 namespace cv {
+struct Scalar { double v[4]; static Scalar all(double x) { Scalar s; s.v[0] = s.v[1] = s.v[2] = s.v[3] = x; return s; } };
 struct Point2f { float x, y; Point2f() : x(0), y(0) {} Point2f(float x_, float y_) : x(x_), y(y_) {} };
 struct Point3f { float x, y, z; Point3f() : x(0), y(0), z(0) {} Point3f(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {} };
 struct KeyPoint { Point2f pt; float size; KeyPoint() : size(0) {} KeyPoint(Point2f p, float s) : pt(p), size(s) {} };
 class Mat {
  public:
-  Mat() : rows(0), cols(0) {}
+  Mat() : rows(0), cols(0), type_(0) {}
+  // typed dense matrix filled with a scalar: the range / label / ground images of lidar/projection.h:63-65 (element access only)
+  Mat(int r, int c, int type, const Scalar& s) : rows(r), cols(c), type_(type) {
+    const size_t e = type == CV_8S ? 1 : 4;
+    bytes.assign((size_t)r * c * e, 0);
+    for (size_t i = 0; i < (size_t)r * c; ++i) {
+      if (type == CV_32F) { const float f = (float)s.v[0]; std::memcpy(&bytes[4 * i], &f, 4); }
+      else if (type == CV_32S) { const int k = (int)s.v[0]; std::memcpy(&bytes[4 * i], &k, 4); }
+      else bytes[i] = (unsigned char)(signed char)s.v[0];
+    }
+  }
+  template <typename T> T& at(int i, int j) { return *reinterpret_cast<T*>(&bytes[((size_t)i * cols + j) * sizeof(T)]); }
+  template <typename T> const T& at(int i, int j) const { return *reinterpret_cast<const T*>(&bytes[((size_t)i * cols + j) * sizeof(T)]); }
   int rows, cols;
   std::vector<double> v;
+  std::vector<unsigned char> bytes;
+  int type_;
 };
 template <typename T> class Mat_;
 template <typename T>

@@ -7,6 +7,17 @@
 
 namespace Sophus {
 
+// SE3f: the value of SE3d::cast<float>() — every coefficient rounded to the nearest float — as a container the lidar code hands to
+// ceres::SE3TransformPoint<float> through data() (association.cpp:238-239, :286-287)
+class SE3f {
+ public:
+  SE3f() { d_[0] = d_[1] = d_[2] = 0.f; d_[3] = 1.f; d_[4] = d_[5] = d_[6] = 0.f; }
+  float* data() { return d_; }
+  const float* data() const { return d_; }
+ private:
+  float d_[7];
+};
+
 class SE3d {
  public:
   static constexpr int num_parameters = 7;
@@ -14,6 +25,7 @@ class SE3d {
   explicit SE3d(const double* data7) { for (int i = 0; i < 7; ++i) d_[i] = data7[i]; }     // shim-only convenience
   double* data() { return d_; }
   const double* data() const { return d_; }
+  template <typename T> SE3f cast() const { SE3f r; for (int i = 0; i < 7; ++i) r.data()[i] = (T)d_[i]; return r; }
   Eigen::Vector3d translation() const { return Eigen::Vector3d(d_[4], d_[5], d_[6]); }
   Eigen::Quaterniond unit_quaternion() const { return Eigen::Quaterniond(d_[3], d_[0], d_[1], d_[2]); }
   Eigen::Matrix3d rotationMatrix() const { return unit_quaternion().toRotationMatrix(); }
