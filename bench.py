@@ -811,6 +811,22 @@ def cpu_baseline(api, cfg, prob, st, verified):
            "gpu_vs_oracle_iteration_1": {"cost_before": [g["cost_before"], r0["cost_before"]], "cost_after": [g["cost_after"], r0["cost_after"]]},
            "gpu_vs_oracle_solve_K": {"K": CHUNK, "final_cost": [s.final_cost, ref["final_cost"]], "iterations": [s.num_iterations, ref["num_iterations"]],
                                      "successful_steps": [s.num_successful_steps, ref["num_successful_steps"]], "worst_state_rel_diff": worst}}
+    # The evaluation half of the CPU path with the REFERENCE'S OWN functor text where it can be compiled (oracle/_ref: visual_error.hpp /
+    # imu_error.hpp unmodified, one heap functor per block through X::Create as backend.cpp:119-160 builds them, CostFunction::Evaluate with
+    # all Jacobians from `threads` workers): what one Ceres evaluation pass of this window costs the reference, beside the port's figure.
+    try:
+        from oracle import pyref
+        if pyref.build() is not None:
+            rf = pyref.window_eval_timed(cfg, pre, threads=threads, reps=3)
+            out["kind"] = "port (value: whole LM iteration) + reference (reference_functors: the evaluation pass alone)"
+            out["reference_functors"] = {"kind": "reference", "blocks": rf["blocks"], "cores": threads, "reference_functors_eval_ms": 1e3 * rf["evaluate_s"],
+                                         "reference_functors_create_ms": 1e3 * rf["create_s"], "evaluation_passes_per_sec": 1.0 / rf["evaluate_s"],
+                                         "sample": "3 full passes of CostFunction::Evaluate (residuals + Jacobians) over the window's 91 k blocks after creating one heap functor per block "
+                                                   "(the reference rebuilds them twice per tick); Ceres itself (Jet implementation, loss, Schur, Cholesky) is not in the image: "
+                                                   "AutoDiffCostFunction runs over oracle/ref_shim's Jet"}
+            out["reference_functors_eval_ms"] = 1e3 * rf["evaluate_s"]
+    except Exception as e:
+        out["reference_functors"] = {"error": repr(e)}
     # the other legs of the metric, bounded samples (a few seconds each)
     try:
         c2 = syn.config2_pose_only(seed=syn.SEED_CFG2)

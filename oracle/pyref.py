@@ -270,3 +270,30 @@ def scan_to_map(mode, scan, map_, frame_pose, map_pose, para6, w_ground=1.0, w_s
                           C.c_double(w_visual), int(n_features_left), 1 if relocate else 0, C.c_double(resolution), _p(r), _p(J), C.byref(ha), _p(cnt, C.c_int), _p(pr))
     return dict(residuals=r[:cnt[0]].copy(), jacobians=J[:cnt[0]].copy(), huber_a=ha.value, n_lidar=int(cnt[0]), n_other=int(cnt[1]), n_param_blocks=int(cnt[2]),
                 n_lidar_type=int(cnt[3]), prior=pr[:3].copy())
+
+
+def window_eval_timed(cfg, pre, threads=8, reps=3, noise4=(0.1, 0.01, 1e-3, 1e-4)):
+    """The evaluation half of the reference's CPU path on a config-4 style window (lvio_fusion_amd.synthetic.config4_window dict + the
+    flattened pre-integrations [n][467]): one heap functor per block through the reference's own X::Create (backend.cpp:119-160), then
+    `reps` full CostFunction::Evaluate passes (residuals + all Jacobians) on `threads` OpenMP workers.
+    Returns dict(create_s, evaluate_s, blocks, cost = 1/2 sum r^2 without the loss function)."""
+    tc, tf, po = cfg["tc"], cfg["tf"], cfg["po"]
+    c0, c1 = cfg["cam0"], cfg["cam1"]
+    left = Camera.make(c0["fx"], c0["fy"], c0["cx"], c0["cy"], c0["extrinsic"]); right = Camera.make(c1["fx"], c1["fy"], c1["cx"], c1["cy"], c1["extrinsic"])
+    keep = []
+
+    def d(a):
+        a = _f64(a); keep.append(a); return _p(a)
+
+    def i(a):
+        a = _i32(a); keep.append(a); return _p(a, C.c_int)
+    pre = _f64(pre).reshape(-1, 467) if pre is not None and len(pre) else np.zeros((0, 467))
+    n_imu = pre.shape[0]
+    times = np.zeros(2); chk = C.c_double(0.0)
+    lib().lvr_window_eval_timed(len(tc["lm_idx"]), d(tc["left_ob"]), d(tc["right_ob"]), i(tc["lm_idx"]), i(tc["kf_idx"]),
+                                len(tf["lm_idx"]), d(tf["first_ob"]), d(tf["ob"]), i(tf["lm_idx"]), i(tf["kf1_idx"]), i(tf["kf2_idx"]),
+                                len(po["kf_idx"]), d(po["ob"]), i(po["kf_idx"]), i(po["pw_idx"]), d(po["pw"]),
+                                n_imu, d(pre), i([f["kf_i"] for f in cfg["imu"]][:n_imu]), i([f["kf_j"] for f in cfg["imu"]][:n_imu]), d(np.asarray(noise4, np.float64)),
+                                d(cfg["inv_depth"]), d(cfg["poses"]), d(cfg["vel"]), d(cfg["ba"]), d(cfg["bg"]), d(cfg["w_kf"]),
+                                C.byref(left), C.byref(right), int(threads), int(reps), _p(times), C.byref(chk))
+    return dict(create_s=float(times[0]), evaluate_s=float(times[1]), blocks=len(tc["lm_idx"]) + len(tf["lm_idx"]) + len(po["kf_idx"]) + n_imu, cost=0.5 * chk.value)

@@ -11,8 +11,10 @@
 // are included, and src/preintegration.cpp is compiled as a second translation unit (oracle/Makefile), all UNMODIFIED, against the
 // fixed-size Matrix / Quaternion / LLT / inverse stand-in in ref_shim/Eigen/Core (whose header declares the evaluation order it
 // fixes: real Eigen's rounding depends on its version and vector ISA).
+#include <chrono>
 #include <cstring>
 #include <memory>
+#include <vector>
 
 #include "lvio_fusion/ceres/imu_error.hpp"
 #include "lvio_fusion/ceres/lidar_error.hpp"
@@ -251,6 +253,72 @@ void lvr_imu_eval(int n, const lvr_preint* pre, const int* kf_i, const int* kf_j
     if (J) for (int k = 0; k < 8; ++k) Jp[k] = J + (size_t)480 * f + off[k];
     fn->Evaluate(prm, r + 15 * f, J ? Jp : nullptr);
   }
+}
+
+// The evaluation half of the reference's CPU path on a whole window, as the reference runs it: Backend::BuildProblem creates ONE HEAP FUNCTOR PER
+// BLOCK through X::Create (backend.cpp:119-160; twice per tick), and every Levenberg-Marquardt iteration then calls CostFunction::Evaluate —
+// residuals and all Jacobians — on each of them from up to num_threads workers (estimator.cpp:10).  This entry point does exactly that
+// with the reference's own functor text (AutoDiffCostFunction over the stand-in Jet, ImuError's analytic Jacobians) and times the two parts:
+// times2 = {seconds to create every functor, seconds per full evaluation pass (average of `reps`)}; checksum = sum of squared residuals (keeps
+// the work alive and lets the caller compare with its own cost).  Used by bench.py's cpu_baseline (kind "reference").
+void lvr_window_eval_timed(int n_tc, const double* tc_left_ob, const double* tc_right_ob, const int* tc_lm, const int* tc_kf,
+                           int n_tf, const double* tf_first_ob, const double* tf_ob, const int* tf_lm, const int* tf_kf1, const int* tf_kf2,
+                           int n_po, const double* po_ob, const int* po_kf, const int* po_pwi, const double* po_pw,
+                           int n_imu, const lvr_preint* pre, const int* imu_i, const int* imu_j, const double* noise4,
+                           const double* inv_depth, const double* poses, const double* vel, const double* ba, const double* bg, const double* w_kf,
+                           const lvr_camera* left_, const lvr_camera* right_, int threads, int reps, double* times2, double* checksum) {
+  struct Block { std::unique_ptr<ceres::CostFunction> f; const double* prm[8]; int np, nres, sizes[8]; };
+  Camera::Ptr left = make_camera(left_), right = make_camera(right_);
+  if (n_imu > 0) set_imu_noise(noise4);
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<Block> blocks((size_t)n_tc + n_tf + n_po + n_imu);
+  size_t k = 0;
+  for (int i = 0; i < n_tc; ++i, ++k) {      // backend.cpp:123-124
+    Block& b = blocks[k];
+    b.f.reset(TwoCameraReprojectionError::Create(Vector2d(tc_left_ob[2 * i], tc_left_ob[2 * i + 1]), Vector2d(tc_right_ob[2 * i], tc_right_ob[2 * i + 1]), left, right, 5 * w_kf[tc_kf[i]]));
+    b.np = 1; b.nres = 2; b.prm[0] = inv_depth + tc_lm[i]; b.sizes[0] = 1;
+  }
+  for (int i = 0; i < n_tf; ++i, ++k) {      // backend.cpp:138-139
+    Block& b = blocks[k];
+    b.f.reset(TwoFrameReprojectionError::Create(Vector2d(tf_first_ob[2 * i], tf_first_ob[2 * i + 1]), Vector2d(tf_ob[2 * i], tf_ob[2 * i + 1]), left, right, w_kf[tf_kf2[i]]));
+    b.np = 3; b.nres = 2; b.prm[0] = inv_depth + tf_lm[i]; b.prm[1] = poses + 7 * tf_kf1[i]; b.prm[2] = poses + 7 * tf_kf2[i]; b.sizes[0] = 1; b.sizes[1] = 7; b.sizes[2] = 7;
+  }
+  for (int i = 0; i < n_po; ++i, ++k) {      // backend.cpp:129-130
+    Block& b = blocks[k];
+    const double* p = po_pw + 3 * po_pwi[i];
+    b.f.reset(PoseOnlyReprojectionError::Create(Vector2d(po_ob[2 * i], po_ob[2 * i + 1]), Vector3d(p[0], p[1], p[2]), left, w_kf[po_kf[i]]));
+    b.np = 1; b.nres = 2; b.prm[0] = poses + 7 * po_kf[i]; b.sizes[0] = 7;
+  }
+  for (int f = 0; f < n_imu; ++f, ++k) {     // backend.cpp:150-152
+    Block& b = blocks[k];
+    b.f.reset(ImuError::Create(flat_to_preint(pre + f)));
+    const int i = imu_i[f], j = imu_j[f];
+    const double* prm[8] = {poses + 7 * i, vel + 3 * i, ba + 3 * i, bg + 3 * i, poses + 7 * j, vel + 3 * j, ba + 3 * j, bg + 3 * j};
+    const int sz[8] = {7, 3, 3, 3, 7, 3, 3, 3};
+    b.np = 8; b.nres = 15;
+    for (int q = 0; q < 8; ++q) { b.prm[q] = prm[q]; b.sizes[q] = sz[q]; }
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  double sum = 0.0;
+  const long long nb = (long long)blocks.size();
+  for (int rep = 0; rep < reps; ++rep) {
+    double s = 0.0;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads) reduction(+ : s)
+    for (long long q = 0; q < nb; ++q) {
+      const Block& b = blocks[(size_t)q];
+      double r[15], J[15 * 32];
+      double* jac[8];
+      int off = 0;
+      for (int c = 0; c < b.np; ++c) { jac[c] = J + off; off += b.nres * b.sizes[c]; }
+      b.f->Evaluate(b.prm, r, jac);
+      for (int c = 0; c < b.nres; ++c) s += r[c] * r[c];
+    }
+    sum = s;
+  }
+  const auto t2 = std::chrono::steady_clock::now();
+  times2[0] = std::chrono::duration<double>(t1 - t0).count();
+  times2[1] = std::chrono::duration<double>(t2 - t1).count() / (reps > 0 ? reps : 1);
+  *checksum = sum;
 }
 
 // base.hpp helpers instantiated on double / float (the float SE3TransformPoint is the association's transform, association.cpp:289)
