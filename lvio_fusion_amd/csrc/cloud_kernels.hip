@@ -135,30 +135,45 @@ __device__ __forceinline__ int voxel_of(const float4 p, const VoxP v) {
   const int k = (int)(floorf(p.z * v.inv_leaf) - (float)v.minb[2]);
   return i + j * v.div[0] + k * v.div[0] * v.div[1];
 }
-__global__ __launch_bounds__(kC) void k_voxel_key(int n, const float4* __restrict__ pts, VoxP v, unsigned* __restrict__ key, int* __restrict__ val,
-                                                  int* __restrict__ counts) {
+__global__ __launch_bounds__(kC) void k_voxel_key(int n, const float4* __restrict__ pts, VoxP v, unsigned* __restrict__ key, int* __restrict__ val) {
   const int i = blockIdx.x * kC + threadIdx.x;
   if (i >= n) return;
-  const int c = voxel_of(pts[i], v);
-  key[i] = (unsigned)c; val[i] = i;
-  atomicAdd(counts + c, 1);
+  key[i] = (unsigned)voxel_of(pts[i], v); val[i] = i;
 }
-__global__ __launch_bounds__(kC) void k_flag_nonzero(int n, const int* __restrict__ counts, int* __restrict__ flags) {
-  const int i = blockIdx.x * kC + threadIdx.x;
-  if (i < n) flags[i] = counts[i] > 0 ? 1 : 0;
+// a sorted position is the HEAD of its voxel's run when its key differs from its predecessor's
+__global__ __launch_bounds__(kC) void k_voxel_heads(int n, const unsigned* __restrict__ key_sorted, int* __restrict__ flags) {
+  const int j = blockIdx.x * kC + threadIdx.x;
+  if (j < n) flags[j] = (j == 0 || key_sorted[j] != key_sorted[j - 1]) ? 1 : 0;
 }
-// one thread per voxel: the centroid of ALL four fields, accumulated in float over the voxel's points in ascending input index
-// (`order` = point indices sorted stably by voxel; `start` = exclusive scan of the per-voxel counts), then divided by the count
-__global__ __launch_bounds__(kC) void k_voxel_emit(int ncell, const float4* __restrict__ pts, const int* __restrict__ order, const int* __restrict__ start,
-                                                   const int* __restrict__ pos, float4* __restrict__ out) {
-  const int c = blockIdx.x * kC + threadIdx.x;
-  if (c >= ncell) return;
-  const int j0 = start[c], j1 = start[c + 1];
-  if (j1 == j0) return;
+// One thread per run head: the centroid of ALL four fields, accumulated in float over the voxel's points in ascending input index (`order` =
+// point indices sorted stably by voxel, so a voxel is a run of equal keys), then divided by the count; pos = exclusive scan of the head
+// flags = the voxel's output slot (runs come in ascending voxel index).  Nothing here is sized by the voxel GRID (562 k cells for 3.4 k
+// occupied ones at configs[2]): round 3 counted per cell with atomics and scanned two grid-sized arrays.
+__global__ __launch_bounds__(kC) void k_voxel_emit(int n, const float4* __restrict__ pts, const unsigned* __restrict__ key_sorted, const int* __restrict__ order,
+                                                   const int* __restrict__ flags, const int* __restrict__ pos, float4* __restrict__ out) {
+  const int j0 = blockIdx.x * kC + threadIdx.x;
+  if (j0 >= n || !flags[j0]) return;
+  const unsigned k0 = key_sorted[j0];
+  // the ADDS are sequential by definition (float accumulation in input order); the gathers behind them are not: eight points (and the keys that say
+  // whether they still belong to the run) are requested before the first of them is added
   float4 s = pts[order[j0]];
-  for (int j = j0 + 1; j < j1; ++j) { const float4 p = pts[order[j]]; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
-  const float k = (float)(j1 - j0);
-  out[pos[c]] = make_float4(s.x / k, s.y / k, s.z / k, s.w / k);
+  int cnt = 1;
+  for (int q = j0 + 1; q < n; q += 8) {
+    bool in[8]; int o[8]; float4 p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int t = min(q + u, n - 1); in[u] = (q + u < n) && key_sorted[t] == k0; o[u] = order[t]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] = pts[o[u]];
+    bool run = true;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      run = run && in[u];
+      if (run) { s.x += p[u].x; s.y += p[u].y; s.z += p[u].z; s.w += p[u].w; ++cnt; }
+    }
+    if (!run) break;
+  }
+  const float k = (float)cnt;
+  out[pos[j0]] = make_float4(s.x / k, s.y / k, s.z / k, s.w / k);
 }
 
 // ---------------------------------------------------------------------------------------------- uniform grid (cell-sorted copy)
@@ -396,12 +411,12 @@ int lvf_cloud_create(lvf_ctx* ctx, const float* points, int n, int stride_floats
   LVF_TRY(new_cloud(ctx, n, &c));
   if (n) {
     DevBuf<float> src;
-    HostPin<float> stage;                // (pooled pinned staging, released after the stream wait below: DevBuf::upload_staged)
+    HostPin<float> stage;                // (pooled pinned staging: DevBuf::upload_staged)
+    StreamWaitGuard stage_guard(ctx->stream);      // ... which every path out of this scope waits for before the block returns to the pool
     int rc = src.upload_staged(points, (size_t)n * stride_floats, ctx->stream, stage);
     if (rc != LVF_OK) { delete c; return rc; }
     hipLaunchKernelGGL(k_cloud_pack, dim3(gridc(n)), dim3(kC), 0, ctx->stream, n, src.p, stride_floats, intensity_offset, c->pts.p);
-    LVF_HIP(hipGetLastError());
-    LVF_HIP(hipStreamSynchronize(ctx->stream));
+    { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { delete c; return ::lvf::hip_fail(e, "k_cloud_pack", __FILE__, __LINE__); } }      // (no leak of `c`)
   }
   *out = c;
   return LVF_OK;
@@ -495,25 +510,23 @@ int lvf_cloud_voxel_filter(const lvf_cloud* in, float leaf, lvf_cloud** out) {
   }
   // PCL refuses such grids too ("Leaf size is too small for the input dataset. Integer indices would overflow.")
   LVF_REQUIRE(ncell > 0 && ncell <= (1ll << 26), "lvf_cloud_voxel_filter: %lld voxels: leaf size too small for the cloud's extent", ncell);
-  DevBuf<int> counts, flags, pos, start, val, order; DevBuf<unsigned> key, key_sorted;
-  LVF_TRY(counts.alloc(ncell)); LVF_TRY(flags.alloc(ncell)); LVF_TRY(pos.alloc((size_t)ncell + 1)); LVF_TRY(start.alloc((size_t)ncell + 1));
+  DevBuf<int> flags, pos, val, order; DevBuf<unsigned> key, key_sorted;
+  LVF_TRY(flags.alloc(in->n)); LVF_TRY(pos.alloc((size_t)in->n + 1));
   LVF_TRY(key.alloc(in->n)); LVF_TRY(key_sorted.alloc(in->n)); LVF_TRY(val.alloc(in->n)); LVF_TRY(order.alloc(in->n));
-  LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)4 * ncell, s));
-  hipLaunchKernelGGL(k_voxel_key, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, v, key.p, val.p, counts.p);
-  hipLaunchKernelGGL(k_flag_nonzero, dim3(gridc((int)ncell)), dim3(kC), 0, s, (int)ncell, counts.p, flags.p);
+  hipLaunchKernelGGL(k_voxel_key, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, v, key.p, val.p);
   LVF_HIP(hipGetLastError());
   int bits = 1;
   while ((1ll << bits) < ncell) ++bits;
   LVF_TRY(device_sort_pairs_u32(ctx, key.p, key_sorted.p, val.p, order.p, in->n, bits));      // stable: ascending input index inside a voxel
-  LVF_TRY(device_exclusive_scan_i32(ctx, counts.p, (int)ncell, start.p));
-  LVF_TRY(device_exclusive_scan_i32(ctx, flags.p, (int)ncell, pos.p));
+  hipLaunchKernelGGL(k_voxel_heads, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, key_sorted.p, flags.p);
+  LVF_TRY(device_exclusive_scan_i32(ctx, flags.p, in->n, pos.p));
   int total = 0;
-  LVF_TRY(read_back(ctx, &total, pos.p + ncell, sizeof(int)));
+  LVF_TRY(read_back(ctx, &total, pos.p + in->n, sizeof(int)));
   lvf_cloud* c = nullptr;
   LVF_TRY(new_cloud(ctx, total, &c));
-  hipLaunchKernelGGL(k_voxel_emit, dim3(gridc((int)ncell)), dim3(kC), 0, s, (int)ncell, in->pts.p, order.p, start.p, pos.p, c->pts.p);
+  hipLaunchKernelGGL(k_voxel_emit, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, in->pts.p, key_sorted.p, order.p, flags.p, pos.p, c->pts.p);
   LVF_HIP(hipGetLastError());
-  LVF_HIP(hipStreamSynchronize(s));
+  // (no wait: the temporaries return to the context's pool, which reuses them in stream order; the cloud is consumed on the same stream)
   *out = c;
   return LVF_OK;
 }

@@ -289,7 +289,8 @@ int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_float
   lvf_cloud* filtered = nullptr;
   {
     DevBuf<float> src; DevBuf<float4> packed; DevBuf<int> flags;
-    HostPin<float> stage;                // (pooled pinned staging; compact_points below waits for the stream before it goes)
+    HostPin<float> stage;                // (pooled pinned staging)
+    StreamWaitGuard stage_guard(s);      // every path out of this scope — the error returns too — waits for the copy before the block returns to the pool
     LVF_TRY(src.upload_staged(points, (size_t)n * stride_floats, s, stage)); LVF_TRY(packed.alloc(std::max(n, 1))); LVF_TRY(flags.alloc(std::max(n, 1)));
     if (n) hipLaunchKernelGGL(k_ex_preflag, dim3(gride(n)), dim3(kE), 0, s, n, src.p, stride_floats, P.min2, P.max2, packed.p, flags.p);
     LVF_HIP(hipGetLastError());

@@ -461,7 +461,7 @@ int device_exclusive_scan_i32(lvf_ctx* ctx, const int* in, int n, int* out) {
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, out + n, (const unsigned long long*)nullptr, (unsigned long long*)nullptr);
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, n, const_cast<int*>(in), bsums.p, out, 0);
   LVF_HIP(hipGetLastError());
-  LVF_HIP(hipStreamSynchronize(s));   // bsums is freed on return
+  // (bsums goes back to the context's pool on return and is handed out again in stream order: nothing to wait for)
   return LVF_OK;
 }
 
@@ -543,7 +543,8 @@ static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_devic
     return LVF_OK;
   }
   DevBuf<float> src; DevBuf<unsigned> bounds;
-  HostPin<float> stage;                  // (released after the stream wait below)
+  HostPin<float> stage;
+  StreamWaitGuard stage_guard(s);        // every path out of this function waits for the copy before the pinned block returns to the pool
   if (!src_is_device && (rc = src.upload_staged(map_xyz, (size_t)M * stride_floats, s, stage)) != LVF_OK) return fail(rc);
   if ((rc = m->raw.alloc(M)) != LVF_OK || (rc = bounds.alloc(6)) != LVF_OK) return fail(rc);
   // {+max, +max, +max, 0, 0, 0} as ordered-uint bounds: two memsets instead of a copy from a stack array (a pageable copy)
@@ -600,7 +601,8 @@ static int scan_create_impl(lvf_ctx* ctx, const float* scan_xyz, bool src_is_dev
   sc->ctx = ctx; sc->Q = Q;
   int rc = LVF_OK;
   DevBuf<float> src;
-  HostPin<float> stage;                  // (released after the stream wait below)
+  HostPin<float> stage;
+  StreamWaitGuard stage_guard(ctx->stream);      // every path out of this function waits for the copy before the pinned block returns to the pool
   if (Q > 0) {
     if ((!src_is_device && (rc = src.upload_staged(scan_xyz, (size_t)Q * stride_floats, ctx->stream, stage)) != LVF_OK) || (rc = sc->pts.alloc(Q)) != LVF_OK ||
         (rc = sc->idx.alloc((size_t)3 * Q)) != LVF_OK || (rc = sc->d2.alloc((size_t)3 * Q)) != LVF_OK || (rc = sc->valid.alloc(Q)) != LVF_OK) {

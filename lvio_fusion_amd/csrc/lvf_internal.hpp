@@ -260,6 +260,19 @@ inline int copy_down_wait(lvf_ctx* ctx, void* host, const void* dev, size_t byte
 }
 }  // namespace lvf
 
+namespace lvf {
+// Declared right AFTER a pinned staging block that feeds an asynchronous copy (HostPin + DevBuf::upload_staged): destroyed BEFORE it, on every
+// path out of the function — early error returns included — it waits for the stream, so the block never goes back to the process-wide pinned
+// pool (where another thread could take and overwrite it) while the DMA may still be reading it.
+struct StreamWaitGuard {
+  hipStream_t s;
+  explicit StreamWaitGuard(hipStream_t q) : s(q) {}
+  StreamWaitGuard(const StreamWaitGuard&) = delete;
+  StreamWaitGuard& operator=(const StreamWaitGuard&) = delete;
+  ~StreamWaitGuard() { (void)hipStreamSynchronize(s); }
+};
+}  // namespace lvf
+
 struct lvf_state {
   lvf_ctx* ctx = nullptr;
   int n_kf = 0, n_lm = 0;

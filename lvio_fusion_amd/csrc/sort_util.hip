@@ -1,22 +1,128 @@
-// sort_util.hip — a STABLE device sort of (32-bit key, index) pairs (hipCUB's LSD radix sort), kept in its own translation unit so
-// that the template instantiation costs one object file.  Used where an order inside equal keys has to be the INPUT order: the
-// voxel grid accumulates each voxel's centroid in float over its points in ascending input index (cloud_kernels.hip), which is what
-// makes the filter's output independent of scheduling and equal to the sequential restatement bit for bit.
-#include <hipcub/hipcub.hpp>
-
+// sort_util.hip — a STABLE device sort of (32-bit key, index) pairs: hand-written LSD radix sort for gfx950, digits of up to 11 bits.
+//
+// Used where the order inside equal keys has to be the INPUT order: the voxel grid accumulates each voxel's centroid in float over its
+// points in ascending input index (cloud_kernels.hip), which is what makes the filter's output independent of scheduling and equal to the
+// sequential restatement bit for bit.
+//
+// Per digit pass, three launches on the context's stream and no host wait:
+//   k_radix_hist     one workgroup per tile of 4 096 keys: histogram of the digit (<= 2 048 bins) in LDS -> hist[bin][tile] (digit-major, so that ONE exclusive
+//                    scan over the whole table yields every (bin, tile)'s first output slot);
+//   k_radix_scan     that scan, one workgroup of 1 024 threads (the table has bins x tiles entries: 25 k for a 100 k-point cloud and 10-bit digits);
+//   k_radix_scatter  the tile again, sixteen rounds of 256 keys in input order: a key's rank among the keys of its digit is
+//                    (keys of that digit in earlier rounds of the tile) + (in lower waves of this round) + (in lower lanes of its wave) —
+//                    the last from one wave ballot per digit bit (lanes whose digit equals mine), no sorting network, no atomics,
+//                    so equal digits keep their input order: stable.
+// Keys of at most `key_bits` bits take ceil(key_bits / 11) passes of equal digit width (20-bit voxel keys: two 10-bit passes), ping-ponging between the output arrays and a pooled scratch pair.
+// (Round 3 called hipcub::DeviceRadixSort here and waited for the stream after it.)
+#include <algorithm>
 #include "lvf_internal.hpp"
 
 namespace lvf {
 
+// (tiles of 4 096 keys: a quarter of the histogram table of 1 024-key tiles — the one-workgroup scan over it was 29 of a pass's 41 us)
+constexpr int kRT = 256, kRRounds = 16, kRTile = kRT * kRRounds, kRScanT = 1024, kRMaxDigitBits = 11;
+
+// digit = (key >> shift) & (nbins - 1); nbins = 1 << digit_bits <= 2048.  Dynamic LDS: nbins ints.
+__global__ __launch_bounds__(kRT) void k_radix_hist(int n, const unsigned* __restrict__ keys, int shift, int nbins, int* __restrict__ hist, int ntiles) {
+  extern __shared__ int rs_lds[];
+  int* h = rs_lds;
+  for (int b = threadIdx.x; b < nbins; b += kRT) h[b] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kRTile;
+  const unsigned mask = (unsigned)nbins - 1u;
+  for (int r = 0; r < kRRounds; ++r) {
+    const int i = base + r * kRT + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbins; b += kRT) hist[(size_t)b * ntiles + blockIdx.x] = h[b];
+}
+
+// exclusive scan of `total` ints in place, one workgroup: a contiguous chunk per thread, wave scans of the chunk sums on the DPP path
+__global__ __launch_bounds__(kRScanT) void k_radix_scan(int total, int* __restrict__ a) {
+  __shared__ int s_wave[kRScanT / 64];
+  const int per = (total + kRScanT - 1) / kRScanT;
+  const int lo = min(total, (int)threadIdx.x * per), hi = min(total, lo + per);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += a[i];
+  const int incl = wave_incl_scan(sum);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 63) s_wave[w] = incl;
+  __syncthreads();
+  int basev = 0;
+  for (int k = 0; k < w; ++k) basev += s_wave[k];
+  int run = basev + incl - sum;
+  for (int i = lo; i < hi; ++i) { const int v = a[i]; a[i] = run; run += v; }
+}
+
+// Dynamic LDS: s_base[nbins] | s_cnt[waves][nbins].
+__global__ __launch_bounds__(kRT) void k_radix_scatter(int n, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, unsigned* __restrict__ keys_out,
+                                                       int* __restrict__ vals_out, int shift, int digit_bits, const int* __restrict__ hist, int ntiles) {
+  extern __shared__ int rs_lds[];
+  const int nbins = 1 << digit_bits;
+  int* s_base = rs_lds;
+  int* s_cnt = rs_lds + nbins;               // [wave][bin]
+  for (int b = threadIdx.x; b < nbins; b += kRT) s_base[b] = hist[(size_t)b * ntiles + blockIdx.x];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int base = blockIdx.x * kRTile;
+  const unsigned mask = (unsigned)nbins - 1u;
+  for (int r = 0; r < kRRounds; ++r) {
+    for (int b = threadIdx.x; b < (kRT / 64) * nbins; b += kRT) s_cnt[b] = 0;
+    __syncthreads();
+    const int i = base + r * kRT + threadIdx.x;
+    const bool valid = i < n;
+    const unsigned key = valid ? keys_in[i] : 0u;
+    const int val = valid ? vals_in[i] : 0;
+    const unsigned d = (key >> shift) & mask;
+    unsigned long long same = __ballot(valid);          // lanes holding a key of MY digit
+    for (int b = 0; b < digit_bits; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    const int rank = __popcll(same & lt), cnt = __popcll(same);
+    if (valid && rank == 0) s_cnt[w * nbins + d] = cnt;
+    __syncthreads();
+    if (valid) {
+      int off = s_base[d] + rank;
+      for (int k = 0; k < w; ++k) off += s_cnt[k * nbins + d];
+      keys_out[off] = key; vals_out[off] = val;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += kRT) {
+      int add = 0;
+#pragma unroll
+      for (int k = 0; k < kRT / 64; ++k) add += s_cnt[k * nbins + b];
+      s_base[b] += add;
+    }
+    __syncthreads();
+  }
+}
+
 int device_sort_pairs_u32(lvf_ctx* ctx, const unsigned* keys_in, unsigned* keys_out, const int* vals_in, int* vals_out, int n, int key_bits) {
   if (n <= 0) return LVF_OK;
   hipStream_t s = ctx->stream;
-  size_t bytes = 0;
-  LVF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, key_bits, s));
-  DevBuf<unsigned char> tmp;
-  LVF_TRY(tmp.alloc(bytes ? bytes : 1));
-  LVF_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, key_bits, s));
-  LVF_HIP(hipStreamSynchronize(s));          // (tmp is released on return; the pool hands it out again in stream order, so this wait is only belt and braces)
+  const int bits = std::min(32, std::max(1, key_bits));
+  const int passes = (bits + kRMaxDigitBits - 1) / kRMaxDigitBits;      // as few passes as 11-bit digits allow ...
+  const int db = (bits + passes - 1) / passes;                          // ... each as narrow as that number of passes permits
+  const int nbins = 1 << db;
+  const int ntiles = (n + kRTile - 1) / kRTile;
+  DevBuf<int> hist; DevBuf<unsigned> tkeys; DevBuf<int> tvals;
+  LVF_TRY(hist.alloc((size_t)nbins * ntiles));
+  if (passes > 1) { LVF_TRY(tkeys.alloc(n)); LVF_TRY(tvals.alloc(n)); }
+  const unsigned* ki = keys_in; const int* vi = vals_in;
+  for (int p = 0; p < passes; ++p) {
+    // the last pass must land in the caller's arrays: with an odd number of passes the first one writes there, otherwise the scratch pair
+    const bool to_out = ((passes - 1 - p) % 2) == 0;
+    unsigned* ko = to_out ? keys_out : tkeys.p; int* vo = to_out ? vals_out : tvals.p;
+    hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(kRT), (size_t)nbins * sizeof(int), s, n, ki, db * p, nbins, hist.p, ntiles);
+    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kRScanT), 0, s, nbins * ntiles, hist.p);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(kRT), (size_t)(1 + kRT / 64) * nbins * sizeof(int), s, n, ki, vi, ko, vo, db * p, db, hist.p, ntiles);
+    ki = ko; vi = vo;
+  }
+  LVF_HIP(hipGetLastError());
+  // (the scratch buffers go back to the context's pool on return: the pool hands them out again in stream order, nothing to wait for)
   return LVF_OK;
 }
 
