@@ -438,6 +438,10 @@ int lvf_problem_gradient(lvf_problem* p, const lvf_solver_options* o, double* gc
  * after 20 us, so the retry path (LVF_WHY_HANDOVER -> un-chained re-run, lvf_solver_summary::hand_over_retries) can be exercised on an
  * idle GPU.  Also re-enables chaining for the problem.  Not part of the reference surface. */
 int lvf_problem_debug_force_handover_timeout(lvf_problem* p, int n);
+/* Diagnostic (environment LVF_LM_HISTORY=1 when the problem's launch chain is built): out512 receives eight doubles per closed pass of the
+ * last device-loop solve, slot = iteration & 63: {iteration, cost at the point, candidate cost, model cost change, accepted, failure flag,
+ * trust-region radius used, gradient max norm}.  LVF_ERR_STATE without the environment variable. */
+int lvf_problem_debug_history(lvf_problem* p, double* out512);
 
 /* ---- loop-correction tail: Relocator::UpdateNewSubmap / PoseGraph::ForwardUpdate ---------------------------------- */
 /* RelocateRError <7,4> (pose_error.hpp:192-222) batched: block i = RelocateRError(relocated[i], unrelocated[i]) evaluated at the shared

@@ -140,6 +140,7 @@ _SIGS = {
     "lvf_problem_batch_destroy": (C.c_int, [_VP]),
     "lvf_problem_batch_size": (C.c_int, [_VP]),
     "lvf_problem_debug_force_handover_timeout": (C.c_int, [_VP, C.c_int]),
+    "lvf_problem_debug_history": (C.c_int, [_VP, c_double_p]),
     "lvf_problem_batch_uses_tables": (C.c_int, [_VP, C.POINTER(SolverOptions)]),
     "lvf_problem_batch_lm_iteration": (C.c_int, [_VP, C.POINTER(SolverOptions), c_double_p, c_double_p, c_double_p, c_double_p, c_int_p]),
     "lvf_problem_batch_solve": (C.c_int, [_VP, C.POINTER(SolverOptions), C.POINTER(SolverSummary)]),

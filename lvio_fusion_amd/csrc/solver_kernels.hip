@@ -89,8 +89,10 @@ struct lvf_problem {
   std::vector<lvf_problem_batch*> batches;      // the batches that borrow this problem (they are told when it is destroyed)
   lvf::HostPin<int> h_run_first;
   lvf::DevBuf<unsigned long long> dbg, dbg_lin, dbg_sp;
+  lvf::DevBuf<double> dbg_hist;                 // LVF_LM_HISTORY=1: the decisions of the last solve (lvf_problem_debug_history)
   lvf::DevBuf<double> sp_sync;                  // arrival counters of sparse levels chained inside one launch (one 8-byte slot per level, an int in each; cleared with the accumulators)
   lvf::DevBuf<double> sp_W, sp_L, Dinv;         // Dinv: L_kk^-T of every 64x64 diagonal block of the dense corner
+  lvf::DevBuf<double> Ldiag;                    // the factored diagonal blocks L_kk [nb][64][64] (NOT stored back into S: see chol_step_body)
   std::vector<int> perm_h;
   lvf::DevBuf<double> B, gc, C, gr, E, Cd, S, dxc, dxl, scal;
   lvf::DevBuf<double> poses2, vel2, ba2, bg2, invd2;   // candidate state x + dx
@@ -1832,7 +1834,7 @@ __device__ __forceinline__ void factor_panel_wave(double b[16], const int r, con
 //       L_kk^-T for the back substitution.
 //   workgroups behind them     — the rest of step kb-1's trailing update, A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi, which nothing in
 //       this launch reads (the next step does).
-struct CholArgs { double* Sd; int ld, nb; int* fail; double* Dinv; const int* done; unsigned long long* dbg; int last_cols; };   // dbg: LVF_CHOL_TIMING stamps; last_cols: real (un-padded) columns of the last block
+struct CholArgs { double* Sd; int ld, nb; int* fail; double* Dinv; const int* done; unsigned long long* dbg; int last_cols; double* Ldiag; };   // dbg: LVF_CHOL_TIMING stamps; last_cols: real (un-padded) columns of the last block
 __host__ __device__ inline int chol_step_grid(int nb, int kb) {
   const int below = nb - kb - 1;
   return kb >= nb ? 0 : 2 + below + (kb > 0 ? below * (below + 1) / 2 : 0);
@@ -1984,9 +1986,14 @@ __device__ __forceinline__ void chol_step_body(const int bx, const CholArgs& A, 
   if (dbg) { dbg[4] = wall_clock64(); dbg[7] = clock64(); }
   if (bad && r == 0) atomicMax(fail, 1 + kb);
   if (bx == 0 && !panel_wave) {
+    // The factored diagonal block goes to a SIDE buffer, never back into S: every workgroup of this column loads A_kk from S when it starts,
+    // and a workgroup that is dispatched late — a second context's kernels filling the chip (Backend::Optimize beside Relocator,
+    // relocator.cpp:188) — would find L_kk there instead of A_kk and factor garbage (measured: 197 of 400 solves took a step as invalid
+    // under chip-filling traffic; the per-launch "everyone has loaded long before workgroup 0 stores" held only on an otherwise idle GPU).
+    // What reads L_kk afterwards — the right-hand-side row inside the last block, by the back substitution — reads it from there.
 #pragma unroll
     for (int tt = 0; tt < 16; ++tt) if (16 * q + tt > r) a[tt] = 0.0;
-    double2* g2 = reinterpret_cast<double2*>(drow);
+    double2* g2 = reinterpret_cast<double2*>(A.Ldiag + (size_t)kb * kNB * kNB + (size_t)r * kNB + 16 * q);
 #pragma unroll
     for (int c = 0; c < 8; ++c) g2[c] = make_double2(a[2 * c], a[2 * c + 1]);
   }
@@ -2330,7 +2337,7 @@ __device__ __forceinline__ T ld_off32(const T* base, unsigned byte_off) {     //
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 constexpr int kBT = 512, kBParts = kBT / 64, kBackPre = 256 / kBParts, kBackInv = 64 / kBParts, kTailPre = 6;
-struct BackArgs { const double* Sd; int ld, d; const double* Dinv; double* xout; SpBack sp; const int* done; };
+struct BackArgs { const double* Sd; int ld, d; const double* Dinv; double* xout; SpBack sp; const int* done; const double* Ldiag; };
 __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
   const int dv = done_flag_issue(A.done);
   const double* S = A.Sd; const int ld = A.ld, d = A.d; const double* Dinv = A.Dinv; double* xout = A.xout; const SpBack& sp = A.sp;
@@ -2370,7 +2377,10 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
     const double* dv = Dinv + (size_t)kb * kNB * kNB + kBackInv * part_u;
 #pragma unroll
     for (int t = 0; t < kBackInv; ++t) xi[t] = ld_off32(dv + t, (unsigned)kNB * c_off);
-    yv = (r0 + c < d) ? ld_off32(S + (size_t)d * ld + r0, c_off) : 0.0;
+    // the forward-substituted right-hand side: row d of the factor — a panel tile of S for every block but the last, whose part sits in
+    // the factored DIAGONAL block (kept in the side buffer: chol_step_body)
+    const double* yrow = (d / kNB == kb) ? A.Ldiag + (size_t)kb * kNB * kNB + (size_t)(d - r0) * kNB : S + (size_t)d * ld + r0;
+    yv = (r0 + c < d) ? ld_off32(yrow, c_off) : 0.0;
   };
   prefetch(nblk - 1);
   // the stored L_bb^-1 and the node table go to LDS: ALL of a thread's requests are issued before the first LDS write (written as a
@@ -2644,6 +2654,7 @@ struct DecideArgs {
   double *poses, *vel, *ba, *bg, *invd;                 // the state
   const double *poses2, *vel2, *ba2, *bg2, *invd2;      // the candidate
   unsigned long long* dbg;                              // LVF_COST_TIMING=1: wall_clock64() stamps (100 MHz), else null
+  double* hist;                                         // LVF_LM_HISTORY=1: eight doubles per closed pass (64 passes), else null
 };
 constexpr int kDT = 256;
 // COHERENT: the sums are read past the caches (the caller is the last workgroup of the launch that produced part of them)
@@ -2741,6 +2752,10 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
     c->iter = lc.iter; c->successes = lc.successes; c->invalid_run = lc.invalid_run; c->accepted = lc.accepted; c->solved = lc.solved;
     c->done = lc.done; c->termination = lc.termination; c->why = lc.why; c->rejected = lc.rejected;
     s_iter = lc.iter; s_done = lc.done;
+    if (A.hist) {                                      // diagnostic: what this pass decided on
+      double* h = A.hist + 8 * (it & 63);
+      h[0] = (double)it; h[1] = cost_before; h[2] = cost_new; h[3] = model; h[4] = accepted ? 1.0 : 0.0; h[5] = (double)hfail; h[6] = lc.last_radius; h[7] = gmax;
+    }
     if (A.dbg) A.dbg[3] = wall_clock64();
   }
   __syncthreads();
@@ -2959,7 +2974,7 @@ static void fill_back_args(lvf_problem* p, BackArgs& ba, size_t* lds_bytes) {
   sb.prod_items = ((doubles + 9 * (size_t)max_items) * sizeof(double) <= lds_cap) ? max_items : 0;
   doubles += 9 * (size_t)sb.prod_items;
   *lds_bytes = doubles * sizeof(double);
-  ba.Sd = p->S.p + (size_t)p->off * (p->ld + 1); ba.ld = p->ld; ba.d = p->ndense; ba.Dinv = p->Dinv.p; ba.xout = p->dxc.p; ba.sp = sb;
+  ba.Sd = p->S.p + (size_t)p->off * (p->ld + 1); ba.ld = p->ld; ba.d = p->ndense; ba.Dinv = p->Dinv.p; ba.Ldiag = p->Ldiag.p; ba.xout = p->dxc.p; ba.sp = sb;
 }
 
 // the work list of the band Schur complement for the current rows-per-slice setting; its length is part of the launch grid
@@ -3157,7 +3172,7 @@ static int build_chain(lvf_problem* p) {
       c.first_own_level = next_level;
     }
   }
-  c.chol.Sd = p->S.p + (size_t)p->off * (p->ld + 1); c.chol.ld = p->ld; c.chol.nb = p->nb; c.chol.fail = fail; c.chol.Dinv = p->Dinv.p; c.chol.done = done;
+  c.chol.Sd = p->S.p + (size_t)p->off * (p->ld + 1); c.chol.ld = p->ld; c.chol.nb = p->nb; c.chol.fail = fail; c.chol.Dinv = p->Dinv.p; c.chol.Ldiag = p->Ldiag.p; c.chol.done = done;
   c.chol.last_cols = p->ndense + 1 - kNB * (p->nb - 1);       // (the right-hand-side row is the last real one)
   fill_back_args(p, c.back, &c.back_lds);
   c.back.done = done;
@@ -3195,6 +3210,9 @@ static int build_chain(lvf_problem* p) {
     a.scal = p->scal.p; a.ctl = ctl; a.rec = p->rec; a.ticket = reinterpret_cast<int*>(p->scal.p + SC_TICKET); a.n_kf = p->n_kf; a.n_lm = p->n_lm;
     a.poses = p->st->poses.p; a.vel = p->st->vel.p; a.ba = p->st->ba.p; a.bg = p->st->bg.p; a.invd = p->st->inv_depth.p;
     a.poses2 = p->poses2.p; a.vel2 = p->vel2.p; a.ba2 = p->ba2.p; a.bg2 = p->bg2.p; a.invd2 = p->invd2.p;
+    static const bool lm_history = std::getenv("LVF_LM_HISTORY") != nullptr;
+    a.hist = nullptr;
+    if (lm_history) { LVF_TRY(p->dbg_hist.ensure(8 * 64)); a.hist = p->dbg_hist.p; }
   }
   c.batchable = c.fast && p->compact && c.has_imu && !c.has_prior && c.merged_level0 && c.lin.nblocks > 0 && c.cost.nblocks > 0;
   { const StateP sp = state_ptrs(p->st); std::memcpy(p->chain_state, &sp, sizeof(sp)); }
@@ -3768,7 +3786,7 @@ int problem_configure(lvf_problem* p) {
   LVF_TRY(build_elimination_plan(p));                 // sets ld, off, off_pose, ndense, aug, nb and the sparse levels
   cfg_mark("elimination plan");
   const size_t nS = (size_t)p->dpad * p->dpad;
-  LVF_TRY(p->Dinv.ensure((size_t)p->nb * kNB * kNB));
+  LVF_TRY(p->Dinv.ensure((size_t)p->nb * kNB * kNB)); LVF_TRY(p->Ldiag.ensure((size_t)p->nb * kNB * kNB));
   LVF_TRY(p->B.ensure(nS)); LVF_TRY(p->S.ensure((size_t)p->ld * p->ld)); LVF_TRY(p->gc.ensure(p->dpad)); LVF_TRY(p->dxc.ensure(p->dpad));
   LVF_TRY(p->C.ensure(p->n_lm)); LVF_TRY(p->gr.ensure(p->n_lm)); LVF_TRY(p->Cd.ensure(p->n_lm)); LVF_TRY(p->dxl.ensure(p->n_lm));
   LVF_TRY(p->scal.ensure(SC_ALLOC)); LVF_TRY(p->sp_sync.ensure(kSpMaxLevels));
@@ -4382,6 +4400,15 @@ int lvf_problem_batch_destroy(lvf_problem_batch* b) {
   return LVF_OK;
 }
 int lvf_problem_batch_size(const lvf_problem_batch* b) { return b ? b->W : -1; }
+// diagnostic (LVF_LM_HISTORY=1): {iteration, cost_before, cost_new, model, accepted, fail flag, radius, gradient max} of the passes of the last solve
+int lvf_problem_debug_history(lvf_problem* p, double* out512) {
+  LVF_REQUIRE(p && out512, "lvf_problem_debug_history: null argument");
+  if (!p->dbg_hist.p) { set_error("lvf_problem_debug_history: LVF_LM_HISTORY is not set"); return LVF_ERR_STATE; }
+  LVF_TRY(lvf::enter(p->ctx));
+  LVF_HIP(hipMemcpyAsync(out512, p->dbg_hist.p, 512 * 8, hipMemcpyDeviceToHost, p->ctx->stream));
+  LVF_HIP(hipStreamSynchronize(p->ctx->stream));
+  return LVF_OK;
+}
 // test hook (see lvf.h)
 int lvf_problem_debug_force_handover_timeout(lvf_problem* p, int n) {
   LVF_REQUIRE(p && n >= 0, "lvf_problem_debug_force_handover_timeout: bad argument");

@@ -13,7 +13,14 @@
 //   * model_cost_change = -dx^T (g + H dx / 2); rho = (cost - cost_new) / model_cost_change;
 //     accept iff rho > min_relative_decrease (1e-3): radius /= max(1/3, 1 - (2 rho - 1)^3), decrease_factor = 2;
 //     else radius /= decrease_factor, decrease_factor *= 2; an INVALID step (solver failure or model_cost_change <= 0): radius *= 0.5.
-//     (Jacobi column scaling is algebraically a no-op here.)  The whole loop with Ceres' termination order: lm_solve below.
+//     The whole loop with Ceres' termination order: lm_solve below.
+//   * DECLARED DIFFERENCE — Jacobi column scaling (a Ceres default) is NOT modelled.  Upstream scales column j of J by s_j = 1 / (1 + sqrt(H0_jj))
+//     (H0 = J^T J of the FIRST iteration, frozen) and clamps the diagonal of the SCALED normal equations: in unscaled terms its damping is
+//     D^2_jj = clamp(s_j^2 H_jj, 1e-6, 1e32) / s_j^2.  Where the clamp is inactive that is H_jj — identical to the line above, and the step is
+//     the same (the scaling is a change of variables).  It differs only in columns with s_j^2 H_jj < 1e-6: there upstream damps with
+//     1e-6 (1 + sqrt(H0_jj))^2 / radius, this file with max(H_jj, 1e-6) / radius.  On every window of tests/ and bench.py all diagonals are
+//     >> 1 (pixels-per-metre Jacobians, IMU information), so neither clamp ever acts; a problem with a near-zero column (an unobserved
+//     direction) would see a slightly different — still tiny — damping.  The GPU follows this file, not upstream, in that corner.
 // Unknown ordering of the reduced (camera) system, d = 15 n_kf:
 //   [ pose tangent 6 x n_kf (keyframe-major) | (v 3, ba 3, bg 3) x n_kf ].
 #pragma once
