@@ -25,39 +25,7 @@ __device__ __forceinline__ void param_slots(int mode, int& i0, int& i1, int& i2)
   if (mode == 0) { i0 = 1; i1 = 2; i2 = 5; } else { i0 = 0; i1 = 3; i2 = 4; }
 }
 
-// correspondences: scan point (double), first neighbour pa, unit normal — SoA [3][Q]; invalid points keep valid = 0
-__device__ __forceinline__ void icp_build_body(const int bx, int Q, const float4* __restrict__ scan, const int* __restrict__ idx,
-                                               const uint8_t* __restrict__ valid, const float4* __restrict__ map_raw,
-                                               double* __restrict__ P, double* __restrict__ PA, double* __restrict__ N,
-                                               IcpDev* __restrict__ dev) {
-  const int i = bx * kTI + threadIdx.x;
-  const bool ok = i < Q && valid[i];
-  if (ok) {
-    const float4 p = scan[i];
-    const float4 a = map_raw[idx[3 * i]], b = map_raw[idx[3 * i + 1]], c = map_raw[idx[3 * i + 2]];
-    const double pa[3] = {(double)a.x, (double)a.y, (double)a.z}, pb[3] = {(double)b.x, (double)b.y, (double)b.z}, pc[3] = {(double)c.x, (double)c.y, (double)c.z};
-    double n[3];
-    plane_normal(pa, pb, pc, n);
-    P[i] = (double)p.x; P[Q + i] = (double)p.y; P[2 * Q + i] = (double)p.z;
-    PA[i] = pa[0]; PA[Q + i] = pa[1]; PA[2 * Q + i] = pa[2];
-    N[i] = n[0]; N[Q + i] = n[1]; N[2 * Q + i] = n[2];
-  }
-  const unsigned long long m = __ballot(ok);
-  if (dev && (threadIdx.x & 63) == 0 && m) atomicAdd(&dev->nvalid, __popcll(m));
-}
-__global__ __launch_bounds__(kTI) void k_icp_build(int Q, const float4* __restrict__ scan, const int* __restrict__ idx,
-                                                   const uint8_t* __restrict__ valid, const float4* __restrict__ map_raw,
-                                                   double* __restrict__ P, double* __restrict__ PA, double* __restrict__ N,
-                                                   IcpDev* __restrict__ dev) {
-  icp_build_body(blockIdx.x, Q, scan, idx, valid, map_raw, P, PA, N, dev);
-}
-// table form (blockIdx.y = candidate); the valid correspondences are counted by the first linearisation pass (IcpDev::count_valid)
-__global__ __launch_bounds__(kTI) void k_icp_build_b(const KnnJob* __restrict__ jobs, int sub) {
-  const KnnJob& J = jobs[2 * blockIdx.y + sub];
-  if ((long long)blockIdx.x * kTI >= (long long)J.Q) return;
-  icp_build_body(blockIdx.x, J.Q, J.scan, J.idx, J.valid, J.map_raw, J.corr, J.corr + (size_t)3 * J.Q, J.corr + (size_t)6 * J.Q, nullptr);
-}
-
+// (the correspondences — scan point, first neighbour pa, unit plane normal, SoA [3][Q] — are written by the association kernel: knn_kernels.hip)
 // the sums other workgroups added with L2 atomics, read past this CU's L1
 __device__ __forceinline__ double fresh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double clampd(double v) { return fmin(fmax(v, 1e-6), 1e32); }
@@ -235,12 +203,6 @@ static IcpArgs make_args(const double* Twc1, const lvf_icp_options* opt) {
   a.mode = opt->mode; a.max_iters = opt->max_num_iterations;
   return a;
 }
-int launch_icp_build_batch(hipStream_t q, const KnnJob* jobs, int n, int sub, int max_Q) {
-  if (n <= 0 || max_Q <= 0) return LVF_OK;
-  hipLaunchKernelGGL(k_icp_build_b, dim3((max_Q + kTI - 1) / kTI, n), dim3(kTI), 0, q, jobs, sub);
-  LVF_HIP(hipGetLastError());
-  return LVF_OK;
-}
 int launch_icp_eval_batch(hipStream_t q, const IcpJob* jobs, SmDev* devs, int n, int sub, int max_Q, bool with_j) {
   if (n <= 0) return LVF_OK;
   const dim3 g(icp_blocks(max_Q), n);
@@ -286,10 +248,10 @@ extern "C" int lvf_icp_solve(lvf_map* m, lvf_scan* sc, const double* map_pose, c
   hipStream_t q = m->ctx->stream;
   const int Q = sc->Q;
   std::memset(summary, 0, sizeof(*summary));
-  // 1. association at the frame's current pose (association.cpp:287-301 / :345-359)
-  LVF_TRY(lvf_knn3(m, sc, frame_pose, opt->thr));
-  // 2. correspondences + device solver state
+  // 1. association at the frame's current pose (association.cpp:287-301 / :345-359) + 2. the correspondences (:303-314), one launch
   if (sc->corr.n < (size_t)9 * std::max(Q, 1)) LVF_TRY(sc->corr.alloc((size_t)9 * std::max(Q, 1)));
+  LVF_TRY(launch_knn3_build(m, sc, frame_pose, opt->thr, sc->corr.p));
+  // device solver state
   if (!sc->icp_dev.p) LVF_TRY(sc->icp_dev.alloc(sizeof(IcpDev)));
   double* P = sc->corr.p; double* PA = P + (size_t)3 * Q; double* N = PA + (size_t)3 * Q;
   // (the solver state travels through a pinned mirror owned by the scan: from a stack variable both copies went through the runtime's
@@ -297,12 +259,11 @@ extern "C" int lvf_icp_solve(lvf_map* m, lvf_scan* sc, const double* map_pose, c
   LVF_TRY(sc->icp_host.reserve(sizeof(IcpDev)));
   IcpDev& h = *reinterpret_cast<IcpDev*>(sc->icp_host.p);
   init_dev(h, opt->mode, rpyxyz);
+  h.count_valid = 1;                         // (the accepted queries are counted by the first linearisation pass)
   const int i0 = opt->mode == 0 ? 1 : 0, i1 = opt->mode == 0 ? 2 : 3, i2 = opt->mode == 0 ? 5 : 4;
   IcpDev* dev = reinterpret_cast<IcpDev*>(sc->icp_dev.p);
   LVF_HIP(hipMemcpyAsync(dev, &h, sizeof(h), hipMemcpyHostToDevice, q));
   IcpArgs a = make_args(map_pose, opt);
-  const int grid = (std::max(Q, 1) + kTI - 1) / kTI;
-  if (Q > 0) hipLaunchKernelGGL(k_icp_build, dim3(grid), dim3(kTI), 0, q, Q, sc->pts.p, sc->idx.p, sc->valid.p, m->raw.p, P, PA, N, dev);
   // 3. LM iterations, all on device
   LVF_TRY(run_lm(q, Q, P, PA, N, sc->valid.p, a, dev, &h));
   rpyxyz[i0] = h.x[0]; rpyxyz[i1] = h.x[1]; rpyxyz[i2] = h.x[2];

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include "lvf_internal.hpp"
 #include "scan_match_dev.hpp"
+#include "lidar_eval.hpp"
 
 // The float32 arithmetic below must round after every multiply and add (bit-exact d2 / transform): the default
 // -ffp-contract=fast would fuse them (HIP's own __fmul_rn/__fadd_rn are plain operators compiled with the
@@ -380,10 +381,14 @@ __device__ __forceinline__ void group_merge_best3(float bd[3], int bi[3]) {
   }
 }
 
-template <bool STATS>
+// BUILD: the query's writer lane also builds the point-to-plane correspondence of an accepted query (association.cpp:303-314: the scan point
+// and its first neighbour as doubles, the unit normal of the plane through the three neighbours) into corr = P | PA | N (SoA [3][Q] each) — what
+// k_icp_build did in a launch of its own: one launch and the round trip of the indices less per sub-problem.
+template <bool STATS, bool BUILD = false>
 __device__ __forceinline__ void knn3_body(const int bx, int Q, const float4* __restrict__ scan, const float* tfv, const LevelsP& L,
                                           float thr, int* __restrict__ idx, float* __restrict__ d2,
-                                          uint8_t* __restrict__ valid, KnnStats* __restrict__ stats) {
+                                          uint8_t* __restrict__ valid, KnnStats* __restrict__ stats,
+                                          const float4* __restrict__ map_raw = nullptr, double* __restrict__ corr = nullptr) {
   const int t = bx * kB + threadIdx.x;
   const int g_lane = t & (kGroup - 1);
   const int i = min(t / kGroup, Q - 1);          // surplus groups of the last block shadow the last query (no divergent exit
@@ -431,7 +436,18 @@ __device__ __forceinline__ void knn3_body(const int bx, int Q, const float4* __r
   if (writer) {
     idx[3 * i + 0] = bi[0]; idx[3 * i + 1] = bi[1]; idx[3 * i + 2] = bi[2];
     d2[3 * i + 0] = bd[0]; d2[3 * i + 1] = bd[1]; d2[3 * i + 2] = bd[2];
-    valid[i] = (bi[0] >= 0 && bd[0] < thr && bi[1] >= 0 && bd[1] < thr && bi[2] >= 0 && bd[2] < thr) ? 1 : 0;
+    const bool ok = bi[0] >= 0 && bd[0] < thr && bi[1] >= 0 && bd[1] < thr && bi[2] >= 0 && bd[2] < thr;
+    valid[i] = ok ? 1 : 0;
+    if (BUILD && ok) {
+      const float4 a = map_raw[bi[0]], b = map_raw[bi[1]], c = map_raw[bi[2]];
+      const double pa[3] = {(double)a.x, (double)a.y, (double)a.z}, pb[3] = {(double)b.x, (double)b.y, (double)b.z}, pc[3] = {(double)c.x, (double)c.y, (double)c.z};
+      double n[3];
+      plane_normal(pa, pb, pc, n);
+      double* P = corr; double* PA = corr + (size_t)3 * Q; double* N = corr + (size_t)6 * Q;
+      P[i] = (double)p.x; P[Q + i] = (double)p.y; P[2 * Q + i] = (double)p.z;
+      PA[i] = pa[0]; PA[Q + i] = pa[1]; PA[2 * Q + i] = pa[2];
+      N[i] = n[0]; N[Q + i] = n[1]; N[2 * Q + i] = n[2];
+    }
   }
 }
 template <bool STATS>
@@ -440,6 +456,11 @@ __global__ __launch_bounds__(kB) void k_knn3(int Q, const float4* __restrict__ s
                                              uint8_t* __restrict__ valid, KnnStats* __restrict__ stats) {
   knn3_body<STATS>(blockIdx.x, Q, scan, tfa.v, L, thr, idx, d2, valid, stats);
 }
+// association + correspondence build in one launch (lvf_icp_solve)
+__global__ __launch_bounds__(kB) void k_knn3_build(int Q, const float4* __restrict__ scan, const TfArg tfa, const LevelsP L, float thr, int* __restrict__ idx,
+                                                   float* __restrict__ d2, uint8_t* __restrict__ valid, const float4* __restrict__ map_raw, double* __restrict__ corr) {
+  knn3_body<false, true>(blockIdx.x, Q, scan, tfa.v, L, thr, idx, d2, valid, nullptr, map_raw, corr);
+}
 // Many associations in one launch: blockIdx.y = candidate, the job (scan, map pyramid, gate, outputs) comes from a device table and the
 // float transform from the candidate's device record — the pose the previous sub-problem left there never visits the host.
 __global__ __launch_bounds__(kB) void k_knn3_b(const KnnJob* __restrict__ jobs, const SmDev* __restrict__ devs, int sub) {
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(kB) void k_knn3_b(const KnnJob* __restrict__ jobs, 
   if ((long long)blockIdx.x * (kB / kGroup) >= (long long)J.Q) return;      // (uniform per workgroup; also Q == 0: nothing to associate)
   const SmDev& D = devs[blockIdx.y];
   if (!D.has[sub]) return;
-  knn3_body<false>(blockIdx.x, J.Q, J.scan, D.tf, J.L, J.thr, J.idx, J.d2, J.valid, nullptr);
+  knn3_body<false, true>(blockIdx.x, J.Q, J.scan, D.tf, J.L, J.thr, J.idx, J.d2, J.valid, nullptr, J.map_raw, J.corr);
 }
 
 // exclusive prefix sum of n ints on the context's stream; out has n + 1 entries (out[n] = grand total).  in != out.
@@ -481,6 +502,16 @@ LevelsP levels_of(const lvf_map* m) {
     L.l[k] = LevelP{lv.sorted.p, lv.cell_start.p, GridP{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz}};
   }
   return L;
+}
+int launch_knn3_build(lvf_map* m, lvf_scan* sc, const double* pose, float thr, double* corr) {
+  if (sc->Q <= 0) return LVF_OK;
+  TfArg tf;
+  for (int k = 0; k < 7; ++k) tf.v[k] = (float)pose[k];   // Sophus SE3d::cast<float>()  association.cpp:287
+  hipLaunchKernelGGL(k_knn3_build, dim3(knn_grid(sc->Q)), dim3(kB), 0, m->ctx->stream, sc->Q, sc->pts.p, tf, levels_of(m), thr, sc->idx.p, sc->d2.p, sc->valid.p,
+                     m->raw.p, corr);
+  LVF_HIP(hipGetLastError());
+  sc->searched = true;
+  return LVF_OK;
 }
 int launch_knn3_batch(hipStream_t q, const KnnJob* jobs, const SmDev* devs, int n, int sub, int max_Q) {
   if (n <= 0 || max_Q <= 0) return LVF_OK;

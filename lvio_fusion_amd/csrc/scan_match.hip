@@ -188,8 +188,7 @@ int scan_match_run(lvf_ctx* ctx, const SmJobView* jobs, int n, const lvf_scan_ma
       sa.prev = prev; sa.next = m; sa.first_of_outer = first ? 1 : 0;
       hipLaunchKernelGGL(k_sm_step, gs, dim3(64), 0, q, dd, sa);
       first = false;
-      LVF_TRY(launch_knn3_batch(q, dk, dd, n, m, max_Q[m]));            // association.cpp:287-301 / :345-359
-      LVF_TRY(launch_icp_build_batch(q, dk, n, m, max_Q[m]));           // :303-314 / :361-372
+      LVF_TRY(launch_knn3_batch(q, dk, dd, n, m, max_Q[m]));            // association.cpp:287-301 / :345-359 and the correspondences, :303-314 / :361-372
       for (int li = 0; li < std::max(1, opt->max_num_iterations); ++li) {
         LVF_TRY(launch_icp_eval_batch(q, di, dd, n, m, max_Q[m], true));
         if (opt->max_num_iterations == 0) break;

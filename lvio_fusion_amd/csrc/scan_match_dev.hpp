@@ -58,8 +58,8 @@ struct IcpJob { int Q; const double *P, *PA, *N; const uint8_t* valid; IcpArgs a
 constexpr int kIcpMaxBlocks = 128;   // k_icp_eval grid cap (grid-stride above it)
 
 // launchers (the kernels stay in their translation units: the association is compiled without FMA contraction)
-int launch_knn3_batch(hipStream_t q, const KnnJob* jobs, const SmDev* devs, int n, int sub, int max_Q);
-int launch_icp_build_batch(hipStream_t q, const KnnJob* jobs, int n, int sub, int max_Q);
+int launch_knn3_batch(hipStream_t q, const KnnJob* jobs, const SmDev* devs, int n, int sub, int max_Q);      // association + correspondence build
+int launch_knn3_build(lvf_map* m, lvf_scan* sc, const double* pose, float thr, double* corr);                 // the same for one (map, scan) pair
 int launch_icp_eval_batch(hipStream_t q, const IcpJob* jobs, SmDev* devs, int n, int sub, int max_Q, bool with_j);
 LevelsP levels_of(const lvf_map* m);
 
