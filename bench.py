@@ -529,7 +529,7 @@ def icp_leg(api, syn, ctx, verified):
             api.knn3(mp, sc, c3["pose0"], thr)
         ctx.timer_end()
         ms = ctx.timer_ms() / reps
-        stats = np.zeros((Q, 4), np.int32); lv = np.zeros((8, 4), np.float32); nl = C.c_int()
+        stats = np.zeros((Q, 6), np.int32); lv = np.zeros((8, 4), np.float32); nl = C.c_int()
         pose = np.ascontiguousarray(c3["pose0"], dtype=np.float64)
         api._chk(ctx.L.lvf_knn3_debug_stats(mp.h, sc.h, pose.ctypes.data_as(_lib.c_double_p), float(thr), stats.ctypes.data_as(_lib.c_int_p),
                                             lv.ctypes.data_as(_lib.c_float_p), C.byref(nl)))

@@ -209,10 +209,10 @@ int lvf_scan_destroy(lvf_scan* s);
  * exact 3-NN of every point. */
 int lvf_knn3(lvf_map* m, lvf_scan* s, const double* pose, float thr);
 int lvf_scan_download(lvf_scan* s, int32_t* idx3, float* d2_3, uint8_t* valid);
-/* Diagnostic only: per-point search statistics stats4[Q][4] = {candidates, range lookups, last grid level, shells}
- * and the grid pyramid levels4[L][4] = {cell, nx, ny, nz}; the caller provides room for 8 levels (the pyramid halves the cell
+/* Diagnostic only: per-point search statistics stats6[Q][6] = {candidates, range lookups, last grid level, shells, start, end}
+ * (start / end: the 100 MHz wall clock when the point's wave began and finished, low 31 bits) and the grid pyramid levels4[L][4] = {cell, nx, ny, nz}; the caller provides room for 8 levels (the pyramid halves the cell
  * per level, at most 8 levels). */
-int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* s, const double* pose, float thr, int32_t* stats4, float* levels4,
+int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* s, const double* pose, float thr, int32_t* stats6, float* levels4,
                          int* n_levels);
 
 /* ---- map-cloud maintenance on device (the steps immediately before the association) ------------- */

@@ -9,7 +9,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "liblvf_hip.so")
+SO_PATH = os.environ.get("LVF_LIB_PATH") or os.path.join(HERE, "liblvf_hip.so")      # (LVF_LIB_PATH: another build of the same library, for A/B runs on one box)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "lvf.h")
 
 c_double_p = C.POINTER(C.c_double)

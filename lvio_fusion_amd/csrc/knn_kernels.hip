@@ -224,7 +224,7 @@ __device__ __forceinline__ void best3_push(float d, int i, float bd[3], int bi[3
   } else { bd[2] = d; bi[2] = i; }
 }
 
-struct KnnStats { int candidates, lookups, level, shells; };
+struct KnnStats { int candidates, lookups, level, shells, t_start, t_end; };   // t_*: wall_clock64() (100 MHz) of the query's wave, low 31 bits
 
 constexpr int kGroup = 8;   // lanes cooperating on one query (8 queries per wave64)
 
@@ -400,7 +400,8 @@ __device__ __forceinline__ void knn3_body(const int bx, int Q, const float4* __r
   const float qz = tf_row(T.a + 6, p.x, p.y, p.z, p.z, T.t[2]);
   float bd[3] = {INFINITY, INFINITY, INFINITY};
   int bi[3] = {-1, -1, -1};
-  KnnStats st{0, 0, 0, 0};
+  KnnStats st{0, 0, 0, 0, 0, 0};
+  if (STATS) st.t_start = (int)((long long)wall_clock64() & 0x7fffffff);
   KnnStats* stp = STATS ? &st : nullptr;
   // fine -> coarse: shells 0..1 of the finest grid, shells 0..2 of every coarser one; dense neighbourhoods finish in the
   // finest grid, sparse ones escalate to a grid whose cells are 2x larger instead of walking dozens of empty fine shells.
@@ -431,6 +432,7 @@ __device__ __forceinline__ void knn3_body(const int bx, int Q, const float4* __r
   if (STATS) {
 #pragma unroll
     for (int mask = 1; mask < kGroup; mask <<= 1) { st.candidates += __shfl_xor(st.candidates, mask); st.lookups += __shfl_xor(st.lookups, mask); }
+    st.t_end = (int)((long long)wall_clock64() & 0x7fffffff);
     if (writer) stats[i] = st;
   }
   if (writer) {
@@ -658,8 +660,8 @@ int lvf_scan_destroy(lvf_scan* s) { delete s; return LVF_OK; }
 
 // diagnostic (not part of the reference surface): per-query search statistics {candidates, range lookups, last level,
 // shells}, and the grid pyramid geometry {cell, nx, ny, nz} per level.
-int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* sc, const double* pose, float thr, int32_t* stats4, float* levels4, int* n_levels) {
-  LVF_REQUIRE(m && sc && pose && stats4, "lvf_knn3_debug_stats: null argument");
+int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* sc, const double* pose, float thr, int32_t* stats6, float* levels4, int* n_levels) {
+  LVF_REQUIRE(m && sc && pose && stats6, "lvf_knn3_debug_stats: null argument");
   LVF_TRY(lvf::enter(m->ctx));
   if (n_levels) *n_levels = m->n_levels;
   if (levels4) for (int k = 0; k < m->n_levels; ++k) { levels4[4 * k] = m->levels[k].cell; levels4[4 * k + 1] = (float)m->levels[k].nx; levels4[4 * k + 2] = (float)m->levels[k].ny; levels4[4 * k + 3] = (float)m->levels[k].nz; }
@@ -672,7 +674,7 @@ int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* sc, const double* pose, float thr
   hipLaunchKernelGGL(k_knn3<true>, dim3(knn_grid(sc->Q)), dim3(kB), 0, m->ctx->stream, sc->Q, sc->pts.p, tf, L, thr,
                      sc->idx.p, sc->d2.p, sc->valid.p, st.p);
   LVF_HIP(hipGetLastError());
-  LVF_HIP(hipMemcpyAsync(stats4, st.p, (size_t)sc->Q * sizeof(KnnStats), hipMemcpyDeviceToHost, m->ctx->stream));
+  LVF_HIP(hipMemcpyAsync(stats6, st.p, (size_t)sc->Q * sizeof(KnnStats), hipMemcpyDeviceToHost, m->ctx->stream));
   LVF_HIP(hipStreamSynchronize(m->ctx->stream));
   sc->searched = true;
   return LVF_OK;
