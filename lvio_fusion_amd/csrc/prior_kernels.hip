@@ -10,13 +10,11 @@
 // so the ambient 7-D Jacobian is taken exactly as the reference's autodiff does — with dual numbers (djet.hpp).
 // At most one block per keyframe: a latency-bound corner, one thread per block.
 #include "lvf_internal.hpp"
-#include "se3_jet.hpp"
+#include "prior_eval.hpp"
 
 namespace lvf {
 
-// One thread per prior block.  kf_a == -2: RError on pose kf_b with q0 = target[0..4); kf_a == -1: PoseError on pose kf_b with origin = target[0..7);
-// kf_a >= 0: PoseGraphError between Twc1 = pose kf_a and Twc2 = pose kf_b with rpyxyz_ = target[0..6).
-// Outputs: res [n][6]; ja, jb [n][6][7] row-major (ja is all-zero for PoseError blocks).
+// One thread per prior block (prior_eval.hpp).  Outputs: res [n][6]; ja, jb [n][6][7] row-major (ja is all-zero for PoseError blocks).
 template <bool WITH_J>
 __global__ __launch_bounds__(64) void k_pose_prior(int n, const int* __restrict__ kf_a, const int* __restrict__ kf_b,
                                                    const double* __restrict__ target, const double* __restrict__ weight,
@@ -24,59 +22,7 @@ __global__ __launch_bounds__(64) void k_pose_prior(int n, const int* __restrict_
                                                    double* __restrict__ res, double* __restrict__ ja, double* __restrict__ jb) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
-  typedef DJet<14> J;
-  const int a = kf_a[i], b = kf_b[i];
-  const double w = weight[i], v = vv[i];
-  const double* tg = target + 7 * i;
-  if (a == -2) {
-    // RError <4,7> (pose_error.hpp:88-110): r_k = w (q_k - q0_k) on the four quaternion components; rows 4,5 are padding
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      res[6 * i + k] = k < 4 ? w * (poses[7 * b + k] - tg[k]) : 0.0;
-      if (WITH_J) {
-#pragma unroll
-        for (int c = 0; c < 7; ++c) { ja[(size_t)42 * i + 7 * k + c] = 0.0; jb[(size_t)42 * i + 7 * k + c] = (k < 4 && c == k) ? w : 0.0; }
-      }
-    }
-    return;
-  }
-  J rp[6];
-  double scale[6], offs[6], sign;
-  if (a >= 0) {
-    J T1[7], T2[7], inv1[7], rel[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) { T1[k] = J(poses[7 * a + k], k); T2[k] = J(poses[7 * b + k], 7 + k); }
-    se3_inverse(T1, inv1);
-    se3_product(inv1, T2, rel);
-    se3_to_rpyxyz(rel, rp);
-    scale[0] = scale[1] = scale[2] = v * w; scale[3] = w; scale[4] = scale[5] = 10 * w;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) offs[k] = tg[k];
-    sign = -1.0;   // r = scale * (target - rpyxyz)
-  } else {
-    J O[7], P[7], invo[7], rel[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) { O[k] = J(tg[k]); P[k] = J(poses[7 * b + k], 7 + k); }
-    se3_inverse(O, invo);
-    se3_product(invo, P, rel);
-    se3_to_rpyxyz(rel, rp);
-    scale[0] = scale[1] = scale[2] = v * w; scale[3] = scale[4] = scale[5] = w;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) offs[k] = 0.0;
-    sign = 1.0;    // r = scale * rpyxyz
-  }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    res[6 * i + k] = (sign < 0.0) ? scale[k] * (offs[k] - rp[k].a) : scale[k] * rp[k].a;
-    if (WITH_J) {
-      const double s = sign * scale[k];
-#pragma unroll
-      for (int c = 0; c < 7; ++c) {
-        ja[(size_t)42 * i + 7 * k + c] = s * rp[k].v[c];
-        jb[(size_t)42 * i + 7 * k + c] = s * rp[k].v[7 + c];
-      }
-    }
-  }
+  pose_prior_eval<WITH_J>(kf_a[i], kf_b[i], target + 7 * i, weight[i], vv[i], poses, res + 6 * i, WITH_J ? ja + (size_t)42 * i : nullptr, WITH_J ? jb + (size_t)42 * i : nullptr);
 }
 
 int launch_pose_prior(lvf_batch* b, const lvf_state* st, bool want_j) {

@@ -18,6 +18,7 @@
 #include <unordered_map>
 
 #include "factor_eval.hpp"
+#include "prior_eval.hpp"
 #include "lvf_internal.hpp"
 #include "imu_eval.hpp"
 
@@ -85,6 +86,7 @@ struct lvf_problem {
   int band_rows = 64;           // landmark rows per slice of the band Schur complement (a batch uses more: fewer output atomics)
   lvf::DevBuf<int4> band_work; lvf::DevBuf<int> n_band_work_dev; lvf::HostPin<int> h_n_band_work;
   int n_band_work = 0, band_rows_built = 0;
+  bool band_pending = false; hipEvent_t ev_band = nullptr;      // the item count of the list is still on its way (awaited just before the Schur launch)
   int band_epoch = 0;                 // bumped whenever the landmark bands change (a batch keeps its own, wider-slice work lists: lvf_problem_batch)
   std::vector<lvf_problem_batch*> batches;      // the batches that borrow this problem (they are told when it is destroyed)
   lvf::HostPin<int> h_run_first;
@@ -1134,25 +1136,22 @@ __global__ __launch_bounds__(kT) void k_tf_reduce_bt(const TfReduceArgs* __restr
 // ------------------------------------------------------------------------------------------------ pose priors
 // consumes the materialised PoseGraphError / PoseError outputs of launch_pose_prior (res[n][6], ja/jb [n][6][7]); no loss
 // function (backend.cpp:171,176).  <= n_kf blocks: one thread per block, global atomics.
-__global__ __launch_bounds__(64) void k_lin_prior(int n, const double* __restrict__ res, const double* __restrict__ ja,
-                                                  const double* __restrict__ jb, const int* __restrict__ kf_a, const int* __restrict__ kf_b,
-                                                  const double* __restrict__ poses, const uint8_t* __restrict__ pose_const,
-                                                  double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  const int a = kf_a[i], b = kf_b[i];
+// (res, ja, jb: THIS block's 6 residuals and 6 x 7 ambient Jacobian rows — global arrays of launch_pose_prior, or the thread's own copies)
+__device__ __forceinline__ void lin_prior_block(const int i, const int a, const int b, const double* __restrict__ res, const double* __restrict__ ja,
+                                                const double* __restrict__ jb, const double* __restrict__ poses, const uint8_t* __restrict__ pose_const,
+                                                double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost) {
   double r[6], La[36], Lb[36];   // local Jacobians, row-major 6 x 6
   double c = 0.0;
-  for (int k = 0; k < 6; ++k) { r[k] = res[6 * i + k]; c += 0.5 * r[k] * r[k]; }
+  for (int k = 0; k < 6; ++k) { r[k] = res[k]; c += 0.5 * r[k] * r[k]; }
   for (int k = 0; k < 6; ++k) {
-    const double* row = jb + (size_t)42 * i + 7 * k;
+    const double* row = jb + 7 * k;
     const double sc = (pose_const[b] & 1) ? 0.0 : 1.0;
     double l3[3];
     quat_row_to_local(row, poses + 7 * b, l3);
     Lb[6 * k] = sc * l3[0]; Lb[6 * k + 1] = sc * l3[1]; Lb[6 * k + 2] = sc * l3[2];
     Lb[6 * k + 3] = sc * row[4]; Lb[6 * k + 4] = sc * row[5]; Lb[6 * k + 5] = sc * row[6];
     if (a >= 0) {
-      const double* rowa = ja + (size_t)42 * i + 7 * k;
+      const double* rowa = ja + 7 * k;
       const double sa = (pose_const[a] & 1) ? 0.0 : 1.0;
       quat_row_to_local(rowa, poses + 7 * a, l3);
       La[6 * k] = sa * l3[0]; La[6 * k + 1] = sa * l3[1]; La[6 * k + 2] = sa * l3[2];
@@ -1188,6 +1187,36 @@ __global__ __launch_bounds__(64) void k_lin_prior(int n, const double* __restric
       }
     }
   }
+}
+__global__ __launch_bounds__(64) void k_lin_prior(int n, const double* __restrict__ res, const double* __restrict__ ja,
+                                                  const double* __restrict__ jb, const int* __restrict__ kf_a, const int* __restrict__ kf_b,
+                                                  const double* __restrict__ poses, const uint8_t* __restrict__ pose_const,
+                                                  double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  lin_prior_block(i, kf_a[i], kf_b[i], res + 6 * i, ja + (size_t)42 * i, jb + (size_t)42 * i, poses, pose_const, B, ld, gc, cost);
+}
+// The same with the evaluation inside (prior_eval.hpp): the block's residuals and ambient Jacobians never leave the thread — one launch
+// instead of k_pose_prior + k_lin_prior on the LM loop's path (a window with weak frames pays it every iteration), nothing materialised.
+struct PriorArgs { int n; const int *kf_a, *kf_b; const double *target, *weight, *vv; };
+__global__ __launch_bounds__(64) void k_prior_lin(PriorArgs P, const double* __restrict__ poses, const uint8_t* __restrict__ pose_const,
+                                                  double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= P.n) return;
+  double res[6], ja[42], jb[42];
+  const int a = P.kf_a[i], b = P.kf_b[i];
+  pose_prior_eval<true>(a, b, P.target + 7 * i, P.weight[i], P.vv[i], poses, res, ja, jb);
+  lin_prior_block(i, a, b, res, ja, jb, poses, pose_const, B, ld, gc, cost);
+}
+// 1/2 |r|^2 of every prior block at `poses` (the candidate), added to the striped cost: k_pose_prior<false> + k_cost_sq in one launch
+__global__ __launch_bounds__(64) void k_prior_cost(PriorArgs P, const double* __restrict__ poses, double* __restrict__ cost) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= P.n) return;
+  double res[6];
+  pose_prior_eval<false>(P.kf_a[i], P.kf_b[i], P.target + 7 * i, P.weight[i], P.vv[i], poses, res, nullptr, nullptr);
+  double c = 0.0;
+  for (int k = 0; k < 6; ++k) c += 0.5 * res[k] * res[k];
+  atomicAdd(cost + (i & (kStripes - 1)), c);
 }
 __global__ __launch_bounds__(kT) void k_cost_sq(int n, const double* __restrict__ res, double* __restrict__ cost) {
   const int i = blockIdx.x * kT + threadIdx.x;
@@ -2898,6 +2927,7 @@ lvf_problem::~lvf_problem() {
   lvf::stage_clock_free(clk);
   if (rec && !lvf::HostPinPool::get().give(rec, lvf::Pool::bucket(sizeof(lvf::LmCtl)))) (void)hipHostFree(rec);
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+  if (ev_band) (void)hipEventDestroy(ev_band);
 }
 namespace lvf {
 
@@ -2981,7 +3011,9 @@ static void fill_back_args(lvf_problem* p, BackArgs& ba, size_t* lds_bytes) {
 static inline int band_rows_clamped(int rows) { return std::min(kBandRowsMax, std::max(16, rows)); }
 // work list of p's band Schur complement for `rows` landmark rows per slice, into buffers of the caller's (the problem's own list, or a
 // batch's: a batch sums over wider slices and must not touch its members)
-static int build_band_work(lvf_problem* p, int rows_in, DevBuf<int4>& work, int* n_work) {
+// `defer`: do not wait for the item count — an event is recorded behind its copy and await_band_work() collects it right before the first
+// launch that needs it (the Schur complement's), by which time the linearisation launches enqueued in between have long kept the device busy
+static int build_band_work(lvf_problem* p, int rows_in, DevBuf<int4>& work, int* n_work, bool defer = false) {
   hipStream_t q = p->ctx->stream;
   const int rows = band_rows_clamped(rows_in);
   const int n_slices = (p->n_lm + rows - 1) / rows;
@@ -2991,13 +3023,20 @@ static int build_band_work(lvf_problem* p, int rows_in, DevBuf<int4>& work, int*
   hipLaunchKernelGGL(k_band_work, dim3(n_slices), dim3(64), 0, q, rows, p->dp, p->lm_nactive.p, p->lm_order.p, p->lm_kmin.p, p->lm_kmax.p, work.p, p->n_band_work_dev.p);
   LVF_HIP(hipGetLastError());
   LVF_HIP(hipMemcpyAsync(p->h_n_band_work.p, p->n_band_work_dev.p, sizeof(int), hipMemcpyDeviceToHost, q));
+  if (defer) {
+    if (!p->ev_band) LVF_HIP(hipEventCreateWithFlags(&p->ev_band, hipEventDisableTiming));
+    LVF_HIP(hipEventRecord(p->ev_band, q));
+    p->band_pending = true;
+    *n_work = 0;
+    return LVF_OK;
+  }
   LVF_HIP(hipStreamSynchronize(q));
   *n_work = p->h_n_band_work[0];
   return LVF_OK;
 }
 static int ensure_band_work(lvf_problem* p) {
   if (!p->band_ready || p->n_lm == 0 || p->band_rows_built == p->band_rows) return LVF_OK;
-  LVF_TRY(build_band_work(p, p->band_rows, p->band_work, &p->n_band_work));
+  LVF_TRY(build_band_work(p, p->band_rows, p->band_work, &p->n_band_work, /*defer=*/true));
   p->band_rows_built = p->band_rows;
   return LVF_OK;
 }
@@ -3372,12 +3411,26 @@ static int enqueue_linearize(lvf_problem* p, double huber, bool gated, bool iter
                        p->st->poses.p, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
   }
   if (c.has_prior) {
-    LVF_TRY(launch_pose_prior(p->prior, p->st, true));
-    hipLaunchKernelGGL(k_lin_prior, dim3((p->prior->n + 63) / 64), dim3(64), 0, q, p->prior->n, p->prior->res.p, p->prior->jac[0].p,
-                       p->prior->jac[1].p, p->prior->idx_a.p, p->prior->idx_b.p, p->st->poses.p, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
+    const lvf_batch* pb = p->prior;
+    const PriorArgs P{pb->n, pb->idx_a.p, pb->idx_b.p, pb->table.p, pb->ob_a.p, pb->ob_b.p};
+    hipLaunchKernelGGL(k_prior_lin, dim3((pb->n + 63) / 64), dim3(64), 0, q, P, p->st->poses.p, p->pose_const.p, p->B.p, p->dpad, p->gc.p, cost);
   }
   LVF_HIP(hipGetLastError());
   p->linearized = true;
+  return LVF_OK;
+}
+
+// the deferred item count of the band work list (build_band_work) -> the Schur launch's arguments
+static int await_band_work(lvf_problem* p) {
+  if (!p->band_pending) return LVF_OK;
+  LVF_HIP(hipEventSynchronize(p->ev_band));
+  p->band_pending = false;
+  p->n_band_work = p->h_n_band_work[0];
+  if (p->chain && p->chain->merged_level0) {
+    SchurSp0Args& a = p->chain->ssp0;
+    a.n_work = p->n_band_work;
+    a.nblocks = a.n_work + a.sp.nblocks + a.sp_b.nblocks + a.sp_c.nblocks;
+  }
   return LVF_OK;
 }
 
@@ -3400,6 +3453,7 @@ static int enqueue_reduced_system(lvf_problem* p, const double* radius_dev, bool
   if (!early && c.early) p->accum_clean = false;       // the tap wrote S: the next iteration must clear it
   if (level0_done) *level0_done = false;
   if (p->n_lm) {
+    LVF_TRY(await_band_work(p));                       // (patches c.ssp0: `c` refers to the problem's chain)
     if (c.merged_level0) {
       SchurSp0Args sa = c.ssp0;
       if (!gated) sa.done = nullptr;
@@ -3493,9 +3547,9 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
   ca.huber = p->huber;
   if (c.has_imu && !c.imu_in_cost) LVF_TRY(launch_imu_args(q, c.imu_cost, false));
   if (c.has_prior) {
-    StateView view(p->ctx, p->n_kf, p->n_lm, p->poses2.p, p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->st->w_visual.p);
-    LVF_TRY(launch_pose_prior(p->prior, &view.v, false));
-    hipLaunchKernelGGL(k_cost_sq, dim3(grid(6 * p->prior->n)), dim3(kT), 0, q, 6 * p->prior->n, p->prior->res.p, p->scal.p + SC_COST_NEW);
+    const lvf_batch* pb = p->prior;
+    const PriorArgs P{pb->n, pb->idx_a.p, pb->idx_b.p, pb->table.p, pb->ob_a.p, pb->ob_b.p};
+    hipLaunchKernelGGL(k_prior_cost, dim3((pb->n + 63) / 64), dim3(64), 0, q, P, p->poses2.p, p->scal.p + SC_COST_NEW);
   }
   if (ca.nblocks > 0) {
     if (!end_zero) ca.zero_wgs = 0;
@@ -3505,9 +3559,9 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
     LVF_CHAIN_LAUNCH(p, ST_COST, k_cost_decide, dim3(ca.nblocks + ca.zero_wgs), dim3(kT), 0, q, ca, da, end_zero ? 1 : 0);
     p->accum_clean = ca.zero_wgs > 0;
     if (p->accum_clean) p->linearized = false;         // the normal equations of this iteration are gone: no reduced-system tap
-    stage_mark(p, ST_COST, 1 + (c.has_imu && !c.imu_in_cost ? 1 : 0) + (c.has_prior ? 2 : 0));
+    stage_mark(p, ST_COST, 1 + (c.has_imu && !c.imu_in_cost ? 1 : 0) + (c.has_prior ? 1 : 0));
   } else {
-    stage_mark(p, ST_COST, (c.has_imu ? 1 : 0) + (c.has_prior ? 2 : 0));
+    stage_mark(p, ST_COST, (c.has_imu ? 1 : 0) + (c.has_prior ? 1 : 0));
     LVF_CHAIN_LAUNCH(p, ST_DECIDE, k_lm_decide, dim3(1), dim3(kDT), 0, q, c.dec);
     stage_mark(p, ST_DECIDE, 1);
   }
@@ -4016,6 +4070,7 @@ static int batch_build_tables(lvf_problem_batch* b, double huber) {
   if (b->orphaned) { set_error("lvf_problem_batch: a member problem was destroyed before the batch"); return LVF_ERR_STATE; }
   for (lvf_problem* p : b->probs) {
     if (chain_stale(p)) LVF_TRY(build_chain(p));
+    LVF_TRY(await_band_work(p));             // (the member's own list: its count shares the pinned slot build_band_work reads below)
     all = all && p->chain->batchable;
   }
   b->tables = all;
@@ -4319,7 +4374,12 @@ static void summary_from_ctl(const lvf_problem* p, const LmCtl& c, lvf_solver_su
 
 // The device LM loop: iterations are enqueued back to back, each closed on device (k_lm_decide); the host only watches a mirror of the
 // control block to stop enqueueing once the loop has finished (an iteration enqueued after the end costs ~20 empty launches).
-int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary) {
+int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary) { return lvf_problem_solve_then(p, o, summary, nullptr, nullptr); }
+
+// lvf_problem_solve with a caller's launches enqueued BEHIND the last iteration and AHEAD of the wait that ends the solve (`tail(user)`,
+// called once per pass of the hand-over retry loop, i.e. once in practice): the persistent window packs and copies its state back in
+// the same stream wait instead of a second one (window.hip).
+int lvf_problem_solve_then(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary, int (*tail)(void*), void* user) {
   LVF_REQUIRE(p && o && summary, "lvf_problem_solve: null argument");
   LVF_TRY(lvf::enter(p->ctx));
   LmCtl c;
@@ -4330,6 +4390,7 @@ int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_su
     LVF_TRY(lvf_problem_cost(p, o, &cost));
     c.initial_cost = c.cost = cost;
     summary_from_ctl(p, c, summary);
+    if (tail) LVF_TRY(tail(user));
     return LVF_OK;
   }
   LVF_TRY(upload_ctl(p, c));
@@ -4343,6 +4404,7 @@ int lvf_problem_solve(lvf_problem* p, const lvf_solver_options* o, lvf_solver_su
       if (o->max_solver_time_in_seconds > 0.0 &&
           std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) { timed_out = true; break; }
     }
+    if (tail) LVF_TRY(tail(user));
     LVF_TRY(download_ctl(p, &c));
     if (!handover_pending(p, c)) break;
     LVF_TRY(rearm_after_handover(p, &c));     // a chained hand-over timed out: the loop goes on from the same point, un-chained

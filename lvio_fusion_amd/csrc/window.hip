@@ -940,27 +940,36 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
     LVF_TRY(problem_configure(w->prob));
   }
   const auto t_configured = now();
-  LVF_TRY(lvf_problem_solve(w->prob, o, summary));
-  const auto t_solved = now();
-  // ---- read-back: poses, velocities, biases by keyframe position; inverse depths in landmark-index order
-  {
-    if (n_lm) hipLaunchKernelGGL(k_da_scatter_invd, dim3((n_lm + 255) / 256), dim3(256), 0, s, n_lm, w->d_slot_lm.p, st->inv_depth.p, w->d_lm_invd_out.p, reinterpret_cast<LmDev*>(w->d_lmtab.p));
+  // ---- solve, with the read-back (poses, velocities, biases by keyframe position; inverse depths in landmark-index order) enqueued
+  // behind the last iteration and ahead of the wait that ends the solve: ONE stream wait per tick for both
+  size_t offs[5];
+  struct PackCtx { lvf_window* w; lvf_state* st; hipStream_t s; int n_kf, n_lm; size_t nl; size_t* offs; };
+  PackCtx pc{w, st, s, n_kf, n_lm, nl, offs};
+  auto pack_tail = [](void* u) -> int {
+    PackCtx& c = *static_cast<PackCtx*>(u);
+    lvf_window* w = c.w; lvf_state* st = c.st; hipStream_t s = c.s;
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    if (c.n_lm) hipLaunchKernelGGL(k_da_scatter_invd, dim3((c.n_lm + 255) / 256), dim3(256), 0, s, c.n_lm, w->d_slot_lm.p, st->inv_depth.p, w->d_lm_invd_out.p, reinterpret_cast<LmDev*>(w->d_lmtab.p));
     PackArgs pa{};
     size_t at = 0;
-    size_t offs[5];
     auto segp = [&](const void* src, size_t bytes, int slot) {
-      offs[slot] = at;
+      c.offs[slot] = at;
       if (bytes) { pa.src[pa.n_segs] = static_cast<const unsigned char*>(src); pa.off[pa.n_segs] = at; pa.words[pa.n_segs] = (unsigned)((bytes + 15) / 16); ++pa.n_segs; }
       at += up16(bytes);
     };
-    segp(st->poses.p, (size_t)7 * n_kf * 8, 0); segp(st->vel.p, (size_t)3 * n_kf * 8, 1); segp(st->ba.p, (size_t)3 * n_kf * 8, 2); segp(st->bg.p, (size_t)3 * n_kf * 8, 3);
-    segp(w->d_lm_invd_out.p, nl * 8, 4);
+    segp(st->poses.p, (size_t)7 * c.n_kf * 8, 0); segp(st->vel.p, (size_t)3 * c.n_kf * 8, 1); segp(st->ba.p, (size_t)3 * c.n_kf * 8, 2); segp(st->bg.p, (size_t)3 * c.n_kf * 8, 3);
+    segp(w->d_lm_invd_out.p, c.nl * 8, 4);
     LVF_TRY(w->d_stage.ensure(at + 16)); LVF_TRY(w->h_state.reserve(at / 8 + 2));
     pa.stage = w->d_stage.p;
     hipLaunchKernelGGL(k_window_pack, dim3(32), dim3(256), 0, s, pa);
     LVF_HIP(hipGetLastError());
     LVF_HIP(hipMemcpyAsync(w->h_state.p, w->d_stage.p, at, hipMemcpyDeviceToHost, s));
-    LVF_HIP(hipStreamSynchronize(s));
+    return LVF_OK;
+  };
+  LVF_TRY(lvf_problem_solve_then(w->prob, o, summary, pack_tail, &pc));      // (the wait for the control block also covers the copy above: same stream, enqueued first)
+  if (o->max_num_iterations <= 0) LVF_HIP(hipStreamSynchronize(s));            // (no iteration, no control block to wait for)
+  const auto t_solved = now();
+  {
     const double *poses = w->h_state.p + offs[0] / 8, *vel = w->h_state.p + offs[1] / 8, *ba = w->h_state.p + offs[2] / 8, *bg = w->h_state.p + offs[3] / 8,
                  *invd = w->h_state.p + offs[4] / 8;
     for (int k = 0; k < n_kf; ++k) {
