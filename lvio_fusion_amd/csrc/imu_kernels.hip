@@ -24,12 +24,11 @@ namespace lvf {
 // through exactly the same sequence of operations as in the scalar algorithm — the elimination step k updates all (i, j) > k
 // independently, the 15 columns of the inverse are independent, Cholesky column j is independent over rows i — so the result
 // is bit-identical and only the loop nests that were independent run side by side.
-__global__ __launch_bounds__(256) void k_imu_sqrt_info(int n, const double* __restrict__ pre, double* __restrict__ sqrt_info) {
+__device__ __forceinline__ void imu_sqrt_info_body(const int f, const double* __restrict__ pre, double* __restrict__ sqrt_info) {
 #pragma clang fp contract(off)
   __shared__ double LU[225], X[225], L[225];
   __shared__ int piv[15];
-  const int f = blockIdx.x, tid = threadIdx.x;
-  if (f >= n) return;
+  const int tid = threadIdx.x;
   const double* cov = pre + (size_t)f * kPre + OFF_COV;
   if (tid < 225) { LU[tid] = cov[tid]; L[tid] = 0.0; }
   __syncthreads();
@@ -102,6 +101,24 @@ __global__ __launch_bounds__(256) void k_imu_sqrt_info(int n, const double* __re
   }
   double* S = sqrt_info + (size_t)f * 225;
   if (tid < 225) { const int i = tid / 15, j = tid - 15 * i; S[15 * i + j] = L[15 * j + i]; }
+}
+__global__ __launch_bounds__(256) void k_imu_sqrt_info(int n, const double* __restrict__ pre, double* __restrict__ sqrt_info) {
+  if ((int)blockIdx.x >= n) return;
+  imu_sqrt_info_body(blockIdx.x, pre, sqrt_info);
+}
+// The persistent window's form: a factor whose pre-integration has not changed since the previous tick (src[f] = the slot its matrix had
+// then, in `prev`) is COPIED; only the others are factored — in steady state the one pair the newest keyframe brought (imu_error.hpp:32
+// re-derives the matrix on every Evaluate; round 3 re-factored all of a window's pairs every tick).
+__global__ __launch_bounds__(256) void k_imu_sqrt_info_cached(int n, const double* __restrict__ pre, double* __restrict__ sqrt_info, const int* __restrict__ src,
+                                                              const double* __restrict__ prev) {
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const int s = src[f];
+  if (s >= 0) {                                      // (workgroup-uniform)
+    if (threadIdx.x < 225) sqrt_info[(size_t)f * 225 + threadIdx.x] = prev[(size_t)s * 225 + threadIdx.x];
+    return;
+  }
+  imu_sqrt_info_body(f, pre, sqrt_info);
 }
 
 // --------------------------------------------------------------------------------- ImuError evaluate
@@ -300,6 +317,12 @@ __global__ __launch_bounds__(256) void k_preintegrate(const int* __restrict__ of
 int launch_imu_sqrt_info(lvf_batch* b) {
   if (b->n == 0) return LVF_OK;
   hipLaunchKernelGGL(k_imu_sqrt_info, dim3(b->n), dim3(256), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p);
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+int launch_imu_sqrt_info_cached(lvf_batch* b, const int* src_dev, const double* prev_dev) {
+  if (b->n == 0) return LVF_OK;
+  hipLaunchKernelGGL(k_imu_sqrt_info_cached, dim3(b->n), dim3(256), 0, b->ctx->stream, b->n, b->pre.p, b->sqrt_info.p, src_dev, prev_dev);
   LVF_HIP(hipGetLastError());
   return LVF_OK;
 }

@@ -143,6 +143,7 @@ struct DevBuf {  // owning device buffer
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
+  void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); std::swap(bytes, o.bytes); pool.swap(o.pool); }
   void release() {
     if (p) { if (!(pool && pool->put(p, bytes))) (void)hipFree(p); }
     p = nullptr; cap = 0; bytes = 0; pool.reset();
@@ -480,6 +481,7 @@ int launch_two_camera(lvf_batch* b, const lvf_state* st, bool want_j);
 int launch_lidar_normals(lvf_batch* b, const double* d_pb, const double* d_pc);
 int launch_lidar_plane(lvf_batch* b, const double* rpyxyz_host, bool want_j);
 int launch_imu_sqrt_info(lvf_batch* b);
+int launch_imu_sqrt_info_cached(lvf_batch* b, const int* src_dev, const double* prev_dev);   // src[f] >= 0: copy prev[src[f]] instead of factoring
 // arrays to clear before a linearisation (one launch, or extra workgroups of another launch)
 constexpr int kZeroListMax = 8;
 // tri[k] > 0: entry k is a square matrix of that leading dimension of which only the LOWER triangle (widened to the 64-column block of

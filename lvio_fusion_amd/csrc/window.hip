@@ -35,6 +35,7 @@ struct lvf_window {
     double w_visual = 1.0;
     bool good_imu = false, has_pre = false;
     lvf_preint pre;
+    unsigned pre_ver = 0;                                // identifies the CONTENT of `pre` (lvf_window::pre_counter at the time it last changed)
     std::vector<Obs> obs;                                // kept sorted by landmark id (BuildProblem's iteration order) lazily
     bool sorted = true;
     bool d_dirty = true;                                 // device-side assembly: the frame's segment of the feature arena is stale
@@ -91,6 +92,9 @@ struct lvf_window {
   lvf::DevBuf<int> d_wgcnt, d_wgbase, d_slot, d_slot_lm, d_counts;
   lvf::DevBuf<double> d_lm_invd_out;
   lvf::HostPin<int> h_counts;
+  // ImuError information matrices across ticks: slot f of `sq_prev` holds sqrt_info of the pre-integration version sq_ver[f] (what the
+  // previous tick left in the IMU batch); a factor whose version is found there is copied instead of factored again (k_imu_sqrt_info_cached)
+  lvf::DevBuf<double> sq_prev; std::vector<unsigned> sq_ver; lvf::DevBuf<int> d_sq_src; unsigned pre_counter = 0; bool sq_valid = false;
   hipEvent_t ev_counts = nullptr;                        // recorded behind the counters' copy: the host waits for it, not for the work queued after it
   std::vector<lvf::LmHot> hot;                           // per-tick compact copy of what the feature walk reads of a landmark
   lvf::HostPin<unsigned char> h_stage;                   // the tick's packed upload (records + plain segments)
@@ -550,8 +554,9 @@ int lvf_window_set_imu(lvf_window* w, int64_t kf_id, const double* vel3, const d
   LVF_REQUIRE(it != w->kf_index.end(), "lvf_window_set_imu: keyframe %lld is not in the window", (long long)kf_id);
   lvf_window::Kf& k = w->kfs[it->second];
   std::memcpy(k.vel, vel3, 24); std::memcpy(k.ba, ba3, 24); std::memcpy(k.bg, bg3, 24);
+  const bool had = k.has_pre;
   k.good_imu = true; k.has_pre = pre != nullptr;
-  if (pre) k.pre = *pre;
+  if (pre && !(had && std::memcmp(&k.pre, pre, sizeof(lvf_preint)) == 0)) { k.pre = *pre; k.pre_ver = ++w->pre_counter; }      // (an unchanged pre-integration keeps its cached matrix)
   return LVF_OK;
 }
 int lvf_window_add_landmark(lvf_window* w, int64_t lm_id, int64_t birth_kf_id, const double* left_ob2, const double* right_ob2, double inv_depth) {
@@ -805,7 +810,20 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
       lvf_preint* dst = reinterpret_cast<lvf_preint*>(seg(b->pre.p, 467 * ni * 8));
       for (size_t f = 0; f < ni; ++f) dst[f] = w->kfs[imu_j[f]].pre;
       std::memcpy(seg(b->idx_a.p, ni * 4), imu_i.data(), ni * 4); std::memcpy(seg(b->idx_b.p, ni * 4), imu_j.data(), ni * 4);
-    }
+      // where each factor's information matrix sits in what the previous tick left (-1: not there, factor it)
+      LVF_TRY(w->d_sq_src.ensure(ni + 4));
+      int32_t* src = reinterpret_cast<int32_t*>(seg(w->d_sq_src.p, ni * 4));
+      std::vector<unsigned> ver(ni);
+      if (!w->sq_valid) w->sq_ver.clear();            // (a tick that failed after the swap below, or the host-assembly path, left nothing to reuse)
+      for (size_t f = 0; f < ni; ++f) {
+        ver[f] = w->kfs[imu_j[f]].pre_ver;
+        src[f] = -1;
+        for (size_t g = 0; g < w->sq_ver.size(); ++g) if (w->sq_ver[g] == ver[f]) { src[f] = (int32_t)g; break; }
+      }
+      b->sqrt_info.swap(w->sq_prev);                 // last tick's matrices become the source; the batch gets the other buffer
+      w->sq_ver = std::move(ver);
+      w->sq_valid = false;                           // until this tick's matrices are on their way (below)
+    } else w->sq_ver.clear();
     b->host_kf1 = imu_i; b->host_kf2 = imu_j;
     LVF_TRY(b->sqrt_info.ensure((size_t)225 * ni)); LVF_TRY(b->res.ensure((size_t)15 * ni));
     for (int q = 0; q < 8; ++q) LVF_TRY(b->jac[q].ensure((size_t)15 * b->block_size[q] * ni));
@@ -865,7 +883,7 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
   LVF_HIP(hipMemcpyAsync(w->h_counts.p, w->d_counts.p, (4 + 2 * kDaMaxKf) * sizeof(int), hipMemcpyDeviceToHost, s));
   if (!w->ev_counts) LVF_HIP(hipEventCreateWithFlags(&w->ev_counts, hipEventDisableTiming));
   LVF_HIP(hipEventRecord(w->ev_counts, s));
-  if (w->n_imu) LVF_TRY(launch_imu_sqrt_info(w->imu));          // runs while the host reads the counters and configures the problem
+  if (w->n_imu) { LVF_TRY(launch_imu_sqrt_info_cached(w->imu, w->d_sq_src.p, w->sq_prev.p)); w->sq_valid = true; }      // runs while the host reads the counters and configures the problem
   LVF_HIP(hipEventSynchronize(w->ev_counts));
   const int* hc = w->h_counts.p;
   const size_t ntc = (size_t)hc[0], ntf = (size_t)hc[1], npo = (size_t)hc[2];
@@ -1193,6 +1211,7 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   hipLaunchKernelGGL(k_window_unpack, dim3(ua.g_tc + ua.g_tf + ua.g_po + ua.g_seg), dim3(256), 0, s, ua);
   LVF_HIP(hipGetLastError());
   if (w->n_imu) LVF_TRY(launch_imu_sqrt_info(w->imu));
+  w->sq_valid = false;                               // (this path factors every pair: nothing is tracked for the cached form)
   const auto t_uploaded = now();
   if (!w->prob) {
     LVF_TRY(lvf_problem_create(ctx, st, w->tc, w->tf, w->po, w->imu, &w->prob));

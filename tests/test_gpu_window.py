@@ -54,6 +54,15 @@ def test_ticks_match_from_scratch_assembly(oracle, with_imu, weak_thr, device_as
         for i in np.nonzero(tf["kf2_idx"] == t)[0]:
             l = int(tf["lm_idx"][i])
             win.add_observation(5000 + l, 100 + t, tf["ob"][i]); obs[t][l] = tf["ob"][i]
+        if with_imu and t == 7:
+            # an older pair is re-integrated (Repropagate after a bias change: preintegration.cpp:100-121): the window must factor ITS
+            # information matrix again and keep re-using the untouched pairs' (the per-keyframe cache of lvf_window_solve)
+            f5 = cfg["imu"][5]
+            noise2 = dict(syn.IMU_NOISE) if isinstance(syn.IMU_NOISE, dict) else tuple(2.0 * x for x in syn.IMU_NOISE)
+            if isinstance(noise2, dict):
+                noise2 = {k: 2.0 * v for k, v in noise2.items()}
+            pre[5] = oracle.imu_preintegrate(f5["samples"], f5["acc0"], f5["gyr0"], f5["ba"], f5["bg"], noise2)
+            win.set_imu(100 + 6, vel[6], ba[6], bg[6], pre[5])
         if t in (5, 8):      # an older frame loses a tracked feature (what the outlier gate does): its device-side feature segment is re-sent
             k_old = t - 2
             cand = [l for l in sorted(obs[k_old]) if birth[l] != k_old]

@@ -20,6 +20,7 @@ obs_by_kf = {}
 for i, k in enumerate(tf["kf2_idx"]):
     obs_by_kf.setdefault(int(k), []).append(i)
 ticks, worst, known_max, removed_total = [], 0.0, 0, 0
+rss60 = 0
 rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
 for t in range(N):
     win.add_keyframe(1000 + t, cfg["poses"][t], cfg["w_kf"][t])
