@@ -1444,7 +1444,11 @@ __global__ __launch_bounds__(256) void k_schur_lds(int n_lm, int dp, int ldE, in
 // those columns (plus the tile holding the g_rho column) and only forms the band's lower-triangular tiles.  At configs[3]
 // that is ~1/5 of the MFMAs and ~1/30 of the E bytes of the dense SYRK.  Correctness never depends on the ordering: the
 // band of each slice is computed from the actual kmin/kmax of its rows.
-constexpr int kBandRows = 64, kBandRowsMax = 256, kBandTilesPerGroup = 32;     // rows per slice: 64 for one window, up to 256 in a batch (fewer output atomics)
+constexpr int kBandTilesPerWave = 8;        // output tiles (16 x 16 accumulators) a wave of the band Schur complement carries.  (Measured round 4, same box: 16 — one
+// workgroup covers most slices' whole band, E read once instead of ~2x — needs > 256 VGPRs: 0.204 -> 0.254 ms / iteration spilling under the two-waves-per-SIMD
+// attribute below, 0.206 / 8 windows 0.375 -> 0.435 ms with one wave per SIMD; 4 — more, smaller workgroups — 8 windows 0.43 -> 0.59 ms.  The launch is bound by
+// how many workgroups overlap their fetch -> LDS -> matrix-core chains, not by E's bytes.)
+constexpr int kBandRows = 64, kBandRowsMax = 256, kBandTilesPerGroup = 4 * kBandTilesPerWave;     // rows per slice: 64 for one window, up to 256 in a batch (fewer output atomics)
 __global__ __launch_bounds__(kT) void k_lm_range(int n, const int* __restrict__ lm, const int* __restrict__ k1, const int* __restrict__ k2,
                                                  int* __restrict__ kmin, int* __restrict__ kmax) {
   const int i = blockIdx.x * kT + threadIdx.x;
@@ -1596,9 +1600,9 @@ __device__ __forceinline__ void schur_band_body(const int bx, const int by, int 
   int* rowid = reinterpret_cast<int*>(icd + kSchurRows);
   for (int r = tid; r < rows; r += 256) rowid[r] = (k_begin + r < k_end) ? order[k_begin + r] : -1;
   // this wave's tiles: t = tbase + w + 4 s; local tile columns (a = row tile, b = column tile), extra row tile = index nbt
-  int ta[kSchurTilesPerWave], tb[kSchurTilesPerWave], nt = 0;
+  int ta[kBandTilesPerWave], tb[kBandTilesPerWave], nt = 0;
 #pragma unroll
-  for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_) {
+  for (int s_ = 0; s_ < kBandTilesPerWave; ++s_) {
     const int t = tbase + w + 4 * s_;
     ta[s_] = 0; tb[s_] = 0;
     if (t < ntiles) {
@@ -1611,9 +1615,9 @@ __device__ __forceinline__ void schur_band_body(const int bx, const int by, int 
       nt = s_ + 1;
     }
   }
-  double4_t acc[kSchurTilesPerWave];
+  double4_t acc[kBandTilesPerWave];
 #pragma unroll
-  for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_) acc[s_] = double4_t{0.0, 0.0, 0.0, 0.0};
+  for (int s_ = 0; s_ < kBandTilesPerWave; ++s_) acc[s_] = double4_t{0.0, 0.0, 0.0, 0.0};
   // staging: thread (row fr = tid >> 4, column fc = tid & 15) carries column fc of every staged 16-column tile of its row:
   // no index arithmetic beyond one add per tile, 128-byte runs per 16 lanes
   constexpr int kPf = 20;                  // tiles prefetched in registers (ldl <= 320); wider bands finish through fetch_tail
@@ -1651,13 +1655,13 @@ __device__ __forceinline__ void schur_band_body(const int bx, const int by, int 
       const double* row = Es + (kk + lk) * ldl;
       const double wgt = icd[kk + lk];
 #pragma unroll
-      for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_)
+      for (int s_ = 0; s_ < kBandTilesPerWave; ++s_)
         if (s_ < nt) acc[s_] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[16 * ta[s_] + lc] * wgt, row[16 * tb[s_] + lc], acc[s_], 0, 0, 0);
     }
   }
   mark(2);
 #pragma unroll
-  for (int s_ = 0; s_ < kSchurTilesPerWave; ++s_) {
+  for (int s_ = 0; s_ < kBandTilesPerWave; ++s_) {
     if (s_ >= nt) continue;
     const int gti = ta[s_] < nbt ? t0 + ta[s_] : tl, gtj = t0 + tb[s_];
 #pragma unroll
