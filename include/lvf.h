@@ -199,6 +199,12 @@ int lvf_preintegrate(lvf_ctx* ctx, int n, const int32_t* offset, const double* s
  * Builds a uniform-grid index on device.  max_radius2 = the largest squared gate that will be queried
  * (e.g. resolution^2*100); it only sizes the cells, any thr may be queried later. */
 int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats, float max_radius2, lvf_map** out);
+/* n indices at once: out[i] is what lvf_map_create(ctx, map_xyz[i], M[i], stride_floats, max_radius2[i]) builds (the same pyramid, the same
+ * association results), with the host waits shared between the maps — the old-frame maps of a set of loop-closure candidates
+ * (relocator.cpp:196-206 -> Mapping::Relocate, mapping.cpp:251-262: one BuildOldMapFrame + kd-tree build per candidate and cloud).
+ * On error no map is returned (out[i] = NULL for all i). */
+int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const int* M, int stride_floats, const float* max_radius2,
+                         lvf_map** out);
 int lvf_map_destroy(lvf_map* m);
 int lvf_scan_create(lvf_ctx* ctx, const float* scan_xyz, int Q, int stride_floats, lvf_scan** out);
 int lvf_scan_destroy(lvf_scan* s);

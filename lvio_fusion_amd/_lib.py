@@ -160,6 +160,7 @@ _SIGS = {
     "lvf_batch_jacobian_dev": (_VP, [_VP, C.c_int]),
     "lvf_preintegrate": (C.c_int, [_VP, C.c_int, c_int_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "lvf_map_create": (C.c_int, [_VP, c_float_p, C.c_int, C.c_int, C.c_float, C.POINTER(_VP)]),
+    "lvf_map_create_batch": (C.c_int, [_VP, C.c_int, C.POINTER(c_float_p), c_int_p, C.c_int, c_float_p, C.POINTER(_VP)]),
     "lvf_map_destroy": (C.c_int, [_VP]),
     "lvf_scan_create": (C.c_int, [_VP, c_float_p, C.c_int, C.c_int, C.POINTER(_VP)]),
     "lvf_scan_destroy": (C.c_int, [_VP]),

@@ -377,6 +377,27 @@ class Map:
             self.ctx.L.lvf_map_destroy(self.h)
             self.h = C.c_void_p()
 
+    @classmethod
+    def create_batch(cls, ctx, clouds, max_radius2):
+        """lvf_map_create_batch: one Map per cloud (host arrays of one column count), the host waits shared between them"""
+        arrs = [_f(c) for c in clouds]
+        n = len(arrs)
+        thr = np.ascontiguousarray(np.broadcast_to(np.asarray(max_radius2, np.float32), (n,)))
+        if n == 0:
+            return []
+        stride = arrs[0].shape[1] if arrs[0].ndim == 2 else 3
+        assert all((a.shape[1] if a.ndim == 2 else 3) == stride for a in arrs), "clouds of one batch share their column count"
+        ptrs = (_lib.c_float_p * n)(*[a.ctypes.data_as(_lib.c_float_p) for a in arrs])
+        Ms = np.array([a.shape[0] for a in arrs], np.int32)
+        hs = (C.c_void_p * n)()
+        _chk(ctx.L.lvf_map_create_batch(ctx.h, n, ptrs, Ms.ctypes.data_as(_lib.c_int_p), stride, thr.ctypes.data_as(_lib.c_float_p), hs))
+        out = []
+        for i in range(n):
+            m = cls.__new__(cls)
+            m.ctx, m.M, m.h = ctx, int(Ms[i]), C.c_void_p(hs[i])
+            out.append(m)
+        return out
+
 
 class Scan:
     def __init__(self, ctx, xyz):

@@ -527,8 +527,10 @@ int launch_knn3_batch(hipStream_t q, const KnnJob* jobs, const SmDev* devs, int 
 
 extern "C" {
 
-// Builds one grid level (counting sort of the map by cell) into lv.  *occupancy = point-weighted mean cell population.
-static int build_level(lvf_map* m, lvf_map::Level& lv, float cell, const float lo[3], const float hi[3], double* occupancy) {
+// Enqueues the build of one grid level (counting sort of the map by cell) into lv; nothing is waited for.  *sumsq_dev receives
+// sum(count^2) over the cells (point-weighted mean cell population = that / M); `t` holds the temporaries and must outlive the launches.
+struct LevelTmp { DevBuf<int> cell_of, counts, bsums; DevBuf<unsigned long long> bsq; };
+static int enqueue_level(lvf_map* m, lvf_map::Level& lv, float cell, const float lo[3], const float hi[3], LevelTmp& t, unsigned long long* sumsq_dev) {
   hipStream_t s = m->ctx->stream;
   const int M = m->M;
   lv.nx = (int)(std::floor((hi[0] - lo[0]) / cell) + 1); lv.ny = (int)(std::floor((hi[1] - lo[1]) / cell) + 1);
@@ -537,23 +539,35 @@ static int build_level(lvf_map* m, lvf_map::Level& lv, float cell, const float l
   const int ncells = lv.nx * lv.ny * lv.nz;
   const GridP g{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz};
   const int gridM = (M + kB - 1) / kB, nb = (ncells + kScanChunk - 1) / kScanChunk;
-  DevBuf<int> cell_of, counts, bsums;
-  DevBuf<unsigned long long> bsq, sumsq;
+  DevBuf<int>&cell_of = t.cell_of, &counts = t.counts, &bsums = t.bsums;
+  DevBuf<unsigned long long>& bsq = t.bsq;
   LVF_TRY(cell_of.alloc(M)); LVF_TRY(counts.alloc(ncells)); LVF_TRY(bsums.alloc(nb)); LVF_TRY(bsq.alloc(nb));
-  LVF_TRY(sumsq.alloc(1)); LVF_TRY(lv.cell_start.alloc((size_t)ncells + 1)); LVF_TRY(lv.sorted.alloc(M));
+  LVF_TRY(lv.cell_start.alloc((size_t)ncells + 1)); LVF_TRY(lv.sorted.alloc(M));
   LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)ncells * sizeof(int), s));
   hipLaunchKernelGGL(k_cell_count, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, g, cell_of.p, counts.p);
   // exclusive scan of the counts -> cell_start[0..ncells]; the pass also yields sum(count^2) and leaves the counts zeroed, so the
   // same array is the scatter cursor
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p, bsq.p);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, lv.cell_start.p + ncells, bsq.p, sumsq.p);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, lv.cell_start.p + ncells, bsq.p, sumsq_dev);
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p, lv.cell_start.p, 1);
   hipLaunchKernelGGL(k_cell_scatter, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, cell_of.p, lv.cell_start.p, counts.p, lv.sorted.p);
   LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+// one level, waited for.  *occupancy = point-weighted mean cell population.
+static int build_level(lvf_map* m, lvf_map::Level& lv, float cell, const float lo[3], const float hi[3], double* occupancy) {
+  LevelTmp t;
+  DevBuf<unsigned long long> sumsq;
+  LVF_TRY(sumsq.alloc(1));
+  LVF_TRY(enqueue_level(m, lv, cell, lo, hi, t, sumsq.p));
   unsigned long long ss = 0;
   LVF_TRY(read_back(m->ctx, &ss, sumsq.p, sizeof(ss)));   // (waits for the stream: temporaries are freed on return)
-  *occupancy = (double)ss / (double)M;
+  *occupancy = (double)ss / (double)m->M;
   return LVF_OK;
+}
+__global__ void k_bounds_init(int n, unsigned* __restrict__ bounds) {      // [n][min xyz | max xyz] as ordered uints
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6 * n) bounds[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
 }
 
 // src_is_device: map_xyz already lives in HBM (a lvf_cloud): no upload
@@ -621,6 +635,90 @@ static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_devic
 int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats, float max_radius2, lvf_map** out) {
   return map_create_impl(ctx, map_xyz, false, M, stride_floats, max_radius2, out);
 }
+
+// n map indices at once (the old-frame maps of a set of loop-closure candidates: relocator.cpp:196-206 -> mapping.cpp:251-262, one
+// BuildOldMapFrame + kd-tree build per candidate and cloud).  The same pyramids as n calls of lvf_map_create, but the host waits that
+// call makes per map — once for the bounding box, once per grid level for its occupancy — are shared: one wait for all boxes, one per
+// ROUND of levels (every map that still grows builds its next level in the round).  16 maps: 64 stream waits become 4.
+int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const int* M, int stride_floats, const float* max_radius2, lvf_map** out) {
+  LVF_REQUIRE(ctx && out && (n == 0 || (map_xyz && M && max_radius2)) && n >= 0 && stride_floats >= 3, "lvf_map_create_batch: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    out[i] = nullptr;
+    LVF_REQUIRE(M[i] >= 0 && (M[i] == 0 || map_xyz[i]), "lvf_map_create_batch: bad cloud %d (M=%d)", i, M[i]);
+    LVF_REQUIRE(max_radius2[i] > 0.0f && std::isfinite(max_radius2[i]), "lvf_map_create_batch: max_radius2[%d] must be finite > 0", i);
+  }
+  if (n == 0) return LVF_OK;
+  LVF_TRY(lvf::enter(ctx));
+  hipStream_t s = ctx->stream;
+  struct Item { std::unique_ptr<lvf_map> m; float lo[3], hi[3], cell; lvf_map::Level built[LVF_MAX_GRID_LEVELS]; int nb = 0; bool growing = false; };
+  std::vector<Item> it((size_t)n);
+  std::vector<DevBuf<float>> src((size_t)n);
+  std::vector<HostPin<float>> stage((size_t)n);
+  StreamWaitGuard stage_guard(s);          // every path out waits for the copies before the pinned blocks return to the pool
+  DevBuf<unsigned> bounds; DevBuf<unsigned long long> sumsq;
+  LVF_TRY(bounds.alloc((size_t)6 * n)); LVF_TRY(sumsq.alloc((size_t)n));
+  hipLaunchKernelGGL(k_bounds_init, dim3((6 * n + 255) / 256), dim3(256), 0, s, n, bounds.p);
+  for (int i = 0; i < n; ++i) {
+    it[i].m.reset(new lvf_map());
+    lvf_map* m = it[i].m.get();
+    m->ctx = ctx; m->M = M[i];
+    if (M[i] == 0) {                       // an empty map: one 1-cell level with no points
+      auto& lv = m->levels[0];
+      LVF_TRY(lv.cell_start.alloc(2));
+      LVF_HIP(hipMemsetAsync(lv.cell_start.p, 0, 2 * sizeof(int), s));
+      lv.cell = std::sqrt(max_radius2[i]); lv.inv_cell = 1.0f / lv.cell;
+      m->n_levels = 1;
+      continue;
+    }
+    LVF_TRY(src[i].upload_staged(map_xyz[i], (size_t)M[i] * stride_floats, s, stage[i]));
+    LVF_TRY(m->raw.alloc(M[i]));
+    hipLaunchKernelGGL(k_pack_bounds, dim3(std::min(kBoundsMaxBlocks, (M[i] + kB - 1) / kB)), dim3(kB), 0, s, M[i], src[i].p, stride_floats, m->raw.p, bounds.p + 6 * i);
+  }
+  LVF_HIP(hipGetLastError());
+  std::vector<unsigned> hb((size_t)6 * n);
+  LVF_TRY(read_back(ctx, hb.data(), bounds.p, hb.size() * sizeof(unsigned)));          // ONE wait for every bounding box
+  static const double occ_env = [] { const char* e = std::getenv("LVF_KNN_OCC"); return e ? std::atof(e) : 0.0; }();
+  const double kMaxCells = 32.0 * 1024 * 1024, kTargetOcc = occ_env > 0.0 ? occ_env : 128.0;
+  auto ncells_for = [](const Item& a, float c) {
+    return (std::floor((a.hi[0] - a.lo[0]) / c) + 1) * (std::floor((a.hi[1] - a.lo[1]) / c) + 1) * (std::floor((a.hi[2] - a.lo[2]) / c) + 1);
+  };
+  int growing = 0;
+  for (int i = 0; i < n; ++i) {
+    if (M[i] == 0) continue;
+    Item& a = it[i];
+    for (int k = 0; k < 3; ++k) { a.lo[k] = ord2f(hb[6 * i + k]); a.hi[k] = ord2f(hb[6 * i + 3 + k]); }
+    for (int k = 0; k < 3; ++k)
+      if (!std::isfinite(a.lo[k]) || !std::isfinite(a.hi[k])) { set_error("lvf_map_create_batch: non-finite coordinates in map %d", i); return LVF_ERR_INVALID; }
+    a.cell = std::sqrt(max_radius2[i]) * 0.5f;                       // the pyramid rule of map_create_impl
+    while (ncells_for(a, a.cell) > kMaxCells) a.cell *= 1.25f;
+    a.growing = true; ++growing;
+  }
+  std::vector<unsigned long long> hs((size_t)n);
+  while (growing > 0) {
+    std::vector<LevelTmp> tmp((size_t)n);                            // (live until the round's wait)
+    for (int i = 0; i < n; ++i)
+      if (it[i].growing) LVF_TRY(enqueue_level(it[i].m.get(), it[i].built[it[i].nb], it[i].cell, it[i].lo, it[i].hi, tmp[i], sumsq.p + i));
+    LVF_TRY(read_back(ctx, hs.data(), sumsq.p, hs.size() * sizeof(unsigned long long)));      // ONE wait per round of levels
+    for (int i = 0; i < n; ++i) {
+      Item& a = it[i];
+      if (!a.growing) continue;
+      const double occ = (double)hs[i] / (double)M[i];
+      ++a.nb;
+      if (occ <= kTargetOcc || a.nb == LVF_MAX_GRID_LEVELS || ncells_for(a, a.cell * 0.5f) > kMaxCells) { a.growing = false; --growing; }
+      else a.cell *= 0.5f;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    Item& a = it[i];
+    if (M[i] > 0) {
+      a.m->n_levels = a.nb;
+      for (int k = 0; k < a.nb; ++k) a.m->levels[k] = std::move(a.built[a.nb - 1 - k]);   // finest first
+    }
+  }
+  LVF_HIP(hipStreamSynchronize(s));        // (the empty maps' memsets; the sources of the copies)
+  for (int i = 0; i < n; ++i) out[i] = it[i].m.release();
+  return LVF_OK;
+}
 int lvf_map_create_from_cloud(const lvf_cloud* c, float max_radius2, lvf_map** out) {
   LVF_REQUIRE(c, "lvf_map_create_from_cloud: null cloud");
   return map_create_impl(c->ctx, reinterpret_cast<const float*>(c->pts.p), true, c->n, 4, max_radius2, out);
@@ -644,9 +742,14 @@ static int scan_create_impl(lvf_ctx* ctx, const float* scan_xyz, bool src_is_dev
       delete sc; return rc;
     }
     hipLaunchKernelGGL(k_pack, dim3((Q + kB - 1) / kB), dim3(kB), 0, ctx->stream, Q, src_is_device ? scan_xyz : src.p, stride_floats, sc->pts.p);
-    LVF_HIP(hipGetLastError());
-    LVF_HIP(hipStreamSynchronize(ctx->stream));
-  }
+    if (hipGetLastError() != hipSuccess) { delete sc; set_error("lvf_scan_create: launch failed"); return LVF_ERR_HIP; }
+    if (!src_is_device) {
+      // no wait: everything that touches the scan later runs on this stream, behind the copy.  The staging moves into the scan (a
+      // creation per loop-closure candidate and cloud used to cost one stream wait each: 16 per configs[4] batch)
+      sc->create_src.swap(src); sc->create_stage.swap(stage); sc->create_in_flight = true;
+      stage_guard.dismiss();
+    }
+  } else stage_guard.dismiss();
   *out = sc;
   return LVF_OK;
 }
@@ -658,7 +761,11 @@ int lvf_scan_create_from_cloud(const lvf_cloud* c, lvf_scan** out) {
   return scan_create_impl(c->ctx, reinterpret_cast<const float*>(c->pts.p), true, c->n, 4, out);
 }
 
-int lvf_scan_destroy(lvf_scan* s) { delete s; return LVF_OK; }
+int lvf_scan_destroy(lvf_scan* s) {
+  if (s && s->create_in_flight && lvf::enter(s->ctx) == LVF_OK) (void)hipStreamSynchronize(s->ctx->stream);     // (the pinned block goes back to a pool other threads draw from)
+  delete s;
+  return LVF_OK;
+}
 
 // diagnostic (not part of the reference surface): per-query search statistics {candidates, range lookups, last level,
 // shells}, and the grid pyramid geometry {cell, nx, ny, nz} per level.

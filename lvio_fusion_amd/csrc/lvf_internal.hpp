@@ -112,6 +112,7 @@ struct HostPin {
   HostPin(const HostPin&) = delete;
   HostPin& operator=(const HostPin&) = delete;
   ~HostPin() { drop(); }
+  void swap(HostPin& o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(bytes, o.bytes); }
   void drop() {
     if (p && !HostPinPool::get().give(p, bytes)) (void)hipHostFree(p);
     p = nullptr; cap = 0; bytes = 0;
@@ -267,10 +268,12 @@ namespace lvf {
 // pool (where another thread could take and overwrite it) while the DMA may still be reading it.
 struct StreamWaitGuard {
   hipStream_t s;
+  bool armed = true;
   explicit StreamWaitGuard(hipStream_t q) : s(q) {}
   StreamWaitGuard(const StreamWaitGuard&) = delete;
   StreamWaitGuard& operator=(const StreamWaitGuard&) = delete;
-  ~StreamWaitGuard() { (void)hipStreamSynchronize(s); }
+  void dismiss() { armed = false; }        // the staging block has found an owner that outlives the copy
+  ~StreamWaitGuard() { if (armed) (void)hipStreamSynchronize(s); }
 };
 }  // namespace lvf
 
@@ -352,6 +355,8 @@ struct lvf_scan {
   lvf::DevBuf<double> corr;          // ICP correspondences: p | pa | n, each SoA [3][Q]
   lvf::DevBuf<char> icp_dev;         // device-resident LM state of lvf_icp_solve
   lvf::HostPin<char> icp_host;       // its pinned host mirror (initial state up, result down: real asynchronous copies)
+  // the upload of lvf_scan_create is not waited for: its staging (pinned block + raw device copy) belongs to the scan until the scan goes
+  lvf::DevBuf<float> create_src; lvf::HostPin<float> create_stage; bool create_in_flight = false;
 };
 
 struct lvf_cloud {

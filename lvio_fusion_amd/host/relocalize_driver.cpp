@@ -98,16 +98,23 @@ static bool evaluate_batch(lvf_ctx* ctx, const std::vector<Candidate>& cands, co
   std::vector<lvf_scan_match_job> jobs(ids.size());
   bool ok = true;
   auto chk = [&](int rc) { if (rc != LVF_OK && ok) { ok = false; *err = lvf_last_error(); } return rc == LVF_OK; };
-  for (size_t k = 0; k < ids.size() && ok; ++k) {
+  // every candidate's map indices in ONE call: the host waits of an index build are shared between them (lvf_map_create_batch)
+  std::vector<const float*> src; std::vector<int> M; std::vector<float> thr; std::vector<lvf_map**> dst;
+  for (size_t k = 0; k < ids.size(); ++k) {
     const Candidate& c = cands[ids[k]];
     lvf_scan_match_job& j = jobs[k];
     std::memset(&j, 0, sizeof(j));
-    if (!c.map_ground.empty())
-      chk(lvf_map_create(ctx, c.map_ground.data(), (int)c.map_ground.size() / 4, 4, o.thr_ground, &j.map_ground)) &&
-          chk(lvf_scan_create(ctx, c.query_ground.data(), (int)c.query_ground.size() / 4, 4, &j.scan_ground));
-    if (ok && !c.map_surf.empty())
-      chk(lvf_map_create(ctx, c.map_surf.data(), (int)c.map_surf.size() / 4, 4, o.thr_surf, &j.map_surf)) &&
-          chk(lvf_scan_create(ctx, c.query_surf.data(), (int)c.query_surf.size() / 4, 4, &j.scan_surf));
+    if (!c.map_ground.empty()) { src.push_back(c.map_ground.data()); M.push_back((int)c.map_ground.size() / 4); thr.push_back(o.thr_ground); dst.push_back(&j.map_ground); }
+    if (!c.map_surf.empty()) { src.push_back(c.map_surf.data()); M.push_back((int)c.map_surf.size() / 4); thr.push_back(o.thr_surf); dst.push_back(&j.map_surf); }
+  }
+  std::vector<lvf_map*> made(src.size(), nullptr);
+  if (!src.empty() && chk(lvf_map_create_batch(ctx, (int)src.size(), src.data(), M.data(), 4, thr.data(), made.data())))
+    for (size_t i = 0; i < made.size(); ++i) *dst[i] = made[i];
+  for (size_t k = 0; k < ids.size() && ok; ++k) {
+    const Candidate& c = cands[ids[k]];
+    lvf_scan_match_job& j = jobs[k];
+    if (j.map_ground) chk(lvf_scan_create(ctx, c.query_ground.data(), (int)c.query_ground.size() / 4, 4, &j.scan_ground));
+    if (ok && j.map_surf) chk(lvf_scan_create(ctx, c.query_surf.data(), (int)c.query_surf.size() / 4, 4, &j.scan_surf));
     std::memcpy(j.map_pose, c.map_pose, 56); std::memcpy(j.frame_pose, c.init_pose, 56); std::memcpy(j.last_pose, c.last_pose, 56);
     j.has_last_pose = 1;
   }

@@ -99,13 +99,24 @@ def evaluate_candidates_batched(api, ctx, cands, resolution=0.2):
     opt = api.scan_match_options(resolution, outer_iterations=4, prior_weight=0.0)
     handles, jobs = [], []
     try:
-        for cand in cands:
-            mg, ms, qg, qs = split_candidate(cand)
-            mpg = api.Map(ctx, mg, opt.thr_ground) if len(mg) else None
+        # every candidate's map indices in ONE call (lvf_map_create_batch: the host waits of an index build are shared between them)
+        parts = [split_candidate(cand) for cand in cands]
+        clouds, thrs, where = [], [], []
+        for k, (mg, ms, qg, qs) in enumerate(parts):
+            if len(mg):
+                clouds.append(mg); thrs.append(opt.thr_ground); where.append((k, "map_ground"))
+            if len(ms):
+                clouds.append(ms); thrs.append(opt.thr_surf); where.append((k, "map_surf"))
+        maps = api.Map.create_batch(ctx, clouds, thrs) if clouds else []
+        handles += maps
+        made = [dict(map_ground=None, map_surf=None) for _ in cands]
+        for m, (k, key) in zip(maps, where):
+            made[k][key] = m
+        for cand, (mg, ms, qg, qs), mk in zip(cands, parts, made):
+            mpg, mps = mk["map_ground"], mk["map_surf"]
             scg = api.Scan(ctx, qg) if mpg is not None else None
-            mps = api.Map(ctx, ms, opt.thr_surf) if len(ms) else None
             scs = api.Scan(ctx, qs) if mps is not None else None
-            handles += [x for x in (mpg, scg, mps, scs) if x is not None]
+            handles += [x for x in (scg, scs) if x is not None]
             jobs.append(dict(map_ground=mpg, scan_ground=scg, map_surf=mps, scan_surf=scs, map_pose=cand["map_pose"], frame_pose=cand["init_pose"],
                              last_pose=cand["last_pose"]))
         res, _ = api.scan_match_batch(ctx, jobs, opt, RELOCATE_BASE_SCORE)

@@ -73,3 +73,42 @@ def test_knn_edge_cases(ctx, oracle):
     q3 = np.array([[1, 2, 3, 0], [100, 100, 100, 0], [-50, 2, 3, 0], [1.5, 2, 3, 0]], np.float32)
     _check(api, ctx, oracle, m3, q3, pose, 4.0)
     _check(api, ctx, oracle, m3, q3, pose, np.float32(np.inf), exact_all=True)
+
+
+@pytest.mark.gpu
+def test_maps_created_in_one_batch_equal_maps_created_one_by_one():
+    """lvf_map_create_batch shares the host waits of the index builds between the maps (the old-frame maps of a set of loop-closure
+    candidates: relocator.cpp:196-206 -> mapping.cpp:251-262); every map must be the one lvf_map_create builds: same pyramid, same
+    association (indices and d2 bit for bit).  Mixed sizes and gates, an empty cloud, a one-point cloud."""
+    import ctypes as C
+    from lvio_fusion_amd import api, _lib
+    rng = np.random.default_rng(77)
+    ctx = api.Context(0)
+    clouds = [rng.uniform(-20, 20, (5000, 3)).astype(np.float32) * np.array([1, 1, 0.05], np.float32),      # a flat sheet (dense cells)
+              rng.normal(0, 6, (1200, 4)).astype(np.float32)[:, :3].copy(),
+              np.zeros((0, 3), np.float32),
+              np.array([[1.0, 2.0, 3.0]], np.float32),
+              rng.uniform(-3, 3, (30000, 3)).astype(np.float32)]
+    thr = [4.0, 1.0, 1.0, 4.0, 0.25]
+    batch = api.Map.create_batch(ctx, clouds, thr)
+    assert len(batch) == len(clouds) and api.Map.create_batch(ctx, [], 1.0) == []
+    pose = np.array([0.02, -0.01, 0.03, 1.0, 0.1, -0.2, 0.05]); pose[:4] /= np.linalg.norm(pose[:4])
+    q = rng.uniform(-8, 8, (4000, 3)).astype(np.float32)
+
+    def pyramid(m):
+        stats = np.zeros((len(q), 6), np.int32); lv = np.zeros((8, 4), np.float32); nl = C.c_int()
+        sc = api.Scan(ctx, q)
+        api._chk(ctx.L.lvf_knn3_debug_stats(m.h, sc.h, pose.ctypes.data_as(_lib.c_double_p), 1.0, stats.ctypes.data_as(_lib.c_int_p), lv.ctypes.data_as(_lib.c_float_p), C.byref(nl)))
+        sc.close()
+        return lv[:nl.value].copy()
+
+    for cloud, t, mb in zip(clouds, thr, batch):
+        ms = api.Map(ctx, cloud, t)
+        assert np.array_equal(pyramid(ms), pyramid(mb))
+        sa, sb = api.Scan(ctx, q), api.Scan(ctx, q)
+        api.knn3(ms, sa, pose, t); api.knn3(mb, sb, pose, t)
+        ia, da, va = sa.download(); ib, db, vb = sb.download()
+        assert np.array_equal(ia, ib) and np.array_equal(da, db) and np.array_equal(va, vb)
+        for h in (sa, sb, ms, mb):
+            h.close()
+    ctx.close()
