@@ -471,7 +471,7 @@ __device__ __forceinline__ bool cell_runs(int c, int& start, int& len) {
 int problem_configure(lvf_problem* p);
 }  // namespace lvf
 // lvf_problem_solve with a caller's launches enqueued behind the last iteration and ahead of the wait that ends the solve (solver_kernels.hip)
-extern "C" int lvf_problem_solve_then(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary, int (*tail)(void*), void* user);
+extern "C" __attribute__((visibility("hidden"))) int lvf_problem_solve_then(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary, int (*tail)(void*), void* user);
 namespace lvf {
 // stable LSD radix sort of (key, value) pairs by the low `key_bits` bits of the key (sort_util.hip)
 int device_sort_pairs_u32(lvf_ctx* ctx, const unsigned* keys_in, unsigned* keys_out, const int* vals_in, int* vals_out, int n, int key_bits);
