@@ -64,15 +64,16 @@ __device__ void icp_step(const IcpArgs& args, IcpDev* dev) {
   }
   dev->model = ok ? 0.5 * (dx[0] * (D0 * dx[0] - g[0]) + dx[1] * (D1 * dx[1] - g[1]) + dx[2] * (D2 * dx[2] - g[2])) : -1.0;
   for (int q = 0; q < 3; ++q) dev->xc[q] = dev->x[q] + dx[q];
-  dev->cost_cand = 0.0;
   const double dn = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
   const double xn = sqrt(dev->x[0] * dev->x[0] + dev->x[1] * dev->x[1] + dev->x[2] * dev->x[2]);
   if (ok && dev->model > 0.0 && dn <= args.parameter_tolerance * (xn + args.parameter_tolerance)) dev->done = 1;      // (a VALID step this small: the candidate is not taken)
 }
 
-__device__ void icp_decide(const IcpArgs& args, IcpDev* dev) {
+// The candidate pass has just summed H, g and the cost AT xc into accC (k_icp_eval<true>): judge the step; an accepted candidate's sums
+// become the current linearisation (no pass at the new x), a rejected or invalid step keeps the old one (no pass at the old x either)
+__device__ void icp_decide(const IcpArgs& args, IcpDev* dev, const bool have_j = true) {
   if (dev->done) return;
-  double cand = fresh(&dev->cost_cand);
+  double cand = fresh(&dev->accC[9]);
   if (args.prior_w > 0.0) {
     const double w2 = args.prior_w * args.prior_w;
     for (int q = 0; q < 3; ++q) { const double dxp = dev->xc[q] - dev->x0[q]; cand += 0.5 * w2 * dxp * dxp; }
@@ -91,6 +92,7 @@ __device__ void icp_decide(const IcpArgs& args, IcpDev* dev) {
       const double rho = (dev->cost_cur - cand) / dev->model;
       if (rho > args.min_relative_decrease) {
         for (int q = 0; q < 3; ++q) dev->x[q] = dev->xc[q];
+        if (have_j) for (int q = 0; q < 10; ++q) dev->acc[q] = fresh(&dev->accC[q]);
         dev->cost_cur = cand;
         dev->successes += 1;
         const double t = 2.0 * rho - 1.0;
@@ -100,14 +102,19 @@ __device__ void icp_decide(const IcpArgs& args, IcpDev* dev) {
     }
   }
   if (dev->iters >= args.max_iters || dev->radius < 1e-32) dev->done = 1;
-  for (int q = 0; q < 11; ++q) dev->acc[q] = 0.0;
+  for (int q = 0; q < 11; ++q) dev->accC[q] = 0.0;
 }
 
 // stand-alone forms (problems with no correspondences never launch k_icp_eval)
 __global__ void k_icp_step(const IcpArgs args, IcpDev* dev) { icp_step(args, dev); }
-__global__ void k_icp_decide(const IcpArgs args, IcpDev* dev) { icp_decide(args, dev); }
+__global__ void k_icp_decide_step(const IcpArgs args, IcpDev* dev) { icp_decide(args, dev); icp_step(args, dev); }
 
-template <bool WITH_J>
+// CAND = false: the pass at x that opens a solve (sums into acc, then the first damped step); CAND = true: the pass at the candidate xc of
+// every LM iteration (sums into accC, then the decision and — unless the solve ended — the next step).  ONE launch per LM iteration:
+// ceres::Solve evaluates the cost at the candidate and, once the step is accepted, the Jacobian at the same point; here both come from
+// the same pass (round 3: a Jacobian pass at x and a cost-only pass at xc per iteration, eight launches for four iterations instead of five).
+// WITH_J = false (with CAND): the pass of the LAST iteration the options allow — no step can follow it, so the cost alone is summed.
+template <bool CAND, bool WITH_J = true>
 __device__ __forceinline__ void icp_eval_body(const int bx, const int nbx, int Q, const double* __restrict__ P, const double* __restrict__ PA,
                                               const double* __restrict__ N, const uint8_t* __restrict__ valid,
                                               const IcpArgs& args, IcpDev* __restrict__ dev) {
@@ -119,7 +126,7 @@ __device__ __forceinline__ void icp_eval_body(const int bx, const int nbx, int Q
     for (int k = 0; k < 6; ++k) a.rpyxyz[k] = dev->rpyxyz[k];
     int i0, i1, i2;
     param_slots(args.mode, i0, i1, i2);
-    const double* x = WITH_J ? dev->x : dev->xc;
+    const double* x = CAND ? dev->xc : dev->x;
     a.rpyxyz[i0] = x[0]; a.rpyxyz[i1] = x[1]; a.rpyxyz[i2] = x[2];
     a.weight = args.weight; a.mode = args.mode;
     derive_lidar(a, U);
@@ -158,10 +165,10 @@ __device__ __forceinline__ void icp_eval_body(const int bx, const int nbx, int Q
     double s = 0.0;
 #pragma unroll
     for (int w2 = 0; w2 < kTI / 64; ++w2) s += s_part[w2][threadIdx.x];
-    if (s != 0.0) atomicAdd(WITH_J ? &dev->acc[threadIdx.x] : &dev->cost_cand, s);
+    if (s != 0.0) atomicAdd(CAND ? &dev->accC[threadIdx.x] : &dev->acc[threadIdx.x], s);
   }
-  // the LAST workgroup to get here runs the scalar tail of the phase (3x3 damped solve after the J pass, accept/reject after the
-  // cost pass): two launches per LM iteration instead of four
+  // the LAST workgroup to get here runs the scalar tail of the pass (accept / reject of the candidate, then the 3x3 damped solve for the
+  // next one): one launch per LM iteration
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
@@ -169,27 +176,28 @@ __device__ __forceinline__ void icp_eval_body(const int bx, const int nbx, int Q
     if (t == (unsigned)nbx - 1u) {
       __threadfence();
       dev->ticket = 0;
-      if (WITH_J) icp_step(args, dev); else icp_decide(args, dev);
+      if (CAND) icp_decide(args, dev, WITH_J);
+      if (WITH_J) icp_step(args, dev);
     }
   }
 }
-template <bool WITH_J>
+template <bool CAND, bool WITH_J>
 __global__ __launch_bounds__(kTI) void k_icp_eval(int Q, const double* __restrict__ P, const double* __restrict__ PA,
                                                   const double* __restrict__ N, const uint8_t* __restrict__ valid,
                                                   const IcpArgs args, IcpDev* __restrict__ dev) {
-  icp_eval_body<WITH_J>(blockIdx.x, gridDim.x, Q, P, PA, N, valid, args, dev);
+  icp_eval_body<CAND, WITH_J>(blockIdx.x, gridDim.x, Q, P, PA, N, valid, args, dev);
 }
 static __host__ __device__ inline int icp_blocks(int Q) { const int b = ((Q > 1 ? Q : 1) + kTI - 1) / kTI; return b < kIcpMaxBlocks ? b : kIcpMaxBlocks; }
 // table form: blockIdx.y = candidate; a candidate's own workgroup count is what its ticket counts (one workgroup even for Q = 0: the
 // scalar tail — the damped 3 x 3 solve / the decision — must run for problems with no correspondences too)
-template <bool WITH_J>
+template <bool CAND, bool WITH_J>
 __global__ __launch_bounds__(kTI) void k_icp_eval_b(const IcpJob* __restrict__ jobs, SmDev* __restrict__ devs, int sub) {
   SmDev& D = devs[blockIdx.y];
   if (!D.has[sub]) return;
   const IcpJob& J = jobs[2 * blockIdx.y + sub];
   const int nbx = icp_blocks(J.Q);
   if ((int)blockIdx.x >= nbx) return;
-  icp_eval_body<WITH_J>(blockIdx.x, nbx, J.Q, J.P, J.PA, J.N, J.valid, J.args, &D.icp);
+  icp_eval_body<CAND, WITH_J>(blockIdx.x, nbx, J.Q, J.P, J.PA, J.N, J.valid, J.args, &D.icp);
 }
 
 }  // namespace lvf
@@ -203,11 +211,12 @@ static IcpArgs make_args(const double* Twc1, const lvf_icp_options* opt) {
   a.mode = opt->mode; a.max_iters = opt->max_num_iterations;
   return a;
 }
-int launch_icp_eval_batch(hipStream_t q, const IcpJob* jobs, SmDev* devs, int n, int sub, int max_Q, bool with_j) {
+int launch_icp_eval_batch(hipStream_t q, const IcpJob* jobs, SmDev* devs, int n, int sub, int max_Q, bool candidate, bool last) {
   if (n <= 0) return LVF_OK;
   const dim3 g(icp_blocks(max_Q), n);
-  if (with_j) hipLaunchKernelGGL(k_icp_eval_b<true>, g, dim3(kTI), 0, q, jobs, devs, sub);
-  else hipLaunchKernelGGL(k_icp_eval_b<false>, g, dim3(kTI), 0, q, jobs, devs, sub);
+  if (!candidate) hipLaunchKernelGGL((k_icp_eval_b<false, true>), g, dim3(kTI), 0, q, jobs, devs, sub);
+  else if (last) hipLaunchKernelGGL((k_icp_eval_b<true, false>), g, dim3(kTI), 0, q, jobs, devs, sub);
+  else hipLaunchKernelGGL((k_icp_eval_b<true, true>), g, dim3(kTI), 0, q, jobs, devs, sub);
   LVF_HIP(hipGetLastError());
   return LVF_OK;
 }
@@ -222,12 +231,14 @@ static void init_dev(IcpDev& h, int mode, const double* rpyxyz) {
 static int run_lm(hipStream_t q, int Q, const double* P, const double* PA, const double* N, const uint8_t* valid, const IcpArgs& a,
                   IcpDev* dev, IcpDev* host_out) {
   const int grid = std::min((std::max(Q, 1) + kTI - 1) / kTI, kIcpMaxBlocks);
-  for (int it = 0; it < std::max(1, a.max_iters); ++it) {
-    if (Q > 0) hipLaunchKernelGGL(k_icp_eval<true>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, valid, a, dev);
-    else hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1), 0, q, a, dev);
-    if (a.max_iters == 0) break;
-    if (Q > 0) hipLaunchKernelGGL(k_icp_eval<false>, dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, valid, a, dev);
-    else hipLaunchKernelGGL(k_icp_decide, dim3(1), dim3(1), 0, q, a, dev);
+  // the pass at x (linearisation + first step), then ONE pass per LM iteration at its candidate (decision + next step)
+  // (the last iteration's pass sums the cost alone: no step can follow it)
+  if (Q > 0) hipLaunchKernelGGL((k_icp_eval<false, true>), dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, valid, a, dev);
+  else hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1), 0, q, a, dev);
+  for (int it = 0; it < a.max_iters; ++it) {
+    if (Q <= 0) hipLaunchKernelGGL(k_icp_decide_step, dim3(1), dim3(1), 0, q, a, dev);
+    else if (it + 1 == a.max_iters) hipLaunchKernelGGL((k_icp_eval<true, false>), dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, valid, a, dev);
+    else hipLaunchKernelGGL((k_icp_eval<true, true>), dim3(grid), dim3(kTI), 0, q, Q, P, PA, N, valid, a, dev);
   }
   LVF_HIP(hipGetLastError());
   LVF_HIP(hipMemcpyAsync(host_out, dev, sizeof(IcpDev), hipMemcpyDeviceToHost, q));

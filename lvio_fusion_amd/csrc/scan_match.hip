@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void k_sm_step(SmDev* __restrict__ devs, const 
     h.xc[0] = h.xc[1] = h.xc[2] = 0.0;
     for (int k = 0; k < 6; ++k) h.rpyxyz[k] = d.rpyxyz[k];
     h.radius = 1e4; h.decrease = 2.0;
-    for (int k = 0; k < 11; ++k) h.acc[k] = 0.0;
+    for (int k = 0; k < 11; ++k) { h.acc[k] = 0.0; h.accC[k] = 0.0; }
     h.cost_cand = 0.0; h.cost_cur = 0.0; h.initial_cost = 0.0; h.model = 0.0;
     h.done = d.has[m] ? 0 : 1; h.iters = 0; h.successes = 0; h.nvalid = 0; h.first = 1; h.invalid_run = 0; h.ticket = 0u; h.count_valid = 1;
     for (int k = 0; k < 7; ++k) d.tf[k] = (float)d.pose[k];        // Sophus SE3d::cast<float>()
@@ -189,11 +189,9 @@ int scan_match_run(lvf_ctx* ctx, const SmJobView* jobs, int n, const lvf_scan_ma
       hipLaunchKernelGGL(k_sm_step, gs, dim3(64), 0, q, dd, sa);
       first = false;
       LVF_TRY(launch_knn3_batch(q, dk, dd, n, m, max_Q[m]));            // association.cpp:287-301 / :345-359 and the correspondences, :303-314 / :361-372
-      for (int li = 0; li < std::max(1, opt->max_num_iterations); ++li) {
-        LVF_TRY(launch_icp_eval_batch(q, di, dd, n, m, max_Q[m], true));
-        if (opt->max_num_iterations == 0) break;
-        LVF_TRY(launch_icp_eval_batch(q, di, dd, n, m, max_Q[m], false));
-      }
+      LVF_TRY(launch_icp_eval_batch(q, di, dd, n, m, max_Q[m], false, false));            // the pass at x: linearisation + first step
+      for (int li = 0; li < opt->max_num_iterations; ++li)
+        LVF_TRY(launch_icp_eval_batch(q, di, dd, n, m, max_Q[m], true, li + 1 == opt->max_num_iterations));      // one pass per LM iteration, at its candidate
       prev = m;
     }
     if (first) {     // no sub-problem at all: rpyxyz still follows the pose, nothing to solve

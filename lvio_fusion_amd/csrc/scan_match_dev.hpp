@@ -16,7 +16,8 @@ struct IcpDev {
   double x[3], x0[3], xc[3];
   double radius, decrease;
   double acc[11];            // H lower (00,10,11,20,21,22), g (3), cost — at x ; [10] = number of valid correspondences (first pass)
-  double cost_cand;          // data cost at xc
+  double accC[11];           // the same sums at the candidate xc (one pass per LM iteration: an accepted candidate's linearisation is already there)
+  double cost_cand;          // (unused since the candidate pass carries its Jacobian: kept for the record layout's readers)
   double cost_cur, initial_cost, model;
   double rpyxyz[6];
   int done, iters, successes, nvalid, first;
@@ -60,7 +61,7 @@ constexpr int kIcpMaxBlocks = 128;   // k_icp_eval grid cap (grid-stride above i
 // launchers (the kernels stay in their translation units: the association is compiled without FMA contraction)
 int launch_knn3_batch(hipStream_t q, const KnnJob* jobs, const SmDev* devs, int n, int sub, int max_Q);      // association + correspondence build
 int launch_knn3_build(lvf_map* m, lvf_scan* sc, const double* pose, float thr, double* corr);                 // the same for one (map, scan) pair
-int launch_icp_eval_batch(hipStream_t q, const IcpJob* jobs, SmDev* devs, int n, int sub, int max_Q, bool with_j);
+int launch_icp_eval_batch(hipStream_t q, const IcpJob* jobs, SmDev* devs, int n, int sub, int max_Q, bool candidate, bool last);   // candidate: the pass at xc (decision + next step) instead of the opening pass at x; last: cost only
 LevelsP levels_of(const lvf_map* m);
 
 }  // namespace lvf
