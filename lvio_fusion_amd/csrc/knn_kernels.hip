@@ -49,10 +49,10 @@ __host__ __device__ inline float ord2f(unsigned u) {
 // the cloud, and every workgroup reduces through LDS first: atomics on ONE address serialise at ~65 ns each in L2 (measured: one
 // atomic per wave = 5.3 k per address cost 365 us on a 340 k-point cloud).
 constexpr int kBoundsMaxBlocks = 256;
-__global__ __launch_bounds__(kB) void k_pack_bounds(int M, const float* __restrict__ src, int stride, float4* __restrict__ dst,
-                                                    unsigned* __restrict__ bounds /* min xyz, max xyz */) {
+__device__ __forceinline__ void pack_bounds_body(const int bx, const int nbx, int M, const float* __restrict__ src, int stride, float4* __restrict__ dst,
+                                                 unsigned* __restrict__ bounds /* min xyz, max xyz */) {
   float x = INFINITY, y = INFINITY, z = INFINITY, X = -INFINITY, Y = -INFINITY, Z = -INFINITY;
-  for (int i = blockIdx.x * kB + threadIdx.x; i < M; i += gridDim.x * kB) {
+  for (int i = bx * kB + threadIdx.x; i < M; i += nbx * kB) {
     const float* s = src + (size_t)i * stride;
     const float a = s[0], b = s[1], c = s[2];
     dst[i] = make_float4(a, b, c, 0.0f);
@@ -72,15 +72,27 @@ __global__ __launch_bounds__(kB) void k_pack_bounds(int M, const float* __restri
     if (threadIdx.x < 3) atomicMin(bounds + threadIdx.x, f2ord(v)); else atomicMax(bounds + threadIdx.x, f2ord(v));
   }
 }
+__global__ __launch_bounds__(kB) void k_pack_bounds(int M, const float* __restrict__ src, int stride, float4* __restrict__ dst,
+                                                    unsigned* __restrict__ bounds) {
+  pack_bounds_body(blockIdx.x, gridDim.x, M, src, stride, dst, bounds);
+}
+// table forms (blockIdx.y = map) of the index build's launches: lvf_map_create_batch enqueues ONE launch per step for all the maps of a
+// round instead of one per map (16 loop-closure maps x 3 grid levels x 6 steps were ~290 launches of a few microseconds each)
+struct PackJob { int M, stride, nbx, pad; const float* src; float4* dst; unsigned* bounds; };
+__global__ __launch_bounds__(kB) void k_pack_bounds_t(const PackJob* __restrict__ jobs) {
+  const PackJob J = jobs[blockIdx.y];
+  if ((int)blockIdx.x >= J.nbx) return;
+  pack_bounds_body(blockIdx.x, J.nbx, J.M, J.src, J.stride, J.dst, J.bounds);
+}
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_cell, int n) {
   int c = (int)floorf((v - o) * inv_cell);
   return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
 
-__global__ __launch_bounds__(kB) void k_cell_count(int M, const float4* __restrict__ pts, GridP g, int* __restrict__ cell_of,
-                                                   int* __restrict__ counts) {
-  const int i = blockIdx.x * kB + threadIdx.x;
+__device__ __forceinline__ void cell_count_body(const int bx, int M, const float4* __restrict__ pts, const GridP& g, int* __restrict__ cell_of,
+                                                int* __restrict__ counts) {
+  const int i = bx * kB + threadIdx.x;
   int c = -1;
   if (i < M) {
     const float4 p = pts[i];
@@ -90,6 +102,10 @@ __global__ __launch_bounds__(kB) void k_cell_count(int M, const float4* __restri
   int start, len;
   const bool head = cell_runs(c, start, len);
   if (head && c >= 0) atomicAdd(counts + c, len);
+}
+__global__ __launch_bounds__(kB) void k_cell_count(int M, const float4* __restrict__ pts, GridP g, int* __restrict__ cell_of,
+                                                   int* __restrict__ counts) {
+  cell_count_body(blockIdx.x, M, pts, g, cell_of, counts);
 }
 
 // (sum over cells of count^2) / M is the population of the cell a random map point lives in, i.e. the candidates a query in a
@@ -112,26 +128,30 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* s_warp, int& tot
 }
 // block_sq (optional): per-workgroup sum of squares of the inputs — the grid build's occupancy statistic rides along the pass
 // that reads every count anyway (it used to be its own kernel with a same-address atomic per workgroup)
-__global__ __launch_bounds__(kScanT) void k_scan_reduce(int n, const int* __restrict__ in, int* __restrict__ block_sums,
-                                                        unsigned long long* __restrict__ block_sq) {
+__device__ __forceinline__ void scan_reduce_body(const int bx, int n, const int* __restrict__ in, int* __restrict__ block_sums,
+                                                 unsigned long long* __restrict__ block_sq) {
   __shared__ int s_warp[kScanT / 64];
   __shared__ unsigned long long s_sq[kScanT / 64];
-  const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanE;
+  const int base = bx * kScanChunk + threadIdx.x * kScanE;
   int v = 0;
   unsigned long long sq = 0;
   for (int e = 0; e < kScanE; ++e) if (base + e < n) { const int c = in[base + e]; v += c; sq += (unsigned long long)c * (unsigned long long)c; }
   int total;
   (void)block_exclusive_scan(v, s_warp, total);
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+  if (threadIdx.x == 0) block_sums[bx] = total;
   if (block_sq) {
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o);
     if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < kScanT / 64; ++k) t += s_sq[k]; block_sq[blockIdx.x] = t; }
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < kScanT / 64; ++k) t += s_sq[k]; block_sq[bx] = t; }
   }
 }
-__global__ __launch_bounds__(kScanT) void k_scan_sums(int nb, int* __restrict__ block_sums, int* __restrict__ grand_total,
-                                                      const unsigned long long* __restrict__ block_sq, unsigned long long* __restrict__ sq_total) {
+__global__ __launch_bounds__(kScanT) void k_scan_reduce(int n, const int* __restrict__ in, int* __restrict__ block_sums,
+                                                        unsigned long long* __restrict__ block_sq) {
+  scan_reduce_body(blockIdx.x, n, in, block_sums, block_sq);
+}
+__device__ __forceinline__ void scan_sums_body(int nb, int* __restrict__ block_sums, int* __restrict__ grand_total,
+                                               const unsigned long long* __restrict__ block_sq, unsigned long long* __restrict__ sq_total) {
   __shared__ int s_warp[kScanT / 64];
   if (block_sq) {                                  // total of the per-workgroup square sums
     __shared__ unsigned long long s_sq[kScanT / 64];
@@ -154,23 +174,30 @@ __global__ __launch_bounds__(kScanT) void k_scan_sums(int nb, int* __restrict__ 
   }
   if (threadIdx.x == 0) *grand_total = carry;
 }
+__global__ __launch_bounds__(kScanT) void k_scan_sums(int nb, int* __restrict__ block_sums, int* __restrict__ grand_total,
+                                                      const unsigned long long* __restrict__ block_sq, unsigned long long* __restrict__ sq_total) {
+  scan_sums_body(nb, block_sums, grand_total, block_sq, sq_total);
+}
 // clear_in: zero the input after reading it (the grid build re-uses the count array as the scatter cursor)
-__global__ __launch_bounds__(kScanT) void k_scan_apply(int n, int* in, const int* __restrict__ block_sums,
-                                                       int* __restrict__ out, int clear_in) {
+__device__ __forceinline__ void scan_apply_body(const int bx, int n, int* in, const int* __restrict__ block_sums, int* __restrict__ out, int clear_in) {
   __shared__ int s_warp[kScanT / 64];
-  const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanE;
+  const int base = bx * kScanChunk + threadIdx.x * kScanE;
   int e_v[kScanE];
   int v = 0;
   for (int e = 0; e < kScanE; ++e) { e_v[e] = (base + e < n) ? in[base + e] : 0; v += e_v[e]; }
   int total;
-  int run = block_sums[blockIdx.x] + block_exclusive_scan(v, s_warp, total);
+  int run = block_sums[bx] + block_exclusive_scan(v, s_warp, total);
   for (int e = 0; e < kScanE; ++e) { if (base + e < n) { out[base + e] = run; if (clear_in) in[base + e] = 0; } run += e_v[e]; }
 }
+__global__ __launch_bounds__(kScanT) void k_scan_apply(int n, int* in, const int* __restrict__ block_sums,
+                                                       int* __restrict__ out, int clear_in) {
+  scan_apply_body(blockIdx.x, n, in, block_sums, out, clear_in);
+}
 
-__global__ __launch_bounds__(kB) void k_cell_scatter(int M, const float4* __restrict__ pts, const int* __restrict__ cell_of,
-                                                     const int* __restrict__ cell_start, int* __restrict__ cursor,
-                                                     float4* __restrict__ sorted) {
-  const int i = blockIdx.x * kB + threadIdx.x;
+__device__ __forceinline__ void cell_scatter_body(const int bx, int M, const float4* __restrict__ pts, const int* __restrict__ cell_of,
+                                                  const int* __restrict__ cell_start, int* __restrict__ cursor,
+                                                  float4* __restrict__ sorted) {
+  const int i = bx * kB + threadIdx.x;
   const int c = (i < M) ? cell_of[i] : -1;
   int start, len;
   const bool head = cell_runs(c, start, len);
@@ -181,6 +208,45 @@ __global__ __launch_bounds__(kB) void k_cell_scatter(int M, const float4* __rest
   float4 p = pts[i];
   p.w = __int_as_float(i);
   sorted[cell_start[c] + base + ((int)(threadIdx.x & 63) - start)] = p;
+}
+__global__ __launch_bounds__(kB) void k_cell_scatter(int M, const float4* __restrict__ pts, const int* __restrict__ cell_of,
+                                                     const int* __restrict__ cell_start, int* __restrict__ cursor,
+                                                     float4* __restrict__ sorted) {
+  cell_scatter_body(blockIdx.x, M, pts, cell_of, cell_start, cursor, sorted);
+}
+// one grid level of one map (table entry of the batched index build)
+struct LevelJob {
+  int M, ncells, gridM, nb;
+  GridP g;
+  const float4* raw; int* cell_of; int* counts; int* bsums; unsigned long long* bsq; int* cell_start; float4* sorted; unsigned long long* sumsq;
+};
+__global__ __launch_bounds__(kB) void k_level_zero_t(const LevelJob* __restrict__ jobs) {            // counts = 0
+  const LevelJob& J = jobs[blockIdx.y];
+  for (int i = blockIdx.x * kB + threadIdx.x; i < J.ncells; i += gridDim.x * kB) J.counts[i] = 0;
+}
+__global__ __launch_bounds__(kB) void k_cell_count_t(const LevelJob* __restrict__ jobs) {
+  const LevelJob& J = jobs[blockIdx.y];
+  if ((int)blockIdx.x >= J.gridM) return;
+  cell_count_body(blockIdx.x, J.M, J.raw, J.g, J.cell_of, J.counts);
+}
+__global__ __launch_bounds__(kScanT) void k_scan_reduce_t(const LevelJob* __restrict__ jobs) {
+  const LevelJob& J = jobs[blockIdx.y];
+  if ((int)blockIdx.x >= J.nb) return;
+  scan_reduce_body(blockIdx.x, J.ncells, J.counts, J.bsums, J.bsq);
+}
+__global__ __launch_bounds__(kScanT) void k_scan_sums_t(const LevelJob* __restrict__ jobs) {
+  const LevelJob& J = jobs[blockIdx.y];
+  scan_sums_body(J.nb, J.bsums, J.cell_start + J.ncells, J.bsq, J.sumsq);
+}
+__global__ __launch_bounds__(kScanT) void k_scan_apply_t(const LevelJob* __restrict__ jobs) {
+  const LevelJob& J = jobs[blockIdx.y];
+  if ((int)blockIdx.x >= J.nb) return;
+  scan_apply_body(blockIdx.x, J.ncells, J.counts, J.bsums, J.cell_start, 1);
+}
+__global__ __launch_bounds__(kB) void k_cell_scatter_t(const LevelJob* __restrict__ jobs) {
+  const LevelJob& J = jobs[blockIdx.y];
+  if ((int)blockIdx.x >= J.gridM) return;
+  cell_scatter_body(blockIdx.x, J.M, J.raw, J.cell_of, J.cell_start, J.counts, J.sorted);
 }
 
 __global__ __launch_bounds__(kB) void k_pack(int Q, const float* __restrict__ src, int stride, float4* __restrict__ dst) {
@@ -530,6 +596,22 @@ extern "C" {
 // Enqueues the build of one grid level (counting sort of the map by cell) into lv; nothing is waited for.  *sumsq_dev receives
 // sum(count^2) over the cells (point-weighted mean cell population = that / M); `t` holds the temporaries and must outlive the launches.
 struct LevelTmp { DevBuf<int> cell_of, counts, bsums; DevBuf<unsigned long long> bsq; };
+// allocations and geometry of one level -> the job record the kernels take (nothing is launched)
+static int prepare_level(lvf_map* m, lvf_map::Level& lv, float cell, const float lo[3], const float hi[3], LevelTmp& t, unsigned long long* sumsq_dev, LevelJob* job) {
+  const int M = m->M;
+  lv.nx = (int)(std::floor((hi[0] - lo[0]) / cell) + 1); lv.ny = (int)(std::floor((hi[1] - lo[1]) / cell) + 1);
+  lv.nz = (int)(std::floor((hi[2] - lo[2]) / cell) + 1);
+  lv.cell = cell; lv.inv_cell = 1.0f / cell; lv.ox = lo[0]; lv.oy = lo[1]; lv.oz = lo[2];
+  const int ncells = lv.nx * lv.ny * lv.nz;
+  const int gridM = (M + kB - 1) / kB, nb = (ncells + kScanChunk - 1) / kScanChunk;
+  LVF_TRY(t.cell_of.alloc(M)); LVF_TRY(t.counts.alloc(ncells)); LVF_TRY(t.bsums.alloc(nb)); LVF_TRY(t.bsq.alloc(nb));
+  LVF_TRY(lv.cell_start.alloc((size_t)ncells + 1)); LVF_TRY(lv.sorted.alloc(M));
+  job->M = M; job->ncells = ncells; job->gridM = gridM; job->nb = nb;
+  job->g = GridP{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz};
+  job->raw = m->raw.p; job->cell_of = t.cell_of.p; job->counts = t.counts.p; job->bsums = t.bsums.p; job->bsq = t.bsq.p;
+  job->cell_start = lv.cell_start.p; job->sorted = lv.sorted.p; job->sumsq = sumsq_dev;
+  return LVF_OK;
+}
 static int enqueue_level(lvf_map* m, lvf_map::Level& lv, float cell, const float lo[3], const float hi[3], LevelTmp& t, unsigned long long* sumsq_dev) {
   hipStream_t s = m->ctx->stream;
   const int M = m->M;
@@ -654,10 +736,15 @@ int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const
   std::vector<Item> it((size_t)n);
   std::vector<DevBuf<float>> src((size_t)n);
   std::vector<HostPin<float>> stage((size_t)n);
-  StreamWaitGuard stage_guard(s);          // every path out waits for the copies before the pinned blocks return to the pool
+  // job tables travel through one pinned block per step (every step ends with a stream wait before the block is written again)
+  HostPin<unsigned char> h_tab; DevBuf<unsigned char> d_tab;
+  StreamWaitGuard stage_guard(s);          // (declared AFTER every pinned block: destroyed first) every path out waits for the copies before the blocks return to the pool
   DevBuf<unsigned> bounds; DevBuf<unsigned long long> sumsq;
   LVF_TRY(bounds.alloc((size_t)6 * n)); LVF_TRY(sumsq.alloc((size_t)n));
   hipLaunchKernelGGL(k_bounds_init, dim3((6 * n + 255) / 256), dim3(256), 0, s, n, bounds.p);
+  LVF_TRY(h_tab.reserve((size_t)n * std::max(sizeof(PackJob), sizeof(LevelJob)))); LVF_TRY(d_tab.alloc((size_t)n * std::max(sizeof(PackJob), sizeof(LevelJob))));
+  PackJob* pj = reinterpret_cast<PackJob*>(h_tab.p);
+  int n_pack = 0, max_pack_blocks = 0;
   for (int i = 0; i < n; ++i) {
     it[i].m.reset(new lvf_map());
     lvf_map* m = it[i].m.get();
@@ -672,7 +759,13 @@ int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const
     }
     LVF_TRY(src[i].upload_staged(map_xyz[i], (size_t)M[i] * stride_floats, s, stage[i]));
     LVF_TRY(m->raw.alloc(M[i]));
-    hipLaunchKernelGGL(k_pack_bounds, dim3(std::min(kBoundsMaxBlocks, (M[i] + kB - 1) / kB)), dim3(kB), 0, s, M[i], src[i].p, stride_floats, m->raw.p, bounds.p + 6 * i);
+    const int nbx = std::min(kBoundsMaxBlocks, (M[i] + kB - 1) / kB);
+    pj[n_pack++] = PackJob{M[i], stride_floats, nbx, 0, src[i].p, m->raw.p, bounds.p + 6 * i};
+    max_pack_blocks = std::max(max_pack_blocks, nbx);
+  }
+  if (n_pack) {
+    LVF_HIP(hipMemcpyAsync(d_tab.p, h_tab.p, (size_t)n_pack * sizeof(PackJob), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pack_bounds_t, dim3(max_pack_blocks, n_pack), dim3(kB), 0, s, reinterpret_cast<const PackJob*>(d_tab.p));
   }
   LVF_HIP(hipGetLastError());
   std::vector<unsigned> hb((size_t)6 * n);
@@ -696,8 +789,24 @@ int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const
   std::vector<unsigned long long> hs((size_t)n);
   while (growing > 0) {
     std::vector<LevelTmp> tmp((size_t)n);                            // (live until the round's wait)
-    for (int i = 0; i < n; ++i)
-      if (it[i].growing) LVF_TRY(enqueue_level(it[i].m.get(), it[i].built[it[i].nb], it[i].cell, it[i].lo, it[i].hi, tmp[i], sumsq.p + i));
+    LevelJob* lj = reinterpret_cast<LevelJob*>(h_tab.p);
+    int nj = 0, gM = 0, gS = 0, gZ = 0;
+    for (int i = 0; i < n; ++i) {
+      if (!it[i].growing) continue;
+      LVF_TRY(prepare_level(it[i].m.get(), it[i].built[it[i].nb], it[i].cell, it[i].lo, it[i].hi, tmp[i], sumsq.p + i, &lj[nj]));
+      gM = std::max(gM, lj[nj].gridM); gS = std::max(gS, lj[nj].nb); gZ = std::max(gZ, std::min(512, (lj[nj].ncells + kB - 1) / kB));
+      ++nj;
+    }
+    LVF_HIP(hipMemcpyAsync(d_tab.p, h_tab.p, (size_t)nj * sizeof(LevelJob), hipMemcpyHostToDevice, s));
+    const LevelJob* dj = reinterpret_cast<const LevelJob*>(d_tab.p);
+    // the six steps of a level build (build_level), each ONE launch over all the maps of the round
+    hipLaunchKernelGGL(k_level_zero_t, dim3(gZ, nj), dim3(kB), 0, s, dj);
+    hipLaunchKernelGGL(k_cell_count_t, dim3(gM, nj), dim3(kB), 0, s, dj);
+    hipLaunchKernelGGL(k_scan_reduce_t, dim3(gS, nj), dim3(kScanT), 0, s, dj);
+    hipLaunchKernelGGL(k_scan_sums_t, dim3(1, nj), dim3(kScanT), 0, s, dj);
+    hipLaunchKernelGGL(k_scan_apply_t, dim3(gS, nj), dim3(kScanT), 0, s, dj);
+    hipLaunchKernelGGL(k_cell_scatter_t, dim3(gM, nj), dim3(kB), 0, s, dj);
+    LVF_HIP(hipGetLastError());
     LVF_TRY(read_back(ctx, hs.data(), sumsq.p, hs.size() * sizeof(unsigned long long)));      // ONE wait per round of levels
     for (int i = 0; i < n; ++i) {
       Item& a = it[i];
