@@ -855,8 +855,10 @@ static int scan_create_impl(lvf_ctx* ctx, const float* scan_xyz, bool src_is_dev
     if (!src_is_device) {
       // no wait: everything that touches the scan later runs on this stream, behind the copy.  The staging moves into the scan (a
       // creation per loop-closure candidate and cloud used to cost one stream wait each: 16 per configs[4] batch)
-      sc->create_src.swap(src); sc->create_stage.swap(stage); sc->create_in_flight = true;
-      stage_guard.dismiss();
+      if (hipEventCreateWithFlags(&sc->create_done, hipEventDisableTiming) == hipSuccess && hipEventRecord(sc->create_done, ctx->stream) == hipSuccess) {
+        sc->create_src.swap(src); sc->create_stage.swap(stage);
+        stage_guard.dismiss();
+      }                                              // (no event: the guard waits, as before)
     }
   } else stage_guard.dismiss();
   *out = sc;
@@ -870,11 +872,7 @@ int lvf_scan_create_from_cloud(const lvf_cloud* c, lvf_scan** out) {
   return scan_create_impl(c->ctx, reinterpret_cast<const float*>(c->pts.p), true, c->n, 4, out);
 }
 
-int lvf_scan_destroy(lvf_scan* s) {
-  if (s && s->create_in_flight && lvf::enter(s->ctx) == LVF_OK) (void)hipStreamSynchronize(s->ctx->stream);     // (the pinned block goes back to a pool other threads draw from)
-  delete s;
-  return LVF_OK;
-}
+int lvf_scan_destroy(lvf_scan* s) { delete s; return LVF_OK; }      // (~lvf_scan waits for the creation's upload before its pinned block returns to the pool)
 
 // diagnostic (not part of the reference surface): per-query search statistics {candidates, range lookups, last level,
 // shells}, and the grid pyramid geometry {cell, nx, ny, nz} per level.

@@ -356,7 +356,8 @@ struct lvf_scan {
   lvf::DevBuf<char> icp_dev;         // device-resident LM state of lvf_icp_solve
   lvf::HostPin<char> icp_host;       // its pinned host mirror (initial state up, result down: real asynchronous copies)
   // the upload of lvf_scan_create is not waited for: its staging (pinned block + raw device copy) belongs to the scan until the scan goes
-  lvf::DevBuf<float> create_src; lvf::HostPin<float> create_stage; bool create_in_flight = false;
+  lvf::DevBuf<float> create_src; lvf::HostPin<float> create_stage; hipEvent_t create_done = nullptr;      // recorded behind the upload: what lvf_scan_destroy waits for (the context may be gone by then)
+  ~lvf_scan() { if (create_done) { (void)hipEventSynchronize(create_done); (void)hipEventDestroy(create_done); } }      // (runs before the members above are released)
 };
 
 struct lvf_cloud {

@@ -137,6 +137,7 @@ int scan_match_run(lvf_ctx* ctx, const SmJobView* jobs, int n, const lvf_scan_ma
   // host tables in ONE pinned block: records | knn jobs | icp jobs
   const size_t b_dev = (size_t)n * sizeof(SmDev), b_knn = (size_t)2 * n * sizeof(KnnJob), b_icp = (size_t)2 * n * sizeof(IcpJob);
   HostPin<char> stage;
+  StreamWaitGuard stage_guard(q);          // an error between the table's upload and the wait below must not hand the pinned block back while the copy runs
   LVF_TRY(stage.reserve(b_dev + b_knn + b_icp));
   std::memset(stage.p, 0, b_dev + b_knn + b_icp);
   SmDev* hd = reinterpret_cast<SmDev*>(stage.p);
@@ -203,6 +204,7 @@ int scan_match_run(lvf_ctx* ctx, const SmJobView* jobs, int n, const lvf_scan_ma
   LVF_HIP(hipGetLastError());
   LVF_HIP(hipMemcpyAsync(stage.p, tab.p, b_dev, hipMemcpyDeviceToHost, q));
   LVF_HIP(hipStreamSynchronize(q));
+  stage_guard.dismiss();
   for (int c = 0; c < n; ++c) {
     const SmDev& d = hd[c];
     lvf_scan_match_result& r = out[c];
