@@ -210,6 +210,18 @@ __global__ __launch_bounds__(kT) void k_zero_multi(ZeroList z) {
   for (unsigned long long i = (unsigned long long)blockIdx.x * kT + threadIdx.x; i < n2; i += (unsigned long long)gridDim.x * kT) p2[i] = make_double2(0.0, 0.0);
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
 }
+// k_zero_multi + k_lm_range_init in one launch (problem_configure): slice z.count of the grid's y sets the landmark tracks to "none yet"
+__global__ __launch_bounds__(kT) void k_zero_multi_ranges(ZeroList z, int n_lm, int* __restrict__ kmin, int* __restrict__ kmax) {
+  if ((int)blockIdx.y == z.count) {
+    for (int l = blockIdx.x * kT + threadIdx.x; l < n_lm; l += gridDim.x * kT) { kmin[l] = 0x7fffffff; kmax[l] = -1; }
+    return;
+  }
+  double* p = z.p[blockIdx.y];
+  const unsigned long long n = z.n[blockIdx.y], n2 = n / 2;
+  double2* p2 = reinterpret_cast<double2*>(p);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * kT + threadIdx.x; i < n2; i += (unsigned long long)gridDim.x * kT) p2[i] = make_double2(0.0, 0.0);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
+}
 // workgroup `wg` of `n_wgs` (kT threads each) clears its share of every array of the list
 // (static indices only: a run-time index into the by-value pointer table would put it in scratch memory)
 __device__ __forceinline__ void zero_list_share(const ZeroList& zero, const int wg, const int n_wgs) {
@@ -1469,8 +1481,8 @@ __device__ __forceinline__ int lm_sort_key(int kmin, int kmax, int n_kf) {
 // counting sort by key, one workgroup (n_lm is ~1e4; 4 n_kf + 1 buckets in LDS)
 // (per-wave copies of the histogram — 16x fewer lanes per address — measured SLOWER, 15.7 vs 13.6 us: the two passes are bound by their
 // dependent load -> LDS atomic round trips, not by address conflicts)
-__global__ __launch_bounds__(1024) void k_lm_sort(int n_lm, int n_kf, const int* __restrict__ kmin, const int* __restrict__ kmax,
-                                                  int* __restrict__ order, int* __restrict__ n_active) {
+__device__ __forceinline__ void lm_sort_body(int n_lm, int n_kf, const int* __restrict__ kmin, const int* __restrict__ kmax,
+                                             int* __restrict__ order, int* __restrict__ n_active) {
   extern __shared__ int bucket[];
   const int nb = 4 * n_kf + 1;
   for (int b = threadIdx.x; b < nb; b += 1024) bucket[b] = 0;
@@ -1496,11 +1508,15 @@ __global__ __launch_bounds__(1024) void k_lm_sort(int n_lm, int n_kf, const int*
   __syncthreads();
   for (int l = threadIdx.x; l < n_lm; l += 1024) order[atomicAdd(&bucket[lm_sort_key(kmin[l], kmax[l], n_kf)], 1)] = l;
 }
+__global__ __launch_bounds__(1024) void k_lm_sort(int n_lm, int n_kf, const int* __restrict__ kmin, const int* __restrict__ kmax,
+                                                  int* __restrict__ order, int* __restrict__ n_active) {
+  lm_sort_body(n_lm, n_kf, kmin, kmax, order, n_active);
+}
 
 // ---- compact landmark layout, built once per problem_configure
 // eoff[l] = first slot of landmark l, len_l = kmax_l - kmin_l slots (one per keyframe after the first); *n_slots = their total
-__global__ __launch_bounds__(1024) void k_lm_offsets(int n_lm, const int* __restrict__ kmin, const int* __restrict__ kmax, int* __restrict__ eoff,
-                                                     int* __restrict__ n_slots) {
+__device__ __forceinline__ void lm_offsets_body(int n_lm, const int* __restrict__ kmin, const int* __restrict__ kmax, int* __restrict__ eoff,
+                                                int* __restrict__ n_slots) {
   // 16 k landmarks per pass: every thread requests its 16 (kmin, kmax) pairs up front (a load inside the per-1024 loop was waited for
   // before the next was issued: 10 dependent round trips at 10 k landmarks), scans run inside waves, two workgroup barriers per pass
   constexpr int kG = 16;
@@ -1545,12 +1561,38 @@ __global__ __launch_bounds__(1024) void k_lm_offsets(int n_lm, const int* __rest
   }
   if (tid == 0) *n_slots = total;
 }
+__global__ __launch_bounds__(1024) void k_lm_offsets(int n_lm, const int* __restrict__ kmin, const int* __restrict__ kmax, int* __restrict__ eoff,
+                                                     int* __restrict__ n_slots) {
+  lm_offsets_body(n_lm, kmin, kmax, eoff, n_slots);
+}
+// the counting sort and the slot offsets are two one-workgroup chains over the same (kmin, kmax) with nothing in common but their inputs:
+// ONE launch of two workgroups runs them side by side (a persistent window reconfigures every tick: 14 us + 9 us + a launch gap became 14 us)
+__global__ __launch_bounds__(1024) void k_lm_sort_offsets(int n_lm, int n_kf, const int* __restrict__ kmin, const int* __restrict__ kmax, int* __restrict__ order,
+                                                          int* __restrict__ n_active, int* __restrict__ eoff, int* __restrict__ n_slots) {
+  if (blockIdx.x == 0) lm_sort_body(n_lm, n_kf, kmin, kmax, order, n_active);
+  else lm_offsets_body(n_lm, kmin, kmax, eoff, n_slots);
+}
 __global__ __launch_bounds__(kT) void k_tf_slots(int n, const int* __restrict__ lm, const int* __restrict__ k2, const int* __restrict__ kmin,
                                                  const int* __restrict__ eoff, int* __restrict__ slot) {
   const int i = blockIdx.x * kT + threadIdx.x;
   if (i >= n) return;
   const int l = lm[i];
   slot[i] = eoff[l] + (k2[i] - kmin[l] - 1);
+}
+// k_tf_slots and k_zero_slots in one launch: workgroups [0, g_slots) take the blocks, the rest clear the slot records
+__global__ __launch_bounds__(kT) void k_tf_slots_zero(int n, int g_slots, const int* __restrict__ lm, const int* __restrict__ k2, const int* __restrict__ kmin,
+                                                      const int* __restrict__ eoff, int* __restrict__ slot, const int* __restrict__ n_slots, double* __restrict__ slotB) {
+  if ((int)blockIdx.x < g_slots) {
+    const int i = blockIdx.x * kT + threadIdx.x;
+    if (i >= n) return;
+    const int l = lm[i];
+    slot[i] = eoff[l] + (k2[i] - kmin[l] - 1);
+    return;
+  }
+  const size_t nz = (size_t)*n_slots * 4;     // double2 elements
+  double2* b = reinterpret_cast<double2*>(slotB);
+  const size_t gz = gridDim.x - g_slots;
+  for (size_t i = (size_t)(blockIdx.x - g_slots) * kT + threadIdx.x; i < nz; i += gz * kT) b[i] = make_double2(0.0, 0.0);
 }
 // slots of keyframes that do not observe their landmark (gaps in a track) are never written by the linearisation: cleared once here
 // sorted copies of the TwoFrame block arrays: block i of the copy = block perm[i] of the batch
@@ -3953,34 +3995,54 @@ int problem_configure(lvf_problem* p) {
   // landmark tracks -> band-limited Schur (device side: the TwoFrame indices already live there)
   p->band_ready = false;
   static const bool band_on = [] { const char* e = std::getenv("LVF_SCHUR_BAND"); return !(e && e[0] == '0'); }();
-  if (band_on && p->n_lm > 0 && (size_t)(4 * p->n_kf + 1) * sizeof(int) <= 48 * 1024) {
-    LVF_TRY(p->lm_kmin.ensure(p->n_lm)); LVF_TRY(p->lm_kmax.ensure(p->n_lm)); LVF_TRY(p->lm_order.ensure(p->n_lm)); LVF_TRY(p->lm_nactive.ensure(1));
+  const bool band_ok = band_on && p->n_lm > 0 && (size_t)(4 * p->n_kf + 1) * sizeof(int) <= 48 * 1024;
+  // compact landmark layout + slabs (atomic-free TwoFrame linearisation): needs the sorted work list, one block per (landmark,
+  // keyframe), the landmark's first keyframe ahead of its observations, and the merged band-Schur launch
+  static const bool compact_on = [] { const char* e = std::getenv("LVF_COMPACT"); return !(e && e[0] == '0'); }();
+  const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRowsMax * sizeof(int);
+  const bool merged = shb <= 64 * 1024 && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024;
+  const bool want_compact = band_ok && compact_on && merged && p->dp <= 320 && two_frame && two_frame->n && p->tf_work.n && p->n_kf <= kMaxStagedKf && p->tf_unique_lk2 && p->tf_k1_first;
+  LVF_TRY(p->E.ensure((size_t)p->n_lm * p->ldE));
+  if (band_ok) { LVF_TRY(p->lm_kmin.ensure(p->n_lm)); LVF_TRY(p->lm_kmax.ensure(p->n_lm)); LVF_TRY(p->lm_order.ensure(p->n_lm)); LVF_TRY(p->lm_nactive.ensure(1)); }
+  // atomic-free mode: E's non-zero pattern is fixed for the problem and fully overwritten by every linearisation — cleared once, here;
+  // one launch for the clears AND the landmark tracks' initial values (a persistent window reconfigures every tick)
+  {
+    ZeroList z{};
+    if (want_compact && p->n_lm) { z.p[z.count] = p->E.p; z.n[z.count] = (unsigned long long)p->n_lm * p->ldE; ++z.count; }
+    z.p[z.count] = reinterpret_cast<double*>(p->pose_const.p); z.n[z.count] = (unsigned long long)(p->n_kf + 7) / 8; ++z.count;      // (the buffer's capacity is padded)
+    z.p[z.count] = p->dxc.p; z.n[z.count] = (unsigned long long)p->dpad; ++z.count;
+    hipLaunchKernelGGL(k_zero_multi_ranges, dim3(512, z.count + (band_ok ? 1 : 0)), dim3(kT), 0, ctx->stream, z, p->n_lm, band_ok ? p->lm_kmin.p : nullptr, band_ok ? p->lm_kmax.p : nullptr);
+    LVF_HIP(hipGetLastError());
+  }
+  if (band_ok) {
     hipStream_t q = ctx->stream;
-    hipLaunchKernelGGL(k_lm_range_init, dim3(grid(p->n_lm)), dim3(kT), 0, q, p->n_lm, p->lm_kmin.p, p->lm_kmax.p);
     if (two_frame && two_frame->n)
       hipLaunchKernelGGL(k_lm_range, dim3(grid(two_frame->n)), dim3(kT), 0, q, two_frame->n, two_frame->idx_a.p, two_frame->idx_b.p, two_frame->idx_c.p,
                          p->lm_kmin.p, p->lm_kmax.p);
+    if (want_compact) {
+      LVF_TRY(p->lm_eoff.ensure(p->n_lm)); LVF_TRY(p->n_slots.ensure(1));
+      // (the slot offsets ride beside the sort: two independent one-workgroup chains, one launch)
+      hipLaunchKernelGGL(k_lm_sort_offsets, dim3(2), dim3(1024), (size_t)(4 * p->n_kf + 1) * sizeof(int), q, p->n_lm, p->n_kf, p->lm_kmin.p, p->lm_kmax.p, p->lm_order.p,
+                         p->lm_nactive.p, p->lm_eoff.p, p->n_slots.p);
+    } else
     hipLaunchKernelGGL(k_lm_sort, dim3(1), dim3(1024), (size_t)(4 * p->n_kf + 1) * sizeof(int), q, p->n_lm, p->n_kf, p->lm_kmin.p, p->lm_kmax.p, p->lm_order.p,
                        p->lm_nactive.p);
     LVF_HIP(hipGetLastError());
     p->band_ready = true;
     p->band_rows_built = 0;         // the bands changed: the work list is rebuilt with the next chain
     p->band_epoch += 1;
-    // compact landmark layout + slabs (atomic-free TwoFrame linearisation): needs the sorted work list, one block per (landmark,
-    // keyframe), the landmark's first keyframe ahead of its observations, and the merged band-Schur launch
-    static const bool compact_on = [] { const char* e = std::getenv("LVF_COMPACT"); return !(e && e[0] == '0'); }();
-    const size_t shb = ((size_t)kSchurRows * (p->ldE + 16) + kSchurRows) * sizeof(double) + kBandRowsMax * sizeof(int);
-    const bool merged = shb <= 64 * 1024 && p->sp_levels.n > 0 && (size_t)p->sp_shmem[0] <= 64 * 1024;
-    if (compact_on && merged && p->dp <= 320 && two_frame && two_frame->n && p->tf_work.n && p->n_kf <= kMaxStagedKf && p->tf_unique_lk2 && p->tf_k1_first) {
+    if (want_compact) {
       const size_t cap_slots = (size_t)p->n_lm * (size_t)std::max(p->n_kf - 1, 1);      // worst case: every landmark seen by every later keyframe
       const int n_wg = (int)p->tf_work.n;
-      LVF_TRY(p->lm_eoff.ensure(p->n_lm)); LVF_TRY(p->n_slots.ensure(1)); LVF_TRY(p->tf_slot.ensure(two_frame->n));
+      LVF_TRY(p->tf_slot.ensure(two_frame->n));
       LVF_TRY(p->slotB.ensure(cap_slots * 8));
       LVF_TRY(p->Ct.ensure(p->n_lm)); LVF_TRY(p->grt.ensure(p->n_lm));
       LVF_TRY(p->slabP.ensure((size_t)n_wg * p->n_kf * kSlabRow)); LVF_TRY(p->slabQ.ensure((size_t)n_wg * kSlabQ));
-      hipLaunchKernelGGL(k_lm_offsets, dim3(1), dim3(1024), 0, q, p->n_lm, p->lm_kmin.p, p->lm_kmax.p, p->lm_eoff.p, p->n_slots.p);
-      hipLaunchKernelGGL(k_tf_slots, dim3(grid(two_frame->n)), dim3(kT), 0, q, two_frame->n, p->tf_lm(), p->tf_k2(), p->lm_kmin.p, p->lm_eoff.p, p->tf_slot.p);
-      hipLaunchKernelGGL(k_zero_slots, dim3(256), dim3(kT), 0, q, p->n_slots.p, p->slotB.p);
+      {
+        const int g_slots = grid(two_frame->n);
+        hipLaunchKernelGGL(k_tf_slots_zero, dim3(g_slots + 256), dim3(kT), 0, q, two_frame->n, g_slots, p->tf_lm(), p->tf_k2(), p->lm_kmin.p, p->lm_eoff.p, p->tf_slot.p,
+                           p->n_slots.p, p->slotB.p);
+      }
       LVF_HIP(hipGetLastError());
       // run_first[k] = first workgroup of current keyframe k's run (the work list is sorted by k2); run_first[n_kf] = n_wg
       LVF_TRY(p->h_run_first.reserve((size_t)p->n_kf + 1));
@@ -3994,16 +4056,6 @@ int problem_configure(lvf_problem* p) {
       LVF_TRY(p->run_first.assign(p->h_run_first.p, (size_t)p->n_kf + 1, q));
       p->compact = true;
     }
-  }
-  LVF_TRY(p->E.ensure((size_t)p->n_lm * p->ldE));
-  // atomic-free mode: E's non-zero pattern is fixed for the problem and fully overwritten by every linearisation — cleared once, here
-  {
-    ZeroList z{};                    // one launch for the three clears (a persistent window reconfigures every tick)
-    if (p->compact && p->n_lm) { z.p[z.count] = p->E.p; z.n[z.count] = (unsigned long long)p->n_lm * p->ldE; ++z.count; }
-    z.p[z.count] = reinterpret_cast<double*>(p->pose_const.p); z.n[z.count] = (unsigned long long)(p->n_kf + 7) / 8; ++z.count;      // (the buffer's capacity is padded)
-    z.p[z.count] = p->dxc.p; z.n[z.count] = (unsigned long long)p->dpad; ++z.count;
-    hipLaunchKernelGGL(k_zero_multi, dim3(512, z.count), dim3(kT), 0, ctx->stream, z);
-    LVF_HIP(hipGetLastError());
   }
   cfg_mark("device-side layout launches + E");
   // no stream wait here: every host source above is pinned and owned by the problem (or was waited for by the plan builder)
