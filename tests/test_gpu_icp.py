@@ -111,3 +111,34 @@ def test_lidar_solve_on_caller_built_batch(ctx, oracle, scene, mode, prior):
     assert abs(s.final_cost - ref["final_cost"]) <= 1e-6 * abs(ref["final_cost"])
     assert np.allclose(x, ref_x, rtol=1e-6, atol=1e-9)
     b.close(); mp.close(); sc.close()
+
+
+@pytest.mark.parametrize("max_iters", [0, 1, 2, 3])
+@pytest.mark.parametrize("far", [False, True])
+def test_icp_iteration_caps_and_a_far_start(ctx, oracle, scene, max_iters, far):
+    """The device loop runs ONE pass per LM iteration (the candidate pass carries the Jacobian; the last allowed iteration's pass only the
+    cost): every cap, and a start far enough for the trust region to work (rejected / short steps), must end where ceres::Solve's
+    restatement ends — same counts, same state."""
+    from lvio_fusion_amd import api
+    c, q, qg = scene
+    mode = 1
+    qq, mm = q[~qg], c["map"][~c["map_ground"]]
+    thr, w, huber = c["thr_surf"], syn.W_LIDAR_SURF, 0.1
+    pose0 = np.array(c["pose0"], float)
+    if far:
+        d = np.array([0.03, -0.02, 0.05, 1.0]); d /= np.linalg.norm(d)
+        pose0 = oracle.se3_mul(np.concatenate([d, [0.6, -0.4, 0.1]]), pose0)
+    rel = oracle.se3_mul(oracle.se3_inv(c["map_pose"]), pose0)
+    rpyxyz0 = oracle.se3_to_rpyxyz(rel)
+    ref_x, ref = oracle.icp_solve(mm, qq, c["map_pose"], pose0, rpyxyz0, mode, thr, w, huber, prior_w=0.0, max_iters=max_iters)
+    mp, sc = api.Map(ctx, mm, thr), api.Scan(ctx, qq)
+    x = rpyxyz0.copy()
+    s = api.icp_solve(mp, sc, c["map_pose"], pose0, x, mode, thr, w, huber, prior_weight=0.0, max_num_iterations=max_iters)
+    assert s.num_residual_blocks == ref["num_residual_blocks"]
+    assert (s.num_iterations, s.num_successful_steps) == (ref["num_iterations"], ref["num_successful_steps"])
+    assert abs(s.initial_cost - ref["initial_cost"]) <= 1e-9 * abs(ref["initial_cost"])
+    assert abs(s.final_cost - ref["final_cost"]) <= 1e-6 * abs(ref["final_cost"]) + 1e-12
+    assert np.allclose(x, ref_x, rtol=1e-6, atol=1e-9)
+    if max_iters == 0:
+        assert np.array_equal(x, rpyxyz0) and s.num_iterations == 0
+    mp.close(); sc.close()
