@@ -112,3 +112,28 @@ def test_maps_created_in_one_batch_equal_maps_created_one_by_one():
         for h in (sa, sb, ms, mb):
             h.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_map_batch_rejects_a_bad_cloud_as_a_whole():
+    """One cloud with an infinite coordinate (an unbounded grid) fails the whole lvf_map_create_batch call (no map is returned), like lvf_map_create fails for it alone;
+    the context stays usable."""
+    from lvio_fusion_amd import api
+    rng = np.random.default_rng(5)
+    ctx = api.Context(0)
+    good = rng.uniform(-5, 5, (2000, 3)).astype(np.float32)
+    bad = good.copy(); bad[17, 1] = np.inf
+    with pytest.raises(api.LvfError):
+        api.Map(ctx, bad, 1.0)
+    with pytest.raises(api.LvfError):
+        api.Map.create_batch(ctx, [good, bad, good], 1.0)
+    with pytest.raises(api.LvfError):
+        api.Map.create_batch(ctx, [good], [-1.0])
+    maps = api.Map.create_batch(ctx, [good, good[:10]], [1.0, 4.0])          # the context still works
+    sc = api.Scan(ctx, good[:100])
+    api.knn3(maps[0], sc, np.array([0, 0, 0, 1.0, 0, 0, 0]), 1.0)
+    idx, d2, valid = sc.download()
+    assert np.array_equal(idx[:, 0], np.arange(100)) and np.all(d2[:, 0] == 0.0)      # every query is a map point
+    for h in maps + [sc]:
+        h.close()
+    ctx.close()
