@@ -28,7 +28,11 @@ __device__ __forceinline__ void param_slots(int mode, int& i0, int& i1, int& i2)
 // (the correspondences — scan point, first neighbour pa, unit plane normal, SoA [3][Q] — are written by the association kernel: knn_kernels.hip)
 // the sums other workgroups added with L2 atomics, read past this CU's L1
 __device__ __forceinline__ double fresh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double clampd(double v) { return fmin(fmax(v, 1e-6), 1e32); }
+// LM damping under Ceres' Jacobi column scaling, in unscaled terms (oracle/robust.h lm_damping): h = H_jj now, h0 = H_jj at iteration 0
+__device__ __forceinline__ double lm_damping(double h, double h0) {
+  const double sj = 1.0 / (1.0 + sqrt(h0)), s2 = sj * sj;
+  return fmin(fmax(h * s2, 1e-6), 1e32) / s2;
+}
 
 // 3x3 damped normal equations; PoseErrorRPZ / PoseErrorYXY prior (pose_error.hpp:135-190): residual_k = w (x_k - x0_k)
 __device__ void icp_step(const IcpArgs& args, IcpDev* dev) {
@@ -43,11 +47,11 @@ __device__ void icp_step(const IcpArgs& args, IcpDev* dev) {
     for (int q = 0; q < 3; ++q) { const double dxp = dev->x[q] - dev->x0[q]; g[q] += w2 * dxp; cost += 0.5 * w2 * dxp * dxp; }
   }
   dev->cost_cur = cost;
-  if (dev->first) { dev->initial_cost = cost; dev->first = 0; if (dev->count_valid) dev->nvalid = (int)fresh(&dev->acc[10]); }
+  if (dev->first) { dev->initial_cost = cost; dev->first = 0; dev->h0[0] = H[0]; dev->h0[1] = H[2]; dev->h0[2] = H[5]; if (dev->count_valid) dev->nvalid = (int)fresh(&dev->acc[10]); }
   const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
   if (gmax <= args.gradient_tolerance || dev->radius < 1e-32) { dev->done = 1; return; }      // top of ceres::Solve's loop: gradient tolerance, smallest trust region
   const double inv_r = 1.0 / dev->radius;
-  const double D0 = clampd(H[0]) * inv_r, D1 = clampd(H[2]) * inv_r, D2 = clampd(H[5]) * inv_r;
+  const double D0 = lm_damping(H[0], dev->h0[0]) * inv_r, D1 = lm_damping(H[2], dev->h0[1]) * inv_r, D2 = lm_damping(H[5], dev->h0[2]) * inv_r;
   // Cholesky of [[a00,.,.],[a10,a11,.],[a20,a21,a22]]
   const double a00 = H[0] + D0, a10 = H[1], a11 = H[2] + D1, a20 = H[3], a21 = H[4], a22 = H[5] + D2;
   const double l00 = sqrt(a00), l10 = a10 / l00, l20 = a20 / l00;

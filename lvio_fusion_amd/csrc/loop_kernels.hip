@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kLT) void k_relocate_solve(int n, const double* __r
   int iters = 0, successes = 0, termination = 1;
   // ceres::Solve's TrustRegionMinimizer order (declared semantics: oracle/lm.h lm_solve; this problem's restatement: oracle/loop.h)
   bool first = true;
+  double h0[3] = {0.0, 0.0, 0.0};
   int invalid_run = 0;
   for (;;) {
     // EigenQuaternionParameterization::ComputeJacobian at q
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(kLT) void k_relocate_solve(int n, const double* __r
 #pragma unroll
     for (int k = 0; k < 6; ++k) h[k] = wg_sum(h[k], red);
     // every thread holds the same sums and takes the same decisions (no divergence across the barriers below)
-    if (first) { initial_cost = cost; first = false; }
+    if (first) { initial_cost = cost; first = false; h0[0] = h[0]; h0[1] = h[2]; h0[2] = h[5]; }      // Jacobi scaling: iteration 0, frozen (oracle/lm.h header)
     if (iters >= o.max_iters) break;
     if (fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))) <= o.gradient_tol) { termination = 0; break; }
     if (radius < 1e-32) { termination = 0; break; }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kLT) void k_relocate_solve(int n, const double* __r
     for (int u = 0; u < 3; ++u) {
 #pragma unroll
       for (int v = 0; v < 3; ++v) A[u][v] = H[u][v];
-      A[u][u] += fmin(fmax(H[u][u], 1e-6), 1e32) / radius;
+      { const double sj = 1.0 / (1.0 + sqrt(h0[u])), s2 = sj * sj; A[u][u] += fmin(fmax(H[u][u] * s2, 1e-6), 1e32) / s2 / radius; }
     }
     const double l00 = sqrt(A[0][0]), l10 = A[1][0] / l00, l20 = A[2][0] / l00;
     const double t11 = A[1][1] - l10 * l10, l11 = sqrt(t11), l21 = (A[2][1] - l20 * l10) / l11;

@@ -35,6 +35,12 @@ struct SpLevels { int n; int first[kSpMaxLevels]; int count[kSpMaxLevels]; };
 // "Early" sparse levels (see Chain::early): the level reads its columns as  B (natural order, what the ImuError factors accumulated) +
 // LM damping + the updates of the levels below (all S holds there), instead of entries k_prepare assembled — so it does not have to wait
 // for k_prepare and can ride in an earlier launch.  B == nullptr: the classic form (S holds the assembled entries).
+// Ceres' Jacobi column scaling (Solver::Options::jacobi_scaling, a default the reference leaves on: backend.cpp:206-211; declared in
+// oracle/lm.h's header): s_j = 1 / (1 + sqrt(H0_jj)) with H0 = diag(J^T J) of the solve's FIRST linearisation, frozen for the solve; the LM
+// diagonal is clamped on the SCALED system, which in unscaled terms is D_jj = clamp(s_j^2 H_jj, 1e-6, 1e32) / s_j^2 (lm_damping).  h0 holds
+// H0 in the natural order [15 n_kf camera unknowns | n_lm inverse depths]; while *frozen == 0 (the first pass of a solve) the kernels that
+// form the damping store H_jj there, afterwards they read it (k_lm_decide raises the flag).
+struct JacobiDev { double* h0; const int* frozen; };
 struct SpSrc {
   const double* B; int ldB, dp; const double* gc; const double* radius; const int* rows_nat;
   // levels CHAINED inside one launch (the Schur complement's: it lasts long enough for three of them): the level waits until `wait_target`
@@ -51,6 +57,7 @@ struct SpSrc {
   int rmw_read;            // diagnostic: chained reads by returning atomics instead of agent-scope loads
   unsigned long long* dbg; // LVF_SP_TIMING=1: eight wall_clock64() stamps per workgroup (tile 0 of every node), else null
   int s_zero;              // the level has nothing below it (level 0, early form): its part of S is still all zeros, not read
+  JacobiDev jac{nullptr, nullptr};
 };
 struct SpArgs {          // one sparse level
   const SpNode* nodes; int first, tiles; const int* rows; double* S; int ld; double* W; int wstride; double* Lout; int* fail; int nblocks; const int* done;
@@ -97,6 +104,7 @@ struct lvf_problem {
   lvf::DevBuf<double> Ldiag;                    // the factored diagonal blocks L_kk [nb][64][64] (NOT stored back into S: see chol_step_body)
   std::vector<int> perm_h;
   lvf::DevBuf<double> B, gc, C, gr, E, Cd, S, dxc, dxl, scal;
+  lvf::DevBuf<double> jh0;                      // Jacobi scaling of the running solve: diag(J^T J) of its first pass (JacobiDev)
   lvf::DevBuf<double> poses2, vel2, ba2, bg2, invd2;   // candidate state x + dx
   lvf::DevBuf<uint8_t> pose_const;
   lvf::DevBuf<int> fail;
@@ -176,6 +184,7 @@ struct LmCtl {
   int accepted, solved;                            // of the last iteration
   int done, termination;                           // done != 0: the remaining launches of this window return immediately
   int why, rejected;                               // LVF_WHY_* reason of the termination ; rejected / invalid steps so far
+  int jfrozen;                                     // Jacobi scaling taken (JacobiDev): 0 until the solve's first pass has been decided on
 };
 
 // lower-triangle accumulation of a 6x6 block pair J_a^T J_b into B at (ra, rb) block offsets (ra >= rb required
@@ -1238,7 +1247,16 @@ __global__ __launch_bounds__(kT) void k_cost_sq(int n, const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ damping / assembly
-__device__ __forceinline__ double clamp_diag(double v) { return fmin(fmax(v, 1e-6), 1e32); }
+__device__ __forceinline__ double lm_damping(double h, double h0) {
+  const double sj = 1.0 / (1.0 + sqrt(h0)), s2 = sj * sj;
+  return fmin(fmax(h * s2, 1e-6), 1e32) / s2;
+}
+// the damping of unknown `slot` whose diagonal entry is h in this pass; the thread that OWNS the entry's assembly records H0 in the first pass
+__device__ __forceinline__ double lm_damping_own(double h, const JacobiDev& j, int slot, int frozen) {
+  double h0 = h;
+  if (frozen) h0 = j.h0[slot]; else j.h0[slot] = h;
+  return lm_damping(h, h0);
+}
 
 // One launch prepares the damped system of a step:
 //   blocks [0, nS_blocks)      : S (lower, in ELIMINATION order: S row I holds unknown iperm[I]) = B (lower, natural order) + Dc on
@@ -1247,7 +1265,7 @@ __device__ __forceinline__ double clamp_diag(double v) { return fmin(fmax(v, 1e-
 //                                produce E^T Cd^-1 g_rho)
 //   block 0 / thread 0         : resets the per-step scalars (candidate cost, model change, norms) and the Cholesky fail flag
 struct PrepArgs {
-  int ld, dpad; const int* iperm; const double *B, *gc; const double* radius; double* S; unsigned nS_blocks; int n_lm, dp, ldE; const double *C, *gr;
+  int ld, dpad, jl0 /* = d: the first landmark slot of jac.h0 */; const int* iperm; const double *B, *gc; const double* radius; double* S; unsigned nS_blocks; int n_lm, dp, ldE; const double *C, *gr;
   double *Cd, *E, *scal; int nblocks; const int* done;
   // atomic-free mode (slotB != nullptr): per-landmark totals from the slot records
   const int *eoff, *kmin, *kmax; const double* slotB; double *Ct, *grt;
@@ -1255,6 +1273,7 @@ struct PrepArgs {
   // corner's entries (rows / columns >= off) are ADDED, and the columns of the sparse blocks are left alone (the levels form them themselves)
   int early, off;
   int own_blocks; SpArgs ride;       // workgroups [own_blocks, nblocks): a sparse level riding in this launch
+  JacobiDev jac;
 };
 __device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs& A) {
   if (bx0 >= (unsigned)A.nblocks || (A.done && *A.done)) return;
@@ -1262,6 +1281,7 @@ __device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs&
   const unsigned bx = bx0 - (unsigned)A.ride.nblocks;
   const int ld = A.ld, dpad = A.dpad; const int* __restrict__ iperm = A.iperm; const double* __restrict__ B = A.B; const double* __restrict__ gc = A.gc;
   const double inv_radius = 1.0 / *A.radius;
+  const int jf = *A.jac.frozen;
   double* __restrict__ S = A.S; const unsigned nS_blocks = A.nS_blocks; const int n_lm = A.n_lm, dp = A.dp, ldE = A.ldE;
   const double* __restrict__ C = A.C; const double* __restrict__ gr = A.gr; double* __restrict__ Cd = A.Cd; double* __restrict__ E = A.E; double* __restrict__ scal = A.scal;
   if (bx == 0 && scal) reset_step_scalars(scal);
@@ -1286,7 +1306,7 @@ __device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs&
       if (live && j0 == 0) {
         const double c = C[l] + v[0], g = gr[l] + v[1];
         A.Ct[l] = c; A.grt[l] = g;
-        Cd[l] = c + clamp_diag(c) * inv_radius;
+        Cd[l] = c + lm_damping_own(c, A.jac, A.jl0 + l, jf) * inv_radius;
         double* el = E + (size_t)l * ldE;
         el[dp] = g;
         if (len > 0) {
@@ -1299,7 +1319,7 @@ __device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs&
     const int l = (bx - nS_blocks) * kT + threadIdx.x;
     if (l >= n_lm) return;
     const double c = C[l];
-    Cd[l] = c + clamp_diag(c) * inv_radius;
+    Cd[l] = c + lm_damping_own(c, A.jac, A.jl0 + l, jf) * inv_radius;
     E[(size_t)l * ldE + dp] = gr[l];
     return;
   }
@@ -1321,7 +1341,7 @@ __device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs&
   if (oi >= 0) {
     if (oj >= 0 && J <= I) {
       v = B[(size_t)max(oi, oj) * dpad + min(oi, oj)];
-      if (I == J) v += clamp_diag(v) * inv_radius;
+      if (I == J) v += lm_damping_own(v, A.jac, oi, jf) * inv_radius;
     }
   } else if (oi == -2) {
     v = (oj >= 0) ? -gc[oj] : (J == I ? 1e300 : 0.0);   // huge corner keeps the augmented matrix positive definite
@@ -2137,10 +2157,11 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
   if (src.B) {
     if (tid < 9) {                         // what k_prepare would have stored in the diagonal block: B + clamp(diag B) / radius
       const double inv_radius = 1.0 / radius;
+      const int jf = *src.jac.frozen;
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
         double b = c <= tid ? src.B[(size_t)(nb0 + tid) * src.ldB + nb0 + c] : 0.0;
-        if (c == tid) b += clamp_diag(b) * inv_radius;
+        if (c == tid) b += lm_damping_own(b, src.jac, nb0 + tid, jf) * inv_radius;      // (every tile workgroup of the node stores the same H0)
         bd[c] = b;
       }
     }
@@ -2659,14 +2680,15 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
                                                 double* __restrict__ poses2, double* __restrict__ vel2, double* __restrict__ ba2,
                                                 double* __restrict__ bg2, double* __restrict__ invd2, double* __restrict__ scal, int d, int ld,
                                                 const double* __restrict__ B, const double* __restrict__ gc, double inv_radius,
-                                                const unsigned char* __restrict__ pose_const) {
+                                                const unsigned char* __restrict__ pose_const, const JacobiDev jac) {
   const int i = vb * kT + threadIdx.x;
   // step_norm / x_norm as Ceres takes them (trust_region_minimizer.cc): |x - x_plus_delta| and |x| over the AMBIENT parameter vector of the
   // reduced program — the quaternion's four coefficients, not its three tangent increments; constant pose blocks are not part of it
   double m = 0.0, n2 = 0.0, g = 0.0, x2 = 0.0;
   if (i < d) {
     const double dx = dxc[i];
-    m = -0.5 * dx * (clamp_diag(B[(size_t)i * ld + i]) * inv_radius * dx - gc[i]);
+    const double h = B[(size_t)i * ld + i];
+    m = -0.5 * dx * (lm_damping(h, *jac.frozen ? jac.h0[i] : h) * inv_radius * dx - gc[i]);      // (first pass: H0 = H, being recorded by the assembly)
     const bool rot = i < 6 * n_kf && (i % 6) < 3;           // rotation increments enter through the quaternion difference below
     n2 = rot ? 0.0 : dx * dx;
     g = fabs(gc[i]);
@@ -2707,12 +2729,12 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
 struct TailArgs {
   int g_lm, n_lm, dp, ldE; const double *E, *C, *Cd, *gr, *dxc; double *dxl, *scal; const int *kmin, *kmax; int n_kf; StateP s;
   double *poses2, *vel2, *ba2, *bg2, *invd2; int d, ld; const double *B, *gc; const double* radius; int nblocks; const int* done;
-  const unsigned char* pose_const;
+  const unsigned char* pose_const; JacobiDev jac;
 };
 __device__ __forceinline__ void step_tail_body(const int bx, const TailArgs& A) {
   if (bx >= A.nblocks || (A.done && *A.done)) return;
   if (bx < A.g_lm) landmark_back_body(bx, A.g_lm, A.n_lm, A.dp, A.ldE, A.E, A.C, A.Cd, A.gr, A.dxc, A.s.inv_depth, A.dxl, A.invd2, A.scal, A.kmin, A.kmax);
-  else apply_step_body(bx - A.g_lm, A.n_kf, 0, A.s, A.dxc, A.dxl, A.poses2, A.vel2, A.ba2, A.bg2, A.invd2, A.scal, A.d, A.ld, A.B, A.gc, 1.0 / *A.radius, A.pose_const);
+  else apply_step_body(bx - A.g_lm, A.n_kf, 0, A.s, A.dxc, A.dxl, A.poses2, A.vel2, A.ba2, A.bg2, A.invd2, A.scal, A.d, A.ld, A.B, A.gc, 1.0 / *A.radius, A.pose_const, A.jac);
 }
 __global__ __launch_bounds__(kT) void k_step_tail(TailArgs a) { step_tail_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_step_tail_b(const TailArgs* __restrict__ t) { step_tail_body(blockIdx.x, t[blockIdx.y]); }
@@ -2826,6 +2848,7 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
     c->cost_before = lc.cost_before; c->cost_after = lc.cost_after; c->model = lc.model; c->dxnorm = lc.dxnorm; c->xnorm = lc.xnorm; c->gmax = lc.gmax;
     c->iter = lc.iter; c->successes = lc.successes; c->invalid_run = lc.invalid_run; c->accepted = lc.accepted; c->solved = lc.solved;
     c->done = lc.done; c->termination = lc.termination; c->why = lc.why; c->rejected = lc.rejected;
+    if (hfail < kFailHandover) c->jfrozen = 1;      // the Jacobi scaling of this solve is the first pass's (a pass that is re-run after a hand-over time-out takes it again)
     s_iter = lc.iter; s_done = lc.done;
     if (A.hist) {                                      // diagnostic: what this pass decided on
       double* h = A.hist + 8 * (it & 63);
@@ -3104,6 +3127,8 @@ static int build_chain(lvf_problem* p) {
   LmCtl* ctl = p->ctl.p;
   const int* done = &ctl->done;
   const double* radius = &ctl->radius;
+  LVF_TRY(p->jh0.ensure((size_t)p->d + p->n_lm + 1));
+  const JacobiDev jac{p->jh0.p, &ctl->jfrozen};
   const StateP s = state_ptrs(p->st);
   const StateP s2{p->poses2.p, p->vel2.p, p->ba2.p, p->bg2.p, p->invd2.p, p->st->w_visual.p};
   double* cost = p->scal.p + SC_COST;
@@ -3176,7 +3201,7 @@ static int build_chain(lvf_problem* p) {
   // damped system
   {
     PrepArgs& a = c.prep;
-    a.ld = p->ld; a.dpad = p->dpad; a.iperm = p->iperm.p; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.S = p->S.p;
+    a.ld = p->ld; a.dpad = p->dpad; a.iperm = p->iperm.p; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.S = p->S.p; a.jac = jac; a.jl0 = p->d;
     // (the lower triangle, folded: prepare_body)
     a.nS_blocks = (unsigned)(((size_t)((p->ld + 1) / 2) * (p->ld + 1) + kT - 1) / kT); a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.C = p->C.p; a.gr = p->gr.p; a.Cd = p->Cd.p; a.E = p->E.p;
     a.eoff = p->lm_eoff.p; a.kmin = p->lm_kmin.p; a.kmax = p->lm_kmax.p; a.slotB = p->compact ? p->slotB.p : nullptr; a.Ct = p->Ct.p; a.grt = p->grt.p;
@@ -3200,6 +3225,7 @@ static int build_chain(lvf_problem* p) {
     static const int chain_fenced = [] { const char* e = std::getenv("LVF_CHAIN_FENCE"); return (e && e[0] == '0') ? 0 : 1; }();
     a.src = c.early ? SpSrc{p->B.p, p->dpad, p->dp, p->gc.p, radius, p->sp_rows_nat.p, nullptr, 0, nullptr, chain_fenced, chain_timeout, p->off, std::getenv("LVF_CHAIN_RMW_READ") ? 1 : 0, nullptr, lv == 0 ? 1 : 0}
                     : SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, chain_fenced, chain_timeout, p->off, 0, nullptr, 0};
+    a.src.jac = jac;
     c.sp_lds[lv] = p->sp_shmem[lv];
   }
   c.merged_level0 = false;
@@ -3269,7 +3295,7 @@ static int build_chain(lvf_problem* p) {
     a.n_lm = p->n_lm; a.dp = p->dp; a.ldE = p->ldE; a.E = p->E.p; a.C = p->compact ? p->Ct.p : p->C.p; a.Cd = p->Cd.p;
     a.gr = p->compact ? p->grt.p : p->gr.p; a.dxc = p->dxc.p; a.dxl = p->dxl.p; a.scal = p->scal.p;
     a.kmin = p->band_ready ? p->lm_kmin.p : nullptr; a.kmax = p->lm_kmax.p; a.n_kf = p->n_kf; a.s = s; a.poses2 = p->poses2.p; a.vel2 = p->vel2.p; a.ba2 = p->ba2.p;
-    a.bg2 = p->bg2.p; a.invd2 = p->invd2.p; a.d = p->d; a.ld = p->dpad; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.nblocks = a.g_lm + grid(p->d); a.done = done; a.pose_const = p->pose_const.p;
+    a.bg2 = p->bg2.p; a.invd2 = p->invd2.p; a.d = p->d; a.ld = p->dpad; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.nblocks = a.g_lm + grid(p->d); a.done = done; a.pose_const = p->pose_const.p; a.jac = jac;
     c.tail_lds = (size_t)p->ldE * sizeof(double);
   }
   fill_cost_visual(p, c.cost.a);

@@ -56,12 +56,12 @@ inline void icp_solve(const float* map, int M, int mstride, const float* query, 
     if (prior_w > 0.0) for (int k = 0; k < 3; ++k) c += 0.5 * w2 * (xx[k] - x0[k]) * (xx[k] - x0[k]);
     return c;
   };
-  auto clampd = [](double v) { return std::fmin(std::fmax(v, 1e-6), 1e32); };
   double radius = 1e4, decrease = 2.0, cost = 0.0;
   out->iters = 0; out->successes = 0; out->nres = nv + (prior_w > 0.0 ? 1 : 0);
   // the loop of ceres::Solve (DENSE_QR, mapping.cpp:159-163), in TrustRegionMinimizer's order — see lm.h lm_solve for the declared semantics
   bool first = true;
   int invalid_run = 0;
+  double h0[3] = {0, 0, 0};      // Jacobi scaling: diag(J^T J) at iteration 0, frozen for the solve (lm.h header, robust.h lm_damping)
   for (;;) {
     double H[3][3] = {}, g[3] = {};
     cost = 0.0;
@@ -75,12 +75,12 @@ inline void icp_solve(const float* map, int M, int mstride, const float* query, 
       for (int u = 0; u < 3; ++u) { g[u] += J[u] * rs; for (int v = 0; v < 3; ++v) H[u][v] += J[u] * J[v]; }
     }
     if (prior_w > 0.0) for (int k = 0; k < 3; ++k) { H[k][k] += w2; g[k] += w2 * (x[k] - x0[k]); cost += 0.5 * w2 * (x[k] - x0[k]) * (x[k] - x0[k]); }
-    if (first) { out->initial_cost = cost; first = false; }
+    if (first) { out->initial_cost = cost; first = false; for (int u = 0; u < 3; ++u) h0[u] = H[u][u]; }
     if (out->iters >= max_iters) break;
     if (std::fmax(std::fabs(g[0]), std::fmax(std::fabs(g[1]), std::fabs(g[2]))) <= 1e-10) break;
     if (radius < 1e-32) break;
     double A[3][3], D[3];
-    for (int u = 0; u < 3; ++u) { D[u] = clampd(H[u][u]) / radius; for (int v = 0; v < 3; ++v) A[u][v] = H[u][v]; A[u][u] += D[u]; }
+    for (int u = 0; u < 3; ++u) { D[u] = lm_damping(H[u][u], h0[u]) / radius; for (int v = 0; v < 3; ++v) A[u][v] = H[u][v]; A[u][u] += D[u]; }
     // 3x3 Cholesky solve A dx = -g
     const double l00 = std::sqrt(A[0][0]), l10 = A[1][0] / l00, l20 = A[2][0] / l00;
     const double t11 = A[1][1] - l10 * l10, l11 = std::sqrt(t11), l21 = (A[2][1] - l20 * l10) / l11;

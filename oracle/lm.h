@@ -8,19 +8,21 @@
 //   * cost = 1/2 sum rho(|r_b|^2); Huber(a) on visual blocks, no loss on ImuError (backend.cpp:98,159);
 //   * Corrector with rho'' <= 0: r_b and J_b scaled by sqrt(rho');
 //   * pose blocks: ProductParameterization(EigenQuaternion, Identity3): J_local = J_ambient * blockdiag(P(q), I3);
-//   * normal equations H = J^T J, g = J^T r; LM diagonal D^2 = clamp(diag H, 1e-6, 1e32);
+//   * normal equations H = J^T J, g = J^T r; LM diagonal D^2 = clamp(diag H, 1e-6, 1e32) taken on the Jacobi-SCALED system (next bullet but one);
 //     step solves (H + D^2 / radius) dx = -g exactly, eliminating the 1x1 inverse-depth blocks first (Schur);
 //   * model_cost_change = -dx^T (g + H dx / 2); rho = (cost - cost_new) / model_cost_change;
 //     accept iff rho > min_relative_decrease (1e-3): radius /= max(1/3, 1 - (2 rho - 1)^3), decrease_factor = 2;
 //     else radius /= decrease_factor, decrease_factor *= 2; an INVALID step (solver failure or model_cost_change <= 0): radius *= 0.5.
 //     The whole loop with Ceres' termination order: lm_solve below.
-//   * DECLARED DIFFERENCE — Jacobi column scaling (a Ceres default) is NOT modelled.  Upstream scales column j of J by s_j = 1 / (1 + sqrt(H0_jj))
-//     (H0 = J^T J of the FIRST iteration, frozen) and clamps the diagonal of the SCALED normal equations: in unscaled terms its damping is
-//     D^2_jj = clamp(s_j^2 H_jj, 1e-6, 1e32) / s_j^2.  Where the clamp is inactive that is H_jj — identical to the line above, and the step is
-//     the same (the scaling is a change of variables).  It differs only in columns with s_j^2 H_jj < 1e-6: there upstream damps with
-//     1e-6 (1 + sqrt(H0_jj))^2 / radius, this file with max(H_jj, 1e-6) / radius.  On every window of tests/ and bench.py all diagonals are
-//     >> 1 (pixels-per-metre Jacobians, IMU information), so neither clamp ever acts; a problem with a near-zero column (an unobserved
-//     direction) would see a slightly different — still tiny — damping.  The GPU follows this file, not upstream, in that corner.
+//   * Jacobi column scaling (Solver::Options::jacobi_scaling, a Ceres default the reference leaves on: backend.cpp:206-211 builds its options
+//     with defaults).  Upstream (trust_region_minimizer.cc, EvaluateGradientAndJacobian): at ITERATION 0 only, s_j = 1 / (1 + sqrt(H0_jj)),
+//     H0_jj = squared norm of column j of the robustified tangent-space Jacobian at the start point; s stays FROZEN for the rest of the
+//     solve; every Jacobian is column-scaled by s before the strategy sees it; levenberg_marquardt_strategy.cc clamps the diagonal of the
+//     SCALED normal equations, diag_j = clamp(s_j^2 H_jj, 1e-6, 1e32), solves (Js^T Js + diag / radius) y = -Js^T r and the minimizer maps the
+//     step back, dx_j = s_j y_j.  Substituting y = dx / s: (H + D^2 / radius) dx = -g with
+//         D^2_jj = clamp(s_j^2 H_jj, 1e-6, 1e32) / s_j^2            (lm_damping below),
+//     i.e. H_jj itself wherever the clamp is inactive and 1e-6 (1 + sqrt(H0_jj))^2 in a near-zero column.  model_cost_change and the
+//     gradient are scale-free (J dx = Js y; the gradient is taken before the columns are scaled).  JacobiScale carries H0 through a solve.
 // Unknown ordering of the reduced (camera) system, d = 15 n_kf:
 //   [ pose tangent 6 x n_kf (keyframe-major) | (v 3, ba 3, bg 3) x n_kf ].
 #pragma once
@@ -277,18 +279,33 @@ inline void apply_step(const Window& w, const std::vector<double>& dc, const std
   for (int l = 0; l < w.n_lm; ++l) inv_depth[l] = w.inv_depth[l] + dl[l];
 }
 
+// Jacobi scaling state of one solve: H0 = diag(J^T J) at iteration 0 (camera part d, landmark part n_lm), frozen once taken.
+// (unscaled_clamp: NOT Ceres — the clamp taken on the unscaled diagonal, max(H_jj, 1e-6): what this file did before the scaling was restated;
+// kept so that a test can show a window on which the two differ)
+struct JacobiScale { std::vector<double> c, l; bool frozen = false; bool unscaled_clamp = false; };
+// (lm_damping: robust.h)
+
 // The trial step of one LM iteration at trust-region radius `radius`: linearise, damp, Schur-eliminate, solve, back-substitute, model
 // cost change, candidate state and its cost.  Nothing is committed.  cand_* receive the candidate (sizes 7/3/3/3 n_kf, n_lm).
+// `js`: the solve's Jacobi scaling (taken from THIS linearisation if not frozen yet); null = a one-iteration solve (H0 = H).
 inline void lm_trial_step(const Window& w, double huber_a, double radius, LmStep& out, std::vector<double>& np, std::vector<double>& nv,
-                          std::vector<double>& nba, std::vector<double>& nbg, std::vector<double>& nd) {
+                          std::vector<double>& nba, std::vector<double>& nbg, std::vector<double>& nd, JacobiScale* js = nullptr) {
   Linearization L;
   window_linearize(w, huber_a, L);
   const int d = L.d, dp = L.dp, nl = w.n_lm;
   const double mu = radius;
-  auto clampd = [](double v) { return std::fmin(std::fmax(v, 1e-6), 1e32); };
+  JacobiScale local;
+  if (!js) js = &local;
+  if (!js->frozen) {
+    js->c.resize(d); js->l.resize(nl);
+    for (int i = 0; i < d; ++i) js->c[i] = L.B[(size_t)i * d + i];
+    for (int l = 0; l < nl; ++l) js->l[l] = L.C[l];
+    js->frozen = true;
+  }
   std::vector<double> Dc(d), Dl(nl), Cd(nl);
-  for (int i = 0; i < d; ++i) Dc[i] = clampd(L.B[(size_t)i * d + i]) / mu;
-  for (int l = 0; l < nl; ++l) { Dl[l] = clampd(L.C[l]) / mu; Cd[l] = L.C[l] + Dl[l]; }
+  auto damp = [&](double h, double h0) { return js->unscaled_clamp ? std::fmin(std::fmax(h, 1e-6), 1e32) : lm_damping(h, h0); };
+  for (int i = 0; i < d; ++i) Dc[i] = damp(L.B[(size_t)i * d + i], js->c[i]) / mu;
+  for (int l = 0; l < nl; ++l) { Dl[l] = damp(L.C[l], js->l[l]) / mu; Cd[l] = L.C[l] + Dl[l]; }
   out.S = L.B;
   for (int i = 0; i < d; ++i) out.S[(size_t)i * d + i] += Dc[i];
   out.rhs.assign(d, 0.0);
@@ -371,9 +388,9 @@ inline void radius_step_rejected(double* radius, double* decrease_factor) { *rad
 inline void radius_step_invalid(double* radius) { *radius *= 0.5; }      // StepIsInvalid: decrease_factor untouched
 
 // One iteration with the radius handed in (no termination tests): the per-iteration parity point of lvf_problem_lm_iteration.
-inline void lm_iteration(Window& w, double huber_a, double min_relative_decrease, double* radius, double* decrease_factor, LmStep& out) {
+inline void lm_iteration(Window& w, double huber_a, double min_relative_decrease, double* radius, double* decrease_factor, LmStep& out, JacobiScale* js = nullptr) {
   std::vector<double> np, nv, nba, nbg, nd;
-  lm_trial_step(w, huber_a, *radius, out, np, nv, nba, nbg, nd);
+  lm_trial_step(w, huber_a, *radius, out, np, nv, nba, nbg, nd, js);
   const bool valid = out.solved && out.model_cost_change > 0.0;
   if (!valid) { radius_step_invalid(radius); return; }
   if (out.rho > min_relative_decrease) {
@@ -398,6 +415,7 @@ inline void lm_iteration(Window& w, double huber_a, double min_relative_decrease
 //   relative_decrease > min_relative_decrease -> accept (x = candidate, re-linearise, StepAccepted) else StepRejected.
 struct SolveOptions {
   int max_num_iterations; double huber_a, initial_trust_region_radius, function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease;
+  bool unscaled_clamp = false;      // test-only: see JacobiScale
 };
 enum { LVO_CONVERGENCE = 0, LVO_NO_CONVERGENCE = 1, LVO_FAILURE = 2 };
 enum { LVO_WHY_NONE = 0, LVO_WHY_GRADIENT = 1, LVO_WHY_PARAMETER = 2, LVO_WHY_FUNCTION = 3, LVO_WHY_MIN_RADIUS = 4, LVO_WHY_MAX_ITERATIONS = 5, LVO_WHY_INVALID_STEPS = 6 };
@@ -415,9 +433,11 @@ inline void lm_solve(Window& w, const SolveOptions& o, SolveSummary& s, double* 
   double cost = 0.0;
   LmStep st;
   std::vector<double> np, nv, nba, nbg, nd;
+  JacobiScale js;            // taken at the first linearisation (iteration 0), frozen for the whole solve
+  js.unscaled_clamp = o.unscaled_clamp;
   for (;;) {
     // (the trial step re-linearises at x: after a rejected step that reproduces the previous linearisation — Ceres keeps it)
-    lm_trial_step(w, o.huber_a, radius, st, np, nv, nba, nbg, nd);
+    lm_trial_step(w, o.huber_a, radius, st, np, nv, nba, nbg, nd, &js);
     if (!have_cost) { s.initial_cost = st.cost_before; have_cost = true; }
     cost = st.cost_before;
     if (s.num_iterations >= o.max_num_iterations) { s.termination = LVO_NO_CONVERGENCE; s.why = LVO_WHY_MAX_ITERATIONS; break; }   // (<= 0: only the initial cost)

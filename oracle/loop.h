@@ -20,7 +20,6 @@ struct RelocOut { double initial_cost, final_cost; int iters, successes, termina
 
 inline void relocate_rotation_solve(int n, const double* relocated, const double* unrelocated, double* q4, int max_iters, double function_tol,
                                     double gradient_tol, double parameter_tol, double min_rel_decrease, double radius0, RelocOut* out) {
-  auto clampd = [](double v) { return std::fmin(std::fmax(v, 1e-6), 1e32); };
   auto cost_at = [&](const double* q) {
     double c = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -36,6 +35,7 @@ inline void relocate_rotation_solve(int n, const double* relocated, const double
   // ceres::Solve's TrustRegionMinimizer order (declared in lm.h lm_solve)
   bool first = true;
   int invalid_run = 0;
+  double h0[3] = {0, 0, 0};      // Jacobi scaling: diag(J^T J) at iteration 0, frozen for the solve (lm.h header, robust.h lm_damping)
   for (;;) {
     double H[3][3] = {}, g[3] = {};
     cost = 0.0;
@@ -52,12 +52,12 @@ inline void relocate_rotation_solve(int n, const double* relocated, const double
         for (int u = 0; u < 3; ++u) { g[u] += Jl[u] * rr[k].a; for (int v = 0; v < 3; ++v) H[u][v] += Jl[u] * Jl[v]; }
       }
     }
-    if (first) { out->initial_cost = cost; first = false; }
+    if (first) { out->initial_cost = cost; first = false; for (int u = 0; u < 3; ++u) h0[u] = H[u][u]; }
     if (out->iters >= max_iters) break;                               // NO_CONVERGENCE (termination stays 1)
     if (std::fmax(std::fabs(g[0]), std::fmax(std::fabs(g[1]), std::fabs(g[2]))) <= gradient_tol) { out->termination = 0; break; }
     if (radius < 1e-32) { out->termination = 0; break; }              // "minimum trust region radius reached" is a CONVERGENCE in Ceres
     double A[3][3], D[3];
-    for (int u = 0; u < 3; ++u) { D[u] = clampd(H[u][u]) / radius; for (int v = 0; v < 3; ++v) A[u][v] = H[u][v]; A[u][u] += D[u]; }
+    for (int u = 0; u < 3; ++u) { D[u] = lm_damping(H[u][u], h0[u]) / radius; for (int v = 0; v < 3; ++v) A[u][v] = H[u][v]; A[u][u] += D[u]; }
     const double l00 = std::sqrt(A[0][0]), l10 = A[1][0] / l00, l20 = A[2][0] / l00;
     const double t11 = A[1][1] - l10 * l10, l11 = std::sqrt(t11), l21 = (A[2][1] - l20 * l10) / l11;
     const double t22 = A[2][2] - l20 * l20 - l21 * l21, l22 = std::sqrt(t22);

@@ -327,24 +327,37 @@ double lvo_window_linearize(const lvo_window_c* c, double huber_a, double* B, do
 }
 // out6 = {cost_before, cost_after, model_cost_change, rho, accepted, solved}; S[d*d], rhs[d] optional taps.
 // The state arrays inside c are updated in place when the step is accepted; radius/decrease_factor are updated.
-void lvo_window_lm_iteration(lvo_window_c* c, double huber_a, double min_relative_decrease, double* radius,
-                             double* decrease_factor, double* out6, double* S, double* rhs) {
+// h0 (may be null: a one-iteration solve, H0 = this linearisation's diagonal): the solve's Jacobi scaling state, 15 n_kf + n_lm doubles of
+// diag(J^T J) at iteration 0; *frozen == 0 -> taken from this linearisation and written back with *frozen = 1 (lm.h JacobiScale).
+void lvo_window_lm_iteration_js(lvo_window_c* c, double huber_a, double min_relative_decrease, double* radius,
+                                double* decrease_factor, double* out6, double* S, double* rhs, double* h0, int* frozen) {
   Window w; std::vector<imu::Preint> pre; to_window(c, w, pre);
   LmStep st;
-  lm_iteration(w, huber_a, min_relative_decrease, radius, decrease_factor, st);
+  JacobiScale js;
+  const int d = 15 * w.n_kf;
+  if (h0 && frozen && *frozen) { js.c.assign(h0, h0 + d); js.l.assign(h0 + d, h0 + d + w.n_lm); js.frozen = true; }
+  lm_iteration(w, huber_a, min_relative_decrease, radius, decrease_factor, st, h0 ? &js : nullptr);
+  if (h0 && frozen && !*frozen && js.frozen) { std::memcpy(h0, js.c.data(), 8 * (size_t)d); std::memcpy(h0 + d, js.l.data(), 8 * (size_t)w.n_lm); *frozen = 1; }
   out6[0] = st.cost_before; out6[1] = st.cost_after; out6[2] = st.model_cost_change; out6[3] = st.rho;
   out6[4] = st.accepted ? 1.0 : 0.0; out6[5] = st.solved ? 1.0 : 0.0;
   if (S) std::memcpy(S, st.S.data(), st.S.size() * 8);
   if (rhs) std::memcpy(rhs, st.rhs.data(), st.rhs.size() * 8);
 }
 
+void lvo_window_lm_iteration(lvo_window_c* c, double huber_a, double min_relative_decrease, double* radius,
+                             double* decrease_factor, double* out6, double* S, double* rhs) {
+  lvo_window_lm_iteration_js(c, huber_a, min_relative_decrease, radius, decrease_factor, out6, S, rhs, nullptr, nullptr);
+}
+
 // The whole solve (lm.h lm_solve: Ceres' TrustRegionMinimizer loop restated).  opts7 = {max_num_iterations, huber_a, initial radius,
 // function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease}; out9 = {initial_cost, final_cost, num_iterations,
 // num_successful_steps, num_unsuccessful_steps, termination, why, final_radius, final_decrease_factor, num_trials}; trace (may be null): 6 doubles
 // per trial step, max_num_iterations + 1 rows.  The state arrays inside c are updated in place.
+// opts7[7] (an EIGHTH value) != 0: the pre-round-5 damping (clamp on the unscaled diagonal) — test-only, see lm.h JacobiScale
 void lvo_window_solve(lvo_window_c* c, const double* opts7, double* out9 /* 10 values */, double* trace) {
   Window w; std::vector<imu::Preint> pre; to_window(c, w, pre);
   SolveOptions o{(int)opts7[0], opts7[1], opts7[2], opts7[3], opts7[4], opts7[5], opts7[6]};
+  o.unscaled_clamp = opts7[7] != 0.0;
   SolveSummary s;
   lm_solve(w, o, s, trace);
   out9[0] = s.initial_cost; out9[1] = s.final_cost; out9[2] = s.num_iterations; out9[3] = s.num_successful_steps; out9[4] = s.num_unsuccessful_steps;

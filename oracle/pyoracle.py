@@ -476,22 +476,30 @@ class Window:
         cost = lib().lvo_window_linearize(C.byref(self.c), C.c_double(huber_a), _p(B), _p(gc), _p(E), _p(Cc), _p(gr))
         return dict(cost=cost, B=B, gc=gc, E=E, C=Cc, gr=gr)
 
-    def lm_iteration(self, radius, decrease_factor=2.0, huber_a=1.0, min_relative_decrease=1e-3):
+    def lm_iteration(self, radius, decrease_factor=2.0, huber_a=1.0, min_relative_decrease=1e-3, jacobi=None):
+        """one LM iteration at the radius handed in.  `jacobi`: None = a one-iteration solve (Jacobi scaling from this linearisation);
+        a dict (start with {}) = the scaling state of a chain of calls that restates ONE ceres::Solve: taken at the first call, frozen after."""
         r, dfac = C.c_double(radius), C.c_double(decrease_factor)
         out6 = np.empty(6); S = np.empty((self.d, self.d)); rhs = np.empty(self.d)
-        lib().lvo_window_lm_iteration(C.byref(self.c), C.c_double(huber_a), C.c_double(min_relative_decrease), C.byref(r), C.byref(dfac),
-                                      _p(out6), _p(S), _p(rhs))
+        if jacobi is None:
+            h0p, frp = None, None
+        else:
+            jacobi.setdefault("h0", np.zeros(self.d + self.n_lm)); jacobi.setdefault("frozen", C.c_int(0))
+            h0p, frp = _p(jacobi["h0"]), C.byref(jacobi["frozen"])
+        lib().lvo_window_lm_iteration_js(C.byref(self.c), C.c_double(huber_a), C.c_double(min_relative_decrease), C.byref(r), C.byref(dfac),
+                                         _p(out6), _p(S), _p(rhs), h0p, frp)
         return dict(cost_before=out6[0], cost_after=out6[1], model_cost_change=out6[2], rho=out6[3], accepted=bool(out6[4]),
                     solved=bool(out6[5]), radius=r.value, decrease_factor=dfac.value, S=S, rhs=rhs)
 
     WHY = ("none", "gradient_tolerance", "parameter_tolerance", "function_tolerance", "min_trust_region_radius", "max_num_iterations", "consecutive_invalid_steps")
 
     def solve(self, max_num_iterations=50, huber_a=1.0, initial_trust_region_radius=1e4, function_tolerance=1e-6, gradient_tolerance=1e-10,
-              parameter_tolerance=1e-8, min_relative_decrease=1e-3):
+              parameter_tolerance=1e-8, min_relative_decrease=1e-3, unscaled_clamp=False):
         """ceres::Solve's TrustRegionMinimizer loop restated (oracle/lm.h lm_solve): chained trial steps with ITS radius / decrease factor
         and Ceres' termination order.  The state arrays of this Window are updated in place.  trace rows: (cost_before, cost_after,
         radius used, accepted, valid, rho)."""
-        opts = _f64([max_num_iterations, huber_a, initial_trust_region_radius, function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease])
+        opts = _f64([max_num_iterations, huber_a, initial_trust_region_radius, function_tolerance, gradient_tolerance, parameter_tolerance, min_relative_decrease,
+                     1.0 if unscaled_clamp else 0.0])      # (unscaled_clamp: test-only, NOT Ceres — oracle/lm.h JacobiScale)
         out = np.zeros(10); trace = np.zeros((max(0, int(max_num_iterations)) + 1, 6))
         lib().lvo_window_solve(C.byref(self.c), _p(opts), _p(out), _p(trace))
         n = int(out[9])

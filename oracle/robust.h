@@ -65,4 +65,11 @@ inline void pose_jac_to_local(const double pose[7], int rows, const double* J7, 
   }
 }
 
+// Levenberg-Marquardt damping of unknown j under Ceres' Jacobi column scaling (declared in lm.h's header), in UNSCALED terms:
+// clamp(s^2 h, 1e-6, 1e32) / s^2 with s = 1 / (1 + sqrt(h0)); h = H_jj of this linearisation, h0 = H_jj at iteration 0 of the solve.
+inline double lm_damping(double h, double h0) {
+  const double s = 1.0 / (1.0 + std::sqrt(h0)), s2 = s * s;
+  return std::fmin(std::fmax(h * s2, 1e-6), 1e32) / s2;
+}
+
 }  // namespace lvo

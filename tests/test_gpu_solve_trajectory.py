@@ -97,6 +97,66 @@ def test_device_loop_equals_oracle_chain(ctx, oracle, n_kf, n_lm, seed, K):
     close(w)
 
 
+def weak_window(n_kf=8, n_lm=300, seed=5, w_weak=4e-7):
+    """A window with NEAR-ZERO columns: the last keyframe's visual weight is ~0, so the landmarks born there (seen by their TwoCamera
+    block only, weight 5 w) have C_l = (5 w dpx/drho)^2 < 1e-6, and their inverse depths start 50 % off so that the columns carry a
+    gradient.  There Ceres' clamp acts on the Jacobi-SCALED diagonal: damping 1e-6 (1 + sqrt(H0_jj))^2 / radius instead of
+    max(H_jj, 1e-6) / radius (oracle/lm.h header).  With a small trust region the two give different iterates."""
+    cfg = dict(syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=40, seed=seed, imu_samples=5))
+    cfg["w_kf"] = np.array(cfg["w_kf"], dtype=np.float64).copy(); cfg["w_kf"][-1] = w_weak
+    born_last = cfg["tc"]["lm_idx"][cfg["tc"]["kf_idx"] == n_kf - 1]
+    cfg["inv_depth"] = np.array(cfg["inv_depth"], dtype=np.float64).copy(); cfg["inv_depth"][born_last] *= 1.5
+    return cfg, born_last
+
+
+@pytest.mark.parametrize("radius,K", [(1e-5, 12), (1e-6, 12)])
+def test_near_zero_columns_take_ceres_jacobi_scaled_damping(ctx, oracle, radius, K):
+    """the device loop follows Ceres' Jacobi column scaling (s_j = 1 / (1 + sqrt(H0_jj)) frozen at iteration 0, clamp on
+    the scaled diagonal) — on a window where that differs from a clamp on the unscaled diagonal by 100x the parity tolerance."""
+    from lvio_fusion_amd import api
+    cfg, born_last = weak_window()
+    w = make(api, ctx, oracle, cfg["n_kf"], cfg["n_lm"], 5, cfg=cfg)
+    o = options(api, max_num_iterations=K, initial_trust_region_radius=radius)
+    ref = w["win"].solve(**okw(o))
+    # the case discriminates: the pre-round-5 damping lands somewhere else
+    pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+    old = oracle.Window(cfg, pre)
+    old.solve(unscaled_clamp=True, **okw(o))
+    gap = np.abs(old.inv_depth - w["win"].inv_depth)[born_last] / np.abs(w["win"].inv_depth[born_last])
+    assert gap.max() > 1e-5, f"the window no longer tells the scaled clamp from the unscaled one ({gap.max():.2e})"
+    s = w["prob"].solve(o)
+    check(api, w, s, ref, f"weak last keyframe, radius {radius:g}")
+    got = np.asarray(w["st"].get(api.INV_DEPTH))[born_last]
+    assert np.abs(got - w["win"].inv_depth[born_last]).max() <= 1e-6 * np.abs(got).max()
+    assert np.abs(got - old.inv_depth[born_last]).max() > 10e-6 * np.abs(got).max(), "the device follows the UNSCALED clamp"
+    close(w)
+
+
+def test_near_zero_columns_batched_and_per_iteration(ctx, oracle):
+    """the same corner through the batched loop (tables) and through the per-iteration entry point (one-iteration solves: the scaling is
+    retaken at every call, as chained one-iteration ceres::Solve calls would)"""
+    from lvio_fusion_amd import api
+    cfg, born_last = weak_window()
+    ws = [make(api, ctx, oracle, cfg["n_kf"], cfg["n_lm"], 5, cfg=cfg) for _ in range(2)] + [make(api, ctx, oracle, 8, 300, 6)]
+    o = options(api, max_num_iterations=8, initial_trust_region_radius=1e-5)
+    b = api.ProblemBatch(ctx, [w["prob"] for w in ws])
+    ss = b.solve(o)
+    for i, w in enumerate(ws):
+        check(api, w, ss[i], w["win"].solve(**okw(o)), f"batched weak window {i}")
+    b.close()
+    close(*ws)
+    w = make(api, ctx, oracle, cfg["n_kf"], cfg["n_lm"], 5, cfg=cfg)
+    r, d = 1e-5, 2.0
+    for it in range(4):
+        g = w["prob"].lm_iteration(options(api), r, d)
+        ref = w["win"].lm_iteration(r, d)
+        assert abs(g["cost_after"] - ref["cost_after"]) <= 1e-6 * abs(ref["cost_after"]) and bool(g["accepted"]) == ref["accepted"], (it, g, ref["cost_after"])
+        r, d = ref["radius"], ref["decrease_factor"]
+        got = np.asarray(w["st"].get(api.INV_DEPTH))[born_last]
+        assert np.abs(got - w["win"].inv_depth[born_last]).max() <= 1e-6 * np.abs(got).max(), it
+    close(w)
+
+
 @pytest.mark.parametrize("perturb,radius,seed", [(20.0, 1e16, 5), (20.0, 1e4, 5), (30.0, 1e10, 9)])
 def test_rejected_steps_follow_the_oracle(ctx, oracle, perturb, radius, seed):
     """Far starts: several steps are rejected (radius / decrease_factor, decrease_factor doubling) before the loop recovers; every later

@@ -83,23 +83,44 @@ def cost_only(oracle, cfg, pre, state, huber_a=1.0):
     return dense_system(oracle, cfg, pre, state, huber_a)[2]
 
 
-@pytest.mark.parametrize("n_kf,n_lm,seed", [(5, 40, 101), (7, 90, 202)])
-def test_lm_iteration_matches_dense_numpy_solve(oracle, n_kf, n_lm, seed):
+def weak_last_keyframe(cfg, w=2e-7):
+    """The window with a NEAR-ZERO column: the last keyframe's visual weight is ~0, so a landmark born there (seen by its TwoCamera block
+    only, weight 5 w) has C_l = (5 w dpx/drho)^2 << 1e-6 — the corner where Ceres' Jacobi-scaled diagonal clamp and a clamp on the unscaled
+    diagonal damp differently (oracle/lm.h header)."""
+    cfg = dict(cfg); cfg["w_kf"] = np.array(cfg["w_kf"], dtype=np.float64).copy(); cfg["w_kf"][-1] = w
+    return cfg
+
+
+@pytest.mark.parametrize("n_kf,n_lm,seed,weak", [(5, 40, 101, False), (7, 90, 202, False), (6, 60, 303, True)])
+def test_lm_iteration_matches_dense_numpy_solve(oracle, n_kf, n_lm, seed, weak):
+    """The numpy side follows Ceres LITERALLY (trust_region_minimizer.cc / levenberg_marquardt_strategy.cc): Jacobi scaling s = 1 / (1 + |J_j|)
+    taken at iteration 0 and frozen, the Jacobian column-scaled, the diagonal of the SCALED normal equations clamped to [1e-6, 1e32], the
+    scaled system solved and the step mapped back dx = s y; lm.h states the same in unscaled terms (lm_damping)."""
     cfg = syn.config4_window(n_kf=n_kf, n_lm=n_lm, n_prewindow=20, seed=seed, imu_samples=4)
+    if weak:
+        cfg = weak_last_keyframe(cfg)
     pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
     win = oracle.Window(cfg, pre)
     state = [np.array(cfg[k], dtype=np.float64) for k in ("poses", "vel", "ba", "bg", "inv_depth")]
-    radius, dec = 1e4, 2.0
-    clampd = lambda v: np.minimum(np.maximum(v, 1e-6), 1e32)
+    radius, dec = (1.0 if weak else 1e4), 2.0
     seen_reject = False
+    jac_scale, js_state, clamp_active = None, {}, 0
     for it in range(5):
         if it == 3:
             radius = 1e-3 * radius      # a tiny region after a few accepted steps, to visit the damping-dominated regime too
         J, r, cost = dense_system(oracle, cfg, pre, state)
+        if jac_scale is None:
+            jac_scale = 1.0 / (1.0 + np.sqrt((J * J).sum(axis=0)))
+        Js = J * jac_scale
         H, g = J.T @ J, J.T @ r
-        D = clampd(np.diag(H)) / radius
-        dx = np.linalg.solve(H + np.diag(D), -g)
-        model = -dx @ (g + 0.5 * H @ dx)
+        Hs, gs = Js.T @ Js, Js.T @ r
+        diag = np.minimum(np.maximum(np.diag(Hs), 1e-6), 1e32)
+        live = (J * J).sum(axis=0) > 0          # (columns of constant blocks are not in Ceres' program; here they are zero columns)
+        clamp_active += int(((np.diag(Hs) < 1e-6) & live).sum())
+        y = np.linalg.solve(Hs + np.diag(diag / radius), -gs)
+        dx = jac_scale * y
+        model = -(Js @ y) @ (r + 0.5 * (Js @ y))
+        D = diag / jac_scale ** 2 / radius       # the same damping in unscaled terms
         new = [s.copy() for s in state]
         for k in range(n_kf):
             new[0][k, :4] = quat_plus(state[0][k, :4], dx[6 * k:6 * k + 3]); new[0][k, 4:] += dx[6 * k + 3:6 * k + 6]
@@ -108,7 +129,7 @@ def test_lm_iteration_matches_dense_numpy_solve(oracle, n_kf, n_lm, seed):
         new[4] = state[4] + dx[15 * n_kf:]
         cand = cost_only(oracle, cfg, pre, new)
         rho = (cost - cand) / model
-        ref = win.lm_iteration(radius, dec)
+        ref = win.lm_iteration(radius, dec, jacobi=js_state)
         assert abs(ref["cost_before"] - cost) <= 1e-10 * cost
         assert abs(ref["model_cost_change"] - model) <= 1e-7 * abs(model)
         assert abs(ref["cost_after"] - cand) <= 1e-7 * cand
@@ -131,6 +152,32 @@ def test_lm_iteration_matches_dense_numpy_solve(oracle, n_kf, n_lm, seed):
         for a, b in zip(state, (win.poses, win.vel, win.ba, win.bg, win.inv_depth)):
             assert np.abs(a - b).max() <= 1e-8 * max(1.0, np.abs(b).max())
     assert it == 4
+    assert (clamp_active > 0) == weak, "the weak-keyframe window is there to make the scaled-diagonal clamp act; the others must not touch it"
+
+
+def test_jacobi_scaled_clamp_differs_from_unscaled_clamp(oracle):
+    """In a near-zero column upstream damps with 1e-6 (1 + sqrt(H0_jj))^2 / radius, a clamp on the UNSCALED diagonal with max(H_jj, 1e-6) /
+    radius: the weak-keyframe window must tell the two apart (otherwise the test above could not either)."""
+    cfg = weak_last_keyframe(syn.config4_window(n_kf=6, n_lm=60, n_prewindow=20, seed=303, imu_samples=4))
+    pre = np.stack([oracle.imu_preintegrate(f["samples"], f["acc0"], f["gyr0"], f["ba"], f["bg"], syn.IMU_NOISE) for f in cfg["imu"]])
+    state = [np.array(cfg[k], dtype=np.float64) for k in ("poses", "vel", "ba", "bg", "inv_depth")]
+    J, r, _ = dense_system(oracle, cfg, pre, state)
+    H, g = J.T @ J, J.T @ r
+    h = np.diag(H)
+    weak = (h > 0) & (h < 1e-6)
+    assert weak.sum() >= 1
+    s2 = 1.0 / (1.0 + np.sqrt(h)) ** 2
+    d_up = np.minimum(np.maximum(h * s2, 1e-6), 1e32) / s2
+    d_old = np.minimum(np.maximum(h, 1e-6), 1e32)
+    assert np.all(d_up[weak] > d_old[weak] * (1 + 1e-5)) and np.allclose(d_up[~weak & (h > 1e-3)], d_old[~weak & (h > 1e-3)], rtol=1e-12)
+    radius = 1e-2
+    dx_up = np.linalg.solve(H + np.diag(d_up / radius), -g); dx_old = np.linalg.solve(H + np.diag(d_old / radius), -g)
+    assert np.abs(dx_up[weak] - dx_old[weak]).max() > 1e-5 * np.abs(dx_up[weak]).max()
+    ref = oracle.Window(cfg, pre).lm_iteration(radius, 2.0)
+    d = 15 * cfg["n_kf"]
+    A = H + np.diag(d_up / radius)
+    S = A[:d, :d] - A[:d, d:] @ np.diag(1.0 / np.diag(A[d:, d:])) @ A[d:, :d]
+    assert np.abs(ref["S"] - S).max() <= 1e-9 * np.abs(S).max()
 
 
 @pytest.mark.parametrize("mode,huber_a,prior_w", [(0, 0.0, 0.0), (1, 0.1, 0.0), (0, 0.0, 50.0), (1, 0.1, 30.0)])
@@ -163,15 +210,18 @@ def test_icp_solve_matches_numpy_lm(oracle, mode, huber_a, prior_w):
     # ceres::Solve's TrustRegionMinimizer order (declared in oracle/lm.h lm_solve): the iteration cap, the gradient and the smallest radius
     # at the top; invalid step -> radius / 2; parameter then function tolerance BEFORE the step-quality test (the candidate is not taken)
     radius, dec, iters, succ, invalid = 1e4, 2.0, 0, 0, 0
-    first_cost = None
+    first_cost, jac_scale = None, None
     while True:
         J, r, cost = lin(x)
         first_cost = cost if first_cost is None else first_cost
         H, g = J.T @ J, J.T @ r
         if iters >= 4 or np.abs(g).max() <= 1e-10 or radius < 1e-32:
             break
-        D = np.minimum(np.maximum(np.diag(H), 1e-6), 1e32) / radius
-        dx = np.linalg.solve(H + np.diag(D), -g)
+        if jac_scale is None:              # Jacobi scaling: iteration 0, frozen (Ceres default, also under DENSE_QR)
+            jac_scale = 1.0 / (1.0 + np.sqrt(np.diag(H)))
+        Hs = H * np.outer(jac_scale, jac_scale)
+        D = np.minimum(np.maximum(np.diag(Hs), 1e-6), 1e32) / radius
+        dx = jac_scale * np.linalg.solve(Hs + np.diag(D), -jac_scale * g)
         model = -dx @ (g + 0.5 * H @ dx)
         if not model > 0:
             iters += 1; invalid += 1
@@ -221,9 +271,9 @@ def test_solve_loop_is_the_chain_of_iterations(oracle, perturb, radius):
     K = 25
     s = a.solve(max_num_iterations=K, initial_trust_region_radius=radius, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
     assert s["num_iterations"] == K and s["why"] == "max_num_iterations" and s["termination"] == 1
-    r, d, acc = radius, 2.0, []
+    r, d, acc, js = radius, 2.0, [], {}      # js: ONE solve's Jacobi scaling, taken by the first call and frozen
     for k in range(K):
-        o = b.lm_iteration(r, d)
+        o = b.lm_iteration(r, d, jacobi=js)
         close = lambda x, y: abs(x - y) <= 1e-11 * abs(y)           # (OpenMP reductions: the cost sums are not bit-reproducible run to run)
         assert close(o["cost_before"], s["trace"][k, 0]) and close(o["cost_after"], s["trace"][k, 1]) and close(r, s["trace"][k, 2]) and o["accepted"] == bool(s["trace"][k, 3])
         acc.append(o["accepted"]); r, d = o["radius"], o["decrease_factor"]
