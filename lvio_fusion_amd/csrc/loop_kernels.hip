@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kLT) void k_relocate_solve(int n, const double* __r
 #pragma unroll
     for (int k = 0; k < 6; ++k) h[k] = wg_sum(h[k], red);
     // every thread holds the same sums and takes the same decisions (no divergence across the barriers below)
-    if (first) { initial_cost = cost; first = false; h0[0] = h[0]; h0[1] = h[2]; h0[2] = h[5]; }      // Jacobi scaling: iteration 0, frozen (oracle/lm.h header)
+    if (first) { initial_cost = cost; first = false; h0[0] = h[0]; h0[1] = h[2]; h0[2] = h[5]; }      // Jacobi scaling: iteration 0, frozen (Ceres default jacobi_scaling; relocator.cpp:259 solves with default options)
     if (iters >= o.max_iters) break;
     if (fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))) <= o.gradient_tol) { termination = 0; break; }
     if (radius < 1e-32) { termination = 0; break; }

@@ -24,7 +24,7 @@ struct IcpDev {
   int invalid_run;           // consecutive invalid steps (solver failure or model_cost_change <= 0): 5 end the solve
   unsigned ticket;           // workgroups that have finished the running k_icp_eval (the last one does the scalar tail)
   int count_valid;           // 1: nvalid is taken from acc[10] by the first step (batched chain: nobody else counts)
-  double h0[3];              // Jacobi scaling of this solve: diag(J^T J) at its first linearisation, frozen (Ceres default; oracle/lm.h header, oracle/icp.h)
+  double h0[3];              // Jacobi scaling of this solve: diag(J^T J) at its first linearisation, frozen (Ceres default jacobi_scaling; mapping.cpp:159-163 solves with default options)
 };
 
 struct IcpArgs {
