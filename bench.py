@@ -531,7 +531,7 @@ def icp_leg(api, syn, ctx, verified):
         ms = ctx.timer_ms() / reps
         stats = np.zeros((Q, 6), np.int32); lv = np.zeros((8, 4), np.float32); nl = C.c_int()
         pose = np.ascontiguousarray(c3["pose0"], dtype=np.float64)
-        api._chk(ctx.L.lvf_knn3_debug_stats(mp.h, sc.h, pose.ctypes.data_as(_lib.c_double_p), float(thr), stats.ctypes.data_as(_lib.c_int_p),
+        api._chk(ctx.L.lvf_knn3_debug_stats2(mp.h, sc.h, pose.ctypes.data_as(_lib.c_double_p), float(thr), stats.ctypes.data_as(_lib.c_int_p), 6,
                                             lv.ctypes.data_as(_lib.c_float_p), C.byref(nl)))
         cand = float(stats[:, 0].sum())
         api.knn3(mp, sc, c3["pose0"], thr)

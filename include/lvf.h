@@ -215,11 +215,20 @@ int lvf_scan_destroy(lvf_scan* s);
  * exact 3-NN of every point. */
 int lvf_knn3(lvf_map* m, lvf_scan* s, const double* pose, float thr);
 int lvf_scan_download(lvf_scan* s, int32_t* idx3, float* d2_3, uint8_t* valid);
-/* Diagnostic only: per-point search statistics stats6[Q][6] = {candidates, range lookups, last grid level, shells, start, end}
- * (start / end: the 100 MHz wall clock when the point's wave began and finished, low 31 bits) and the grid pyramid levels4[L][4] = {cell, nx, ny, nz}; the caller provides room for 8 levels (the pyramid halves the cell
- * per level, at most 8 levels). */
-int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* s, const double* pose, float thr, int32_t* stats6, float* levels4,
+/* Diagnostic only: per-point search statistics and the grid pyramid levels4[L][4] = {cell, nx, ny, nz}; the caller provides room for 8
+ * levels (the pyramid halves the cell per level, at most 8 levels).
+ *   lvf_knn3_debug_stats : stats4[Q][4] = {candidates, range lookups, last grid level, shells}.
+ *   lvf_knn3_debug_stats2: stats[Q][stride], 4 <= stride <= 6, the same four + {start, end} (the 100 MHz wall clock when the point's wave
+ *                          began and finished, low 31 bits).  The record width is an ARGUMENT: it grew once under a fixed name. */
+int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* s, const double* pose, float thr, int32_t* stats4, float* levels4,
                          int* n_levels);
+int lvf_knn3_debug_stats2(lvf_map* m, lvf_scan* s, const double* pose, float thr, int32_t* stats, int stride, float* levels4,
+                          int* n_levels);
+
+/* Test hook: the stable (key, value) pair sort under lvf_cloud_voxel_filter on host arrays; only the low key_bits bits of a key order the
+ * pairs, equal keys keep their input order.  Not part of the reference surface. */
+int lvf_debug_sort_pairs_u32(lvf_ctx* ctx, const uint32_t* keys, const int32_t* vals, int n, int key_bits, uint32_t* keys_out,
+                             int32_t* vals_out);
 
 /* ---- map-cloud maintenance on device (the steps immediately before the association) ------------- */
 /* A cloud is n x (x, y, z, intensity) float32 in HBM (pcl::PointXYZI payload).  points: strided host records, xyz at the

@@ -167,6 +167,8 @@ _SIGS = {
     "lvf_knn3": (C.c_int, [_VP, _VP, c_double_p, C.c_float]),
     "lvf_scan_download": (C.c_int, [_VP, c_int_p, c_float_p, c_u8_p]),
     "lvf_knn3_debug_stats": (C.c_int, [_VP, _VP, c_double_p, C.c_float, c_int_p, c_float_p, C.POINTER(C.c_int)]),
+    "lvf_debug_sort_pairs_u32": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP]),
+    "lvf_knn3_debug_stats2": (C.c_int, [_VP, _VP, c_double_p, C.c_float, c_int_p, C.c_int, c_float_p, C.POINTER(C.c_int)]),
     "lvf_icp_solve": (C.c_int, [_VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(IcpOptions), C.POINTER(IcpSummary)]),
     "lvf_cloud_create": (C.c_int, [_VP, c_float_p, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
     "lvf_cloud_destroy": (C.c_int, [_VP]),

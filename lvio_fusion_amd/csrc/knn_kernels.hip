@@ -723,9 +723,10 @@ int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats,
 // call makes per map — once for the bounding box, once per grid level for its occupancy — are shared: one wait for all boxes, one per
 // ROUND of levels (every map that still grows builds its next level in the round).  16 maps: 64 stream waits become 4.
 int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const int* M, int stride_floats, const float* max_radius2, lvf_map** out) {
+  if (out && n > 0) for (int i = 0; i < n; ++i) out[i] = nullptr;
   LVF_REQUIRE(ctx && out && (n == 0 || (map_xyz && M && max_radius2)) && n >= 0 && stride_floats >= 3, "lvf_map_create_batch: bad arguments");
+  for (int i = 0; i < n; ++i) out[i] = nullptr;      // (before any check that can return: "NULL for all i on error" holds on every path)
   for (int i = 0; i < n; ++i) {
-    out[i] = nullptr;
     LVF_REQUIRE(M[i] >= 0 && (M[i] == 0 || map_xyz[i]), "lvf_map_create_batch: bad cloud %d (M=%d)", i, M[i]);
     LVF_REQUIRE(max_radius2[i] > 0.0f && std::isfinite(max_radius2[i]), "lvf_map_create_batch: max_radius2[%d] must be finite > 0", i);
   }
@@ -876,7 +877,18 @@ int lvf_scan_destroy(lvf_scan* s) { delete s; return LVF_OK; }      // (~lvf_sca
 
 // diagnostic (not part of the reference surface): per-query search statistics {candidates, range lookups, last level,
 // shells}, and the grid pyramid geometry {cell, nx, ny, nz} per level.
-int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* sc, const double* pose, float thr, int32_t* stats6, float* levels4, int* n_levels) {
+// lvf_knn3_debug_stats2: `stride` int32 per query, 4 <= stride <= 6: {candidates, range lookups, last level, shells[, wave start, wave end clock]}.
+// lvf_knn3_debug_stats keeps its round-3 contract ([Q][4]): the record grew to six fields in round 4 under the old name, which overran a
+// caller's [Q][4] buffer.
+static int knn3_debug_stats_impl(lvf_map* m, lvf_scan* sc, const double* pose, float thr, int32_t* stats, int stride, float* levels4, int* n_levels);
+int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* sc, const double* pose, float thr, int32_t* stats4, float* levels4, int* n_levels) {
+  return knn3_debug_stats_impl(m, sc, pose, thr, stats4, 4, levels4, n_levels);
+}
+int lvf_knn3_debug_stats2(lvf_map* m, lvf_scan* sc, const double* pose, float thr, int32_t* stats, int stride, float* levels4, int* n_levels) {
+  LVF_REQUIRE(stride >= 4 && stride <= (int)(sizeof(KnnStats) / sizeof(int32_t)), "lvf_knn3_debug_stats2: stride must be 4..%d", (int)(sizeof(KnnStats) / sizeof(int32_t)));
+  return knn3_debug_stats_impl(m, sc, pose, thr, stats, stride, levels4, n_levels);
+}
+static int knn3_debug_stats_impl(lvf_map* m, lvf_scan* sc, const double* pose, float thr, int32_t* stats6, int stride, float* levels4, int* n_levels) {
   LVF_REQUIRE(m && sc && pose && stats6, "lvf_knn3_debug_stats: null argument");
   LVF_TRY(lvf::enter(m->ctx));
   if (n_levels) *n_levels = m->n_levels;
@@ -890,8 +902,16 @@ int lvf_knn3_debug_stats(lvf_map* m, lvf_scan* sc, const double* pose, float thr
   hipLaunchKernelGGL(k_knn3<true>, dim3(knn_grid(sc->Q)), dim3(kB), 0, m->ctx->stream, sc->Q, sc->pts.p, tf, L, thr,
                      sc->idx.p, sc->d2.p, sc->valid.p, st.p);
   LVF_HIP(hipGetLastError());
-  LVF_HIP(hipMemcpyAsync(stats6, st.p, (size_t)sc->Q * sizeof(KnnStats), hipMemcpyDeviceToHost, m->ctx->stream));
-  LVF_HIP(hipStreamSynchronize(m->ctx->stream));
+  constexpr int kW = (int)(sizeof(KnnStats) / sizeof(int32_t));
+  if (stride == kW) {
+    LVF_HIP(hipMemcpyAsync(stats6, st.p, (size_t)sc->Q * sizeof(KnnStats), hipMemcpyDeviceToHost, m->ctx->stream));
+    LVF_HIP(hipStreamSynchronize(m->ctx->stream));
+  } else {
+    std::vector<int32_t> h((size_t)sc->Q * kW);
+    LVF_HIP(hipMemcpyAsync(h.data(), st.p, (size_t)sc->Q * sizeof(KnnStats), hipMemcpyDeviceToHost, m->ctx->stream));
+    LVF_HIP(hipStreamSynchronize(m->ctx->stream));
+    for (int q = 0; q < sc->Q; ++q) for (int k = 0; k < stride; ++k) stats6[(size_t)q * stride + k] = h[(size_t)q * kW + k];
+  }
   sc->searched = true;
   return LVF_OK;
 }

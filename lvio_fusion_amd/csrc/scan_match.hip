@@ -269,9 +269,12 @@ int lvf_scan_match_batch(lvf_ctx* ctx, const lvf_scan_match_job* jobs, int n, co
                 "lvf_scan_match_batch: candidate %d: a map and its scan must be given together", c);
     for (const lvf_map* m : {J.map_ground, J.map_surf}) LVF_REQUIRE(!m || m->ctx == ctx, "lvf_scan_match_batch: candidate %d: handle of another context", c);
     for (const lvf_scan* s : {J.scan_ground, J.scan_surf}) LVF_REQUIRE(!s || s->ctx == ctx, "lvf_scan_match_batch: candidate %d: handle of another context", c);
+    // a scan handle carries ONE set of outputs (idx / d2 / valid / correspondences): it may appear once in the whole batch, whatever its role
+    LVF_REQUIRE(!J.scan_ground || J.scan_ground != J.scan_surf, "lvf_scan_match_batch: candidate %d uses one scan handle as ground AND surf (its outputs are per scan)", c);
     for (int e = 0; e < c; ++e)
-      LVF_REQUIRE((!J.scan_ground || J.scan_ground != jobs[e].scan_ground) && (!J.scan_surf || J.scan_surf != jobs[e].scan_surf),
-                  "lvf_scan_match_batch: candidates %d and %d share a scan handle (its outputs are per scan)", e, c);
+      for (const lvf_scan* a : {J.scan_ground, J.scan_surf})
+        LVF_REQUIRE(!a || (a != jobs[e].scan_ground && a != jobs[e].scan_surf),
+                    "lvf_scan_match_batch: candidates %d and %d share a scan handle (its outputs are per scan)", e, c);
     v[c] = SmJobView{{J.map_ground, J.map_surf}, {J.scan_ground, J.scan_surf}, J.map_pose, J.frame_pose, J.has_last_pose ? J.last_pose : nullptr};
   }
   LVF_TRY(scan_match_run(ctx, v.data(), n, opt, results));

@@ -134,7 +134,9 @@ struct lvf_problem {
   lvf::HostPin<lvf::LmCtl> h_ctl;     // pinned staging for uploads / read-backs of the control block
   lvf::Chain* chain = nullptr;        // argument blocks of one iteration
   bool chain_ready = false;
-  bool no_chain = false;              // a chained hand-over timed out once: this problem's levels stay launches of their own from then on
+  bool no_chain = false;              // a chained hand-over timed out: this problem's levels are launches of their own until kUnchainedSolves solves have gone by
+  int unchained_solves = 0;           // solves taken since no_chain was set (chaining is tried again after kUnchainedSolves of them: one scheduling blip
+                                      // under Relocator traffic — relocator.cpp:188 — must not cost a persistent window its chained launches for good)
   int handover_retries = 0;           // iterations re-run because of that (reported in lvf_solver_summary::hand_over_retries)
   int force_handover_timeouts = 0;    // test hook (lvf_problem_debug_force_handover_timeout): the next chain is built with an unreachable wait target
   const void* chain_state[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // the state pointers the chain was built for
@@ -2877,6 +2879,7 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
   // the host only polls `iter` and `done` of its mirror (wait_for_iteration): two uncached stores to the pinned record instead of a
   // system-scope fence and a copy of the whole block; LAST, so that no load of this workgroup queues behind a write that crosses PCIe
   if (A.rec && threadIdx.x == 0) {
+    __hip_atomic_store(&A.rec->why, c->why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);        // (ahead of `done`: a host that sees done also sees why the loop ended)
     __hip_atomic_store(&A.rec->done, s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&A.rec->iter, s_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -3673,7 +3676,7 @@ static int download_ctl(lvf_problem* p, LmCtl* out) {
 // block is re-armed as the aborted iteration found it and the caller enqueues again.  Returns false when there is nothing to retry.
 static bool handover_pending(const lvf_problem* p, const LmCtl& c) { return c.done && c.why == LVF_WHY_HANDOVER && !p->no_chain; }
 static int rearm_after_handover(lvf_problem* p, LmCtl* c) {
-  p->no_chain = true; p->chain_ready = false; p->handover_retries += 1;
+  p->no_chain = true; p->unchained_solves = 0; p->chain_ready = false; p->handover_retries += 1;
   if (p->force_handover_timeouts > 0) p->force_handover_timeouts -= 1;
   c->done = 0; c->termination = 1; c->why = LVF_WHY_MAX_ITERATIONS;
   p->accum_clean = false;                    // (the aborted iteration's partial sums: cleared by an explicit launch before the re-run)
@@ -4475,6 +4478,9 @@ int lvf_problem_solve_then(lvf_problem* p, const lvf_solver_options* o, lvf_solv
     if (tail) LVF_TRY(tail(user));
     return LVF_OK;
   }
+  // a problem that lost its chained launches to a hand-over time-out gets them back after kUnchainedSolves solves (a time-out then simply sets it again)
+  constexpr int kUnchainedSolves = 32;
+  if (p->no_chain && ++p->unchained_solves > kUnchainedSolves && p->force_handover_timeouts == 0) { p->no_chain = false; p->unchained_solves = 0; p->chain_ready = false; }
   LVF_TRY(upload_ctl(p, c));
   const auto wall0 = std::chrono::steady_clock::now();
   bool timed_out = false;
@@ -4486,7 +4492,11 @@ int lvf_problem_solve_then(lvf_problem* p, const lvf_solver_options* o, lvf_solv
       if (o->max_solver_time_in_seconds > 0.0 &&
           std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() >= o->max_solver_time_in_seconds) { timed_out = true; break; }
     }
-    if (tail) LVF_TRY(tail(user));
+    // the caller's launches ride behind the last iteration — unless the host already KNOWS this pass ended in a hand-over time-out (the mirror
+    // carries `why`): the state is not final then, the re-run's pass enqueues them.  (A time-out in the very last iteration enqueued is only
+    // seen after the wait: the tail then runs twice, the second time on the final state.)
+    const bool known_handover = p->rec->done && p->rec->why == LVF_WHY_HANDOVER && !p->no_chain;
+    if (tail && !known_handover) LVF_TRY(tail(user));
     LVF_TRY(download_ctl(p, &c));
     if (!handover_pending(p, c)) break;
     LVF_TRY(rearm_after_handover(p, &c));     // a chained hand-over timed out: the loop goes on from the same point, un-chained

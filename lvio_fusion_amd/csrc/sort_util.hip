@@ -7,7 +7,8 @@
 // Per digit pass, three launches on the context's stream and no host wait:
 //   k_radix_hist     one workgroup per tile of 4 096 keys: histogram of the digit (<= 2 048 bins) in LDS -> hist[bin][tile] (digit-major, so that ONE exclusive
 //                    scan over the whole table yields every (bin, tile)'s first output slot);
-//   k_radix_scan     that scan, one workgroup of 1 024 threads (the table has bins x tiles entries: 25 k for a 100 k-point cloud and 10-bit digits);
+//   k_radix_scan     that scan, one workgroup of 1 024 threads (the table has bins x tiles entries: 25 k for a 100 k-point cloud and 10-bit digits;
+//                    tables beyond 256 k entries — clouds of millions of points — take k_radix_scan_sums + k_radix_scan_chunks, up to 1 024 workgroups);
 //   k_radix_scatter  the tile again, sixteen rounds of 256 keys in input order: a key's rank among the keys of its digit is
 //                    (keys of that digit in earlier rounds of the tile) + (in lower waves of this round) + (in lower lanes of its wave) —
 //                    the last from one wave ballot per digit bit (lanes whose digit equals mine), no sorting network, no atomics,
@@ -23,13 +24,14 @@ namespace lvf {
 constexpr int kRT = 256, kRRounds = 16, kRTile = kRT * kRRounds, kRScanT = 1024, kRMaxDigitBits = 11;
 
 // digit = (key >> shift) & (nbins - 1); nbins = 1 << digit_bits <= 2048.  Dynamic LDS: nbins ints.
-__global__ __launch_bounds__(kRT) void k_radix_hist(int n, const unsigned* __restrict__ keys, int shift, int nbins, int* __restrict__ hist, int ntiles) {
+// `mask`: the digit's live bits — nbins - 1, except in the LAST pass of a key whose width is not a multiple of the digit width, where only the
+// remaining key bits count (bits above key_bits never influence the order: the contract hipcub's end_bit gave the callers)
+__global__ __launch_bounds__(kRT) void k_radix_hist(int n, const unsigned* __restrict__ keys, int shift, int nbins, unsigned mask, int* __restrict__ hist, int ntiles) {
   extern __shared__ int rs_lds[];
   int* h = rs_lds;
   for (int b = threadIdx.x; b < nbins; b += kRT) h[b] = 0;
   __syncthreads();
   const int base = blockIdx.x * kRTile;
-  const unsigned mask = (unsigned)nbins - 1u;
   for (int r = 0; r < kRRounds; ++r) {
     const int i = base + r * kRT + threadIdx.x;
     if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1);
@@ -38,26 +40,58 @@ __global__ __launch_bounds__(kRT) void k_radix_hist(int n, const unsigned* __res
   for (int b = threadIdx.x; b < nbins; b += kRT) hist[(size_t)b * ntiles + blockIdx.x] = h[b];
 }
 
-// exclusive scan of `total` ints in place, one workgroup: a contiguous chunk per thread, wave scans of the chunk sums on the DPP path
-__global__ __launch_bounds__(kRScanT) void k_radix_scan(int total, int* __restrict__ a) {
+__device__ __forceinline__ int wave_sum_i(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o); return v; }      // (lane 0 holds the sum)
+
+// exclusive scan of a[lo0, hi0) in place starting from `start`, by one workgroup: a contiguous chunk per thread, wave scans of the chunk
+// sums on the DPP path
+__device__ __forceinline__ void wg_excl_scan(int* __restrict__ a, const int lo0, const int hi0, const int start) {
   __shared__ int s_wave[kRScanT / 64];
+  const int total = hi0 - lo0;
   const int per = (total + kRScanT - 1) / kRScanT;
-  const int lo = min(total, (int)threadIdx.x * per), hi = min(total, lo + per);
+  const int lo = lo0 + min(total, (int)threadIdx.x * per), hi = min(hi0, lo + per);
   int sum = 0;
   for (int i = lo; i < hi; ++i) sum += a[i];
   const int incl = wave_incl_scan(sum);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 63) s_wave[w] = incl;
   __syncthreads();
-  int basev = 0;
+  int basev = start;
   for (int k = 0; k < w; ++k) basev += s_wave[k];
   int run = basev + incl - sum;
   for (int i = lo; i < hi; ++i) { const int v = a[i]; a[i] = run; run += v; }
 }
+// small tables (a 100 k-point cloud with 10-bit digits: 25 k entries): ONE workgroup
+__global__ __launch_bounds__(kRScanT) void k_radix_scan(int total, int* __restrict__ a) { wg_excl_scan(a, 0, total, 0); }
+// large tables (a 10 M-point cloud: 5 M entries — one workgroup walking them was the bottleneck of a pass): `chunk` entries per workgroup,
+// two launches: the chunk sums, then every workgroup scans its chunk from the sum of the chunks before it (<= kRScanMaxGroups of them:
+// each workgroup adds them up itself, no third launch)
+constexpr int kRScanMaxGroups = 1024, kRScanOneGroupMax = 1 << 18;
+__global__ __launch_bounds__(kRScanT) void k_radix_scan_sums(int total, const int* __restrict__ a, int chunk, int* __restrict__ part) {
+  __shared__ int s_w[kRScanT / 64];
+  const int lo = blockIdx.x * chunk, hi = min(total, lo + chunk);
+  int sum = 0;
+  for (int i = lo + (int)threadIdx.x; i < hi; i += kRScanT) sum += a[i];
+  sum = wave_sum_i(sum);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < kRScanT / 64; ++k) t += s_w[k]; part[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(kRScanT) void k_radix_scan_chunks(int total, int* __restrict__ a, int chunk, const int* __restrict__ part) {
+  __shared__ int s_w[kRScanT / 64];
+  __shared__ int s_start;
+  int v = (int)threadIdx.x < (int)blockIdx.x ? part[threadIdx.x] : 0;      // (gridDim.x <= kRScanMaxGroups = the block size)
+  v = wave_sum_i(v);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < kRScanT / 64; ++k) t += s_w[k]; s_start = t; }
+  __syncthreads();
+  const int lo = blockIdx.x * chunk;
+  wg_excl_scan(a, lo, min(total, lo + chunk), s_start);
+}
 
 // Dynamic LDS: s_base[nbins] | s_cnt[waves][nbins].
 __global__ __launch_bounds__(kRT) void k_radix_scatter(int n, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, unsigned* __restrict__ keys_out,
-                                                       int* __restrict__ vals_out, int shift, int digit_bits, const int* __restrict__ hist, int ntiles) {
+                                                       int* __restrict__ vals_out, int shift, int digit_bits, unsigned mask, const int* __restrict__ hist, int ntiles) {
   extern __shared__ int rs_lds[];
   const int nbins = 1 << digit_bits;
   int* s_base = rs_lds;
@@ -66,7 +100,6 @@ __global__ __launch_bounds__(kRT) void k_radix_scatter(int n, const unsigned* __
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int base = blockIdx.x * kRTile;
-  const unsigned mask = (unsigned)nbins - 1u;
   for (int r = 0; r < kRRounds; ++r) {
     for (int b = threadIdx.x; b < (kRT / 64) * nbins; b += kRT) s_cnt[b] = 0;
     __syncthreads();
@@ -108,17 +141,28 @@ int device_sort_pairs_u32(lvf_ctx* ctx, const unsigned* keys_in, unsigned* keys_
   const int db = (bits + passes - 1) / passes;                          // ... each as narrow as that number of passes permits
   const int nbins = 1 << db;
   const int ntiles = (n + kRTile - 1) / kRTile;
-  DevBuf<int> hist; DevBuf<unsigned> tkeys; DevBuf<int> tvals;
+  DevBuf<int> hist, part; DevBuf<unsigned> tkeys; DevBuf<int> tvals;
   LVF_TRY(hist.alloc((size_t)nbins * ntiles));
+  const int total = nbins * ntiles;
+  const int groups = total <= kRScanOneGroupMax ? 1 : std::min(kRScanMaxGroups, (total + kRScanOneGroupMax / 4 - 1) / (kRScanOneGroupMax / 4));
+  const int chunk = (total + groups - 1) / groups;
+  if (groups > 1) LVF_TRY(part.alloc(groups));
   if (passes > 1) { LVF_TRY(tkeys.alloc(n)); LVF_TRY(tvals.alloc(n)); }
   const unsigned* ki = keys_in; const int* vi = vals_in;
   for (int p = 0; p < passes; ++p) {
     // the last pass must land in the caller's arrays: with an odd number of passes the first one writes there, otherwise the scratch pair
     const bool to_out = ((passes - 1 - p) % 2) == 0;
     unsigned* ko = to_out ? keys_out : tkeys.p; int* vo = to_out ? vals_out : tvals.p;
-    hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(kRT), (size_t)nbins * sizeof(int), s, n, ki, db * p, nbins, hist.p, ntiles);
-    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kRScanT), 0, s, nbins * ntiles, hist.p);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(kRT), (size_t)(1 + kRT / 64) * nbins * sizeof(int), s, n, ki, vi, ko, vo, db * p, db, hist.p, ntiles);
+    // the digit's live bits: all db of them, except in the last pass when db * passes > bits (13-bit keys: digits of 7 and 6 bits)
+    const int live = std::min(db, bits - db * p);
+    const unsigned mask = (1u << live) - 1u;
+    hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(kRT), (size_t)nbins * sizeof(int), s, n, ki, db * p, nbins, mask, hist.p, ntiles);
+    if (groups == 1) hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kRScanT), 0, s, total, hist.p);
+    else {
+      hipLaunchKernelGGL(k_radix_scan_sums, dim3(groups), dim3(kRScanT), 0, s, total, hist.p, chunk, part.p);
+      hipLaunchKernelGGL(k_radix_scan_chunks, dim3(groups), dim3(kRScanT), 0, s, total, hist.p, chunk, part.p);
+    }
+    hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(kRT), (size_t)(1 + kRT / 64) * nbins * sizeof(int), s, n, ki, vi, ko, vo, db * p, db, mask, hist.p, ntiles);
     ki = ko; vi = vo;
   }
   LVF_HIP(hipGetLastError());
@@ -127,3 +171,25 @@ int device_sort_pairs_u32(lvf_ctx* ctx, const unsigned* keys_in, unsigned* keys_
 }
 
 }  // namespace lvf
+
+extern "C" {
+// Test hook (tests/test_gpu_cloud.py): the stable pair sort under VoxelGrid on host arrays.  keys_out / vals_out [n]; key_bits as in
+// device_sort_pairs_u32 (bits above it must not influence the order).  Not part of the reference surface.
+int lvf_debug_sort_pairs_u32(lvf_ctx* ctx, const uint32_t* keys, const int32_t* vals, int n, int key_bits, uint32_t* keys_out, int32_t* vals_out) {
+  LVF_REQUIRE(ctx && n >= 0 && (n == 0 || (keys && vals && keys_out && vals_out)) && key_bits >= 1 && key_bits <= 32, "lvf_debug_sort_pairs_u32: bad arguments");
+  if (n == 0) return LVF_OK;
+  LVF_TRY(lvf::enter(ctx));
+  hipStream_t s = ctx->stream;
+  lvf::DevBuf<unsigned> ki, ko; lvf::DevBuf<int> vi, vo;
+  LVF_TRY(ki.alloc(n)); LVF_TRY(ko.alloc(n)); LVF_TRY(vi.alloc(n)); LVF_TRY(vo.alloc(n));
+  LVF_HIP(hipMemcpyAsync(ki.p, keys, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  LVF_HIP(hipMemcpyAsync(vi.p, vals, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  LVF_HIP(hipStreamSynchronize(s));          // (pageable sources: the copies above must not outlive this call's arguments)
+  LVF_TRY(lvf::device_sort_pairs_u32(ctx, ki.p, ko.p, vi.p, vo.p, n, key_bits));
+  LVF_HIP(hipMemcpyAsync(keys_out, ko.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipMemcpyAsync(vals_out, vo.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  LVF_HIP(hipStreamSynchronize(s));
+  return LVF_OK;
+}
+}
+

@@ -147,3 +147,27 @@ def test_align_scan_parity(ctx, oracle, scene):
     assert ok and np.all(g.download()[:, 3] == 0)
     for h in (g, c1, c2):
         h.close()
+
+
+@pytest.mark.parametrize("n,key_bits", [(1, 5), (4097, 13), (100000, 20), (250000, 13), (3000000, 22), (2500000, 32)])
+def test_stable_pair_sort(ctx, n, key_bits):
+    """The radix sort under VoxelGrid (csrc/sort_util.hip) against numpy's stable argsort: only the low key_bits bits order the pairs — stray
+    bits above them must not (13 bits = digits of 7 + 6 bits: the last digit is masked to what is left) — equal keys keep their
+    input order, and tables beyond 256 k (bins x tiles) entries take the multi-workgroup scan."""
+    import ctypes as C
+    rng = np.random.default_rng(n + key_bits)
+    mask = np.uint32((1 << key_bits) - 1) if key_bits < 32 else np.uint32(0xFFFFFFFF)
+    keys = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    if key_bits < 32:
+        stray = rng.random(n) < 0.5
+        keys = np.where(stray, keys, keys & mask).astype(np.uint32)      # half of the keys carry garbage above key_bits
+    if n > 1000:
+        keys[rng.integers(0, n, n // 3)] = keys[0]                         # long runs of one key: stability is visible
+    vals = np.arange(n, dtype=np.int32)
+    ko, vo = np.empty_like(keys), np.empty_like(vals)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    from lvio_fusion_amd import api
+    api._chk(ctx.L.lvf_debug_sort_pairs_u32(ctx.h, vp(keys), vp(vals), n, key_bits, vp(ko), vp(vo)))
+    order = np.argsort(keys & mask, kind="stable")
+    assert np.array_equal(vo, vals[order])
+    assert np.array_equal(ko, keys[order])

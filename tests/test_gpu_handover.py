@@ -68,6 +68,12 @@ def test_forced_timeout_is_retried_unchained(ctx, oracle, n_kf, n_lm, seed):
     reset(api, st, cfg)
     again = prob.solve(opt)
     assert again.hand_over_retries == 1 and abs(again.final_cost - ref.final_cost) <= 1e-9 * abs(ref.final_cost)
+    # chaining comes back after 32 un-chained solves (one scheduling blip must not cost a persistent window its chained launches for
+    # good); the answers do not move across the switch
+    for k in range(36):
+        reset(api, st, cfg)
+        s = prob.solve(opt)
+        assert s.hand_over_retries == 1 and s.num_iterations == ref.num_iterations and abs(s.final_cost - ref.final_cost) <= 1e-9 * abs(ref.final_cost), k
     reset(api, st, cfg)
     o1 = prob.lm_iteration(opt, 1e4, 2.0)
     reset(api, st, cfg)

@@ -98,7 +98,7 @@ def test_maps_created_in_one_batch_equal_maps_created_one_by_one():
     def pyramid(m):
         stats = np.zeros((len(q), 6), np.int32); lv = np.zeros((8, 4), np.float32); nl = C.c_int()
         sc = api.Scan(ctx, q)
-        api._chk(ctx.L.lvf_knn3_debug_stats(m.h, sc.h, pose.ctypes.data_as(_lib.c_double_p), 1.0, stats.ctypes.data_as(_lib.c_int_p), lv.ctypes.data_as(_lib.c_float_p), C.byref(nl)))
+        api._chk(ctx.L.lvf_knn3_debug_stats2(m.h, sc.h, pose.ctypes.data_as(_lib.c_double_p), 1.0, stats.ctypes.data_as(_lib.c_int_p), 6, lv.ctypes.data_as(_lib.c_float_p), C.byref(nl)))
         sc.close()
         return lv[:nl.value].copy()
 

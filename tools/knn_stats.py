@@ -13,7 +13,7 @@ def main():
     for name, thr in (("ground", c3["thr_ground"]), ("surf", c3["thr_surf"])):
         pose = np.asarray(c3["pose0"], np.float64)
         stats = np.zeros((Q, 6), np.int32); lv = np.zeros((8, 4), np.float32); nl = C.c_int()
-        api._chk(ctx.L.lvf_knn3_debug_stats(mp.h, sc.h, pose.ctypes.data_as(_lib.c_double_p), float(thr), stats.ctypes.data_as(_lib.c_int_p),
+        api._chk(ctx.L.lvf_knn3_debug_stats2(mp.h, sc.h, pose.ctypes.data_as(_lib.c_double_p), float(thr), stats.ctypes.data_as(_lib.c_int_p), 6,
                                             lv.ctypes.data_as(_lib.c_float_p), C.byref(nl)))
         print(name, "Q", Q, "M", len(mpts), "levels", nl.value, lv[:nl.value].tolist())
         for k, nm in enumerate(("candidates", "lookups", "level", "shells")):

@@ -10,7 +10,7 @@ BIN = float(os.environ.get("BIN_US", "10"))
 Q = len(c3["query"]); pose = np.asarray(c3["pose0"], np.float64)
 for rep in range(2):
     stats = np.zeros((Q, 6), np.int32); lv = np.zeros((8, 4), np.float32); nl = C.c_int()
-    api._chk(ctx.L.lvf_knn3_debug_stats(mp.h, sc.h, pose.ctypes.data_as(_lib.c_double_p), 4.0, stats.ctypes.data_as(_lib.c_int_p), lv.ctypes.data_as(_lib.c_float_p), C.byref(nl)))
+    api._chk(ctx.L.lvf_knn3_debug_stats2(mp.h, sc.h, pose.ctypes.data_as(_lib.c_double_p), 4.0, stats.ctypes.data_as(_lib.c_int_p), 6, lv.ctypes.data_as(_lib.c_float_p), C.byref(nl)))
 t0 = stats[:, 4].astype(np.int64); t1 = stats[:, 5].astype(np.int64)
 # one wave = 8 consecutive queries
 w0 = t0[::8]; w1 = t1[::8]; cand = stats[:, 0].reshape(-1, 8).sum(1) if Q % 8 == 0 else None
