@@ -107,6 +107,10 @@ void* lvf_ctx_stream(lvf_ctx* ctx);
 int lvf_timer_begin(lvf_ctx* ctx);
 int lvf_timer_end(lvf_ctx* ctx);
 int lvf_timer_elapsed_ms(lvf_ctx* ctx, float* ms);
+/* Box calibration for the latency-bound legs (bench.py `box_calibration`): out8 = {ns per dependent fp64 FMA of one wave, shader clocks per
+ * such FMA, effective shader clock MHz during the chain, us per empty launch back to back, us for launch + stream wait of one empty
+ * kernel, rated shader clock MHz, memory clock MHz, compute units}.  Not part of the reference surface. */
+int lvf_box_calibration(lvf_ctx* ctx, double* out8);
 
 /* ---- parameter state (the caller-owned double* blocks of the Ceres problem, mirrored in HBM) - */
 enum lvf_field {

@@ -109,6 +109,7 @@ _SIGS = {
     "lvf_timer_begin": (C.c_int, [_VP]),
     "lvf_timer_end": (C.c_int, [_VP]),
     "lvf_timer_elapsed_ms": (C.c_int, [_VP, c_float_p]),
+    "lvf_box_calibration": (C.c_int, [_VP, c_double_p]),
     "lvf_state_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(_VP)]),
     "lvf_state_destroy": (C.c_int, [_VP]),
     "lvf_state_set": (C.c_int, [_VP, C.c_int, c_double_p]),

@@ -575,6 +575,15 @@ def event_pair_us(ctx, reps=25):
     return float(np.median(v))
 
 
+def box_calibration(ctx):
+    """lvf_box_calibration as a dict (see include/lvf.h)"""
+    v = np.zeros(8)
+    _chk(ctx.L.lvf_box_calibration(ctx.h, _dp(v)))
+    return {"ns_per_dependent_fp64_fma": float(v[0]), "shader_clocks_per_dependent_fp64_fma": float(v[1]), "effective_sclk_mhz": float(v[2]),
+            "empty_launch_us_back_to_back": float(v[3]), "empty_launch_plus_wait_us": float(v[4]), "rated_sclk_mhz": float(v[5]),
+            "rated_mclk_mhz": float(v[6]), "compute_units": int(v[7])}
+
+
 def default_solver_options():
     o = SolverOptions()
     _lib.lib().lvf_solver_options_default(C.byref(o))

@@ -1,4 +1,7 @@
 // capi.hip — the extern "C" surface of include/lvf.h: context, parameter state, factor batches.
+#include <chrono>
+#include <algorithm>
+#include <vector>
 #include <cstdlib>
 #include "lvf_internal.hpp"
 
@@ -157,6 +160,80 @@ int lvf_timer_elapsed_ms(lvf_ctx* c, float* ms) {
   LVF_REQUIRE(c && ms, "null argument");
   LVF_HIP(hipEventSynchronize(c->ev1));
   LVF_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return LVF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ box calibration
+}  // extern "C"
+namespace lvf {
+// one wave, kCalN dependent v_fma_f64: what every latency-bound chain of the solver (pivot sweeps, back substitution) is made of
+constexpr int kCalN = 4096;
+__global__ __launch_bounds__(64) void k_cal_fma_chain(double* out, unsigned long long* t, double y) {
+  double x = 1.0 + 1e-9 * threadIdx.x;
+  const unsigned long long w0 = wall_clock64(), c0 = clock64();
+#pragma unroll 64
+  for (int i = 0; i < kCalN; ++i) x = fma(x, y, 1e-3);
+  const unsigned long long c1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0) { t[0] = w1 - w0; t[1] = c1 - c0; }
+  out[threadIdx.x] = x;
+}
+__global__ void k_cal_empty() {}
+}  // namespace lvf
+extern "C" {
+// What the box this process landed on is worth for the latency-bound legs, so that a headline measured on two boxes can be compared
+// (the driver's 3 945 it/s against the builder's 4 873 on the same commit).  out[8]:
+//   [0] ns per dependent v_fma_f64 of ONE wave (100 MHz wall clock around 4 096 of them, best of 5)
+//   [1] shader clocks per dependent v_fma_f64 (clock64 around the same chain)
+//   [2] effective shader clock in MHz while that chain ran ([1] / [0] * 1000)
+//   [3] us per EMPTY kernel launch, back to back on the context's stream (64 launches between two events, median of 5)
+//   [4] us from enqueueing one empty kernel to the host seeing it finished (launch + stream wait, median of 21)
+//   [5] hipDeviceAttributeClockRate in MHz (the part's rated shader clock), [6] hipDeviceAttributeMemoryClockRate in MHz, [7] compute units
+int lvf_box_calibration(lvf_ctx* ctx, double* out8) {
+  LVF_REQUIRE(ctx && out8, "lvf_box_calibration: null argument");
+  LVF_TRY(lvf::enter(ctx));
+  hipStream_t q = ctx->stream;
+  for (int k = 0; k < 8; ++k) out8[k] = 0.0;
+  lvf::DevBuf<double> sink; lvf::DevBuf<unsigned long long> t;
+  LVF_TRY(sink.alloc(64)); LVF_TRY(t.alloc(2));
+  double best_ns = 1e300, best_clk = 0.0;
+  for (int rep = 0; rep < 6; ++rep) {
+    hipLaunchKernelGGL(lvf::k_cal_fma_chain, dim3(1), dim3(64), 0, q, sink.p, t.p, 0.999);
+    unsigned long long h[2] = {0, 0};
+    LVF_HIP(hipMemcpyAsync(h, t.p, sizeof(h), hipMemcpyDeviceToHost, q));
+    LVF_HIP(hipStreamSynchronize(q));
+    if (rep == 0) continue;                        // (first launch: code load)
+    const double ns = 10.0 * (double)h[0] / lvf::kCalN;      // wall_clock64: 100 MHz
+    if (ns < best_ns) { best_ns = ns; best_clk = (double)h[1] / lvf::kCalN; }
+  }
+  out8[0] = best_ns; out8[1] = best_clk; out8[2] = best_ns > 0.0 ? 1e3 * best_clk / best_ns : 0.0;
+  {
+    std::vector<float> ms(5);
+    for (float& m : ms) {
+      LVF_HIP(hipEventRecord(ctx->ev0, q));
+      for (int i = 0; i < 64; ++i) hipLaunchKernelGGL(lvf::k_cal_empty, dim3(1), dim3(64), 0, q);
+      LVF_HIP(hipEventRecord(ctx->ev1, q));
+      LVF_HIP(hipEventSynchronize(ctx->ev1));
+      LVF_HIP(hipEventElapsedTime(&m, ctx->ev0, ctx->ev1));
+    }
+    std::sort(ms.begin(), ms.end());
+    out8[3] = 1e3 * ms[2] / 64.0;
+  }
+  {
+    std::vector<double> us(21);
+    for (double& u : us) {
+      const auto t0 = std::chrono::steady_clock::now();
+      hipLaunchKernelGGL(lvf::k_cal_empty, dim3(1), dim3(64), 0, q);
+      LVF_HIP(hipStreamSynchronize(q));
+      u = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    std::sort(us.begin(), us.end());
+    out8[4] = us[10];
+  }
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeClockRate, ctx->device) == hipSuccess) out8[5] = v / 1e3;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMemoryClockRate, ctx->device) == hipSuccess) out8[6] = v / 1e3;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess) out8[7] = v;
+  LVF_HIP(hipGetLastError());
   return LVF_OK;
 }
 

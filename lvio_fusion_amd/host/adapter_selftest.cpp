@@ -7,6 +7,8 @@
 //   adapter_selftest lidar <dir>    ScanToMapWithGround/Segmented's problem (association.cpp:270-384) + Mapping's solve
 //                                   (mapping.cpp:153-163)
 // Raw little-endian arrays: <dir>/<name>.f64 / .i32 in, <dir>/out_<name>.f64 out; a one-line JSON summary on stdout.
+#include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -56,17 +58,19 @@ static int run_window(const std::string& dir) {
   auto pre = rd<double>(dir, "preint.f64"); auto imu_i = rd<int32_t>(dir, "imu_i.i32"), imu_j = rd<int32_t>(dir, "imu_j.i32");
   (void)n_lm;
 
-  adapt::Problem problem;
+  std::vector<ceres::CostFunction*> probe_cf;          // first block of each functor type, for Evaluate() spot checks
+  std::vector<std::vector<double*>> probe_params;
+  int n_prior = 0;
+  // Backend::BuildProblem's loop (backend.cpp:96-183) into `problem`: one heap functor per block through the reference's Create signatures
+  auto build_problem = [&](adapt::Problem& problem) {
   ceres::LossFunction* loss_function = new ceres::HuberLoss(1.0);
   ceres::LocalParameterization* local_parameterization =
       new ceres::ProductParameterization(new ceres::EigenQuaternionParameterization(), new ceres::IdentityParameterization(3));
-  std::vector<ceres::CostFunction*> probe_cf;          // first block of each functor type, for Evaluate() spot checks
-  std::vector<std::vector<double*>> probe_params;
   auto remember = [&](size_t want, ceres::CostFunction* cf, std::vector<double*> prm) {
     if (probe_cf.size() == want) { probe_cf.push_back(cf); probe_params.push_back(prm); }
   };
   size_t itc = 0, itf = 0, ipo = 0, iimu = 0;
-  int n_prior = 0;
+  n_prior = 0;
   double* para_last_kf = nullptr;
   for (int k = 0; k < n_kf; ++k) {
     double* para_kf = &poses[7 * k];
@@ -122,6 +126,9 @@ static int run_window(const std::string& dir) {
     para_last_kf = para_kf;
   }
   if (const_kf >= 0) problem.SetParameterBlockConstant(&poses[7 * const_kf]);
+  };
+  adapt::Problem problem;
+  build_problem(problem);
 
   if (std::getenv("LVF_SELFTEST_HOSTONLY")) {      // host-side cost of the Ceres-surface path (no GPU needed): classify the blocks
     for (int rep = 0; rep < 3; ++rep) {
@@ -241,6 +248,34 @@ static int run_window(const std::string& dir) {
     adapt::Solve(options, &problem, &s2);
     std::fprintf(stderr, "adapt::Solve (warm repeat): %.3f ms = preprocess %.3f + minimize %.3f + postprocess %.3f\n", 1e3 * s2.total_time_in_seconds,
                  1e3 * s2.preprocessor_time_in_seconds, 1e3 * s2.minimizer_time_in_seconds, 1e3 * s2.postprocessor_time_in_seconds);
+    poses = p2; vel = v2; ba = a2; bg = g2; invd = d2;
+  }
+  if (std::getenv("LVF_SELFTEST_TICK")) {
+    // One backend tick through the Ceres surface as the reference runs it (backend.cpp:203-211): a fresh adapt::Problem, BuildProblem's loop
+    // (one X::Create heap functor + AddResidualBlock per block), adapt::Solve, and the Problem's destructor (it owns the functors).  The
+    // state is restored between repeats; the ceres::Problem here is include/lvf_ceres_compat.h's stand-in (Ceres itself is not in the image).
+    std::vector<double> p2 = poses, v2 = vel, a2 = ba, g2 = bg, d2 = invd;
+    std::vector<std::array<double, 4>> tms;
+    for (int rep = 0; rep < 5; ++rep) {
+      poses = p2; vel = v2; ba = a2; bg = g2; invd = d2;
+      const auto t0 = std::chrono::steady_clock::now();
+      auto t1 = t0, t2 = t0;
+      {
+        adapt::Problem tick;
+        build_problem(tick);
+        t1 = std::chrono::steady_clock::now();
+        ceres::Solver::Summary st;
+        adapt::Solve(options, &tick, &st);
+        t2 = std::chrono::steady_clock::now();
+      }
+      const auto t3 = std::chrono::steady_clock::now();
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return 1e3 * std::chrono::duration<double>(b - a).count(); };
+      tms.push_back({ms(t0, t3), ms(t0, t1), ms(t1, t2), ms(t2, t3)});
+    }
+    std::sort(tms.begin(), tms.end());
+    const auto& m = tms[tms.size() / 2];
+    std::fprintf(stderr, "ceres-surface tick (median of 5): %.3f ms = build (Create + AddResidualBlock x %d) %.3f + adapt::Solve %.3f + ~Problem %.3f\n", m[0],
+                 summary.num_residual_blocks_reduced, m[1], m[2], m[3]);
     poses = p2; vel = v2; ba = a2; bg = g2; invd = d2;
   }
   std::printf("{\"ok\": %d, \"message\": \"%s\", \"cost0\": %.17g, \"initial_cost\": %.17g, \"final_cost\": %.17g, \"successful\": %d, \"unsuccessful\": %d, "

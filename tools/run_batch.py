@@ -24,15 +24,8 @@ def reset(st, cfg):
         st.set(field, cfg[key])
 
 
-def main():
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    Ws = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8, 16]
-    ctx = api.Context(0)
-    opt = api.default_solver_options()
-    opt.max_num_iterations = iters; opt.function_tolerance = 0.0; opt.parameter_tolerance = 0.0; opt.gradient_tolerance = 0.0
-    wins = [build(ctx, 0xC0FFEE + i) for i in range(max(Ws))]
+def single(ctx, opt, iters, cfg, st, prob):
     # per-call API
-    cfg, st, hs, prob = wins[0]
     r, d = 1e4, 2.0
     for _ in range(3):
         o = prob.lm_iteration(opt, r, d); r, d = o["radius"], o["decrease_factor"]
@@ -45,9 +38,22 @@ def main():
         reset(st, cfg)
         t0 = time.perf_counter(); s = prob.solve(opt); dt = time.perf_counter() - t0
     print(f"device loop, 1 window: {1e3 * dt / s.num_iterations:.3f} ms/it ({s.num_iterations / dt:.0f} it/s), {s.num_iterations} its, cost {s.initial_cost:.4g} -> {s.final_cost:.4g}")
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    Ws = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8, 16]
+    ctx = api.Context(0)
+    opt = api.default_solver_options()
+    opt.max_num_iterations = iters; opt.function_tolerance = 0.0; opt.parameter_tolerance = 0.0; opt.gradient_tolerance = 0.0
+    wins = [build(ctx, 0xC0FFEE + i) for i in range(max(Ws))]
+    batch_only = "batchonly" in sys.argv[3:]       # (PMC passes of the batched chain alone: tools/prof_batch_pmc.sh)
+    cfg, st, hs, prob = wins[0]
+    if not batch_only:
+        single(ctx, opt, iters, cfg, st, prob)
     for W in Ws:
         b = api.ProblemBatch(ctx, [w[3] for w in wins[:W]])
-        for rep in range(2):
+        for rep in range(1 if batch_only else 2):
             for w in wins[:W]:
                 reset(w[1], w[0])
             t0 = time.perf_counter(); ss = b.solve(opt); dt = time.perf_counter() - t0
