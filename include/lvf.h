@@ -507,6 +507,9 @@ typedef struct lvf_window_options {
 void lvf_window_options_default(lvf_window_options* o);
 int lvf_window_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera* right, const lvf_window_options* opt, lvf_window** out);
 int lvf_window_destroy(lvf_window* w);
+/* w_visual = frame->weights.visual.  The reference keeps its weights as FLOAT (adapt/weights.h:10): pass the float's value.  PoseOnly / TwoFrame
+ * blocks of the keyframe take it as it is (backend.cpp:129, :138); its TwoCamera blocks take `5 * frame->weights.visual` formed as the reference
+ * forms it, a float product widened to double: (double)(5.0f * (float)w_visual) (backend.cpp:123). */
 int lvf_window_add_keyframe(lvf_window* w, int64_t kf_id, const double* pose7, double w_visual);
 /* marks the frame good_imu with its Vw / linearised biases; pre (may be NULL) = frame->preintegration from the previous keyframe */
 int lvf_window_set_imu(lvf_window* w, int64_t kf_id, const double* vel3, const double* ba3, const double* bg3, const lvf_preint* pre);
@@ -526,6 +529,11 @@ int lvf_window_get_imu(const lvf_window* w, int64_t kf_id, double* vel3, double*
 int lvf_window_get_inv_depth(const lvf_window* w, int64_t lm_id, double* inv_depth);
 /* counts8 = {keyframes, landmarks in the problem, TwoCamera, TwoFrame, PoseOnly, ImuError, prior blocks, landmarks known} of the last solve */
 int lvf_window_counts(const lvf_window* w, int32_t* counts8);
+/* Test hook: the block lists of the last lvf_window_solve, kind 0 TwoCamera / 1 PoseOnly / 2 TwoFrame / 3 ImuError / 4 weak-constraint priors,
+ * in the device batches' order with keyframe and landmark IDS: ids[capacity][3] = {landmark, first / previous keyframe, keyframe} (-1 where a
+ * kind has none), vals[capacity][8] = {weight handed to the reference's Create, ob x, y, first (right) ob x, y, pw x, y, z}; *n = blocks of the
+ * kind.  What tests compare with Backend::BuildProblem's own output (backend.cpp:96-183).  Not part of the reference surface. */
+int lvf_window_debug_blocks(lvf_window* w, int kind, int capacity, int64_t* ids, double* vals, int* n);
 
 #ifdef __cplusplus
 }

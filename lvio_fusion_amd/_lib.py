@@ -205,6 +205,7 @@ _SIGS = {
     "lvf_window_get_imu": (C.c_int, [_VP, C.c_int64, c_double_p, c_double_p, c_double_p]),
     "lvf_window_get_inv_depth": (C.c_int, [_VP, C.c_int64, c_double_p]),
     "lvf_window_counts": (C.c_int, [_VP, c_int_p]),
+    "lvf_window_debug_blocks": (C.c_int, [_VP, C.c_int, C.c_int, _VP, c_double_p, C.POINTER(C.c_int)]),
     "lvf_solver_options_default": (None, [C.POINTER(SolverOptions)]),
     "lvf_problem_create": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "lvf_problem_destroy": (C.c_int, [_VP]),

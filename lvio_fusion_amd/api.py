@@ -553,6 +553,15 @@ class Window:
         _chk(self.ctx.L.lvf_window_get_inv_depth(self.h, int(lm_id), C.byref(d)))
         return d.value
 
+    def debug_blocks(self, kind):
+        """(ids [n][3] int64, vals [n][8]) of the last solve's blocks of one kind (lvf_window_debug_blocks: 0 TwoCamera, 1 PoseOnly, 2 TwoFrame,
+        3 ImuError, 4 priors)"""
+        n = C.c_int()
+        _chk(self.ctx.L.lvf_window_debug_blocks(self.h, int(kind), 0, None, None, C.byref(n)))
+        ids = np.zeros((max(n.value, 1), 3), np.int64); vals = np.zeros((max(n.value, 1), 8))
+        _chk(self.ctx.L.lvf_window_debug_blocks(self.h, int(kind), n.value, ids.ctypes.data_as(C.c_void_p), _dp(vals), C.byref(n)))
+        return ids[:n.value], vals[:n.value]
+
     def counts(self):
         c = np.zeros(8, np.int32)
         _chk(self.ctx.L.lvf_window_counts(self.h, _ip(c)))

@@ -1249,14 +1249,20 @@ __global__ __launch_bounds__(kT) void k_cost_sq(int n, const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ damping / assembly
+// (the fp64 square root and two divisions of the literal form cost k_prepare / k_tf_reduce / k_step_tail 6.6 us per iteration between them
+// when every diagonal entry took them — profiles/r05_a; they are only needed where the clamp can act:  s^2 h >= 1e-6  <=  h >= 2e-6 (1 + h0),
+// because (1 + sqrt(h0))^2 <= 2 (1 + h0); there clamp(s^2 h) / s^2 = h up to one rounding.  A column that was empty at iteration 0 has s = 1.)
 __device__ __forceinline__ double lm_damping(double h, double h0) {
+  if (h >= 2e-6 * (1.0 + h0) && h < 1e32) return h;
+  if (h0 == 0.0) return fmin(fmax(h, 1e-6), 1e32);
   const double sj = 1.0 / (1.0 + sqrt(h0)), s2 = sj * sj;
   return fmin(fmax(h * s2, 1e-6), 1e32) / s2;
 }
-// the damping of unknown `slot` whose diagonal entry is h in this pass; the thread that OWNS the entry's assembly records H0 in the first pass
-__device__ __forceinline__ double lm_damping_own(double h, const JacobiDev& j, int slot, int frozen) {
-  double h0 = h;
-  if (frozen) h0 = j.h0[slot]; else j.h0[slot] = h;
+// the damping of unknown `slot` whose diagonal entry is h in this pass; the thread that OWNS the entry's assembly records H0 in the first
+// pass.  h0_loaded = jac.h0[slot], requested by the caller together with its other loads (so that it is not a dependent round trip here).
+__device__ __forceinline__ double lm_damping_own(double h, const JacobiDev& j, int slot, int frozen, double h0_loaded) {
+  double h0 = h0_loaded;
+  if (!frozen) { h0 = h; j.h0[slot] = h; }
   return lm_damping(h, h0);
 }
 
@@ -1297,6 +1303,7 @@ __device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs&
       const bool live = l < n_lm;
       const int lc = live ? l : 0;
       const int k1 = A.kmin[lc], len = live ? max(0, A.kmax[lc] - k1) : 0;
+      const double h0l = A.jac.h0[A.jl0 + lc];
       const double2* sb = reinterpret_cast<const double2*>(A.slotB + (size_t)A.eoff[lc] * 8);
       double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int j = j0; j < len; j += 8) {
@@ -1308,7 +1315,7 @@ __device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs&
       if (live && j0 == 0) {
         const double c = C[l] + v[0], g = gr[l] + v[1];
         A.Ct[l] = c; A.grt[l] = g;
-        Cd[l] = c + lm_damping_own(c, A.jac, A.jl0 + l, jf) * inv_radius;
+        Cd[l] = c + lm_damping_own(c, A.jac, A.jl0 + l, jf, h0l) * inv_radius;
         double* el = E + (size_t)l * ldE;
         el[dp] = g;
         if (len > 0) {
@@ -1320,8 +1327,8 @@ __device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs&
     }
     const int l = (bx - nS_blocks) * kT + threadIdx.x;
     if (l >= n_lm) return;
-    const double c = C[l];
-    Cd[l] = c + lm_damping_own(c, A.jac, A.jl0 + l, jf) * inv_radius;
+    const double c = C[l], h0l = A.jac.h0[A.jl0 + l];
+    Cd[l] = c + lm_damping_own(c, A.jac, A.jl0 + l, jf, h0l) * inv_radius;
     E[(size_t)l * ldE + dp] = gr[l];
     return;
   }
@@ -1342,8 +1349,9 @@ __device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs&
   double v = 0.0;
   if (oi >= 0) {
     if (oj >= 0 && J <= I) {
+      const double h0d = I == J ? A.jac.h0[oi] : 0.0;
       v = B[(size_t)max(oi, oj) * dpad + min(oi, oj)];
-      if (I == J) v += lm_damping_own(v, A.jac, oi, jf) * inv_radius;
+      if (I == J) v += lm_damping_own(v, A.jac, oi, jf, h0d) * inv_radius;
     }
   } else if (oi == -2) {
     v = (oj >= 0) ? -gc[oj] : (J == I ? 1e300 : 0.0);   // huge corner keeps the augmented matrix positive definite
@@ -2160,10 +2168,11 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     if (tid < 9) {                         // what k_prepare would have stored in the diagonal block: B + clamp(diag B) / radius
       const double inv_radius = 1.0 / radius;
       const int jf = *src.jac.frozen;
+      const double h0d = src.jac.h0[nb0 + tid];
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
         double b = c <= tid ? src.B[(size_t)(nb0 + tid) * src.ldB + nb0 + c] : 0.0;
-        if (c == tid) b += lm_damping_own(b, src.jac, nb0 + tid, jf) * inv_radius;      // (every tile workgroup of the node stores the same H0)
+        if (c == tid) b += lm_damping_own(b, src.jac, nb0 + tid, jf, h0d) * inv_radius;      // (every tile workgroup of the node stores the same H0)
         bd[c] = b;
       }
     }
@@ -2689,8 +2698,8 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
   double m = 0.0, n2 = 0.0, g = 0.0, x2 = 0.0;
   if (i < d) {
     const double dx = dxc[i];
-    const double h = B[(size_t)i * ld + i];
-    m = -0.5 * dx * (lm_damping(h, *jac.frozen ? jac.h0[i] : h) * inv_radius * dx - gc[i]);      // (first pass: H0 = H, being recorded by the assembly)
+    const double h = B[(size_t)i * ld + i], h0d = jac.h0[i];
+    m = -0.5 * dx * (lm_damping(h, *jac.frozen ? h0d : h) * inv_radius * dx - gc[i]);      // (first pass: H0 = H, being recorded by the assembly)
     const bool rot = i < 6 * n_kf && (i % 6) < 3;           // rotation increments enter through the quaternion difference below
     n2 = rot ? 0.0 : dx * dx;
     g = fabs(gc[i]);

@@ -114,6 +114,9 @@ struct lvf_window {
 
 namespace lvf {
 
+// the TwoCamera block weight as the reference forms it (backend.cpp:123: `5 * frame->weights.visual`, float arithmetic: adapt/weights.h:10)
+static inline double two_camera_weight(double w_visual) { return (double)(5.0f * (float)w_visual); }
+
 // Landmark::ToWorld (src/lvio_fusion/src/landmark.cpp:15-19): Pixel2Robot through the RIGHT camera, then the birth pose
 static void to_world(const lvf_camera& right, const double rob[2], double inv_depth, const double birth_pose[7], double pw[3]) {
   const double d = 1.0 / inv_depth;
@@ -237,7 +240,9 @@ static void landmarks_hot(const lvf_window* w, std::vector<LmHot>& hot) {
 // The host reads back 4 + 2 n_kf counters (block totals, TwoFrame blocks and near visual blocks per keyframe) for the work list, the
 // IMU / prior decisions and the launch shapes.
 struct LmDev { double right_ob[2]; double pw[3]; double inv_depth; long long birth_kf; int fixed; int alive; };
-struct FrameDev { long long id; int start, cnt; long long arena_off; double zrow[3], zoff; double R[9], t[3]; };
+// w_tc: the weight backend.cpp:123 hands TwoCameraReprojectionError::Create for a landmark born in this frame, `5 * frame->weights.visual` — a FLOAT
+// product (adapt/weights.h:10 declares the weights float), widened to double by the call: (double)(5.0f * (float)w_visual)
+struct FrameDev { long long id; int start, cnt; long long arena_off; double zrow[3], zoff; double R[9], t[3]; double w_tc; };
 static_assert(sizeof(LmDev) == 64 && sizeof(FrameDev) % 8 == 0, "device table records");
 constexpr int kDaMaxKf = 64;
 struct DaArgs {
@@ -246,7 +251,7 @@ struct DaArgs {
   double Re[9], te[3], fx, fy, cx, cy, far_z;      // right camera (Landmark::ToWorld goes through it), Camera::Far threshold
   unsigned char* cls; unsigned char* used; int* wgcnt; int* wgbase; int* slot; int* slot_lm; int* counts;   // counts: [0..3] tc, tf, po, n_lm | tf per kf [64] | near per kf [64]
   double* state_invd; double* lm_invd_out;
-  double2 *tc_l, *tc_r; int32_t *tc_lm, *tc_kf;
+  double2 *tc_l, *tc_r; int32_t *tc_lm, *tc_kf; double* tc_w;
   double2 *tf_f, *tf_o; int32_t *tf_lm, *tf_k1, *tf_k2;
   double2* po_o; double* po_pw; int32_t *po_kf, *po_pi;
 };
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(256) void k_da_emit(DaArgs a) {
   const double2 ob = a.obs_xy[i];
   const LmDev L = a.lm[lm];
   if (c == 1) {
-    a.tc_l[idx] = ob; a.tc_r[idx] = make_double2(L.right_ob[0], L.right_ob[1]); a.tc_lm[idx] = a.slot[lm]; a.tc_kf[idx] = k;
+    a.tc_l[idx] = ob; a.tc_r[idx] = make_double2(L.right_ob[0], L.right_ob[1]); a.tc_lm[idx] = a.slot[lm]; a.tc_kf[idx] = k; a.tc_w[idx] = F.w_tc;
   } else if (c == 2) {
     a.tf_f[idx] = make_double2(L.right_ob[0], L.right_ob[1]); a.tf_o[idx] = ob; a.tf_lm[idx] = a.slot[lm];
     a.tf_k1[idx] = da_birth_pos(s_id, a.n_kf, L.birth_kf); a.tf_k2[idx] = k;
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256) void k_flag_outliers(int n, const double2* __r
 //   TwoCamera {left ob, right ob, landmark slot, keyframe}   TwoFrame {first ob, ob, landmark slot, k1, k2}   PoseOnly {ob, pw, keyframe, table row}
 // — into one pinned buffer, followed by the small plain arrays (state, IMU pre-integrations and indices, priors); k_window_unpack turns
 // the records into the batches' SoA arrays and copies the plain segments to their buffers.
-struct TcRec { double l[2], r[2]; int32_t lm, kf, pad0, pad1; };
+struct TcRec { double l[2], r[2]; int32_t lm, kf; double w; };      // w: the block's weight (two_camera_weight)
 struct TfRec { double f[2], o[2]; int32_t lm, k1, k2, pad0; };
 struct PoRec { double o[2], pw[3]; int32_t kf, pi; };
 static_assert(sizeof(TcRec) == 48 && sizeof(TfRec) == 48 && sizeof(PoRec) == 48, "staging records are 48 bytes");
@@ -457,7 +462,7 @@ constexpr int kMaxSegs = 96;            // (the whole UnpackArgs block stays und
 struct UnpackArgs {
   const unsigned char* stage;
   int ntc, ntf, npo; size_t off_tc, off_tf, off_po;
-  double2 *tc_l, *tc_r; int32_t *tc_lm, *tc_kf;
+  double2 *tc_l, *tc_r; int32_t *tc_lm, *tc_kf; double* tc_w;
   double2 *tf_f, *tf_o; int32_t *tf_lm, *tf_k1, *tf_k2;
   double2* po_o; double* po_pw; int32_t *po_kf, *po_pi;
   int n_segs; unsigned char* seg_dst[kMaxSegs]; size_t seg_off[kMaxSegs]; unsigned seg_words[kMaxSegs];   // 16-byte words (sizes are padded up)
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(256) void k_window_unpack(UnpackArgs a) {
   const int t = threadIdx.x;
   if (b < a.g_tc) {
     const int i = b * 256 + t;
-    if (i < a.ntc) { const TcRec r = reinterpret_cast<const TcRec*>(a.stage + a.off_tc)[i]; a.tc_l[i] = make_double2(r.l[0], r.l[1]); a.tc_r[i] = make_double2(r.r[0], r.r[1]); a.tc_lm[i] = r.lm; a.tc_kf[i] = r.kf; }
+    if (i < a.ntc) { const TcRec r = reinterpret_cast<const TcRec*>(a.stage + a.off_tc)[i]; a.tc_l[i] = make_double2(r.l[0], r.l[1]); a.tc_r[i] = make_double2(r.r[0], r.r[1]); a.tc_lm[i] = r.lm; a.tc_kf[i] = r.kf; if (a.tc_w) a.tc_w[i] = r.w; }
     return;
   }
   b -= a.g_tc;
@@ -753,6 +758,7 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
       hse3::rotate(inv_e, inv_pose + 4, t);
       d.zoff = t[2] + inv_e[6];
       std::memcpy(d.R, &Rk[(size_t)9 * k], 72); std::memcpy(d.t, f.pose + 4, 24);
+      d.w_tc = two_camera_weight(f.w_visual);
     }
   }
   // landmark table: all of it after a (re)allocation or a tick on the host path, otherwise only what add_landmark / slide / prune touched
@@ -862,7 +868,7 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
   LVF_TRY(w->d_cls.ensure(n_obs + 16)); LVF_TRY(w->d_wgcnt.ensure((size_t)3 * n_wg + 4)); LVF_TRY(w->d_wgbase.ensure((size_t)3 * n_wg + 4));
   LVF_TRY(w->d_slot.ensure(nl + 4)); LVF_TRY(w->d_slot_lm.ensure(nl + 4)); LVF_TRY(w->d_lm_invd_out.ensure(nl + 4));
   LVF_TRY(w->h_counts.reserve(4 + 2 * kDaMaxKf));
-  LVF_TRY(w->tc->ob_a.ensure(2 * std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->ob_b.ensure(2 * std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->idx_a.ensure(std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->idx_b.ensure(std::min(n_obs, nl) + 2));
+  LVF_TRY(w->tc->ob_a.ensure(2 * std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->ob_b.ensure(2 * std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->idx_a.ensure(std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->idx_b.ensure(std::min(n_obs, nl) + 2)); LVF_TRY(w->tc->wblk.ensure(std::min(n_obs, nl) + 2));
   LVF_TRY(w->tf->ob_a.ensure(2 * n_obs + 2)); LVF_TRY(w->tf->ob_b.ensure(2 * n_obs + 2)); LVF_TRY(w->tf->idx_a.ensure(n_obs + 2)); LVF_TRY(w->tf->idx_b.ensure(n_obs + 2)); LVF_TRY(w->tf->idx_c.ensure(n_obs + 2));
   LVF_TRY(w->po->ob_a.ensure(2 * n_obs + 2)); LVF_TRY(w->po->idx_a.ensure(n_obs + 2)); LVF_TRY(w->po->idx_b.ensure(n_obs + 2)); LVF_TRY(w->po->table.ensure(3 * n_obs + 2));
   DaArgs da{};
@@ -873,7 +879,7 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
   da.fx = w->right.fx; da.fy = w->right.fy; da.cx = w->right.cx; da.cy = w->right.cy; da.far_z = w->opt.baseline * 50.0;
   da.cls = w->d_cls.p; da.used = w->d_used.p; da.wgcnt = w->d_wgcnt.p; da.wgbase = w->d_wgbase.p; da.slot = w->d_slot.p; da.slot_lm = w->d_slot_lm.p; da.counts = w->d_counts.p;
   da.state_invd = st->inv_depth.p; da.lm_invd_out = w->d_lm_invd_out.p;
-  da.tc_l = reinterpret_cast<double2*>(w->tc->ob_a.p); da.tc_r = reinterpret_cast<double2*>(w->tc->ob_b.p); da.tc_lm = w->tc->idx_a.p; da.tc_kf = w->tc->idx_b.p;
+  da.tc_l = reinterpret_cast<double2*>(w->tc->ob_a.p); da.tc_r = reinterpret_cast<double2*>(w->tc->ob_b.p); da.tc_lm = w->tc->idx_a.p; da.tc_kf = w->tc->idx_b.p; da.tc_w = w->tc->wblk.p;
   da.tf_f = reinterpret_cast<double2*>(w->tf->ob_a.p); da.tf_o = reinterpret_cast<double2*>(w->tf->ob_b.p); da.tf_lm = w->tf->idx_a.p; da.tf_k1 = w->tf->idx_b.p; da.tf_k2 = w->tf->idx_c.p;
   da.po_o = reinterpret_cast<double2*>(w->po->ob_a.p); da.po_pw = w->po->table.p; da.po_kf = w->po->idx_a.p; da.po_pi = w->po->idx_b.p;
   if (n_wg) hipLaunchKernelGGL(k_da_classify, dim3(n_wg), dim3(256), 0, s, da);
@@ -911,7 +917,7 @@ static int window_solve_device(lvf_window* w, const lvf_solver_options* o, lvf_s
   w->n_tc = (int)ntc; w->n_tf = (int)ntf; w->n_po = (int)npo; w->n_prior = (int)pr_b.size();
   st->n_lm = n_lm; st->inv_depth.n = n_lm;
   auto idx_ok = [](lvf_batch* b, int n, int nkf, int nlm) { b->n = n; b->min_n_kf = nkf; b->min_n_lm = nlm; b->evaluated = false; };
-  w->tc->ob_a.n = w->tc->ob_b.n = 2 * ntc; w->tc->idx_a.n = w->tc->idx_b.n = ntc;
+  w->tc->ob_a.n = w->tc->ob_b.n = 2 * ntc; w->tc->idx_a.n = w->tc->idx_b.n = w->tc->wblk.n = ntc;
   idx_ok(w->tc, w->n_tc, n_kf, n_lm);
   w->tf->ob_a.n = w->tf->ob_b.n = 2 * ntf; w->tf->idx_a.n = w->tf->idx_b.n = w->tf->idx_c.n = ntf;
   idx_ok(w->tf, w->n_tf, n_kf, n_lm);
@@ -1080,7 +1086,7 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
       if (l.birth_kf == f.id) {
         if (l.slot < 0) { l.slot = (int)w->slot_lm.size(); w->slot_lm.push_back(ob.lm); }
         TcRec& r = tcr[ntc++];
-        r.l[0] = ob.ob[0]; r.l[1] = ob.ob[1]; r.r[0] = l.right_ob[0]; r.r[1] = l.right_ob[1]; r.lm = l.slot; r.kf = k;
+        r.l[0] = ob.ob[0]; r.l[1] = ob.ob[1]; r.r[0] = l.right_ob[0]; r.r[1] = l.right_ob[1]; r.lm = l.slot; r.kf = k; r.w = two_camera_weight(f.w_visual);
         continue;
       }
       const double* pw = l.pw;
@@ -1164,7 +1170,7 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
     for (int l = 0; l < n_lm; ++l) si[l] = w->lms[w->slot_lm[l]].inv_depth;
   }
   // block arrays (filled by the unpack kernel from the records)
-  LVF_TRY(w->tc->ob_a.ensure(2 * ntc)); LVF_TRY(w->tc->ob_b.ensure(2 * ntc)); LVF_TRY(w->tc->idx_a.ensure(ntc)); LVF_TRY(w->tc->idx_b.ensure(ntc));
+  LVF_TRY(w->tc->ob_a.ensure(2 * ntc)); LVF_TRY(w->tc->ob_b.ensure(2 * ntc)); LVF_TRY(w->tc->idx_a.ensure(ntc)); LVF_TRY(w->tc->idx_b.ensure(ntc)); LVF_TRY(w->tc->wblk.ensure(ntc));
   idx_ok(w->tc, w->n_tc, n_kf, n_lm);
   LVF_TRY(w->tf->ob_a.ensure(2 * ntf)); LVF_TRY(w->tf->ob_b.ensure(2 * ntf)); LVF_TRY(w->tf->idx_a.ensure(ntf)); LVF_TRY(w->tf->idx_b.ensure(ntf)); LVF_TRY(w->tf->idx_c.ensure(ntf));
   idx_ok(w->tf, w->n_tf, n_kf, n_lm);
@@ -1204,7 +1210,7 @@ int lvf_window_solve(lvf_window* w, const lvf_solver_options* o, lvf_solver_summ
   LVF_TRY(send_records());
   if (cur > off_po) LVF_HIP(hipMemcpyAsync(w->d_stage.p + off_po, hs + off_po, cur - off_po, hipMemcpyHostToDevice, s));
   ua.stage = w->d_stage.p; ua.ntc = (int)ntc; ua.ntf = (int)ntf; ua.npo = (int)npo; ua.off_tc = off_tc; ua.off_tf = off_tf; ua.off_po = off_po;
-  ua.tc_l = reinterpret_cast<double2*>(w->tc->ob_a.p); ua.tc_r = reinterpret_cast<double2*>(w->tc->ob_b.p); ua.tc_lm = w->tc->idx_a.p; ua.tc_kf = w->tc->idx_b.p;
+  ua.tc_l = reinterpret_cast<double2*>(w->tc->ob_a.p); ua.tc_r = reinterpret_cast<double2*>(w->tc->ob_b.p); ua.tc_lm = w->tc->idx_a.p; ua.tc_kf = w->tc->idx_b.p; ua.tc_w = w->tc->wblk.p;
   ua.tf_f = reinterpret_cast<double2*>(w->tf->ob_a.p); ua.tf_o = reinterpret_cast<double2*>(w->tf->ob_b.p); ua.tf_lm = w->tf->idx_a.p; ua.tf_k1 = w->tf->idx_b.p; ua.tf_k2 = w->tf->idx_c.p;
   ua.po_o = reinterpret_cast<double2*>(w->po->ob_a.p); ua.po_pw = w->po->table.p; ua.po_kf = w->po->idx_a.p; ua.po_pi = w->po->idx_b.p;
   ua.g_tc = (int)((ntc + 255) / 256); ua.g_tf = (int)((ntf + 255) / 256); ua.g_po = (int)((npo + 255) / 256); ua.g_seg = 64;
@@ -1327,4 +1333,60 @@ int lvf_window_reject_outliers(lvf_window* w, double max_px, int64_t* removed_lm
   return LVF_OK;
 }
 
+// Test hook (tests/test_gpu_window.py): the block lists of the LAST lvf_window_solve as they sit in the device batches — in the batch's order,
+// keyframe positions translated to keyframe ids and landmark slots to landmark ids — so that the assembly (host walk or device kernels) can be
+// compared with the reference's Backend::BuildProblem block by block (backend.cpp:96-183; tests/golden/ref_v4.npz).
+//   kind 0 TwoCamera : ids {landmark, -1, keyframe}            vals {5 w_visual[kf], left ob x, y, right ob x, y, 0, 0, 0}
+//   kind 1 PoseOnly  : ids {-1, -1, keyframe}                  vals {w_visual[kf], ob x, y, 0, 0, pw x, y, z}
+//   kind 2 TwoFrame  : ids {landmark, first keyframe, keyframe} vals {w_visual[kf], ob x, y, first (right) ob x, y, 0, 0, 0}
+//   kind 3 ImuError  : ids {-1, keyframe i, keyframe j}
+//   kind 4 priors    : ids {-1, previous keyframe or -1 (PoseError), keyframe}   vals {weight, v, 0, ...}
+// ids [capacity][3], vals [capacity][8]; *n = blocks of that kind (may exceed capacity: only `capacity` are written).
+int lvf_window_debug_blocks(lvf_window* w, int kind, int capacity, int64_t* ids, double* vals, int* n) {
+  LVF_REQUIRE(w && n && kind >= 0 && kind <= 4 && capacity >= 0 && (capacity == 0 || (ids && vals)), "lvf_window_debug_blocks: bad arguments");
+  LVF_TRY(lvf::enter(w->ctx));
+  hipStream_t s = w->ctx->stream;
+  lvf_batch* b = kind == 0 ? w->tc : kind == 1 ? w->po : kind == 2 ? w->tf : kind == 3 ? w->imu : w->prior;
+  const int nb = kind == 0 ? w->n_tc : kind == 1 ? w->n_po : kind == 2 ? w->n_tf : kind == 3 ? w->n_imu : w->n_prior;
+  *n = nb;
+  if (!b || nb == 0 || capacity == 0) return LVF_OK;
+  const int m = std::min(nb, capacity), n_kf = (int)w->kfs.size();
+  auto get_i = [&](const lvf::DevBuf<int32_t>& d, std::vector<int32_t>& h, size_t cnt) -> int { h.resize(cnt); LVF_HIP(hipMemcpyAsync(h.data(), d.p, cnt * 4, hipMemcpyDeviceToHost, s)); return LVF_OK; };
+  auto get_d = [&](const lvf::DevBuf<double>& d, std::vector<double>& h, size_t cnt) -> int { h.resize(cnt); LVF_HIP(hipMemcpyAsync(h.data(), d.p, cnt * 8, hipMemcpyDeviceToHost, s)); return LVF_OK; };
+  std::vector<int32_t> ia, ib, ic, slot_lm;
+  std::vector<double> oa, ob, tab;
+  if (kind <= 2) { LVF_TRY(get_i(b->idx_a, ia, m)); LVF_TRY(get_d(b->ob_a, oa, (size_t)2 * m)); }
+  if (kind == 0 || kind == 2) { LVF_TRY(get_i(b->idx_b, ib, m)); LVF_TRY(get_d(b->ob_b, ob, (size_t)2 * m)); }
+  std::vector<double> wb;
+  if (kind == 0 && b->wblk.n >= (size_t)m) LVF_TRY(get_d(b->wblk, wb, m));
+  if (kind == 2) LVF_TRY(get_i(b->idx_c, ic, m));
+  if (kind == 1) { LVF_TRY(get_i(b->idx_b, ib, m)); LVF_TRY(get_d(b->table, tab, (size_t)3 * b->n_table)); }
+  if (kind == 3) { LVF_TRY(get_i(b->idx_a, ia, m)); LVF_TRY(get_i(b->idx_b, ib, m)); }
+  if (kind == 4) { LVF_TRY(get_i(b->idx_a, ia, m)); LVF_TRY(get_i(b->idx_b, ib, m)); LVF_TRY(get_d(b->ob_a, oa, m)); LVF_TRY(get_d(b->ob_b, ob, m)); }
+  const bool need_slots = kind == 0 || kind == 2;
+  if (need_slots && (int)w->slot_lm.size() != w->n_lm_problem) {      // device assembly: the slot table lives on the device
+    slot_lm.resize((size_t)w->n_lm_problem);
+    if (w->n_lm_problem) LVF_HIP(hipMemcpyAsync(slot_lm.data(), w->d_slot_lm.p, (size_t)w->n_lm_problem * 4, hipMemcpyDeviceToHost, s));
+  }
+  LVF_HIP(hipStreamSynchronize(s));
+  const std::vector<int>* sl = nullptr;
+  std::vector<int> sl_copy;
+  if (need_slots) { if (slot_lm.empty() && (int)w->slot_lm.size() == w->n_lm_problem) sl = &w->slot_lm; else { sl_copy.assign(slot_lm.begin(), slot_lm.end()); sl = &sl_copy; } }
+  auto kf_id = [&](int pos) -> int64_t { return (pos >= 0 && pos < n_kf) ? w->kfs[pos].id : -1; };
+  auto lm_id = [&](int slot) -> int64_t { return (sl && slot >= 0 && slot < (int)sl->size()) ? w->lms[(*sl)[slot]].id : -1; };
+  auto wv = [&](int pos) { return (pos >= 0 && pos < n_kf) ? w->kfs[pos].w_visual : 0.0; };
+  for (int i = 0; i < m; ++i) {
+    int64_t* I = ids + 3 * (size_t)i; double* V = vals + 8 * (size_t)i;
+    I[0] = I[1] = I[2] = -1;
+    for (int q = 0; q < 8; ++q) V[q] = 0.0;
+    if (kind == 0) { I[0] = lm_id(ia[i]); I[2] = kf_id(ib[i]); V[0] = wb.empty() ? 5 * wv(ib[i]) : wb[i]; V[1] = oa[2 * i]; V[2] = oa[2 * i + 1]; V[3] = ob[2 * i]; V[4] = ob[2 * i + 1]; }
+    else if (kind == 1) { I[2] = kf_id(ia[i]); V[0] = wv(ia[i]); V[1] = oa[2 * i]; V[2] = oa[2 * i + 1]; const int t = ib[i]; if (t >= 0 && t < b->n_table) { V[5] = tab[3 * t]; V[6] = tab[3 * t + 1]; V[7] = tab[3 * t + 2]; } }
+    else if (kind == 2) { I[0] = lm_id(ia[i]); I[1] = kf_id(ib[i]); I[2] = kf_id(ic[i]); V[0] = wv(ic[i]); V[1] = ob[2 * i]; V[2] = ob[2 * i + 1]; V[3] = oa[2 * i]; V[4] = oa[2 * i + 1]; }
+    else if (kind == 3) { I[1] = kf_id(ia[i]); I[2] = kf_id(ib[i]); }
+    else { I[1] = kf_id(ia[i]); I[2] = kf_id(ib[i]); V[0] = oa[i]; V[1] = ob[i]; }
+  }
+  return LVF_OK;
+}
+
 }  // extern "C"
+

@@ -25,8 +25,8 @@ def can_build():
 def build(force=False):
     """Compiles the reference headers where they lie (never copied).  No-op without /root/reference (the GPU box uses the
     prebuilt .so that travelled with the snapshot, if any)."""
-    if can_build() and (force or not os.path.exists(_SO)):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    if can_build():          # (make is incremental: a no-op when the drivers, the shims and the reference sources are older than the library)
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"] + (["-B"] if force else []))
     return _SO if os.path.exists(_SO) else None
 
 
@@ -297,3 +297,48 @@ def window_eval_timed(cfg, pre, threads=8, reps=3, noise4=(0.1, 0.01, 1e-3, 1e-4
                                 d(cfg["inv_depth"]), d(cfg["poses"]), d(cfg["vel"]), d(cfg["ba"]), d(cfg["bg"]), d(cfg["w_kf"]),
                                 C.byref(left), C.byref(right), int(threads), int(reps), _p(times), C.byref(chk))
     return dict(create_s=float(times[0]), evaluate_s=float(times[1]), blocks=len(tc["lm_idx"]) + len(tf["lm_idx"]) + len(po["kf_idx"]) + n_imu, cost=0.5 * chk.value)
+
+
+# ---- Backend::BuildProblem (src/backend.cpp:96-183) run by the reference itself: oracle/ref_driver_backend.cpp
+class _BpCamera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("extrinsic", C.c_double * 7)]
+
+
+class _BpInput(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("first_active", C.c_int), ("time", C.c_void_p), ("pose", C.c_void_p), ("w_visual", C.c_void_p), ("good_imu", C.c_void_p),
+                ("imu_initialized", C.c_int), ("n_lm", C.c_int), ("lm_id", C.c_void_p), ("lm_birth", C.c_void_p), ("lm_inv_depth", C.c_void_p), ("lm_right_ob", C.c_void_p),
+                ("n_obs", C.c_int), ("obs_lm", C.c_void_p), ("obs_frame", C.c_void_p), ("obs_xy", C.c_void_p)]
+
+
+BP_KINDS = ("TwoCamera", "PoseOnly", "TwoFrame", "ImuError", "PoseGraphError", "PoseError")
+BP_TYPES = ("VisualError", "WeakError", "LidarError", "NavsatError", "PoseError", "ImuError", "Other")      # adapt/problem.h:11-20
+
+
+def backend_build_problem(cam0, cam1, baseline, time, pose, w_visual, good_imu, first_active, imu_initialized, lm_id, lm_birth, lm_inv_depth, lm_right_ob,
+                          obs_lm, obs_frame, obs_xy):
+    """The reference's own Backend::BuildProblem over the window given as flat arrays (frames in ascending time, [first_active:] active).  Returns
+    dict(rec_i [n][6] = kind, ProblemType, landmark index, frame a, frame b, has-loss; rec_d [n][8] = weight, ob, first ob, pw; num_frames,
+    num_parameter_blocks): one row per residual block in the order the reference added them."""
+    def cam(c):
+        o = _BpCamera(); o.fx, o.fy, o.cx, o.cy = c["fx"], c["fy"], c["cx"], c["cy"]
+        for i in range(7):
+            o.extrinsic[i] = float(c["extrinsic"][i])
+        return o
+    keep = [np.ascontiguousarray(time, np.float64), np.ascontiguousarray(pose, np.float64), np.ascontiguousarray(w_visual, np.float64), np.ascontiguousarray(good_imu, np.uint8),
+            np.ascontiguousarray(lm_id, np.int64), np.ascontiguousarray(lm_birth, np.int32), np.ascontiguousarray(lm_inv_depth, np.float64),
+            np.ascontiguousarray(lm_right_ob, np.float64), np.ascontiguousarray(obs_lm, np.int32), np.ascontiguousarray(obs_frame, np.int32), np.ascontiguousarray(obs_xy, np.float64)]
+    a = _BpInput()
+    a.n_frames, a.first_active, a.imu_initialized, a.n_lm, a.n_obs = len(keep[0]), int(first_active), int(bool(imu_initialized)), len(keep[4]), len(keep[8])
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    a.time, a.pose, a.w_visual, a.good_imu, a.lm_id, a.lm_birth, a.lm_inv_depth, a.lm_right_ob, a.obs_lm, a.obs_frame, a.obs_xy = map(vp, keep)
+    cap = a.n_obs + 2 * a.n_frames + 8
+    rec_i = np.full((cap, 6), -9, np.int32); rec_d = np.zeros((cap, 8)); nf, npb = C.c_int(), C.c_int()
+    c0, c1 = cam(cam0), cam(cam1)
+    L = lib()
+    L.lvr_backend_build_problem.restype = C.c_int
+    n = L.lvr_backend_build_problem(C.byref(c0), C.byref(c1), C.c_double(baseline), C.byref(a), cap, rec_i.ctypes.data_as(C.c_void_p), rec_d.ctypes.data_as(C.c_void_p),
+                                    C.byref(nf), C.byref(npb))
+    if n < 0 or n > cap:
+        raise RuntimeError(f"lvr_backend_build_problem: {n}")
+    return dict(rec_i=rec_i[:n], rec_d=rec_d[:n], num_frames=nf.value, num_parameter_blocks=npb.value)
+

@@ -62,6 +62,7 @@ template <typename CostFunctor, int kNumResiduals, int... Ns>
 class AutoDiffCostFunction : public SizedCostFunction<kNumResiduals, Ns...> {
  public:
   explicit AutoDiffCostFunction(CostFunctor* functor) : functor_(functor) {}
+  const CostFunctor* functor() const { return functor_.get(); }      // shim-only (oracle/ref_driver_backend.cpp reads the recorded blocks' constants)
   bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
     constexpr int K = sizeof...(Ns);
     constexpr int kTotal = internal::Sum<Ns...>::value;
@@ -109,6 +110,16 @@ class HuberLoss : public LossFunction {
   double a_, b_;
 };
 class LocalParameterization { public: virtual ~LocalParameterization() {} };
+// (type names only: backend.cpp:99-101 builds ProductParameterization(EigenQuaternionParameterization, IdentityParameterization(3)); the shim's
+// Problem records the pointer it is handed and nothing else)
+class EigenQuaternionParameterization : public LocalParameterization {};
+class IdentityParameterization : public LocalParameterization { public: explicit IdentityParameterization(int size) : size_(size) {} int size_; };
+class ProductParameterization : public LocalParameterization {
+ public:
+  ProductParameterization(LocalParameterization* a, LocalParameterization* b) : a_(a), b_(b) {}
+  ~ProductParameterization() override { delete a_; delete b_; }
+  LocalParameterization *a_, *b_;
+};
 namespace internal { struct ResidualBlock { CostFunction* cost; LossFunction* loss; std::vector<double*> params; }; }
 typedef internal::ResidualBlock* ResidualBlockId;
 class Problem {
@@ -133,7 +144,13 @@ class Problem {
   std::vector<ResidualBlockId> blocks_;
   std::vector<std::pair<double*, int>> params_;
 };
-struct Solver { struct Options {}; struct Summary { double final_cost = 0; int num_residual_blocks_reduced = 0; }; };
+enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
+struct Solver {
+  struct Options {      // the fields backend.cpp:206-209, :262-265 and mapping.cpp:159-161 set (values recorded, no solver behind them)
+    LinearSolverType linear_solver_type = SPARSE_NORMAL_CHOLESKY; double max_solver_time_in_seconds = 1e9; int max_num_iterations = 50; int num_threads = 1;
+  };
+  struct Summary { double final_cost = 0; int num_residual_blocks_reduced = 0; };
+};
 inline void Solve(const Solver::Options&, Problem*, Solver::Summary*) {}      // no solver in the shim (declared semantics: oracle/lm.h, oracle/icp.h)
 
 // declared so that imu_error.hpp:231-274 (ImuInitGError::Create, initialisation only — not on the hot path) compiles; never evaluated

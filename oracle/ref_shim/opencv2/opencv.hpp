@@ -10,6 +10,9 @@
 #include <stdlib.h>
 #include <bitset>
 #include <cstring>
+#include <list>
+#include <memory>
+#include <string>
 #include <vector>
 typedef unsigned char uchar;
 #define CV_8S 1
@@ -17,6 +20,7 @@ typedef unsigned char uchar;
 #define CV_32F 5
 namespace cv {
 struct Scalar { double v[4]; static Scalar all(double x) { Scalar s; s.v[0] = s.v[1] = s.v[2] = s.v[3] = x; return s; } };
+struct Point2i { int x, y; Point2i() : x(0), y(0) {} Point2i(int x_, int y_) : x(x_), y(y_) {} };
 struct Point2f { float x, y; Point2f() : x(0), y(0) {} Point2f(float x_, float y_) : x(x_), y(y_) {} };
 struct Point3f { float x, y, z; Point3f() : x(0), y(0), z(0) {} Point3f(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {} };
 struct KeyPoint { Point2f pt; float size; KeyPoint() : size(0) {} KeyPoint(Point2f p, float s) : pt(p), size(s) {} };
@@ -59,4 +63,8 @@ class Mat_ : public Mat {
 };
 template <typename T> void MatCommaInitializer_<T>::put(T x) { if (k_ < m_->v.size()) m_->v[k_] = (double)x; ++k_; }
 template <typename T> MatCommaInitializer_<T>::operator Mat() const { return *m_; }
+// names the front-end headers mention (frontend.h -> visual/local_map.h, visual/extractor.h) so that src/backend.cpp compiles as a translation
+// unit of its own (oracle/ref_driver_backend.cpp); nothing of the front end is ever constructed
+template <typename T> struct Ptr : std::shared_ptr<T> { Ptr() {} Ptr(const std::shared_ptr<T>& p) : std::shared_ptr<T>(p) {} };
+class DescriptorMatcher { public: static Ptr<DescriptorMatcher> create(const std::string&) { return Ptr<DescriptorMatcher>(); } };
 }  // namespace cv

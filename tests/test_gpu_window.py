@@ -212,3 +212,43 @@ def test_reject_outliers_matches_the_reference_gate(oracle):
     win.solve(opt)
     assert win.counts()["tf"] == 0
     win.close(); ctx.close()
+
+
+@pytest.mark.parametrize("device_assembly", [True, False])
+@pytest.mark.parametrize("with_imu", [True, False])
+def test_block_lists_equal_the_references_build_problem(oracle, with_imu, device_assembly):
+    """the block lists lvf_window assembles — by its device kernels and by its host walk — against the lists the REFERENCE's
+    own Backend::BuildProblem produced for the same 12 ticks (src/backend.cpp:96-183 compiled unmodified: oracle/ref_driver_backend.cpp ->
+    tests/golden/ref_v4.npz, tests/window_replay.py's drive).  BIT FOR BIT: which blocks, in which order, on which landmark / keyframes, with
+    which observations and which weight (TwoCamera: the reference's FLOAT product 5 * weights.visual); the frozen world point of PoseOnly
+    blocks to 1e-12 (Landmark::ToWorld is floating-point arithmetic in another operation order); the weak-constraint priors exactly where
+    the reference's VisualError census puts them."""
+    import os
+    from lvio_fusion_amd import api
+    from tests import window_replay as wr
+    R4 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_v4.npz"))
+    tag = f"imu{int(with_imu)}"
+    ctx = api.Context(0)
+    drive = wr.Drive(with_imu)
+    seen = {k: 0 for k in wr.KINDS}
+    for t, first, win in wr.replay_window(api, ctx, drive, device_assembly, oracle.imu_preintegrate):
+        got = wr.window_lists(win)
+        for kind in wr.KINDS:
+            ids, vals = R4[f"{tag}_t{t}_{kind}_ids"], R4[f"{tag}_t{t}_{kind}_vals"]
+            g = got[kind]
+            what = f"{tag} device_assembly={device_assembly} tick {t} {kind}"
+            assert g["ids"].shape == ids.shape and np.array_equal(g["ids"], ids), f"{what}: block set / order / indices differ from the reference's BuildProblem"
+            if kind in ("TwoCamera", "TwoFrame"):
+                assert np.array_equal(g["vals"][:, :5], vals[:, :5]), f"{what}: weight / observations"
+            elif kind == "PoseOnly":
+                assert np.array_equal(g["vals"][:, :3], vals[:, :3]), f"{what}: weight / observation"
+                if len(ids):
+                    assert np.abs(g["vals"][:, 5:8] - vals[:, 5:8]).max() <= 1e-12 * np.abs(vals[:, 5:8]).max(), f"{what}: frozen world point"
+            elif kind in ("PoseGraphError", "PoseError"):
+                assert np.array_equal(g["vals"][:, :2], vals[:, :2]), f"{what}: prior weight / v"
+            seen[kind] += len(ids)
+        meta = R4[f"{tag}_meta"][t]
+        cnt = win.counts()
+        assert cnt["kf"] == meta[0] and cnt["tc"] + cnt["tf"] + cnt["po"] + cnt["imu"] + cnt["prior"] == meta[3]
+    assert seen["PoseOnly"] > 0 and seen["TwoFrame"] > 0 and (with_imu or (seen["PoseGraphError"] > 0 and seen["PoseError"] > 0))
+    ctx.close()

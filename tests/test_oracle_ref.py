@@ -394,3 +394,64 @@ def test_oracle_association_equals_reference_scan_to_map_fixture(oracle):
             assert np.allclose(r, R3[tag + "_residuals"], rtol=1e-12, atol=1e-15) and np.allclose(J, R3[tag + "_jacobians"], rtol=1e-12, atol=1e-15)
             assert np.array_equal(R3[tag + "_prior"], np.zeros(3))          # the prior's target is para itself (pose_error.hpp:135-190)
         assert len(r) > 1000
+
+
+# ---- round 5: the problem assembly pinned to the reference's own text.  src/backend.cpp (Backend::BuildProblem, :96-183) and src/landmark.cpp
+# are compiled UNMODIFIED into oracle/_ref (oracle/ref_driver_backend.cpp builds the Frame / Feature / Landmark graph and reads the recorded
+# blocks back); its block lists over tests/window_replay.py's drive travel as tests/golden/ref_v4.npz (tests/golden/make_ref_golden_backend.py).
+# The consumer of the fixture is tests/test_gpu_window.py (lvf_window_*'s host and device assembly, bit for bit).
+def test_build_problem_fixture_equals_reference_live():
+    from oracle import pyref
+    if not pyref.available():
+        pytest.skip("/root/reference is not present (GPU box): tests/golden/ref_v4.npz is the pin there")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_ref_golden_backend as g
+    from tests import window_replay as wr
+    R4 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_v4.npz"))
+    for with_imu in (True, False):
+        ticks, meta = g.reference_ticks(with_imu)
+        tag = f"imu{int(with_imu)}"
+        assert np.array_equal(R4[f"{tag}_meta"], np.array([meta[t] for t in range(wr.N_KF)], np.int64))
+        for (t, kind), v in ticks.items():
+            for field in ("ids", "vals", "type", "loss"):
+                a, b = R4[f"{tag}_t{t}_{kind}_{field}"], v[field]
+                assert a.shape == b.shape and np.array_equal(a, b.astype(a.dtype)), f"{tag} tick {t} {kind} {field}: the fixture is stale (regenerate tests/golden/ref_v4.npz)"
+
+
+def test_build_problem_fixture_follows_the_documented_rules():
+    """What the reference's lists say about BuildProblem, checked on the fixture itself (so the GPU-side comparison is read with the right
+    expectations): per keyframe the features come in ascending landmark id; TwoCamera carries ProblemType::Other and 5 x the frame's visual
+    weight; PoseOnly / TwoFrame carry VisualError or WeakError (Camera::Far); every visual block shares the Huber loss, IMU / prior blocks have
+    none; a keyframe gets a prior iff it has no ImuError block AT THAT POINT of the loop and fewer than 20 VisualError blocks."""
+    from tests import window_replay as wr
+    from oracle import pyref
+    R4 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_v4.npz"))
+    T = pyref.BP_TYPES
+    for with_imu in (True, False):
+        drive = wr.Drive(with_imu)
+        tag = f"imu{int(with_imu)}"
+        for t in range(wr.N_KF):
+            _, first = drive.tick(t)
+            get = lambda kind, f: R4[f"{tag}_t{t}_{kind}_{f}"]
+            tc, po, tf = (dict(ids=get(k, "ids"), vals=get(k, "vals"), type=get(k, "type"), loss=get(k, "loss")) for k in ("TwoCamera", "PoseOnly", "TwoFrame"))
+            assert np.all(tc["type"] == T.index("Other")) and np.all(np.isin(po["type"], (T.index("VisualError"), T.index("WeakError")))) and np.all(np.isin(tf["type"], (0, 1)))
+            assert np.all(tc["loss"] == 1) and np.all(po["loss"] == 1) and np.all(tf["loss"] == 1)
+            w = drive.w_kf                                 # float-representable: Weights::visual is a float (adapt/weights.h:10) ...
+            w5 = (np.float32(5) * w.astype(np.float32)).astype(np.float64)      # ... and `5 * frame->weights.visual` a FLOAT product (backend.cpp:123)
+            assert np.array_equal(tc["vals"][:, 0], w5[tc["ids"][:, 2] - wr.KF_ID0]) and np.array_equal(tf["vals"][:, 0], w[tf["ids"][:, 2] - wr.KF_ID0])
+            assert np.array_equal(po["vals"][:, 0], w[po["ids"][:, 2] - wr.KF_ID0])
+            for b in (tc, tf):      # keyframe-major, ascending landmark id inside a keyframe
+                key = b["ids"][:, 2] * 10 ** 6 + b["ids"][:, 0]
+                assert np.all(np.diff(key) > 0)
+            assert np.all(np.diff(po["ids"][:, 2]) >= 0) and np.all(tf["ids"][:, 1] < tf["ids"][:, 2]) and np.all(tf["ids"][:, 1] >= wr.KF_ID0 + first)
+            imu = get("ImuError", "ids")
+            assert len(imu) == (t - first if with_imu else 0) and np.all(get("ImuError", "loss") == 0)
+            near = {k: 0 for k in range(first, t + 1)}
+            for b in (po, tf):
+                for kf, ty in zip(b["ids"][:, 2], b["type"]):
+                    near[int(kf) - wr.KF_ID0] += int(ty == T.index("VisualError"))
+            expect = [k for k in range(first, t + 1) if not (with_imu and k > first) and near[k] < 20]
+            got = sorted(int(x) - wr.KF_ID0 for x in np.concatenate([get("PoseGraphError", "ids")[:, 2], get("PoseError", "ids")[:, 2]]))
+            assert got == expect, (tag, t, got, expect)
+            pg, pe = get("PoseGraphError", "ids"), get("PoseError", "ids")
+            assert np.all(pg[:, 1] == pg[:, 2] - 1) and np.all(pe[:, 2] == wr.KF_ID0 + first) and np.all(get("PoseGraphError", "vals")[:, :2] == [100.0, 0.0])
