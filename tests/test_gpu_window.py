@@ -119,6 +119,8 @@ def test_ticks_match_from_scratch_assembly(oracle, with_imu, weak_thr, device_as
         arr = lambda x, w: np.array(x).reshape(-1, w) if len(x) else np.zeros((0, w))
         hs = []
         btc = api.two_camera_batch(ctx, cam0, cam1, arr(b_tc[0], 2), arr(b_tc[1], 2), np.array(b_tc[2], np.int32), np.array(b_tc[3], np.int32)); hs.append(btc)
+        if len(b_tc[3]):     # the window forms the TwoCamera weight as the reference does, `5 * frame->weights.visual` in FLOAT (backend.cpp:123, adapt/weights.h:10)
+            btc.set_block_weights((np.float32(5) * np.array([cfg["w_kf"][act[p]] for p in b_tc[3]], np.float32)).astype(np.float64))
         btf = api.two_frame_batch(ctx, cam0, cam1, arr(b_tf[0], 2), arr(b_tf[1], 2), np.array(b_tf[2], np.int32), np.array(b_tf[3], np.int32), np.array(b_tf[4], np.int32)); hs.append(btf)
         bpo = api.pose_only_batch(ctx, cam0, arr(b_po[0], 2), np.array(b_po[1], np.int32), np.array(b_po[2], np.int32), arr(pw_tab, 3) if pw_tab else np.zeros((1, 3))); hs.append(bpo)
         bim = api.imu_batch(ctx, np.array(imu_pre), imu_i, imu_j) if imu_i else None

@@ -26,6 +26,11 @@ class Drive:
     def __init__(self, with_imu, seed=SEED):
         self.with_imu = with_imu
         self.cfg = cfg = syn.config4_window(n_kf=N_KF, n_lm=N_LM, n_prewindow=0, seed=seed, imu_samples=4)
+        # the camera extrinsics as the reference holds them: Sophus::SE3d keeps a UNIT quaternion (estimator.cpp:36-83 builds them from a matrix
+        # through SE3d's constructor, which normalises); kitti.yaml's 7-digit matrices give |q| - 1 = 2.7e-7 if taken over as they are, and the
+        # reference's SE3d arithmetic (Landmark::ToWorld, Camera::Far) assumes |q| = 1
+        for cam in ("cam0", "cam1"):
+            c = dict(cfg[cam]); e = np.array(c["extrinsic"], np.float64); e[:4] /= np.linalg.norm(e[:4]); c["extrinsic"] = e; cfg[cam] = c
         tc, tf = cfg["tc"], cfg["tf"]
         rng = np.random.default_rng(seed + 1)
         # landmark ids are NOT in creation order: BuildProblem walks a frame's features in ascending landmark id (std::map)
