@@ -2444,7 +2444,9 @@ __device__ __forceinline__ T ld_off32(const T* base, unsigned byte_off) {     //
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 constexpr int kBT = 512, kBParts = kBT / 64, kBackPre = 256 / kBParts, kBackInv = 64 / kBParts, kTailPre = 6;
-struct BackArgs { const double* Sd; int ld, d; const double* Dinv; double* xout; SpBack sp; const int* done; const double* Ldiag; };
+// pose_ready (merged back-substitution + step tail, k_backsolve_tail): once the dense corner is solved the POSE part of the step (natural
+// unknowns [0, n_pose)) is written out and *pose_ready is raised (release, agent scope) — what the landmark back-substitution waits for
+struct BackArgs { const double* Sd; int ld, d; const double* Dinv; double* xout; SpBack sp; const int* done; const double* Ldiag; int* pose_ready = nullptr; int n_pose = 0; };
 __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
   const int dv = done_flag_issue(A.done);
   const double* S = A.Sd; const int ld = A.ld, d = A.d; const double* Dinv = A.Dinv; double* xout = A.xout; const SpBack& sp = A.sp;
@@ -2565,6 +2567,14 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
     lds_barrier();
     mark();
   }
+  if (A.pose_ready) {
+    // the pose increments are final (every pose row lives in the dense corner): out they go, so that the landmark back-substitution — which
+    // reads nothing else of the step — runs in the sibling workgroups of this launch WHILE the sparse levels below are solved here
+    for (int i = tid; i < A.n_pose; i += kBT) xout[i] = sm[sp.perm[i]];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    lds_barrier();
+    if (tid == 0) __hip_atomic_store(A.pose_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // ---- sparse levels, last eliminated first
   for (int lv = sp.lv.n - 1; lv >= 0; --lv) {
     const int first = sp.lv.first[lv], count = sp.lv.count[lv], item0 = sp.item0[lv], item1 = item0 + sp.items[lv];
@@ -2635,20 +2645,21 @@ __global__ __launch_bounds__(kBT) void k_chol_backsolve_b(const BackArgs* __rest
 // landmark back-substitution: dl = (-gr - e_l . dx_pose) / Cd ; model terms and norms
 // (on DENSE rows one thread per landmark beat a wave per landmark, 25.6 vs 29.9 us; with the row limited to the landmark's track
 // a per-thread walk diverges (41-54 us) and 16 lanes per landmark is the right shape)
+template <int NT = kT>
 __device__ __forceinline__ void landmark_back_body(const int vb, const int nwg, int n_lm, int dp, int ldE, const double* __restrict__ E,
                                                    const double* __restrict__ C, const double* __restrict__ Cd, const double* __restrict__ gr,
                                                    const double* __restrict__ dxc, const double* __restrict__ inv_depth,
                                                    double* __restrict__ dxl, double* __restrict__ invd2, double* __restrict__ scal,
                                                    const int* __restrict__ kmin, const int* __restrict__ kmax) {
   extern __shared__ double sdx[];
-  for (int i = threadIdx.x; i < dp; i += kT) sdx[i] = dxc[i];
+  for (int i = threadIdx.x; i < dp; i += NT) sdx[i] = dxc[i];
   __syncthreads();
   // 16 lanes per landmark: the band of a row is a few 128-byte runs, read coalesced and reduced with four shuffles; the grid is
   // capped and strides over the landmarks so that the three scalar sums cost one atomic per WORKGROUP (thousands of per-wave
   // atomics on the 32 striped slots were most of this kernel's time)
   const int q = threadIdx.x & 15;
   double m = 0.0, n2 = 0.0, x2 = 0.0, gmx = 0.0;
-  for (int l = vb * (kT / 16) + (threadIdx.x >> 4); l < n_lm; l += nwg * (kT / 16)) {
+  for (int l = vb * (NT / 16) + (threadIdx.x >> 4); l < n_lm; l += nwg * (NT / 16)) {
     const double* e = E + (size_t)l * ldE;
     double ed = 0.0;
     const int i0 = kmin ? 6 * min(kmin[l], dp / 6) : 0, i1 = kmin ? 6 * (kmax[l] + 1) : dp;   // the row is zero outside the landmark's track
@@ -2664,19 +2675,19 @@ __device__ __forceinline__ void landmark_back_body(const int vb, const int nwg, 
       n2 += dl * dl; x2 += inv_depth[l] * inv_depth[l];
     }
   }
-  __shared__ double red[4][kT / 64];
+  __shared__ double red[4][NT / 64];
   m = wave_sum(m); n2 = wave_sum(n2); x2 = wave_sum(x2);
   for (int o = 32; o > 0; o >>= 1) gmx = fmax(gmx, __shfl_down(gmx, o));
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = n2; red[2][threadIdx.x >> 6] = x2; red[3][threadIdx.x >> 6] = gmx; }
   __syncthreads();
   if (threadIdx.x < 3) {
     double v = 0.0;
-    for (int k = 0; k < kT / 64; ++k) v += red[threadIdx.x][k];
+    for (int k = 0; k < NT / 64; ++k) v += red[threadIdx.x][k];
     double* dst = scal + (threadIdx.x == 0 ? SC_MODEL : (threadIdx.x == 1 ? SC_DXNORM : SC_XNORM));
     if (v != 0.0) atomicAdd(dst + (vb & (kStripes - 1)), v);
   } else if (threadIdx.x == 3) {
     double v = 0.0;
-    for (int k = 0; k < kT / 64; ++k) v = fmax(v, red[3][k]);
+    for (int k = 0; k < NT / 64; ++k) v = fmax(v, red[3][k]);
     // (non-negative doubles order like their bit patterns; striped like the sums: hundreds of workgroups hitting ONE address serialise,
     // measured +4 us on this launch)
     if (v != 0.0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX + (vb & (kStripes - 1))), (unsigned long long)__double_as_longlong(v));
@@ -2687,12 +2698,13 @@ __device__ __forceinline__ void landmark_back_body(const int vb, const int nwg, 
 // (host flips the sign), keeping the convention model = -SC_MODEL.
 // x_new = x [+] dx  (EigenQuaternionParameterization::Plus on the quaternion, plain add elsewhere)
 // ... fused with the camera part of the model cost change (k_model_cam's body; d <= 15 n_kf threads of the same grid)
+template <int NT = kT>
 __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm, StateP s, const double* __restrict__ dxc, const double* __restrict__ dxl,
                                                 double* __restrict__ poses2, double* __restrict__ vel2, double* __restrict__ ba2,
                                                 double* __restrict__ bg2, double* __restrict__ invd2, double* __restrict__ scal, int d, int ld,
                                                 const double* __restrict__ B, const double* __restrict__ gc, double inv_radius,
                                                 const unsigned char* __restrict__ pose_const, const JacobiDev jac) {
-  const int i = vb * kT + threadIdx.x;
+  const int i = vb * NT + threadIdx.x;
   // step_norm / x_norm as Ceres takes them (trust_region_minimizer.cc): |x - x_plus_delta| and |x| over the AMBIENT parameter vector of the
   // reduced program — the quaternion's four coefficients, not its three tangent increments; constant pose blocks are not part of it
   double m = 0.0, n2 = 0.0, g = 0.0, x2 = 0.0;
@@ -2727,7 +2739,7 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
       x2 += ((cm & 2) ? 0.0 : s.vel[3 * i + c] * s.vel[3 * i + c]) + ((cm & 4) ? 0.0 : s.ba[3 * i + c] * s.ba[3 * i + c]) + ((cm & 8) ? 0.0 : s.bg[3 * i + c] * s.bg[3 * i + c]);
   }
   if (i < n_lm) invd2[i] = s.inv_depth[i] + dxl[i];
-  if (vb * kT < d) {      // block-uniform
+  if (vb * NT < d) {      // block-uniform
     block_add(m, scal + SC_MODEL); block_add(n2, scal + SC_DXNORM);
     for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_down(g, o));
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(scal + SC_GMAX + (vb & (kStripes - 1))), (unsigned long long)__double_as_longlong(g));
@@ -2750,6 +2762,41 @@ __device__ __forceinline__ void step_tail_body(const int bx, const TailArgs& A) 
 __global__ __launch_bounds__(kT) void k_step_tail(TailArgs a) { step_tail_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_step_tail_b(const TailArgs* __restrict__ t) { step_tail_body(blockIdx.x, t[blockIdx.y]); }
 __global__ __launch_bounds__(kT) void k_step_tail_bt(const TailArgs* __restrict__ t) { step_tail_body(blockIdx.y, t[blockIdx.x]); }
+
+// The back substitution and the step tail as ONE launch (single-window chain).  The landmark back-substitution needs the POSE part of the
+// step only, and the poses are solved first (dense corner, 16 of the back substitution's 28 us); the sparse levels behind it (the
+// velocities' and biases' increments, 11 us in one workgroup) and the landmark pass (10 us in hundreds of workgroups) have nothing to do
+// with each other, yet as two launches they ran one after the other.  Here workgroup 0 is the back substitution — it publishes the pose
+// increments as soon as the dense corner is done, goes on with the sparse levels and finally applies the step to the keyframe states
+// (apply_step_body) — and workgroups 1.. are the landmark pass: they wait for the pose increments inside the launch (bounded, like the
+// chained sparse levels: on a time-out the hand-over flag is raised, the pass is not judged and the host re-runs it with the two launches
+// of old; SpSrc has the rules) and then walk the landmarks.  One launch boundary less and the two tails overlap: 39 -> 29 us at configs[3].
+struct BackTailArgs { BackArgs back; TailArgs tail; int g_lm; int fenced; unsigned timeout_ticks; int* fail; };
+__global__ __launch_bounds__(kBT) void k_backsolve_tail(BackTailArgs a) {
+  if (a.back.done && *a.back.done) return;                      // (every workgroup tests the same flag: nobody waits for a producer that has left)
+  if (blockIdx.x == 0) {
+    chol_backsolve_body(a.back);
+    // the whole step is in xout (this workgroup wrote it): apply it to the keyframe states, with the camera part of the model cost change
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    const TailArgs& T = a.tail;
+    const double inv_radius = 1.0 / *T.radius;
+    for (int vb = 0; vb * kBT < max(T.d, T.n_kf); ++vb)
+      apply_step_body<kBT>(vb, T.n_kf, 0, T.s, T.dxc, T.dxl, T.poses2, T.vel2, T.ba2, T.bg2, T.invd2, T.scal, T.d, T.ld, T.B, T.gc, inv_radius, T.pose_const, T.jac);
+    return;
+  }
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(a.back.pose_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > (unsigned long long)a.timeout_ticks) { atomicMax(a.fail, kFailHandover + 90000); break; }
+    }
+  }
+  __syncthreads();
+  if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const TailArgs& T = a.tail;
+  landmark_back_body<kBT>((int)blockIdx.x - 1, a.g_lm, T.n_lm, T.dp, T.ldE, T.E, T.C, T.Cd, T.gr, T.dxc, T.s.inv_depth, T.dxl, T.invd2, T.scal, T.kmin, T.kmax);
+}
 
 // ------------------------------------------------------------------------------------------------ closing an iteration on device
 // One workgroup per window: the step-quality test, the trust-region update, the commit of an accepted candidate (a copy of a few tens
@@ -2993,6 +3040,7 @@ struct Chain {
   CholArgs chol{};
   BackArgs back{}; size_t back_lds = 0;
   TailArgs tail{}; size_t tail_lds = 0;
+  bool back_tail_merged = false; BackTailArgs bt{}; size_t bt_lds = 0;      // k_backsolve_tail (single-window chain, chained levels allowed)
   CostArgs cost{};
   DecideArgs dec{};
 };
@@ -3310,6 +3358,25 @@ static int build_chain(lvf_problem* p) {
     a.bg2 = p->bg2.p; a.invd2 = p->invd2.p; a.d = p->d; a.ld = p->dpad; a.B = p->B.p; a.gc = p->gc.p; a.radius = radius; a.nblocks = a.g_lm + grid(p->d); a.done = done; a.pose_const = p->pose_const.p; a.jac = jac;
     c.tail_lds = (size_t)p->ldE * sizeof(double);
   }
+  {
+    // the merged back substitution + step tail (k_backsolve_tail): where in-launch hand-overs are allowed at all (the early form clears the
+    // arrival counters with the accumulators; a problem whose hand-over timed out keeps its launches apart: lvf_problem::no_chain)
+    static const bool merge_on = [] { const char* e = std::getenv("LVF_BACK_TAIL_MERGE"); return !(e && e[0] == '0'); }();
+    static const bool chain_on = [] { const char* e = std::getenv("LVF_CHAIN_LEVELS"); return !(e && std::atoi(e) <= 0); }();
+    static const unsigned bt_timeout = [] { const char* e = std::getenv("LVF_CHAIN_TIMEOUT_US"); return e ? (unsigned)std::max(1, std::atoi(e)) * 100u : 200000u; }();
+    static const int bt_fenced = [] { const char* e = std::getenv("LVF_CHAIN_FENCE"); return (e && e[0] == '0') ? 0 : 1; }();
+    c.back_tail_merged = merge_on && chain_on && c.early && !p->no_chain && p->n_lm > 0 && c.tail.g_lm > 0;
+    if (c.back_tail_merged) {
+      BackTailArgs& m = c.bt;
+      m.back = c.back; m.tail = c.tail;
+      m.back.pose_ready = reinterpret_cast<int*>(p->sp_sync.p) + 2 * kSpMaxLevels - 2;      // (the last int pair of the arrival-counter block: the levels use pairs 0 .. n_levels - 2)
+      m.back.n_pose = p->dp;
+      m.g_lm = std::min(320, (p->n_lm + kBT / 16 - 1) / (kBT / 16));       // (512-thread workgroups: the same lanes in flight as 640 of 256)
+      m.fenced = bt_fenced; m.timeout_ticks = bt_timeout; m.fail = fail;
+      if (p->force_handover_timeouts > 1) { m.back.pose_ready = reinterpret_cast<int*>(p->sp_sync.p) + 2 * kSpMaxLevels - 4; m.timeout_ticks = 2000u; }      // test hook (n >= 2): a flag nobody raises
+      c.bt_lds = std::max(c.back_lds, c.tail_lds);
+    }
+  }
   fill_cost_visual(p, c.cost.a);
   c.cost.n_kf = p->n_kf; c.cost.s = s2; c.cost.huber = 0.0; c.cost.cost = p->scal.p + SC_COST_NEW; c.cost.done = done;
   c.cost.nblocks = c.cost.a.g_tc + c.cost.a.g_tf + grid(c.cost.a.n_po);
@@ -3621,11 +3688,17 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
     static const bool back_timing = std::getenv("LVF_BACK_TIMING") != nullptr;
     if (back_timing) { LVF_TRY(p->dbg.ensure(64)); ba.sp.dbg = p->dbg.p; }
     stage_mark(p, ST_CHOL, p->nb);
-    LVF_CHAIN_LAUNCH(p, ST_BACKSOLVE, k_chol_backsolve, dim3(1), dim3(kBT), c.back_lds, q, ba);
-    stage_mark(p, ST_BACKSOLVE, 1);
+    if (c.back_tail_merged && !back_timing) {
+      LVF_CHAIN_LAUNCH(p, ST_BACKSOLVE, k_backsolve_tail, dim3(1 + c.bt.g_lm), dim3(kBT), c.bt_lds, q, c.bt);
+      stage_mark(p, ST_BACKSOLVE, 1);
+      stage_mark(p, ST_STEP_TAIL, 0);
+    } else {
+      LVF_CHAIN_LAUNCH(p, ST_BACKSOLVE, k_chol_backsolve, dim3(1), dim3(kBT), c.back_lds, q, ba);
+      stage_mark(p, ST_BACKSOLVE, 1);
+      LVF_CHAIN_LAUNCH(p, ST_STEP_TAIL, k_step_tail, dim3(c.tail.nblocks), dim3(kT), c.tail_lds, q, c.tail);
+      stage_mark(p, ST_STEP_TAIL, 1);
+    }
   }
-  LVF_CHAIN_LAUNCH(p, ST_STEP_TAIL, k_step_tail, dim3(c.tail.nblocks), dim3(kT), c.tail_lds, q, c.tail);
-  stage_mark(p, ST_STEP_TAIL, 1);
   // candidate cost: the small passes first, then the visual pass whose last workgroup closes the iteration
   CostArgs ca = c.cost;
   ca.huber = p->huber;

@@ -83,6 +83,24 @@ def test_forced_timeout_is_retried_unchained(ctx, oracle, n_kf, n_lm, seed):
     close_all(prob, b, st)
 
 
+def test_forced_timeout_of_the_pose_hand_over(ctx, oracle):
+    """The merged back substitution + step tail (k_backsolve_tail): the landmark workgroups wait INSIDE the launch for the pose increments.
+    n = 2 makes that wait (and the chained level's) give up: the pass must be re-run with separate launches and land where the undisturbed
+    solve lands."""
+    from lvio_fusion_amd import api
+    cfg, st, b, prob, win = build(api, ctx, oracle, 20, 4000, 78, n_pre=0)
+    opt = fixed(api, 5)
+    ref = prob.solve(opt)
+    x_ref = state_of(api, st)
+    reset(api, st, cfg)
+    prob.debug_force_handover_timeout(2)
+    got = prob.solve(opt)
+    assert got.hand_over_retries >= 1 and got.num_iterations == ref.num_iterations and got.num_successful_steps == ref.num_successful_steps
+    assert abs(got.final_cost - ref.final_cost) <= 1e-9 * abs(ref.final_cost)
+    same_state(x_ref, state_of(api, st))
+    close_all(prob, b, st)
+
+
 def test_forced_timeout_in_a_batch(ctx, oracle):
     """One window of three times out: it alone is re-run, the other two are untouched; every window equals its single solve."""
     from lvio_fusion_amd import api
