@@ -2446,7 +2446,7 @@ __device__ __forceinline__ T ld_off32(const T* base, unsigned byte_off) {     //
 constexpr int kBT = 512, kBParts = kBT / 64, kBackPre = 256 / kBParts, kBackInv = 64 / kBParts, kTailPre = 6;
 // pose_ready (merged back-substitution + step tail, k_backsolve_tail): once the dense corner is solved the POSE part of the step (natural
 // unknowns [0, n_pose)) is written out and *pose_ready is raised (release, agent scope) — what the landmark back-substitution waits for
-struct BackArgs { const double* Sd; int ld, d; const double* Dinv; double* xout; SpBack sp; const int* done; const double* Ldiag; int* pose_ready = nullptr; int n_pose = 0; };
+struct BackArgs { const double* Sd; int ld, d; const double* Dinv; double* xout; SpBack sp; const int* done; const double* Ldiag; int* pose_ready = nullptr; int n_pose = 0; int pose_fenced = 0; };
 __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
   const int dv = done_flag_issue(A.done);
   const double* S = A.Sd; const int ld = A.ld, d = A.d; const double* Dinv = A.Dinv; double* xout = A.xout; const SpBack& sp = A.sp;
@@ -2570,10 +2570,14 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
   if (A.pose_ready) {
     // the pose increments are final (every pose row lives in the dense corner): out they go, so that the landmark back-substitution — which
     // reads nothing else of the step — runs in the sibling workgroups of this launch WHILE the sparse levels below are solved here
-    for (int i = tid; i < A.n_pose; i += kBT) xout[i] = sm[sp.perm[i]];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    lds_barrier();
-    if (tid == 0) __hip_atomic_store(A.pose_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // The increments and the flag travel as agent-scope ATOMICS (written through to the coherence point, read there by the consumers): an
+    // agent-scope release / acquire FENCE pair instead writes this XCD's dirty L2 lines back and makes every consumer invalidate its L2 —
+    // measured: 6 us on this workgroup's path and the landmark pass twice as long (320 workgroups flushing the E rows out of each other's
+    // L2).  pose_fenced (LVF_CHAIN_FENCE=2) adds the fences back for A/B.
+    for (int i = tid; i < A.n_pose; i += kBT) __hip_atomic_store(xout + i, sm[sp.perm[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (A.pose_fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave's stores have been performed before the flag goes up
+    if (tid == 0) __hip_atomic_store(A.pose_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- sparse levels, last eliminated first
   for (int lv = sp.lv.n - 1; lv >= 0; --lv) {
@@ -2645,14 +2649,15 @@ __global__ __launch_bounds__(kBT) void k_chol_backsolve_b(const BackArgs* __rest
 // landmark back-substitution: dl = (-gr - e_l . dx_pose) / Cd ; model terms and norms
 // (on DENSE rows one thread per landmark beat a wave per landmark, 25.6 vs 29.9 us; with the row limited to the landmark's track
 // a per-thread walk diverges (41-54 us) and 16 lanes per landmark is the right shape)
-template <int NT = kT>
+// COH_DX: the pose increments were published by a sibling workgroup of THIS launch as agent-scope atomic stores: read past the non-coherent cache levels
+template <int NT = kT, bool COH_DX = false>
 __device__ __forceinline__ void landmark_back_body(const int vb, const int nwg, int n_lm, int dp, int ldE, const double* __restrict__ E,
                                                    const double* __restrict__ C, const double* __restrict__ Cd, const double* __restrict__ gr,
                                                    const double* __restrict__ dxc, const double* __restrict__ inv_depth,
                                                    double* __restrict__ dxl, double* __restrict__ invd2, double* __restrict__ scal,
                                                    const int* __restrict__ kmin, const int* __restrict__ kmax) {
   extern __shared__ double sdx[];
-  for (int i = threadIdx.x; i < dp; i += NT) sdx[i] = dxc[i];
+  for (int i = threadIdx.x; i < dp; i += NT) sdx[i] = COH_DX ? __hip_atomic_load(dxc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : dxc[i];
   __syncthreads();
   // 16 lanes per landmark: the band of a row is a few 128-byte runs, read coalesced and reduced with four shuffles; the grid is
   // capped and strides over the landmarks so that the three scalar sums cost one atomic per WORKGROUP (thousands of per-wave
@@ -2698,7 +2703,9 @@ __device__ __forceinline__ void landmark_back_body(const int vb, const int nwg, 
 // (host flips the sign), keeping the convention model = -SC_MODEL.
 // x_new = x [+] dx  (EigenQuaternionParameterization::Plus on the quaternion, plain add elsewhere)
 // ... fused with the camera part of the model cost change (k_model_cam's body; d <= 15 n_kf threads of the same grid)
-template <int NT = kT>
+// PARTS: bit 0 = the pose unknowns (sums over [0, 6 n_kf), candidate poses), bit 1 = the (v, ba, bg) unknowns (sums over [6 n_kf, d), candidate
+// velocities / biases); 3 = everything (k_step_tail).  k_backsolve_tail runs the two parts in different workgroups at different times.
+template <int NT = kT, int PARTS = 3>
 __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm, StateP s, const double* __restrict__ dxc, const double* __restrict__ dxl,
                                                 double* __restrict__ poses2, double* __restrict__ vel2, double* __restrict__ ba2,
                                                 double* __restrict__ bg2, double* __restrict__ invd2, double* __restrict__ scal, int d, int ld,
@@ -2708,7 +2715,7 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
   // step_norm / x_norm as Ceres takes them (trust_region_minimizer.cc): |x - x_plus_delta| and |x| over the AMBIENT parameter vector of the
   // reduced program — the quaternion's four coefficients, not its three tangent increments; constant pose blocks are not part of it
   double m = 0.0, n2 = 0.0, g = 0.0, x2 = 0.0;
-  if (i < d) {
+  if (i < d && ((PARTS & 1) || i >= 6 * n_kf) && ((PARTS & 2) || i < 6 * n_kf)) {
     const double dx = dxc[i];
     const double h = B[(size_t)i * ld + i], h0d = jac.h0[i];
     m = -0.5 * dx * (lm_damping(h, *jac.frozen ? h0d : h) * inv_radius * dx - gc[i]);      // (first pass: H0 = H, being recorded by the assembly)
@@ -2716,7 +2723,8 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
     n2 = rot ? 0.0 : dx * dx;
     g = fabs(gc[i]);
   }
-  if (i < n_kf) {
+  const int cm_kf = (i < n_kf && pose_const) ? pose_const[i] : 0;      // bit 0: pose, bits 1..3: v, ba, bg held constant
+  if (i < n_kf && (PARTS & 1)) {
     const double* p = s.poses + 7 * i; const double* dlt = dxc + 6 * i;
     const double nrm = sqrt(dlt[0] * dlt[0] + dlt[1] * dlt[1] + dlt[2] * dlt[2]);
     double* o = poses2 + 7 * i;
@@ -2730,11 +2738,13 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
       o[2] = cw * xz + dx * xy - dy * xx + dz * xw;
     } else { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
     for (int c = 0; c < 3; ++c) o[4 + c] = p[4 + c] + dlt[3 + c];
+    for (int c = 0; c < 4; ++c) n2 += (o[c] - p[c]) * (o[c] - p[c]);
+    if (!(cm_kf & 1)) for (int c = 0; c < 7; ++c) x2 += p[c] * p[c];
+  }
+  if (i < n_kf && (PARTS & 2)) {
+    const int cm = cm_kf;
     const double* dv = dxc + 6 * n_kf + 9 * i;
     for (int c = 0; c < 3; ++c) { vel2[3 * i + c] = s.vel[3 * i + c] + dv[c]; ba2[3 * i + c] = s.ba[3 * i + c] + dv[3 + c]; bg2[3 * i + c] = s.bg[3 * i + c] + dv[6 + c]; }
-    for (int c = 0; c < 4; ++c) n2 += (o[c] - p[c]) * (o[c] - p[c]);
-    const int cm = pose_const ? pose_const[i] : 0;      // bit 0: pose, bits 1..3: v, ba, bg held constant
-    if (!(cm & 1)) for (int c = 0; c < 7; ++c) x2 += p[c] * p[c];
     for (int c = 0; c < 3; ++c)
       x2 += ((cm & 2) ? 0.0 : s.vel[3 * i + c] * s.vel[3 * i + c]) + ((cm & 4) ? 0.0 : s.ba[3 * i + c] * s.ba[3 * i + c]) + ((cm & 8) ? 0.0 : s.bg[3 * i + c] * s.bg[3 * i + c]);
   }
@@ -2774,28 +2784,45 @@ __global__ __launch_bounds__(kT) void k_step_tail_bt(const TailArgs* __restrict_
 struct BackTailArgs { BackArgs back; TailArgs tail; int g_lm; int fenced; unsigned timeout_ticks; int* fail; };
 __global__ __launch_bounds__(kBT) void k_backsolve_tail(BackTailArgs a) {
   if (a.back.done && *a.back.done) return;                      // (every workgroup tests the same flag: nobody waits for a producer that has left)
+  const TailArgs& T = a.tail;
   if (blockIdx.x == 0) {
     chol_backsolve_body(a.back);
-    // the whole step is in xout (this workgroup wrote it): apply it to the keyframe states, with the camera part of the model cost change
+    // the whole step is in xout (this workgroup wrote it): the velocities' and biases' part is applied here, with its share of the model cost
+    // change.  (Requesting what that part reads — B's diagonal, the gradient, the states — ahead of the back substitution was measured
+    // SLOWER: 36.1 vs 33.1 us for the launch; the registers it holds across the solve cost more than the three round trips it saves.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    const TailArgs& T = a.tail;
     const double inv_radius = 1.0 / *T.radius;
     for (int vb = 0; vb * kBT < max(T.d, T.n_kf); ++vb)
-      apply_step_body<kBT>(vb, T.n_kf, 0, T.s, T.dxc, T.dxl, T.poses2, T.vel2, T.ba2, T.bg2, T.invd2, T.scal, T.d, T.ld, T.B, T.gc, inv_radius, T.pose_const, T.jac);
+      apply_step_body<kBT, 2>(vb, T.n_kf, 0, T.s, T.dxc, T.dxl, T.poses2, T.vel2, T.ba2, T.bg2, T.invd2, T.scal, T.d, T.ld, T.B, T.gc, inv_radius, T.pose_const, T.jac);
+    if (a.back.sp.dbg && threadIdx.x == 0) a.back.sp.dbg[55] = wall_clock64();      // LVF_BACK_TIMING: the step is applied
     return;
   }
+  unsigned long long* ldbg = (a.back.sp.dbg && (blockIdx.x == 2 || blockIdx.x == gridDim.x - 1) && threadIdx.x == 0) ? a.back.sp.dbg + (blockIdx.x == 2 ? 56 : 59) : nullptr;
+  if (ldbg) ldbg[0] = wall_clock64();
   if (threadIdx.x == 0) {
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(a.back.pose_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_s_sleep(16);
       if (wall_clock64() - t0 > (unsigned long long)a.timeout_ticks) { atomicMax(a.fail, kFailHandover + 90000); break; }
     }
   }
   __syncthreads();
   if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  const TailArgs& T = a.tail;
-  landmark_back_body<kBT>((int)blockIdx.x - 1, a.g_lm, T.n_lm, T.dp, T.ldE, T.E, T.C, T.Cd, T.gr, T.dxc, T.s.inv_depth, T.dxl, T.invd2, T.scal, T.kmin, T.kmax);
+  if (ldbg) ldbg[1] = wall_clock64();
+  if (blockIdx.x == 1) {
+    // the pose part of the step: candidate poses and the pose unknowns' share of the model cost change / step norm (the increments are read
+    // at the coherence point into LDS; apply_step_body takes them from there)
+    extern __shared__ double sdx_pose[];
+    for (int i = threadIdx.x; i < T.dp; i += kBT) sdx_pose[i] = __hip_atomic_load(T.dxc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double inv_radius = 1.0 / *T.radius;
+    for (int vb = 0; vb * kBT < max(T.dp, T.n_kf); ++vb)
+      apply_step_body<kBT, 1>(vb, T.n_kf, 0, T.s, sdx_pose, T.dxl, T.poses2, T.vel2, T.ba2, T.bg2, T.invd2, T.scal, T.d, T.ld, T.B, T.gc, inv_radius, T.pose_const, T.jac);
+    return;
+  }
+  landmark_back_body<kBT, true>((int)blockIdx.x - 2, a.g_lm, T.n_lm, T.dp, T.ldE, T.E, T.C, T.Cd, T.gr, T.dxc, T.s.inv_depth, T.dxl, T.invd2, T.scal, T.kmin, T.kmax);
+  if (ldbg) ldbg[2] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------ closing an iteration on device
@@ -3364,17 +3391,22 @@ static int build_chain(lvf_problem* p) {
     static const bool merge_on = [] { const char* e = std::getenv("LVF_BACK_TAIL_MERGE"); return !(e && e[0] == '0'); }();
     static const bool chain_on = [] { const char* e = std::getenv("LVF_CHAIN_LEVELS"); return !(e && std::atoi(e) <= 0); }();
     static const unsigned bt_timeout = [] { const char* e = std::getenv("LVF_CHAIN_TIMEOUT_US"); return e ? (unsigned)std::max(1, std::atoi(e)) * 100u : 200000u; }();
-    static const int bt_fenced = [] { const char* e = std::getenv("LVF_CHAIN_FENCE"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int bt_fenced = [] { const char* e = std::getenv("LVF_CHAIN_FENCE"); return e ? std::atoi(e) : 1; }();
+    static const bool bt_big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(k_backsolve_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
     c.back_tail_merged = merge_on && chain_on && c.early && !p->no_chain && p->n_lm > 0 && c.tail.g_lm > 0;
     if (c.back_tail_merged) {
       BackTailArgs& m = c.bt;
       m.back = c.back; m.tail = c.tail;
       m.back.pose_ready = reinterpret_cast<int*>(p->sp_sync.p) + 2 * kSpMaxLevels - 2;      // (the last int pair of the arrival-counter block: the levels use pairs 0 .. n_levels - 2)
       m.back.n_pose = p->dp;
-      m.g_lm = std::min(320, (p->n_lm + kBT / 16 - 1) / (kBT / 16));       // (512-thread workgroups: the same lanes in flight as 640 of 256)
-      m.fenced = bt_fenced; m.timeout_ticks = bt_timeout; m.fail = fail;
+      // (one round of workgroups: the launch's register and LDS footprint is the back substitution's, so about one workgroup fits a CU, and a
+      // landmark workgroup that has to wait for a CU starts after the others are done)
+      static const int bt_wgs = [] { const char* e = std::getenv("LVF_BACK_TAIL_WGS"); return e ? std::max(1, std::atoi(e)) : 224; }();
+      m.g_lm = std::min(bt_wgs, (p->n_lm + kBT / 16 - 1) / (kBT / 16));
+      m.fenced = bt_fenced == 2; m.back.pose_fenced = bt_fenced == 2; m.timeout_ticks = bt_timeout; m.fail = fail;
       if (p->force_handover_timeouts > 1) { m.back.pose_ready = reinterpret_cast<int*>(p->sp_sync.p) + 2 * kSpMaxLevels - 4; m.timeout_ticks = 2000u; }      // test hook (n >= 2): a flag nobody raises
       c.bt_lds = std::max(c.back_lds, c.tail_lds);
+      if (c.bt_lds > 64 * 1024 && !bt_big_lds) c.back_tail_merged = false;
     }
   }
   fill_cost_visual(p, c.cost.a);
@@ -3688,8 +3720,10 @@ static int enqueue_iteration(lvf_problem* p, bool end_zero) {
     static const bool back_timing = std::getenv("LVF_BACK_TIMING") != nullptr;
     if (back_timing) { LVF_TRY(p->dbg.ensure(64)); ba.sp.dbg = p->dbg.p; }
     stage_mark(p, ST_CHOL, p->nb);
-    if (c.back_tail_merged && !back_timing) {
-      LVF_CHAIN_LAUNCH(p, ST_BACKSOLVE, k_backsolve_tail, dim3(1 + c.bt.g_lm), dim3(kBT), c.bt_lds, q, c.bt);
+    if (c.back_tail_merged) {
+      BackTailArgs bt = c.bt;
+      if (back_timing) bt.back.sp.dbg = p->dbg.p;
+      LVF_CHAIN_LAUNCH(p, ST_BACKSOLVE, k_backsolve_tail, dim3(2 + c.bt.g_lm), dim3(kBT), c.bt_lds, q, bt);
       stage_mark(p, ST_BACKSOLVE, 1);
       stage_mark(p, ST_STEP_TAIL, 0);
     } else {
@@ -3801,7 +3835,11 @@ static int lm_iteration(lvf_problem* p, const lvf_solver_options* o, double* rad
     unsigned long long t[64];
     LVF_HIP(hipMemcpy(t, p->dbg.p, sizeof(t), hipMemcpyDeviceToHost));
     std::fprintf(stderr, "backsolve phases (us):");
-    for (unsigned long long k = 1; k < t[63] && k < 63; ++k) std::fprintf(stderr, " %.2f", (double)(t[k] - t[k - 1]) * 0.01);
+    for (unsigned long long k = 1; k < t[63] && k < 55; ++k) std::fprintf(stderr, " %.2f", (double)(t[k] - t[k - 1]) * 0.01);
+    if (p->chain && p->chain->back_tail_merged)
+      std::fprintf(stderr, " | merged launch, us after workgroup 0's start: step applied %.2f ; first landmark workgroup starts %.2f, sees the poses %.2f, done %.2f ; last one starts %.2f, sees %.2f, done %.2f",
+                   (double)(t[55] - t[0]) * 0.01, (double)(t[56] - t[0]) * 0.01, (double)(t[57] - t[0]) * 0.01, (double)(t[58] - t[0]) * 0.01, (double)(t[59] - t[0]) * 0.01,
+                   (double)(t[60] - t[0]) * 0.01, (double)(t[61] - t[0]) * 0.01);
     std::fprintf(stderr, "\n");
   }
   out->cost_before = c.cost_before; out->cost_after = c.cost_after; out->model = c.model; out->dxnorm = c.dxnorm; out->xnorm = c.xnorm; out->gmax = c.gmax;
