@@ -2574,7 +2574,13 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
     // agent-scope release / acquire FENCE pair instead writes this XCD's dirty L2 lines back and makes every consumer invalidate its L2 —
     // measured: 6 us on this workgroup's path and the landmark pass twice as long (320 workgroups flushing the E rows out of each other's
     // L2).  pose_fenced (LVF_CHAIN_FENCE=2) adds the fences back for A/B.
-    for (int i = tid; i < A.n_pose; i += kBT) __hip_atomic_store(xout + i, sm[sp.perm[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      int last = -1;
+      for (int i = tid; i < A.n_pose; i += kBT) { __hip_atomic_store(xout + i, sm[sp.perm[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = i; }
+      // (a store is acknowledged to the wave before it is necessarily performed; a load of the same address is ordered behind it and RETURNS:
+      // once it is back — the s_waitcnt below — the store is where the consumers read.  Round 3 met the same with returnless atomic adds.)
+      if (last >= 0) { const double chk = __hip_atomic_load(xout + last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); asm volatile("" ::"v"(chk)); }
+    }
     if (A.pose_fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave's stores have been performed before the flag goes up
     if (tid == 0) __hip_atomic_store(A.pose_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
