@@ -3237,6 +3237,12 @@ static int build_chain(lvf_problem* p) {
     for (int lv = 0; lv < std::min(3, p->sp_levels.n); ++lv) fits = fits && (size_t)p->sp_shmem[lv] <= 64 * 1024;
     c.early = early_on && c.fast && c.has_imu && schur_merged && fits && p->sp_levels.n >= 2;      // (one level: it already hides in the Schur launch)
   }
+  // the merged back substitution + step tail (k_backsolve_tail) hands the pose increments over inside a launch: allowed where in-launch
+  // hand-overs are allowed at all (a problem whose hand-over timed out keeps its launches apart: lvf_problem::no_chain); its flag lives in the
+  // arrival-counter block, which is then cleared with the accumulators whether or not sparse levels are chained
+  static const bool bt_merge_on = [] { const char* e = std::getenv("LVF_BACK_TAIL_MERGE"); return !(e && e[0] == '0'); }();
+  static const bool bt_chain_on = [] { const char* e = std::getenv("LVF_CHAIN_LEVELS"); return !(e && std::atoi(e) <= 0); }();
+  const bool bt_wanted = bt_merge_on && bt_chain_on && !p->no_chain && p->n_lm > 0;
   {
     int k = 0;
     static const bool tri_on = [] { const char* e = std::getenv("LVF_ZERO_TRI"); return !(e && e[0] == '0'); }();
@@ -3248,7 +3254,8 @@ static int build_chain(lvf_problem* p) {
     };
     add(p->B.p, (size_t)p->dpad * p->dpad, p->dpad); add(p->gc.p, p->dpad);
     if (p->n_lm) { if (!p->compact) add(p->E.p, (size_t)p->n_lm * p->ldE); add(p->C.p, p->n_lm); add(p->gr.p, p->n_lm); }
-    if (c.early) { add(p->S.p, (size_t)p->ld * p->ld, p->ld); add(p->sp_sync.p, kSpMaxLevels); }     // early sparse levels add into S before k_prepare does; their arrival counters
+    if (c.early) add(p->S.p, (size_t)p->ld * p->ld, p->ld);      // early sparse levels add into S before k_prepare does
+    if (c.early || bt_wanted) add(p->sp_sync.p, kSpMaxLevels);     // the arrival counters of chained levels / the pose hand-over flag
     c.zero_end = c.zero; c.zero_end.count = k;         // cleared at the END of an iteration, beside the cost pass (the scalars: by the decision itself)
     add(p->scal.p, SC_N);
     c.zero.count = k;
@@ -3392,14 +3399,10 @@ static int build_chain(lvf_problem* p) {
     c.tail_lds = (size_t)p->ldE * sizeof(double);
   }
   {
-    // the merged back substitution + step tail (k_backsolve_tail): where in-launch hand-overs are allowed at all (the early form clears the
-    // arrival counters with the accumulators; a problem whose hand-over timed out keeps its launches apart: lvf_problem::no_chain)
-    static const bool merge_on = [] { const char* e = std::getenv("LVF_BACK_TAIL_MERGE"); return !(e && e[0] == '0'); }();
-    static const bool chain_on = [] { const char* e = std::getenv("LVF_CHAIN_LEVELS"); return !(e && std::atoi(e) <= 0); }();
     static const unsigned bt_timeout = [] { const char* e = std::getenv("LVF_CHAIN_TIMEOUT_US"); return e ? (unsigned)std::max(1, std::atoi(e)) * 100u : 200000u; }();
     static const int bt_fenced = [] { const char* e = std::getenv("LVF_CHAIN_FENCE"); return e ? std::atoi(e) : 1; }();
     static const bool bt_big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(k_backsolve_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
-    c.back_tail_merged = merge_on && chain_on && c.early && !p->no_chain && p->n_lm > 0 && c.tail.g_lm > 0;
+    c.back_tail_merged = bt_wanted && c.tail.g_lm > 0;
     if (c.back_tail_merged) {
       BackTailArgs& m = c.bt;
       m.back = c.back; m.tail = c.tail;
@@ -3414,6 +3417,9 @@ static int build_chain(lvf_problem* p) {
       c.bt_lds = std::max(c.back_lds, c.tail_lds);
       if (c.bt_lds > 64 * 1024 && !bt_big_lds) c.back_tail_merged = false;
     }
+    static const bool chain_info = std::getenv("LVF_CHAIN_INFO") != nullptr;
+    if (chain_info) std::fprintf(stderr, "chain: n_kf %d n_lm %d fast %d has_imu %d early %d compact %d levels %d no_chain %d merged_level0 %d back_tail_merged %d (g_lm %d, lds %zu)\n", p->n_kf, p->n_lm, (int)c.fast, (int)c.has_imu,
+                                 (int)c.early, (int)p->compact, c.n_levels, (int)p->no_chain, (int)c.merged_level0, (int)c.back_tail_merged, c.bt.g_lm, c.bt_lds);
   }
   fill_cost_visual(p, c.cost.a);
   c.cost.n_kf = p->n_kf; c.cost.s = s2; c.cost.huber = 0.0; c.cost.cost = p->scal.p + SC_COST_NEW; c.cost.done = done;
