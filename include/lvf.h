@@ -125,6 +125,12 @@ int lvf_state_create(lvf_ctx* ctx, int n_kf, int n_lm, lvf_state** out);
 int lvf_state_destroy(lvf_state* st);
 int lvf_state_set(lvf_state* st, int field, const double* host);
 int lvf_state_get(lvf_state* st, int field, double* host);
+/* lvf_state_create + the fields in one staged upload and one wait; a NULL field takes its default (identity poses, zeros, unit weights). */
+int lvf_state_create_from(lvf_ctx* ctx, int n_kf, int n_lm, const double* poses, const double* vel, const double* ba, const double* bg,
+                          const double* inv_depth, const double* w_visual, lvf_state** out);
+/* lvf_state_set for every field at once: ONE staged upload and one wait; a NULL pointer leaves that field as it is. */
+int lvf_state_set_all(lvf_state* st, const double* poses, const double* vel, const double* ba, const double* bg, const double* inv_depth,
+                      const double* w_visual);
 /* dst <- src (all fields; same n_kf / n_lm), device to device, asynchronous on dst's context: restoring a saved estimate without a host
  * round trip. */
 int lvf_state_copy(lvf_state* dst, const lvf_state* src);
@@ -145,6 +151,11 @@ int lvf_two_camera_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera
                           const int32_t* kf_idx, lvf_batch** out);
 /* parameter blocks (pose,v,ba,bg)[kf_i], (pose,v,ba,bg)[kf_j]; sqrt_info = LLT(cov^-1).L^T is factorised
  * once here (the reference re-inverts on every Evaluate: imu_error.hpp:32). */
+/* The caller VOUCHES that a TwoFrame batch has the shape Backend::BuildProblem always produces (backend.cpp:105-140) — sorted by current
+ * keyframe, first keyframe < current keyframe, at most one block per (landmark, current keyframe), one first keyframe per landmark — and hands
+ * blocks_per_kf2[n_kf]: lvf_problem_create then skips its host pass over the blocks.  A false claim gives wrong results; callers that cannot
+ * prove it do not call this (include/lvf_ceres_adapter.hpp proves it block by block while adapt::Problem is being filled). */
+int lvf_two_frame_set_shape(lvf_batch* two_frame, int n_kf, const int32_t* blocks_per_kf2);
 /* Optional per-block weights of a TwoCamera batch = each functor's `weight` constructor argument (visual_error.hpp:112; the reference
  * passes 5 * frame->weights.visual, backend.cpp:123).  weight[n] replaces 5 * w_visual[kf_idx[i]]; NULL restores the per-keyframe rule. */
 int lvf_two_camera_set_block_weights(lvf_batch* b, const double* weight);

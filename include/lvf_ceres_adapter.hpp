@@ -640,6 +640,12 @@ struct Window {
   std::vector<int> order_kind, order_idx;          // per residual block: which batch, which row
   lvf_camera left, right; bool have_left = false, have_right = false;
   double huber = -2.0;                             // -2 = not seen yet
+  // The TwoFrame blocks' shape, proved block by block while they arrive (WindowBuilder::add): sorted by current keyframe, first keyframe
+  // < current keyframe, one block per (landmark, current keyframe), one first keyframe per landmark — what Backend::BuildProblem always
+  // produces (backend.cpp:105-140).  While it holds the device side is told so (lvf_two_frame_set_shape) and skips its own pass over the blocks.
+  bool tf_shape_ok = true; int tf_last_k2 = -1;
+  std::vector<int32_t> tf_per_k2;                  // blocks per current keyframe
+  std::vector<int32_t> lm_first_kf, lm_last_k2;    // per landmark (index into lm_ptr): first keyframe of its TwoFrame blocks, current keyframe of the last one
 };
 
 // what can only be checked once every block is in: parameter blocks the device solver cannot hold constant individually.
@@ -741,7 +747,15 @@ struct WindowBuilder {
         if (!use_loss(loss)) return err(i, "visual blocks must share one HuberLoss/TrivialLoss");
         w->order_kind.push_back(1); w->order_idx.push_back((int)w->tf_lm.size());
         w->tf_f.insert(w->tf_f.end(), f->first_ob, f->first_ob + 2); w->tf_o.insert(w->tf_o.end(), f->ob, f->ob + 2);
-        w->tf_lm.push_back(lm_of(params[0])); w->tf_k1.push_back(k1); w->tf_k2.push_back(k2);
+        const int lm = lm_of(params[0]);
+        w->tf_lm.push_back(lm); w->tf_k1.push_back(k1); w->tf_k2.push_back(k2);
+        if (w->tf_shape_ok) {
+          if ((size_t)lm >= w->lm_first_kf.size()) { w->lm_first_kf.resize((size_t)lm + 1 + w->lm_first_kf.size() / 2, -1); w->lm_last_k2.resize(w->lm_first_kf.size(), -1); }
+          if ((size_t)k2 >= w->tf_per_k2.size()) w->tf_per_k2.resize((size_t)k2 + 1, 0);
+          const bool ok = k2 >= w->tf_last_k2 && k1 < k2 && w->lm_last_k2[lm] < k2 && (w->lm_first_kf[lm] < 0 || w->lm_first_kf[lm] == k1);
+          w->tf_shape_ok = ok;
+          w->tf_last_k2 = k2; w->lm_last_k2[lm] = k2; w->lm_first_kf[lm] = k1; ++w->tf_per_k2[k2];
+        }
         break;
       }
       case Kind::TwoCamera: {
@@ -827,7 +841,6 @@ inline bool upload_window(lvf_ctx* ctx, ceres::Problem* problem, const Window& w
   using clk = std::chrono::steady_clock;
   const bool timing = std::getenv("LVF_ADAPTER_TIMING") != nullptr;
   const auto u0 = clk::now();
-  if (lvf_state_create(ctx, n_kf, n_lm, &d->h.st) != LVF_OK) return fail(lvf_last_error());
   std::vector<double> poses(7 * (size_t)n_kf), vel(3 * (size_t)n_kf, 0.0), ba(vel), bg(vel), invd(n_lm);
   for (int k = 0; k < n_kf; ++k) {
     std::memcpy(&poses[7 * (size_t)k], w.pose_ptr[k], 56);
@@ -836,10 +849,8 @@ inline bool upload_window(lvf_ctx* ctx, ceres::Problem* problem, const Window& w
     if (w.bg_ptr[k]) std::memcpy(&bg[3 * (size_t)k], w.bg_ptr[k], 24);
   }
   for (int l = 0; l < n_lm; ++l) invd[l] = *w.lm_ptr[l];
+  if (lvf_state_create_from(ctx, n_kf, n_lm, poses.data(), vel.data(), ba.data(), bg.data(), n_lm ? invd.data() : nullptr, w.w_kf.data(), &d->h.st) != LVF_OK) return fail(lvf_last_error());
   lvf_state* st = d->h.st;
-  if (lvf_state_set(st, LVF_POSES, poses.data()) || lvf_state_set(st, LVF_VEL, vel.data()) || lvf_state_set(st, LVF_BA, ba.data()) ||
-      lvf_state_set(st, LVF_BG, bg.data()) || lvf_state_set(st, LVF_W_VISUAL, w.w_kf.data()) || (n_lm && lvf_state_set(st, LVF_INV_DEPTH, invd.data())))
-    return fail(lvf_last_error());
   const auto u1 = clk::now();
   if (!w.tc_lm.empty()) {
     if (lvf_two_camera_create(ctx, &w.left, &w.right, (int)w.tc_lm.size(), w.tc_l.data(), w.tc_r.data(), w.tc_lm.data(), w.tc_kf.data(), &d->tc) != LVF_OK)
@@ -851,6 +862,11 @@ inline bool upload_window(lvf_ctx* ctx, ceres::Problem* problem, const Window& w
     if (lvf_two_frame_create(ctx, &w.left, &w.right, (int)w.tf_lm.size(), w.tf_f.data(), w.tf_o.data(), w.tf_lm.data(), w.tf_k1.data(), w.tf_k2.data(), &d->tf) != LVF_OK)
       return fail(lvf_last_error());
     d->h.keep(d->tf);
+    if (w.tf_shape_ok) {             // BuildProblem's shape, proved while the blocks arrived: the device side need not walk them again
+      std::vector<int32_t> per(w.tf_per_k2);
+      per.resize((size_t)n_kf, 0);
+      if (lvf_two_frame_set_shape(d->tf, n_kf, per.data()) != LVF_OK) return fail(lvf_last_error());
+    }
   }
   if (!w.po_kf.empty()) {
     if (lvf_pose_only_create(ctx, &w.left, (int)w.po_kf.size(), w.po_o.data(), w.po_kf.data(), w.po_pi.data(), (int)w.po_kf.size(), w.po_pw.data(), &d->po) != LVF_OK)

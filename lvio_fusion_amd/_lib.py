@@ -115,6 +115,9 @@ _SIGS = {
     "lvf_state_set": (C.c_int, [_VP, C.c_int, c_double_p]),
     "lvf_state_get": (C.c_int, [_VP, C.c_int, c_double_p]),
     "lvf_state_copy": (C.c_int, [_VP, _VP]),
+    "lvf_state_create_from": (C.c_int, [_VP, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(_VP)]),
+    "lvf_state_set_all": (C.c_int, [_VP, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "lvf_two_frame_set_shape": (C.c_int, [_VP, C.c_int, c_int_p]),
     "lvf_pose_only_create": (C.c_int, [_VP, C.POINTER(Camera), C.c_int, c_double_p, c_int_p, c_int_p, C.c_int, c_double_p, C.POINTER(_VP)]),
     "lvf_two_frame_create": (C.c_int, [_VP, C.POINTER(Camera), C.POINTER(Camera), C.c_int, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, C.POINTER(_VP)]),
     "lvf_two_camera_create": (C.c_int, [_VP, C.POINTER(Camera), C.POINTER(Camera), C.c_int, c_double_p, c_double_p, c_int_p, c_int_p, C.POINTER(_VP)]),

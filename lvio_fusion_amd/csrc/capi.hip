@@ -238,7 +238,10 @@ int lvf_box_calibration(lvf_ctx* ctx, double* out8) {
 }
 
 // ------------------------------------------------------------------------------------------------ state
-int lvf_state_create(lvf_ctx* ctx, int n_kf, int n_lm, lvf_state** out) {
+// A state with its fields set in the same breath: ONE staged upload and one wait.  A NULL field takes its default (identity poses, zero
+// velocities / biases / inverse depths, unit visual weights).
+int lvf_state_create_from(lvf_ctx* ctx, int n_kf, int n_lm, const double* poses, const double* vel, const double* ba, const double* bg, const double* inv_depth,
+                          const double* w_visual, lvf_state** out) {
   LVF_REQUIRE(ctx && out, "lvf_state_create: null ctx/out");
   LVF_REQUIRE(n_kf >= 0 && n_lm >= 0, "lvf_state_create: negative size");
   LVF_TRY(lvf::enter(ctx));
@@ -249,21 +252,32 @@ int lvf_state_create(lvf_ctx* ctx, int n_kf, int n_lm, lvf_state** out) {
       (rc = st->bg.alloc((size_t)3 * n_kf)) || (rc = st->inv_depth.alloc(n_lm)) || (rc = st->w_visual.alloc(n_kf))) {
     delete st; return rc;
   }
-  // identity poses, zero elsewhere, unit weights: a defined state even before the caller uploads
-  std::vector<double> id((size_t)7 * n_kf, 0.0), ones(n_kf, 1.0);
-  for (int k = 0; k < n_kf; ++k) id[7 * k + 3] = 1.0;
   hipStream_t s = ctx->stream;
-  if (n_kf) {
-    LVF_HIP(hipMemcpyAsync(st->poses.p, id.data(), id.size() * 8, hipMemcpyHostToDevice, s));
-    LVF_HIP(hipMemcpyAsync(st->w_visual.p, ones.data(), ones.size() * 8, hipMemcpyHostToDevice, s));
-    LVF_HIP(hipMemsetAsync(st->vel.p, 0, (size_t)24 * n_kf, s));
-    LVF_HIP(hipMemsetAsync(st->ba.p, 0, (size_t)24 * n_kf, s));
-    LVF_HIP(hipMemsetAsync(st->bg.p, 0, (size_t)24 * n_kf, s));
+  const size_t k = (size_t)n_kf, l = (size_t)n_lm, total = 17 * k + l;
+  if (total) {
+    lvf::HostPin<double> stage;
+    lvf::StreamWaitGuard guard(s);             // (the pinned block goes back to the pool only after the copies have been waited for)
+    if ((rc = stage.reserve(total))) { guard.dismiss(); delete st; return rc; }
+    double* h = stage.p;
+    double *hp = h, *hv = h + 7 * k, *ha = hv + 3 * k, *hg = ha + 3 * k, *hw = hg + 3 * k, *hd = hw + k;
+    if (poses) std::memcpy(hp, poses, 7 * k * 8); else for (size_t i = 0; i < k; ++i) { double* q = hp + 7 * i; q[0] = q[1] = q[2] = 0.0; q[3] = 1.0; q[4] = q[5] = q[6] = 0.0; }
+    if (vel) std::memcpy(hv, vel, 3 * k * 8); else std::memset(hv, 0, 3 * k * 8);
+    if (ba) std::memcpy(ha, ba, 3 * k * 8); else std::memset(ha, 0, 3 * k * 8);
+    if (bg) std::memcpy(hg, bg, 3 * k * 8); else std::memset(hg, 0, 3 * k * 8);
+    if (w_visual) std::memcpy(hw, w_visual, k * 8); else for (size_t i = 0; i < k; ++i) hw[i] = 1.0;
+    if (inv_depth) std::memcpy(hd, inv_depth, l * 8); else std::memset(hd, 0, l * 8);
+    hipError_t e = hipSuccess;
+    auto up = [&](double* dst, const double* src, size_t n) { if (n && e == hipSuccess) e = hipMemcpyAsync(dst, src, n * 8, hipMemcpyHostToDevice, s); };
+    up(st->poses.p, hp, 7 * k); up(st->vel.p, hv, 3 * k); up(st->ba.p, ha, 3 * k); up(st->bg.p, hg, 3 * k); up(st->w_visual.p, hw, k); up(st->inv_depth.p, hd, l);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { delete st; return lvf::hip_fail(e, "lvf_state_create: upload", __FILE__, __LINE__); }
+    guard.dismiss();
   }
-  if (n_lm) LVF_HIP(hipMemsetAsync(st->inv_depth.p, 0, (size_t)8 * n_lm, s));
-  LVF_HIP(hipStreamSynchronize(s));
   *out = st;
   return LVF_OK;
+}
+int lvf_state_create(lvf_ctx* ctx, int n_kf, int n_lm, lvf_state** out) {
+  return lvf_state_create_from(ctx, n_kf, n_lm, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out);
 }
 int lvf_state_destroy(lvf_state* st) { delete st; return LVF_OK; }
 
@@ -284,6 +298,26 @@ int lvf_state_set(lvf_state* st, int field, const double* host) {
   double* p; size_t n;
   LVF_TRY(state_field(st, field, &p, &n));
   if (n) LVF_TRY(lvf::copy_up_wait(st->ctx, p, host, n * 8));
+  return LVF_OK;
+}
+// every field in ONE staged upload and one wait (lvf_state_set is a copy and a wait per field: six of them were 0.12 ms of adapt::Solve);
+// any pointer may be NULL (that field is left as it is)
+int lvf_state_set_all(lvf_state* st, const double* poses, const double* vel, const double* ba, const double* bg, const double* inv_depth, const double* w_visual) {
+  LVF_REQUIRE(st, "lvf_state_set_all: null state");
+  LVF_TRY(lvf::enter(st->ctx));
+  hipStream_t q = st->ctx->stream;
+  const size_t k = (size_t)st->n_kf, l = (size_t)st->n_lm;
+  struct Seg { const double* src; double* dst; size_t n; } seg[6] = {{poses, st->poses.p, 7 * k}, {vel, st->vel.p, 3 * k}, {ba, st->ba.p, 3 * k}, {bg, st->bg.p, 3 * k}, {inv_depth, st->inv_depth.p, l}, {w_visual, st->w_visual.p, k}};
+  size_t total = 0;
+  for (const Seg& g : seg) if (g.src) total += g.n;
+  if (total == 0) return LVF_OK;
+  lvf::HostPin<double> stage;
+  lvf::StreamWaitGuard guard(q);             // (the pinned block returns to the pool only after the copies have been waited for, on every path out)
+  LVF_TRY(stage.reserve(total));
+  size_t at = 0;
+  for (const Seg& g : seg) if (g.src && g.n) { std::memcpy(stage.p + at, g.src, g.n * 8); LVF_HIP(hipMemcpyAsync(g.dst, stage.p + at, g.n * 8, hipMemcpyHostToDevice, q)); at += g.n; }
+  LVF_HIP(hipStreamSynchronize(q));
+  guard.dismiss();
   return LVF_OK;
 }
 // dst <- src, every field, device to device on dst's stream; nothing is waited for (a later call on the same context is ordered after it)
@@ -380,6 +414,33 @@ int lvf_two_camera_create(lvf_ctx* ctx, const lvf_camera* left, const lvf_camera
   b->min_n_lm = max_idx(lm_idx, n) + 1;
   LVF_HIP(hipStreamSynchronize(s));
   *out = b;
+  return LVF_OK;
+}
+
+// The caller VOUCHES for the shape Backend::BuildProblem's TwoFrame blocks always have (backend.cpp:105-140: frames in time order, a frame's
+// features in one pass, landmarks keyed by id) and hands the blocks-per-current-keyframe counts:
+//   * the blocks are sorted by current keyframe (kf2 ascending);            * first keyframe < current keyframe in every block;
+//   * at most one block per (landmark, current keyframe);                   * every landmark has ONE first keyframe.
+// lvf_problem_create then skips its own host pass over the blocks (0.3 ms of adapt::Solve at 72 k blocks).  A false claim gives wrong results
+// (plain stores into a landmark's E row meeting adds): callers that cannot prove it — include/lvf_ceres_adapter.hpp proves it block by block
+// while the problem is being built — do not call this.
+int lvf_two_frame_set_shape(lvf_batch* b, int n_kf, const int32_t* blocks_per_kf2) {
+  LVF_REQUIRE(b && b->kind == LVF_K_TWO_FRAME, "lvf_two_frame_set_shape: not a two-frame batch");
+  LVF_REQUIRE(n_kf >= b->min_n_kf && (n_kf == 0 || blocks_per_kf2), "lvf_two_frame_set_shape: n_kf %d below the batch's keyframe indices (%d)", n_kf, b->min_n_kf);
+  long long total = 0;
+  for (int k = 0; k < n_kf; ++k) { LVF_REQUIRE(blocks_per_kf2[k] >= 0, "lvf_two_frame_set_shape: negative count"); total += blocks_per_kf2[k]; }
+  LVF_REQUIRE(total == (long long)b->n, "lvf_two_frame_set_shape: the counts add up to %lld, the batch has %d blocks", total, b->n);
+  // (cheap necessary conditions on the host copies the batch keeps: a caller's slip should fail here, not as a wrong solve)
+  if (!b->host_kf2.empty()) {
+    int at = 0;
+    for (int k = 0; k < n_kf; ++k) {
+      const int c = blocks_per_kf2[k];
+      if (c > 0) LVF_REQUIRE(b->host_kf2[at] == k && b->host_kf2[at + c - 1] == k, "lvf_two_frame_set_shape: run %d is not the blocks of current keyframe %d", k, k);
+      at += c;
+    }
+  }
+  b->kf2_counts.assign(blocks_per_kf2, blocks_per_kf2 + n_kf);
+  b->sorted_by_kf = true; b->unique_lk2_known = true;
   return LVF_OK;
 }
 
