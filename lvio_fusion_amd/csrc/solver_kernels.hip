@@ -3320,8 +3320,8 @@ static int build_chain(lvf_problem* p) {
     SpArgs& a = c.sp[lv];
     a.nodes = p->sp_nodes.p; a.first = p->sp_levels.first[lv]; a.tiles = p->sp_tiles[lv]; a.rows = p->sp_rows.p; a.S = p->S.p; a.ld = p->ld; a.W = p->sp_W.p;
     a.wstride = p->sp_wstride; a.Lout = p->sp_L.p; a.fail = fail; a.nblocks = p->sp_levels.count[lv] * p->sp_tiles[lv]; a.done = done;
-    // (2 ms at 100 MHz before a chained level gives up on the level below; LVF_CHAIN_TIMEOUT_US overrides; LVF_CHAIN_FENCE=0: relaxed hand-over, A/B only)
-    static const unsigned chain_timeout = [] { const char* e = std::getenv("LVF_CHAIN_TIMEOUT_US"); return e ? (unsigned)std::max(1, std::atoi(e)) * 100u : 200000u; }();
+    // (0.5 ms at 100 MHz before a chained level gives up on the level below — a hand-over normally takes microseconds, and a retry costs one iteration of 0.2 ms: round 4 waited 2 ms, ten iterations of latency on a shared GPU; LVF_CHAIN_TIMEOUT_US overrides; LVF_CHAIN_FENCE=0: relaxed hand-over, A/B only)
+    static const unsigned chain_timeout = [] { const char* e = std::getenv("LVF_CHAIN_TIMEOUT_US"); return e ? (unsigned)std::max(1, std::atoi(e)) * 100u : 50000u; }();
     static const int chain_fenced = [] { const char* e = std::getenv("LVF_CHAIN_FENCE"); return (e && e[0] == '0') ? 0 : 1; }();
     a.src = c.early ? SpSrc{p->B.p, p->dpad, p->dp, p->gc.p, radius, p->sp_rows_nat.p, nullptr, 0, nullptr, chain_fenced, chain_timeout, p->off, std::getenv("LVF_CHAIN_RMW_READ") ? 1 : 0, nullptr, lv == 0 ? 1 : 0}
                     : SpSrc{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, chain_fenced, chain_timeout, p->off, 0, nullptr, 0};
@@ -3399,7 +3399,7 @@ static int build_chain(lvf_problem* p) {
     c.tail_lds = (size_t)p->ldE * sizeof(double);
   }
   {
-    static const unsigned bt_timeout = [] { const char* e = std::getenv("LVF_CHAIN_TIMEOUT_US"); return e ? (unsigned)std::max(1, std::atoi(e)) * 100u : 200000u; }();
+    static const unsigned bt_timeout = [] { const char* e = std::getenv("LVF_CHAIN_TIMEOUT_US"); return e ? (unsigned)std::max(1, std::atoi(e)) * 100u : 50000u; }();
     static const int bt_fenced = [] { const char* e = std::getenv("LVF_CHAIN_FENCE"); return e ? std::atoi(e) : 1; }();
     static const bool bt_big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(k_backsolve_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
     c.back_tail_merged = bt_wanted && c.tail.g_lm > 0;
