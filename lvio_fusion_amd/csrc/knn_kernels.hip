@@ -28,7 +28,6 @@
 namespace lvf {
 
 constexpr int kB = 256;
-constexpr int kMaxLevels = LVF_MAX_GRID_LEVELS;
 
 // round-to-nearest primitives defined UNDER the pragma above (the HIP header versions carry the `contract` flag)
 __device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
@@ -72,10 +71,6 @@ __device__ __forceinline__ void pack_bounds_body(const int bx, const int nbx, in
     if (threadIdx.x < 3) atomicMin(bounds + threadIdx.x, f2ord(v)); else atomicMax(bounds + threadIdx.x, f2ord(v));
   }
 }
-__global__ __launch_bounds__(kB) void k_pack_bounds(int M, const float* __restrict__ src, int stride, float4* __restrict__ dst,
-                                                    unsigned* __restrict__ bounds) {
-  pack_bounds_body(blockIdx.x, gridDim.x, M, src, stride, dst, bounds);
-}
 // table forms (blockIdx.y = map) of the index build's launches: lvf_map_create_batch enqueues ONE launch per step for all the maps of a
 // round instead of one per map (16 loop-closure maps x 3 grid levels x 6 steps were ~290 launches of a few microseconds each)
 struct PackJob { int M, stride, nbx, pad; const float* src; float4* dst; unsigned* bounds; };
@@ -102,10 +97,6 @@ __device__ __forceinline__ void cell_count_body(const int bx, int M, const float
   int start, len;
   const bool head = cell_runs(c, start, len);
   if (head && c >= 0) atomicAdd(counts + c, len);
-}
-__global__ __launch_bounds__(kB) void k_cell_count(int M, const float4* __restrict__ pts, GridP g, int* __restrict__ cell_of,
-                                                   int* __restrict__ counts) {
-  cell_count_body(blockIdx.x, M, pts, g, cell_of, counts);
 }
 
 // (sum over cells of count^2) / M is the population of the cell a random map point lives in, i.e. the candidates a query in a
@@ -208,11 +199,6 @@ __device__ __forceinline__ void cell_scatter_body(const int bx, int M, const flo
   float4 p = pts[i];
   p.w = __int_as_float(i);
   sorted[cell_start[c] + base + ((int)(threadIdx.x & 63) - start)] = p;
-}
-__global__ __launch_bounds__(kB) void k_cell_scatter(int M, const float4* __restrict__ pts, const int* __restrict__ cell_of,
-                                                     const int* __restrict__ cell_start, int* __restrict__ cursor,
-                                                     float4* __restrict__ sorted) {
-  cell_scatter_body(blockIdx.x, M, pts, cell_of, cell_start, cursor, sorted);
 }
 // one grid level of one map (table entry of the batched index build)
 struct LevelJob {
@@ -612,128 +598,23 @@ static int prepare_level(lvf_map* m, lvf_map::Level& lv, float cell, const float
   job->cell_start = lv.cell_start.p; job->sorted = lv.sorted.p; job->sumsq = sumsq_dev;
   return LVF_OK;
 }
-static int enqueue_level(lvf_map* m, lvf_map::Level& lv, float cell, const float lo[3], const float hi[3], LevelTmp& t, unsigned long long* sumsq_dev) {
-  hipStream_t s = m->ctx->stream;
-  const int M = m->M;
-  lv.nx = (int)(std::floor((hi[0] - lo[0]) / cell) + 1); lv.ny = (int)(std::floor((hi[1] - lo[1]) / cell) + 1);
-  lv.nz = (int)(std::floor((hi[2] - lo[2]) / cell) + 1);
-  lv.cell = cell; lv.inv_cell = 1.0f / cell; lv.ox = lo[0]; lv.oy = lo[1]; lv.oz = lo[2];
-  const int ncells = lv.nx * lv.ny * lv.nz;
-  const GridP g{lv.ox, lv.oy, lv.oz, lv.cell, lv.inv_cell, lv.nx, lv.ny, lv.nz};
-  const int gridM = (M + kB - 1) / kB, nb = (ncells + kScanChunk - 1) / kScanChunk;
-  DevBuf<int>&cell_of = t.cell_of, &counts = t.counts, &bsums = t.bsums;
-  DevBuf<unsigned long long>& bsq = t.bsq;
-  LVF_TRY(cell_of.alloc(M)); LVF_TRY(counts.alloc(ncells)); LVF_TRY(bsums.alloc(nb)); LVF_TRY(bsq.alloc(nb));
-  LVF_TRY(lv.cell_start.alloc((size_t)ncells + 1)); LVF_TRY(lv.sorted.alloc(M));
-  LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)ncells * sizeof(int), s));
-  hipLaunchKernelGGL(k_cell_count, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, g, cell_of.p, counts.p);
-  // exclusive scan of the counts -> cell_start[0..ncells]; the pass also yields sum(count^2) and leaves the counts zeroed, so the
-  // same array is the scatter cursor
-  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p, bsq.p);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanT), 0, s, nb, bsums.p, lv.cell_start.p + ncells, bsq.p, sumsq_dev);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanT), 0, s, ncells, counts.p, bsums.p, lv.cell_start.p, 1);
-  hipLaunchKernelGGL(k_cell_scatter, dim3(gridM), dim3(kB), 0, s, M, m->raw.p, cell_of.p, lv.cell_start.p, counts.p, lv.sorted.p);
-  LVF_HIP(hipGetLastError());
-  return LVF_OK;
-}
-// one level, waited for.  *occupancy = point-weighted mean cell population.
-static int build_level(lvf_map* m, lvf_map::Level& lv, float cell, const float lo[3], const float hi[3], double* occupancy) {
-  LevelTmp t;
-  DevBuf<unsigned long long> sumsq;
-  LVF_TRY(sumsq.alloc(1));
-  LVF_TRY(enqueue_level(m, lv, cell, lo, hi, t, sumsq.p));
-  unsigned long long ss = 0;
-  LVF_TRY(read_back(m->ctx, &ss, sumsq.p, sizeof(ss)));   // (waits for the stream: temporaries are freed on return)
-  *occupancy = (double)ss / (double)m->M;
-  return LVF_OK;
-}
 __global__ void k_bounds_init(int n, unsigned* __restrict__ bounds) {      // [n][min xyz | max xyz] as ordered uints
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 6 * n) bounds[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
 }
 
-// src_is_device: map_xyz already lives in HBM (a lvf_cloud): no upload
-static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_device, int M, int stride_floats, float max_radius2, lvf_map** out) {
-  LVF_REQUIRE(ctx && out, "lvf_map_create: null ctx/out");
-  LVF_REQUIRE(M >= 0 && (M == 0 || map_xyz) && stride_floats >= 3, "lvf_map_create: bad cloud (M=%d stride=%d)", M, stride_floats);
-  LVF_REQUIRE(max_radius2 > 0.0f && std::isfinite(max_radius2), "lvf_map_create: max_radius2 must be finite > 0");
-  LVF_TRY(lvf::enter(ctx));
+// n map indices at once (one, or the old-frame maps of a set of loop-closure candidates: relocator.cpp:196-206 -> mapping.cpp:251-262, one
+// BuildOldMapFrame + kd-tree build per candidate and cloud).  The host waits of a build are shared between the maps — one wait for all
+// bounding boxes — and, round 5, between the LEVELS: the pyramid rule (coarsest cell = gate radius / 2; a finer level, cell halved, while
+// the point-weighted cell population is above the target) needs a level's occupancy before it knows whether the next one is wanted, which
+// made a build one stream wait and six launches PER LEVEL.  Now every level that might be wanted is built in the SAME round — the levels of
+// one map are jobs of the table launches like the maps of a batch are — as long as it has at most 2 cells per map point; one wait returns all the
+// occupancies, the levels behind the first one that meets the target are dropped.  The pyramid kept is the one the level-by-level build
+// keeps; 16 maps of 3 levels: 64 stream waits -> 4 in round 4 -> 2.
+// src_is_device[i]: map_xyz[i] already lives in HBM (a lvf_cloud): no upload.
+static int map_create_many(lvf_ctx* ctx, int n, const float* const* map_xyz, const bool* src_is_device, const int* M, int stride_floats, const float* max_radius2, lvf_map** out) {
   hipStream_t s = ctx->stream;
-  auto* m = new lvf_map();
-  m->ctx = ctx; m->M = M;
-  auto fail = [&](int rc) { delete m; return rc; };
-  int rc;
-  if (M == 0) {   // an empty map: one 1-cell level with no points
-    auto& lv = m->levels[0];
-    if ((rc = lv.cell_start.alloc(2)) != LVF_OK) return fail(rc);
-    LVF_HIP(hipMemsetAsync(lv.cell_start.p, 0, 2 * sizeof(int), s));
-    LVF_HIP(hipStreamSynchronize(s));
-    lv.cell = std::sqrt(max_radius2); lv.inv_cell = 1.0f / lv.cell;
-    m->n_levels = 1;
-    *out = m;
-    return LVF_OK;
-  }
-  DevBuf<float> src; DevBuf<unsigned> bounds;
-  HostPin<float> stage;
-  StreamWaitGuard stage_guard(s);        // every path out of this function waits for the copy before the pinned block returns to the pool
-  if (!src_is_device && (rc = src.upload_staged(map_xyz, (size_t)M * stride_floats, s, stage)) != LVF_OK) return fail(rc);
-  if ((rc = m->raw.alloc(M)) != LVF_OK || (rc = bounds.alloc(6)) != LVF_OK) return fail(rc);
-  // {+max, +max, +max, 0, 0, 0} as ordered-uint bounds: two memsets instead of a copy from a stack array (a pageable copy)
-  LVF_HIP(hipMemsetAsync(bounds.p, 0xff, 3 * sizeof(unsigned), s));
-  LVF_HIP(hipMemsetAsync(bounds.p + 3, 0, 3 * sizeof(unsigned), s));
-  hipLaunchKernelGGL(k_pack_bounds, dim3(std::min(kBoundsMaxBlocks, (M + kB - 1) / kB)), dim3(kB), 0, s, M, src_is_device ? map_xyz : src.p, stride_floats, m->raw.p, bounds.p);
-  unsigned hb[6];
-  if ((rc = read_back(ctx, hb, bounds.p, sizeof(hb))) != LVF_OK) return fail(rc);
-  float lo[3], hi[3];
-  for (int k = 0; k < 3; ++k) { lo[k] = ord2f(hb[k]); hi[k] = ord2f(hb[3 + k]); }
-  for (int k = 0; k < 3; ++k)
-    if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) { set_error("lvf_map_create: non-finite map coordinates"); return fail(LVF_ERR_INVALID); }
-  // Grid pyramid.  Coarsest level: cell = gate radius / 2, so its first two shells cover the whole gate.  Each finer
-  // level halves the cell and is added while the POINT-WEIGHTED cell population (sum count^2 / M) is above
-  // kTargetOcc: lidar density varies by 100x between 5 m and 30 m range, so the plain mean over cells is dominated by
-  // the sparse far field while most queries sit in the dense near field.
-  static const double occ_env = [] { const char* e = std::getenv("LVF_KNN_OCC"); return e ? std::atof(e) : 0.0; }();      // experiment knob
-  const double kMaxCells = 32.0 * 1024 * 1024, kTargetOcc = occ_env > 0.0 ? occ_env : 128.0;
-  auto ncells_for = [&](float c) {
-    return (std::floor((hi[0] - lo[0]) / c) + 1) * (std::floor((hi[1] - lo[1]) / c) + 1) * (std::floor((hi[2] - lo[2]) / c) + 1);
-  };
-  float cell = std::sqrt(max_radius2) * 0.5f;
-  while (ncells_for(cell) > kMaxCells) cell *= 1.25f;
-  lvf_map::Level built[LVF_MAX_GRID_LEVELS];
-  int nb = 0;
-  for (;;) {
-    double occ = 0.0;
-    if ((rc = build_level(m, built[nb], cell, lo, hi, &occ)) != LVF_OK) return fail(rc);
-    ++nb;
-    if (occ <= kTargetOcc || nb == LVF_MAX_GRID_LEVELS || ncells_for(cell * 0.5f) > kMaxCells) break;
-    cell *= 0.5f;
-  }
-  m->n_levels = nb;
-  for (int k = 0; k < nb; ++k) m->levels[k] = std::move(built[nb - 1 - k]);   // finest first
-  *out = m;
-  return LVF_OK;
-}
-
-int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats, float max_radius2, lvf_map** out) {
-  return map_create_impl(ctx, map_xyz, false, M, stride_floats, max_radius2, out);
-}
-
-// n map indices at once (the old-frame maps of a set of loop-closure candidates: relocator.cpp:196-206 -> mapping.cpp:251-262, one
-// BuildOldMapFrame + kd-tree build per candidate and cloud).  The same pyramids as n calls of lvf_map_create, but the host waits that
-// call makes per map — once for the bounding box, once per grid level for its occupancy — are shared: one wait for all boxes, one per
-// ROUND of levels (every map that still grows builds its next level in the round).  16 maps: 64 stream waits become 4.
-int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const int* M, int stride_floats, const float* max_radius2, lvf_map** out) {
-  if (out && n > 0) for (int i = 0; i < n; ++i) out[i] = nullptr;
-  LVF_REQUIRE(ctx && out && (n == 0 || (map_xyz && M && max_radius2)) && n >= 0 && stride_floats >= 3, "lvf_map_create_batch: bad arguments");
-  for (int i = 0; i < n; ++i) out[i] = nullptr;      // (before any check that can return: "NULL for all i on error" holds on every path)
-  for (int i = 0; i < n; ++i) {
-    LVF_REQUIRE(M[i] >= 0 && (M[i] == 0 || map_xyz[i]), "lvf_map_create_batch: bad cloud %d (M=%d)", i, M[i]);
-    LVF_REQUIRE(max_radius2[i] > 0.0f && std::isfinite(max_radius2[i]), "lvf_map_create_batch: max_radius2[%d] must be finite > 0", i);
-  }
-  if (n == 0) return LVF_OK;
-  LVF_TRY(lvf::enter(ctx));
-  hipStream_t s = ctx->stream;
-  struct Item { std::unique_ptr<lvf_map> m; float lo[3], hi[3], cell; lvf_map::Level built[LVF_MAX_GRID_LEVELS]; int nb = 0; bool growing = false; };
+  struct Item { std::unique_ptr<lvf_map> m; float lo[3], hi[3], cell; lvf_map::Level built[LVF_MAX_GRID_LEVELS]; int nb = 0; bool growing = false; int round_first = 0, round_n = 0; };
   std::vector<Item> it((size_t)n);
   std::vector<DevBuf<float>> src((size_t)n);
   std::vector<HostPin<float>> stage((size_t)n);
@@ -741,9 +622,10 @@ int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const
   HostPin<unsigned char> h_tab; DevBuf<unsigned char> d_tab;
   StreamWaitGuard stage_guard(s);          // (declared AFTER every pinned block: destroyed first) every path out waits for the copies before the blocks return to the pool
   DevBuf<unsigned> bounds; DevBuf<unsigned long long> sumsq;
-  LVF_TRY(bounds.alloc((size_t)6 * n)); LVF_TRY(sumsq.alloc((size_t)n));
+  const size_t max_jobs = (size_t)n * LVF_MAX_GRID_LEVELS;
+  LVF_TRY(bounds.alloc((size_t)6 * n)); LVF_TRY(sumsq.alloc(max_jobs));
   hipLaunchKernelGGL(k_bounds_init, dim3((6 * n + 255) / 256), dim3(256), 0, s, n, bounds.p);
-  LVF_TRY(h_tab.reserve((size_t)n * std::max(sizeof(PackJob), sizeof(LevelJob)))); LVF_TRY(d_tab.alloc((size_t)n * std::max(sizeof(PackJob), sizeof(LevelJob))));
+  LVF_TRY(h_tab.reserve(max_jobs * std::max(sizeof(PackJob), sizeof(LevelJob)))); LVF_TRY(d_tab.alloc(max_jobs * std::max(sizeof(PackJob), sizeof(LevelJob))));
   PackJob* pj = reinterpret_cast<PackJob*>(h_tab.p);
   int n_pack = 0, max_pack_blocks = 0;
   for (int i = 0; i < n; ++i) {
@@ -758,10 +640,11 @@ int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const
       m->n_levels = 1;
       continue;
     }
-    LVF_TRY(src[i].upload_staged(map_xyz[i], (size_t)M[i] * stride_floats, s, stage[i]));
+    const bool dev = src_is_device && src_is_device[i];
+    if (!dev) LVF_TRY(src[i].upload_staged(map_xyz[i], (size_t)M[i] * stride_floats, s, stage[i]));
     LVF_TRY(m->raw.alloc(M[i]));
     const int nbx = std::min(kBoundsMaxBlocks, (M[i] + kB - 1) / kB);
-    pj[n_pack++] = PackJob{M[i], stride_floats, nbx, 0, src[i].p, m->raw.p, bounds.p + 6 * i};
+    pj[n_pack++] = PackJob{M[i], stride_floats, nbx, 0, dev ? map_xyz[i] : src[i].p, m->raw.p, bounds.p + 6 * i};
     max_pack_blocks = std::max(max_pack_blocks, nbx);
   }
   if (n_pack) {
@@ -771,8 +654,13 @@ int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const
   LVF_HIP(hipGetLastError());
   std::vector<unsigned> hb((size_t)6 * n);
   LVF_TRY(read_back(ctx, hb.data(), bounds.p, hb.size() * sizeof(unsigned)));          // ONE wait for every bounding box
-  static const double occ_env = [] { const char* e = std::getenv("LVF_KNN_OCC"); return e ? std::atof(e) : 0.0; }();
-  const double kMaxCells = 32.0 * 1024 * 1024, kTargetOcc = occ_env > 0.0 ? occ_env : 128.0;
+  // Grid pyramid.  Coarsest level: cell = gate radius / 2, so its first two shells cover the whole gate.  Each finer level halves the cell
+  // and is kept while the POINT-WEIGHTED cell population (sum count^2 / M) of the level above it is over kTargetOcc: lidar density varies
+  // by 100x between 5 m and 30 m range, so the plain mean over cells is dominated by the sparse far field while most queries sit in the
+  // dense near field.
+  static const double occ_env = [] { const char* e = std::getenv("LVF_KNN_OCC"); return e ? std::atof(e) : 0.0; }();      // experiment knob
+  static const int spec_levels = [] { const char* e = std::getenv("LVF_MAP_SPEC_LEVELS"); return e ? std::max(1, std::atoi(e)) : LVF_MAX_GRID_LEVELS; }();      // 1: the level-by-level build of round 4 (A/B)
+  const double kMaxCells = 32.0 * 1024 * 1024, kSpecCells = 4.0 * 1024 * 1024, kTargetOcc = occ_env > 0.0 ? occ_env : 128.0;
   auto ncells_for = [](const Item& a, float c) {
     return (std::floor((a.hi[0] - a.lo[0]) / c) + 1) * (std::floor((a.hi[1] - a.lo[1]) / c) + 1) * (std::floor((a.hi[2] - a.lo[2]) / c) + 1);
   };
@@ -782,25 +670,32 @@ int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const
     Item& a = it[i];
     for (int k = 0; k < 3; ++k) { a.lo[k] = ord2f(hb[6 * i + k]); a.hi[k] = ord2f(hb[6 * i + 3 + k]); }
     for (int k = 0; k < 3; ++k)
-      if (!std::isfinite(a.lo[k]) || !std::isfinite(a.hi[k])) { set_error("lvf_map_create_batch: non-finite coordinates in map %d", i); return LVF_ERR_INVALID; }
-    a.cell = std::sqrt(max_radius2[i]) * 0.5f;                       // the pyramid rule of map_create_impl
+      if (!std::isfinite(a.lo[k]) || !std::isfinite(a.hi[k])) { set_error("lvf_map_create: non-finite coordinates in map %d", i); return LVF_ERR_INVALID; }
+    a.cell = std::sqrt(max_radius2[i]) * 0.5f;
     while (ncells_for(a, a.cell) > kMaxCells) a.cell *= 1.25f;
     a.growing = true; ++growing;
   }
-  std::vector<unsigned long long> hs((size_t)n);
+  std::vector<unsigned long long> hs(max_jobs);
   while (growing > 0) {
-    std::vector<LevelTmp> tmp((size_t)n);                            // (live until the round's wait)
+    std::vector<LevelTmp> tmp(max_jobs);                             // (live until the round's wait)
     LevelJob* lj = reinterpret_cast<LevelJob*>(h_tab.p);
     int nj = 0, gM = 0, gS = 0, gZ = 0;
     for (int i = 0; i < n; ++i) {
-      if (!it[i].growing) continue;
-      LVF_TRY(prepare_level(it[i].m.get(), it[i].built[it[i].nb], it[i].cell, it[i].lo, it[i].hi, tmp[i], sumsq.p + i, &lj[nj]));
-      gM = std::max(gM, lj[nj].gridM); gS = std::max(gS, lj[nj].nb); gZ = std::max(gZ, std::min(512, (lj[nj].ncells + kB - 1) / kB));
-      ++nj;
+      Item& a = it[i];
+      if (!a.growing) continue;
+      // the levels of this round: the next one, and every finer one that could still be wanted and is cheap enough to build on spec
+      a.round_first = nj; a.round_n = 0;
+      float c = a.cell;
+      for (int k = 0; a.nb + k < LVF_MAX_GRID_LEVELS && k < spec_levels; ++k, c *= 0.5f) {
+        if (k > 0 && ncells_for(a, c) > std::min(kSpecCells, 2.0 * M[i])) break;      // (the finest level kept has about as many cells as the map has points — measured 0.1 .. 1.05 M on the lidar maps of configs[2] and [4]; a level beyond 2 M is 8x that and rarely wanted: it costs a second round when it is)
+        LVF_TRY(prepare_level(a.m.get(), a.built[a.nb + k], c, a.lo, a.hi, tmp[nj], sumsq.p + nj, &lj[nj]));
+        gM = std::max(gM, lj[nj].gridM); gS = std::max(gS, lj[nj].nb); gZ = std::max(gZ, std::min(512, (lj[nj].ncells + kB - 1) / kB));
+        ++nj; ++a.round_n;
+      }
     }
     LVF_HIP(hipMemcpyAsync(d_tab.p, h_tab.p, (size_t)nj * sizeof(LevelJob), hipMemcpyHostToDevice, s));
     const LevelJob* dj = reinterpret_cast<const LevelJob*>(d_tab.p);
-    // the six steps of a level build (build_level), each ONE launch over all the maps of the round
+    // the six steps of a level build, each ONE launch over all the (map, level) jobs of the round
     hipLaunchKernelGGL(k_level_zero_t, dim3(gZ, nj), dim3(kB), 0, s, dj);
     hipLaunchKernelGGL(k_cell_count_t, dim3(gM, nj), dim3(kB), 0, s, dj);
     hipLaunchKernelGGL(k_scan_reduce_t, dim3(gS, nj), dim3(kScanT), 0, s, dj);
@@ -808,19 +703,26 @@ int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const
     hipLaunchKernelGGL(k_scan_apply_t, dim3(gS, nj), dim3(kScanT), 0, s, dj);
     hipLaunchKernelGGL(k_cell_scatter_t, dim3(gM, nj), dim3(kB), 0, s, dj);
     LVF_HIP(hipGetLastError());
-    LVF_TRY(read_back(ctx, hs.data(), sumsq.p, hs.size() * sizeof(unsigned long long)));      // ONE wait per round of levels
+    LVF_TRY(read_back(ctx, hs.data(), sumsq.p, (size_t)nj * sizeof(unsigned long long)));      // ONE wait per round
     for (int i = 0; i < n; ++i) {
       Item& a = it[i];
       if (!a.growing) continue;
-      const double occ = (double)hs[i] / (double)M[i];
-      ++a.nb;
-      if (occ <= kTargetOcc || a.nb == LVF_MAX_GRID_LEVELS || ncells_for(a, a.cell * 0.5f) > kMaxCells) { a.growing = false; --growing; }
-      else a.cell *= 0.5f;
+      int k = 0;
+      for (; k < a.round_n; ++k) {
+        const double occ = (double)hs[a.round_first + k] / (double)M[i];
+        ++a.nb;
+        if (occ <= kTargetOcc || a.nb == LVF_MAX_GRID_LEVELS || ncells_for(a, a.cell * 0.5f) > kMaxCells) { a.growing = false; --growing; ++k; break; }
+        a.cell *= 0.5f;
+      }
+      // levels built on spec behind the last one kept: dropped (their buffers go back to the pool)
+      for (int q = k; q < a.round_n; ++q) a.built[a.nb + (q - k)] = lvf_map::Level();
     }
   }
+  static const bool info = std::getenv("LVF_MAP_INFO") != nullptr;
   for (int i = 0; i < n; ++i) {
     Item& a = it[i];
     if (M[i] > 0) {
+      if (info) { std::fprintf(stderr, "map %d: M %d, %d levels:", i, M[i], a.nb); for (int k = 0; k < a.nb; ++k) std::fprintf(stderr, " %.3f/%d", a.built[k].cell, a.built[k].nx * a.built[k].ny * a.built[k].nz); std::fprintf(stderr, "  (next would be %.0f cells)\n", ncells_for(a, a.built[a.nb - 1].cell * 0.5f)); }
       a.m->n_levels = a.nb;
       for (int k = 0; k < a.nb; ++k) a.m->levels[k] = std::move(a.built[a.nb - 1 - k]);   // finest first
     }
@@ -828,6 +730,31 @@ int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const
   LVF_HIP(hipStreamSynchronize(s));        // (the empty maps' memsets; the sources of the copies)
   for (int i = 0; i < n; ++i) out[i] = it[i].m.release();
   return LVF_OK;
+}
+
+static int map_create_impl(lvf_ctx* ctx, const float* map_xyz, bool src_is_device, int M, int stride_floats, float max_radius2, lvf_map** out) {
+  LVF_REQUIRE(ctx && out, "lvf_map_create: null ctx/out");
+  LVF_REQUIRE(M >= 0 && (M == 0 || map_xyz) && stride_floats >= 3, "lvf_map_create: bad cloud (M=%d stride=%d)", M, stride_floats);
+  LVF_REQUIRE(max_radius2 > 0.0f && std::isfinite(max_radius2), "lvf_map_create: max_radius2 must be finite > 0");
+  LVF_TRY(lvf::enter(ctx));
+  *out = nullptr;
+  return map_create_many(ctx, 1, &map_xyz, &src_is_device, &M, stride_floats, &max_radius2, out);
+}
+
+int lvf_map_create(lvf_ctx* ctx, const float* map_xyz, int M, int stride_floats, float max_radius2, lvf_map** out) {
+  return map_create_impl(ctx, map_xyz, false, M, stride_floats, max_radius2, out);
+}
+
+int lvf_map_create_batch(lvf_ctx* ctx, int n, const float* const* map_xyz, const int* M, int stride_floats, const float* max_radius2, lvf_map** out) {
+  if (out && n > 0) for (int i = 0; i < n; ++i) out[i] = nullptr;
+  LVF_REQUIRE(ctx && out && (n == 0 || (map_xyz && M && max_radius2)) && n >= 0 && stride_floats >= 3, "lvf_map_create_batch: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    LVF_REQUIRE(M[i] >= 0 && (M[i] == 0 || map_xyz[i]), "lvf_map_create_batch: bad cloud %d (M=%d)", i, M[i]);
+    LVF_REQUIRE(max_radius2[i] > 0.0f && std::isfinite(max_radius2[i]), "lvf_map_create_batch: max_radius2[%d] must be finite > 0", i);
+  }
+  if (n == 0) return LVF_OK;
+  LVF_TRY(lvf::enter(ctx));
+  return map_create_many(ctx, n, map_xyz, nullptr, M, stride_floats, max_radius2, out);
 }
 int lvf_map_create_from_cloud(const lvf_cloud* c, float max_radius2, lvf_map** out) {
   LVF_REQUIRE(c, "lvf_map_create_from_cloud: null cloud");

@@ -52,3 +52,26 @@ for rep in range(4):
         1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t3 - t0), best, [r.score - 20 for r in res]))
 t0 = time.perf_counter(); b, rec = rl.relocalize(api, ctx, cands, batched=True); print("relocalize(batched=True): %.2f ms" % (1e3 * (time.perf_counter() - t0)))
 t0 = time.perf_counter(); b, rec = rl.relocalize(api, ctx, cands); print("relocalize(one at a time, clouds split beforehand): %.2f ms" % (1e3 * (time.perf_counter() - t0)))
+# ---- the batched form by part (what relocalize(batched=True) does)
+for rep in range(4):
+    t0 = time.perf_counter()
+    parts = [rl.split_candidate(c) for c in cands]
+    clouds, thrs = [], []
+    for mg, ms, qg, qs in parts:
+        clouds += [mg, ms]; thrs += [opt.thr_ground, opt.thr_surf]
+    t1 = time.perf_counter()
+    maps = api.Map.create_batch(ctx, clouds, thrs)
+    t2 = time.perf_counter()
+    scans = []
+    for mg, ms, qg, qs in parts:
+        scans += [api.Scan(ctx, qg), api.Scan(ctx, qs)]
+    t3 = time.perf_counter()
+    jobs = [dict(map_ground=maps[2 * k], scan_ground=scans[2 * k], map_surf=maps[2 * k + 1], scan_surf=scans[2 * k + 1], map_pose=c["map_pose"], frame_pose=c["init_pose"],
+                 last_pose=c["last_pose"]) for k, c in enumerate(cands)]
+    res, _ = api.scan_match_batch(ctx, jobs, opt, 20.0)
+    t4 = time.perf_counter()
+    for h in maps + scans:
+        h.close()
+    t5 = time.perf_counter()
+    print("batched by part (ms): split %.3f  Map.create_batch(16) %.3f  16 scans %.3f  scan_match_batch %.3f  close %.3f  total %.3f" % tuple(
+        1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0)))

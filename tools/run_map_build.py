@@ -9,7 +9,7 @@ ctx = api.Context(0)
 if which == "config3":
     c3 = syn.config3_icp(); pts = c3["map"]; thr = c3["thr_ground"]
 else:
-    cand = syn.config5_candidates(1, overlap="full")[0]; pts = cand["map_ground"] if "map_ground" in cand else list(cand.values())[0]; thr = 4.0
+    cand = syn.config5_candidates(1)[0]; print({k: getattr(v, "shape", v) for k, v in cand.items()}); pts = [v for v in cand.values() if getattr(v, "ndim", 0) == 2 and v.shape[0] > 1000][0]; thr = 4.0
 cloud = api.Cloud(ctx, np.ascontiguousarray(pts[:, :3], np.float32))
 m = api.Map(ctx, cloud, thr); m.close()
 ctx.synchronize()
