@@ -295,6 +295,10 @@ typedef struct lvf_lidar_extract_debug {
  * points_surf as NEW device clouds (robot frame; intensity = ring + relative time as the reference writes it). */
 int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_floats, const lvf_lidar_params* prm, const double* extrinsic7,
                       lvf_cloud** ground_out, lvf_cloud** surf_out, lvf_lidar_extract_debug* dbg);
+/* Test / A-B hook, process-wide: 1 = lvf_lidar_extract takes the host-counted path of rounds 2-4 (every stage's output count is read back
+ * before the next stage is sized: 13 stream waits per scan) instead of the device-counted one (one wait); returns the previous setting.  The
+ * environment variable LVF_EXTRACT_HOST_COUNTS=1 sets the initial value.  Not part of the reference surface. */
+int lvf_debug_extract_host_counts(int on);
 /* kNN index / query scan straight from device-resident clouds (no host round trip) */
 int lvf_map_create_from_cloud(const lvf_cloud* c, float max_radius2, lvf_map** out);
 int lvf_scan_create_from_cloud(const lvf_cloud* c, lvf_scan** out);

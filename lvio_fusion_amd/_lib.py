@@ -187,6 +187,7 @@ _SIGS = {
     "lvf_map_create_from_cloud": (C.c_int, [_VP, C.c_float, C.POINTER(_VP)]),
     "lvf_scan_create_from_cloud": (C.c_int, [_VP, C.POINTER(_VP)]),
     "lvf_lidar_params_default": (None, [C.POINTER(LidarParams)]),
+    "lvf_debug_extract_host_counts": (C.c_int, [C.c_int]),
     "lvf_lidar_extract": (C.c_int, [_VP, c_float_p, C.c_int, C.c_int, C.POINTER(LidarParams), c_double_p, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(LidarExtractDebug)]),
     "lvf_scan_match_options_default": (None, [C.POINTER(ScanMatchOptions), C.c_double]),
     "lvf_scan_match": (C.c_int, [_VP, _VP, _VP, _VP, c_double_p, c_double_p, c_double_p, C.POINTER(ScanMatchOptions), C.POINTER(ScanMatchResult)]),

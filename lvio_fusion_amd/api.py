@@ -332,6 +332,11 @@ def lidar_params(**kw):
     return p
 
 
+def extract_host_counts(ctx, on):
+    """test / A-B hook: route lidar_extract through the host-counted path (process-wide); returns the previous setting"""
+    return bool(ctx.L.lvf_debug_extract_host_counts(1 if on else 0))
+
+
 def lidar_extract(ctx, points, extrinsic, params=None, debug=False):
     """FeatureAssociation::Process on device: raw sensor-frame scan -> (ground Cloud, surf Cloud[, debug dict])."""
     a = _f(points); e = _d(extrinsic)

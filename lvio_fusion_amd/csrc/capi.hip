@@ -147,6 +147,10 @@ int lvf_ctx_destroy(lvf_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  if (c->scan_status) (void)hipFree(c->scan_status);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   c->pool->close();                 // objects that outlive their context free straight to the driver from now on
   if (g_pool == c->pool) g_pool.reset();
   delete c;

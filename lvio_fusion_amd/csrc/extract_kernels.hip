@@ -19,8 +19,12 @@
 // orientations are taken on the HOST; every atan2 of floats — host or device — is cr_atan2f (cr_math.hpp: correctly rounded, one
 // operation sequence for both sides), sqrtf is IEEE on both: the per-pixel decisions are reproducible bit for bit.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include "cr_math.hpp"
 #include "lvf_internal.hpp"
@@ -63,8 +67,16 @@ __device__ __forceinline__ bool pixel_of(const float4 p, const ExP P, int& row, 
   if (col >= P.Cn) col -= P.Cn;
   return !(col < 0 || col >= P.Cn);
 }
-__global__ __launch_bounds__(kE) void k_ex_project(int m, const float4* __restrict__ pts, ExP P, int* __restrict__ pixel_src) {
+// pixel_src = -1, size = 0, rows = 0 in one launch (three fills otherwise)
+__global__ __launch_bounds__(kE) void k_ex_clear(int npix, int* __restrict__ pixel_src, int* __restrict__ size, unsigned long long* __restrict__ rows) {
   const int i = blockIdx.x * kE + threadIdx.x;
+  if (i >= npix) return;
+  pixel_src[i] = -1; size[i] = 0; rows[i] = 0ull;
+}
+// (m_dev, here and below: the point count as an earlier launch left it on the device — the device-counted path — clips the by-value one)
+__global__ __launch_bounds__(kE) void k_ex_project(int m, const int* __restrict__ m_dev, const float4* __restrict__ pts, ExP P, int* __restrict__ pixel_src) {
+  const int i = blockIdx.x * kE + threadIdx.x;
+  if (m_dev) m = min(m, *m_dev);
   if (i >= m) return;
   int row, col;
   if (pixel_of(pts[i], P, row, col)) atomicMax(pixel_src + (size_t)row * P.Cn + col, i);   // the last point in scan order wins
@@ -201,16 +213,46 @@ __device__ __forceinline__ float ori_first_half(float x, float y, OriP o, bool& 
   latch = (double)(ori - o.start) > kPi;
   return ori;
 }
-__global__ __launch_bounds__(kE) void k_ex_latch(int m, const float4* __restrict__ seg, OriP o, int* __restrict__ latch) {
+// FindStartEndAngle (projection.cpp:42-56): the reference's float / double promotions, for the host-counted path on the host and for the
+// device-counted one in a one-thread launch
+__host__ __device__ inline OriP find_start_end(const float4 first, const float4 last, double cycle) {
+  OriP o;
+  float start = -cr_atan2f(first.y, first.x);
+  float end = -cr_atan2f(last.y, last.x) + 2 * kPi;
+  if (end - start > 3 * kPi) end -= 2 * kPi;
+  else if (end - start < kPi) end += 2 * kPi;
+  o.start = start; o.end = end; o.diff = end - start; o.cycle = cycle;
+  return o;
+}
+// what the device-counted path keeps on the device between launches
+struct ExDev { int cnt[4]; /* filtered, segmented, ground picks, surf picks */ };
+// the device-counted path's source of the orientations: the filtered cloud's first and last point (count on the device)
+struct OriSrc { const float4* filtered; const int* m_dev; double cycle; };
+__device__ __forceinline__ OriP ori_of(const OriSrc& src) {
+  const int m = *src.m_dev;
+  const float4 unit = make_float4(1, 0, 0, 0);
+  return find_start_end(m ? src.filtered[0] : unit, m ? src.filtered[m - 1] : unit, src.cycle);
+}
+__global__ __launch_bounds__(kE) void k_ex_latch(int m, const int* __restrict__ m_dev, const float4* __restrict__ seg, OriP o, const OriSrc op,
+                                                 int* __restrict__ latch) {
   const int i = blockIdx.x * kE + threadIdx.x;
+  if (m_dev) m = min(m, *m_dev);
   if (i >= m) return;
+  if (op.m_dev) o = ori_of(op);
   bool l;
   (void)ori_first_half(seg[i].x, seg[i].y, o, l);
   latch[i] = l ? 1 : 0;
 }
-__global__ __launch_bounds__(kE) void k_ex_reltime(int m, float4* __restrict__ seg, OriP o, const int* __restrict__ latch_before) {
+__device__ __forceinline__ void reltime_body(const int i, float4* __restrict__ seg, const OriP o, const int* __restrict__ latch_before);
+__global__ __launch_bounds__(kE) void k_ex_reltime(int m, const int* __restrict__ m_dev, float4* __restrict__ seg, OriP o, const OriSrc op,
+                                                   const int* __restrict__ latch_before) {
   const int i = blockIdx.x * kE + threadIdx.x;
+  if (m_dev) m = min(m, *m_dev);
   if (i >= m) return;
+  if (op.m_dev) o = ori_of(op);
+  reltime_body(i, seg, o, latch_before);
+}
+__device__ __forceinline__ void reltime_body(const int i, float4* __restrict__ seg, const OriP o, const int* __restrict__ latch_before) {
   float4 p = seg[i];
   float ori;
   if (latch_before[i] == 0) { bool l; ori = ori_first_half(p.x, p.y, o, l); }
@@ -226,11 +268,43 @@ __global__ __launch_bounds__(kE) void k_ex_reltime(int m, float4* __restrict__ s
 }
 
 // CalculateSmoothness + ExtractFeatures' sector test for segmented point k
-__global__ __launch_bounds__(kE) void k_ex_pick(int m, int Cn, const float4* __restrict__ seg, const float* __restrict__ rg, const int* __restrict__ seg_ground,
+__device__ __forceinline__ void pick_body(const int k, const int m, int Cn, const float* __restrict__ rg, const int* __restrict__ seg_ground, const int* __restrict__ seg_row,
+                                          const int* __restrict__ pixpos, int* __restrict__ pick_ground, int* __restrict__ pick_surf, float* __restrict__ curv_out);
+__global__ __launch_bounds__(kE) void k_ex_pick(int m, const int* __restrict__ m_dev, int Cn, const float4* __restrict__ seg, const float* __restrict__ rg, const int* __restrict__ seg_ground,
                                                 const int* __restrict__ seg_row, const int* __restrict__ pixpos /* exclusive prefix over pixels */,
                                                 int* __restrict__ pick_ground, int* __restrict__ pick_surf, float* __restrict__ curv_out) {
   const int k = blockIdx.x * kE + threadIdx.x;
+  if (m_dev) m = min(m, *m_dev);
   if (k >= m) return;
+  pick_body(k, m, Cn, rg, seg_ground, seg_row, pixpos, pick_ground, pick_surf, curv_out);
+}
+// the picks of point k and its relative time in one launch (device-counted path: the two touch different arrays)
+__global__ __launch_bounds__(kE) void k_ex_pick_reltime(int m, const int* __restrict__ m_dev, int Cn, float4* __restrict__ seg, const float* __restrict__ rg,
+                                                        const int* __restrict__ seg_ground, const int* __restrict__ seg_row, const int* __restrict__ pixpos,
+                                                        int* __restrict__ pick_ground, int* __restrict__ pick_surf, float* __restrict__ curv_out, const OriSrc op,
+                                                        const int* __restrict__ latch_before) {
+  const int k = blockIdx.x * kE + threadIdx.x;
+  m = min(m, *m_dev);
+  if (k >= m) return;
+  pick_body(k, m, Cn, rg, seg_ground, seg_row, pixpos, pick_ground, pick_surf, curv_out);
+  reltime_body(k, seg, ori_of(op), latch_before);
+}
+// the segmented cloud's records and, for the device-counted path, the latch condition of each (k_ex_latch's value: the same point)
+__global__ __launch_bounds__(kE) void k_ex_segemit_latch(int npix, int Cn, const int* __restrict__ flags, const int* __restrict__ pos, const float4* __restrict__ full,
+                                                         const float* __restrict__ range, const signed char* __restrict__ ground, float4* __restrict__ seg,
+                                                         float* __restrict__ seg_range, int* __restrict__ seg_ground, int* __restrict__ seg_row, const OriSrc op,
+                                                         int* __restrict__ latch) {
+  const int idx = blockIdx.x * kE + threadIdx.x;
+  if (idx >= npix || !flags[idx]) return;
+  const int k = pos[idx];
+  const float4 p = full[idx];
+  seg[k] = p; seg_range[k] = range[idx]; seg_ground[k] = ground[idx] == 1 ? 1 : 0; seg_row[k] = idx / Cn;
+  bool l;
+  (void)ori_first_half(p.x, p.y, ori_of(op), l);
+  latch[k] = l ? 1 : 0;
+}
+__device__ __forceinline__ void pick_body(const int k, const int m, int Cn, const float* __restrict__ rg, const int* __restrict__ seg_ground, const int* __restrict__ seg_row,
+                                          const int* __restrict__ pixpos, int* __restrict__ pick_ground, int* __restrict__ pick_surf, float* __restrict__ curv_out) {
   // entries the reference leaves stale (k < 5, k >= size - 5 of its never-cleared array) read as 0
   float curv = 0.0f;
   if (k >= 5 && k < m - 5) {
@@ -259,32 +333,14 @@ __global__ __launch_bounds__(kE) void k_ex_pick(int m, int Cn, const float4* __r
 
 using namespace lvf;
 
-extern "C" {
+static std::atomic<int> g_extract_host_counts{[] { const char* e = std::getenv("LVF_EXTRACT_HOST_COUNTS"); return (e && e[0] == '1') ? 1 : 0; }()};
 
-void lvf_lidar_params_default(lvf_lidar_params* p) {
-  if (!p) return;
-  p->num_scans = 64; p->horizon_scan = 1800; p->ang_res_y = 0.427f; p->ang_bottom = 24.9f; p->ground_rows = 60;   // config/kitti.yaml:35-39
-  p->cycle_time = 0.1036; p->min_range = 5.0f; p->max_range = 30.0f; p->resolution = 0.2f;                        // :40-45
-  p->ransac_seed = 12345;
-}
-
-int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_floats, const lvf_lidar_params* prm, const double* extrinsic7,
-                      lvf_cloud** ground_out, lvf_cloud** surf_out, lvf_lidar_extract_debug* dbg) {
-  LVF_REQUIRE(ctx && prm && extrinsic7 && ground_out && surf_out, "lvf_lidar_extract: null argument");
-  LVF_REQUIRE(n >= 0 && (n == 0 || points) && stride_floats >= 3, "lvf_lidar_extract: bad scan (n=%d stride=%d)", n, stride_floats);
-  LVF_REQUIRE(prm->num_scans > 1 && prm->num_scans <= 64 && prm->horizon_scan > 0 && prm->ground_rows >= 0 && prm->ground_rows < prm->num_scans,
-              "lvf_lidar_extract: unsupported geometry (num_scans <= 64, 0 <= ground_rows < num_scans)");
-  LVF_TRY(lvf::enter(ctx));
+// The host-counted path (rounds 2-4; kept as the fallback of the device-counted one and as its reference in the tests): every stage reads its
+// output count back before the next one is sized — 13 stream waits per scan.
+static int extract_host_counted(lvf_ctx* ctx, const float* points, int n, int stride_floats, const lvf_lidar_params* prm, const double* extrinsic7, const ExP& P,
+                                lvf_cloud** ground_out, lvf_cloud** surf_out, lvf_lidar_extract_debug* dbg) {
   hipStream_t s = ctx->stream;
-  ExP P;
-  P.R = prm->num_scans; P.Cn = prm->horizon_scan; P.ground_rows = prm->ground_rows;
-  P.ang_res_x = (float)(360.0 / (float)prm->horizon_scan); P.ang_res_y = prm->ang_res_y; P.ang_bottom = prm->ang_bottom;
-  const float alpha_x = (float)((double)P.ang_res_x / 180.0 * M_PI), alpha_y = (float)((double)P.ang_res_y / 180.0 * M_PI);
-  P.sin_ax = std::sin(alpha_x); P.cos_ax = std::cos(alpha_x); P.sin_ay = std::sin(alpha_y); P.cos_ay = std::cos(alpha_y);
-  P.theta = (float)(60.0 / 180.0 * M_PI);
-  P.min2 = prm->min_range * prm->min_range; P.max2 = prm->max_range * prm->max_range;
   const int npix = P.R * P.Cn;
-  if (dbg) dbg->n_filtered = dbg->n_segmented = dbg->n_ground_raw = dbg->n_surf_raw = 0;
   // ---- Preprocess
   lvf_cloud* filtered = nullptr;
   {
@@ -306,7 +362,7 @@ int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_float
   LVF_HIP(hipMemsetAsync(pixel_src.p, 0xff, (size_t)4 * npix, s));      // -1
   LVF_HIP(hipMemsetAsync(size.p, 0, (size_t)4 * npix, s));
   LVF_HIP(hipMemsetAsync(rows.p, 0, (size_t)8 * npix, s));
-  if (m) hipLaunchKernelGGL(k_ex_project, dim3(gride(m)), dim3(kE), 0, s, m, filtered->pts.p, P, pixel_src.p);
+  if (m) hipLaunchKernelGGL(k_ex_project, dim3(gride(m)), dim3(kE), 0, s, m, (const int*)nullptr, filtered->pts.p, P, pixel_src.p);
   hipLaunchKernelGGL(k_ex_fill, dim3(gride(npix)), dim3(kE), 0, s, npix, filtered->pts.p, P, pixel_src.p, full.p, range.p);
   hipLaunchKernelGGL(k_ex_ground, dim3(gride(npix)), dim3(kE), 0, s, npix, full.p, range.p, P, ground.p, parent.p);
   hipLaunchKernelGGL(k_ex_union, dim3(gride(npix)), dim3(kE), 0, s, npix, range.p, P, parent.p);
@@ -329,15 +385,7 @@ int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_float
     std::memcpy(&num, mb, sizeof(int));
     if (m) { std::memcpy(&ends[0], mb + 16, sizeof(float4)); std::memcpy(&ends[1], mb + 32, sizeof(float4)); }
   }
-  // FindStartEndAngle (projection.cpp:42-56), host arithmetic like the reference
-  OriP o;
-  {
-    float start = -cr_atan2f(ends[0].y, ends[0].x);
-    float end = -cr_atan2f(ends[1].y, ends[1].x) + 2 * M_PI;
-    if (end - start > 3 * M_PI) end -= 2 * M_PI;
-    else if (end - start < M_PI) end += 2 * M_PI;
-    o.start = start; o.end = end; o.diff = end - start; o.cycle = prm->cycle_time;
-  }
+  const OriP o = find_start_end(ends[0], ends[1], prm->cycle_time);      // FindStartEndAngle (projection.cpp:42-56)
   DevBuf<float4> seg; DevBuf<float> seg_range, curv; DevBuf<int> seg_ground, seg_row, latch, latch_pos, pick_g, pick_s;
   const int mm = std::max(num, 1);
   LVF_TRY(seg.alloc(mm)); LVF_TRY(seg_range.alloc(mm)); LVF_TRY(curv.alloc(mm)); LVF_TRY(seg_ground.alloc(mm)); LVF_TRY(seg_row.alloc(mm));
@@ -345,11 +393,11 @@ int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_float
   lvf_cloud *g_raw = nullptr, *s_raw = nullptr;
   if (num) {
     hipLaunchKernelGGL(k_ex_segemit, dim3(gride(npix)), dim3(kE), 0, s, npix, P.Cn, flags.p, pos.p, full.p, range.p, ground.p, seg.p, seg_range.p, seg_ground.p, seg_row.p);
-    hipLaunchKernelGGL(k_ex_latch, dim3(gride(num)), dim3(kE), 0, s, num, seg.p, o, latch.p);
+    hipLaunchKernelGGL(k_ex_latch, dim3(gride(num)), dim3(kE), 0, s, num, (const int*)nullptr, seg.p, o, OriSrc{nullptr, nullptr, 0.0}, latch.p);
     LVF_HIP(hipGetLastError());
     LVF_TRY(device_exclusive_scan_i32(ctx, latch.p, num, latch_pos.p));
-    hipLaunchKernelGGL(k_ex_pick, dim3(gride(num)), dim3(kE), 0, s, num, P.Cn, seg.p, seg_range.p, seg_ground.p, seg_row.p, pos.p, pick_g.p, pick_s.p, curv.p);
-    hipLaunchKernelGGL(k_ex_reltime, dim3(gride(num)), dim3(kE), 0, s, num, seg.p, o, latch_pos.p);
+    hipLaunchKernelGGL(k_ex_pick, dim3(gride(num)), dim3(kE), 0, s, num, (const int*)nullptr, P.Cn, seg.p, seg_range.p, seg_ground.p, seg_row.p, pos.p, pick_g.p, pick_s.p, curv.p);
+    hipLaunchKernelGGL(k_ex_reltime, dim3(gride(num)), dim3(kE), 0, s, num, (const int*)nullptr, seg.p, o, OriSrc{nullptr, nullptr, 0.0}, latch_pos.p);
     LVF_HIP(hipGetLastError());
   }
   LVF_TRY(compact_points(ctx, seg.p, num, pick_g.p, &g_raw)); guard.add(g_raw);
@@ -375,5 +423,142 @@ int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_float
   LVF_HIP(hipStreamSynchronize(s));
   return LVF_OK;
 }
+
+// The device-counted path: ONE stream wait per scan.  Every intermediate cloud is a buffer of the raw scan's (or the range image's) capacity
+// with its count in device memory; launches are sized by the capacity and read the count; scans / compactions are one launch each
+// (device_scan1); the start / end orientations are taken by a one-thread launch with the host's arithmetic; the PCL tail is dc_pcl_tail.
+// The counts (and the tail's verdict) come back in one read before the two extrinsic transforms, which are then sized exactly.
+// *done = false: a scan outside what the path was sized for (the tail's a-priori bounds) — the caller takes the host-counted path.
+static int extract_device_counted(lvf_ctx* ctx, const float* points, int n, int stride_floats, const lvf_lidar_params* prm, const double* extrinsic7, const ExP& P,
+                                  lvf_cloud** ground_out, lvf_cloud** surf_out, lvf_lidar_extract_debug* dbg, bool* done) {
+  hipStream_t s = ctx->stream;
+  *done = false;
+  static const bool timing = std::getenv("LVF_EXTRACT_TIMING") != nullptr;
+  const auto t_in = std::chrono::steady_clock::now();
+  auto us_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+  const int npix = P.R * P.Cn;
+  const int capseg = std::min(npix, n);               // a segmented point is a pixel AND a filtered point
+  DevBuf<ExDev> exd;
+  LVF_TRY(exd.alloc(1));
+  ExDev* ex = exd.p;
+  // ---- what does not depend on the scan goes first: it runs while the host is still preparing the upload
+  DevBuf<int> pixel_src, size; DevBuf<unsigned long long> rows;
+  LVF_TRY(pixel_src.alloc(npix)); LVF_TRY(size.alloc(npix)); LVF_TRY(rows.alloc(npix));
+  hipLaunchKernelGGL(k_ex_clear, dim3(gride(npix)), dim3(kE), 0, s, npix, pixel_src.p, size.p, rows.p);
+  DevBuf<unsigned char> tail_state;
+  std::shared_ptr<void> tail_keep;      // the tail's scratch: alive until this function has waited for the streams (declared before the guard below)
+  struct SideGuard { lvf_ctx* c; ~SideGuard() { if (c->stream2) (void)hipStreamSynchronize(c->stream2); } } side_guard{ctx};      // an error return must not release scratch the side stream still uses
+  DcTailPlan plan;
+  LVF_TRY(dc_tail_begin(ctx, capseg, prm->resolution, prm->max_range, tail_state, tail_keep, &plan));
+  if (!plan.supported) return LVF_OK;
+  // ---- Preprocess
+  DevBuf<float> src; DevBuf<float4> packed, filtered; DevBuf<int> pflags;
+  HostPin<float> stage;                // (pooled pinned staging)
+  StreamWaitGuard stage_guard(s);      // every path out — the error returns too — waits for the copy before the block returns to the pool
+  LVF_TRY(src.upload_staged(points, (size_t)n * stride_floats, s, stage)); LVF_TRY(packed.alloc(n)); LVF_TRY(pflags.alloc(n)); LVF_TRY(filtered.alloc(n));
+  const double us_upload = us_since(t_in);
+  hipLaunchKernelGGL(k_ex_preflag, dim3(gride(n)), dim3(kE), 0, s, n, src.p, stride_floats, P.min2, P.max2, packed.p, pflags.p);
+  LVF_HIP(hipGetLastError());
+  LVF_TRY(device_scan1(ctx, pflags.p, n, nullptr, nullptr, &ex->cnt[0], packed.p, filtered.p));
+  const int* m_dev = &ex->cnt[0];
+  // ---- projection, ground, segmentation
+  DevBuf<int> parent, flags, pos, label; DevBuf<float4> full; DevBuf<float> range; DevBuf<signed char> ground;
+  LVF_TRY(parent.alloc(npix)); LVF_TRY(flags.alloc(npix)); LVF_TRY(pos.alloc((size_t)npix + 1));
+  LVF_TRY(label.alloc(npix)); LVF_TRY(full.alloc(npix)); LVF_TRY(range.alloc(npix)); LVF_TRY(ground.alloc(npix));
+  hipLaunchKernelGGL(k_ex_project, dim3(gride(n)), dim3(kE), 0, s, n, m_dev, filtered.p, P, pixel_src.p);
+  hipLaunchKernelGGL(k_ex_fill, dim3(gride(npix)), dim3(kE), 0, s, npix, filtered.p, P, pixel_src.p, full.p, range.p);
+  hipLaunchKernelGGL(k_ex_ground, dim3(gride(npix)), dim3(kE), 0, s, npix, full.p, range.p, P, ground.p, parent.p);
+  hipLaunchKernelGGL(k_ex_union, dim3(gride(npix)), dim3(kE), 0, s, npix, range.p, P, parent.p);
+  hipLaunchKernelGGL(k_ex_stats, dim3(gride(npix)), dim3(kE), 0, s, npix, P.Cn, parent.p, size.p, rows.p);
+  hipLaunchKernelGGL(k_ex_segflag, dim3(gride(npix)), dim3(kE), 0, s, npix, parent.p, size.p, rows.p, ground.p, flags.p, label.p);
+  LVF_HIP(hipGetLastError());
+  LVF_TRY(device_scan1(ctx, flags.p, npix, nullptr, pos.p, &ex->cnt[1], nullptr, nullptr));
+  const int* num_dev = &ex->cnt[1];
+  // ---- AdjustDistortion, CalculateSmoothness, ExtractFeatures' picks
+  DevBuf<float4> seg, g_raw, s_raw; DevBuf<float> seg_range, curv; DevBuf<int> seg_ground, seg_row, latch, latch_pos, pick_g, pick_s;
+  const int mm = std::max(capseg, 1);
+  LVF_TRY(seg.alloc(mm)); LVF_TRY(seg_range.alloc(mm)); LVF_TRY(curv.alloc(mm)); LVF_TRY(seg_ground.alloc(mm)); LVF_TRY(seg_row.alloc(mm));
+  LVF_TRY(latch.alloc(mm)); LVF_TRY(latch_pos.alloc((size_t)mm + 1)); LVF_TRY(pick_g.alloc(mm)); LVF_TRY(pick_s.alloc(mm));
+  LVF_TRY(g_raw.alloc(mm)); LVF_TRY(s_raw.alloc(mm));
+  const OriSrc op{filtered.p, m_dev, prm->cycle_time};      // (start / end orientations: every thread of the two launches below takes them itself)
+  hipLaunchKernelGGL(k_ex_segemit_latch, dim3(gride(npix)), dim3(kE), 0, s, npix, P.Cn, flags.p, pos.p, full.p, range.p, ground.p, seg.p, seg_range.p, seg_ground.p, seg_row.p, op,
+                     latch.p);
+  LVF_HIP(hipGetLastError());
+  LVF_TRY(device_scan1(ctx, latch.p, capseg, num_dev, latch_pos.p, nullptr, nullptr, nullptr));
+  hipLaunchKernelGGL(k_ex_pick_reltime, dim3(gride(capseg)), dim3(kE), 0, s, capseg, num_dev, P.Cn, seg.p, seg_range.p, seg_ground.p, seg_row.p, pos.p, pick_g.p, pick_s.p, curv.p, op,
+                     latch_pos.p);
+  LVF_HIP(hipGetLastError());
+  // ---- the picks' compactions and the PCL tail (association.cpp:210-234): the ground half on the side stream, the surf half on this one
+  hipStream_t q = s;
+  LVF_TRY(dc_tail_fork(ctx, plan, &q));
+  LVF_TRY(device_scan1_on(ctx, q, plan.lane_ground, pick_g.p, capseg, num_dev, nullptr, &ex->cnt[2], seg.p, g_raw.p));
+  LVF_TRY(device_scan1_on(ctx, s, 0, pick_s.p, capseg, num_dev, nullptr, &ex->cnt[3], seg.p, s_raw.p));
+  DevBuf<float4> surf_pre, ground_pre;
+  LVF_TRY(dc_tail_run(ctx, plan, q, s_raw.p, &ex->cnt[3], g_raw.p, &ex->cnt[2], (unsigned long long)prm->ransac_seed, tail_state, tail_keep, surf_pre, ground_pre));
+  // ---- the one read-back: the four counts here, the tail's four and its verdict
+  int hc[4] = {0, 0, 0, 0}, ht[5] = {0, 0, 0, 0, 0};
+  {
+    LVF_TRY(ctx->mailbox.reserve(4096));
+    char* mb = ctx->mailbox.p;
+    LVF_HIP(hipMemcpyAsync(mb, ex->cnt, sizeof(hc), hipMemcpyDeviceToHost, s));
+    LVF_HIP(hipMemcpyAsync(mb + 64, tail_state.p + dc_state_counts_offset(), sizeof(ht), hipMemcpyDeviceToHost, s));
+    const double us_enq = us_since(t_in);
+    LVF_HIP(hipStreamSynchronize(s));
+    if (timing) std::fprintf(stderr, "extract: upload enqueued at %.1f us, all launches enqueued at %.1f us, stream drained at %.1f us\n", us_upload, us_enq, us_since(t_in));
+    std::memcpy(hc, mb, sizeof(hc)); std::memcpy(ht, mb + 64, sizeof(ht));
+  }
+  if (ht[4] != 0) return LVF_OK;                        // outside the tail's a-priori bounds: the host-counted path decides (and reports)
+  if (dbg) {
+    dbg->n_filtered = hc[0]; dbg->n_segmented = hc[1]; dbg->n_ground_raw = hc[2]; dbg->n_surf_raw = hc[3];
+    if (dbg->label_mat) LVF_HIP(hipMemcpyAsync(dbg->label_mat, label.p, (size_t)4 * npix, hipMemcpyDeviceToHost, s));
+    if (dbg->ground_mat) LVF_HIP(hipMemcpyAsync(dbg->ground_mat, ground.p, (size_t)npix, hipMemcpyDeviceToHost, s));
+    if (dbg->range_mat) LVF_HIP(hipMemcpyAsync(dbg->range_mat, range.p, (size_t)4 * npix, hipMemcpyDeviceToHost, s));
+    if (dbg->ground_raw && hc[2]) LVF_HIP(hipMemcpyAsync(dbg->ground_raw, g_raw.p, (size_t)16 * hc[2], hipMemcpyDeviceToHost, s));
+    if (dbg->surf_raw && hc[3]) LVF_HIP(hipMemcpyAsync(dbg->surf_raw, s_raw.p, (size_t)16 * hc[3], hipMemcpyDeviceToHost, s));
+    LVF_HIP(hipStreamSynchronize(s));
+  }
+  // ---- Sensor2Robot (association.cpp:236-247), sized exactly; consumed on the same stream, nothing to wait for
+  LVF_TRY(transform_points(ctx, ground_pre.p, ht[3], extrinsic7, ground_out));
+  const int rc = transform_points(ctx, surf_pre.p, ht[1], extrinsic7, surf_out);
+  if (rc != LVF_OK) { lvf_cloud_destroy(*ground_out); *ground_out = nullptr; return rc; }
+  *done = true;
+  return LVF_OK;
+}
+
+extern "C" {
+
+void lvf_lidar_params_default(lvf_lidar_params* p) {
+  if (!p) return;
+  p->num_scans = 64; p->horizon_scan = 1800; p->ang_res_y = 0.427f; p->ang_bottom = 24.9f; p->ground_rows = 60;   // config/kitti.yaml:35-39
+  p->cycle_time = 0.1036; p->min_range = 5.0f; p->max_range = 30.0f; p->resolution = 0.2f;                        // :40-45
+  p->ransac_seed = 12345;
+}
+
+int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_floats, const lvf_lidar_params* prm, const double* extrinsic7,
+                      lvf_cloud** ground_out, lvf_cloud** surf_out, lvf_lidar_extract_debug* dbg) {
+  LVF_REQUIRE(ctx && prm && extrinsic7 && ground_out && surf_out, "lvf_lidar_extract: null argument");
+  LVF_REQUIRE(n >= 0 && (n == 0 || points) && stride_floats >= 3, "lvf_lidar_extract: bad scan (n=%d stride=%d)", n, stride_floats);
+  LVF_REQUIRE(prm->num_scans > 1 && prm->num_scans <= 64 && prm->horizon_scan > 0 && prm->ground_rows >= 0 && prm->ground_rows < prm->num_scans,
+              "lvf_lidar_extract: unsupported geometry (num_scans <= 64, 0 <= ground_rows < num_scans)");
+  LVF_TRY(lvf::enter(ctx));
+  ExP P;
+  P.R = prm->num_scans; P.Cn = prm->horizon_scan; P.ground_rows = prm->ground_rows;
+  P.ang_res_x = (float)(360.0 / (float)prm->horizon_scan); P.ang_res_y = prm->ang_res_y; P.ang_bottom = prm->ang_bottom;
+  const float alpha_x = (float)((double)P.ang_res_x / 180.0 * M_PI), alpha_y = (float)((double)P.ang_res_y / 180.0 * M_PI);
+  P.sin_ax = std::sin(alpha_x); P.cos_ax = std::cos(alpha_x); P.sin_ay = std::sin(alpha_y); P.cos_ay = std::cos(alpha_y);
+  P.theta = (float)(60.0 / 180.0 * M_PI);
+  P.min2 = prm->min_range * prm->min_range; P.max2 = prm->max_range * prm->max_range;
+  if (dbg) dbg->n_filtered = dbg->n_segmented = dbg->n_ground_raw = dbg->n_surf_raw = 0;
+  *ground_out = nullptr; *surf_out = nullptr;
+  if (n > 0 && !g_extract_host_counts.load()) {
+    bool done = false;
+    LVF_TRY(extract_device_counted(ctx, points, n, stride_floats, prm, extrinsic7, P, ground_out, surf_out, dbg, &done));
+    if (done) return LVF_OK;
+  }
+  return extract_host_counted(ctx, points, n, stride_floats, prm, extrinsic7, P, ground_out, surf_out, dbg);
+}
+
+// Test / A-B hook: 1 = lvf_lidar_extract takes the host-counted path (process-wide).  Not part of the reference surface.
+int lvf_debug_extract_host_counts(int on) { const int was = g_extract_host_counts.exchange(on ? 1 : 0); return was; }
 
 }  // extern "C"

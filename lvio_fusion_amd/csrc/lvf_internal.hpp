@@ -215,6 +215,15 @@ struct lvf_ctx {
   int num_cu = 256;
   lvf::HostPin<char> mailbox;       // pinned landing zone of the small read-backs (counters, bounds, moments): see lvf::read_back
   lvf::HostPin<char> stage;         // pinned staging of host arrays up to 1 MB that are copied and waited for in one call (lvf_state_set / _get)
+  // status words + ticket of the one-launch scan (sort_util.hip device_scan1): self-cleaning through the epoch, so it lives with the context
+  // (two lanes: launches on the context's stream use lane 0, launches on its side stream lane 1)
+  unsigned long long* scan_status = nullptr;
+  int scan_tiles = 0;
+  unsigned scan_epoch = 0;
+  // side stream for the second of two independent launch chains inside one call (lvf_lidar_extract's ground tail beside the surf tail), with
+  // the events that fork it off the context's stream and join it back; created on first use (lvf::side_stream)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace lvf {
@@ -476,10 +485,35 @@ extern "C" __attribute__((visibility("hidden"))) int lvf_problem_solve_then(lvf_
 namespace lvf {
 // stable LSD radix sort of (key, value) pairs by the low `key_bits` bits of the key (sort_util.hip)
 int device_sort_pairs_u32(lvf_ctx* ctx, const unsigned* keys_in, unsigned* keys_out, const int* vals_in, int* vals_out, int n, int key_bits);
+// the same with the key count and width on the device (written by an earlier launch on the stream): n keys of `bits` bits, digits of db bits, nbins = 1 << db
+struct SortP { int n, bits, db, nbins; };
+constexpr int kSortMaxDigitBits = 11;
+// (one job per independent sort: its stream, its arrays, and its scratch — which must outlive the launches when the stream is the side stream)
+struct SortScratch { DevBuf<int> hist; DevBuf<unsigned> tkeys; DevBuf<int> tvals; };
+struct SortJobDc {
+  hipStream_t q; const unsigned* keys_in; unsigned* keys_out; const int* vals_in; int* vals_out; const SortP* sp; SortScratch* keep;
+  const unsigned* ki; const int* vi; unsigned* ko; int* vo;      // (cursor of the passes)
+};
+int device_sort_pairs_u32_dc_multi(lvf_ctx* ctx, int n_jobs, SortJobDc* jobs, int cap, int passes);
+// exclusive scan (and order-preserving compaction of float4 records) in one launch, element count optionally on the device (sort_util.hip)
+int device_scan1(lvf_ctx* ctx, const int* in, int cap, const int* n_dev, int* pos, int* total_out, const float4* pts, float4* out);
+// the same on stream q with status lane `lane` (0: the context's stream, 1: its side stream)
+int device_scan1_on(lvf_ctx* ctx, hipStream_t q, int lane, const int* in, int cap, const int* n_dev, int* pos, int* total_out, const float4* pts, float4* out);
+// the context's side stream and fork / join events (created on first use)
+int side_stream(lvf_ctx* ctx, hipStream_t* out);
 // every extern "C" entry point starts here: selects the context's device and allocator for the calling thread
 int enter(lvf_ctx* ctx);
 int device_exclusive_scan_i32(lvf_ctx* ctx, const int* in, int n, int* out);
 int compact_points(lvf_ctx* ctx, const float4* pts, int n, const int* flags_dev, lvf_cloud** out);
+// the PCL tail of the feature extraction with the counts on the device, and what reads its state back (cloud_kernels.hip)
+struct DcTailPlan { bool supported, two_streams; int cap, passes, grid_cells, lane_ground, max_iterations, min_neighbors; float leaf, radius, thr; };
+int dc_tail_begin(lvf_ctx* ctx, int cap, float resolution, float max_range, DevBuf<unsigned char>& state, std::shared_ptr<void>& keep, DcTailPlan* plan);
+int dc_tail_fork(lvf_ctx* ctx, const DcTailPlan& plan, hipStream_t* q);
+int dc_tail_run(lvf_ctx* ctx, const DcTailPlan& plan, hipStream_t q, const float4* surf_raw, const int* n_surf_raw, const float4* ground_raw, const int* n_ground_raw,
+                unsigned long long seed, DevBuf<unsigned char>& state, std::shared_ptr<void>& keep, DevBuf<float4>& surf_out, DevBuf<float4>& ground_out);
+int dc_state_bytes();
+int dc_state_counts_offset();      // int cnt[4] (surf voxels, surf features, ground voxels, ground features), then int err
+int transform_points(lvf_ctx* ctx, const float4* in, int n, const double* pose, lvf_cloud** out);
 // kernels / launchers implemented in the .hip translation units
 int launch_pose_only(lvf_batch* b, const lvf_state* st, bool want_j);
 int launch_two_frame(lvf_batch* b, const lvf_state* st, bool want_j);

@@ -21,13 +21,12 @@
 namespace lvf {
 
 // (tiles of 4 096 keys: a quarter of the histogram table of 1 024-key tiles — the one-workgroup scan over it was 29 of a pass's 41 us)
-constexpr int kRT = 256, kRRounds = 16, kRTile = kRT * kRRounds, kRScanT = 1024, kRMaxDigitBits = 11;
+constexpr int kRT = 256, kRRounds = 16, kRTile = kRT * kRRounds, kRScanT = 1024, kRMaxDigitBits = kSortMaxDigitBits;
 
 // digit = (key >> shift) & (nbins - 1); nbins = 1 << digit_bits <= 2048.  Dynamic LDS: nbins ints.
 // `mask`: the digit's live bits — nbins - 1, except in the LAST pass of a key whose width is not a multiple of the digit width, where only the
 // remaining key bits count (bits above key_bits never influence the order: the contract hipcub's end_bit gave the callers)
-__global__ __launch_bounds__(kRT) void k_radix_hist(int n, const unsigned* __restrict__ keys, int shift, int nbins, unsigned mask, int* __restrict__ hist, int ntiles) {
-  extern __shared__ int rs_lds[];
+__device__ __forceinline__ void radix_hist_body(int n, const unsigned* __restrict__ keys, int shift, int nbins, unsigned mask, int* __restrict__ hist, int ntiles, int* rs_lds) {
   int* h = rs_lds;
   for (int b = threadIdx.x; b < nbins; b += kRT) h[b] = 0;
   __syncthreads();
@@ -38,6 +37,24 @@ __global__ __launch_bounds__(kRT) void k_radix_hist(int n, const unsigned* __res
   }
   __syncthreads();
   for (int b = threadIdx.x; b < nbins; b += kRT) hist[(size_t)b * ntiles + blockIdx.x] = h[b];
+}
+__global__ __launch_bounds__(kRT) void k_radix_hist(int n, const unsigned* __restrict__ keys, int shift, int nbins, unsigned mask, int* __restrict__ hist, int ntiles) {
+  extern __shared__ int rs_lds[];
+  radix_hist_body(n, keys, shift, nbins, mask, hist, ntiles, rs_lds);
+}
+// the same with the element count and the digit split on the DEVICE (SortP, written by the launch that sized the keys): the host fixes only the
+// number of passes and the capacity; workgroups beyond the live tiles write the zeros the table scan expects
+__device__ __forceinline__ void sortp_pass(const SortP& sp, int p, int& shift, unsigned& mask) {
+  shift = sp.db * p;
+  const int live = max(0, min(sp.db, sp.bits - sp.db * p));
+  mask = (1u << live) - 1u;
+}
+__global__ __launch_bounds__(kRT) void k_radix_hist_dc(const SortP* __restrict__ spp, const unsigned* __restrict__ keys, int p, int* __restrict__ hist, int ntiles) {
+  extern __shared__ int rs_lds[];
+  const SortP sp = *spp;
+  int shift; unsigned mask;
+  sortp_pass(sp, p, shift, mask);
+  radix_hist_body(sp.n, keys, shift, sp.nbins, mask, hist, ntiles, rs_lds);
 }
 
 __device__ __forceinline__ int wave_sum_i(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o); return v; }      // (lane 0 holds the sum)
@@ -62,6 +79,7 @@ __device__ __forceinline__ void wg_excl_scan(int* __restrict__ a, const int lo0,
 }
 // small tables (a 100 k-point cloud with 10-bit digits: 25 k entries): ONE workgroup
 __global__ __launch_bounds__(kRScanT) void k_radix_scan(int total, int* __restrict__ a) { wg_excl_scan(a, 0, total, 0); }
+__global__ __launch_bounds__(kRScanT) void k_radix_scan_dc(const SortP* __restrict__ spp, int ntiles, int* __restrict__ a) { wg_excl_scan(a, 0, spp->nbins * ntiles, 0); }
 // large tables (a 10 M-point cloud: 5 M entries — one workgroup walking them was the bottleneck of a pass): `chunk` entries per workgroup,
 // two launches: the chunk sums, then every workgroup scans its chunk from the sum of the chunks before it (<= kRScanMaxGroups of them:
 // each workgroup adds them up itself, no third launch)
@@ -90,9 +108,8 @@ __global__ __launch_bounds__(kRScanT) void k_radix_scan_chunks(int total, int* _
 }
 
 // Dynamic LDS: s_base[nbins] | s_cnt[waves][nbins].
-__global__ __launch_bounds__(kRT) void k_radix_scatter(int n, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, unsigned* __restrict__ keys_out,
-                                                       int* __restrict__ vals_out, int shift, int digit_bits, unsigned mask, const int* __restrict__ hist, int ntiles) {
-  extern __shared__ int rs_lds[];
+__device__ __forceinline__ void radix_scatter_body(int n, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, unsigned* __restrict__ keys_out,
+                                                   int* __restrict__ vals_out, int shift, int digit_bits, unsigned mask, const int* __restrict__ hist, int ntiles, int* rs_lds) {
   const int nbins = 1 << digit_bits;
   int* s_base = rs_lds;
   int* s_cnt = rs_lds + nbins;               // [wave][bin]
@@ -132,6 +149,20 @@ __global__ __launch_bounds__(kRT) void k_radix_scatter(int n, const unsigned* __
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(kRT) void k_radix_scatter(int n, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, unsigned* __restrict__ keys_out,
+                                                       int* __restrict__ vals_out, int shift, int digit_bits, unsigned mask, const int* __restrict__ hist, int ntiles) {
+  extern __shared__ int rs_lds[];
+  radix_scatter_body(n, keys_in, vals_in, keys_out, vals_out, shift, digit_bits, mask, hist, ntiles, rs_lds);
+}
+__global__ __launch_bounds__(kRT) void k_radix_scatter_dc(const SortP* __restrict__ spp, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in,
+                                                          unsigned* __restrict__ keys_out, int* __restrict__ vals_out, int p, const int* __restrict__ hist, int ntiles) {
+  extern __shared__ int rs_lds[];
+  const SortP sp = *spp;
+  if ((long long)blockIdx.x * kRTile >= (long long)sp.n) return;      // (a tile without keys: uniform per workgroup)
+  int shift; unsigned mask;
+  sortp_pass(sp, p, shift, mask);
+  radix_scatter_body(sp.n, keys_in, vals_in, keys_out, vals_out, shift, sp.db, mask, hist, ntiles, rs_lds);
+}
 
 int device_sort_pairs_u32(lvf_ctx* ctx, const unsigned* keys_in, unsigned* keys_out, const int* vals_in, int* vals_out, int n, int key_bits) {
   if (n <= 0) return LVF_OK;
@@ -167,6 +198,141 @@ int device_sort_pairs_u32(lvf_ctx* ctx, const unsigned* keys_in, unsigned* keys_
   }
   LVF_HIP(hipGetLastError());
   // (the scratch buffers go back to the context's pool on return: the pool hands them out again in stream order, nothing to wait for)
+  return LVF_OK;
+}
+
+// The sort with the count and the key width on the device.  `passes` digit passes are enqueued whatever the keys turn out to need (the launch
+// that wrote *sp raises its error flag when they need more); `cap` = the arrays' capacity.  Several independent sorts (each on its own stream)
+// are enqueued step by step, one launch of each in turn, so that none of them waits for the host to finish enqueueing the other.
+int device_sort_pairs_u32_dc_multi(lvf_ctx* ctx, int n_jobs, SortJobDc* jobs, int cap, int passes) {
+  (void)ctx;
+  if (cap <= 0) return LVF_OK;
+  const int nbins_max = 1 << kRMaxDigitBits;
+  const int ntiles = (cap + kRTile - 1) / kRTile;
+  if ((long long)nbins_max * ntiles > kRScanOneGroupMax) { set_error("device_sort_pairs_u32_dc: %d keys are beyond the one-workgroup table scan", cap); return LVF_ERR_INVALID; }
+  for (int k = 0; k < n_jobs; ++k) {
+    SortScratch& K = *jobs[k].keep;
+    LVF_TRY(K.hist.alloc((size_t)nbins_max * ntiles));
+    if (passes > 1) { LVF_TRY(K.tkeys.alloc(cap)); LVF_TRY(K.tvals.alloc(cap)); }
+    jobs[k].ki = jobs[k].keys_in; jobs[k].vi = jobs[k].vals_in;
+  }
+  for (int p = 0; p < passes; ++p) {
+    const bool to_out = ((passes - 1 - p) % 2) == 0;
+    for (int k = 0; k < n_jobs; ++k) {
+      SortJobDc& J = jobs[k];
+      J.ko = to_out ? J.keys_out : J.keep->tkeys.p; J.vo = to_out ? J.vals_out : J.keep->tvals.p;
+      hipLaunchKernelGGL(k_radix_hist_dc, dim3(ntiles), dim3(kRT), (size_t)nbins_max * sizeof(int), J.q, J.sp, J.ki, p, J.keep->hist.p, ntiles);
+    }
+    for (int k = 0; k < n_jobs; ++k) hipLaunchKernelGGL(k_radix_scan_dc, dim3(1), dim3(kRScanT), 0, jobs[k].q, jobs[k].sp, ntiles, jobs[k].keep->hist.p);
+    for (int k = 0; k < n_jobs; ++k) {
+      SortJobDc& J = jobs[k];
+      hipLaunchKernelGGL(k_radix_scatter_dc, dim3(ntiles), dim3(kRT), (size_t)(1 + kRT / 64) * nbins_max * sizeof(int), J.q, J.sp, J.ki, J.vi, J.ko, J.vo, p, J.keep->hist.p, ntiles);
+      J.ki = J.ko; J.vi = J.vo;
+    }
+  }
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+
+// ---- exclusive scan / order-preserving compaction in ONE launch, element count on the device ---------------------------------------------
+// A tile of 2 048 flags per workgroup.  Tiles are handed out by a ticket (so a tile only ever waits for tiles that already run), every tile
+// publishes its sum as {epoch, sum} — a relaxed agent-scope atomic store of one 64-bit word: the word IS the message, nothing else has to be
+// made visible, so nobody fences — and the first wave of a tile reads the sums of ALL the tiles before it, 64 per load (a cloud of 115 k points
+// is 57 tiles: one load).  The epoch (a per-context launch counter) makes the status array self-cleaning; the tile holding the last ticket puts
+// the ticket counter back to 0.  Replaces three scan launches, the compaction launch and — where the count is only needed by later launches —
+// the read-back between them.
+constexpr int kS1T = 256, kS1E = 8, kS1Tile = kS1T * kS1E;
+template <bool COMPACT>
+__global__ __launch_bounds__(kS1T) void k_scan1(int cap, const int* __restrict__ n_dev, const int* __restrict__ in, int* __restrict__ pos, int* __restrict__ total_out,
+                                                unsigned long long* status, int* ticket, unsigned epoch, int ntiles, const float4* __restrict__ pts,
+                                                float4* __restrict__ out) {
+  __shared__ int s_tile, s_prefix, s_wave[kS1T / 64];
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1);
+  __syncthreads();
+  const int tile = s_tile;
+  const int n = n_dev ? min(cap, *n_dev) : cap;
+  const int base = tile * kS1Tile + (int)threadIdx.x * kS1E;
+  int v[kS1E];
+  int sum = 0;
+#pragma unroll
+  for (int e = 0; e < kS1E; ++e) { v[e] = (base + e < n) ? in[base + e] : 0; sum += v[e]; }
+  const int incl = wave_incl_scan(sum);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 63) s_wave[w] = incl;
+  __syncthreads();
+  int wbase = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kS1T / 64; ++k) { const int q = s_wave[k]; if (k < w) wbase += q; tot += q; }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(status + tile, ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tile == ntiles - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (every ticket of this launch has been taken)
+  }
+  if (w == 0) {
+    int acc = 0;
+    for (int t = lane; t < tile; t += 64) {
+      unsigned long long st;
+      do { st = __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(st >> 32) != epoch);
+      acc += (int)(unsigned)(st & 0xffffffffull);
+    }
+    acc = wave_sum_i(acc);
+    if (lane == 0) s_prefix = acc;
+  }
+  __syncthreads();
+  const int prefix = s_prefix;
+  int run = prefix + wbase + incl - sum;
+#pragma unroll
+  for (int e = 0; e < kS1E; ++e) {
+    const int i = base + e;
+    if (i < n) {
+      if (pos) pos[i] = run;
+      if (COMPACT) { if (v[e]) out[run] = pts[i]; }
+    }
+    run += v[e];
+  }
+  if (tile == ntiles - 1 && threadIdx.x == 0) {
+    if (total_out) *total_out = prefix + tot;
+    if (pos) pos[n] = prefix + tot;
+  }
+}
+// in[0 .. n) -> pos[0 .. n] (optional; pos[n] = the total), *total_out (optional), and — with pts / out — out[pos[i]] = pts[i] where in[i] != 0.
+// n = *n_dev clipped to cap, or cap when n_dev is null.
+int device_scan1_on(lvf_ctx* ctx, hipStream_t s, int lane, const int* in, int cap, const int* n_dev, int* pos, int* total_out, const float4* pts, float4* out) {
+  const int ntiles = std::max(1, (cap + kS1Tile - 1) / kS1Tile);
+  if (ntiles > ctx->scan_tiles) {
+    LVF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) LVF_HIP(hipStreamSynchronize(ctx->stream2));
+    if (ctx->scan_status) (void)hipFree(ctx->scan_status);
+    ctx->scan_status = nullptr; ctx->scan_tiles = 0;
+    const int want = std::max(1024, ntiles + ntiles / 2);
+    const size_t words = (size_t)2 * want + 2;            // [lane][tile] status words, then one ticket word per lane
+    LVF_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->scan_status), words * sizeof(unsigned long long)));
+    LVF_HIP(hipMemset(ctx->scan_status, 0, words * sizeof(unsigned long long)));
+    ctx->scan_tiles = want; ctx->scan_epoch = 0;
+  }
+  unsigned long long* status = ctx->scan_status + (size_t)lane * ctx->scan_tiles;
+  int* ticket = reinterpret_cast<int*>(ctx->scan_status + (size_t)2 * ctx->scan_tiles + lane);
+  unsigned epoch = ++ctx->scan_epoch;
+  if (epoch == 0) {          // the counter wrapped: every stale word could match again
+    LVF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) LVF_HIP(hipStreamSynchronize(ctx->stream2));
+    LVF_HIP(hipMemset(ctx->scan_status, 0, ((size_t)2 * ctx->scan_tiles + 2) * sizeof(unsigned long long)));
+    epoch = ctx->scan_epoch = 1;
+  }
+  if (pts && out) hipLaunchKernelGGL(k_scan1<true>, dim3(ntiles), dim3(kS1T), 0, s, cap, n_dev, in, pos, total_out, status, ticket, epoch, ntiles, pts, out);
+  else hipLaunchKernelGGL(k_scan1<false>, dim3(ntiles), dim3(kS1T), 0, s, cap, n_dev, in, pos, total_out, status, ticket, epoch, ntiles, pts, out);
+  LVF_HIP(hipGetLastError());
+  return LVF_OK;
+}
+int device_scan1(lvf_ctx* ctx, const int* in, int cap, const int* n_dev, int* pos, int* total_out, const float4* pts, float4* out) {
+  return device_scan1_on(ctx, ctx->stream, 0, in, cap, n_dev, pos, total_out, pts, out);
+}
+int side_stream(lvf_ctx* ctx, hipStream_t* out) {
+  if (!ctx->stream2) {
+    LVF_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    LVF_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    LVF_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  *out = ctx->stream2;
   return LVF_OK;
 }
 

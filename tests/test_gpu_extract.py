@@ -34,8 +34,17 @@ def close_fraction(a, b, tol):
     return float((d < tol).mean())
 
 
+@pytest.fixture(params=["device_counts", "host_counts"])
+def counts_path(request, ctx):
+    """lvf_lidar_extract's two paths: counts kept on the device (one stream wait per scan, the default) / read back after every stage"""
+    from lvio_fusion_amd import api
+    was = api.extract_host_counts(ctx, request.param == "host_counts")
+    yield request.param
+    api.extract_host_counts(ctx, was)
+
+
 @pytest.mark.parametrize("seed", [0x5CA9, 77])
-def test_extract_stages_and_clouds(ctx, oracle, seed):
+def test_extract_stages_and_clouds(ctx, oracle, seed, counts_path):
     from lvio_fusion_amd import api
     scan = syn.raw_scan(seed=seed)
     ext = syn.lidar_extrinsic()
@@ -66,7 +75,7 @@ def test_extract_stages_and_clouds(ctx, oracle, seed):
     g.close(); s.close()
 
 
-def test_extract_edge_cases(ctx):
+def test_extract_edge_cases(ctx, counts_path):
     from lvio_fusion_amd import api
     ext = syn.lidar_extrinsic()
     g, s = api.lidar_extract(ctx, np.zeros((0, 4), np.float32), ext)
@@ -77,6 +86,33 @@ def test_extract_edge_cases(ctx):
     near = np.zeros((50, 4), np.float32); near[:, 0] = 1.0          # inside min_range: all gated out
     g, s = api.lidar_extract(ctx, near, ext)
     assert len(g) == 0 and len(s) == 0
+    # a handful of points: every stage sees a count of a few (or zero) — ground picks below RANSAC's three, voxel grids of one cell
+    few = syn.raw_scan(seed=3)[::400]
+    g, s, dbg = api.lidar_extract(ctx, few, ext, debug=True)
+    assert dbg["n_filtered"] > 0 and len(g) + len(s) <= dbg["n_segmented"] + 1
+
+
+def test_both_count_paths_agree_on_many_scans(ctx):
+    """device-counted against host-counted path, bit for bit, on scans of different sizes and seeds (the oracle comparison above pins two of them)"""
+    from lvio_fusion_amd import api
+    ext = syn.lidar_extrinsic()
+    for seed, step in ((11, 1), (12, 1), (13, 2), (14, 7), (15, 50), (16, 3)):
+        scan = syn.raw_scan(seed=seed)[::step]
+        out = {}
+        for host in (False, True):
+            was = api.extract_host_counts(ctx, host)
+            try:
+                g, s, dbg = api.lidar_extract(ctx, scan, ext, debug=True)
+                out[host] = (g.download(), s.download(), dbg)
+                g.close(); s.close()
+            finally:
+                api.extract_host_counts(ctx, was)
+        for k in (0, 1):
+            assert out[False][k].shape == out[True][k].shape and np.array_equal(out[False][k].view(np.uint32), out[True][k].view(np.uint32)), (seed, step, k)
+        for k in ("n_filtered", "n_segmented"):
+            assert out[False][2][k] == out[True][2][k]
+        for k in ("ground_raw", "surf_raw", "label_mat", "range_mat"):
+            assert np.array_equal(out[False][2][k].view(np.uint32), out[True][2][k].view(np.uint32)), (seed, step, k)
 
 
 def test_extract_feeds_scan_matching(ctx):
