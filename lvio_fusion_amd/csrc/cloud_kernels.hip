@@ -452,17 +452,38 @@ static int new_cloud(lvf_ctx* ctx, int n, lvf_cloud** out) {
   return LVF_OK;
 }
 // out (a NEW cloud) = the flagged points of pts[0..n), input order preserved — shared with extract_kernels.hip
+// (device_scan1's tiles read every earlier tile's sum: fine for thousands of tiles, not for a 30 M-cell grid — beyond this the three-launch scan)
+constexpr int kScan1Max = 1 << 22;
+static int scan_i32(lvf_ctx* ctx, const int* in, int n, int* pos) {
+  if (n <= kScan1Max) return device_scan1(ctx, in, n, nullptr, pos, nullptr, nullptr, nullptr);
+  return device_exclusive_scan_i32(ctx, in, n, pos);
+}
 int compact_points(lvf_ctx* ctx, const float4* pts, int n, const int* flags_dev, lvf_cloud** out) {
-  hipStream_t s = ctx->stream;
-  DevBuf<int> pos;
-  LVF_TRY(pos.alloc((size_t)n + 1));
-  LVF_TRY(device_exclusive_scan_i32(ctx, flags_dev, n, pos.p));
+  if (n > kScan1Max) {
+    hipStream_t s = ctx->stream;
+    DevBuf<int> pos;
+    LVF_TRY(pos.alloc((size_t)n + 1));
+    LVF_TRY(device_exclusive_scan_i32(ctx, flags_dev, n, pos.p));
+    int total = 0;
+    LVF_TRY(read_back(ctx, &total, pos.p + n, sizeof(int)));
+    LVF_TRY(new_cloud(ctx, total, out));
+    if (total) hipLaunchKernelGGL(k_compact, dim3(gridc(n)), dim3(kC), 0, s, n, pts, flags_dev, pos.p, (*out)->pts.p);
+    LVF_HIP(hipGetLastError());
+    LVF_HIP(hipStreamSynchronize(s));
+    return LVF_OK;
+  }
+  // ONE launch (device_scan1: scan + compaction) into a block of the input's capacity, then the count comes back (round 4: three scan launches,
+  // the count, a block of exactly that size, the compaction launch, a second wait)
+  lvf_cloud* c = nullptr;
+  LVF_TRY(new_cloud(ctx, n, &c));
+  DevBuf<int> total_dev;
+  int rc = total_dev.alloc(1);
+  if (rc == LVF_OK) rc = device_scan1(ctx, flags_dev, n, nullptr, nullptr, total_dev.p, pts, c->pts.p);
   int total = 0;
-  LVF_TRY(read_back(ctx, &total, pos.p + n, sizeof(int)));
-  LVF_TRY(new_cloud(ctx, total, out));
-  if (total) hipLaunchKernelGGL(k_compact, dim3(gridc(n)), dim3(kC), 0, s, n, pts, flags_dev, pos.p, (*out)->pts.p);
-  LVF_HIP(hipGetLastError());
-  LVF_HIP(hipStreamSynchronize(s));
+  if (rc == LVF_OK) rc = read_back(ctx, &total, total_dev.p, sizeof(int));
+  if (rc != LVF_OK) { delete c; return rc; }
+  c->n = total; c->pts.n = (size_t)total;
+  *out = c;
   return LVF_OK;
 }
 // out = the flagged points of `in`, input order preserved
@@ -886,7 +907,7 @@ int lvf_cloud_voxel_filter(const lvf_cloud* in, float leaf, lvf_cloud** out) {
   while ((1ll << bits) < ncell) ++bits;
   LVF_TRY(device_sort_pairs_u32(ctx, key.p, key_sorted.p, val.p, order.p, in->n, bits));      // stable: ascending input index inside a voxel
   hipLaunchKernelGGL(k_voxel_heads, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, (const int*)nullptr, key_sorted.p, flags.p);
-  LVF_TRY(device_exclusive_scan_i32(ctx, flags.p, in->n, pos.p));
+  LVF_TRY(scan_i32(ctx, flags.p, in->n, pos.p));
   int total = 0;
   LVF_TRY(read_back(ctx, &total, pos.p + in->n, sizeof(int)));
   lvf_cloud* c = nullptr;
@@ -913,15 +934,15 @@ int lvf_cloud_radius_outlier_filter(const lvf_cloud* in, float radius, int min_n
   while (dims(cell, d) > (1ll << 25)) cell *= 1.5f;   // bigger cells stay correct, only slower
   const int ncell = d[0] * d[1] * d[2];
   const GridC g{lo[0], lo[1], lo[2], 1.0f / cell, d[0], d[1], d[2]};
-  DevBuf<int> cell_of, counts, cursor, start, flags;
+  DevBuf<int> cell_of, counts2, start, flags;
   DevBuf<float4> sorted;
-  LVF_TRY(cell_of.alloc(in->n)); LVF_TRY(counts.alloc(ncell)); LVF_TRY(cursor.alloc(ncell)); LVF_TRY(start.alloc((size_t)ncell + 1));
+  LVF_TRY(cell_of.alloc(in->n)); LVF_TRY(counts2.alloc((size_t)2 * ncell)); LVF_TRY(start.alloc((size_t)ncell + 1));
   LVF_TRY(flags.alloc(in->n)); LVF_TRY(sorted.alloc(in->n));
-  LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)4 * ncell, s));
-  LVF_HIP(hipMemsetAsync(cursor.p, 0, (size_t)4 * ncell, s));
+  struct { int* p; } counts{counts2.p}, cursor{counts2.p + ncell};      // (one block, one clear)
+  LVF_HIP(hipMemsetAsync(counts2.p, 0, (size_t)8 * ncell, s));
   hipLaunchKernelGGL(k_grid_count, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, (const int*)nullptr, in->pts.p, g, (const GridC*)nullptr, cell_of.p, counts.p);
   LVF_HIP(hipGetLastError());
-  LVF_TRY(device_exclusive_scan_i32(ctx, counts.p, ncell, start.p));
+  LVF_TRY(scan_i32(ctx, counts.p, ncell, start.p));
   hipLaunchKernelGGL(k_grid_scatter, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, (const int*)nullptr, in->pts.p, cell_of.p, start.p, cursor.p, sorted.p);
   hipLaunchKernelGGL(k_radius_count, dim3(gridc(in->n)), dim3(kC), 0, s, in->n, (const int*)nullptr, in->pts.p, g, (const GridC*)nullptr, start.p, sorted.p, radius * radius, min_neighbors, flags.p);
   LVF_HIP(hipGetLastError());

@@ -271,7 +271,11 @@ __global__ __launch_bounds__(kS1T) void k_scan1(int cap, const int* __restrict__
     int acc = 0;
     for (int t = lane; t < tile; t += 64) {
       unsigned long long st;
-      do { st = __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(st >> 32) != epoch);
+      unsigned polls = 0;
+      do {
+        st = __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++polls > (1u << 23)) __builtin_trap();      // (seconds: the status block was corrupted — fail the launch rather than hang the queue)
+      } while ((unsigned)(st >> 32) != epoch);
       acc += (int)(unsigned)(st & 0xffffffffull);
     }
     acc = wave_sum_i(acc);
@@ -306,7 +310,10 @@ int device_scan1_on(lvf_ctx* ctx, hipStream_t s, int lane, const int* in, int ca
     const int want = std::max(1024, ntiles + ntiles / 2);
     const size_t words = (size_t)2 * want + 2;            // [lane][tile] status words, then one ticket word per lane
     LVF_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->scan_status), words * sizeof(unsigned long long)));
-    LVF_HIP(hipMemset(ctx->scan_status, 0, words * sizeof(unsigned long long)));
+    // (on the context's stream and waited for: a plain hipMemset goes to the null stream, which a non-blocking stream does not order against —
+    // the clear could land in the middle of the launch below, hand a ticket out twice and leave a tile waiting for ever)
+    LVF_HIP(hipMemsetAsync(ctx->scan_status, 0, words * sizeof(unsigned long long), ctx->stream));
+    LVF_HIP(hipStreamSynchronize(ctx->stream));
     ctx->scan_tiles = want; ctx->scan_epoch = 0;
   }
   unsigned long long* status = ctx->scan_status + (size_t)lane * ctx->scan_tiles;
@@ -315,7 +322,8 @@ int device_scan1_on(lvf_ctx* ctx, hipStream_t s, int lane, const int* in, int ca
   if (epoch == 0) {          // the counter wrapped: every stale word could match again
     LVF_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->stream2) LVF_HIP(hipStreamSynchronize(ctx->stream2));
-    LVF_HIP(hipMemset(ctx->scan_status, 0, ((size_t)2 * ctx->scan_tiles + 2) * sizeof(unsigned long long)));
+    LVF_HIP(hipMemsetAsync(ctx->scan_status, 0, ((size_t)2 * ctx->scan_tiles + 2) * sizeof(unsigned long long), ctx->stream));
+    LVF_HIP(hipStreamSynchronize(ctx->stream));
     epoch = ctx->scan_epoch = 1;
   }
   if (pts && out) hipLaunchKernelGGL(k_scan1<true>, dim3(ntiles), dim3(kS1T), 0, s, cap, n_dev, in, pos, total_out, status, ticket, epoch, ntiles, pts, out);
