@@ -9,7 +9,7 @@
 //                    scan over the whole table yields every (bin, tile)'s first output slot);
 //   k_radix_scan     that scan, one workgroup of 1 024 threads (the table has bins x tiles entries: 25 k for a 100 k-point cloud and 10-bit digits;
 //                    tables beyond 256 k entries — clouds of millions of points — take k_radix_scan_sums + k_radix_scan_chunks, up to 1 024 workgroups);
-//   k_radix_scatter  the tile again, sixteen rounds of 256 keys in input order: a key's rank among the keys of its digit is
+//   k_radix_scatter  the tile again, four rounds of 1 024 keys in input order: a key's rank among the keys of its digit is
 //                    (keys of that digit in earlier rounds of the tile) + (in lower waves of this round) + (in lower lanes of its wave) —
 //                    the last from one wave ballot per digit bit (lanes whose digit equals mine), no sorting network, no atomics,
 //                    so equal digits keep their input order: stable.
@@ -107,20 +107,27 @@ __global__ __launch_bounds__(kRScanT) void k_radix_scan_chunks(int total, int* _
   wg_excl_scan(a, lo, min(total, lo + chunk), s_start);
 }
 
-// Dynamic LDS: s_base[nbins] | s_cnt[waves][nbins].
+// Dynamic LDS: s_base[nbins] ints | s_cnt[waves][nbins] BYTES (a wave holds at most 64 keys of a digit).  1 024 threads = 16 waves: a tile is four
+// rounds of 1 024 keys (with 256 threads it was sixteen rounds of four barriers each, 20 us per pass on a 50 k-key sort whose dozen tiles cannot
+// fill the chip anyway).
+constexpr int kRST = 1024, kRSRounds = kRTile / kRST, kRSWaves = kRST / 64;
+static_assert(kRSRounds * kRST == kRTile, "a tile is a whole number of scatter rounds");
+__host__ __device__ inline size_t radix_scatter_lds(int nbins) { return (size_t)nbins * sizeof(int) + (size_t)kRSWaves * nbins; }
 __device__ __forceinline__ void radix_scatter_body(int n, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, unsigned* __restrict__ keys_out,
                                                    int* __restrict__ vals_out, int shift, int digit_bits, unsigned mask, const int* __restrict__ hist, int ntiles, int* rs_lds) {
   const int nbins = 1 << digit_bits;
   int* s_base = rs_lds;
-  int* s_cnt = rs_lds + nbins;               // [wave][bin]
-  for (int b = threadIdx.x; b < nbins; b += kRT) s_base[b] = hist[(size_t)b * ntiles + blockIdx.x];
+  unsigned char* s_cnt = reinterpret_cast<unsigned char*>(rs_lds + nbins);      // [wave][bin]
+  unsigned* s_cnt_w = reinterpret_cast<unsigned*>(rs_lds + nbins);              // the same as words, for clearing
+  for (int b = threadIdx.x; b < nbins; b += kRST) s_base[b] = hist[(size_t)b * ntiles + blockIdx.x];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int base = blockIdx.x * kRTile;
-  for (int r = 0; r < kRRounds; ++r) {
-    for (int b = threadIdx.x; b < (kRT / 64) * nbins; b += kRT) s_cnt[b] = 0;
+  for (int r = 0; r < kRSRounds; ++r) {
+    if (base + r * kRST >= n) break;                  // (uniform: the rest of the tile holds no keys)
+    for (int b = threadIdx.x; b < kRSWaves * nbins / 4; b += kRST) s_cnt_w[b] = 0u;
     __syncthreads();
-    const int i = base + r * kRT + threadIdx.x;
+    const int i = base + r * kRST + threadIdx.x;
     const bool valid = i < n;
     const unsigned key = valid ? keys_in[i] : 0u;
     const int val = valid ? vals_in[i] : 0;
@@ -132,29 +139,29 @@ __device__ __forceinline__ void radix_scatter_body(int n, const unsigned* __rest
       same &= bit ? bal : ~bal;
     }
     const int rank = __popcll(same & lt), cnt = __popcll(same);
-    if (valid && rank == 0) s_cnt[w * nbins + d] = cnt;
+    if (valid && rank == 0) s_cnt[w * nbins + d] = (unsigned char)cnt;      // (<= 64)
     __syncthreads();
     if (valid) {
       int off = s_base[d] + rank;
-      for (int k = 0; k < w; ++k) off += s_cnt[k * nbins + d];
+      for (int k = 0; k < w; ++k) { const int c = s_cnt[k * nbins + d]; off += c; }
       keys_out[off] = key; vals_out[off] = val;
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nbins; b += kRT) {
+    for (int b = threadIdx.x; b < nbins; b += kRST) {
       int add = 0;
 #pragma unroll
-      for (int k = 0; k < kRT / 64; ++k) add += s_cnt[k * nbins + b];
+      for (int k = 0; k < kRSWaves; ++k) add += s_cnt[k * nbins + b];
       s_base[b] += add;
     }
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(kRT) void k_radix_scatter(int n, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, unsigned* __restrict__ keys_out,
+__global__ __launch_bounds__(kRST) void k_radix_scatter(int n, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, unsigned* __restrict__ keys_out,
                                                        int* __restrict__ vals_out, int shift, int digit_bits, unsigned mask, const int* __restrict__ hist, int ntiles) {
   extern __shared__ int rs_lds[];
   radix_scatter_body(n, keys_in, vals_in, keys_out, vals_out, shift, digit_bits, mask, hist, ntiles, rs_lds);
 }
-__global__ __launch_bounds__(kRT) void k_radix_scatter_dc(const SortP* __restrict__ spp, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in,
+__global__ __launch_bounds__(kRST) void k_radix_scatter_dc(const SortP* __restrict__ spp, const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in,
                                                           unsigned* __restrict__ keys_out, int* __restrict__ vals_out, int p, const int* __restrict__ hist, int ntiles) {
   extern __shared__ int rs_lds[];
   const SortP sp = *spp;
@@ -193,7 +200,7 @@ int device_sort_pairs_u32(lvf_ctx* ctx, const unsigned* keys_in, unsigned* keys_
       hipLaunchKernelGGL(k_radix_scan_sums, dim3(groups), dim3(kRScanT), 0, s, total, hist.p, chunk, part.p);
       hipLaunchKernelGGL(k_radix_scan_chunks, dim3(groups), dim3(kRScanT), 0, s, total, hist.p, chunk, part.p);
     }
-    hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(kRT), (size_t)(1 + kRT / 64) * nbins * sizeof(int), s, n, ki, vi, ko, vo, db * p, db, mask, hist.p, ntiles);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(kRST), radix_scatter_lds(nbins), s, n, ki, vi, ko, vo, db * p, db, mask, hist.p, ntiles);
     ki = ko; vi = vo;
   }
   LVF_HIP(hipGetLastError());
@@ -226,7 +233,7 @@ int device_sort_pairs_u32_dc_multi(lvf_ctx* ctx, int n_jobs, SortJobDc* jobs, in
     for (int k = 0; k < n_jobs; ++k) hipLaunchKernelGGL(k_radix_scan_dc, dim3(1), dim3(kRScanT), 0, jobs[k].q, jobs[k].sp, ntiles, jobs[k].keep->hist.p);
     for (int k = 0; k < n_jobs; ++k) {
       SortJobDc& J = jobs[k];
-      hipLaunchKernelGGL(k_radix_scatter_dc, dim3(ntiles), dim3(kRT), (size_t)(1 + kRT / 64) * nbins_max * sizeof(int), J.q, J.sp, J.ki, J.vi, J.ko, J.vo, p, J.keep->hist.p, ntiles);
+      hipLaunchKernelGGL(k_radix_scatter_dc, dim3(ntiles), dim3(kRST), radix_scatter_lds(nbins_max), J.q, J.sp, J.ki, J.vi, J.ko, J.vo, p, J.keep->hist.p, ntiles);
       J.ki = J.ko; J.vi = J.vo;
     }
   }
