@@ -267,11 +267,18 @@ __global__ __launch_bounds__(kC) void k_radius_count(int n, const int* __restric
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
     const int row = (z * g.ny + y) * g.nx;
     const int lo = cell_start[row + x0], hi = cell_start[row + x1 + 1];   // x-adjacent cells are contiguous
-    for (int j = lo; j < hi && cnt <= min_neighbors; ++j) {
-      const float4 q = sorted[j];
-      const float dx = p.x - q.x, dyy = p.y - q.y, dzz = p.z - q.z;
-      const float d = (dx * dx + dyy * dyy) + dzz * dzz;
-      cnt += d < r2 ? 1 : 0;
+    // eight candidates per round trip, requested unconditionally and counted afterwards (one at a time behind the `cnt` test every candidate was
+    // its own dependent load: a point of a sparse region walked its 27 cells at one L2 latency per point — 141 us for the launch on 100 k points)
+    for (int j = lo; j < hi && cnt <= min_neighbors; j += 8) {
+      float4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = sorted[min(j + u, hi - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float dx = p.x - q[u].x, dyy = p.y - q[u].y, dzz = p.z - q[u].z;
+        const float d = (dx * dx + dyy * dyy) + dzz * dzz;
+        cnt += ((j + u < hi) & (d < r2)) ? 1 : 0;
+      }
     }
   }
   flags[i] = cnt > min_neighbors ? 1 : 0;
