@@ -142,14 +142,16 @@ __global__ __launch_bounds__(kE) void k_ex_union(int npix, const float* __restri
   const int idx = blockIdx.x * kE + threadIdx.x;
   if (idx >= npix || parent[idx] < 0) return;
   const int i = idx / P.Cn, j = idx - i * P.Cn;
-  const float ra = range[idx];
   const int jr = j + 1 == P.Cn ? 0 : j + 1;                               // the range image wraps in azimuth
   const int right = i * P.Cn + jr;
-  if (right != idx && parent[right] >= 0 && linked(ra, range[right], P.sin_ax, P.cos_ax, P.theta)) uf_unite(parent, idx, right);
-  if (i + 1 < P.R) {
-    const int down = idx + P.Cn;
-    if (parent[down] >= 0 && linked(ra, range[down], P.sin_ay, P.cos_ay, P.theta)) uf_unite(parent, idx, down);
-  }
+  const bool has_down = i + 1 < P.R;
+  const int down = has_down ? idx + P.Cn : idx;
+  // (both neighbours' state and range are requested before either link is tested: behind the short-circuits they were four dependent round trips)
+  const float ra = range[idx], rr = range[right], rd = range[down];
+  const int pr = parent[right], pd = parent[down];
+  const bool link_r = (right != idx) & (pr >= 0), link_d = has_down & (pd >= 0);
+  if (link_r && linked(ra, rr, P.sin_ax, P.cos_ax, P.theta)) uf_unite(parent, idx, right);
+  if (link_d && linked(ra, rd, P.sin_ay, P.cos_ay, P.theta)) uf_unite(parent, idx, down);
 }
 // segment size and the 64-bit mask of rows its pixels (other than the seed) lie in.  A wave holds 64 consecutive pixels of one
 // or two image rows and neighbouring pixels mostly share their segment, so the root's counters are touched once per run of
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(kE) void k_ex_stats(int npix, int Cn, int* __restri
   const int idx = blockIdx.x * kE + threadIdx.x;
   const bool live = idx < npix && parent[idx] >= 0;
   const int root = live ? uf_find(parent, idx) : -1;
+  if (live) parent[idx] = root;        // (path compression for k_ex_segflag's look-up: roots do not change any more, a concurrent walk only gets shorter)
   if (Cn < 64) {                     // a wave could span more than two rows: plain per-pixel counters
     if (live) { atomicAdd(size + root, 1); if (idx != root) atomicOr(rows + root, 1ull << (idx / Cn)); }
     return;
