@@ -533,10 +533,10 @@ static int compact_cloud(const lvf_cloud* in, const int* flags_dev, lvf_cloud** 
 // launches — the voxel grid's origin and dimensions, the sort's digit split, the radius grid, RANSAC's bookkeeping, the least-squares refit —
 // is computed by the LAST workgroup of the launch that produces its inputs (arrival counter behind a fence) or by a one-thread launch, with
 // the same arithmetic.  Results are the host-counted path's bit for bit (tests/test_gpu_extract.py runs both).
-__global__ void k_dc_init(DcState* __restrict__ st, int* __restrict__ ransac_counts, int n_ransac) {
+__global__ void k_dc_init(DcState* __restrict__ st, int* __restrict__ ransac_counts, int n_ransac, int cnt2) {
   const int t = threadIdx.x;
   for (int i = t; i < n_ransac; i += blockDim.x) ransac_counts[i] = 0;
-  if (t < 4) st->cnt[t] = 0;
+  if (t < 4) st->cnt[t] = t == 2 ? cnt2 : 0;          // (cnt2: lvf_cloud_segment_plane enters the chain at the plane fit with a host-known count)
   if (t < 6) st->tick[t] = 0;
   if (t < 24) st->bounds[t / 6][t % 6] = (t % 6) < 3 ? 0xffffffffu : 0u;
   if (t < 19) st->mom.v[t] = 0ull;
@@ -747,7 +747,7 @@ int dc_tail_begin(lvf_ctx* ctx, int cap, float resolution, float max_range, DevB
   LVF_TRY(state.alloc(sizeof(DcState)));
   LVF_TRY(K.ransac_counts.alloc(plan->max_iterations));
   LVF_TRY(K.counts2.alloc((size_t)2 * plan->grid_cells));
-  hipLaunchKernelGGL(k_dc_init, dim3(1), dim3(64), 0, s, reinterpret_cast<DcState*>(state.p), K.ransac_counts.p, plan->max_iterations);
+  hipLaunchKernelGGL(k_dc_init, dim3(1), dim3(64), 0, s, reinterpret_cast<DcState*>(state.p), K.ransac_counts.p, plan->max_iterations, 0);
   LVF_HIP(hipMemsetAsync(K.counts2.p, 0, (size_t)8 * plan->grid_cells, s));      // the radius grid's counts | cursor (one block, one clear)
   LVF_HIP(hipGetLastError());
   plan->supported = true;
@@ -994,70 +994,38 @@ int lvf_cloud_segment_plane(const lvf_cloud* in, float distance_threshold, int m
   if (in->n < 3) return new_cloud(ctx, 0, out);          // SACSegmentation cannot fit a model: no inliers
   hipStream_t s = ctx->stream;
   const int n = in->n;
-  DevBuf<int> counts, flags; DevBuf<MomI> mom;
-  LVF_TRY(counts.alloc(max_iterations)); LVF_TRY(flags.alloc(n)); LVF_TRY(mom.alloc(1));
-  // scale of the exact moment sums: |coordinate| < 2^e  =>  |x y| 2^shift < 2^60
-  float blo[3], bhi[3];
-  LVF_TRY(cloud_bounds(in, blo, bhi));
-  float maxabs = 0.0f;
-  for (int k = 0; k < 3; ++k) maxabs = std::max(maxabs, std::max(std::fabs(blo[k]), std::fabs(bhi[k])));
-  int e2 = 0;
-  (void)std::frexp(maxabs, &e2);
-  const int shift = 60 - 2 * std::max(e2, 0);
-  const double mom_scale = std::ldexp(1.0, shift);
-  LVF_HIP(hipMemsetAsync(counts.p, 0, (size_t)4 * max_iterations, s));
-  const int gx = std::min(gridc(n), 8);      // x 100 hypotheses = 800 workgroups, one counter atomic each
-  hipLaunchKernelGGL(k_ransac_count, dim3(gx, max_iterations), dim3(kC), 0, s, n, (const int*)nullptr, in->pts.p, (unsigned long long)seed, distance_threshold, counts.p);
+  // One launch chain and ONE wait (round 4: five — the bounding box for the moment scale, the hypothesis counts, the winner's three points, the
+  // moments, the inlier count — with RANSAC's bookkeeping and the refit on the host in between).  The chain is the ground half of the feature
+  // extraction's tail: the moment scale by the last workgroup of the bounds pass, pcl::RandomSampleConsensus' bookkeeping and the winning plane
+  // by a one-thread launch (k_ransac_pick), the least-squares refit by the last workgroup of the first inlier pass, the inliers' compaction by
+  // device_scan1 — the host arithmetic of round 4, on the device.
+  DevBuf<unsigned char> state; DevBuf<int> counts, flags;
+  LVF_TRY(state.alloc(sizeof(DcState))); LVF_TRY(counts.alloc(max_iterations)); LVF_TRY(flags.alloc(n));
+  DcState* st = reinterpret_cast<DcState*>(state.p);
+  const int* n_dev = &st->cnt[2];
+  hipLaunchKernelGGL(k_dc_init, dim3(1), dim3(64), 0, s, st, counts.p, max_iterations, n);
+  DcSetup su; su.mode = 2; su.slot = 3; su.which = 0; su.f0 = 0.0f; su.i0 = 0;
+  const int gb = std::min(n > (1 << 18) ? kCapBlocks : kDcBoundsBlocks, gridc(n));
+  hipLaunchKernelGGL(k_dc_bounds, dim3(gb), dim3(kC), 0, s, n, n_dev, in->pts.p, st, su);
+  hipLaunchKernelGGL(k_ransac_count, dim3(std::min(gridc(n), 8), max_iterations), dim3(kC), 0, s, n, n_dev, in->pts.p, (unsigned long long)seed, distance_threshold, counts.p);
+  hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, s, n_dev, n, in->pts.p, counts.p, max_iterations, (unsigned long long)seed, st);
+  hipLaunchKernelGGL(k_plane_inliers, dim3(gb), dim3(kC), 0, s, n, n_dev, in->pts.p, 0.0f, 0.0f, 0.0f, 0.0f, &st->plane[0], distance_threshold, flags.p, &st->mom, 0.0, st);
+  hipLaunchKernelGGL(k_plane_inliers, dim3(gb), dim3(kC), 0, s, n, n_dev, in->pts.p, 0.0f, 0.0f, 0.0f, 0.0f, &st->plane[1], distance_threshold, flags.p, (MomI*)nullptr, 0.0, (DcState*)nullptr);
   LVF_HIP(hipGetLastError());
-  std::vector<int> hc(max_iterations);
-  LVF_TRY(read_back(ctx, hc.data(), counts.p, (size_t)4 * max_iterations));
-  // pcl::RandomSampleConsensus::computeModel's bookkeeping, applied in hypothesis order
-  int best = -1, best_count = 0, used = 0;
-  double k = 1.0;
-  const double log_probability = std::log(1.0 - 0.99);
-  for (int h = 0; h < max_iterations && (double)h < k; ++h) {
-    used = h + 1;
-    if (hc[h] > best_count) {
-      best_count = hc[h]; best = h;
-      const double w = (double)best_count / (double)n;
-      double p_no_outliers = 1.0 - w * w * w;
-      p_no_outliers = std::max(std::numeric_limits<double>::epsilon(), p_no_outliers);
-      p_no_outliers = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no_outliers);
-      k = log_probability / std::log(p_no_outliers);
-    }
-  }
-  if (iterations_used) *iterations_used = used;
-  if (best < 0) return new_cloud(ctx, 0, out);
-  // recompute the winning plane on the host from its three sample points (same float arithmetic as the device)
-  int id[3];
-  sample3(seed, best, n, id);
-  float4 sp[3];
-  {
-    LVF_TRY(ctx->mailbox.reserve(4096));
-    for (int q = 0; q < 3; ++q) LVF_HIP(hipMemcpyAsync(ctx->mailbox.p + 16 * q, in->pts.p + id[q], sizeof(float4), hipMemcpyDeviceToHost, s));
-    LVF_HIP(hipStreamSynchronize(s));
-    std::memcpy(sp, ctx->mailbox.p, sizeof(sp));
-  }
-  float co[4];
-  {
-    const float ux = sp[1].x - sp[0].x, uy = sp[1].y - sp[0].y, uz = sp[1].z - sp[0].z, vx = sp[2].x - sp[0].x, vy = sp[2].y - sp[0].y, vz = sp[2].z - sp[0].z;
-    float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
-    const float inv = 1.0f / std::sqrt((nx * nx + ny * ny) + nz * nz);
-    nx *= inv; ny *= inv; nz *= inv;
-    co[0] = nx; co[1] = ny; co[2] = nz; co[3] = -((nx * sp[0].x + ny * sp[0].y) + nz * sp[0].z);
-  }
-  // optimizeModelCoefficients: least-squares plane through the inliers, then re-select (SACSegmentation::segment)
-  LVF_HIP(hipMemsetAsync(mom.p, 0, sizeof(MomI), s));
-  hipLaunchKernelGGL(k_plane_inliers, dim3(std::min(kCapBlocks, gridc(n))), dim3(kC), 0, s, n, (const int*)nullptr, in->pts.p, co[0], co[1], co[2], co[3], (const PlaneP*)nullptr, distance_threshold, flags.p, mom.p, mom_scale, (DcState*)nullptr);
-  LVF_HIP(hipGetLastError());
-  MomI hm;
-  LVF_TRY(read_back(ctx, &hm, mom.p, sizeof(hm)));
-  if (refit_plane(hm, shift, co)) {
-    hipLaunchKernelGGL(k_plane_inliers, dim3(std::min(kCapBlocks, gridc(n))), dim3(kC), 0, s, n, (const int*)nullptr, in->pts.p, co[0], co[1], co[2], co[3], (const PlaneP*)nullptr, distance_threshold, flags.p, (MomI*)nullptr, 0.0, (DcState*)nullptr);
-    LVF_HIP(hipGetLastError());
-  }
-  if (coefficients4) for (int q = 0; q < 4; ++q) coefficients4[q] = co[q];
-  return compact_cloud(in, flags.p, out);
+  lvf_cloud* c = nullptr;
+  LVF_TRY(new_cloud(ctx, n, &c));
+  DcState h;
+  int rc = n <= kScan1Max ? device_scan1(ctx, flags.p, n, nullptr, nullptr, &st->cnt[3], in->pts.p, c->pts.p) : LVF_OK;
+  static_assert(sizeof(DcState) <= 4096, "DcState comes back through the context's mailbox");
+  if (rc == LVF_OK) rc = read_back(ctx, &h, st, sizeof(DcState));
+  if (rc != LVF_OK) { delete c; return rc; }
+  if (h.err & kDcErrBounds) { delete c; set_error("cloud has non-finite coordinates"); return LVF_ERR_INVALID; }
+  if (iterations_used) *iterations_used = h.ransac_used;
+  if (coefficients4) for (int q = 0; q < 4; ++q) coefficients4[q] = h.plane[1].valid ? (double)h.plane[1].co[q] : 0.0;
+  if (n > kScan1Max) { delete c; return compact_cloud(in, flags.p, out); }      // (beyond the one-launch scan: the three-launch compaction)
+  c->n = h.cnt[3]; c->pts.n = (size_t)h.cnt[3];
+  *out = c;
+  return LVF_OK;
 }
 
 }  // extern "C"
