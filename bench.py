@@ -938,6 +938,24 @@ def relocalize_leg(api, syn, ctx, n=8, device=0):
         tb.append(time.perf_counter() - t0)
     dtb = float(np.median(tb))
     sameb = bool(np.array_equal(rec[:, [0, 8]], recb[:, [0, 8]]) and np.allclose(rec[:, 1:8], recb[:, 1:8], rtol=0, atol=1e-9))
+    # ... with the candidates' clouds RESIDENT in HBM (api.Cloud = lvf_cloud: what a pipeline that keeps frame->feature_lidar on the device —
+    # lvf_lidar_extract's outputs, lvf_cloud_concat for BuildOldMapFrame — hands over): no 6 MB of map points over PCIe per relocalisation
+    for c in cands:
+        rl.resident_candidate(api, ctx, c)
+    rl.evaluate_candidates_batched(api, ctx, cands[:2], resident=True)
+    tr = []
+    for _ in range(5):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        resr = rl.evaluate_candidates_batched(api, ctx, cands, resident=True)
+        tr.append(time.perf_counter() - t0)
+    dtr = float(np.median(tr))
+    order = np.argsort(recb[:, 8])
+    samer = bool(all(int(r.score) - rl.RELOCATE_BASE_SCORE == int(recb[order[k], 0]) and np.allclose(np.array(r.relative_o_c[:]), recb[order[k], 1:8], rtol=0, atol=1e-12)
+                     for k, r in enumerate(resr)))
+    for c in cands:
+        for h in c.pop("resident"):
+            h.close()
     # the same candidates with three more contexts (streams + host threads) on the same GPU: a candidate is a latency chain
     workers = [api.Context(int(device) if isinstance(device, int) else 0) for _ in range(3)]
     rl.relocalize(api, ctx, cands[:4], workers=workers)
@@ -953,6 +971,8 @@ def relocalize_leg(api, syn, ctx, n=8, device=0):
             "ms_total": 1e3 * dtb, "candidates_per_sec": n / dtb, "best": None if bestb is None else {"candidate": bestb[0], "score": bestb[1]},
             "note": "ms_total = all candidates in ONE launch chain (lvf_scan_match_batch) incl. 16 map-index builds and scan uploads; one_at_a_time / four_streams: the round-3 forms",
             "batched_same_records_as_one_at_a_time": sameb,
+            "clouds_resident_in_hbm": {"ms_total": 1e3 * dtr, "candidates_per_sec": n / dtr, "same_records_as_uploaded_clouds": samer,
+                                       "note": "the candidates' map / scan clouds are lvf_cloud objects already (lvf_map_create_batch_from_clouds, lvf_scan_create_from_cloud): index builds + the batched solve, no PCIe upload"},
             "one_at_a_time": {"ms_total": 1e3 * dt, "candidates_per_sec": n / dt},
             "scores": [float(x) for x in rec[np.argsort(rec[:, 8]), 0]],
             "four_streams": {"ms_total": 1e3 * dt4, "candidates_per_sec": n / dt4, "same_records_as_one_stream": same}}

@@ -301,6 +301,9 @@ int lvf_lidar_extract(lvf_ctx* ctx, const float* points, int n, int stride_float
 int lvf_debug_extract_host_counts(int on);
 /* kNN index / query scan straight from device-resident clouds (no host round trip) */
 int lvf_map_create_from_cloud(const lvf_cloud* c, float max_radius2, lvf_map** out);
+/* ... of n device-resident clouds in one call (lvf_map_create_batch's shared waits and launches, no upload): the old-frame maps of a set of
+ * loop-closure candidates whose per-keyframe clouds are kept as lvf_cloud (relocator.cpp:196-206 -> mapping.cpp:251-262) */
+int lvf_map_create_batch_from_clouds(lvf_ctx* ctx, int n, const lvf_cloud* const* clouds, const float* max_radius2, lvf_map** out);
 int lvf_scan_create_from_cloud(const lvf_cloud* c, lvf_scan** out);
 
 /* ---- one scan-to-map sub-problem (3-DoF LM on device) ---------------------------------------- */

@@ -185,6 +185,7 @@ _SIGS = {
     "lvf_cloud_radius_outlier_filter": (C.c_int, [_VP, C.c_float, C.c_int, C.POINTER(_VP)]),
     "lvf_cloud_segment_plane": (C.c_int, [_VP, C.c_float, C.c_int, C.c_uint64, C.POINTER(_VP), c_double_p, C.POINTER(C.c_int)]),
     "lvf_map_create_from_cloud": (C.c_int, [_VP, C.c_float, C.POINTER(_VP)]),
+    "lvf_map_create_batch_from_clouds": (C.c_int, [_VP, C.c_int, C.POINTER(_VP), c_float_p, C.POINTER(_VP)]),
     "lvf_scan_create_from_cloud": (C.c_int, [_VP, C.POINTER(_VP)]),
     "lvf_lidar_params_default": (None, [C.POINTER(LidarParams)]),
     "lvf_debug_extract_host_counts": (C.c_int, [C.c_int]),

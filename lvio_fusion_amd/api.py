@@ -384,9 +384,21 @@ class Map:
 
     @classmethod
     def create_batch(cls, ctx, clouds, max_radius2):
-        """lvf_map_create_batch: one Map per cloud (host arrays of one column count), the host waits shared between them"""
+        """lvf_map_create_batch: one Map per cloud (host arrays of one column count, or device-resident Cloud objects: no upload), the host
+        waits shared between them"""
+        n = len(clouds)
+        if n and all(isinstance(c, Cloud) for c in clouds):
+            thr = np.ascontiguousarray(np.broadcast_to(np.asarray(max_radius2, np.float32), (n,)))
+            hc = (C.c_void_p * n)(*[c.h for c in clouds])
+            hs = (C.c_void_p * n)()
+            _chk(ctx.L.lvf_map_create_batch_from_clouds(ctx.h, n, hc, thr.ctypes.data_as(_lib.c_float_p), hs))
+            out = []
+            for i in range(n):
+                m = cls.__new__(cls)
+                m.ctx, m.M, m.h = ctx, len(clouds[i]), C.c_void_p(hs[i])
+                out.append(m)
+            return out
         arrs = [_f(c) for c in clouds]
-        n = len(arrs)
         thr = np.ascontiguousarray(np.broadcast_to(np.asarray(max_radius2, np.float32), (n,)))
         if n == 0:
             return []

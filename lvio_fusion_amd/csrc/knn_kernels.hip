@@ -761,6 +761,24 @@ int lvf_map_create_from_cloud(const lvf_cloud* c, float max_radius2, lvf_map** o
   return map_create_impl(c->ctx, reinterpret_cast<const float*>(c->pts.p), true, c->n, 4, max_radius2, out);
 }
 
+// the indices of n device-resident clouds in one call (Mapping::BuildOldMapFrame's merged clouds of every loop-closure candidate, mapping.cpp:78-137,
+// when the per-keyframe clouds live in HBM as lvf_cloud): lvf_map_create_batch without the 6 MB of map points crossing PCIe
+int lvf_map_create_batch_from_clouds(lvf_ctx* ctx, int n, const lvf_cloud* const* clouds, const float* max_radius2, lvf_map** out) {
+  if (out && n > 0) for (int i = 0; i < n; ++i) out[i] = nullptr;
+  LVF_REQUIRE(ctx && out && (n == 0 || (clouds && max_radius2)) && n >= 0, "lvf_map_create_batch_from_clouds: bad arguments");
+  if (n == 0) return LVF_OK;
+  std::vector<const float*> src((size_t)n);
+  std::vector<int> M((size_t)n);
+  std::unique_ptr<bool[]> dev(new bool[(size_t)n]);
+  for (int i = 0; i < n; ++i) {
+    LVF_REQUIRE(clouds[i] && clouds[i]->ctx == ctx, "lvf_map_create_batch_from_clouds: cloud %d is null or of another context", i);
+    LVF_REQUIRE(max_radius2[i] > 0.0f && std::isfinite(max_radius2[i]), "lvf_map_create_batch_from_clouds: max_radius2[%d] must be finite > 0", i);
+    src[i] = reinterpret_cast<const float*>(clouds[i]->pts.p); M[i] = clouds[i]->n; dev[i] = true;
+  }
+  LVF_TRY(lvf::enter(ctx));
+  return map_create_many(ctx, n, src.data(), dev.get(), M.data(), 4, max_radius2, out);
+}
+
 int lvf_map_destroy(lvf_map* m) { delete m; return LVF_OK; }
 
 static int scan_create_impl(lvf_ctx* ctx, const float* scan_xyz, bool src_is_device, int Q, int stride_floats, lvf_scan** out) {

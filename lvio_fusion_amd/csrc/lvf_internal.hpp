@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -146,6 +147,11 @@ struct HostPin {
   const T& operator[](size_t i) const { return p[i]; }
 };
 
+// uploads up to this size go through pooled pinned staging (LVF_STAGE_MAX_KB: A/B)
+inline size_t stage_max_bytes() {
+  static const size_t v = [] { const char* e = std::getenv("LVF_STAGE_MAX_KB"); return e ? (size_t)std::atol(e) << 10 : (size_t)1 << 20; }();
+  return v;
+}
 template <typename T>
 struct DevBuf {  // owning device buffer
   T* p = nullptr;
@@ -204,7 +210,7 @@ struct DevBuf {  // owning device buffer
   int upload_staged(const T* host, size_t count, hipStream_t s, Stage& stage) {
     LVF_TRY(alloc(count));
     if (!count) return LVF_OK;
-    if (count * sizeof(T) > ((size_t)1 << 20)) {       // large: the copy through host memory costs more than the pinning (5.4 MB: +0.5 ms)
+    if (count * sizeof(T) > stage_max_bytes()) {       // large: the copy through host memory costs more than the pinning (5.4 MB: +0.5 ms)
       LVF_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
       return LVF_OK;
     }

@@ -93,14 +93,23 @@ def split_candidate(cand):
     return cand["split"]
 
 
-def evaluate_candidates_batched(api, ctx, cands, resolution=0.2):
+def resident_candidate(api, ctx, cand):
+    """the candidate's four clouds as device-resident api.Cloud objects — what a pipeline that keeps frame->feature_lidar in HBM
+    (lvf_lidar_extract's outputs, lvf_cloud_concat for BuildOldMapFrame) hands to the relocator; cached on the candidate"""
+    if "resident" not in cand:
+        cand["resident"] = tuple(api.Cloud(ctx, np.ascontiguousarray(a[:, :4] if a.shape[1] >= 4 else np.c_[a[:, :3], np.zeros(len(a))], np.float32)) for a in split_candidate(cand))
+    return cand["resident"]
+
+
+def evaluate_candidates_batched(api, ctx, cands, resolution=0.2, resident=False):
     """All of this rank's candidates in ONE launch chain (lvf_scan_match_batch): map indices and scans are created per candidate, the 4 x
-    {ground, surf} solves of every candidate run side by side and the records come back with one read.  Returns the result list."""
+    {ground, surf} solves of every candidate run side by side and the records come back with one read.  Returns the result list.
+    `resident`: the clouds are taken from the device (resident_candidate) instead of being uploaded."""
     opt = api.scan_match_options(resolution, outer_iterations=4, prior_weight=0.0)
     handles, jobs = [], []
     try:
         # every candidate's map indices in ONE call (lvf_map_create_batch: the host waits of an index build are shared between them)
-        parts = [split_candidate(cand) for cand in cands]
+        parts = [resident_candidate(api, ctx, cand) if resident else split_candidate(cand) for cand in cands]
         clouds, thrs, where = [], [], []
         for k, (mg, ms, qg, qs) in enumerate(parts):
             if len(mg):

@@ -262,3 +262,28 @@ def test_batched_candidates_with_missing_clouds(ctx, oracle):
         api.scan_match_batch(ctx, [jobs[3], dict(jobs[3])], opt)
     for h in hs:
         h.close()
+
+
+def test_batched_candidates_from_resident_clouds(ctx):
+    """lvf_map_create_batch_from_clouds + lvf_scan_create_from_cloud: candidates whose clouds already live in HBM (lvf_cloud) give the records
+    of the same candidates uploaded from host arrays — the indices are built from the same points, so every association is the same."""
+    from lvio_fusion_amd import api
+    cands = syn.config5_candidates(6, seed=99, n_query=4000, n_az=300)
+    up = rl.evaluate_candidates_batched(api, ctx, cands)
+    res = rl.evaluate_candidates_batched(api, ctx, cands, resident=True)
+    for a, b in zip(up, res):
+        assert a.score == b.score
+        assert np.allclose(np.array(a.relative_o_c[:]), np.array(b.relative_o_c[:]), rtol=1e-9, atol=1e-12)
+        assert (a.ground.num_residual_blocks, a.surf.num_residual_blocks) == (b.ground.num_residual_blocks, b.surf.num_residual_blocks)
+    # the entry point's argument checks: a cloud of another context, an empty batch
+    other = api.Context(0)
+    try:
+        foreign = api.Cloud(other, np.zeros((10, 4), np.float32))
+        with pytest.raises(api.LvfError):
+            api.Map.create_batch(ctx, [foreign], [1.0])
+        foreign.close()
+    finally:
+        other.close()
+    for c in cands:
+        for h in c.pop("resident"):
+            h.close()
