@@ -960,6 +960,39 @@ int lvf_cloud_radius_outlier_filter(const lvf_cloud* in, float radius, int min_n
   LVF_TRY(lvf::enter(ctx));
   if (in->n == 0) return new_cloud(ctx, 0, out);
   hipStream_t s = ctx->stream;
+  const int n = in->n;
+  if (n <= kScan1Max) {
+    // One launch chain and ONE wait (round 4: the bounding box came back first, to size the grid).  The grid arrays are sized by the cloud — 8
+    // cells per point, at least 64 k — and the last workgroup of the bounds pass fits the grid into them (cell = radius, enlarged by 1.5 until
+    // it fits: bigger cells stay correct, only slower; the kept points do not depend on the cell size).
+    const int grid_cells = (int)std::min<long long>(1ll << 22, std::max<long long>(1ll << 16, 8ll * n));
+    DevBuf<unsigned char> state; DevBuf<int> cell_of, counts2, start, flags; DevBuf<float4> sorted;
+    LVF_TRY(state.alloc(sizeof(DcState)));
+    LVF_TRY(cell_of.alloc(n)); LVF_TRY(counts2.alloc((size_t)2 * grid_cells)); LVF_TRY(start.alloc((size_t)grid_cells + 1)); LVF_TRY(flags.alloc(n)); LVF_TRY(sorted.alloc(n));
+    DcState* st = reinterpret_cast<DcState*>(state.p);
+    const int* n_dev = &st->cnt[2];
+    int* counts = counts2.p; int* cursor = counts2.p + grid_cells;
+    hipLaunchKernelGGL(k_dc_init, dim3(1), dim3(64), 0, s, st, (int*)nullptr, 0, n);
+    LVF_HIP(hipMemsetAsync(counts2.p, 0, (size_t)8 * grid_cells, s));
+    DcSetup su; su.mode = 1; su.slot = 1; su.which = 0; su.f0 = radius; su.i0 = grid_cells;
+    hipLaunchKernelGGL(k_dc_bounds, dim3(std::min(n > (1 << 18) ? kCapBlocks : kDcBoundsBlocks, gridc(n))), dim3(kC), 0, s, n, n_dev, in->pts.p, st, su);
+    hipLaunchKernelGGL(k_grid_count, dim3(gridc(n)), dim3(kC), 0, s, n, n_dev, in->pts.p, GridC{}, &st->grid, cell_of.p, counts);
+    LVF_HIP(hipGetLastError());
+    LVF_TRY(device_scan1(ctx, counts, grid_cells, &st->grid_ncell, start.p, nullptr, nullptr, nullptr));
+    hipLaunchKernelGGL(k_grid_scatter, dim3(gridc(n)), dim3(kC), 0, s, n, n_dev, in->pts.p, cell_of.p, start.p, cursor, sorted.p);
+    hipLaunchKernelGGL(k_radius_count, dim3(gridc(n)), dim3(kC), 0, s, n, n_dev, in->pts.p, GridC{}, &st->grid, start.p, sorted.p, radius * radius, min_neighbors, flags.p);
+    LVF_HIP(hipGetLastError());
+    lvf_cloud* c = nullptr;
+    LVF_TRY(new_cloud(ctx, n, &c));
+    int h[5] = {0, 0, 0, 0, 0};                       // cnt[4], err
+    int rc = device_scan1(ctx, flags.p, n, nullptr, nullptr, &st->cnt[3], in->pts.p, c->pts.p);
+    if (rc == LVF_OK) rc = read_back(ctx, h, state.p + offsetof(DcState, cnt), sizeof(h));
+    if (rc != LVF_OK) { delete c; return rc; }
+    if (h[4] & kDcErrBounds) { delete c; set_error("cloud has non-finite coordinates"); return LVF_ERR_INVALID; }
+    c->n = h[3]; c->pts.n = (size_t)h[3];
+    *out = c;
+    return LVF_OK;
+  }
   float lo[3], hi[3];
   LVF_TRY(cloud_bounds(in, lo, hi));
   float cell = radius * 1.0001f;               // strictly larger than the radius: the 27-cell stencil is exhaustive

@@ -171,3 +171,28 @@ def test_stable_pair_sort(ctx, n, key_bits):
     order = np.argsort(keys & mask, kind="stable")
     assert np.array_equal(vo, vals[order])
     assert np.array_equal(ko, keys[order])
+
+
+def test_radius_filter_on_millions_of_points(ctx):
+    """The one-launch scan / compaction (device_scan1) with thousands of tiles: a 3 M-point cloud = a dense lattice (every point has its 6 axis
+    neighbours within the radius: kept) with isolated points sprinkled through the input (removed).  The output must be the lattice points in
+    input order, bit for bit."""
+    from lvio_fusion_amd import api
+    rng = np.random.default_rng(5)
+    side = 143                                              # 143^3 = 2 924 207 lattice points, spacing 0.1
+    g = (np.arange(side, dtype=np.float32) * np.float32(0.1))
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    n_out = 20000
+    iso = np.stack([np.float32(100.0) + np.float32(3.0) * np.arange(n_out, dtype=np.float32), rng.uniform(-1, 1, n_out).astype(np.float32) * 0 + np.float32(50.0),
+                    np.zeros(n_out, np.float32)], -1)    # a line of points 3 m apart, far from the lattice
+    pts = np.zeros((len(lat) + n_out, 4), np.float32)
+    where = np.sort(rng.choice(len(pts), n_out, replace=False))
+    mask = np.zeros(len(pts), bool); mask[where] = True
+    pts[mask, :3] = iso; pts[~mask, :3] = lat
+    pts[:, 3] = np.arange(len(pts), dtype=np.float32) % 251
+    cl = api.Cloud(ctx, pts)
+    out = cl.radius_outlier_filter(0.15, 4)
+    got = out.download()
+    assert got.shape == (len(lat), 4)
+    assert np.array_equal(got.view(np.uint32), pts[~mask].view(np.uint32))
+    out.close(); cl.close()
