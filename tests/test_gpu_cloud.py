@@ -182,9 +182,9 @@ def test_radius_filter_on_millions_of_points(ctx):
     side = 143                                              # 143^3 = 2 924 207 lattice points, spacing 0.1
     g = (np.arange(side, dtype=np.float32) * np.float32(0.1))
     lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
-    n_out = 20000
-    iso = np.stack([np.float32(100.0) + np.float32(3.0) * np.arange(n_out, dtype=np.float32), rng.uniform(-1, 1, n_out).astype(np.float32) * 0 + np.float32(50.0),
-                    np.zeros(n_out, np.float32)], -1)    # a line of points 3 m apart, far from the lattice
+    n_out = 2000                                            # a 50 x 40 sheet of points 1 m apart, 20 m above the lattice
+    iy, ix = np.divmod(np.arange(n_out), 50)
+    iso = np.stack([ix.astype(np.float32), iy.astype(np.float32), np.full(n_out, 20.0, np.float32)], -1)
     pts = np.zeros((len(lat) + n_out, 4), np.float32)
     where = np.sort(rng.choice(len(pts), n_out, replace=False))
     mask = np.zeros(len(pts), bool); mask[where] = True
