@@ -130,3 +130,25 @@ def test_extract_feeds_scan_matching(ctx):
     assert res.ground.num_residual_blocks > 100 and res.surf.num_residual_blocks > 100
     err0 = np.abs(moved[4:]).max(); err1 = np.abs(np.array(res.pose[:])[4:]).max()
     assert err1 < 0.5 * err0                                         # matching a scan against itself pulls the pose back to identity
+
+
+def test_parameters_outside_the_device_counted_path(ctx):
+    """The device-counted path sizes the voxel keys and the radius grid from max_range / resolution BEFORE it sees a point; parameters beyond
+    what it can size (here: 2^26 voxels) go through the host-counted path without the caller noticing — and parameters inside it, but
+    unusual (a wide range gate, a coarse resolution), still give the host-counted path's clouds bit for bit."""
+    from lvio_fusion_amd import api
+    ext = syn.lidar_extrinsic()
+    scan = syn.raw_scan(seed=21)[::3]
+    for kw in (dict(max_range=400.0, resolution=0.05), dict(max_range=60.0, min_range=1.0), dict(resolution=0.5), dict(ground_rows=40, num_scans=64)):
+        prm = api.lidar_params(**kw)
+        out = {}
+        for host in (False, True):
+            was = api.extract_host_counts(ctx, host)
+            try:
+                g, s = api.lidar_extract(ctx, scan, ext, params=prm)
+                out[host] = (g.download(), s.download())
+                g.close(); s.close()
+            finally:
+                api.extract_host_counts(ctx, was)
+        for k in (0, 1):
+            assert out[False][k].shape == out[True][k].shape and np.array_equal(out[False][k].view(np.uint32), out[True][k].view(np.uint32)), (kw, k)
