@@ -541,11 +541,32 @@ int launch_lidar_normals(lvf_batch* b, const double* d_pb, const double* d_pc);
 int launch_lidar_plane(lvf_batch* b, const double* rpyxyz_host, bool want_j);
 int launch_imu_sqrt_info(lvf_batch* b);
 int launch_imu_sqrt_info_cached(lvf_batch* b, const int* src_dev, const double* prev_dev);   // src[f] >= 0: copy prev[src[f]] instead of factoring
+// A pointer MEMBER of a kernel-argument struct.  The solver's kernels take their arguments by value for one window and read them from a device
+// table (one entry per window, blockIdx = window) for a batch.  A plain `double*` loaded from such a table is a GENERIC pointer to the
+// compiler — it cannot know the table only ever holds global-memory addresses — so every access through it becomes a FLAT instruction:
+// counted by vmcnt AND lgkmcnt (a wait for an LDS result also waits for every load in flight, and the reverse), no scalar-base addressing
+// (64-bit VALU address arithmetic per access).  All batched kernels were flat-only while their single-window twins used global_*
+// (ISA, round 5).  GP<T> stores the address as a global-address-space pointer on the device side (same 8 bytes, same bits), converts to
+// T* where it is used, and address-space inference does the rest.  On the host it is a plain pointer.
+template <typename T>
+struct GP {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(1))) T* ptr_t;
+#else
+  typedef T* ptr_t;
+#endif
+  ptr_t p;
+  GP() = default;
+  __host__ __device__ GP(T* q) : p((ptr_t)q) {}
+  __host__ __device__ operator T*() const { return (T*)p; }
+  __host__ __device__ T* operator->() const { return (T*)p; }
+};
+static_assert(sizeof(GP<double>) == sizeof(double*), "GP<T> is a pointer");
 // arrays to clear before a linearisation (one launch, or extra workgroups of another launch)
 constexpr int kZeroListMax = 8;
 // tri[k] > 0: entry k is a square matrix of that leading dimension of which only the LOWER triangle (widened to the 64-column block of
 // the diagonal) is ever written, so only that is cleared (B and S: half of the 9.4 MB per window and iteration)
-struct ZeroList { double* p[kZeroListMax]; unsigned long long n[kZeroListMax]; int tri[kZeroListMax]; int count; };
+struct ZeroList { GP<double> p[kZeroListMax]; unsigned long long n[kZeroListMax]; int tri[kZeroListMax]; int count; };
 // cost_stripes (optional): 32 striped accumulators that receive 1/2 |r|^2 of every factor
 // zero (optional): arrays cleared by extra workgroups of the same launch
 int launch_imu(lvf_batch* b, const lvf_state* st, bool want_j, double* cost_stripes = nullptr, const ZeroList* zero = nullptr);

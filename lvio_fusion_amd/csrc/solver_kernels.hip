@@ -40,9 +40,9 @@ struct SpLevels { int n; int first[kSpMaxLevels]; int count[kSpMaxLevels]; };
 // diagonal is clamped on the SCALED system, which in unscaled terms is D_jj = clamp(s_j^2 H_jj, 1e-6, 1e32) / s_j^2 (lm_damping).  h0 holds
 // H0 in the natural order [15 n_kf camera unknowns | n_lm inverse depths]; while *frozen == 0 (the first pass of a solve) the kernels that
 // form the damping store H_jj there, afterwards they read it (k_lm_decide raises the flag).
-struct JacobiDev { double* h0; const int* frozen; };
+struct JacobiDev { GP<double> h0; GP<const int> frozen; };
 struct SpSrc {
-  const double* B; int ldB, dp; const double* gc; const double* radius; const int* rows_nat;
+  GP<const double> B; int ldB, dp; GP<const double> gc; GP<const double> radius; GP<const int> rows_nat;
   // levels CHAINED inside one launch (the Schur complement's: it lasts long enough for three of them): the level waits until `wait_target`
   // workgroups of the level below have arrived at *wait_counter, and arrives at *done_counter itself.  What it reads of the level
   // below are RETURNING atomic adds into S (agent scope), read back with agent-scope atomic loads; the arrival is a RELEASE add, the
@@ -51,16 +51,16 @@ struct SpSrc {
   // first — nothing DEPENDS on that: a consumer that does not see its producers within `timeout_ticks` raises the hand-over flag
   // (SC_FAIL >= kFailHandover), the decision ends the loop WITHOUT taking or counting the step (LVF_WHY_HANDOVER) and the host re-runs
   // the iteration with every level in a launch of its own (lvf_problem::no_chain) — a scheduling delay never becomes a numerical outcome.
-  int* wait_counter; int wait_target; int* done_counter;
+  GP<int> wait_counter; int wait_target; GP<int> done_counter;
   int fenced; unsigned timeout_ticks;      // wall_clock64() ticks (100 MHz) before the hand-over is given up
   int strip_end;           // S rows / columns below it belong to sparse blocks (lvf_problem::off)
   int rmw_read;            // diagnostic: chained reads by returning atomics instead of agent-scope loads
-  unsigned long long* dbg; // LVF_SP_TIMING=1: eight wall_clock64() stamps per workgroup (tile 0 of every node), else null
+  GP<unsigned long long> dbg; // LVF_SP_TIMING=1: eight wall_clock64() stamps per workgroup (tile 0 of every node), else null
   int s_zero;              // the level has nothing below it (level 0, early form): its part of S is still all zeros, not read
   JacobiDev jac{nullptr, nullptr};
 };
 struct SpArgs {          // one sparse level
-  const SpNode* nodes; int first, tiles; const int* rows; double* S; int ld; double* W; int wstride; double* Lout; int* fail; int nblocks; const int* done;
+  GP<const SpNode> nodes; int first, tiles; GP<const int> rows; GP<double> S; int ld; GP<double> W; int wstride; GP<double> Lout; GP<int> fail; int nblocks; GP<const int> done;
   SpSrc src;
 };
 __device__ __forceinline__ void sp_ride(const int vb, const SpArgs& a);     // workgroup vb of the level (defined with k_sp_eliminate)
@@ -169,7 +169,7 @@ __device__ __forceinline__ void block_add(double v, double* dst) {
   if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst + ((blockIdx.x + blockIdx.y) & (kStripes - 1)), v);
 }
 
-struct StateP { const double *poses, *vel, *ba, *bg, *inv_depth, *w_kf; };
+struct StateP { GP<const double> poses, vel, ba, bg, inv_depth, w_kf; };
 
 // Device-resident control block of one window's Levenberg-Marquardt loop.  Everything that changes from one iteration to the next
 // lives here (trust-region radius, costs, accept / reject, termination), so the arguments of every kernel of an iteration are
@@ -354,7 +354,7 @@ struct TfWork { int first, count, k2; };
 //     contiguous range, sums them and completes the row (k1 columns, g_rho column) and Cd;
 //   * every workgroup writes its LDS table of keyframe-indexed sums to its own slab (slabP[wg][k1][64], slabQ[wg][32]); k_tf_reduce adds
 //     the slabs of a run into B / gc, each entry of B having exactly one owner there.
-struct TfCompact { int on; const int* slot; double *slotB, *slabP, *slabQ; int staged; };
+struct TfCompact { int on; GP<const int> slot; GP<double> slotB, slabP, slabQ; int staged; };
 constexpr int kSlabRow = 64, kSlabQ = 32;
 constexpr int kAccSlots = 63;   // 21 (B[k1,k1] lower) + 6 (g[k1]) + 36 (cross block, rows = k2 tangent, cols = k1 tangent)
 constexpr int kStageWave = 64 * 9 + 32;   // doubles of LDS staging per wave (segmented first-keyframe sums): 64 x (8 + 1 pad) values + 64 ints
@@ -637,13 +637,13 @@ __device__ __forceinline__ void lin_tf_sorted_body(const int vb, const TfWork* _
 // TwoCamera, a TwoFrame and a PoseOnly segment): as three back-to-back launches of 4-9 us they were mostly launch boundaries.
 struct CostVisual {
   int n_tc, n_tf, n_po, g_tc, g_tf;
-  const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; const double* tc_w; CamD tc_left, tc_right;
-  const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1, *tf_k2; CamD tf_left, tf_right;
-  const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
+  GP<const double2> tc_lo, tc_ro; GP<const int> tc_lm, tc_kf; GP<const double> tc_w; CamD tc_left, tc_right;
+  GP<const double2> tf_fo, tf_ob; GP<const int> tf_lm, tf_k1, tf_k2; CamD tf_left, tf_right;
+  GP<const double2> po_ob; GP<const int> po_kf, po_pwi; GP<const double> po_pw; CamD po_cam;
 };
-struct ImuEvalArgs { int n; const double *pre, *sqrt_info; const int *kf_i, *kf_j; };      // ImuError factors evaluated inside a merged launch
+struct ImuEvalArgs { int n; GP<const double> pre, sqrt_info; GP<const int> kf_i, kf_j; };      // ImuError factors evaluated inside a merged launch
 struct CostArgs {
-  CostVisual a; int n_kf; StateP s; double huber; double* cost; int nblocks; const int* done;
+  CostVisual a; int n_kf; StateP s; double huber; GP<double> cost; int nblocks; GP<const int> done;
   ImuEvalArgs imu; int g_imu;       // workgroups [0, g_imu) evaluate one ImuError factor each, the visual passes follow
   int tiles;                        // tiles of kT blocks per visual workgroup (0 = 1)
   ZeroList zero; int zero_wgs;      // workgroups [nblocks, nblocks + zero_wgs) of the merged cost + decision launch clear the accumulators for the NEXT linearisation
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(kT) void k_lin_po(int n, int n_kf, const double2* _
 
 // ------------------------------------------------------------------------------------------------ IMU
 // consumes the materialised ImuError outputs (res[n][15], eight Jacobian blocks) of launch_imu; one wave per factor
-struct ImuJ { const double* j[8]; };
+struct ImuJ { GP<const double> j[8]; };
 __global__ __launch_bounds__(64) void k_lin_imu(int n, int n_kf, const double* __restrict__ res, ImuJ J, const int* __restrict__ kf_i,
                                                 const int* __restrict__ kf_j, const double* __restrict__ poses,
                                                 const uint8_t* __restrict__ pose_const, double* __restrict__ B, int ld,
@@ -1040,18 +1040,18 @@ __device__ __forceinline__ void lin_imu_eval_body(const int f, const ImuEvalArgs
 struct LinVisual {
   int n_tfw, g_tc;
   // TwoFrame
-  const TfWork* work; const double2 *tf_fo, *tf_ob; const int *tf_lm, *tf_k1; CamD tf_left, tf_right; int unique_lk2; TfCompact cp;
+  GP<const TfWork> work; GP<const double2> tf_fo, tf_ob; GP<const int> tf_lm, tf_k1; CamD tf_left, tf_right; int unique_lk2; TfCompact cp;
   // TwoCamera
-  int n_tc; const double2 *tc_lo, *tc_ro; const int *tc_lm, *tc_kf; const double* tc_w; CamD tc_left, tc_right;
+  int n_tc; GP<const double2> tc_lo, tc_ro; GP<const int> tc_lm, tc_kf; GP<const double> tc_w; CamD tc_left, tc_right;
   // PoseOnly
-  int n_po, g_po; const double2* po_ob; const int *po_kf, *po_pwi; const double* po_pw; CamD po_cam;
+  int n_po, g_po; GP<const double2> po_ob; GP<const int> po_kf, po_pwi; GP<const double> po_pw; CamD po_cam;
   // ImuError: evaluated inside the launch (imu.pre != nullptr) or ahead of it by k_imu<true> (imu_res / imu_J)
-  int n_imu; const double* imu_res; ImuJ imu_J; const int *imu_i, *imu_j; ImuEvalArgs imu;
+  int n_imu; GP<const double> imu_res; ImuJ imu_J; GP<const int> imu_i, imu_j; ImuEvalArgs imu;
 };
 struct LinArgs {
-  LinVisual v; int n_kf; StateP s; double huber; const uint8_t* pose_const; double* B; int ld; double* gc; double* E; int ldE; double *C, *gr, *cost;
-  int nblocks; const int* done; unsigned long long* dbg; int rows;
-  double* scal_reset;      // early sparse levels: the per-step scalars and the fail flag are reset HERE (the levels start before k_prepare, which resets them otherwise)
+  LinVisual v; int n_kf; StateP s; double huber; GP<const uint8_t> pose_const; GP<double> B; int ld; GP<double> gc; GP<double> E; int ldE; GP<double> C, gr, cost;
+  int nblocks; GP<const int> done; GP<unsigned long long> dbg; int rows;
+  GP<double> scal_reset;      // early sparse levels: the per-step scalars and the fail flag are reset HERE (the levels start before k_prepare, which resets them otherwise)
 };
 __device__ __forceinline__ void reset_step_scalars(double* scal) {
   for (int k = SC_COST_NEW + threadIdx.x; k < SC_N; k += kT) scal[k] = 0.0;
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void k_
 //                                                                      + sum of slabP[.][k][0..27) over every later workgroup (k as first keyframe)
 //   the rest                     one thread per (k2, k1 < k2, entry of the 6x6 cross block) = sum of slabP[.][k1][27..63) over run(k2)
 struct TfReduceArgs {
-  int n_kf, n_wg; const int* run_first; const double *slabP, *slabQ; double* B; int ld; double* gc; int nblocks; const int* done;
+  int n_kf, n_wg; GP<const int> run_first; GP<const double> slabP, slabQ; GP<double> B; int ld; GP<double> gc; int nblocks; GP<const int> done;
   int own_blocks; SpArgs ride;       // workgroups [own_blocks, nblocks): a sparse level riding in this launch (early form)
 };
 __device__ __forceinline__ void tf_reduce_body(const int bx0, const TfReduceArgs& A) {
@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(64) void k_lin_prior(int n, const double* __restric
 }
 // The same with the evaluation inside (prior_eval.hpp): the block's residuals and ambient Jacobians never leave the thread — one launch
 // instead of k_pose_prior + k_lin_prior on the LM loop's path (a window with weak frames pays it every iteration), nothing materialised.
-struct PriorArgs { int n; const int *kf_a, *kf_b; const double *target, *weight, *vv; };
+struct PriorArgs { int n; GP<const int> kf_a, kf_b; GP<const double> target, weight, vv; };
 __global__ __launch_bounds__(64) void k_prior_lin(PriorArgs P, const double* __restrict__ poses, const uint8_t* __restrict__ pose_const,
                                                   double* __restrict__ B, int ld, double* __restrict__ gc, double* __restrict__ cost) {
   const int i = blockIdx.x * 64 + threadIdx.x;
@@ -1273,10 +1273,10 @@ __device__ __forceinline__ double lm_damping_own(double h, const JacobiDev& j, i
 //                                produce E^T Cd^-1 g_rho)
 //   block 0 / thread 0         : resets the per-step scalars (candidate cost, model change, norms) and the Cholesky fail flag
 struct PrepArgs {
-  int ld, dpad, jl0 /* = d: the first landmark slot of jac.h0 */; const int* iperm; const double *B, *gc; const double* radius; double* S; unsigned nS_blocks; int n_lm, dp, ldE; const double *C, *gr;
-  double *Cd, *E, *scal; int nblocks; const int* done;
+  int ld, dpad, jl0 /* = d: the first landmark slot of jac.h0 */; GP<const int> iperm; GP<const double> B, gc; GP<const double> radius; GP<double> S; unsigned nS_blocks; int n_lm, dp, ldE; GP<const double> C, gr;
+  GP<double> Cd, E, scal; int nblocks; GP<const int> done;
   // atomic-free mode (slotB != nullptr): per-landmark totals from the slot records
-  const int *eoff, *kmin, *kmax; const double* slotB; double *Ct, *grt;
+  GP<const int> eoff, kmin, kmax; GP<const double> slotB; GP<double> Ct, grt;
   // early form (early != 0): S was cleared with the accumulators and sparse levels may already have added into the dense corner, so the
   // corner's entries (rows / columns >= off) are ADDED, and the columns of the sparse blocks are left alone (the levels form them themselves)
   int early, off;
@@ -1363,7 +1363,7 @@ __device__ __forceinline__ void prepare_body(const unsigned bx0, const PrepArgs&
 }
 __global__ __launch_bounds__(kT) void k_prepare(PrepArgs a) { prepare_body(blockIdx.x, a); }
 __global__ __launch_bounds__(kT) void k_prepare_b(const PrepArgs* __restrict__ t) { prepare_body(blockIdx.x, t[blockIdx.y]); }
-__global__ __launch_bounds__(kT) void k_prepare_bt(const PrepArgs* __restrict__ t) { prepare_body(blockIdx.y, t[blockIdx.x]); }
+__global__ __launch_bounds__(kT) void k_prepare_bt(const PrepArgs* __restrict__ t) { const PrepArgs a = t[blockIdx.x]; prepare_body(blockIdx.y, a); }
 
 // ------------------------------------------------------------------------------------------------ Schur reduce (MFMA f64)
 // T = Ea^T diag(1/Cd) Ea with Ea = [E | g_rho] (n_lm x ldE).  One wave per (16x16 output tile, K-chunk); tiles on or
@@ -1754,7 +1754,7 @@ __global__ __launch_bounds__(256) void k_schur_band(int dp, int ldE, const doubl
                                                     double* __restrict__ S) {
   schur_band_body(blockIdx.x, blockIdx.y, dp, ldE, E, Cd, order, n_active_p, kmin, kmax, d, ldS, S);
 }
-struct LmBand { const int* order; const int* n_active; const int* kmin; const int* kmax; };   // null order => dense SYRK
+struct LmBand { GP<const int> order; GP<const int> n_active; GP<const int> kmin; GP<const int> kmax; };   // null order => dense SYRK
 static int launch_schur(hipStream_t q, int n_lm, int dp, int ldE, const double* E, const double* Cd, int d, int ldS, double* S, const LmBand& band) {
   const int nt = ldE / 16, ntile = nt * (nt + 1) / 2;
   if (band.order) {
@@ -1939,7 +1939,7 @@ __device__ __forceinline__ void factor_panel_wave(double b[16], const int r, con
 //       L_kk^-T for the back substitution.
 //   workgroups behind them     — the rest of step kb-1's trailing update, A[bi][bj] -= P_bi P_bj^T for kb < bj <= bi, which nothing in
 //       this launch reads (the next step does).
-struct CholArgs { double* Sd; int ld, nb; int* fail; double* Dinv; const int* done; unsigned long long* dbg; int last_cols; double* Ldiag; };   // dbg: LVF_CHOL_TIMING stamps; last_cols: real (un-padded) columns of the last block
+struct CholArgs { GP<double> Sd; int ld, nb; GP<int> fail; GP<double> Dinv; GP<const int> done; GP<unsigned long long> dbg; int last_cols; GP<double> Ldiag; };   // dbg: LVF_CHOL_TIMING stamps; last_cols: real (un-padded) columns of the last block
 __host__ __device__ inline int chol_step_grid(int nb, int kb) {
   const int below = nb - kb - 1;
   return kb >= nb ? 0 : 2 + below + (kb > 0 ? below * (below + 1) / 2 : 0);
@@ -2192,7 +2192,7 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
     // a dispatch order this code does not expect) the hand-over flag is raised instead of hanging; the step is then NOT judged: see SpSrc
     if (tid == 0) {
       const unsigned long long t0 = wall_clock64();
-      while (__hip_atomic_fetch_add(src.wait_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < src.wait_target) {
+      while (__hip_atomic_fetch_add((int*)src.wait_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < src.wait_target) {
         __builtin_amdgcn_s_sleep(4);
         if (wall_clock64() - t0 > (unsigned long long)src.timeout_ticks) { atomicMax(fail, kFailHandover + nd.id); break; }
       }
@@ -2339,8 +2339,8 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
   if (src.done_counter) {
     __syncthreads();                       // every wave has its returns (the barrier drains vmcnt)
     if (tid == 0) {
-      if (src.fenced) __hip_atomic_fetch_add(src.done_counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      else __hip_atomic_fetch_add(src.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (src.fenced) __hip_atomic_fetch_add((int*)src.done_counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_fetch_add((int*)src.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (stamp) stamp[6] = wall_clock64();
@@ -2384,11 +2384,11 @@ __global__ __launch_bounds__(256) void k_sp_eliminate_b(const SpArgs* __restrict
 // does not read — the Schur complement touches the pose corner and the pose part of the rhs row, level 0 reads its own (v,ba,bg)
 // columns — so they are independent; later levels depend on level 0 and stay launches of their own.
 struct SchurSp0Args {
-  int n_slices, n_groups, dp, ldE; const double *E, *Cd; const int *order, *n_active, *kmin, *kmax; int d_local, ldS; double* S_pose;
+  int n_slices, n_groups, dp, ldE; GP<const double> E, Cd; GP<const int> order, n_active, kmin, kmax; int d_local, ldS; GP<double> S_pose;
   SpArgs sp;             // the sparse level riding in the launch (sp.nblocks == 0: Schur complement only): level 0, or — early form — the first one left
   SpArgs sp_b, sp_c;     // early form: the next two levels, chained behind it inside the launch (SpSrc::wait_counter)
-  int nblocks; const int* done; unsigned long long* dbg; int rows;
-  const int4* work; int n_work;      // (slice, group, band lo | hi << 16, slice end) items; the sparse levels run in the first workgroups, the items behind
+  int nblocks; GP<const int> done; GP<unsigned long long> dbg; int rows;
+  GP<const int4> work; int n_work;      // (slice, group, band lo | hi << 16, slice end) items; the sparse levels run in the first workgroups, the items behind
 };
 __device__ __forceinline__ void schur_sp0_body(const int b, const SchurSp0Args& A) {
   if (b >= A.nblocks) return;
@@ -2417,10 +2417,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 struct SpBack {                    // what the back substitution needs of the plan
   SpLevels lv;
   int item0[kSpMaxLevels], items[kSpMaxLevels];   // the level's slice of rows/owner/W
-  const SpNode* nodes; const int* rows; const int* owner; const double* W; const double* Linv; const int* perm;
+  GP<const SpNode> nodes; GP<const int> rows; GP<const int> owner; GP<const double> W; GP<const double> Linv; GP<const int> perm;
   int off, aug, d_total, total_items, n_nodes, max_count, linv_in_lds;
   int prod_items;                  // > 0: LDS room for that many (row x 9) products => conflict-free two-stage sums; 0: LDS atomics
-  unsigned long long* dbg;         // LVF_BACK_TIMING=1: wall_clock64() stamps (100 MHz) at the phase boundaries, else null
+  GP<unsigned long long> dbg;         // LVF_BACK_TIMING=1: wall_clock64() stamps (100 MHz) at the phase boundaries, else null
 };
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the global prefetches
@@ -2446,7 +2446,7 @@ __device__ __forceinline__ T ld_off32(const T* base, unsigned byte_off) {     //
 constexpr int kBT = 512, kBParts = kBT / 64, kBackPre = 256 / kBParts, kBackInv = 64 / kBParts, kTailPre = 6;
 // pose_ready (merged back-substitution + step tail, k_backsolve_tail): once the dense corner is solved the POSE part of the step (natural
 // unknowns [0, n_pose)) is written out and *pose_ready is raised (release, agent scope) — what the landmark back-substitution waits for
-struct BackArgs { const double* Sd; int ld, d; const double* Dinv; double* xout; SpBack sp; const int* done; const double* Ldiag; int* pose_ready = nullptr; int n_pose = 0; int pose_fenced = 0; };
+struct BackArgs { GP<const double> Sd; int ld, d; GP<const double> Dinv; GP<double> xout; SpBack sp; GP<const int> done; GP<const double> Ldiag; GP<int> pose_ready = nullptr; int n_pose = 0; int pose_fenced = 0; };
 __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
   const int dv = done_flag_issue(A.done);
   const double* S = A.Sd; const int ld = A.ld, d = A.d; const double* Dinv = A.Dinv; double* xout = A.xout; const SpBack& sp = A.sp;
@@ -2498,7 +2498,7 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
   double lpre[kLinvPre];
   const int n_linv = sp.linv_in_lds ? 81 * sp.n_nodes : 0;
 #pragma unroll
-  for (int u = 0; u < kLinvPre; ++u) { const int i = tid + kBT * u; lpre[u] = i < n_linv ? ld_off32(sp.Linv, 8u * (unsigned)i) : 0.0; }
+  for (int u = 0; u < kLinvPre; ++u) { const int i = tid + kBT * u; lpre[u] = i < n_linv ? ld_off32((const double*)sp.Linv, 8u * (unsigned)i) : 0.0; }
   SpNode ndpre = SpNode{0, 0, 0, 0};
   if (tid < sp.n_nodes) ndpre = sp.nodes[tid];
 #pragma unroll
@@ -2519,10 +2519,10 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) tW[u][q] = 0.0;
     if (ok) {
-      tR[u] = ld_off32(sp.rows, 4u * (unsigned)g);
-      tK[u] = ld_off32(sp.owner, 4u * (unsigned)g);
+      tR[u] = ld_off32((const int*)sp.rows, 4u * (unsigned)g);
+      tK[u] = ld_off32((const int*)sp.owner, 4u * (unsigned)g);
 #pragma unroll
-      for (int q = 0; q < 9; ++q) tW[u][q] = ld_off32(sp.W, 8u * ((unsigned)q * (unsigned)sp.total_items + (unsigned)g));
+      for (int q = 0; q < 9; ++q) tW[u][q] = ld_off32((const double*)sp.W, 8u * ((unsigned)q * (unsigned)sp.total_items + (unsigned)g));
     }
   }
   if (dv) return;                          // (every request above is in flight behind the flag's)
@@ -2583,7 +2583,7 @@ __device__ __forceinline__ void chol_backsolve_body(const BackArgs& A) {
     }
     if (A.pose_fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave's stores have been performed before the flag goes up
-    if (tid == 0) __hip_atomic_store(A.pose_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store((int*)A.pose_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- sparse levels, last eliminated first
   for (int lv = sp.lv.n - 1; lv >= 0; --lv) {
@@ -2766,9 +2766,9 @@ __device__ __forceinline__ void apply_step_body(const int vb, int n_kf, int n_lm
 // landmark back-substitution and the camera-side step / model terms as ONE launch: workgroups [0, g_lm) walk the landmarks,
 // the rest apply dx to the keyframe states (independent of the landmark results)
 struct TailArgs {
-  int g_lm, n_lm, dp, ldE; const double *E, *C, *Cd, *gr, *dxc; double *dxl, *scal; const int *kmin, *kmax; int n_kf; StateP s;
-  double *poses2, *vel2, *ba2, *bg2, *invd2; int d, ld; const double *B, *gc; const double* radius; int nblocks; const int* done;
-  const unsigned char* pose_const; JacobiDev jac;
+  int g_lm, n_lm, dp, ldE; GP<const double> E, C, Cd, gr, dxc; GP<double> dxl, scal; GP<const int> kmin, kmax; int n_kf; StateP s;
+  GP<double> poses2, vel2, ba2, bg2, invd2; int d, ld; GP<const double> B, gc; GP<const double> radius; int nblocks; GP<const int> done;
+  GP<const unsigned char> pose_const; JacobiDev jac;
 };
 __device__ __forceinline__ void step_tail_body(const int bx, const TailArgs& A) {
   if (bx >= A.nblocks || (A.done && *A.done)) return;
@@ -2787,7 +2787,7 @@ __global__ __launch_bounds__(kT) void k_step_tail_bt(const TailArgs* __restrict_
 // (apply_step_body) — and workgroups 1.. are the landmark pass: they wait for the pose increments inside the launch (bounded, like the
 // chained sparse levels: on a time-out the hand-over flag is raised, the pass is not judged and the host re-runs it with the two launches
 // of old; SpSrc has the rules) and then walk the landmarks.  One launch boundary less and the two tails overlap: 39 -> 29 us at configs[3].
-struct BackTailArgs { BackArgs back; TailArgs tail; int g_lm; int fenced; unsigned timeout_ticks; int* fail; };
+struct BackTailArgs { BackArgs back; TailArgs tail; int g_lm; int fenced; unsigned timeout_ticks; GP<int> fail; };
 __global__ __launch_bounds__(kBT) void k_backsolve_tail(BackTailArgs a) {
   if (a.back.done && *a.back.done) return;                      // (every workgroup tests the same flag: nobody waits for a producer that has left)
   const TailArgs& T = a.tail;
@@ -2808,7 +2808,7 @@ __global__ __launch_bounds__(kBT) void k_backsolve_tail(BackTailArgs a) {
   if (ldbg) ldbg[0] = wall_clock64();
   if (threadIdx.x == 0) {
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(a.back.pose_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    while (__hip_atomic_load((int*)a.back.pose_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       __builtin_amdgcn_s_sleep(16);
       if (wall_clock64() - t0 > (unsigned long long)a.timeout_ticks) { atomicMax(a.fail, kFailHandover + 90000); break; }
     }
@@ -2837,12 +2837,12 @@ __global__ __launch_bounds__(kBT) void k_backsolve_tail(BackTailArgs a) {
 // TrustRegionMinimizer does on the host between evaluations (declared semantics: oracle/lm.h).  The scalars arrive as 32-way striped
 // sums (block_add); `rec` (optional, host-mapped) receives a copy of the control block so a waiting host sees progress without a copy.
 struct DecideArgs {
-  const double* scal; LmCtl* ctl; LmCtl* rec; int* ticket;
+  GP<const double> scal; GP<LmCtl> ctl; GP<LmCtl> rec; GP<int> ticket;
   int n_kf, n_lm;
-  double *poses, *vel, *ba, *bg, *invd;                 // the state
-  const double *poses2, *vel2, *ba2, *bg2, *invd2;      // the candidate
-  unsigned long long* dbg;                              // LVF_COST_TIMING=1: wall_clock64() stamps (100 MHz), else null
-  double* hist;                                         // LVF_LM_HISTORY=1: eight doubles per closed pass (64 passes), else null
+  GP<double> poses, vel, ba, bg, invd;                 // the state
+  GP<const double> poses2, vel2, ba2, bg2, invd2;      // the candidate
+  GP<unsigned long long> dbg;                              // LVF_COST_TIMING=1: wall_clock64() stamps (100 MHz), else null
+  GP<double> hist;                                         // LVF_LM_HISTORY=1: eight doubles per closed pass (64 passes), else null
 };
 constexpr int kDT = 256;
 // COHERENT: the sums are read past the caches (the caller is the last workgroup of the launch that produced part of them)
@@ -2866,7 +2866,7 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
   __syncthreads();
   if (s_skip) return;
   if (A.dbg && threadIdx.x == 0) A.dbg[2] = wall_clock64();
-  if (threadIdx.x < kStripes) const_cast<double*>(A.scal)[SC_COST + threadIdx.x] = 0.0;      // read above; the next linearisation adds into it
+  if (threadIdx.x < kStripes) const_cast<double*>((const double*)A.scal)[SC_COST + threadIdx.x] = 0.0;      // read above; the next linearisation adds into it
   if (threadIdx.x == 0) {
     // the fields of the control block are read up front (independent requests, one wait) and written back once at the end: read and
     // written where the logic uses them they were 1.2 us of dependent traffic.  (A whole-struct copy goes through a scratch segment.)
@@ -2950,8 +2950,8 @@ __device__ __forceinline__ void lm_decide_body(const DecideArgs& A) {
   __syncthreads();
   if (s_commit) {
     // (eight 16-byte requests per thread in flight: as a load-store loop the 80 KB of inverse depths took 3.9 us of this one workgroup)
-    const double2* __restrict__ p2 = reinterpret_cast<const double2*>(A.invd2);
-    double2* __restrict__ q2 = reinterpret_cast<double2*>(A.invd);
+    const double2* __restrict__ p2 = reinterpret_cast<const double2*>((const double*)A.invd2);
+    double2* __restrict__ q2 = reinterpret_cast<double2*>((double*)A.invd);
     const int n2 = A.n_lm / 2;
     for (int i0 = 0; i0 < n2; i0 += 8 * kDT) {      // (n2 > 0 inside)
       double vx[8], vy[8];             // (scalars: an array of double2 is not split into registers and lands in scratch)

@@ -291,14 +291,30 @@ __global__ __launch_bounds__(kS1T) void k_scan1(int cap, const int* __restrict__
   __syncthreads();
   const int prefix = s_prefix;
   int run = prefix + wbase + incl - sum;
+  if (COMPACT) {
+    // the thread's records are requested together (index clamped), then stored where flagged: as `if (flag) out[..] = pts[i]` every load sat
+    // in its own branch and was waited for before its store — eight dependent round trips per thread
+    if (base < n && sum != 0) {
+      float4 pv[kS1E];
 #pragma unroll
-  for (int e = 0; e < kS1E; ++e) {
-    const int i = base + e;
-    if (i < n) {
-      if (pos) pos[i] = run;
-      if (COMPACT) { if (v[e]) out[run] = pts[i]; }
+      for (int e = 0; e < kS1E; ++e) pv[e] = pts[min(base + e, n - 1)];
+#pragma unroll
+      for (int e = 0; e < kS1E; ++e) {
+        if (pos && base + e < n) pos[base + e] = run;
+        if (v[e]) out[run] = pv[e];
+        run += v[e];
+      }
+    } else if (pos) {
+#pragma unroll
+      for (int e = 0; e < kS1E; ++e) if (base + e < n) pos[base + e] = run;      // (no flag set: every position of the thread has the same prefix)
     }
-    run += v[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < kS1E; ++e) {
+      const int i = base + e;
+      if (i < n && pos) pos[i] = run;
+      run += v[e];
+    }
   }
   if (tile == ntiles - 1 && threadIdx.x == 0) {
     if (total_out) *total_out = prefix + tot;

@@ -346,7 +346,8 @@ __global__ __launch_bounds__(1024) void k_da_scan(DaArgs a) {
 #pragma unroll
     for (int g = 0; g < kG; ++g) {
       const int l = sb + g * 1024 + tid, lc = min(l, a.nl - 1);
-      ubits |= (l < a.nl && a.used[lc]) ? (1u << g) : 0u;
+      const unsigned char u = a.used[lc];                // (read unconditionally: behind `l < a.nl &&` each of the 16 loads sat in its own branch and was waited for there)
+      ubits |= ((l < a.nl) & (u != 0)) ? (1u << g) : 0u;
       invd[g] = a.lm[lc].inv_depth;
     }
     int rank[kG];
