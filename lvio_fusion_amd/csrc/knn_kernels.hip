@@ -73,7 +73,7 @@ __device__ __forceinline__ void pack_bounds_body(const int bx, const int nbx, in
 }
 // table forms (blockIdx.y = map) of the index build's launches: lvf_map_create_batch enqueues ONE launch per step for all the maps of a
 // round instead of one per map (16 loop-closure maps x 3 grid levels x 6 steps were ~290 launches of a few microseconds each)
-struct PackJob { int M, stride, nbx, pad; const float* src; float4* dst; unsigned* bounds; };
+struct PackJob { int M, stride, nbx, pad; GP<const float> src; GP<float4> dst; GP<unsigned> bounds; };
 __global__ __launch_bounds__(kB) void k_pack_bounds_t(const PackJob* __restrict__ jobs) {
   const PackJob J = jobs[blockIdx.y];
   if ((int)blockIdx.x >= J.nbx) return;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void cell_scatter_body(const int bx, int M, const flo
 struct LevelJob {
   int M, ncells, gridM, nb;
   GridP g;
-  const float4* raw; int* cell_of; int* counts; int* bsums; unsigned long long* bsq; int* cell_start; float4* sorted; unsigned long long* sumsq;
+  GP<const float4> raw; GP<int> cell_of; GP<int> counts; GP<int> bsums; GP<unsigned long long> bsq; GP<int> cell_start; GP<float4> sorted; GP<unsigned long long> sumsq;
 };
 __global__ __launch_bounds__(kB) void k_level_zero_t(const LevelJob* __restrict__ jobs) {            // counts = 0
   const LevelJob& J = jobs[blockIdx.y];

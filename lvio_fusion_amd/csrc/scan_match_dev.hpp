@@ -8,7 +8,7 @@
 namespace lvf {
 
 struct GridP { float ox, oy, oz, cell, inv_cell; int nx, ny, nz; };
-struct LevelP { const float4* sorted; const int* cell_start; GridP g; };
+struct LevelP { GP<const float4> sorted; GP<const int> cell_start; GridP g; };
 struct LevelsP { LevelP l[LVF_MAX_GRID_LEVELS]; int n; };   // l[0] = finest ... l[n-1] = coarsest (cell >= gate radius / 2)
 
 // LM state of one scan-to-map sub-problem (ceres::Solve's TrustRegionMinimizer on 3 unknowns: oracle/icp.h), device-resident
@@ -51,11 +51,11 @@ struct SmDev {
 
 // association of one (candidate, sub-problem): table entry [2 * candidate + sub]
 struct KnnJob {
-  const float4* scan; int Q; LevelsP L; float thr;
-  int* idx; float* d2; uint8_t* valid;
-  const float4* map_raw; double* corr;      // correspondences P | PA | N, SoA [3][Q] each
+  GP<const float4> scan; int Q; LevelsP L; float thr;
+  GP<int> idx; GP<float> d2; GP<uint8_t> valid;
+  GP<const float4> map_raw; GP<double> corr;      // correspondences P | PA | N, SoA [3][Q] each
 };
-struct IcpJob { int Q; const double *P, *PA, *N; const uint8_t* valid; IcpArgs args; };
+struct IcpJob { int Q; GP<const double> P, PA, N; GP<const uint8_t> valid; IcpArgs args; };
 
 constexpr int kIcpMaxBlocks = 128;   // k_icp_eval grid cap (grid-stride above it)
 
