@@ -1110,13 +1110,21 @@ __device__ __forceinline__ void tf_reduce_body(const int bx0, const TfReduceArgs
     const int r0 = A.run_first[k], r1 = A.run_first[k + 1];
     double acc = 0.0;
     if (v < 27) {
+      // the eight slab values are requested together — the row (P or Q slab) chosen by address, the workgroup index clamped — and added in
+      // order afterwards: as `if (wg >= r1) acc += P[..]; else if (wg >= r0) acc += Q[..]` every load sat in its own branch behind the
+      // previous addition, eight dependent round trips per thread
+      const double* slabP = A.slabP; const double* slabQ = A.slabQ;
+      double t8[8]; bool keep[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int wg = 64 * c + g + 8 * u;
-        if (wg >= A.n_wg) break;
-        if (wg >= r1) acc += A.slabP[((size_t)wg * n_kf + k) * kSlabRow + v];       // k as the blocks' first keyframe (later workgroups)
-        else if (wg >= r0) acc += A.slabQ[(size_t)wg * kSlabQ + v];                   // k as the blocks' current keyframe
+        const int wg = 64 * c + g + 8 * u, wgc = min(wg, A.n_wg - 1);
+        const bool useP = wgc >= r1;               // k as the blocks' first keyframe (later workgroups); else k as their current keyframe
+        keep[u] = (wg < A.n_wg) & (wgc >= r0);
+        const double* src = useP ? slabP + ((size_t)wgc * n_kf + k) * kSlabRow + v : slabQ + (size_t)wgc * kSlabQ + v;
+        t8[u] = *src;
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = keep[u] ? acc + t8[u] : acc;
     }
     part[g][v] = acc;
     __syncthreads();
@@ -1143,7 +1151,17 @@ __device__ __forceinline__ void tf_reduce_body(const int bx0, const TfReduceArgs
   while ((k2 + 1) * k2 / 2 <= pr) ++k2;
   const int k1 = pr - k2 * (k2 - 1) / 2;
   double acc = 0.0;
-  for (int wg = A.run_first[k2]; wg < A.run_first[k2 + 1]; ++wg) acc += A.slabP[((size_t)wg * n_kf + k1) * kSlabRow + 27 + el];
+  {
+    const double* slabP = A.slabP;
+    const int w0 = A.run_first[k2], w1 = A.run_first[k2 + 1];
+    for (int wg = w0; wg < w1; wg += 4) {            // four rows per round trip (index clamped), added in order
+      double t4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t4[u] = slabP[((size_t)min(wg + u, w1 - 1) * n_kf + k1) * kSlabRow + 27 + el];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = (wg + u < w1) ? acc + t4[u] : acc;
+    }
+  }
   if (acc != 0.0) {
     const int x = el / 6, y = el - 6 * x;                              // x: k2 tangent index, y: k1 tangent index
     A.B[(size_t)(6 * k2 + x) * A.ld + 6 * k1 + y] += acc;
@@ -1503,10 +1521,12 @@ __global__ __launch_bounds__(kT) void k_lm_range_init(int n_lm, int* __restrict_
   if (l < n_lm) { kmin[l] = 0x7fffffff; kmax[l] = -1; }
 }
 __device__ __forceinline__ int lm_sort_key(int kmin, int kmax, int n_kf) {
-  if (kmax < 0) return 4 * n_kf;                       // no pose-dependent block: nothing to eliminate, ordered last
+  // (branch-free on purpose: with `if (kmax < 0) return ..` in front, the compiler sinks the caller's kmin load into the branch behind the
+  // kmax load's wait — two dependent round trips per landmark instead of one)
   const int len = kmax - kmin + 1;
-  const int cls = len <= 8 ? 0 : (len <= 16 ? 1 : (len <= 32 ? 2 : 3));
-  return cls * n_kf + kmin;
+  const int cls = (len > 8) + (len > 16) + (len > 32);
+  const int none = kmax >> 31;                          // all ones: no pose-dependent block — nothing to eliminate, ordered last
+  return (none & (4 * n_kf)) | (~none & (cls * n_kf + kmin));
 }
 // counting sort by key, one workgroup (n_lm is ~1e4; 4 n_kf + 1 buckets in LDS)
 // (per-wave copies of the histogram — 16x fewer lanes per address — measured SLOWER, 15.7 vs 13.6 us: the two passes are bound by their
@@ -1517,7 +1537,16 @@ __device__ __forceinline__ void lm_sort_body(int n_lm, int n_kf, const int* __re
   const int nb = 4 * n_kf + 1;
   for (int b = threadIdx.x; b < nb; b += 1024) bucket[b] = 0;
   __syncthreads();
-  for (int l = threadIdx.x; l < n_lm; l += 1024) atomicAdd(&bucket[lm_sort_key(kmin[l], kmax[l], n_kf)], 1);
+  // (16 landmarks per thread and pass, their tracks requested together and the keys kept for the second sweep: as `for (l ..) atomicAdd(&bucket[
+  // key(kmin[l], kmax[l])], 1)` every iteration waited for its own two loads before its LDS atomic — twice ten dependent round trips at 10 k landmarks)
+  constexpr int kG = 16;
+  for (int sb = 0; sb < n_lm; sb += kG * 1024) {
+    int key[kG];
+#pragma unroll
+    for (int g = 0; g < kG; ++g) { const int lc = min(sb + g * 1024 + (int)threadIdx.x, n_lm - 1); key[g] = lm_sort_key(kmin[lc], kmax[lc], n_kf); }
+#pragma unroll
+    for (int g = 0; g < kG; ++g) if (sb + g * 1024 + (int)threadIdx.x < n_lm) atomicAdd(&bucket[key[g]], 1);
+  }
   __syncthreads();
   if (nb <= 1024) {                         // exclusive scan of the bucket counts: 16 wave scans + 16 wave totals
     __shared__ int wsum[16];
@@ -1536,7 +1565,13 @@ __device__ __forceinline__ void lm_sort_body(int n_lm, int n_kf, const int* __re
     *n_active = bucket[nb - 1];
   }
   __syncthreads();
-  for (int l = threadIdx.x; l < n_lm; l += 1024) order[atomicAdd(&bucket[lm_sort_key(kmin[l], kmax[l], n_kf)], 1)] = l;
+  for (int sb = 0; sb < n_lm; sb += kG * 1024) {
+    int key[kG];
+#pragma unroll
+    for (int g = 0; g < kG; ++g) { const int lc = min(sb + g * 1024 + (int)threadIdx.x, n_lm - 1); key[g] = lm_sort_key(kmin[lc], kmax[lc], n_kf); }
+#pragma unroll
+    for (int g = 0; g < kG; ++g) { const int l = sb + g * 1024 + (int)threadIdx.x; if (l < n_lm) order[atomicAdd(&bucket[key[g]], 1)] = l; }
+  }
 }
 __global__ __launch_bounds__(1024) void k_lm_sort(int n_lm, int n_kf, const int* __restrict__ kmin, const int* __restrict__ kmax,
                                                   int* __restrict__ order, int* __restrict__ n_active) {
@@ -1560,7 +1595,7 @@ __device__ __forceinline__ void lm_offsets_body(int n_lm, const int* __restrict_
     for (int g = 0; g < kG; ++g) {
       const int l = sb + g * 1024 + tid, lc = min(l, n_lm - 1);
       const int lo = kmin[lc], hi = kmax[lc];
-      c[g] = (l < n_lm && hi >= 0) ? max(0, hi - lo) : 0;
+      c[g] = max(0, hi - lo) & -(int)((l < n_lm) & (hi >= 0));      // (branch-free: behind `l < n_lm && hi >= 0 ? .. : 0` the kmin load was sunk into a branch behind the kmax load's wait, 32 dependent round trips)
     }
 #pragma unroll
     for (int g = 0; g < kG; ++g) {
@@ -2169,9 +2204,14 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
       const double inv_radius = 1.0 / radius;
       const int jf = *src.jac.frozen;
       const double h0d = src.jac.h0[nb0 + tid];
+      // (the row's nine entries are requested together, column clamped to the diagonal: as `c <= tid ? B[..] : 0` each load sat behind its own
+      // branch and was waited for there — nine dependent round trips at the head of every sparse level)
+      double braw[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) braw[c] = src.B[(size_t)(nb0 + tid) * src.ldB + nb0 + min(c, tid)];
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
-        double b = c <= tid ? src.B[(size_t)(nb0 + tid) * src.ldB + nb0 + c] : 0.0;
+        double b = c <= tid ? braw[c] : 0.0;
         if (c == tid) b += lm_damping_own(b, src.jac, nb0 + tid, jf, h0d) * inv_radius;      // (every tile workgroup of the node stores the same H0)
         bd[c] = b;
       }
@@ -2208,8 +2248,15 @@ __device__ __forceinline__ void sp_eliminate_body(const int vb, const SpNode* __
 #pragma unroll
   for (int c = 0; c < 9; ++c) a[c] = 0.0;
   if (tid < 9) {
+    double sraw[9];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) a[c] = ((c <= tid && !src.s_zero) ? ld_s(&S[(size_t)(col + tid) * ld + col + c]) : 0.0) + bd[c];
+    for (int c = 0; c < 9; ++c) sraw[c] = 0.0;
+    if (!src.s_zero) {                      // (all nine requested together, column clamped to the diagonal: see phase A)
+#pragma unroll
+      for (int c = 0; c < 9; ++c) sraw[c] = ld_s(&S[(size_t)(col + tid) * ld + col + min(c, tid)]);
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) a[c] = (c <= tid ? sraw[c] : 0.0) + bd[c];
   }
   if (has0 && !src.s_zero) {
     double* srow = S + (size_t)rw0 * ld + col;
