@@ -31,9 +31,14 @@ __device__ __forceinline__ void radix_hist_body(int n, const unsigned* __restric
   for (int b = threadIdx.x; b < nbins; b += kRT) h[b] = 0;
   __syncthreads();
   const int base = blockIdx.x * kRTile;
-  for (int r = 0; r < kRRounds; ++r) {
-    const int i = base + r * kRT + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1);
+  if (base < n) {                          // (uniform; a tile beyond the keys only writes its zeros)
+    // the thread's sixteen keys are requested together (index clamped), then counted: as `if (i < n) atomicAdd(&h[key(keys[i])], 1)` every
+    // round waited for its own load before its LDS atomic — sixteen dependent round trips
+    unsigned kk[kRRounds];
+#pragma unroll
+    for (int r = 0; r < kRRounds; ++r) kk[r] = keys[min(base + r * kRT + (int)threadIdx.x, n - 1)];
+#pragma unroll
+    for (int r = 0; r < kRRounds; ++r) if (base + r * kRT + (int)threadIdx.x < n) atomicAdd(&h[(kk[r] >> shift) & mask], 1);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < nbins; b += kRT) hist[(size_t)b * ntiles + blockIdx.x] = h[b];
