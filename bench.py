@@ -152,6 +152,7 @@ def main():
                     help="process-group backend for --gpus > 1.  nccl (= RCCL over xGMI) is the product path and needs one GPU per rank; gloo exercises the SAME multi-rank "
                          "branch (timing all-gather, solo reference, sharded relocalisation + gather) with every rank on the visible GPU(s) round-robin and CPU tensors in "
                          "the collectives — a correctness dry run on a 1-GPU box, never a scaling figure")
+    ap.add_argument("--legs-file", default=os.path.join(ROOT, "bench_legs.json"), help="where the full record goes (the stdout line is the compact one)")
     ap.add_argument("--fail-rank", type=int, default=-1, help="test hook: this rank raises inside its share of the relocalisation leg (the collective must still complete)")
     ap.add_argument("--legs", default="all", help="comma list of legs to run (default all): batched_windows_8,batched_windows_16,batched_windows_64,small_windows_100,pose_only_K1,icp,scan_match_frame,map_maintenance,window_tick,ceres_surface_solve,relocalize_8_candidates")
     args = ap.parse_args()
@@ -281,20 +282,6 @@ def main():
             out["legs"] = legs(api, syn, ctx, local_rank, verified, args.legs)
         except Exception as e:
             out["legs"] = {"error": repr(e)}
-        if isinstance(out.get("legs"), dict) and isinstance(out["legs"].get("icp"), dict) and "roofline_icp" in out["legs"]["icp"]:
-            out["roofline_icp"] = out["legs"]["icp"]["roofline_icp"]
-        if isinstance(out.get("legs"), dict) and isinstance(out["legs"].get("batched_windows_64"), dict) and "roofline_batched" in out["legs"]["batched_windows_64"]:
-            out["roofline_batched"] = out["legs"]["batched_windows_64"]["roofline_batched"]
-        for key in ("batched_windows_8", "batched_windows_64", "small_windows_100", "window_tick", "ceres_surface_solve", "icp", "scan_match_frame"):     # the drop-in costs and the metric's second half, top level
-            if isinstance(out.get("legs"), dict) and key in out["legs"]:
-                out[key] = out["legs"][key]
-        L = out.get("legs") if isinstance(out.get("legs"), dict) else {}
-        if isinstance(L.get("ceres_surface_solve"), dict) and "ceres_surface_tick_ms" in L["ceres_surface_solve"]:
-            out["ceres_surface_tick_ms"] = L["ceres_surface_solve"]["ceres_surface_tick_ms"]
-        if isinstance(L.get("scan_match_frame"), dict):
-            out["scan_match_frame_incl_index_ms"] = L["scan_match_frame"].get("scan_match_frame_incl_index_ms")
-        if isinstance(L.get("icp"), dict):
-            out["icp_mpairs_per_sec_incl_index"] = L["icp"].get("icp_mpairs_per_sec_incl_index")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(api, cfg, prob, st, verified)
@@ -341,6 +328,12 @@ def main():
                                                        "scores": [float(x) for x in live[np.argsort(live[:, 8]), 0]],
                                                        "relative_o_c": [[float(v) for v in row[1:8]] for row in live[np.argsort(live[:, 8])]],
                                                        "error": err, "errors_by_rank": errs if gloo else None}}
+    # what the N > 1 record proves about itself: ranks the process group saw, one device UUID per rank, a checksum of the
+    # gathered table — and, on the product backend, the same table once more through the C-ABI communicator (lvf_comm_*: RCCL opened by the library)
+    if world > 1:
+        seen = ranks_seen(api, ctx, dist, torch, rank, world, local_rank, coll_dev, gloo, rec if not args.no_extras else None)
+        if rank == 0:
+            out["ranks_seen"] = seen
     for h in (prob, st0) + tuple(handles):
         if h is not None:
             h.close()
@@ -348,7 +341,174 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out, args.legs_file)
+
+
+def _r(x, n=4):
+    """numbers to n significant digits (the line is for a parser with an 8 KB window, the sidecar keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, n) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def combined_speedup(out):
+    """north_star's target as a number: the local-BA + ICP iteration rate of the 50-keyframe / 10 000-landmark / 100 000-lidar-point window against
+    the CPU path.  One combined iteration = one LM iteration of the window + one association-and-linearisation pass over the 100 000 scan points,
+    the map index rebuilt inside the pass on BOTH sides (the reference rebuilds its kd-tree per call, association.cpp:279,337).
+    CPU seconds = 1 / cpu_baseline.value + 1e5 / (cpu Mpairs/s incl. tree build); GPU seconds = ms_per_step + pair_incl_index_device_cloud.ms."""
+    try:
+        cb = out["cpu_baseline"]
+        icp = out["legs"]["icp"]
+        cpu_ba_s = 1.0 / cb["value"]
+        cpu_icp_s = 1e5 / (cb["icp_mpairs_per_sec"]["incl_tree_build"] * 1e6)
+        gpu_ba_s = 1e-3 * out["ms_per_step"]
+        gpu_icp_s = 1e-3 * icp["pair_incl_index_device_cloud"]["ms"]
+        x = (cpu_ba_s + cpu_icp_s) / (gpu_ba_s + gpu_icp_s)
+        return {"combined_ba_plus_icp": x, "ba_alone": cpu_ba_s / gpu_ba_s, "icp_alone_incl_index": cpu_icp_s / gpu_icp_s, "target": 10.0, "met": bool(x >= 10.0),
+                "cpu_ms": [1e3 * cpu_ba_s, 1e3 * cpu_icp_s], "gpu_ms": [1e3 * gpu_ba_s, 1e3 * gpu_icp_s],
+                "def": "(1/cpu it/s + 1e5/cpu pairs/s incl. kd-tree build) / (ms_per_step + ICP pass incl. index build, device cloud)"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
+def compact_line(out):
+    """The ONE stdout line the driver parses (its window is 8 KB: VERDICT r05 item 1): every object once, numbers to 4-5 digits, notes dropped.
+    Everything else goes to bench_legs.json (and stderr)."""
+    L = out.get("legs") if isinstance(out.get("legs"), dict) else {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = dict(out.get("config") or {})
+    line["config"] = cfg
+    line["steps_executed"] = out.get("steps_executed")
+    line["repeat_ms_per_step_min_median_max"] = out.get("repeat_ms_per_step_min_median_max")
+    r = out.get("roofline") or {}
+    line["roofline"] = r if "error" in r else _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_per_iteration", "share_of_iteration"))
+    if "traffic" not in line["roofline"] and "error" not in line["roofline"]:
+        line["roofline"]["traffic"] = None
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind", "sample", "reference_functors_eval_ms", "error"))
+        if isinstance(cb.get("icp_mpairs_per_sec"), dict):
+            c["icp_mpairs_per_sec"] = _pick(cb["icp_mpairs_per_sec"], ("value", "incl_tree_build", "cores"))
+        if isinstance(cb.get("pose_only_K1_passes_per_sec"), dict):
+            c["pose_only_K1_passes_per_sec"] = cb["pose_only_K1_passes_per_sec"].get("value")
+        line["cpu_baseline"] = c
+        line["speedup_vs_cpu"] = combined_speedup(out)
+    icp = L.get("icp") if isinstance(L.get("icp"), dict) else {}
+    if icp:
+        line["icp_mpairs_per_sec"] = icp.get("icp_mpairs_per_sec")
+        if isinstance(icp.get("icp_mpairs_per_sec_incl_index"), dict):
+            line["icp_mpairs_per_sec_incl_index"] = _pick(icp["icp_mpairs_per_sec_incl_index"], ("host_cloud", "device_cloud"))
+        if isinstance(icp.get("roofline_icp"), dict):
+            line["roofline_icp"] = _pick(icp["roofline_icp"], ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "traffic", "traffic_over_algorithmic",
+                                                              "candidates_per_query_mean", "error"))
+    for key in ("batched_windows_8", "batched_windows_16", "batched_windows_64"):
+        if isinstance(L.get(key), dict):
+            line[key] = _pick(L[key], ("windows", "lm_iters_per_sec_aggregate", "ms_per_batched_iteration", "error"))
+    b64 = L.get("batched_windows_64") if isinstance(L.get("batched_windows_64"), dict) else {}
+    if isinstance(b64.get("roofline_batched"), dict):
+        line["roofline_batched"] = _pick(b64["roofline_batched"], ("bound", "windows", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic"))
+    if isinstance(L.get("small_windows_100"), dict):
+        line["small_windows_100"] = _pick(L["small_windows_100"], ("windows", "n_kf", "lm_iters_per_sec_aggregate", "single_window_ms_per_iteration", "error"))
+    if isinstance(L.get("pose_only_K1"), dict):
+        line["pose_only_K1"] = _pick(L["pose_only_K1"], ("blocks", "passes_per_sec", "avg_kernel_ms", "error"))
+        if isinstance(L["pose_only_K1"].get("roofline"), dict):
+            line["pose_only_K1"]["hbm_frac"] = L["pose_only_K1"]["roofline"].get("frac")
+    if isinstance(L.get("window_tick"), dict):
+        line["window_tick_ms_1_iteration"] = L["window_tick"].get("ms_per_tick_1_iteration")
+    cs = L.get("ceres_surface_solve") if isinstance(L.get("ceres_surface_solve"), dict) else {}
+    if cs:
+        line["ceres_surface"] = _pick(cs, ("adapt_solve_ms", "ceres_surface_tick_ms", "reference_text_tick_ms", "error"))
+    if isinstance(L.get("scan_match_frame"), dict):
+        line["scan_match_frame_ms"] = _pick(L["scan_match_frame"], ("ms_per_frame", "scan_match_frame_incl_index_ms"))
+    rc = L.get("relocalize_8_candidates") if isinstance(L.get("relocalize_8_candidates"), dict) else {}
+    if rc:
+        line["relocalize_8_candidates"] = _pick(rc, ("ms_total", "candidates_per_sec", "ranks", "best", "error", "comm"))
+    bc = out.get("box_calibration") or {}
+    line["box_calibration"] = _pick(bc, ("ns_per_dependent_fp64_fma", "empty_launch_us_back_to_back", "effective_sclk_mhz", "lm_iteration_in_dependent_fma_times",
+                                         "lm_iteration_in_empty_launch_times", "error"))
+    for k in ("per_rank_median_seconds_for_K_steps", "single_gpu_seconds_same_work", "scaling_efficiency_T1_over_TN", "dist_backend", "ranks_seen"):
+        if k in out:
+            line[k] = out[k]
+    line["verified"] = out.get("verified")
+    line["detail"] = "bench_legs.json"
+    return _r(line, 5)
+
+
+def ranks_seen(api, ctx, dist, torch, rank, world, local_rank, coll_dev, gloo, table):
+    """Collective on every rank.  Returns (rank 0) {group_world_size, backend, device_uuids[rank], distinct_devices, table_crc32, lvf_comm{...}}."""
+    import threading
+    import zlib
+    seen = {"group_world_size": dist.get_world_size(), "backend": dist.get_backend()}
+    try:
+        u = str(torch.cuda.get_device_properties(local_rank).uuid)
+    except Exception:
+        u = f"device-{local_rank}"
+    raw = np.frombuffer(u.encode()[:48].ljust(48, b" "), np.uint8).copy()
+    t = torch.from_numpy(raw).to(coll_dev)
+    allu = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(allu, t)
+    seen["device_uuids"] = [bytes(x.cpu().numpy()).decode().strip() for x in allu]
+    seen["distinct_devices"] = len(set(seen["device_uuids"]))
+    if table is not None:
+        seen["table_crc32"] = zlib.crc32(np.ascontiguousarray(table, np.float64).tobytes())
+        seen["table_rows"] = int(np.asarray(table).reshape(-1, 9).shape[0])
+    if gloo:
+        seen["lvf_comm"] = {"skipped": "gloo dry run: RCCL refuses two ranks on one device"}
+        return seen
+    # the C-ABI communicator: rank 0's unique id travels over the process group; bounded (a wedged RCCL init must not take the line down)
+    res = {}
+
+    def work():
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+            if rank == 0:
+                idt = torch.from_numpy(np.frombuffer(api.comm_unique_id(), np.uint8).copy()).to(coll_dev)
+            dist.broadcast(idt, 0)
+            comm = api.Comm(ctx, world, rank, bytes(idt.cpu().numpy()))
+            res["world_size"] = comm.world_size
+            if table is not None:
+                mine = np.ascontiguousarray(np.asarray(table, np.float64).reshape(world, -1)[rank])
+                got = comm.allgather(mine)
+                res["same_table_as_process_group"] = bool(np.array_equal(got.reshape(-1), np.asarray(table, np.float64).reshape(-1), equal_nan=True))
+            comm.close()
+        except Exception as e:
+            res["error"] = repr(e)[:200]
+    th = threading.Thread(target=work, daemon=True)
+    th.start(); th.join(60.0)
+    if th.is_alive():
+        res["error"] = "timeout after 60 s"
+    seen["lvf_comm"] = res
+    return seen
+
+
+def emit(out, legs_file=None):
+    """full record -> bench_legs.json (+ gpurun_out/ when present) and stderr; the compact record -> the final stdout line"""
+    full = json.dumps(out)
+    for path in (legs_file or os.path.join(ROOT, "bench_legs.json"), os.path.join(ROOT, "gpurun_out", "bench_legs.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(full + "\n")
+        except Exception:
+            pass
+    print(full, file=sys.stderr, flush=True)
+    line = json.dumps(compact_line(out), separators=(",", ":"))
+    if len(line) > 6000:      # never again a line the driver cannot read: shed the optional objects, largest first
+        c = json.loads(line)
+        for k in ("box_calibration", "relocalize_8_candidates", "ceres_surface", "small_windows_100", "pose_only_K1", "batched_windows_16", "scan_match_frame_ms", "verified"):
+            c.pop(k, None)
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) <= 6000:
+                break
+    print(line, flush=True)
 
 
 def box_calibration(api, ctx, ms_per_step):
@@ -1027,7 +1187,7 @@ def cpu_baseline(api, cfg, prob, st, verified):
         from oracle import pyref
         if pyref.build() is not None:
             rf = pyref.window_eval_timed(cfg, pre, threads=threads, reps=3)
-            out["kind"] = "port (value: whole LM iteration) + reference (reference_functors: the evaluation pass alone)"
+            out["kind_note"] = "value: whole LM iteration of the port; reference_functors: the reference's own functor text (oracle/_ref), the evaluation pass alone"
             out["reference_functors"] = {"kind": "reference", "blocks": rf["blocks"], "cores": threads, "reference_functors_eval_ms": 1e3 * rf["evaluate_s"],
                                          "reference_functors_create_ms": 1e3 * rf["create_s"], "evaluation_passes_per_sec": 1.0 / rf["evaluate_s"],
                                          "sample": "3 full passes of CostFunction::Evaluate (residuals + Jacobians) over the window's 91 k blocks after creating one heap functor per block "

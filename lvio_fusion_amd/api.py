@@ -610,6 +610,44 @@ def box_calibration(ctx):
             "rated_mclk_mhz": float(v[6]), "compute_units": int(v[7])}
 
 
+def comm_unique_id():
+    """lvf_comm_get_unique_id: the 128 bytes rank 0 hands to the other ranks out of band"""
+    buf = (C.c_ubyte * 128)()
+    _chk(_lib.lib().lvf_comm_get_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf)
+
+
+class Comm:
+    """lvf_comm_*: the path's one exchange through the C-ABI (RCCL opened by the library; world_size 1 needs none)"""
+    def __init__(self, ctx, world_size=1, rank=0, unique_id=None):
+        self.ctx, self.h = ctx, C.c_void_p()
+        idbuf = None
+        if unique_id is not None:
+            if len(unique_id) != 128:
+                raise ValueError("unique id must be the 128 bytes of comm_unique_id()")
+            idbuf = C.cast((C.c_ubyte * 128).from_buffer_copy(unique_id), C.c_void_p)
+        _chk(ctx.L.lvf_comm_create(ctx.h, int(world_size), int(rank), idbuf, C.byref(self.h)))
+
+    @property
+    def world_size(self):
+        return int(self.ctx.L.lvf_comm_world_size(self.h))
+
+    @property
+    def rank(self):
+        return int(self.ctx.L.lvf_comm_rank(self.h))
+
+    def allgather(self, send):
+        a = _d(send).ravel()
+        out = np.empty((self.world_size, a.size))
+        _chk(self.ctx.L.lvf_comm_allgather(self.h, _dp(a), int(a.size), _dp(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lvf_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 def default_solver_options():
     o = SolverOptions()
     _lib.lib().lvf_solver_options_default(C.byref(o))
