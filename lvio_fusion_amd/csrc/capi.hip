@@ -127,6 +127,7 @@ int lvf_ctx_create(int device, void* hip_stream, lvf_ctx** out) {
   auto* c = new lvf_ctx();
   c->device = device;
   g_pool = c->pool;
+  c->pool->set_cap_from_device();
   c->num_cu = prop.multiProcessorCount;
   if (hip_stream) { c->stream = static_cast<hipStream_t>(hip_stream); c->own_stream = false; }
   else {

@@ -1,6 +1,7 @@
 // lvf_internal.hpp — host-side objects behind the opaque C-ABI handles of include/lvf.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdlib>
@@ -49,7 +50,26 @@ struct Pool {
   // context is doing now.  (Round 4 refused the new block instead — 4 GB cap — so after the 64-window batches of bench.py had filled the pool
   // with sizes nothing else asks for, every later allocation of a run was a hipMalloc and every release a device-synchronising hipFree: the
   // map index built in 1.0 ms instead of 0.13, the feature extraction in 0.65 ms instead of 0.41, in that process only.)
-  static constexpr size_t kMaxHeld = (size_t)16 << 30;
+  // The cap is a quarter of what the device had free when the context was created, at most 16 GB (lvf::enter sets it; a 16-GB constant on a
+  // 16-64 GB part, or with several contexts on one GPU, let gigabytes sit parked while a new bucket size failed to allocate: ADVICE r05).
+  // A failed hipMalloc additionally drains this pool and retries once (DevBuf::raw_alloc).
+  static constexpr size_t kMaxHeldCeiling = (size_t)16 << 30;
+  size_t kMaxHeld = (size_t)4 << 30;
+  void set_cap_from_device() {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+      std::lock_guard<std::mutex> g(mu);
+      kMaxHeld = std::min(kMaxHeldCeiling, std::max((size_t)256 << 20, free_b / 4));
+    }
+  }
+  // everything parked goes back to the device (the caller's hipMalloc failed): returns the bytes released
+  size_t drain() {
+    std::unordered_multimap<size_t, void*> all;
+    size_t n = 0;
+    { std::lock_guard<std::mutex> g(mu); all.swap(parked); n = held; held = 0; }
+    for (auto& kv : all) (void)hipFree(kv.second);
+    return n;
+  }
   static size_t bucket(size_t bytes) {
     if (bytes <= 4096) return (bytes + 255) & ~(size_t)255;
     size_t b = 4096;
@@ -176,6 +196,10 @@ struct DevBuf {  // owning device buffer
     void* q = pool ? pool->get(bytes) : nullptr;
     if (!q) {
       hipError_t e = hipMalloc(&q, bytes);
+      if (e == hipErrorOutOfMemory && pool && pool->drain() > 0) {      // parked blocks of other sizes were holding the memory: give them back, once
+        (void)hipGetLastError();
+        e = hipMalloc(&q, bytes);
+      }
       if (e != hipSuccess) { bytes = 0; pool.reset(); return ::lvf::hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
     }
     p = static_cast<T*>(q);

@@ -40,59 +40,9 @@ class SizedCostFunction : public CostFunction {
   }
 };
 
-namespace internal {
-template <int... Ns> struct Sum;
-template <> struct Sum<> { static constexpr int value = 0; };
-template <int N0, int... Ns> struct Sum<N0, Ns...> { static constexpr int value = N0 + Sum<Ns...>::value; };
-
-// calls functor(p[0], ..., p[K-1], residuals)
-template <typename Functor, typename T, int K> struct Call;
-#define LVF_REF_CALL(K, ...) \
-  template <typename Functor, typename T> struct Call<Functor, T, K> { static bool Run(const Functor& f, T const* const* p, T* r) { return f(__VA_ARGS__, r); } };
-LVF_REF_CALL(1, p[0])
-LVF_REF_CALL(2, p[0], p[1])
-LVF_REF_CALL(3, p[0], p[1], p[2])
-LVF_REF_CALL(4, p[0], p[1], p[2], p[3])
-LVF_REF_CALL(5, p[0], p[1], p[2], p[3], p[4])
-LVF_REF_CALL(6, p[0], p[1], p[2], p[3], p[4], p[5])
-#undef LVF_REF_CALL
-}  // namespace internal
-
-template <typename CostFunctor, int kNumResiduals, int... Ns>
-class AutoDiffCostFunction : public SizedCostFunction<kNumResiduals, Ns...> {
- public:
-  explicit AutoDiffCostFunction(CostFunctor* functor) : functor_(functor) {}
-  const CostFunctor* functor() const { return functor_.get(); }      // shim-only (oracle/ref_driver_backend.cpp reads the recorded blocks' constants)
-  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
-    constexpr int K = sizeof...(Ns);
-    constexpr int kTotal = internal::Sum<Ns...>::value;
-    const int sizes[K] = {Ns...};
-    if (!jacobians) return internal::Call<CostFunctor, double, K>::Run(*functor_, parameters, residuals);
-    typedef Jet<double, kTotal> JetT;
-    JetT x[kTotal];
-    JetT out[kNumResiduals];
-    const JetT* blocks[K];
-    int off = 0;
-    for (int b = 0; b < K; ++b) {
-      blocks[b] = x + off;
-      for (int j = 0; j < sizes[b]; ++j) x[off + j] = JetT(parameters[b][j], off + j);
-      off += sizes[b];
-    }
-    if (!internal::Call<CostFunctor, JetT, K>::Run(*functor_, blocks, out)) return false;
-    for (int r = 0; r < kNumResiduals; ++r) residuals[r] = out[r].a;
-    off = 0;
-    for (int b = 0; b < K; ++b) {
-      if (jacobians[b])
-        for (int r = 0; r < kNumResiduals; ++r)
-          for (int j = 0; j < sizes[b]; ++j) jacobians[b][r * sizes[b] + j] = out[r].v[off + j];
-      off += sizes[b];
-    }
-    return true;
-  }
-
- private:
-  std::unique_ptr<CostFunctor> functor_;
-};
+}  // namespace ceres
+#include "autodiff_shim.h"
+namespace ceres {
 
 // ---- the problem-building surface adapt/problem.h:34-88 and association.cpp:270-384 name: loss functions, local parameterisations (type
 // names only), and a ceres::Problem that RECORDS what is added (no solver): the driver reads the blocks back and evaluates them.
@@ -152,16 +102,5 @@ struct Solver {
   struct Summary { double final_cost = 0; int num_residual_blocks_reduced = 0; };
 };
 inline void Solve(const Solver::Options&, Problem*, Solver::Summary*) {}      // no solver in the shim (declared semantics: oracle/lm.h, oracle/icp.h)
-
-// declared so that imu_error.hpp:231-274 (ImuInitGError::Create, initialisation only — not on the hot path) compiles; never evaluated
-enum NumericDiffMethodType { CENTRAL, FORWARD, RIDDERS };
-template <typename CostFunctor, NumericDiffMethodType kMethod, int kNumResiduals, int... Ns>
-class NumericDiffCostFunction : public SizedCostFunction<kNumResiduals, Ns...> {
- public:
-  explicit NumericDiffCostFunction(CostFunctor* functor) : functor_(functor) {}
-  bool Evaluate(double const* const*, double*, double**) const override { return false; }
- private:
-  std::unique_ptr<CostFunctor> functor_;
-};
 
 }  // namespace ceres

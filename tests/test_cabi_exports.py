@@ -111,3 +111,27 @@ def test_host_alloc_works_without_a_device():
     for p, n in blocks:
         L.lvf_host_free(p, n)
     L.lvf_host_free(None, 0)
+
+
+def test_compiled_dropin_loads_and_links_the_hip_library():
+    """oracle/_ref/liblvf_dropin.so (the reference's backend.cpp / association.cpp compiled unmodified against include/reference_patch): it loads,
+    exports its two entry points and takes every lvf_* symbol it needs from liblvf_hip.so — no compute without a GPU"""
+    import ctypes
+    import subprocess
+    import pytest
+    from oracle import pydropin
+    if not pydropin.available():
+        pytest.skip("needs /root/reference at build time")
+    so = pydropin.build()
+    lib = ctypes.CDLL(so)
+    for name in ("lvd_backend_solve", "lvd_scan_to_map_solve", "lvd_sources"):
+        getattr(lib, name)
+    nm = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+    needed = sorted({l.split()[-1] for l in nm.splitlines() if " lvf_" in l})
+    assert "lvf_problem_solve" in needed or any(n.startswith("lvf_problem") for n in needed)
+    from lvio_fusion_amd import _lib
+    declared = set(_lib.declared_symbols())
+    assert set(needed) <= declared, sorted(set(needed) - declared)
+    # the reference's factories resolve to the library's cost functions: no Jet-differentiated TwoFrame / PoseOnly functor is instantiated
+    syms = subprocess.run(["nm", "-DC", so], capture_output=True, text=True).stdout
+    assert "gpu::TwoFrameReprojectionError" in syms and "AutoDiffCostFunction<lvio_fusion::TwoFrameReprojectionError" not in syms
