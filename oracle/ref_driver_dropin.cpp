@@ -144,8 +144,10 @@ int lvd_backend_solve(const lvd_camera* c0, const lvd_camera* c1, double baselin
   Camera::baseline = baseline;
   Imu::devices_.clear();
   if (in->imu_initialized) {
-    Imu::Create(SE3d(), in->imu_noise4[0], in->imu_noise4[1], in->imu_noise4[2], in->imu_noise4[3], 9.81007);
-    Imu::Get()->initialized = true;
+    Imu::Create(SE3d(), 0, 0, 0, 0, 9.81007);
+    Imu::Ptr d = Imu::Get();                 // (Create's argument order is acc_n, acc_w, gyr_n, gyr_w — imu.h:49: set by name)
+    d->ACC_N = in->imu_noise4[0]; d->GYR_N = in->imu_noise4[1]; d->ACC_W = in->imu_noise4[2]; d->GYR_W = in->imu_noise4[3];
+    d->initialized = true;
   }
   std::vector<Frame::Ptr> frames((size_t)in->n_frames);
   size_t sample0 = 0;
