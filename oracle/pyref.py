@@ -342,3 +342,74 @@ def backend_build_problem(cam0, cam1, baseline, time, pose, w_visual, good_imu, 
         raise RuntimeError(f"lvr_backend_build_problem: {n}")
     return dict(rec_i=rec_i[:n], rec_d=rec_d[:n], num_frames=nf.value, num_parameter_blocks=npb.value)
 
+
+
+# ---- round 6: the reference's CONTROL code (mapping.cpp, pose_graph.cpp, relocator.cpp compiled unmodified; ceres::Solve = ref_shim/ceres/solve_shim.h,
+# the DECLARED LM loop); driver: oracle/ref_driver_mapping.cpp
+def _cat_clouds(clouds):
+    """list of [n][4] float32 clouds (None: the frame carries no lidar feature) -> (counts int32 with -1 for None, concatenated [sum n][4])"""
+    cnt = np.array([-1 if c is None else len(c) for c in clouds], np.int32)
+    parts = [np.ascontiguousarray(c, np.float32).reshape(-1, 4) for c in clouds if c is not None and len(c)]
+    return cnt, (np.concatenate(parts) if parts else np.zeros((0, 4), np.float32))
+
+
+def mapping_optimize(time, pose, ground, surf, first_active, w_ground, w_surf, w_visual, n_features_left, resolution=0.2):
+    """Mapping::Optimize (mapping.cpp:139-191) over frames [first_active:], frames before it only enter the map through Mapping::ToWorld.
+    ground / surf: per frame [n][4] float32 body-frame clouds (or None).  Returns dict(pose [n][7] afterwards, world_counts [n][2])."""
+    time, pose = _f64(time), _f64(pose)
+    n = len(time)
+    ng, G = _cat_clouds(ground)
+    ns, S = _cat_clouds([s if g is not None else None for g, s in zip(ground, surf)])
+    ns = np.where(ng < 0, 0, ns).astype(np.int32)
+    nf = _i32(n_features_left)
+    out = np.empty((n, 7)); wc = np.zeros((n, 2), np.int32)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    lib().lvr_mapping_optimize(n, _p(time), _p(pose), vp(ng), vp(ns), vp(G), vp(S), int(first_active), C.c_double(w_ground), C.c_double(w_surf), C.c_double(w_visual),
+                               vp(nf), C.c_double(resolution), _p(out), vp(wc))
+    return dict(pose=out, world_counts=wc)
+
+
+def mapping_relocate(time, pose, ground, surf, old_index, cur_ground, cur_surf, cur_pose, rel_in, w_ground, w_surf, w_visual, resolution=0.2):
+    """Mapping::Relocate (mapping.cpp:251-300) of a current frame against the old keyframes `time/pose/ground/surf` around frames[old_index].
+    Returns dict(score (int), relative_o_c [7], map_pose [7], map_counts [2])."""
+    time, pose = _f64(time), _f64(pose)
+    n = len(time)
+    ng, G = _cat_clouds(ground); ns, S = _cat_clouds(surf)
+    cg, cs = np.ascontiguousarray(cur_ground, np.float32).reshape(-1, 4), np.ascontiguousarray(cur_surf, np.float32).reshape(-1, 4)
+    cp, ri = _f64(cur_pose), _f64(rel_in)
+    rel = np.empty(7); mp = np.empty(7); mc = np.zeros(2, np.int32)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    L = lib(); L.lvr_mapping_relocate.restype = C.c_int
+    score = L.lvr_mapping_relocate(n, _p(time), _p(pose), vp(ng), vp(ns), vp(G), vp(S), int(old_index), vp(cg), len(cg), vp(cs), len(cs), _p(cp), _p(ri),
+                                   C.c_double(w_ground), C.c_double(w_surf), C.c_double(w_visual), C.c_double(resolution), _p(rel), _p(mp), vp(mc))
+    return dict(score=int(score), relative_o_c=rel, map_pose=mp, map_counts=mc)
+
+
+def pose_graph_optimize(time, pose, vw, section_A, submap_A, submap_B, start_after=None):
+    """PoseGraph::BuildProblem + Optimize (pose_graph.cpp:163-224).  Returns dict(pose [n][7], vw [n][3], counts = (residual blocks, AddParameterBlock calls, num_frames))."""
+    time, pose, vw, sa = _f64(time), _f64(pose), _f64(vw), _f64(section_A)
+    n = len(time)
+    out = np.empty((n, 7)); vo = np.empty((n, 3)); c3 = np.zeros(3, np.int32); s3 = np.zeros(3)
+    sa_after = _f64(start_after) if start_after is not None else None
+    lib().lvr_pose_graph_optimize(n, _p(time), _p(pose), _p(vw), len(sa), _p(sa), C.c_double(submap_A), C.c_double(submap_B), _p(sa_after) if sa_after is not None else None, _p(out), _p(vo),
+                                  c3.ctypes.data_as(C.c_void_p), _p(s3))
+    return dict(pose=out, vw=vo, counts=tuple(int(x) for x in c3))
+
+
+def update_new_submap(time, pose, old_pose, relative_o_c, best):
+    """Relocator::UpdateNewSubmap (relocator.cpp:247-282).  Returns the new sub-map's poses [n][7] afterwards."""
+    time, pose, old_pose, rel = _f64(time), _f64(pose), _f64(old_pose), _f64(relative_o_c)
+    out = np.empty((len(time), 7))
+    lib().lvr_update_new_submap(len(time), _p(time), _p(pose), _p(old_pose), _p(rel), int(best), _p(out))
+    return out
+
+
+def scan_to_map_solve(mode, scan, map_pts, frame_pose, map_pose, para6, w_ground, w_surf, w_visual, n_features_left, relocate, resolution=0.2, max_num_iterations=4):
+    """the reference's ScanToMapWithGround / WithSegmented problem solved by the stand-in ceres::Solve.  Returns (para [6], dict summary)."""
+    scan = np.ascontiguousarray(scan, np.float32).reshape(-1, 4); map_pts = np.ascontiguousarray(map_pts, np.float32).reshape(-1, 4)
+    fp, mp = _f64(frame_pose), _f64(map_pose)
+    para = np.array(para6, np.float64).copy(); s6 = np.zeros(6)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    lib().lvr_scan_to_map_solve(int(mode), vp(scan), len(scan), vp(map_pts), len(map_pts), _p(fp), _p(mp), _p(para), C.c_double(w_ground), C.c_double(w_surf),
+                                C.c_double(w_visual), int(n_features_left), int(bool(relocate)), C.c_double(resolution), int(max_num_iterations), _p(s6))
+    return para, dict(initial_cost=s6[0], final_cost=s6[1], num_residual_blocks=int(s6[2]), num_iterations=int(s6[3]), num_successful_steps=int(s6[4]), termination=int(s6[5]))

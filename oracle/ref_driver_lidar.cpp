@@ -49,7 +49,6 @@ unsigned long Frame::current_frame_id = 0;
 Frame::Frame() : id(0), time(0) {}                           // (src/frame.cpp is not compiled: see the header of this file)
 Vector3d Frame::t() { std::abort(); }
 SE3d Map::ComputePose(double) { std::abort(); }
-Frames Map::GetKeyFrames(double, double, int) { std::abort(); }
 }  // namespace lvio_fusion
 
 using namespace lvio_fusion;

@@ -10,7 +10,7 @@
 namespace pcl {
 struct PointXYZ { union { float data[4]; struct { float x, y, z; }; }; PointXYZ() : data{0, 0, 0, 1} {} };
 struct PointXYZI { union { float data[4]; struct { float x, y, z; }; }; union { struct { float intensity; }; float data_c[4]; }; PointXYZI() : data{0, 0, 0, 1}, data_c{0, 0, 0, 0} {} };
-struct PointXYZRGB { union { float data[4]; struct { float x, y, z; }; }; union { struct { float rgb; }; float data_c[4]; }; PointXYZRGB() : data{0, 0, 0, 1}, data_c{0, 0, 0, 0} {} };
+struct PointXYZRGB { union { float data[4]; struct { float x, y, z; }; }; union { struct { float rgb; }; struct { std::uint8_t b, g, r, a; }; float data_c[4]; }; PointXYZRGB() : data{0, 0, 0, 1}, data_c{0, 0, 0, 0} {} };
 struct PCLHeader { std::uint32_t seq = 0; std::uint64_t stamp = 0; };
 template <typename PointT>
 struct PointCloud {

@@ -4,6 +4,7 @@
 // inverse()/operator* are used by PoseGraphError's first constructor (pose_error.hpp:13-17) and sensor.h's inline methods.
 #pragma once
 #include <Eigen/Core>
+#include <sophus/so3.hpp>
 
 namespace Sophus {
 
@@ -23,6 +24,8 @@ class SE3d {
   static constexpr int num_parameters = 7;
   SE3d() { d_[0] = d_[1] = d_[2] = 0.0; d_[3] = 1.0; d_[4] = d_[5] = d_[6] = 0.0; }
   explicit SE3d(const double* data7) { for (int i = 0; i < 7; ++i) d_[i] = data7[i]; }     // shim-only convenience
+  SE3d(const SO3d& r, const Eigen::Vector3d& t) { for (int i = 0; i < 4; ++i) d_[i] = r.data()[i]; d_[4] = t.x(); d_[5] = t.y(); d_[6] = t.z(); }
+  SO3d so3() const { return SO3d(d_); }
   double* data() { return d_; }
   const double* data() const { return d_; }
   template <typename T> SE3f cast() const { SE3f r; for (int i = 0; i < 7; ++i) r.data()[i] = (T)d_[i]; return r; }
