@@ -493,10 +493,11 @@ static int extract_device_counted(lvf_ctx* ctx, const float* points, int n, int 
   LVF_HIP(hipGetLastError());
   // ---- the picks' compactions and the PCL tail (association.cpp:210-234): the ground half on the side stream, the surf half on this one
   hipStream_t q = s;
+  DevBuf<float4> surf_pre, ground_pre;
+  SideGuard side_fork_guard{ctx};      // declared AFTER every buffer the side stream touches (seg, pick_g, g_raw, ground_pre ...): on an error return it waits for stream2 before they go back to the pool
   LVF_TRY(dc_tail_fork(ctx, plan, &q));
   LVF_TRY(device_scan1_on(ctx, q, plan.lane_ground, pick_g.p, capseg, num_dev, nullptr, &ex->cnt[2], seg.p, g_raw.p));
   LVF_TRY(device_scan1_on(ctx, s, 0, pick_s.p, capseg, num_dev, nullptr, &ex->cnt[3], seg.p, s_raw.p));
-  DevBuf<float4> surf_pre, ground_pre;
   LVF_TRY(dc_tail_run(ctx, plan, q, s_raw.p, &ex->cnt[3], g_raw.p, &ex->cnt[2], (unsigned long long)prm->ransac_seed, tail_state, tail_keep, surf_pre, ground_pre));
   // ---- the one read-back: the four counts here, the tail's four and its verdict
   int hc[4] = {0, 0, 0, 0}, ht[5] = {0, 0, 0, 0, 0};
@@ -507,6 +508,7 @@ static int extract_device_counted(lvf_ctx* ctx, const float* points, int n, int 
     LVF_HIP(hipMemcpyAsync(mb + 64, tail_state.p + dc_state_counts_offset(), sizeof(ht), hipMemcpyDeviceToHost, s));
     const double us_enq = us_since(t_in);
     LVF_HIP(hipStreamSynchronize(s));
+    stage_guard.dismiss();             // the upload has been waited for: no second full stream wait when this scope ends (the transforms below are consumed on the same stream)
     if (timing) std::fprintf(stderr, "extract: upload enqueued at %.1f us, all launches enqueued at %.1f us, stream drained at %.1f us\n", us_upload, us_enq, us_since(t_in));
     std::memcpy(hc, mb, sizeof(hc)); std::memcpy(ht, mb + 64, sizeof(ht));
   }

@@ -263,6 +263,10 @@ struct lvf_ctx {
   unsigned long long* scan_status = nullptr;
   int scan_tiles = 0;
   unsigned scan_epoch = 0;
+  // set by device_scan1_on (the one-launch scan's sticky error word, raised by a tile that gave up waiting for a predecessor): the next small
+  // read_back() of this context fetches it along with the counts and fails with LVF_ERR_STATE instead of handing out a count that may be wrong.
+  // A context is driven by ONE host thread at a time (tickets, status words and the epoch live on it, unguarded): INTEGRATION.md, threading.
+  unsigned long long* scan_err = nullptr;
   // side stream for the second of two independent launch chains inside one call (lvf_lidar_extract's ground tail beside the surf tail), with
   // the events that fork it off the context's stream and join it back; created on first use (lvf::side_stream)
   hipStream_t stream2 = nullptr;
@@ -282,12 +286,27 @@ inline int read_back(lvf_ctx* ctx, void* host_out, const void* dev, size_t bytes
     if (e != hipSuccess) return ::lvf::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
     return LVF_OK;
   }
-  LVF_TRY(ctx->mailbox.reserve(4096));
+  LVF_TRY(ctx->mailbox.reserve(4096 + 64));
   hipError_t e = hipMemcpyAsync(ctx->mailbox.p, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
   if (e != hipSuccess) return ::lvf::hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+  unsigned long long* const scan_err = ctx->scan_err;
+  if (scan_err) {                // a one-launch scan ran on this context since the last look: its error word rides along
+    ctx->scan_err = nullptr;
+    e = hipMemcpyAsync(reinterpret_cast<char*>(ctx->mailbox.p) + 4096, scan_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) return ::lvf::hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+  }
   e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) return ::lvf::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
   std::memcpy(host_out, ctx->mailbox.p, bytes);
+  if (scan_err) {
+    unsigned long long w = 0;
+    std::memcpy(&w, reinterpret_cast<const char*>(ctx->mailbox.p) + 4096, sizeof(w));
+    if (w != 0) {
+      (void)hipMemsetAsync(scan_err, 0, sizeof(unsigned long long), ctx->stream);
+      ::lvf::set_error("device scan: tile %llu of launch %llu never published its sum (status block corrupted, or one context driven by two host threads)", (w & 0xffffffffull) - 1, w >> 32);
+      return LVF_ERR_STATE;
+    }
+  }
   return LVF_OK;
 }
 // host array -> device / device -> host array, waited for, through the context's pinned staging when it is at most 1 MB (the same
@@ -523,7 +542,11 @@ __device__ __forceinline__ bool cell_runs(int c, int& start, int& len) {
 // TwoFrame work list; called by lvf_problem_create and, every tick, by the persistent window (window.hip)
 int problem_configure(lvf_problem* p);
 }  // namespace lvf
-// lvf_problem_solve with a caller's launches enqueued behind the last iteration and ahead of the wait that ends the solve (solver_kernels.hip)
+// lvf_problem_solve with a caller's launches enqueued behind the last iteration and ahead of the wait that ends the solve (solver_kernels.hip).
+// CONTRACT: tail(user) MUST be idempotent — pure enqueues that can be repeated (pack + copy, as window.hip's): it runs once per pass of the
+// hand-over retry loop, and when a chained hand-over times out in the LAST iteration enqueued (seen only after the wait) it has already run on a
+// state that is not final and runs again behind the un-chained re-run.  A tail that accumulates, consumes a buffer or enqueues once-only work
+// must not be passed here.
 extern "C" __attribute__((visibility("hidden"))) int lvf_problem_solve_then(lvf_problem* p, const lvf_solver_options* o, lvf_solver_summary* summary, int (*tail)(void*), void* user);
 namespace lvf {
 // stable LSD radix sort of (key, value) pairs by the low `key_bits` bits of the key (sort_util.hip)

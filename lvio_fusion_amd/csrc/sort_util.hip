@@ -257,7 +257,7 @@ constexpr int kS1T = 256, kS1E = 8, kS1Tile = kS1T * kS1E;
 template <bool COMPACT>
 __global__ __launch_bounds__(kS1T) void k_scan1(int cap, const int* __restrict__ n_dev, const int* __restrict__ in, int* __restrict__ pos, int* __restrict__ total_out,
                                                 unsigned long long* status, int* ticket, unsigned epoch, int ntiles, const float4* __restrict__ pts,
-                                                float4* __restrict__ out) {
+                                                float4* __restrict__ out, unsigned long long* __restrict__ err) {
   __shared__ int s_tile, s_prefix, s_wave[kS1T / 64];
   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1);
   __syncthreads();
@@ -286,7 +286,10 @@ __global__ __launch_bounds__(kS1T) void k_scan1(int cap, const int* __restrict__
       unsigned polls = 0;
       do {
         st = __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (++polls > (1u << 23)) __builtin_trap();      // (seconds: the status block was corrupted — fail the launch rather than hang the queue)
+        // (seconds without the predecessor's word: the status block was corrupted, or two host threads drove ONE context — tickets are per
+        // context.  The launch is NOT trapped (that would take the queue, i.e. the process, down with it): the sticky error word is raised, this
+        // tile goes on with what it has, and the host's next count read-back of this context fails with LVF_ERR_STATE — read_back())
+        if (++polls > (1u << 23)) { atomicExch(err, ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)(t + 1)); break; }
       } while ((unsigned)(st >> 32) != epoch);
       acc += (int)(unsigned)(st & 0xffffffffull);
     }
@@ -334,9 +337,9 @@ int device_scan1_on(lvf_ctx* ctx, hipStream_t s, int lane, const int* in, int ca
     LVF_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->stream2) LVF_HIP(hipStreamSynchronize(ctx->stream2));
     if (ctx->scan_status) (void)hipFree(ctx->scan_status);
-    ctx->scan_status = nullptr; ctx->scan_tiles = 0;
+    ctx->scan_status = nullptr; ctx->scan_tiles = 0; ctx->scan_err = nullptr;
     const int want = std::max(1024, ntiles + ntiles / 2);
-    const size_t words = (size_t)2 * want + 2;            // [lane][tile] status words, then one ticket word per lane
+    const size_t words = (size_t)2 * want + 3;            // [lane][tile] status words, one ticket word per lane, then the sticky error word
     LVF_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->scan_status), words * sizeof(unsigned long long)));
     // (on the context's stream and waited for: a plain hipMemset goes to the null stream, which a non-blocking stream does not order against —
     // the clear could land in the middle of the launch below, hand a ticket out twice and leave a tile waiting for ever)
@@ -350,12 +353,14 @@ int device_scan1_on(lvf_ctx* ctx, hipStream_t s, int lane, const int* in, int ca
   if (epoch == 0) {          // the counter wrapped: every stale word could match again
     LVF_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->stream2) LVF_HIP(hipStreamSynchronize(ctx->stream2));
-    LVF_HIP(hipMemsetAsync(ctx->scan_status, 0, ((size_t)2 * ctx->scan_tiles + 2) * sizeof(unsigned long long), ctx->stream));
+    LVF_HIP(hipMemsetAsync(ctx->scan_status, 0, ((size_t)2 * ctx->scan_tiles + 3) * sizeof(unsigned long long), ctx->stream));
     LVF_HIP(hipStreamSynchronize(ctx->stream));
     epoch = ctx->scan_epoch = 1;
   }
-  if (pts && out) hipLaunchKernelGGL(k_scan1<true>, dim3(ntiles), dim3(kS1T), 0, s, cap, n_dev, in, pos, total_out, status, ticket, epoch, ntiles, pts, out);
-  else hipLaunchKernelGGL(k_scan1<false>, dim3(ntiles), dim3(kS1T), 0, s, cap, n_dev, in, pos, total_out, status, ticket, epoch, ntiles, pts, out);
+  unsigned long long* err = ctx->scan_status + (size_t)2 * ctx->scan_tiles + 2;
+  ctx->scan_err = err;                  // read_back() looks at it on the next count read-back of this context
+  if (pts && out) hipLaunchKernelGGL(k_scan1<true>, dim3(ntiles), dim3(kS1T), 0, s, cap, n_dev, in, pos, total_out, status, ticket, epoch, ntiles, pts, out, err);
+  else hipLaunchKernelGGL(k_scan1<false>, dim3(ntiles), dim3(kS1T), 0, s, cap, n_dev, in, pos, total_out, status, ticket, epoch, ntiles, pts, out, err);
   LVF_HIP(hipGetLastError());
   return LVF_OK;
 }
