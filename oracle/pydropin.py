@@ -91,15 +91,16 @@ def backend_solve(cam0, cam1, baseline, time, pose, w_visual, good_imu, first_ac
     (a.time, a.pose, a.w_visual, a.good_imu, a.vel, a.ba, a.bg, a.imu_ns, a.imu_samples, a.imu_acc0, a.imu_gyr0, a.pre_ba, a.pre_bg, a.imu_noise4, a.lm_id, a.lm_birth,
      a.lm_inv_depth, a.lm_right_ob, a.obs_lm, a.obs_frame, a.obs_xy) = map(vp, keep)
     pose_o = np.empty((n, 7)); invd_o = np.empty(a.n_lm); vel_o = np.zeros((n, 3)); ba_o = np.zeros((n, 3)); bg_o = np.zeros((n, 3)); s8 = np.zeros(8)
-    msg = C.create_string_buffer(512)
+    msg = C.create_string_buffer(512); t4 = np.zeros(4)
     c0, c1 = _cam(cam0), _cam(cam1)
     L = lib()
     L.lvd_backend_solve.restype = C.c_int
     rc = L.lvd_backend_solve(C.byref(c0), C.byref(c1), C.c_double(baseline), C.byref(a), int(max_num_iterations), vp(pose_o), vp(invd_o), vp(vel_o), vp(ba_o), vp(bg_o), vp(s8),
-                             msg, 512)
+                             msg, 512, vp(t4))
     return dict(rc=rc, pose=pose_o, inv_depth=invd_o, vel=vel_o, ba=ba_o, bg=bg_o, initial_cost=s8[0], final_cost=s8[1], num_successful_steps=int(s8[2]),
                 num_unsuccessful_steps=int(s8[3]), num_residual_blocks=int(s8[4]), termination_type=int(s8[5]), num_frames=int(s8[6]), recorded=bool(s8[7]),
-                message=msg.value.decode(errors="replace"))
+                message=msg.value.decode(errors="replace"),
+                times_ms=dict(object_graph=t4[0], build_problem=t4[1], adapt_solve=t4[2], destroy_and_read_back=t4[3]))
 
 
 def scan_to_map_solve(mode, scan, map_pts, frame_pose, map_pose, para6, w_ground, w_surf, w_visual, n_features_left, relocate, resolution, max_num_iterations):

@@ -136,8 +136,11 @@ const char* lvd_sources(void) {
 // max_num_iterations from the caller, no time cap: parity needs a deterministic iteration count).  The results are read from where the reference
 // keeps them: frame->pose, &landmark->inv_depth, frame->Vw, frame->bias.linearized_{ba,bg}.
 // summary8 = {initial_cost, final_cost, successful steps, unsuccessful steps, residual blocks, termination_type, adapt::Problem::num_frames, recorder usable}
+// times_ms4 (may be null) = {object graph built by this driver, Backend::BuildProblem, adapt::Solve, ~Problem + read-back}
 int lvd_backend_solve(const lvd_camera* c0, const lvd_camera* c1, double baseline, const lvd_input* in, int max_num_iterations, double* pose_out,
-                      double* inv_depth_out, double* vel_out, double* ba_out, double* bg_out, double* summary8, char* message, int message_cap) {
+                      double* inv_depth_out, double* vel_out, double* ba_out, double* bg_out, double* summary8, char* message, int message_cap, double* times_ms4) {
+  const auto tick0 = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   Camera::devices_.clear();
   Camera::Create(c0->fx, c0->fy, c0->cx, c0->cy, SE3d(c0->extrinsic));
   Camera::Create(c1->fx, c1->fy, c1->cx, c1->cy, SE3d(c1->extrinsic));
@@ -194,9 +197,14 @@ int lvd_backend_solve(const lvd_camera* c0, const lvd_camera* c1, double baselin
   std::memset(storage, 0, sizeof(storage));
   Backend* be = reinterpret_cast<Backend*>(storage);
   int rc = 0;
+  const double t_graph = ms_since(tick0);
+  double t_build = 0.0, t_solve = 0.0;
+  const auto tick1 = std::chrono::steady_clock::now();
   {
     adapt::Problem problem;
     be->BuildProblem(active, problem);                  // <- the reference's text, adding gpu:: cost functions through the patched factories
+    t_build = ms_since(tick1);
+    const auto tick2 = std::chrono::steady_clock::now();
     ceres::Solver::Options options;                     // Backend::Optimize, backend.cpp:205-211
     options.linear_solver_type = ceres::SPARSE_SCHUR;
     options.num_threads = num_threads;
@@ -204,6 +212,7 @@ int lvd_backend_solve(const lvd_camera* c0, const lvd_camera* c1, double baselin
     ceres::Solver::Summary summary;
     const bool recorded = problem.recorder.usable(&problem);
     adapt::Solve(options, &problem, &summary);          // <- reference_patch/lvio_fusion/adapt/problem.h: gpu::Solve on the MI355X
+    t_solve = ms_since(tick2);
     summary8[0] = summary.initial_cost; summary8[1] = summary.final_cost; summary8[2] = summary.num_successful_steps; summary8[3] = summary.num_unsuccessful_steps;
     summary8[4] = summary.num_residual_blocks; summary8[5] = (double)summary.termination_type; summary8[6] = problem.num_frames; summary8[7] = recorded ? 1.0 : 0.0;
     if (message && message_cap > 0) { std::strncpy(message, summary.message.c_str(), (size_t)message_cap - 1); message[message_cap - 1] = 0; }
@@ -215,6 +224,7 @@ int lvd_backend_solve(const lvd_camera* c0, const lvd_camera* c1, double baselin
       for (int i = 0; i < 3; ++i) { vel_out[3 * k + i] = frames[k]->Vw[i]; ba_out[3 * k + i] = frames[k]->bias.linearized_ba[i]; bg_out[3 * k + i] = frames[k]->bias.linearized_bg[i]; }
   }
   for (int l = 0; l < in->n_lm; ++l) inv_depth_out[l] = lms[l]->inv_depth;
+  if (times_ms4) { times_ms4[0] = t_graph; times_ms4[1] = t_build; times_ms4[2] = t_solve; times_ms4[3] = ms_since(tick1) - t_build - t_solve; }
   for (auto& f : frames) { f->features_left.clear(); f->last_keyframe.reset(); }
   for (auto& L : lms) { L->observations.clear(); L->first_observation.reset(); }
   return rc;

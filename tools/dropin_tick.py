@@ -30,14 +30,16 @@ def main():
                 lm_id=5000 + np.arange(n_lm), lm_birth=birth, lm_inv_depth=cfg["inv_depth"], lm_right_ob=right, obs_lm=obs_lm, obs_frame=obs_fr, obs_xy=obs_xy,
                 vel=cfg["vel"], ba=cfg["ba"], bg=cfg["bg"], imu=[None] + cfg["imu"], imu_noise=syn.IMU_NOISE)
     pydropin.lib()
-    ts = []
+    ts, parts = [], []
     for _ in range(reps + 1):
         t0 = time.perf_counter()
         out = pydropin.backend_solve(cams["cam0"], cams["cam1"], syn.baseline(), max_num_iterations=1, **args)
-        ts.append(time.perf_counter() - t0)
+        ts.append(time.perf_counter() - t0); parts.append(out["times_ms"])
     assert out["rc"] == 0, out["message"]
     print({"blocks": out["num_residual_blocks"], "recorded": out["recorded"], "cost": [out["initial_cost"], out["final_cost"]],
            "dropin_tick_ms_incl_graph_build_median": 1e3 * float(np.median(ts[1:])), "all_ms": [round(1e3 * t, 2) for t in ts],
+           "parts_ms_median": {k: round(float(np.median([p[k] for p in parts[1:]])), 3) for k in parts[0]},
+           "reference_tick_ms": round(float(np.median([p["build_problem"] + p["adapt_solve"] + p["destroy_and_read_back"] for p in parts[1:]])), 3),
            "note": "python -> ctypes -> the driver builds the reference's object graph (frames, landmarks, features: heap objects, std::map inserts) -> Backend::BuildProblem -> "
                    "adapt::Solve (1 LM iteration on the MI355X) -> read back; LVF_ADAPTER_TIMING=1 prints gpu::Solve's own split"})
 
