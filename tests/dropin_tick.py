@@ -2,7 +2,7 @@
 Backend::BuildProblem (src/backend.cpp:96-183, compiled unmodified into oracle/_ref/liblvf_dropin.so with include/reference_patch ahead of the reference's
 headers) walking its pointer graph — std::map<time, Frame>, std::map<id, Feature>, weak_ptr locks, one heap cost function per block — followed by
 adapt::Solve = gpu::Solve with max_num_iterations = 1, against lvf_window_solve on the same window.  Test infrastructure (it loads oracle/_ref): a tool,
-not a bench.py leg.      python tools/dropin_tick.py [reps]"""
+not a bench.py leg (it lives under tests/ because it loads oracle/_ref).      python tests/dropin_tick.py [reps]"""
 import os
 import sys
 import time
