@@ -122,6 +122,8 @@ def test_compiled_dropin_loads_and_links_the_hip_library():
     from oracle import pydropin
     if not pydropin.available():
         pytest.skip("needs /root/reference at build time")
+    from lvio_fusion_amd import _lib
+    _lib.build(force=False)               # the drop-in links liblvf_hip.so: make sure it exists before `make dropin`
     so = pydropin.build()
     lib = ctypes.CDLL(so)
     for name in ("lvd_backend_solve", "lvd_scan_to_map_solve", "lvd_sources"):
@@ -129,7 +131,6 @@ def test_compiled_dropin_loads_and_links_the_hip_library():
     nm = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
     needed = sorted({l.split()[-1] for l in nm.splitlines() if " lvf_" in l})
     assert "lvf_problem_solve" in needed or any(n.startswith("lvf_problem") for n in needed)
-    from lvio_fusion_amd import _lib
     declared = set(_lib.declared_symbols())
     assert set(needed) <= declared, sorted(set(needed) - declared)
     # the reference's factories resolve to the library's cost functions: no Jet-differentiated TwoFrame / PoseOnly functor is instantiated
