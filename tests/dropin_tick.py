@@ -14,8 +14,9 @@ from lvio_fusion_amd import api, synthetic as syn      # noqa: E402
 from oracle import pydropin                            # noqa: E402
 
 
-def main():
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+def baseline_window_inputs():
+    """the BASELINE window (50 keyframes, 10 000 landmarks, no pre-window landmarks) as the flat arrays oracle/pydropin.backend_solve takes:
+    -> (cfg with float-rounded observations / weights and unit extrinsic quaternions as the reference holds them, cams, kwargs)"""
     cfg = syn.config4_window(n_prewindow=0)
     n_kf, n_lm = cfg["n_kf"], cfg["n_lm"]
     tc, tf = cfg["tc"], cfg["tf"]
@@ -29,6 +30,12 @@ def main():
     args = dict(time=10.0 + 0.5 * np.arange(n_kf), pose=cfg["poses"], w_visual=f32(cfg["w_kf"]), good_imu=np.ones(n_kf, np.uint8), first_active=0, imu_initialized=True,
                 lm_id=5000 + np.arange(n_lm), lm_birth=birth, lm_inv_depth=cfg["inv_depth"], lm_right_ob=right, obs_lm=obs_lm, obs_frame=obs_fr, obs_xy=obs_xy,
                 vel=cfg["vel"], ba=cfg["ba"], bg=cfg["bg"], imu=[None] + cfg["imu"], imu_noise=syn.IMU_NOISE)
+    return cfg, cams, args
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    cfg, cams, args = baseline_window_inputs()
     pydropin.lib()
     ts, parts = [], []
     for _ in range(reps + 1):

@@ -84,7 +84,7 @@ def _oracle_window(oracle, drive, lists, first, t, pre):
 
 
 @pytest.mark.parametrize("with_imu", [True, False])
-@pytest.mark.parametrize("t", [3, 7, 11])
+@pytest.mark.parametrize("t", [0, 1, 3, 7, 11])      # t = 0: a one-keyframe window (TwoCamera blocks + the weak-constraint PoseError only)
 def test_build_problem_and_solve_from_the_reference_text(dropin, oracle, with_imu, t):
     from lvio_fusion_amd import api
     K = 4
@@ -165,3 +165,46 @@ def test_scan_to_map_from_the_reference_text(dropin, oracle, mode, relocate):
     assert np.allclose(out["para"], ref_x, rtol=1e-6, atol=1e-9)
     assert abs(out["final_cost"] - ref["final_cost"]) <= 1e-6 * abs(ref["final_cost"])
     m.close(); sc.close(); ctx.close()
+
+
+def test_baseline_window_through_the_reference_text(dropin):
+    """the BASELINE window itself (50 keyframes, 10 000 landmarks, 81 839 residual blocks): the reference's own Backend::BuildProblem -> adapt::Solve
+    (3 LM iterations on the MI355X) against lvf_problem_solve on the flat batches of the same blocks"""
+    from lvio_fusion_amd import api
+    from tests.dropin_tick import baseline_window_inputs
+    K = 3
+    cfg, cams, args = baseline_window_inputs()
+    out = dropin.backend_solve(cams["cam0"], cams["cam1"], syn.baseline(), max_num_iterations=K, **args)
+    assert out["rc"] == 0, out["message"]
+    assert out["recorded"] and out["num_frames"] == cfg["n_kf"]
+    f32 = lambda x: np.asarray(x, np.float32).astype(np.float64)
+    tc, tf = cfg["tc"], cfg["tf"]
+    # BuildProblem's block census (backend.cpp:112-178): a TwoCamera block per landmark at its birth keyframe, a TwoFrame block per later observation,
+    # an ImuError per consecutive pair, and ONE weak-constraint PoseError: keyframe 0 has no ImuError yet and no VisualError block when it is checked
+    assert out["num_residual_blocks"] == len(tc["lm_idx"]) + len(tf["lm_idx"]) + (cfg["n_kf"] - 1) + 1
+    ctx = api.Context(0)
+    c2 = dict(cfg); c2["cam0"], c2["cam1"] = cams["cam0"], cams["cam1"]
+    pre = api.preintegrate_or_none(ctx, c2)
+    st = api.State(ctx, cfg["n_kf"], cfg["n_lm"])
+    for field, val in ((api.POSES, cfg["poses"]), (api.VEL, cfg["vel"]), (api.BA, cfg["ba"]), (api.BG, cfg["bg"]), (api.INV_DEPTH, cfg["inv_depth"]), (api.W_VISUAL, f32(cfg["w_kf"]))):
+        st.set(field, val)
+    o = np.argsort(tc["kf_idx"], kind="stable")
+    hs = [api.two_camera_batch(ctx, cams["cam0"], cams["cam1"], f32(tc["left_ob"])[o], f32(tc["right_ob"])[o], tc["lm_idx"][o], tc["kf_idx"][o]),
+          api.two_frame_batch(ctx, cams["cam0"], cams["cam1"], f32(tf["first_ob"]), f32(tf["ob"]), tf["lm_idx"], tf["kf1_idx"], tf["kf2_idx"]),
+          None, api.imu_batch(ctx, pre, [f["kf_i"] for f in cfg["imu"]], [f["kf_j"] for f in cfg["imu"]])]
+    prob = api.Problem(ctx, st, *hs)
+    bpr = api.pose_prior_batch(ctx, [-1], [0], np.array([cfg["poses"][0]]), np.array([100.0]), np.array([0.0]))
+    prob.set_pose_priors(bpr)
+    opt = api.default_solver_options(); opt.max_num_iterations = K
+    s = prob.solve(opt)
+    assert out["num_successful_steps"] == s.num_successful_steps and s.num_successful_steps >= 2
+    assert abs(out["initial_cost"] - s.initial_cost) <= 1e-7 * s.initial_cost and abs(out["final_cost"] - s.final_cost) <= 1e-6 * s.final_cost
+    assert_parity(out["pose"], st.get(api.POSES).reshape(-1, 7), "poses")
+    assert_parity(out["inv_depth"], st.get(api.INV_DEPTH), "inverse depths")
+    assert_parity(out["vel"], st.get(api.VEL).reshape(-1, 3), "velocities")
+    assert_parity(out["ba"], st.get(api.BA).reshape(-1, 3), "ba"); assert_parity(out["bg"], st.get(api.BG).reshape(-1, 3), "bg")
+    prob.close(); bpr.close()
+    for h in hs + [st]:
+        if h is not None:
+            h.close()
+    ctx.close()
