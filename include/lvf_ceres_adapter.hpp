@@ -68,7 +68,7 @@ inline ThreadContext& thread_context() {
   return tc;
 }
 
-enum class Kind { PoseOnly, TwoFrame, TwoCamera, Imu, LidarPlaneRPZ, LidarPlaneYXY, PoseErrorRPZ, PoseErrorYXY, PoseGraph, Pose, R };
+enum class Kind { PoseOnly, TwoFrame, TwoCamera, Imu, LidarPlaneRPZ, LidarPlaneYXY, PoseErrorRPZ, PoseErrorYXY, PoseGraph, Pose, R, RelocateR };
 
 // RAII for the C handles used inside one call
 struct Handles {
@@ -393,6 +393,21 @@ class RError : public ceres::SizedCostFunction<4, 7>, public GpuCostFunction {
   }
   double origin[7];
   double weight;
+};
+
+// RelocateRError <7,4>  pose_error.hpp:192-222 ; Create(relocated, unrelocated) :215 — the blocks of Relocator::UpdateNewSubmap's rotation solve
+// (src/relocator.cpp:258-264: one quaternion parameter block under EigenQuaternionParameterization, one block per keyframe of the new sub-map)
+class RelocateRError : public ceres::SizedCostFunction<7, 4>, public GpuCostFunction {
+ public:
+  RelocateRError(const double relocated_[7], const double unrelocated_[7]) { std::memcpy(relocated, relocated_, 56); std::memcpy(unrelocated, unrelocated_, 56); }
+  static ceres::CostFunction* Create(const double relocated[7], const double unrelocated[7]) { return new RelocateRError(relocated, unrelocated); }
+  Kind kind() const override { return Kind::RelocateR; }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    ThreadContext& tc = thread_context();
+    if (!tc.ctx) return false;
+    return lvf_relocate_r_evaluate(tc.ctx, 1, relocated, unrelocated, parameters[0], residuals, (jacobians && jacobians[0]) ? jacobians[0] : nullptr) == LVF_OK;
+  }
+  double relocated[7], unrelocated[7];
 };
 
 // --------------------------------------------------------------------------------------------- problem -> device
@@ -906,6 +921,40 @@ inline void to_lvf_options(const ceres::Solver::Options& o, double huber, lvf_so
   out->min_relative_decrease = o.min_relative_decrease;
 }
 
+// ---- Relocator::UpdateNewSubmap's rotation solve (relocator.cpp:251-268): N x RelocateRError on ONE quaternion block (x, y, z, w) under
+// EigenQuaternionParameterization, no loss; the whole LM loop is one device launch (lvf_relocate_rotation_solve), the quaternion is updated in place
+inline bool solve_relocate_rotation(const ceres::Solver::Options& options, ceres::Problem* problem, const std::vector<BlockView>& blocks,
+                                    ceres::Solver::Summary* summary, const Fail& fail) {
+  ThreadContext& tc = thread_context();
+  if (!tc.ctx) return fail("no device context: " + tc.error);
+  double* q = blocks[0].params[0];
+  std::vector<double> rel(7 * blocks.size()), un(7 * blocks.size());
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    if (blocks[i].g->kind() != Kind::RelocateR) return fail("RelocateRError blocks mixed with other cost functions");
+    if (blocks[i].params[0] != q) return fail("RelocateRError blocks on different parameter blocks");
+    if (blocks[i].loss) return fail("a loss function on a RelocateRError block");
+    const RelocateRError* e = static_cast<const RelocateRError*>(blocks[i].g);
+    std::memcpy(&rel[7 * i], e->relocated, 56); std::memcpy(&un[7 * i], e->unrelocated, 56);
+  }
+  if (problem->ParameterBlockSize(q) != 4 || problem->GetParameterization(q) == nullptr) return fail("the rotation block must be a 4-block with EigenQuaternionParameterization");
+  if (problem->IsParameterBlockConstant(q)) {
+    summary->termination_type = ceres::CONVERGENCE; summary->num_residual_blocks = (int)blocks.size(); summary->num_residual_blocks_reduced = 0;
+    summary->num_successful_steps = summary->num_unsuccessful_steps = 0; summary->message = "constant block"; return true;
+  }
+  lvf_solver_options o;
+  to_lvf_options(options, 0.0, &o);
+  lvf_solver_summary s;
+  if (lvf_relocate_rotation_solve(tc.ctx, (int)blocks.size(), rel.data(), un.data(), q, &o, &s) != LVF_OK) return fail(lvf_last_error());
+  summary->initial_cost = s.initial_cost; summary->final_cost = s.final_cost;
+  summary->num_successful_steps = s.num_successful_steps; summary->num_unsuccessful_steps = s.num_unsuccessful_steps;
+  summary->num_residual_blocks = summary->num_residual_blocks_reduced = (int)blocks.size();
+  summary->num_parameter_blocks = summary->num_parameter_blocks_reduced = 1;
+  if (s.termination == 2) return fail("the rotation solve failed (five invalid steps in a row)");
+  summary->termination_type = s.termination == 0 ? ceres::CONVERGENCE : ceres::NO_CONVERGENCE;
+  summary->message = "lvf_relocate_rotation_solve";
+  return true;
+}
+
 inline bool solve_window(const ceres::Solver::Options& options, ceres::Problem* problem, const Window& w,
                          ceres::Solver::Summary* summary, const Fail& fail, double classify_seconds) {
   ThreadContext& tc = thread_context();
@@ -977,7 +1026,7 @@ class Recorder {
     const GpuCostFunction* g = detail::as_gpu(cost_function, cache_);
     if (!g) { usable_ = false; return; }
     const Kind k = g->kind();
-    if (k == Kind::LidarPlaneRPZ || k == Kind::LidarPlaneYXY || k == Kind::PoseErrorRPZ || k == Kind::PoseErrorYXY) { usable_ = false; return; }   // scan-to-map problems: a few thousand blocks, walked
+    if (k == Kind::LidarPlaneRPZ || k == Kind::LidarPlaneYXY || k == Kind::PoseErrorRPZ || k == Kind::PoseErrorYXY || k == Kind::RelocateR) { usable_ = false; return; }   // scan-to-map / rotation problems: few blocks, walked
     if (!builder_.add(i, g, loss_function, parameter_blocks)) usable_ = false;
   }
   void SetParameterBlockConstant(double* values) { constant_.insert(values, 1); }
@@ -1024,6 +1073,7 @@ inline void Solve(const ceres::Solver::Options& options, ceres::Problem* problem
     summary->message = "empty problem";
     return;
   }
+  if (blocks[0].g->kind() == Kind::RelocateR) { detail::solve_relocate_rotation(options, problem, blocks, summary, fail); summary->total_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); return; }
   bool lidar = false;
   for (const auto& b : blocks) {
     const Kind k = b.g->kind();

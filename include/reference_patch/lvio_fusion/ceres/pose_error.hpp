@@ -1,19 +1,21 @@
 // reference_patch/lvio_fusion/ceres/pose_error.hpp — shadows src/lvio_fusion/include/lvio_fusion/ceres/pose_error.hpp on the include path.
 // PoseGraphError::Create (:40-49, both overloads), PoseError::Create (:78-81), RError::Create (:103-106), PoseErrorRPZ::Create (:155-158) and
-// PoseErrorYXY::Create (:183-186) return the MI355X library's tagged cost functions; TError and RelocateRError (solved by
-// lvf_relocate_rotation_solve in this library, relocator.cpp:247-282) keep the reference's host classes.
+// PoseErrorYXY::Create (:183-186) and RelocateRError::Create (:215-218: the blocks of Relocator::UpdateNewSubmap's rotation solve, which gpu::Solve
+// runs as ONE device launch, lvf_relocate_rotation_solve) return the MI355X library's tagged cost functions; TError keeps the reference's host class.
 #pragma once
 #define PoseGraphError PoseGraphError_host
 #define PoseError PoseError_host
 #define RError RError_host
 #define PoseErrorRPZ PoseErrorRPZ_host
 #define PoseErrorYXY PoseErrorYXY_host
+#define RelocateRError RelocateRError_host
 #include_next "lvio_fusion/ceres/pose_error.hpp"
 #undef PoseGraphError
 #undef PoseError
 #undef RError
 #undef PoseErrorRPZ
 #undef PoseErrorYXY
+#undef RelocateRError
 
 #include "lvf_ceres_adapter.hpp"
 
@@ -71,6 +73,16 @@ public:
     static ceres::CostFunction *Create(double *rpyxyz, double weight = 1)
     {
         return gpu::PoseErrorYXY::Create(rpyxyz, weight);
+    }
+};
+
+class RelocateRError : public RelocateRError_host
+{
+public:
+    using RelocateRError_host::RelocateRError_host;
+    static ceres::CostFunction *Create(SE3d relocated, SE3d unrelocated)
+    {
+        return gpu::RelocateRError::Create(relocated.data(), unrelocated.data());
     }
 };
 

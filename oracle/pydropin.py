@@ -116,3 +116,36 @@ def scan_to_map_solve(mode, scan, map_pts, frame_pose, map_pose, para6, w_ground
     rc = L.lvd_scan_to_map_solve(int(mode), vp(scan), len(scan), vp(map_pts), len(map_pts), vp(fp), vp(mp), vp(para), C.c_double(w_ground), C.c_double(w_surf),
                                  C.c_double(w_visual), int(n_features_left), int(bool(relocate)), C.c_double(resolution), int(max_num_iterations), vp(s4), msg, 512)
     return dict(rc=rc, para=para, final_cost=s4[0], num_residual_blocks_reduced=int(s4[1]), termination_type=int(s4[2]), n_lidar=int(s4[3]), message=msg.value.decode(errors="replace"))
+
+
+# ---- the reference's CONTROL code on the GPU: mapping.cpp, pose_graph.cpp, relocator.cpp compiled unmodified into this library too (ceres::Solve =
+# gpu::Solve).  Same entry points and marshalling as oracle/pyref.py's CPU pins (oracle/ref_driver_mapping.cpp serves both builds).
+def _through_dropin(fn_name, *args, **kw):
+    from . import pyref
+    saved = pyref._lib
+    pyref._lib = lib()
+    try:
+        return getattr(pyref, fn_name)(*args, **kw)
+    finally:
+        pyref._lib = saved
+
+
+def mapping_optimize(*a, **k):
+    """Mapping::Optimize (mapping.cpp:139-191) from the reference's text, every adapt::Solve on the MI355X"""
+    return _through_dropin("mapping_optimize", *a, **k)
+
+
+def mapping_relocate(*a, **k):
+    """Mapping::Relocate (mapping.cpp:251-300) from the reference's text, every ceres::Solve on the MI355X"""
+    return _through_dropin("mapping_relocate", *a, **k)
+
+
+def pose_graph_optimize(*a, **k):
+    """PoseGraph::BuildProblem + Optimize (pose_graph.cpp:163-224) from the reference's text, ceres::Solve on the MI355X"""
+    return _through_dropin("pose_graph_optimize", *a, **k)
+
+
+def update_new_submap(*a, **k):
+    """Relocator::UpdateNewSubmap (relocator.cpp:247-282) from the reference's text: RelocateRError::Create -> gpu::RelocateRError, ceres::Solve ->
+    lvf_relocate_rotation_solve"""
+    return _through_dropin("update_new_submap", *a, **k)

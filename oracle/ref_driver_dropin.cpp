@@ -53,7 +53,8 @@
 #undef private
 #undef protected
 
-// the reference calls ceres::Solve directly at mapping.cpp:277,291 / pose_graph.cpp:206 (not compiled into this library yet): it is the GPU here too
+// the reference calls ceres::Solve directly at mapping.cpp:277,291, pose_graph.cpp:206 and relocator.cpp:270 (all compiled into this library,
+// driven by ref_driver_mapping.cpp with -DLVF_DROPIN_BUILD): it is the GPU here too
 namespace ceres {
 void Solve(const Solver::Options& options, Problem* problem, Solver::Summary* summary) { lvio_fusion::gpu::Solve(options, problem, summary, nullptr); }
 }  // namespace ceres
@@ -69,22 +70,13 @@ Frame::Frame() : id(0), time(0) {}                                              
 Vector3d Frame::t() { std::abort(); }
 // ---- referenced by functions of backend.cpp / association.cpp that the driver never calls; their homes are not compiled here
 void Frame::RemoveFeature(visual::Feature::Ptr) { std::abort(); }                         // src/frame.cpp
-void Frontend::UpdateCache() { std::abort(); }                                            // src/frontend.cpp
+void Frontend::UpdateCache() {}                                                           // src/frontend.cpp (not on the path; PoseGraph::ForwardUpdate calls it)
 void Frontend::UpdateImu(const Bias&) { std::abort(); }
 void Initializer::Initialize(double, double) { std::abort(); }                            // src/initializer.cpp
-Frame::Ptr Map::GetKeyFrame(double) { std::abort(); }                                     // src/map.cpp
 SE3d Map::ComputePose(double) { std::abort(); }
-Frames Map::GetKeyFrames(double, double, int) { std::abort(); }
-void Mapping::Optimize(Frames&) { std::abort(); }                                         // src/mapping.cpp
-void Mapping::ToWorld(Frame::Ptr) { std::abort(); }
-void Mapping::ToWorld(double) { std::abort(); }
 std::vector<Navsat::Ptr> Navsat::devices_;                                                // src/navsat.cpp
 void Navsat::Optimize(const Section&) { std::abort(); }
 void Navsat::QuickFix(double, double) { std::abort(); }
-bool PoseGraph::AddSection(double) { std::abort(); }                                      // src/pose_graph.cpp
-void PoseGraph::ForwardUpdate(SE3d, double, bool) { std::abort(); }
-void PoseGraph::ForwardUpdate(SE3d, const Frames&) { std::abort(); }
-Atlas PoseGraph::GetSections(double, double) { std::abort(); }
 namespace imu {
 void RePredictVel(Frames&, Frame::Ptr&) { std::abort(); }                                 // src/tools.cpp
 void RecoverBias(Frames&) { std::abort(); }

@@ -35,7 +35,9 @@
 #include <Eigen/Core>
 #include <Eigen/Geometry>
 #include <ceres/ceres.h>
-#include <ceres/solve_shim.h>
+#ifndef LVF_DROPIN_BUILD
+#include <ceres/solve_shim.h>      // the CPU pin: ceres::Solve = the declared LM loop.  (The compiled drop-in defines ceres::Solve as gpu::Solve: ref_driver_dropin.cpp.)
+#endif
 #include <opencv2/opencv.hpp>
 #include <pcl/common/common_headers.h>
 #include <pcl/common/io.h>
@@ -203,7 +205,11 @@ void lvr_pose_graph_optimize(int n, const double* time, const double* pose, cons
   {
     adapt::Problem problem;
     PoseGraph::Instance().BuildProblem(sections, submap, problem);      // <- the reference's text
+#ifdef LVF_DROPIN_BUILD
+    counts3[0] = problem.NumResidualBlocks(); counts3[1] = problem.NumParameterBlocks(); counts3[2] = problem.num_frames;      // (distinct blocks: old, start, sections)
+#else
     counts3[0] = problem.NumResidualBlocks(); counts3[1] = (int)problem.recorded_parameter_blocks().size(); counts3[2] = problem.num_frames;
+#endif
     if (start_after) lvio_fusion::Map::Instance().GetKeyFrame(submap_B)->pose = SE3d(start_after);
     PoseGraph::Instance().Optimize(sections, submap, problem);          // <- the reference's text (ceres::Solve = solve_shim.h)
   }
@@ -234,6 +240,7 @@ void lvr_update_new_submap(int n, const double* time, const double* pose, const 
   for (auto& f : frames) f->loop_closure.reset();
 }
 
+#ifndef LVF_DROPIN_BUILD
 // ceres::Solve of the stand-in on a scan-to-map problem built by the reference's text (mode 0 / 1), for a direct comparison with oracle/icp.h's loop
 void lvr_scan_to_map_solve(int mode, const float* scan, int n_scan, const float* map, int n_map, const double* frame_pose, const double* map_pose, double* para6,
                            double w_ground, double w_surf, double w_visual, int n_features_left, int relocate, double resolution, int max_num_iterations, double* summary6) {
@@ -256,5 +263,7 @@ void lvr_scan_to_map_solve(int mode, const float* scan, int n_scan, const float*
   summary6[0] = summary.initial_cost; summary6[1] = summary.final_cost; summary6[2] = summary.num_residual_blocks_reduced; summary6[3] = summary.num_iterations;
   summary6[4] = summary.num_successful_steps; summary6[5] = (double)summary.termination_type;
 }
+
+#endif
 
 }  // extern "C"

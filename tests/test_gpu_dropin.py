@@ -208,3 +208,53 @@ def test_baseline_window_through_the_reference_text(dropin):
         if h is not None:
             h.close()
     ctx.close()
+
+
+# ---- the reference's CONTROL code (mapping.cpp, pose_graph.cpp, relocator.cpp: compiled unmodified into the drop-in library as well) with every
+# ceres::Solve / adapt::Solve on the MI355X, against what the SAME text left behind on the CPU with the declared LM loop (tests/golden/ref_v5.npz)
+def _r5():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_v5.npz"))
+
+
+def _close(a, b, tol=1e-6):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return a.shape == b.shape and np.all(np.abs(a - b) <= tol * (1e-3 + np.abs(b)))
+
+
+def test_mapping_optimize_from_the_reference_text_on_the_gpu(dropin):
+    from tests import mapping_replay as mr
+    c = mr.optimize_case()
+    r = dropin.mapping_optimize(c["time"], c["pose"], c["ground"], c["surf"], c["first_active"], c["w_ground"], c["w_surf"], c["w_visual"], c["n_features_left"])
+    R5 = _r5()
+    assert _close(r["pose"], R5["optimize_pose"]), np.abs(r["pose"] - R5["optimize_pose"]).max(axis=1)
+    assert np.array_equal(r["world_counts"], R5["optimize_world_counts"])
+
+
+@pytest.mark.parametrize("name,kw", (("relocate", {}), ("relocate_sparse", dict(seed=0x0A75, keep=(140, 260))), ("relocate_poor", dict(seed=0x0A76, keep=(30, 45)))))
+def test_mapping_relocate_from_the_reference_text_on_the_gpu(dropin, name, kw):
+    from tests import mapping_replay as mr
+    c = mr.relocate_case(**kw)
+    r = dropin.mapping_relocate(c["time"], c["pose"], c["ground"], c["surf"], c["old_index"], c["cur_ground"], c["cur_surf"], c["cur_pose"], c["rel_in"],
+                                c["w_ground"], c["w_surf"], c["w_visual"])
+    R5 = _r5()
+    assert r["score"] == int(R5[name + "_score"])
+    assert _close(r["relative_o_c"], R5[name + "_relative_o_c"]) and np.array_equal(r["map_counts"], R5[name + "_map_counts"])
+
+
+def test_pose_graph_optimize_from_the_reference_text_on_the_gpu(dropin):
+    from tests import mapping_replay as mr
+    c = mr.pose_graph_case()
+    r = dropin.pose_graph_optimize(c["time"], c["pose"], c["vw"], c["section_A"], c["submap_A"], c["submap_B"], c["start_after"])
+    R5 = _r5()
+    assert _close(r["pose"], R5["pose_graph_pose"]), np.abs(r["pose"] - R5["pose_graph_pose"]).max(axis=1)
+    assert _close(r["vw"], R5["pose_graph_vw"])
+    ns = len(c["section_A"])
+    assert r["counts"] == (2 * ns + 1, ns + 2, ns + 2)
+
+
+def test_update_new_submap_from_the_reference_text_on_the_gpu(dropin):
+    from tests import mapping_replay as mr
+    c = mr.submap_case()
+    P = dropin.update_new_submap(c["time"], c["pose"], c["old_pose"], c["relative_o_c"], c["best"])
+    assert _close(P, _r5()["submap_pose"]), np.abs(P - _r5()["submap_pose"]).max(axis=1)
