@@ -153,6 +153,10 @@ def main():
                          "branch (timing all-gather, solo reference, sharded relocalisation + gather) with every rank on the visible GPU(s) round-robin and CPU tensors in "
                          "the collectives — a correctness dry run on a 1-GPU box, never a scaling figure")
     ap.add_argument("--legs-file", default=os.path.join(ROOT, "bench_legs.json"), help="where the full record goes (the stdout line is the compact one)")
+    ap.add_argument("--check-lvf-comm", action="store_true",
+                    help="--gpus > 1, nccl: also push the gathered table through the C-ABI communicator (lvf_comm_*: the library dlopens /opt/rocm's RCCL) and compare.  "
+                         "Off by default: torch brings its own RCCL into the process, and two RCCL builds in one process have been seen to refuse ncclCommInitRank "
+                         "(tests/test_gpu_comm_world2.py exercises lvf_comm_* in torch-free processes instead)")
     ap.add_argument("--fail-rank", type=int, default=-1, help="test hook: this rank raises inside its share of the relocalisation leg (the collective must still complete)")
     ap.add_argument("--legs", default="all", help="comma list of legs to run (default all): batched_windows_8,batched_windows_16,batched_windows_64,small_windows_100,pose_only_K1,icp,scan_match_frame,map_maintenance,window_tick,ceres_surface_solve,relocalize_8_candidates")
     args = ap.parse_args()
@@ -331,7 +335,7 @@ def main():
     # what the N > 1 record proves about itself: ranks the process group saw, one device UUID per rank, a checksum of the
     # gathered table — and, on the product backend, the same table once more through the C-ABI communicator (lvf_comm_*: RCCL opened by the library)
     if world > 1:
-        seen = ranks_seen(api, ctx, dist, torch, rank, world, local_rank, coll_dev, gloo, rec if not args.no_extras else None)
+        seen = ranks_seen(api, ctx, dist, torch, rank, world, local_rank, coll_dev, gloo, rec if not args.no_extras else None, args.check_lvf_comm)
         if rank == 0:
             out["ranks_seen"] = seen
     for h in (prob, st0) + tuple(handles):
@@ -442,7 +446,7 @@ def compact_line(out):
     return _r(line, 5)
 
 
-def ranks_seen(api, ctx, dist, torch, rank, world, local_rank, coll_dev, gloo, table):
+def ranks_seen(api, ctx, dist, torch, rank, world, local_rank, coll_dev, gloo, table, check_lvf_comm=False):
     """Collective on every rank.  Returns (rank 0) {group_world_size, backend, device_uuids[rank], distinct_devices, table_crc32, lvf_comm{...}}."""
     import threading
     import zlib
@@ -462,6 +466,9 @@ def ranks_seen(api, ctx, dist, torch, rank, world, local_rank, coll_dev, gloo, t
         seen["table_rows"] = int(np.asarray(table).reshape(-1, 9).shape[0])
     if gloo:
         seen["lvf_comm"] = {"skipped": "gloo dry run: RCCL refuses two ranks on one device"}
+        return seen
+    if not check_lvf_comm:
+        seen["lvf_comm"] = {"skipped": "--check-lvf-comm not given (two RCCL builds in one process: see --help); covered by tests/test_gpu_comm_world2.py"}
         return seen
     # the C-ABI communicator: rank 0's unique id travels over the process group; bounded (a wedged RCCL init must not take the line down)
     res = {}
