@@ -149,3 +149,8 @@ def update_new_submap(*a, **k):
     """Relocator::UpdateNewSubmap (relocator.cpp:247-282) from the reference's text: RelocateRError::Create -> gpu::RelocateRError, ceres::Solve ->
     lvf_relocate_rotation_solve"""
     return _through_dropin("update_new_submap", *a, **k)
+
+
+def environment_optimize(*a, **k):
+    """Environment::Optimize (environment.cpp:18-115) from the reference's text, adapt::Solve on the MI355X"""
+    return _through_dropin("environment_optimize", *a, **k)

@@ -413,3 +413,17 @@ def scan_to_map_solve(mode, scan, map_pts, frame_pose, map_pose, para6, w_ground
     lib().lvr_scan_to_map_solve(int(mode), vp(scan), len(scan), vp(map_pts), len(map_pts), _p(fp), _p(mp), _p(para), C.c_double(w_ground), C.c_double(w_surf),
                                 C.c_double(w_visual), int(n_features_left), int(bool(relocate)), C.c_double(resolution), int(max_num_iterations), _p(s6))
     return para, dict(initial_cost=s6[0], final_cost=s6[1], num_residual_blocks=int(s6[2]), num_iterations=int(s6[3]), num_successful_steps=int(s6[4]), termination=int(s6[5]))
+
+
+def environment_optimize(cam0, cam1, baseline, pose3, vel3, ba3, bg3, w_visual, samples, acc0, gyr0, noise4, inv_depth, right_ob, left_ob):
+    """Environment::Optimize (environment.cpp:18-115) on frames [birth, last, cur]: returns cur's pose after the solve (the lidar half is inert: mapping == null)."""
+    def cam(c):
+        return _f64(np.concatenate([[c["fx"], c["fy"], c["cx"], c["cy"]], c["extrinsic"]]))
+    c0, c1 = cam(cam0), cam(cam1)
+    pose3, vel3, ba3, bg3 = _f64(pose3), _f64(vel3), _f64(ba3), _f64(bg3)
+    samples = _f64(samples).reshape(-1, 7); acc0, gyr0, noise4 = _f64(acc0), _f64(gyr0), _f64(noise4)
+    inv_depth, right_ob, left_ob = _f64(inv_depth), _f64(right_ob), _f64(left_ob)
+    out = np.empty(7)
+    lib().lvr_environment_optimize(_p(c0), _p(c1), C.c_double(baseline), _p(pose3), _p(vel3), _p(ba3), _p(bg3), C.c_double(w_visual), len(samples), _p(samples), _p(acc0),
+                                   _p(gyr0), _p(noise4), len(inv_depth), _p(inv_depth), _p(right_ob), _p(left_ob), _p(out))
+    return out

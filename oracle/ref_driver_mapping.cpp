@@ -3,6 +3,8 @@
 //                                                          :193-220, Relocate :251-300 — the whole file is compiled, UNMODIFIED)
 //   /root/reference/src/lvio_fusion/src/pose_graph.cpp   (PoseGraph::BuildProblem :163-199, Optimize :201-224, ForwardUpdate :227-252)
 //   /root/reference/src/lvio_fusion/src/relocator.cpp    (Relocator::UpdateNewSubmap :247-282)
+//   /root/reference/src/lvio_fusion/src/environment.cpp  (Environment::Optimize :18-115 — the third adapt::Solve call site: one free pose, PoseOnly blocks,
+//                                                          one ImuError whose other seven parameter blocks are constant)
 // as translation units of their own (oracle/Makefile) against the stand-in third-party headers of oracle/ref_shim/.  ceres::Solve is the DECLARED
 // Levenberg-Marquardt loop (ref_shim/ceres/solve_shim.h, included HERE and nowhere else) over the recording ceres::Problem, so the reference's
 // outer loops run END TO END: four passes x {ground, surf} of Mapping::Relocate with its score arithmetic, the per-keyframe chain of Mapping::Optimize
@@ -45,6 +47,11 @@
 
 #define private public
 #define protected public
+#include "lvio_fusion/adapt/environment.h"
+#include "lvio_fusion/visual/camera.h"
+#include "lvio_fusion/visual/feature.h"
+#include "lvio_fusion/visual/landmark.h"
+#include "lvio_fusion/ceres/imu_error.hpp"
 #include "lvio_fusion/frontend.h"
 #include "lvio_fusion/lidar/association.h"
 #include "lvio_fusion/lidar/lidar.h"
@@ -77,6 +84,8 @@ void se32rpyxyz(const SE3d relative_i_j, double* rpyxyz) { ceres::SE3ToRpyxyz<do
 SE3d rpyxyz2se3(const double* rpyxyz) { double se3[7]; ceres::RpyxyzToSE3<double>(rpyxyz, se3); return SE3d(se3); }
 // ---- referenced by a function of pose_graph.cpp this driver never calls (PoseGraph::AddSection); its home, src/utility.cpp, is not compiled
 double vectors_degree_angle(Vector3d, Vector3d) { std::abort(); }
+// ---- referenced by Environment::Step (never called here); its home, src/frame.cpp, is not compiled
+Observation Frame::GetObservation() { std::abort(); }
 }  // namespace lvio_fusion
 
 using namespace lvio_fusion;
@@ -238,6 +247,64 @@ void lvr_update_new_submap(int n, const double* time, const double* pose, const 
   reinterpret_cast<Relocator*>(storage)->UpdateNewSubmap(frames[(size_t)best], kfs);      // <- the reference's text
   for (int k = 0; k < n; ++k) std::memcpy(pose_out + 7 * k, frames[(size_t)k]->pose.data(), 7 * sizeof(double));
   for (auto& f : frames) f->loop_closure.reset();
+}
+
+// Environment::Optimize (environment.cpp:18-115) on ONE keyframe `cur` with its predecessor `last`: PoseOnlyReprojectionError blocks for every feature of
+// `cur` (world point = Landmark::ToWorld of a landmark born in frame `birth`), one ImuError (last -> cur) with every block but cur's pose constant, HuberLoss(1),
+// ceres defaults (50 iterations), DENSE_QR; estimator_->mapping is null (the lidar half computes a local rpyxyz it never applies: environment.cpp:78-110).
+// frames: [birth, last, cur] poses / vel / ba / bg; samples [ns][7] of the (last -> cur) pre-integration.  pose_out[7] = the returned pose.
+void lvr_environment_optimize(const double* cam0_11, const double* cam1_11, double baseline, const double* pose3x7, const double* vel3x3, const double* ba3x3,
+                              const double* bg3x3, double w_visual, int ns, const double* samples, const double* acc0, const double* gyr0, const double* noise4,
+                              int n_lm, const double* inv_depth, const double* right_ob, const double* left_ob, double* pose_out) {
+  Camera::devices_.clear();
+  Camera::Create(cam0_11[0], cam0_11[1], cam0_11[2], cam0_11[3], SE3d(cam0_11 + 4));
+  Camera::Create(cam1_11[0], cam1_11[1], cam1_11[2], cam1_11[3], SE3d(cam1_11 + 4));
+  Camera::baseline = baseline;
+  Imu::devices_.clear();
+  Imu::Create(SE3d(), 0, 0, 0, 0, 9.81007);
+  { Imu::Ptr d = Imu::Get(); d->ACC_N = noise4[0]; d->GYR_N = noise4[1]; d->ACC_W = noise4[2]; d->GYR_W = noise4[3]; d->initialized = true; }
+  Frame::Ptr fr[3];
+  for (int k = 0; k < 3; ++k) {
+    fr[k] = Frame::Ptr(new Frame());
+    fr[k]->id = (unsigned long)(k + 1); fr[k]->time = 30.0 + 0.5 * k; fr[k]->pose = SE3d(pose3x7 + 7 * k);
+    fr[k]->weights.visual = w_visual; fr[k]->good_imu = true;
+    fr[k]->Vw = Vector3d(vel3x3[3 * k], vel3x3[3 * k + 1], vel3x3[3 * k + 2]);
+    fr[k]->bias = Bias(Vector3d(ba3x3[3 * k], ba3x3[3 * k + 1], ba3x3[3 * k + 2]), Vector3d(bg3x3[3 * k], bg3x3[3 * k + 1], bg3x3[3 * k + 2]));
+    if (k > 0) fr[k]->last_keyframe = fr[k - 1];
+  }
+  fr[2]->preintegration = imu::Preintegration::Create(fr[1]->bias);
+  {
+    const Vector3d a0(acc0[0], acc0[1], acc0[2]), g0(gyr0[0], gyr0[1], gyr0[2]);
+    for (int s_ = 0; s_ < ns; ++s_) { const double* q = samples + 7 * s_; fr[2]->preintegration->Append(q[0], Vector3d(q[1], q[2], q[3]), Vector3d(q[4], q[5], q[6]), a0, g0); }
+  }
+  std::vector<visual::Landmark::Ptr> lms((size_t)n_lm);
+  for (int l = 0; l < n_lm; ++l) {
+    visual::Landmark::Ptr L = visual::Landmark::Create(inv_depth[l]);
+    L->id = (unsigned long)(7000 + l);
+    cv::KeyPoint kr(cv::Point2f((float)right_ob[2 * l], (float)right_ob[2 * l + 1]), 1.0f);
+    visual::Feature::Ptr right = visual::Feature::Create(fr[0], kr, L);
+    right->is_on_left_image = false;
+    L->first_observation = right;
+    cv::KeyPoint kl(cv::Point2f((float)left_ob[2 * l], (float)left_ob[2 * l + 1]), 1.0f);
+    visual::Feature::Ptr ft = visual::Feature::Create(fr[2], kl, L);
+    fr[2]->features_left[L->id] = ft; L->observations[fr[2]->id] = ft;
+    lms[(size_t)l] = L;
+  }
+  lvio_fusion::Map::Instance().Reset();
+  for (int k = 0; k < 3; ++k) lvio_fusion::Map::Instance().keyframes[fr[k]->time] = fr[k];
+  // Estimator: never constructed (its constructor reads a config file and builds the whole system); zeroed storage = null `mapping`
+  void* emem = std::calloc(1, sizeof(Estimator));
+  Environment::estimator_ = Estimator::Ptr(reinterpret_cast<Estimator*>(emem), [](Estimator* p) { std::free(p); });
+  Environment::num_frames_per_env_ = 10;
+  Environment* env = new Environment();                 // frames_ = the keyframes after a time in [0, 1): all three
+  env->state_ = env->frames_.find(fr[2]->time);
+  const SE3d result = env->Optimize();                  // <- the reference's text
+  std::memcpy(pose_out, result.data(), 7 * sizeof(double));
+  delete env;
+  Environment::estimator_.reset();
+  for (auto& L : lms) { L->observations.clear(); L->first_observation.reset(); }
+  for (int k = 0; k < 3; ++k) { fr[k]->features_left.clear(); fr[k]->last_keyframe.reset(); }
+  lvio_fusion::Map::Instance().Reset();
 }
 
 #ifndef LVF_DROPIN_BUILD

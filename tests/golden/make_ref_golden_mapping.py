@@ -1,6 +1,6 @@
 """Generates tests/golden/ref_v5.npz: what the REFERENCE's own control code leaves behind on tests/mapping_replay.py's cases —
-Mapping::Optimize / Mapping::Relocate (src/mapping.cpp), PoseGraph::BuildProblem / Optimize (src/pose_graph.cpp) and Relocator::UpdateNewSubmap
-(src/relocator.cpp) compiled UNMODIFIED into oracle/_ref/liblvf_ref.so (oracle/ref_driver_mapping.cpp; third-party headers: the stand-ins of
+Mapping::Optimize / Mapping::Relocate (src/mapping.cpp), PoseGraph::BuildProblem / Optimize (src/pose_graph.cpp), Relocator::UpdateNewSubmap
+(src/relocator.cpp) and Environment::Optimize (src/environment.cpp) compiled UNMODIFIED into oracle/_ref/liblvf_ref.so (oracle/ref_driver_mapping.cpp; third-party headers: the stand-ins of
 oracle/ref_shim; ceres::Solve: the declared LM loop of oracle/ref_shim/ceres/solve_shim.h).  Needs /root/reference (build container).
     python tests/golden/make_ref_golden_mapping.py
 The fixture is DATA (poses, scores, counts); the cases themselves are rebuilt from tests/mapping_replay.py wherever the fixture is used."""
@@ -32,6 +32,9 @@ def generate():
     out["pose_graph_pose"] = r["pose"]; out["pose_graph_vw"] = r["vw"]; out["pose_graph_counts"] = np.array(r["counts"])
     c = mr.submap_case()
     out["submap_pose"] = pyref.update_new_submap(c["time"], c["pose"], c["old_pose"], c["relative_o_c"], c["best"])
+    c = mr.environment_case()
+    out["environment_pose"] = pyref.environment_optimize(c["cam0"], c["cam1"], c["baseline"], c["pose3"], c["vel3"], c["ba3"], c["bg3"], c["w_visual"], c["samples"], c["acc0"],
+                                                         c["gyr0"], c["noise4"], c["inv_depth"], c["right_ob"], c["left_ob"])
     return out
 
 

@@ -104,6 +104,40 @@ def submap_case(n=6, seed=0x0A74):
     return dict(time=70.0 + 0.5 * np.arange(n), pose=P, old_pose=old, relative_o_c=np.stack(rel), best=3)
 
 
+def environment_case(seed=0x0A77, n_lm=60):
+    """Environment::Optimize (environment.cpp:18-115; the RL episodes' per-step solve, one independent window per environment): the current keyframe's pose
+    is the only free block — PoseOnly blocks for its features (landmarks born two keyframes earlier), one ImuError to its predecessor with every other block
+    constant.  Frames [birth, last, cur]; observations rounded to float (cv::Point2f)."""
+    cfg = syn.config4_window(n_kf=3, n_lm=n_lm, n_prewindow=0, seed=seed, imu_samples=6)
+    cams = {}
+    for cam in ("cam0", "cam1"):
+        c = dict(cfg[cam]); e = np.array(c["extrinsic"], np.float64); e[:4] /= np.linalg.norm(e[:4]); c["extrinsic"] = e; cams[cam] = c
+    f32 = lambda x: np.asarray(x, np.float32).astype(np.float64)
+    P = cfg["poses_true"].copy()
+    cur = _perturb(P[2], 0.6, [0.08, -0.05, 0.03])
+    rng = np.random.default_rng(seed + 1)
+    # landmarks born in frame 0 (right-image observation + inverse depth there), seen by the left camera of frame 2
+    d = rng.uniform(6.0, 40.0, n_lm)
+    u = rng.uniform(100, 1100, n_lm); v = rng.uniform(60, 320, n_lm)
+    c1 = cams["cam1"]
+    right_ob = f32(np.stack([u, v], -1))
+    ps = np.stack([(right_ob[:, 0] - c1["cx"]) / c1["fx"] * d, (right_ob[:, 1] - c1["cy"]) / c1["fy"] * d, d], -1)
+    pw = syn.se3_apply(P[0], syn.se3_apply(c1["extrinsic"], ps))
+    px, z = syn.project(cams["cam0"], np.tile(P[2], (n_lm, 1)), pw)
+    keep = (z > 2.0) & (px[:, 0] > 0) & (px[:, 0] < 1241) & (px[:, 1] > 0) & (px[:, 1] < 376)
+    left_ob = f32(px[keep] + rng.normal(0, 0.5, px[keep].shape))
+    f = cfg["imu"][1]
+    pose3 = np.stack([P[0], P[1], cur])
+    return dict(cam0=cams["cam0"], cam1=cams["cam1"], baseline=syn.baseline(), pose3=pose3, vel3=cfg["vel"], ba3=np.stack([cfg["ba"][0], f["ba"], cfg["ba"][2]]),
+                bg3=np.stack([cfg["bg"][0], f["bg"], cfg["bg"][2]]), w_visual=float(np.float32(syn.W_VISUAL)), samples=f["samples"], acc0=f["acc0"], gyr0=f["gyr0"],
+                noise4=syn.IMU_NOISE, inv_depth=1.0 / d[keep], right_ob=right_ob[keep], left_ob=left_ob, pw=pw[keep], pose_true=P[2])
+
+
+def environment_optimize(B, c):
+    """Environment::Optimize by hand: a two-keyframe window [last, cur] with last's pose and all velocity / bias blocks constant (environment.cpp:62-68)"""
+    return B.environment_solve(c)
+
+
 # ------------------------------------------------------------------------------------------------ compositions
 # `B` is a backend: an object with  transform(cloud, pose) -> world cloud (Mapping::MergeScan),  scan_match(map_ground, map_surf, scan_ground, scan_surf, map_pose,
 # frame_pose, outer, prior_weight) -> (pose, score_ground, score_surf),  se3_mul / se3_inv,  forward_update(T, poses, vw) -> (poses, vw),
@@ -233,3 +267,24 @@ class OracleBackend:
     def rotation_solve(self, relocated, unrelocated):
         q, _ = self.o.relocate_rotation_solve(relocated, unrelocated, [0, 0, 0, 1.0])
         return np.asarray(q, np.float64)
+
+    def environment_solve(self, c):
+        o = self.o
+        n = len(c["inv_depth"])
+        pre = o.imu_preintegrate(c["samples"], c["acc0"], c["gyr0"], c["ba3"][1], c["bg3"][1], c["noise4"])
+        cfg = dict(n_kf=2, n_lm=0, poses=c["pose3"][1:], vel=c["vel3"][1:], ba=c["ba3"][1:], bg=c["bg3"][1:], inv_depth=np.zeros(0), w_kf=np.full(2, c["w_visual"]),
+                   cam0=c["cam0"], cam1=c["cam1"],
+                   tc=dict(left_ob=np.zeros((0, 2)), right_ob=np.zeros((0, 2)), lm_idx=np.zeros(0, np.int32), kf_idx=np.zeros(0, np.int32)),
+                   tf=dict(first_ob=np.zeros((0, 2)), ob=np.zeros((0, 2)), lm_idx=np.zeros(0, np.int32), kf1_idx=np.zeros(0, np.int32), kf2_idx=np.zeros(0, np.int32)),
+                   po=dict(ob=c["left_ob"], kf_idx=np.ones(n, np.int32), pw_idx=np.arange(n, dtype=np.int32), pw=world_points(o, c)), imu=[dict(kf_i=0, kf_j=1)])
+        win = o.Window(cfg, np.stack([pre]), pose_const=np.array([1, 0], np.uint8), vbb_const=np.array([7, 7], np.uint8), use=("po", "imu"))
+        win.solve()
+        return win.poses[1].copy()
+
+
+def world_points(o, c):
+    """Landmark::ToWorld (src/landmark.cpp:15-19) of every landmark: Pixel2Robot of the right-image observation at depth 1 / inv_depth, then the birth frame's pose"""
+    c1 = c["cam1"]
+    d = 1.0 / np.asarray(c["inv_depth"], np.float64)
+    ps = np.stack([(c["right_ob"][:, 0] - c1["cx"]) * d / c1["fx"], (c["right_ob"][:, 1] - c1["cy"]) * d / c1["fy"], d], -1)
+    return np.stack([o.se3_apply(c["pose3"][0], o.se3_apply(c1["extrinsic"], p)) for p in ps])

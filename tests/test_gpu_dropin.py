@@ -258,3 +258,13 @@ def test_update_new_submap_from_the_reference_text_on_the_gpu(dropin):
     c = mr.submap_case()
     P = dropin.update_new_submap(c["time"], c["pose"], c["old_pose"], c["relative_o_c"], c["best"])
     assert _close(P, _r5()["submap_pose"]), np.abs(P - _r5()["submap_pose"]).max(axis=1)
+
+
+def test_environment_optimize_from_the_reference_text_on_the_gpu(dropin):
+    """Environment::Optimize (environment.cpp:18-115, compiled unmodified): the third adapt::Solve call site — the recorder follows its SetParameterBlockConstant
+    calls, gpu::Solve holds the seven constant blocks"""
+    from tests import mapping_replay as mr
+    c = mr.environment_case()
+    P = dropin.environment_optimize(c["cam0"], c["cam1"], c["baseline"], c["pose3"], c["vel3"], c["ba3"], c["bg3"], c["w_visual"], c["samples"], c["acc0"], c["gyr0"],
+                                    c["noise4"], c["inv_depth"], c["right_ob"], c["left_ob"])
+    assert _close(P, _r5()["environment_pose"]), np.abs(P - _r5()["environment_pose"])

@@ -66,6 +66,31 @@ class GpuBackend:
         q, _ = self.api.relocate_rotation_solve(self.ctx, relocated, unrelocated, [0, 0, 0, 1.0])
         return np.asarray(q, np.float64)
 
+    def environment_solve(self, c):
+        """the two-keyframe window [last, cur] of Environment::Optimize through the flat C-ABI: lvf_problem_set_pose_constant / _set_vbb_constant"""
+        api = self.api
+        n = len(c["inv_depth"])
+        cfg = dict(imu=[dict(samples=c["samples"], acc0=c["acc0"], gyr0=c["gyr0"], ba=c["ba3"][1], bg=c["bg3"][1], kf_i=0, kf_j=1)])
+        pre = api.preintegrate_or_none(self.ctx, cfg)
+        st = api.State(self.ctx, 2, 0)
+        for field, val in ((api.POSES, c["pose3"][1:]), (api.VEL, c["vel3"][1:]), (api.BA, c["ba3"][1:]), (api.BG, c["bg3"][1:]), (api.W_VISUAL, np.full(2, c["w_visual"]))):
+            st.set(field, val)
+        pw = mr.world_points(_HostAlgebra, c)
+        bpo = api.pose_only_batch(self.ctx, c["cam0"], c["left_ob"], np.ones(n, np.int32), np.arange(n, dtype=np.int32), pw)
+        bimu = api.imu_batch(self.ctx, pre, [0], [1])
+        prob = api.Problem(self.ctx, st, None, None, bpo, bimu)
+        prob.set_pose_constant(0, True)
+        for k in (0, 1):
+            prob.set_vbb_constant(k, True, True, True)
+        prob.solve(api.default_solver_options())
+        out = st.get(api.POSES).reshape(-1, 7)[1].copy()
+        prob.close(); bpo.close(); bimu.close(); st.close()
+        return out
+
+
+class _HostAlgebra:
+    se3_apply = staticmethod(syn.se3_apply)
+
 
 @pytest.fixture(scope="module")
 def backend():
@@ -125,3 +150,9 @@ def test_update_new_submap_equals_the_reference_text(backend):
     c = mr.submap_case()
     P = mr.update_new_submap(backend, c)
     assert close(P, R5["submap_pose"]), np.abs(P - R5["submap_pose"]).max(axis=1)
+
+
+def test_environment_optimize_equals_the_reference_text(backend):
+    c = mr.environment_case()
+    P = mr.environment_optimize(backend, c)
+    assert close(P, R5["environment_pose"]), np.abs(P - R5["environment_pose"])

@@ -72,3 +72,11 @@ def test_update_new_submap_composition_equals_the_reference(oracle):
     P = mr.update_new_submap(mr.OracleBackend(oracle), c)
     assert close(P, R5["submap_pose"])
     assert np.all(np.abs(R5["submap_pose"] - c["pose"]).max(axis=1) > 0.1)
+
+
+def test_environment_optimize_composition_equals_the_reference(oracle):
+    """Environment::Optimize (environment.cpp:18-115), the third adapt::Solve call site: one free pose, PoseOnly blocks, one ImuError with seven constant blocks"""
+    c = mr.environment_case()
+    P = mr.environment_optimize(mr.OracleBackend(oracle), c)
+    assert close(P, R5["environment_pose"])
+    assert np.abs(R5["environment_pose"][4:] - c["pose_true"][4:]).max() < 0.1 * np.abs(c["pose3"][2][4:] - c["pose_true"][4:]).max(), "the solve pulls the pose to the truth"
