@@ -21,7 +21,7 @@ def generate():
     c = mr.optimize_case()
     r = pyref.mapping_optimize(c["time"], c["pose"], c["ground"], c["surf"], c["first_active"], c["w_ground"], c["w_surf"], c["w_visual"], c["n_features_left"])
     out["optimize_pose"] = r["pose"]; out["optimize_world_counts"] = r["world_counts"]
-    for name, kw in (("relocate", {}), ("relocate_sparse", dict(seed=0x0A75, keep=(140, 260))), ("relocate_poor", dict(seed=0x0A76, keep=(30, 45)))):
+    for name, kw in mr.RELOCATE_CASES:
         c = mr.relocate_case(**kw)
         r = pyref.mapping_relocate(c["time"], c["pose"], c["ground"], c["surf"], c["old_index"], c["cur_ground"], c["cur_surf"], c["cur_pose"], c["rel_in"],
                                    c["w_ground"], c["w_surf"], c["w_visual"])

@@ -59,10 +59,14 @@ def optimize_case():
                 w_ground=syn.W_LIDAR_GROUND, w_surf=syn.W_LIDAR_SURF, w_visual=syn.W_VISUAL)
 
 
-def relocate_case(seed=0x0A72, keep=None):
+RELOCATE_CASES = (("relocate", {}), ("relocate_sparse", dict(seed=0x0A75, keep=(140, 260))), ("relocate_poor", dict(seed=0x0A76, keep=(30, 45))),
+                  ("relocate_large", dict(seed=0x0A78, drive=dict(n_az=1400, max_ground=5000, max_surf=8000))))      # 15 k + 24 k map points, 5 k + 8 k scan points
+
+
+def relocate_case(seed=0x0A72, keep=None, drive=None):
     """Mapping::Relocate: three old keyframes (the loop's old frame in the middle), the current frame sees the same place from 0.9 m further on with a
     perturbed initial relative pose"""
-    d = lidar_drive(4, seed)
+    d = lidar_drive(4, seed, **(drive or {}))
     cur_true = d["poses_true"][3]
     g, s = d["ground"][3], d["surf"][3]
     if keep is not None:

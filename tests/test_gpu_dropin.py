@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from lvio_fusion_amd import synthetic as syn
+from tests import mapping_replay as mr
 from tests import window_replay as wr
 from tests.helpers import assert_parity
 
@@ -231,7 +232,7 @@ def test_mapping_optimize_from_the_reference_text_on_the_gpu(dropin):
     assert np.array_equal(r["world_counts"], R5["optimize_world_counts"])
 
 
-@pytest.mark.parametrize("name,kw", (("relocate", {}), ("relocate_sparse", dict(seed=0x0A75, keep=(140, 260))), ("relocate_poor", dict(seed=0x0A76, keep=(30, 45)))))
+@pytest.mark.parametrize("name,kw", mr.RELOCATE_CASES)
 def test_mapping_relocate_from_the_reference_text_on_the_gpu(dropin, name, kw):
     from tests import mapping_replay as mr
     c = mr.relocate_case(**kw)

@@ -106,7 +106,7 @@ def test_mapping_optimize_chain_equals_the_reference_text(backend):
     assert close(P, R5["optimize_pose"]), np.abs(P - R5["optimize_pose"]).max(axis=1)
 
 
-@pytest.mark.parametrize("name,kw", (("relocate", {}), ("relocate_sparse", dict(seed=0x0A75, keep=(140, 260))), ("relocate_poor", dict(seed=0x0A76, keep=(30, 45)))))
+@pytest.mark.parametrize("name,kw", mr.RELOCATE_CASES)
 def test_mapping_relocate_equals_the_reference_text(backend, name, kw):
     c = mr.relocate_case(**kw)
     score, rel, map_pose, counts = mr.mapping_relocate(backend, c)
@@ -115,9 +115,9 @@ def test_mapping_relocate_equals_the_reference_text(backend, name, kw):
 
 
 def test_relocate_through_the_batched_entry_point_equals_the_reference_text(backend):
-    """lvf_scan_match_batch (what a rank runs for its share of the loop-closure candidates) on the three relocate cases at once"""
+    """lvf_scan_match_batch (what a rank runs for its share of the loop-closure candidates) on the relocate cases at once"""
     api, ctx = backend.api, backend.ctx
-    names = (("relocate", {}), ("relocate_sparse", dict(seed=0x0A75, keep=(140, 260))), ("relocate_poor", dict(seed=0x0A76, keep=(30, 45))))
+    names = mr.RELOCATE_CASES
     opt = api.scan_match_options(mr.RES, outer_iterations=4, prior_weight=0.0)
     jobs, handles, cases = [], [], []
     for name, kw in names:
@@ -133,8 +133,9 @@ def test_relocate_through_the_batched_entry_point_equals_the_reference_text(back
     for name, r in zip(cases, res):
         assert r.score == int(R5[name + "_score"])
         assert close(np.array(r.relative_o_c[:]), R5[name + "_relative_o_c"])
-    # Relocator::CorrectLoop's arg-max over `loop_closure->score = score - 20`, `>=` (relocator.cpp:196-204): the saturated candidate
-    assert best == 0
+    # Relocator::CorrectLoop's arg-max over `loop_closure->score = score - 20`, `>=` (relocator.cpp:196-204): the LAST of the best-scoring candidates
+    scores = [int(R5[n + "_score"]) for n in cases]
+    assert best == max(i for i, v in enumerate(scores) if v == max(scores)) and max(scores) - 20 > 0
     for h in handles:
         h.close()
 

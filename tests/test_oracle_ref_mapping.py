@@ -13,7 +13,7 @@ import pytest
 from tests import mapping_replay as mr
 
 R5 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_v5.npz"))
-RELOCATE = (("relocate", {}), ("relocate_sparse", dict(seed=0x0A75, keep=(140, 260))), ("relocate_poor", dict(seed=0x0A76, keep=(30, 45))))
+RELOCATE = mr.RELOCATE_CASES
 
 
 def close(a, b, tol=1e-9):
@@ -51,7 +51,7 @@ def test_mapping_relocate_composition_equals_the_reference(oracle, name, kw):
 
 def test_relocate_scores_spread():
     s = [int(R5[n + "_score"]) for n, _ in RELOCATE]
-    assert s[0] == 49 and s[0] > s[1] > s[2], s          # saturated (20 + 30 - cost terms), partial overlap, poor overlap
+    assert s[0] == 49 and s[0] > s[1] > s[2] and s[3] == 49, s          # saturated (20 + 30 - cost terms), partial overlap, poor overlap, the large case saturated again
 
 
 def test_pose_graph_composition_equals_the_reference(oracle):
