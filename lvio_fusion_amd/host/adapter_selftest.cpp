@@ -385,6 +385,52 @@ static int run_posegraph(const std::string& dir) {
   return summary.termination_type == ceres::FAILURE ? 1 : 0;
 }
 
+// Relocator::UpdateNewSubmap's rotation solve (src/lvio_fusion/src/relocator.cpp:251-268), block for block: one quaternion parameter block under
+// EigenQuaternionParameterization (identity to begin with), one RelocateRError per keyframe of the new sub-map, no loss, default options.
+// gpu::Solve hands the problem to lvf_relocate_rotation_solve (one device launch); CostFunction::Evaluate is the batched functor on a batch of one.
+static int run_relocate(const std::string& dir) {
+  auto rel = rd<double>(dir, "relocated.f64"), un = rd<double>(dir, "unrelocated.f64");      // [n][7] each
+  const int n = (int)(rel.size() / 7);
+  double q[4] = {0.0, 0.0, 0.0, 1.0};
+  std::vector<double> probe;
+  int soft_fail = 0;
+  {
+    adapt::Problem problem;
+    problem.AddParameterBlock(q, 4, new ceres::EigenQuaternionParameterization());
+    for (int i = 0; i < n; ++i) problem.AddResidualBlock(ProblemType::Other, gpu::RelocateRError::Create(&rel[7 * i], &un[7 * i]), nullptr, q);
+    {   // Evaluate spot check at a non-unit quaternion (the functor does not normalise: pose_error.hpp:199-212)
+      ceres::CostFunction* cf = gpu::RelocateRError::Create(&rel[0], &un[0]);
+      double x[4] = {0.02, -0.01, 0.03, 0.98}; double* xp[1] = {x}; double r[7], J[28]; double* Jp[1] = {J};
+      if (!cf->Evaluate(xp, r, Jp)) { std::fprintf(stderr, "RelocateRError Evaluate failed: %s\n", lvf_last_error()); return 1; }
+      double r2[7];
+      if (!cf->Evaluate(xp, r2, nullptr) || std::memcmp(r, r2, sizeof(r)) != 0) { std::fprintf(stderr, "residual-only Evaluate differs\n"); return 1; }
+      probe.insert(probe.end(), r, r + 7); probe.insert(probe.end(), J, J + 28);
+      delete cf;
+    }
+    ceres::Solver::Options options;
+    options.linear_solver_type = ceres::DENSE_QR;
+    ceres::Solver::Summary summary;
+    adapt::Solve(options, &problem, &summary);
+    if (summary.termination_type == ceres::FAILURE) { std::fprintf(stderr, "rotation solve failed: %s\n", summary.message.c_str()); return 1; }
+    probe.push_back(summary.initial_cost); probe.push_back(summary.final_cost); probe.push_back(summary.num_successful_steps); probe.push_back(summary.num_residual_blocks_reduced);
+  }
+  {   // a RelocateRError block mixed with another cost function is refused softly, the quaternion untouched
+    adapt::Problem problem;
+    double q2[4] = {0.0, 0.0, 0.0, 1.0}, pose[7] = {0, 0, 0, 1, 0, 0, 0};
+    problem.AddParameterBlock(q2, 4, new ceres::EigenQuaternionParameterization());
+    problem.AddParameterBlock(pose, 7, new ceres::ProductParameterization(new ceres::EigenQuaternionParameterization(), new ceres::IdentityParameterization(3)));
+    problem.AddResidualBlock(ProblemType::Other, gpu::RelocateRError::Create(&rel[0], &un[0]), nullptr, q2);
+    problem.AddResidualBlock(ProblemType::Other, gpu::PoseError::Create(pose), nullptr, pose);
+    ceres::Solver::Options options; ceres::Solver::Summary summary;
+    adapt::Solve(options, &problem, &summary);
+    soft_fail = summary.termination_type == ceres::FAILURE && q2[0] == 0.0 && q2[1] == 0.0 && q2[2] == 0.0 && q2[3] == 1.0;
+  }
+  wr(dir, "out_probe.f64", probe);
+  wr(dir, "out_q.f64", std::vector<double>(q, q + 4));
+  std::printf("{\"ok\": 1, \"n\": %d, \"mixed_problem_refused_softly\": %d}\n", n, soft_fail);
+  return 0;
+}
+
 // a cost function the adapter does not own must be refused softly (parameters untouched, FAILURE reported)
 struct Foreign : ceres::SizedCostFunction<1, 1> {
   bool Evaluate(double const* const* p, double* r, double** J) const override { r[0] = p[0][0]; if (J && J[0]) J[0][0] = 1; return true; }
@@ -451,11 +497,12 @@ static int run_environment(const std::string& dir) {
 
 int main(int argc, char** argv) {
   if (argc >= 2 && std::string(argv[1]) == "foreign") return run_foreign();
-  if (argc < 3) { std::fprintf(stderr, "usage: %s window|lidar|posegraph|environment <dir> | foreign\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s window|lidar|posegraph|environment|relocate <dir> | foreign\n", argv[0]); return 2; }
   const std::string mode = argv[1];
   if (mode == "window") return run_window(argv[2]);
   if (mode == "lidar") return run_lidar(argv[2]);
   if (mode == "posegraph") return run_posegraph(argv[2]);
   if (mode == "environment") return run_environment(argv[2]);
+  if (mode == "relocate") return run_relocate(argv[2]);
   return 2;
 }

@@ -367,3 +367,25 @@ def test_environment_optimize_through_adapter(tmp_path, oracle, with_imu):
     assert (out["successful"], out["unsuccessful"], out["termination"] == 0) == (ref["num_successful_steps"], ref["num_unsuccessful_steps"], ref["termination"] == 0), (out, ref["why"])
     assert_parity(np.fromfile(os.path.join(d, "out_pose.f64")), win.poses[0], "the environment frame's pose")
     assert ref["final_cost"] < ref["initial_cost"] and ref["num_successful_steps"] >= 2
+
+
+def test_relocate_rotation_through_adapter(tmp_path, oracle):
+    """Relocator::UpdateNewSubmap's problem (relocator.cpp:251-268) built with gpu::RelocateRError::Create and solved by adapt::Solve -> gpu::Solve ->
+    lvf_relocate_rotation_solve; CostFunction::Evaluate against the oracle's autodiff; a mixed problem is refused softly"""
+    rng = np.random.default_rng(21)
+    m = 7
+    un = np.zeros((m, 7)); un[:, :4] = syn.quat_from_ypr(*rng.normal(0, 0.3, (3, m))); un[:, 4:] = rng.normal(0, 5, (m, 3))
+    R = np.concatenate([syn.quat_from_ypr(0.05, -0.02, 0.03), [0, 0, 0]])
+    rel = syn.se3_mul(np.tile(R, (m, 1)), un) + rng.normal(0, 1e-3, (m, 7))
+    d = str(tmp_path)
+    _dump(d, "relocated.f64", rel, np.float64); _dump(d, "unrelocated.f64", un, np.float64)
+    out = _run("relocate", d)
+    assert out["ok"] == 1 and out["n"] == m and out["mixed_problem_refused_softly"] == 1
+    q_ref, s_ref = oracle.relocate_rotation_solve(rel, un, [0, 0, 0, 1.0])
+    q = np.fromfile(os.path.join(d, "out_q.f64"))
+    assert np.abs(q - q_ref).max() <= 1e-9
+    probe = np.fromfile(os.path.join(d, "out_probe.f64"))
+    r0, J0 = oracle.relocate_r(rel[0], un[0], [0.02, -0.01, 0.03, 0.98])
+    assert_parity(probe[:7], r0, "RelocateRError::Evaluate r"); assert_parity(probe[7:35].reshape(7, 4), J0, "RelocateRError::Evaluate J")
+    assert abs(probe[35] - s_ref["initial_cost"]) <= 1e-9 * s_ref["initial_cost"] and abs(probe[36] - s_ref["final_cost"]) <= 1e-6 * max(s_ref["final_cost"], 1e-12)
+    assert int(probe[37]) == s_ref["num_successful_steps"] and int(probe[38]) == m
